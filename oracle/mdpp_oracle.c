@@ -1,0 +1,448 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see mdpp_oracle.h for scope, sources, pinning).
+ * Scalar restatement, one env instance at a time, written for clarity not speed. */
+#include "mdpp_oracle.h"
+#include "np_random.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORA_MAX_L 8
+#define ORA_MAX_DELAY 64
+#define ORA_MAX_DIM 64
+#define ORA_MAX_ORDER 8
+
+/* ======================================================================
+ * Discrete
+ * ==================================================================== */
+struct ora_discrete {
+    int S, A, L, delay, every_n;
+    int has_p_noise, has_r_noise;
+    double p_noise, r_noise, scale, shift, term_reward;
+    int32_t *P;
+    double *rtable;
+    uint8_t *is_term;
+    double *init_cdf;
+    /* per-instance state */
+    int hist[ORA_MAX_L + 1]; /* last L+1 states of augmented_state; -1 = NaN slot */
+    double ring[ORA_MAX_DELAY];
+    int steps;               /* total_transitions_episode */
+    np_pcg64 env_rng;        /* self._np_random */
+    np_pcg64 space_rng;      /* self.observation_spaces[0].np_random */
+};
+
+static long ipow(long b, int e) { long r = 1; while (e-- > 0) r *= b; return r; }
+
+ora_discrete *ora_d_create(int S, int A, int L, int delay, int every_n,
+                           int has_p_noise, double p_noise, int has_r_noise, double r_noise,
+                           double scale, double shift, double term_reward,
+                           const int32_t *P, const double *rtable, const uint8_t *is_term,
+                           const double *init_dist) {
+    if (L < 1 || L > ORA_MAX_L || delay < 0 || delay > ORA_MAX_DELAY) return NULL;
+    ora_discrete *e = (ora_discrete *)calloc(1, sizeof(*e));
+    e->S = S; e->A = A; e->L = L; e->delay = delay; e->every_n = every_n;
+    e->has_p_noise = has_p_noise; e->p_noise = p_noise;
+    e->has_r_noise = has_r_noise; e->r_noise = r_noise;
+    e->scale = scale; e->shift = shift; e->term_reward = term_reward;
+    long nk = ipow(S, L);
+    e->P = (int32_t *)malloc(sizeof(int32_t) * S * A);
+    memcpy(e->P, P, sizeof(int32_t) * S * A);
+    e->rtable = (double *)malloc(sizeof(double) * nk);
+    memcpy(e->rtable, rtable, sizeof(double) * nk);
+    e->is_term = (uint8_t *)malloc(S);
+    memcpy(e->is_term, is_term, S);
+    e->init_cdf = (double *)malloc(sizeof(double) * S);
+    np_build_cdf(init_dist, S, e->init_cdf);
+    return e;
+}
+
+void ora_d_destroy(ora_discrete *e) {
+    if (!e) return;
+    free(e->P); free(e->rtable); free(e->is_term); free(e->init_cdf); free(e);
+}
+
+void ora_d_set_rng(ora_discrete *e, const uint64_t a[6], const uint64_t b[6]) {
+    np_pcg64_load(&e->env_rng, a); np_pcg64_load(&e->space_rng, b);
+}
+void ora_d_get_rng(const ora_discrete *e, uint64_t a[6], uint64_t b[6]) {
+    np_pcg64_store(&e->env_rng, a); np_pcg64_store(&e->space_rng, b);
+}
+
+/* reset(): rl_toy_env.py:2250 (ring cleared), :2255-2257 (choice from rho_0 on the
+ * env RNG), :2275-2278 (NaN-filled history), :2358-2369 (counters). */
+int64_t ora_d_reset(ora_discrete *e) {
+    for (int i = 0; i < e->delay; i++) e->ring[i] = 0.0;
+    int s0 = np_choice_cdf(&e->env_rng, e->init_cdf, e->S);
+    for (int i = 0; i < e->L; i++) e->hist[i] = -1;
+    e->hist[e->L] = s0;
+    e->steps = 0;
+    return s0;
+}
+
+void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8_t *done) {
+    const int S = e->S, L = e->L;
+    /* D1: table lookup, :1603 */
+    int nxt = e->P[e->hist[L] * e->A + action];
+    /* D2: categorical P-noise on the state-space RNG, :1604-1622 + discrete_extended.py:11-23 */
+    if (e->has_p_noise) {
+        double cdf[256], probs[256];
+        for (int i = 0; i < S; i++) probs[i] = 1.0 * e->p_noise / (double)(S - 1);
+        probs[nxt] = 1 - e->p_noise;
+        np_build_cdf(probs, S, cdf);
+        nxt = np_choice_cdf(&e->space_rng, cdf, S);
+    }
+    /* D3: history shift, :2050-2052; :2058 */
+    for (int i = 0; i < L; i++) e->hist[i] = e->hist[i + 1];
+    e->hist[L] = nxt;
+    e->steps += 1;
+    /* D4: rewardable-sequence lookup, :1821-1845 */
+    double r = 0.0;
+    if (e->hist[0] >= 0) {
+        long key = 0;
+        for (int i = 1; i <= L; i++) key = key * S + e->hist[i];
+        r = e->rtable[key];
+    }
+    /* D5: delay FIFO, :1970-1973 */
+    if (e->delay > 0) {
+        double out = e->ring[0];
+        memmove(e->ring, e->ring + 1, sizeof(double) * (e->delay - 1));
+        e->ring[e->delay - 1] = r;
+        r = out;
+    }
+    /* D6: every-n mask, noise, affine, :1975-1990 */
+    if (e->steps % e->every_n != 0) r = 0.0;
+    if (e->has_r_noise) r += 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+    r *= e->scale;
+    r += e->shift;
+    /* D7: :2102-2109 */
+    uint8_t d = e->is_term[nxt];
+    if (d) r += e->term_reward * e->scale;
+    *obs = nxt; *reward = r; *done = d;
+}
+
+void ora_d_rollout(ora_discrete *e, int T, const int32_t *actions, const uint8_t *reset_after,
+                   int64_t *obs, double *reward, uint8_t *done, int64_t *reset_obs) {
+    for (int t = 0; t < T; t++) {
+        ora_d_step(e, actions[t], &obs[t], &reward[t], &done[t]);
+        int rs = reset_after ? reset_after[t] : done[t];
+        int64_t ro = 0;
+        if (rs) ro = ora_d_reset(e);
+        if (reset_obs) reset_obs[t] = ro;
+    }
+}
+
+/* ======================================================================
+ * Continuous, move_to_a_point
+ * ==================================================================== */
+typedef struct { double v; int is32; } rew_t; /* np.float32 vs Python float */
+
+struct ora_continuous {
+    int D, n_rel, order, make_denser, has_p_noise, has_r_noise, delay, every_n, n_boxes;
+    int rel[ORA_MAX_DIM];
+    float inertia32, amax32, smax32, radius32, alw32;
+    float tpow32[ORA_MAX_ORDER + 1];  /* float32(time_unit ** k) */
+    double fact[ORA_MAX_ORDER + 1];   /* k! as float64 */
+    double smax, amax;
+    float target[ORA_MAX_DIM];
+    double p_noise, r_noise, scale, shift, term_reward;
+    float *box_lo, *box_hi;
+    /* state */
+    float sd[ORA_MAX_ORDER + 1][ORA_MAX_DIM]; /* state_derivatives */
+    float cur[ORA_MAX_DIM];                   /* curr_state == augmented_state[-1] */
+    rew_t ring[ORA_MAX_DELAY];
+    int steps, reached;
+    np_pcg64 env_rng;    /* self._np_random */
+    np_pcg64 space_rng;  /* self.feature_space.np_random */
+};
+
+ora_continuous *ora_c_create(int D, int n_rel, const int32_t *rel_idx, int order,
+                             double inertia, double time_unit, double state_max,
+                             double action_max, const float *target, double target_radius,
+                             int make_denser, double action_loss_weight,
+                             int has_p_noise, double p_noise, int has_r_noise, double r_noise,
+                             int delay, int every_n, double scale, double shift,
+                             double term_reward, int n_boxes, const float *box_lo,
+                             const float *box_hi) {
+    if (D > ORA_MAX_DIM || order > ORA_MAX_ORDER || order < 1 || delay > ORA_MAX_DELAY) return NULL;
+    ora_continuous *e = (ora_continuous *)calloc(1, sizeof(*e));
+    e->D = D; e->n_rel = n_rel; e->order = order; e->make_denser = make_denser;
+    for (int i = 0; i < n_rel; i++) { e->rel[i] = rel_idx[i]; e->target[i] = target[i]; }
+    e->inertia32 = (float)inertia;
+    e->amax = action_max; e->smax = state_max;
+    e->amax32 = (float)action_max; e->smax32 = (float)state_max;
+    e->radius32 = (float)target_radius; e->alw32 = (float)action_loss_weight;
+    double f = 1.0;
+    for (int k = 1; k <= order; k++) {
+        f *= (double)k;
+        e->fact[k] = f;
+        e->tpow32[k] = (float)pow(time_unit, (double)k); /* Python float ** int */
+    }
+    e->has_p_noise = has_p_noise; e->p_noise = p_noise;
+    e->has_r_noise = has_r_noise; e->r_noise = r_noise;
+    e->delay = delay; e->every_n = every_n;
+    e->scale = scale; e->shift = shift; e->term_reward = term_reward;
+    e->n_boxes = n_boxes;
+    if (n_boxes > 0) {
+        size_t nb = sizeof(float) * n_boxes * n_rel;
+        e->box_lo = (float *)malloc(nb); memcpy(e->box_lo, box_lo, nb);
+        e->box_hi = (float *)malloc(nb); memcpy(e->box_hi, box_hi, nb);
+    }
+    return e;
+}
+
+void ora_c_destroy(ora_continuous *e) {
+    if (!e) return;
+    free(e->box_lo); free(e->box_hi); free(e);
+}
+void ora_c_set_rng(ora_continuous *e, const uint64_t a[6], const uint64_t b[6]) {
+    np_pcg64_load(&e->env_rng, a); np_pcg64_load(&e->space_rng, b);
+}
+void ora_c_get_rng(const ora_continuous *e, uint64_t a[6], uint64_t b[6]) {
+    np_pcg64_store(&e->env_rng, a); np_pcg64_store(&e->space_rng, b);
+}
+void ora_c_get_derivs(const ora_continuous *e, float *out) {
+    for (int k = 0; k <= e->order; k++)
+        for (int i = 0; i < e->D; i++) out[k * e->D + i] = e->sd[k][i];
+}
+
+/* is_terminal_state for hypercubes, :945-952 (Box.contains on the relevant dims) */
+static int in_term_box(const ora_continuous *e, const float *s) {
+    for (int b = 0; b < e->n_boxes; b++) {
+        int in = 1;
+        for (int j = 0; j < e->n_rel; j++) {
+            float x = s[e->rel[j]];
+            if (!(x >= e->box_lo[b * e->n_rel + j] && x <= e->box_hi[b * e->n_rel + j])) { in = 0; break; }
+        }
+        if (in) return 1;
+    }
+    return 0;
+}
+
+/* np.linalg.norm of a contiguous float32 vector = sqrt(x.dot(x)) in float32.
+ * numpy's FLOAT_dot hands the vector to cblas_sdot (scipy-openblas 0.3.29,
+ * third-party, not under /root/reference); for n < 32 OpenBLAS's x86_64 sdot
+ * runs its scalar tail: float32 products accumulated sequentially in a double,
+ * rounded to float32 once at the end (checked against numpy for n = 1..31 in
+ * tests/test_np_random.py::test_float32_norm_semantics). */
+static float norm32_rel_minus_target(const ora_continuous *e, const float *s) {
+    double acc = 0.0;
+    for (int j = 0; j < e->n_rel; j++) {
+        float d = s[e->rel[j]] - e->target[j];
+        float p = d * d;
+        acc += (double)p;
+    }
+    return sqrtf((float)acc);
+}
+static float norm32(const float *x, int n) {
+    double acc = 0.0;
+    for (int j = 0; j < n; j++) { float p = x[j] * x[j]; acc += (double)p; }
+    return sqrtf((float)acc);
+}
+
+/* reset(): :2250 ring, :2284-2307 rejection sampling from feature_space
+ * (gymnasium Box.sample: uniform(low, high) per bounded dim, normal() when
+ * unbounded), :2311-2323 derivatives / history, :2358-2369 counters. */
+void ora_c_reset(ora_continuous *e, float *obs) {
+    for (int i = 0; i < e->delay; i++) { e->ring[i].v = 0.0; e->ring[i].is32 = 0; }
+    const int bounded = isfinite(e->smax);
+    const double lo = (double)(-e->smax32), range = (double)e->smax32 - (double)(-e->smax32);
+    for (;;) {
+        for (int i = 0; i < e->D; i++) {
+            double v = bounded ? lo + range * np_random(&e->space_rng)
+                               : 0.0 + 1.0 * np_standard_normal(&e->space_rng);
+            e->cur[i] = (float)v;
+        }
+        if (!in_term_box(e, e->cur)) break;
+    }
+    for (int k = 0; k <= e->order; k++)
+        for (int i = 0; i < e->D; i++) e->sd[k][i] = 0.0f;
+    for (int i = 0; i < e->D; i++) { e->sd[0][i] = e->cur[i]; obs[i] = e->cur[i]; }
+    e->steps = 0; e->reached = 0;
+}
+
+void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
+                int *reward_is32, uint8_t *done) {
+    const int D = e->D, n = e->order;
+    float nxt[ORA_MAX_DIM];
+    /* C1: Box.contains(action), :1640 */
+    int ok = 1;
+    for (int i = 0; i < D; i++) if (!(a[i] >= -e->amax32 && a[i] <= e->amax32)) ok = 0;
+    if (ok) {
+        /* C2: :1654-1669.  float32 * weak Python float stays float32; dividing by the
+         * np.float64 factorial promotes to float64; += rounds back to float32. */
+        for (int i = 0; i < D; i++) e->sd[n][i] = a[i] / e->inertia32;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n - i; j++)
+                for (int c = 0; c < D; c++) {
+                    float prod = e->sd[i + j + 1][c] * e->tpow32[j + 1];
+                    double term = (double)prod / e->fact[j + 1];
+                    e->sd[i][c] = (float)((double)e->sd[i][c] + term);
+                }
+        for (int i = 0; i < D; i++) nxt[i] = e->sd[0][i];
+    } else {
+        for (int i = 0; i < D; i++) nxt[i] = e->cur[i]; /* "stay", :1671-1672 */
+    }
+    /* C3: :1682-1691 (D normals from the env RNG, or float64 zeros) */
+    for (int i = 0; i < D; i++) {
+        double nz = e->has_p_noise ? 0.0 + e->p_noise * np_standard_normal(&e->env_rng) : 0.0;
+        nxt[i] = (float)((double)nxt[i] + nz);
+    }
+    /* C4: :1694-1717 */
+    int inside = 1;
+    for (int i = 0; i < D; i++) if (!(nxt[i] >= -e->smax32 && nxt[i] <= e->smax32)) inside = 0;
+    if (!inside) {
+        for (int i = 0; i < D; i++) {
+            float x = nxt[i]; /* np.clip = minimum(maximum(x, lo), hi); NaN propagates */
+            if (x < -e->smax32) x = -e->smax32;
+            if (x > e->smax32) x = e->smax32;
+            nxt[i] = x;
+        }
+        for (int k = 0; k <= n; k++)
+            for (int i = 0; i < D; i++) e->sd[k][i] = 0.0f;
+        for (int i = 0; i < D; i++) e->sd[0][i] = nxt[i];
+    }
+    /* C5: :1719-1725 */
+    float dist_new = norm32_rel_minus_target(e, nxt);
+    if (dist_new < e->radius32) e->reached = 1;
+    e->steps += 1; /* :2058 */
+    /* C6: :1912-1945 */
+    rew_t r;
+    if (e->make_denser) {
+        float dist_old = norm32_rel_minus_target(e, e->cur);
+        r.v = (double)(float)(-dist_new + dist_old);
+    } else {
+        r.v = (dist_new < e->radius32) ? 1.0 : 0.0;
+    }
+    {
+        float pen = e->alw32 * norm32(a, D);
+        r.v = (double)((float)r.v - pen);
+        r.is32 = 1;
+    }
+    /* C7: :1968-1990 */
+    if (e->delay > 0) {
+        rew_t out = e->ring[0];
+        memmove(e->ring, e->ring + 1, sizeof(rew_t) * (e->delay - 1));
+        e->ring[e->delay - 1] = r;
+        r = out;
+    }
+    if (e->steps % e->every_n != 0) { r.v = 0.0; r.is32 = 0; }
+    if (e->has_r_noise) {
+        double nz = 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+        if (r.is32) r.v = (double)((float)r.v + (float)nz); else r.v = r.v + nz;
+    }
+    if (r.is32) {
+        r.v = (double)((float)r.v * (float)e->scale);
+        r.v = (double)((float)r.v + (float)e->shift);
+    } else {
+        r.v = r.v * e->scale;
+        r.v = r.v + e->shift;
+    }
+    /* C8 + :2102-2109 */
+    uint8_t d = (uint8_t)(in_term_box(e, nxt) || e->reached);
+    if (d) {
+        double add = e->term_reward * e->scale;
+        if (r.is32) r.v = (double)((float)r.v + (float)add); else r.v = r.v + add;
+    }
+    for (int i = 0; i < D; i++) { e->cur[i] = nxt[i]; obs[i] = nxt[i]; }
+    *reward = r.v; *reward_is32 = r.is32; *done = d;
+}
+
+void ora_c_rollout(ora_continuous *e, int T, const float *actions, const uint8_t *reset_after,
+                   float *obs, double *reward, uint8_t *done, float *reset_obs) {
+    const int D = e->D;
+    for (int t = 0; t < T; t++) {
+        int is32;
+        ora_c_step(e, actions + (size_t)t * D, obs + (size_t)t * D, &reward[t], &is32, &done[t]);
+        int rs = reset_after ? reset_after[t] : done[t];
+        if (reset_obs) memset(reset_obs + (size_t)t * D, 0, sizeof(float) * D);
+        if (rs) {
+            float tmp[ORA_MAX_DIM];
+            ora_c_reset(e, tmp);
+            if (reset_obs) memcpy(reset_obs + (size_t)t * D, tmp, sizeof(float) * D);
+        }
+    }
+}
+
+/* ======================================================================
+ * Image observations
+ * ==================================================================== */
+static long floordiv(long a, long b) { long q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) q--; return q; }
+
+void ora_i_draw(const ora_image_cfg *c, uint64_t rngw[6], int *R, int *cx, int *cy,
+                int *angle, int *flip) {
+    np_pcg64 g; np_pcg64_load(&g, rngw);
+    int r = c->R0;
+    *cx = (int)(c->W / 2.0); *cy = (int)(c->H / 2.0);
+    if (c->has_scale) { /* :149-169 */
+        double ls = c->log_min_R + np_random(&g) * (c->log_max_R - c->log_min_R);
+        r = (int)exp(ls);
+    }
+    if (c->has_shift) { /* :172-181: integers(-max_shift + 1, max_shift), Python // quantisation */
+        double mw = c->W / 2.0 - r, mh = c->H / 2.0 - r;
+        long aw = np_integers(&g, (int64_t)(-mw + 1), (int64_t)mw);
+        long ah = np_integers(&g, (int64_t)(-mh + 1), (int64_t)mh);
+        aw = floordiv(aw, c->sh_quant) * c->sh_quant;
+        ah = floordiv(ah, c->sh_quant) * c->sh_quant;
+        *cx += (int)aw; *cy += (int)ah;
+    }
+    *angle = 0;
+    if (c->has_rotate) { /* :247-254 */
+        long rot = np_integers(&g, 0, 360);
+        *angle = (int)(floordiv(rot, c->ro_quant) * c->ro_quant);
+    }
+    *flip = 0;
+    if (c->has_flip) { /* :257-262 */
+        if (np_integers(&g, 0, 2) == 0) *flip = (np_integers(&g, 0, 2) == 0) ? 1 : 2;
+    }
+    *R = r;
+    np_pcg64_store(&g, rngw);
+}
+
+static double round15(double v) { /* Python round(v, 15) for |v| <= 1 */
+    /* round-half-even on the decimal representation; use the correctly rounded
+     * decimal conversion the C library provides. */
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.15f", v);
+    return strtod(buf, NULL);
+}
+
+void ora_i_rotate_flip_transpose(int W, int H, const uint8_t *src, int angle, int flip, uint8_t *obs) {
+    uint8_t *rot = (uint8_t *)calloc((size_t)W * H, 1);
+    angle = ((angle % 360) + 360) % 360;
+    if (angle == 0) {
+        memcpy(rot, src, (size_t)W * H);
+    } else if (angle == 180) {
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) rot[y * W + x] = src[(H - 1 - y) * W + (W - 1 - x)];
+    } else if ((angle == 90 || angle == 270) && W == H) {
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++)
+            rot[y * W + x] = (angle == 90) ? src[x * W + (W - 1 - y)] : src[(H - 1 - x) * W + y];
+    } else {
+        const double PI = 3.141592653589793;
+        double a = -((double)angle * (PI / 180.0)); /* -math.radians(angle) */
+        double m0 = round15(cos(a)), m1 = round15(sin(a)), m3 = round15(-sin(a)), m4 = round15(cos(a));
+        double cxr = W / 2.0, cyr = H / 2.0;
+        double m2 = (m0 * (-cxr) + m1 * (-cyr) + 0.0) + cxr;
+        double m5 = (m3 * (-cxr) + m4 * (-cyr) + 0.0) + cyr;
+#define ORA_FIX(v) ((int)floor((v) * 65536.0 + 0.5))
+        int a0 = ORA_FIX(m0), a1 = ORA_FIX(m1), a3 = ORA_FIX(m3), a4 = ORA_FIX(m4);
+        int a2 = ORA_FIX(m2 + m0 * 0.5 + m1 * 0.5), a5 = ORA_FIX(m5 + m3 * 0.5 + m4 * 0.5);
+        for (int y = 0; y < H; y++) {
+            int xx = a2, yy = a5;
+            for (int x = 0; x < W; x++) {
+                int xin = xx >> 16;
+                if (xin >= 0 && xin < W) {
+                    int yin = yy >> 16;
+                    if (yin >= 0 && yin < H) rot[y * W + x] = src[yin * W + xin];
+                }
+                xx += a0; yy += a3;
+            }
+            a2 += a1; a5 += a4;
+        }
+    }
+    /* flip (:257-262), then the transpose of :264-266: obs[x][y] = img[y][x] */
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+        int sx = (flip == 1) ? W - 1 - x : x, sy = (flip == 2) ? H - 1 - y : y;
+        obs[x * H + y] = rot[sy * W + sx];
+    }
+    free(rot);
+}

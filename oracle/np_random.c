@@ -1,0 +1,108 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see np_random.h for scope and sources). */
+#include "np_random.h"
+#include <math.h>
+#include "np_ziggurat_tables.inc"
+
+static const uint64_t ki_double[256] = NPZ_KI_INIT;
+static const double wi_double[256] = NPZ_WI_INIT;
+static const double fi_double[256] = NPZ_FI_INIT;
+static const double ziggurat_nor_r = 3.6541528853610087963519472518;
+static const double ziggurat_nor_inv_r = 0.27366123732975827203338247596;
+
+typedef unsigned __int128 u128;
+/* PCG_DEFAULT_MULTIPLIER_128 = 0x2360ED051FC65DA44385DF649FCCF645 */
+#define PCG_MULT ((((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL)
+
+void np_pcg64_load(np_pcg64 *g, const uint64_t w[6]) {
+    g->s_lo = w[0]; g->s_hi = w[1]; g->inc_lo = w[2]; g->inc_hi = w[3];
+    g->has32 = (uint32_t)w[4]; g->u32 = (uint32_t)w[5];
+}
+void np_pcg64_store(const np_pcg64 *g, uint64_t w[6]) {
+    w[0] = g->s_lo; w[1] = g->s_hi; w[2] = g->inc_lo; w[3] = g->inc_hi;
+    w[4] = g->has32; w[5] = g->u32;
+}
+
+/* pcg_setseq_128_step_r, then pcg_output_xsl_rr_128_64 of the NEW state. */
+uint64_t np_next64(np_pcg64 *g) {
+    u128 s = ((u128)g->s_hi << 64) | g->s_lo;
+    u128 inc = ((u128)g->inc_hi << 64) | g->inc_lo;
+    s = s * PCG_MULT + inc;
+    g->s_lo = (uint64_t)s; g->s_hi = (uint64_t)(s >> 64);
+    uint64_t x = g->s_hi ^ g->s_lo;
+    unsigned rot = (unsigned)(g->s_hi >> 58);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+/* pcg64_next32: hands out the low half first and buffers the high half. */
+uint32_t np_next32(np_pcg64 *g) {
+    if (g->has32) { g->has32 = 0; return g->u32; }
+    uint64_t n = np_next64(g);
+    g->has32 = 1; g->u32 = (uint32_t)(n >> 32);
+    return (uint32_t)n;
+}
+
+double np_random(np_pcg64 *g) {
+    return (double)(np_next64(g) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+double np_standard_normal(np_pcg64 *g) {
+    for (;;) {
+        uint64_t r = np_next64(g);
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 0x1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * wi_double[idx];
+        if (sign) x = -x;
+        if (rabs < ki_double[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -ziggurat_nor_inv_r * log1p(-np_random(g));
+                double yy = -log1p(-np_random(g));
+                if (yy + yy > xx * xx)
+                    return ((rabs >> 8) & 0x1) ? -(ziggurat_nor_r + xx) : ziggurat_nor_r + xx;
+            }
+        } else {
+            if (((fi_double[idx - 1] - fi_double[idx]) * np_random(g) + fi_double[idx]) <
+                exp(-0.5 * x * x))
+                return x;
+        }
+    }
+}
+
+/* Generator.integers(low, high) for the default int64 dtype with a range that
+ * fits 32 bits: random_bounded_uint64 -> buffered_bounded_lemire_uint32. */
+int64_t np_integers(np_pcg64 *g, int64_t low, int64_t high) {
+    uint64_t rng = (uint64_t)(high - 1 - low);
+    if (rng == 0) return low;
+    if (rng == 0xFFFFFFFFULL) return low + (int64_t)np_next32(g);
+    uint32_t rng32 = (uint32_t)rng, rng_excl = rng32 + 1;
+    uint64_t m = (uint64_t)np_next32(g) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        uint32_t threshold = (0xFFFFFFFFU - rng32) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)np_next32(g) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return low + (int64_t)(m >> 32);
+}
+
+void np_build_cdf(const double *p, int n, double *cdf) {
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) { acc += p[i]; cdf[i] = acc; }
+    double last = cdf[n - 1];
+    for (int i = 0; i < n; i++) cdf[i] /= last;
+}
+
+/* searchsorted(cdf, u, side='right'): number of entries <= u. */
+int np_choice_cdf(np_pcg64 *g, const double *cdf, int n) {
+    double u = np_random(g);
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}

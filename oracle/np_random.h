@@ -1,0 +1,44 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the
+ * product path (mdp_playground_amd/); only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may use anything under oracle/.
+ *
+ * CPU restatement of the slice of numpy.random.Generator(PCG64) that
+ * RLToyEnv.step()/reset() consumes.  numpy is a third-party dependency of the
+ * reference (unpinned in /root/reference/setup.py:112; numpy 2.2.6 in this
+ * image) and is NOT under /root/reference, so the published algorithms are
+ * restated here:
+ *   - PCG64 = pcg_setseq_128_xsl_rr_64 (O'Neill), numpy/random/src/pcg64/pcg64.h
+ *   - next_double, random_standard_normal (256-layer ziggurat),
+ *     buffered_bounded_lemire_uint32: numpy/random/src/distributions/distributions.c
+ *   - Generator.choice(n, p=p) == searchsorted(cumsum(p)/cumsum(p)[-1], random(), 'right')
+ *     (numpy/random/_generator.pyx, "choice")
+ * Call sites in the reference that define what must be reproduced:
+ *   mdp_playground/spaces/discrete_extended.py:11-23 (choice with p),
+ *   mdp_playground/envs/rl_toy_env.py:403,413 (normal), :2255 (choice),
+ *   mdp_playground/spaces/image_multi_discrete.py:166,175-176,250,258-259
+ *   (random / integers), gymnasium Box.sample -> Generator.uniform.
+ * Pinned by tests/test_np_random.py against numpy itself (same image on the
+ * GPU box) and, end to end, by the golden vectors in tests/golden/.
+ */
+#ifndef ORACLE_NP_RANDOM_H
+#define ORACLE_NP_RANDOM_H
+#include <stdint.h>
+
+typedef struct {
+    uint64_t s_lo, s_hi;     /* 128-bit LCG state */
+    uint64_t inc_lo, inc_hi; /* 128-bit increment (odd) */
+    uint32_t has32;          /* numpy's pcg64_state.has_uint32 */
+    uint32_t u32;            /* numpy's pcg64_state.uinteger */
+} np_pcg64;
+
+void np_pcg64_load(np_pcg64 *g, const uint64_t w[6]);
+void np_pcg64_store(const np_pcg64 *g, uint64_t w[6]);
+uint64_t np_next64(np_pcg64 *g);
+uint32_t np_next32(np_pcg64 *g);
+double np_random(np_pcg64 *g);                       /* Generator.random() */
+double np_standard_normal(np_pcg64 *g);              /* Generator.standard_normal() */
+int64_t np_integers(np_pcg64 *g, int64_t low, int64_t high); /* integers(low, high), high exclusive, |range| < 2^32 */
+int np_choice_cdf(np_pcg64 *g, const double *cdf, int n);    /* choice(n, p) given the normalised cdf */
+void np_build_cdf(const double *p, int n, double *cdf);      /* cumsum(p) / cumsum(p)[-1] */
+
+#endif

@@ -1,0 +1,255 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front end of oracle/_build/libmdpp_oracle.so (the scalar C restatement of
+RLToyEnv.step()/reset(); see mdpp_oracle.h for the reference file:line map).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (mdp_playground_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmdpp_oracle.so")
+
+
+def build(force=False):
+    srcs = ["mdpp_oracle.c", "np_random.c", "mdpp_oracle.h", "np_random.h",
+            "np_ziggurat_tables.inc", "Makefile"]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+        L.ora_d_create.restype = vp
+        L.ora_d_create.argtypes = [i32] * 5 + [i32, f64, i32, f64, f64, f64, f64] + [vp] * 4
+        L.ora_d_destroy.argtypes = [vp]
+        L.ora_d_set_rng.argtypes = [vp, vp, vp]
+        L.ora_d_get_rng.argtypes = [vp, vp, vp]
+        L.ora_d_reset.restype = C.c_int64
+        L.ora_d_reset.argtypes = [vp]
+        L.ora_d_step.argtypes = [vp, i32, vp, vp, vp]
+        L.ora_d_rollout.argtypes = [vp, i32] + [vp] * 6
+        L.ora_c_create.restype = vp
+        L.ora_c_create.argtypes = ([i32, i32, vp, i32, f64, f64, f64, f64, vp, f64, i32, f64,
+                                    i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
+        L.ora_c_destroy.argtypes = [vp]
+        L.ora_c_set_rng.argtypes = [vp, vp, vp]
+        L.ora_c_get_rng.argtypes = [vp, vp, vp]
+        L.ora_c_reset.argtypes = [vp, vp]
+        L.ora_c_step.argtypes = [vp] * 6
+        L.ora_c_get_derivs.argtypes = [vp, vp]
+        L.ora_c_rollout.argtypes = [vp, i32] + [vp] * 6
+        L.ora_i_draw.argtypes = [vp] * 7
+        L.ora_i_rotate_flip_transpose.argtypes = [i32, i32, vp, i32, i32, vp]
+        for name in ("np_next64", "np_next32"):
+            getattr(L, name).argtypes = [vp]
+        L.np_next64.restype = C.c_uint64
+        L.np_next32.restype = C.c_uint32
+        L.np_random.restype = f64
+        L.np_random.argtypes = [vp]
+        L.np_standard_normal.restype = f64
+        L.np_standard_normal.argtypes = [vp]
+        L.np_integers.restype = C.c_int64
+        L.np_integers.argtypes = [vp, C.c_int64, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def pcg_words(gen):
+    """6 x uint64 words of a numpy Generator(PCG64) state: s_lo, s_hi, inc_lo, inc_hi, has32, u32."""
+    st = gen.bit_generator.state
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array([s & m, s >> 64, inc & m, inc >> 64, st["has_uint32"], st["uinteger"]],
+                    dtype=np.uint64)
+
+
+class NpPCG64(C.Structure):
+    """Mirror of np_pcg64 for driving the RNG primitives directly from tests."""
+    _fields_ = [("s_lo", C.c_uint64), ("s_hi", C.c_uint64), ("inc_lo", C.c_uint64),
+                ("inc_hi", C.c_uint64), ("has32", C.c_uint32), ("u32", C.c_uint32)]
+
+    @classmethod
+    def from_words(cls, w):
+        w = [int(x) for x in w]
+        return cls(w[0], w[1], w[2], w[3], w[4], w[5])
+
+
+def rtable_from_sequences(S, L, keys, vals):
+    """Dense float64[S**L] reward table; key = sum seq[i] * S**(L-1-i)."""
+    t = np.zeros(S ** L, dtype=np.float64)
+    for seq, v in zip(keys, vals):
+        k = 0
+        for s in seq:
+            k = k * S + int(s)
+        t[k] = v
+    return t
+
+
+class DiscreteOracle:
+    def __init__(self, S, A, L, delay, every_n, P, rtable, terminal_states, init_dist,
+                 transition_noise=None, reward_noise=None, reward_scale=1.0,
+                 reward_shift=0.0, term_state_reward=0.0):
+        self.S, self.A, self.L = S, A, L
+        self._P = np.ascontiguousarray(P, dtype=np.int32).reshape(S, A)
+        self._rt = np.ascontiguousarray(rtable, dtype=np.float64)
+        assert self._rt.size == S ** L
+        it = np.zeros(S, dtype=np.uint8)
+        it[np.asarray(terminal_states, dtype=np.int64)] = 1
+        self._it = it
+        self._id = np.ascontiguousarray(init_dist, dtype=np.float64)
+        has_p = bool(transition_noise)                 # rl_toy_env.py:1604 truthiness
+        has_r = reward_noise is not None               # :398-405 lambda exists even for std 0
+        self.h = lib().ora_d_create(S, A, L, delay, every_n, int(has_p),
+                                    float(transition_noise or 0.0), int(has_r),
+                                    float(reward_noise or 0.0), float(reward_scale),
+                                    float(reward_shift), float(term_state_reward),
+                                    _p(self._P), _p(self._rt), _p(self._it), _p(self._id))
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_d_destroy(self.h)
+            self.h = None
+
+    def set_rng(self, env_words, space_words):
+        a = np.ascontiguousarray(env_words, dtype=np.uint64)
+        b = np.ascontiguousarray(space_words, dtype=np.uint64)
+        lib().ora_d_set_rng(self.h, _p(a), _p(b))
+
+    def get_rng(self):
+        a = np.zeros(6, np.uint64)
+        b = np.zeros(6, np.uint64)
+        lib().ora_d_get_rng(self.h, _p(a), _p(b))
+        return a, b
+
+    def reset(self):
+        return int(lib().ora_d_reset(self.h))
+
+    def step(self, action):
+        o = C.c_int64()
+        r = C.c_double()
+        d = C.c_uint8()
+        lib().ora_d_step(self.h, int(action), C.byref(o), C.byref(r), C.byref(d))
+        return o.value, r.value, bool(d.value)
+
+    def rollout(self, actions, reset_after=None):
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        T = actions.shape[0]
+        ra = None if reset_after is None else np.ascontiguousarray(reset_after, dtype=np.uint8)
+        obs = np.zeros(T, np.int64)
+        rew = np.zeros(T, np.float64)
+        done = np.zeros(T, np.uint8)
+        ro = np.zeros(T, np.int64)
+        lib().ora_d_rollout(self.h, T, _p(actions), _p(ra), _p(obs), _p(rew), _p(done), _p(ro))
+        return obs, rew, done.astype(bool), ro
+
+
+class ContinuousOracle:
+    def __init__(self, D, relevant_indices, order, inertia, time_unit, state_space_max,
+                 action_space_max, target_point, target_radius, make_denser,
+                 action_loss_weight=0.0, transition_noise=None, reward_noise=None, delay=0,
+                 every_n=1, reward_scale=1.0, reward_shift=0.0, term_state_reward=0.0,
+                 box_lo=None, box_hi=None):
+        self.D, self.order = D, order
+        rel = np.ascontiguousarray(relevant_indices, dtype=np.int32)
+        tgt = np.ascontiguousarray(target_point, dtype=np.float32)
+        nb = 0 if box_lo is None else len(box_lo)
+        blo = None if nb == 0 else np.ascontiguousarray(box_lo, dtype=np.float32)
+        bhi = None if nb == 0 else np.ascontiguousarray(box_hi, dtype=np.float32)
+        self._keep = (rel, tgt, blo, bhi)
+        self.h = lib().ora_c_create(
+            D, len(rel), _p(rel), order, float(inertia), float(time_unit),
+            float(state_space_max), float(action_space_max), _p(tgt), float(target_radius),
+            int(bool(make_denser)), float(action_loss_weight),
+            int(transition_noise is not None), float(transition_noise or 0.0),
+            int(reward_noise is not None), float(reward_noise or 0.0),
+            int(delay), int(every_n), float(reward_scale), float(reward_shift),
+            float(term_state_reward), nb, _p(blo), _p(bhi))
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_c_destroy(self.h)
+            self.h = None
+
+    def set_rng(self, env_words, space_words):
+        a = np.ascontiguousarray(env_words, dtype=np.uint64)
+        b = np.ascontiguousarray(space_words, dtype=np.uint64)
+        lib().ora_c_set_rng(self.h, _p(a), _p(b))
+
+    def get_rng(self):
+        a = np.zeros(6, np.uint64)
+        b = np.zeros(6, np.uint64)
+        lib().ora_c_get_rng(self.h, _p(a), _p(b))
+        return a, b
+
+    def reset(self):
+        obs = np.zeros(self.D, np.float32)
+        lib().ora_c_reset(self.h, _p(obs))
+        return obs
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float32)
+        obs = np.zeros(self.D, np.float32)
+        r = C.c_double()
+        is32 = C.c_int()
+        d = C.c_uint8()
+        lib().ora_c_step(self.h, _p(a), _p(obs), C.byref(r), C.byref(is32), C.byref(d))
+        return obs, r.value, bool(is32.value), bool(d.value)
+
+    def derivs(self):
+        sd = np.zeros((self.order + 1, self.D), np.float32)
+        lib().ora_c_get_derivs(self.h, _p(sd))
+        return sd
+
+    def rollout(self, actions, reset_after=None):
+        actions = np.ascontiguousarray(actions, dtype=np.float32)
+        T = actions.shape[0]
+        ra = None if reset_after is None else np.ascontiguousarray(reset_after, dtype=np.uint8)
+        obs = np.zeros((T, self.D), np.float32)
+        rew = np.zeros(T, np.float64)
+        done = np.zeros(T, np.uint8)
+        ro = np.zeros((T, self.D), np.float32)
+        lib().ora_c_rollout(self.h, T, _p(actions), _p(ra), _p(obs), _p(rew), _p(done), _p(ro))
+        return obs, rew, done.astype(bool), ro
+
+
+class ImageCfg(C.Structure):
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("has_scale", C.c_int), ("has_shift", C.c_int),
+                ("has_rotate", C.c_int), ("has_flip", C.c_int), ("sh_quant", C.c_int),
+                ("ro_quant", C.c_int), ("R0", C.c_int), ("log_min_R", C.c_double),
+                ("log_max_R", C.c_double)]
+
+
+def image_draw(cfg, rng_words):
+    """Advance the image-space RNG by one observation; returns (R, cx, cy, angle, flip)."""
+    vals = [C.c_int() for _ in range(5)]
+    lib().ora_i_draw(C.byref(cfg), _p(rng_words), *[C.byref(v) for v in vals])
+    return tuple(v.value for v in vals)
+
+
+def image_rotate_flip_transpose(src, angle, flip):
+    H, W = src.shape
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    out = np.zeros((W, H), np.uint8)
+    lib().ora_i_rotate_flip_transpose(W, H, _p(src), int(angle), int(flip), _p(out))
+    return out

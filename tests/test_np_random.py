@@ -1,0 +1,111 @@
+"""Pin the oracle's numpy.random restatement (oracle/np_random.c) against numpy itself.
+
+numpy is the third-party arithmetic behind every random draw of RLToyEnv
+(SURVEY.md §8c); the same numpy wheel is installed on the GPU box, so this pin
+runs there too.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as ora
+
+
+def _pair(seed):
+    g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    st = ora.NpPCG64.from_words(ora.pcg_words(g))
+    return g, st
+
+
+@pytest.mark.parametrize("seed", [0, 1, 12345, 2**63 - 1])
+def test_next64_and_random(seed):
+    L = ora.lib()
+    g, st = _pair(seed)
+    raw = g.bit_generator.random_raw(1000)
+    mine = np.array([L.np_next64(C.byref(st)) for _ in range(1000)], dtype=np.uint64)
+    assert np.array_equal(raw, mine)
+    u = g.random(1000)
+    mine = np.array([L.np_random(C.byref(st)) for _ in range(1000)])
+    assert np.array_equal(u, mine)
+
+
+@pytest.mark.parametrize("seed", [0, 7, 99])
+def test_standard_normal_bit_exact(seed):
+    L = ora.lib()
+    g, st = _pair(seed)
+    n = 400_000  # ~100 tail draws and ~5000 wedge rejections
+    z = g.standard_normal(n)
+    mine = np.array([L.np_standard_normal(C.byref(st)) for _ in range(n)])
+    assert np.array_equal(z, mine)
+    assert (np.abs(z) > 3.6541528853610088).sum() > 20  # tail branch exercised
+    # and the generator ends in the same state
+    assert np.array_equal(ora.pcg_words(g)[:4],
+                          np.array([st.s_lo, st.s_hi, st.inc_lo, st.inc_hi], dtype=np.uint64))
+
+
+def test_normal_scaled_matches():
+    L = ora.lib()
+    g, st = _pair(3)
+    for sigma in (0.05, 0.3, 1.0):
+        a = g.normal(0, sigma, 1000)
+        b = np.array([0.0 + sigma * L.np_standard_normal(C.byref(st)) for _ in range(1000)])
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("lohi", [(-21, 22), (0, 360), (0, 2), (-29, 30), (0, 1), (5, 1000003)])
+def test_integers_scalar_stream(lohi):
+    """Scalar Generator.integers() calls interleaved with random(): exercises the
+    buffered 32-bit half (has_uint32) exactly as ImageMultiDiscrete does."""
+    L = ora.lib()
+    lo, hi = lohi
+    g, st = _pair(11)
+    for i in range(3000):
+        a = int(g.integers(lo, hi))
+        b = int(L.np_integers(C.byref(st), lo, hi))
+        assert a == b, (i, a, b)
+        if i % 7 == 3:
+            assert g.random() == L.np_random(C.byref(st))
+    w = ora.pcg_words(g)
+    assert (int(w[4]), int(w[5])) == (st.has32, st.u32)
+
+
+def test_integers_float_bounds_like_reference():
+    # image_multi_discrete.py:175 passes floats: integers(-21.0, 22.0)
+    L = ora.lib()
+    g, st = _pair(5)
+    for _ in range(500):
+        assert int(g.integers(-21.0, 22.0)) == int(L.np_integers(C.byref(st), -21, 22))
+
+
+@pytest.mark.parametrize("n", [6, 8, 16])
+def test_choice_with_p(n):
+    L = ora.lib()
+    g, st = _pair(21)
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        noise = rng.uniform(0.01, 0.99)
+        nxt = int(rng.integers(n))
+        probs = np.ones(n) * noise / (n - 1)
+        probs[nxt] = 1 - noise
+        a = int(np.squeeze(g.choice(n, size=1, p=probs, replace=True)))
+        cdf = np.zeros(n)
+        L.np_build_cdf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.np_build_cdf(probs.ctypes.data_as(C.c_void_p), n, cdf.ctypes.data_as(C.c_void_p))
+        L.np_choice_cdf.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        b = L.np_choice_cdf(C.byref(st), cdf.ctypes.data_as(C.c_void_p), n)
+        assert a == b
+
+
+def test_float32_norm_semantics():
+    """np.linalg.norm(float32 vector) == sqrt(float32(sum_double(float32(x_i*x_i)))) for
+    n < 32 (OpenBLAS sdot scalar tail) - the summation the oracle and the kernels use."""
+    rng = np.random.default_rng(1)
+    f = np.float32
+    for n in (1, 2, 4, 12, 31):
+        for _ in range(500):
+            x = rng.uniform(-10, 10, n).astype(f)
+            acc = np.float64(0)
+            for v in x:
+                acc += np.float64(f(v * v))
+            assert np.sqrt(f(acc)) == np.linalg.norm(x)

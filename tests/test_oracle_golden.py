@@ -1,0 +1,63 @@
+"""Oracle (oracle/mdpp_oracle.c) vs the reference itself.
+
+Every fixture under tests/golden/ was produced by tools/refgen/gen_golden.py
+running the reference RLToyEnv (mdp_playground/envs/rl_toy_env.py) in the build
+container.  Here the oracle is seeded with the reference's post-construction
+PCG64 states, fed the same actions and reset schedule, and must reproduce obs,
+reward (float64 bit pattern) and done for every step, plus the RNG end state.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import oracle as ora
+
+
+@pytest.mark.parametrize("name", gu.DISCRETE)
+def test_discrete_rollouts_bit_exact(name):
+    g = gu.load(name)
+    E, T = g["action"].shape
+    for e in range(E):
+        o = gu.discrete_oracle_from_golden(name, g, e)
+        # the env RNG was re-seeded and drew the initial state at the end of
+        # __init__ (:831-833): start from a fresh PCG64(seed) and reset()
+        seed_env = int(g["seed_dict"][e][0])
+        fresh = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed_env)))
+        o.set_rng(ora.pcg_words(fresh), g["rng_space"][e])
+        s0 = o.reset()
+        assert s0 == int(g["init_state"][e])
+        assert np.array_equal(o.get_rng()[0], g["rng_env"][e])
+        obs, rew, done, ro = o.rollout(g["action"][e], g["reset_after"][e])
+        assert np.array_equal(obs, g["obs"][e].astype(np.int64)), name
+        assert np.array_equal(done, g["done"][e]), name
+        assert np.array_equal(rew.view(np.uint64), g["reward"][e].view(np.uint64)), name
+        ra = g["reset_after"][e]
+        assert np.array_equal(ro[ra], g["reset_obs"][e][ra].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", gu.CONTINUOUS)
+def test_continuous_rollouts_bit_exact(name):
+    g = gu.load(name)
+    E, T, D = g["action"].shape
+    for e in range(E):
+        o = gu.continuous_oracle_from_golden(name)
+        seed_env = int(g["seed_dict"][e][0])
+        seed_space = int(g["seed_dict"][e][5])
+        fresh = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed_env)))
+        fresh_sp = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed_space)))
+        o.set_rng(ora.pcg_words(fresh), ora.pcg_words(fresh_sp))
+        s0 = o.reset()
+        assert np.array_equal(s0, g["init_state"][e])
+        r_env, r_sp = o.get_rng()
+        assert np.array_equal(r_env, g["rng_env"][e])
+        assert np.array_equal(r_sp, g["rng_space"][e])
+        ra = g["reset_after"][e]
+        for t in range(T):
+            obs, r, is32, d = o.step(g["action"][e, t])
+            assert np.array_equal(obs.view(np.uint32), g["obs"][e, t].view(np.uint32)), (name, e, t)
+            assert np.array_equal(o.derivs().view(np.uint32), g["sd"][e, t].view(np.uint32)), (name, e, t)
+            assert d == bool(g["done"][e, t]), (name, e, t)
+            assert np.float64(r).view(np.uint64) == g["reward"][e, t].view(np.uint64), \
+                (name, e, t, r, g["reward"][e, t])
+            if ra[t]:
+                assert np.array_equal(o.reset(), g["reset_obs"][e, t])

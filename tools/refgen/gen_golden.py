@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the *reference* RLToyEnv.
+
+THIS CONTAINER ONLY.  Needs /root/reference (read-only) and the gymnasium API
+stand-in under tools/refgen/gymnasium_standin (gymnasium itself is not
+installed here; see DESIGN.md "Oracle pinning").  Nothing in here travels to
+the GPU box except the .npz / .json it writes under tests/golden/.
+
+    python tools/refgen/gen_golden.py            # regenerate everything
+
+What is recorded per case (arrays are [E, T, ...]; E = env instances, one per
+seed; T = steps):
+  * the config dict (JSON) and the seed of every instance
+  * everything __init__ generated: transition matrix, rewardable sequences,
+    terminal states, init-state distribution, seed_dict
+  * the PCG64 state of every generator step()/reset() draws from, captured
+    right after construction
+  * the action fed at every step, whether reset() was called after the step
+  * per step: obs, reward (float64), done; internal curr_state / derivatives
+"""
+import contextlib
+import io
+import json
+import logging
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "gymnasium_standin"))
+sys.path.insert(1, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+OUT = os.path.abspath(os.path.join(HERE, "..", "..", "tests", "golden"))
+
+
+def make_env(config):
+    from mdp_playground.envs.rl_toy_env import RLToyEnv
+
+    cfg = dict(config)
+    if isinstance(cfg.get("seed"), dict):
+        cfg["seed"] = dict(cfg["seed"])
+    cfg["log_level"] = logging.CRITICAL
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = RLToyEnv(**cfg)
+    return env
+
+
+def pcg_state(gen):
+    st = gen.bit_generator.state
+    assert st["bit_generator"] == "PCG64"
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array(
+        [s & m, s >> 64, inc & m, inc >> 64, st["has_uint32"], st["uinteger"]],
+        dtype=np.uint64,
+    )
+
+
+BASE_D = dict(state_space_type="discrete", action_space_type="discrete",
+              state_space_size=8, action_space_size=8)
+CFG1 = dict(BASE_D, delay=0)
+CFG2 = dict(BASE_D, delay=4, sequence_length=3)
+CFG2N = dict(CFG2, transition_noise=0.2, reward_noise=0.3, reward_scale=2.5,
+             reward_shift=-1.75, term_state_reward=-0.5, reward_every_n_steps=1)
+BASE_C = dict(state_space_type="continuous", state_space_dim=12,
+              relevant_indices=[0, 1, 2, 3], irrelevant_features=True,
+              target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10,
+              action_space_max=1, inertia=1, make_denser=True,
+              reward_function="move_to_a_point")
+CFG3 = dict(BASE_C, transition_dynamics_order=1, time_unit=1)
+CFG5 = dict(BASE_C, transition_dynamics_order=2, time_unit=0.1,
+            transition_noise=0.05, reward_noise=0.05)
+CFG4 = dict(CFG1, image_representations=True, image_width=84, image_height=84,
+            image_transforms="shift,rotate", image_sh_quant=1, image_ro_quant=1)
+
+CASES = {
+    # --- discrete ------------------------------------------------------
+    "d_cfg1": dict(config=CFG1, seeds=list(range(8)), T=150, reset="on_done"),
+    "d_cfg2": dict(config=CFG2, seeds=list(range(16)), T=300, reset="on_done"),
+    "d_cfg2_noreset": dict(config=CFG2, seeds=list(range(4)), T=60, reset="never"),
+    "d_cfg2_noise": dict(config=CFG2N, seeds=list(range(8)), T=300, reset="mixed"),
+    "d_s16_l2_d1": dict(
+        config=dict(BASE_D, state_space_size=16, action_space_size=16, delay=1,
+                    sequence_length=2, reward_every_n_steps=2, reward_density=0.1,
+                    transition_noise=0.1, reward_scale=0.5),
+        seeds=list(range(4)), T=200, reset="on_done"),
+    "d_l1_d0_pnoise": dict(
+        config=dict(BASE_D, delay=0, sequence_length=1, transition_noise=0.5,
+                    terminal_state_density=0.125),
+        seeds=list(range(4)), T=200, reset="mixed"),
+    "d_l4_repeats": dict(
+        config=dict(BASE_D, delay=2, sequence_length=4, repeats_in_sequences=True,
+                    reward_density=0.05, reward_noise=1.0),
+        seeds=list(range(4)), T=200, reset="on_done"),
+    "d_rdist": dict(
+        config=dict(BASE_D, delay=1, sequence_length=2, reward_dist=[0.25, 1.0]),
+        seeds=list(range(4)), T=200, reset="on_done"),
+    "d_diam2": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=12, action_space_size=6, diameter=2, delay=0,
+                    sequence_length=3, terminal_state_density=0.34),
+        seeds=list(range(4)), T=200, reset="on_done"),
+    "d_notmax": dict(
+        config=dict(BASE_D, delay=0, sequence_length=2, maximally_connected=False),
+        seeds=list(range(4)), T=100, reset="on_done"),
+    # the reference's own passing tests use seed *dicts*
+    "d_kat_everyn": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=8, action_space_size=8, reward_density=0.25,
+                    make_denser=False, terminal_state_density=0.25,
+                    maximally_connected=True, repeats_in_sequences=False, delay=0,
+                    sequence_length=3, reward_scale=1.0, generate_random_mdp=True,
+                    seed={"env": 0, "relevant_state_space": 8,
+                          "relevant_action_space": 8}),
+        seeds=[None], T=6, reset="never", actions=[6, 2, 2, 4, 4, 6]),
+    # --- continuous ------------------------------------------------------
+    "c_cfg3": dict(config=CFG3, seeds=list(range(8)), T=250, reset="on_done",
+                   bad_action_every=37),
+    "c_cfg5": dict(config=CFG5, seeds=list(range(8)), T=250, reset="on_done",
+                   bad_action_every=41),
+    "c_order3_delay3": dict(
+        config=dict(BASE_C, transition_dynamics_order=3, time_unit=0.3, inertia=2.0,
+                    transition_noise=0.02, delay=3, reward_scale=2.0,
+                    reward_shift=0.5, action_loss_weight=0.1),
+        seeds=list(range(4)), T=250, reset="on_done", bad_action_every=50),
+    "c_sparse_term": dict(
+        config=dict(state_space_type="continuous", state_space_dim=2,
+                    transition_dynamics_order=1, inertia=1.0, time_unit=1.0,
+                    state_space_max=5, action_space_max=1, make_denser=False,
+                    target_point=[1.0, -1.0], target_radius=1.5,
+                    terminal_states=[[-3.0, 3.0], [3.0, 3.0]], term_state_edge=2.0,
+                    term_state_reward=-1.0, reward_scale=2.0,
+                    reward_function="move_to_a_point"),
+        seeds=list(range(8)), T=200, reset="on_done"),
+    "c_small_radius_hit": dict(
+        config=dict(state_space_type="continuous", state_space_dim=2,
+                    transition_dynamics_order=1, inertia=1.0, time_unit=1.0,
+                    state_space_max=2, action_space_max=1, make_denser=True,
+                    target_point=[0.0, 0.0], target_radius=0.8, reward_noise=0.1,
+                    reward_every_n_steps=2, reward_function="move_to_a_point"),
+        seeds=list(range(8)), T=200, reset="mixed"),
+    # --- discrete + image observations -------------------------------------
+    "i_cfg4": dict(config=CFG4, seeds=[0, 1], T=24, reset="on_done"),
+    "i_100_all": dict(
+        config=dict(CFG1, image_representations=True, image_width=100,
+                    image_height=100, image_transforms="shift,scale,rotate,flip",
+                    image_sh_quant=2, image_ro_quant=5,
+                    image_scale_range=(0.5, 1.5)),
+        seeds=[0, 1], T=24, reset="on_done"),
+    "i_none": dict(
+        config=dict(CFG1, image_representations=True, image_width=84,
+                    image_height=84),
+        seeds=[3], T=10, reset="on_done"),
+}
+
+
+def jsonable(cfg):
+    def conv(v):
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, (np.floating,)):
+            return float(v)
+        if isinstance(v, (list, tuple)):
+            return [conv(x) for x in v]
+        if isinstance(v, dict):
+            return {k: conv(x) for k, x in v.items()}
+        return v
+    return conv(cfg)
+
+
+def run_case(name, case):
+    base = case["config"]
+    kind = base["state_space_type"]
+    image = bool(base.get("image_representations", False))
+    T = case["T"]
+    rec = {k: [] for k in ("obs", "reward", "done", "action", "reset_after",
+                           "reset_obs", "curr_state")}
+    tables = {k: [] for k in ("P", "terminal_states", "init_dist", "rew_keys",
+                              "rew_vals", "rng_env", "rng_space", "rng_image",
+                              "init_obs", "init_state", "seed_dict", "sd")}
+    seed_names = ["env", "relevant_state_space", "relevant_action_space",
+                  "irrelevant_state_space", "irrelevant_action_space", "state_space",
+                  "action_space", "image_representations"]
+    for e, seed in enumerate(case["seeds"]):
+        cfg = dict(base)
+        if seed is not None:
+            cfg["seed"] = seed
+        env = make_env(cfg)
+        arng = np.random.default_rng(1000003 * (e + 1) + 17)  # action/reset policy rng
+        sdict = env.seed_dict
+        tables["seed_dict"].append(
+            np.array([sdict.get(k, -1) if sdict.get(k, -1) is not None else -1
+                      for k in seed_names], dtype=np.int64))
+        tables["rng_env"].append(pcg_state(env._np_random))
+        if kind == "discrete":
+            S = int(env.state_space_size[0])
+            L = env.sequence_length
+            tables["P"].append(np.array(env.transition_matrix.tolist(), dtype=np.int64))
+            tables["terminal_states"].append(
+                np.array(env.config["terminal_states"], dtype=np.int64))
+            tables["init_dist"].append(
+                np.array(env.config["relevant_init_state_dist"], dtype=np.float64))
+            keys, vals = [], []
+            for seq, v in env.rewardable_sequences.items():
+                if len(seq) == L:
+                    keys.append(list(seq))
+                    vals.append(float(v))
+            tables["rew_keys"].append(np.array(keys, dtype=np.int64).reshape(-1, L))
+            tables["rew_vals"].append(np.array(vals, dtype=np.float64))
+            tables["rng_space"].append(pcg_state(env.observation_spaces[0].np_random))
+            if image:
+                tables["rng_image"].append(pcg_state(env.observation_space.np_random))
+        else:
+            tables["rng_space"].append(pcg_state(env.feature_space.np_random))
+        co = env.curr_obs  # NB: __init__ stores reset()'s (obs, info) tuple here
+        tables["init_obs"].append(np.array(co[0] if isinstance(co, tuple) else co))
+        tables["init_state"].append(np.array(env.curr_state))
+        r = {k: [] for k in rec}
+        sdrec = []
+        for t in range(T):
+            if kind == "discrete":
+                if "actions" in case:
+                    a = int(case["actions"][t])
+                else:
+                    a = int(arng.integers(env.action_space_size[0]))
+                act = a
+                r["action"].append(a)
+            else:
+                D = env.state_space_dim
+                amax = env.action_space_max
+                a = arng.uniform(-amax, amax, D).astype(np.float32)
+                bae = case.get("bad_action_every")
+                if bae and t % bae == bae - 1:
+                    a[int(arng.integers(D))] = np.float32(amax * 1.5)
+                act = a
+                r["action"].append(a.copy())
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                obs, rew, done, trunc, info = env.step(act)
+            r["obs"].append(np.array(obs).copy())
+            r["reward"].append(np.float64(rew))
+            r["done"].append(bool(done))
+            r["curr_state"].append(np.array(env.curr_state).copy())
+            if kind == "continuous":
+                sdrec.append(np.stack([np.array(x, dtype=np.float32)
+                                       for x in env.state_derivatives]))
+            mode = case["reset"]
+            do_reset = (mode == "on_done" and done) or (
+                mode == "mixed" and ((done and arng.random() < 0.6)
+                                     or arng.random() < 0.02))
+            r["reset_after"].append(bool(do_reset))
+            if do_reset:
+                ro, _ = env.reset()
+                r["reset_obs"].append(np.array(ro).copy())
+            else:
+                r["reset_obs"].append(np.zeros_like(np.array(obs)))
+        for k in rec:
+            rec[k].append(np.stack(r[k]))
+        if kind == "continuous":
+            tables["sd"].append(np.stack(sdrec))
+        env.close()
+
+    out = {}
+    for k, v in rec.items():
+        out[k] = np.stack(v)
+    ragged = ("rew_keys", "rew_vals", "terminal_states")
+    for k, v in tables.items():
+        if not v:
+            continue
+        if k in ragged:
+            for e, arr in enumerate(v):
+                out[f"{k}_{e}"] = arr
+        else:
+            out[k] = np.stack(v)
+    out["reward"] = out["reward"].astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    n_done = int(out["done"].sum())
+    n_reset = int(out["reset_after"].sum())
+    print(f"{name}: E={len(case['seeds'])} T={T} dones={n_done} resets={n_reset}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
+    meta = {}
+    for name, case in CASES.items():
+        meta[name] = jsonable({k: v for k, v in case.items()})
+        if only and name not in only:
+            continue
+        run_case(name, case)
+    with open(os.path.join(OUT, "cases.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    import PIL
+    import scipy
+    with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
+        f.write(f"python {sys.version.split()[0]}\nnumpy {np.__version__}\n"
+                f"scipy {scipy.__version__}\npillow {PIL.__version__}\n"
+                "gymnasium: API stand-in (tools/refgen/gymnasium_standin)\n"
+                "reference: automl/mdp-playground @ 2025-09-26\n")
+
+
+if __name__ == "__main__":
+    main()
