@@ -1,0 +1,177 @@
+/* mdpp.h — C ABI of libmdpp_hip.so: batched RLToyEnv.step()/reset() on MI355X (gfx950).
+ *
+ * One handle = one shard of env instances on one GPU.  Every `*_dev` pointer is a
+ * DEVICE pointer owned by the caller (the Python layer passes torch tensors'
+ * data_ptr()); every `*_host` pointer is host memory.  All work is enqueued on the
+ * caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
+ * stream) and is asynchronous with respect to the host.  The library owns only its
+ * per-env state and tables (freed by mdpp_destroy); nothing is allocated inside
+ * mdpp_step / mdpp_step_n / mdpp_reset (graph-capturable).  A handle is not
+ * thread-safe.  Every function returns 0 on success or a negative MDPP_E* code and
+ * never throws; mdpp_last_error() gives the message.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *   mdpp_create + mdpp_upload_*   RLToyEnv.__init__            mdp_playground/envs/rl_toy_env.py:216-853
+ *                                 (the tables themselves are generated on the host by
+ *                                  mdp_playground_amd/mdp.py, restating :855-1575)
+ *   mdpp_seed_streams             RLToyEnv.seed / Space.seed   rl_toy_env.py:2379-2406,
+ *                                                              spaces/discrete_extended.py:7-9
+ *   mdpp_reset                    RLToyEnv.reset               rl_toy_env.py:2217-2377
+ *   mdpp_step                     RLToyEnv.step                rl_toy_env.py:1992-2125
+ *                                 (transition_function :1577-1725, reward_function :1782-1990,
+ *                                  ImageMultiDiscrete.get_image_representation
+ *                                  spaces/image_multi_discrete.py:129-288)
+ *   mdpp_step_n                   a Python loop of K step() calls (e.g. example.py:69-86)
+ *   mdpp_get_state/set_state      get/set_augmented_state      rl_toy_env.py:2127-2215
+ *                                 (plus the RNG streams, ring and counters the reference omits)
+ */
+#ifndef MDPP_H
+#define MDPP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDPP_ABI_VERSION 1
+
+enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
+       MDPP_EUNSUPPORTED = -5 };
+
+enum { MDPP_KIND_DISCRETE = 0, MDPP_KIND_CONTINUOUS = 1 };
+enum { MDPP_RNG_NUMPY_PCG64 = 0,   /* per-env numpy Generator(PCG64) streams: reference-exact */
+       MDPP_RNG_PHILOX = 1 };      /* counter-based Philox4x32-10 keyed by (seed, global env id) */
+enum { MDPP_AUTORESET_DISABLED = 0, MDPP_AUTORESET_SAME_STEP = 1 };
+enum { MDPP_OBS_I64 = 0, MDPP_OBS_I32 = 1, MDPP_OBS_F32 = 2, MDPP_OBS_IMAGE_U8 = 3 };
+/* RNG streams, named after the generator object they mirror in the reference */
+enum { MDPP_STREAM_ENV = 0,        /* RLToyEnv._np_random: reset draw, reward noise, continuous P-noise */
+       MDPP_STREAM_SPACE = 1,      /* discrete: observation_spaces[0] (P-noise); continuous: feature_space (reset) */
+       MDPP_STREAM_IMAGE = 2,      /* observation_space (ImageMultiDiscrete transforms) */
+       MDPP_NUM_STREAMS = 3 };
+/* per-env status bits (mdpp_status) */
+enum { MDPP_STATUS_BAD_ACTION = 1u };   /* discrete: action out of range (reference: IndexError);
+                                           continuous: action rejected by Box.contains -> "stay" (:1671) */
+
+typedef struct mdpp_env mdpp_env;
+
+#define MDPP_MAX_DIM 32
+#define MDPP_MAX_ORDER 4
+#define MDPP_MAX_BOXES 8
+
+typedef struct {
+    int32_t abi_version;        /* MDPP_ABI_VERSION */
+    int32_t kind;               /* MDPP_KIND_* */
+    int32_t num_envs;           /* env instances in this shard */
+    int64_t env_id_offset;      /* global id of local env 0 (multi-GPU sharding; Philox keys use the global id) */
+    int32_t rng_mode;           /* MDPP_RNG_* */
+    int32_t autoreset;          /* MDPP_AUTORESET_* */
+    int32_t max_episode_steps;  /* 0 = never truncate (RLToyFiniteHorizon-v0: 100) */
+    int32_t obs_dtype;          /* MDPP_OBS_* */
+    uint64_t philox_seed;       /* MDPP_RNG_PHILOX only */
+
+    /* reward post-processing shared by both kinds, rl_toy_env.py:1968-1990, :2105-2109 */
+    int32_t delay;              /* reward_buffer length */
+    int32_t every_n;            /* reward_every_n_steps */
+    int32_t has_reward_noise;   /* "reward_noise" in config (a normal is drawn even for std 0) */
+    double reward_noise;        /* std */
+    double reward_scale, reward_shift, term_state_reward;
+
+    /* ---- discrete ---- */
+    int32_t S, A, L;            /* state_space_size, action_space_size, sequence_length */
+    int32_t num_tables;         /* 1 = one MDP shared by all envs; num_envs = one MDP per env */
+    int32_t unit_rewards;       /* 1: every rewardable sequence pays exactly 1.0 (bitmask table) */
+    int32_t has_transition_noise;
+    double transition_noise;
+
+    /* ---- continuous (move_to_a_point) ---- */
+    int32_t D, n_rel, order;    /* state_space_dim, len(relevant_indices), transition_dynamics_order */
+    int32_t rel_idx[MDPP_MAX_DIM];
+    int32_t make_denser;
+    int32_t has_p_noise;        /* "transition_noise" in config (D normals drawn even for std 0) */
+    double p_noise;             /* std */
+    double inertia, time_unit, state_space_max, action_space_max;
+    double target_radius, action_loss_weight;
+    float target[MDPP_MAX_DIM];
+    int32_t n_boxes;            /* terminal hypercubes, rl_toy_env.py:908-952 */
+    float box_lo[MDPP_MAX_BOXES * MDPP_MAX_DIM];
+    float box_hi[MDPP_MAX_BOXES * MDPP_MAX_DIM];
+
+    /* ---- image observations for discrete envs (ImageMultiDiscrete) ---- */
+    int32_t image;              /* 1: obs is uint8[W][H][1] per env */
+    int32_t img_w, img_h;
+    int32_t img_has_scale, img_has_shift, img_has_rotate, img_has_flip;
+    int32_t img_sh_quant, img_ro_quant;
+    int32_t img_r0;             /* circle_radius */
+    int32_t img_r_min, img_r_max; /* radii that can occur (scale transform), templates cover [r_min, r_max] */
+    double img_log_min_r, img_log_max_r;
+    int32_t img_tpl_size;       /* templates are (2*tpl_half+1)^2 bitmaps */
+} mdpp_config;
+
+/* Lifetime */
+int mdpp_abi_version(void);
+int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out);
+void mdpp_destroy(mdpp_env *h);
+const char *mdpp_last_error(const mdpp_env *h);   /* h may be NULL: last create() error */
+
+/* Discrete tables (host pointers; T = cfg.num_tables):
+ *   P        uint8 [T][S][A]      transition matrix                       rl_toy_env.py:1050-1151
+ *   rtable   double[T][S^L] or, when cfg.unit_rewards, NULL with
+ *   rbits    uint8 [T][ceil(S^L/8)] bit k set <=> sequence with key k is rewardable (:1508)
+ *   is_term  uint8 [T][S]                                                 :868-889
+ *   init_cdf double[T][S]  cumsum(rho_0)/cumsum(rho_0)[-1]                :1003-1018, :2255
+ *   noise_cdf double[S][S] row n = normalised cdf of the P-noise categorical whose mode is n
+ *            (:1605-1612); NULL when cfg.has_transition_noise == 0 */
+int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P_host, const double *rtable_host,
+                                const uint8_t *rbits_host, const uint8_t *is_term_host,
+                                const double *init_cdf_host, const double *noise_cdf_host);
+
+/* Image templates (host): uint8 [S][n_radii][n_cls][tpl][tpl], polygon rasters centred in the
+ * template; cls_x/cls_y int16 [S][n_radii][W or H] map a centre coordinate to its template class. */
+int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl_host, int32_t n_radii, int32_t n_cls_x,
+                                int32_t n_cls_y, const int16_t *cls_x_host, const int16_t *cls_y_host);
+
+/* RNG streams.  words_host: uint64 [num_envs][6] = PCG64 {state_lo, state_hi, inc_lo, inc_hi,
+ * has_uint32, uinteger} exactly as numpy's bit_generator.state reports them. */
+int mdpp_seed_streams(mdpp_env *h, int stream, const uint64_t *words_host);
+int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words_host);
+
+/* reset(): mask_dev == NULL resets every env, else only envs with mask_dev[i] != 0.
+ * obs_dev receives the new first observation of the reset envs (others untouched). */
+int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, void *stream);
+
+/* step(): actions int32[N] (discrete) or float32[N][D] (continuous); obs per cfg.obs_dtype
+ * ([N], [N][D] or [N][W][H]); reward float32[N]; terminated/truncated uint8[N].
+ * final_obs_dev (nullable): with same-step autoreset, the last observation of episodes that ended. */
+int mdpp_step(mdpp_env *h, const void *actions_dev, void *obs_dev, float *reward_dev,
+              uint8_t *terminated_dev, uint8_t *truncated_dev, void *final_obs_dev, void *stream);
+
+/* K fused steps in one launch, per-env state held in registers between steps.
+ * actions [K][N](…), outputs [K][N](…), time-major. */
+int mdpp_step_n(mdpp_env *h, int K, const void *actions_dev, void *obs_dev, float *reward_dev,
+                uint8_t *terminated_dev, uint8_t *truncated_dev, void *stream);
+
+/* Per-env internal state <-> host (synchronous; checkpoint / set_augmented_state).
+ * Discrete: hist int32[N][L+1] (-1 = NaN slot), steps int32[N], ring double[N][delay].
+ * Continuous: derivs float[N][order+1][D], cur float[N][D], steps int32[N],
+ *             ring double[N][delay] + ring_is32 uint8[N][delay], reached uint8[N]. */
+int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist_host, int32_t *steps_host, double *ring_host);
+int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist_host, const int32_t *steps_host,
+                            const double *ring_host);
+int mdpp_get_state_continuous(mdpp_env *h, float *derivs_host, float *cur_host, int32_t *steps_host,
+                              double *ring_host, uint8_t *ring_is32_host, uint8_t *reached_host);
+int mdpp_set_state_continuous(mdpp_env *h, const float *derivs_host, const float *cur_host,
+                              const int32_t *steps_host, const double *ring_host,
+                              const uint8_t *ring_is32_host, const uint8_t *reached_host);
+
+/* Per-env sticky status bits (MDPP_STATUS_*), cleared by the call. flags_host: uint32[N]. */
+int mdpp_status(mdpp_env *h, uint32_t *flags_host);
+
+/* Kernel timing with HIP events on the caller's stream (bench.py roofline leg):
+ * begin/end bracket any number of launches; returns elapsed milliseconds. */
+int mdpp_timer_begin(mdpp_env *h, void *stream);
+int mdpp_timer_end(mdpp_env *h, void *stream, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDPP_H */

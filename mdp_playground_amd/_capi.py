@@ -1,0 +1,107 @@
+"""ctypes binding of libmdpp_hip.so (include/mdpp.h).  No fallback: if the HIP library is
+missing or does not export the ABI, importing the vector env raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
+
+MDPP_ABI_VERSION = 1
+MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
+KIND_DISCRETE, KIND_CONTINUOUS = 0, 1
+RNG_NUMPY_PCG64, RNG_PHILOX = 0, 1
+AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1
+OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
+STREAM_ENV, STREAM_SPACE, STREAM_IMAGE = 0, 1, 2
+STATUS_BAD_ACTION = 1
+
+EXPORTS = [
+    "mdpp_abi_version", "mdpp_create", "mdpp_destroy", "mdpp_last_error",
+    "mdpp_upload_discrete_tables", "mdpp_upload_image_templates", "mdpp_seed_streams",
+    "mdpp_get_streams", "mdpp_reset", "mdpp_step", "mdpp_step_n", "mdpp_get_state_discrete",
+    "mdpp_set_state_discrete", "mdpp_get_state_continuous", "mdpp_set_state_continuous",
+    "mdpp_status", "mdpp_timer_begin", "mdpp_timer_end",
+]
+
+
+class MdppConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("kind", C.c_int32), ("num_envs", C.c_int32),
+        ("env_id_offset", C.c_int64), ("rng_mode", C.c_int32), ("autoreset", C.c_int32),
+        ("max_episode_steps", C.c_int32), ("obs_dtype", C.c_int32), ("philox_seed", C.c_uint64),
+        ("delay", C.c_int32), ("every_n", C.c_int32), ("has_reward_noise", C.c_int32),
+        ("reward_noise", C.c_double), ("reward_scale", C.c_double), ("reward_shift", C.c_double),
+        ("term_state_reward", C.c_double),
+        ("S", C.c_int32), ("A", C.c_int32), ("L", C.c_int32), ("num_tables", C.c_int32),
+        ("unit_rewards", C.c_int32), ("has_transition_noise", C.c_int32),
+        ("transition_noise", C.c_double),
+        ("D", C.c_int32), ("n_rel", C.c_int32), ("order", C.c_int32),
+        ("rel_idx", C.c_int32 * MAX_DIM), ("make_denser", C.c_int32), ("has_p_noise", C.c_int32),
+        ("p_noise", C.c_double), ("inertia", C.c_double), ("time_unit", C.c_double),
+        ("state_space_max", C.c_double), ("action_space_max", C.c_double),
+        ("target_radius", C.c_double), ("action_loss_weight", C.c_double),
+        ("target", C.c_float * MAX_DIM), ("n_boxes", C.c_int32),
+        ("box_lo", C.c_float * (MAX_BOXES * MAX_DIM)), ("box_hi", C.c_float * (MAX_BOXES * MAX_DIM)),
+        ("image", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32),
+        ("img_has_scale", C.c_int32), ("img_has_shift", C.c_int32), ("img_has_rotate", C.c_int32),
+        ("img_has_flip", C.c_int32), ("img_sh_quant", C.c_int32), ("img_ro_quant", C.c_int32),
+        ("img_r0", C.c_int32), ("img_r_min", C.c_int32), ("img_r_max", C.c_int32),
+        ("img_log_min_r", C.c_double), ("img_log_max_r", C.c_double), ("img_tpl_size", C.c_int32),
+    ]
+
+
+class MdppError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libmdpp_hip.so and declare every prototype of include/mdpp.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MdppError(
+            f"{LIB_PATH} is missing: build it with `python -m mdp_playground_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise MdppError(f"{LIB_PATH} does not export {name}")
+    vp, i32 = C.c_void_p, C.c_int
+    L.mdpp_abi_version.restype = i32
+    L.mdpp_create.argtypes = [C.POINTER(MdppConfig), i32, C.POINTER(vp)]
+    L.mdpp_destroy.argtypes = [vp]
+    L.mdpp_destroy.restype = None
+    L.mdpp_last_error.argtypes = [vp]
+    L.mdpp_last_error.restype = C.c_char_p
+    L.mdpp_upload_discrete_tables.argtypes = [vp] * 7
+    L.mdpp_upload_image_templates.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.mdpp_seed_streams.argtypes = [vp, i32, vp]
+    L.mdpp_get_streams.argtypes = [vp, i32, vp]
+    L.mdpp_reset.argtypes = [vp, vp, vp, vp]
+    L.mdpp_step.argtypes = [vp] * 8
+    L.mdpp_step_n.argtypes = [vp, i32] + [vp] * 6
+    L.mdpp_get_state_discrete.argtypes = [vp] * 4
+    L.mdpp_set_state_discrete.argtypes = [vp] * 4
+    L.mdpp_get_state_continuous.argtypes = [vp] * 7
+    L.mdpp_set_state_continuous.argtypes = [vp] * 7
+    L.mdpp_status.argtypes = [vp, vp]
+    L.mdpp_timer_begin.argtypes = [vp, vp]
+    L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    if L.mdpp_abi_version() != MDPP_ABI_VERSION:
+        raise MdppError("libmdpp_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(lib, handle, rc, what):
+    if rc != 0:
+        msg = lib.mdpp_last_error(handle)
+        raise MdppError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def nptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

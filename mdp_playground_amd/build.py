@@ -1,0 +1,68 @@
+"""Build libmdpp_hip.so (the HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m mdp_playground_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the float32/float64
+arithmetic of the continuous kernel must not be fused into FMAs (parity with numpy).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libmdpp_hip.so")
+SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_continuous.hip", "mdpp_image.hip"]
+HEADERS = ["mdpp_internal.hpp", "mdpp_rng.hpp", "np_ziggurat_tables.inc",
+           os.path.join("..", "..", "include", "mdpp.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout)
+        return r.stdout
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for out in ex.map(run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if jobs or force or _stale(OUT, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

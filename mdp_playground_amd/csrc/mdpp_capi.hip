@@ -1,0 +1,509 @@
+// C ABI of libmdpp_hip.so (see include/mdpp.h): handle lifetime, table/stream upload, dispatch.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "mdpp_internal.hpp"
+
+using namespace mdpp;
+
+static std::string g_create_err;
+
+#define HIPCHK(h, expr)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+            return MDPP_EHIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+static int fail(mdpp_env *h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+static uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+extern "C" int mdpp_abi_version(void) { return MDPP_ABI_VERSION; }
+
+extern "C" const char *mdpp_last_error(const mdpp_env *h) {
+    return h ? h->err.c_str() : g_create_err.c_str();
+}
+
+static void free_all(mdpp_env *h) {
+    void *ptrs[] = {h->d_P, h->d_rtable, h->d_rbits, h->d_is_term, h->d_init_cdf, h->d_noise_cdf,
+                    h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
+                    h->d_img_tpl, h->d_img_clsx, h->d_img_clsy, h->d_img_rot};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
+        if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
+        if (h->d_rng_inc[s]) (void)hipFree(h->d_rng_inc[s]);
+    }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+}
+
+extern "C" void mdpp_destroy(mdpp_env *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_all(h);
+    delete h;
+}
+
+static int alloc_zero(mdpp_env *h, void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    HIPCHK(h, hipMalloc(p, bytes));
+    HIPCHK(h, hipMemset(*p, 0, bytes));
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
+    if (!cfg || !out) return fail(nullptr, MDPP_EINVAL, "mdpp_create: null argument");
+    if (cfg->abi_version != MDPP_ABI_VERSION)
+        return fail(nullptr, MDPP_EINVAL, "mdpp_create: abi_version mismatch");
+    if (cfg->num_envs <= 0) return fail(nullptr, MDPP_EINVAL, "mdpp_create: num_envs <= 0");
+    if (cfg->delay < 0 || cfg->every_n < 1)
+        return fail(nullptr, MDPP_EINVAL, "mdpp_create: need delay >= 0 and reward_every_n_steps >= 1");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return fail(nullptr, MDPP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    mdpp_env *h = new mdpp_env();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    h->cfg = *cfg;
+    h->device = device;
+    h->tick = 0; h->reset_tick = 0;
+    h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
+    h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
+    h->d_img_tpl = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
+    for (int s = 0; s < MDPP_NUM_STREAMS; s++) { h->d_rng_s[s] = h->d_rng_inc[s] = nullptr; h->streams_ready[s] = false; }
+    h->tables_ready = false;
+    h->ev0 = h->ev1 = nullptr;
+    const size_t N = (size_t)cfg->num_envs;
+    int rc = MDPP_OK;
+#define TRY(x) do { rc = (x); if (rc != MDPP_OK) { g_create_err = h->err; free_all(h); delete h; return rc; } } while (0)
+#define TRYHIP(x) do { hipError_t e2_ = (x); if (e2_ != hipSuccess) { g_create_err = std::string(#x) + ": " + hipGetErrorString(e2_); free_all(h); delete h; return MDPP_EHIP; } } while (0)
+    TRYHIP(hipEventCreate(&h->ev0));
+    TRYHIP(hipEventCreate(&h->ev1));
+    TRY(alloc_zero(h, &h->d_status, N * sizeof(uint32_t)));
+    if (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64) {
+        for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
+            if (s == MDPP_STREAM_IMAGE && !cfg->image) continue;
+            TRY(alloc_zero(h, &h->d_rng_s[s], N * 16));
+            TRY(alloc_zero(h, &h->d_rng_inc[s], N * 16));
+        }
+        if (cfg->image) TRY(alloc_zero(h, &h->d_rng_half, N * 8));
+    } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
+        g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
+    }
+
+    if (cfg->kind == MDPP_KIND_DISCRETE) {
+        if (cfg->S < 2 || cfg->S > 255 || cfg->A < 1 || cfg->L < 1 || cfg->L > 7) {
+            g_create_err = "mdpp_create: discrete needs 2 <= S <= 255, A >= 1, 1 <= L <= 7";
+            free_all(h); delete h; return MDPP_EUNSUPPORTED;
+        }
+        if (cfg->num_tables != 1 && cfg->num_tables != cfg->num_envs) {
+            g_create_err = "mdpp_create: num_tables must be 1 or num_envs"; free_all(h); delete h; return MDPP_EINVAL;
+        }
+        double nk = pow((double)cfg->S, (double)cfg->L);
+        if (nk > 4.0e9) { g_create_err = "mdpp_create: S^L too large"; free_all(h); delete h; return MDPP_EUNSUPPORTED; }
+        if (cfg->unit_rewards && cfg->delay > 32) {
+            g_create_err = "mdpp_create: unit_rewards needs delay <= 32"; free_all(h); delete h; return MDPP_EINVAL;
+        }
+        h->nkeys = (uint32_t)nk;
+        h->rbits_stride = (h->nkeys + 7u) / 8u;
+        const size_t T = (size_t)cfg->num_tables;
+        TRY(alloc_zero(h, &h->d_P, T * cfg->S * cfg->A));
+        TRY(alloc_zero(h, &h->d_is_term, T * cfg->S));
+        TRY(alloc_zero(h, &h->d_init_cdf, T * cfg->S * sizeof(double)));
+        if (cfg->unit_rewards) TRY(alloc_zero(h, &h->d_rbits, T * h->rbits_stride));
+        else TRY(alloc_zero(h, &h->d_rtable, T * (size_t)h->nkeys * sizeof(double)));
+        if (cfg->has_transition_noise) TRY(alloc_zero(h, &h->d_noise_cdf, (size_t)cfg->S * cfg->S * sizeof(double)));
+        TRY(alloc_zero(h, &h->d_state, N * sizeof(uint4)));
+        if (!cfg->unit_rewards && cfg->delay > 0) {
+            TRY(alloc_zero(h, &h->d_ring, (size_t)cfg->delay * N * sizeof(uint32_t)));
+            TRYHIP(hipMemset(h->d_ring, 0xFF, (size_t)cfg->delay * N * sizeof(uint32_t)));
+        }
+        DiscreteArgs &a = h->dargs;
+        memset(&a, 0, sizeof(a));
+        a.N = cfg->num_envs; a.S = cfg->S; a.A = cfg->A; a.L = cfg->L; a.delay = cfg->delay;
+        a.every_n = cfg->every_n; a.shared_tables = (cfg->num_tables == 1); a.unit_rewards = cfg->unit_rewards;
+        a.has_p_noise = cfg->has_transition_noise; a.has_r_noise = cfg->has_reward_noise;
+        a.autoreset = cfg->autoreset; a.max_steps = cfg->max_episode_steps;
+        a.obs_i32 = (cfg->obs_dtype == MDPP_OBS_I32 || cfg->image);
+        a.philox = (cfg->rng_mode == MDPP_RNG_PHILOX);
+        a.nkeys = h->nkeys; a.philox_seed = cfg->philox_seed; a.env_id_offset = cfg->env_id_offset;
+        a.r_noise = cfg->reward_noise; a.scale = cfg->reward_scale; a.shift = cfg->reward_shift;
+        a.term_add = cfg->term_state_reward * cfg->reward_scale;
+        a.P = (const uint8_t *)h->d_P; a.rtable = (const double *)h->d_rtable;
+        a.rbits = (const uint8_t *)h->d_rbits; a.is_term = (const uint8_t *)h->d_is_term;
+        a.init_cdf = (const double *)h->d_init_cdf; a.noise_cdf = (const double *)h->d_noise_cdf;
+        a.rbits_stride = h->rbits_stride;
+        // LDS carve for the shared-table path
+        uint32_t off = 0;
+        a.lds_P = off; off = align16(off + cfg->S * cfg->A);
+        a.lds_term = off; off = align16(off + cfg->S);
+        a.lds_init = off; off = align16(off + cfg->S * 8);
+        uint32_t rew_bytes = cfg->unit_rewards ? h->rbits_stride : h->nkeys * 8u;
+        a.rew_in_lds = rew_bytes <= 48u * 1024u;
+        a.lds_rew = off; if (a.rew_in_lds) off = align16(off + rew_bytes);
+        uint32_t noise_bytes = (uint32_t)cfg->S * cfg->S * 8u;
+        a.noise_in_lds = cfg->has_transition_noise && noise_bytes <= 32u * 1024u;
+        a.lds_noise = off; if (a.noise_in_lds) off = align16(off + noise_bytes);
+        a.lds_bytes = off;
+        a.state = (uint4 *)h->d_state; a.ring_keys = (uint32_t *)h->d_ring;
+        a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
+        a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
+        a.status = (uint32_t *)h->d_status;
+    } else if (cfg->kind == MDPP_KIND_CONTINUOUS) {
+        if (cfg->D < 1 || cfg->D > MDPP_MAX_DIM || cfg->order < 1 || cfg->order > MDPP_MAX_ORDER ||
+            cfg->n_rel < 1 || cfg->n_rel > cfg->D || cfg->n_boxes < 0 || cfg->n_boxes > MDPP_MAX_BOXES) {
+            g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes <= 8";
+            free_all(h); delete h; return MDPP_EUNSUPPORTED;
+        }
+        const size_t D = (size_t)cfg->D;
+        TRY(alloc_zero(h, &h->d_sd, (size_t)(cfg->order + 1) * D * N * sizeof(float)));
+        TRY(alloc_zero(h, &h->d_cur, D * N * sizeof(float)));
+        TRY(alloc_zero(h, &h->d_meta, N * sizeof(uint2)));
+        if (cfg->delay > 0) {
+            std::vector<uint32_t> init((size_t)cfg->delay * N, kRingPyZero);
+            TRY(alloc_zero(h, &h->d_ring, init.size() * sizeof(uint32_t)));
+            TRYHIP(hipMemcpy(h->d_ring, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        ContinuousArgs &a = h->cargs;
+        memset(&a, 0, sizeof(a));
+        a.N = cfg->num_envs; a.D = cfg->D; a.n_rel = cfg->n_rel; a.order = cfg->order;
+        a.delay = cfg->delay; a.every_n = cfg->every_n; a.make_denser = cfg->make_denser;
+        a.has_p_noise = cfg->has_p_noise; a.has_r_noise = cfg->has_reward_noise;
+        a.bounded = isfinite(cfg->state_space_max) ? 1 : 0;
+        a.autoreset = cfg->autoreset; a.max_steps = cfg->max_episode_steps;
+        a.philox = (cfg->rng_mode == MDPP_RNG_PHILOX); a.n_boxes = cfg->n_boxes;
+        a.philox_seed = cfg->philox_seed; a.env_id_offset = cfg->env_id_offset;
+        a.inertia32 = (float)cfg->inertia; a.amax32 = (float)cfg->action_space_max;
+        a.smax32 = (float)cfg->state_space_max; a.radius32 = (float)cfg->target_radius;
+        a.alw32 = (float)cfg->action_loss_weight;
+        a.scale = cfg->reward_scale; a.shift = cfg->reward_shift;
+        a.term_add = cfg->term_state_reward * cfg->reward_scale;
+        a.scale32 = (float)a.scale; a.shift32 = (float)a.shift; a.term_add32 = (float)a.term_add;
+        double f = 1.0;
+        for (int k = 1; k <= cfg->order; k++) {
+            f *= (double)k; a.fact[k] = f;
+            a.tpow32[k] = (float)pow(cfg->time_unit, (double)k);
+        }
+        a.p_noise = cfg->p_noise; a.r_noise = cfg->reward_noise;
+        a.reset_lo = (double)(-a.smax32); a.reset_range = (double)a.smax32 - (double)(-a.smax32);
+        a.rel_prefix = 1;
+        for (int j = 0; j < cfg->n_rel; j++) {
+            if (cfg->rel_idx[j] < 0 || cfg->rel_idx[j] >= cfg->D) {
+                g_create_err = "mdpp_create: relevant index out of range"; free_all(h); delete h; return MDPP_EINVAL;
+            }
+            a.rel[j] = cfg->rel_idx[j]; a.target[j] = cfg->target[j];
+            if (cfg->rel_idx[j] != j) a.rel_prefix = 0;
+        }
+        for (int b = 0; b < cfg->n_boxes * cfg->n_rel; b++) { a.box_lo[b] = cfg->box_lo[b]; a.box_hi[b] = cfg->box_hi[b]; }
+        a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
+        a.ring = (uint32_t *)h->d_ring;
+        a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
+        a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
+        a.status = (uint32_t *)h->d_status;
+        h->tables_ready = true;
+    } else {
+        g_create_err = "mdpp_create: unknown kind"; free_all(h); delete h; return MDPP_EINVAL;
+    }
+#undef TRY
+#undef TRYHIP
+    *out = h;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const double *rtable,
+                                           const uint8_t *rbits, const uint8_t *is_term,
+                                           const double *init_cdf, const double *noise_cdf) {
+    if (!h) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_DISCRETE) return fail(h, MDPP_EINVAL, "upload_discrete_tables: not a discrete handle");
+    if (!P || !is_term || !init_cdf) return fail(h, MDPP_EINVAL, "upload_discrete_tables: null table");
+    if (h->cfg.unit_rewards ? !rbits : !rtable) return fail(h, MDPP_EINVAL, "upload_discrete_tables: reward table missing");
+    if (h->cfg.has_transition_noise && !noise_cdf) return fail(h, MDPP_EINVAL, "upload_discrete_tables: noise_cdf missing");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->cfg.num_tables, S = (size_t)h->cfg.S, A = (size_t)h->cfg.A;
+    // every P entry must be a valid state id: the kernels index tables with it unchecked
+    for (size_t k = 0; k < T * S * A; k++)
+        if (P[k] >= S) return fail(h, MDPP_EINVAL, "upload_discrete_tables: P entry out of range");
+    HIPCHK(h, hipMemcpy(h->d_P, P, T * S * A, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_is_term, is_term, T * S, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_init_cdf, init_cdf, T * S * sizeof(double), hipMemcpyHostToDevice));
+    if (h->cfg.unit_rewards)
+        HIPCHK(h, hipMemcpy(h->d_rbits, rbits, T * h->rbits_stride, hipMemcpyHostToDevice));
+    else
+        HIPCHK(h, hipMemcpy(h->d_rtable, rtable, T * (size_t)h->nkeys * sizeof(double), hipMemcpyHostToDevice));
+    if (h->cfg.has_transition_noise)
+        HIPCHK(h, hipMemcpy(h->d_noise_cdf, noise_cdf, S * S * sizeof(double), hipMemcpyHostToDevice));
+    h->tables_ready = true;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_seed_streams(mdpp_env *h, int stream, const uint64_t *words) {
+    if (!h || !words) return MDPP_EINVAL;
+    if (h->cfg.rng_mode != MDPP_RNG_NUMPY_PCG64) return fail(h, MDPP_ESTATE, "seed_streams: handle is in Philox mode");
+    if (stream < 0 || stream >= MDPP_NUM_STREAMS || !h->d_rng_s[stream]) return fail(h, MDPP_EINVAL, "seed_streams: bad stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.num_envs;
+    std::vector<uint64_t> st(2 * N), inc(2 * N);
+    std::vector<uint32_t> half(2 * N);
+    for (size_t i = 0; i < N; i++) {
+        st[2 * i] = words[6 * i]; st[2 * i + 1] = words[6 * i + 1];
+        inc[2 * i] = words[6 * i + 2]; inc[2 * i + 1] = words[6 * i + 3];
+        half[2 * i] = (uint32_t)words[6 * i + 4]; half[2 * i + 1] = (uint32_t)words[6 * i + 5];
+    }
+    HIPCHK(h, hipMemcpy(h->d_rng_s[stream], st.data(), N * 16, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_rng_inc[stream], inc.data(), N * 16, hipMemcpyHostToDevice));
+    if (stream == MDPP_STREAM_IMAGE && h->d_rng_half)
+        HIPCHK(h, hipMemcpy(h->d_rng_half, half.data(), N * 8, hipMemcpyHostToDevice));
+    h->streams_ready[stream] = true;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words) {
+    if (!h || !words) return MDPP_EINVAL;
+    if (h->cfg.rng_mode != MDPP_RNG_NUMPY_PCG64) return fail(h, MDPP_ESTATE, "get_streams: handle is in Philox mode");
+    if (stream < 0 || stream >= MDPP_NUM_STREAMS || !h->d_rng_s[stream]) return fail(h, MDPP_EINVAL, "get_streams: bad stream");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    std::vector<uint64_t> st(2 * N), inc(2 * N);
+    std::vector<uint32_t> half(2 * N, 0);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_rng_s[stream], N * 16, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(inc.data(), h->d_rng_inc[stream], N * 16, hipMemcpyDeviceToHost));
+    if (stream == MDPP_STREAM_IMAGE && h->d_rng_half)
+        HIPCHK(h, hipMemcpy(half.data(), h->d_rng_half, N * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        words[6 * i] = st[2 * i]; words[6 * i + 1] = st[2 * i + 1];
+        words[6 * i + 2] = inc[2 * i]; words[6 * i + 3] = inc[2 * i + 1];
+        words[6 * i + 4] = half[2 * i]; words[6 * i + 5] = half[2 * i + 1];
+    }
+    return MDPP_OK;
+}
+
+static int check_ready(mdpp_env *h, const char *what) {
+    if (!h->tables_ready) return fail(h, MDPP_ESTATE, std::string(what) + ": tables not uploaded");
+    if (h->cfg.rng_mode == MDPP_RNG_NUMPY_PCG64) {
+        if (!h->streams_ready[MDPP_STREAM_ENV] || !h->streams_ready[MDPP_STREAM_SPACE])
+            return fail(h, MDPP_ESTATE, std::string(what) + ": RNG streams not seeded");
+        if (h->cfg.image && !h->streams_ready[MDPP_STREAM_IMAGE])
+            return fail(h, MDPP_ESTATE, std::string(what) + ": image RNG stream not seeded");
+    }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, void *stream) {
+    if (!h) return MDPP_EINVAL;
+    int rc = check_ready(h, "mdpp_reset");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->cfg.kind == MDPP_KIND_DISCRETE) {
+        if (h->cfg.image) return fail(h, MDPP_EUNSUPPORTED, "mdpp_reset: image observations not built yet");
+        return launch_discrete_reset(h, mask_dev, obs_dev, s);
+    }
+    return launch_continuous_reset(h, mask_dev, (float *)obs_dev, s);
+}
+
+static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float *reward,
+                       uint8_t *term, uint8_t *trunc, void *final_obs, void *stream) {
+    if (!h) return MDPP_EINVAL;
+    if (K < 1) return fail(h, MDPP_EINVAL, "step: K < 1");
+    if (!actions || !obs || !reward || !term || !trunc) return fail(h, MDPP_EINVAL, "step: null buffer");
+    int rc = check_ready(h, "mdpp_step");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->cfg.kind == MDPP_KIND_DISCRETE) {
+        if (h->cfg.image) return fail(h, MDPP_EUNSUPPORTED, "mdpp_step: image observations not built yet");
+        return launch_discrete_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
+    }
+    return launch_continuous_step(h, K, (const float *)actions, (float *)obs, reward, term, trunc,
+                                  (float *)final_obs, s);
+}
+
+extern "C" int mdpp_step(mdpp_env *h, const void *actions, void *obs, float *reward, uint8_t *term,
+                         uint8_t *trunc, void *final_obs, void *stream) {
+    return step_common(h, 1, actions, obs, reward, term, trunc, final_obs, stream);
+}
+
+extern "C" int mdpp_step_n(mdpp_env *h, int K, const void *actions, void *obs, float *reward,
+                           uint8_t *term, uint8_t *trunc, void *stream) {
+    return step_common(h, K, actions, obs, reward, term, trunc, nullptr, stream);
+}
+
+extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *, int32_t, int32_t, int32_t,
+                                           const int16_t *, const int16_t *) {
+    return fail(h, MDPP_EUNSUPPORTED, "image observations not built yet");
+}
+
+// ---- state export / import ------------------------------------------------------------------
+extern "C" int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist, int32_t *steps, double *ring) {
+    if (!h || h->cfg.kind != MDPP_KIND_DISCRETE) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    const int L = h->cfg.L, d = h->cfg.delay;
+    std::vector<uint32_t> st(4 * N);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_state, N * 16, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> keys;
+    std::vector<double> rt;
+    if (!h->cfg.unit_rewards && d > 0) {
+        keys.resize((size_t)d * N);
+        HIPCHK(h, hipMemcpy(keys.data(), h->d_ring, keys.size() * 4, hipMemcpyDeviceToHost));
+        const size_t T = (size_t)h->cfg.num_tables;
+        rt.resize(T * h->nkeys);
+        HIPCHK(h, hipMemcpy(rt.data(), h->d_rtable, rt.size() * 8, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < N; i++) {
+        uint64_t hb = ((uint64_t)st[4 * i + 1] << 32) | st[4 * i];
+        if (hist)
+            for (int j = 0; j <= L; j++) { // hist[0] oldest ... hist[L] newest
+                uint32_t b = (uint32_t)((hb >> (8 * (L - j))) & 0xFF);
+                hist[i * (L + 1) + j] = (b == 0xFF) ? -1 : (int32_t)b;
+            }
+        if (steps) steps[i] = (int32_t)st[4 * i + 2];
+        if (ring) {
+            for (int j = 0; j < d; j++) { // ring[0] pays out next
+                double v;
+                if (h->cfg.unit_rewards) v = ((st[4 * i + 3] >> (d - 1 - j)) & 1u) ? 1.0 : 0.0;
+                else {
+                    uint32_t k = keys[(size_t)((h->tick + j) % d) * N + i];
+                    v = (k == kNoKey) ? 0.0 : rt[(h->cfg.num_tables == 1 ? 0 : i) * h->nkeys + k];
+                }
+                ring[i * d + j] = v;
+            }
+        }
+    }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const int32_t *steps,
+                                       const double *ring) {
+    if (!h || h->cfg.kind != MDPP_KIND_DISCRETE || !hist || !steps) return MDPP_EINVAL;
+    if (ring && !h->cfg.unit_rewards)
+        return fail(h, MDPP_EUNSUPPORTED, "set_state_discrete: ring import needs unit_rewards (values are stored as sequence keys)");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    const int L = h->cfg.L, d = h->cfg.delay;
+    std::vector<uint32_t> st(4 * N);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_state, N * 16, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        uint64_t hb = ~0ULL;
+        for (int j = 0; j <= L; j++) {
+            int32_t v = hist[i * (L + 1) + j];
+            if (v >= h->cfg.S) return fail(h, MDPP_EINVAL, "set_state_discrete: state id out of range");
+            hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v);
+        }
+        st[4 * i] = (uint32_t)hb; st[4 * i + 1] = (uint32_t)(hb >> 32);
+        st[4 * i + 2] = (uint32_t)steps[i];
+        if (ring) {
+            uint32_t bits = 0;
+            for (int j = 0; j < d; j++) bits |= (ring[i * d + j] != 0.0 ? 1u : 0u) << (d - 1 - j);
+            st[4 * i + 3] = bits;
+        }
+    }
+    HIPCHK(h, hipMemcpy(h->d_state, st.data(), N * 16, hipMemcpyHostToDevice));
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_get_state_continuous(mdpp_env *h, float *derivs, float *cur, int32_t *steps,
+                                         double *ring, uint8_t *ring_is32, uint8_t *reached) {
+    if (!h || h->cfg.kind != MDPP_KIND_CONTINUOUS) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs, D = (size_t)h->cfg.D;
+    const int n = h->cfg.order, d = h->cfg.delay;
+    if (derivs) {
+        std::vector<float> sd((size_t)(n + 1) * D * N);
+        HIPCHK(h, hipMemcpy(sd.data(), h->d_sd, sd.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++)
+            for (int k = 0; k <= n; k++)
+                for (size_t c = 0; c < D; c++) derivs[(i * (n + 1) + k) * D + c] = sd[((size_t)k * D + c) * N + i];
+    }
+    if (cur) {
+        std::vector<float> cu(D * N);
+        HIPCHK(h, hipMemcpy(cu.data(), h->d_cur, cu.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++) for (size_t c = 0; c < D; c++) cur[i * D + c] = cu[c * N + i];
+    }
+    if (steps || reached) {
+        std::vector<uint32_t> me(2 * N);
+        HIPCHK(h, hipMemcpy(me.data(), h->d_meta, N * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++) {
+            if (steps) steps[i] = (int32_t)me[2 * i];
+            if (reached) reached[i] = (uint8_t)(me[2 * i + 1] & 1u);
+        }
+    }
+    if (ring && d > 0) {
+        std::vector<uint32_t> rg((size_t)d * N);
+        HIPCHK(h, hipMemcpy(rg.data(), h->d_ring, rg.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++)
+            for (int j = 0; j < d; j++) {
+                uint32_t b = rg[(size_t)((h->tick + j) % d) * N + i];
+                float f; memcpy(&f, &b, 4);
+                ring[i * d + j] = (b == kRingPyZero) ? 0.0 : (double)f;
+                if (ring_is32) ring_is32[i * d + j] = (b != kRingPyZero);
+            }
+    }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_set_state_continuous(mdpp_env *h, const float *derivs, const float *cur,
+                                         const int32_t *steps, const double *ring,
+                                         const uint8_t *ring_is32, const uint8_t *reached) {
+    if (!h || h->cfg.kind != MDPP_KIND_CONTINUOUS || !derivs || !cur || !steps) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs, D = (size_t)h->cfg.D;
+    const int n = h->cfg.order, d = h->cfg.delay;
+    std::vector<float> sd((size_t)(n + 1) * D * N), cu(D * N);
+    std::vector<uint32_t> me(2 * N);
+    for (size_t i = 0; i < N; i++) {
+        for (int k = 0; k <= n; k++)
+            for (size_t c = 0; c < D; c++) sd[((size_t)k * D + c) * N + i] = derivs[(i * (n + 1) + k) * D + c];
+        for (size_t c = 0; c < D; c++) cu[c * N + i] = cur[i * D + c];
+        me[2 * i] = (uint32_t)steps[i];
+        me[2 * i + 1] = reached ? (reached[i] ? 1u : 0u) : 0u;
+    }
+    HIPCHK(h, hipMemcpy(h->d_sd, sd.data(), sd.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_cur, cu.data(), cu.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_meta, me.data(), N * 8, hipMemcpyHostToDevice));
+    if (ring && d > 0) {
+        std::vector<uint32_t> rg((size_t)d * N);
+        for (size_t i = 0; i < N; i++)
+            for (int j = 0; j < d; j++) {
+                uint32_t b = kRingPyZero;
+                if (!ring_is32 || ring_is32[i * d + j]) { float f = (float)ring[i * d + j]; memcpy(&b, &f, 4); }
+                rg[(size_t)((h->tick + j) % d) * N + i] = b;
+            }
+        HIPCHK(h, hipMemcpy(h->d_ring, rg.data(), rg.size() * 4, hipMemcpyHostToDevice));
+    }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_status(mdpp_env *h, uint32_t *flags) {
+    if (!h || !flags) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    HIPCHK(h, hipMemcpy(flags, h->d_status, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->d_status, 0, N * 4));
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_timer_begin(mdpp_env *h, void *stream) {
+    if (!h) return MDPP_EINVAL;
+    HIPCHK(h, hipEventRecord(h->ev0, (hipStream_t)stream));
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_timer_end(mdpp_env *h, void *stream, float *ms) {
+    if (!h || !ms) return MDPP_EINVAL;
+    HIPCHK(h, hipEventRecord(h->ev1, (hipStream_t)stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return MDPP_OK;
+}

@@ -1,0 +1,104 @@
+// Internal definitions shared by the translation units of libmdpp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/mdpp.h"
+
+namespace mdpp {
+
+constexpr int kBlock = 256;         // 4 wavefronts of 64 lanes; one lane per env instance
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr uint32_t kRingPyZero = 0x7FC0DE1Au; // float32 ring slot holding Python's float 0.0
+
+// ---- discrete: kernel arguments (passed by value; wave-uniform => SGPRs) -------------------
+struct DiscreteArgs {
+    int32_t N;
+    int32_t S, A, L, delay, every_n;
+    int32_t shared_tables;      // 1: tables staged in LDS once per block; 0: one table set per env
+    int32_t unit_rewards;       // reward table is a bitmask of keys, every reward = 1.0
+    int32_t has_p_noise, has_r_noise;
+    int32_t autoreset, max_steps, obs_i32;
+    int32_t philox;
+    uint32_t nkeys;             // S^L
+    uint32_t tick;              // number of env steps taken by this handle before this launch
+    uint64_t philox_seed;
+    int64_t env_id_offset;
+    double r_noise, scale, shift, term_add; // term_add = term_state_reward * reward_scale
+    // tables (device)
+    const uint8_t *P;           // [T][S][A]
+    const double *rtable;       // [T][nkeys]      (unit_rewards == 0)
+    const uint8_t *rbits;       // [T][rbits_stride] (unit_rewards == 1)
+    const uint8_t *is_term;     // [T][S]
+    const double *init_cdf;     // [T][S]
+    const double *noise_cdf;    // [S][S]
+    uint32_t rbits_stride;
+    // LDS carve (byte offsets, 16-aligned), shared_tables only
+    uint32_t lds_P, lds_term, lds_rew, lds_init, lds_noise, lds_bytes;
+    uint32_t rew_in_lds, noise_in_lds;
+    // per-env state (device)
+    uint4 *state;               // {hist bytes 0-3, hist bytes 4-7, steps, ring bits}
+    uint32_t *ring_keys;        // [delay][N] keys awaiting payout (unit_rewards == 0)
+    ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc; // PCG64 streams
+    uint32_t *status;
+};
+
+struct ContinuousArgs {
+    int32_t N, D, n_rel, order, delay, every_n;
+    int32_t make_denser, has_p_noise, has_r_noise, bounded;
+    int32_t autoreset, max_steps, philox, n_boxes, rel_prefix;
+    uint32_t tick;
+    uint64_t philox_seed;
+    int64_t env_id_offset;
+    float inertia32, amax32, smax32, radius32, alw32, scale32, shift32, term_add32;
+    float tpow32[MDPP_MAX_ORDER + 1];
+    double fact[MDPP_MAX_ORDER + 1];
+    double p_noise, r_noise, scale, shift, term_add, reset_lo, reset_range;
+    int32_t rel[MDPP_MAX_DIM];
+    float target[MDPP_MAX_DIM];
+    float box_lo[MDPP_MAX_BOXES * MDPP_MAX_DIM];
+    float box_hi[MDPP_MAX_BOXES * MDPP_MAX_DIM];
+    // per-env state (device), struct-of-arrays: consecutive lanes -> consecutive addresses
+    float *sd;                  // [order+1][D][N] state_derivatives
+    float *cur;                 // [D][N] last returned (noisy, clipped) state
+    uint2 *meta;                // {steps, flags: bit0 reached_terminal}
+    uint32_t *ring;             // [delay][N] float32 bit patterns (kRingPyZero = Python 0.0)
+    ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
+    uint32_t *status;
+};
+
+} // namespace mdpp
+
+// The handle.  Plain struct; all members are host-side bookkeeping + device allocations.
+struct mdpp_env {
+    mdpp_config cfg;
+    int device;
+    std::string err;
+    uint32_t tick;              // env steps taken so far (ring head, Philox counter)
+    uint32_t reset_tick;        // reset() calls so far (Philox counter)
+    // device allocations
+    void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
+    void *d_state, *d_ring, *d_status;
+    void *d_sd, *d_cur, *d_meta;
+    void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
+    void *d_img_tpl, *d_img_clsx, *d_img_clsy, *d_img_rot;
+    int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
+    uint32_t nkeys, rbits_stride;
+    bool tables_ready, streams_ready[MDPP_NUM_STREAMS];
+    hipEvent_t ev0, ev1;
+    mdpp::DiscreteArgs dargs;
+    mdpp::ContinuousArgs cargs;
+};
+
+namespace mdpp {
+// implemented in the kernel translation units
+int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
+                         uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
+int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
+int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
+                           uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
+int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);
+int launch_image_obs(mdpp_env *h, const void *state_obs, const uint8_t *mask, uint8_t *img, hipStream_t s);
+} // namespace mdpp

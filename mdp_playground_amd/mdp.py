@@ -1,0 +1,389 @@
+"""Host-side MDP generation for the batched RLToyEnv.
+
+Restates what ``RLToyEnv.__init__`` does before the first ``step()`` —
+/root/reference/mdp_playground/envs/rl_toy_env.py:216-853 (defaults :342-566,
+``init_terminal_states`` :855, ``init_init_state_dist`` :992,
+``init_transition_function`` :1042, ``init_reward_function`` :1253) — and turns the
+result into flat tables the HIP kernels consume.  It draws from numpy
+``Generator(PCG64)`` objects in exactly the order the reference does, so for the same
+config/seed the tables and the post-construction RNG states are identical to the
+reference's (pinned by tests/test_mdp_builder.py against tests/golden/*.npz).
+
+None of this is on the per-step hot path; it runs once per MDP on the host.
+"""
+from __future__ import annotations
+
+import copy
+import sys
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_SEED_KEYS = ("relevant_state_space", "relevant_action_space", "irrelevant_state_space",
+              "irrelevant_action_space", "state_space", "action_space",
+              "image_representations")
+
+
+def new_generator(seed):
+    """gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed)))."""
+    if seed is not None and not (isinstance(seed, int) and seed >= 0):
+        raise TypeError(f"Seed must be a non-negative python int or None, got {seed!r}")
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+
+def pcg64_words(gen) -> np.ndarray:
+    """uint64[6] = {state_lo, state_hi, inc_lo, inc_hi, has_uint32, uinteger} of a PCG64 Generator."""
+    st = gen.bit_generator.state
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array([s & m, s >> 64, inc & m, inc >> 64, st["has_uint32"], st["uinteger"]],
+                    dtype=np.uint64)
+
+
+def fresh_stream_words(seed, count, stride=1) -> np.ndarray:
+    """PCG64 words of ``count`` freshly seeded generators with seeds seed, seed+stride, ..."""
+    out = np.empty((count, 6), dtype=np.uint64)
+    for i in range(count):
+        out[i] = pcg64_words(new_generator(None if seed is None else seed + i * stride))
+    return out
+
+
+@dataclass
+class CommonParams:
+    delay: int = 0
+    sequence_length: int = 1
+    reward_every_n_steps: int = 1
+    reward_noise: float | None = None       # std; None = no draw at all
+    reward_scale: float = 1.0
+    reward_shift: float = 0.0
+    term_state_reward: float = 0.0
+    seed_dict: dict = field(default_factory=dict)
+
+
+@dataclass
+class DiscreteMDP(CommonParams):
+    kind: str = "discrete"
+    S: int = 0
+    A: int = 0
+    diameter: int = 1
+    transition_noise: float | None = None
+    P: np.ndarray = None                     # int64 [S, A]
+    terminal_states: np.ndarray = None       # int64 [n_term]
+    init_dist: np.ndarray = None             # float64 [S]
+    rewardable_sequences: dict = None        # tuple(states) -> float (incl. make_denser sub-sequences)
+    space_rng_words: np.ndarray = None       # observation_spaces[0] RNG after P generation
+    image: dict | None = None                # ImageMultiDiscrete parameters, or None
+
+    def reward_table(self) -> np.ndarray:
+        """Dense float64[S**L]; key(seq) = sum seq[i] * S**(L-1-i).  Only full-length keys can
+        match in step() (rl_toy_env.py:1837-1841), shorter make_denser keys never do."""
+        L, S = self.sequence_length, self.S
+        t = np.zeros(S ** L, dtype=np.float64)
+        for seq, val in self.rewardable_sequences.items():
+            if len(seq) != L:
+                continue
+            k = 0
+            for s in seq:
+                k = k * S + int(s)
+            t[k] = val
+        return t
+
+    def is_terminal_table(self) -> np.ndarray:
+        t = np.zeros(self.S, dtype=np.uint8)
+        t[np.asarray(self.terminal_states, dtype=np.int64)] = 1
+        return t
+
+    def init_cdf(self) -> np.ndarray:
+        cdf = np.cumsum(np.asarray(self.init_dist, dtype=np.float64))
+        return cdf / cdf[-1]
+
+    def noise_cdf(self) -> np.ndarray | None:
+        """Row n = normalised cdf Generator.choice builds for the P-noise categorical with mode n
+        (rl_toy_env.py:1605-1612)."""
+        if not self.transition_noise:
+            return None
+        S = self.S
+        out = np.empty((S, S), dtype=np.float64)
+        for n in range(S):
+            probs = np.ones(shape=(S,)) * self.transition_noise / (S - 1)
+            probs[n] = 1 - self.transition_noise
+            cdf = probs.cumsum()
+            cdf /= cdf[-1]
+            out[n] = cdf
+        return out
+
+
+@dataclass
+class ContinuousMDP(CommonParams):
+    kind: str = "continuous"
+    D: int = 0
+    relevant_indices: list = None
+    order: int = 1
+    inertia: float = 1.0
+    time_unit: float = 1.0
+    state_space_max: float = np.inf
+    action_space_max: float = np.inf
+    target_point: np.ndarray = None          # float32 [n_rel]
+    target_radius: float = 0.05
+    make_denser: bool = True
+    action_loss_weight: float = 0.0
+    transition_noise: float | None = None    # std; None = no draw
+    box_lo: np.ndarray = None                # float32 [K, n_rel] terminal hypercubes
+    box_hi: np.ndarray = None
+
+
+def _require(cond, msg):
+    if not cond:
+        raise AssertionError(msg)
+
+
+def _seed_dict(config):
+    """rl_toy_env.py:285-333: an int seed spawns 7 sub-seeds from the env generator."""
+    if "seed" not in config or config["seed"] is None:
+        seed_int = None
+    elif isinstance(config["seed"], dict):
+        sd = dict(config["seed"])
+        return sd, new_generator(sd["env"])
+    elif isinstance(config["seed"], int):
+        seed_int = config["seed"]
+    else:
+        raise TypeError("Unsupported data type for seed, actual config: ",
+                        type(config["seed"]), config)
+    env_rng = new_generator(seed_int)
+    sd = {"env": seed_int}
+    for k in _SEED_KEYS:
+        sd[k] = env_rng.integers(sys.maxsize).item()
+    return sd, env_rng
+
+
+def _common(config, kind, sd):
+    L = config.get("sequence_length", 1)
+    _require(L > 0, 'config["sequence_length"] <= 0. Set to: ' + str(L))
+    every_n = config.get("reward_every_n_steps", L if kind == "discrete" else 1)
+    rn = config.get("reward_noise", None)
+    if callable(rn):
+        raise NotImplementedError("callable reward_noise runs on the host only; the device path "
+                                  "takes a float std (reference rl_toy_env.py:398-403)")
+    return dict(delay=config.get("delay", 0), sequence_length=L, reward_every_n_steps=every_n,
+                reward_noise=None if rn is None else float(rn),
+                reward_scale=config.get("reward_scale", 1.0),
+                reward_shift=config.get("reward_shift", 0.0),
+                term_state_reward=config.get("term_state_reward", 0.0), seed_dict=sd)
+
+
+def _sample_space(rng, n, prob=None, size=1, replace=True):
+    """DiscreteExtended.sample (spaces/discrete_extended.py:11-23)."""
+    sampled = np.squeeze(rng.choice(n, size=size, p=prob, replace=replace))
+    return int(sampled) if sampled.shape == () else sampled
+
+
+def _next_set_prob(S, A, s):
+    """Uniform mass on the independent set following the one s lives in (:1074-1092)."""
+    i_s = s // A
+    prob = np.zeros(shape=(S,))
+    ind_1 = ((i_s + 1) * A) % S
+    ind_2 = ((i_s + 2) * A) % S
+    if ind_2 <= ind_1:
+        ind_2 += S
+    prob[ind_1:ind_2] = np.ones(shape=(A,)) / A
+    return prob
+
+
+def _rewardable_sequences(env_rng, n_nonterm, A, L, fraction, repeats, diameter):
+    """get_sequences, rl_toy_env.py:1273-1473: pick sequence numbers without replacement from
+    the env generator and decode them (base-n digits with repeats, a Lehmer-style mixed-radix
+    code without)."""
+    seqs = []
+    if repeats:
+        total = n_nonterm ** L
+        n_sel = int(fraction * total)
+        if n_sel == 0:
+            n_sel = 1
+            warnings.warn("0 rewardable sequences per independent set for given reward_density, "
+                          "sequence_length, diameter and terminal_state_density. Setting it to 1.")
+        picks = env_rng.choice(total, size=n_sel, replace=False)
+        for i_s in range(diameter):
+            for num in picks:
+                seq = []
+                while len(seq) != L:
+                    seq.append(num % n_nonterm + ((len(seq) + i_s) % diameter) * A)
+                    num = num // n_nonterm
+                seqs.append(seq)
+        return seqs
+    _require(L <= diameter * n_nonterm, "When there are no repeats in sequences, the sequence "
+             "length should be <= diameter * maximum.")
+    radices = [n_nonterm - (i // diameter) for i in range(L)]
+    for i_s in range(diameter):
+        total = np.prod(radices)
+        n_sel = int(fraction * total)
+        if n_sel == 0:
+            n_sel = 1
+            warnings.warn("0 rewardable sequences per independent set for given reward_density, "
+                          "sequence_length, diameter and terminal_state_density. Setting it to 1.")
+        picks = env_rng.choice(total, size=n_sel, replace=False)
+        for num in picks:
+            pools = [list(range(n_nonterm)) for _ in range(diameter)]
+            seq = []
+            for pos, radix in enumerate(radices):
+                which = (pos + i_s) % diameter
+                digit = num % radix
+                seq.append(pools[which].pop(digit) + which * A)
+                num = num // radix
+            _require(seq not in seqs, "None of the generated sequences should have clashed with "
+                     "an existing rewardable sequence when it was generated.")
+            seqs.append(seq)
+    return seqs
+
+
+def build_discrete(config) -> DiscreteMDP:
+    config = copy.deepcopy(config)
+    if config.get("use_custom_mdp", False):
+        raise NotImplementedError("use_custom_mdp (callable / matrix P and R) is not on the device path")
+    sd, env_rng = _seed_dict(config)
+    common = _common(config, "discrete", sd)
+    L = common["sequence_length"]
+    diameter = config.get("diameter", 1)
+    if config.get("irrelevant_features", False):
+        raise NotImplementedError("discrete irrelevant_features (Tuple spaces) is not built yet")
+    _require(isinstance(config["action_space_size"], int),
+             "Did you mean to turn irrelevant_features? If so, please set irrelevant_features = "
+             "True in config. If not, please provide an int for action_space_size.")
+    A = config["action_space_size"]
+    S = A * diameter                                      # :589-591
+    tn = config.get("transition_noise", None)
+    # :868-881 terminal states = the last int(density * A) states of every independent set
+    n_term = int(config.get("terminal_state_density", 0.25) * A)
+    terminal = np.array([j * A - 1 - i for j in range(1, diameter + 1) for i in range(n_term)],
+                        dtype=np.int64)
+    n_nonterm = A - n_term
+    # :1003-1018 rho_0 uniform over non-terminal states
+    init_dist = np.array(([1 / (n_nonterm * diameter) for _ in range(n_nonterm)]
+                          + [0 for _ in range(n_term)]) * diameter)
+    # :1050-1151 P, drawn from the relevant state space's own generator
+    space_rng = new_generator(sd["relevant_state_space"])
+    P = np.full((S, A), -1, dtype=np.int64)
+    if config.get("maximally_connected", True):
+        for s in range(S):
+            if diameter == 1:
+                P[s] = _sample_space(space_rng, S, size=A, replace=False)
+            else:
+                P[s] = _sample_space(space_rng, S, prob=_next_set_prob(S, A, s), size=A,
+                                     replace=False)
+    else:
+        for s in range(S):
+            prob = _next_set_prob(S, A, s)
+            for a in range(A):
+                P[s, a] = _sample_space(space_rng, S, prob=prob)
+    for i_s in range(diameter):
+        for s in range(A - n_term, A):
+            P[i_s * A + s, :] = i_s * A + s               # terminal self-loops, :1135-1151
+    # :1508-1558 rewardable sequences, drawn from the env generator
+    seqs = _rewardable_sequences(env_rng, n_nonterm, A, L, config.get("reward_density", 0.25),
+                                 config.get("repeats_in_sequences", False), diameter)
+    reward_dist = config.get("reward_dist", None)
+    if isinstance(reward_dist, list):                     # :1528-1544
+        n_rews = diameter * len(seqs)
+        rews = [1.0] if n_rews == 1 else np.linspace(reward_dist[0], reward_dist[1], num=n_rews)
+        _require(rews[-1] == 1.0, "reward_dist interval must end at 1.0")
+        env_rng.shuffle(rews)
+        reward_dist = lambda rng, r_dict: rews[len(r_dict)]  # noqa: E731
+    make_denser = config.get("make_denser", False)
+    table = {}
+    for seq in seqs:                                      # insert_sequence, :1475-1504
+        seq = tuple(int(x) for x in seq)
+        table[seq] = reward_dist(env_rng, table) if callable(reward_dist) else 1.0
+        if make_denser:
+            for n in range(1, len(seq)):
+                sub = seq[:n]
+                if sub not in table:
+                    table[sub] = 0.0
+                table[sub] += table[seq] * n / len(seq)
+    image = None
+    if config.get("image_representations", False):
+        image = _image_params(config, sd)
+    return DiscreteMDP(kind="discrete", S=S, A=A, diameter=diameter,
+                       transition_noise=None if not tn else float(tn), P=P,
+                       terminal_states=terminal, init_dist=init_dist,
+                       rewardable_sequences=table, space_rng_words=pcg64_words(space_rng),
+                       image=image, **common)
+
+
+def _image_params(config, sd):
+    """Defaults of rl_toy_env.py:442-496 and the ImageMultiDiscrete ctor call at :707-717."""
+    transforms = config.get("image_transforms", "none")
+    sh_quant = config.get("image_sh_quant", 1 if "shift" in transforms else None)
+    ro_quant = config.get("image_ro_quant", 1 if "rotate" in transforms else None)
+    scale_range = config.get("image_scale_range", (0.5, 1.5) if "scale" in transforms else None)
+    return dict(width=config.get("image_width", 100), height=config.get("image_height", 100),
+                transforms=transforms, sh_quant=sh_quant, ro_quant=ro_quant,
+                scale_range=None if scale_range is None else tuple(scale_range),
+                circle_radius=20, seed=sd["image_representations"])
+
+
+def build_continuous(config) -> ContinuousMDP:
+    config = copy.deepcopy(config)
+    if config.get("use_custom_mdp", False):
+        raise NotImplementedError("use_custom_mdp is not on the device path")
+    sd, _ = _seed_dict(config)
+    common = _common(config, "continuous", sd)
+    D = config["state_space_dim"]
+    rf = config.get("reward_function", "move_to_a_point")
+    if rf != "move_to_a_point":
+        raise NotImplementedError("only reward_function='move_to_a_point' is built (SURVEY.md §8f)")
+    if config.get("image_representations", False):
+        raise NotImplementedError("ImageContinuous observations are not built yet (SURVEY.md §8f)")
+    _require(common["sequence_length"] == 1, "move_to_a_point needs sequence_length == 1")
+    if config.get("irrelevant_features", False):
+        _require("relevant_indices" in config,
+                 "Please provide dimensions of state space relevant to rewards.")
+    rel = list(config.get("relevant_indices", range(D)))
+    if "target_point" in config:
+        target = np.array(config["target_point"], dtype=np.float32)
+        _require(target.shape == (len(rel),),
+                 "target_point should have dimensionality = relevant_state_space dimensionality")
+    else:
+        # The reference falls back to float64 zeros of length state_space_dim (:654), which
+        # silently promotes the reward arithmetic to float64; require the explicit form instead.
+        raise NotImplementedError("please pass target_point explicitly (float32 semantics)")
+    tn = config.get("transition_noise", None)
+    if callable(tn):
+        raise NotImplementedError("callable transition_noise runs on the host only")
+    box_lo = box_hi = None
+    if "terminal_states" in config:
+        if callable(config["terminal_states"]):
+            raise NotImplementedError("callable terminal_states runs on the host only")
+        ts = config["terminal_states"]
+        for i, c in enumerate(ts):
+            _require(len(c) == len(rel), "Specified terminal state centres should have "
+                     "dimensionality = number of relevant_indices. That was not the case for "
+                     "centre no.: " + str(i))
+        edge = config["term_state_edge"]
+        box_lo = np.array([[c[j] - edge / 2 for j in range(len(rel))] for c in ts]).astype(np.float32)
+        box_hi = np.array([[c[j] + edge / 2 for j in range(len(rel))] for c in ts]).astype(np.float32)
+    return ContinuousMDP(
+        kind="continuous", D=D, relevant_indices=rel,
+        order=config.get("transition_dynamics_order", 1), inertia=config.get("inertia", 1.0),
+        time_unit=config.get("time_unit", 1.0),
+        state_space_max=config.get("state_space_max", np.inf),
+        action_space_max=config.get("action_space_max", np.inf),
+        target_point=target, target_radius=config.get("target_radius", 0.05),
+        make_denser=config.get("make_denser", True),
+        action_loss_weight=config.get("action_loss_weight", 0.0),
+        transition_noise=None if tn is None else float(tn), box_lo=box_lo, box_hi=box_hi, **common)
+
+
+def build_mdp(config):
+    """Dispatch on state_space_type like rl_toy_env.py:339,499-543."""
+    if config == {}:
+        config = {"state_space_size": 8, "action_space_size": 8, "state_space_type": "discrete",
+                  "action_space_type": "discrete", "terminal_state_density": 0.25,
+                  "maximally_connected": True}
+    kind = config["state_space_type"].lower()
+    if kind == "discrete":
+        return build_discrete(config)
+    if kind == "continuous":
+        return build_continuous(config)
+    if kind == "grid":
+        raise NotImplementedError("grid envs are not built yet (SURVEY.md §8f rank 2)")
+    raise ValueError("Unknown state_space_type")

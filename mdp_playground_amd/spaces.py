@@ -1,0 +1,62 @@
+"""Minimal space descriptors for the vector env (gymnasium is not a dependency here).
+
+They mirror what the reference exposes through ``env.observation_space`` /
+``env.action_space`` — spaces/discrete_extended.py, spaces/box_extended.py,
+spaces/image_multi_discrete.py — each with its own numpy generator seeded at construction.
+"""
+import numpy as np
+
+
+def _gen(seed):
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+
+class DiscreteSpace:
+    def __init__(self, n, seed=None):
+        self.n = int(n)
+        self.shape = ()
+        self.dtype = np.dtype(np.int64)
+        self.np_random = _gen(seed)
+
+    def sample(self, max=None, prob=None, size=1, replace=True):
+        """DiscreteExtended.sample (spaces/discrete_extended.py:11-23)."""
+        if max is None:
+            max = self.n
+        s = np.squeeze(self.np_random.choice(max, size=size, p=prob, replace=replace))
+        return int(s) if s.shape == () else s
+
+    def contains(self, x):
+        return bool(np.issubdtype(np.asarray(x).dtype, np.integer) and 0 <= int(x) < self.n)
+
+    def __repr__(self):
+        return f"DiscreteSpace({self.n})"
+
+
+class BoxSpace:
+    def __init__(self, low, high, shape, dtype=np.float32, seed=None):
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self.low = np.full(self.shape, low, dtype=self.dtype)
+        self.high = np.full(self.shape, high, dtype=self.dtype)
+        self.np_random = _gen(seed)
+
+    def sample(self):
+        """gymnasium Box.sample for an all-bounded or all-unbounded box."""
+        if np.all(np.isfinite(self.low)) and np.all(np.isfinite(self.high)):
+            s = self.np_random.uniform(low=self.low, high=self.high, size=self.shape)
+        else:
+            s = self.np_random.normal(size=self.shape)
+        return s.astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return bool(np.can_cast(x.dtype, self.dtype) and x.shape == self.shape
+                    and np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f"BoxSpace({self.low.flat[0]}, {self.high.flat[0]}, {self.shape}, {self.dtype})"
+
+
+class ImageSpace(BoxSpace):
+    def __init__(self, width, height):
+        super().__init__(0, 255, (width, height, 1), dtype=np.uint8)

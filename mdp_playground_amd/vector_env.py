@@ -1,0 +1,401 @@
+"""RLToyVectorEnv — the reference's RLToyEnv (mdp_playground/envs/rl_toy_env.py:26) batched on
+one MI355X: same config dict, Gym-style reset/step, torch tensors in and out.
+
+Each env instance i of the batch behaves exactly like one reference object:
+
+* ``RLToyVectorEnv(num_envs=N, **config)`` — one MDP (tables generated on the host from
+  ``config["seed"]`` exactly as ``RLToyEnv.__init__`` does) shared by N instances.  Instance i is
+  the reference env built from ``config`` and then ``reset(seed=seed_dict["env"] + i)`` (what a
+  gymnasium SyncVectorEnv does); its space generator (discrete P-noise, continuous reset
+  sampling) is the reference's own for i = 0 and ``Space.seed(space_seed + i)`` for i > 0.
+* ``RLToyVectorEnv(seeds=[s0, s1, ...], **config)`` — N *different* MDPs: instance i is the
+  reference ``RLToyEnv(**{**config, "seed": seeds[i]})`` verbatim (tables per env in HBM).
+
+``rng="numpy"`` (default) keeps numpy ``Generator(PCG64)`` streams per env on the device, so
+noise and resets are bit-identical to the reference under identical seeds; ``rng="philox"`` is a
+stateless counter-based alternative (no RNG state in HBM, own stream, same distributions).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from . import mdp as mdp_mod
+from .spaces import BoxSpace, DiscreteSpace, ImageSpace
+
+_AUTORESET = {"disabled": capi.AUTORESET_DISABLED, "same_step": capi.AUTORESET_SAME_STEP}
+
+
+def _stack(arrs, dtype):
+    return np.ascontiguousarray(np.stack([np.asarray(a) for a in arrs]), dtype=dtype)
+
+
+class RLToyVectorEnv:
+    metadata = {"render_modes": []}
+
+    def __init__(self, num_envs=None, device=None, *, seeds=None, rng="numpy",
+                 autoreset="same_step", max_episode_steps=None, env_id_offset=0,
+                 philox_seed=None, **config):
+        self._lib = capi.load()
+        self._h = None
+        if not torch.cuda.is_available():
+            raise capi.MdppError("RLToyVectorEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        if autoreset not in _AUTORESET:
+            raise ValueError("autoreset must be 'same_step' or 'disabled'")
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise capi.MdppError("device must be a cuda (ROCm) device")
+        self.config = copy.deepcopy(config)   # the reference mutates its config (:339,...); we do not
+        if seeds is not None:
+            if num_envs is not None and num_envs != len(seeds):
+                raise ValueError("num_envs != len(seeds)")
+            num_envs = len(seeds)
+            self.mdps = [mdp_mod.build_mdp({**config, "seed": s}) for s in seeds]
+        else:
+            if num_envs is None:
+                num_envs = 1
+            self.mdps = [mdp_mod.build_mdp(config)]
+        self.num_envs = int(num_envs)
+        self.env_id_offset = int(env_id_offset)
+        self.autoreset = autoreset
+        self.rng = rng
+        m = self.mdps[0]
+        self.kind = m.kind
+        self.seed_dict = m.seed_dict
+        self._per_env = seeds is not None
+        self.seeded_streams = {}
+
+        cfg = capi.MdppConfig()
+        cfg.abi_version = capi.MDPP_ABI_VERSION
+        cfg.kind = capi.KIND_DISCRETE if m.kind == "discrete" else capi.KIND_CONTINUOUS
+        cfg.num_envs = self.num_envs
+        cfg.env_id_offset = self.env_id_offset
+        cfg.rng_mode = capi.RNG_NUMPY_PCG64 if rng == "numpy" else capi.RNG_PHILOX
+        cfg.autoreset = _AUTORESET[autoreset]
+        cfg.max_episode_steps = int(max_episode_steps or 0)
+        if philox_seed is None:
+            e = m.seed_dict.get("env")
+            philox_seed = 0x9E3779B97F4A7C15 if e is None else int(e)
+        cfg.philox_seed = int(philox_seed) & (2 ** 64 - 1)
+        cfg.delay = int(m.delay)
+        cfg.every_n = int(m.reward_every_n_steps)
+        cfg.has_reward_noise = int(m.reward_noise is not None)
+        cfg.reward_noise = float(m.reward_noise or 0.0)
+        cfg.reward_scale = float(m.reward_scale)
+        cfg.reward_shift = float(m.reward_shift)
+        cfg.term_state_reward = float(m.term_state_reward)
+        if m.kind == "discrete":
+            self._init_discrete(cfg)
+        else:
+            self._init_continuous(cfg)
+        h = C.c_void_p()
+        rc = self._lib.mdpp_create(C.byref(cfg), self.device.index or 0, C.byref(h))
+        capi.check(self._lib, None, rc, "mdpp_create")
+        self._h = h
+        self._cfg = cfg
+        if m.kind == "discrete":
+            self._upload_discrete()
+        self._alloc_buffers()
+        if rng == "numpy":
+            self._seed_streams(self.seed_dict.get("env"), initial=True)
+        # the reference constructor ends with reset(seed=seed_dict["env"]) (:831-833)
+        self._reset_all()
+
+    # ------------------------------------------------------------------ construction helpers
+    def _init_discrete(self, cfg):
+        m = self.mdps[0]
+        for o in self.mdps[1:]:
+            if (o.S, o.A, o.sequence_length, o.delay) != (m.S, m.A, m.sequence_length, m.delay):
+                raise ValueError("per-env MDPs must share S, A, sequence_length and delay")
+        if m.image is not None:
+            raise NotImplementedError("image_representations is not built yet")
+        cfg.S, cfg.A, cfg.L = m.S, m.A, m.sequence_length
+        cfg.num_tables = self.num_envs if self._per_env else 1
+        unit = all(v == 1.0 for mm in self.mdps for k, v in mm.rewardable_sequences.items()
+                   if len(k) == mm.sequence_length)
+        cfg.unit_rewards = int(unit and m.delay <= 32)
+        cfg.has_transition_noise = int(bool(m.transition_noise))
+        cfg.transition_noise = float(m.transition_noise or 0.0)
+        dtype_o = self.config.get("dtype_o", self.config.get("dtype_s", np.int64))
+        self._obs_torch_dtype = torch.int32 if np.dtype(dtype_o) == np.int32 else torch.int64
+        cfg.obs_dtype = capi.OBS_I32 if self._obs_torch_dtype == torch.int32 else capi.OBS_I64
+        self.single_observation_space = DiscreteSpace(m.S, seed=m.seed_dict.get("relevant_state_space"))
+        self.single_action_space = DiscreteSpace(m.A, seed=m.seed_dict.get("relevant_action_space"))
+        self.transition_matrix = m.P
+        self.rewardable_sequences = m.rewardable_sequences
+
+    def _upload_discrete(self):
+        ms = self.mdps
+        unit = bool(self._cfg.unit_rewards)
+        P = _stack([m.P for m in ms], np.uint8)
+        is_term = _stack([m.is_terminal_table() for m in ms], np.uint8)
+        init_cdf = _stack([m.init_cdf() for m in ms], np.float64)
+        rtable = rbits = None
+        if unit:
+            rbits = _stack([np.packbits((m.reward_table() != 0).astype(np.uint8), bitorder="little")
+                            for m in ms], np.uint8)
+        else:
+            rtable = _stack([m.reward_table() for m in ms], np.float64)
+        noise = ms[0].noise_cdf()
+        noise = None if noise is None else np.ascontiguousarray(noise, dtype=np.float64)
+        rc = self._lib.mdpp_upload_discrete_tables(self._h, capi.nptr(P), capi.nptr(rtable),
+                                                   capi.nptr(rbits), capi.nptr(is_term),
+                                                   capi.nptr(init_cdf), capi.nptr(noise))
+        capi.check(self._lib, self._h, rc, "mdpp_upload_discrete_tables")
+
+    def _init_continuous(self, cfg):
+        m = self.mdps[0]
+        if self._per_env:
+            # continuous MDPs carry no generated tables: per-env seeds only change the streams
+            pass
+        cfg.D, cfg.n_rel, cfg.order = m.D, len(m.relevant_indices), m.order
+        for j, r in enumerate(m.relevant_indices):
+            cfg.rel_idx[j] = int(r)
+            cfg.target[j] = float(m.target_point[j])
+        cfg.make_denser = int(bool(m.make_denser))
+        cfg.has_p_noise = int(m.transition_noise is not None)
+        cfg.p_noise = float(m.transition_noise or 0.0)
+        cfg.inertia, cfg.time_unit = float(m.inertia), float(m.time_unit)
+        cfg.state_space_max, cfg.action_space_max = float(m.state_space_max), float(m.action_space_max)
+        cfg.target_radius, cfg.action_loss_weight = float(m.target_radius), float(m.action_loss_weight)
+        nb = 0 if m.box_lo is None else len(m.box_lo)
+        if nb > capi.MAX_BOXES:
+            raise NotImplementedError(f"at most {capi.MAX_BOXES} terminal hypercubes")
+        cfg.n_boxes = nb
+        for b in range(nb):
+            for j in range(cfg.n_rel):
+                cfg.box_lo[b * cfg.n_rel + j] = float(m.box_lo[b][j])
+                cfg.box_hi[b * cfg.n_rel + j] = float(m.box_hi[b][j])
+        cfg.obs_dtype = capi.OBS_F32
+        self._obs_torch_dtype = torch.float32
+        self.single_observation_space = BoxSpace(-m.state_space_max, m.state_space_max, (m.D,),
+                                                 seed=m.seed_dict.get("state_space"))
+        self.single_action_space = BoxSpace(-m.action_space_max, m.action_space_max, (m.D,),
+                                            seed=m.seed_dict.get("action_space"))
+
+    def _alloc_buffers(self):
+        N, dev = self.num_envs, self.device
+        shape = (N,) if self.kind == "discrete" else (N, self.mdps[0].D)
+        self._obs = torch.zeros(shape, dtype=self._obs_torch_dtype, device=dev)
+        self._final_obs = torch.zeros(shape, dtype=self._obs_torch_dtype, device=dev)
+        self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
+        self._term = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+
+    def _seed_streams(self, env_seed, initial):
+        """Env streams: PCG64(SeedSequence(env_seed + global id)), i.e. what reset(seed=...) does
+        (gymnasium Env.reset -> seeding.np_random; rl_toy_env.py:2225).  Space streams are only
+        (re)built at construction."""
+        N, off = self.num_envs, self.env_id_offset
+        if self._per_env:
+            env_words = np.stack([mdp_mod.pcg64_words(mdp_mod.new_generator(
+                m.seed_dict["env"] if env_seed is None or initial else env_seed + off + i))
+                for i, m in enumerate(self.mdps)])
+        else:
+            base = None if env_seed is None else env_seed + off
+            env_words = mdp_mod.fresh_stream_words(base, N)
+        self._put_stream(capi.STREAM_ENV, env_words)
+        if not initial:
+            return
+        if self.kind == "discrete":
+            if self._per_env:
+                sp = np.stack([m.space_rng_words for m in self.mdps])
+            else:
+                R = self.seed_dict["relevant_state_space"]
+                sp = mdp_mod.fresh_stream_words(R + off, N)
+                if off == 0:
+                    sp[0] = self.mdps[0].space_rng_words   # the reference's own generator, post-P
+        else:
+            if self._per_env:
+                sp = np.stack([mdp_mod.pcg64_words(mdp_mod.new_generator(m.seed_dict["state_space"]))
+                               for m in self.mdps])
+            else:
+                sp = mdp_mod.fresh_stream_words(self.seed_dict["state_space"] + off, N)
+        self._put_stream(capi.STREAM_SPACE, sp)
+
+    def _put_stream(self, stream, words):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        assert words.shape == (self.num_envs, 6)
+        self.seeded_streams[stream] = words.copy()   # what was last uploaded (tests, checkpoints)
+        rc = self._lib.mdpp_seed_streams(self._h, stream, capi.nptr(words))
+        capi.check(self._lib, self._h, rc, "mdpp_seed_streams")
+
+    # ------------------------------------------------------------------ Gym-style API
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _reset_all(self, mask=None):
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mptr = C.c_void_p(mask.data_ptr())
+        rc = self._lib.mdpp_reset(self._h, mptr, C.c_void_p(self._obs.data_ptr()), self._stream())
+        capi.check(self._lib, self._h, rc, "mdpp_reset")
+        return self._obs
+
+    def reset(self, seed=None, options=None, mask=None):
+        """reset(seed=None) -> (obs, {}), rl_toy_env.py:2217.  ``seed`` re-seeds env i's generator
+        with seed + i first, as the reference (gymnasium Env.reset) does.  ``mask`` (bool[N])
+        restricts the reset to some envs."""
+        if seed is not None:
+            if self.rng != "numpy":
+                raise capi.MdppError("reset(seed=...) re-seeds numpy streams; this env uses rng='philox'")
+            if not isinstance(seed, int) or seed < 0:
+                raise TypeError("seed must be a non-negative python int")
+            self._seed_streams(seed, initial=False)
+        return self._reset_all(mask), {}
+
+    def step(self, actions):
+        """step(actions) -> (obs, reward, terminated, truncated, info), rl_toy_env.py:1992.
+        Returned tensors alias preallocated device buffers (valid until the next call)."""
+        a = self._as_actions(actions, None)
+        rc = self._lib.mdpp_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                                 C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._term.data_ptr()),
+                                 C.c_void_p(self._trunc.data_ptr()),
+                                 C.c_void_p(self._final_obs.data_ptr()), self._stream())
+        capi.check(self._lib, self._h, rc, "mdpp_step")
+        info = {"final_obs": self._final_obs} if self.autoreset == "same_step" else {}
+        return self._obs, self._reward, self._term.view(torch.bool), self._trunc.view(torch.bool), info
+
+    def rollout(self, actions, out=None):
+        """K fused steps in ONE kernel launch (per-env state stays in registers).
+        actions: [K, N] int32 or [K, N, D] float32, time-major.  Returns (obs, reward, terminated,
+        truncated) with a leading K axis; equivalent to K step() calls."""
+        K = int(actions.shape[0])
+        a = self._as_actions(actions, K)
+        if out is None:
+            out = self.alloc_rollout(K)
+        obs, rew, term, trunc = out
+        rc = self._lib.mdpp_step_n(self._h, K, C.c_void_p(a.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                   C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
+                                   C.c_void_p(trunc.data_ptr()), self._stream())
+        capi.check(self._lib, self._h, rc, "mdpp_step_n")
+        return obs, rew, term.view(torch.bool), trunc.view(torch.bool)
+
+    def alloc_rollout(self, K):
+        N, dev = self.num_envs, self.device
+        shape = (K, N) if self.kind == "discrete" else (K, N, self.mdps[0].D)
+        return (torch.empty(shape, dtype=self._obs_torch_dtype, device=dev),
+                torch.empty((K, N), dtype=torch.float32, device=dev),
+                torch.empty((K, N), dtype=torch.uint8, device=dev),
+                torch.empty((K, N), dtype=torch.uint8, device=dev))
+
+    def _as_actions(self, actions, K):
+        want = torch.int32 if self.kind == "discrete" else torch.float32
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.device)
+        if self.kind == "continuous" and actions.dtype != torch.float32:
+            # the reference rejects non-float32 actions (Box.contains -> "stay", :1640,:1671);
+            # a batched API cannot flag dtype per env, so raise instead of silently staying
+            raise TypeError(f"continuous actions must be float32, got {actions.dtype}")
+        a = actions.to(device=self.device, dtype=want).contiguous()
+        lead = (self.num_envs,) if K is None else (K, self.num_envs)
+        shape = lead if self.kind == "discrete" else lead + (self.mdps[0].D,)
+        if tuple(a.shape) != shape:
+            raise ValueError(f"actions must have shape {shape}, got {tuple(a.shape)}")
+        return a
+
+    # ------------------------------------------------------------------ state access
+    def get_augmented_state(self):
+        """Batched get_augmented_state() (rl_toy_env.py:2127) plus what the reference leaves out:
+        reward ring, step counters, reached flags.  Host numpy arrays (synchronises)."""
+        N = self.num_envs
+        if self.kind == "discrete":
+            L, d = self._cfg.L, self._cfg.delay
+            hist = np.zeros((N, L + 1), np.int32)
+            steps = np.zeros(N, np.int32)
+            ring = np.zeros((N, d), np.float64)
+            rc = self._lib.mdpp_get_state_discrete(self._h, capi.nptr(hist), capi.nptr(steps), capi.nptr(ring))
+            capi.check(self._lib, self._h, rc, "mdpp_get_state_discrete")
+            return {"curr_state": hist[:, -1].astype(np.int64), "curr_obs": hist[:, -1].astype(np.int64),
+                    "augmented_state": hist, "total_transitions_episode": steps, "reward_buffer": ring}
+        D, n, d = self._cfg.D, self._cfg.order, self._cfg.delay
+        sd = np.zeros((N, n + 1, D), np.float32)
+        cur = np.zeros((N, D), np.float32)
+        steps = np.zeros(N, np.int32)
+        ring = np.zeros((N, d), np.float64)
+        is32 = np.zeros((N, d), np.uint8)
+        reached = np.zeros(N, np.uint8)
+        rc = self._lib.mdpp_get_state_continuous(self._h, capi.nptr(sd), capi.nptr(cur), capi.nptr(steps),
+                                                 capi.nptr(ring), capi.nptr(is32), capi.nptr(reached))
+        capi.check(self._lib, self._h, rc, "mdpp_get_state_continuous")
+        return {"curr_state": cur, "curr_obs": cur, "augmented_state": cur, "state_derivatives": sd,
+                "total_transitions_episode": steps, "reward_buffer": ring, "reward_buffer_is32": is32,
+                "reached_terminal": reached.astype(bool)}
+
+    def set_augmented_state(self, state):
+        """Inverse of get_augmented_state() (rl_toy_env.py:2168)."""
+        if self.kind == "discrete":
+            hist = np.ascontiguousarray(state["augmented_state"], dtype=np.int32)
+            steps = np.ascontiguousarray(state["total_transitions_episode"], dtype=np.int32)
+            ring = state.get("reward_buffer")
+            ring = None if ring is None or not self._cfg.unit_rewards else np.ascontiguousarray(ring, np.float64)
+            rc = self._lib.mdpp_set_state_discrete(self._h, capi.nptr(hist), capi.nptr(steps), capi.nptr(ring))
+            capi.check(self._lib, self._h, rc, "mdpp_set_state_discrete")
+            return
+        sd = np.ascontiguousarray(state["state_derivatives"], dtype=np.float32)
+        cur = np.ascontiguousarray(state["curr_state"], dtype=np.float32)
+        steps = np.ascontiguousarray(state["total_transitions_episode"], dtype=np.int32)
+        ring = state.get("reward_buffer")
+        ring = None if ring is None else np.ascontiguousarray(ring, np.float64)
+        is32 = state.get("reward_buffer_is32")
+        is32 = None if is32 is None else np.ascontiguousarray(is32, np.uint8)
+        reached = state.get("reached_terminal")
+        reached = None if reached is None else np.ascontiguousarray(reached, np.uint8)
+        rc = self._lib.mdpp_set_state_continuous(self._h, capi.nptr(sd), capi.nptr(cur), capi.nptr(steps),
+                                                 capi.nptr(ring), capi.nptr(is32), capi.nptr(reached))
+        capi.check(self._lib, self._h, rc, "mdpp_set_state_continuous")
+
+    def get_rng_streams(self, stream=capi.STREAM_ENV):
+        words = np.zeros((self.num_envs, 6), np.uint64)
+        rc = self._lib.mdpp_get_streams(self._h, stream, capi.nptr(words))
+        capi.check(self._lib, self._h, rc, "mdpp_get_streams")
+        return words
+
+    def status(self):
+        """Per-env sticky fault bits (bad action, ...), cleared by the call."""
+        flags = np.zeros(self.num_envs, np.uint32)
+        rc = self._lib.mdpp_status(self._h, capi.nptr(flags))
+        capi.check(self._lib, self._h, rc, "mdpp_status")
+        return flags
+
+    # kernel timing on the caller's stream (HIP events inside the library)
+    def timer_begin(self):
+        capi.check(self._lib, self._h, self._lib.mdpp_timer_begin(self._h, self._stream()), "mdpp_timer_begin")
+
+    def timer_end(self):
+        ms = C.c_float()
+        capi.check(self._lib, self._h, self._lib.mdpp_timer_end(self._h, self._stream(), C.byref(ms)), "mdpp_timer_end")
+        return ms.value
+
+    def close(self):
+        if self._h is not None:
+            torch.cuda.synchronize(self.device)
+            self._lib.mdpp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_vec(env_id="RLToyVec-v0", num_envs=1, **kwargs):
+    """gym.make-style entry: 'RLToyVec-v0' and 'RLToyVecFiniteHorizon-v0' (max_episode_steps=100),
+    the batched counterparts of RLToy-v0 / RLToyFiniteHorizon-v0 (mdp_playground/__init__.py:3-12)."""
+    if env_id == "RLToyVec-v0":
+        return RLToyVectorEnv(num_envs=num_envs, **kwargs)
+    if env_id == "RLToyVecFiniteHorizon-v0":
+        kwargs.setdefault("max_episode_steps", 100)
+        return RLToyVectorEnv(num_envs=num_envs, **kwargs)
+    raise ValueError(f"unknown env id {env_id}")

@@ -1,0 +1,70 @@
+"""Host-side MDP generator (mdp_playground_amd/mdp.py) vs what the reference's __init__
+produced (tables and post-construction RNG states recorded in tests/golden/)."""
+import warnings
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from mdp_playground_amd import mdp
+
+
+@pytest.mark.parametrize("name", gu.DISCRETE + gu.IMAGE)
+def test_discrete_tables_match_reference(name):
+    g = gu.load(name)
+    E = g["action"].shape[0]
+    for e in range(E):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = mdp.build_mdp(gu.case_config(name, e))
+        assert np.array_equal(m.P, g["P"][e])
+        assert sorted(m.terminal_states.tolist()) == sorted(g[f"terminal_states_{e}"].tolist())
+        assert np.array_equal(m.init_dist, g["init_dist"][e])
+        keys = {tuple(int(x) for x in k): float(v)
+                for k, v in zip(g[f"rew_keys_{e}"], g[f"rew_vals_{e}"])}
+        mine = {k: v for k, v in m.rewardable_sequences.items() if len(k) == m.sequence_length}
+        assert mine == keys
+        assert np.array_equal(m.space_rng_words, g["rng_space"][e])
+        names = ["env", "relevant_state_space", "relevant_action_space", "irrelevant_state_space",
+                 "irrelevant_action_space", "state_space", "action_space", "image_representations"]
+        for k, v in zip(names, g["seed_dict"][e]):
+            if v >= 0:
+                assert m.seed_dict[k] == int(v)
+
+
+@pytest.mark.parametrize("name", gu.CONTINUOUS)
+def test_continuous_params(name):
+    g = gu.load(name)
+    m = mdp.build_mdp(gu.case_config(name, 0))
+    p = gu.continuous_params(gu.CASES[name]["config"])
+    assert m.D == p["D"] and m.order == p["order"] and m.relevant_indices == p["relevant_indices"]
+    assert m.seed_dict["state_space"] == int(g["seed_dict"][0][5])
+    if p["box_lo"] is not None:
+        assert np.array_equal(m.box_lo, p["box_lo"]) and np.array_equal(m.box_hi, p["box_hi"])
+
+
+def test_kat1_seed0_cfg2():
+    """SURVEY.md Appendix A KAT-1 (BASELINE cfg 2, int seed 0)."""
+    m = mdp.build_mdp(dict(seed=0, state_space_type="discrete", action_space_type="discrete",
+                           state_space_size=8, action_space_size=8, delay=4, sequence_length=3))
+    assert m.seed_dict["relevant_state_space"] == 5874934615388537134
+    assert m.seed_dict["image_representations"] == 5595227450766711102
+    assert m.P[0].tolist() == [0, 2, 4, 7, 1, 6, 5, 3]
+    assert m.P[5].tolist() == [6, 0, 3, 7, 2, 5, 1, 4]
+    assert m.P[6].tolist() == [6] * 8 and m.P[7].tolist() == [7] * 8
+    assert sorted(m.terminal_states.tolist()) == [6, 7]
+    assert m.reward_every_n_steps == 3
+    assert len(m.rewardable_sequences) == 30
+    assert (0, 1, 2) in m.rewardable_sequences and (5, 4, 2) in m.rewardable_sequences
+
+
+def test_error_behaviour_matches_reference():
+    with pytest.raises(ValueError):
+        mdp.build_mdp({"state_space_type": "banana"})
+    with pytest.raises(TypeError):
+        mdp.build_mdp({"state_space_type": "discrete", "action_space_size": 8, "seed": "x"})
+    with pytest.raises(AssertionError):
+        mdp.build_mdp({"state_space_type": "discrete", "action_space_size": 8,
+                       "sequence_length": 0, "seed": 0})
+    with pytest.raises(AssertionError):
+        mdp.build_mdp({"state_space_type": "discrete", "action_space_size": [8, 8], "seed": 0})
