@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched RLToyEnv.step() hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 4096 --warmup 512
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): discrete 8 states x 8 actions, reward_delay 4,
+sequence_length 3, 65 536 env instances per GPU sharing one MDP, uniform random actions
+(synthetic, pre-generated on the device), same-step autoreset, numpy-exact PCG64 streams.
+A "step" is one env step of every instance of every rank.  Steps run as fused rollouts of
+--fuse steps per launch (mdpp_step_n); with N > 1 each launch is followed by ONE RCCL
+all-gather that assembles the global observation tensor on every rank (env ids are sharded
+contiguously, weak scaling).  The single-launch-per-step path (mdpp_step) is reported beside it.
+
+Rank 0 prints ONE JSON line: the driver contract plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42,
+                 config=dict(state_space_type="discrete", action_space_type="discrete",
+                             state_space_size=8, action_space_size=8, delay=4,
+                             sequence_length=3, seed=0)),
+    # cfg2 with both noises on (every step draws from two PCG64 streams)
+    "cfg2_noise": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42,
+                       config=dict(state_space_type="discrete", action_space_type="discrete",
+                                   state_space_size=8, action_space_size=8, delay=4,
+                                   sequence_length=3, transition_noise=0.1, reward_noise=0.1,
+                                   seed=0)),
+    # BASELINE.json configs[2]
+    "cfg3": dict(kind="continuous", envs=65536, alg_bytes_fused=102, alg_bytes_step=206,
+                 config=dict(state_space_type="continuous", state_space_dim=12,
+                             relevant_indices=[0, 1, 2, 3], irrelevant_features=True,
+                             target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10,
+                             action_space_max=1, transition_dynamics_order=1, inertia=1,
+                             time_unit=1, make_denser=True, reward_function="move_to_a_point",
+                             seed=0)),
+    # BASELINE.json configs[4] (per-GPU shard of the 524 288-env job)
+    "cfg5": dict(kind="continuous", envs=65536, alg_bytes_fused=102, alg_bytes_step=350,
+                 config=dict(state_space_type="continuous", state_space_dim=12,
+                             relevant_indices=[0, 1, 2, 3], irrelevant_features=True,
+                             target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10,
+                             action_space_max=1, transition_dynamics_order=2, inertia=1,
+                             time_unit=0.1, transition_noise=0.05, reward_noise=0.05,
+                             make_denser=True, reward_function="move_to_a_point", seed=0)),
+}
+
+
+def make_actions(wl, K, N, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if wl["kind"] == "discrete":
+        A = wl["config"]["action_space_size"]
+        return torch.randint(0, A, (K, N), generator=g, device=device, dtype=torch.int32)
+    D = wl["config"]["state_space_dim"]
+    amax = wl["config"]["action_space_max"]
+    return (torch.rand((K, N, D), generator=g, device=device, dtype=torch.float32) * 2 - 1) * amax
+
+
+def cpu_baseline(wl, seconds=12.0):
+    """The oracle (a scalar C port of the reference step(), oracle/mdpp_oracle.c) timed on ONE
+    host core over a bounded sample of the same workload: 64 env instances stepped with random
+    actions and reset-on-done until ~`seconds` of CPU time have been spent."""
+    from mdp_playground_amd import mdp as mdp_mod
+    from oracle import oracle as ora
+    m = mdp_mod.build_mdp(wl["config"])
+    n_envs, chunk = 64, 20000
+    rng = np.random.default_rng(12345)
+    envs = []
+    for i in range(n_envs):
+        if m.kind == "discrete":
+            o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps,
+                                   m.P, m.reward_table(), m.terminal_states, m.init_dist,
+                                   m.transition_noise, m.reward_noise, m.reward_scale,
+                                   m.reward_shift, m.term_state_reward)
+            sp = mdp_mod.new_generator(m.seed_dict["relevant_state_space"] + i)
+        else:
+            o = ora.ContinuousOracle(m.D, m.relevant_indices, m.order, m.inertia, m.time_unit,
+                                     m.state_space_max, m.action_space_max, m.target_point,
+                                     m.target_radius, m.make_denser, m.action_loss_weight,
+                                     m.transition_noise, m.reward_noise, m.delay,
+                                     m.reward_every_n_steps, m.reward_scale, m.reward_shift,
+                                     m.term_state_reward, m.box_lo, m.box_hi)
+            sp = mdp_mod.new_generator(m.seed_dict["state_space"] + i)
+        o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator((m.seed_dict["env"] or 0) + i)),
+                  mdp_mod.pcg64_words(sp))
+        o.reset()
+        envs.append(o)
+    if m.kind == "discrete":
+        acts = rng.integers(0, m.A, size=chunk).astype(np.int32)
+    else:
+        acts = rng.uniform(-m.action_space_max, m.action_space_max, size=(chunk, m.D)).astype(np.float32)
+    steps, spent = 0, 0.0
+    while spent < seconds:
+        for o in envs:
+            t0 = time.perf_counter()
+            o.rollout(acts, None)
+            spent += time.perf_counter() - t0
+            steps += chunk
+            if spent >= seconds:
+                break
+    return {"value": steps / spent, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} env-steps of the same workload ({n_envs} instances, reset on done) "
+                      f"through oracle/mdpp_oracle.c on 1 host core in {spent:.1f} s; "
+                      f"host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--fuse", type=int, default=128, help="env steps per fused launch (mdpp_step_n)")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=None, help="env instances per GPU")
+    ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-step", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from mdp_playground_amd import RLToyVectorEnv
+    from mdp_playground_amd.dist import ObsGatherer
+
+    wl = WORKLOADS[args.workload]
+    N = args.envs or wl["envs"]
+    F = max(1, min(args.fuse, args.steps))
+    env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
+                         autoreset="same_step", **wl["config"])
+    acts = make_actions(wl, F, N, device, 12345 + rank)
+    out = env.alloc_rollout(F)
+    gather = ObsGatherer(out[0], world, dist) if world > 1 else None
+
+    def run(steps):
+        left, launches = steps, 0
+        while left > 0:
+            k = min(F, left)
+            if k == F:
+                env.rollout(acts, out)
+            else:
+                env.rollout(acts[:k], tuple(t[:k] for t in out))
+            if gather is not None:
+                gather()
+            left -= k
+            launches += 1
+        return launches
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(max(args.warmup, 1))
+    barrier()
+    if world == 1:
+        env.timer_begin()
+    t0 = time.perf_counter()
+    launches = run(args.steps)
+    if world == 1:
+        kernel_ms = env.timer_end()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # roofline leg without the collective: HIP events around plain launches on this rank
+        env.timer_begin()
+        launches_r = 0
+        for _ in range(8):
+            env.rollout(acts, out)
+            launches_r += 1
+        kernel_ms = env.timer_end() * (args.steps / (launches_r * F))
+    total_steps = world * N * args.steps
+    value = total_steps / elapsed
+
+    # ---- roofline of the dominant kernel (fused rollout), per launch
+    per_launch_s = (kernel_ms / 1e3) / (args.steps / F)
+    alg_bytes = wl["alg_bytes_fused"] * N * F
+    achieved = alg_bytes / per_launch_s / 1e9
+    kname = "k_discrete_step" if wl["kind"] == "discrete" else "k_continuous_step"
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                "alg_bytes_per_env_step": wl["alg_bytes_fused"],
+                "launch_us": per_launch_s * 1e6, "env_steps_per_launch": N * F}
+
+    single = None
+    if not args.no_single_step:
+        a1 = acts[0].contiguous()
+        for _ in range(50):
+            env.step(a1)
+        torch.cuda.synchronize(device)
+        n1 = 500
+        env.timer_begin()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            env.step(a1)
+        ms1 = env.timer_end()
+        torch.cuda.synchronize(device)
+        wall1 = time.perf_counter() - t1
+        b1 = wl["alg_bytes_step"] * N
+        single = {"env_steps_per_s": N * n1 / wall1, "launch_us_events": ms1 * 1e3 / n1,
+                  "alg_bytes_per_env_step": wl["alg_bytes_step"],
+                  "hbm_frac_events": b1 / (ms1 / 1e3 / n1) / 1e9 / HBM_PEAK_GBS}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl)
+    env.close()
+
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/f64" if wl["kind"] == "discrete" else "f32/f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: BASELINE.json configs "
+                                   f"({json.dumps(wl['config'], sort_keys=True)}), "
+                                   f"{N} env instances per GPU, random actions, same-step autoreset, "
+                                   f"fused rollout of {F} steps per launch, rng={args.rng}",
+                       "envs_per_gpu": N, "fuse": F,
+                       "collective": "all_gather(obs) per launch" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu, "single_step": single,
+            "launches": launches, "elapsed_s": elapsed,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
