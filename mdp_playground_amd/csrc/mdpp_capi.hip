@@ -26,6 +26,18 @@ static int fail(mdpp_env *h, int code, const std::string &msg) {
 
 static uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// Inverse of PCG64's 128-bit LCG multiplier modulo 2^128 (Newton iteration; the multiplier is odd).
+static unsigned __int128 pcg_mult_inverse() {
+    static unsigned __int128 inv = 0;
+    if (inv == 0) {
+        const unsigned __int128 m = (((unsigned __int128)0x2360ED051FC65DA4ULL) << 64) | 0x4385DF649FCCF645ULL;
+        unsigned __int128 x = m; // correct to 3 bits
+        for (int it = 0; it < 7; it++) x *= 2 - m * x;
+        inv = x;
+    }
+    return inv;
+}
+
 extern "C" int mdpp_abi_version(void) { return MDPP_ABI_VERSION; }
 
 extern "C" const char *mdpp_last_error(const mdpp_env *h) {
@@ -239,6 +251,29 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         HIPCHK(h, hipMemcpy(h->d_rtable, rtable, T * (size_t)h->nkeys * sizeof(double), hipMemcpyHostToDevice));
     if (h->cfg.has_transition_noise)
         HIPCHK(h, hipMemcpy(h->d_noise_cdf, noise_cdf, S * S * sizeof(double), hipMemcpyHostToDevice));
+    // ---- derived constants of the fused fast path (see DiscreteArgs) ----
+    {
+        DiscreteArgs &a = h->dargs;
+        const mdpp_config &c = h->cfg;
+        a.fast_ok = (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise &&
+                     c.L <= 3 && c.S <= 16 && c.delay <= 32 && c.rng_mode == MDPP_RNG_NUMPY_PCG64 &&
+                     a.rew_in_lds && !c.image) ? 1u : 0u;
+        a.s_shift = 0xFFFFFFFFu;
+        for (uint32_t b = 1; b < 8; b++) if ((1u << b) == (uint32_t)c.S) a.s_shift = b;
+        a.key_mask = h->nkeys - 1u;
+        a.spow = 1; for (int j = 0; j < c.L - 1; j++) a.spow *= (uint32_t)c.S;
+        a.term_mask = 0;
+        if (c.S <= 64) for (size_t s = 0; s < S; s++) if (is_term[s]) a.term_mask |= 1ULL << s;
+        for (int j = 0; j < 16; j++) a.init_thr[j] = ~0ULL;
+        if (c.S <= 16)
+            for (size_t j = 0; j < S; j++) a.init_thr[j] = (uint64_t)ceil(ldexp(init_cdf[j], 53));
+        for (int q = 0; q < 4; q++) {
+            double r = (q & 2) ? 1.0 : 0.0;
+            r *= a.scale; r += a.shift;
+            if (q & 1) r += a.term_add;
+            a.rsel[q] = (float)r;
+        }
+    }
     h->tables_ready = true;
     return MDPP_OK;
 }
@@ -260,6 +295,11 @@ extern "C" int mdpp_seed_streams(mdpp_env *h, int stream, const uint64_t *words)
     HIPCHK(h, hipMemcpy(h->d_rng_inc[stream], inc.data(), N * 16, hipMemcpyHostToDevice));
     if (stream == MDPP_STREAM_IMAGE && h->d_rng_half)
         HIPCHK(h, hipMemcpy(h->d_rng_half, half.data(), N * 8, hipMemcpyHostToDevice));
+    if (stream == MDPP_STREAM_ENV && h->cfg.kind == MDPP_KIND_DISCRETE) {
+        // start states drawn ahead from the old stream are void: empty every env's queue
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, hipMemset2D((char *)h->d_state + 4, 16, 0, 4, N));
+    }
     h->streams_ready[stream] = true;
     return MDPP_OK;
 }
@@ -277,8 +317,18 @@ extern "C" int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words) {
     HIPCHK(h, hipMemcpy(inc.data(), h->d_rng_inc[stream], N * 16, hipMemcpyDeviceToHost));
     if (stream == MDPP_STREAM_IMAGE && h->d_rng_half)
         HIPCHK(h, hipMemcpy(half.data(), h->d_rng_half, N * 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> rec;
+    const bool queued = stream == MDPP_STREAM_ENV && h->cfg.kind == MDPP_KIND_DISCRETE && h->dargs.fast_ok;
+    if (queued) {
+        rec.resize(4 * N);
+        HIPCHK(h, hipMemcpy(rec.data(), h->d_state, N * 16, hipMemcpyDeviceToHost));
+    }
     for (size_t i = 0; i < N; i++) {
-        words[6 * i] = st[2 * i]; words[6 * i + 1] = st[2 * i + 1];
+        unsigned __int128 s = ((unsigned __int128)st[2 * i + 1] << 64) | st[2 * i];
+        const unsigned __int128 c = ((unsigned __int128)inc[2 * i + 1] << 64) | inc[2 * i];
+        if (queued) // un-draw the start states still waiting in the queue: s_prev = (s - inc) * M^-1
+            for (uint32_t q = (rec[4 * i + 1] >> 24) & 7u; q > 0; q--) s = (s - c) * pcg_mult_inverse();
+        words[6 * i] = (uint64_t)s; words[6 * i + 1] = (uint64_t)(s >> 64);
         words[6 * i + 2] = inc[2 * i]; words[6 * i + 3] = inc[2 * i + 1];
         words[6 * i + 4] = half[2 * i]; words[6 * i + 5] = half[2 * i + 1];
     }
@@ -398,7 +448,8 @@ extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const i
             if (v >= h->cfg.S) return fail(h, MDPP_EINVAL, "set_state_discrete: state id out of range");
             hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v);
         }
-        st[4 * i] = (uint32_t)hb; st[4 * i + 1] = (uint32_t)(hb >> 32);
+        st[4 * i] = (uint32_t)hb;
+        if (!h->dargs.fast_ok) st[4 * i + 1] = (uint32_t)(hb >> 32); // fast path: word 1 is the draw queue
         st[4 * i + 2] = (uint32_t)steps[i];
         if (ring) {
             uint32_t bits = 0;

@@ -32,62 +32,21 @@ __device__ __forceinline__ uint32_t d_reset_draw(const DiscreteArgs &a, const DT
     return (uint32_t)searchsorted_right(t.init_cdf, a.S, u);
 }
 
-// One env step on registers.  Returns the reward (float64 like the reference's Python float).
-template <class GE, class GS>
-__device__ __forceinline__ double d_step_lane(const DiscreteArgs &a, const DTables &t,
-                                              uint64_t &hist, uint32_t &steps, uint32_t &ringbits,
-                                              uint32_t *ring_slot, int action, GE &env_rng,
-                                              GS &space_rng, uint32_t &nxt_out, bool &done_out,
-                                              uint32_t &status) {
-    const int S = a.S, A = a.A, L = a.L;
-    if (action < 0 && action >= -A) action += A;       // numpy negative indexing
-    if (action < 0 || action >= A) { status |= MDPP_STATUS_BAD_ACTION; action = 0; }
-    uint32_t cur = (uint32_t)(hist & 0xFF);
-    uint32_t nxt = t.P[cur * A + action];                                   // D1
-    if (a.has_p_noise) {                                                    // D2
-        double u = np_random(space_rng);
-        nxt = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, u);
-    }
-    hist = (hist << 8) | nxt;                                               // D3
-    steps += 1;
-    uint32_t key = kNoKey;                                                  // D4
-    if (((hist >> (8 * L)) & 0xFF) != 0xFF) {
-        key = 0;
-        for (int j = L - 1; j >= 0; j--) key = key * S + (uint32_t)((hist >> (8 * j)) & 0xFF);
-    }
-    double r;
-    if (a.unit_rewards) {
-        uint32_t bit = 0;
-        if (key != kNoKey) bit = (t.rbits[key >> 3] >> (key & 7)) & 1u;
-        if (a.delay > 0) {                                                  // D5 (shift register)
-            uint32_t out = (ringbits >> (a.delay - 1)) & 1u;
-            ringbits = (ringbits << 1) | bit;
-            bit = out;
-        }
-        r = bit ? 1.0 : 0.0;
-    } else {
-        if (a.delay > 0) {                                                  // D5 (key ring)
-            uint32_t out = *ring_slot;
-            *ring_slot = key;
-            key = out;
-        }
-        r = (key != kNoKey) ? t.rtable[key] : 0.0;
-    }
-    if (steps % (uint32_t)a.every_n != 0) r = 0.0;                          // D6
-    if (a.has_r_noise) r += 0.0 + a.r_noise * np_standard_normal(env_rng);
-    r *= a.scale;
-    r += a.shift;
-    bool done = t.is_term[nxt] != 0;                                        // D7
-    if (done) r += a.term_add;
-    nxt_out = nxt; done_out = done;
-    return r;
-}
-
 __device__ __forceinline__ uint64_t d_fresh_hist(uint32_t s0) {
     return 0xFFFFFFFFFFFFFF00ULL | (uint64_t)s0;
 }
 
-template <bool PHILOX>
+constexpr int kPrefetch = 8; // actions fetched this many steps ahead of their use
+
+// NOISE: any per-step random draw (P-noise and/or reward noise).  UNIT: every rewardable sequence
+// pays exactly 1.0 (bitmask table, shift-register delay line).  The common benchmark shape
+// (no noise, unit rewards) compiles to a loop with no float64 arithmetic at all: the four
+// possible rewards {paid, not paid} x {terminal, not} are formed once per launch with the
+// reference's own float64 operation order (:1987-1990, :2107) and selected per step.
+// LDSTAB: the (single, shared) MDP's tables are read from LDS; otherwise from HBM/L2 with one
+// table set per env (or table 0 for a shared MDP too large for LDS).  Kept a template parameter
+// so that table pointers have one provenance and lower to ds_read / global_load, not flat_load.
+template <bool PHILOX, bool NOISE, bool UNIT, bool LDSTAB>
 __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                                                           const int32_t *__restrict__ actions,
                                                           void *__restrict__ obs,
@@ -99,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     DTables t;
     const int tid = threadIdx.x;
     const long i = (long)blockIdx.x * kBlock + tid;
-    if (a.shared_tables) {
+    if (LDSTAB) {
         // Stage the shared MDP into LDS: a few hundred bytes for 8x8 (P 64 B + flags 8 B +
         // reward bitmask 64 B + cdf 64 B).
         for (int k = tid; k < a.S * a.A; k += kBlock) lds[a.lds_P + k] = a.P[k];
@@ -107,94 +66,169 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             lds[a.lds_term + k] = a.is_term[k];
             ((double *)(lds + a.lds_init))[k] = a.init_cdf[k];
         }
-        if (a.rew_in_lds) {
-            if (a.unit_rewards)
-                for (uint32_t k = tid; k < a.rbits_stride; k += kBlock) lds[a.lds_rew + k] = a.rbits[k];
-            else
-                for (uint32_t k = tid; k < a.nkeys; k += kBlock)
-                    ((double *)(lds + a.lds_rew))[k] = a.rtable[k];
-        }
-        if (a.has_p_noise && a.noise_in_lds)
+        if (UNIT)
+            for (uint32_t k = tid; k < a.rbits_stride; k += kBlock) lds[a.lds_rew + k] = a.rbits[k];
+        else
+            for (uint32_t k = tid; k < a.nkeys; k += kBlock)
+                ((double *)(lds + a.lds_rew))[k] = a.rtable[k];
+        if (NOISE && a.has_p_noise)
             for (int k = tid; k < a.S * a.S; k += kBlock)
                 ((double *)(lds + a.lds_noise))[k] = a.noise_cdf[k];
         __syncthreads();
         t.P = lds + a.lds_P;
         t.is_term = lds + a.lds_term;
         t.init_cdf = (const double *)(lds + a.lds_init);
-        t.rbits = a.rew_in_lds ? lds + a.lds_rew : a.rbits;
-        t.rtable = a.rew_in_lds ? (const double *)(lds + a.lds_rew) : a.rtable;
-        t.noise_cdf = (a.has_p_noise && a.noise_in_lds) ? (const double *)(lds + a.lds_noise) : a.noise_cdf;
+        t.rbits = lds + a.lds_rew;
+        t.rtable = (const double *)(lds + a.lds_rew);
+        t.noise_cdf = (const double *)(lds + a.lds_noise);
     }
     if (i >= a.N) return;
-    if (!a.shared_tables) {
-        t.P = a.P + (size_t)i * a.S * a.A;
-        t.is_term = a.is_term + (size_t)i * a.S;
-        t.init_cdf = a.init_cdf + (size_t)i * a.S;
-        t.rbits = a.rbits + (size_t)i * a.rbits_stride;
-        t.rtable = a.rtable + (size_t)i * a.nkeys;
+    if (!LDSTAB) {
+        const size_t ti = a.shared_tables ? 0 : (size_t)i;
+        t.P = a.P + ti * a.S * a.A;
+        t.is_term = a.is_term + ti * a.S;
+        t.init_cdf = a.init_cdf + ti * a.S;
+        t.rbits = a.rbits + ti * a.rbits_stride;
+        t.rtable = a.rtable + ti * a.nkeys;
         t.noise_cdf = a.noise_cdf;
     }
+    const int S = a.S, A = a.A, L = a.L;
+    const long N = a.N;
 
     uint4 st = a.state[i];
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;
     uint32_t steps = st.z, ringbits = st.w, status = 0;
+    uint32_t phase = steps % (uint32_t)a.every_n; // steps % every_n, kept incrementally below
 
+    // Streams live in registers for the whole launch.  The env stream is needed by reward noise
+    // and by every in-kernel reset(); with 2 of 8 states terminal some lane of a wave resets on
+    // almost every step, so it is loaded up front rather than inside the divergent branch.
     Pcg64 env_pcg, sp_pcg;
     Philox env_phx, sp_phx;
-    bool env_loaded = false;
+    const bool use_env = (NOISE && a.has_r_noise) || a.autoreset;
+    const bool use_sp = NOISE && a.has_p_noise;
     if (!PHILOX) {
-        if (a.has_r_noise) { env_pcg.load(a.env_s, a.env_inc, i); env_loaded = true; }
-        if (a.has_p_noise) sp_pcg.load(a.sp_s, a.sp_inc, i);
+        if (use_env) env_pcg.load(a.env_s, a.env_inc, i);
+        if (use_sp) sp_pcg.load(a.sp_s, a.sp_inc, i);
     }
 
-    for (int k = 0; k < K; k++) {
-        const uint32_t tick = a.tick + (uint32_t)k;
-        const long o = (long)k * a.N + i;
-        int action = actions[o];
-        uint32_t *slot = nullptr;
-        if (!a.unit_rewards && a.delay > 0)
-            slot = a.ring_keys + (size_t)(tick % (uint32_t)a.delay) * a.N + i;
-        uint32_t nxt; bool done; double r;
-        if (PHILOX) {
-            env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
-            sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
-            r = d_step_lane(a, t, hist, steps, ringbits, slot, action, env_phx, sp_phx, nxt, done, status);
-        } else {
-            r = d_step_lane(a, t, hist, steps, ringbits, slot, action, env_pcg, sp_pcg, nxt, done, status);
+    // rewards of the noise-free unit path: index = paid*2 + terminal
+    float rsel[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double r = (q & 2) ? 1.0 : 0.0;
+        r *= a.scale;
+        r += a.shift;
+        if (q & 1) r += a.term_add;
+        rsel[q] = (float)r;
+    }
+
+    // software pipeline on the action stream: kPrefetch loads in flight per lane
+    int nextact[kPrefetch];
+#pragma unroll
+    for (int u = 0; u < kPrefetch; u++) nextact[u] = (u < K) ? actions[(long)u * N + i] : 0;
+
+    for (int k0 = 0; k0 < K; k0 += kPrefetch) {
+        int act[kPrefetch];
+#pragma unroll
+        for (int u = 0; u < kPrefetch; u++) act[u] = nextact[u];
+#pragma unroll
+        for (int u = 0; u < kPrefetch; u++) {
+            const int kn = k0 + kPrefetch + u;
+            nextact[u] = (kn < K) ? actions[(long)kn * N + i] : 0;
         }
-        bool truncated = (a.max_steps > 0) && (steps >= (uint32_t)a.max_steps);
-        uint32_t out_state = nxt;
-        if (a.autoreset && (done || truncated)) {
-            // gymnasium "same-step" autoreset: report the terminal transition's reward/flags,
-            // hand back the first observation of the next episode (reset(), :2250-2278).
-            if (final_obs) {
-                if (a.obs_i32) ((int32_t *)final_obs)[o] = (int32_t)nxt;
-                else ((int64_t *)final_obs)[o] = (int64_t)nxt;
-            }
-            uint32_t s0;
+#pragma unroll
+        for (int u = 0; u < kPrefetch; u++) {
+            const int k = k0 + u;
+            if (k >= K) break;
+            const uint32_t tick = a.tick + (uint32_t)k;
+            const long o = (long)k * N + i;
+            int action = act[u];
             if (PHILOX) {
-                s0 = d_reset_draw(a, t, env_phx);
-            } else {
-                if (!env_loaded) { env_pcg.load(a.env_s, a.env_inc, i); env_loaded = true; }
-                s0 = d_reset_draw(a, t, env_pcg);
+                env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
+                sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
             }
-            hist = d_fresh_hist(s0);
-            steps = 0; ringbits = 0;
-            if (!a.unit_rewards)
-                for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * a.N + i] = kNoKey;
-            out_state = s0;
+            if (action < 0 && action >= -A) action += A;       // numpy negative indexing
+            if (action < 0 || action >= A) { status |= MDPP_STATUS_BAD_ACTION; action = 0; }
+            const uint32_t cur = (uint32_t)hist & 0xFFu;
+            uint32_t nxt = t.P[cur * A + action];                                   // D1
+            if (NOISE && a.has_p_noise) {                                           // D2
+                double uu = PHILOX ? np_random(sp_phx) : np_random(sp_pcg);
+                nxt = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, uu);
+            }
+            hist = (hist << 8) | nxt;                                               // D3
+            steps += 1;
+            phase = (phase + 1 == (uint32_t)a.every_n) ? 0u : phase + 1;
+            uint32_t key = kNoKey;                                                  // D4
+            if (((hist >> (8 * L)) & 0xFF) != 0xFF) {
+                key = 0;
+                for (int j = L - 1; j >= 0; j--) key = key * S + (uint32_t)((hist >> (8 * j)) & 0xFF);
+            }
+            const bool done = t.is_term[nxt] != 0;                                  // D7
+            float rout;
+            if (UNIT) {
+                uint32_t bit = 0;
+                if (key != kNoKey) bit = (t.rbits[key >> 3] >> (key & 7)) & 1u;
+                if (a.delay > 0) {                                                  // D5 (shift register)
+                    uint32_t out = (ringbits >> (a.delay - 1)) & 1u;
+                    ringbits = (ringbits << 1) | bit;
+                    bit = out;
+                }
+                if (phase != 0) bit = 0;                                            // D6
+                if (NOISE && a.has_r_noise) {
+                    double r = bit ? 1.0 : 0.0;
+                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal(env_phx) : np_standard_normal(env_pcg));
+                    r *= a.scale;
+                    r += a.shift;
+                    if (done) r += a.term_add;
+                    rout = (float)r;
+                } else {
+                    rout = rsel[(bit << 1) | (done ? 1u : 0u)];
+                }
+            } else {
+                if (a.delay > 0) {                                                  // D5 (key ring)
+                    uint32_t *slot = a.ring_keys + (size_t)(tick % (uint32_t)a.delay) * N + i;
+                    uint32_t out = *slot;
+                    *slot = key;
+                    key = out;
+                }
+                double r = (key != kNoKey) ? t.rtable[key] : 0.0;
+                if (phase != 0) r = 0.0;
+                if (NOISE && a.has_r_noise)
+                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal(env_phx) : np_standard_normal(env_pcg));
+                r *= a.scale;
+                r += a.shift;
+                if (done) r += a.term_add;
+                rout = (float)r;
+            }
+            const bool truncated = (a.max_steps > 0) && (steps >= (uint32_t)a.max_steps);
+            uint32_t out_state = nxt;
+            if (a.autoreset && (done || truncated)) {
+                // gymnasium "same-step" autoreset: report the terminal transition's reward/flags,
+                // hand back the first observation of the next episode (reset(), :2250-2278).
+                if (final_obs) {
+                    if (a.obs_i32) ((int32_t *)final_obs)[o] = (int32_t)nxt;
+                    else ((int64_t *)final_obs)[o] = (int64_t)nxt;
+                }
+                const uint32_t s0 = PHILOX ? d_reset_draw(a, t, env_phx) : d_reset_draw(a, t, env_pcg);
+                hist = d_fresh_hist(s0);
+                steps = 0; phase = 0; ringbits = 0;
+                if (!UNIT)
+                    for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * N + i] = kNoKey;
+                out_state = s0;
+            }
+            if (a.obs_i32) ((int32_t *)obs)[o] = (int32_t)out_state;
+            else ((int64_t *)obs)[o] = (int64_t)out_state;
+            reward[o] = rout;
+            term[o] = done ? 1 : 0;
+            trunc[o] = truncated ? 1 : 0;
         }
-        if (a.obs_i32) ((int32_t *)obs)[o] = (int32_t)out_state;
-        else ((int64_t *)obs)[o] = (int64_t)out_state;
-        reward[o] = (float)r;
-        term[o] = done ? 1 : 0;
-        trunc[o] = truncated ? 1 : 0;
     }
 
     a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps, ringbits);
     if (!PHILOX) {
-        if (env_loaded) env_pcg.store(a.env_s, i);
-        if (a.has_p_noise) sp_pcg.store(a.sp_s, i);
+        if (use_env) env_pcg.store(a.env_s, i);
+        if (use_sp) sp_pcg.store(a.sp_s, i);
     }
     if (status) atomicOr(&a.status[i], status);
 }
@@ -209,19 +243,27 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint3
     DTables t;
     const size_t ti = a.shared_tables ? 0 : (size_t)i;
     t.init_cdf = a.init_cdf + ti * a.S;
-    uint32_t s0;
+    uint32_t s0, queue = 0;
     if (PHILOX) {
         Philox g;
         g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), reset_tick, MDPP_NUM_STREAMS);
         s0 = d_reset_draw(a, t, g);
     } else {
-        Pcg64 g;
-        g.load(a.env_s, a.env_inc, i);
-        s0 = d_reset_draw(a, t, g);
-        g.store(a.env_s, i);
+        // fast-path handles keep start states drawn ahead of need in word 1 of the state record
+        // (mdpp_discrete_fast.hip): consume those first, they are the next draws of the stream
+        if (a.fast_ok) queue = a.state[i].y;
+        if (a.fast_ok && ((queue >> 24) & 7u) != 0) {
+            s0 = queue & 0xFu;
+            queue = ((queue & 0x00FFFFFFu) >> 4) | ((((queue >> 24) & 7u) - 1u) << 24);
+        } else {
+            Pcg64 g;
+            g.load(a.env_s, a.env_inc, i);
+            s0 = d_reset_draw(a, t, g);
+            g.store(a.env_s, i);
+        }
     }
     uint64_t hist = d_fresh_hist(s0);
-    a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), 0u, 0u);
+    a.state[i] = make_uint4((uint32_t)hist, a.fast_ok ? queue : (uint32_t)(hist >> 32), 0u, 0u);
     if (!a.unit_rewards)
         for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * a.N + i] = kNoKey;
     if (obs) {
@@ -230,18 +272,48 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint3
     }
 }
 
+template <bool PHILOX, bool NOISE>
+static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                          float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                          hipStream_t s) {
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    const bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds);
+    const size_t lds = ldstab ? a.lds_bytes : 0;
+#define MDPP_D_LAUNCH(UNIT, LDSTAB)                                                               \
+    hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB>), dim3(grid), dim3(kBlock), \
+                       lds, s, a, K, actions, obs, reward, term, trunc, final_obs)
+    if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true); else MDPP_D_LAUNCH(true, false); }
+    else { if (ldstab) MDPP_D_LAUNCH(false, true); else MDPP_D_LAUNCH(false, false); }
+#undef MDPP_D_LAUNCH
+}
+
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
     DiscreteArgs a = h->dargs;
     a.tick = h->tick;
-    const int grid = (a.N + kBlock - 1) / kBlock;
-    const size_t lds = a.shared_tables ? a.lds_bytes : 0;
-    if (a.philox)
-        hipLaunchKernelGGL(k_discrete_step<true>, dim3(grid), dim3(kBlock), lds, s, a, K, actions,
-                           obs, reward, term, trunc, final_obs);
-    else
-        hipLaunchKernelGGL(k_discrete_step<false>, dim3(grid), dim3(kBlock), lds, s, a, K, actions,
-                           obs, reward, term, trunc, final_obs);
+    const bool noise = a.has_p_noise || a.has_r_noise;
+    if (a.fast_ok) {
+        // common shape: dedicated rollout kernel (mdpp_discrete_fast.hip); its buffer descriptors
+        // address < 4 GiB per output array, so very long rollouts go out as several launches
+        const long long kmax = ((1LL << 32) - 1) / (8LL * a.N);
+        if (kmax < 1) { h->err = "k_discrete_rollout_fast: num_envs too large"; return MDPP_EUNSUPPORTED; }
+        const size_t osz = a.obs_i32 ? 4 : 8;
+        for (int k0 = 0; k0 < K;) {
+            const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
+            const size_t off = (size_t)k0 * a.N;
+            a.tick = h->tick + (uint32_t)k0;
+            launch_discrete_fast(a, kc, actions + off, (char *)obs + off * osz, reward + off,
+                                 term + off, trunc + off,
+                                 final_obs ? (void *)((char *)final_obs + off * osz) : nullptr, s);
+            k0 += kc;
+        }
+    } else if (a.philox) {
+        if (noise) launch_step_t<true, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+        else launch_step_t<true, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+    } else {
+        if (noise) launch_step_t<false, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+        else launch_step_t<false, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_discrete_step launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->tick += (uint32_t)K;

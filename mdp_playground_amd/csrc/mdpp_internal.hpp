@@ -43,6 +43,14 @@ struct DiscreteArgs {
     uint32_t *ring_keys;        // [delay][N] keys awaiting payout (unit_rewards == 0)
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc; // PCG64 streams
     uint32_t *status;
+    // ---- precomputed on the host for the fused fast path (mdpp_discrete_fast.hip) ----
+    uint32_t fast_ok;           // shape qualifies: shared LDS tables, unit rewards, no noise, L <= 3, S <= 16
+    uint32_t s_shift;           // log2(S) when S is a power of two, else 0xFFFFFFFF
+    uint32_t key_mask;          // S^L - 1 (power-of-two S)
+    uint32_t spow;              // S^(L-1)
+    uint64_t term_mask;         // bit s set <=> state s terminal (S <= 64)
+    uint64_t init_thr[16];      // ceil(init_cdf[j] * 2^53): cdf[j] <= u  <=>  init_thr[j] <= (r >> 11)
+    float rsel[4];              // reward for {paid*2 + terminal}, formed in float64 like :1987-1990,:2107
 };
 
 struct ContinuousArgs {
@@ -97,6 +105,8 @@ namespace mdpp {
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
+bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
+                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);

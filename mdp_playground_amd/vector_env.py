@@ -130,6 +130,11 @@ class RLToyVectorEnv:
         self.single_action_space = DiscreteSpace(m.A, seed=m.seed_dict.get("relevant_action_space"))
         self.transition_matrix = m.P
         self.rewardable_sequences = m.rewardable_sequences
+        # mirrors DiscreteArgs.fast_ok (mdpp_capi.hip): which kernel serves this handle
+        self.uses_fast_kernel = bool(
+            not self._per_env and cfg.unit_rewards and not cfg.has_transition_noise
+            and not cfg.has_reward_noise and m.sequence_length <= 3 and m.S <= 16
+            and m.delay <= 32 and self.rng == "numpy")
 
     def _upload_discrete(self):
         ms = self.mdps

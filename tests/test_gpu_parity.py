@@ -167,3 +167,111 @@ def test_continuous_fused_rollout_vs_reference_golden(name):
     assert np.array_equal(term.cpu().numpy().T, g["done"])
     assert np.array_equal(rew.cpu().numpy().T, g["reward"].astype(np.float32))
     env.close()
+
+
+# ----------------------------------------------------------------------------- fast rollout kernel
+FAST_VARIANTS = {
+    "cfg2_k100": (dict(gu.CASES["d_cfg2"]["config"], seed=11), {}, 100),
+    "cfg1_k7": (dict(gu.CASES["d_cfg1"]["config"], seed=5), {}, 7),
+    "s6_l2_nonpow2": (dict(state_space_type="discrete", action_space_type="discrete",
+                           state_space_size=6, action_space_size=6, delay=0, sequence_length=2,
+                           reward_scale=2.5, reward_shift=-0.75, term_state_reward=-1.5, seed=2), {}, 64),
+    "s16_l1_trunc": (dict(state_space_type="discrete", action_space_type="discrete",
+                          state_space_size=16, action_space_size=16, delay=1, sequence_length=1,
+                          terminal_state_density=0.0625, seed=4), dict(max_episode_steps=5), 61),
+    "diam2_l3": (dict(state_space_type="discrete", action_space_type="discrete",
+                      state_space_size=12, action_space_size=6, diameter=2, delay=2,
+                      sequence_length=3, reward_every_n_steps=1, seed=9), {}, 80),
+    "cfg2_int32": (dict(gu.CASES["d_cfg2"]["config"], seed=1, dtype_o=np.int32), {}, 40),
+}
+
+
+def _oracle_autoreset_rollout(o, acts, max_steps):
+    """Reference loop: step(); if done (or TimeLimit-truncated): reset()."""
+    T = len(acts)
+    obs = np.zeros(T, np.int64); rew = np.zeros(T); term = np.zeros(T, bool); trunc = np.zeros(T, bool)
+    n = 0
+    for t in range(T):
+        ob, r, d = o.step(int(acts[t]))
+        n += 1
+        tr = bool(max_steps) and n >= max_steps
+        if d or tr:
+            ob = o.reset()
+            n = 0
+        obs[t], rew[t], term[t], trunc[t] = ob, r, d, tr
+    return obs, rew, term, trunc
+
+
+@pytest.mark.parametrize("variant", sorted(FAST_VARIANTS))
+@pytest.mark.parametrize("fused", [True, False])
+def test_discrete_fast_kernel_vs_oracle(variant, fused):
+    cfg, kw, T = FAST_VARIANTS[variant]
+    N = 1000  # not a multiple of the block size
+    env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    assert env.uses_fast_kernel
+    A = env.mdps[0].A
+    acts = np.random.default_rng(3).integers(0, A, size=(T, N)).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    if fused:
+        obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
+        obs, rew, term, trunc = (x.cpu().numpy() for x in (obs, rew, term, trunc))
+    else:
+        obs = np.zeros((T, N), np.int64); rew = np.zeros((T, N), np.float32)
+        term = np.zeros((T, N), bool); trunc = np.zeros((T, N), bool)
+        for t in range(T):
+            o, r, te, tr, info = env.step(torch.as_tensor(acts[t], device=env.device))
+            obs[t], rew[t], term[t], trunc[t] = (x.cpu().numpy() for x in (o, r, te, tr))
+    end_env = env.get_rng_streams(0)
+    for i in range(0, N, 23):
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert o.reset() == int(init[i])
+        eo, er, et, etr = _oracle_autoreset_rollout(o, acts[:, i], kw.get("max_episode_steps", 0))
+        assert np.array_equal(obs[:, i], eo), (variant, i)
+        assert np.array_equal(term[:, i], et) and np.array_equal(trunc[:, i], etr), (variant, i)
+        assert np.array_equal(rew[:, i], er.astype(np.float32)), (variant, i)
+        # the draw-ahead queue must be invisible: reported stream state == reference's
+        assert np.array_equal(o.get_rng()[0][:4], end_env[i][:4]), (variant, i)
+    env.close()
+
+
+def test_discrete_fast_kernel_masked_reset_and_reseed():
+    """reset(mask) consumes queued draws in stream order; reset(seed=) voids the queue."""
+    cfg = dict(gu.CASES["d_cfg2"]["config"], seed=21)
+    N, T = 512, 40
+    env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 8, size=(T, N)).astype(np.int32)
+    oracles = {}
+    for i in range(0, N, 31):
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        o.reset()
+        oracles[i] = o
+    env.rollout(torch.as_tensor(acts, device=env.device))
+    for i, o in oracles.items():
+        _oracle_autoreset_rollout(o, acts[:, i], 0)
+    mask = rng.random(N) < 0.5
+    ob, _ = env.reset(mask=torch.as_tensor(mask, device=env.device))
+    ob = ob.cpu().numpy()
+    for i, o in oracles.items():
+        if mask[i]:
+            assert o.reset() == ob[i]
+    obs2, *_ = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs2 = obs2.cpu().numpy()
+    for i, o in oracles.items():
+        eo, *_ = _oracle_autoreset_rollout(o, acts[:, i], 0)
+        assert np.array_equal(obs2[:, i], eo), i
+    # re-seed: env i restarts from PCG64(SeedSequence(777 + i))
+    ob, _ = env.reset(seed=777)
+    ob = ob.cpu().numpy()
+    obs3, *_ = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs3 = obs3.cpu().numpy()
+    from mdp_playground_amd import mdp as mdp_mod
+    for i in oracles:
+        o = _oracle_for(env, i)
+        o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator(777 + i)), env.seeded_streams[1][i])
+        assert o.reset() == ob[i]
+        eo, *_ = _oracle_autoreset_rollout(o, acts[:, i], 0)
+        assert np.array_equal(obs3[:, i], eo), i
+    env.close()
