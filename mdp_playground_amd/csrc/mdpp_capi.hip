@@ -1,5 +1,7 @@
 // C ABI of libmdpp_hip.so (see include/mdpp.h): handle lifetime, table/stream upload, dispatch.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -47,7 +49,8 @@ extern "C" const char *mdpp_last_error(const mdpp_env *h) {
 static void free_all(mdpp_env *h) {
     void *ptrs[] = {h->d_P, h->d_rtable, h->d_rbits, h->d_is_term, h->d_init_cdf, h->d_noise_cdf,
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
-                    h->d_img_tpl, h->d_img_clsx, h->d_img_clsy, h->d_img_rot};
+                    h->d_img_tpl, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
+                    h->d_img_state_final};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -89,6 +92,9 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
     h->d_img_tpl = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
+    h->d_img_state_out = h->d_img_state_final = nullptr;
+    h->img_ready = false;
+    h->img_n_radii = h->img_n_cls_x = h->img_n_cls_y = 0;
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) { h->d_rng_s[s] = h->d_rng_inc[s] = nullptr; h->streams_ready[s] = false; }
     h->tables_ready = false;
     h->ev0 = h->ev1 = nullptr;
@@ -105,11 +111,20 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             TRY(alloc_zero(h, &h->d_rng_s[s], N * 16));
             TRY(alloc_zero(h, &h->d_rng_inc[s], N * 16));
         }
-        if (cfg->image) TRY(alloc_zero(h, &h->d_rng_half, N * 8));
+        if (cfg->image) {
+            TRY(alloc_zero(h, &h->d_rng_half, N * 8));
+            TRY(alloc_zero(h, &h->d_img_state_out, N * 4));
+            TRY(alloc_zero(h, &h->d_img_state_final, N * 4));
+        }
     } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
     }
 
+    if (cfg->image && (cfg->kind != MDPP_KIND_DISCRETE || cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 ||
+                       cfg->img_w < 1 || cfg->img_h < 1 || cfg->img_tpl_size < 1)) {
+        g_create_err = "mdpp_create: image observations need a discrete env with numpy PCG64 streams";
+        free_all(h); delete h; return MDPP_EUNSUPPORTED;
+    }
     if (cfg->kind == MDPP_KIND_DISCRETE) {
         if (cfg->S < 2 || cfg->S > 255 || cfg->A < 1 || cfg->L < 1 || cfg->L > 7) {
             g_create_err = "mdpp_create: discrete needs 2 <= S <= 255, A >= 1, 1 <= L <= 7";
@@ -342,6 +357,8 @@ static int check_ready(mdpp_env *h, const char *what) {
             return fail(h, MDPP_ESTATE, std::string(what) + ": RNG streams not seeded");
         if (h->cfg.image && !h->streams_ready[MDPP_STREAM_IMAGE])
             return fail(h, MDPP_ESTATE, std::string(what) + ": image RNG stream not seeded");
+        if (h->cfg.image && !h->img_ready)
+            return fail(h, MDPP_ESTATE, std::string(what) + ": image templates not uploaded");
     }
     return MDPP_OK;
 }
@@ -352,7 +369,12 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
-        if (h->cfg.image) return fail(h, MDPP_EUNSUPPORTED, "mdpp_reset: image observations not built yet");
+        if (h->cfg.image) {
+            rc = launch_discrete_reset(h, mask_dev, h->d_img_state_out, s);
+            if (rc || !obs_dev) return rc;
+            return launch_image_obs(h, (const int32_t *)h->d_img_state_out, nullptr, nullptr, nullptr,
+                                    mask_dev, (uint8_t *)obs_dev, nullptr, s);
+        }
         return launch_discrete_reset(h, mask_dev, obs_dev, s);
     }
     return launch_continuous_reset(h, mask_dev, (float *)obs_dev, s);
@@ -367,7 +389,22 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
-        if (h->cfg.image) return fail(h, MDPP_EUNSUPPORTED, "mdpp_step: image observations not built yet");
+        if (h->cfg.image) {
+            // one state step + one render per env step; images are W*H bytes per env and step
+            const size_t N = (size_t)h->cfg.num_envs, isz = (size_t)h->cfg.img_w * h->cfg.img_h;
+            for (int k = 0; k < K; k++) {
+                rc = launch_discrete_step(h, 1, (const int32_t *)actions + k * N, h->d_img_state_out,
+                                          reward + k * N, term + k * N, trunc + k * N,
+                                          h->d_img_state_final, s);
+                if (rc) return rc;
+                rc = launch_image_obs(h, (const int32_t *)h->d_img_state_out,
+                                      (const int32_t *)h->d_img_state_final, term + k * N, trunc + k * N,
+                                      nullptr, (uint8_t *)obs + k * N * isz,
+                                      final_obs ? (uint8_t *)final_obs + k * N * isz : nullptr, s);
+                if (rc) return rc;
+            }
+            return MDPP_OK;
+        }
         return launch_discrete_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
     }
     return launch_continuous_step(h, K, (const float *)actions, (float *)obs, reward, term, trunc,
@@ -384,9 +421,55 @@ extern "C" int mdpp_step_n(mdpp_env *h, int K, const void *actions, void *obs, f
     return step_common(h, K, actions, obs, reward, term, trunc, nullptr, stream);
 }
 
-extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *, int32_t, int32_t, int32_t,
-                                           const int16_t *, const int16_t *) {
-    return fail(h, MDPP_EUNSUPPORTED, "image observations not built yet");
+// Python round(v, 15) for |v| <= 1: correctly rounded decimal conversion, like Pillow's rotate().
+static double round15(double v) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.15f", v);
+    return strtod(buf, nullptr);
+}
+
+extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int32_t n_radii,
+                                           int32_t n_cls_x, int32_t n_cls_y, const int16_t *cls_x,
+                                           const int16_t *cls_y) {
+    if (!h || !tpl || !cls_x || !cls_y) return MDPP_EINVAL;
+    if (!h->cfg.image) return fail(h, MDPP_EINVAL, "upload_image_templates: not an image handle");
+    const mdpp_config &c = h->cfg;
+    if (n_radii != c.img_r_max - c.img_r_min + 1 || n_cls_x < 1 || n_cls_y < 1)
+        return fail(h, MDPP_EINVAL, "upload_image_templates: radii/classes do not match the config");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t S = (size_t)c.S, W = (size_t)c.img_w, H = (size_t)c.img_h;
+    const size_t tb = S * n_radii * n_cls_x * n_cls_y * (size_t)c.img_tpl_size * c.img_tpl_size;
+    for (size_t k = 0; k < S * n_radii * W; k++)
+        if (cls_x[k] >= n_cls_x) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_x out of range");
+    for (size_t k = 0; k < S * n_radii * H; k++)
+        if (cls_y[k] >= n_cls_y) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_y out of range");
+    for (void **p : {&h->d_img_tpl, &h->d_img_clsx, &h->d_img_clsy, &h->d_img_rot})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_img_tpl, tb));
+    HIPCHK(h, hipMemcpy(h->d_img_tpl, tpl, tb, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&h->d_img_clsx, S * n_radii * W * 2));
+    HIPCHK(h, hipMemcpy(h->d_img_clsx, cls_x, S * n_radii * W * 2, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&h->d_img_clsy, S * n_radii * H * 2));
+    HIPCHK(h, hipMemcpy(h->d_img_clsy, cls_y, S * n_radii * H * 2, hipMemcpyHostToDevice));
+    // Pillow Image.rotate(angle) -> transform(AFFINE, NEAREST): fixed-point coefficients per angle
+    // (PIL/Image.py rotate(); libImaging/Geometry.c affine_fixed, third-party, Pillow 12.2.0)
+    std::vector<int32_t> rot(360 * 6);
+    const double cxr = c.img_w / 2.0, cyr = c.img_h / 2.0, PI = 3.141592653589793;
+    for (int ang = 0; ang < 360; ang++) {
+        const double a = -((double)ang * (PI / 180.0));
+        const double m0 = round15(cos(a)), m1 = round15(sin(a)), m3 = round15(-sin(a)), m4 = round15(cos(a));
+        const double m2 = (m0 * (-cxr) + m1 * (-cyr) + 0.0) + cxr;
+        const double m5 = (m3 * (-cxr) + m4 * (-cyr) + 0.0) + cyr;
+        auto FIX = [](double v) { return (int32_t)floor(v * 65536.0 + 0.5); };
+        int32_t *r = &rot[ang * 6];
+        r[0] = FIX(m0); r[1] = FIX(m1); r[3] = FIX(m3); r[4] = FIX(m4);
+        r[2] = FIX(m2 + m0 * 0.5 + m1 * 0.5); r[5] = FIX(m5 + m3 * 0.5 + m4 * 0.5);
+    }
+    HIPCHK(h, hipMalloc(&h->d_img_rot, rot.size() * 4));
+    HIPCHK(h, hipMemcpy(h->d_img_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice));
+    h->img_n_radii = n_radii; h->img_n_cls_x = n_cls_x; h->img_n_cls_y = n_cls_y;
+    h->img_ready = true;
+    return MDPP_OK;
 }
 
 // ---- state export / import ------------------------------------------------------------------

@@ -91,7 +91,8 @@ struct mdpp_env {
     void *d_state, *d_ring, *d_status;
     void *d_sd, *d_cur, *d_meta;
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
-    void *d_img_tpl, *d_img_clsx, *d_img_clsy, *d_img_rot;
+    void *d_img_tpl, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;
+    bool img_ready;
     int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
     uint32_t nkeys, rbits_stride;
     bool tables_ready, streams_ready[MDPP_NUM_STREAMS];
@@ -110,5 +111,7 @@ bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, 
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);
-int launch_image_obs(mdpp_env *h, const void *state_obs, const uint8_t *mask, uint8_t *img, hipStream_t s);
+int launch_image_obs(mdpp_env *h, const int32_t *state_out, const int32_t *state_final,
+                     const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
+                     uint8_t *img_out, uint8_t *img_final, hipStream_t s);
 } // namespace mdpp

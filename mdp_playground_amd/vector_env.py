@@ -114,8 +114,6 @@ class RLToyVectorEnv:
         for o in self.mdps[1:]:
             if (o.S, o.A, o.sequence_length, o.delay) != (m.S, m.A, m.sequence_length, m.delay):
                 raise ValueError("per-env MDPs must share S, A, sequence_length and delay")
-        if m.image is not None:
-            raise NotImplementedError("image_representations is not built yet")
         cfg.S, cfg.A, cfg.L = m.S, m.A, m.sequence_length
         cfg.num_tables = self.num_envs if self._per_env else 1
         unit = all(v == 1.0 for mm in self.mdps for k, v in mm.rewardable_sequences.items()
@@ -128,6 +126,26 @@ class RLToyVectorEnv:
         cfg.obs_dtype = capi.OBS_I32 if self._obs_torch_dtype == torch.int32 else capi.OBS_I64
         self.single_observation_space = DiscreteSpace(m.S, seed=m.seed_dict.get("relevant_state_space"))
         self.single_action_space = DiscreteSpace(m.A, seed=m.seed_dict.get("relevant_action_space"))
+        self._image = None
+        if m.image is not None:
+            if self.rng != "numpy":
+                raise NotImplementedError("image observations need rng='numpy'")
+            from . import image_obs
+            im = m.image
+            self._image = image_obs.build_templates(m.S, im)
+            cfg.image, cfg.img_w, cfg.img_h = 1, im["width"], im["height"]
+            tr = im["transforms"]
+            cfg.img_has_scale, cfg.img_has_shift = int("scale" in tr), int("shift" in tr)
+            cfg.img_has_rotate, cfg.img_has_flip = int("rotate" in tr), int("flip" in tr)
+            cfg.img_sh_quant = int(im["sh_quant"] or 1)
+            cfg.img_ro_quant = int(im["ro_quant"] or 1)
+            cfg.img_r0 = im["circle_radius"]
+            cfg.img_r_min, cfg.img_r_max = self._image["r_min"], self._image["r_max"]
+            cfg.img_log_min_r, cfg.img_log_max_r = self._image["log_min_r"], self._image["log_max_r"]
+            cfg.img_tpl_size = self._image["tpl_size"]
+            cfg.obs_dtype = capi.OBS_IMAGE_U8
+            self._obs_torch_dtype = torch.uint8
+            self.single_observation_space = ImageSpace(im["width"], im["height"])
         self.transition_matrix = m.P
         self.rewardable_sequences = m.rewardable_sequences
         # mirrors DiscreteArgs.fast_ok (mdpp_capi.hip): which kernel serves this handle
@@ -154,6 +172,15 @@ class RLToyVectorEnv:
                                                    capi.nptr(rbits), capi.nptr(is_term),
                                                    capi.nptr(init_cdf), capi.nptr(noise))
         capi.check(self._lib, self._h, rc, "mdpp_upload_discrete_tables")
+        if self._image is not None:
+            t = self._image
+            tpl = np.ascontiguousarray(t["tpl"], dtype=np.uint8)
+            cx = np.ascontiguousarray(t["cls_x"], dtype=np.int16)
+            cy = np.ascontiguousarray(t["cls_y"], dtype=np.int16)
+            rc = self._lib.mdpp_upload_image_templates(self._h, capi.nptr(tpl), tpl.shape[1],
+                                                       t["n_cls_x"], t["n_cls_y"], capi.nptr(cx),
+                                                       capi.nptr(cy))
+            capi.check(self._lib, self._h, rc, "mdpp_upload_image_templates")
 
     def _init_continuous(self, cfg):
         m = self.mdps[0]
@@ -187,7 +214,7 @@ class RLToyVectorEnv:
 
     def _alloc_buffers(self):
         N, dev = self.num_envs, self.device
-        shape = (N,) if self.kind == "discrete" else (N, self.mdps[0].D)
+        shape = self._obs_shape(N)
         self._obs = torch.zeros(shape, dtype=self._obs_torch_dtype, device=dev)
         self._final_obs = torch.zeros(shape, dtype=self._obs_torch_dtype, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -195,6 +222,14 @@ class RLToyVectorEnv:
         self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.observation_space = self.single_observation_space
         self.action_space = self.single_action_space
+
+    def _obs_shape(self, *lead):
+        if self.kind == "continuous":
+            return tuple(lead) + (self.mdps[0].D,)
+        if getattr(self, "_image", None) is not None:
+            im = self.mdps[0].image
+            return tuple(lead) + (im["width"], im["height"], 1)
+        return tuple(lead)
 
     def _seed_streams(self, env_seed, initial):
         """Env streams: PCG64(SeedSequence(env_seed + global id)), i.e. what reset(seed=...) does
@@ -226,6 +261,12 @@ class RLToyVectorEnv:
             else:
                 sp = mdp_mod.fresh_stream_words(self.seed_dict["state_space"] + off, N)
         self._put_stream(capi.STREAM_SPACE, sp)
+        if self.kind == "discrete" and self._image is not None:
+            if self._per_env:
+                im = np.stack([mdp_mod.pcg64_words(mdp_mod.new_generator(m.image["seed"])) for m in self.mdps])
+            else:
+                im = mdp_mod.fresh_stream_words(self.mdps[0].image["seed"] + off, N)
+            self._put_stream(capi.STREAM_IMAGE, im)
 
     def _put_stream(self, stream, words):
         words = np.ascontiguousarray(words, dtype=np.uint64)
@@ -288,7 +329,7 @@ class RLToyVectorEnv:
 
     def alloc_rollout(self, K):
         N, dev = self.num_envs, self.device
-        shape = (K, N) if self.kind == "discrete" else (K, N, self.mdps[0].D)
+        shape = self._obs_shape(K, N)
         return (torch.empty(shape, dtype=self._obs_torch_dtype, device=dev),
                 torch.empty((K, N), dtype=torch.float32, device=dev),
                 torch.empty((K, N), dtype=torch.uint8, device=dev),

@@ -29,6 +29,7 @@ struct ora_discrete {
     int steps;               /* total_transitions_episode */
     np_pcg64 env_rng;        /* self._np_random */
     np_pcg64 space_rng;      /* self.observation_spaces[0].np_random */
+    int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
 };
 
 static long ipow(long b, int e) { long r = 1; while (e-- > 0) r *= b; return r; }
@@ -79,8 +80,21 @@ int64_t ora_d_reset(ora_discrete *e) {
     return s0;
 }
 
+void ora_d_set_philox(ora_discrete *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
+    e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
+}
+void ora_d_philox_explicit_reset(ora_discrete *e) {
+    np_philox_init(&e->env_rng, e->ph_seed, e->ph_env, e->reset_tick, 3);
+    e->reset_tick += 1;
+}
+
 void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8_t *done) {
     const int S = e->S, L = e->L;
+    if (e->philox) {
+        np_philox_init(&e->env_rng, e->ph_seed, e->ph_env, e->tick, 0);
+        np_philox_init(&e->space_rng, e->ph_seed, e->ph_env, e->tick, 1);
+        e->tick += 1;
+    }
     /* D1: table lookup, :1603 */
     int nxt = e->P[e->hist[L] * e->A + action];
     /* D2: categorical P-noise on the state-space RNG, :1604-1622 + discrete_extended.py:11-23 */
@@ -153,6 +167,7 @@ struct ora_continuous {
     int steps, reached;
     np_pcg64 env_rng;    /* self._np_random */
     np_pcg64 space_rng;  /* self.feature_space.np_random */
+    int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
 };
 
 ora_continuous *ora_c_create(int D, int n_rel, const int32_t *rel_idx, int order,
@@ -260,9 +275,22 @@ void ora_c_reset(ora_continuous *e, float *obs) {
     e->steps = 0; e->reached = 0;
 }
 
+void ora_c_set_philox(ora_continuous *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
+    e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
+}
+void ora_c_philox_explicit_reset(ora_continuous *e) {
+    np_philox_init(&e->space_rng, e->ph_seed, e->ph_env, e->reset_tick, 3);
+    e->reset_tick += 1;
+}
+
 void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
                 int *reward_is32, uint8_t *done) {
     const int D = e->D, n = e->order;
+    if (e->philox) {
+        np_philox_init(&e->env_rng, e->ph_seed, e->ph_env, e->tick, 0);
+        np_philox_init(&e->space_rng, e->ph_seed, e->ph_env, e->tick, 1);
+        e->tick += 1;
+    }
     float nxt[ORA_MAX_DIM];
     /* C1: Box.contains(action), :1640 */
     int ok = 1;

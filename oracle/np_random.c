@@ -14,6 +14,7 @@ typedef unsigned __int128 u128;
 #define PCG_MULT ((((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL)
 
 void np_pcg64_load(np_pcg64 *g, const uint64_t w[6]) {
+    g->philox = 0;
     g->s_lo = w[0]; g->s_hi = w[1]; g->inc_lo = w[2]; g->inc_hi = w[3];
     g->has32 = (uint32_t)w[4]; g->u32 = (uint32_t)w[5];
 }
@@ -22,8 +23,33 @@ void np_pcg64_store(const np_pcg64 *g, uint64_t w[6]) {
     w[4] = g->has32; w[5] = g->u32;
 }
 
+void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint32_t tick, uint32_t stream) {
+    g->philox = 1;
+    g->k0 = (uint32_t)seed; g->k1 = (uint32_t)(seed >> 32);
+    g->c0 = (uint32_t)env; g->c1 = (uint32_t)(env >> 32); g->c2 = tick; g->c3 = stream << 24;
+    g->have_spare = 0; g->spare_lo = g->spare_hi = 0;
+    g->has32 = 0; g->u32 = 0;
+}
+
+/* Philox4x32-10: one block gives two 64-bit draws (words 0-1, then words 2-3). */
+static uint64_t philox_next64(np_pcg64 *g) {
+    if (g->have_spare) { g->have_spare = 0; return ((uint64_t)g->spare_hi << 32) | g->spare_lo; }
+    uint32_t x0 = g->c0, x1 = g->c1, x2 = g->c2, x3 = g->c3, a = g->k0, b = g->k1;
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ a, y1 = (uint32_t)p1;
+        uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ b, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        a += 0x9E3779B9u; b += 0xBB67AE85u;
+    }
+    g->c3 += 1;
+    g->spare_lo = x2; g->spare_hi = x3; g->have_spare = 1;
+    return ((uint64_t)x1 << 32) | x0;
+}
+
 /* pcg_setseq_128_step_r, then pcg_output_xsl_rr_128_64 of the NEW state. */
 uint64_t np_next64(np_pcg64 *g) {
+    if (g->philox) return philox_next64(g);
     u128 s = ((u128)g->s_hi << 64) | g->s_lo;
     u128 inc = ((u128)g->inc_hi << 64) | g->inc_lo;
     s = s * PCG_MULT + inc;

@@ -29,7 +29,14 @@ typedef struct {
     uint64_t inc_lo, inc_hi; /* 128-bit increment (odd) */
     uint32_t has32;          /* numpy's pcg64_state.has_uint32 */
     uint32_t u32;            /* numpy's pcg64_state.uinteger */
+    /* Alternative bit generator of the build (NOT in the reference): stateless Philox4x32-10
+     * (Salmon et al., SC'11) keyed by (seed, global env id, tick, stream).  Same next64()
+     * interface, so every distribution above it is shared.  philox != 0 selects it. */
+    uint32_t philox;
+    uint32_t k0, k1, c0, c1, c2, c3, spare_lo, spare_hi, have_spare;
 } np_pcg64;
+
+void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint32_t tick, uint32_t stream);
 
 void np_pcg64_load(np_pcg64 *g, const uint64_t w[6]);
 void np_pcg64_store(const np_pcg64 *g, uint64_t w[6]);

@@ -53,6 +53,10 @@ def lib():
         L.ora_c_step.argtypes = [vp] * 6
         L.ora_c_get_derivs.argtypes = [vp, vp]
         L.ora_c_rollout.argtypes = [vp, i32] + [vp] * 6
+        L.ora_d_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_c_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_d_philox_explicit_reset.argtypes = [vp]
+        L.ora_c_philox_explicit_reset.argtypes = [vp]
         L.ora_i_draw.argtypes = [vp] * 7
         L.ora_i_rotate_flip_transpose.argtypes = [i32, i32, vp, i32, i32, vp]
         for name in ("np_next64", "np_next32"):
@@ -85,7 +89,10 @@ def pcg_words(gen):
 class NpPCG64(C.Structure):
     """Mirror of np_pcg64 for driving the RNG primitives directly from tests."""
     _fields_ = [("s_lo", C.c_uint64), ("s_hi", C.c_uint64), ("inc_lo", C.c_uint64),
-                ("inc_hi", C.c_uint64), ("has32", C.c_uint32), ("u32", C.c_uint32)]
+                ("inc_hi", C.c_uint64), ("has32", C.c_uint32), ("u32", C.c_uint32),
+                ("philox", C.c_uint32), ("k0", C.c_uint32), ("k1", C.c_uint32),
+                ("c0", C.c_uint32), ("c1", C.c_uint32), ("c2", C.c_uint32), ("c3", C.c_uint32),
+                ("spare_lo", C.c_uint32), ("spare_hi", C.c_uint32), ("have_spare", C.c_uint32)]
 
     @classmethod
     def from_words(cls, w):
@@ -141,7 +148,14 @@ class DiscreteOracle:
         lib().ora_d_get_rng(self.h, _p(a), _p(b))
         return a, b
 
-    def reset(self):
+    def set_philox(self, seed, env_id, tick=0, reset_tick=0):
+        self._philox = True
+        lib().ora_d_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
+
+    def reset(self, explicit=True):
+        """explicit=True mirrors a reset() call of its own (mdpp_reset); False an in-step reset."""
+        if getattr(self, "_philox", False) and explicit:
+            lib().ora_d_philox_explicit_reset(self.h)
         return int(lib().ora_d_reset(self.h))
 
     def step(self, action):
@@ -202,7 +216,13 @@ class ContinuousOracle:
         lib().ora_c_get_rng(self.h, _p(a), _p(b))
         return a, b
 
-    def reset(self):
+    def set_philox(self, seed, env_id, tick=0, reset_tick=0):
+        self._philox = True
+        lib().ora_c_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
+
+    def reset(self, explicit=True):
+        if getattr(self, "_philox", False) and explicit:
+            lib().ora_c_philox_explicit_reset(self.h)
         obs = np.zeros(self.D, np.float32)
         lib().ora_c_reset(self.h, _p(obs))
         return obs

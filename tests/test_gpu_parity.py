@@ -275,3 +275,113 @@ def test_discrete_fast_kernel_masked_reset_and_reseed():
         eo, *_ = _oracle_autoreset_rollout(o, acts[:, i], 0)
         assert np.array_equal(obs3[:, i], eo), i
     env.close()
+
+
+# ----------------------------------------------------------------------------- Philox streams
+@pytest.mark.parametrize("fused", [True, False])
+def test_discrete_philox_vs_oracle(fused):
+    """rng='philox': stateless Philox4x32-10 keyed by (seed, GLOBAL env id, tick, stream).  Integer
+    draws are exact; the ziggurat tail uses log1p/exp whose device and glibc versions may differ in
+    the last ulp, hence allclose on rewards."""
+    cfg = dict(gu.CASES["d_cfg2_noise"]["config"], seed=6)
+    N, T, off = 700, 50, 4096
+    env = _venv(num_envs=N, autoreset="same_step", rng="philox", env_id_offset=off, philox_seed=99, **cfg)
+    acts = np.random.default_rng(2).integers(0, 8, size=(T, N)).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    if fused:
+        obs, rew, term, _ = env.rollout(torch.as_tensor(acts, device=env.device))
+        obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    else:
+        obs = np.zeros((T, N), np.int64); rew = np.zeros((T, N), np.float32); term = np.zeros((T, N), bool)
+        for t in range(T):
+            o, r, te, _, _ = env.step(torch.as_tensor(acts[t], device=env.device))
+            obs[t], rew[t], term[t] = o.cpu().numpy(), r.cpu().numpy(), te.cpu().numpy()
+    for i in range(0, N, 13):
+        o = _oracle_for(env, i)
+        o.set_philox(99, off + i)
+        assert o.reset() == int(init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        eo[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], eo), i
+        assert np.array_equal(term[:, i], ed), i
+        assert np.allclose(rew[:, i], er.astype(np.float32), rtol=1e-6, atol=1e-6), i
+    env.close()
+
+
+def test_continuous_philox_vs_oracle_and_sharding_invariance():
+    """Continuous cfg 5 with Philox streams: matches the oracle, and a job split into two shards
+    (env_id_offset) reproduces the unsharded trajectories exactly (global-id keyed streams)."""
+    cfg = dict(gu.CASES["c_cfg5"]["config"], seed=3)
+    N, T = 512, 40
+    rng = np.random.default_rng(4)
+    acts = rng.uniform(-1, 1, size=(T, N, 12)).astype(np.float32)
+    env = _venv(num_envs=N, autoreset="same_step", rng="philox", philox_seed=7, **cfg)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, _ = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    for i in range(0, N, 37):
+        o = _oracle_for(env, i)
+        o.set_philox(7, i)
+        assert np.array_equal(o.reset(), init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        eo[ed] = ero[ed]
+        assert np.allclose(obs[:, i], eo, rtol=1e-6, atol=0), i
+        assert np.allclose(rew[:, i], er.astype(np.float32), rtol=1e-5, atol=1e-5), i
+    env.close()
+    half = N // 2
+    parts = []
+    for r in range(2):
+        e = _venv(num_envs=half, autoreset="same_step", rng="philox", philox_seed=7,
+                  env_id_offset=r * half, **cfg)
+        a = torch.as_tensor(np.ascontiguousarray(acts[:, r * half:(r + 1) * half]), device=e.device)
+        o, rw, _, _ = e.rollout(a)
+        parts.append((o.cpu().numpy(), rw.cpu().numpy()))
+        e.close()
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=1), obs)
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=1), rew)
+
+
+def test_numpy_streams_sharding_invariance_discrete():
+    """rng='numpy': env i is seeded from its GLOBAL id, so 2 shards == 1 big batch."""
+    cfg = dict(gu.CASES["d_cfg2_noise"]["config"], seed=12)
+    N, T = 600, 64
+    acts = np.random.default_rng(1).integers(0, 8, size=(T, N)).astype(np.int32)
+    env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    obs, rew, term, _ = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    env.close()
+    half = N // 2
+    for r in range(2):
+        e = _venv(num_envs=half, autoreset="same_step", env_id_offset=r * half, **cfg)
+        a = torch.as_tensor(np.ascontiguousarray(acts[:, r * half:(r + 1) * half]), device=e.device)
+        o, rw, _, _ = e.rollout(a)
+        if r == 0:
+            # env 0 keeps the reference's own post-construction space generator in both runs
+            assert np.array_equal(o.cpu().numpy(), obs[:, :half])
+            assert np.array_equal(rw.cpu().numpy(), rew[:, :half])
+        else:
+            assert np.array_equal(o.cpu().numpy(), obs[:, half:])
+            assert np.array_equal(rw.cpu().numpy(), rew[:, half:])
+        e.close()
+
+
+# ----------------------------------------------------------------------------- image observations
+@pytest.mark.parametrize("name", gu.IMAGE)
+def test_image_observations_vs_reference_golden(name):
+    """BASELINE cfg 4 shape (84x84 shift+rotate) and a 100x100 all-transforms case: every pixel of
+    every observation equals what the reference (Pillow polygon + rotate) produced."""
+    g = gu.load(name)
+    E, T = g["action"].shape
+    env = _venv(autoreset="same_step", **_seeds_or_cfg(name))
+    assert np.array_equal(env._obs.cpu().numpy(), g["init_obs"])
+    for t in range(T):
+        a = torch.as_tensor(g["action"][:, t].astype(np.int32), device=env.device)
+        obs, rew, term, trunc, info = env.step(a)
+        obs, fin = obs.cpu().numpy(), info["final_obs"].cpu().numpy()
+        d = g["done"][:, t]
+        assert np.array_equal(term.cpu().numpy(), d)
+        assert np.array_equal(rew.cpu().numpy(), g["reward"][:, t].astype(np.float32))
+        assert np.array_equal(obs[~d], g["obs"][:, t][~d]), (name, t)
+        assert np.array_equal(fin[d], g["obs"][:, t][d]), (name, t)          # terminal obs
+        assert np.array_equal(obs[d], g["reset_obs"][:, t][d]), (name, t)    # first obs of next episode
+    env.close()
