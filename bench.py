@@ -50,6 +50,13 @@ WORKLOADS = {
                              action_space_max=1, transition_dynamics_order=1, inertia=1,
                              time_unit=1, make_denser=True, reward_function="move_to_a_point",
                              seed=0)),
+    # BASELINE.json configs[3]: 84x84 polygon images, shift + rotate, 8 192 envs
+    "cfg4": dict(kind="discrete", envs=8192, alg_bytes_fused=7082, alg_bytes_step=7082,
+                 config=dict(state_space_type="discrete", action_space_type="discrete",
+                             state_space_size=8, action_space_size=8, delay=0,
+                             image_representations=True, image_width=84, image_height=84,
+                             image_transforms="shift,rotate", image_sh_quant=1, image_ro_quant=1,
+                             seed=0)),
     # BASELINE.json configs[4] (per-GPU shard of the 524 288-env job)
     "cfg5": dict(kind="continuous", envs=65536, alg_bytes_fused=102, alg_bytes_step=350,
                  config=dict(state_space_type="continuous", state_space_dim=12,
@@ -141,7 +148,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: RCCL, even for N = 1
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)
 
@@ -155,7 +162,7 @@ def main():
                          autoreset="same_step", **wl["config"])
     acts = make_actions(wl, F, N, device, 12345 + rank)
     out = env.alloc_rollout(F)
-    gather = ObsGatherer(out[0], world, dist) if world > 1 else None
+    gather = ObsGatherer(out[0], world, dist) if dist is not None else None
 
     def run(steps):
         left, launches = steps, 0
@@ -178,16 +185,16 @@ def main():
 
     run(max(args.warmup, 1))
     barrier()
-    if world == 1:
+    if gather is None:
         env.timer_begin()
     t0 = time.perf_counter()
     launches = run(args.steps)
-    if world == 1:
+    if gather is None:
         kernel_ms = env.timer_end()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
+    if gather is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -205,7 +212,12 @@ def main():
     per_launch_s = (kernel_ms / 1e3) / (args.steps / F)
     alg_bytes = wl["alg_bytes_fused"] * N * F
     achieved = alg_bytes / per_launch_s / 1e9
-    kname = "k_discrete_step" if wl["kind"] == "discrete" else "k_continuous_step"
+    if wl["kind"] == "continuous":
+        kname = "k_continuous_step"
+    elif wl["config"].get("image_representations"):
+        kname = "k_image_obs"
+    else:
+        kname = "k_discrete_rollout_fast" if env.uses_fast_kernel else "k_discrete_step"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"],
@@ -240,13 +252,13 @@ def main():
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/f64" if wl["kind"] == "discrete" else "f32/f64", "data": "synthetic",
+            "dtype": "u8" if wl["kind"] == "discrete" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: BASELINE.json configs "
                                    f"({json.dumps(wl['config'], sort_keys=True)}), "
                                    f"{N} env instances per GPU, random actions, same-step autoreset, "
                                    f"fused rollout of {F} steps per launch, rng={args.rng}",
                        "envs_per_gpu": N, "fuse": F,
-                       "collective": "all_gather(obs) per launch" if world > 1 else "none"},
+                       "collective": "all_gather(obs) per launch" if gather is not None else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "single_step": single,
             "launches": launches, "elapsed_s": elapsed,
         }

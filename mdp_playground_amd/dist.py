@@ -32,14 +32,16 @@ class ObsGatherer:
         self.world = int(world)
         self.dist = dist_module
         self.group = group
-        self.out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype,
-                               device=local.device)
+        # concatenation form along dim 0 (accepted by both RCCL and gloo), viewed rank-major
+        self._flat = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]),
+                                 dtype=local.dtype, device=local.device)
+        self.out = self._flat.view((self.world,) + tuple(local.shape))
 
     def __call__(self) -> torch.Tensor:
         if self.world == 1 or self.dist is None:
             self.out[0].copy_(self.local)
             return self.out
-        self.dist.all_gather_into_tensor(self.out, self.local, group=self.group)
+        self.dist.all_gather_into_tensor(self._flat, self.local, group=self.group)
         return self.out
 
 
