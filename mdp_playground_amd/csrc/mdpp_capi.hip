@@ -282,6 +282,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         for (int j = 0; j < 16; j++) a.init_thr[j] = ~0ULL;
         if (c.S <= 16)
             for (size_t j = 0; j < S; j++) a.init_thr[j] = (uint64_t)ceil(ldexp(init_cdf[j], 53));
+        a.minv_lo = (uint64_t)pcg_mult_inverse(); a.minv_hi = (uint64_t)(pcg_mult_inverse() >> 64);
         for (int q = 0; q < 4; q++) {
             double r = (q & 2) ? 1.0 : 0.0;
             r *= a.scale; r += a.shift;

@@ -51,6 +51,7 @@ struct DiscreteArgs {
     uint64_t term_mask;         // bit s set <=> state s terminal (S <= 64)
     uint64_t init_thr[16];      // ceil(init_cdf[j] * 2^53): cdf[j] <= u  <=>  init_thr[j] <= (r >> 11)
     float rsel[4];              // reward for {paid*2 + terminal}, formed in float64 like :1987-1990,:2107
+    uint64_t minv_lo, minv_hi;  // inverse of the PCG64 LCG multiplier mod 2^128 (un-drawing)
 };
 
 struct ContinuousArgs {

@@ -203,10 +203,11 @@ def _oracle_autoreset_rollout(o, acts, max_steps):
 
 
 @pytest.mark.parametrize("variant", sorted(FAST_VARIANTS))
-@pytest.mark.parametrize("fused", [True, False])
-def test_discrete_fast_kernel_vs_oracle(variant, fused):
+@pytest.mark.parametrize("fused,N", [(True, 1000), (True, 1024), (False, 1000)])
+def test_discrete_fast_kernel_vs_oracle(variant, fused, N):
+    """N = 1000: partial last block, RNG drawn by the env lanes; N = 1024 and >= 32 fused steps:
+    the helper-wave variant (start states produced by partner waves through an LDS ring)."""
     cfg, kw, T = FAST_VARIANTS[variant]
-    N = 1000  # not a multiple of the block size
     env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
     assert env.uses_fast_kernel
     A = env.mdps[0].A

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "mdp_playground_amd", "csrc")
-VARIANTS = ["", "NOSTORE", "NORESET", "NOREFILL", "NOLDSR", "NOLDSP", "NOLDSR,NOLDSP",
+VARIANTS = ["", "HALFWAVE", "HALFWAVE,NOSTORE", "NOSTORE", "NORESET", "NOREFILL", "NOLDSR", "NOLDSP", "NOLDSR,NOLDSP",
             "NOSTORE,NORESET,NOREFILL", "NOSTORE,NORESET,NOREFILL,NOLDSR,NOLDSP"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
 
@@ -19,7 +19,7 @@ def main():
     import torch
     outdir = os.path.join(ROOT, "gpurun_out", "ablate")
     os.makedirs(outdir, exist_ok=True)
-    objs = [os.path.join(CSRC, f) for f in ("mdpp_capi.o", "mdpp_discrete.o", "mdpp_continuous.o")]
+    objs = [os.path.join(CSRC, f) for f in ("mdpp_capi.o", "mdpp_discrete.o", "mdpp_continuous.o", "mdpp_image.o")]
     for v in VARIANTS:
         tag = v.replace(",", "_") or "FULL"
         obj = os.path.join(outdir, f"fast_{tag}.o")
