@@ -218,8 +218,17 @@ def main():
         kname = "k_image_obs"
     else:
         kname = "k_discrete_rollout_fast" if env.uses_fast_kernel else "k_discrete_step"
+    # HBM bytes per launch from PMC counters: collected offline with rocprofv3 --pmc (separate
+    # passes, gfx950 FETCH_SIZE correction applied) and committed under profiles/; only valid for
+    # the exact launch shape it was measured on.
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}.json")
+    if os.path.exists(tfile):
+        t = json.load(open(tfile))
+        if t.get("envs") == N and t.get("fuse") == F:
+            traffic = t["traffic_bytes_per_launch"]
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"],
                 "launch_us": per_launch_s * 1e6, "env_steps_per_launch": N * F}
 
