@@ -229,6 +229,18 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             if (cfg->rel_idx[j] != j) a.rel_prefix = 0;
         }
         for (int b = 0; b < cfg->n_boxes * cfg->n_rel; b++) { a.box_lo[b] = cfg->box_lo[b]; a.box_hi[b] = cfg->box_hi[b]; }
+        {
+            auto is_pow2 = [](double v) { int e; return v > 0 && isfinite(v) && frexp(v, &e) == 0.5; };
+            a.inertia_pow2 = is_pow2((double)a.inertia32) ? 1u : 0u;
+            a.inv_inertia32 = 1.0f / a.inertia32;
+            a.fact_pow2_mask = 0;
+            for (int k = 1; k <= cfg->order; k++) {
+                a.inv_fact[k] = 1.0 / a.fact[k];
+                if (is_pow2(a.fact[k])) a.fact_pow2_mask |= 1u << k;
+            }
+            a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && cfg->n_boxes == 0 && a.rel_prefix &&
+                         a.bounded && cfg->delay == 0 && cfg->every_n == 1) ? 1u : 0u;
+        }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
@@ -465,6 +477,12 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
         int32_t *r = &rot[ang * 6];
         r[0] = FIX(m0); r[1] = FIX(m1); r[3] = FIX(m3); r[4] = FIX(m4);
         r[2] = FIX(m2 + m0 * 0.5 + m1 * 0.5); r[5] = FIX(m5 + m3 * 0.5 + m4 * 0.5);
+        // Image.rotate() transposes instead for these angles: exact integer maps, same form
+        const int W1 = c.img_w - 1, H1 = c.img_h - 1, ONE = 65536;
+        if (ang == 0) { r[0] = ONE; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = ONE; r[5] = 0; }
+        if (ang == 180) { r[0] = -ONE; r[1] = 0; r[2] = W1 * ONE; r[3] = 0; r[4] = -ONE; r[5] = H1 * ONE; }
+        if (ang == 90 && c.img_w == c.img_h) { r[0] = 0; r[1] = -ONE; r[2] = W1 * ONE; r[3] = ONE; r[4] = 0; r[5] = 0; }
+        if (ang == 270 && c.img_w == c.img_h) { r[0] = 0; r[1] = ONE; r[2] = 0; r[3] = -ONE; r[4] = 0; r[5] = H1 * ONE; }
     }
     HIPCHK(h, hipMalloc(&h->d_img_rot, rot.size() * 4));
     HIPCHK(h, hipMemcpy(h->d_img_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice));

@@ -112,6 +112,11 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
                                                             uint8_t *__restrict__ term,
                                                             uint8_t *__restrict__ trunc,
                                                             float *__restrict__ final_obs) {
+    __shared__ uint64_t s_ki[256];
+    __shared__ double s_wi[256], s_fi[256];
+    const bool any_noise = a.has_p_noise || a.has_r_noise;   // wave-uniform
+    if (any_noise) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
+    const ZigLds zig{s_ki, s_wi, s_fi};
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.N) return;
     const int D = a.D, n = a.order;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             if (d < D) {
                 double nz = 0.0;
                 if (a.has_p_noise)
-                    nz = 0.0 + a.p_noise * (PHILOX ? np_standard_normal(env_phx) : np_standard_normal(env_pcg));
+                    nz = 0.0 + a.p_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
                 nxt[d] = (float)((double)nxt[d] + nz);
             }
         }
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         }
         if (steps % (uint32_t)a.every_n != 0) { r.v = 0.0; r.is32 = false; }
         if (a.has_r_noise) {
-            double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal(env_phx) : np_standard_normal(env_pcg));
+            double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
             if (r.is32) r.v = (double)((float)r.v + (float)nz); else r.v = r.v + nz;
         }
         if (r.is32) {
@@ -394,6 +399,27 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
     ContinuousArgs a = h->cargs;
     a.tick = h->tick;
+    if (a.fast_ok) {
+        // common shape: dedicated rollout kernel (mdpp_continuous_fast.hip); its buffer descriptors
+        // address < 4 GiB per array, so long rollouts go out as several launches
+        const long long kmax = ((1LL << 32) - 1) / ((long long)a.N * a.D * 4);
+        bool served = kmax >= 1;
+        for (int k0 = 0; served && k0 < K;) {
+            const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
+            const size_t off = (size_t)k0 * a.N;
+            served = launch_continuous_fast(a, kc, actions + off * a.D, obs + off * a.D, reward + off,
+                                            term + off, trunc + off,
+                                            final_obs ? final_obs + off * a.D : nullptr, s);
+            if (!served && k0 > 0) { h->err = "k_continuous_rollout_fast: inconsistent dispatch"; return MDPP_EHIP; }
+            k0 += kc;
+        }
+        if (served) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { h->err = std::string("k_continuous_rollout_fast launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+            h->tick += (uint32_t)K;
+            return MDPP_OK;
+        }
+    }
 #define CALL_STEP(DM, OM) launch_step_t<DM, OM>(a, K, actions, obs, reward, term, trunc, final_obs, s)
     MDPP_C_DISPATCH(CALL_STEP);
 #undef CALL_STEP

@@ -1,0 +1,314 @@
+// Fused K-step rollout for the common continuous shape (BASELINE cfg 3 / cfg 5): move_to_a_point,
+// relevant dims = the first n_rel dims, bounded box, no terminal hypercubes, delay 0,
+// reward_every_n_steps 1, numpy PCG64 streams.  Same arithmetic as k_continuous_step
+// (mdpp_continuous.hip; reference rl_toy_env.py:1630-1725, :1912-1990, :2102-2109) with D and the
+// dynamics order as template constants, so every per-dimension loop is straight-line code on
+// registers, and with the work that the general kernel does per step moved out of the way:
+//   * actions ([env][D] float32, 48 B per lane at D = 12) are fetched kCAhead steps ahead with
+//     16-byte buffer loads; observations leave as 16-byte buffer stores;
+//   * divisions by inertia and by k! become exact multiplications when the divisor is a power of
+//     two (1, 2: orders 1-2, the usual inertia), true IEEE divisions otherwise;
+//   * ||s_old - target|| of step k is ||s_new - target|| of step k-1, carried in a register;
+//   * the action-norm penalty (action_loss_weight, default 0) is only evaluated when it can
+//     matter; the box clip + derivative reset runs under a wave-uniform branch;
+//   * Gaussian noise: the ziggurat's hot path (98.8 % of draws: one PCG64 output, one table
+//     compare) is inline with ki/wi staged in LDS; the wedge/tail path is out of line;
+//   * the rare events — episode end (target reached / truncated) with its reset() draws from the
+//     feature-space stream, a rejected action — sit behind wave-uniform unlikely branches.
+// HBM traffic per env step: 4D B action in; 4D B obs + 4 B reward + 2 B flags out (102 B at D = 12).
+// Compile with -ffp-contract=off.
+#include <stdlib.h>
+
+#include "mdpp_internal.hpp"
+#include "mdpp_rng.hpp"
+
+namespace mdpp {
+
+constexpr int kCAheadQuiet = 4, kCAheadNoise = 2; // fewer rows in flight where the RNG needs the registers
+constexpr int kCRsrc = 0x00020000;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bool pow2) {
+    return pow2 ? x * inv : x / div;
+}
+
+template <int D, int ORDER, bool NOISE>
+__global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
+                                                                    const float *__restrict__ actions,
+                                                                    float *__restrict__ obs,
+                                                                    float *__restrict__ reward,
+                                                                    uint8_t *__restrict__ term,
+                                                                    uint8_t *__restrict__ trunc,
+                                                                    float *__restrict__ final_obs) {
+    static_assert(D % 4 == 0 || D == 2, "D must be 2 or a multiple of 4");
+    __shared__ uint64_t s_ki[NOISE ? 256 : 1];
+    __shared__ double s_wi[NOISE ? 256 : 1], s_fi[NOISE ? 256 : 1];
+    const int tid = threadIdx.x;
+    if (NOISE) {
+        zig_stage(s_ki, s_wi, s_fi, tid, kBlock);
+        __syncthreads();
+    }
+    const ZigLds zig{s_ki, s_wi, s_fi};
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    if (i >= (uint32_t)a.N) return;
+    const uint32_t N = (uint32_t)a.N;
+    constexpr int kCAhead = NOISE ? kCAheadNoise : kCAheadQuiet;
+    constexpr int V = (D == 2) ? 1 : D / 4;      // 16-byte pieces per action / observation row
+
+    float sd[ORDER + 1][D], cur[D];
+#pragma unroll
+    for (int k = 0; k <= ORDER; k++)
+#pragma unroll
+        for (int d = 0; d < D; d++) sd[k][d] = a.sd[((size_t)k * D + d) * N + i];
+#pragma unroll
+    for (int d = 0; d < D; d++) cur[d] = a.cur[(size_t)d * N + i];
+    uint2 meta = a.meta[i];
+    uint32_t steps = meta.x, flags = meta.y, status = 0;
+
+    Pcg64 g;
+    if (NOISE) g.load(a.env_s, a.env_inc, i);
+
+    const uint32_t total = (uint32_t)K * N;
+    auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(D * 4), kCRsrc);
+    auto r_obs = __builtin_amdgcn_make_buffer_rsrc((void *)obs, 0, total * (uint32_t)(D * 4), kCRsrc);
+    auto r_rew = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kCRsrc);
+    auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kCRsrc);
+    auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kCRsrc);
+    const uint32_t v1 = i, v4 = i * 4u, vrow = i * (uint32_t)(D * 4);
+    const uint32_t row_bytes = N * (uint32_t)(D * 4);
+
+    const float amax = a.amax32, smax = a.smax32, radius = a.radius32;
+    const bool inertia_pow2 = a.inertia_pow2 != 0;
+    const float inv_inertia = a.inv_inertia32;
+    const bool has_max = a.max_steps > 0, autoreset = a.autoreset != 0;
+    const uint32_t max_steps = (uint32_t)a.max_steps;
+    const bool has_alw = a.alw32 != 0.0f;
+
+    auto norm_rel = [&](const float (&s)[D]) -> float {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            if (j < a.n_rel) {
+                float dd = s[j] - a.target[j];
+                float p = dd * dd;
+                acc += (double)p;
+            }
+        }
+        return sqrtf((float)acc);
+    };
+    auto normal = [&]() -> double { return np_standard_normal_lds(g, zig); };
+
+    float dist_prev = norm_rel(cur);
+
+    auto load_row = [&](int k, float (&dst)[D]) {
+        const uint32_t kk = (uint32_t)min(k, K - 1);
+        if (D == 2) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_act, vrow, kk * row_bytes, 0);
+            dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; q++) {
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_act, vrow + 16u * q, kk * row_bytes, 0);
+                dst[4 * q] = __uint_as_float(v.x); dst[4 * q + 1] = __uint_as_float(v.y);
+                dst[4 * q + 2] = __uint_as_float(v.z); dst[4 * q + 3] = __uint_as_float(v.w);
+            }
+        }
+    };
+
+    float pre[kCAhead][D];
+#pragma unroll
+    for (int u = 0; u < kCAhead; u++) load_row(u, pre[u]);
+
+    auto step = [&](const float (&act)[D], int k) {
+        const uint32_t so = (uint32_t)k * N;
+        float nxt[D];
+        // ---- C1: Box.contains(action)
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) ok = ok && (act[d] >= -amax) && (act[d] <= amax);
+        const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        // ---- C2 (computed for every lane, committed only where the action was admitted)
+        float nsd[ORDER + 1][D];
+#pragma unroll
+        for (int kk = 0; kk <= ORDER; kk++)
+#pragma unroll
+            for (int d = 0; d < D; d++) nsd[kk][d] = sd[kk][d];
+#pragma unroll
+        for (int d = 0; d < D; d++) nsd[ORDER][d] = c_fdiv_or_mul(act[d], a.inertia32, inv_inertia, inertia_pow2);
+#pragma unroll
+        for (int ii = 0; ii < ORDER; ii++) {
+#pragma unroll
+            for (int j = 0; j < ORDER - ii; j++) {
+                const bool fp2 = (a.fact_pow2_mask >> (j + 1)) & 1u;
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    float prod = nsd[ii + j + 1][d] * a.tpow32[j + 1];
+                    double trm = fp2 ? (double)prod * a.inv_fact[j + 1] : (double)prod / a.fact[j + 1];
+                    nsd[ii][d] = (float)((double)nsd[ii][d] + trm);
+                }
+            }
+        }
+        if (__builtin_expect(all_ok, 1)) {
+#pragma unroll
+            for (int kk = 0; kk <= ORDER; kk++)
+#pragma unroll
+                for (int d = 0; d < D; d++) sd[kk][d] = nsd[kk][d];
+#pragma unroll
+            for (int d = 0; d < D; d++) nxt[d] = sd[0][d];
+        } else {
+            status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+#pragma unroll
+            for (int kk = 0; kk <= ORDER; kk++)
+#pragma unroll
+                for (int d = 0; d < D; d++) sd[kk][d] = ok ? nsd[kk][d] : sd[kk][d];
+#pragma unroll
+            for (int d = 0; d < D; d++) nxt[d] = ok ? sd[0][d] : cur[d];          // "stay", :1671
+        }
+        // ---- C3
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (NOISE && a.has_p_noise) nxt[d] = (float)((double)nxt[d] + (0.0 + a.p_noise * normal()));
+            else nxt[d] = nxt[d] + 0.0f;      // float32 += float64 zeros: only turns -0 into +0
+        }
+        // ---- C4
+        bool inside = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) inside = inside && (nxt[d] >= -smax) && (nxt[d] <= smax);
+        if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                float x = nxt[d];
+                x = (x < -smax) ? -smax : x;
+                x = (x > smax) ? smax : x;
+                nxt[d] = inside ? nxt[d] : x;
+            }
+#pragma unroll
+            for (int kk = 0; kk <= ORDER; kk++)
+#pragma unroll
+                for (int d = 0; d < D; d++) sd[kk][d] = inside ? sd[kk][d] : (kk == 0 ? nxt[d] : 0.0f);
+        }
+        // ---- C5
+        const float dist_new = norm_rel(nxt);
+        flags |= (dist_new < radius) ? 1u : 0u;
+        steps += 1;
+        // ---- C6
+        float r;
+        if (a.make_denser) r = -dist_new + dist_prev;
+        else r = (dist_new < radius) ? 1.0f : 0.0f;
+        if (__builtin_expect(has_alw || !all_ok, 0)) {
+            double acc = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; d++) { float p = act[d] * act[d]; acc += (double)p; }
+            r = r - a.alw32 * sqrtf((float)acc);
+        } else {
+            r = r - 0.0f;                       // alw * ||a|| == +0 exactly for an admitted action
+        }
+        // ---- C7 (delay 0, every step pays: the reward stays np.float32 throughout)
+        if (NOISE && a.has_r_noise) r = r + (float)(0.0 + a.r_noise * normal());
+        r = r * a.scale32;
+        r = r + a.shift32;
+        // ---- C8
+        const bool done = (flags & 1u) != 0;
+        r = done ? r + a.term_add32 : r;
+        const bool tr = has_max && steps >= max_steps;
+        dist_prev = dist_new;
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[d] = nxt[d];
+        // ---- episode end: same-step autoreset (reset(), :2284-2323), rare
+        const bool need = autoreset && (done || tr);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {
+            if (need) {
+                if (final_obs) {
+#pragma unroll
+                    for (int d = 0; d < D; d++) final_obs[((size_t)so + i) * D + d] = nxt[d];
+                }
+                Pcg64 sp;
+                sp.load(a.sp_s, a.sp_inc, i);
+#pragma unroll
+                for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));
+                sp.store(a.sp_s, i);
+#pragma unroll
+                for (int kk = 0; kk <= ORDER; kk++)
+#pragma unroll
+                    for (int d = 0; d < D; d++) sd[kk][d] = (kk == 0) ? cur[d] : 0.0f;
+                steps = 0; flags = 0;
+            }
+            dist_prev = norm_rel(cur);
+        }
+        // ---- outputs
+        if (D == 2) {
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[0]), __float_as_uint(cur[1])},
+                                                  r_obs, vrow, so * (uint32_t)(D * 4), 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; q++)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    u32x4{__float_as_uint(cur[4 * q]), __float_as_uint(cur[4 * q + 1]),
+                          __float_as_uint(cur[4 * q + 2]), __float_as_uint(cur[4 * q + 3])},
+                    r_obs, vrow + 16u * q, so * (uint32_t)(D * 4), 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), r_rew, v4, so * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so, 0);
+    };
+
+    const int nfull = K / kCAhead;
+    for (int c = 0; c < nfull; c++) {
+#pragma unroll
+        for (int u = 0; u < kCAhead; u++) {
+            float act[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) act[d] = pre[u][d];
+            load_row(c * kCAhead + kCAhead + u, pre[u]);   // refill this slot for the next chunk
+            step(act, c * kCAhead + u);
+        }
+    }
+    for (int k = nfull * kCAhead; k < K; k++) {
+        float act[D];
+        const int u = k - nfull * kCAhead;
+#pragma unroll
+        for (int uu = 0; uu < kCAhead; uu++)
+            if (uu == u) {
+#pragma unroll
+                for (int d = 0; d < D; d++) act[d] = pre[uu][d];
+            }
+        step(act, k);
+    }
+
+#pragma unroll
+    for (int k = 0; k <= ORDER; k++)
+#pragma unroll
+        for (int d = 0; d < D; d++) a.sd[((size_t)k * D + d) * N + i] = sd[k][d];
+#pragma unroll
+    for (int d = 0; d < D; d++) a.cur[(size_t)d * N + i] = cur[d];
+    a.meta[i] = make_uint2(steps, flags);
+    if (NOISE) g.store(a.env_s, i);
+    if (status) atomicOr(&a.status[i], status);
+}
+
+template <int D, int ORDER>
+static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+                     uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    if (a.has_p_noise || a.has_r_noise)
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, true>), dim3(grid), dim3(kBlock), 0, s, a,
+                           K, actions, obs, reward, term, trunc, final_obs);
+    else
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, false>), dim3(grid), dim3(kBlock), 0, s, a,
+                           K, actions, obs, reward, term, trunc, final_obs);
+}
+
+// Returns false when the shape does not qualify (caller falls back to k_continuous_step).
+bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs,
+                            float *reward, uint8_t *term, uint8_t *trunc, float *final_obs,
+                            hipStream_t s) {
+    if (!a.fast_ok || getenv("MDPP_NO_CFAST")) return false;
+#define MDPP_CF(DD, OO) if (a.D == DD && a.order == OO) { launch_t<DD, OO>(a, K, actions, obs, reward, term, trunc, final_obs, s); return true; }
+    MDPP_CF(12, 1) MDPP_CF(12, 2) MDPP_CF(2, 1) MDPP_CF(2, 2) MDPP_CF(4, 1) MDPP_CF(4, 2) MDPP_CF(8, 1) MDPP_CF(8, 2)
+#undef MDPP_CF
+    return false;
+}
+
+} // namespace mdpp

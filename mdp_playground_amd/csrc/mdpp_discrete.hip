@@ -55,9 +55,14 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                                                           uint8_t *__restrict__ trunc,
                                                           void *__restrict__ final_obs) {
     extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ uint64_t s_ki[NOISE ? 256 : 1];
+    __shared__ double s_wi[NOISE ? 256 : 1], s_fi[NOISE ? 256 : 1];
     DTables t;
     const int tid = threadIdx.x;
     const long i = (long)blockIdx.x * kBlock + tid;
+    if (NOISE) zig_stage(s_ki, s_wi, s_fi, tid, kBlock);
+    if (NOISE && !LDSTAB) __syncthreads();
+    const ZigLds zig{s_ki, s_wi, s_fi};
     if (LDSTAB) {
         // Stage the shared MDP into LDS: a few hundred bytes for 8x8 (P 64 B + flags 8 B +
         // reward bitmask 64 B + cdf 64 B).
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (phase != 0) bit = 0;                                            // D6
                 if (NOISE && a.has_r_noise) {
                     double r = bit ? 1.0 : 0.0;
-                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal(env_phx) : np_standard_normal(env_pcg));
+                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
                     r *= a.scale;
                     r += a.shift;
                     if (done) r += a.term_add;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 double r = (key != kNoKey) ? t.rtable[key] : 0.0;
                 if (phase != 0) r = 0.0;
                 if (NOISE && a.has_r_noise)
-                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal(env_phx) : np_standard_normal(env_pcg));
+                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
                 r *= a.scale;
                 r += a.shift;
                 if (done) r += a.term_add;

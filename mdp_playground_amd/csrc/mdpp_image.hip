@@ -2,9 +2,9 @@
 // /root/reference/mdp_playground/spaces/image_multi_discrete.py:129-288, called from
 // rl_toy_env.py:2095-2096 (step) and :2347-2350 (reset).
 //
-// One workgroup per env image.  Thread 0 draws the transform variates from the env's image-space
+// One wavefront per env image.  The wave draws the transform variates from the env's image-space
 // PCG64 stream in the reference's order (scale: random(); shift: integers() x2; rotate:
-// integers(360); flip: integers(2) [+ integers(2)]), the block then writes the uint8[W][H][1]
+// integers(360); flip: integers(2) [+ integers(2)]) and then writes the uint8[W][H][1]
 // observation with one dword (4 pixels) per lane per store.  A pixel is produced by walking the
 // reference's pipeline backwards:  obs[x][y] = final[y][x]  (the .T at :264-266)
 //   final = flip(rot)                                   (:257-262)
@@ -67,51 +67,77 @@ __device__ Xform draw_xform(const ImageArgs &a, Pcg64 &g, Half32 &h) {
     return x;
 }
 
-__device__ __forceinline__ uint32_t pixel(const ImageArgs &a, const Xform &t, const uint8_t *tp,
-                                          const int32_t *rc, int x, int y) {
-    // obs[x][y] = final[y][x]; undo the flip
-    int fx = (t.flip == 1) ? a.W - 1 - x : x;
-    int fy = (t.flip == 2) ? a.H - 1 - y : y;
-    int xs, ys;
-    if (t.angle == 0) { xs = fx; ys = fy; }
-    else if (t.angle == 180) { xs = a.W - 1 - fx; ys = a.H - 1 - fy; }
-    else if (t.angle == 90 && a.W == a.H) { xs = a.W - 1 - fy; ys = fx; }
-    else if (t.angle == 270 && a.W == a.H) { xs = fy; ys = a.H - 1 - fx; }
-    else {
-        xs = (rc[2] + rc[0] * fx + rc[1] * fy) >> 16;
-        ys = (rc[5] + rc[3] * fx + rc[4] * fy) >> 16;
-        if (xs < 0 || xs >= a.W || ys < 0 || ys >= a.H) return 0;
-    }
-    const int half = a.tpl / 2;
-    int tx = xs - t.cx + half, ty = ys - t.cy + half;
-    if (tx < 0 || tx >= a.tpl || ty < 0 || ty >= a.tpl) return 0;
-    return tp[ty * a.tpl + tx];
-}
-
-__device__ void render(const ImageArgs &a, const Xform &t, int state, uint8_t *lds_tpl,
-                       uint8_t *__restrict__ out) {
-    const int tid = threadIdx.x;
+// One wavefront per env image (4 images per 256-thread workgroup): no workgroup barrier, the
+// transform draw is done redundantly by all 64 lanes from wave-uniform addresses (same cost as
+// one lane), the template is staged into the wave's own slice of LDS.
+//
+// The whole final->source pixel map (transpose, flip, rotation) is ONE integer affine map per
+// image: the host table holds Pillow's 16.16 coefficients for every angle (exact integer rows for
+// 0/90/180/270 on square images, where Pillow transposes instead), the flip is folded into them
+// here.  Pixels outside the polygon's bounding circle (about 3/4 of an 84x84 image at R = 20) are
+// written as zeros without evaluating the map.
+__device__ __forceinline__ void render(const ImageArgs &a, const Xform &t, int state, uint8_t *lds_tpl,
+                                       uint8_t *__restrict__ out, int lane) {
     const int ri = t.R - a.r_min;
     const size_t sr = (size_t)state * a.n_radii + ri;
     const int cx_cls = a.cls_x[sr * a.W + t.cx], cy_cls = a.cls_y[sr * a.H + t.cy];
-    const uint8_t *gt = a.tpl_data + ((sr * a.n_cls_x + cx_cls) * a.n_cls_y + cy_cls) * (size_t)(a.tpl * a.tpl);
-    __syncthreads(); // previous render (if any) is done with lds_tpl
-    for (int k = tid; k < a.tpl * a.tpl; k += blockDim.x) lds_tpl[k] = gt[k];
-    __syncthreads();
-    const int32_t *rc = a.rot + t.angle * 6;
-    const int total = a.W * a.H;
-    for (int p0 = tid * 4; p0 < total; p0 += blockDim.x * 4) {
-        uint32_t word = 0;
+    const int tsz = a.tpl * a.tpl;
+    const uint8_t *gt = a.tpl_data + ((sr * a.n_cls_x + cx_cls) * a.n_cls_y + cy_cls) * (size_t)tsz;
+    // template -> this wave's LDS slice (wave-local: LDS ops of one wave complete in order)
+    for (int k = lane * 4; k < tsz; k += 64 * 4) {
+        uint32_t w = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            int p = p0 + b;
-            if (p < total) {
-                int x = p / a.H, y = p - x * a.H;
-                word |= pixel(a, t, lds_tpl, rc, x, y) << (8 * b);
+        for (int b = 0; b < 4; b++) if (k + b < tsz) w |= (uint32_t)gt[k + b] << (8 * b);
+        *(uint32_t *)(lds_tpl + k) = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // source = A * (fx, fy) + b in 16.16, with (fx, fy) = flip(x, y) folded in
+    int a0 = a.rot[t.angle * 6 + 0], a1 = a.rot[t.angle * 6 + 1], a2 = a.rot[t.angle * 6 + 2];
+    int a3 = a.rot[t.angle * 6 + 3], a4 = a.rot[t.angle * 6 + 4], a5 = a.rot[t.angle * 6 + 5];
+    if (t.flip == 1) { a2 += a0 * (a.W - 1); a5 += a3 * (a.W - 1); a0 = -a0; a3 = -a3; }
+    if (t.flip == 2) { a2 += a1 * (a.H - 1); a5 += a4 * (a.H - 1); a1 = -a1; a4 = -a4; }
+    // centre of the polygon in final-image coordinates: invert the 2x2 part (a rotation, so the
+    // inverse is the transpose up to the 16.16 scale); one pixel of slack covers the rounding
+    const float fa0 = a0 * (1.0f / 65536.0f), fa1 = a1 * (1.0f / 65536.0f);
+    const float fa3 = a3 * (1.0f / 65536.0f), fa4 = a4 * (1.0f / 65536.0f);
+    const float sx = (float)t.cx + 0.5f - a2 * (1.0f / 65536.0f), sy = (float)t.cy + 0.5f - a5 * (1.0f / 65536.0f);
+    const float det = fa0 * fa4 - fa1 * fa3;
+    const float fcx = (fa4 * sx - fa1 * sy) / det, fcy = (fa0 * sy - fa3 * sx) / det;
+    const float rad = (float)t.R + 3.0f, rad2 = rad * rad;
+    const int half = a.tpl / 2, ox = t.cx - half, oy = t.cy - half;
+    const int total = a.W * a.H;
+    auto pixel = [&](int x, int y) -> uint32_t {
+        const int xs = (a2 + a0 * x + a1 * y) >> 16, ys = (a5 + a3 * x + a4 * y) >> 16;
+        const uint32_t tx = (uint32_t)(xs - ox), ty = (uint32_t)(ys - oy);
+        const bool in = (uint32_t)xs < (uint32_t)a.W && (uint32_t)ys < (uint32_t)a.H &&
+                        tx < (uint32_t)a.tpl && ty < (uint32_t)a.tpl;
+        return in ? (uint32_t)lds_tpl[in ? ty * a.tpl + tx : 0] : 0u;
+    };
+    if ((a.H & 3) == 0) {
+        // dword q covers pixels (x, 4*yq .. 4*yq+3); q advances by 64 per iteration, carried in
+        // (x, yq) without a division per dword
+        const int HQ = a.H >> 2, nq = total >> 2;
+        int x = lane / HQ, yq = lane - x * HQ;
+        const int dx = 64 / HQ, dy = 64 - dx * HQ;
+        for (int q = lane; q < nq; q += 64) {
+            uint32_t word = 0;
+            const float ddx = (float)x - fcx, ddy = (float)(4 * yq) + 1.5f - fcy;
+            const bool near = ddx * ddx + ddy * ddy <= rad2 + 3.0f * rad + 2.25f; // any of the 4 pixels within rad
+            if (__builtin_amdgcn_ballot_w64(near) != 0) {
+                if (near) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) word |= pixel(x, 4 * yq + b) << (8 * b);
+                }
             }
+            *(uint32_t *)(out + 4 * (size_t)q) = word;
+            x += dx; yq += dy;
+            if (yq >= HQ) { yq -= HQ; x += 1; }
         }
-        if (p0 + 3 < total) *(uint32_t *)(out + p0) = word;
-        else for (int b = 0; p0 + b < total; b++) out[p0 + b] = (uint8_t)(word >> (8 * b));
+    } else {
+        for (int p = lane; p < total; p += 64) {
+            int x = p / a.H, y = p - x * a.H;
+            out[p] = (uint8_t)pixel(x, y);
+        }
     }
 }
 
@@ -125,28 +151,33 @@ __global__ __launch_bounds__(kBlock) void k_image_obs(ImageArgs a, const int32_t
                                                       const uint8_t *__restrict__ mask,
                                                       uint8_t *__restrict__ img_out,
                                                       uint8_t *__restrict__ img_final) {
-    extern __shared__ __align__(16) uint8_t lds_tpl[];
-    __shared__ Xform xf[2];
-    const int i = blockIdx.x;
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slice = (a.tpl * a.tpl + 15) & ~15;
+    // wave-uniform env index (readfirstlane makes the uniformity visible to the compiler, so the
+    // stream state and the transform live in SGPRs)
+    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wave);
+    if (i >= a.N) return;
     if (mask && !mask[i]) return;
+    uint8_t *lds_tpl = lds_all + wave * slice;
     const bool two = a.autoreset && term && (term[i] | trunc[i]);
-    if (threadIdx.x == 0) {
-        Pcg64 g;
-        g.load(a.rng_s, a.rng_inc, i);
-        uint2 hh = a.rng_half[i];
-        Half32 h{hh.x, hh.y};
-        xf[0] = draw_xform(a, g, h);
-        if (two) xf[1] = draw_xform(a, g, h);
+    Pcg64 g;
+    g.load(a.rng_s, a.rng_inc, i);
+    const uint2 hh = a.rng_half[i];
+    Half32 h{hh.x, hh.y};
+    const Xform x0 = draw_xform(a, g, h);
+    Xform x1 = x0;
+    if (two) x1 = draw_xform(a, g, h);
+    if (lane == 0) {
         g.store(a.rng_s, i);
         a.rng_half[i] = make_uint2(h.has32, h.u32);
     }
-    __syncthreads();
     const size_t isz = (size_t)a.W * a.H;
     if (two) {
-        if (img_final) render(a, xf[0], state_final[i], lds_tpl, img_final + (size_t)i * isz);
-        render(a, xf[1], state_out[i], lds_tpl, img_out + (size_t)i * isz);
+        if (img_final) render(a, x0, state_final[i], lds_tpl, img_final + (size_t)i * isz, lane);
+        render(a, x1, state_out[i], lds_tpl, img_out + (size_t)i * isz, lane);
     } else {
-        render(a, xf[0], state_out[i], lds_tpl, img_out + (size_t)i * isz);
+        render(a, x0, state_out[i], lds_tpl, img_out + (size_t)i * isz, lane);
     }
 }
 
@@ -168,9 +199,11 @@ int launch_image_obs(mdpp_env *h, const int32_t *state_out, const int32_t *state
     a.rng_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_IMAGE];
     a.rng_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_IMAGE];
     a.rng_half = (uint2 *)h->d_rng_half;
-    const size_t lds = ((size_t)a.tpl * a.tpl + 15) & ~(size_t)15;
-    hipLaunchKernelGGL(k_image_obs, dim3(a.N), dim3(kBlock), lds, s, a, state_out, state_final, term,
-                       trunc, mask, img_out, img_final);
+    const int per_block = kBlock / 64;
+    const size_t lds = (size_t)per_block * (((size_t)a.tpl * a.tpl + 15) & ~(size_t)15);
+    if (lds > 64 * 1024) { h->err = "k_image_obs: polygon template too large for LDS"; return MDPP_EUNSUPPORTED; }
+    hipLaunchKernelGGL(k_image_obs, dim3((a.N + per_block - 1) / per_block), dim3(kBlock), lds, s, a,
+                       state_out, state_final, term, trunc, mask, img_out, img_final);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_image_obs launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     return MDPP_OK;

@@ -76,6 +76,12 @@ struct ContinuousArgs {
     uint32_t *ring;             // [delay][N] float32 bit patterns (kRingPyZero = Python 0.0)
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
     uint32_t *status;
+    // ---- precomputed on the host for the fused fast path (mdpp_continuous_fast.hip) ----
+    uint32_t fast_ok;           // PCG64, no hypercubes, relevant dims = a prefix, bounded, delay 0, every_n 1
+    uint32_t inertia_pow2;      // inertia is a power of two: a / inertia == a * inv_inertia32 exactly
+    float inv_inertia32;
+    uint32_t fact_pow2_mask;    // bit k: k! is a power of two (k = 1, 2)
+    double inv_fact[MDPP_MAX_ORDER + 1];
 };
 
 } // namespace mdpp
@@ -112,6 +118,8 @@ bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, 
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);
+bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
 int launch_image_obs(mdpp_env *h, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s);

@@ -120,6 +120,93 @@ __device__ __noinline__ double np_standard_normal(G &g) {
     }
 }
 
+// The same loop entered with the first 64-bit draw `r` already made and already known to have
+// failed the fast accept (callers inline the 98.8 % case and come here for the wedge / tail).
+template <class G>
+__device__ __noinline__ double np_standard_normal_resume(G &g, uint64_t r) {
+    const double nor_r = 3.6541528853610087963519472518;
+    const double nor_inv_r = 0.27366123732975827203338247596;
+    for (;;) {
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 0x1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * d_zig_wi[idx];
+        if (sign) x = -x;
+        if (rabs < d_zig_ki[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -nor_inv_r * log1p(-np_random(g));
+                double yy = -log1p(-np_random(g));
+                if (yy + yy > xx * xx)
+                    return ((rabs >> 8) & 0x1) ? -(nor_r + xx) : nor_r + xx;
+            }
+        } else {
+            if (((d_zig_fi[idx - 1] - d_zig_fi[idx]) * np_random(g) + d_zig_fi[idx]) <
+                exp(-0.5 * x * x))
+                return x;
+        }
+        r = g.next64();
+    }
+}
+
+// Ziggurat tables staged in LDS (6 KiB): with one wavefront per SIMD a table lookup in global
+// memory costs a full L2 round trip per normal.
+struct ZigLds {
+    const uint64_t *ki;
+    const double *wi, *fi;
+};
+__device__ __forceinline__ void zig_stage(uint64_t *ki, double *wi, double *fi, int tid, int nthreads) {
+    for (int k = tid; k < 256; k += nthreads) { ki[k] = d_zig_ki[k]; wi[k] = d_zig_wi[k]; fi[k] = d_zig_fi[k]; }
+}
+
+// Tail of the ziggurat (layer 0, |x| > 3.654): ~0.03 % of draws, out of line.
+template <class G>
+__device__ __noinline__ double np_zig_tail(G &g, uint64_t rabs) {
+    const double nor_r = 3.6541528853610087963519472518;
+    const double nor_inv_r = 0.27366123732975827203338247596;
+    for (;;) {
+        double xx = -nor_inv_r * log1p(-np_random(g));
+        double yy = -log1p(-np_random(g));
+        if (yy + yy > xx * xx)
+            return ((rabs >> 8) & 0x1) ? -(nor_r + xx) : nor_r + xx;
+    }
+}
+
+// random_standard_normal with the accept (98.8 %) inline, the wedge test inline under a
+// wave-uniform branch (some lane of a wave needs it for about half of all draws, so it must not
+// be a function call), and only the tail out of line.  Draw order per lane is numpy's.
+template <class G>
+__device__ __forceinline__ double np_standard_normal_lds(G &g, const ZigLds &z) {
+    uint64_t r = g.next64();
+    int idx = (int)(r & 0xff);
+    uint64_t rabs = (r >> 9) & 0x000fffffffffffffULL;
+    double x = (double)rabs * z.wi[idx];
+    x = ((r >> 8) & 1) ? -x : x;
+    bool pending = !(rabs < z.ki[idx]);
+    while (__builtin_amdgcn_ballot_w64(pending) != 0) {
+        if (pending) {
+            if (idx == 0) {
+                x = np_zig_tail(g, rabs);
+                pending = false;
+            } else {
+                const double u = np_random(g);
+                if (((z.fi[idx - 1] - z.fi[idx]) * u + z.fi[idx]) < exp(-0.5 * x * x)) {
+                    pending = false;
+                } else {
+                    r = g.next64();
+                    idx = (int)(r & 0xff);
+                    rabs = (r >> 9) & 0x000fffffffffffffULL;
+                    x = (double)rabs * z.wi[idx];
+                    x = ((r >> 8) & 1) ? -x : x;
+                    pending = !(rabs < z.ki[idx]);
+                }
+            }
+        }
+    }
+    return x;
+}
+
 // Generator.integers(low, high) for ranges that fit 32 bits: buffered_bounded_lemire_uint32
 template <class G>
 __device__ __forceinline__ int np_integers(G &g, Half32 &h, int low, int high) {

@@ -1,0 +1,66 @@
+// Micro-benchmark of the RNG building blocks at the bench occupancy (one wave per SIMD).
+// hipcc --offload-arch=gfx950 -O3 -I mdp_playground_amd/csrc tools/bench_rng.hip -o gpurun_out/bench_rng
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "mdpp_rng.hpp"
+using namespace mdpp;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
+    __shared__ uint64_t s_ki[256];
+    __shared__ double s_wi[256], s_fi[256];
+    zig_stage(s_ki, s_wi, s_fi, threadIdx.x, 256);
+    __syncthreads();
+    ZigLds zig{s_ki, s_wi, s_fi};
+    Pcg64 g;
+    g.s_lo = threadIdx.x * 7919u + blockIdx.x; g.s_hi = 12345; g.inc_lo = 2 * threadIdx.x + 1; g.inc_hi = 99;
+    double acc = 0; uint64_t x = 0;
+    for (int i = 0; i < iters; i++) {
+        if (MODE == 0) x ^= g.next64();
+        if (MODE == 1) acc += np_random(g);
+        if (MODE == 2) acc += np_standard_normal_lds(g, zig);
+        if (MODE == 3) acc += np_standard_normal(g);
+        if (MODE == 6) { // ziggurat hot path only (rejections ignored)
+            uint64_t r = g.next64(); int idx = (int)(r & 0xff);
+            uint64_t rabs = (r >> 9) & 0x000fffffffffffffULL;
+            double xx = (double)rabs * zig.wi[idx]; xx = ((r >> 8) & 1) ? -xx : xx;
+            acc += (rabs < zig.ki[idx]) ? xx : 0.0;
+        }
+        if (MODE == 7) { // hot path + the extra uniform of the wedge under the ballot branch, no exp
+            uint64_t r = g.next64(); int idx = (int)(r & 0xff);
+            uint64_t rabs = (r >> 9) & 0x000fffffffffffffULL;
+            double xx = (double)rabs * zig.wi[idx]; xx = ((r >> 8) & 1) ? -xx : xx;
+            bool pend = !(rabs < zig.ki[idx]);
+            if (__builtin_amdgcn_ballot_w64(pend) != 0) { if (pend) xx += np_random(g) * zig.fi[idx]; }
+            acc += xx;
+        }
+        if (MODE == 4) { x = x * 6364136223846793005ULL + 1442695040888963407ULL; }
+        if (MODE == 5) { acc = acc * 1.0000001 + 0.5; }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x + (uint64_t)acc;
+}
+
+template <int MODE>
+void run(const char *name, uint64_t *d, int iters) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, d, iters);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256), 0, 0, d, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("%-28s %8.1f ns per call per wave\n", name, ms * 1e6 / iters);
+}
+
+int main() {
+    uint64_t *d; hipMalloc(&d, 65536 * 8);
+    int iters = 20000;
+    run<4>("u64 mul-add (LCG64)", d, iters);
+    run<5>("f64 fma chain", d, iters);
+    run<0>("pcg64 next64", d, iters);
+    run<1>("np_random (uniform double)", d, iters);
+    run<2>("standard_normal (LDS tables)", d, iters);
+    run<3>("standard_normal (global tbl)", d, iters);
+    run<6>("ziggurat hot path only", d, iters);
+    run<7>("hot + wedge uniform, no exp", d, iters);
+    return 0;
+}
