@@ -386,3 +386,96 @@ def test_image_observations_vs_reference_golden(name):
         assert np.array_equal(fin[d], g["obs"][:, t][d]), (name, t)          # terminal obs
         assert np.array_equal(obs[d], g["reset_obs"][:, t][d]), (name, t)    # first obs of next episode
     env.close()
+
+
+# ----------------------------------------------------------------------------- BASELINE full sizes
+def _cfg(name, seed):
+    return dict(gu.CASES[name]["config"], seed=seed)
+
+
+@pytest.mark.parametrize("name,N", [("d_cfg2", 65536), ("c_cfg3", 65536), ("c_cfg5", 65536)])
+def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
+    """At BASELINE's 65 536 envs the oracle cannot replay everything in seconds, so check
+    size-independent properties: (1) one fused K-step launch == K single-step launches bit for
+    bit (two different launch shapes of the same arithmetic), (2) a strided sample of envs ==
+    the oracle, (3) state export -> import -> continue reproduces the continuation."""
+    cfg = _cfg(name, 17)
+    T = 24
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    rng = np.random.default_rng(0)
+    if a.kind == "discrete":
+        acts = torch.as_tensor(rng.integers(0, 8, size=(T, N)).astype(np.int32), device=a.device)
+    else:
+        acts = torch.as_tensor(rng.uniform(-1, 1, size=(T, N, 12)).astype(np.float32), device=a.device)
+    init = a._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = a.rollout(acts)
+    for t in range(T):
+        o, r, te, tr, _ = b.step(acts[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(te, term[t]), (name, t)
+    # (2) oracle on a sample
+    obs_h, rew_h, term_h = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    acts_h = acts.cpu().numpy()
+    for i in range(0, N, 4099):
+        o = _oracle_for(a, i)
+        o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i])
+        s0 = o.reset()
+        assert np.array_equal(np.asarray(s0), init[i])
+        eo, er, ed, ero = o.rollout(acts_h[:, i], None)
+        eo[ed] = ero[ed]
+        assert np.array_equal(obs_h[:, i], eo) and np.array_equal(term_h[:, i], ed), (name, i)
+        assert np.array_equal(rew_h[:, i], er.astype(np.float32)), (name, i)
+    # (3) checkpoint round trip: b's state + streams into a fresh env, both continue identically
+    c = _venv(num_envs=N, autoreset="same_step", **cfg)
+    c.set_augmented_state(b.get_augmented_state())
+    for s in (0, 1):
+        c._put_stream(s, b.get_rng_streams(s))
+    o1, r1, t1, _ = b.rollout(acts[:8])
+    o2, r2, t2, _ = c.rollout(acts[:8])
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2)
+    for e in (a, b, c):
+        e.close()
+
+
+def test_edge_shapes_and_errors():
+    cfg = _cfg("d_cfg2", 1)
+    # ragged sizes: 1 env, and a batch that is not a multiple of the wave or block size
+    for N in (1, 63, 257):
+        env = _venv(num_envs=N, autoreset="same_step", **cfg)
+        acts = torch.randint(0, 8, (5, N), device=env.device, dtype=torch.int32)
+        obs, rew, term, trunc = env.rollout(acts)
+        assert obs.shape == (5, N) and int(obs.max()) < 8
+        env.close()
+    env = _venv(num_envs=64, autoreset="disabled", **cfg)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(65, dtype=torch.int32, device=env.device))       # wrong batch size
+    # out-of-range discrete action: the reference raises IndexError per env; here it is flagged
+    a = torch.zeros(64, dtype=torch.int32, device=env.device)
+    a[3] = 8
+    a[5] = -1            # numpy negative indexing is legal in the reference: last action
+    env.step(a)
+    st = env.status()
+    assert st[3] == 1 and st.sum() == 1
+    assert env.status().sum() == 0                                              # cleared by the read
+    env.close()
+    # continuous: wrong dtype is an error, out-of-box action means "stay" (:1671) + status bit
+    ccfg = _cfg("c_cfg3", 2)
+    env = _venv(num_envs=32, autoreset="disabled", **ccfg)
+    with pytest.raises(TypeError):
+        env.step(torch.zeros((32, 12), dtype=torch.float64, device=env.device))
+    before = env._obs.clone()
+    a = torch.zeros((32, 12), dtype=torch.float32, device=env.device)
+    a[7, 2] = 1.5
+    obs, *_ = env.step(a)
+    assert torch.equal(obs[7], before[7]) and env.status()[7] == 1
+    env.close()
+    # truncation (RLToyFiniteHorizon-v0 semantics)
+    from mdp_playground_amd import make_vec
+    env = make_vec("RLToyVecFiniteHorizon-v0", num_envs=16, autoreset="same_step", max_episode_steps=3,
+                   **dict(cfg, terminal_state_density=0.0))
+    flags = []
+    for _ in range(7):
+        _, _, te, tr, _ = env.step(torch.zeros(16, dtype=torch.int32, device=env.device))
+        flags.append((bool(te.any()), bool(tr.all())))
+    assert flags == [(False, False), (False, False), (False, True)] * 2 + [(False, False)]
+    env.close()
