@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/sec of the batched RLToyEnv.step() hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 4096 --warmup 512
+    python bench.py --gpus 1 --steps 8192 --warmup 1024
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -130,9 +130,9 @@ def cpu_baseline(wl, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
-    ap.add_argument("--warmup", type=int, default=512)
-    ap.add_argument("--fuse", type=int, default=128, help="env steps per fused launch (mdpp_step_n)")
+    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--warmup", type=int, default=1024)
+    ap.add_argument("--fuse", type=int, default=512, help="env steps per fused launch (mdpp_step_n)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU")
     ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"])

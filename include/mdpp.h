@@ -49,8 +49,10 @@ enum { MDPP_STREAM_ENV = 0,        /* RLToyEnv._np_random: reset draw, reward no
        MDPP_STREAM_IMAGE = 2,      /* observation_space (ImageMultiDiscrete transforms) */
        MDPP_NUM_STREAMS = 3 };
 /* per-env status bits (mdpp_status) */
-enum { MDPP_STATUS_BAD_ACTION = 1u };   /* discrete: action out of range (reference: IndexError);
+enum { MDPP_STATUS_BAD_ACTION = 1u,     /* discrete: action out of range (reference: IndexError);
                                            continuous: action rejected by Box.contains -> "stay" (:1671) */
+       MDPP_STATUS_RESET_GAVE_UP = 2u,  /* continuous reset(): 4096 draws all fell into terminal hypercubes */
+       MDPP_STATUS_INTERNAL = 0x80000000u }; /* a bounded in-kernel wait expired (never expected) */
 
 typedef struct mdpp_env mdpp_env;
 

@@ -13,7 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libmdpp_hip.so")
-SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_fast.hip", "mdpp_continuous.hip",
+SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_fast.hip", "mdpp_discrete_pipe.hip",
+           "mdpp_continuous.hip",
            "mdpp_continuous_fast.hip", "mdpp_image.hip"]
 HEADERS = ["mdpp_internal.hpp", "mdpp_rng.hpp", "np_ziggurat_tables.inc",
            os.path.join("..", "..", "include", "mdpp.h")]

@@ -307,9 +307,12 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
             const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
             const size_t off = (size_t)k0 * a.N;
             a.tick = h->tick + (uint32_t)k0;
-            launch_discrete_fast(a, kc, actions + off, (char *)obs + off * osz, reward + off,
-                                 term + off, trunc + off,
-                                 final_obs ? (void *)((char *)final_obs + off * osz) : nullptr, s);
+            void *fo = final_obs ? (void *)((char *)final_obs + off * osz) : nullptr;
+            // long rollouts of full blocks: three-role pipelined kernel (mdpp_discrete_pipe.hip)
+            if (!launch_discrete_pipe(a, kc, actions + off, (char *)obs + off * osz, reward + off,
+                                      term + off, trunc + off, fo, s))
+                launch_discrete_fast(a, kc, actions + off, (char *)obs + off * osz, reward + off,
+                                     term + off, trunc + off, fo, s);
             k0 += kc;
         }
     } else if (a.philox) {

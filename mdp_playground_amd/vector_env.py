@@ -222,6 +222,15 @@ class RLToyVectorEnv:
         self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.observation_space = self.single_observation_space
         self.action_space = self.single_action_space
+        # everything step() passes on every call, prepared once (the call itself is the hot path)
+        self._mdpp_step = self._lib.mdpp_step
+        self._p_obs, self._p_final = self._obs.data_ptr(), self._final_obs.data_ptr()
+        self._p_reward, self._p_term, self._p_trunc = (self._reward.data_ptr(), self._term.data_ptr(),
+                                                        self._trunc.data_ptr())
+        self._term_b, self._trunc_b = self._term.view(torch.bool), self._trunc.view(torch.bool)
+        self._info = {"final_obs": self._final_obs} if self.autoreset == "same_step" else {}
+        self._act_dtype = torch.int32 if self.kind == "discrete" else torch.float32
+        self._act_shape = torch.Size((N,) if self.kind == "discrete" else (N, self.mdps[0].D))
 
     def _obs_shape(self, *lead):
         if self.kind == "continuous":
@@ -303,14 +312,15 @@ class RLToyVectorEnv:
     def step(self, actions):
         """step(actions) -> (obs, reward, terminated, truncated, info), rl_toy_env.py:1992.
         Returned tensors alias preallocated device buffers (valid until the next call)."""
-        a = self._as_actions(actions, None)
-        rc = self._lib.mdpp_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
-                                 C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._term.data_ptr()),
-                                 C.c_void_p(self._trunc.data_ptr()),
-                                 C.c_void_p(self._final_obs.data_ptr()), self._stream())
-        capi.check(self._lib, self._h, rc, "mdpp_step")
-        info = {"final_obs": self._final_obs} if self.autoreset == "same_step" else {}
-        return self._obs, self._reward, self._term.view(torch.bool), self._trunc.view(torch.bool), info
+        a = actions
+        if not (torch.is_tensor(a) and a.dtype == self._act_dtype and a.device == self.device
+                and a.shape == self._act_shape and a.is_contiguous()):
+            a = self._as_actions(actions, None)
+        rc = self._mdpp_step(self._h, a.data_ptr(), self._p_obs, self._p_reward, self._p_term,
+                             self._p_trunc, self._p_final, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            capi.check(self._lib, self._h, rc, "mdpp_step")
+        return self._obs, self._reward, self._term_b, self._trunc_b, self._info
 
     def rollout(self, actions, out=None):
         """K fused steps in ONE kernel launch (per-env state stays in registers).
