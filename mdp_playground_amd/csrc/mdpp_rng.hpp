@@ -93,7 +93,7 @@ __device__ __forceinline__ double np_random(G &g) { // Generator.random()
 
 // random_standard_normal: 256-layer ziggurat
 template <class G>
-__device__ __noinline__ double np_standard_normal(G &g) {
+__device__ __forceinline__ double np_standard_normal(G &g) {
     const double nor_r = 3.6541528853610087963519472518;
     const double nor_inv_r = 0.27366123732975827203338247596;
     for (;;) {
@@ -123,7 +123,7 @@ __device__ __noinline__ double np_standard_normal(G &g) {
 // The same loop entered with the first 64-bit draw `r` already made and already known to have
 // failed the fast accept (callers inline the 98.8 % case and come here for the wedge / tail).
 template <class G>
-__device__ __noinline__ double np_standard_normal_resume(G &g, uint64_t r) {
+__device__ __forceinline__ double np_standard_normal_resume(G &g, uint64_t r) {
     const double nor_r = 3.6541528853610087963519472518;
     const double nor_inv_r = 0.27366123732975827203338247596;
     for (;;) {
@@ -160,9 +160,11 @@ __device__ __forceinline__ void zig_stage(uint64_t *ki, double *wi, double *fi, 
     for (int k = tid; k < 256; k += nthreads) { ki[k] = d_zig_ki[k]; wi[k] = d_zig_wi[k]; fi[k] = d_zig_fi[k]; }
 }
 
-// Tail of the ziggurat (layer 0, |x| > 3.654): ~0.03 % of draws, out of line.
+// Tail of the ziggurat (layer 0, |x| > 3.654): ~0.03 % of draws.  Deliberately NOT a real
+// function call: a generator passed by reference to an out-of-line function must live in
+// memory, and then every draw of the whole kernel goes through scratch (= HBM latency).
 template <class G>
-__device__ __noinline__ double np_zig_tail(G &g, uint64_t rabs) {
+__device__ __forceinline__ double np_zig_tail(G &g, uint64_t rabs) {
     const double nor_r = 3.6541528853610087963519472518;
     const double nor_inv_r = 0.27366123732975827203338247596;
     for (;;) {
@@ -173,38 +175,24 @@ __device__ __noinline__ double np_zig_tail(G &g, uint64_t rabs) {
     }
 }
 
-// random_standard_normal with the accept (98.8 %) inline, the wedge test inline under a
-// wave-uniform branch (some lane of a wave needs it for about half of all draws, so it must not
-// be a function call), and only the tail out of line.  Draw order per lane is numpy's.
+// random_standard_normal: numpy's loop verbatim with the tables in LDS.  Measured at one wave per
+// SIMD (tools/bench_rng.hip, profiles/r01_rng_microbench.txt) this plain form (412 ns per draw per
+// wave) beats both a wave-uniform restructuring of the wedge path and a chord/tangent pre-test
+// that avoids exp() (530-750 ns): the rejection branches are short and rarely re-entered.
 template <class G>
 __device__ __forceinline__ double np_standard_normal_lds(G &g, const ZigLds &z) {
-    uint64_t r = g.next64();
-    int idx = (int)(r & 0xff);
-    uint64_t rabs = (r >> 9) & 0x000fffffffffffffULL;
-    double x = (double)rabs * z.wi[idx];
-    x = ((r >> 8) & 1) ? -x : x;
-    bool pending = !(rabs < z.ki[idx]);
-    while (__builtin_amdgcn_ballot_w64(pending) != 0) {
-        if (pending) {
-            if (idx == 0) {
-                x = np_zig_tail(g, rabs);
-                pending = false;
-            } else {
-                const double u = np_random(g);
-                if (((z.fi[idx - 1] - z.fi[idx]) * u + z.fi[idx]) < exp(-0.5 * x * x)) {
-                    pending = false;
-                } else {
-                    r = g.next64();
-                    idx = (int)(r & 0xff);
-                    rabs = (r >> 9) & 0x000fffffffffffffULL;
-                    x = (double)rabs * z.wi[idx];
-                    x = ((r >> 8) & 1) ? -x : x;
-                    pending = !(rabs < z.ki[idx]);
-                }
-            }
-        }
+    for (;;) {
+        uint64_t r = g.next64();
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 0x1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * z.wi[idx];
+        if (sign) x = -x;
+        if (rabs < z.ki[idx]) return x;
+        if (idx == 0) return np_zig_tail(g, rabs);
+        if (((z.fi[idx - 1] - z.fi[idx]) * np_random(g) + z.fi[idx]) < exp(-0.5 * x * x)) return x;
     }
-    return x;
 }
 
 // Generator.integers(low, high) for ranges that fit 32 bits: buffered_bounded_lemire_uint32

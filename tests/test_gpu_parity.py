@@ -479,3 +479,26 @@ def test_edge_shapes_and_errors():
         flags.append((bool(te.any()), bool(tr.all())))
     assert flags == [(False, False), (False, False), (False, True)] * 2 + [(False, False)]
     env.close()
+
+
+def test_device_normals_match_numpy_stream():
+    """The device ziggurat (chord/tangent pre-test + exp fallback) makes numpy's decisions: the
+    reward-noise stream of 4096 envs x 400 steps (1.6 M normals incl. wedge and tail cases) is
+    compared with numpy's Generator.normal on the same PCG64 states."""
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8,
+               action_space_size=8, delay=0, sequence_length=1, reward_noise=1.0,
+               terminal_state_density=0.0, reward_density=0.0, seed=5)
+    N, T = 4096, 400
+    env = _venv(num_envs=N, autoreset="disabled", **cfg)
+    acts = torch.zeros((T, N), dtype=torch.int32, device=env.device)
+    _, rew, _, _ = env.rollout(acts)
+    rew = rew.cpu().numpy()
+    from mdp_playground_amd import mdp as mdp_mod
+    for i in range(0, N, 97):
+        g = mdp_mod.new_generator(5 + i)
+        g.random()                       # the construction-time reset() draw
+        z = g.normal(0, 1.0, T)
+        # the (single) rewardable state may add 1.0 before the noise: reward = float32(bit + z)
+        ok = (rew[:, i] == z.astype(np.float32)) | (rew[:, i] == (1.0 + z).astype(np.float32))
+        assert ok.all(), (i, int((~ok).sum()))
+    env.close()
