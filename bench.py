@@ -10,8 +10,8 @@ sequence_length 3, 65 536 env instances per GPU sharing one MDP, uniform random 
 (synthetic, pre-generated on the device), same-step autoreset, numpy-exact PCG64 streams.
 A "step" is one env step of every instance of every rank.  Steps run as fused rollouts of
 --fuse steps per launch (mdpp_step_n); with N > 1 each launch is followed by ONE RCCL
-all-gather that assembles the global observation tensor on every rank (env ids are sharded
-contiguously, weak scaling).  The single-launch-per-step path (mdpp_step) is reported beside it.
+all-gather that assembles the current global observation tensor on every rank (env ids are
+sharded contiguously, weak scaling; the gather overlaps the next launch).  The single-launch-per-step path (mdpp_step) is reported beside it.
 
 Rank 0 prints ONE JSON line: the driver contract plus `roofline` and `cpu_baseline`.
 """
@@ -161,21 +161,46 @@ def main():
     env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
                          autoreset="same_step", **wl["config"])
     acts = make_actions(wl, F, N, device, 12345 + rank)
-    out = env.alloc_rollout(F)
-    gather = ObsGatherer(out[0], world, dist) if dist is not None else None
+    outs = [env.alloc_rollout(F), env.alloc_rollout(F)]     # alternate, so a gather can trail a launch
+    out = outs[0]
+    # The collective of the path: after every rollout launch ONE all-gather of the
+    # local CURRENT observation shard ([N_local, ...], 512 KiB per rank for cfg2) gives every rank
+    # the concatenated observation tensor of all world*N envs.  It runs on its own stream and
+    # overlaps the next launch; the per-step observations of a fused rollout stay on their rank.
+    gathers, comm, ev_done = None, None, [None, None]
+    if dist is not None:
+        gathers = [ObsGatherer(o[0][-1], world, dist) for o in outs]
+        comm = torch.cuda.Stream(device=device)
 
     def run(steps):
         left, launches = steps, 0
+        cur = torch.cuda.current_stream(device)
         while left > 0:
             k = min(F, left)
+            j = launches & 1
+            if gathers is not None and ev_done[j] is not None:
+                cur.wait_event(ev_done[j])          # the gather that read this buffer two launches ago
             if k == F:
-                env.rollout(acts, out)
+                env.rollout(acts, outs[j])
             else:
-                env.rollout(acts[:k], tuple(t[:k] for t in out))
-            if gather is not None:
-                gather()
+                env.rollout(acts[:k], tuple(t[:k] for t in outs[j]))
+            if gathers is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    if k == F:
+                        gathers[j]()
+                    else:
+                        gathers[j].local = outs[j][0][k - 1]
+                        gathers[j]()
+                        gathers[j].local = outs[j][0][-1]
+                    ev_done[j] = torch.cuda.Event()
+                    ev_done[j].record(comm)
             left -= k
             launches += 1
+        if comm is not None:
+            cur.wait_stream(comm)
         return launches
 
     def barrier():
@@ -185,16 +210,16 @@ def main():
 
     run(max(args.warmup, 1))
     barrier()
-    if gather is None:
+    if gathers is None:
         env.timer_begin()
     t0 = time.perf_counter()
     launches = run(args.steps)
-    if gather is None:
+    if gathers is None:
         kernel_ms = env.timer_end()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     barrier()
-    if gather is not None:
+    if gathers is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -267,7 +292,8 @@ def main():
                                    f"{N} env instances per GPU, random actions, same-step autoreset, "
                                    f"fused rollout of {F} steps per launch, rng={args.rng}",
                        "envs_per_gpu": N, "fuse": F,
-                       "collective": "all_gather(obs) per launch" if gather is not None else "none"},
+                       "collective": ("all_gather of the current observation shard after every launch, "
+                                      "overlapped on a side stream") if gathers is not None else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "single_step": single,
             "launches": launches, "elapsed_s": elapsed,
         }

@@ -24,7 +24,10 @@
 
 namespace mdpp {
 
-constexpr int kCAheadQuiet = 4, kCAheadNoise = 2; // fewer rows in flight where the RNG needs the registers
+#ifndef MDPP_CAHEAD
+#define MDPP_CAHEAD 4
+#endif
+constexpr int kCAheadQuiet = MDPP_CAHEAD, kCAheadNoise = 2; // fewer rows in flight where the RNG needs the registers
 constexpr int kCRsrc = 0x00020000;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -32,7 +35,7 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
     return pow2 ? x * inv : x / div;
 }
 
-template <int D, int ORDER, bool NOISE>
+template <int D, int ORDER, int NREL, bool NOISE>
 __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
@@ -87,14 +90,20 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
     auto norm_rel = [&](const float (&s)[D]) -> float {
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < D; j++) {
-            if (j < a.n_rel) {
-                float dd = s[j] - a.target[j];
-                float p = dd * dd;
-                acc += (double)p;
-            }
+        for (int j = 0; j < NREL; j++) {
+            float dd = s[j] - a.target[j];
+            float p = dd * dd;
+            acc += (double)p;
         }
         return sqrtf((float)acc);
+    };
+    // |x_d| <= bound for every d, false if any x_d is NaN: for non-negative floats the IEEE order
+    // is the unsigned order of the bit patterns (inf above every finite value, NaN above inf)
+    auto all_within = [&](const float (&v)[D], float bound) -> bool {
+        uint32_t m = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) m = max(m, __float_as_uint(v[d]) & 0x7FFFFFFFu);
+        return m <= __float_as_uint(bound);
     };
     auto normal = [&]() -> double { return np_standard_normal_lds(g, zig); };
 
@@ -124,39 +133,52 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
         const uint32_t so = (uint32_t)k * N;
         float nxt[D];
         // ---- C1: Box.contains(action)
-        bool ok = true;
-#pragma unroll
-        for (int d = 0; d < D; d++) ok = ok && (act[d] >= -amax) && (act[d] <= amax);
+        const bool ok = all_within(act, amax);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
-        // ---- C2 (computed for every lane, committed only where the action was admitted)
-        float nsd[ORDER + 1][D];
+        // ---- C2
+        auto integrate = [&](float (&v)[ORDER + 1][D]) {
+            if (inertia_pow2) {            // wave-uniform choices hoisted out of the per-dimension loops
 #pragma unroll
-        for (int kk = 0; kk <= ORDER; kk++)
+                for (int d = 0; d < D; d++) v[ORDER][d] = act[d] * inv_inertia;
+            } else {
 #pragma unroll
-            for (int d = 0; d < D; d++) nsd[kk][d] = sd[kk][d];
+                for (int d = 0; d < D; d++) v[ORDER][d] = act[d] / a.inertia32;
+            }
 #pragma unroll
-        for (int d = 0; d < D; d++) nsd[ORDER][d] = c_fdiv_or_mul(act[d], a.inertia32, inv_inertia, inertia_pow2);
+            for (int ii = 0; ii < ORDER; ii++) {
 #pragma unroll
-        for (int ii = 0; ii < ORDER; ii++) {
+                for (int j = 0; j < ORDER - ii; j++) {
+                    const float tp = a.tpow32[j + 1];
+                    if ((a.fact_pow2_mask >> (j + 1)) & 1u) {
+                        const double inv = a.inv_fact[j + 1];
 #pragma unroll
-            for (int j = 0; j < ORDER - ii; j++) {
-                const bool fp2 = (a.fact_pow2_mask >> (j + 1)) & 1u;
+                        for (int d = 0; d < D; d++) {
+                            float prod = v[ii + j + 1][d] * tp;
+                            v[ii][d] = (float)((double)v[ii][d] + (double)prod * inv);
+                        }
+                    } else {
+                        const double fct = a.fact[j + 1];
 #pragma unroll
-                for (int d = 0; d < D; d++) {
-                    float prod = nsd[ii + j + 1][d] * a.tpow32[j + 1];
-                    double trm = fp2 ? (double)prod * a.inv_fact[j + 1] : (double)prod / a.fact[j + 1];
-                    nsd[ii][d] = (float)((double)nsd[ii][d] + trm);
+                        for (int d = 0; d < D; d++) {
+                            float prod = v[ii + j + 1][d] * tp;
+                            v[ii][d] = (float)((double)v[ii][d] + (double)prod / fct);
+                        }
+                    }
                 }
             }
-        }
+        };
         if (__builtin_expect(all_ok, 1)) {
-#pragma unroll
-            for (int kk = 0; kk <= ORDER; kk++)
-#pragma unroll
-                for (int d = 0; d < D; d++) sd[kk][d] = nsd[kk][d];
+            integrate(sd);
 #pragma unroll
             for (int d = 0; d < D; d++) nxt[d] = sd[0][d];
         } else {
+            // some lane's action was rejected: integrate a copy, commit it only where admitted
+            float nsd[ORDER + 1][D];
+#pragma unroll
+            for (int kk = 0; kk <= ORDER; kk++)
+#pragma unroll
+                for (int d = 0; d < D; d++) nsd[kk][d] = sd[kk][d];
+            integrate(nsd);
             status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
 #pragma unroll
             for (int kk = 0; kk <= ORDER; kk++)
@@ -171,18 +193,14 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
             if (NOISE && a.has_p_noise) nxt[d] = (float)((double)nxt[d] + (0.0 + a.p_noise * normal()));
             else nxt[d] = nxt[d] + 0.0f;      // float32 += float64 zeros: only turns -0 into +0
         }
-        // ---- C4
-        bool inside = true;
-#pragma unroll
-        for (int d = 0; d < D; d++) inside = inside && (nxt[d] >= -smax) && (nxt[d] <= smax);
+        // ---- C4: one dimension outside the box clips the whole vector and zeroes every
+        // derivative (:1694-1717).  Clipping an in-range coordinate is the identity, so the clip is
+        // applied unconditionally (states are finite here: admitted actions and noise are finite and
+        // the box is bounded, so NaN handling of the reference's np.clip cannot come into play).
+        const bool inside = all_within(nxt, smax);
         if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
 #pragma unroll
-            for (int d = 0; d < D; d++) {
-                float x = nxt[d];
-                x = (x < -smax) ? -smax : x;
-                x = (x > smax) ? smax : x;
-                nxt[d] = inside ? nxt[d] : x;
-            }
+            for (int d = 0; d < D; d++) nxt[d] = __builtin_amdgcn_fmed3f(nxt[d], -smax, smax);
 #pragma unroll
             for (int kk = 0; kk <= ORDER; kk++)
 #pragma unroll
@@ -237,6 +255,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
             dist_prev = norm_rel(cur);
         }
         // ---- outputs
+#ifdef MDPP_ABL_NOSTORE
+        status ^= (__float_as_uint(cur[0]) + __float_as_uint(r) + (done ? 1 : 0) + (tr ? 1 : 0)) & 0x100u;
+        return;
+#endif
         if (D == 2) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[0]), __float_as_uint(cur[1])},
@@ -288,16 +310,16 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
     if (status) atomicOr(&a.status[i], status);
 }
 
-template <int D, int ORDER>
+template <int D, int ORDER, int NREL>
 static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.has_p_noise || a.has_r_noise)
-        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, true>), dim3(grid), dim3(kBlock), 0, s, a,
-                           K, actions, obs, reward, term, trunc, final_obs);
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true>), dim3(grid), dim3(kBlock), 0, s,
+                           a, K, actions, obs, reward, term, trunc, final_obs);
     else
-        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, false>), dim3(grid), dim3(kBlock), 0, s, a,
-                           K, actions, obs, reward, term, trunc, final_obs);
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false>), dim3(grid), dim3(kBlock), 0, s,
+                           a, K, actions, obs, reward, term, trunc, final_obs);
 }
 
 // Returns false when the shape does not qualify (caller falls back to k_continuous_step).
@@ -305,8 +327,9 @@ bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions
                             float *reward, uint8_t *term, uint8_t *trunc, float *final_obs,
                             hipStream_t s) {
     if (!a.fast_ok || getenv("MDPP_NO_CFAST")) return false;
-#define MDPP_CF(DD, OO) if (a.D == DD && a.order == OO) { launch_t<DD, OO>(a, K, actions, obs, reward, term, trunc, final_obs, s); return true; }
-    MDPP_CF(12, 1) MDPP_CF(12, 2) MDPP_CF(2, 1) MDPP_CF(2, 2) MDPP_CF(4, 1) MDPP_CF(4, 2) MDPP_CF(8, 1) MDPP_CF(8, 2)
+#define MDPP_CF(DD, OO, RR) if (a.D == DD && a.order == OO && a.n_rel == RR) { launch_t<DD, OO, RR>(a, K, actions, obs, reward, term, trunc, final_obs, s); return true; }
+    MDPP_CF(12, 1, 4) MDPP_CF(12, 2, 4) MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)
+    MDPP_CF(8, 1, 8) MDPP_CF(8, 2, 8) MDPP_CF(12, 1, 12) MDPP_CF(12, 2, 12)
 #undef MDPP_CF
     return false;
 }
