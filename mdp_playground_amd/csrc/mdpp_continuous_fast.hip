@@ -35,8 +35,18 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
     return pow2 ? x * inv : x / div;
 }
 
-template <int D, int ORDER, int NREL, bool NOISE>
-__global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
+// HELPER (noise only): 512-thread workgroups; waves 4-7 own the envs' PCG64 streams for the launch
+// and produce the D (+1) standard normals of every step into an LDS ring, waves 0-3 integrate and
+// read them back in the reference's draw order.  The numpy-exact ziggurat is ~3/4 of a noisy
+// step's instructions (profiles/r01_rng_microbench.txt) and one wave per SIMD leaves issue slots
+// idle, so running it beside the integrator nearly halves the step time.  Producer and consumer
+// count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
+constexpr int kNRing = 4;                      // steps of normals buffered per env
+constexpr uint32_t kCSpinLimit = 1u << 22;
+constexpr uint32_t kCStatusInternal = 0x80000000u;
+
+template <int D, int ORDER, int NREL, bool NOISE, bool HELPER>
+__global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
                                                                     float *__restrict__ reward,
@@ -46,15 +56,45 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
     static_assert(D % 4 == 0 || D == 2, "D must be 2 or a multiple of 4");
     __shared__ uint64_t s_ki[NOISE ? 256 : 1];
     __shared__ double s_wi[NOISE ? 256 : 1], s_fi[NOISE ? 256 : 1];
+    constexpr int NPS = D + 1;                  // normals per step slot (D transition + 1 reward)
+    __shared__ double s_z[HELPER ? kNRing * NPS * kBlock : 1];   // [slot][draw][lane]
+    __shared__ uint32_t s_prod[kBlock / 64], s_cons[kBlock / 64];
     const int tid = threadIdx.x;
-    if (NOISE) {
-        zig_stage(s_ki, s_wi, s_fi, tid, kBlock);
-        __syncthreads();
-    }
+    if (NOISE) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
+    if (HELPER && tid < kBlock / 64) { s_prod[tid] = 0; s_cons[tid] = 0; }
+    if (NOISE) __syncthreads();
     const ZigLds zig{s_ki, s_wi, s_fi};
-    const uint32_t i = blockIdx.x * kBlock + tid;
-    if (i >= (uint32_t)a.N) return;
+    const int ln = tid & (kBlock - 1), wv = ln >> 6;
+    const uint32_t i = blockIdx.x * kBlock + ln;
+    if (i >= (uint32_t)a.N) return;             // HELPER launches require N % kBlock == 0
     const uint32_t N = (uint32_t)a.N;
+    if (HELPER && tid >= kBlock) {
+        // ---------------- producer lane: the env's noise stream for this launch -----------------
+        Pcg64 hg;
+        hg.load(a.env_s, a.env_inc, i);
+        uint32_t hstatus = 0;
+        for (int k = 0; k < K; k++) {
+            if (k >= kNRing) {                  // wait until the consumer wave freed slot k % kNRing
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&s_cons[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                       (uint32_t)(k - kNRing + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kCSpinLimit) { hstatus |= kCStatusInternal; break; }
+                }
+            }
+            double *slot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
+            if (a.has_p_noise) {
+#pragma unroll
+                for (int d = 0; d < D; d++) slot[d * kBlock] = np_standard_normal_lds(hg, zig);
+            }
+            if (a.has_r_noise) slot[D * kBlock] = np_standard_normal_lds(hg, zig);
+            if ((ln & 63) == 0)
+                __hip_atomic_store(&s_prod[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        hg.store(a.env_s, i);
+        if (hstatus) atomicOr(&a.status[i], hstatus);
+        return;
+    }
     constexpr int kCAhead = NOISE ? kCAheadNoise : kCAheadQuiet;
     constexpr int V = (D == 2) ? 1 : D / 4;      // 16-byte pieces per action / observation row
 
@@ -69,7 +109,9 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
     uint32_t steps = meta.x, flags = meta.y, status = 0;
 
     Pcg64 g;
-    if (NOISE) g.load(a.env_s, a.env_inc, i);
+    if (NOISE && !HELPER) g.load(a.env_s, a.env_inc, i);
+    const double *zslot = s_z + ln;             // HELPER: this step's normals, set per step
+    int zi = 0;
 
     const uint32_t total = (uint32_t)K * N;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(D * 4), kCRsrc);
@@ -105,7 +147,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
         for (int d = 0; d < D; d++) m = max(m, __float_as_uint(v[d]) & 0x7FFFFFFFu);
         return m <= __float_as_uint(bound);
     };
-    auto normal = [&]() -> double { return np_standard_normal_lds(g, zig); };
+    auto normal = [&]() -> double {
+        if (HELPER) return zslot[(zi++) * kBlock];
+        return np_standard_normal_lds(g, zig);
+    };
 
     float dist_prev = norm_rel(cur);
 
@@ -132,6 +177,15 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
     auto step = [&](const float (&act)[D], int k) {
         const uint32_t so = (uint32_t)k * N;
         float nxt[D];
+        if (HELPER) {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&s_prod[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(k + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kCSpinLimit) { status |= kCStatusInternal; break; }
+            }
+            zslot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
+            zi = a.has_p_noise ? 0 : D;
+        }
         // ---- C1: Box.contains(action)
         const bool ok = all_within(act, amax);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
@@ -223,7 +277,12 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
             r = r - 0.0f;                       // alw * ||a|| == +0 exactly for an admitted action
         }
         // ---- C7 (delay 0, every step pays: the reward stays np.float32 throughout)
-        if (NOISE && a.has_r_noise) r = r + (float)(0.0 + a.r_noise * normal());
+        if (NOISE && a.has_r_noise) {
+            if (HELPER) zi = D;
+            r = r + (float)(0.0 + a.r_noise * normal());
+        }
+        if (HELPER && (ln & 63) == 0)   // this wave is done with the step's slot
+            __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         r = r * a.scale32;
         r = r + a.shift32;
         // ---- C8
@@ -306,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_rollout_fast(ContinuousAr
 #pragma unroll
     for (int d = 0; d < D; d++) a.cur[(size_t)d * N + i] = cur[d];
     a.meta[i] = make_uint2(steps, flags);
-    if (NOISE) g.store(a.env_s, i);
+    if (NOISE && !HELPER) g.store(a.env_s, i);
     if (status) atomicOr(&a.status[i], status);
 }
 
@@ -314,12 +373,20 @@ template <int D, int ORDER, int NREL>
 static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
     const int grid = (a.N + kBlock - 1) / kBlock;
-    if (a.has_p_noise || a.has_r_noise)
-        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true>), dim3(grid), dim3(kBlock), 0, s,
-                           a, K, actions, obs, reward, term, trunc, final_obs);
-    else
-        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false>), dim3(grid), dim3(kBlock), 0, s,
-                           a, K, actions, obs, reward, term, trunc, final_obs);
+    if (a.has_p_noise || a.has_r_noise) {
+        // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
+        constexpr bool can_help = (size_t)kNRing * (D + 1) * kBlock * 8 <= 120 * 1024;
+        const bool helper = can_help && K >= 16 && (a.N % kBlock) == 0 && !getenv("MDPP_NO_HELPER");
+        if (can_help && helper)
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help>), dim3(grid),
+                               dim3(2 * kBlock), 0, s, a, K, actions, obs, reward, term, trunc, final_obs);
+        else
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, false>), dim3(grid),
+                               dim3(kBlock), 0, s, a, K, actions, obs, reward, term, trunc, final_obs);
+    } else {
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false, false>), dim3(grid), dim3(kBlock),
+                           0, s, a, K, actions, obs, reward, term, trunc, final_obs);
+    }
 }
 
 // Returns false when the shape does not qualify (caller falls back to k_continuous_step).

@@ -502,3 +502,37 @@ def test_device_normals_match_numpy_stream():
         ok = (rew[:, i] == z.astype(np.float32)) | (rew[:, i] == (1.0 + z).astype(np.float32))
         assert ok.all(), (i, int((~ok).sum()))
     env.close()
+
+
+@pytest.mark.parametrize("name", ["c_cfg5", "c_cfg3"])
+def test_continuous_fast_kernel_shared_vs_oracle(name):
+    """BASELINE cfg 3 / cfg 5 shapes at 512 envs (full 256-env blocks, 40 fused steps): with noise
+    this runs the producer/consumer variant (helper waves draw the normals); every sampled env
+    must equal its oracle bit for bit, including the env stream's end state."""
+    cfg = _cfg(name, 23)
+    N, T = 512, 40
+    env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=11, **cfg)
+    rng = np.random.default_rng(6)
+    acts = rng.uniform(-1, 1, size=(T, N, 12)).astype(np.float32)
+    acts[7, 5, 3] = 2.0                      # one rejected action ("stay")
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs, rew, trunc = obs.cpu().numpy(), rew.cpu().numpy(), trunc.cpu().numpy()
+    end_env = env.get_rng_streams(0)
+    for i in list(range(0, N, 29)) + [5]:
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert np.array_equal(o.reset(), init[i])
+        n = 0
+        for t in range(T):
+            eo, er, _, ed = o.step(acts[t, i])
+            n += 1
+            tr = n >= 11
+            if ed or tr:
+                eo = o.reset()
+                n = 0
+            assert np.array_equal(obs[t, i], eo), (name, i, t)
+            assert rew[t, i] == np.float32(er) and bool(trunc[t, i]) == tr, (name, i, t)
+        assert np.array_equal(o.get_rng()[0][:4], end_env[i][:4]), (name, i)
+    assert env.status()[5] == 1
+    env.close()
