@@ -237,12 +237,7 @@ def main():
     per_launch_s = (kernel_ms / 1e3) / (args.steps / F)
     alg_bytes = wl["alg_bytes_fused"] * N * F
     achieved = alg_bytes / per_launch_s / 1e9
-    if wl["kind"] == "continuous":
-        kname = "k_continuous_step"
-    elif wl["config"].get("image_representations"):
-        kname = "k_image_obs"
-    else:
-        kname = "k_discrete_rollout_fast" if env.uses_fast_kernel else "k_discrete_step"
+    kname = env.rollout_kernel_name(F)
     # HBM bytes per launch from PMC counters: collected offline with rocprofv3 --pmc (separate
     # passes, gfx950 FETCH_SIZE correction applied) and committed under profiles/; only valid for
     # the exact launch shape it was measured on.

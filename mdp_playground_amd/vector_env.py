@@ -337,6 +337,26 @@ class RLToyVectorEnv:
         capi.check(self._lib, self._h, rc, "mdpp_step_n")
         return obs, rew, term.view(torch.bool), trunc.view(torch.bool)
 
+    def rollout_kernel_name(self, K):
+        """Name of the kernel mdpp_step_n(K) dispatches to (mirrors the C++ dispatch; for reports)."""
+        full_blocks = self.num_envs % 256 == 0
+        if self.kind == "discrete":
+            if getattr(self, "_image", None) is not None:
+                return "k_image_obs"
+            if not self.uses_fast_kernel:
+                return "k_discrete_step"
+            if K >= 32 and full_blocks and self.autoreset == "same_step":
+                return "k_discrete_rollout_pipe"
+            return "k_discrete_rollout_fast"
+        m = self.mdps[0]
+        fast = (self.rng == "numpy" and m.box_lo is None and np.isfinite(m.state_space_max)
+                and m.delay == 0 and m.reward_every_n_steps == 1
+                and list(m.relevant_indices) == list(range(len(m.relevant_indices)))
+                and (m.D, m.order, len(m.relevant_indices)) in
+                {(12, 1, 4), (12, 2, 4), (2, 1, 2), (2, 2, 2), (4, 1, 4), (4, 2, 4), (8, 1, 8), (8, 2, 8),
+                 (12, 1, 12), (12, 2, 12)})
+        return "k_continuous_rollout_fast" if fast else "k_continuous_step"
+
     def alloc_rollout(self, K):
         N, dev = self.num_envs, self.device
         shape = self._obs_shape(K, N)
