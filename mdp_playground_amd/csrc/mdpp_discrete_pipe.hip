@@ -181,6 +181,10 @@ __global__ __launch_bounds__(3 * kBlock) void k_discrete_rollout_pipe(DiscreteAr
                     else __builtin_amdgcn_raw_buffer_store_b32(nx, r_fin, v4, so * 4u, 0);
                 }
             }
+#ifdef MDPP_ABL_NOSTORE
+            status ^= (o + __float_as_uint(rout)) & 0x100u;
+            return;
+#endif
             if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(pu32x2{o, 0u}, r_obs, v8, so * 8u, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(o, r_obs, v4, so * 4u, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * 4u, 0);
@@ -274,7 +278,11 @@ __global__ __launch_bounds__(3 * kBlock) void k_discrete_rollout_pipe(DiscreteAr
         const bool pay = phase == 0;
         const uint32_t done = (term32 >> nxt) & 1u;                                   // D7
         const uint32_t tr = (has_max && steps >= max_steps) ? 1u : 0u;
+#ifdef MDPP_ABL_NORESET
+        const bool need = false;
+#else
         const bool need = autoreset && ((done | tr) != 0);
+#endif
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(need && qc == 0) != 0, 0)) {
             uint32_t spins = 0;
             while (__builtin_amdgcn_ballot_w64(need && qc == 0) != 0) {

@@ -536,3 +536,35 @@ def test_continuous_fast_kernel_shared_vs_oracle(name):
         assert np.array_equal(o.get_rng()[0][:4], end_env[i][:4]), (name, i)
     assert env.status()[5] == 1
     env.close()
+
+
+@pytest.mark.parametrize("name,flag", [("d_cfg2", "MDPP_NO_PIPE"), ("c_cfg5", "MDPP_NO_HELPER")])
+def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
+    """The producer/consumer kernels (LDS rings between waves) against the single-role kernels of
+    the same arithmetic, full size, many launches: any lost or duplicated hand-off would show."""
+    import os
+    cfg = _cfg(name, 31)
+    N, F, launches = 65536, 256, 12
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    g = torch.Generator(device=a.device)
+    g.manual_seed(1)
+    for j in range(launches):
+        if a.kind == "discrete":
+            acts = torch.randint(0, 8, (F, N), generator=g, device=a.device, dtype=torch.int32)
+        else:
+            acts = torch.rand((F, N, 12), generator=g, device=a.device) * 2 - 1
+        os.environ.pop(flag, None)
+        ra = a.rollout(acts)
+        torch.cuda.synchronize()
+        os.environ[flag] = "1"
+        try:
+            rb = b.rollout(acts)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop(flag, None)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (name, j)
+    assert np.array_equal(a.get_rng_streams(0), b.get_rng_streams(0))
+    assert (a.status() == 0).all() and (b.status() == 0).all()
+    a.close(); b.close()

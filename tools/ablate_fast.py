@@ -10,7 +10,8 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "mdp_playground_amd", "csrc")
-VARIANTS = ["", "HALFWAVE", "HALFWAVE,NOSTORE", "NOSTORE", "NORESET", "NOREFILL", "NOLDSR", "NOLDSP", "NOLDSR,NOLDSP",
+VARIANTS = ["", "NOSTORE", "NORESET", "NOSTORE,NORESET"]
+OLD_VARIANTS = ["", "HALFWAVE", "HALFWAVE,NOSTORE", "NOSTORE", "NORESET", "NOREFILL", "NOLDSR", "NOLDSP", "NOLDSR,NOLDSP",
             "NOSTORE,NORESET,NOREFILL", "NOSTORE,NORESET,NOREFILL,NOLDSR,NOLDSP"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
 
@@ -19,13 +20,13 @@ def main():
     import torch
     outdir = os.path.join(ROOT, "gpurun_out", "ablate")
     os.makedirs(outdir, exist_ok=True)
-    objs = [os.path.join(CSRC, f) for f in ("mdpp_capi.o", "mdpp_discrete.o", "mdpp_continuous.o", "mdpp_image.o")]
+    objs = [os.path.join(CSRC, f) for f in ("mdpp_capi.o", "mdpp_discrete.o", "mdpp_discrete_fast.o", "mdpp_continuous.o", "mdpp_continuous_fast.o", "mdpp_image.o")]
     for v in VARIANTS:
         tag = v.replace(",", "_") or "FULL"
         obj = os.path.join(outdir, f"fast_{tag}.o")
         so = os.path.join(outdir, f"libmdpp_{tag}.so")
         defs = [f"-DMDPP_ABL_{d}" for d in v.split(",") if d]
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + defs + ["-c", os.path.join(CSRC, "mdpp_discrete_fast.hip"), "-o", obj])
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + defs + ["-c", os.path.join(CSRC, "mdpp_discrete_pipe.hip"), "-o", obj])
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", so] + objs + [obj])
         code = f"""
 import sys, time, torch
@@ -35,7 +36,7 @@ _capi.LIB_PATH = {so!r}
 from mdp_playground_amd import RLToyVectorEnv
 cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8,
            action_space_size=8, delay=4, sequence_length=3, seed=0)
-N, F = 65536, 128
+N, F = 65536, 512
 env = RLToyVectorEnv(num_envs=N, autoreset="same_step", **cfg)
 acts = torch.randint(0, 8, (F, N), device=env.device, dtype=torch.int32)
 out = env.alloc_rollout(F)
