@@ -127,6 +127,39 @@ def cpu_baseline(wl, seconds=12.0):
                       f"host has {os.cpu_count()} cores"}
 
 
+def _cpu_worker(args):
+    wl_name, seconds, wid = args
+    wl = WORKLOADS[wl_name]
+    from mdp_playground_amd import mdp as mdp_mod
+    from oracle import oracle as ora
+    m = mdp_mod.build_mdp(wl["config"])
+    o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps, m.P,
+                           m.reward_table(), m.terminal_states, m.init_dist, m.transition_noise,
+                           m.reward_noise, m.reward_scale, m.reward_shift, m.term_state_reward)
+    o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator(1000 + wid)), m.space_rng_words)
+    o.reset()
+    acts = np.random.default_rng(wid).integers(0, m.A, size=20000).astype(np.int32)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        o.rollout(acts, None)
+        steps += len(acts)
+    return steps, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(wl_name, seconds=4.0):
+    """Same C port, one process per host core (discrete workloads), embarrassingly parallel."""
+    import contextlib
+    import io
+    import multiprocessing as mp
+    n = os.cpu_count() or 1
+    with mp.get_context("fork").Pool(n) as pool, contextlib.redirect_stdout(io.StringIO()):
+        res = pool.map(_cpu_worker, [(wl_name, seconds, w) for w in range(n)])
+    total = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {"value": total / wall, "unit": "env-steps/s", "cores": n, "kind": "port",
+            "sample": f"{total} env-steps, one oracle process per core for {wall:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +178,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # all-core CPU line first: it forks one worker per core, which must happen before this
+    # process has initialised the GPU runtime
+    cpu_all = None
+    wl0 = WORKLOADS[args.workload]
+    if (rank == 0 and world == 1 and not args.no_cpu_baseline and wl0["kind"] == "discrete"
+            and not wl0["config"].get("image_representations")):
+        try:
+            cpu_all = cpu_baseline_all_cores(args.workload)
+        except Exception as e:          # a reported extra, never fatal
+            cpu_all = {"error": repr(e)}
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -289,7 +332,8 @@ def main():
                        "envs_per_gpu": N, "fuse": F,
                        "collective": ("all_gather of the current observation shard after every launch, "
                                       "overlapped on a side stream") if gathers is not None else "none"},
-            "roofline": roofline, "cpu_baseline": cpu, "single_step": single,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+            "single_step": single,
             "launches": launches, "elapsed_s": elapsed,
         }
         print(json.dumps(line), flush=True)
