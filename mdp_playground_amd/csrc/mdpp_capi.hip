@@ -49,8 +49,8 @@ extern "C" const char *mdpp_last_error(const mdpp_env *h) {
 static void free_all(mdpp_env *h) {
     void *ptrs[] = {h->d_P, h->d_rtable, h->d_rbits, h->d_is_term, h->d_init_cdf, h->d_noise_cdf,
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
-                    h->d_img_tpl, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final};
+                    h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
+                    h->d_img_state_final, h->d_img_rec};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -88,12 +88,15 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     memset(&h->cfg, 0, sizeof(h->cfg));
     h->cfg = *cfg;
     h->device = device;
+    h->num_cus = 256;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->num_cus = v; }
     h->tick = 0; h->reset_tick = 0;
     h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
-    h->d_img_tpl = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
-    h->d_img_state_out = h->d_img_state_final = nullptr;
-    h->img_ready = false;
+    h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
+    h->d_img_state_out = h->d_img_state_final = h->d_img_rec = nullptr;
+    h->img_chunk = 16;
+    h->img_ready = false; h->img_fast_ok = false;
     h->img_n_radii = h->img_n_cls_x = h->img_n_cls_y = 0;
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) { h->d_rng_s[s] = h->d_rng_inc[s] = nullptr; h->streams_ready[s] = false; }
     h->tables_ready = false;
@@ -113,8 +116,10 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         if (cfg->image) {
             TRY(alloc_zero(h, &h->d_rng_half, N * 8));
-            TRY(alloc_zero(h, &h->d_img_state_out, N * 4));
-            TRY(alloc_zero(h, &h->d_img_state_final, N * 4));
+            // scratch of one batch of img_chunk env steps: states in, transform records in between
+            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * 4));
+            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * 4));
+            TRY(alloc_zero(h, &h->d_img_rec, 2 * (size_t)h->img_chunk * N * 64));
         }
     } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
@@ -384,8 +389,8 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
         if (h->cfg.image) {
             rc = launch_discrete_reset(h, mask_dev, h->d_img_state_out, s);
-            if (rc || !obs_dev) return rc;
-            return launch_image_obs(h, (const int32_t *)h->d_img_state_out, nullptr, nullptr, nullptr,
+            if (rc) return rc;
+            return launch_image_obs(h, 1, (const int32_t *)h->d_img_state_out, nullptr, nullptr, nullptr,
                                     mask_dev, (uint8_t *)obs_dev, nullptr, s);
         }
         return launch_discrete_reset(h, mask_dev, obs_dev, s);
@@ -403,17 +408,20 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
     hipStream_t s = (hipStream_t)stream;
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
         if (h->cfg.image) {
-            // one state step + one render per env step; images are W*H bytes per env and step
+            // batches of up to img_chunk env steps: one state kernel (states only, a few bytes per
+            // env step), one transform-draw kernel, one render kernel over steps x envs images
+            // (W*H bytes each)
             const size_t N = (size_t)h->cfg.num_envs, isz = (size_t)h->cfg.img_w * h->cfg.img_h;
-            for (int k = 0; k < K; k++) {
-                rc = launch_discrete_step(h, 1, (const int32_t *)actions + k * N, h->d_img_state_out,
-                                          reward + k * N, term + k * N, trunc + k * N,
-                                          h->d_img_state_final, s);
+            for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
+                const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
+                const size_t off = (size_t)k0 * N;
+                rc = launch_discrete_step(h, kc, (const int32_t *)actions + off, h->d_img_state_out,
+                                          reward + off, term + off, trunc + off, h->d_img_state_final, s);
                 if (rc) return rc;
-                rc = launch_image_obs(h, (const int32_t *)h->d_img_state_out,
-                                      (const int32_t *)h->d_img_state_final, term + k * N, trunc + k * N,
-                                      nullptr, (uint8_t *)obs + k * N * isz,
-                                      final_obs ? (uint8_t *)final_obs + k * N * isz : nullptr, s);
+                rc = launch_image_obs(h, kc, (const int32_t *)h->d_img_state_out,
+                                      (const int32_t *)h->d_img_state_final, term + off, trunc + off,
+                                      nullptr, (uint8_t *)obs + off * isz,
+                                      final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
                 if (rc) return rc;
             }
             return MDPP_OK;
@@ -449,6 +457,8 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
     const mdpp_config &c = h->cfg;
     if (n_radii != c.img_r_max - c.img_r_min + 1 || n_cls_x < 1 || n_cls_y < 1)
         return fail(h, MDPP_EINVAL, "upload_image_templates: radii/classes do not match the config");
+    if ((size_t)c.S * n_radii * n_cls_x * n_cls_y >= (1u << 20) || c.img_r_max > 1023 || c.img_w > 65535 || c.img_h > 65535)
+        return fail(h, MDPP_EUNSUPPORTED, "upload_image_templates: more than 2^20 templates, R > 1023 or a side > 65535");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t S = (size_t)c.S, W = (size_t)c.img_w, H = (size_t)c.img_h;
     const size_t tb = S * n_radii * n_cls_x * n_cls_y * (size_t)c.img_tpl_size * c.img_tpl_size;
@@ -456,10 +466,40 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
         if (cls_x[k] >= n_cls_x) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_x out of range");
     for (size_t k = 0; k < S * n_radii * H; k++)
         if (cls_y[k] >= n_cls_y) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_y out of range");
-    for (void **p : {&h->d_img_tpl, &h->d_img_clsx, &h->d_img_clsy, &h->d_img_rot})
+    for (void **p : {&h->d_img_tpl, &h->d_img_tplp, &h->d_img_clsx, &h->d_img_clsy, &h->d_img_rot})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_img_tpl, tb));
     HIPCHK(h, hipMemcpy(h->d_img_tpl, tpl, tb, hipMemcpyHostToDevice));
+    // k_image_obs_fast (mdpp_image.hip render_fast) applies when: dword rows (H % 4 == 0) and
+    // 16-byte chunks (W H % 16 == 0); the template inside its zero border fits a 64-byte LDS
+    // column; the image columns a polygon's bounding circle can span fit the wave's 6 KiB of LDS;
+    // every polygon raster stays within +-R of its centre and the centre keeps R + 1 clear of the
+    // image edge (shift draws |v| <= W/2 - R - 1, image_multi_discrete.py:172-181), so the polygon
+    // never leaves the image.
+    {
+        const int PADW = 8, t = c.img_tpl_size, tp = t + 2 * PADW, half = t / 2;
+        const int span = 2 * c.img_r_max + 9 + 4 + 1;      // columns of the near circle's box, at most
+        bool ok = (c.img_h % 4 == 0) && ((size_t)c.img_w * c.img_h) % 16 == 0 && tp <= 64 &&
+                  (size_t)c.img_w * c.img_h <= (1u << 20) && span * (c.img_h / 4) + 8 <= 1536 &&
+                  c.img_r_max <= (c.img_w < c.img_h ? c.img_w : c.img_h) / 2 - 1;
+        const size_t ntpl = S * n_radii * n_cls_x * n_cls_y;
+        for (size_t k = 0; ok && k < ntpl; k++) {
+            const int R = c.img_r_min + (int)((k / ((size_t)n_cls_x * n_cls_y)) % n_radii);
+            const uint8_t *src = tpl + k * (size_t)t * t;
+            for (int y = 0; y < t && ok; y++)
+                for (int x = 0; x < t; x++)
+                    if (src[y * t + x] && (abs(x - half) > R || abs(y - half) > R)) { ok = false; break; }
+        }
+        h->img_fast_ok = ok;
+        if (ok) {
+            std::vector<uint8_t> padded(ntpl * (size_t)tp * 64, 0);
+            for (size_t k = 0; k < ntpl; k++)
+                for (int y = 0; y < t; y++)
+                    memcpy(&padded[(k * tp + y + PADW) * 64 + PADW], tpl + (k * t + y) * (size_t)t, t);
+            HIPCHK(h, hipMalloc(&h->d_img_tplp, padded.size()));
+            HIPCHK(h, hipMemcpy(h->d_img_tplp, padded.data(), padded.size(), hipMemcpyHostToDevice));
+        }
+    }
     HIPCHK(h, hipMalloc(&h->d_img_clsx, S * n_radii * W * 2));
     HIPCHK(h, hipMemcpy(h->d_img_clsx, cls_x, S * n_radii * W * 2, hipMemcpyHostToDevice));
     HIPCHK(h, hipMalloc(&h->d_img_clsy, S * n_radii * H * 2));

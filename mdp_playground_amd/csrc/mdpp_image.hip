@@ -2,23 +2,52 @@
 // /root/reference/mdp_playground/spaces/image_multi_discrete.py:129-288, called from
 // rl_toy_env.py:2095-2096 (step) and :2347-2350 (reset).
 //
-// One wavefront per env image.  The wave draws the transform variates from the env's image-space
-// PCG64 stream in the reference's order (scale: random(); shift: integers() x2; rotate:
-// integers(360); flip: integers(2) [+ integers(2)]) and then writes the uint8[W][H][1]
-// observation with one dword (4 pixels) per lane per store.  A pixel is produced by walking the
-// reference's pipeline backwards:  obs[x][y] = final[y][x]  (the .T at :264-266)
+// Two kernels per batch of K steps x N envs images:
+//  k_image_draw   one LANE per env: draws the transform variates of the env's images from its
+//                 image-space PCG64 stream in the reference's order (scale: random(); shift:
+//                 integers() x2; rotate: integers(360); flip: integers(2) [+ integers(2)]), for
+//                 every step of the batch, and resolves everything that is per image and scalar
+//                 into a 64-byte record: the fixed-point map, the template, the bounding box.
+//                 (Doing this inside the render kernel put ~400 scalar instructions per wave on
+//                 the CU's single scalar unit: 6 us of a 20 us launch, and vector loads of the
+//                 per-image scalars wait on vmcnt together with the previous image's stores;
+//                 profiles/r01_ablation_image_kernel.txt.)
+//  k_image_obs*   one WAVEFRONT per image, a pure rasteriser: reads the record with scalar loads
+//                 and writes the uint8[W][H][1] observation.  A pixel is produced by walking the
+//                 reference's pipeline backwards:
+//   obs[x][y] = final[y][x]  (the .T at :264-266)
 //   final = flip(rot)                                   (:257-262)
 //   rot[y][x] = src[ys][xs], (xs, ys) = Pillow's NEAREST affine map in 16.16 fixed point
 //               (Image.rotate -> ImagingTransformAffine "affine_fixed"; exact transposes for
 //               0/90/180/270 on square images)           (:247-254)
 //   src = polygon raster: a host-made template (Pillow ImageDraw.polygon at a canonical centre,
 //         one per state x radius x vertex-rounding class) translated to the drawn centre (:186-245)
-// Templates (<= 1.7 KB each for R = 20) are staged in LDS; the 6 fixed-point coefficients of the
-// drawn angle come from a 360-row table made on the host.
+// The whole final->source pixel map (transpose, flip, rotation) is ONE integer affine map per
+// image: the host table holds Pillow's 16.16 coefficients for every angle (exact integer rows for
+// 0/90/180/270 on square images, where Pillow transposes instead), the flip is folded in by the
+// draw kernel.  Templates (<= 1.9 KB each for R = 20) are staged in LDS.
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
+#include <cstdlib>
 
 namespace mdpp {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kImgPad = 8;               // zero border of the fast renderer's templates, pixels
+constexpr int kImgColDw = 1536;          // dwords of LDS image columns per wave (6 KiB)
+
+// One image to rasterise (written by k_image_draw, read with s_load by the renderers).
+struct ImgRec {
+    int32_t a[6];        // source = A (x, y) + b in 16.16: xs = (a2 + a0 x + a1 y) >> 16, ys = (a5 + a3 x + a4 y) >> 16
+    uint32_t cxy;        // polygon centre in the source image: cx | cy << 16
+    uint32_t meta;       // R | two << 10 | skip << 11 | template index << 12
+    float fcx, fcy;      // polygon centre in final-image coordinates
+    uint32_t xr, qr;     // fast renderer: box of the bounding circle, X0 | X1 << 16 columns, Q0 | Q1 << 16 dword rows
+    uint32_t pad[4];
+};
+static_assert(sizeof(ImgRec) == 64, "ImgRec is read as two s_load_dwordx8");
 
 struct ImageArgs {
     int32_t N, W, H, S;
@@ -26,11 +55,16 @@ struct ImageArgs {
     int32_t r0, r_min, r_max, tpl, n_radii, n_cls_x, n_cls_y, autoreset;
     double log_min_r, log_max_r;
     const uint8_t *tpl_data;   // [S][n_radii][n_cls_x][n_cls_y][tpl][tpl], indexed [ty][tx]
+    const uint8_t *tplp_data;  // fast renderer: the same templates inside a kImgPad-wide zero
+                               // border, [..][tplp rows][64 B]; tplp = tpl + 2 * kImgPad <= 64
+    int32_t tplp;
     const int16_t *cls_x;      // [S][n_radii][W]
     const int16_t *cls_y;      // [S][n_radii][H]
     const int32_t *rot;        // [360][6] = a0 a1 a2 a3 a4 a5
     ulonglong2 *rng_s, *rng_inc;
     uint2 *rng_half;           // {has_uint32, uinteger}
+    ImgRec *rec0, *rec1;       // [M]: the image that goes to img_out / the terminal observation of a
+                               // step that ends in a reset (img_final)
 };
 
 struct Xform { int R, cx, cy, angle, flip; };
@@ -40,7 +74,15 @@ __device__ __forceinline__ int floordiv_i(int a, int b) {
     return ((a % b != 0) && ((a < 0) != (b < 0))) ? q - 1 : q;
 }
 
-__device__ Xform draw_xform(const ImageArgs &a, Pcg64 &g, Half32 &h) {
+// Bounds of the shift draws (:172-181) when the radius is fixed (no scale transform): hoisted out
+// of the per-env serial chain, which is latency-bound (one lane per env).
+struct ShiftBounds { int lo_w, hi_w, lo_h, hi_h; };
+__device__ __forceinline__ ShiftBounds shift_bounds(const ImageArgs &a, int R) {
+    const double mw = a.W / 2.0 - R, mh = a.H / 2.0 - R;
+    return ShiftBounds{(int)(-mw + 1), (int)mw, (int)(-mh + 1), (int)mh};   // Generator.integers truncates toward 0
+}
+
+__device__ __forceinline__ Xform draw_xform(const ImageArgs &a, const ShiftBounds &fixed, Pcg64 &g, Half32 &h) {
     Xform x;
     x.R = a.r0;
     x.cx = a.W / 2; x.cy = a.H / 2;              // int(width / 2)
@@ -49,16 +91,17 @@ __device__ Xform draw_xform(const ImageArgs &a, Pcg64 &g, Half32 &h) {
         x.R = (int)exp(ls);
     }
     if (a.has_shift) {
-        double mw = a.W / 2.0 - x.R, mh = a.H / 2.0 - x.R;
-        int aw = np_integers(g, h, (int)(-mw + 1), (int)mw);
-        int ah = np_integers(g, h, (int)(-mh + 1), (int)mh);
-        x.cx += floordiv_i(aw, a.sh_quant) * a.sh_quant;
-        x.cy += floordiv_i(ah, a.sh_quant) * a.sh_quant;
+        ShiftBounds b = fixed;
+        if (a.has_scale) b = shift_bounds(a, x.R);
+        const int aw = np_integers(g, h, b.lo_w, b.hi_w);
+        const int ah = np_integers(g, h, b.lo_h, b.hi_h);
+        x.cx += a.sh_quant == 1 ? aw : floordiv_i(aw, a.sh_quant) * a.sh_quant;
+        x.cy += a.sh_quant == 1 ? ah : floordiv_i(ah, a.sh_quant) * a.sh_quant;
     }
     x.angle = 0;
     if (a.has_rotate) {
-        int r = np_integers(g, h, 0, 360);
-        x.angle = floordiv_i(r, a.ro_quant) * a.ro_quant;
+        const int r = np_integers(g, h, 0, 360);
+        x.angle = a.ro_quant == 1 ? r : floordiv_i(r, a.ro_quant) * a.ro_quant;
     }
     x.flip = 0;
     if (a.has_flip) {
@@ -67,22 +110,148 @@ __device__ Xform draw_xform(const ImageArgs &a, Pcg64 &g, Half32 &h) {
     return x;
 }
 
-// One wavefront per env image (4 images per 256-thread workgroup): no workgroup barrier, the
-// transform draw is done redundantly by all 64 lanes from wave-uniform addresses (same cost as
-// one lane), the template is staged into the wave's own slice of LDS.
-//
-// The whole final->source pixel map (transpose, flip, rotation) is ONE integer affine map per
-// image: the host table holds Pillow's 16.16 coefficients for every angle (exact integer rows for
-// 0/90/180/270 on square images, where Pillow transposes instead), the flip is folded into them
-// here.  Pixels outside the polygon's bounding circle (about 3/4 of an 84x84 image at R = 20) are
-// written as zeros without evaluating the map.
-__device__ __forceinline__ void render(const ImageArgs &a, const Xform &t, int state, uint8_t *lds_tpl,
+__device__ __forceinline__ void make_rec(const ImageArgs &a, const Xform &t, int state, bool two, ImgRec *out) {
+    ImgRec r;
+    int a0 = a.rot[t.angle * 6 + 0], a1 = a.rot[t.angle * 6 + 1], a2 = a.rot[t.angle * 6 + 2];
+    int a3 = a.rot[t.angle * 6 + 3], a4 = a.rot[t.angle * 6 + 4], a5 = a.rot[t.angle * 6 + 5];
+    // source = A * (fx, fy) + b with (fx, fy) = flip(x, y) folded in
+    if (t.flip == 1) { a2 += a0 * (a.W - 1); a5 += a3 * (a.W - 1); a0 = -a0; a3 = -a3; }
+    if (t.flip == 2) { a2 += a1 * (a.H - 1); a5 += a4 * (a.H - 1); a1 = -a1; a4 = -a4; }
+    r.a[0] = a0; r.a[1] = a1; r.a[2] = a2; r.a[3] = a3; r.a[4] = a4; r.a[5] = a5;
+    r.cxy = (uint32_t)t.cx | ((uint32_t)t.cy << 16);
+    const size_t sr = (size_t)state * a.n_radii + (t.R - a.r_min);
+    const int cx_cls = a.n_cls_x > 1 ? a.cls_x[sr * a.W + t.cx] : 0;
+    const int cy_cls = a.n_cls_y > 1 ? a.cls_y[sr * a.H + t.cy] : 0;
+    const uint32_t tix = (uint32_t)((sr * a.n_cls_x + cx_cls) * a.n_cls_y + cy_cls);
+    r.meta = (uint32_t)t.R | (two ? 1u << 10 : 0u) | (tix << 12);
+    // centre of the polygon in final-image coordinates: invert the 2x2 part (a rotation, so the
+    // inverse is the transpose up to the 16.16 scale); the renderers allow a pixel of slack
+    const float fa0 = a0 * (1.0f / 65536.0f), fa1 = a1 * (1.0f / 65536.0f);
+    const float fa3 = a3 * (1.0f / 65536.0f), fa4 = a4 * (1.0f / 65536.0f);
+    const float sx = (float)t.cx + 0.5f - a2 * (1.0f / 65536.0f), sy = (float)t.cy + 0.5f - a5 * (1.0f / 65536.0f);
+    const float det = fa0 * fa4 - fa1 * fa3;
+    r.fcx = (fa4 * sx - fa1 * sy) / det; r.fcy = (fa0 * sy - fa3 * sx) / det;
+    // bounding box of the "near" circle (radius R + 4.5 around the centre: every dword with a
+    // pixel within R + 3) in (column, dword-row) units, a pixel of slack
+    const float rr = (float)t.R + 4.5f;
+    const int HQ = a.H >> 2;
+    const int X0 = max(0, (int)floorf(r.fcx - rr) - 1), X1 = min(a.W, (int)floorf(r.fcx + rr) + 2);
+    const int Q0 = max(0, (int)floorf((r.fcy - rr - 1.5f) * 0.25f) - 1);
+    const int Q1 = min(HQ, (int)floorf((r.fcy + rr - 1.5f) * 0.25f) + 2);
+    r.xr = (uint32_t)X0 | ((uint32_t)max(X1, X0) << 16);
+    r.qr = (uint32_t)Q0 | ((uint32_t)max(Q1, Q0) << 16);
+    r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0;
+    u32x4 *o = (u32x4 *)out;
+    o[0] = u32x4{(uint32_t)r.a[0], (uint32_t)r.a[1], (uint32_t)r.a[2], (uint32_t)r.a[3]};
+    o[1] = u32x4{(uint32_t)r.a[4], (uint32_t)r.a[5], r.cxy, r.meta};
+    o[2] = u32x4{__float_as_uint(r.fcx), __float_as_uint(r.fcy), r.xr, r.qr};
+}
+
+__device__ __forceinline__ uint2 xf_pack(const Xform &x) {
+    return make_uint2((uint32_t)x.cx | ((uint32_t)x.cy << 16),
+                      (uint32_t)x.angle | ((uint32_t)x.flip << 9) | ((uint32_t)x.R << 11));
+}
+__device__ __forceinline__ Xform xf_unpack(uint2 v) {
+    Xform x;
+    x.cx = (int)(v.x & 0xFFFFu); x.cy = (int)(v.x >> 16);
+    x.angle = (int)(v.y & 0x1FFu); x.flip = (int)((v.y >> 9) & 3u); x.R = (int)(v.y >> 11);
+    return x;
+}
+
+constexpr int kImgChunk = 16;            // env steps per batch (mdpp_env::img_chunk)
+
+// One lane per env, K <= kImgChunk steps of a batch (time-major [K][N] arrays): the serial part.
+// An env that is reset in a step (autoreset && (term | trunc)) draws twice there, like the
+// reference's step() then reset(): first the terminal observation's transform (rec1:
+// state_final), then the new episode's (rec0).
+// REC: build the records right here (K = 1: one launch less); otherwise only leave the drawn
+// transforms in the records' pad words for k_image_rec, so that the per-image table lookups and
+// stores run one lane per IMAGE instead of serially per env (60 us -> a few us for 16 steps).
+template <bool REC>
+__global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const int32_t *__restrict__ state_out,
+                                                       const int32_t *__restrict__ state_final,
+                                                       const uint8_t *__restrict__ term,
+                                                       const uint8_t *__restrict__ trunc,
+                                                       const uint8_t *__restrict__ mask) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.N) return;
+    if (mask && !mask[i]) {
+        for (int k = 0; k < K; k++) a.rec0[(long)k * a.N + i].meta = a.rec1[(long)k * a.N + i].meta = 1u << 11; // skip
+        return;
+    }
+    // all the reset flags of the batch in one round trip
+    uint32_t twos = 0;
+    if (a.autoreset && term) {
+#pragma unroll
+        for (int k = 0; k < kImgChunk; k++)
+            if (k < K) twos |= (uint32_t)((term[(long)k * a.N + i] | trunc[(long)k * a.N + i]) != 0) << k;
+    }
+    Pcg64 g;
+    g.load(a.rng_s, a.rng_inc, i);
+    const uint2 hh = a.rng_half[i];
+    Half32 h{hh.x, hh.y};
+    const ShiftBounds sb = shift_bounds(a, a.r0);
+    for (int k = 0; k < K; k++) {
+        const long j = (long)k * a.N + i;
+        const bool two = (twos >> k) & 1u;
+        const Xform x0 = draw_xform(a, sb, g, h);
+        Xform x1 = x0;
+        if (two) x1 = draw_xform(a, sb, g, h);
+        if (REC) {
+            if (two) {
+                make_rec(a, x0, state_final[j], false, &a.rec1[j]);
+                make_rec(a, x1, state_out[j], true, &a.rec0[j]);
+            } else {
+                make_rec(a, x0, state_out[j], false, &a.rec0[j]);
+                a.rec1[j].meta = 1u << 11;                                          // skip
+            }
+        } else {
+            const uint2 p0 = xf_pack(x0), p1 = xf_pack(x1);
+            *(u32x4 *)a.rec0[j].pad = u32x4{p0.x, p0.y, p1.x, p1.y | (two ? 0x80000000u : 0u)};
+        }
+    }
+    g.store(a.rng_s, i);
+    a.rng_half[i] = make_uint2(h.has32, h.u32);
+}
+
+// One lane per image: transforms (pad words of rec0) -> records.  mask is nullptr here (K > 1).
+__global__ __launch_bounds__(kBlock) void k_image_rec(ImageArgs a, long M, const int32_t *__restrict__ state_out,
+                                                      const int32_t *__restrict__ state_final) {
+    const long j = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= M) return;
+    const u32x4 p = *(const u32x4 *)a.rec0[j].pad;
+    const bool two = p.w >> 31;
+    const Xform x0 = xf_unpack(make_uint2(p.x, p.y)), x1 = xf_unpack(make_uint2(p.z, p.w & 0x7FFFFFFFu));
+    if (two) {
+        make_rec(a, x0, state_final[j], false, &a.rec1[j]);
+        make_rec(a, x1, state_out[j], true, &a.rec0[j]);
+    } else {
+        make_rec(a, x0, state_out[j], false, &a.rec0[j]);
+        a.rec1[j].meta = 1u << 11;                                                  // skip
+    }
+}
+
+// Records are read through the constant address space: a wave-uniform address there is always a
+// scalar load (lgkmcnt), so fetching the next image's record never waits for this image's stores.
+struct RecRegs { u32x8 lo; u32x4 hi; };
+__device__ __forceinline__ RecRegs load_rec(const ImgRec *p) {
+    typedef const __attribute__((address_space(4))) u32x8 *cptr8;
+    typedef const __attribute__((address_space(4))) u32x4 *cptr4;
+    return RecRegs{*(cptr8)(uintptr_t)p, *((cptr4)(uintptr_t)p + 2)};
+}
+
+// ---- general renderer ---------------------------------------------------------------------------
+// Any size; four range tests per pixel, one dword (4 pixels) per lane per store.  Pixels outside
+// the polygon's bounding circle (about 3/4 of an 84x84 image at R = 20) are written as zeros
+// without evaluating the map.
+__device__ __forceinline__ void render(const ImageArgs &a, const RecRegs &r, uint8_t *lds_tpl,
                                        uint8_t *__restrict__ out, int lane) {
-    const int ri = t.R - a.r_min;
-    const size_t sr = (size_t)state * a.n_radii + ri;
-    const int cx_cls = a.cls_x[sr * a.W + t.cx], cy_cls = a.cls_y[sr * a.H + t.cy];
+    const int a0 = (int)r.lo[0], a1 = (int)r.lo[1], a2 = (int)r.lo[2], a3 = (int)r.lo[3], a4 = (int)r.lo[4],
+              a5 = (int)r.lo[5];
+    const int cx = (int)(r.lo[6] & 0xFFFFu), cy = (int)(r.lo[6] >> 16), R = (int)(r.lo[7] & 0x3FFu);
+    const float fcx = __uint_as_float(r.hi[0]), fcy = __uint_as_float(r.hi[1]);
     const int tsz = a.tpl * a.tpl;
-    const uint8_t *gt = a.tpl_data + ((sr * a.n_cls_x + cx_cls) * a.n_cls_y + cy_cls) * (size_t)tsz;
+    const uint8_t *gt = a.tpl_data + (size_t)(r.lo[7] >> 12) * (size_t)tsz;
     // template -> this wave's LDS slice (wave-local: LDS ops of one wave complete in order)
     for (int k = lane * 4; k < tsz; k += 64 * 4) {
         uint32_t w = 0;
@@ -91,20 +260,8 @@ __device__ __forceinline__ void render(const ImageArgs &a, const Xform &t, int s
         *(uint32_t *)(lds_tpl + k) = w;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // source = A * (fx, fy) + b in 16.16, with (fx, fy) = flip(x, y) folded in
-    int a0 = a.rot[t.angle * 6 + 0], a1 = a.rot[t.angle * 6 + 1], a2 = a.rot[t.angle * 6 + 2];
-    int a3 = a.rot[t.angle * 6 + 3], a4 = a.rot[t.angle * 6 + 4], a5 = a.rot[t.angle * 6 + 5];
-    if (t.flip == 1) { a2 += a0 * (a.W - 1); a5 += a3 * (a.W - 1); a0 = -a0; a3 = -a3; }
-    if (t.flip == 2) { a2 += a1 * (a.H - 1); a5 += a4 * (a.H - 1); a1 = -a1; a4 = -a4; }
-    // centre of the polygon in final-image coordinates: invert the 2x2 part (a rotation, so the
-    // inverse is the transpose up to the 16.16 scale); one pixel of slack covers the rounding
-    const float fa0 = a0 * (1.0f / 65536.0f), fa1 = a1 * (1.0f / 65536.0f);
-    const float fa3 = a3 * (1.0f / 65536.0f), fa4 = a4 * (1.0f / 65536.0f);
-    const float sx = (float)t.cx + 0.5f - a2 * (1.0f / 65536.0f), sy = (float)t.cy + 0.5f - a5 * (1.0f / 65536.0f);
-    const float det = fa0 * fa4 - fa1 * fa3;
-    const float fcx = (fa4 * sx - fa1 * sy) / det, fcy = (fa0 * sy - fa3 * sx) / det;
-    const float rad = (float)t.R + 3.0f, rad2 = rad * rad;
-    const int half = a.tpl / 2, ox = t.cx - half, oy = t.cy - half;
+    const float rad = (float)R + 3.0f, rad2 = rad * rad;
+    const int half = a.tpl / 2, ox = cx - half, oy = cy - half;
     const int total = a.W * a.H;
     auto pixel = [&](int x, int y) -> uint32_t {
         const int xs = (a2 + a0 * x + a1 * y) >> 16, ys = (a5 + a3 * x + a4 * y) >> 16;
@@ -141,50 +298,180 @@ __device__ __forceinline__ void render(const ImageArgs &a, const Xform &t, int s
     }
 }
 
-// state_out: the state whose image goes to img_out; for envs that were reset in this step
-// (autoreset && (term|trunc)) the terminal state (state_final) is rendered first, consuming the
-// draws the reference's step() made before its reset() (image goes to img_final if given).
-__global__ __launch_bounds__(kBlock) void k_image_obs(ImageArgs a, const int32_t *__restrict__ state_out,
-                                                      const int32_t *__restrict__ state_final,
-                                                      const uint8_t *__restrict__ term,
-                                                      const uint8_t *__restrict__ trunc,
-                                                      const uint8_t *__restrict__ mask,
-                                                      uint8_t *__restrict__ img_out,
-                                                      uint8_t *__restrict__ img_final) {
+// M = K * N images (time-major like the step outputs): rec[j] -> img[j].  Launched on rec0 for the
+// observations and, if the caller wants them, on rec1 for the terminal observations of steps that
+// ended in a reset (other records there say "skip").
+__global__ __launch_bounds__(kBlock) void k_image_obs(ImageArgs a, long M, const ImgRec *__restrict__ rec,
+                                                      uint8_t *__restrict__ img) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slice = (a.tpl * a.tpl + 15) & ~15;
-    // wave-uniform env index (readfirstlane makes the uniformity visible to the compiler, so the
-    // stream state and the transform live in SGPRs)
-    const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wave);
-    if (i >= a.N) return;
-    if (mask && !mask[i]) return;
-    uint8_t *lds_tpl = lds_all + wave * slice;
-    const bool two = a.autoreset && term && (term[i] | trunc[i]);
-    Pcg64 g;
-    g.load(a.rng_s, a.rng_inc, i);
-    const uint2 hh = a.rng_half[i];
-    Half32 h{hh.x, hh.y};
-    const Xform x0 = draw_xform(a, g, h);
-    Xform x1 = x0;
-    if (two) x1 = draw_xform(a, g, h);
-    if (lane == 0) {
-        g.store(a.rng_s, i);
-        a.rng_half[i] = make_uint2(h.has32, h.u32);
+    const long j = __builtin_amdgcn_readfirstlane((int)((long)blockIdx.x * (kBlock / 64) + wave));
+    if (j >= M) return;
+    const RecRegs r = load_rec(rec + j);
+    if (r.lo[7] & (1u << 11)) return;
+    render(a, r, lds_all + wave * slice, img + (size_t)j * ((size_t)a.W * a.H), lane);
+}
+
+// ---- fast renderer (conditions checked on the host, mdpp_capi.hip: img_fast_ok) ----------------
+// Measured on the general renderer (profiles/r01_ablation_image_kernel.txt): the per-pixel map and
+// the four range tests dominate, and stores that leave holes in a cache line are several times
+// slower than full-line stores.  So:
+//  * the four waves of a workgroup share 64 LDS rows of 256 B; wave w owns byte columns
+//    [64 w, 64 w + 64) of every row and holds its image's template there inside a zero border of
+//    kImgPad pixels.  The LDS address of source pixel (xs, ys) is then ONE v_perm_b32 of the two
+//    16.16 accumulators (byte 2 of each = the integer part) and no range test is needed: a dword
+//    whose 4 pixels can touch the polygon's bounding circle ("near", the criterion of the general
+//    renderer) maps, through the isometry, to within R + 8 of the template centre, i.e. inside
+//    the border; the polygon never leaves the image (host-checked), so Pillow's "source outside
+//    the image -> 0" rule can only hit zero template pixels;
+//  * only the near dwords of the bounding box of that circle are evaluated; they go to a
+//    wave-private LDS copy of the image columns the box spans (zero elsewhere);
+//  * the image is then written front to back with 16-byte stores, 1 KiB contiguous per wave
+//    instruction: from the LDS columns where the box is, zeros elsewhere;
+//  * waves are persistent: each walks images j, j + (waves in the grid), ... and has the next
+//    image's record (scalar loads) and template (4 dwordx4 per lane) in flight while it evaluates
+//    the current one; the stores of an image drain while the next one is evaluated.
+struct TplRegs { u32x4 v[4]; };          // a padded template (<= 64 rows x 64 B), 4 chunks per lane
+
+__device__ __forceinline__ TplRegs load_tpl(const ImageArgs &a, uint32_t tix, int lane) {
+    const u32x4 *gt = (const u32x4 *)(a.tplp_data + (size_t)tix * ((size_t)a.tplp * 64));
+    const int nchunk = a.tplp * 4;
+    TplRegs r;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = lane + 64 * j;
+        r.v[j] = gt[c < nchunk ? c : 0];
     }
-    const size_t isz = (size_t)a.W * a.H;
-    if (two) {
-        if (img_final) render(a, x0, state_final[i], lds_tpl, img_final + (size_t)i * isz, lane);
-        render(a, x1, state_out[i], lds_tpl, img_out + (size_t)i * isz, lane);
+    return r;
+}
+
+__device__ __forceinline__ void stage_tpl(const ImageArgs &a, const TplRegs &tp, uint8_t *lds, int wave, int lane) {
+#ifndef MDPP_IMG_ABL_NOTPL
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = lane + 64 * j;
+        if (c < a.tplp * 4) *(u32x4 *)(lds + (c >> 2) * 256 + wave * 64 + (c & 3) * 16) = tp.v[j];
+    }
+#endif
+}
+
+// Evaluation half: the template of this image is already in the wave's LDS columns (stage_tpl);
+// leaves the image columns of the bounding box in lds_col and returns their chunk range.
+struct ColRange { int C0, C1; };
+__device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const RecRegs &r, const uint8_t *lds,
+                                                     uint32_t *lds_col, int wave, int lane) {
+    const int a0 = (int)r.lo[0], a1 = (int)r.lo[1], a2 = (int)r.lo[2], a3 = (int)r.lo[3], a4 = (int)r.lo[4],
+              a5 = (int)r.lo[5];
+    const int cx = (int)(r.lo[6] & 0xFFFFu), cy = (int)(r.lo[6] >> 16), R = (int)(r.lo[7] & 0x3FFu);
+    const float fcx = __uint_as_float(r.hi[0]), fcy = __uint_as_float(r.hi[1]);
+    const int X0 = (int)(r.hi[2] & 0xFFFFu), X1 = (int)(r.hi[2] >> 16);
+    const int Q0 = (int)(r.hi[3] & 0xFFFFu), Q1 = (int)(r.hi[3] >> 16);
+    const float rr = (float)R + 4.5f, rr2 = rr * rr;          // near radius of the general renderer
+    const int HQ = a.H >> 2;
+    const int bw = X1 - X0, bhq = Q1 - Q0;
+    // LDS columns hold image dwords [B0, B1), 16-byte chunks [C0, C1)
+    const int C0 = (X0 * HQ) >> 2, C1 = bw > 0 ? (X1 * HQ + 3) >> 2 : C0, B0 = C0 << 2;
+    for (int c = lane; c < C1 - C0; c += 64) *(u32x4 *)(lds_col + 4 * c) = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (bw > 0 && bhq > 0) {
+        // accumulators carry the template-local source coordinates in 16.16:
+        // bx >> 16 = xs - (cx - half_p) + 64 wave, by >> 16 = ys - (cy - half_p)
+        const int half_p = a.tplp >> 1;
+        const int A2 = a2 - ((cx - half_p) << 16) + ((wave * 64) << 16);
+        const int A5 = a5 - ((cy - half_p) << 16);
+        const int nb = bw * bhq;
+        const uint32_t inv = 65536u / (uint32_t)bhq + 1u;   // k / bhq == (k * inv) >> 16 here (k < 2^16 / bhq)
+        const int kx = (int)(((uint32_t)lane * inv) >> 16);
+        int x = X0 + kx, y = 4 * (Q0 + (lane - kx * bhq));        // y = first pixel row of the dword
+        const int d64 = 64 / bhq, r64 = 4 * (64 - d64 * bhq), yend = 4 * Q1, ywrap = 4 * bhq;
+        for (int k = lane; k < nb; k += 64) {
+            const float ddx = (float)x - fcx, ddy = (float)y + 1.5f - fcy;
+#ifndef MDPP_IMG_ABL_ZERO
+            if (ddx * ddx + ddy * ddy <= rr2) {
+                const int bx = A2 + __mul24(a0, x) + __mul24(a1, y);      // |a_i| <= 2^16, x, y < 2^23
+                const int by = A5 + __mul24(a3, x) + __mul24(a4, y);
+                uint32_t word = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    // byte 2 of each accumulator = its integer part (< 256): address = uy * 256 + ux
+                    const uint32_t addr = __builtin_amdgcn_perm((uint32_t)(by + b * a4), (uint32_t)(bx + b * a1), 0x0c0c0602u);
+                    word |= (uint32_t)lds[addr] << (8 * b);
+                }
+                lds_col[__mul24(x, HQ) + (y >> 2) - B0] = word;
+            }
+#endif
+            x += d64; y += r64;
+            if (y >= yend) { y -= ywrap; x += 1; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    return ColRange{C0, C1};
+}
+
+// Store half: the image front to back, 16 B per lane per store.  NST > 0: exactly NST (=
+// ceil(W H / 1024)) wave-stores, unrolled.
+template <int NST>
+__device__ __forceinline__ void render_fast_store(const ImageArgs &a, const ColRange cr, const uint32_t *lds_col,
+                                                  uint8_t *__restrict__ out, int lane) {
+    const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, a.W * a.H, 0x00020000);
+    const int nchunk = (a.W * a.H) >> 4;
+    auto put = [&](int c) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if ((uint32_t)(c - cr.C0) < (uint32_t)(cr.C1 - cr.C0)) v = *(const u32x4 *)(lds_col + 4 * (c - cr.C0));
+#ifdef MDPP_IMG_ABL_NOSTORE
+        if (v.x == 0x12345678u)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, c * 16, 0, 0);   // beyond the descriptor: dropped
+    };
+    if (NST > 0) {
+#pragma unroll
+        for (int u = 0; u < NST; u++) put(lane + 64 * u);
     } else {
-        render(a, x0, state_out[i], lds_tpl, img_out + (size_t)i * isz, lane);
+        for (int c = lane; c < nchunk; c += 64) put(c);
     }
 }
 
-int launch_image_obs(mdpp_env *h, const int32_t *state_out, const int32_t *state_final,
+// Per image: [next record: s_load] [next template: 4 dwordx4 per lane in flight] evaluate ->
+// stage the next template (its loads have had the whole evaluation to land) -> store.  The only
+// vmcnt wait of an iteration sits after the evaluation, so the 16-byte stores of one image drain
+// under the evaluation of the next.
+template <int NST>
+__global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, const ImgRec *__restrict__ rec,
+                                                           uint8_t *__restrict__ img) {
+    __shared__ __align__(16) uint8_t lds[64 * 256];
+    __shared__ __align__(16) uint32_t lds_cols[kBlock / 64][kImgColDw];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nw = (int)gridDim.x * (kBlock / 64);
+    long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
+    if (j >= M) return;
+    const size_t isz = (size_t)a.W * a.H;
+    RecRegs cur = load_rec(rec + j);
+    stage_tpl(a, load_tpl(a, cur.lo[7] >> 12, lane), lds, wave, lane);
+    for (;;) {
+        const long jn = j + nw;
+        const bool more = jn < M;
+        const bool skip = cur.lo[7] & (1u << 11);
+        const RecRegs nxt = load_rec(rec + (more ? jn : j));
+        const TplRegs tp = load_tpl(a, nxt.lo[7] >> 12, lane);
+        ColRange cr{0, 0};
+        if (!skip) cr = render_fast_eval(a, cur, lds, lds_cols[wave], wave, lane);
+        stage_tpl(a, tp, lds, wave, lane);
+        if (!skip) render_fast_store<NST>(a, cr, lds_cols[wave], img + (size_t)j * isz, lane);
+        if (!more) break;
+        j = jn; cur = nxt;
+    }
+}
+
+// K steps x N envs, arrays time-major; mask (reset only, K = 1) selects envs.  img_out == nullptr:
+// draw only (the reference's reset()/step() consume the variates whether or not anyone looks).
+int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s) {
     const mdpp_config &c = h->cfg;
+    if (K < 1 || K > h->img_chunk || K > kImgChunk || (mask && K != 1)) {
+        h->err = "launch_image_obs: K outside the record scratch"; return MDPP_EINVAL;
+    }
     ImageArgs a;
     a.N = c.num_envs; a.W = c.img_w; a.H = c.img_h; a.S = c.S;
     a.has_scale = c.img_has_scale; a.has_shift = c.img_has_shift; a.has_rotate = c.img_has_rotate;
@@ -199,11 +486,43 @@ int launch_image_obs(mdpp_env *h, const int32_t *state_out, const int32_t *state
     a.rng_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_IMAGE];
     a.rng_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_IMAGE];
     a.rng_half = (uint2 *)h->d_rng_half;
-    const int per_block = kBlock / 64;
-    const size_t lds = (size_t)per_block * (((size_t)a.tpl * a.tpl + 15) & ~(size_t)15);
-    if (lds > 64 * 1024) { h->err = "k_image_obs: polygon template too large for LDS"; return MDPP_EUNSUPPORTED; }
-    hipLaunchKernelGGL(k_image_obs, dim3((a.N + per_block - 1) / per_block), dim3(kBlock), lds, s, a,
-                       state_out, state_final, term, trunc, mask, img_out, img_final);
+    a.tplp_data = (const uint8_t *)h->d_img_tplp; a.tplp = c.img_tpl_size + 2 * kImgPad;
+    a.rec0 = (ImgRec *)h->d_img_rec;
+    a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs;
+    static_assert(kBlock == 256, "render_fast packs four 64-byte template columns into a 256-byte LDS row");
+    if (K == 1) {
+        hipLaunchKernelGGL(k_image_draw<true>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
+                           state_final, term, trunc, mask);
+    } else {
+        const long M = (long)K * a.N;
+        hipLaunchKernelGGL(k_image_draw<false>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
+                           state_final, term, trunc, mask);
+        hipLaunchKernelGGL(k_image_rec, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, M,
+                           state_out, state_final);
+    }
+    if (img_out) {
+        const int per_block = kBlock / 64;
+        const long M = (long)K * a.N;
+        const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
+        if (h->img_fast_ok && !getenv("MDPP_NO_IMGFAST")) {
+            // 40 KiB of LDS per workgroup: 4 resident workgroups per CU
+            const unsigned resident = 4u * (unsigned)h->num_cus;
+            const dim3 grid(nblk < resident ? nblk : resident);
+            const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);
+            for (int pass = 0; pass < (img_final ? 2 : 1); pass++) {
+                const ImgRec *rec = pass ? a.rec1 : a.rec0;
+                uint8_t *img = pass ? img_final : img_out;
+                if (nst == 7) hipLaunchKernelGGL(k_image_obs_fast<7>, grid, dim3(kBlock), 0, s, a, M, rec, img);   // 84 x 84
+                else if (nst == 4) hipLaunchKernelGGL(k_image_obs_fast<4>, grid, dim3(kBlock), 0, s, a, M, rec, img); // 64 x 64
+                else hipLaunchKernelGGL(k_image_obs_fast<0>, grid, dim3(kBlock), 0, s, a, M, rec, img);
+            }
+        } else {
+            const size_t lds = (size_t)per_block * (((size_t)a.tpl * a.tpl + 15) & ~(size_t)15);
+            if (lds > 64 * 1024) { h->err = "k_image_obs: polygon template too large for LDS"; return MDPP_EUNSUPPORTED; }
+            hipLaunchKernelGGL(k_image_obs, dim3(nblk), dim3(kBlock), lds, s, a, M, a.rec0, img_out);
+            if (img_final) hipLaunchKernelGGL(k_image_obs, dim3(nblk), dim3(kBlock), lds, s, a, M, a.rec1, img_final);
+        }
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_image_obs launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     return MDPP_OK;

@@ -90,6 +90,7 @@ struct ContinuousArgs {
 struct mdpp_env {
     mdpp_config cfg;
     int device;
+    int num_cus;                // compute units of `device` (persistent-kernel grids)
     std::string err;
     uint32_t tick;              // env steps taken so far (ring head, Philox counter)
     uint32_t reset_tick;        // reset() calls so far (Philox counter)
@@ -98,8 +99,10 @@ struct mdpp_env {
     void *d_state, *d_ring, *d_status;
     void *d_sd, *d_cur, *d_meta;
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
-    void *d_img_tpl, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;
-    bool img_ready;
+    void *d_img_tpl, *d_img_tplp, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;
+    void *d_img_rec;            // ImgRec [2][img_chunk][N] per-image records (mdpp_image.hip), 64 B each
+    int32_t img_chunk;          // env steps per state-kernel + draw + render batch
+    bool img_ready, img_fast_ok;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
     int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
     uint32_t nkeys, rbits_stride;
     bool tables_ready, streams_ready[MDPP_NUM_STREAMS];
@@ -122,7 +125,7 @@ bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, 
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
-int launch_image_obs(mdpp_env *h, const int32_t *state_out, const int32_t *state_final,
+int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s);
 } // namespace mdpp

@@ -342,7 +342,10 @@ class RLToyVectorEnv:
         full_blocks = self.num_envs % 256 == 0
         if self.kind == "discrete":
             if getattr(self, "_image", None) is not None:
-                return "k_image_obs"
+                # mdpp_capi.hip img_fast_ok (shape part): dword rows, 16-byte chunks, padded template <= 64
+                W, H = int(self._cfg.img_w), int(self._cfg.img_h)
+                fast = H % 4 == 0 and (W * H) % 16 == 0 and self._image["tpl_size"] + 16 <= 64
+                return "k_image_obs_fast" if fast else "k_image_obs"
             if not self.uses_fast_kernel:
                 return "k_discrete_step"
             if K >= 32 and full_blocks and self.autoreset == "same_step":

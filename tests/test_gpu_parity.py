@@ -388,6 +388,85 @@ def test_image_observations_vs_reference_golden(name):
     env.close()
 
 
+IMG_CFGS = {
+    # BASELINE cfg 4: fast renderer (k_image_obs_fast)
+    "cfg4": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8,
+                 action_space_size=8, delay=0, image_representations=True, image_width=84,
+                 image_height=84, image_transforms="shift,rotate", image_sh_quant=1, image_ro_quant=1),
+    # every transform, quantised shift/rotation, 100x100: general renderer (k_image_obs)
+    "all100": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8,
+                   action_space_size=8, delay=0, image_representations=True, image_width=100,
+                   image_height=100, image_transforms="shift,scale,rotate,flip", image_sh_quant=2,
+                   image_ro_quant=15, image_scale_range=(0.5, 1.5)),
+    # 64x64, rotation and flips only (no shift): fast renderer, 4 stores per image
+    "rot64": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=6,
+                  action_space_size=6, delay=0, image_representations=True, image_width=64,
+                  image_height=64, image_transforms="rotate,flip"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(IMG_CFGS))
+def test_image_fused_rollout_equals_single_steps(name):
+    """mdpp_step_n on an image env runs batches of 16 steps (state kernel, serial draw kernel,
+    per-image record kernel, persistent render kernel); mdpp_step runs one step with the draw and
+    the records fused.  Same arithmetic, different launch shapes: bit-identical images, rewards,
+    flags and RNG end states.  K = 40 spans two full batches and a ragged one."""
+    cfg = dict(IMG_CFGS[name], seed=5)
+    N, K = 300, 40
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    assert a.rollout_kernel_name(K) == ("k_image_obs" if name == "all100" else "k_image_obs_fast")
+    acts = torch.as_tensor(np.random.default_rng(2).integers(0, cfg["action_space_size"], size=(K, N)).astype(np.int32),
+                           device=a.device)
+    obs, rew, term, trunc = a.rollout(acts)
+    assert term.any() and not term.all()
+    for t in range(K):
+        o, r, te, tr, _ = b.step(acts[t])
+        assert torch.equal(o, obs[t]), (name, t)
+        assert torch.equal(r, rew[t]) and torch.equal(te, term[t]), (name, t)
+    from mdp_playground_amd import _capi as capi
+    assert np.array_equal(a.get_rng_streams(capi.STREAM_IMAGE), b.get_rng_streams(capi.STREAM_IMAGE))
+    assert np.array_equal(a.get_rng_streams(capi.STREAM_ENV), b.get_rng_streams(capi.STREAM_ENV))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", sorted(IMG_CFGS))
+def test_image_batch_vs_oracle(name):
+    """A few thousand images (all states, hundreds of distinct angles/shifts) against the oracle's
+    draw + Pillow-exact rotate restatement, for the observation, the terminal observation of a
+    step that ends in a reset, and the first observation after it."""
+    from test_image_oracle import _render
+    from mdp_playground_amd import _capi as capi, image_obs, mdp
+    cfg = dict(IMG_CFGS[name], seed=9)
+    N, T = 192, 12
+    env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    twin_cfg = {k: v for k, v in cfg.items() if not k.startswith("image_")}
+    twin = _venv(num_envs=N, autoreset="same_step", **twin_cfg)      # same states, integer observations
+    m = mdp.build_mdp(cfg)
+    tpl = image_obs.build_templates(m.S, m.image)
+    # stream position BEFORE the constructor's reset drew the first observation is not exported;
+    # start from the current one: the next draws are those of step 0
+    words = env.get_rng_streams(capi.STREAM_IMAGE).copy()
+    assert np.array_equal(twin._obs.cpu().numpy().shape, (N,))
+    acts = np.random.default_rng(4).integers(0, cfg["action_space_size"], size=(T, N)).astype(np.int32)
+    n_final = 0
+    for t in range(T):
+        at = torch.as_tensor(acts[t], device=env.device)
+        obs, rew, term, trunc, info = env.step(at)
+        sobs, srew, sterm, _, sinfo = twin.step(at)
+        assert torch.equal(term, sterm) and torch.equal(rew, srew)
+        obs, fin = obs.cpu().numpy(), info["final_obs"].cpu().numpy()
+        st, sfin, d = sobs.cpu().numpy(), sinfo["final_obs"].cpu().numpy(), term.cpu().numpy().astype(bool)
+        for i in range(N):
+            if d[i]:
+                assert np.array_equal(_render(m.image, tpl, int(sfin[i]), words[i]), fin[i]), (name, t, i)
+                n_final += 1
+            assert np.array_equal(_render(m.image, tpl, int(st[i]), words[i]), obs[i]), (name, t, i)
+    assert n_final > 50
+    assert np.array_equal(words, env.get_rng_streams(capi.STREAM_IMAGE))
+    env.close(); twin.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _cfg(name, seed):
     return dict(gu.CASES[name]["config"], seed=seed)
