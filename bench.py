@@ -288,8 +288,12 @@ def main():
     tfile = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}.json")
     if os.path.exists(tfile):
         t = json.load(open(tfile))
-        if t.get("envs") == N and t.get("fuse") == F:
+        if t.get("envs") == N and t.get("fuse") == F and "traffic_bytes_per_launch" in t:
             traffic = t["traffic_bytes_per_launch"]
+        elif t.get("envs") == N and "traffic_bytes_per_env_step" in t:
+            # measured per env step over whole rollouts (tools/pmc_traffic.sh); per-step traffic of a
+            # fused rollout does not depend on the rollout length beyond the per-launch state I/O
+            traffic = int(round(t["traffic_bytes_per_env_step"] * N * F))
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"],

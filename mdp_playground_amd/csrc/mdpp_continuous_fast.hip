@@ -27,7 +27,8 @@ namespace mdpp {
 #ifndef MDPP_CAHEAD
 #define MDPP_CAHEAD 4
 #endif
-constexpr int kCAheadQuiet = MDPP_CAHEAD, kCAheadNoise = 2; // fewer rows in flight where the RNG needs the registers
+constexpr int kCAheadQuiet = MDPP_CAHEAD, kCAheadNoise = 1; // noisy steps take microseconds: one row ahead hides the load, and a
+                                                            // deeper ring would not unroll (step body too large) -> scratch
 constexpr int kCRsrc = 0x00020000;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -190,57 +191,41 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         const bool ok = all_within(act, amax);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
         // ---- C2
-        auto integrate = [&](float (&v)[ORDER + 1][D]) {
-            if (inertia_pow2) {            // wave-uniform choices hoisted out of the per-dimension loops
+        // The reference updates state_derivatives in place, lowest order first (:1654-1669); row i
+        // only reads rows above it, which are still this step's inputs (row n = a / inertia), so
+        // the update is a pure function old rows -> new rows.  Written that way (per-element
+        // float accumulators, every index a compile-time constant) the arrays stay in registers;
+        // the earlier in-place form through an array reference left sd in scratch memory for
+        // D = 12, order 2.
+        float nacc[D];                                   // new highest row: a / inertia
+        if (inertia_pow2) {                              // wave-uniform choice hoisted out of the loops
 #pragma unroll
-                for (int d = 0; d < D; d++) v[ORDER][d] = act[d] * inv_inertia;
-            } else {
-#pragma unroll
-                for (int d = 0; d < D; d++) v[ORDER][d] = act[d] / a.inertia32;
-            }
-#pragma unroll
-            for (int ii = 0; ii < ORDER; ii++) {
-#pragma unroll
-                for (int j = 0; j < ORDER - ii; j++) {
-                    const float tp = a.tpow32[j + 1];
-                    if ((a.fact_pow2_mask >> (j + 1)) & 1u) {
-                        const double inv = a.inv_fact[j + 1];
-#pragma unroll
-                        for (int d = 0; d < D; d++) {
-                            float prod = v[ii + j + 1][d] * tp;
-                            v[ii][d] = (float)((double)v[ii][d] + (double)prod * inv);
-                        }
-                    } else {
-                        const double fct = a.fact[j + 1];
-#pragma unroll
-                        for (int d = 0; d < D; d++) {
-                            float prod = v[ii + j + 1][d] * tp;
-                            v[ii][d] = (float)((double)v[ii][d] + (double)prod / fct);
-                        }
-                    }
-                }
-            }
-        };
-        if (__builtin_expect(all_ok, 1)) {
-            integrate(sd);
-#pragma unroll
-            for (int d = 0; d < D; d++) nxt[d] = sd[0][d];
+            for (int d = 0; d < D; d++) nacc[d] = act[d] * inv_inertia;
         } else {
-            // some lane's action was rejected: integrate a copy, commit it only where admitted
-            float nsd[ORDER + 1][D];
 #pragma unroll
-            for (int kk = 0; kk <= ORDER; kk++)
-#pragma unroll
-                for (int d = 0; d < D; d++) nsd[kk][d] = sd[kk][d];
-            integrate(nsd);
-            status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
-#pragma unroll
-            for (int kk = 0; kk <= ORDER; kk++)
-#pragma unroll
-                for (int d = 0; d < D; d++) sd[kk][d] = ok ? nsd[kk][d] : sd[kk][d];
-#pragma unroll
-            for (int d = 0; d < D; d++) nxt[d] = ok ? sd[0][d] : cur[d];          // "stay", :1671
+            for (int d = 0; d < D; d++) nacc[d] = act[d] / a.inertia32;
         }
+#pragma unroll
+        for (int ii = 0; ii < ORDER; ii++) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                float acc = sd[ii][d];
+#pragma unroll
+                for (int j = 0; j < ORDER; j++) {
+                    if (j >= ORDER - ii) continue;        // constant trip count: `ORDER - ii` as the bound defeats the unroller
+                    const float hi = (ii + j + 1 == ORDER) ? nacc[d] : sd[(ii + j + 1 < ORDER) ? ii + j + 1 : ORDER][d];
+                    const float prod = hi * a.tpow32[j + 1];
+                    if ((a.fact_pow2_mask >> (j + 1)) & 1u) acc = (float)((double)acc + (double)prod * a.inv_fact[j + 1]);
+                    else acc = (float)((double)acc + (double)prod / a.fact[j + 1]);
+                }
+                sd[ii][d] = ok ? acc : sd[ii][d];        // rejected action: "stay", nothing moves
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) sd[ORDER][d] = ok ? nacc[d] : sd[ORDER][d];
+        status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+#pragma unroll
+        for (int d = 0; d < D; d++) nxt[d] = ok ? sd[0][d] : cur[d];                  // "stay", :1671
         // ---- C3
 #pragma unroll
         for (int d = 0; d < D; d++) {

@@ -5,6 +5,30 @@
 #include "mdpp_rng.hpp"
 using namespace mdpp;
 
+// candidate: wedge test decided by a float32 exp with a guard band, float64 exp only inside it
+template <class G>
+__device__ __forceinline__ double normal_f32guard(G &g, const ZigLds &z) {
+    for (;;) {
+        uint64_t r = g.next64();
+        int idx = (int)(r & 0xff);
+        r >>= 8;
+        int sign = (int)(r & 0x1);
+        uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+        double x = (double)rabs * z.wi[idx];
+        if (sign) x = -x;
+        if (rabs < z.ki[idx]) return x;
+        if (idx == 0) return np_zig_tail(g, rabs);
+        const double lhs = (z.fi[idx - 1] - z.fi[idx]) * np_random(g) + z.fi[idx];
+        const double t = -0.5 * x * x;
+        const double e32 = (double)__expf((float)t);
+        bool acc;
+        if (lhs < e32 * (1.0 - 1e-5)) acc = true;
+        else if (lhs > e32 * (1.0 + 1e-5)) acc = false;
+        else acc = lhs < exp(t);
+        if (acc) return x;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
     __shared__ uint64_t s_ki[256];
@@ -20,6 +44,7 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
         if (MODE == 1) acc += np_random(g);
         if (MODE == 2) acc += np_standard_normal_lds(g, zig);
         if (MODE == 3) acc += np_standard_normal(g);
+        if (MODE == 8) acc += normal_f32guard(g, zig);
         if (MODE == 6) { // ziggurat hot path only (rejections ignored)
             uint64_t r = g.next64(); int idx = (int)(r & 0xff);
             uint64_t rabs = (r >> 9) & 0x000fffffffffffffULL;
@@ -60,6 +85,7 @@ int main() {
     run<1>("np_random (uniform double)", d, iters);
     run<2>("standard_normal (LDS tables)", d, iters);
     run<3>("standard_normal (global tbl)", d, iters);
+    run<8>("standard_normal f32-guard", d, iters);
     run<6>("ziggurat hot path only", d, iters);
     run<7>("hot + wedge uniform, no exp", d, iters);
     return 0;

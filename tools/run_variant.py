@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Run the cfg2 fused rollout with one ablation build (for rocprofv3 --pmc).  GPU box only.
-usage: python3 tools/run_variant.py <so-path> [launches]"""
+"""Run fused rollouts of one bench workload with one (ablation) build, for rocprofv3 --pmc.
+GPU box only.  usage: python3 tools/run_variant.py <so-path or -> [launches] [workload] [fuse]"""
 import os
 import sys
 
@@ -12,14 +12,17 @@ from mdp_playground_amd import _capi  # noqa: E402
 if len(sys.argv) > 1 and sys.argv[1] != "-":
     _capi.LIB_PATH = os.path.abspath(sys.argv[1])
 from mdp_playground_amd import RLToyVectorEnv  # noqa: E402
+import bench  # noqa: E402
 
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8,
-           action_space_size=8, delay=4, sequence_length=3, seed=0)
-N, F = 65536, 128
-env = RLToyVectorEnv(num_envs=N, autoreset="same_step", **cfg)
-acts = torch.randint(0, 8, (F, N), device=env.device, dtype=torch.int32)
+wname = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+F = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+wl = bench.WORKLOADS[wname]
+N = wl["envs"]
+env = RLToyVectorEnv(num_envs=N, autoreset="same_step", **wl["config"])
+acts = bench.make_actions(wl, F, N, env.device, 12345)
 out = env.alloc_rollout(F)
 for _ in range(n):
     env.rollout(acts, out)
 torch.cuda.synchronize()
+print(f"workload={wname} envs={N} fuse={F} launches={n}")
