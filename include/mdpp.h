@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 1
+#define MDPP_ABI_VERSION 2
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
@@ -47,7 +47,8 @@ enum { MDPP_OBS_I64 = 0, MDPP_OBS_I32 = 1, MDPP_OBS_F32 = 2, MDPP_OBS_IMAGE_U8 =
 enum { MDPP_STREAM_ENV = 0,        /* RLToyEnv._np_random: reset draw, reward noise, continuous P-noise */
        MDPP_STREAM_SPACE = 1,      /* discrete: observation_spaces[0] (P-noise); continuous: feature_space (reset) */
        MDPP_STREAM_IMAGE = 2,      /* observation_space (ImageMultiDiscrete transforms) */
-       MDPP_NUM_STREAMS = 3 };
+       MDPP_STREAM_SPACE_IRR = 3,  /* discrete, irrelevant_features: observation_spaces[1] (its P-noise) */
+       MDPP_NUM_STREAMS = 4 };
 /* per-env status bits (mdpp_status) */
 enum { MDPP_STATUS_BAD_ACTION = 1u,     /* discrete: action out of range (reference: IndexError);
                                            continuous: action rejected by Box.contains -> "stay" (:1671) */
@@ -84,6 +85,11 @@ typedef struct {
     int32_t unit_rewards;       /* 1: every rewardable sequence pays exactly 1.0 (bitmask table) */
     int32_t has_transition_noise;
     double transition_noise;
+    /* irrelevant_features=True (rl_toy_env.py:2028-2035, :2063-2092): a second, reward-irrelevant
+     * sub-space with its own transition table and P-noise generator; actions and observations
+     * become pairs [N][2] = (relevant, irrelevant) */
+    int32_t irrelevant;
+    int32_t S_irr, A_irr;
 
     /* ---- continuous (move_to_a_point) ---- */
     int32_t D, n_rel, order;    /* state_space_dim, len(relevant_indices), transition_dynamics_order */
@@ -127,6 +133,13 @@ int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P_host, const double
                                 const uint8_t *rbits_host, const uint8_t *is_term_host,
                                 const double *init_cdf_host, const double *noise_cdf_host);
 
+/* Irrelevant sub-space tables (host; shared by all envs or one set per env like the others):
+ *   P_irr uint8 [T][S_irr][A_irr]   transition_function_irrelevant            rl_toy_env.py:1153-1228
+ *   init_cdf_irr double[T][S_irr]   cumsum(irrelevant_init_state_dist) normalised  :1025-1037, :2260
+ *   noise_cdf_irr double[S_irr][S_irr]  as noise_cdf, for the irrelevant P-noise  :2068-2076; NULL without noise */
+int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P_irr_host, const double *init_cdf_irr_host,
+                                    const double *noise_cdf_irr_host);
+
 /* Image templates (host): uint8 [S][n_radii][n_cls][tpl][tpl], polygon rasters centred in the
  * template; cls_x/cls_y int16 [S][n_radii][W or H] map a centre coordinate to its template class. */
 int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl_host, int32_t n_radii, int32_t n_cls_x,
@@ -141,8 +154,9 @@ int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words_host);
  * obs_dev receives the new first observation of the reset envs (others untouched). */
 int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, void *stream);
 
-/* step(): actions int32[N] (discrete) or float32[N][D] (continuous); obs per cfg.obs_dtype
- * ([N], [N][D] or [N][W][H]); reward float32[N]; terminated/truncated uint8[N].
+/* step(): actions int32[N] (discrete; int32[N][2] with cfg.irrelevant) or float32[N][D]
+ * (continuous); obs per cfg.obs_dtype ([N], [N][2] with cfg.irrelevant, [N][D] or [N][W][H]);
+ * reward float32[N]; terminated/truncated uint8[N].
  * final_obs_dev (nullable): with same-step autoreset, the last observation of episodes that ended. */
 int mdpp_step(mdpp_env *h, const void *actions_dev, void *obs_dev, float *reward_dev,
               uint8_t *terminated_dev, uint8_t *truncated_dev, void *final_obs_dev, void *stream);
@@ -159,6 +173,9 @@ int mdpp_step_n(mdpp_env *h, int K, const void *actions_dev, void *obs_dev, floa
 int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist_host, int32_t *steps_host, double *ring_host);
 int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist_host, const int32_t *steps_host,
                             const double *ring_host);
+/* cfg.irrelevant: the irrelevant part of curr_state, int32[N] (curr_state[1], :2089) */
+int mdpp_get_state_irrelevant(mdpp_env *h, int32_t *irr_host);
+int mdpp_set_state_irrelevant(mdpp_env *h, const int32_t *irr_host);
 int mdpp_get_state_continuous(mdpp_env *h, float *derivs_host, float *cur_host, int32_t *steps_host,
                               double *ring_host, uint8_t *ring_is32_host, uint8_t *reached_host);
 int mdpp_set_state_continuous(mdpp_env *h, const float *derivs_host, const float *cur_host,

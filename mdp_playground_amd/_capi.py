@@ -6,13 +6,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 1
+MDPP_ABI_VERSION = 2
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS = 0, 1
 RNG_NUMPY_PCG64, RNG_PHILOX = 0, 1
 AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1
 OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
-STREAM_ENV, STREAM_SPACE, STREAM_IMAGE = 0, 1, 2
+STREAM_ENV, STREAM_SPACE, STREAM_IMAGE, STREAM_SPACE_IRR = 0, 1, 2, 3
 STATUS_BAD_ACTION = 1
 
 EXPORTS = [
@@ -21,6 +21,7 @@ EXPORTS = [
     "mdpp_get_streams", "mdpp_reset", "mdpp_step", "mdpp_step_n", "mdpp_get_state_discrete",
     "mdpp_set_state_discrete", "mdpp_get_state_continuous", "mdpp_set_state_continuous",
     "mdpp_status", "mdpp_timer_begin", "mdpp_timer_end",
+    "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
 ]
 
 
@@ -35,6 +36,7 @@ class MdppConfig(C.Structure):
         ("S", C.c_int32), ("A", C.c_int32), ("L", C.c_int32), ("num_tables", C.c_int32),
         ("unit_rewards", C.c_int32), ("has_transition_noise", C.c_int32),
         ("transition_noise", C.c_double),
+        ("irrelevant", C.c_int32), ("S_irr", C.c_int32), ("A_irr", C.c_int32),
         ("D", C.c_int32), ("n_rel", C.c_int32), ("order", C.c_int32),
         ("rel_idx", C.c_int32 * MAX_DIM), ("make_denser", C.c_int32), ("has_p_noise", C.c_int32),
         ("p_noise", C.c_double), ("inertia", C.c_double), ("time_unit", C.c_double),
@@ -88,6 +90,9 @@ def load():
     L.mdpp_set_state_discrete.argtypes = [vp] * 4
     L.mdpp_get_state_continuous.argtypes = [vp] * 7
     L.mdpp_set_state_continuous.argtypes = [vp] * 7
+    L.mdpp_upload_discrete_irrelevant.argtypes = [vp] * 4
+    L.mdpp_get_state_irrelevant.argtypes = [vp, vp]
+    L.mdpp_set_state_irrelevant.argtypes = [vp, vp]
     L.mdpp_status.argtypes = [vp, vp]
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]

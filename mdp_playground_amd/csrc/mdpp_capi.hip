@@ -49,6 +49,7 @@ extern "C" const char *mdpp_last_error(const mdpp_env *h) {
 static void free_all(mdpp_env *h) {
     void *ptrs[] = {h->d_P, h->d_rtable, h->d_rbits, h->d_is_term, h->d_init_cdf, h->d_noise_cdf,
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
+                    h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
                     h->d_img_state_final, h->d_img_rec};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -93,6 +94,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->tick = 0; h->reset_tick = 0;
     h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
+    h->d_P1 = h->d_init_cdf1 = h->d_noise_cdf1 = h->d_irr_state = nullptr;
+    h->irr_ready = false;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = nullptr;
     h->img_chunk = 16;
@@ -111,6 +114,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     if (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64) {
         for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
             if (s == MDPP_STREAM_IMAGE && !cfg->image) continue;
+            if (s == MDPP_STREAM_SPACE_IRR && !(cfg->kind == MDPP_KIND_DISCRETE && cfg->irrelevant)) continue;
             TRY(alloc_zero(h, &h->d_rng_s[s], N * 16));
             TRY(alloc_zero(h, &h->d_rng_inc[s], N * 16));
         }
@@ -146,6 +150,17 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         h->nkeys = (uint32_t)nk;
         h->rbits_stride = (h->nkeys + 7u) / 8u;
         const size_t T = (size_t)cfg->num_tables;
+        if (cfg->irrelevant) {
+            if (cfg->S_irr < 2 || cfg->S_irr > 255 || cfg->A_irr < 1 || cfg->image) {
+                g_create_err = "mdpp_create: irrelevant sub-space needs 2 <= S_irr <= 255, A_irr >= 1, no image observations";
+                free_all(h); delete h; return MDPP_EUNSUPPORTED;
+            }
+            TRY(alloc_zero(h, &h->d_P1, T * cfg->S_irr * cfg->A_irr));
+            TRY(alloc_zero(h, &h->d_init_cdf1, T * cfg->S_irr * sizeof(double)));
+            if (cfg->has_transition_noise)
+                TRY(alloc_zero(h, &h->d_noise_cdf1, (size_t)cfg->S_irr * cfg->S_irr * sizeof(double)));
+            TRY(alloc_zero(h, &h->d_irr_state, N * sizeof(uint32_t)));
+        }
         TRY(alloc_zero(h, &h->d_P, T * cfg->S * cfg->A));
         TRY(alloc_zero(h, &h->d_is_term, T * cfg->S));
         TRY(alloc_zero(h, &h->d_init_cdf, T * cfg->S * sizeof(double)));
@@ -188,6 +203,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
+        a.irr = cfg->irrelevant ? 1 : 0; a.S1 = cfg->S_irr; a.A1 = cfg->A_irr;
+        a.P1 = (const uint8_t *)h->d_P1; a.init_cdf1 = (const double *)h->d_init_cdf1;
+        a.noise_cdf1 = (const double *)h->d_noise_cdf1; a.irr_state = (uint32_t *)h->d_irr_state;
+        a.sp1_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE_IRR];
+        a.sp1_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE_IRR];
     } else if (cfg->kind == MDPP_KIND_CONTINUOUS) {
         if (cfg->D < 1 || cfg->D > MDPP_MAX_DIM || cfg->order < 1 || cfg->order > MDPP_MAX_ORDER ||
             cfg->n_rel < 1 || cfg->n_rel > cfg->D || cfg->n_boxes < 0 || cfg->n_boxes > MDPP_MAX_BOXES) {
@@ -289,7 +309,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         const mdpp_config &c = h->cfg;
         a.fast_ok = (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise &&
                      c.L <= 3 && c.S <= 16 && c.delay <= 32 && c.rng_mode == MDPP_RNG_NUMPY_PCG64 &&
-                     a.rew_in_lds && !c.image) ? 1u : 0u;
+                     a.rew_in_lds && !c.image && !c.irrelevant) ? 1u : 0u;
         a.s_shift = 0xFFFFFFFFu;
         for (uint32_t b = 1; b < 8; b++) if ((1u << b) == (uint32_t)c.S) a.s_shift = b;
         a.key_mask = h->nkeys - 1u;
@@ -308,6 +328,45 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         }
     }
     h->tables_ready = true;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P1, const double *init_cdf1,
+                                               const double *noise_cdf1) {
+    if (!h) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_DISCRETE || !h->cfg.irrelevant)
+        return fail(h, MDPP_EINVAL, "upload_discrete_irrelevant: not a handle with an irrelevant sub-space");
+    if (!P1 || !init_cdf1) return fail(h, MDPP_EINVAL, "upload_discrete_irrelevant: null table");
+    if (h->cfg.has_transition_noise && !noise_cdf1) return fail(h, MDPP_EINVAL, "upload_discrete_irrelevant: noise_cdf missing");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t T = (size_t)h->cfg.num_tables, S1 = (size_t)h->cfg.S_irr, A1 = (size_t)h->cfg.A_irr;
+    for (size_t k = 0; k < T * S1 * A1; k++)
+        if (P1[k] >= S1) return fail(h, MDPP_EINVAL, "upload_discrete_irrelevant: P entry out of range");
+    HIPCHK(h, hipMemcpy(h->d_P1, P1, T * S1 * A1, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_init_cdf1, init_cdf1, T * S1 * sizeof(double), hipMemcpyHostToDevice));
+    if (h->cfg.has_transition_noise)
+        HIPCHK(h, hipMemcpy(h->d_noise_cdf1, noise_cdf1, S1 * S1 * sizeof(double), hipMemcpyHostToDevice));
+    h->irr_ready = true;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_get_state_irrelevant(mdpp_env *h, int32_t *irr) {
+    if (!h || !irr) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_DISCRETE || !h->cfg.irrelevant) return fail(h, MDPP_EINVAL, "get_state_irrelevant: no irrelevant sub-space");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(irr, h->d_irr_state, (size_t)h->cfg.num_envs * 4, hipMemcpyDeviceToHost));
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_set_state_irrelevant(mdpp_env *h, const int32_t *irr) {
+    if (!h || !irr) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_DISCRETE || !h->cfg.irrelevant) return fail(h, MDPP_EINVAL, "set_state_irrelevant: no irrelevant sub-space");
+    for (int i = 0; i < h->cfg.num_envs; i++)
+        if (irr[i] < 0 || irr[i] >= h->cfg.S_irr) return fail(h, MDPP_EINVAL, "set_state_irrelevant: state out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(h->d_irr_state, irr, (size_t)h->cfg.num_envs * 4, hipMemcpyHostToDevice));
     return MDPP_OK;
 }
 
@@ -377,7 +436,11 @@ static int check_ready(mdpp_env *h, const char *what) {
             return fail(h, MDPP_ESTATE, std::string(what) + ": image RNG stream not seeded");
         if (h->cfg.image && !h->img_ready)
             return fail(h, MDPP_ESTATE, std::string(what) + ": image templates not uploaded");
+        if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->streams_ready[MDPP_STREAM_SPACE_IRR])
+            return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space RNG stream not seeded");
     }
+    if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->irr_ready)
+        return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space tables not uploaded");
     return MDPP_OK;
 }
 

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, u
     uint32_t status = 0;
     if (PHILOX) {
         Philox g;
-        g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), reset_tick, MDPP_NUM_STREAMS);
+        g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), reset_tick, kPhiloxResetStream);
         c_reset_lane<DMAX, OMAX>(a, g, sd, cur, status);
     } else {
         Pcg64 g;

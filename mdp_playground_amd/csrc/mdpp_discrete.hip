@@ -46,7 +46,10 @@ constexpr int kPrefetch = 8; // actions fetched this many steps ahead of their u
 // LDSTAB: the (single, shared) MDP's tables are read from LDS; otherwise from HBM/L2 with one
 // table set per env (or table 0 for a shared MDP too large for LDS).  Kept a template parameter
 // so that table pointers have one provenance and lower to ds_read / global_load, not flat_load.
-template <bool PHILOX, bool NOISE, bool UNIT, bool LDSTAB>
+// IRR: a second, reward-irrelevant sub-space (irrelevant_features=True, :2028-2035, :2063-2092):
+// actions and observations are pairs, the irrelevant part has its own table (read from HBM/L2) and
+// its own P-noise generator, and reset() draws its start state after the relevant one (:2259-2264).
+template <bool PHILOX, bool NOISE, bool UNIT, bool LDSTAB, bool IRR>
 __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                                                           const int32_t *__restrict__ actions,
                                                           void *__restrict__ obs,
@@ -108,14 +111,26 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     // Streams live in registers for the whole launch.  The env stream is needed by reward noise
     // and by every in-kernel reset(); with 2 of 8 states terminal some lane of a wave resets on
     // almost every step, so it is loaded up front rather than inside the divergent branch.
-    Pcg64 env_pcg, sp_pcg;
-    Philox env_phx, sp_phx;
+    Pcg64 env_pcg, sp_pcg, sp1_pcg;
+    Philox env_phx, sp_phx, sp1_phx;
     const bool use_env = (NOISE && a.has_r_noise) || a.autoreset;
     const bool use_sp = NOISE && a.has_p_noise;
     if (!PHILOX) {
         if (use_env) env_pcg.load(a.env_s, a.env_inc, i);
         if (use_sp) sp_pcg.load(a.sp_s, a.sp_inc, i);
+        if (IRR && use_sp) sp1_pcg.load(a.sp1_s, a.sp1_inc, i);
     }
+    // irrelevant sub-space: state + tables (one set per env or shared, like the relevant ones)
+    uint32_t cur1 = 0;
+    const uint8_t *P1 = nullptr;
+    const double *init_cdf1 = nullptr;
+    if (IRR) {
+        const size_t ti = a.shared_tables ? 0 : (size_t)i;
+        cur1 = a.irr_state[i];
+        P1 = a.P1 + ti * a.S1 * a.A1;
+        init_cdf1 = a.init_cdf1 + ti * a.S1;
+    }
+    constexpr int AW = IRR ? 2 : 1;              // ints per action / observation
 
     // rewards of the noise-free unit path: index = paid*2 + terminal
     float rsel[4];
@@ -129,18 +144,22 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     }
 
     // software pipeline on the action stream: kPrefetch loads in flight per lane
-    int nextact[kPrefetch];
+    int nextact[kPrefetch], nextact1[kPrefetch];
 #pragma unroll
-    for (int u = 0; u < kPrefetch; u++) nextact[u] = (u < K) ? actions[(long)u * N + i] : 0;
+    for (int u = 0; u < kPrefetch; u++) {
+        nextact[u] = (u < K) ? actions[((long)u * N + i) * AW] : 0;
+        nextact1[u] = (IRR && u < K) ? actions[((long)u * N + i) * AW + 1] : 0;
+    }
 
     for (int k0 = 0; k0 < K; k0 += kPrefetch) {
-        int act[kPrefetch];
+        int act[kPrefetch], act1[kPrefetch];
 #pragma unroll
-        for (int u = 0; u < kPrefetch; u++) act[u] = nextact[u];
+        for (int u = 0; u < kPrefetch; u++) { act[u] = nextact[u]; act1[u] = nextact1[u]; }
 #pragma unroll
         for (int u = 0; u < kPrefetch; u++) {
             const int kn = k0 + kPrefetch + u;
-            nextact[u] = (kn < K) ? actions[(long)kn * N + i] : 0;
+            nextact[u] = (kn < K) ? actions[((long)kn * N + i) * AW] : 0;
+            nextact1[u] = (IRR && kn < K) ? actions[((long)kn * N + i) * AW + 1] : 0;
         }
 #pragma unroll
         for (int u = 0; u < kPrefetch; u++) {
@@ -152,6 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             if (PHILOX) {
                 env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
                 sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
+                if (IRR) sp1_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, kPhiloxIrrStream);
             }
             if (action < 0 && action >= -A) action += A;       // numpy negative indexing
             if (action < 0 || action >= A) { status |= MDPP_STATUS_BAD_ACTION; action = 0; }
@@ -206,24 +226,47 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (done) r += a.term_add;
                 rout = (float)r;
             }
+            if (IRR) {                                                              // :2063-2082
+                int action1 = act1[u];
+                if (action1 < 0 && action1 >= -a.A1) action1 += a.A1;
+                if (action1 < 0 || action1 >= a.A1) { status |= MDPP_STATUS_BAD_ACTION; action1 = 0; }
+                uint32_t nxt1 = P1[cur1 * a.A1 + action1];
+                if (NOISE && a.has_p_noise) {
+                    double uu = PHILOX ? np_random(sp1_phx) : np_random(sp1_pcg);
+                    nxt1 = (uint32_t)searchsorted_right(a.noise_cdf1 + (size_t)nxt1 * a.S1, a.S1, uu);
+                }
+                cur1 = nxt1;
+            }
             const bool truncated = (a.max_steps > 0) && (steps >= (uint32_t)a.max_steps);
             uint32_t out_state = nxt;
             if (a.autoreset && (done || truncated)) {
                 // gymnasium "same-step" autoreset: report the terminal transition's reward/flags,
                 // hand back the first observation of the next episode (reset(), :2250-2278).
                 if (final_obs) {
-                    if (a.obs_i32) ((int32_t *)final_obs)[o] = (int32_t)nxt;
-                    else ((int64_t *)final_obs)[o] = (int64_t)nxt;
+                    if (a.obs_i32) ((int32_t *)final_obs)[o * AW] = (int32_t)nxt;
+                    else ((int64_t *)final_obs)[o * AW] = (int64_t)nxt;
+                    if (IRR) {
+                        if (a.obs_i32) ((int32_t *)final_obs)[o * AW + 1] = (int32_t)cur1;
+                        else ((int64_t *)final_obs)[o * AW + 1] = (int64_t)cur1;
+                    }
                 }
                 const uint32_t s0 = PHILOX ? d_reset_draw(a, t, env_phx) : d_reset_draw(a, t, env_pcg);
+                if (IRR) {
+                    const double u1 = PHILOX ? np_random(env_phx) : np_random(env_pcg);
+                    cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, u1);
+                }
                 hist = d_fresh_hist(s0);
                 steps = 0; phase = 0; ringbits = 0;
                 if (!UNIT)
                     for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * N + i] = kNoKey;
                 out_state = s0;
             }
-            if (a.obs_i32) ((int32_t *)obs)[o] = (int32_t)out_state;
-            else ((int64_t *)obs)[o] = (int64_t)out_state;
+            if (a.obs_i32) ((int32_t *)obs)[o * AW] = (int32_t)out_state;
+            else ((int64_t *)obs)[o * AW] = (int64_t)out_state;
+            if (IRR) {
+                if (a.obs_i32) ((int32_t *)obs)[o * AW + 1] = (int32_t)cur1;
+                else ((int64_t *)obs)[o * AW + 1] = (int64_t)cur1;
+            }
             reward[o] = rout;
             term[o] = done ? 1 : 0;
             trunc[o] = truncated ? 1 : 0;
@@ -234,7 +277,9 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     if (!PHILOX) {
         if (use_env) env_pcg.store(a.env_s, i);
         if (use_sp) sp_pcg.store(a.sp_s, i);
+        if (IRR && use_sp) sp1_pcg.store(a.sp1_s, i);
     }
+    if (IRR) a.irr_state[i] = cur1;
     if (status) atomicOr(&a.status[i], status);
 }
 
@@ -248,11 +293,13 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint3
     DTables t;
     const size_t ti = a.shared_tables ? 0 : (size_t)i;
     t.init_cdf = a.init_cdf + ti * a.S;
-    uint32_t s0, queue = 0;
+    uint32_t s0, queue = 0, s1 = 0;
+    const double *init_cdf1 = a.irr ? a.init_cdf1 + ti * a.S1 : nullptr;
     if (PHILOX) {
         Philox g;
-        g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), reset_tick, MDPP_NUM_STREAMS);
+        g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), reset_tick, kPhiloxResetStream);
         s0 = d_reset_draw(a, t, g);
+        if (a.irr) s1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(g));      // :2259-2264
     } else {
         // fast-path handles keep start states drawn ahead of need in word 1 of the state record
         // (mdpp_discrete_fast.hip): consume those first, they are the next draws of the stream
@@ -264,16 +311,23 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint3
             Pcg64 g;
             g.load(a.env_s, a.env_inc, i);
             s0 = d_reset_draw(a, t, g);
+            if (a.irr) s1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(g));  // :2259-2264
             g.store(a.env_s, i);
         }
     }
+    if (a.irr) a.irr_state[i] = s1;
     uint64_t hist = d_fresh_hist(s0);
     a.state[i] = make_uint4((uint32_t)hist, a.fast_ok ? queue : (uint32_t)(hist >> 32), 0u, 0u);
     if (!a.unit_rewards)
         for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * a.N + i] = kNoKey;
     if (obs) {
-        if (a.obs_i32) ((int32_t *)obs)[i] = (int32_t)s0;
-        else ((int64_t *)obs)[i] = (int64_t)s0;
+        const long w = a.irr ? 2 : 1;
+        if (a.obs_i32) ((int32_t *)obs)[i * w] = (int32_t)s0;
+        else ((int64_t *)obs)[i * w] = (int64_t)s0;
+        if (a.irr) {
+            if (a.obs_i32) ((int32_t *)obs)[i * w + 1] = (int32_t)s1;
+            else ((int64_t *)obs)[i * w + 1] = (int64_t)s1;
+        }
     }
 }
 
@@ -284,11 +338,16 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds);
     const size_t lds = ldstab ? a.lds_bytes : 0;
-#define MDPP_D_LAUNCH(UNIT, LDSTAB)                                                               \
-    hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB>), dim3(grid), dim3(kBlock), \
+#define MDPP_D_LAUNCH(UNIT, LDSTAB, IRR)                                                               \
+    hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB, IRR>), dim3(grid), dim3(kBlock), \
                        lds, s, a, K, actions, obs, reward, term, trunc, final_obs)
-    if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true); else MDPP_D_LAUNCH(true, false); }
-    else { if (ldstab) MDPP_D_LAUNCH(false, true); else MDPP_D_LAUNCH(false, false); }
+    if (a.irr) {
+        if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true, true); else MDPP_D_LAUNCH(true, false, true); }
+        else { if (ldstab) MDPP_D_LAUNCH(false, true, true); else MDPP_D_LAUNCH(false, false, true); }
+    } else {
+        if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true, false); else MDPP_D_LAUNCH(true, false, false); }
+        else { if (ldstab) MDPP_D_LAUNCH(false, true, false); else MDPP_D_LAUNCH(false, false, false); }
+    }
 #undef MDPP_D_LAUNCH
 }
 

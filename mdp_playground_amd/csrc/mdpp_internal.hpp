@@ -12,6 +12,9 @@ namespace mdpp {
 constexpr int kBlock = 256;         // 4 wavefronts of 64 lanes; one lane per env instance
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 constexpr uint32_t kRingPyZero = 0x7FC0DE1Au; // float32 ring slot holding Python's float 0.0
+// Philox stream ids beyond the MDPP_STREAM_* indices (keys are (seed, env id, tick, stream id)):
+constexpr uint32_t kPhiloxResetStream = 3;    // an explicit reset(), keyed by the reset tick
+constexpr uint32_t kPhiloxIrrStream = 4;      // P-noise of the irrelevant sub-space
 
 // ---- discrete: kernel arguments (passed by value; wave-uniform => SGPRs) -------------------
 struct DiscreteArgs {
@@ -43,6 +46,13 @@ struct DiscreteArgs {
     uint32_t *ring_keys;        // [delay][N] keys awaiting payout (unit_rewards == 0)
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc; // PCG64 streams
     uint32_t *status;
+    // ---- irrelevant sub-space (cfg.irrelevant; general kernel only) ----
+    int32_t irr, S1, A1;
+    const uint8_t *P1;          // [T][S1][A1]
+    const double *init_cdf1;    // [T][S1]
+    const double *noise_cdf1;   // [S1][S1]
+    uint32_t *irr_state;        // [N] irrelevant part of curr_state
+    ulonglong2 *sp1_s, *sp1_inc; // observation_spaces[1] PCG64 streams
     // ---- precomputed on the host for the fused fast path (mdpp_discrete_fast.hip) ----
     uint32_t fast_ok;           // shape qualifies: shared LDS tables, unit rewards, no noise, L <= 3, S <= 16
     uint32_t s_shift;           // log2(S) when S is a power of two, else 0xFFFFFFFF
@@ -97,6 +107,8 @@ struct mdpp_env {
     // device allocations
     void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
     void *d_state, *d_ring, *d_status;
+    void *d_P1, *d_init_cdf1, *d_noise_cdf1, *d_irr_state;   // irrelevant sub-space
+    bool irr_ready;
     void *d_sd, *d_cur, *d_meta;
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
     void *d_img_tpl, *d_img_tplp, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;

@@ -74,6 +74,14 @@ class DiscreteMDP(CommonParams):
     rewardable_sequences: dict = None        # tuple(states) -> float (incl. make_denser sub-sequences)
     space_rng_words: np.ndarray = None       # observation_spaces[0] RNG after P generation
     image: dict | None = None                # ImageMultiDiscrete parameters, or None
+    # irrelevant sub-space (irrelevant_features=True: Tuple spaces, rl_toy_env.py:2028-2092)
+    irrelevant: bool = False
+    S_irr: int = 0
+    A_irr: int = 0
+    P_irr: np.ndarray = None                 # int64 [S_irr, A_irr]
+    init_dist_irr: np.ndarray = None         # float64 [S_irr], uniform (:1025-1037)
+    space_irr_rng_words: np.ndarray = None   # observation_spaces[1] RNG after P generation
+    space_seeds: tuple = None                # seeds the two sub-space generators were made from
 
     def reward_table(self) -> np.ndarray:
         """Dense float64[S**L]; key(seq) = sum seq[i] * S**(L-1-i).  Only full-length keys can
@@ -98,12 +106,16 @@ class DiscreteMDP(CommonParams):
         cdf = np.cumsum(np.asarray(self.init_dist, dtype=np.float64))
         return cdf / cdf[-1]
 
-    def noise_cdf(self) -> np.ndarray | None:
+    def init_cdf_irr(self) -> np.ndarray:
+        cdf = np.cumsum(np.asarray(self.init_dist_irr, dtype=np.float64))
+        return cdf / cdf[-1]
+
+    def noise_cdf(self, irrelevant=False) -> np.ndarray | None:
         """Row n = normalised cdf Generator.choice builds for the P-noise categorical with mode n
-        (rl_toy_env.py:1605-1612)."""
+        (rl_toy_env.py:1605-1612; irrelevant sub-space :2068-2076)."""
         if not self.transition_noise:
             return None
-        S = self.S
+        S = self.S_irr if irrelevant else self.S
         out = np.empty((S, S), dtype=np.float64)
         for n in range(S):
             probs = np.ones(shape=(S,)) * self.transition_noise / (S - 1)
@@ -244,13 +256,22 @@ def build_discrete(config) -> DiscreteMDP:
     common = _common(config, "discrete", sd)
     L = common["sequence_length"]
     diameter = config.get("diameter", 1)
-    if config.get("irrelevant_features", False):
-        raise NotImplementedError("discrete irrelevant_features (Tuple spaces) is not built yet")
-    _require(isinstance(config["action_space_size"], int),
-             "Did you mean to turn irrelevant_features? If so, please set irrelevant_features = "
-             "True in config. If not, please provide an int for action_space_size.")
-    A = config["action_space_size"]
+    irrelevant = bool(config.get("irrelevant_features", False))
+    A_irr = 0
+    if irrelevant:
+        _require(len(config["action_space_size"]) == 2,
+                 "Currently, 1st sub-state (and action) space is assumed to be relevant to rewards "
+                 "and 2nd one is irrelevant. Please provide a list with sizes for the 2.")
+        A, A_irr = (int(x) for x in config["action_space_size"])
+        if config.get("image_representations", False):
+            raise NotImplementedError("image observations of Tuple (irrelevant_features) spaces are not built")
+    else:
+        _require(isinstance(config["action_space_size"], int),
+                 "Did you mean to turn irrelevant_features? If so, please set irrelevant_features = "
+                 "True in config. If not, please provide an int for action_space_size.")
+        A = config["action_space_size"]
     S = A * diameter                                      # :589-591
+    S_irr = A_irr * diameter
     tn = config.get("transition_noise", None)
     # :868-881 terminal states = the last int(density * A) states of every independent set
     n_term = int(config.get("terminal_state_density", 0.25) * A)
@@ -260,8 +281,15 @@ def build_discrete(config) -> DiscreteMDP:
     # :1003-1018 rho_0 uniform over non-terminal states
     init_dist = np.array(([1 / (n_nonterm * diameter) for _ in range(n_nonterm)]
                           + [0 for _ in range(n_term)]) * diameter)
-    # :1050-1151 P, drawn from the relevant state space's own generator
-    space_rng = new_generator(sd["relevant_state_space"])
+    # :1050-1151 P, drawn from the relevant state space's own generator.  With an irrelevant
+    # sub-space the two state spaces are wrapped in a TupleExtended seeded with
+    # seed_dict["state_space"] (:725-728), and gymnasium's Tuple.seed(int) (third-party, 0.29 / 1.x)
+    # re-seeds every sub-space: subseeds = Generator(seed).integers(int32 max, size=len(spaces)).
+    space_seeds = (sd["relevant_state_space"], sd.get("irrelevant_state_space"))
+    if irrelevant:
+        subseeds = new_generator(sd["state_space"]).integers(np.iinfo(np.int32).max, size=2)
+        space_seeds = (int(subseeds[0]), int(subseeds[1]))
+    space_rng = new_generator(space_seeds[0])
     P = np.full((S, A), -1, dtype=np.int64)
     if config.get("maximally_connected", True):
         for s in range(S):
@@ -278,6 +306,19 @@ def build_discrete(config) -> DiscreteMDP:
     for i_s in range(diameter):
         for s in range(A - n_term, A):
             P[i_s * A + s, :] = i_s * A + s               # terminal self-loops, :1135-1151
+    P_irr = init_dist_irr = irr_words = None
+    if irrelevant:                                        # :1153-1228, always the prob= form
+        irr_rng = new_generator(space_seeds[1])
+        P_irr = np.full((S_irr, A_irr), -1, dtype=np.int64)
+        for s in range(S_irr):
+            prob = _next_set_prob(S_irr, A_irr, s)
+            if config.get("maximally_connected", True):
+                P_irr[s] = _sample_space(irr_rng, S_irr, prob=prob, size=A_irr, replace=False)
+            else:
+                for a in range(A_irr):
+                    P_irr[s, a] = _sample_space(irr_rng, S_irr, prob=prob)
+        init_dist_irr = np.array([1 / S_irr for _ in range(S_irr)])     # :1025-1037
+        irr_words = pcg64_words(irr_rng)
     # :1508-1558 rewardable sequences, drawn from the env generator
     seqs = _rewardable_sequences(env_rng, n_nonterm, A, L, config.get("reward_density", 0.25),
                                  config.get("repeats_in_sequences", False), diameter)
@@ -306,7 +347,9 @@ def build_discrete(config) -> DiscreteMDP:
                        transition_noise=None if not tn else float(tn), P=P,
                        terminal_states=terminal, init_dist=init_dist,
                        rewardable_sequences=table, space_rng_words=pcg64_words(space_rng),
-                       image=image, **common)
+                       image=image, irrelevant=irrelevant, S_irr=S_irr, A_irr=A_irr, P_irr=P_irr,
+                       init_dist_irr=init_dist_irr, space_irr_rng_words=irr_words,
+                       space_seeds=space_seeds, **common)
 
 
 def _image_params(config, sd):

@@ -32,6 +32,37 @@ class DiscreteSpace:
         return f"DiscreteSpace({self.n})"
 
 
+class TupleSpace:
+    """TupleExtended (spaces/tuple_extended.py): seeding it re-seeds every sub-space the way
+    gymnasium's Tuple.seed(int) does (third-party, 0.29 / 1.x): one int32 sub-seed per sub-space
+    drawn from Generator(seed)."""
+
+    def __init__(self, spaces, seed=None):
+        self.spaces = tuple(spaces)
+        self.shape = None
+        self.dtype = None
+        self.np_random = _gen(seed)
+        if isinstance(seed, int):
+            subseeds = self.np_random.integers(np.iinfo(np.int32).max, size=len(self.spaces))
+            for sp, ss in zip(self.spaces, subseeds):
+                sp.np_random = _gen(int(ss))
+
+    def sample(self):
+        return tuple(sp.sample() for sp in self.spaces)
+
+    def contains(self, x):
+        return len(x) == len(self.spaces) and all(sp.contains(v) for sp, v in zip(self.spaces, x))
+
+    def __getitem__(self, i):
+        return self.spaces[i]
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __repr__(self):
+        return "TupleSpace(" + ", ".join(repr(sp) for sp in self.spaces) + ")"
+
+
 class BoxSpace:
     def __init__(self, low, high, shape, dtype=np.float32, seed=None):
         self.shape = tuple(shape)

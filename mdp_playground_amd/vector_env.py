@@ -25,7 +25,7 @@ import torch
 
 from . import _capi as capi
 from . import mdp as mdp_mod
-from .spaces import BoxSpace, DiscreteSpace, ImageSpace
+from .spaces import BoxSpace, DiscreteSpace, ImageSpace, TupleSpace
 
 _AUTORESET = {"disabled": capi.AUTORESET_DISABLED, "same_step": capi.AUTORESET_SAME_STEP}
 
@@ -112,7 +112,8 @@ class RLToyVectorEnv:
     def _init_discrete(self, cfg):
         m = self.mdps[0]
         for o in self.mdps[1:]:
-            if (o.S, o.A, o.sequence_length, o.delay) != (m.S, m.A, m.sequence_length, m.delay):
+            if (o.S, o.A, o.sequence_length, o.delay, o.S_irr, o.A_irr) != \
+                    (m.S, m.A, m.sequence_length, m.delay, m.S_irr, m.A_irr):
                 raise ValueError("per-env MDPs must share S, A, sequence_length and delay")
         cfg.S, cfg.A, cfg.L = m.S, m.A, m.sequence_length
         cfg.num_tables = self.num_envs if self._per_env else 1
@@ -126,6 +127,18 @@ class RLToyVectorEnv:
         cfg.obs_dtype = capi.OBS_I32 if self._obs_torch_dtype == torch.int32 else capi.OBS_I64
         self.single_observation_space = DiscreteSpace(m.S, seed=m.seed_dict.get("relevant_state_space"))
         self.single_action_space = DiscreteSpace(m.A, seed=m.seed_dict.get("relevant_action_space"))
+        self._irr = bool(m.irrelevant)
+        if self._irr:
+            # Tuple spaces (:718-733): (relevant, irrelevant) pairs
+            cfg.irrelevant, cfg.S_irr, cfg.A_irr = 1, m.S_irr, m.A_irr
+            self.single_observation_space = TupleSpace(
+                [self.single_observation_space,
+                 DiscreteSpace(m.S_irr, seed=m.seed_dict.get("irrelevant_state_space"))],
+                seed=m.seed_dict.get("state_space"))
+            self.single_action_space = TupleSpace(
+                [self.single_action_space,
+                 DiscreteSpace(m.A_irr, seed=m.seed_dict.get("irrelevant_action_space"))],
+                seed=m.seed_dict.get("action_space"))
         self._image = None
         if m.image is not None:
             if self.rng != "numpy":
@@ -152,7 +165,7 @@ class RLToyVectorEnv:
         self.uses_fast_kernel = bool(
             not self._per_env and cfg.unit_rewards and not cfg.has_transition_noise
             and not cfg.has_reward_noise and m.sequence_length <= 3 and m.S <= 16
-            and m.delay <= 32 and self.rng == "numpy")
+            and m.delay <= 32 and self.rng == "numpy" and not self._irr)
 
     def _upload_discrete(self):
         ms = self.mdps
@@ -172,6 +185,14 @@ class RLToyVectorEnv:
                                                    capi.nptr(rbits), capi.nptr(is_term),
                                                    capi.nptr(init_cdf), capi.nptr(noise))
         capi.check(self._lib, self._h, rc, "mdpp_upload_discrete_tables")
+        if self._irr:
+            P1 = _stack([m.P_irr for m in ms], np.uint8)
+            cdf1 = _stack([m.init_cdf_irr() for m in ms], np.float64)
+            noise1 = ms[0].noise_cdf(irrelevant=True)
+            noise1 = None if noise1 is None else np.ascontiguousarray(noise1, dtype=np.float64)
+            rc = self._lib.mdpp_upload_discrete_irrelevant(self._h, capi.nptr(P1), capi.nptr(cdf1),
+                                                           capi.nptr(noise1))
+            capi.check(self._lib, self._h, rc, "mdpp_upload_discrete_irrelevant")
         if self._image is not None:
             t = self._image
             tpl = np.ascontiguousarray(t["tpl"], dtype=np.uint8)
@@ -230,7 +251,8 @@ class RLToyVectorEnv:
         self._term_b, self._trunc_b = self._term.view(torch.bool), self._trunc.view(torch.bool)
         self._info = {"final_obs": self._final_obs} if self.autoreset == "same_step" else {}
         self._act_dtype = torch.int32 if self.kind == "discrete" else torch.float32
-        self._act_shape = torch.Size((N,) if self.kind == "discrete" else (N, self.mdps[0].D))
+        self._act_shape = torch.Size(((N, 2) if getattr(self, "_irr", False) else (N,))
+                                     if self.kind == "discrete" else (N, self.mdps[0].D))
 
     def _obs_shape(self, *lead):
         if self.kind == "continuous":
@@ -238,6 +260,8 @@ class RLToyVectorEnv:
         if getattr(self, "_image", None) is not None:
             im = self.mdps[0].image
             return tuple(lead) + (im["width"], im["height"], 1)
+        if getattr(self, "_irr", False):
+            return tuple(lead) + (2,)
         return tuple(lead)
 
     def _seed_streams(self, env_seed, initial):
@@ -259,7 +283,8 @@ class RLToyVectorEnv:
             if self._per_env:
                 sp = np.stack([m.space_rng_words for m in self.mdps])
             else:
-                R = self.seed_dict["relevant_state_space"]
+                # (with an irrelevant sub-space the Tuple re-seeded both state spaces: space_seeds)
+                R = self.mdps[0].space_seeds[0]
                 sp = mdp_mod.fresh_stream_words(R + off, N)
                 if off == 0:
                     sp[0] = self.mdps[0].space_rng_words   # the reference's own generator, post-P
@@ -270,6 +295,14 @@ class RLToyVectorEnv:
             else:
                 sp = mdp_mod.fresh_stream_words(self.seed_dict["state_space"] + off, N)
         self._put_stream(capi.STREAM_SPACE, sp)
+        if self.kind == "discrete" and self._irr:
+            if self._per_env:
+                sp1 = np.stack([m.space_irr_rng_words for m in self.mdps])
+            else:
+                sp1 = mdp_mod.fresh_stream_words(self.mdps[0].space_seeds[1] + off, N)
+                if off == 0:
+                    sp1[0] = self.mdps[0].space_irr_rng_words
+            self._put_stream(capi.STREAM_SPACE_IRR, sp1)
         if self.kind == "discrete" and self._image is not None:
             if self._per_env:
                 im = np.stack([mdp_mod.pcg64_words(mdp_mod.new_generator(m.image["seed"])) for m in self.mdps])
@@ -378,7 +411,10 @@ class RLToyVectorEnv:
             raise TypeError(f"continuous actions must be float32, got {actions.dtype}")
         a = actions.to(device=self.device, dtype=want).contiguous()
         lead = (self.num_envs,) if K is None else (K, self.num_envs)
-        shape = lead if self.kind == "discrete" else lead + (self.mdps[0].D,)
+        if self.kind == "discrete":
+            shape = lead + (2,) if self._irr else lead
+        else:
+            shape = lead + (self.mdps[0].D,)
         if tuple(a.shape) != shape:
             raise ValueError(f"actions must have shape {shape}, got {tuple(a.shape)}")
         return a
@@ -395,7 +431,13 @@ class RLToyVectorEnv:
             ring = np.zeros((N, d), np.float64)
             rc = self._lib.mdpp_get_state_discrete(self._h, capi.nptr(hist), capi.nptr(steps), capi.nptr(ring))
             capi.check(self._lib, self._h, rc, "mdpp_get_state_discrete")
-            return {"curr_state": hist[:, -1].astype(np.int64), "curr_obs": hist[:, -1].astype(np.int64),
+            cur = hist[:, -1].astype(np.int64)
+            if self._irr:                              # curr_state = (relevant, irrelevant), :2089
+                irr = np.zeros(N, np.int32)
+                rc = self._lib.mdpp_get_state_irrelevant(self._h, capi.nptr(irr))
+                capi.check(self._lib, self._h, rc, "mdpp_get_state_irrelevant")
+                cur = np.stack([cur, irr.astype(np.int64)], axis=1)
+            return {"curr_state": cur, "curr_obs": cur,
                     "augmented_state": hist, "total_transitions_episode": steps, "reward_buffer": ring}
         D, n, d = self._cfg.D, self._cfg.order, self._cfg.delay
         sd = np.zeros((N, n + 1, D), np.float32)
@@ -420,6 +462,10 @@ class RLToyVectorEnv:
             ring = None if ring is None or not self._cfg.unit_rewards else np.ascontiguousarray(ring, np.float64)
             rc = self._lib.mdpp_set_state_discrete(self._h, capi.nptr(hist), capi.nptr(steps), capi.nptr(ring))
             capi.check(self._lib, self._h, rc, "mdpp_set_state_discrete")
+            if self._irr:
+                irr = np.ascontiguousarray(np.asarray(state["curr_state"])[:, 1], dtype=np.int32)
+                rc = self._lib.mdpp_set_state_irrelevant(self._h, capi.nptr(irr))
+                capi.check(self._lib, self._h, rc, "mdpp_set_state_irrelevant")
             return
         sd = np.ascontiguousarray(state["state_derivatives"], dtype=np.float32)
         cur = np.ascontiguousarray(state["curr_state"], dtype=np.float32)

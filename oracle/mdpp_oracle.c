@@ -30,6 +30,11 @@ struct ora_discrete {
     np_pcg64 env_rng;        /* self._np_random */
     np_pcg64 space_rng;      /* self.observation_spaces[0].np_random */
     int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
+    /* irrelevant sub-space (irrelevant_features=True), rl_toy_env.py:2028-2035, :2063-2092 */
+    int irr, S1, A1, irr_state;
+    int32_t *P1;
+    double *init_cdf1;
+    np_pcg64 space1_rng;     /* self.observation_spaces[1].np_random */
 };
 
 static long ipow(long b, int e) { long r = 1; while (e-- > 0) r *= b; return r; }
@@ -59,8 +64,18 @@ ora_discrete *ora_d_create(int S, int A, int L, int delay, int every_n,
 
 void ora_d_destroy(ora_discrete *e) {
     if (!e) return;
-    free(e->P); free(e->rtable); free(e->is_term); free(e->init_cdf); free(e);
+    free(e->P); free(e->rtable); free(e->is_term); free(e->init_cdf); free(e->P1); free(e->init_cdf1); free(e);
 }
+
+void ora_d_set_irrelevant(ora_discrete *e, int S1, int A1, const int32_t *P1, const double *init_dist1) {
+    e->irr = 1; e->S1 = S1; e->A1 = A1;
+    e->P1 = (int32_t *)malloc(sizeof(int32_t) * S1 * A1);
+    memcpy(e->P1, P1, sizeof(int32_t) * S1 * A1);
+    e->init_cdf1 = (double *)malloc(sizeof(double) * S1);
+    np_build_cdf(init_dist1, S1, e->init_cdf1);
+}
+void ora_d_set_rng_irr(ora_discrete *e, const uint64_t w[6]) { np_pcg64_load(&e->space1_rng, w); }
+void ora_d_get_rng_irr(const ora_discrete *e, uint64_t w[6]) { np_pcg64_store(&e->space1_rng, w); }
 
 void ora_d_set_rng(ora_discrete *e, const uint64_t a[6], const uint64_t b[6]) {
     np_pcg64_load(&e->env_rng, a); np_pcg64_load(&e->space_rng, b);
@@ -132,6 +147,41 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
     uint8_t d = e->is_term[nxt];
     if (d) r += e->term_reward * e->scale;
     *obs = nxt; *reward = r; *done = d;
+}
+
+/* Tuple spaces: reset() draws the irrelevant start state right after the relevant one, from the
+ * same env generator (:2259-2264); step() moves the irrelevant part with its own table and its own
+ * P-noise generator after the reward was computed (:2063-2082).  obs = (relevant, irrelevant). */
+void ora_d_reset2(ora_discrete *e, int64_t out[2]) {
+    out[0] = ora_d_reset(e);
+    e->irr_state = np_choice_cdf(&e->env_rng, e->init_cdf1, e->S1);
+    out[1] = e->irr_state;
+}
+
+void ora_d_step2(ora_discrete *e, int action, int action_irr, int64_t obs[2], double *reward, uint8_t *done) {
+    ora_d_step(e, action, &obs[0], reward, done);
+    int nxt = e->P1[e->irr_state * e->A1 + action_irr];
+    if (e->has_p_noise) {
+        if (e->philox) np_philox_init(&e->space1_rng, e->ph_seed, e->ph_env, e->tick - 1, 4);
+        double cdf[256], probs[256];
+        for (int i = 0; i < e->S1; i++) probs[i] = 1.0 * e->p_noise / (double)(e->S1 - 1);
+        probs[nxt] = 1 - e->p_noise;
+        np_build_cdf(probs, e->S1, cdf);
+        nxt = np_choice_cdf(&e->space1_rng, cdf, e->S1);
+    }
+    e->irr_state = nxt;
+    obs[1] = nxt;
+}
+
+void ora_d_rollout2(ora_discrete *e, int T, const int32_t *actions /* [T][2] */, const uint8_t *reset_after,
+                    int64_t *obs /* [T][2] */, double *reward, uint8_t *done, int64_t *reset_obs /* [T][2] */) {
+    for (int t = 0; t < T; t++) {
+        ora_d_step2(e, actions[2 * t], actions[2 * t + 1], &obs[2 * t], &reward[t], &done[t]);
+        int rs = reset_after ? reset_after[t] : done[t];
+        int64_t ro[2] = {0, 0};
+        if (rs) ora_d_reset2(e, ro);
+        if (reset_obs) { reset_obs[2 * t] = ro[0]; reset_obs[2 * t + 1] = ro[1]; }
+    }
 }
 
 void ora_d_rollout(ora_discrete *e, int T, const int32_t *actions, const uint8_t *reset_after,

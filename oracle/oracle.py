@@ -43,6 +43,12 @@ def lib():
         L.ora_d_reset.argtypes = [vp]
         L.ora_d_step.argtypes = [vp, i32, vp, vp, vp]
         L.ora_d_rollout.argtypes = [vp, i32] + [vp] * 6
+        L.ora_d_set_irrelevant.argtypes = [vp, i32, i32, vp, vp]
+        L.ora_d_set_rng_irr.argtypes = [vp, vp]
+        L.ora_d_get_rng_irr.argtypes = [vp, vp]
+        L.ora_d_reset2.argtypes = [vp, vp]
+        L.ora_d_step2.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.ora_d_rollout2.argtypes = [vp, i32] + [vp] * 6
         L.ora_c_create.restype = vp
         L.ora_c_create.argtypes = ([i32, i32, vp, i32, f64, f64, f64, f64, vp, f64, i32, f64,
                                     i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
@@ -152,16 +158,40 @@ class DiscreteOracle:
         self._philox = True
         lib().ora_d_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
 
+    # ---- irrelevant sub-space (Tuple observations / actions): states and actions become pairs
+    def set_irrelevant(self, P_irr, init_dist_irr):
+        P1 = np.ascontiguousarray(P_irr, dtype=np.int32)
+        d1 = np.ascontiguousarray(init_dist_irr, dtype=np.float64)
+        self._irr = True
+        lib().ora_d_set_irrelevant(self.h, P1.shape[0], P1.shape[1], _p(P1), _p(d1))
+
+    def set_rng_irr(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        lib().ora_d_set_rng_irr(self.h, _p(w))
+
+    def get_rng_irr(self):
+        w = np.zeros(6, np.uint64)
+        lib().ora_d_get_rng_irr(self.h, _p(w))
+        return w
+
     def reset(self, explicit=True):
         """explicit=True mirrors a reset() call of its own (mdpp_reset); False an in-step reset."""
         if getattr(self, "_philox", False) and explicit:
             lib().ora_d_philox_explicit_reset(self.h)
+        if getattr(self, "_irr", False):
+            o = np.zeros(2, np.int64)
+            lib().ora_d_reset2(self.h, _p(o))
+            return int(o[0]), int(o[1])
         return int(lib().ora_d_reset(self.h))
 
     def step(self, action):
-        o = C.c_int64()
         r = C.c_double()
         d = C.c_uint8()
+        if getattr(self, "_irr", False):
+            o = np.zeros(2, np.int64)
+            lib().ora_d_step2(self.h, int(action[0]), int(action[1]), _p(o), C.byref(r), C.byref(d))
+            return (int(o[0]), int(o[1])), r.value, bool(d.value)
+        o = C.c_int64()
         lib().ora_d_step(self.h, int(action), C.byref(o), C.byref(r), C.byref(d))
         return o.value, r.value, bool(d.value)
 
@@ -169,6 +199,13 @@ class DiscreteOracle:
         actions = np.ascontiguousarray(actions, dtype=np.int32)
         T = actions.shape[0]
         ra = None if reset_after is None else np.ascontiguousarray(reset_after, dtype=np.uint8)
+        if getattr(self, "_irr", False):
+            obs = np.zeros((T, 2), np.int64)
+            rew = np.zeros(T, np.float64)
+            done = np.zeros(T, np.uint8)
+            ro = np.zeros((T, 2), np.int64)
+            lib().ora_d_rollout2(self.h, T, _p(actions), _p(ra), _p(obs), _p(rew), _p(done), _p(ro))
+            return obs, rew, done.astype(bool), ro
         obs = np.zeros(T, np.int64)
         rew = np.zeros(T, np.float64)
         done = np.zeros(T, np.uint8)

@@ -13,7 +13,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 with open(os.path.join(GOLDEN, "cases.json")) as _f:
     CASES = json.load(_f)
 
-DISCRETE = sorted(k for k in CASES if k.startswith("d_"))
+IRRELEVANT = sorted(k for k in CASES if k.startswith("d_irr"))      # Tuple spaces: pairs of states / actions
+DISCRETE = sorted(k for k in CASES if k.startswith("d_") and k not in IRRELEVANT)
 CONTINUOUS = sorted(k for k in CASES if k.startswith("c_"))
 IMAGE = sorted(k for k in CASES if k.startswith("i_"))
 
@@ -53,6 +54,8 @@ def discrete_oracle_from_golden(name, g, e):
                            g[f"terminal_states_{e}"], g["init_dist"][e],
                            p["transition_noise"], p["reward_noise"], p["reward_scale"],
                            p["reward_shift"], p["term_state_reward"])
+    if "P_irr" in g.files:
+        o.set_irrelevant(g["P_irr"][e], g["init_dist_irr"][e])
     return o
 
 

@@ -93,6 +93,8 @@ def _oracle_for(env, i):
         o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps, m.P,
                                m.reward_table(), m.terminal_states, m.init_dist, m.transition_noise,
                                m.reward_noise, m.reward_scale, m.reward_shift, m.term_state_reward)
+        if m.irrelevant:
+            o.set_irrelevant(m.P_irr, m.init_dist_irr)
     else:
         o = ora.ContinuousOracle(m.D, m.relevant_indices, m.order, m.inertia, m.time_unit,
                                  m.state_space_max, m.action_space_max, m.target_point,
@@ -128,6 +130,85 @@ def test_discrete_shared_mdp_4096_envs_vs_oracle(noise):
         assert np.array_equal(rew[:, i], er.astype(np.float32)), i
         we, ws = o.get_rng()
         assert np.array_equal(we[:4], end_env[i][:4]) and np.array_equal(ws[:4], end_sp[i][:4])
+    env.close()
+
+
+# ----------------------------------------------------------------------------- irrelevant features
+@pytest.mark.parametrize("name", gu.IRRELEVANT)
+def test_irrelevant_features_stepwise_vs_reference_golden(name):
+    """irrelevant_features=True (Tuple spaces): pairs of actions in, pairs of states out; the
+    reference's own trajectories incl. masked resets, and all four generators' end states."""
+    from mdp_playground_amd import _capi as capi
+    g = gu.load(name)
+    E, T, _ = g["action"].shape
+    env = _venv(autoreset="disabled", **_seeds_or_cfg(name))
+    assert np.array_equal(env._obs.cpu().numpy(), g["init_state"].astype(np.int64))
+    assert np.array_equal(env.get_rng_streams(0), g["rng_env"])
+    # (state and increment; the stale 32-bit buffer word of a generator that never draws 32-bit
+    # integers is not carried to the device)
+    assert np.array_equal(env.get_rng_streams(capi.STREAM_SPACE)[:, :4], g["rng_space"][:, :4])
+    assert np.array_equal(env.get_rng_streams(capi.STREAM_SPACE_IRR)[:, :4], g["rng_space_irr"][:, :4])
+    for t in range(T):
+        a = torch.as_tensor(g["action"][:, t].astype(np.int32), device=env.device)
+        obs, rew, term, trunc, _ = env.step(a)
+        assert np.array_equal(obs.cpu().numpy(), g["obs"][:, t].astype(np.int64)), (name, t)
+        assert np.array_equal(term.cpu().numpy(), g["done"][:, t]), (name, t)
+        assert np.array_equal(rew.cpu().numpy(), g["reward"][:, t].astype(np.float32)), (name, t)
+        ra = g["reset_after"][:, t]
+        if ra.any():
+            o, _ = env.reset(mask=torch.as_tensor(ra, device=env.device))
+            assert np.array_equal(o.cpu().numpy()[ra], g["reset_obs"][:, t][ra].astype(np.int64))
+    st = env.get_augmented_state()
+    assert np.array_equal(st["curr_state"], env._obs.cpu().numpy())
+    env.close()
+
+
+@pytest.mark.parametrize("name", [n for n in gu.IRRELEVANT if gu.CASES[n]["reset"] == "on_done"])
+def test_irrelevant_features_fused_rollout_vs_reference_golden(name):
+    g = gu.load(name)
+    env = _venv(autoreset="same_step", **_seeds_or_cfg(name))
+    acts = torch.as_tensor(np.ascontiguousarray(g["action"].transpose(1, 0, 2).astype(np.int32)), device=env.device)
+    obs, rew, term, trunc = env.rollout(acts)
+    exp = g["obs"].astype(np.int64).copy()
+    ra = g["reset_after"]
+    exp[ra] = g["reset_obs"].astype(np.int64)[ra]
+    assert np.array_equal(obs.cpu().numpy().transpose(1, 0, 2), exp)
+    assert np.array_equal(term.cpu().numpy().T, g["done"])
+    assert np.array_equal(rew.cpu().numpy().T, g["reward"].astype(np.float32))
+    env.close()
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_irrelevant_features_2048_envs_vs_oracle(rng):
+    """One shared MDP with an irrelevant sub-space and both noises, 2 048 instances with their own
+    streams (numpy PCG64, or Philox keyed by the global env id), fused rollout with same-step
+    autoreset and final observations through single steps; every 5th instance against the oracle."""
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(gu.CASES["d_irr_noise"]["config"], seed=21)
+    N, T, off = 2048, 80, 4096
+    kw = dict(rng="philox", philox_seed=5, env_id_offset=off) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    r = np.random.default_rng(8)
+    acts = np.stack([r.integers(0, 8, size=(T, N)), r.integers(0, 5, size=(T, N))], axis=2).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    for i in range(0, N, 5):
+        o = _oracle_for(env, i)
+        if rng == "philox":
+            o.set_philox(5, off + i)
+        else:
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+            o.set_rng_irr(env.seeded_streams[capi.STREAM_SPACE_IRR][i])
+        assert list(o.reset()) == [int(x) for x in init[i]]
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        exp = eo.copy()
+        exp[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], exp), i
+        assert np.array_equal(term[:, i], ed), i
+        assert np.array_equal(rew[:, i], er.astype(np.float32)), i
+        if rng == "numpy":
+            assert np.array_equal(o.get_rng_irr()[:4], env.get_rng_streams(capi.STREAM_SPACE_IRR)[i][:4])
     env.close()
 
 

@@ -9,7 +9,7 @@ import golden_util as gu
 from mdp_playground_amd import mdp
 
 
-@pytest.mark.parametrize("name", gu.DISCRETE + gu.IMAGE)
+@pytest.mark.parametrize("name", gu.DISCRETE + gu.IMAGE + gu.IRRELEVANT)
 def test_discrete_tables_match_reference(name):
     g = gu.load(name)
     E = g["action"].shape[0]
@@ -25,6 +25,11 @@ def test_discrete_tables_match_reference(name):
         mine = {k: v for k, v in m.rewardable_sequences.items() if len(k) == m.sequence_length}
         assert mine == keys
         assert np.array_equal(m.space_rng_words, g["rng_space"][e])
+        if name in gu.IRRELEVANT:
+            # second table and the generator it was drawn from (re-seeded by the Tuple space)
+            assert np.array_equal(m.P_irr, g["P_irr"][e])
+            assert np.array_equal(m.init_dist_irr, g["init_dist_irr"][e])
+            assert np.array_equal(m.space_irr_rng_words, g["rng_space_irr"][e])
         names = ["env", "relevant_state_space", "relevant_action_space", "irrelevant_state_space",
                  "irrelevant_action_space", "state_space", "action_space", "image_representations"]
         for k, v in zip(names, g["seed_dict"][e]):

@@ -35,6 +35,30 @@ def test_discrete_rollouts_bit_exact(name):
         assert np.array_equal(ro[ra], g["reset_obs"][e][ra].astype(np.int64))
 
 
+@pytest.mark.parametrize("name", gu.IRRELEVANT)
+def test_discrete_irrelevant_features_rollouts_bit_exact(name):
+    """irrelevant_features=True: Tuple observations/actions, a second transition table and a
+    second P-noise generator (observation_spaces[1]); reset() draws both start states from the env
+    generator (rl_toy_env.py:2028-2035, :2063-2092, :2255-2264)."""
+    g = gu.load(name)
+    E, T, _ = g["action"].shape
+    for e in range(E):
+        o = gu.discrete_oracle_from_golden(name, g, e)
+        seed_env = int(g["seed_dict"][e][0])
+        fresh = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed_env)))
+        o.set_rng(ora.pcg_words(fresh), g["rng_space"][e])
+        o.set_rng_irr(g["rng_space_irr"][e])
+        s0 = o.reset()
+        assert list(s0) == [int(x) for x in g["init_state"][e]]
+        assert np.array_equal(o.get_rng()[0], g["rng_env"][e])
+        obs, rew, done, ro = o.rollout(g["action"][e], g["reset_after"][e])
+        assert np.array_equal(obs, g["obs"][e].astype(np.int64)), name
+        assert np.array_equal(done, g["done"][e]), name
+        assert np.array_equal(rew.view(np.uint64), g["reward"][e].view(np.uint64)), name
+        ra = g["reset_after"][e]
+        assert np.array_equal(ro[ra], g["reset_obs"][e][ra].astype(np.int64))
+
+
 @pytest.mark.parametrize("name", gu.CONTINUOUS)
 def test_continuous_rollouts_bit_exact(name):
     g = gu.load(name)

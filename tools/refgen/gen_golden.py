@@ -116,6 +116,28 @@ CASES = {
                     seed={"env": 0, "relevant_state_space": 8,
                           "relevant_action_space": 8}),
         seeds=[None], T=6, reset="never", actions=[6, 2, 2, 4, 4, 6]),
+    # --- discrete with an irrelevant sub-space (Tuple spaces; second table, second P-noise stream)
+    "d_irr_plain": dict(     # the config of the reference's test_discrete_irr_features (:1729-1774)
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=[8, 10], action_space_size=[8, 10],
+                    irrelevant_features=True, reward_density=0.25, make_denser=True,
+                    terminal_state_density=0.25, maximally_connected=True,
+                    repeats_in_sequences=False, delay=1, sequence_length=1,
+                    reward_scale=1.0, generate_random_mdp=True),
+        seeds=list(range(4)), T=120, reset="on_done"),
+    "d_irr_noise": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=[8, 5], action_space_size=[8, 5],
+                    irrelevant_features=True, delay=2, sequence_length=2,
+                    transition_noise=0.3, reward_noise=0.2, reward_scale=1.5,
+                    reward_shift=0.25, term_state_reward=-1.0),
+        seeds=list(range(6)), T=200, reset="mixed"),
+    "d_irr_notmax": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=[6, 12], action_space_size=[6, 4],
+                    irrelevant_features=True, delay=0, sequence_length=3,
+                    maximally_connected=False, transition_noise=0.1),
+        seeds=list(range(4)), T=150, reset="on_done"),
     # --- continuous ------------------------------------------------------
     "c_cfg3": dict(config=CFG3, seeds=list(range(8)), T=250, reset="on_done",
                    bad_action_every=37),
@@ -180,7 +202,8 @@ def run_case(name, case):
                            "reset_obs", "curr_state")}
     tables = {k: [] for k in ("P", "terminal_states", "init_dist", "rew_keys",
                               "rew_vals", "rng_env", "rng_space", "rng_image",
-                              "init_obs", "init_state", "seed_dict", "sd")}
+                              "init_obs", "init_state", "seed_dict", "sd",
+                              "P_irr", "init_dist_irr", "rng_space_irr")}
     seed_names = ["env", "relevant_state_space", "relevant_action_space",
                   "irrelevant_state_space", "irrelevant_action_space", "state_space",
                   "action_space", "image_representations"]
@@ -211,6 +234,12 @@ def run_case(name, case):
             tables["rew_keys"].append(np.array(keys, dtype=np.int64).reshape(-1, L))
             tables["rew_vals"].append(np.array(vals, dtype=np.float64))
             tables["rng_space"].append(pcg_state(env.observation_spaces[0].np_random))
+            if env.irrelevant_features:
+                tables["P_irr"].append(np.array(
+                    env.config["transition_function_irrelevant"].tolist(), dtype=np.int64))
+                tables["init_dist_irr"].append(
+                    np.array(env.config["irrelevant_init_state_dist"], dtype=np.float64))
+                tables["rng_space_irr"].append(pcg_state(env.observation_spaces[1].np_random))
             if image:
                 tables["rng_image"].append(pcg_state(env.observation_space.np_random))
         else:
@@ -222,7 +251,10 @@ def run_case(name, case):
         sdrec = []
         for t in range(T):
             if kind == "discrete":
-                if "actions" in case:
+                if env.irrelevant_features:
+                    a = [int(arng.integers(env.action_space_size[0])),
+                         int(arng.integers(env.action_space_size[1]))]
+                elif "actions" in case:
                     a = int(case["actions"][t])
                 else:
                     a = int(arng.integers(env.action_space_size[0]))
