@@ -65,6 +65,16 @@ WORKLOADS = {
                              action_space_max=1, transition_dynamics_order=2, inertia=1,
                              time_unit=0.1, transition_noise=0.05, reward_noise=0.05,
                              make_denser=True, reward_function="move_to_a_point", seed=0)),
+    # SURVEY.md §8f rank 2 (not a BASELINE config): the reference's test_grid_env shape, 65 536 envs
+    "grid": dict(kind="grid", envs=65536, alg_bytes_fused=30, alg_bytes_step=62,
+                 config=dict(state_space_type="grid", grid_shape=(8, 8), reward_function="move_to_a_point",
+                             make_denser=True, target_point=[5, 5], reward_scale=3.0,
+                             term_state_reward=-0.25, seed=0)),
+    # the irrelevant-sub-space variant of cfg2's MDP size (Tuple spaces), also §8f rank 2
+    "cfg2_irr": dict(kind="discrete", envs=65536, alg_bytes_fused=30, alg_bytes_step=62,
+                     config=dict(state_space_type="discrete", action_space_type="discrete",
+                                 state_space_size=[8, 8], action_space_size=[8, 8],
+                                 irrelevant_features=True, delay=4, sequence_length=3, seed=0)),
 }
 
 
@@ -73,7 +83,15 @@ def make_actions(wl, K, N, device, seed):
     g.manual_seed(seed)
     if wl["kind"] == "discrete":
         A = wl["config"]["action_space_size"]
+        if isinstance(A, (list, tuple)):       # irrelevant_features: (relevant, irrelevant) pairs
+            return torch.stack([torch.randint(0, a, (K, N), generator=g, device=device, dtype=torch.int32)
+                                for a in A], dim=2).contiguous()
         return torch.randint(0, A, (K, N), generator=g, device=device, dtype=torch.int32)
+    if wl["kind"] == "grid":                    # one +-1 (or a noop) in a random dimension
+        G = len(wl["config"]["grid_shape"]) * (2 if wl["config"].get("irrelevant_features") else 1)
+        which = torch.randint(0, G, (K, N, 1), generator=g, device=device)
+        val = torch.randint(-1, 2, (K, N, 1), generator=g, device=device, dtype=torch.int32)
+        return torch.zeros((K, N, G), dtype=torch.int32, device=device).scatter_(2, which, val)
     D = wl["config"]["state_space_dim"]
     amax = wl["config"]["action_space_max"]
     return (torch.rand((K, N, D), generator=g, device=device, dtype=torch.float32) * 2 - 1) * amax
@@ -90,12 +108,25 @@ def cpu_baseline(wl, seconds=12.0):
     rng = np.random.default_rng(12345)
     envs = []
     for i in range(n_envs):
+        if m.kind == "grid":
+            o = ora.GridOracle(m.grid_shape, m.target_point, m.make_denser, m.transition_noise,
+                               m.reward_noise, m.reward_every_n_steps, m.reward_scale, m.reward_shift,
+                               m.term_state_reward)
+            o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator((m.seed_dict["env"] or 0) + i)),
+                      mdp_mod.pcg64_words(mdp_mod.new_generator(m.seed_dict["state_space"] + i)),
+                      mdp_mod.pcg64_words(mdp_mod.new_generator(m.seed_dict["action_space"] + i)))
+            o.reset()
+            envs.append(o)
+            continue
         if m.kind == "discrete":
             o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps,
                                    m.P, m.reward_table(), m.terminal_states, m.init_dist,
                                    m.transition_noise, m.reward_noise, m.reward_scale,
                                    m.reward_shift, m.term_state_reward)
-            sp = mdp_mod.new_generator(m.seed_dict["relevant_state_space"] + i)
+            sp = mdp_mod.new_generator(m.space_seeds[0] + i)
+            if m.irrelevant:
+                o.set_irrelevant(m.P_irr, m.init_dist_irr)
+                o.set_rng_irr(mdp_mod.pcg64_words(mdp_mod.new_generator(m.space_seeds[1] + i)))
         else:
             o = ora.ContinuousOracle(m.D, m.relevant_indices, m.order, m.inertia, m.time_unit,
                                      m.state_space_max, m.action_space_max, m.target_point,
@@ -108,7 +139,13 @@ def cpu_baseline(wl, seconds=12.0):
                   mdp_mod.pcg64_words(sp))
         o.reset()
         envs.append(o)
-    if m.kind == "discrete":
+    if m.kind == "grid":
+        G = len(m.grid_shape)
+        acts = np.zeros((chunk, G), np.int32)
+        acts[np.arange(chunk), rng.integers(0, G, size=chunk)] = rng.integers(-1, 2, size=chunk)
+    elif m.kind == "discrete" and m.irrelevant:
+        acts = np.stack([rng.integers(0, m.A, size=chunk), rng.integers(0, m.A_irr, size=chunk)], axis=1).astype(np.int32)
+    elif m.kind == "discrete":
         acts = rng.integers(0, m.A, size=chunk).astype(np.int32)
     else:
         acts = rng.uniform(-m.action_space_max, m.action_space_max, size=(chunk, m.D)).astype(np.float32)
@@ -183,7 +220,8 @@ def main():
     cpu_all = None
     wl0 = WORKLOADS[args.workload]
     if (rank == 0 and world == 1 and not args.no_cpu_baseline and wl0["kind"] == "discrete"
-            and not wl0["config"].get("image_representations")):
+            and not wl0["config"].get("image_representations")
+            and not wl0["config"].get("irrelevant_features")):
         try:
             cpu_all = cpu_baseline_all_cores(args.workload)
         except Exception as e:          # a reported extra, never fatal

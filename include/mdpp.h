@@ -21,6 +21,8 @@
  *                                 (transition_function :1577-1725, reward_function :1782-1990,
  *                                  ImageMultiDiscrete.get_image_representation
  *                                  spaces/image_multi_discrete.py:129-288)
+ *                                 (grid: transition :1727-1778, reward :1947-1965,
+ *                                  GridActionSpace spaces/grid_action_space.py:13-39)
  *   mdpp_step_n                   a Python loop of K step() calls (e.g. example.py:69-86)
  *   mdpp_get_state/set_state      get/set_augmented_state      rl_toy_env.py:2127-2215
  *                                 (plus the RNG streams, ring and counters the reference omits)
@@ -33,22 +35,23 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 2
+#define MDPP_ABI_VERSION 3
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
 
-enum { MDPP_KIND_DISCRETE = 0, MDPP_KIND_CONTINUOUS = 1 };
+enum { MDPP_KIND_DISCRETE = 0, MDPP_KIND_CONTINUOUS = 1, MDPP_KIND_GRID = 2 };
 enum { MDPP_RNG_NUMPY_PCG64 = 0,   /* per-env numpy Generator(PCG64) streams: reference-exact */
        MDPP_RNG_PHILOX = 1 };      /* counter-based Philox4x32-10 keyed by (seed, global env id) */
 enum { MDPP_AUTORESET_DISABLED = 0, MDPP_AUTORESET_SAME_STEP = 1 };
 enum { MDPP_OBS_I64 = 0, MDPP_OBS_I32 = 1, MDPP_OBS_F32 = 2, MDPP_OBS_IMAGE_U8 = 3 };
 /* RNG streams, named after the generator object they mirror in the reference */
 enum { MDPP_STREAM_ENV = 0,        /* RLToyEnv._np_random: reset draw, reward noise, continuous P-noise */
-       MDPP_STREAM_SPACE = 1,      /* discrete: observation_spaces[0] (P-noise); continuous: feature_space (reset) */
+       MDPP_STREAM_SPACE = 1,      /* discrete: observation_spaces[0] (P-noise); continuous, grid: feature_space (reset) */
        MDPP_STREAM_IMAGE = 2,      /* observation_space (ImageMultiDiscrete transforms) */
        MDPP_STREAM_SPACE_IRR = 3,  /* discrete, irrelevant_features: observation_spaces[1] (its P-noise) */
-       MDPP_NUM_STREAMS = 4 };
+       MDPP_STREAM_ACTION = 4,     /* grid: action_space (GridActionSpace.sample of a noisy action) */
+       MDPP_NUM_STREAMS = 5 };
 /* per-env status bits (mdpp_status) */
 enum { MDPP_STATUS_BAD_ACTION = 1u,     /* discrete: action out of range (reference: IndexError);
                                            continuous: action rejected by Box.contains -> "stay" (:1671) */
@@ -104,6 +107,12 @@ typedef struct {
     float box_lo[MDPP_MAX_BOXES * MDPP_MAX_DIM];
     float box_hi[MDPP_MAX_BOXES * MDPP_MAX_DIM];
 
+    /* ---- grid (move_to_a_point), rl_toy_env.py:1727-1778, :1947-1965; uses make_denser,
+     * has_transition_noise / transition_noise (probability of a re-drawn action) from above ---- */
+    int32_t grid_dims;          /* 2, or 4 with irrelevant_features (the grid repeated, :604-608) */
+    int32_t grid_shape[4];
+    int32_t grid_target[2];
+
     /* ---- image observations for discrete envs (ImageMultiDiscrete) ---- */
     int32_t image;              /* 1: obs is uint8[W][H][1] per env */
     int32_t img_w, img_h;
@@ -154,8 +163,9 @@ int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words_host);
  * obs_dev receives the new first observation of the reset envs (others untouched). */
 int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, void *stream);
 
-/* step(): actions int32[N] (discrete; int32[N][2] with cfg.irrelevant) or float32[N][D]
- * (continuous); obs per cfg.obs_dtype ([N], [N][2] with cfg.irrelevant, [N][D] or [N][W][H]);
+/* step(): actions int32[N] (discrete; int32[N][2] with cfg.irrelevant), float32[N][D]
+ * (continuous) or int32[N][grid_dims] (grid); obs per cfg.obs_dtype ([N], [N][2] with
+ * cfg.irrelevant, [N][D], [N][grid_dims] or [N][W][H]);
  * reward float32[N]; terminated/truncated uint8[N].
  * final_obs_dev (nullable): with same-step autoreset, the last observation of episodes that ended. */
 int mdpp_step(mdpp_env *h, const void *actions_dev, void *obs_dev, float *reward_dev,
@@ -176,6 +186,10 @@ int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist_host, const int32_t
 /* cfg.irrelevant: the irrelevant part of curr_state, int32[N] (curr_state[1], :2089) */
 int mdpp_get_state_irrelevant(mdpp_env *h, int32_t *irr_host);
 int mdpp_set_state_irrelevant(mdpp_env *h, const int32_t *irr_host);
+/* Grid: cells int32[N][grid_dims], steps int32[N], reached uint8[N] (the latched target flag, :1776) */
+int mdpp_get_state_grid(mdpp_env *h, int32_t *cells_host, int32_t *steps_host, uint8_t *reached_host);
+int mdpp_set_state_grid(mdpp_env *h, const int32_t *cells_host, const int32_t *steps_host,
+                        const uint8_t *reached_host);
 int mdpp_get_state_continuous(mdpp_env *h, float *derivs_host, float *cur_host, int32_t *steps_host,
                               double *ring_host, uint8_t *ring_is32_host, uint8_t *reached_host);
 int mdpp_set_state_continuous(mdpp_env *h, const float *derivs_host, const float *cur_host,

@@ -6,13 +6,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 2
+MDPP_ABI_VERSION = 3
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
-KIND_DISCRETE, KIND_CONTINUOUS = 0, 1
+KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
 RNG_NUMPY_PCG64, RNG_PHILOX = 0, 1
 AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1
 OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
-STREAM_ENV, STREAM_SPACE, STREAM_IMAGE, STREAM_SPACE_IRR = 0, 1, 2, 3
+STREAM_ENV, STREAM_SPACE, STREAM_IMAGE, STREAM_SPACE_IRR, STREAM_ACTION = 0, 1, 2, 3, 4
 STATUS_BAD_ACTION = 1
 
 EXPORTS = [
@@ -22,6 +22,7 @@ EXPORTS = [
     "mdpp_set_state_discrete", "mdpp_get_state_continuous", "mdpp_set_state_continuous",
     "mdpp_status", "mdpp_timer_begin", "mdpp_timer_end",
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
+    "mdpp_get_state_grid", "mdpp_set_state_grid",
 ]
 
 
@@ -44,6 +45,7 @@ class MdppConfig(C.Structure):
         ("target_radius", C.c_double), ("action_loss_weight", C.c_double),
         ("target", C.c_float * MAX_DIM), ("n_boxes", C.c_int32),
         ("box_lo", C.c_float * (MAX_BOXES * MAX_DIM)), ("box_hi", C.c_float * (MAX_BOXES * MAX_DIM)),
+        ("grid_dims", C.c_int32), ("grid_shape", C.c_int32 * 4), ("grid_target", C.c_int32 * 2),
         ("image", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32),
         ("img_has_scale", C.c_int32), ("img_has_shift", C.c_int32), ("img_has_rotate", C.c_int32),
         ("img_has_flip", C.c_int32), ("img_sh_quant", C.c_int32), ("img_ro_quant", C.c_int32),
@@ -93,6 +95,8 @@ def load():
     L.mdpp_upload_discrete_irrelevant.argtypes = [vp] * 4
     L.mdpp_get_state_irrelevant.argtypes = [vp, vp]
     L.mdpp_set_state_irrelevant.argtypes = [vp, vp]
+    L.mdpp_get_state_grid.argtypes = [vp] * 4
+    L.mdpp_set_state_grid.argtypes = [vp] * 4
     L.mdpp_status.argtypes = [vp, vp]
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]

@@ -115,9 +115,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
             if (s == MDPP_STREAM_IMAGE && !cfg->image) continue;
             if (s == MDPP_STREAM_SPACE_IRR && !(cfg->kind == MDPP_KIND_DISCRETE && cfg->irrelevant)) continue;
+            if (s == MDPP_STREAM_ACTION && cfg->kind != MDPP_KIND_GRID) continue;
             TRY(alloc_zero(h, &h->d_rng_s[s], N * 16));
             TRY(alloc_zero(h, &h->d_rng_inc[s], N * 16));
         }
+        if (cfg->kind == MDPP_KIND_GRID) TRY(alloc_zero(h, &h->d_rng_half, N * 8));   // action stream's 32-bit half
         if (cfg->image) {
             TRY(alloc_zero(h, &h->d_rng_half, N * 8));
             // scratch of one batch of img_chunk env steps: states in, transform records in between
@@ -272,6 +274,35 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
         h->tables_ready = true;
+    } else if (cfg->kind == MDPP_KIND_GRID) {
+        bool ok = (cfg->grid_dims == 2 || cfg->grid_dims == 4) && cfg->delay == 0 && !cfg->image;
+        for (int d = 0; ok && d < cfg->grid_dims; d++) ok = cfg->grid_shape[d] >= 1 && cfg->grid_shape[d] <= 254;
+        if (!ok) {
+            g_create_err = "mdpp_create: grid needs 2 (or 4) dimensions of 1..254 cells, delay 0, no image observations";
+            free_all(h); delete h; return MDPP_EUNSUPPORTED;
+        }
+        TRY(alloc_zero(h, &h->d_state, N * sizeof(uint4)));
+        GridArgs &a = h->gargs;
+        memset(&a, 0, sizeof(a));
+        a.N = cfg->num_envs; a.G = cfg->grid_dims;
+        for (int d = 0; d < cfg->grid_dims; d++) a.shape[d] = cfg->grid_shape[d];
+        a.target[0] = cfg->grid_target[0]; a.target[1] = cfg->grid_target[1];
+        a.make_denser = cfg->make_denser; a.has_p_noise = cfg->has_transition_noise;
+        a.has_r_noise = cfg->has_reward_noise; a.every_n = cfg->every_n;
+        a.autoreset = cfg->autoreset; a.max_steps = cfg->max_episode_steps;
+        a.obs_i32 = (cfg->obs_dtype == MDPP_OBS_I32);
+        a.philox = (cfg->rng_mode == MDPP_RNG_PHILOX);
+        a.philox_seed = cfg->philox_seed; a.env_id_offset = cfg->env_id_offset;
+        a.p_noise = cfg->transition_noise; a.r_noise = cfg->reward_noise;
+        a.scale = cfg->reward_scale; a.shift = cfg->reward_shift;
+        a.term_add = cfg->term_state_reward * cfg->reward_scale;
+        a.state = (uint4 *)h->d_state;
+        a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
+        a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
+        a.act_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ACTION]; a.act_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ACTION];
+        a.act_half = (uint2 *)h->d_rng_half;
+        a.status = (uint32_t *)h->d_status;
+        h->tables_ready = true;      // a grid env has no tables
     } else {
         g_create_err = "mdpp_create: unknown kind"; free_all(h); delete h; return MDPP_EINVAL;
     }
@@ -350,6 +381,45 @@ extern "C" int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P1, c
     return MDPP_OK;
 }
 
+extern "C" int mdpp_get_state_grid(mdpp_env *h, int32_t *cells, int32_t *steps, uint8_t *reached) {
+    if (!h || !cells || !steps || !reached) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_GRID) return fail(h, MDPP_EINVAL, "get_state_grid: not a grid handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    const int G = h->cfg.grid_dims;
+    std::vector<uint32_t> st(4 * N);
+    HIPCHK(h, hipMemcpy(st.data(), h->d_state, N * 16, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        for (int d = 0; d < G; d++) cells[i * G + d] = (int32_t)((st[4 * i] >> (8 * d)) & 0xFF);
+        steps[i] = (int32_t)st[4 * i + 1];
+        reached[i] = (uint8_t)(st[4 * i + 2] & 1u);
+    }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_set_state_grid(mdpp_env *h, const int32_t *cells, const int32_t *steps, const uint8_t *reached) {
+    if (!h || !cells || !steps) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_GRID) return fail(h, MDPP_EINVAL, "set_state_grid: not a grid handle");
+    const size_t N = (size_t)h->cfg.num_envs;
+    const int G = h->cfg.grid_dims;
+    std::vector<uint32_t> st(4 * N, 0);
+    for (size_t i = 0; i < N; i++) {
+        for (int d = 0; d < G; d++) {
+            // a reset can leave the index one past the grid (Box.sample of an int box), like the reference
+            if (cells[i * G + d] < 0 || cells[i * G + d] > h->cfg.grid_shape[d])
+                return fail(h, MDPP_EINVAL, "set_state_grid: cell out of range");
+            st[4 * i] |= (uint32_t)cells[i * G + d] << (8 * d);
+        }
+        st[4 * i + 1] = (uint32_t)steps[i];
+        st[4 * i + 2] = reached ? (uint32_t)(reached[i] & 1u) : 0u;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(h->d_state, st.data(), N * 16, hipMemcpyHostToDevice));
+    return MDPP_OK;
+}
+
 extern "C" int mdpp_get_state_irrelevant(mdpp_env *h, int32_t *irr) {
     if (!h || !irr) return MDPP_EINVAL;
     if (h->cfg.kind != MDPP_KIND_DISCRETE || !h->cfg.irrelevant) return fail(h, MDPP_EINVAL, "get_state_irrelevant: no irrelevant sub-space");
@@ -385,7 +455,7 @@ extern "C" int mdpp_seed_streams(mdpp_env *h, int stream, const uint64_t *words)
     }
     HIPCHK(h, hipMemcpy(h->d_rng_s[stream], st.data(), N * 16, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_rng_inc[stream], inc.data(), N * 16, hipMemcpyHostToDevice));
-    if (stream == MDPP_STREAM_IMAGE && h->d_rng_half)
+    if ((stream == MDPP_STREAM_IMAGE || stream == MDPP_STREAM_ACTION) && h->d_rng_half)
         HIPCHK(h, hipMemcpy(h->d_rng_half, half.data(), N * 8, hipMemcpyHostToDevice));
     if (stream == MDPP_STREAM_ENV && h->cfg.kind == MDPP_KIND_DISCRETE) {
         // start states drawn ahead from the old stream are void: empty every env's queue
@@ -407,7 +477,7 @@ extern "C" int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words) {
     std::vector<uint32_t> half(2 * N, 0);
     HIPCHK(h, hipMemcpy(st.data(), h->d_rng_s[stream], N * 16, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(inc.data(), h->d_rng_inc[stream], N * 16, hipMemcpyDeviceToHost));
-    if (stream == MDPP_STREAM_IMAGE && h->d_rng_half)
+    if ((stream == MDPP_STREAM_IMAGE || stream == MDPP_STREAM_ACTION) && h->d_rng_half)
         HIPCHK(h, hipMemcpy(half.data(), h->d_rng_half, N * 8, hipMemcpyDeviceToHost));
     std::vector<uint32_t> rec;
     const bool queued = stream == MDPP_STREAM_ENV && h->cfg.kind == MDPP_KIND_DISCRETE && h->dargs.fast_ok;
@@ -436,6 +506,8 @@ static int check_ready(mdpp_env *h, const char *what) {
             return fail(h, MDPP_ESTATE, std::string(what) + ": image RNG stream not seeded");
         if (h->cfg.image && !h->img_ready)
             return fail(h, MDPP_ESTATE, std::string(what) + ": image templates not uploaded");
+        if (h->cfg.kind == MDPP_KIND_GRID && !h->streams_ready[MDPP_STREAM_ACTION])
+            return fail(h, MDPP_ESTATE, std::string(what) + ": action-space RNG stream not seeded");
         if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->streams_ready[MDPP_STREAM_SPACE_IRR])
             return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space RNG stream not seeded");
     }
@@ -458,6 +530,7 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
         }
         return launch_discrete_reset(h, mask_dev, obs_dev, s);
     }
+    if (h->cfg.kind == MDPP_KIND_GRID) return launch_grid_reset(h, mask_dev, obs_dev, s);
     return launch_continuous_reset(h, mask_dev, (float *)obs_dev, s);
 }
 
@@ -491,6 +564,8 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
         }
         return launch_discrete_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
     }
+    if (h->cfg.kind == MDPP_KIND_GRID)
+        return launch_grid_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
     return launch_continuous_step(h, K, (const float *)actions, (float *)obs, reward, term, trunc,
                                   (float *)final_obs, s);
 }

@@ -15,6 +15,7 @@ constexpr uint32_t kRingPyZero = 0x7FC0DE1Au; // float32 ring slot holding Pytho
 // Philox stream ids beyond the MDPP_STREAM_* indices (keys are (seed, env id, tick, stream id)):
 constexpr uint32_t kPhiloxResetStream = 3;    // an explicit reset(), keyed by the reset tick
 constexpr uint32_t kPhiloxIrrStream = 4;      // P-noise of the irrelevant sub-space
+constexpr uint32_t kPhiloxActionStream = 5;   // grid: the re-drawn noisy action
 
 // ---- discrete: kernel arguments (passed by value; wave-uniform => SGPRs) -------------------
 struct DiscreteArgs {
@@ -94,6 +95,22 @@ struct ContinuousArgs {
     double inv_fact[MDPP_MAX_ORDER + 1];
 };
 
+// ---- grid (mdpp_grid.hip) ----
+struct GridArgs {
+    int32_t N, G;               // envs; state dimensions (2 or 4)
+    int32_t shape[4], target[2];
+    int32_t make_denser, has_p_noise, has_r_noise, every_n;
+    int32_t autoreset, max_steps, obs_i32, philox;
+    uint32_t tick;
+    uint64_t philox_seed;
+    int64_t env_id_offset;
+    double p_noise, r_noise, scale, shift, term_add;
+    uint4 *state;               // {cells (one byte per dimension), steps, flags: bit0 reached target, -}
+    ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc, *act_s, *act_inc;
+    uint2 *act_half;            // numpy's buffered 32-bit half of the action stream
+    uint32_t *status;
+};
+
 } // namespace mdpp
 
 // The handle.  Plain struct; all members are host-side bookkeeping + device allocations.
@@ -121,6 +138,7 @@ struct mdpp_env {
     hipEvent_t ev0, ev1;
     mdpp::DiscreteArgs dargs;
     mdpp::ContinuousArgs cargs;
+    mdpp::GridArgs gargs;
 };
 
 namespace mdpp {
@@ -137,6 +155,9 @@ bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, 
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
+int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
+                     uint8_t *trunc, void *final_obs, hipStream_t s);
+int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
 int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s);

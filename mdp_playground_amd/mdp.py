@@ -145,6 +145,17 @@ class ContinuousMDP(CommonParams):
     box_hi: np.ndarray = None
 
 
+@dataclass
+class GridMDP(CommonParams):
+    kind: str = "grid"
+    grid_shape: tuple = ()                   # doubled with irrelevant_features (:604-608)
+    n_rel: int = 2                           # leading dimensions the reward looks at
+    target_point: list = None
+    make_denser: bool = False
+    transition_noise: float | None = None    # probability of replacing the action (:1736)
+    terminal_states: list = None             # kept for the record: they never terminate, see build_grid
+
+
 def _require(cond, msg):
     if not cond:
         raise AssertionError(msg)
@@ -416,6 +427,50 @@ def build_continuous(config) -> ContinuousMDP:
         transition_noise=None if tn is None else float(tn), box_lo=box_lo, box_hi=box_hi, **common)
 
 
+def build_grid(config) -> GridMDP:
+    """Grid envs, rl_toy_env.py:539-541, :604-608, :655-657, :780-811, :958-987.  What the reference
+    actually supports is narrower than its docstring, and the limits are kept:
+      * exactly 2 grid dimensions (the augmented state keeps 2 coordinates, :2055-2056, and the
+        reward subtracts the target from them, :1949-1958);
+      * delay 0 and sequence_length 1 (otherwise reward_function builds a ragged np.array out of
+        NaN placeholders and coordinate lists and raises, :1949);
+      * list-form terminal_states never terminate an episode: they become Box(dtype=int64) spaces
+        and is_terminal_state() asks them whether a float64 array is contained (:973-982), which
+        gymnasium's Box.contains answers with False for any non-castable dtype.  Only reaching
+        the target ends an episode (:1770-1776)."""
+    config = copy.deepcopy(config)
+    if config.get("use_custom_mdp", False):
+        raise NotImplementedError("use_custom_mdp is not on the device path")
+    sd, _env_rng = _seed_dict(config)
+    common = _common(config, "grid", sd)
+    _require("grid_shape" in config, "grid envs need grid_shape")
+    shape = tuple(int(g) for g in config["grid_shape"])
+    if config.get("reward_function") != "move_to_a_point":
+        raise NotImplementedError("grid envs: only reward_function='move_to_a_point' exists (:79)")
+    if "make_denser" not in config:
+        raise AttributeError("'RLToyEnv' object has no attribute 'make_denser'")   # what the reference raises (:1949)
+    if len(shape) != 2:
+        raise NotImplementedError("the reference's grid reward only works for 2-D grids (:1949-1958 broadcast error)")
+    if common["delay"] != 0 or common["sequence_length"] != 1:
+        raise NotImplementedError("the reference's grid reward raises for delay > 0 or sequence_length > 1 (:1949)")
+    if callable(config.get("terminal_states")):
+        raise NotImplementedError("callable terminal_states runs on the host only")
+    if config.get("image_representations", False):
+        raise NotImplementedError("ImageContinuous observations are not built yet (SURVEY.md §8f rank 3)")
+    tn = config.get("transition_noise", None)
+    if callable(tn):
+        raise NotImplementedError("callable transition_noise runs on the host only")
+    target = [int(x) for x in config["target_point"]]
+    _require(len(target) == 2, "target_point must have one coordinate per grid dimension")
+    if max(shape) > 254:
+        raise NotImplementedError("grid sides up to 254 cells")
+    irr = bool(config.get("irrelevant_features", False))
+    return GridMDP(kind="grid", grid_shape=shape * 2 if irr else shape, n_rel=2, target_point=target,
+                   make_denser=bool(config["make_denser"]),
+                   transition_noise=None if not tn else float(tn),
+                   terminal_states=config.get("terminal_states"), **common)
+
+
 def build_mdp(config):
     """Dispatch on state_space_type like rl_toy_env.py:339,499-543."""
     if config == {}:
@@ -428,5 +483,5 @@ def build_mdp(config):
     if kind == "continuous":
         return build_continuous(config)
     if kind == "grid":
-        raise NotImplementedError("grid envs are not built yet (SURVEY.md §8f rank 2)")
+        return build_grid(config)
     raise ValueError("Unknown state_space_type")

@@ -74,7 +74,8 @@ class RLToyVectorEnv:
 
         cfg = capi.MdppConfig()
         cfg.abi_version = capi.MDPP_ABI_VERSION
-        cfg.kind = capi.KIND_DISCRETE if m.kind == "discrete" else capi.KIND_CONTINUOUS
+        cfg.kind = {"discrete": capi.KIND_DISCRETE, "continuous": capi.KIND_CONTINUOUS,
+                    "grid": capi.KIND_GRID}[m.kind]
         cfg.num_envs = self.num_envs
         cfg.env_id_offset = self.env_id_offset
         cfg.rng_mode = capi.RNG_NUMPY_PCG64 if rng == "numpy" else capi.RNG_PHILOX
@@ -91,8 +92,11 @@ class RLToyVectorEnv:
         cfg.reward_scale = float(m.reward_scale)
         cfg.reward_shift = float(m.reward_shift)
         cfg.term_state_reward = float(m.term_state_reward)
+        self._irr = False
         if m.kind == "discrete":
             self._init_discrete(cfg)
+        elif m.kind == "grid":
+            self._init_grid(cfg)
         else:
             self._init_continuous(cfg)
         h = C.c_void_p()
@@ -203,6 +207,26 @@ class RLToyVectorEnv:
                                                        capi.nptr(cy))
             capi.check(self._lib, self._h, rc, "mdpp_upload_image_templates")
 
+    def _init_grid(self, cfg):
+        """Grid envs (rl_toy_env.py:539-541, :780-811): int64 cell vectors, one-hot +-1 actions."""
+        m = self.mdps[0]
+        G = len(m.grid_shape)
+        cfg.grid_dims = G
+        for d in range(G):
+            cfg.grid_shape[d] = int(m.grid_shape[d])
+        cfg.grid_target[0], cfg.grid_target[1] = int(m.target_point[0]), int(m.target_point[1])
+        cfg.make_denser = int(bool(m.make_denser))
+        cfg.has_transition_noise = int(bool(m.transition_noise))
+        cfg.transition_noise = float(m.transition_noise or 0.0)
+        dtype_o = self.config.get("dtype_o", self.config.get("dtype_s", np.int64))
+        self._obs_torch_dtype = torch.int32 if np.dtype(dtype_o) == np.int32 else torch.int64
+        cfg.obs_dtype = capi.OBS_I32 if self._obs_torch_dtype == torch.int32 else capi.OBS_I64
+        # Box(0, grid_shape, int64) / GridActionSpace(-1, 1) (:780-800)
+        self.single_observation_space = BoxSpace(0, 1, (G,), dtype=np.int64, seed=m.seed_dict.get("state_space"))
+        self.single_observation_space.high = np.asarray(m.grid_shape, dtype=np.int64)
+        self.single_action_space = BoxSpace(-1, 1, (G,), dtype=np.int64, seed=m.seed_dict.get("action_space"))
+        self._image = None
+
     def _init_continuous(self, cfg):
         m = self.mdps[0]
         if self._per_env:
@@ -250,13 +274,19 @@ class RLToyVectorEnv:
                                                         self._trunc.data_ptr())
         self._term_b, self._trunc_b = self._term.view(torch.bool), self._trunc.view(torch.bool)
         self._info = {"final_obs": self._final_obs} if self.autoreset == "same_step" else {}
-        self._act_dtype = torch.int32 if self.kind == "discrete" else torch.float32
-        self._act_shape = torch.Size(((N, 2) if getattr(self, "_irr", False) else (N,))
-                                     if self.kind == "discrete" else (N, self.mdps[0].D))
+        self._act_dtype = torch.float32 if self.kind == "continuous" else torch.int32
+        if self.kind == "discrete":
+            self._act_shape = torch.Size((N, 2) if self._irr else (N,))
+        elif self.kind == "grid":
+            self._act_shape = torch.Size((N, len(self.mdps[0].grid_shape)))
+        else:
+            self._act_shape = torch.Size((N, self.mdps[0].D))
 
     def _obs_shape(self, *lead):
         if self.kind == "continuous":
             return tuple(lead) + (self.mdps[0].D,)
+        if self.kind == "grid":
+            return tuple(lead) + (len(self.mdps[0].grid_shape),)
         if getattr(self, "_image", None) is not None:
             im = self.mdps[0].image
             return tuple(lead) + (im["width"], im["height"], 1)
@@ -295,6 +325,13 @@ class RLToyVectorEnv:
             else:
                 sp = mdp_mod.fresh_stream_words(self.seed_dict["state_space"] + off, N)
         self._put_stream(capi.STREAM_SPACE, sp)
+        if self.kind == "grid":                      # GridActionSpace(seed=seed_dict["action_space"]), :793-797
+            if self._per_env:
+                ac = np.stack([mdp_mod.pcg64_words(mdp_mod.new_generator(m.seed_dict["action_space"]))
+                               for m in self.mdps])
+            else:
+                ac = mdp_mod.fresh_stream_words(self.seed_dict["action_space"] + off, N)
+            self._put_stream(capi.STREAM_ACTION, ac)
         if self.kind == "discrete" and self._irr:
             if self._per_env:
                 sp1 = np.stack([m.space_irr_rng_words for m in self.mdps])
@@ -384,6 +421,8 @@ class RLToyVectorEnv:
             if K >= 32 and full_blocks and self.autoreset == "same_step":
                 return "k_discrete_rollout_pipe"
             return "k_discrete_rollout_fast"
+        if self.kind == "grid":
+            return "k_grid_step"
         m = self.mdps[0]
         fast = (self.rng == "numpy" and m.box_lo is None and np.isfinite(m.state_space_max)
                 and m.delay == 0 and m.reward_every_n_steps == 1
@@ -402,7 +441,7 @@ class RLToyVectorEnv:
                 torch.empty((K, N), dtype=torch.uint8, device=dev))
 
     def _as_actions(self, actions, K):
-        want = torch.int32 if self.kind == "discrete" else torch.float32
+        want = torch.float32 if self.kind == "continuous" else torch.int32
         if not torch.is_tensor(actions):
             actions = torch.as_tensor(np.asarray(actions), device=self.device)
         if self.kind == "continuous" and actions.dtype != torch.float32:
@@ -413,6 +452,12 @@ class RLToyVectorEnv:
         lead = (self.num_envs,) if K is None else (K, self.num_envs)
         if self.kind == "discrete":
             shape = lead + (2,) if self._irr else lead
+        elif self.kind == "grid":
+            # the reference treats a non-integer action as outside the action space (noop, :1731);
+            # a batched API cannot flag dtype per env, so raise instead of silently staying
+            if actions.dtype.is_floating_point:
+                raise TypeError(f"grid actions must be integers, got {actions.dtype}")
+            shape = lead + (len(self.mdps[0].grid_shape),)
         else:
             shape = lead + (self.mdps[0].D,)
         if tuple(a.shape) != shape:
@@ -439,6 +484,16 @@ class RLToyVectorEnv:
                 cur = np.stack([cur, irr.astype(np.int64)], axis=1)
             return {"curr_state": cur, "curr_obs": cur,
                     "augmented_state": hist, "total_transitions_episode": steps, "reward_buffer": ring}
+        if self.kind == "grid":
+            G = self._cfg.grid_dims
+            cells = np.zeros((N, G), np.int32)
+            steps = np.zeros(N, np.int32)
+            reached = np.zeros(N, np.uint8)
+            rc = self._lib.mdpp_get_state_grid(self._h, capi.nptr(cells), capi.nptr(steps), capi.nptr(reached))
+            capi.check(self._lib, self._h, rc, "mdpp_get_state_grid")
+            cur = cells.astype(np.int64)
+            return {"curr_state": cur, "curr_obs": cur, "augmented_state": cur[:, :2],
+                    "total_transitions_episode": steps, "reached_terminal": reached.astype(bool)}
         D, n, d = self._cfg.D, self._cfg.order, self._cfg.delay
         sd = np.zeros((N, n + 1, D), np.float32)
         cur = np.zeros((N, D), np.float32)
@@ -466,6 +521,14 @@ class RLToyVectorEnv:
                 irr = np.ascontiguousarray(np.asarray(state["curr_state"])[:, 1], dtype=np.int32)
                 rc = self._lib.mdpp_set_state_irrelevant(self._h, capi.nptr(irr))
                 capi.check(self._lib, self._h, rc, "mdpp_set_state_irrelevant")
+            return
+        if self.kind == "grid":
+            cells = np.ascontiguousarray(state["curr_state"], dtype=np.int32)
+            steps = np.ascontiguousarray(state["total_transitions_episode"], dtype=np.int32)
+            reached = state.get("reached_terminal")
+            reached = None if reached is None else np.ascontiguousarray(reached, np.uint8)
+            rc = self._lib.mdpp_set_state_grid(self._h, capi.nptr(cells), capi.nptr(steps), capi.nptr(reached))
+            capi.check(self._lib, self._h, rc, "mdpp_set_state_grid")
             return
         sd = np.ascontiguousarray(state["state_derivatives"], dtype=np.float32)
         cur = np.ascontiguousarray(state["curr_state"], dtype=np.float32)

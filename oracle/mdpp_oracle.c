@@ -196,6 +196,126 @@ void ora_d_rollout(ora_discrete *e, int T, const int32_t *actions, const uint8_t
 }
 
 /* ======================================================================
+ * Grid, move_to_a_point (rl_toy_env.py:1727-1778 transition, :1947-1965 reward,
+ * :2325-2345 reset; spaces/grid_action_space.py:13-39)
+ * ==================================================================== */
+struct ora_grid {
+    int G;                   /* state dimensions: 2, or 4 with irrelevant_features (:604-608) */
+    int shape[4], target[2];
+    int make_denser, has_p_noise, has_r_noise, every_n;
+    double p_noise, r_noise, scale, shift, term_reward;
+    int state[4], steps, reached;
+    np_pcg64 env_rng;        /* self._np_random: noise trigger (:1736), reward noise */
+    np_pcg64 space_rng;      /* self.feature_space.np_random: reset() sample (:2326) */
+    np_pcg64 action_rng;     /* self.action_space.np_random: the noisy action (:1738) */
+    int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
+};
+
+ora_grid *ora_g_create(int G, const int32_t *shape, const int32_t *target, int make_denser,
+                       int has_p_noise, double p_noise, int has_r_noise, double r_noise,
+                       int every_n, double scale, double shift, double term_reward) {
+    if (G != 2 && G != 4) return NULL;
+    ora_grid *e = (ora_grid *)calloc(1, sizeof(*e));
+    e->G = G;
+    for (int i = 0; i < G; i++) e->shape[i] = shape[i];
+    e->target[0] = target[0]; e->target[1] = target[1];
+    e->make_denser = make_denser; e->has_p_noise = has_p_noise; e->p_noise = p_noise;
+    e->has_r_noise = has_r_noise; e->r_noise = r_noise; e->every_n = every_n;
+    e->scale = scale; e->shift = shift; e->term_reward = term_reward;
+    return e;
+}
+void ora_g_destroy(ora_grid *e) { free(e); }
+void ora_g_set_rng(ora_grid *e, const uint64_t env[6], const uint64_t space[6], const uint64_t action[6]) {
+    np_pcg64_load(&e->env_rng, env); np_pcg64_load(&e->space_rng, space); np_pcg64_load(&e->action_rng, action);
+}
+void ora_g_get_rng(const ora_grid *e, uint64_t env[6], uint64_t space[6], uint64_t action[6]) {
+    np_pcg64_store(&e->env_rng, env); np_pcg64_store(&e->space_rng, space); np_pcg64_store(&e->action_rng, action);
+}
+void ora_g_set_philox(ora_grid *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
+    e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
+}
+void ora_g_philox_explicit_reset(ora_grid *e) {
+    np_philox_init(&e->space_rng, e->ph_seed, e->ph_env, e->reset_tick, 3);
+    e->reset_tick += 1;
+}
+
+/* reset(): feature_space.sample() of a Box(0, grid_shape, int64) (:780-788, :2326): per dimension
+ * floor(uniform(0, g + 1)) -- so the cell index g, one past the grid, can come out, as in the
+ * reference; the terminal-state resampling loop never triggers (Box(int64).contains(float64 array)
+ * is False under gymnasium's dtype check, :973-982). */
+void ora_g_reset(ora_grid *e, int64_t *obs) {
+    for (int i = 0; i < e->G; i++) {
+        double v = 0.0 + ((double)(e->shape[i] + 1) - 0.0) * np_random(&e->space_rng);
+        e->state[i] = (int)floor(v);
+        obs[i] = e->state[i];
+    }
+    e->steps = 0; e->reached = 0;
+}
+
+void ora_g_step(ora_grid *e, const int32_t *action, int64_t *obs, double *reward, uint8_t *done) {
+    const int G = e->G;
+    if (e->philox) {
+        np_philox_init(&e->env_rng, e->ph_seed, e->ph_env, e->tick, 0);
+        np_philox_init(&e->space_rng, e->ph_seed, e->ph_env, e->tick, 1);
+        np_philox_init(&e->action_rng, e->ph_seed, e->ph_env, e->tick, 5);
+        e->tick += 1;
+    }
+    int a[4], old0 = e->state[0], old1 = e->state[1];
+    /* GridActionSpace.contains: every entry in {-1, 0, 1} and at most one non-zero */
+    int ok = 1, nz = 0;
+    for (int i = 0; i < G; i++) { a[i] = action[i]; if (a[i] < -1 || a[i] > 1) ok = 0; nz += a[i] != 0; }
+    if (nz > 1) ok = 0;
+    if (ok) {
+        if (e->has_p_noise) {
+            if (np_random(&e->env_rng) < e->p_noise) {                /* :1736 uniform() */
+                for (;;) {                                               /* :1737-1749 */
+                    int ind = (int)np_integers(&e->action_rng, 0, G);
+                    int val = (int)np_integers(&e->action_rng, 0, 3);
+                    int na[4] = {0, 0, 0, 0}, same = 1;
+                    na[ind] = val - 1;
+                    for (int i = 0; i < G; i++) if (na[i] != a[i]) same = 0;
+                    if (!same) { for (int i = 0; i < G; i++) a[i] = na[i]; break; }
+                }
+            }
+        }
+        for (int i = 0; i < G; i++) {                                    /* :1751-1761 */
+            int n = e->state[i] + a[i];
+            if (n < 0) n = 0;
+            if (n >= e->shape[i]) n = e->shape[i] - 1;
+            e->state[i] = n;
+        }
+    }                                                                    /* else: noop, :1763-1768 */
+    if (e->state[0] == e->target[0] && e->state[1] == e->target[1]) e->reached = 1;   /* :1770-1776 */
+    e->steps += 1;
+    double r = 0.0;
+    if (e->make_denser) {                                                /* :1949-1960 */
+        int d_old = abs(old0 - e->target[0]) + abs(old1 - e->target[1]);
+        int d_new = abs(e->state[0] - e->target[0]) + abs(e->state[1] - e->target[1]);
+        r += (double)(d_old - d_new);
+    } else if (e->state[0] == e->target[0] && e->state[1] == e->target[1]) r += 1.0;  /* :1962-1965 */
+    if (e->steps % e->every_n != 0) r = 0.0;                             /* :1975-1978 */
+    if (e->has_r_noise) r += 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+    r *= e->scale;
+    r += e->shift;
+    uint8_t d = (uint8_t)e->reached;                                     /* :2102-2104 */
+    if (d) r += e->term_reward * e->scale;
+    for (int i = 0; i < G; i++) obs[i] = e->state[i];
+    *reward = r; *done = d;
+}
+
+void ora_g_rollout(ora_grid *e, int T, const int32_t *actions, const uint8_t *reset_after,
+                   int64_t *obs, double *reward, uint8_t *done, int64_t *reset_obs) {
+    const int G = e->G;
+    for (int t = 0; t < T; t++) {
+        ora_g_step(e, actions + (size_t)t * G, obs + (size_t)t * G, &reward[t], &done[t]);
+        int rs = reset_after ? reset_after[t] : done[t];
+        int64_t ro[4] = {0, 0, 0, 0};
+        if (rs) ora_g_reset(e, ro);
+        if (reset_obs) for (int i = 0; i < G; i++) reset_obs[(size_t)t * G + i] = ro[i];
+    }
+}
+
+/* ======================================================================
  * Continuous, move_to_a_point
  * ==================================================================== */
 typedef struct { double v; int is32; } rew_t; /* np.float32 vs Python float */

@@ -49,6 +49,16 @@ def lib():
         L.ora_d_reset2.argtypes = [vp, vp]
         L.ora_d_step2.argtypes = [vp, i32, i32, vp, vp, vp]
         L.ora_d_rollout2.argtypes = [vp, i32] + [vp] * 6
+        L.ora_g_create.restype = vp
+        L.ora_g_create.argtypes = [i32, vp, vp, i32, i32, f64, i32, f64, i32, f64, f64, f64]
+        L.ora_g_destroy.argtypes = [vp]
+        L.ora_g_set_rng.argtypes = [vp, vp, vp, vp]
+        L.ora_g_get_rng.argtypes = [vp, vp, vp, vp]
+        L.ora_g_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_g_philox_explicit_reset.argtypes = [vp]
+        L.ora_g_reset.argtypes = [vp, vp]
+        L.ora_g_step.argtypes = [vp, vp, vp, vp, vp]
+        L.ora_g_rollout.argtypes = [vp, i32] + [vp] * 6
         L.ora_c_create.restype = vp
         L.ora_c_create.argtypes = ([i32, i32, vp, i32, f64, f64, f64, f64, vp, f64, i32, f64,
                                     i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
@@ -211,6 +221,64 @@ class DiscreteOracle:
         done = np.zeros(T, np.uint8)
         ro = np.zeros(T, np.int64)
         lib().ora_d_rollout(self.h, T, _p(actions), _p(ra), _p(obs), _p(rew), _p(done), _p(ro))
+        return obs, rew, done.astype(bool), ro
+
+
+class GridOracle:
+    def __init__(self, grid_shape, target_point, make_denser, transition_noise=None, reward_noise=None,
+                 every_n=1, reward_scale=1.0, reward_shift=0.0, term_state_reward=0.0):
+        self.G = len(grid_shape)
+        sh = np.ascontiguousarray(grid_shape, dtype=np.int32)
+        tg = np.ascontiguousarray(target_point, dtype=np.int32)
+        self.h = lib().ora_g_create(self.G, _p(sh), _p(tg), int(bool(make_denser)),
+                                    int(bool(transition_noise)), float(transition_noise or 0.0),
+                                    int(reward_noise is not None), float(reward_noise or 0.0),
+                                    int(every_n), float(reward_scale), float(reward_shift),
+                                    float(term_state_reward))
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_g_destroy(self.h)
+            self.h = None
+
+    def set_rng(self, env_words, space_words, action_words):
+        w = [np.ascontiguousarray(x, dtype=np.uint64) for x in (env_words, space_words, action_words)]
+        lib().ora_g_set_rng(self.h, _p(w[0]), _p(w[1]), _p(w[2]))
+
+    def get_rng(self):
+        w = [np.zeros(6, np.uint64) for _ in range(3)]
+        lib().ora_g_get_rng(self.h, _p(w[0]), _p(w[1]), _p(w[2]))
+        return w
+
+    def set_philox(self, seed, env_id, tick=0, reset_tick=0):
+        self._philox = True
+        lib().ora_g_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
+
+    def reset(self, explicit=True):
+        if getattr(self, "_philox", False) and explicit:
+            lib().ora_g_philox_explicit_reset(self.h)
+        o = np.zeros(self.G, np.int64)
+        lib().ora_g_reset(self.h, _p(o))
+        return o
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.int32)
+        o = np.zeros(self.G, np.int64)
+        r = C.c_double()
+        d = C.c_uint8()
+        lib().ora_g_step(self.h, _p(a), _p(o), C.byref(r), C.byref(d))
+        return o, r.value, bool(d.value)
+
+    def rollout(self, actions, reset_after=None):
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        T = actions.shape[0]
+        ra = None if reset_after is None else np.ascontiguousarray(reset_after, dtype=np.uint8)
+        obs = np.zeros((T, self.G), np.int64)
+        rew = np.zeros(T, np.float64)
+        done = np.zeros(T, np.uint8)
+        ro = np.zeros((T, self.G), np.int64)
+        lib().ora_g_rollout(self.h, T, _p(actions), _p(ra), _p(obs), _p(rew), _p(done), _p(ro))
         return obs, rew, done.astype(bool), ro
 
 

@@ -17,6 +17,7 @@ IRRELEVANT = sorted(k for k in CASES if k.startswith("d_irr"))      # Tuple spac
 DISCRETE = sorted(k for k in CASES if k.startswith("d_") and k not in IRRELEVANT)
 CONTINUOUS = sorted(k for k in CASES if k.startswith("c_"))
 IMAGE = sorted(k for k in CASES if k.startswith("i_"))
+GRID = sorted(k for k in CASES if k.startswith("g_"))
 
 
 def load(name):
@@ -85,3 +86,16 @@ def continuous_params(cfg):
 
 def continuous_oracle_from_golden(name):
     return ora.ContinuousOracle(**continuous_params(CASES[name]["config"]))
+
+
+def grid_params(cfg):
+    """Scalar parameters of a grid env as rl_toy_env.py:342-566 defaults them."""
+    shape = list(cfg["grid_shape"]) * (2 if cfg.get("irrelevant_features") else 1)   # :604-608
+    return dict(grid_shape=shape, target_point=list(cfg["target_point"]), make_denser=cfg["make_denser"],
+                transition_noise=cfg.get("transition_noise"), reward_noise=cfg.get("reward_noise"),
+                every_n=cfg.get("reward_every_n_steps", 1), reward_scale=cfg.get("reward_scale", 1.0),
+                reward_shift=cfg.get("reward_shift", 0.0), term_state_reward=cfg.get("term_state_reward", 0.0))
+
+
+def grid_oracle_from_golden(name):
+    return ora.GridOracle(**grid_params(CASES[name]["config"]))

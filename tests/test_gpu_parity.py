@@ -89,6 +89,9 @@ def test_discrete_same_step_autoreset_final_obs():
 def _oracle_for(env, i):
     from oracle import oracle as ora
     m = env.mdps[i if env._per_env else 0]
+    if m.kind == "grid":
+        return ora.GridOracle(m.grid_shape, m.target_point, m.make_denser, m.transition_noise, m.reward_noise,
+                              m.reward_every_n_steps, m.reward_scale, m.reward_shift, m.term_state_reward)
     if m.kind == "discrete":
         o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps, m.P,
                                m.reward_table(), m.terminal_states, m.init_dist, m.transition_noise,
@@ -209,6 +212,99 @@ def test_irrelevant_features_2048_envs_vs_oracle(rng):
         assert np.array_equal(rew[:, i], er.astype(np.float32)), i
         if rng == "numpy":
             assert np.array_equal(o.get_rng_irr()[:4], env.get_rng_streams(capi.STREAM_SPACE_IRR)[i][:4])
+    env.close()
+
+
+# ----------------------------------------------------------------------------- grid envs
+@pytest.mark.parametrize("name", gu.GRID)
+def test_grid_stepwise_vs_reference_golden(name):
+    """Grid envs against the reference's own trajectories: clipped moves, out-of-space actions as
+    noops (status bit), noisy actions re-drawn from the action space's generator, dense / sparse
+    rewards, the latched target flag, masked resets from the feature space's generator."""
+    from mdp_playground_amd import _capi as capi
+    g = gu.load(name)
+    E, T, G = g["action"].shape
+    env = _venv(autoreset="disabled", **_seeds_or_cfg(name))
+    assert np.array_equal(env._obs.cpu().numpy(), g["init_state"])
+    assert np.array_equal(env.get_rng_streams(0), g["rng_env"])
+    bad_seen = False
+    for t in range(T):
+        a = torch.as_tensor(g["action"][:, t].astype(np.int32), device=env.device)
+        obs, rew, term, trunc, _ = env.step(a)
+        assert np.array_equal(obs.cpu().numpy(), g["obs"][:, t]), (name, t)
+        assert np.array_equal(term.cpu().numpy(), g["done"][:, t]), (name, t)
+        assert np.array_equal(rew.cpu().numpy(), g["reward"][:, t].astype(np.float32)), (name, t)
+        bad = (np.abs(g["action"][:, t]).sum(axis=1) > 1) | (np.abs(g["action"][:, t]).max(axis=1) > 1)
+        assert np.array_equal((env.status() & capi.STATUS_BAD_ACTION) != 0, bad), (name, t)
+        bad_seen |= bool(bad.any())
+        ra = g["reset_after"][:, t]
+        if ra.any():
+            o, _ = env.reset(mask=torch.as_tensor(ra, device=env.device))
+            assert np.array_equal(o.cpu().numpy()[ra], g["reset_obs"][:, t][ra])
+    assert bad_seen == ("bad_action_every" in gu.CASES[name])
+    assert np.array_equal(env.get_rng_streams(capi.STREAM_ACTION)[:, :4] == g["rng_action"][:, :4],
+                          np.ones((E, 4), bool)) == (not gu.CASES[name]["config"].get("transition_noise"))
+    st = env.get_augmented_state()
+    assert np.array_equal(st["curr_state"], env._obs.cpu().numpy())
+    env.set_augmented_state(st)
+    env.close()
+
+
+@pytest.mark.parametrize("name", [n for n in gu.GRID if gu.CASES[n]["reset"] == "on_done"])
+def test_grid_fused_rollout_vs_reference_golden(name):
+    g = gu.load(name)
+    env = _venv(autoreset="same_step", **_seeds_or_cfg(name))
+    acts = torch.as_tensor(np.ascontiguousarray(g["action"].transpose(1, 0, 2).astype(np.int32)), device=env.device)
+    obs, rew, term, trunc = env.rollout(acts)
+    exp = g["obs"].copy()
+    ra = g["reset_after"]
+    exp[ra] = g["reset_obs"][ra]
+    assert np.array_equal(obs.cpu().numpy().transpose(1, 0, 2), exp)
+    assert np.array_equal(term.cpu().numpy().T, g["done"])
+    assert np.array_equal(rew.cpu().numpy().T, g["reward"].astype(np.float32))
+    env.close()
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_grid_4096_envs_vs_oracle(rng):
+    """One grid config with both noises and an irrelevant grid, 4 096 instances with their own
+    streams (numpy PCG64, or Philox keyed by the global env id), fused rollout with same-step
+    autoreset; every 7th instance against the oracle, incl. the three generators' end states."""
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(state_space_type="grid", grid_shape=(5, 6), reward_function="move_to_a_point", make_denser=True,
+               target_point=[2, 2], irrelevant_features=True, transition_noise=0.25, reward_noise=0.1,
+               reward_scale=2.0, term_state_reward=0.5, seed=13)
+    N, T, off = 4096, 120, 8192
+    kw = dict(rng="philox", philox_seed=3, env_id_offset=off) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    r = np.random.default_rng(2)
+    acts = np.zeros((T, N, 4), np.int32)
+    which = r.integers(0, 4, size=(T, N))
+    val = r.integers(-1, 2, size=(T, N))
+    np.put_along_axis(acts, which[..., None], val[..., None], axis=2)
+    acts[r.random((T, N)) < 0.02] = 1                      # outside the action space: noop
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    assert term.any()
+    ends = [env.get_rng_streams(s) for s in (capi.STREAM_ENV, capi.STREAM_SPACE, capi.STREAM_ACTION)] if rng == "numpy" else None
+    for i in range(0, N, 7):
+        o = _oracle_for(env, i)
+        if rng == "philox":
+            o.set_philox(3, off + i)
+        else:
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i], env.seeded_streams[capi.STREAM_ACTION][i])
+        assert np.array_equal(o.reset(), init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        exp = eo.copy()
+        exp[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], exp), i
+        assert np.array_equal(term[:, i], ed), i
+        assert np.array_equal(rew[:, i], er.astype(np.float32)), i
+        if rng == "numpy":
+            w = o.get_rng()
+            assert all(np.array_equal(w[k][:4], ends[k][i][:4]) for k in range(3)), i
+            assert np.array_equal(w[2][4:], ends[2][i][4:]), i          # numpy's buffered 32-bit half
     env.close()
 
 

@@ -59,6 +59,29 @@ def test_discrete_irrelevant_features_rollouts_bit_exact(name):
         assert np.array_equal(ro[ra], g["reset_obs"][e][ra].astype(np.int64))
 
 
+@pytest.mark.parametrize("name", gu.GRID)
+def test_grid_rollouts_bit_exact(name):
+    """Grid envs (rl_toy_env.py:1727-1778, :1947-1965): moves with clipping, actions outside the
+    action space applied as noops, noisy actions re-drawn from the action space's generator,
+    Manhattan-distance / sparse rewards, the latched target flag, reset() from the feature space."""
+    g = gu.load(name)
+    E, T, G = g["action"].shape
+    for e in range(E):
+        o = gu.grid_oracle_from_golden(name)
+        sd = g["seed_dict"][e]
+        fresh = lambda s: ora.pcg_words(np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(s)))))  # noqa: E731
+        o.set_rng(fresh(sd[0]), fresh(sd[5]), g["rng_action"][e])
+        assert np.array_equal(o.reset(), g["init_state"][e])
+        w = o.get_rng()
+        assert np.array_equal(w[0], g["rng_env"][e]) and np.array_equal(w[1][:4], g["rng_space"][e][:4])
+        obs, rew, done, ro = o.rollout(g["action"][e], g["reset_after"][e])
+        assert np.array_equal(obs, g["obs"][e]), name
+        assert np.array_equal(done, g["done"][e]), name
+        assert np.array_equal(rew.view(np.uint64), g["reward"][e].view(np.uint64)), name
+        ra = g["reset_after"][e]
+        assert np.array_equal(ro[ra], g["reset_obs"][e][ra])
+
+
 @pytest.mark.parametrize("name", gu.CONTINUOUS)
 def test_continuous_rollouts_bit_exact(name):
     g = gu.load(name)

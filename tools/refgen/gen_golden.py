@@ -138,6 +138,24 @@ CASES = {
                     irrelevant_features=True, delay=0, sequence_length=3,
                     maximally_connected=False, transition_noise=0.1),
         seeds=list(range(4)), T=150, reset="on_done"),
+    # --- grid envs: 2-D, delay 0, sequence_length 1 (anything else raises
+    # inside the reference's reward_function) --------------------------------------------------
+    "g_dense": dict(      # the env of the reference's test_grid_env (:1057-1110)
+        config=dict(state_space_type="grid", grid_shape=(8, 8), delay=0, sequence_length=1,
+                    reward_function="move_to_a_point", make_denser=True, target_point=[5, 5],
+                    reward_scale=3.0, terminal_states=[[5, 5], [2, 3], [2, 4], [3, 3], [3, 4]],
+                    term_state_reward=-0.25),
+        seeds=list(range(6)), T=150, reset="on_done", bad_action_every=23),
+    "g_noise_sparse": dict(
+        config=dict(state_space_type="grid", grid_shape=(5, 7), reward_function="move_to_a_point",
+                    make_denser=False, target_point=[2, 3], transition_noise=0.3, reward_noise=0.2,
+                    reward_every_n_steps=2, reward_shift=0.5, term_state_reward=1.5),
+        seeds=list(range(6)), T=200, reset="mixed", bad_action_every=31),
+    "g_irr": dict(
+        config=dict(state_space_type="grid", grid_shape=(6, 9), reward_function="move_to_a_point",
+                    make_denser=True, target_point=[1, 7], irrelevant_features=True,
+                    transition_noise=0.2, reward_scale=0.5),
+        seeds=list(range(4)), T=200, reset="on_done"),
     # --- continuous ------------------------------------------------------
     "c_cfg3": dict(config=CFG3, seeds=list(range(8)), T=250, reset="on_done",
                    bad_action_every=37),
@@ -203,7 +221,7 @@ def run_case(name, case):
     tables = {k: [] for k in ("P", "terminal_states", "init_dist", "rew_keys",
                               "rew_vals", "rng_env", "rng_space", "rng_image",
                               "init_obs", "init_state", "seed_dict", "sd",
-                              "P_irr", "init_dist_irr", "rng_space_irr")}
+                              "P_irr", "init_dist_irr", "rng_space_irr", "rng_action")}
     seed_names = ["env", "relevant_state_space", "relevant_action_space",
                   "irrelevant_state_space", "irrelevant_action_space", "state_space",
                   "action_space", "image_representations"]
@@ -244,6 +262,8 @@ def run_case(name, case):
                 tables["rng_image"].append(pcg_state(env.observation_space.np_random))
         else:
             tables["rng_space"].append(pcg_state(env.feature_space.np_random))
+            if kind == "grid":
+                tables["rng_action"].append(pcg_state(env.action_space.np_random))
         co = env.curr_obs  # NB: __init__ stores reset()'s (obs, info) tuple here
         tables["init_obs"].append(np.array(co[0] if isinstance(co, tuple) else co))
         tables["init_state"].append(np.array(env.curr_state))
@@ -260,6 +280,23 @@ def run_case(name, case):
                     a = int(arng.integers(env.action_space_size[0]))
                 act = a
                 r["action"].append(a)
+            elif kind == "grid":
+                G = len(env.grid_shape)
+                a = [0] * G
+                u = arng.random()
+                if u < 0.45:                           # head for the target: episodes end often
+                    cs, tp = [int(x) for x in env.curr_state], env.target_point
+                    i = int(arng.integers(2))
+                    if cs[i] == tp[i]:
+                        i = 1 - i
+                    a[i] = int(np.sign(tp[i] - cs[i]))
+                elif u < 0.95:
+                    a[int(arng.integers(G))] = int(arng.integers(3)) - 1
+                bae = case.get("bad_action_every")
+                if bae and t % bae == bae - 1:        # not in the action space: applied as a noop
+                    a = [1] * G if (t // bae) % 2 else [2] + [0] * (G - 1)
+                act = a
+                r["action"].append(list(a))
             else:
                 D = env.state_space_dim
                 amax = env.action_space_max
