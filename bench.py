@@ -70,6 +70,16 @@ WORKLOADS = {
                  config=dict(state_space_type="grid", grid_shape=(8, 8), reward_function="move_to_a_point",
                              make_denser=True, target_point=[5, 5], reward_scale=3.0,
                              term_state_reward=-0.25, seed=0)),
+    # SURVEY.md §8f rank 3 (not a BASELINE config): continuous env with ImageContinuous observations,
+    # 100x100 RGB (the reference's defaults), 8 192 envs; 30 000 B written per env step
+    "img_cont": dict(kind="continuous", envs=8192, alg_bytes_fused=30000 + 8 + 6, alg_bytes_step=30000 + 8 + 6 + 48,
+                     fuse_max=32,      # 246 MB of pictures per step: 32 steps = 7.9 GB per rollout buffer
+                     config=dict(state_space_type="continuous", state_space_dim=2, transition_dynamics_order=1,
+                                 inertia=1.0, time_unit=1.0, state_space_max=5, action_space_max=1,
+                                 make_denser=True, target_point=[1.0, -1.0], target_radius=0.5,
+                                 terminal_states=[[-3.0, 3.0], [3.0, 3.0]], term_state_edge=2.0,
+                                 reward_function="move_to_a_point", image_representations=True,
+                                 image_width=100, image_height=100, seed=0)),
     # the irrelevant-sub-space variant of cfg2's MDP size (Tuple spaces), also §8f rank 2
     "cfg2_irr": dict(kind="discrete", envs=65536, alg_bytes_fused=30, alg_bytes_step=62,
                      config=dict(state_space_type="discrete", action_space_type="discrete",
@@ -238,7 +248,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     N = args.envs or wl["envs"]
-    F = max(1, min(args.fuse, args.steps))
+    F = max(1, min(args.fuse, args.steps, wl.get("fuse_max", args.fuse)))
     env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
                          autoreset="same_step", **wl["config"])
     acts = make_actions(wl, F, N, device, 12345 + rank)
@@ -357,8 +367,9 @@ def main():
                   "hbm_frac_events": b1 / (ms1 / 1e3 / n1) / 1e9 / HBM_PEAK_GBS}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not (
+            wl["kind"] == "continuous" and wl["config"].get("image_representations")):
+        cpu = cpu_baseline(wl)      # (the C port has no timed picture path for continuous envs)
     env.close()
 
     if rank == 0:

@@ -113,8 +113,10 @@ typedef struct {
     int32_t grid_shape[4];
     int32_t grid_target[2];
 
-    /* ---- image observations for discrete envs (ImageMultiDiscrete) ---- */
-    int32_t image;              /* 1: obs is uint8[W][H][1] per env */
+    /* ---- image observations: discrete envs (ImageMultiDiscrete: polygons, random transforms), or
+     * continuous envs (ImageContinuous, spaces/image_continuous.py:116-277: RGB pictures, uses image,
+     * img_w, img_h and img_r0 = radius of the agent / target discs only) ---- */
+    int32_t image;              /* 1: obs is uint8[W][H][1] per env (discrete) or uint8[n_sub W][H][3] (continuous) */
     int32_t img_w, img_h;
     int32_t img_has_scale, img_has_shift, img_has_rotate, img_has_flip;
     int32_t img_sh_quant, img_ro_quant;
@@ -153,6 +155,10 @@ int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P_irr_host, cons
  * template; cls_x/cls_y int16 [S][n_radii][W or H] map a centre coordinate to its template class. */
 int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl_host, int32_t n_radii, int32_t n_cls_x,
                                 int32_t n_cls_y, const int16_t *cls_x_host, const int16_t *cls_y_host);
+
+/* Continuous image observations: disc uint8 [(2 R + 1)][(2 R + 1)], non-zero = covered, R = cfg.img_r0:
+ * the raster of Pillow's ellipse with the integer bounding box centre +- R (image_continuous.py:190-207). */
+int mdpp_upload_image_disc(mdpp_env *h, const uint8_t *disc_host);
 
 /* RNG streams.  words_host: uint64 [num_envs][6] = PCG64 {state_lo, state_hi, inc_lo, inc_hi,
  * has_uint32, uinteger} exactly as numpy's bit_generator.state reports them. */

@@ -113,14 +113,14 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     TRY(alloc_zero(h, &h->d_status, N * sizeof(uint32_t)));
     if (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64) {
         for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
-            if (s == MDPP_STREAM_IMAGE && !cfg->image) continue;
+            if (s == MDPP_STREAM_IMAGE && !(cfg->image && cfg->kind == MDPP_KIND_DISCRETE)) continue;
             if (s == MDPP_STREAM_SPACE_IRR && !(cfg->kind == MDPP_KIND_DISCRETE && cfg->irrelevant)) continue;
             if (s == MDPP_STREAM_ACTION && cfg->kind != MDPP_KIND_GRID) continue;
             TRY(alloc_zero(h, &h->d_rng_s[s], N * 16));
             TRY(alloc_zero(h, &h->d_rng_inc[s], N * 16));
         }
         if (cfg->kind == MDPP_KIND_GRID) TRY(alloc_zero(h, &h->d_rng_half, N * 8));   // action stream's 32-bit half
-        if (cfg->image) {
+        if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE) {
             TRY(alloc_zero(h, &h->d_rng_half, N * 8));
             // scratch of one batch of img_chunk env steps: states in, transform records in between
             TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * 4));
@@ -131,9 +131,16 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
     }
 
-    if (cfg->image && (cfg->kind != MDPP_KIND_DISCRETE || cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 ||
-                       cfg->img_w < 1 || cfg->img_h < 1 || cfg->img_tpl_size < 1)) {
-        g_create_err = "mdpp_create: image observations need a discrete env with numpy PCG64 streams";
+    if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE &&
+        (cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 || cfg->img_w < 1 || cfg->img_h < 1 || cfg->img_tpl_size < 1)) {
+        g_create_err = "mdpp_create: image observations of a discrete env need numpy PCG64 streams";
+        free_all(h); delete h; return MDPP_EUNSUPPORTED;
+    }
+    if (cfg->image && cfg->kind == MDPP_KIND_CONTINUOUS &&
+        ((cfg->D != 2 && cfg->D != 4) || !isfinite(cfg->state_space_max) || cfg->img_w < 1 || cfg->img_h < 1 ||
+         ((size_t)cfg->img_w * cfg->img_h) % 16 != 0 || cfg->img_r0 < 1 || cfg->img_r0 > 15)) {
+        g_create_err = "mdpp_create: ImageContinuous observations need 2 or 4 bounded state dimensions, "
+                       "width * height divisible by 16 and a disc radius of 1..15";
         free_all(h); delete h; return MDPP_EUNSUPPORTED;
     }
     if (cfg->kind == MDPP_KIND_DISCRETE) {
@@ -266,7 +273,12 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
                 if (is_pow2(a.fact[k])) a.fact_pow2_mask |= 1u << k;
             }
             a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && cfg->n_boxes == 0 && a.rel_prefix &&
-                         a.bounded && cfg->delay == 0 && cfg->every_n == 1) ? 1u : 0u;
+                         a.bounded && cfg->delay == 0 && cfg->every_n == 1 && !cfg->image) ? 1u : 0u;
+            a.image_quirk = cfg->image ? 1 : 0;
+        }
+        if (cfg->image) {   // scratch of one batch of img_chunk env steps: the states the pictures are made from
+            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * D * sizeof(float)));
+            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * D * sizeof(float)));
         }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
@@ -378,6 +390,19 @@ extern "C" int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P1, c
     if (h->cfg.has_transition_noise)
         HIPCHK(h, hipMemcpy(h->d_noise_cdf1, noise_cdf1, S1 * S1 * sizeof(double), hipMemcpyHostToDevice));
     h->irr_ready = true;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_upload_image_disc(mdpp_env *h, const uint8_t *disc) {
+    if (!h || !disc) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_CONTINUOUS || !h->cfg.image)
+        return fail(h, MDPP_EINVAL, "upload_image_disc: not a continuous handle with image observations");
+    const int T = 2 * h->cfg.img_r0 + 1;
+    for (int r = 0; r < 32; r++) h->imgc_disc_rows[r] = 0;
+    for (int dy = 0; dy < T; dy++)
+        for (int dx = 0; dx < T; dx++)
+            if (disc[dy * T + dx]) h->imgc_disc_rows[dy] |= 1u << dx;
+    h->img_ready = true;
     return MDPP_OK;
 }
 
@@ -502,15 +527,17 @@ static int check_ready(mdpp_env *h, const char *what) {
     if (h->cfg.rng_mode == MDPP_RNG_NUMPY_PCG64) {
         if (!h->streams_ready[MDPP_STREAM_ENV] || !h->streams_ready[MDPP_STREAM_SPACE])
             return fail(h, MDPP_ESTATE, std::string(what) + ": RNG streams not seeded");
-        if (h->cfg.image && !h->streams_ready[MDPP_STREAM_IMAGE])
+        if (h->cfg.image && h->cfg.kind == MDPP_KIND_DISCRETE && !h->streams_ready[MDPP_STREAM_IMAGE])
             return fail(h, MDPP_ESTATE, std::string(what) + ": image RNG stream not seeded");
-        if (h->cfg.image && !h->img_ready)
+        if (h->cfg.image && h->cfg.kind == MDPP_KIND_DISCRETE && !h->img_ready)
             return fail(h, MDPP_ESTATE, std::string(what) + ": image templates not uploaded");
         if (h->cfg.kind == MDPP_KIND_GRID && !h->streams_ready[MDPP_STREAM_ACTION])
             return fail(h, MDPP_ESTATE, std::string(what) + ": action-space RNG stream not seeded");
         if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->streams_ready[MDPP_STREAM_SPACE_IRR])
             return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space RNG stream not seeded");
     }
+    if (h->cfg.image && h->cfg.kind == MDPP_KIND_CONTINUOUS && !h->img_ready)
+        return fail(h, MDPP_ESTATE, std::string(what) + ": image disc raster not uploaded");
     if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->irr_ready)
         return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space tables not uploaded");
     return MDPP_OK;
@@ -531,6 +558,12 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
         return launch_discrete_reset(h, mask_dev, obs_dev, s);
     }
     if (h->cfg.kind == MDPP_KIND_GRID) return launch_grid_reset(h, mask_dev, obs_dev, s);
+    if (h->cfg.image) {
+        rc = launch_continuous_reset(h, mask_dev, (float *)h->d_img_state_out, s);
+        if (rc || !obs_dev) return rc;
+        return launch_imagec_obs(h, 1, (const float *)h->d_img_state_out, nullptr, nullptr, nullptr, mask_dev,
+                                 (uint8_t *)obs_dev, nullptr, s);
+    }
     return launch_continuous_reset(h, mask_dev, (float *)obs_dev, s);
 }
 
@@ -566,6 +599,24 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
     }
     if (h->cfg.kind == MDPP_KIND_GRID)
         return launch_grid_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
+    if (h->cfg.image) {
+        // batches of up to img_chunk env steps: one state kernel, one render kernel over steps x envs
+        // pictures (3 W H bytes per 2-D sub-space each)
+        const size_t N = (size_t)h->cfg.num_envs, D = (size_t)h->cfg.D;
+        const size_t isz = (size_t)(D > 2 ? 2 : 1) * h->cfg.img_w * h->cfg.img_h * 3;
+        for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
+            const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
+            const size_t off = (size_t)k0 * N;
+            rc = launch_continuous_step(h, kc, (const float *)actions + off * D, (float *)h->d_img_state_out,
+                                        reward + off, term + off, trunc + off, (float *)h->d_img_state_final, s);
+            if (rc) return rc;
+            rc = launch_imagec_obs(h, kc, (const float *)h->d_img_state_out, (const float *)h->d_img_state_final,
+                                   term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
+                                   final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
+            if (rc) return rc;
+        }
+        return MDPP_OK;
+    }
     return launch_continuous_step(h, K, (const float *)actions, (float *)obs, reward, term, trunc,
                                   (float *)final_obs, s);
 }

@@ -207,6 +207,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 #pragma unroll
         for (int d = 0; d < DMAX; d++)
             if (d < D) inside = inside && (nxt[d] >= -a.smax32) && (nxt[d] <= a.smax32);
+        // image observations: the reference asks the ImageContinuous space whether it contains the
+        // state VECTOR, which it never does (spaces/image_continuous.py:292-302 returns None), so every
+        // step takes this branch: a clip that is the identity inside the box, and zeroed derivatives
+        if (a.image_quirk) inside = false;
         if (!inside) {
 #pragma unroll
             for (int d = 0; d < DMAX; d++) {

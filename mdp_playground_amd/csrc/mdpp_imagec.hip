@@ -1,0 +1,156 @@
+// ImageContinuous observations of continuous envs:
+// /root/reference/mdp_playground/spaces/image_continuous.py:116-277, called from
+// rl_toy_env.py:2095-2096 (step) and :2347-2350 (reset).
+//
+// Per 2-D sub-space one W x H RGB picture: background (208,208,208); the terminal hypercubes as
+// black rectangles (inclusive corner pixels from convert_to_pixel, :176-188); the target as a green
+// disc and the agent as a blue disc, both Pillow ellipses with the integer bounding box centre +- R
+// (:190-207), i.e. one fixed (2R+1)^2 raster (made on the host with Pillow, uploaded as row
+// bitmasks) at an integer position; the irrelevant sub-space's picture shows only its agent disc;
+// the pictures are concatenated along the first axis of the [x][y][channel] observation (:209-250).
+// convert_to_pixel (:252-277): (v - min) / (max - min) in float32, times the image size in
+// float64, truncated toward zero.  No random draws.
+//
+// One wavefront per image.  Phase 1 paints 2-bit colour codes {0 background, 1 terminal, 2 target,
+// 3 agent} of the n_sub * W * H pixels into LDS with ds_or / ds_and (shapes are a few hundred
+// pixels); phase 2 streams the picture out: a lane takes 16 consecutive pixels (one dword of codes),
+// expands them to 48 bytes and writes three 16-byte stores, so a wave instruction covers 3 KiB
+// contiguous; groups that are all background skip the expansion.  Write-bound: 3 W H n_sub bytes
+// per observation and nothing else.
+#include <string.h>
+
+#include "mdpp_internal.hpp"
+
+namespace mdpp {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct ImageCArgs {
+    int32_t N, D, W, H, R, n_sub, n_boxes, autoreset;
+    float smax;
+    float target[2];
+    float box_lo[MDPP_MAX_BOXES * 2], box_hi[MDPP_MAX_BOXES * 2];   // first two relevant dimensions
+    uint32_t disc_rows[32];     // bit dx of row dy: pixel (dx, dy) of the (2R+1)^2 disc raster
+};
+
+__device__ __forceinline__ int ic_px(float v, float smax, int size) {
+    const float lo = -smax, hi = smax;
+    const float f = (v - lo) / (hi - lo);
+    return (int)((double)f * (double)size);
+}
+
+// states [M][D] float32 (time-major batches of the step kernel's observations); flags (nullable):
+// only images with term | trunc set are rendered (the terminal observations of reset steps).
+__global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, const float *__restrict__ states,
+                                                       const uint8_t *__restrict__ term,
+                                                       const uint8_t *__restrict__ trunc,
+                                                       const uint8_t *__restrict__ mask,
+                                                       uint8_t *__restrict__ img) {
+    extern __shared__ __align__(16) uint32_t lds_codes[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long j = __builtin_amdgcn_readfirstlane((int)((long)blockIdx.x * (kBlock / 64) + wave));
+    if (j >= M) return;
+    if (mask && !mask[j % a.N]) return;
+    if (term && !(term[j] | trunc[j])) return;
+    const int npix = a.n_sub * a.W * a.H, ngroup = npix >> 4;      // W * H % 16 == 0 (host-checked)
+    uint32_t *codes = lds_codes + (size_t)wave * ngroup;
+    for (int g = lane; g < ngroup; g += 64) codes[g] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const float *st = states + (size_t)j * a.D;
+    auto paint = [&](int p, uint32_t code, bool clear) {           // pixel index p = (sub W + x) H + y
+        uint32_t *w = codes + (p >> 4);
+        const int sh = 2 * (p & 15);
+        if (clear) atomicAnd(w, ~(3u << sh));
+        atomicOr(w, code << sh);
+    };
+    // terminal hypercubes (relevant picture only), inclusive pixel rectangles
+    for (int b = 0; b < a.n_boxes; b++) {
+        const int x0 = max(ic_px(a.box_lo[2 * b], a.smax, a.W), 0), y0 = max(ic_px(a.box_lo[2 * b + 1], a.smax, a.H), 0);
+        const int x1 = min(ic_px(a.box_hi[2 * b], a.smax, a.W), a.W - 1), y1 = min(ic_px(a.box_hi[2 * b + 1], a.smax, a.H), a.H - 1);
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+        if (bw <= 0 || bh <= 0) continue;
+        for (int k = lane; k < bw * bh; k += 64) {
+            const int dx = k / bh, dy = k - dx * bh;
+            paint((x0 + dx) * a.H + y0 + dy, 1u, false);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int T = 2 * a.R + 1;
+    auto disc = [&](int sub, int cx, int cy, uint32_t code, bool clear) {
+        for (int k = lane; k < T * T; k += 64) {
+            const int dy = k / T, dx = k - dy * T;
+            const int x = cx - a.R + dx, y = cy - a.R + dy;
+            if (((a.disc_rows[dy] >> dx) & 1u) && x >= 0 && x < a.W && y >= 0 && y < a.H)
+                paint((sub * a.W + x) * a.H + y, code, clear);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    disc(0, ic_px(a.target[0], a.smax, a.W), ic_px(a.target[1], a.smax, a.H), 2u, true);   // over the rectangles
+    disc(0, ic_px(st[0], a.smax, a.W), ic_px(st[1], a.smax, a.H), 3u, false);              // 3 = 0b11: OR overrides
+    if (a.n_sub > 1) disc(1, ic_px(st[2], a.smax, a.W), ic_px(st[3], a.smax, a.H), 3u, false);
+
+    // phase 2: 16 pixels -> 48 bytes per lane
+    const size_t isz = (size_t)npix * 3;
+    const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)j * isz), 0, (int)isz, 0x00020000);
+    for (int g = lane; g < ngroup; g += 64) {
+        const uint32_t c = codes[g];
+        u32x4 o0, o1, o2;
+        if (__builtin_amdgcn_ballot_w64(c != 0u) == 0) {
+            o0 = o1 = o2 = u32x4{0xD0D0D0D0u, 0xD0D0D0D0u, 0xD0D0D0D0u, 0xD0D0D0D0u};
+        } else {
+            uint32_t d[12];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                         // 4 pixels -> 3 dwords
+                uint32_t px[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t code = (c >> (2 * (4 * q + e))) & 3u;
+                    // bytes R, G, B as a little-endian 24-bit value
+                    px[e] = code == 0 ? 0xD0D0D0u : code == 1 ? 0u : code == 2 ? 0x00FF00u : 0xFF0000u;
+                }
+                d[3 * q] = px[0] | (px[1] << 24);
+                d[3 * q + 1] = (px[1] >> 8) | (px[2] << 16);
+                d[3 * q + 2] = (px[2] >> 16) | (px[3] << 8);
+            }
+            o0 = u32x4{d[0], d[1], d[2], d[3]};
+            o1 = u32x4{d[4], d[5], d[6], d[7]};
+            o2 = u32x4{d[8], d[9], d[10], d[11]};
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o0, r_out, g * 48, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, r_out, g * 48 + 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o2, r_out, g * 48 + 32, 0, 0);
+    }
+}
+
+// K steps x N envs (time-major).  pass 0: states -> img_out for every image; pass 1 (img_final):
+// final_states -> img_final for the steps that ended in a reset.
+int launch_imagec_obs(mdpp_env *h, int K, const float *states, const float *final_states, const uint8_t *term,
+                      const uint8_t *trunc, const uint8_t *mask, uint8_t *img_out, uint8_t *img_final, hipStream_t s) {
+    const mdpp_config &c = h->cfg;
+    ImageCArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = c.num_envs; a.D = c.D; a.W = c.img_w; a.H = c.img_h; a.R = c.img_r0; a.n_sub = c.D > 2 ? 2 : 1;
+    a.n_boxes = c.n_boxes; a.autoreset = c.autoreset;
+    a.smax = (float)c.state_space_max;
+    a.target[0] = c.target[0]; a.target[1] = c.target[1];
+    for (int b = 0; b < c.n_boxes; b++)
+        for (int d = 0; d < 2; d++) {
+            a.box_lo[2 * b + d] = c.box_lo[b * c.n_rel + d];
+            a.box_hi[2 * b + d] = c.box_hi[b * c.n_rel + d];
+        }
+    for (int r = 0; r < 32; r++) a.disc_rows[r] = h->imgc_disc_rows[r];
+    const long M = (long)K * a.N;
+    const int per_block = kBlock / 64;
+    const size_t lds = (size_t)per_block * ((size_t)a.n_sub * a.W * a.H / 16) * 4;
+    if (lds > 64 * 1024) { h->err = "k_imagec_obs: image too large for the LDS colour map"; return MDPP_EUNSUPPORTED; }
+    const dim3 grid((unsigned)((M + per_block - 1) / per_block));
+    if (img_out)
+        hipLaunchKernelGGL(k_imagec_obs, grid, dim3(kBlock), lds, s, a, M, states, nullptr, nullptr, mask, img_out);
+    if (img_final && final_states && term)
+        hipLaunchKernelGGL(k_imagec_obs, grid, dim3(kBlock), lds, s, a, M, final_states, term, trunc, mask, img_final);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("k_imagec_obs launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    return MDPP_OK;
+}
+
+} // namespace mdpp

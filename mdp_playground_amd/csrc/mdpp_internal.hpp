@@ -88,6 +88,7 @@ struct ContinuousArgs {
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
     uint32_t *status;
     // ---- precomputed on the host for the fused fast path (mdpp_continuous_fast.hip) ----
+    int32_t image_quirk;        // image observations: every step clips and zeroes the derivatives (see k_continuous_step C4)
     uint32_t fast_ok;           // PCG64, no hypercubes, relevant dims = a prefix, bounded, delay 0, every_n 1
     uint32_t inertia_pow2;      // inertia is a power of two: a / inertia == a * inv_inertia32 exactly
     float inv_inertia32;
@@ -131,6 +132,7 @@ struct mdpp_env {
     void *d_img_tpl, *d_img_tplp, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;
     void *d_img_rec;            // ImgRec [2][img_chunk][N] per-image records (mdpp_image.hip), 64 B each
     int32_t img_chunk;          // env steps per state-kernel + draw + render batch
+    uint32_t imgc_disc_rows[32]; // continuous image observations: the disc raster, one bitmask per row
     bool img_ready, img_fast_ok;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
     int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
     uint32_t nkeys, rbits_stride;
@@ -155,6 +157,8 @@ bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, 
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
+int launch_imagec_obs(mdpp_env *h, int K, const float *states, const float *final_states, const uint8_t *term,
+                      const uint8_t *trunc, const uint8_t *mask, uint8_t *img_out, uint8_t *img_final, hipStream_t s);
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
                      uint8_t *trunc, void *final_obs, hipStream_t s);
 int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);

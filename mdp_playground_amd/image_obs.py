@@ -128,3 +128,21 @@ def _self_check(S, params, t):
                 if not np.array_equal(ref, mine):
                     raise RuntimeError("Pillow polygon raster is not translation invariant here "
                                        f"(state {s}, R {R}, centre {(cx, cy)}); cannot use templates")
+
+
+def disc_template(R):
+    """(2R+1)^2 raster (uint8, 1 = covered) of Pillow's ellipse with the integer bounding box
+    centre +- R: what ImageContinuous draws for the agent and the target
+    (/root/reference/mdp_playground/spaces/image_continuous.py:190-207).  Integer bounding boxes make
+    the raster independent of the position, so the device needs this one template."""
+    T = 2 * R + 1
+    img = Image.new("L", (T, T), 0)
+    ImageDraw.Draw(img).ellipse([(0, 0), (2 * R, 2 * R)], fill=255)
+    t = (np.array(img) != 0).astype(np.uint8)
+    # self-check of the translation invariance relied on
+    big = Image.new("L", (4 * T, 4 * T), 0)
+    ImageDraw.Draw(big).ellipse([(T + 3, T + 5), (T + 3 + 2 * R, T + 5 + 2 * R)], fill=255)
+    b = (np.array(big) != 0).astype(np.uint8)
+    if not (np.array_equal(b[T + 5:T + 5 + T, T + 3:T + 3 + T], t) and b.sum() == t.sum()):
+        raise RuntimeError("Pillow ellipse raster is not translation invariant here; cannot use a template")
+    return t

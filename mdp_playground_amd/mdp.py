@@ -143,6 +143,7 @@ class ContinuousMDP(CommonParams):
     transition_noise: float | None = None    # std; None = no draw
     box_lo: np.ndarray = None                # float32 [K, n_rel] terminal hypercubes
     box_hi: np.ndarray = None
+    image: dict | None = None                # ImageContinuous parameters (width, height, circle_radius), or None
 
 
 @dataclass
@@ -385,13 +386,20 @@ def build_continuous(config) -> ContinuousMDP:
     rf = config.get("reward_function", "move_to_a_point")
     if rf != "move_to_a_point":
         raise NotImplementedError("only reward_function='move_to_a_point' is built (SURVEY.md §8f)")
+    image = None
     if config.get("image_representations", False):
-        raise NotImplementedError("ImageContinuous observations are not built yet (SURVEY.md §8f)")
+        # ImageContinuous(feature_space, width, height, term_spaces, target_point, circle_radius=5)
+        # (:770-778): RGB, relevant_indices left at its default [0, 1], at most 2 + 2 dimensions
+        image = dict(width=config.get("image_width", 100), height=config.get("image_height", 100),
+                     circle_radius=5)
     _require(common["sequence_length"] == 1, "move_to_a_point needs sequence_length == 1")
     if config.get("irrelevant_features", False):
         _require("relevant_indices" in config,
                  "Please provide dimensions of state space relevant to rewards.")
     rel = list(config.get("relevant_indices", range(D)))
+    if image is not None and (D not in (2, 4) or len(rel) != 2):
+        raise NotImplementedError("ImageContinuous observations: 2 relevant dimensions, and 2 or 4 state "
+                                  "dimensions in all (the reference's picture is built from dims [0, 1] and [2, 3])")
     if "target_point" in config:
         target = np.array(config["target_point"], dtype=np.float32)
         _require(target.shape == (len(rel),),
@@ -424,7 +432,8 @@ def build_continuous(config) -> ContinuousMDP:
         target_point=target, target_radius=config.get("target_radius", 0.05),
         make_denser=config.get("make_denser", True),
         action_loss_weight=config.get("action_loss_weight", 0.0),
-        transition_noise=None if tn is None else float(tn), box_lo=box_lo, box_hi=box_hi, **common)
+        transition_noise=None if tn is None else float(tn), box_lo=box_lo, box_hi=box_hi, image=image,
+        **common)
 
 
 def build_grid(config) -> GridMDP:

@@ -106,6 +106,10 @@ class RLToyVectorEnv:
         self._cfg = cfg
         if m.kind == "discrete":
             self._upload_discrete()
+        elif m.kind == "continuous" and self._image is not None:
+            disc = np.ascontiguousarray(self._image["disc"], dtype=np.uint8)
+            rc = self._lib.mdpp_upload_image_disc(self._h, capi.nptr(disc))
+            capi.check(self._lib, self._h, rc, "mdpp_upload_image_disc")
         self._alloc_buffers()
         if rng == "numpy":
             self._seed_streams(self.seed_dict.get("env"), initial=True)
@@ -254,6 +258,22 @@ class RLToyVectorEnv:
         self._obs_torch_dtype = torch.float32
         self.single_observation_space = BoxSpace(-m.state_space_max, m.state_space_max, (m.D,),
                                                  seed=m.seed_dict.get("state_space"))
+        self._image = None
+        if m.image is not None:
+            # ImageContinuous observations (:770-778): uint8 [n_sub * W][H][3]; no random transforms
+            from . import image_obs
+            im = m.image
+            if (im["width"] * im["height"]) % 16 != 0:
+                raise NotImplementedError("ImageContinuous on the device: image_width * image_height must be "
+                                          "divisible by 16")
+            if not np.isfinite(m.state_space_max):
+                raise AssertionError("ImageContinuous needs a bounded feature space")   # image_continuous.py:62-63
+            self._image = dict(im, disc=image_obs.disc_template(im["circle_radius"]), n_sub=2 if m.D > 2 else 1)
+            cfg.image, cfg.img_w, cfg.img_h, cfg.img_r0 = 1, im["width"], im["height"], im["circle_radius"]
+            cfg.obs_dtype = capi.OBS_IMAGE_U8
+            self._obs_torch_dtype = torch.uint8
+            self.single_observation_space = BoxSpace(0, 255, (self._image["n_sub"] * im["width"], im["height"], 3),
+                                                     dtype=np.uint8)
         self.single_action_space = BoxSpace(-m.action_space_max, m.action_space_max, (m.D,),
                                             seed=m.seed_dict.get("action_space"))
 
@@ -284,6 +304,9 @@ class RLToyVectorEnv:
 
     def _obs_shape(self, *lead):
         if self.kind == "continuous":
+            if getattr(self, "_image", None) is not None:
+                im = self._image
+                return tuple(lead) + (im["n_sub"] * im["width"], im["height"], 3)
             return tuple(lead) + (self.mdps[0].D,)
         if self.kind == "grid":
             return tuple(lead) + (len(self.mdps[0].grid_shape),)
@@ -424,6 +447,8 @@ class RLToyVectorEnv:
         if self.kind == "grid":
             return "k_grid_step"
         m = self.mdps[0]
+        if getattr(self, "_image", None) is not None:
+            return "k_imagec_obs"
         fast = (self.rng == "numpy" and m.box_lo is None and np.isfinite(m.state_space_max)
                 and m.delay == 0 and m.reward_every_n_steps == 1
                 and list(m.relevant_indices) == list(range(len(m.relevant_indices)))

@@ -322,6 +322,7 @@ typedef struct { double v; int is32; } rew_t; /* np.float32 vs Python float */
 
 struct ora_continuous {
     int D, n_rel, order, make_denser, has_p_noise, has_r_noise, delay, every_n, n_boxes;
+    int image_quirk;
     int rel[ORA_MAX_DIM];
     float inertia32, amax32, smax32, radius32, alw32;
     float tpow32[ORA_MAX_ORDER + 1];  /* float32(time_unit ** k) */
@@ -374,6 +375,8 @@ ora_continuous *ora_c_create(int D, int n_rel, const int32_t *rel_idx, int order
     }
     return e;
 }
+
+void ora_c_set_image_quirk(ora_continuous *e, int on) { e->image_quirk = on; }
 
 void ora_c_destroy(ora_continuous *e) {
     if (!e) return;
@@ -488,6 +491,10 @@ void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
     /* C4: :1694-1717 */
     int inside = 1;
     for (int i = 0; i < D; i++) if (!(nxt[i] >= -e->smax32 && nxt[i] <= e->smax32)) inside = 0;
+    /* image_representations=True: observation_space is the ImageContinuous space, whose contains()
+     * returns None for a state vector (spaces/image_continuous.py:292-302), so the reference takes
+     * the out-of-bounds branch on EVERY step: clip (a no-op inside the box) and zero all derivatives */
+    if (e->image_quirk) inside = 0;
     if (!inside) {
         for (int i = 0; i < D; i++) {
             float x = nxt[i]; /* np.clip = minimum(maximum(x, lo), hi); NaN propagates */
@@ -643,4 +650,56 @@ void ora_i_rotate_flip_transpose(int W, int H, const uint8_t *src, int angle, in
         obs[x * H + y] = rot[sy * W + sx];
     }
     free(rot);
+}
+
+/* ======================================================================
+ * ImageContinuous.get_image_representation (spaces/image_continuous.py:116-277) for a continuous
+ * env: per 2-D sub-space one W x H RGB picture -- background (208,208,208); the terminal
+ * hypercubes as black rectangles (corner pixels from convert_to_pixel, inclusive, :176-188); the
+ * target as a green disc and the agent as a blue disc, both Pillow ellipses with the integer
+ * bounding box centre +- R (:190-207), i.e. a fixed (2R+1)^2 raster `disc` (made by the caller
+ * with Pillow, the third-party rasteriser the reference calls) at an integer position; the
+ * irrelevant sub-space's picture shows only its agent disc; pictures are concatenated along the
+ * first axis after the transpose (:209-212, :239-250).  out: uint8 [n_sub * W][H][3].
+ * convert_to_pixel (:252-277): ((v - min) / (max - min)) in float32, times the image size in
+ * float64, truncated toward zero. */
+static void ic_pixel(float vx, float vy, float smax, int W, int H, int *px, int *py) {
+    const float lo = -smax, hi = smax;
+    const float fx = (vx - lo) / (hi - lo), fy = (vy - lo) / (hi - lo);
+    *px = (int)((double)fx * (double)W);
+    *py = (int)((double)fy * (double)H);
+}
+
+void ora_ic_render(int W, int H, int R, const uint8_t *disc /* [(2R+1)*(2R+1)], [dy][dx] */,
+                   int D, const float *state, float smax, const float *target /* [2] */,
+                   int n_boxes, const float *box_lo, const float *box_hi /* [n_boxes*2] */,
+                   uint8_t *out) {
+    const int n_sub = D > 2 ? 2 : 1, T = 2 * R + 1;
+    for (int sub = 0; sub < n_sub; sub++) {
+        uint8_t *img = out + (size_t)sub * W * H * 3;      /* [x][y][c] */
+        for (size_t k = 0; k < (size_t)W * H * 3; k++) img[k] = 208;
+        if (sub == 0) {
+            for (int b = 0; b < n_boxes; b++) {
+                int x0, y0, x1, y1;
+                ic_pixel(box_lo[2 * b], box_lo[2 * b + 1], smax, W, H, &x0, &y0);
+                ic_pixel(box_hi[2 * b], box_hi[2 * b + 1], smax, W, H, &x1, &y1);
+                for (int x = x0 < 0 ? 0 : x0; x <= x1 && x < W; x++)
+                    for (int y = y0 < 0 ? 0 : y0; y <= y1 && y < H; y++)
+                        img[((size_t)x * H + y) * 3] = img[((size_t)x * H + y) * 3 + 1] = img[((size_t)x * H + y) * 3 + 2] = 0;
+            }
+        }
+        for (int pass = (sub == 0 ? 0 : 1); pass < 2; pass++) {    /* 0: target (green), 1: agent (blue) */
+            int cx, cy;
+            if (pass == 0) ic_pixel(target[0], target[1], smax, W, H, &cx, &cy);
+            else ic_pixel(state[2 * sub], state[2 * sub + 1], smax, W, H, &cx, &cy);
+            for (int dy = 0; dy < T; dy++)
+                for (int dx = 0; dx < T; dx++) {
+                    if (!disc[dy * T + dx]) continue;
+                    const int x = cx - R + dx, y = cy - R + dy;
+                    if (x < 0 || x >= W || y < 0 || y >= H) continue;
+                    uint8_t *p = img + ((size_t)x * H + y) * 3;
+                    p[0] = 0; p[1] = pass == 0 ? 255 : 0; p[2] = pass == 0 ? 0 : 255;
+                }
+        }
+    }
 }

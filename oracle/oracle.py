@@ -63,6 +63,8 @@ def lib():
         L.ora_c_create.argtypes = ([i32, i32, vp, i32, f64, f64, f64, f64, vp, f64, i32, f64,
                                     i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
         L.ora_c_destroy.argtypes = [vp]
+        L.ora_c_set_image_quirk.argtypes = [vp, i32]
+        L.ora_ic_render.argtypes = [i32, i32, i32, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp]
         L.ora_c_set_rng.argtypes = [vp, vp, vp]
         L.ora_c_get_rng.argtypes = [vp, vp, vp]
         L.ora_c_reset.argtypes = [vp, vp]
@@ -310,6 +312,10 @@ class ContinuousOracle:
             lib().ora_c_destroy(self.h)
             self.h = None
 
+    def set_image_quirk(self, on=True):
+        """image_representations=True: every step clips and zeroes the derivatives (mdpp_oracle.c C4)."""
+        lib().ora_c_set_image_quirk(self.h, int(on))
+
     def set_rng(self, env_words, space_words):
         a = np.ascontiguousarray(env_words, dtype=np.uint64)
         b = np.ascontiguousarray(space_words, dtype=np.uint64)
@@ -363,6 +369,31 @@ class ImageCfg(C.Structure):
                 ("has_rotate", C.c_int), ("has_flip", C.c_int), ("sh_quant", C.c_int),
                 ("ro_quant", C.c_int), ("R0", C.c_int), ("log_min_R", C.c_double),
                 ("log_max_R", C.c_double)]
+
+
+def disc_template(R):
+    """(2R+1)^2 raster of Pillow's ellipse with the integer bounding box centre +- R (what
+    ImageContinuous draws for the agent and the target, spaces/image_continuous.py:190-207)."""
+    import PIL.Image as Image
+    import PIL.ImageDraw as ImageDraw
+    T = 2 * R + 1
+    img = Image.new("L", (T, T), 0)
+    ImageDraw.Draw(img).ellipse([(0, 0), (2 * R, 2 * R)], fill=255)
+    return (np.array(img) != 0).astype(np.uint8)
+
+
+def image_continuous_render(W, H, R, state, smax, target, box_lo=None, box_hi=None):
+    """uint8 [n_sub * W, H, 3] observation of a continuous state (2 or 4 dims)."""
+    state = np.ascontiguousarray(state, dtype=np.float32)
+    D = state.shape[0]
+    disc = np.ascontiguousarray(disc_template(R))
+    tgt = np.ascontiguousarray(target, dtype=np.float32)
+    nb = 0 if box_lo is None else len(box_lo)
+    lo = None if nb == 0 else np.ascontiguousarray(box_lo, dtype=np.float32)
+    hi = None if nb == 0 else np.ascontiguousarray(box_hi, dtype=np.float32)
+    out = np.zeros(((2 if D > 2 else 1) * W, H, 3), np.uint8)
+    lib().ora_ic_render(W, H, R, _p(disc), D, _p(state), C.c_float(smax), _p(tgt), nb, _p(lo), _p(hi), _p(out))
+    return out
 
 
 def image_draw(cfg, rng_words):

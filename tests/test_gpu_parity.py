@@ -644,6 +644,78 @@ def test_image_batch_vs_oracle(name):
     env.close(); twin.close()
 
 
+# ----------------------------------------------------------------------------- ImageContinuous
+@pytest.mark.parametrize("name", gu.IMAGE_CONT)
+def test_continuous_image_observations_vs_reference_golden(name):
+    """Continuous envs with image_representations: every pixel of the RGB pictures the reference
+    drew (Pillow rectangles and ellipses), rewards and flags under the every-step
+    clip-and-zero-derivatives quirk, masked resets, terminal pictures of reset steps."""
+    g = gu.load(name)
+    E, T, D = g["action"].shape
+    env = _venv(autoreset="disabled", **_seeds_or_cfg(name))
+    assert np.array_equal(env._obs.cpu().numpy(), g["init_obs"])
+    for t in range(T):
+        a = torch.as_tensor(g["action"][:, t], device=env.device)
+        obs, rew, term, trunc, _ = env.step(a)
+        assert np.array_equal(obs.cpu().numpy(), g["obs"][:, t]), (name, t)
+        assert np.array_equal(term.cpu().numpy(), g["done"][:, t]), (name, t)
+        assert np.array_equal(rew.cpu().numpy(), g["reward"][:, t].astype(np.float32)), (name, t)
+        ra = g["reset_after"][:, t]
+        if ra.any():
+            o, _ = env.reset(mask=torch.as_tensor(ra, device=env.device))
+            assert np.array_equal(o.cpu().numpy()[ra], g["reset_obs"][:, t][ra])
+    st = env.get_augmented_state()
+    assert np.array_equal(st["state_derivatives"].view(np.uint32), g["sd"][:, -1].view(np.uint32)) or g["reset_after"][:, -1].any()
+    env.close()
+
+
+def test_continuous_image_batch_vs_oracle_and_fused():
+    """512 envs x 40 steps of a 4-D env with terminal hypercubes and both noises: the fused rollout
+    (batches of 16 steps: state kernel + render kernel) equals single steps bit for bit, and every
+    4th env's pictures (observation, terminal observation of reset steps, first observation after)
+    equal the oracle's."""
+    from oracle import oracle as ora
+    cfg = dict(state_space_type="continuous", state_space_dim=4, relevant_indices=[0, 1],
+               transition_dynamics_order=2, inertia=1.0, time_unit=1.0, state_space_max=4, action_space_max=1,
+               make_denser=True, target_point=[1.5, -2.0], target_radius=0.7,
+               terminal_states=[[-2.0, 2.0], [3.0, 0.0]], term_state_edge=1.5, transition_noise=0.1,
+               reward_noise=0.05, reward_function="move_to_a_point", image_representations=True,
+               image_width=64, image_height=80, seed=4)
+    N, K = 512, 40
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    assert a.rollout_kernel_name(K) == "k_imagec_obs"
+    acts = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, size=(K, N, 4)).astype(np.float32), device=a.device)
+    obs, rew, term, trunc = a.rollout(acts)
+    assert term.any()
+    fins = []
+    for t in range(K):
+        o, r, te, tr, info = b.step(acts[t])
+        assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(te, term[t]), t
+        fins.append(info["final_obs"].cpu().numpy().copy())
+    obs_h, term_h, rew_h, acts_h = obs.cpu().numpy(), term.cpu().numpy(), rew.cpu().numpy(), acts.cpu().numpy()
+    m = a.mdps[0]
+
+    def picture(state):
+        return ora.image_continuous_render(64, 80, 5, state, 4.0, cfg["target_point"], m.box_lo, m.box_hi)
+    n_final = 0
+    for i in range(0, N, 4):
+        o = _oracle_for(a, i)
+        o.set_image_quirk(True)
+        o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i])
+        o.reset()
+        for t in range(K):
+            st, r, is32, d = o.step(acts_h[t, i])
+            assert d == bool(term_h[t, i]) and np.float32(r) == rew_h[t, i], (i, t)
+            if d:
+                assert np.array_equal(picture(st), fins[t][i]), (i, t)
+                n_final += 1
+                st = o.reset()
+            assert np.array_equal(picture(st), obs_h[t, i]), (i, t)
+    assert n_final > 20
+    a.close(); b.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _cfg(name, seed):
     return dict(gu.CASES[name]["config"], seed=seed)

@@ -79,3 +79,42 @@ def test_template_shapes_and_areas():
     assert t["tpl"].shape[:2] == (8, 1) and t["tpl_size"] == 43
     areas = t["tpl"][:, 0, 0, 0].astype(bool).sum(axis=(1, 2))
     assert areas[0] == 569 and areas[-1] == 1255      # 569-1255 px set
+
+
+@pytest.mark.parametrize("name", gu.IMAGE_CONT)
+def test_oracle_continuous_images_match_reference(name):
+    """ImageContinuous observations of continuous envs (spaces/image_continuous.py:116-277): every
+    pixel of every RGB picture, and the dynamics quirk that comes with them (with image
+    observations the reference clips and zeroes the derivatives on EVERY step)."""
+    g = gu.load(name)
+    cfg = gu.CASES[name]["config"]
+    E, T, D = g["action"].shape
+    p = gu.continuous_params(cfg)
+    W, H = cfg["image_width"], cfg["image_height"]
+
+    def picture(state):
+        return ora.image_continuous_render(W, H, 5, state, cfg["state_space_max"], cfg["target_point"],
+                                           p["box_lo"], p["box_hi"])
+    for e in range(E):
+        o = ora.ContinuousOracle(**p)
+        o.set_image_quirk(True)
+        sd = g["seed_dict"][e]
+        fresh = lambda s: ora.pcg_words(np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(s)))))  # noqa: E731
+        o.set_rng(fresh(sd[0]), fresh(sd[5]))
+        s0 = o.reset()
+        assert np.array_equal(s0, g["init_state"][e])
+        assert np.array_equal(picture(s0), g["init_obs"][e])
+        for t in range(T):
+            st, r, is32, d = o.step(g["action"][e, t])
+            assert np.array_equal(st.view(np.uint32), g["curr_state"][e, t].view(np.uint32)), (name, e, t)
+            assert np.array_equal(o.derivs().view(np.uint32), g["sd"][e, t].view(np.uint32)), (name, e, t)
+            assert np.float64(r).view(np.uint64) == g["reward"][e, t].view(np.uint64) and d == bool(g["done"][e, t])
+            assert np.array_equal(picture(st), g["obs"][e, t]), (name, e, t)
+            if g["reset_after"][e, t]:
+                assert np.array_equal(picture(o.reset()), g["reset_obs"][e, t]), (name, e, t)
+
+
+def test_disc_template_is_pillows_ellipse():
+    t = image_obs.disc_template(5)
+    assert t.shape == (11, 11) and int(t.sum()) == 97          # the 97 blue pixels of the reference's agent
+    assert np.array_equal(t, ora.disc_template(5))

@@ -182,6 +182,24 @@ CASES = {
                     target_point=[0.0, 0.0], target_radius=0.8, reward_noise=0.1,
                     reward_every_n_steps=2, reward_function="move_to_a_point"),
         seeds=list(range(8)), T=200, reset="mixed"),
+    # --- continuous + ImageContinuous observations: RGB pictures, and the
+    # reference's quirk that every step takes the clip-and-zero-derivatives branch -----------------
+    "ci_2d": dict(
+        config=dict(state_space_type="continuous", state_space_dim=2, transition_dynamics_order=2,
+                    inertia=1.0, time_unit=1.0, state_space_max=5, action_space_max=1,
+                    make_denser=True, target_point=[1.0, -1.0], target_radius=0.5,
+                    terminal_states=[[-3.0, 3.0], [3.0, 3.0]], term_state_edge=2.0,
+                    reward_function="move_to_a_point", image_representations=True,
+                    image_width=100, image_height=100),
+        seeds=[0, 1, 2], T=40, reset="on_done", bad_action_every=17),
+    "ci_4d_noise": dict(
+        config=dict(state_space_type="continuous", state_space_dim=4, relevant_indices=[0, 1],
+                    transition_dynamics_order=1, inertia=1.0, time_unit=0.5, state_space_max=3,
+                    action_space_max=1, make_denser=False, target_point=[-1.0, 2.0],
+                    target_radius=0.6, transition_noise=0.3, reward_noise=0.1,
+                    reward_function="move_to_a_point", image_representations=True,
+                    image_width=64, image_height=48),
+        seeds=[0, 1], T=40, reset="mixed"),
     # --- discrete + image observations -------------------------------------
     "i_cfg4": dict(config=CFG4, seeds=[0, 1], T=24, reset="on_done"),
     "i_100_all": dict(
