@@ -60,6 +60,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
     constexpr int NPS = D + 1;                  // normals per step slot (D transition + 1 reward)
     __shared__ double s_z[HELPER ? kNRing * NPS * kBlock : 1];   // [slot][draw][lane]
     __shared__ uint32_t s_prod[kBlock / 64], s_cons[kBlock / 64];
+    __shared__ __align__(16) float s_tr[(D > 4 ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
     const int tid = threadIdx.x;
     if (NOISE) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
     if (HELPER && tid < kBlock / 64) { s_prod[tid] = 0; s_cons[tid] = 0; }
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
     auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kCRsrc);
     auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kCRsrc);
     const uint32_t v1 = i, v4 = i * 4u, vrow = i * (uint32_t)(D * 4);
+    const bool full_wave = (i - (i & 63u)) + 64u <= N;     // all 64 lanes of this wave own an env
     const uint32_t row_bytes = N * (uint32_t)(D * 4);
 
     const float amax = a.amax32, smax = a.smax32, radius = a.radius32;
@@ -308,12 +310,31 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[0]), __float_as_uint(cur[1])},
                                                   r_obs, vrow, so * (uint32_t)(D * 4), 0);
         } else {
+            if (V > 1 && full_wave) {
+            // rows of D floats -> the wave's 64 rows as one contiguous block, through a wave-private
+            // LDS tile: every store instruction then writes 1 KiB of consecutive bytes instead of 64
+            // pieces of 16 B at a stride of 4 D bytes (+15 % on cfg3, tools/ablate_cont.py)
+            u32x4 *tile = (u32x4 *)(s_tr + (size_t)wv * 64 * D);
+            const int l = ln & 63;
 #pragma unroll
             for (int q = 0; q < V; q++)
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    u32x4{__float_as_uint(cur[4 * q]), __float_as_uint(cur[4 * q + 1]),
-                          __float_as_uint(cur[4 * q + 2]), __float_as_uint(cur[4 * q + 3])},
-                    r_obs, vrow + 16u * q, so * (uint32_t)(D * 4), 0);
+                tile[l * V + q] = u32x4{__float_as_uint(cur[4 * q]), __float_as_uint(cur[4 * q + 1]),
+                                        __float_as_uint(cur[4 * q + 2]), __float_as_uint(cur[4 * q + 3])};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const uint32_t wbase = (i - (uint32_t)l) * (uint32_t)(D * 4);
+#pragma unroll
+            for (int q = 0; q < V; q++)
+                __builtin_amdgcn_raw_buffer_store_b128(tile[q * 64 + l], r_obs, wbase + (uint32_t)(q * 64 + l) * 16u,
+                                                       so * (uint32_t)(D * 4), 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            } else {                              // D = 4 rows are contiguous as they are; ragged last wave
+#pragma unroll
+                for (int q = 0; q < V; q++)
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        u32x4{__float_as_uint(cur[4 * q]), __float_as_uint(cur[4 * q + 1]),
+                              __float_as_uint(cur[4 * q + 2]), __float_as_uint(cur[4 * q + 3])},
+                        r_obs, vrow + 16u * q, so * (uint32_t)(D * 4), 0);
+            }
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), r_rew, v4, so * 4u, 0);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so, 0);

@@ -8,7 +8,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CSRC = os.path.join(ROOT, "mdp_playground_amd", "csrc")
 VARIANTS = ["", "-DMDPP_CAHEAD=2", "-DMDPP_CAHEAD=8", "-DMDPP_ABL_NOSTORE"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
-OBJS = ["mdpp_capi.o", "mdpp_discrete.o", "mdpp_discrete_fast.o", "mdpp_discrete_pipe.o", "mdpp_continuous.o", "mdpp_image.o"]
+sys.path.insert(0, ROOT)
+from mdp_playground_amd import build as B  # noqa: E402
+OBJS = [os.path.splitext(f)[0] + ".o" for f in B.SOURCES if f != "mdpp_continuous_fast.hip"]
 
 
 def main():
@@ -29,7 +31,7 @@ from mdp_playground_amd import RLToyVectorEnv
 cfg = dict(state_space_type="continuous", state_space_dim=12, relevant_indices=[0, 1, 2, 3], irrelevant_features=True,
            target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10, action_space_max=1,
            transition_dynamics_order=1, inertia=1, time_unit=1, make_denser=True, reward_function="move_to_a_point", seed=0)
-N, F = 65536, 128
+N, F = 65536, 512
 env = RLToyVectorEnv(num_envs=N, autoreset="same_step", **cfg)
 acts = (torch.rand((F, N, 12), device=env.device) * 2 - 1)
 out = env.alloc_rollout(F)
