@@ -159,6 +159,11 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
 
     auto load_row = [&](int k, float (&dst)[D]) {
         const uint32_t kk = (uint32_t)min(k, K - 1);
+#ifdef MDPP_ABL_NOLOAD
+#pragma unroll
+        for (int d = 0; d < D; d++) dst[d] = 0.001f * (float)((kk + d + i) & 1023u) - 0.5f;
+        return;
+#endif
         if (D == 2) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_act, vrow, kk * row_bytes, 0);

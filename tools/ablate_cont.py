@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CSRC = os.path.join(ROOT, "mdp_playground_amd", "csrc")
-VARIANTS = ["", "-DMDPP_CAHEAD=2", "-DMDPP_CAHEAD=8", "-DMDPP_ABL_NOSTORE"]
+VARIANTS = ["", "-DMDPP_ABL_NOLOAD", "-DMDPP_ABL_NOSTORE", "-DMDPP_ABL_NOLOAD -DMDPP_ABL_NOSTORE"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]
 sys.path.insert(0, ROOT)
 from mdp_playground_amd import build as B  # noqa: E402
@@ -19,7 +19,7 @@ def main():
     for n, v in enumerate(VARIANTS):
         obj = os.path.join(outdir, f"cf_{n}.o")
         so = os.path.join(outdir, f"libmdpp_c{n}.so")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ([v] if v else []) + ["-c", os.path.join(CSRC, "mdpp_continuous_fast.hip"), "-o", obj],
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + v.split() + ["-c", os.path.join(CSRC, "mdpp_continuous_fast.hip"), "-o", obj],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", so] + [os.path.join(CSRC, o) for o in OBJS] + [obj])
         code = f"""
