@@ -20,7 +20,8 @@ def main():
     import torch
     outdir = os.path.join(ROOT, "gpurun_out", "ablate")
     os.makedirs(outdir, exist_ok=True)
-    objs = [os.path.join(CSRC, f) for f in ("mdpp_capi.o", "mdpp_discrete.o", "mdpp_discrete_fast.o", "mdpp_continuous.o", "mdpp_continuous_fast.o", "mdpp_image.o")]
+    from mdp_playground_amd import build as B
+    objs = [os.path.join(CSRC, os.path.splitext(f)[0] + ".o") for f in B.SOURCES if f != "mdpp_discrete_pipe.hip"]
     for v in VARIANTS:
         tag = v.replace(",", "_") or "FULL"
         obj = os.path.join(outdir, f"fast_{tag}.o")
