@@ -116,7 +116,7 @@ typedef struct {
     /* ---- image observations: discrete envs (ImageMultiDiscrete: polygons, random transforms), or
      * continuous envs (ImageContinuous, spaces/image_continuous.py:116-277: RGB pictures, uses image,
      * img_w, img_h and img_r0 = radius of the agent / target discs only) ---- */
-    int32_t image;              /* 1: obs is uint8[W][H][1] per env (discrete) or uint8[n_sub W][H][3] (continuous) */
+    int32_t image;              /* 1: obs is uint8[W][H][1] per env (discrete) or uint8[n_sub W][H][3] (continuous, grid) */
     int32_t img_w, img_h;
     int32_t img_has_scale, img_has_shift, img_has_rotate, img_has_flip;
     int32_t img_sh_quant, img_ro_quant;
@@ -159,6 +159,10 @@ int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl_host, int32_t n_
 /* Continuous image observations: disc uint8 [(2 R + 1)][(2 R + 1)], non-zero = covered, R = cfg.img_r0:
  * the raster of Pillow's ellipse with the integer bounding box centre +- R (image_continuous.py:190-207). */
 int mdpp_upload_image_disc(mdpp_env *h, const uint8_t *disc_host);
+/* Grid envs with image observations additionally: lines uint8 [n_sub W][H], non-zero = white grid line
+ * (Pillow's draw.line from the reference's end points, image_continuous.py:145-165); the terminal
+ * cells drawn as rectangles ride in cfg.box_lo[2 b + d] (cell coordinates), cfg.n_boxes of them. */
+int mdpp_upload_image_lines(mdpp_env *h, const uint8_t *lines_host);
 
 /* RNG streams.  words_host: uint64 [num_envs][6] = PCG64 {state_lo, state_hi, inc_lo, inc_hi,
  * has_uint32, uinteger} exactly as numpy's bit_generator.state reports them. */

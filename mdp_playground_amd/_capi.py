@@ -22,7 +22,7 @@ EXPORTS = [
     "mdpp_set_state_discrete", "mdpp_get_state_continuous", "mdpp_set_state_continuous",
     "mdpp_status", "mdpp_timer_begin", "mdpp_timer_end",
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
-    "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc",
+    "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
 ]
 
 
@@ -96,6 +96,7 @@ def load():
     L.mdpp_get_state_irrelevant.argtypes = [vp, vp]
     L.mdpp_set_state_irrelevant.argtypes = [vp, vp]
     L.mdpp_upload_image_disc.argtypes = [vp, vp]
+    L.mdpp_upload_image_lines.argtypes = [vp, vp]
     L.mdpp_get_state_grid.argtypes = [vp] * 4
     L.mdpp_set_state_grid.argtypes = [vp] * 4
     L.mdpp_status.argtypes = [vp, vp]

@@ -99,7 +99,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = nullptr;
     h->img_chunk = 16;
-    h->img_ready = false; h->img_fast_ok = false;
+    h->img_ready = false; h->img_fast_ok = false; h->img_lines_ready = false;
+    for (int r = 0; r < 32; r++) h->imgc_disc_rows[r] = 0;
     h->img_n_radii = h->img_n_cls_x = h->img_n_cls_y = 0;
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) { h->d_rng_s[s] = h->d_rng_inc[s] = nullptr; h->streams_ready[s] = false; }
     h->tables_ready = false;
@@ -287,13 +288,22 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.status = (uint32_t *)h->d_status;
         h->tables_ready = true;
     } else if (cfg->kind == MDPP_KIND_GRID) {
-        bool ok = (cfg->grid_dims == 2 || cfg->grid_dims == 4) && cfg->delay == 0 && !cfg->image;
+        bool ok = (cfg->grid_dims == 2 || cfg->grid_dims == 4) && cfg->delay == 0;
         for (int d = 0; ok && d < cfg->grid_dims; d++) ok = cfg->grid_shape[d] >= 1 && cfg->grid_shape[d] <= 254;
+        if (ok && cfg->image)
+            ok = cfg->img_w >= 1 && cfg->img_h >= 1 && ((size_t)cfg->img_w * cfg->img_h) % 16 == 0 &&
+                 cfg->img_r0 >= 1 && cfg->img_r0 <= 15 && cfg->n_boxes >= 0 && cfg->n_boxes <= MDPP_MAX_BOXES;
         if (!ok) {
-            g_create_err = "mdpp_create: grid needs 2 (or 4) dimensions of 1..254 cells, delay 0, no image observations";
+            g_create_err = "mdpp_create: grid needs 2 (or 4) dimensions of 1..254 cells and delay 0; with image "
+                           "observations also width * height divisible by 16, disc radius 1..15, <= 8 terminal cells";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         TRY(alloc_zero(h, &h->d_state, N * sizeof(uint4)));
+        if (cfg->image) {   // scratch of one batch of img_chunk env steps: the cells the pictures are made from
+            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * cfg->grid_dims * 4));
+            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * cfg->grid_dims * 4));
+            TRY(alloc_zero(h, &h->d_img_tpl, (size_t)(cfg->grid_dims / 2) * cfg->img_w * cfg->img_h / 16 * 2));   // grid-line bits
+        }
         GridArgs &a = h->gargs;
         memset(&a, 0, sizeof(a));
         a.N = cfg->num_envs; a.G = cfg->grid_dims;
@@ -302,7 +312,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.make_denser = cfg->make_denser; a.has_p_noise = cfg->has_transition_noise;
         a.has_r_noise = cfg->has_reward_noise; a.every_n = cfg->every_n;
         a.autoreset = cfg->autoreset; a.max_steps = cfg->max_episode_steps;
-        a.obs_i32 = (cfg->obs_dtype == MDPP_OBS_I32);
+        a.obs_i32 = (cfg->obs_dtype == MDPP_OBS_I32 || cfg->image);
         a.philox = (cfg->rng_mode == MDPP_RNG_PHILOX);
         a.philox_seed = cfg->philox_seed; a.env_id_offset = cfg->env_id_offset;
         a.p_noise = cfg->transition_noise; a.r_noise = cfg->reward_noise;
@@ -395,14 +405,31 @@ extern "C" int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P1, c
 
 extern "C" int mdpp_upload_image_disc(mdpp_env *h, const uint8_t *disc) {
     if (!h || !disc) return MDPP_EINVAL;
-    if (h->cfg.kind != MDPP_KIND_CONTINUOUS || !h->cfg.image)
-        return fail(h, MDPP_EINVAL, "upload_image_disc: not a continuous handle with image observations");
+    if ((h->cfg.kind != MDPP_KIND_CONTINUOUS && h->cfg.kind != MDPP_KIND_GRID) || !h->cfg.image)
+        return fail(h, MDPP_EINVAL, "upload_image_disc: not a continuous / grid handle with image observations");
     const int T = 2 * h->cfg.img_r0 + 1;
     for (int r = 0; r < 32; r++) h->imgc_disc_rows[r] = 0;
     for (int dy = 0; dy < T; dy++)
         for (int dx = 0; dx < T; dx++)
             if (disc[dy * T + dx]) h->imgc_disc_rows[dy] |= 1u << dx;
-    h->img_ready = true;
+    h->img_ready = h->cfg.kind == MDPP_KIND_CONTINUOUS || h->img_lines_ready;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_upload_image_lines(mdpp_env *h, const uint8_t *lines) {
+    if (!h || !lines) return MDPP_EINVAL;
+    if (h->cfg.kind != MDPP_KIND_GRID || !h->cfg.image)
+        return fail(h, MDPP_EINVAL, "upload_image_lines: not a grid handle with image observations");
+    const size_t npix = (size_t)(h->cfg.grid_dims / 2) * h->cfg.img_w * h->cfg.img_h;
+    std::vector<uint16_t> bits(npix / 16, 0);
+    for (size_t p = 0; p < npix; p++)
+        if (lines[p]) bits[p >> 4] |= (uint16_t)(1u << (p & 15));
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_img_tpl, bits.data(), bits.size() * 2, hipMemcpyHostToDevice));
+    h->img_lines_ready = true;
+    bool disc = false;
+    for (int r = 0; r < 32; r++) disc = disc || h->imgc_disc_rows[r] != 0;
+    h->img_ready = disc;
     return MDPP_OK;
 }
 
@@ -536,8 +563,8 @@ static int check_ready(mdpp_env *h, const char *what) {
         if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->streams_ready[MDPP_STREAM_SPACE_IRR])
             return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space RNG stream not seeded");
     }
-    if (h->cfg.image && h->cfg.kind == MDPP_KIND_CONTINUOUS && !h->img_ready)
-        return fail(h, MDPP_ESTATE, std::string(what) + ": image disc raster not uploaded");
+    if (h->cfg.image && h->cfg.kind != MDPP_KIND_DISCRETE && !h->img_ready)
+        return fail(h, MDPP_ESTATE, std::string(what) + ": image disc raster (and grid-line mask) not uploaded");
     if (h->cfg.kind == MDPP_KIND_DISCRETE && h->cfg.irrelevant && !h->irr_ready)
         return fail(h, MDPP_ESTATE, std::string(what) + ": irrelevant sub-space tables not uploaded");
     return MDPP_OK;
@@ -557,11 +584,16 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
         }
         return launch_discrete_reset(h, mask_dev, obs_dev, s);
     }
-    if (h->cfg.kind == MDPP_KIND_GRID) return launch_grid_reset(h, mask_dev, obs_dev, s);
+    if (h->cfg.kind == MDPP_KIND_GRID) {
+        if (!h->cfg.image) return launch_grid_reset(h, mask_dev, obs_dev, s);
+        rc = launch_grid_reset(h, mask_dev, h->d_img_state_out, s);
+        if (rc || !obs_dev) return rc;
+        return launch_imagec_obs(h, 1, h->d_img_state_out, nullptr, nullptr, nullptr, mask_dev, (uint8_t *)obs_dev, nullptr, s);
+    }
     if (h->cfg.image) {
         rc = launch_continuous_reset(h, mask_dev, (float *)h->d_img_state_out, s);
         if (rc || !obs_dev) return rc;
-        return launch_imagec_obs(h, 1, (const float *)h->d_img_state_out, nullptr, nullptr, nullptr, mask_dev,
+        return launch_imagec_obs(h, 1, h->d_img_state_out, nullptr, nullptr, nullptr, mask_dev,
                                  (uint8_t *)obs_dev, nullptr, s);
     }
     return launch_continuous_reset(h, mask_dev, (float *)obs_dev, s);
@@ -597,8 +629,23 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
         }
         return launch_discrete_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
     }
-    if (h->cfg.kind == MDPP_KIND_GRID)
+    if (h->cfg.kind == MDPP_KIND_GRID && !h->cfg.image)
         return launch_grid_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
+    if (h->cfg.kind == MDPP_KIND_GRID) {
+        const size_t N = (size_t)h->cfg.num_envs, G = (size_t)h->cfg.grid_dims;
+        const size_t isz = (G / 2) * h->cfg.img_w * h->cfg.img_h * 3;
+        for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
+            const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
+            const size_t off = (size_t)k0 * N;
+            rc = launch_grid_step(h, kc, (const int32_t *)actions + off * G, h->d_img_state_out, reward + off, term + off,
+                                  trunc + off, h->d_img_state_final, s);
+            if (rc) return rc;
+            rc = launch_imagec_obs(h, kc, h->d_img_state_out, h->d_img_state_final, term + off, trunc + off, nullptr,
+                                   (uint8_t *)obs + off * isz, final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
+            if (rc) return rc;
+        }
+        return MDPP_OK;
+    }
     if (h->cfg.image) {
         // batches of up to img_chunk env steps: one state kernel, one render kernel over steps x envs
         // pictures (3 W H bytes per 2-D sub-space each)
@@ -610,7 +657,7 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
             rc = launch_continuous_step(h, kc, (const float *)actions + off * D, (float *)h->d_img_state_out,
                                         reward + off, term + off, trunc + off, (float *)h->d_img_state_final, s);
             if (rc) return rc;
-            rc = launch_imagec_obs(h, kc, (const float *)h->d_img_state_out, (const float *)h->d_img_state_final,
+            rc = launch_imagec_obs(h, kc, h->d_img_state_out, h->d_img_state_final,
                                    term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
                                    final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
             if (rc) return rc;

@@ -1,4 +1,4 @@
-// ImageContinuous observations of continuous envs:
+// ImageContinuous observations of continuous and grid envs:
 // /root/reference/mdp_playground/spaces/image_continuous.py:116-277, called from
 // rl_toy_env.py:2095-2096 (step) and :2347-2350 (reset).
 //
@@ -10,6 +10,10 @@
 // the pictures are concatenated along the first axis of the [x][y][channel] observation (:209-250).
 // convert_to_pixel (:252-277): (v - min) / (max - min) in float32, times the image size in
 // float64, truncated toward zero.  No random draws.
+// Grid envs (draw_grid, :139-207): the same picture plus white grid lines (a per-config bit mask
+// made on the host with Pillow's draw.line from the reference's end points), terminal CELLS as
+// rectangles convert_to_pixel(cell) .. convert_to_pixel(cell + 1), discs at cell + 0.5, and
+// convert_to_pixel in float64 throughout: int(v / g * size).
 //
 // One wavefront per image.  Phase 1 paints 2-bit colour codes {0 background, 1 terminal, 2 target,
 // 3 agent} of the n_sub * W * H pixels into LDS with ds_or / ds_and (shapes are a few hundred
@@ -31,6 +35,9 @@ struct ImageCArgs {
     float target[2];
     float box_lo[MDPP_MAX_BOXES * 2], box_hi[MDPP_MAX_BOXES * 2];   // first two relevant dimensions
     uint32_t disc_rows[32];     // bit dx of row dy: pixel (dx, dy) of the (2R+1)^2 disc raster
+    // grid envs
+    int32_t G, shape[4], gtarget[2], term_cells[MDPP_MAX_BOXES * 2];
+    const uint16_t *lines;      // [n_sub W H / 16] grid-line bits of 16 consecutive pixels
 };
 
 __device__ __forceinline__ int ic_px(float v, float smax, int size) {
@@ -39,9 +46,13 @@ __device__ __forceinline__ int ic_px(float v, float smax, int size) {
     return (int)((double)f * (double)size);
 }
 
-// states [M][D] float32 (time-major batches of the step kernel's observations); flags (nullable):
-// only images with term | trunc set are rendered (the terminal observations of reset steps).
-__global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, const float *__restrict__ states,
+__device__ __forceinline__ int ig_px(double v, int g, int size) { return (int)((v - 0.0) / (double)(g - 0) * (double)size); }
+
+// states [M][D] float32, or [M][G] int32 cells for GRID (time-major batches of the step kernel's
+// observations); flags (nullable): only images with term | trunc set are rendered (the terminal
+// observations of reset steps).
+template <bool GRID>
+__global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, const void *__restrict__ states_v,
                                                        const uint8_t *__restrict__ term,
                                                        const uint8_t *__restrict__ trunc,
                                                        const uint8_t *__restrict__ mask,
@@ -56,7 +67,8 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
     uint32_t *codes = lds_codes + (size_t)wave * ngroup;
     for (int g = lane; g < ngroup; g += 64) codes[g] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const float *st = states + (size_t)j * a.D;
+    const float *st = (const float *)states_v + (size_t)j * a.D;
+    const int32_t *cell = (const int32_t *)states_v + (size_t)j * a.G;
     auto paint = [&](int p, uint32_t code, bool clear) {           // pixel index p = (sub W + x) H + y
         uint32_t *w = codes + (p >> 4);
         const int sh = 2 * (p & 15);
@@ -65,8 +77,15 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
     };
     // terminal hypercubes (relevant picture only), inclusive pixel rectangles
     for (int b = 0; b < a.n_boxes; b++) {
-        const int x0 = max(ic_px(a.box_lo[2 * b], a.smax, a.W), 0), y0 = max(ic_px(a.box_lo[2 * b + 1], a.smax, a.H), 0);
-        const int x1 = min(ic_px(a.box_hi[2 * b], a.smax, a.W), a.W - 1), y1 = min(ic_px(a.box_hi[2 * b + 1], a.smax, a.H), a.H - 1);
+        int x0, y0, x1, y1;
+        if (GRID) {
+            x0 = ig_px(a.term_cells[2 * b], a.shape[0], a.W); y0 = ig_px(a.term_cells[2 * b + 1], a.shape[1], a.H);
+            x1 = ig_px(a.term_cells[2 * b] + 1.0, a.shape[0], a.W); y1 = ig_px(a.term_cells[2 * b + 1] + 1.0, a.shape[1], a.H);
+        } else {
+            x0 = ic_px(a.box_lo[2 * b], a.smax, a.W); y0 = ic_px(a.box_lo[2 * b + 1], a.smax, a.H);
+            x1 = ic_px(a.box_hi[2 * b], a.smax, a.W); y1 = ic_px(a.box_hi[2 * b + 1], a.smax, a.H);
+        }
+        x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, a.W - 1); y1 = min(y1, a.H - 1);
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
         if (bw <= 0 || bh <= 0) continue;
         for (int k = lane; k < bw * bh; k += 64) {
@@ -85,17 +104,24 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
-    disc(0, ic_px(a.target[0], a.smax, a.W), ic_px(a.target[1], a.smax, a.H), 2u, true);   // over the rectangles
-    disc(0, ic_px(st[0], a.smax, a.W), ic_px(st[1], a.smax, a.H), 3u, false);              // 3 = 0b11: OR overrides
-    if (a.n_sub > 1) disc(1, ic_px(st[2], a.smax, a.W), ic_px(st[3], a.smax, a.H), 3u, false);
+    if (GRID) {     // discs at the cell centres; both sub-spaces scaled with the relevant grid's size (:261-262)
+        disc(0, ig_px(a.gtarget[0] + 0.5, a.shape[0], a.W), ig_px(a.gtarget[1] + 0.5, a.shape[1], a.H), 2u, true);
+        disc(0, ig_px(cell[0] + 0.5, a.shape[0], a.W), ig_px(cell[1] + 0.5, a.shape[1], a.H), 3u, false);
+        if (a.n_sub > 1) disc(1, ig_px(cell[2] + 0.5, a.shape[0], a.W), ig_px(cell[3] + 0.5, a.shape[1], a.H), 3u, false);
+    } else {
+        disc(0, ic_px(a.target[0], a.smax, a.W), ic_px(a.target[1], a.smax, a.H), 2u, true);   // over the rectangles
+        disc(0, ic_px(st[0], a.smax, a.W), ic_px(st[1], a.smax, a.H), 3u, false);              // 3 = 0b11: OR overrides
+        if (a.n_sub > 1) disc(1, ic_px(st[2], a.smax, a.W), ic_px(st[3], a.smax, a.H), 3u, false);
+    }
 
     // phase 2: 16 pixels -> 48 bytes per lane
     const size_t isz = (size_t)npix * 3;
     const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)j * isz), 0, (int)isz, 0x00020000);
     for (int g = lane; g < ngroup; g += 64) {
         const uint32_t c = codes[g];
+        const uint32_t ln = GRID ? (uint32_t)a.lines[g] : 0u;       // white where no shape covers the line
         u32x4 o0, o1, o2;
-        if (__builtin_amdgcn_ballot_w64(c != 0u) == 0) {
+        if (__builtin_amdgcn_ballot_w64((c | ln) != 0u) == 0) {
             o0 = o1 = o2 = u32x4{0xD0D0D0D0u, 0xD0D0D0D0u, 0xD0D0D0D0u, 0xD0D0D0D0u};
         } else {
             uint32_t d[12];
@@ -106,7 +132,8 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
                 for (int e = 0; e < 4; e++) {
                     const uint32_t code = (c >> (2 * (4 * q + e))) & 3u;
                     // bytes R, G, B as a little-endian 24-bit value
-                    px[e] = code == 0 ? 0xD0D0D0u : code == 1 ? 0u : code == 2 ? 0x00FF00u : 0xFF0000u;
+                    const uint32_t bg = (GRID && ((ln >> (4 * q + e)) & 1u)) ? 0xFFFFFFu : 0xD0D0D0u;
+                    px[e] = code == 0 ? bg : code == 1 ? 0u : code == 2 ? 0x00FF00u : 0xFF0000u;
                 }
                 d[3 * q] = px[0] | (px[1] << 24);
                 d[3 * q + 1] = (px[1] >> 8) | (px[2] << 16);
@@ -124,30 +151,42 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
 
 // K steps x N envs (time-major).  pass 0: states -> img_out for every image; pass 1 (img_final):
 // final_states -> img_final for the steps that ended in a reset.
-int launch_imagec_obs(mdpp_env *h, int K, const float *states, const float *final_states, const uint8_t *term,
+int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_states, const uint8_t *term,
                       const uint8_t *trunc, const uint8_t *mask, uint8_t *img_out, uint8_t *img_final, hipStream_t s) {
     const mdpp_config &c = h->cfg;
+    const bool grid = c.kind == MDPP_KIND_GRID;
     ImageCArgs a;
     memset(&a, 0, sizeof(a));
-    a.N = c.num_envs; a.D = c.D; a.W = c.img_w; a.H = c.img_h; a.R = c.img_r0; a.n_sub = c.D > 2 ? 2 : 1;
+    a.N = c.num_envs; a.W = c.img_w; a.H = c.img_h; a.R = c.img_r0;
     a.n_boxes = c.n_boxes; a.autoreset = c.autoreset;
-    a.smax = (float)c.state_space_max;
-    a.target[0] = c.target[0]; a.target[1] = c.target[1];
-    for (int b = 0; b < c.n_boxes; b++)
-        for (int d = 0; d < 2; d++) {
-            a.box_lo[2 * b + d] = c.box_lo[b * c.n_rel + d];
-            a.box_hi[2 * b + d] = c.box_hi[b * c.n_rel + d];
-        }
+    if (grid) {
+        a.G = c.grid_dims; a.D = c.grid_dims; a.n_sub = c.grid_dims / 2;
+        for (int d = 0; d < c.grid_dims; d++) a.shape[d] = c.grid_shape[d];
+        a.gtarget[0] = c.grid_target[0]; a.gtarget[1] = c.grid_target[1];
+        for (int b = 0; b < c.n_boxes * 2; b++) a.term_cells[b] = (int32_t)c.box_lo[b];   // terminal cells ride in box_lo
+        a.lines = (const uint16_t *)h->d_img_tpl;
+    } else {
+        a.D = c.D; a.n_sub = c.D > 2 ? 2 : 1;
+        a.smax = (float)c.state_space_max;
+        a.target[0] = c.target[0]; a.target[1] = c.target[1];
+        for (int b = 0; b < c.n_boxes; b++)
+            for (int d = 0; d < 2; d++) {
+                a.box_lo[2 * b + d] = c.box_lo[b * c.n_rel + d];
+                a.box_hi[2 * b + d] = c.box_hi[b * c.n_rel + d];
+            }
+    }
     for (int r = 0; r < 32; r++) a.disc_rows[r] = h->imgc_disc_rows[r];
     const long M = (long)K * a.N;
     const int per_block = kBlock / 64;
     const size_t lds = (size_t)per_block * ((size_t)a.n_sub * a.W * a.H / 16) * 4;
     if (lds > 64 * 1024) { h->err = "k_imagec_obs: image too large for the LDS colour map"; return MDPP_EUNSUPPORTED; }
-    const dim3 grid((unsigned)((M + per_block - 1) / per_block));
-    if (img_out)
-        hipLaunchKernelGGL(k_imagec_obs, grid, dim3(kBlock), lds, s, a, M, states, nullptr, nullptr, mask, img_out);
-    if (img_final && final_states && term)
-        hipLaunchKernelGGL(k_imagec_obs, grid, dim3(kBlock), lds, s, a, M, final_states, term, trunc, mask, img_final);
+    const dim3 grd((unsigned)((M + per_block - 1) / per_block));
+#define MDPP_IC_LAUNCH(GR, st, te, tr, im) hipLaunchKernelGGL((k_imagec_obs<GR>), grd, dim3(kBlock), lds, s, a, M, st, te, tr, mask, im)
+    if (img_out) { if (grid) MDPP_IC_LAUNCH(true, states, nullptr, nullptr, img_out); else MDPP_IC_LAUNCH(false, states, nullptr, nullptr, img_out); }
+    if (img_final && final_states && term) {
+        if (grid) MDPP_IC_LAUNCH(true, final_states, term, trunc, img_final); else MDPP_IC_LAUNCH(false, final_states, term, trunc, img_final);
+    }
+#undef MDPP_IC_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_imagec_obs launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     return MDPP_OK;

@@ -133,7 +133,7 @@ struct mdpp_env {
     void *d_img_rec;            // ImgRec [2][img_chunk][N] per-image records (mdpp_image.hip), 64 B each
     int32_t img_chunk;          // env steps per state-kernel + draw + render batch
     uint32_t imgc_disc_rows[32]; // continuous image observations: the disc raster, one bitmask per row
-    bool img_ready, img_fast_ok;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
+    bool img_ready, img_fast_ok, img_lines_ready;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
     int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
     uint32_t nkeys, rbits_stride;
     bool tables_ready, streams_ready[MDPP_NUM_STREAMS];
@@ -157,7 +157,7 @@ bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, 
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
-int launch_imagec_obs(mdpp_env *h, int K, const float *states, const float *final_states, const uint8_t *term,
+int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_states, const uint8_t *term,
                       const uint8_t *trunc, const uint8_t *mask, uint8_t *img_out, uint8_t *img_final, hipStream_t s);
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
                      uint8_t *trunc, void *final_obs, hipStream_t s);

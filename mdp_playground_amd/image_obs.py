@@ -146,3 +146,22 @@ def disc_template(R):
     if not (np.array_equal(b[T + 5:T + 5 + T, T + 3:T + 3 + T], t) and b.sum() == t.sum()):
         raise RuntimeError("Pillow ellipse raster is not translation invariant here; cannot use a template")
     return t
+
+
+def grid_line_mask(W, H, grid_shape):
+    """uint8 [n_sub * W, H] (indexed [x][y], 1 = white): the grid lines ImageContinuous draws for a
+    grid env, made with Pillow's draw.line from the reference's own end points
+    (/root/reference/mdp_playground/spaces/image_continuous.py:145-165 — which spaces the horizontal
+    lines by the x-count of the grid)."""
+    out = []
+    for offset in range(0, len(grid_shape), 2):
+        img = Image.new("L", (W, H), 0)
+        d = ImageDraw.Draw(img)
+        for i in range(1, grid_shape[0 + offset] + 1):
+            x_ = i * W // grid_shape[0 + offset] - 1
+            d.line([(x_, H), (x_, 0)], fill=255)
+        for j in range(1, grid_shape[1 + offset]):
+            y_ = j * H // grid_shape[0 + offset]
+            d.line([(W, y_), (0, y_)], fill=255)
+        out.append((np.array(img).T != 0).astype(np.uint8))
+    return np.ascontiguousarray(np.concatenate(out, axis=0))

@@ -155,6 +155,7 @@ class GridMDP(CommonParams):
     make_denser: bool = False
     transition_noise: float | None = None    # probability of replacing the action (:1736)
     terminal_states: list = None             # kept for the record: they never terminate, see build_grid
+    image: dict | None = None                # ImageContinuous parameters (width, height, circle_radius), or None
 
 
 def _require(cond, msg):
@@ -464,8 +465,14 @@ def build_grid(config) -> GridMDP:
         raise NotImplementedError("the reference's grid reward raises for delay > 0 or sequence_length > 1 (:1949)")
     if callable(config.get("terminal_states")):
         raise NotImplementedError("callable terminal_states runs on the host only")
+    image = None
     if config.get("image_representations", False):
-        raise NotImplementedError("ImageContinuous observations are not built yet (SURVEY.md §8f rank 3)")
+        # ImageContinuous(feature_space, width, height, term_spaces, target_point, circle_radius=5,
+        # grid_shape=...) (:800-811): RGB, grid lines, terminal cells drawn (though they never terminate)
+        image = dict(width=config.get("image_width", 100), height=config.get("image_height", 100),
+                     circle_radius=5)
+        if len(config.get("terminal_states") or []) > 8:
+            raise NotImplementedError("at most 8 terminal cells are drawn on the device")
     tn = config.get("transition_noise", None)
     if callable(tn):
         raise NotImplementedError("callable transition_noise runs on the host only")
@@ -477,7 +484,7 @@ def build_grid(config) -> GridMDP:
     return GridMDP(kind="grid", grid_shape=shape * 2 if irr else shape, n_rel=2, target_point=target,
                    make_denser=bool(config["make_denser"]),
                    transition_noise=None if not tn else float(tn),
-                   terminal_states=config.get("terminal_states"), **common)
+                   terminal_states=config.get("terminal_states"), image=image, **common)
 
 
 def build_mdp(config):

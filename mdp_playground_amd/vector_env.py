@@ -106,10 +106,14 @@ class RLToyVectorEnv:
         self._cfg = cfg
         if m.kind == "discrete":
             self._upload_discrete()
-        elif m.kind == "continuous" and self._image is not None:
+        elif self._image is not None:
             disc = np.ascontiguousarray(self._image["disc"], dtype=np.uint8)
             rc = self._lib.mdpp_upload_image_disc(self._h, capi.nptr(disc))
             capi.check(self._lib, self._h, rc, "mdpp_upload_image_disc")
+            if m.kind == "grid":
+                lines = np.ascontiguousarray(self._image["lines"], dtype=np.uint8)
+                rc = self._lib.mdpp_upload_image_lines(self._h, capi.nptr(lines))
+                capi.check(self._lib, self._h, rc, "mdpp_upload_image_lines")
         self._alloc_buffers()
         if rng == "numpy":
             self._seed_streams(self.seed_dict.get("env"), initial=True)
@@ -230,6 +234,24 @@ class RLToyVectorEnv:
         self.single_observation_space.high = np.asarray(m.grid_shape, dtype=np.int64)
         self.single_action_space = BoxSpace(-1, 1, (G,), dtype=np.int64, seed=m.seed_dict.get("action_space"))
         self._image = None
+        if m.image is not None:
+            # ImageContinuous with grid lines (:800-811): uint8 [n_sub * W][H][3]
+            from . import image_obs
+            im = m.image
+            if (im["width"] * im["height"]) % 16 != 0:
+                raise NotImplementedError("ImageContinuous on the device: image_width * image_height must be "
+                                          "divisible by 16")
+            self._image = dict(im, disc=image_obs.disc_template(im["circle_radius"]), n_sub=G // 2,
+                               lines=image_obs.grid_line_mask(im["width"], im["height"], list(m.grid_shape)))
+            cfg.image, cfg.img_w, cfg.img_h, cfg.img_r0 = 1, im["width"], im["height"], im["circle_radius"]
+            cells = m.terminal_states or []
+            cfg.n_boxes = len(cells)
+            for b, c in enumerate(cells):            # terminal cells (drawn, never terminating) ride in box_lo
+                cfg.box_lo[2 * b], cfg.box_lo[2 * b + 1] = float(c[0]), float(c[1])
+            cfg.obs_dtype = capi.OBS_IMAGE_U8
+            self._obs_torch_dtype = torch.uint8
+            self.single_observation_space = BoxSpace(0, 255, (self._image["n_sub"] * im["width"], im["height"], 3),
+                                                     dtype=np.uint8)
 
     def _init_continuous(self, cfg):
         m = self.mdps[0]
@@ -309,6 +331,9 @@ class RLToyVectorEnv:
                 return tuple(lead) + (im["n_sub"] * im["width"], im["height"], 3)
             return tuple(lead) + (self.mdps[0].D,)
         if self.kind == "grid":
+            if getattr(self, "_image", None) is not None:
+                im = self._image
+                return tuple(lead) + (im["n_sub"] * im["width"], im["height"], 3)
             return tuple(lead) + (len(self.mdps[0].grid_shape),)
         if getattr(self, "_image", None) is not None:
             im = self.mdps[0].image
@@ -445,7 +470,7 @@ class RLToyVectorEnv:
                 return "k_discrete_rollout_pipe"
             return "k_discrete_rollout_fast"
         if self.kind == "grid":
-            return "k_grid_step"
+            return "k_imagec_obs" if getattr(self, "_image", None) is not None else "k_grid_step"
         m = self.mdps[0]
         if getattr(self, "_image", None) is not None:
             return "k_imagec_obs"

@@ -703,3 +703,44 @@ void ora_ic_render(int W, int H, int R, const uint8_t *disc /* [(2R+1)*(2R+1)], 
         }
     }
 }
+
+/* ImageContinuous of a GRID env (draw_grid, spaces/image_continuous.py:139-207): white grid lines
+ * (the caller's `lines` mask, drawn with Pillow exactly as :145-165 does), terminal cells as black
+ * rectangles from convert_to_pixel(cell) to convert_to_pixel(cell + 1) inclusive, the target and the
+ * agent as discs at convert_to_pixel(cell + 0.5); convert_to_pixel here is float64:
+ * int((v - 0) / (g - 0) * size).  out: uint8 [n_sub * W][H][3], n_sub = G / 2. */
+static int ig_px(double v, int g, int size) { return (int)((v - 0.0) / (double)(g - 0) * (double)size); }
+
+void ora_ig_render(int W, int H, int R, const uint8_t *disc, int G, const int32_t *shape, const int32_t *cells,
+                   const int32_t *target, int n_term, const int32_t *term_cells /* [n_term*2] */,
+                   const uint8_t *lines /* [n_sub*W*H], [x][y] */, uint8_t *out) {
+    const int n_sub = G / 2, T = 2 * R + 1;
+    for (int sub = 0; sub < n_sub; sub++) {
+        uint8_t *img = out + (size_t)sub * W * H * 3;
+        const uint8_t *ln = lines + (size_t)sub * W * H;
+        for (size_t k = 0; k < (size_t)W * H; k++) img[3 * k] = img[3 * k + 1] = img[3 * k + 2] = ln[k] ? 255 : 208;
+        if (sub == 0) {
+            for (int b = 0; b < n_term; b++) {
+                const int x0 = ig_px(term_cells[2 * b], shape[0], W), y0 = ig_px(term_cells[2 * b + 1], shape[1], H);
+                const int x1 = ig_px(term_cells[2 * b] + 1.0, shape[0], W), y1 = ig_px(term_cells[2 * b + 1] + 1.0, shape[1], H);
+                for (int x = x0 < 0 ? 0 : x0; x <= x1 && x < W; x++)
+                    for (int y = y0 < 0 ? 0 : y0; y <= y1 && y < H; y++)
+                        img[((size_t)x * H + y) * 3] = img[((size_t)x * H + y) * 3 + 1] = img[((size_t)x * H + y) * 3 + 2] = 0;
+            }
+        }
+        for (int pass = (sub == 0 ? 0 : 1); pass < 2; pass++) {
+            const double vx = pass == 0 ? target[0] + 0.5 : cells[2 * sub] + 0.5;
+            const double vy = pass == 0 ? target[1] + 0.5 : cells[2 * sub + 1] + 0.5;
+            /* both sub-spaces are scaled with the RELEVANT grid's size (feature_space.high[relevant_indices]) */
+            const int cx = ig_px(vx, shape[0], W), cy = ig_px(vy, shape[1], H);
+            for (int dy = 0; dy < T; dy++)
+                for (int dx = 0; dx < T; dx++) {
+                    if (!disc[dy * T + dx]) continue;
+                    const int x = cx - R + dx, y = cy - R + dy;
+                    if (x < 0 || x >= W || y < 0 || y >= H) continue;
+                    uint8_t *p = img + ((size_t)x * H + y) * 3;
+                    p[0] = 0; p[1] = pass == 0 ? 255 : 0; p[2] = pass == 0 ? 0 : 255;
+                }
+        }
+    }
+}

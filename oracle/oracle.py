@@ -64,6 +64,7 @@ def lib():
                                     i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
         L.ora_c_destroy.argtypes = [vp]
         L.ora_c_set_image_quirk.argtypes = [vp, i32]
+        L.ora_ig_render.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
         L.ora_ic_render.argtypes = [i32, i32, i32, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp]
         L.ora_c_set_rng.argtypes = [vp, vp, vp]
         L.ora_c_get_rng.argtypes = [vp, vp, vp]
@@ -393,6 +394,39 @@ def image_continuous_render(W, H, R, state, smax, target, box_lo=None, box_hi=No
     hi = None if nb == 0 else np.ascontiguousarray(box_hi, dtype=np.float32)
     out = np.zeros(((2 if D > 2 else 1) * W, H, 3), np.uint8)
     lib().ora_ic_render(W, H, R, _p(disc), D, _p(state), C.c_float(smax), _p(tgt), nb, _p(lo), _p(hi), _p(out))
+    return out
+
+
+def grid_line_mask(W, H, grid_shape):
+    """uint8 [n_sub * W, H]: 1 where ImageContinuous draws its white grid lines, made with Pillow's
+    draw.line from the reference's own end points (spaces/image_continuous.py:145-165, incl. its use
+    of the x-count of the grid for the horizontal spacing)."""
+    import PIL.Image as Image
+    import PIL.ImageDraw as ImageDraw
+    out = []
+    for offset in range(0, len(grid_shape), 2):
+        img = Image.new("L", (W, H), 0)
+        d = ImageDraw.Draw(img)
+        for i in range(1, grid_shape[0 + offset] + 1):
+            x_ = i * W // grid_shape[0 + offset] - 1
+            d.line([(x_, H), (x_, 0)], fill=255)
+        for j in range(1, grid_shape[1 + offset]):
+            y_ = j * H // grid_shape[0 + offset]
+            d.line([(W, y_), (0, y_)], fill=255)
+        out.append((np.array(img).T != 0).astype(np.uint8))     # [x][y]
+    return np.concatenate(out, axis=0)
+
+
+def image_grid_render(W, H, R, grid_shape, cells, target, terminal_cells):
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    G = cells.shape[0]
+    sh = np.ascontiguousarray(grid_shape, dtype=np.int32)
+    tg = np.ascontiguousarray(target, dtype=np.int32)
+    tc = np.ascontiguousarray(terminal_cells if terminal_cells is not None else [], dtype=np.int32).reshape(-1, 2)
+    disc = np.ascontiguousarray(disc_template(R))
+    lines = np.ascontiguousarray(grid_line_mask(W, H, list(grid_shape)))
+    out = np.zeros(((G // 2) * W, H, 3), np.uint8)
+    lib().ora_ig_render(W, H, R, _p(disc), G, _p(sh), _p(cells), _p(tg), len(tc), _p(tc), _p(lines), _p(out))
     return out
 
 

@@ -18,6 +18,7 @@ DISCRETE = sorted(k for k in CASES if k.startswith("d_") and k not in IRRELEVANT
 CONTINUOUS = sorted(k for k in CASES if k.startswith("c_"))
 IMAGE = sorted(k for k in CASES if k.startswith("i_"))
 GRID = sorted(k for k in CASES if k.startswith("g_"))
+IMAGE_GRID = sorted(k for k in CASES if k.startswith("gi_"))     # grid envs with ImageContinuous observations
 IMAGE_CONT = sorted(k for k in CASES if k.startswith("ci_"))    # continuous envs with ImageContinuous observations
 
 

@@ -716,6 +716,61 @@ def test_continuous_image_batch_vs_oracle_and_fused():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name", gu.IMAGE_GRID)
+def test_grid_image_observations_vs_reference_golden(name):
+    """Grid envs with image_representations: every pixel of the reference's pictures (grid lines,
+    terminal cells, discs at cell centres, irrelevant grid), rewards, flags, masked resets."""
+    g = gu.load(name)
+    E, T, G = g["action"].shape
+    env = _venv(autoreset="disabled", **_seeds_or_cfg(name))
+    assert np.array_equal(env._obs.cpu().numpy(), g["init_obs"])
+    for t in range(T):
+        a = torch.as_tensor(g["action"][:, t].astype(np.int32), device=env.device)
+        obs, rew, term, trunc, _ = env.step(a)
+        assert np.array_equal(obs.cpu().numpy(), g["obs"][:, t]), (name, t)
+        assert np.array_equal(term.cpu().numpy(), g["done"][:, t]), (name, t)
+        assert np.array_equal(rew.cpu().numpy(), g["reward"][:, t].astype(np.float32)), (name, t)
+        ra = g["reset_after"][:, t]
+        if ra.any():
+            o, _ = env.reset(mask=torch.as_tensor(ra, device=env.device))
+            assert np.array_equal(o.cpu().numpy()[ra], g["reset_obs"][:, t][ra])
+    assert np.array_equal(env.get_augmented_state()["curr_state"], g["curr_state"][:, -1]) or g["reset_after"][:, -1].any()
+    env.close()
+
+
+def test_grid_image_fused_equals_single_steps_and_oracle():
+    from oracle import oracle as ora
+    cfg = dict(state_space_type="grid", grid_shape=(6, 5), reward_function="move_to_a_point", make_denser=True,
+               target_point=[2, 3], irrelevant_features=True, transition_noise=0.2, terminal_states=[[0, 0], [5, 4]],
+               image_representations=True, image_width=48, image_height=64, seed=8)
+    N, K = 384, 40
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    r = np.random.default_rng(6)
+    acts = np.zeros((K, N, 4), np.int32)
+    np.put_along_axis(acts, r.integers(0, 4, size=(K, N, 1)), r.integers(-1, 2, size=(K, N, 1)).astype(np.int32), axis=2)
+    acts_t = torch.as_tensor(acts, device=a.device)
+    obs, rew, term, trunc = a.rollout(acts_t)
+    assert term.any()
+    for t in range(K):
+        o, rr, te, tr, info = b.step(acts_t[t])
+        assert torch.equal(o, obs[t]) and torch.equal(rr, rew[t]) and torch.equal(te, term[t]), t
+    obs_h, term_h = obs.cpu().numpy(), term.cpu().numpy()
+    m = a.mdps[0]
+    for i in range(0, N, 6):
+        o = _oracle_for(a, i)
+        o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i], a.seeded_streams[4][i])
+        o.reset()
+        for t in range(K):
+            st, r_, d = o.step(acts[t, i])
+            assert d == bool(term_h[t, i]), (i, t)
+            if d:
+                st = o.reset()
+            pic = ora.image_grid_render(48, 64, 5, m.grid_shape, st, cfg["target_point"], cfg["terminal_states"])
+            assert np.array_equal(pic, obs_h[t, i]), (i, t)
+    a.close(); b.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _cfg(name, seed):
     return dict(gu.CASES[name]["config"], seed=seed)

@@ -118,3 +118,37 @@ def test_disc_template_is_pillows_ellipse():
     t = image_obs.disc_template(5)
     assert t.shape == (11, 11) and int(t.sum()) == 97          # the 97 blue pixels of the reference's agent
     assert np.array_equal(t, ora.disc_template(5))
+
+
+@pytest.mark.parametrize("name", gu.IMAGE_GRID)
+def test_oracle_grid_images_match_reference(name):
+    """ImageContinuous observations of grid envs: grid lines, terminal cells, target and agent discs
+    at the cell centres, the irrelevant grid as a second picture; every pixel."""
+    g = gu.load(name)
+    cfg = gu.CASES[name]["config"]
+    E, T, G = g["action"].shape
+    p = gu.grid_params(cfg)
+    W, H = cfg["image_width"], cfg["image_height"]
+
+    def picture(cells):
+        return ora.image_grid_render(W, H, 5, p["grid_shape"], cells, cfg["target_point"], cfg.get("terminal_states"))
+    for e in range(E):
+        o = ora.GridOracle(**p)
+        sd = g["seed_dict"][e]
+        fresh = lambda s: ora.pcg_words(np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(s)))))  # noqa: E731
+        o.set_rng(fresh(sd[0]), fresh(sd[5]), g["rng_action"][e])
+        s0 = o.reset()
+        assert np.array_equal(s0, g["init_state"][e])
+        assert np.array_equal(picture(s0), g["init_obs"][e])
+        for t in range(T):
+            st, r, d = o.step(g["action"][e, t])
+            assert np.array_equal(st, g["curr_state"][e, t]) and d == bool(g["done"][e, t]), (name, e, t)
+            assert np.float64(r).view(np.uint64) == g["reward"][e, t].view(np.uint64), (name, e, t)
+            assert np.array_equal(picture(st), g["obs"][e, t]), (name, e, t)
+            if g["reset_after"][e, t]:
+                assert np.array_equal(picture(o.reset()), g["reset_obs"][e, t]), (name, e, t)
+
+
+def test_grid_line_mask_host_equals_oracle_helper():
+    for shape in [(8, 8), (4, 6, 4, 6)]:
+        assert np.array_equal(image_obs.grid_line_mask(96, 80, list(shape)), ora.grid_line_mask(96, 80, list(shape)))

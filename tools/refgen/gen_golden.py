@@ -200,6 +200,19 @@ CASES = {
                     reward_function="move_to_a_point", image_representations=True,
                     image_width=64, image_height=48),
         seeds=[0, 1], T=40, reset="mixed"),
+    # --- grid + ImageContinuous observations (grid lines, terminal cells drawn as rectangles) ----
+    "gi_8x8": dict(
+        config=dict(state_space_type="grid", grid_shape=(8, 8), reward_function="move_to_a_point",
+                    make_denser=True, target_point=[5, 5], reward_scale=3.0,
+                    terminal_states=[[2, 3], [7, 7], [0, 4]], term_state_reward=-0.25,
+                    image_representations=True, image_width=96, image_height=80),
+        seeds=[0, 1, 2], T=40, reset="on_done", bad_action_every=13),
+    "gi_irr_noise": dict(
+        config=dict(state_space_type="grid", grid_shape=(4, 6), reward_function="move_to_a_point",
+                    make_denser=False, target_point=[1, 2], irrelevant_features=True,
+                    transition_noise=0.25, reward_noise=0.1, terminal_states=[[0, 0]],
+                    image_representations=True, image_width=64, image_height=64),
+        seeds=[0, 1], T=40, reset="mixed"),
     # --- discrete + image observations -------------------------------------
     "i_cfg4": dict(config=CFG4, seeds=[0, 1], T=24, reset="on_done"),
     "i_100_all": dict(
