@@ -776,7 +776,8 @@ def _cfg(name, seed):
     return dict(gu.CASES[name]["config"], seed=seed)
 
 
-@pytest.mark.parametrize("name,N", [("d_cfg2", 65536), ("c_cfg3", 65536), ("c_cfg5", 65536)])
+@pytest.mark.parametrize("name,N", [("d_cfg2", 65536), ("c_cfg3", 65536), ("c_cfg5", 65536),
+                                    ("d_irr_noise", 65536), ("g_noise_sparse", 65536)])
 def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     """At BASELINE's 65 536 envs the oracle cannot replay everything in seconds, so check
     size-independent properties: (1) one fused K-step launch == K single-step launches bit for
@@ -787,8 +788,21 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     rng = np.random.default_rng(0)
-    if a.kind == "discrete":
+    from mdp_playground_amd import _capi as capi
+    streams = [0, 1]
+    if a.kind == "discrete" and a._irr:
+        m = a.mdps[0]
+        acts = torch.as_tensor(np.stack([rng.integers(0, m.A, size=(T, N)), rng.integers(0, m.A_irr, size=(T, N))],
+                                        axis=2).astype(np.int32), device=a.device)
+        streams.append(capi.STREAM_SPACE_IRR)
+    elif a.kind == "discrete":
         acts = torch.as_tensor(rng.integers(0, 8, size=(T, N)).astype(np.int32), device=a.device)
+    elif a.kind == "grid":
+        G = len(a.mdps[0].grid_shape)
+        ac = np.zeros((T, N, G), np.int32)
+        np.put_along_axis(ac, rng.integers(0, G, size=(T, N, 1)), rng.integers(-1, 2, size=(T, N, 1)).astype(np.int32), axis=2)
+        acts = torch.as_tensor(ac, device=a.device)
+        streams.append(capi.STREAM_ACTION)
     else:
         acts = torch.as_tensor(rng.uniform(-1, 1, size=(T, N, 12)).astype(np.float32), device=a.device)
     init = a._obs.cpu().numpy().copy()
@@ -801,7 +815,12 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     acts_h = acts.cpu().numpy()
     for i in range(0, N, 4099):
         o = _oracle_for(a, i)
-        o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i])
+        if a.kind == "grid":
+            o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i], a.seeded_streams[capi.STREAM_ACTION][i])
+        else:
+            o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i])
+            if a.kind == "discrete" and a._irr:
+                o.set_rng_irr(a.seeded_streams[capi.STREAM_SPACE_IRR][i])
         s0 = o.reset()
         assert np.array_equal(np.asarray(s0), init[i])
         eo, er, ed, ero = o.rollout(acts_h[:, i], None)
@@ -811,7 +830,7 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     # (3) checkpoint round trip: b's state + streams into a fresh env, both continue identically
     c = _venv(num_envs=N, autoreset="same_step", **cfg)
     c.set_augmented_state(b.get_augmented_state())
-    for s in (0, 1):
+    for s in streams:
         c._put_stream(s, b.get_rng_streams(s))
     o1, r1, t1, _ = b.rollout(acts[:8])
     o2, r2, t2, _ = c.rollout(acts[:8])
