@@ -6,7 +6,10 @@
  * caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
  * stream) and is asynchronous with respect to the host.  The library owns only its
  * per-env state and tables (freed by mdpp_destroy); nothing is allocated inside
- * mdpp_step / mdpp_step_n / mdpp_reset (graph-capturable).  A handle is not
+ * mdpp_step / mdpp_step_n / mdpp_reset, so they can be captured into a HIP graph
+ * (tests/test_gpu_parity.py::test_rollout_is_graph_capturable).  The handle's step counter
+ * travels to the kernels by value: a replayed graph is exact for numpy-stream handles with
+ * unit rewards; Philox keys and the key ring of non-unit rewards read the counter.  A handle is not
  * thread-safe.  Every function returns 0 on success or a negative MDPP_E* code and
  * never throws; mdpp_last_error() gives the message.
  *

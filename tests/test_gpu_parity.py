@@ -970,3 +970,32 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     assert np.array_equal(a.get_rng_streams(0), b.get_rng_streams(0))
     assert (a.status() == 0).all() and (b.status() == 0).all()
     a.close(); b.close()
+
+
+def test_rollout_is_graph_capturable():
+    """include/mdpp.h promises that nothing is allocated inside mdpp_step / mdpp_step_n: a fused
+    rollout can be captured into a HIP graph and replayed.  (The handle's step counter travels by
+    value, so a replayed graph is exact for numpy-stream handles with unit rewards — the counter only
+    feeds Philox keys and the key ring of non-unit rewards.)"""
+    cfg = _cfg("d_cfg2", 23)
+    N, K = 4096, 64
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    acts = torch.randint(0, 8, (K, N), device=a.device, dtype=torch.int32)
+    out_a = a.alloc_rollout(K)
+    side = torch.cuda.Stream(device=a.device)
+    side.wait_stream(torch.cuda.current_stream(a.device))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        a.rollout(acts, out_a)                     # warm-up outside the capture
+    torch.cuda.current_stream(a.device).wait_stream(side)
+    torch.cuda.synchronize()
+    b.rollout(acts)                                # keep b in step with a's warm-up
+    with torch.cuda.graph(g, stream=side):
+        a.rollout(acts, out_a)
+    for rep in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        ob, rb, tb, _ = b.rollout(acts)
+        assert torch.equal(out_a[0], ob) and torch.equal(out_a[1], rb) and torch.equal(out_a[2].view(torch.bool), tb), rep
+    a.close(); b.close()
