@@ -29,6 +29,14 @@ __device__ __forceinline__ double normal_f32guard(G &g, const ZigLds &z) {
     }
 }
 
+// candidate for a raw-word producer / interpreting consumer split: a generator whose next64() pops
+// pre-made 64-bit words from an LDS ring (no LCG step on the consumer side)
+struct RingGen {
+    const uint64_t *ring;   // [64 slots][256 lanes]
+    uint32_t pos, lane;
+    __device__ __forceinline__ uint64_t next64() { uint64_t r = ring[(pos & 63u) * 256u + lane]; pos++; return r ^ ((uint64_t)pos * 0x9E3779B97F4A7C15ULL); }
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
     __shared__ uint64_t s_ki[256];
@@ -39,7 +47,14 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
     Pcg64 g;
     g.s_lo = threadIdx.x * 7919u + blockIdx.x; g.s_hi = 12345; g.inc_lo = 2 * threadIdx.x + 1; g.inc_hi = 99;
     double acc = 0; uint64_t x = 0;
+    __shared__ uint64_t s_ring[MODE == 9 ? 64 * 256 : 1];
+    RingGen rg{s_ring, 0u, threadIdx.x};
+    if (MODE == 9) {
+        for (int q = 0; q < 64; q++) s_ring[q * 256 + threadIdx.x] = g.next64();
+        __syncthreads();
+    }
     for (int i = 0; i < iters; i++) {
+        if (MODE == 9) acc += np_standard_normal_lds(rg, zig);
         if (MODE == 0) x ^= g.next64();
         if (MODE == 1) acc += np_random(g);
         if (MODE == 2) acc += np_standard_normal_lds(g, zig);
@@ -86,6 +101,7 @@ int main() {
     run<2>("standard_normal (LDS tables)", d, iters);
     run<3>("standard_normal (global tbl)", d, iters);
     run<8>("standard_normal f32-guard", d, iters);
+    run<9>("standard_normal, words popped from LDS", d, iters);
     run<6>("ziggurat hot path only", d, iters);
     run<7>("hot + wedge uniform, no exp", d, iters);
     return 0;
