@@ -324,6 +324,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.act_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ACTION]; a.act_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ACTION];
         a.act_half = (uint2 *)h->d_rng_half;
         a.status = (uint32_t *)h->d_status;
+        a.minv_lo = (uint64_t)pcg_mult_inverse(); a.minv_hi = (uint64_t)(pcg_mult_inverse() >> 64);
         h->tables_ready = true;      // a grid env has no tables
     } else {
         g_create_err = "mdpp_create: unknown kind"; free_all(h); delete h; return MDPP_EINVAL;

@@ -20,6 +20,7 @@
 // observation) + 4 (reward) + 2 (flags) = 30 B for a plain 2-D grid.
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
+#include <cstdlib>
 
 namespace mdpp {
 
@@ -211,12 +212,198 @@ __global__ __launch_bounds__(kBlock) void k_grid_reset(GridArgs a, uint32_t rese
         }
 }
 
+// ---- fused rollout for the quiet case (numpy streams, no noise, K steps per launch) -------------
+// k_grid_step spends most of a step on things this shape does not need: wave-uniform branches on run
+// time flags (a taken branch is an unhidden refetch with one wave per SIMD), and the in-step reset(),
+// which runs its two PCG64 steps for the whole wave whenever ANY lane reached the target (~60 % of
+// the steps of a 64-lane wave under a random policy).  Here the flags are template parameters, the
+// step body is straight-line, and start cells are drawn AHEAD of need into a per-lane register
+// queue that is topped up for all lanes at once when some lane runs dry; what is left in the queue
+// at the end of the launch is un-drawn (inverse LCG step), so the stream position is again exactly
+// the reference's.  Every global access is a buffer instruction with a per-lane offset that never
+// changes plus a per-step scalar offset.
+constexpr int kGQ = 4;                        // start cells queued per lane
+constexpr int kGRsrc = 0x00020000;
+
+template <bool OBS64, bool G4, bool DENSE>
+__global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K, const int32_t *__restrict__ actions,
+                                                              void *__restrict__ obs, float *__restrict__ reward,
+                                                              uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
+                                                              void *__restrict__ final_obs) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int G = G4 ? 4 : 2;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint32_t)a.N) return;
+    const uint32_t N = (uint32_t)a.N;
+    const uint4 st = a.state[i];
+    uint32_t cells = st.x, steps = st.y, flags = st.z, status = 0;   // one byte per dimension
+    Pcg64 sp;
+    sp.load(a.sp_s, a.sp_inc, i);
+    uint32_t queue[kGQ];                          // queued start cells, queue[0] next; qn of them valid
+#pragma unroll
+    for (int q = 0; q < kGQ; q++) queue[q] = 0;
+    uint32_t qn = 0;
+    const double rng0 = (double)(a.shape[0] + 1), rng1 = (double)(a.shape[1] + 1);
+    const double rng2 = (double)(a.shape[2] + 1), rng3 = (double)(a.shape[3] + 1);
+    auto draw_cell = [&]() __attribute__((always_inline)) -> uint32_t {          // feature_space.sample(): floor(uniform(0, g + 1)) per dimension
+        uint32_t c = (uint32_t)(int)floor(0.0 + (rng0 - 0.0) * np_random(sp));
+        c |= (uint32_t)(int)floor(0.0 + (rng1 - 0.0) * np_random(sp)) << 8;
+        if (G4) {
+            c |= (uint32_t)(int)floor(0.0 + (rng2 - 0.0) * np_random(sp)) << 16;
+            c |= (uint32_t)(int)floor(0.0 + (rng3 - 0.0) * np_random(sp)) << 24;
+        }
+        return c;
+    };
+    // (always_inline: as a real function it would take the stream and the queue by reference, i.e.
+    // keep them in scratch memory for the whole kernel)
+    auto refill = [&]() __attribute__((always_inline)) {     // top every lane's queue up, most lanes active in every round
+        for (int round = 0; round < kGQ; round++) {
+            if (__builtin_amdgcn_ballot_w64(qn < (uint32_t)kGQ) == 0) break;
+            if (qn < (uint32_t)kGQ) {
+                const uint32_t c = draw_cell();
+#pragma unroll
+                for (int q = 0; q < kGQ; q++) queue[q] = (qn == (uint32_t)q) ? c : queue[q];
+                qn++;
+            }
+        }
+    };
+    if (a.autoreset) refill();
+
+    const uint32_t total = (uint32_t)K * N;
+    auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(G * 4), kGRsrc);
+    auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (uint32_t)(G * (OBS64 ? 8 : 4)), kGRsrc);
+    auto r_fin = __builtin_amdgcn_make_buffer_rsrc(final_obs ? final_obs : obs, 0, total * (uint32_t)(G * (OBS64 ? 8 : 4)), kGRsrc);
+    auto r_rew = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kGRsrc);
+    auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kGRsrc);
+    auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kGRsrc);
+    const uint32_t vact = i * (uint32_t)(G * 4), vobs = i * (uint32_t)(G * (OBS64 ? 8 : 4)), v4 = i * 4u, v1 = i;
+    const uint32_t row_act = N * (uint32_t)(G * 4), row_obs = N * (uint32_t)(G * (OBS64 ? 8 : 4));
+    const int t0 = a.target[0], t1 = a.target[1];
+    const int m0 = a.shape[0] - 1, m1 = a.shape[1] - 1, m2 = a.shape[2] - 1, m3 = a.shape[3] - 1;
+    const bool has_max = a.max_steps > 0, autoreset = a.autoreset != 0;
+    const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n;
+    uint32_t phase = steps % every_n;
+
+    constexpr int kPre = 8;
+    auto load_act = [&](int k) -> i32x4 {
+        const uint32_t kk = (uint32_t)min(k, K - 1);
+        if (G4) return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(r_act, vact, kk * row_act, 0));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_act, vact, kk * row_act, 0);
+        return i32x4{(int)v.x, (int)v.y, 0, 0};
+    };
+    auto put_cells = [&](decltype(r_obs) rs, uint32_t so, uint32_t c) {
+        const uint32_t c0 = c & 0xFFu, c1 = (c >> 8) & 0xFFu, c2 = (c >> 16) & 0xFFu, c3 = c >> 24;
+        if (OBS64) {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, 0u, c1, 0u}, rs, vobs, so * row_obs, 0);
+            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2, 0u, c3, 0u}, rs, vobs + 16u, so * row_obs, 0);
+        } else {
+            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, c1, c2, c3}, rs, vobs, so * row_obs, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{c0, c1}, rs, vobs, so * row_obs, 0);
+        }
+    };
+    i32x4 pre[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
+
+    // straight-line step body: the run-time options (autoreset, reward_every_n_steps, episode limit)
+    // are folded into selects rather than branches
+    auto step = [&](const int k, const i32x4 act) __attribute__((always_inline)) {
+        // every lane must hold a start cell before the step may end its episode; the refill tops
+        // all lanes up to kGQ, so this branch is taken once in several dozen steps
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) refill();
+        // GridActionSpace.contains: every entry in {-1, 0, 1}, at most one non-zero
+        const uint32_t a0 = (uint32_t)(act.x + 1), a1 = (uint32_t)(act.y + 1), a2 = (uint32_t)(act.z + 1), a3 = (uint32_t)(act.w + 1);
+        const int nz = (act.x != 0) + (act.y != 0) + (G4 ? (act.z != 0) + (act.w != 0) : 0);
+        const bool ok = a0 <= 2u && a1 <= 2u && (!G4 || (a2 <= 2u && a3 <= 2u)) && nz <= 1;
+        status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+        const int c0 = (int)(cells & 0xFFu), c1 = (int)((cells >> 8) & 0xFFu);
+        const int c2 = (int)((cells >> 16) & 0xFFu), c3 = (int)(cells >> 24);
+        const int n0 = ok ? min(max(c0 + act.x, 0), m0) : c0, n1 = ok ? min(max(c1 + act.y, 0), m1) : c1;
+        const int n2 = (G4 && ok) ? min(max(c2 + act.z, 0), m2) : c2, n3 = (G4 && ok) ? min(max(c3 + act.w, 0), m3) : c3;
+        const bool on_target = n0 == t0 && n1 == t1;
+        flags |= on_target ? 1u : 0u;
+        steps += 1;
+        double r = 0.0;
+        if (DENSE) r += (double)((abs(c0 - t0) + abs(c1 - t1)) - (abs(n0 - t0) + abs(n1 - t1)));
+        else r += on_target ? 1.0 : 0.0;
+        phase = (phase + 1 >= every_n) ? 0u : phase + 1;          // steps % every_n, carried
+        r = phase != 0 ? 0.0 : r;
+        r *= a.scale;
+        r += a.shift;
+        const bool done = (flags & 1u) != 0;
+        r += done ? a.term_add : 0.0;             // r is not -0.0 here (a +0.0 shift was just added), so + 0.0 is the identity
+        const bool tr = has_max && steps >= max_steps;
+        uint32_t nc = (uint32_t)n0 | ((uint32_t)n1 << 8) | ((uint32_t)n2 << 16) | ((uint32_t)n3 << 24);
+        const uint32_t so = (uint32_t)k;
+        const bool need = autoreset && (done || tr);
+        if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
+            if (need) put_cells(r_fin, so, nc);
+        }
+        // pop the next queued start cell where the episode ended
+        nc = need ? queue[0] : nc;
+#pragma unroll
+        for (int q = 0; q + 1 < kGQ; q++) queue[q] = need ? queue[q + 1] : queue[q];
+        qn -= need ? 1u : 0u;
+        steps = need ? 0u : steps;
+        flags = need ? 0u : flags;
+        phase = need ? 0u : phase;
+        cells = nc;
+        put_cells(r_obs, so, nc);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)r), r_rew, v4, so * N * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so * N, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so * N, 0);
+    };
+    const int nfull = K / kPre;
+    for (int c = 0; c < nfull; c++) {
+#pragma unroll
+        for (int u = 0; u < kPre; u++) {
+            const i32x4 act = pre[u];
+            pre[u] = load_act(c * kPre + kPre + u);
+            step(c * kPre + u, act);
+        }
+    }
+    for (int k = nfull * kPre; k < K; k++) {
+        i32x4 act = pre[0];
+#pragma unroll
+        for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
+        step(k, act);
+    }
+    // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128), G uniforms per queued cell
+    for (uint32_t q = qn * (uint32_t)G; q > 0; q--) {
+        const uint64_t lo = sp.s_lo - sp.inc_lo;
+        const uint64_t hi = sp.s_hi - sp.inc_hi - (sp.s_lo < sp.inc_lo ? 1ULL : 0ULL);
+        sp.s_lo = lo * a.minv_lo;
+        sp.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+    }
+    sp.store(a.sp_s, i);
+    a.state[i] = make_uint4(cells, steps, flags, 0u);
+    if (status) atomicOr(&a.status[i], status);
+}
+
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
                      uint8_t *trunc, void *final_obs, hipStream_t s) {
     GridArgs a = h->gargs;
     a.tick = h->tick;
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
+    // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)
+    if (!a.philox && !noise && !getenv("MDPP_NO_GFAST") &&
+        (unsigned long long)K * a.N * a.G * 8ULL < (1ULL << 32)) {
+#define MDPP_GF_LAUNCH(O64, G4, DN) hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN>), dim3(grid), dim3(kBlock), 0, s, a, K, \
+                                                       actions, obs, reward, term, trunc, final_obs)
+#define MDPP_GF_DN(O64, G4) do { if (a.make_denser) MDPP_GF_LAUNCH(O64, G4, true); else MDPP_GF_LAUNCH(O64, G4, false); } while (0)
+        if (a.obs_i32) { if (a.G == 4) MDPP_GF_DN(false, true); else MDPP_GF_DN(false, false); }
+        else { if (a.G == 4) MDPP_GF_DN(true, true); else MDPP_GF_DN(true, false); }
+#undef MDPP_GF_DN
+#undef MDPP_GF_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { h->err = std::string("k_grid_rollout_fast launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+        h->tick += (uint32_t)K;
+        return MDPP_OK;
+    }
 #define MDPP_G_LAUNCH(PH, NZ) hipLaunchKernelGGL((k_grid_step<PH, NZ>), dim3(grid), dim3(kBlock), 0, s, a, K, actions, \
                                                  obs, reward, term, trunc, final_obs)
     if (a.philox) { if (noise) MDPP_G_LAUNCH(true, true); else MDPP_G_LAUNCH(true, false); }

@@ -109,6 +109,7 @@ struct GridArgs {
     uint4 *state;               // {cells (one byte per dimension), steps, flags: bit0 reached target, -}
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc, *act_s, *act_inc;
     uint2 *act_half;            // numpy's buffered 32-bit half of the action stream
+    uint64_t minv_lo, minv_hi;  // inverse of the PCG64 LCG multiplier mod 2^128 (un-drawing queued reset cells)
     uint32_t *status;
 };
 

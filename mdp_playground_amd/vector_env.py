@@ -470,7 +470,11 @@ class RLToyVectorEnv:
                 return "k_discrete_rollout_pipe"
             return "k_discrete_rollout_fast"
         if self.kind == "grid":
-            return "k_imagec_obs" if getattr(self, "_image", None) is not None else "k_grid_step"
+            if getattr(self, "_image", None) is not None:
+                return "k_imagec_obs"
+            m = self.mdps[0]
+            quiet = self.rng == "numpy" and not m.transition_noise and m.reward_noise is None
+            return "k_grid_rollout_fast" if quiet else "k_grid_step"
         m = self.mdps[0]
         if getattr(self, "_image", None) is not None:
             return "k_imagec_obs"

@@ -308,6 +308,74 @@ def test_grid_4096_envs_vs_oracle(rng):
     env.close()
 
 
+GRID_FAST = {
+    "dense_2d": (dict(grid_shape=(8, 8), make_denser=True, target_point=[5, 5], reward_scale=3.0,
+                      term_state_reward=-0.25), {}, 4100),
+    "sparse_4d_i32_every2": (dict(grid_shape=(5, 7), make_denser=False, target_point=[1, 2], irrelevant_features=True,
+                                  reward_every_n_steps=2, reward_shift=0.5, dtype_s=np.int32), {}, 1000),
+    "dense_2d_horizon": (dict(grid_shape=(6, 6), make_denser=True, target_point=[0, 0]), dict(max_episode_steps=9), 1024),
+    "dense_2d_noreset": (dict(grid_shape=(4, 9), make_denser=True, target_point=[3, 8], term_state_reward=1.0),
+                         dict(autoreset="disabled"), 777),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(GRID_FAST))
+def test_grid_fast_rollout_kernel_vs_oracle(variant):
+    """k_grid_rollout_fast (quiet numpy-stream grid handles): start cells drawn ahead into a register
+    queue and un-drawn at the end of the launch.  Every env against its oracle over several launches
+    of different lengths — observations, rewards, flags, truncation, the terminal observations, and
+    the feature-space generator's state after every launch (the un-draw must leave it exactly where
+    the reference's would be)."""
+    from mdp_playground_amd import _capi as capi
+    cfg_extra, env_kw, N = GRID_FAST[variant]
+    cfg = dict(state_space_type="grid", reward_function="move_to_a_point", seed=31, **cfg_extra)
+    kw = dict(autoreset="same_step")
+    kw.update(env_kw)
+    env = _venv(num_envs=N, **kw, **cfg)
+    assert env.rollout_kernel_name(8) == "k_grid_rollout_fast"
+    G = len(env.mdps[0].grid_shape)
+    horizon = env_kw.get("max_episode_steps", 0)
+    auto = kw["autoreset"] == "same_step"
+    r = np.random.default_rng(12)
+    oracles = []
+    init = env._obs.cpu().numpy().copy()
+    for i in range(0, N, 9):
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i], env.seeded_streams[capi.STREAM_ACTION][i])
+        assert np.array_equal(o.reset(), init[i])
+        oracles.append((i, o, [0]))
+    for K in (1, 7, 64, 33):
+        acts = np.zeros((K, N, G), np.int32)
+        toward = r.random((K, N)) < 0.5
+        np.put_along_axis(acts, r.integers(0, G, size=(K, N, 1)), r.integers(-1, 2, size=(K, N, 1)).astype(np.int32), axis=2)
+        acts[r.random((K, N)) < 0.01] = 1                       # outside the action space
+        del toward
+        at = torch.as_tensor(acts, device=env.device)
+        if K == 1:
+            o1, r1, t1, tr1, info = env.step(at[0])
+            obs, rew, term, trunc = o1[None].cpu().numpy(), r1[None].cpu().numpy(), t1[None].cpu().numpy(), tr1[None].cpu().numpy()
+            fin = info["final_obs"].cpu().numpy() if auto else None
+        else:
+            obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(at))
+            fin = None
+        sp_end = env.get_rng_streams(capi.STREAM_SPACE)
+        for i, o, ep in oracles:
+            for t in range(K):
+                st, rr, d = o.step(acts[t, i])
+                ep[0] += 1
+                tr = bool(horizon) and ep[0] >= horizon
+                assert d == bool(term[t, i]) and tr == bool(trunc[t, i]), (variant, K, i, t)
+                assert np.float32(rr) == rew[t, i], (variant, K, i, t)
+                if auto and (d or tr):
+                    if fin is not None:
+                        assert np.array_equal(fin[i], st), (variant, K, i)
+                    st = o.reset(explicit=False)
+                    ep[0] = 0
+                assert np.array_equal(obs[t, i], st), (variant, K, i, t)
+            assert np.array_equal(o.get_rng()[1][:4], sp_end[i][:4]), (variant, K, i)
+    env.close()
+
+
 # ----------------------------------------------------------------------------- continuous
 @pytest.mark.parametrize("name", gu.CONTINUOUS)
 def test_continuous_stepwise_vs_reference_golden(name):

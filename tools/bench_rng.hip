@@ -37,6 +37,15 @@ struct RingGen {
     __device__ __forceinline__ uint64_t next64() { uint64_t r = ring[(pos & 63u) * 256u + lane]; pos++; return r ^ ((uint64_t)pos * 0x9E3779B97F4A7C15ULL); }
 };
 
+// candidate: one 64-bit word of lookahead per lane; the LCG step for the NEXT word has no consumer in
+// the hot path, so it can be scheduled under the table-lookup latency of the current one
+struct Ahead64 {
+    Pcg64 g;
+    uint64_t ahead;
+    __device__ __forceinline__ void prime() { ahead = g.next64(); }
+    __device__ __forceinline__ uint64_t next64() { const uint64_t r = ahead; ahead = g.next64(); return r; }
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
     __shared__ uint64_t s_ki[256];
@@ -53,7 +62,10 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
         for (int q = 0; q < 64; q++) s_ring[q * 256 + threadIdx.x] = g.next64();
         __syncthreads();
     }
+    Ahead64 ag{g, 0};
+    if (MODE == 10) ag.prime();
     for (int i = 0; i < iters; i++) {
+        if (MODE == 10) acc += np_standard_normal_lds(ag, zig);
         if (MODE == 9) acc += np_standard_normal_lds(rg, zig);
         if (MODE == 0) x ^= g.next64();
         if (MODE == 1) acc += np_random(g);
@@ -102,6 +114,7 @@ int main() {
     run<3>("standard_normal (global tbl)", d, iters);
     run<8>("standard_normal f32-guard", d, iters);
     run<9>("standard_normal, words popped from LDS", d, iters);
+    run<10>("standard_normal, one word of lookahead", d, iters);
     run<6>("ziggurat hot path only", d, iters);
     run<7>("hot + wedge uniform, no exp", d, iters);
     return 0;
