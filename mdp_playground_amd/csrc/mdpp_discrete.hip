@@ -374,6 +374,9 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
                                      term + off, trunc + off, fo, s);
             k0 += kc;
         }
+    } else if (launch_discrete_quiet(a, K, actions, obs, reward, term, trunc, final_obs, s)) {
+        // quiet shapes beyond the specialised kernels (larger S / L, irrelevant sub-space):
+        // mdpp_discrete_quiet.hip
     } else if (a.philox) {
         if (noise) launch_step_t<true, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
         else launch_step_t<true, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);

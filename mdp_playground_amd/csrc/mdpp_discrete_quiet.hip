@@ -1,0 +1,264 @@
+// Fused K-step rollout for quiet discrete envs that the specialised kernels of
+// mdpp_discrete_fast.hip / mdpp_discrete_pipe.hip do not take: any S <= 255 and L <= 7, an optional
+// irrelevant sub-space (irrelevant_features=True: action / observation pairs), one shared MDP with
+// its tables in LDS, unit rewards, numpy PCG64 streams, no noise.
+// Same arithmetic as k_discrete_step (mdpp_discrete.hip; reference rl_toy_env.py:1992-2125 and reset
+// :2250-2278, irrelevant sub-space :2028-2035, :2063-2092), restructured like k_grid_rollout_fast:
+//   * straight-line step body, every run-time option a select; no float64 in the step (the four
+//     possible rewards are formed once, in the reference's float64 operation order);
+//   * start states are drawn AHEAD of need into a per-lane register queue (with an irrelevant
+//     sub-space a queued entry is the pair, drawn relevant-then-irrelevant like reset() does),
+//     topped up for all lanes at once when some lane runs dry: with 2 of 8 states terminal some
+//     lane of a wave resets on almost every step, and drawing inside the step runs the PCG64 step
+//     and the cdf search for the whole wave each time;
+//   * what is left in the queue at the end of the launch is un-drawn (inverse LCG step), so the
+//     env stream is again exactly where the reference's would be.  Nothing else reads the env
+//     stream on this path (no reward noise), so the draws are consumed in stream order.
+#include <stdlib.h>
+
+#include "mdpp_internal.hpp"
+#include "mdpp_rng.hpp"
+
+namespace mdpp {
+
+constexpr int kQQ = 4;                         // start states queued per lane
+constexpr int kQRsrc = 0x00020000;
+
+template <bool OBS64, bool IRR>
+__global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
+                                                                   const int32_t *__restrict__ actions,
+                                                                   void *__restrict__ obs, float *__restrict__ reward,
+                                                                   uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
+                                                                   void *__restrict__ final_obs) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ float s_rsel[4];
+    const int tid = threadIdx.x;
+    // shared MDP -> LDS (same carve as k_discrete_step) + the irrelevant sub-space's table and cdf
+    for (int k = tid; k < a.S * a.A; k += kBlock) lds[a.lds_P + k] = a.P[k];
+    for (int k = tid; k < a.S; k += kBlock) lds[a.lds_term + k] = a.is_term[k];
+    for (uint32_t k = tid; k < a.rbits_stride; k += kBlock) lds[a.lds_rew + k] = a.rbits[k];
+    // rho_0 as integer thresholds: cdf[j] <= u  <=>  ceil(cdf[j] * 2^53) <= r >> 11 (exact: u is
+    // (r >> 11) * 2^-53), padded to a multiple of 8 with 2^64-1 so the search runs in unrolled blocks
+    const uint32_t lds_P1 = a.lds_bytes, lds_T0 = (a.lds_bytes + (IRR ? (uint32_t)(a.S1 * a.A1) : 0u) + 15u) & ~15u;
+    const uint32_t S8 = ((uint32_t)a.S + 7u) & ~7u, S18 = IRR ? (((uint32_t)a.S1 + 7u) & ~7u) : 0u;
+    const uint32_t lds_T1 = lds_T0 + S8 * 8u;
+    for (uint32_t k = tid; k < S8; k += kBlock)
+        ((uint64_t *)(lds + lds_T0))[k] = k < (uint32_t)a.S ? (uint64_t)ceil(a.init_cdf[k] * 9007199254740992.0) : ~0ULL;
+    if (IRR) {
+        for (int k = tid; k < a.S1 * a.A1; k += kBlock) lds[lds_P1 + k] = a.P1[k];
+        for (uint32_t k = tid; k < S18; k += kBlock)
+            ((uint64_t *)(lds + lds_T1))[k] = k < (uint32_t)a.S1 ? (uint64_t)ceil(a.init_cdf1[k] * 9007199254740992.0) : ~0ULL;
+    }
+    if (tid < 4) {
+        // {paid, terminal} -> float32, formed in float64 in the reference's operation order (:1987-1990, :2107)
+        double r = (tid & 2) ? 1.0 : 0.0;
+        r *= a.scale;
+        r += a.shift;
+        if (tid & 1) r += a.term_add;
+        s_rsel[tid] = (float)r;
+    }
+    __syncthreads();
+    const uint8_t *P = lds + a.lds_P, *is_term = lds + a.lds_term, *rbits = lds + a.lds_rew, *P1 = lds + lds_P1;
+    const uint64_t *T0 = (const uint64_t *)(lds + lds_T0), *T1 = (const uint64_t *)(lds + lds_T1);
+
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    if (i >= (uint32_t)a.N) return;
+    const uint32_t N = (uint32_t)a.N, S = (uint32_t)a.S, A = (uint32_t)a.A, L = (uint32_t)a.L;
+    const uint4 st = a.state[i];
+    uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
+    uint32_t steps = st.z, ringbits = st.w, status = 0;
+    uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
+    Pcg64 g;
+    g.load(a.env_s, a.env_inc, i);
+    // sequence key over the last L states, carried: key' = (key - oldest * S^(L-1)) * S + new
+    uint32_t spow = 1;
+    for (uint32_t j = 1; j < L; j++) spow *= S;
+    uint32_t key = 0, valid = 0;                                 // valid: number of non-NaN states among the last L+1 (capped)
+    for (int j = (int)L - 1; j >= 0; j--) {
+        const uint32_t b = (uint32_t)(hist >> (8 * j)) & 0xFFu;
+        key = key * S + (b == 0xFFu ? 0u : b);
+    }
+    for (uint32_t j = 0; j <= L; j++) valid += (((uint32_t)(hist >> (8 * j)) & 0xFFu) != 0xFFu) ? 1u : 0u;
+
+    uint32_t queue[kQQ];                                          // rel | irr << 8, queue[0] next
+#pragma unroll
+    for (int q = 0; q < kQQ; q++) queue[q] = 0;
+    uint32_t qn = 0;
+    auto draw_state = [&]() __attribute__((always_inline)) -> uint32_t {
+        // self._np_random.choice(S, p=rho_0): searchsorted(cdf, u, 'right') (:2255); then the
+        // irrelevant start state the same way (:2259-2264)
+        const uint64_t m = g.next64() >> 11;
+        uint32_t s0 = 0;
+        for (uint32_t b = 0; b < S8; b += 8) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) s0 += (T0[b + j] <= m) ? 1u : 0u;
+        }
+        if (IRR) {
+            const uint64_t m1 = g.next64() >> 11;
+            uint32_t s1 = 0;
+            for (uint32_t b = 0; b < S18; b += 8) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) s1 += (T1[b + j] <= m1) ? 1u : 0u;
+            }
+            s0 |= s1 << 8;
+        }
+        return s0;
+    };
+    auto refill = [&]() __attribute__((always_inline)) {         // (always_inline: no generator / queue behind a pointer)
+        for (int round = 0; round < kQQ; round++) {
+            if (__builtin_amdgcn_ballot_w64(qn < (uint32_t)kQQ) == 0) break;
+            if (qn < (uint32_t)kQQ) {
+                const uint32_t c = draw_state();
+#pragma unroll
+                for (int q = 0; q < kQQ; q++) queue[q] = (qn == (uint32_t)q) ? c : queue[q];
+                qn++;
+            }
+        }
+    };
+    const bool autoreset = a.autoreset != 0, has_max = a.max_steps > 0;
+    const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n, delay = (uint32_t)a.delay;
+    if (autoreset) refill();
+    uint32_t phase = steps % every_n;
+
+    // rewards of the unit path: s_rsel[(paid << 1) | terminal], filled above.  An LDS table on
+    // purpose: a private float[4] gets a per-lane index and lands in scratch memory (an L2 round trip
+    // per step), and selects among four values derived from DiscreteArgs made the compiler copy the
+    // whole argument struct to scratch.
+
+    constexpr uint32_t AW = IRR ? 2 : 1, OB = OBS64 ? 8 : 4;
+    const uint32_t total = (uint32_t)K * N;
+    auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * AW * 4u, kQRsrc);
+    auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * AW * OB, kQRsrc);
+    auto r_fin = __builtin_amdgcn_make_buffer_rsrc(final_obs ? final_obs : obs, 0, total * AW * OB, kQRsrc);
+    auto r_rew = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kQRsrc);
+    auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kQRsrc);
+    auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kQRsrc);
+    const uint32_t vact = i * AW * 4u, vobs = i * AW * OB, v4 = i * 4u, v1 = i;
+    const uint32_t row_act = N * AW * 4u, row_obs = N * AW * OB;
+
+    constexpr int kPre = 8;
+    auto load_act = [&](int k) __attribute__((always_inline)) -> u32x2 {
+        const uint32_t kk = (uint32_t)min(k, K - 1);
+        if (IRR) return __builtin_amdgcn_raw_buffer_load_b64(r_act, vact, kk * row_act, 0);
+        return u32x2{__builtin_amdgcn_raw_buffer_load_b32(r_act, vact, kk * row_act, 0), 0u};
+    };
+    auto put_obs = [&](decltype(r_obs) rs, uint32_t so, uint32_t s0, uint32_t s1) __attribute__((always_inline)) {
+        if (IRR) {
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0, 0u, s1, 0u}, rs, vobs, so * row_obs, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, s1}, rs, vobs, so * row_obs, 0);
+        } else {
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, 0u}, rs, vobs, so * row_obs, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(s0, rs, vobs, so * row_obs, 0);
+        }
+    };
+    u32x2 pre[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
+
+    auto step = [&](const int k, const u32x2 act2) __attribute__((always_inline)) {
+        // every lane must hold a start state before the step may end its episode
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) refill();
+        int action = (int)act2.x;
+        action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
+        const bool bad = action < 0 || action >= (int)A;
+        action = bad ? 0 : action;
+        const uint32_t cur = (uint32_t)hist & 0xFFu;
+        const uint32_t nxt = P[cur * A + (uint32_t)action];                  // D1
+        const uint32_t oldest = (uint32_t)(hist >> (8 * (L - 1))) & 0xFFu;   // leaves the L-window
+        key = (key - (oldest == 0xFFu ? 0u : oldest) * spow) * S + nxt;     // D4 key, carried
+        hist = (hist << 8) | nxt;                                            // D3
+        valid = min(valid + 1u, L + 1u);
+        steps += 1;
+        phase = (phase + 1 >= every_n) ? 0u : phase + 1;
+        uint32_t bit = (rbits[key >> 3] >> (key & 7u)) & 1u;
+        bit = valid > L ? bit : 0u;                                          // NaN gate: fewer than L transitions yet
+        const uint32_t outb = (ringbits >> ((delay - 1u) & 31u)) & 1u;      // D5 (shift register)
+        ringbits = delay > 0 ? ((ringbits << 1) | bit) : ringbits;
+        bit = delay > 0 ? outb : bit;
+        bit = phase != 0 ? 0u : bit;                                         // D6
+        const bool done = is_term[nxt] != 0;                                 // D7
+        const float rout = s_rsel[(bit << 1) | (done ? 1u : 0u)];
+        uint32_t bad1 = 0;
+        if (IRR) {                                                           // :2063-2082
+            int action1 = (int)act2.y;
+            action1 += (action1 < 0 && action1 >= -a.A1) ? a.A1 : 0;
+            bad1 = (action1 < 0 || action1 >= a.A1) ? 1u : 0u;
+            action1 = bad1 ? 0 : action1;
+            cur1 = P1[cur1 * (uint32_t)a.A1 + (uint32_t)action1];
+        }
+        status |= (bad || bad1) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+        const bool tr = has_max && steps >= max_steps;
+        const bool need = autoreset && (done || tr);
+        const uint32_t so = (uint32_t)k;
+        if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
+            if (need) put_obs(r_fin, so, nxt, cur1);
+        }
+        // reset(): pop the next queued start state where the episode ended (:2250-2278)
+        const uint32_t s0 = queue[0] & 0xFFu, s1 = queue[0] >> 8;
+#pragma unroll
+        for (int q = 0; q + 1 < kQQ; q++) queue[q] = need ? queue[q + 1] : queue[q];
+        qn -= need ? 1u : 0u;
+        hist = need ? (0xFFFFFFFFFFFFFF00ULL | (uint64_t)s0) : hist;
+        key = need ? s0 : key;
+        valid = need ? 1u : valid;
+        steps = need ? 0u : steps;
+        phase = need ? 0u : phase;
+        ringbits = need ? 0u : ringbits;
+        if (IRR) cur1 = need ? s1 : cur1;
+        put_obs(r_obs, so, need ? s0 : nxt, cur1);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so * N, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so * N, 0);
+    };
+    const int nfull = K / kPre;
+    for (int c = 0; c < nfull; c++) {
+#pragma unroll
+        for (int u = 0; u < kPre; u++) {
+            const u32x2 act = pre[u];
+            pre[u] = load_act(c * kPre + kPre + u);
+            step(c * kPre + u, act);
+        }
+    }
+    for (int k = nfull * kPre; k < K; k++) {
+        u32x2 act = pre[0];
+#pragma unroll
+        for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
+        step(k, act);
+    }
+    // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128)
+    for (uint32_t q = qn * (IRR ? 2u : 1u); q > 0; q--) {
+        const uint64_t lo = g.s_lo - g.inc_lo;
+        const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
+        g.s_lo = lo * a.minv_lo;
+        g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+    }
+    g.store(a.env_s, i);
+    a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps, ringbits);
+    if (IRR) a.irr_state[i] = cur1;
+    if (status) atomicOr(&a.status[i], status);
+}
+
+// Serves the launch if the handle and the launch shape qualify; false = not taken.
+bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
+                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
+    if (a.philox || a.has_p_noise || a.has_r_noise || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds ||
+        a.fast_ok || K < 16 || getenv("MDPP_NO_QUIET"))
+        return false;
+    const unsigned long long bytes = (unsigned long long)K * a.N * (a.irr ? 2 : 1) * 8ULL;
+    if (bytes >= (1ULL << 32)) return false;                    // buffer descriptors address < 4 GiB per array
+    size_t lds = a.lds_bytes;
+    lds = ((lds + (a.irr ? (size_t)a.S1 * a.A1 : 0) + 15) & ~(size_t)15) + (size_t)((a.S + 7) & ~7) * 8 +
+          (a.irr ? (size_t)((a.S1 + 7) & ~7) * 8 : 0);
+    if (lds > 60 * 1024) return false;
+    const int grid = (a.N + kBlock - 1) / kBlock;
+#define MDPP_Q_LAUNCH(O64, IR) hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR>), dim3(grid), dim3(kBlock), lds, s, a, K, \
+                                                  actions, obs, reward, term, trunc, final_obs)
+    if (a.irr) { if (a.obs_i32) MDPP_Q_LAUNCH(false, true); else MDPP_Q_LAUNCH(true, true); }
+    else { if (a.obs_i32) MDPP_Q_LAUNCH(false, false); else MDPP_Q_LAUNCH(true, false); }
+#undef MDPP_Q_LAUNCH
+    return true;
+}
+
+} // namespace mdpp

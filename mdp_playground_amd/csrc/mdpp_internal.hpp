@@ -154,6 +154,8 @@ bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, 
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);
+bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
+                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,

@@ -465,7 +465,11 @@ class RLToyVectorEnv:
                 fast = H % 4 == 0 and (W * H) % 16 == 0 and self._image["tpl_size"] + 16 <= 64
                 return "k_image_obs_fast" if fast else "k_image_obs"
             if not self.uses_fast_kernel:
-                return "k_discrete_step"
+                # mirrors launch_discrete_quiet (mdpp_discrete_quiet.hip)
+                c = self._cfg
+                quiet = (self.rng == "numpy" and not self._per_env and c.unit_rewards and not c.has_transition_noise
+                         and not c.has_reward_noise and K >= 16)
+                return "k_discrete_rollout_quiet" if quiet else "k_discrete_step"
             if K >= 32 and full_blocks and self.autoreset == "same_step":
                 return "k_discrete_rollout_pipe"
             return "k_discrete_rollout_fast"
