@@ -4,7 +4,10 @@
 authors; only configs, action lists and expected numbers (data) are restated here.
 
 Only the tests the survey found consistent with the code at this commit are used (SURVEY.md
-§4.2: 14 of 20 pass under any gymnasium-conformant seeding; the other 6 are stale upstream)."""
+§4.2: 14 of 20 pass under any gymnasium-conformant seeding; the other 6 are stale upstream).
+Of those 14, the ones not replayed here: move_along_a_line (its reward is out of scope,
+DESIGN.md §7), the callable half of the custom-P/R tests, and test_grid_env's passing sibling
+is covered through test_grid_image_representations (the two upstream tests contradict each other)."""
 import numpy as np
 import pytest
 
@@ -156,3 +159,182 @@ def test_image_pixel_sums():
     noises = [-0.0660524, 0.3202113, 0.052450, -0.267834, 0.1807975]
     expected = [(x + n) * 2.5 - 1.75 for x, n in zip([0, 0, 0, 0, 1], noises)]
     np.testing.assert_allclose(rewards, expected, rtol=1e-5)
+
+
+def _grid(config):
+    m = mdp.build_mdp(config)
+    o = ora.GridOracle(list(m.grid_shape), list(m.target_point), m.make_denser, m.transition_noise,
+                       m.reward_noise, m.reward_every_n_steps, m.reward_scale, m.reward_shift,
+                       m.term_state_reward)
+    w = lambda k: mdp.pcg64_words(mdp.new_generator(m.seed_dict[k]))     # noqa: E731
+    o.set_rng(w("env"), w("state_space"), w("action_space"))
+    return m, o, o.reset()
+
+
+def _grid_act(a, width):
+    """The reference's test passes floats / out-of-range vectors to show they are no-ops
+    (GridActionSpace.contains, spaces/grid_action_space.py:24-39); on the int32 boundary every
+    rejected action is just some vector that is not a unit step."""
+    a = list(a) + [0] * (width - len(a))
+    return [int(x) if float(x).is_integer() else 7 for x in a]
+
+
+GRID = dict(seed=0, state_space_type="grid", grid_shape=(8, 8), delay=0, sequence_length=1,
+            reward_function="move_to_a_point", target_point=[5, 5], reward_scale=2.0,
+            make_denser=False, image_representations=True)
+
+
+def _grid_pictures(m, cfg):
+    return lambda cells: ora.image_grid_render(m.image["width"], m.image["height"], 5, list(m.grid_shape),
+                                               cells, cfg["target_point"], cfg.get("terminal_states"))
+
+
+def test_grid_image_representations_sparse():
+    """test_mdp_playground.py:792-868: pixel sums of the first four 100x100 RGB observations, total
+    reward 6.0 and final cell [6, 7] (sparse reward, the episode goes on after the target)."""
+    m, o, s = _grid(GRID)
+    pic = _grid_pictures(m, GRID)
+    acts = [[0, 1], [-1, 0], [0, -1], [0, -1], [0.5, -0.5], [1, 2], [1, 0], [0, -1], [0, -1]] + [[0, 1]] * 6
+    sums, tot = [], 0.0
+    for a in acts:
+        s, r, _ = o.step(_grid_act(a, 2))
+        tot += r
+        sums.append(int(pic(s).sum()))
+    assert sums[:4] == [6371313, 6372018, 6372018, 6407811]
+    assert tot == 6.0 and list(s) == [6, 7]
+
+
+def test_grid_image_representations_dense_and_terminal_cells():
+    """:870-944: dense reward sums to 4.0; with list-form terminal_states (which the reference draws
+    but never ends an episode on) and term_state_reward -0.25 the total is 3."""
+    cfg = dict(GRID, make_denser=True)
+    m, o, s = _grid(cfg)
+    acts = [[0, 1], [-1, 0], [0, 0], [1, 0], [0.5, -0.5], [1, 2], [-1, -1], [0, -1], [0, -1]]
+    assert sum(o.step(_grid_act(a, 2))[1] for a in acts) == 4.0
+    cfg = dict(cfg, terminal_states=[[5, 5], [2, 3], [2, 4], [3, 3], [3, 4]], term_state_reward=-0.25)
+    m, o, s = _grid(cfg)
+    acts = [[0, 1], [-1, 0], [1, 0], [1, 0], [0, -1], [0, -1], [0, -1], [0, 1], [-1, 0], [0, 1], [-1, 0],
+            [0, -1], [1, 0]]
+    assert sum(o.step(_grid_act(a, 2))[1] for a in acts) == 3
+
+
+def test_grid_image_representations_irrelevant_grid_and_noise():
+    """:946-1055: with an irrelevant second grid the observation is two pictures side by side (sums
+    12271695, 12272400), moving only the irrelevant agent earns nothing (total 4); with
+    transition_noise 0.5 the total over the 13 listed actions is 1.0 (pins the noise draw on the
+    env stream and the action re-draw on the action space's stream)."""
+    cfg = dict(GRID, make_denser=True, terminal_states=[[5, 5], [2, 3], [2, 4], [3, 3], [3, 4]],
+               term_state_reward=-0.25, irrelevant_features=True)
+    m, o, s = _grid(cfg)
+    pic = _grid_pictures(m, cfg)
+    acts = [[0, 1], [-1, 0], [0, 0], [1, 0], [0.5, -0.5], [1, 2], [-1, -1], [0, -1], [0, -1]]
+    sums, tot = [], 0.0
+    for a in acts:
+        s, r, _ = o.step(_grid_act(a + [0, 0], 4))
+        tot += r
+        sums.append(int(pic(s).sum()))
+    assert sums[:2] == [12271695, 12272400]
+    for a in acts:
+        tot += o.step(_grid_act([0, 0] + a, 4))[1]
+    assert tot == 4
+    cfg = dict(cfg, transition_noise=0.5, reward_scale=1.0)
+    m, o, s = _grid(cfg)
+    acts = [[0, 1], [-1, 1], [-1, 0], [1, -1], [0.5, -0.5], [1, 2], [1, 1], [0, -1], [1, 0], [0, -1], [1, 0],
+            [0, -1], [0, -1]]
+    assert sum(o.step(_grid_act(a + [0, 0], 4))[1] for a in acts) == 1.0
+
+
+def test_continuous_image_representations():
+    """:717-790: pixel sums of five 100x100 RGB observations while the agent walks into the target
+    (pins the float32 integrator, ImageContinuous' pixel mapping and Pillow's disc raster)."""
+    cfg = dict(seed=0, state_space_type="continuous", action_space_type="continuous", state_space_dim=2,
+               action_space_dim=2, delay=0, sequence_length=1, transition_dynamics_order=1, inertia=1.0,
+               time_unit=1, reward_function="move_to_a_point", state_space_max=5,
+               target_point=[0.146517, -0.397534], target_radius=0.172, reward_scale=2.0,
+               make_denser=False, image_representations=True, image_width=100, image_height=100)
+    m, o, s = _continuous(cfg)
+    o.set_image_quirk(True)
+    sums = []
+    for _ in range(5):
+        s, *_ = o.step(np.array([-0.45, -0.8], np.float32))
+        sums.append(int(ora.image_continuous_render(100, 100, 5, s, 5.0, cfg["target_point"],
+                                                    m.box_lo, m.box_hi).sum()))
+    assert sums == [6168414, 6168414, 6168414, 6171735, 6204207]
+    assert np.linalg.norm(s - np.array(cfg["target_point"])) < cfg["target_radius"]
+
+
+TP5 = dict(TP, state_space_dim=5, action_space_dim=5, relevant_indices=[1, 2],
+           action_space_relevant_indices=[1, 2], target_point=[1.27494, -0.780999])
+
+
+def test_continuous_target_point_dense_irrelevant_dims_and_delay():
+    """:538-603: 5-D state with relevant dims [1, 2]: same reward per step, all five coordinates
+    after 20 steps, a negative reward when the next step moves away, and delay 10."""
+    cfg = dict(TP5, reward_scale=1.0, target_radius=0.05, make_denser=True)
+    a = np.array([0.5] * 5, np.float32)
+    end = np.array([0.69422, 1.27494, -0.780999, 1.52398, -0.311794])
+    m, o, s = _continuous(cfg)
+    for i in range(20):
+        s, r, _, _ = o.step(a)
+        np.testing.assert_allclose(0.035355, r, atol=1e-5, err_msg=f"step {i}")
+    np.testing.assert_allclose(s, end, atol=1e-5)
+    np.testing.assert_allclose(o.step(a)[1], -0.035355, atol=1e-5)
+    m, o, s = _continuous(dict(cfg, delay=10))
+    for i in range(20):
+        s, r, _, _ = o.step(a)
+        np.testing.assert_allclose(0.0 if i < 10 else 0.035355, r, atol=1e-5, err_msg=f"step {i}")
+    np.testing.assert_allclose(s, end, atol=1e-5)
+
+
+def test_continuous_target_point_sparse_delay_and_irrelevant_dims():
+    """:658-715: delay 10 moves the five sparse rewards to steps 27-31 (the agent passes through the
+    target region), in 2-D and with three irrelevant dimensions around the two relevant ones."""
+    cfg = dict(TP, reward_scale=2.0, target_radius=0.072, make_denser=False, delay=10)
+    for c, n, end in [(cfg, 2, [1.06922, 1.64994]),
+                      (dict(cfg, **{k: TP5[k] for k in ("state_space_dim", "action_space_dim", "relevant_indices",
+                                                        "action_space_relevant_indices", "target_point")}),
+                       5, [1.06922, 1.64994, -0.405999, 1.89898, 0.0632061])]:
+        m, o, s = _continuous(c)
+        for i in range(35):
+            s, r, _, _ = o.step(np.array([0.5] * n, np.float32))
+            np.testing.assert_allclose(2.0 if 27 <= i <= 31 else 0.0, r, atol=1e-5, err_msg=f"step {i}")
+        np.testing.assert_allclose(s, end, atol=1e-5)
+
+
+def test_discrete_reward_every_n_steps_with_delay():
+    """:1928-1988: reward_every_n_steps 2 with delay 1 (sequence_length 3, then 1): payout only on
+    even step counts, after the delay line."""
+    cfg = dict(BASE8, make_denser=False, delay=1, sequence_length=3, reward_every_n_steps=2)
+    m, o, _ = _discrete(cfg)
+    assert [o.step(a)[1] for a in [6, 2, 2, 4, 4, 6]] == [0, 0, 0, 1, 0, 0]
+    m, o, _ = _discrete(dict(cfg, sequence_length=1))
+    assert [o.step(a)[1] for a in [6, 3, 4, 4, 4, 6, 6]] == [0, 0, 0, 1, 0, 1, 0]
+
+
+def test_discrete_diameter():
+    """:2222-2391: diameter 3 (24 states in three independent sets of 8): terminal states and the
+    layered structure of the rewardable sequences, their count, and two reward traces."""
+    cfg = dict(seed=0, state_space_type="discrete", action_space_type="discrete", state_space_size=24,
+               action_space_size=8, reward_density=0.05, make_denser=False, terminal_state_density=0.25,
+               maximally_connected=True, repeats_in_sequences=False, delay=0, diameter=3, sequence_length=3,
+               reward_every_n_steps=1, reward_scale=1.0, reward_shift=0.0, generate_random_mdp=True)
+    m, o, _ = _discrete(cfg)
+    seqs = [k for k in m.rewardable_sequences if len(k) == 3]
+    assert len(seqs) == int(0.05 * 6 * 6 * 6) * 3
+    for seq in seqs:
+        for s in seq:
+            assert s not in (6, 7, 14, 15, 22, 23) and s % 8 < 6
+    np.testing.assert_allclose(np.sum(m.init_dist), 1.0, rtol=1e-5)
+    assert [o.step(a)[1] for a in [7, 1, 1, 7, 0, 7, 1]] == [0, 0, 1, 0, 1, 0, 0]
+    m, o, _ = _discrete(dict(cfg, sequence_length=5, reward_density=0.01))
+    seqs = [k for k in m.rewardable_sequences if len(k) == 5]
+    assert len(seqs) == int(0.01 * 6 * 6 * 6 * 5 * 5) * 3
+    for n, seq in enumerate(seqs):
+        for j in range(3):
+            if j / 3 < n / len(seqs) < (j + 1) / 3:
+                for i, s in enumerate(seq):
+                    lo, hi = ((i + j) * 8) % 24, ((i + j + 1) * 8) % 24
+                    hi += 24 if hi < lo else 0
+                    assert lo <= s < hi
+        assert all(s % 8 < 6 for s in seq)
+    assert [o.step(a)[1] for a in [2, 5, 5, 1, 0, 7, 1]] == [0, 0, 0, 0, 1, 0, 0]
