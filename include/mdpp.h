@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 3
+#define MDPP_ABI_VERSION 4
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
@@ -60,6 +60,11 @@ enum { MDPP_STATUS_BAD_ACTION = 1u,     /* discrete: action out of range (refere
                                            continuous: action rejected by Box.contains -> "stay" (:1671) */
        MDPP_STATUS_RESET_GAVE_UP = 2u,  /* continuous reset(): 4096 draws all fell into terminal hypercubes */
        MDPP_STATUS_INTERNAL = 0x80000000u }; /* a bounded in-kernel wait expired (never expected) */
+
+/* what a discrete env's reward table is keyed by */
+enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences, rl_toy_env.py:1837-1841) */
+       MDPP_REWARD_STATE_ACTION = 1 }; /* (s, a) of the transition: use_custom_mdp with a reward MATRIX
+                                          (:1259-1267, :1817-1818); no NaN gate, needs unit_rewards = 0 */
 
 typedef struct mdpp_env mdpp_env;
 
@@ -89,6 +94,7 @@ typedef struct {
     int32_t S, A, L;            /* state_space_size, action_space_size, sequence_length */
     int32_t num_tables;         /* 1 = one MDP shared by all envs; num_envs = one MDP per env */
     int32_t unit_rewards;       /* 1: every rewardable sequence pays exactly 1.0 (bitmask table) */
+    int32_t reward_kind;        /* MDPP_REWARD_*: what the reward table is keyed by */
     int32_t has_transition_noise;
     double transition_noise;
     /* irrelevant_features=True (rl_toy_env.py:2028-2035, :2063-2092): a second, reward-irrelevant
@@ -137,7 +143,9 @@ const char *mdpp_last_error(const mdpp_env *h);   /* h may be NULL: last create(
 
 /* Discrete tables (host pointers; T = cfg.num_tables):
  *   P        uint8 [T][S][A]      transition matrix                       rl_toy_env.py:1050-1151
- *   rtable   double[T][S^L] or, when cfg.unit_rewards, NULL with
+ *   rtable   double[T][S^L] (MDPP_REWARD_SEQUENCES) or double[T][S][A] (MDPP_REWARD_STATE_ACTION:
+ *            use_custom_mdp with a reward matrix, R(s, a) of the transition s, a -> s', :1259-1267)
+ *            or, when cfg.unit_rewards, NULL with
  *   rbits    uint8 [T][ceil(S^L/8)] bit k set <=> sequence with key k is rewardable (:1508)
  *   is_term  uint8 [T][S]                                                 :868-889
  *   init_cdf double[T][S]  cumsum(rho_0)/cumsum(rho_0)[-1]                :1003-1018, :2255

@@ -6,9 +6,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 3
+MDPP_ABI_VERSION = 4
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
+REWARD_SEQUENCES, REWARD_STATE_ACTION = 0, 1
 RNG_NUMPY_PCG64, RNG_PHILOX = 0, 1
 AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1
 OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
@@ -35,7 +36,7 @@ class MdppConfig(C.Structure):
         ("reward_noise", C.c_double), ("reward_scale", C.c_double), ("reward_shift", C.c_double),
         ("term_state_reward", C.c_double),
         ("S", C.c_int32), ("A", C.c_int32), ("L", C.c_int32), ("num_tables", C.c_int32),
-        ("unit_rewards", C.c_int32), ("has_transition_noise", C.c_int32),
+        ("unit_rewards", C.c_int32), ("reward_kind", C.c_int32), ("has_transition_noise", C.c_int32),
         ("transition_noise", C.c_double),
         ("irrelevant", C.c_int32), ("S_irr", C.c_int32), ("A_irr", C.c_int32),
         ("D", C.c_int32), ("n_rel", C.c_int32), ("order", C.c_int32),

@@ -152,7 +152,12 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         if (cfg->num_tables != 1 && cfg->num_tables != cfg->num_envs) {
             g_create_err = "mdpp_create: num_tables must be 1 or num_envs"; free_all(h); delete h; return MDPP_EINVAL;
         }
-        double nk = pow((double)cfg->S, (double)cfg->L);
+        const bool rew_sa = cfg->reward_kind == MDPP_REWARD_STATE_ACTION;
+        if ((cfg->reward_kind != MDPP_REWARD_SEQUENCES && !rew_sa) || (rew_sa && cfg->unit_rewards)) {
+            g_create_err = "mdpp_create: reward_kind must be MDPP_REWARD_SEQUENCES or, with unit_rewards = 0, MDPP_REWARD_STATE_ACTION";
+            free_all(h); delete h; return MDPP_EINVAL;
+        }
+        double nk = rew_sa ? (double)cfg->S * (double)cfg->A : pow((double)cfg->S, (double)cfg->L);
         if (nk > 4.0e9) { g_create_err = "mdpp_create: S^L too large"; free_all(h); delete h; return MDPP_EUNSUPPORTED; }
         if (cfg->unit_rewards && cfg->delay > 32) {
             g_create_err = "mdpp_create: unit_rewards needs delay <= 32"; free_all(h); delete h; return MDPP_EINVAL;
@@ -186,6 +191,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         memset(&a, 0, sizeof(a));
         a.N = cfg->num_envs; a.S = cfg->S; a.A = cfg->A; a.L = cfg->L; a.delay = cfg->delay;
         a.every_n = cfg->every_n; a.shared_tables = (cfg->num_tables == 1); a.unit_rewards = cfg->unit_rewards;
+        a.rew_sa = rew_sa ? 1 : 0;
         a.has_p_noise = cfg->has_transition_noise; a.has_r_noise = cfg->has_reward_noise;
         a.autoreset = cfg->autoreset; a.max_steps = cfg->max_episode_steps;
         a.obs_i32 = (cfg->obs_dtype == MDPP_OBS_I32 || cfg->image);

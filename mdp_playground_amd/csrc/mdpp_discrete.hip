@@ -189,6 +189,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 key = 0;
                 for (int j = L - 1; j >= 0; j--) key = key * S + (uint32_t)((hist >> (8 * j)) & 0xFF);
             }
+            // custom reward matrix: R(s, a) of this transition, whatever s' (noise included) was (:1259-1267)
+            if (!UNIT && a.rew_sa) key = cur * (uint32_t)A + (uint32_t)action;
             const bool done = t.is_term[nxt] != 0;                                  // D7
             float rout;
             if (UNIT) {

@@ -23,6 +23,7 @@ struct DiscreteArgs {
     int32_t S, A, L, delay, every_n;
     int32_t shared_tables;      // 1: tables staged in LDS once per block; 0: one table set per env
     int32_t unit_rewards;       // reward table is a bitmask of keys, every reward = 1.0
+    int32_t rew_sa;             // reward table keyed by (state, action) of the transition (custom reward matrix)
     int32_t has_p_noise, has_r_noise;
     int32_t autoreset, max_steps, obs_i32;
     int32_t philox;

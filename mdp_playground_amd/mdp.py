@@ -82,10 +82,15 @@ class DiscreteMDP(CommonParams):
     init_dist_irr: np.ndarray = None         # float64 [S_irr], uniform (:1025-1037)
     space_irr_rng_words: np.ndarray = None   # observation_spaces[1] RNG after P generation
     space_seeds: tuple = None                # seeds the two sub-space generators were made from
+    # use_custom_mdp with matrices (rl_toy_env.py:1232-1236, :1259-1267): R(s, a), float64 [S, A]
+    reward_matrix: np.ndarray = None
 
     def reward_table(self) -> np.ndarray:
         """Dense float64[S**L]; key(seq) = sum seq[i] * S**(L-1-i).  Only full-length keys can
-        match in step() (rl_toy_env.py:1837-1841), shorter make_denser keys never do."""
+        match in step() (rl_toy_env.py:1837-1841), shorter make_denser keys never do.
+        With a custom reward matrix: float64[S*A], key = s * A + a."""
+        if self.reward_matrix is not None:
+            return np.ascontiguousarray(self.reward_matrix, dtype=np.float64).ravel()
         L, S = self.sequence_length, self.S
         t = np.zeros(S ** L, dtype=np.float64)
         for seq, val in self.rewardable_sequences.items():
@@ -264,7 +269,7 @@ def _rewardable_sequences(env_rng, n_nonterm, A, L, fraction, repeats, diameter)
 def build_discrete(config) -> DiscreteMDP:
     config = copy.deepcopy(config)
     if config.get("use_custom_mdp", False):
-        raise NotImplementedError("use_custom_mdp (callable / matrix P and R) is not on the device path")
+        return _build_discrete_custom(config)
     sd, env_rng = _seed_dict(config)
     common = _common(config, "discrete", sd)
     L = common["sequence_length"]
@@ -363,6 +368,59 @@ def build_discrete(config) -> DiscreteMDP:
                        image=image, irrelevant=irrelevant, S_irr=S_irr, A_irr=A_irr, P_irr=P_irr,
                        init_dist_irr=init_dist_irr, space_irr_rng_words=irr_words,
                        space_seeds=space_seeds, **common)
+
+
+def _build_discrete_custom(config) -> DiscreteMDP:
+    """use_custom_mdp=True with P and R given as MATRICES (rl_toy_env.py:346-348, :586-587,
+    :859-866, :997-1000 + :617-618, :1232-1236, :1259-1267).  Callables stay on the host: a Python
+    function cannot be restated as a table lookup."""
+    _require("transition_function" in config, "use_custom_mdp needs transition_function")   # :347
+    _require("reward_function" in config, "use_custom_mdp needs reward_function")           # :348
+    if callable(config["transition_function"]) or callable(config["reward_function"]):
+        raise NotImplementedError("use_custom_mdp with callables runs on the host only; the device "
+                                  "path takes transition_function / reward_function as S x A arrays")
+    if config.get("irrelevant_features", False):
+        raise NotImplementedError("use_custom_mdp with irrelevant_features is not built")
+    sd, _env_rng = _seed_dict(config)
+    common = _common(config, "discrete", sd)
+    _require(isinstance(config["action_space_size"], int),
+             "Did you mean to turn irrelevant_features? If so, please set irrelevant_features = "
+             "True in config. If not, please provide an int for action_space_size.")
+    A, S = config["action_space_size"], int(config["state_space_size"])    # :586-587: S is taken as given
+    diameter = config.get("diameter", 1)
+    P = np.asarray(config["transition_function"])
+    R = np.asarray(config["reward_function"], dtype=np.float64)
+    if P.shape != (S, A) or R.shape != (S, A):
+        raise IndexError("transition_function and reward_function must be state_space_size x action_space_size arrays")
+    if P.dtype.kind not in "iu" or P.min() < 0 or P.max() >= S:
+        raise IndexError("transition_function entries must be state indices in [0, state_space_size)")
+    n_term = int(config.get("terminal_state_density", 0.25) * A)           # :868-870 (A, not S)
+    if "terminal_states" in config:                                        # :859-866
+        if callable(config["terminal_states"]):
+            raise NotImplementedError("callable terminal_states runs on the host only")
+        terminal = np.asarray(config["terminal_states"], dtype=np.int64).reshape(-1)
+        terminal = terminal[(terminal >= 0) & (terminal < S)]              # `s in list`: others never match
+    else:
+        terminal = np.array([j * A - 1 - i for j in range(1, diameter + 1) for i in range(n_term)],
+                            dtype=np.int64)
+    if "relevant_init_state_dist" in config:                               # :617-618
+        init_dist = np.asarray(config["relevant_init_state_dist"], dtype=np.float64)
+    elif "init_state_dist" in config:
+        init_dist = np.asarray(config["init_state_dist"], dtype=np.float64)
+    else:                                                                  # :1003-1018 (sized by A)
+        n_nonterm = A - n_term
+        init_dist = np.array(([1 / (n_nonterm * diameter) for _ in range(n_nonterm)]
+                              + [0 for _ in range(n_term)]) * diameter)
+    if init_dist.shape != (S,):
+        raise ValueError("'a' and 'p' must have same size")                # what Generator.choice raises in reset()
+    tn = config.get("transition_noise", None)
+    image = _image_params(config, sd) if config.get("image_representations", False) else None
+    return DiscreteMDP(kind="discrete", S=S, A=A, diameter=diameter,
+                       transition_noise=None if not tn else float(tn), P=P.astype(np.int64),
+                       terminal_states=terminal, init_dist=init_dist, rewardable_sequences={},
+                       space_rng_words=pcg64_words(new_generator(sd["relevant_state_space"])),
+                       image=image, space_seeds=(sd["relevant_state_space"], sd.get("irrelevant_state_space")),
+                       reward_matrix=R, **common)
 
 
 def _image_params(config, sd):

@@ -131,7 +131,11 @@ class RLToyVectorEnv:
         cfg.num_tables = self.num_envs if self._per_env else 1
         unit = all(v == 1.0 for mm in self.mdps for k, v in mm.rewardable_sequences.items()
                    if len(k) == mm.sequence_length)
-        cfg.unit_rewards = int(unit and m.delay <= 32)
+        custom_r = [mm.reward_matrix is not None for mm in self.mdps]
+        if any(custom_r) and not all(custom_r):
+            raise ValueError("per-env MDPs must all use a reward matrix or all use rewardable sequences")
+        cfg.reward_kind = capi.REWARD_STATE_ACTION if custom_r[0] else capi.REWARD_SEQUENCES
+        cfg.unit_rewards = int(unit and m.delay <= 32 and not custom_r[0])
         cfg.has_transition_noise = int(bool(m.transition_noise))
         cfg.transition_noise = float(m.transition_noise or 0.0)
         dtype_o = self.config.get("dtype_o", self.config.get("dtype_s", np.int64))
@@ -173,6 +177,7 @@ class RLToyVectorEnv:
             self.single_observation_space = ImageSpace(im["width"], im["height"])
         self.transition_matrix = m.P
         self.rewardable_sequences = m.rewardable_sequences
+        self.reward_matrix = m.reward_matrix               # use_custom_mdp with matrices (:1259-1267)
         # mirrors DiscreteArgs.fast_ok (mdpp_capi.hip): which kernel serves this handle
         self.uses_fast_kernel = bool(
             not self._per_env and cfg.unit_rewards and not cfg.has_transition_noise

@@ -35,6 +35,8 @@ struct ora_discrete {
     int32_t *P1;
     double *init_cdf1;
     np_pcg64 space1_rng;     /* self.observation_spaces[1].np_random */
+    /* use_custom_mdp with a reward MATRIX: R(s, a) of the transition (:1259-1267, :1817-1818) */
+    double *rmat;            /* [S*A] or NULL */
 };
 
 static long ipow(long b, int e) { long r = 1; while (e-- > 0) r *= b; return r; }
@@ -64,7 +66,18 @@ ora_discrete *ora_d_create(int S, int A, int L, int delay, int every_n,
 
 void ora_d_destroy(ora_discrete *e) {
     if (!e) return;
-    free(e->P); free(e->rtable); free(e->is_term); free(e->init_cdf); free(e->P1); free(e->init_cdf1); free(e);
+    free(e->P); free(e->rtable); free(e->is_term); free(e->init_cdf); free(e->P1); free(e->init_cdf1);
+    free(e->rmat); free(e);
+}
+
+/* use_custom_mdp=True with "reward_function" given as an S x A array: the reference wraps it as
+ * lambda s, a: reward_matrix[s[-2], a] (:1259-1267) and reward_function() calls that instead of
+ * the rewardable-sequence lookup, without the NaN gate (:1817-1818); delay FIFO, every-n, noise and
+ * the affine map then apply as for every env (:1968-1990). */
+void ora_d_set_reward_matrix(ora_discrete *e, const double *R) {
+    free(e->rmat);
+    e->rmat = (double *)malloc(sizeof(double) * e->S * e->A);
+    memcpy(e->rmat, R, sizeof(double) * e->S * e->A);
 }
 
 void ora_d_set_irrelevant(ora_discrete *e, int S1, int A1, const int32_t *P1, const double *init_dist1) {
@@ -111,7 +124,8 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
         e->tick += 1;
     }
     /* D1: table lookup, :1603 */
-    int nxt = e->P[e->hist[L] * e->A + action];
+    const int prev = e->hist[L];
+    int nxt = e->P[prev * e->A + action];
     /* D2: categorical P-noise on the state-space RNG, :1604-1622 + discrete_extended.py:11-23 */
     if (e->has_p_noise) {
         double cdf[256], probs[256];
@@ -126,7 +140,9 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
     e->steps += 1;
     /* D4: rewardable-sequence lookup, :1821-1845 */
     double r = 0.0;
-    if (e->hist[0] >= 0) {
+    if (e->rmat) {
+        r = e->rmat[prev * e->A + action];   /* s[-2] is the state the transition started from */
+    } else if (e->hist[0] >= 0) {
         long key = 0;
         for (int i = 1; i <= L; i++) key = key * S + e->hist[i];
         r = e->rtable[key];

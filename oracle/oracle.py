@@ -44,6 +44,7 @@ def lib():
         L.ora_d_step.argtypes = [vp, i32, vp, vp, vp]
         L.ora_d_rollout.argtypes = [vp, i32] + [vp] * 6
         L.ora_d_set_irrelevant.argtypes = [vp, i32, i32, vp, vp]
+        L.ora_d_set_reward_matrix.argtypes = [vp, vp]
         L.ora_d_set_rng_irr.argtypes = [vp, vp]
         L.ora_d_get_rng_irr.argtypes = [vp, vp]
         L.ora_d_reset2.argtypes = [vp, vp]
@@ -170,6 +171,12 @@ class DiscreteOracle:
     def set_philox(self, seed, env_id, tick=0, reset_tick=0):
         self._philox = True
         lib().ora_d_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
+
+    def set_reward_matrix(self, R):
+        """use_custom_mdp with reward_function given as an S x A array (rl_toy_env.py:1259-1267)."""
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        assert R.shape == (self.S, self.A)
+        lib().ora_d_set_reward_matrix(self.h, _p(R))
 
     # ---- irrelevant sub-space (Tuple observations / actions): states and actions become pairs
     def set_irrelevant(self, P_irr, init_dist_irr):

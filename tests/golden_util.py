@@ -57,6 +57,8 @@ def discrete_oracle_from_golden(name, g, e):
                            g[f"terminal_states_{e}"], g["init_dist"][e],
                            p["transition_noise"], p["reward_noise"], p["reward_scale"],
                            p["reward_shift"], p["term_state_reward"])
+    if "rew_matrix" in g.files:                      # use_custom_mdp with matrices
+        o.set_reward_matrix(g["rew_matrix"][e])
     if "P_irr" in g.files:
         o.set_irrelevant(g["P_irr"][e], g["init_dist_irr"][e])
     return o

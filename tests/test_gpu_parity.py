@@ -95,9 +95,13 @@ def _oracle_for(env, i):
         return ora.GridOracle(m.grid_shape, m.target_point, m.make_denser, m.transition_noise, m.reward_noise,
                               m.reward_every_n_steps, m.reward_scale, m.reward_shift, m.term_state_reward)
     if m.kind == "discrete":
+        custom = m.reward_matrix is not None
         o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps, m.P,
-                               m.reward_table(), m.terminal_states, m.init_dist, m.transition_noise,
+                               np.zeros(m.S ** m.sequence_length) if custom else m.reward_table(),
+                               m.terminal_states, m.init_dist, m.transition_noise,
                                m.reward_noise, m.reward_scale, m.reward_shift, m.term_state_reward)
+        if custom:
+            o.set_reward_matrix(m.reward_matrix)
         if m.irrelevant:
             o.set_irrelevant(m.P_irr, m.init_dist_irr)
     else:
@@ -135,6 +139,45 @@ def test_discrete_shared_mdp_4096_envs_vs_oracle(noise):
         assert np.array_equal(rew[:, i], er.astype(np.float32)), i
         we, ws = o.get_rng()
         assert np.array_equal(we[:4], end_env[i][:4]) and np.array_equal(ws[:4], end_sp[i][:4])
+    env.close()
+
+
+@pytest.mark.parametrize("name,rng", [("d_custom_pr", "numpy"), ("d_custom_noise", "numpy"),
+                                      ("d_custom_noise", "philox")])
+def test_discrete_custom_matrices_2048_envs_vs_oracle(name, rng):
+    """use_custom_mdp with P and R matrices (reward keyed by the transition's (s, a)): one shared MDP
+    in LDS, 2048 instances, fused rollout with same-step autoreset then single steps, every 5th
+    instance against its own oracle instance; negative action indices wrap like numpy's."""
+    cfg = dict(gu.CASES[name]["config"], seed=11)
+    N, T, T1 = 2048, 64, 8
+    kw = dict(rng="philox", philox_seed=99) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    A = cfg["action_space_size"]
+    acts = np.random.default_rng(6).integers(0, A, size=(T + T1, N)).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts[:T], device=env.device))
+    obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    single = []
+    for t in range(T, T + T1):
+        o1, r1, d1, _, _ = env.step(torch.as_tensor(acts[t], device=env.device))
+        single.append((o1.cpu().numpy().copy(), r1.cpu().numpy().copy(), d1.cpu().numpy().copy()))
+    for i in range(0, N, 5):
+        o = _oracle_for(env, i)
+        if rng == "philox":
+            o.set_philox(99, i)
+            assert o.reset() == int(init[i])
+        else:
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+            assert o.reset() == int(init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        exp = eo.copy()
+        exp[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], exp[:T]) and np.array_equal(term[:, i], ed[:T]), i
+        # (Philox mode: the ziggurat tail's log1p/exp may differ from glibc's in the last ulp)
+        same = np.array_equal if rng == "numpy" else (lambda x, y: np.allclose(x, y, rtol=1e-6, atol=1e-6))
+        assert same(rew[:, i], er[:T].astype(np.float32)), i
+        for k, (o1, r1, d1) in enumerate(single):
+            assert o1[i] == exp[T + k] and d1[i] == ed[T + k] and same(r1[i], np.float32(er[T + k])), (i, k)
     env.close()
 
 

@@ -338,3 +338,25 @@ def test_discrete_diameter():
                     assert lo <= s < hi
         assert all(s % 8 < 6 for s in seq)
     assert [o.step(a)[1] for a in [2, 5, 5, 1, 0, 7, 1]] == [0, 0, 0, 0, 1, 0, 0]
+
+
+def test_discrete_custom_P_R_matrices():
+    """:1990-2036: use_custom_mdp with P and R given as matrices, delay 1, reward_scale 2: the reward
+    of transition (s, a) is R[s, a], one step late.  (The second half of the upstream test passes
+    the same tables as Python callables, which stay on the host.)"""
+    cfg = dict(seed=0, state_space_type="discrete", action_space_type="discrete", state_space_size=8,
+               action_space_size=5, terminal_state_density=0.25, repeats_in_sequences=False, delay=1,
+               reward_scale=2.0, use_custom_mdp=True,
+               transition_function=np.random.default_rng(0).integers(8, size=(8, 5)),
+               reward_function=np.random.default_rng(1).integers(4, size=(8, 5)),
+               init_state_dist=np.array([1 / 8 for _ in range(8)]))
+    m = mdp.build_mdp(cfg)
+    o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps, m.P,
+                           np.zeros(m.S ** m.sequence_length), m.terminal_states, m.init_dist,
+                           m.transition_noise, m.reward_noise, m.reward_scale, m.reward_shift,
+                           m.term_state_reward)
+    o.set_reward_matrix(m.reward_matrix)
+    o.set_rng(mdp.pcg64_words(mdp.new_generator(m.seed_dict["env"])), m.space_rng_words)
+    o.reset()
+    acts = [4, 4, 2, 3, 4, 2, 4, 1, 0, int(np.random.default_rng(0).integers(5)), 4]
+    assert [o.step(a)[1] for a in acts] == [0, 2, 2, 6, 6, 2, 0, 2, 6, 2, 2]

@@ -116,6 +116,25 @@ CASES = {
                     seed={"env": 0, "relevant_state_space": 8,
                           "relevant_action_space": 8}),
         seeds=[None], T=6, reset="never", actions=[6, 2, 2, 4, 4, 6]),
+    # --- use_custom_mdp with P and R given as matrices (lists here, arrays when handed to the env)
+    "d_custom_pr": dict(     # the env of the reference's test_discrete_custom_P_R (:1990-2036)
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=8, action_space_size=5, terminal_state_density=0.25,
+                    repeats_in_sequences=False, delay=1, reward_scale=2.0, use_custom_mdp=True,
+                    transition_function=np.random.default_rng(0).integers(8, size=(8, 5)).tolist(),
+                    reward_function=np.random.default_rng(1).integers(4, size=(8, 5)).tolist(),
+                    init_state_dist=[1 / 8 for _ in range(8)]),
+        seeds=list(range(4)), T=200, reset="on_done"),
+    "d_custom_noise": dict(  # float rewards, own terminal states and rho_0, both noises, every-n 2
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=12, action_space_size=6, delay=3, reward_every_n_steps=2,
+                    reward_scale=1.5, reward_shift=-0.25, term_state_reward=-0.5,
+                    transition_noise=0.2, reward_noise=0.1, use_custom_mdp=True,
+                    transition_function=np.random.default_rng(5).integers(12, size=(12, 6)).tolist(),
+                    reward_function=np.round(np.random.default_rng(6).normal(size=(12, 6)), 3).tolist(),
+                    terminal_states=[3, 7],
+                    init_state_dist=(np.arange(1, 13) * (np.arange(12) % 4 != 3) / 54.0).tolist()),
+        seeds=list(range(4)), T=200, reset="mixed"),
     # --- discrete with an irrelevant sub-space (Tuple spaces; second table, second P-noise stream)
     "d_irr_plain": dict(     # the config of the reference's test_discrete_irr_features (:1729-1774)
         config=dict(state_space_type="discrete", action_space_type="discrete",
@@ -252,7 +271,8 @@ def run_case(name, case):
     tables = {k: [] for k in ("P", "terminal_states", "init_dist", "rew_keys",
                               "rew_vals", "rng_env", "rng_space", "rng_image",
                               "init_obs", "init_state", "seed_dict", "sd",
-                              "P_irr", "init_dist_irr", "rng_space_irr", "rng_action")}
+                              "P_irr", "init_dist_irr", "rng_space_irr", "rng_action",
+                              "rew_matrix")}
     seed_names = ["env", "relevant_state_space", "relevant_action_space",
                   "irrelevant_state_space", "irrelevant_action_space", "state_space",
                   "action_space", "image_representations"]
@@ -260,6 +280,9 @@ def run_case(name, case):
         cfg = dict(base)
         if seed is not None:
             cfg["seed"] = seed
+        if cfg.get("use_custom_mdp"):
+            for k in ("transition_function", "reward_function", "init_state_dist"):
+                cfg[k] = np.array(cfg[k])
         env = make_env(cfg)
         arng = np.random.default_rng(1000003 * (e + 1) + 17)  # action/reset policy rng
         sdict = env.seed_dict
@@ -276,13 +299,15 @@ def run_case(name, case):
             tables["init_dist"].append(
                 np.array(env.config["relevant_init_state_dist"], dtype=np.float64))
             keys, vals = [], []
-            for seq, v in env.rewardable_sequences.items():
+            for seq, v in getattr(env, "rewardable_sequences", {}).items():
                 if len(seq) == L:
                     keys.append(list(seq))
                     vals.append(float(v))
             tables["rew_keys"].append(np.array(keys, dtype=np.int64).reshape(-1, L))
             tables["rew_vals"].append(np.array(vals, dtype=np.float64))
             tables["rng_space"].append(pcg_state(env.observation_spaces[0].np_random))
+            if env.use_custom_mdp:
+                tables["rew_matrix"].append(np.array(env.reward_matrix, dtype=np.float64))
             if env.irrelevant_features:
                 tables["P_irr"].append(np.array(
                     env.config["transition_function_irrelevant"].tolist(), dtype=np.int64))
