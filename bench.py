@@ -80,6 +80,13 @@ WORKLOADS = {
                                  terminal_states=[[-3.0, 3.0], [3.0, 3.0]], term_state_edge=2.0,
                                  reward_function="move_to_a_point", image_representations=True,
                                  image_width=100, image_height=100, seed=0)),
+    # §8f rank 2, last item (not a BASELINE config): reward_function move_along_a_line, the env of the
+    # reference's test_continuous_dynamics_move_along_a_line; the per-step line fit is f64 arithmetic
+    "line": dict(kind="continuous", envs=65536, alg_bytes_fused=38, alg_bytes_step=38 + 16 + 24 + 8 + 160,
+                 config=dict(state_space_type="continuous", state_space_dim=4, transition_dynamics_order=1,
+                             inertia=1, time_unit=1, delay=0, sequence_length=10, reward_scale=1.0,
+                             action_space_max=1, state_space_max=100, reward_function="move_along_a_line",
+                             seed=0)),
     # the irrelevant-sub-space variant of cfg2's MDP size (Tuple spaces), also §8f rank 2
     "cfg2_irr": dict(kind="discrete", envs=65536, alg_bytes_fused=30, alg_bytes_step=62,
                      config=dict(state_space_type="discrete", action_space_type="discrete",
@@ -144,6 +151,8 @@ def cpu_baseline(wl, seconds=12.0):
                                      m.transition_noise, m.reward_noise, m.delay,
                                      m.reward_every_n_steps, m.reward_scale, m.reward_shift,
                                      m.term_state_reward, m.box_lo, m.box_hi)
+            if m.reward_function == "move_along_a_line":
+                o.set_line_reward(m.sequence_length, m.delay)
             sp = mdp_mod.new_generator(m.seed_dict["state_space"] + i)
         o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator((m.seed_dict["env"] or 0) + i)),
                   mdp_mod.pcg64_words(sp))

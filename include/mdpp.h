@@ -66,6 +66,12 @@ enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences
        MDPP_REWARD_STATE_ACTION = 1 }; /* (s, a) of the transition: use_custom_mdp with a reward MATRIX
                                           (:1259-1267, :1817-1818); no NaN gate, needs unit_rewards = 0 */
 
+/* reward_function of a continuous env */
+enum { MDPP_CREWARD_MOVE_TO_A_POINT = 0,    /* rl_toy_env.py:1912-1945 */
+       MDPP_CREWARD_MOVE_ALONG_A_LINE = 1 }; /* :1864-1910: minus the mean distance of the last L states from
+                                                the line fitted through them (first right-singular vector);
+                                                n_rel <= 4, L <= 64, no image observations */
+
 typedef struct mdpp_env mdpp_env;
 
 #define MDPP_MAX_DIM 32
@@ -103,8 +109,9 @@ typedef struct {
     int32_t irrelevant;
     int32_t S_irr, A_irr;
 
-    /* ---- continuous (move_to_a_point) ---- */
+    /* ---- continuous ---- */
     int32_t D, n_rel, order;    /* state_space_dim, len(relevant_indices), transition_dynamics_order */
+    int32_t reward_function;    /* MDPP_CREWARD_*; move_along_a_line takes sequence_length from L above */
     int32_t rel_idx[MDPP_MAX_DIM];
     int32_t make_denser;
     int32_t has_p_noise;        /* "transition_noise" in config (D normals drawn even for std 0) */

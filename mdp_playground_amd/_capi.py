@@ -10,6 +10,7 @@ MDPP_ABI_VERSION = 4
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
 REWARD_SEQUENCES, REWARD_STATE_ACTION = 0, 1
+CREWARD_MOVE_TO_A_POINT, CREWARD_MOVE_ALONG_A_LINE = 0, 1
 RNG_NUMPY_PCG64, RNG_PHILOX = 0, 1
 AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1
 OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
@@ -39,7 +40,7 @@ class MdppConfig(C.Structure):
         ("unit_rewards", C.c_int32), ("reward_kind", C.c_int32), ("has_transition_noise", C.c_int32),
         ("transition_noise", C.c_double),
         ("irrelevant", C.c_int32), ("S_irr", C.c_int32), ("A_irr", C.c_int32),
-        ("D", C.c_int32), ("n_rel", C.c_int32), ("order", C.c_int32),
+        ("D", C.c_int32), ("n_rel", C.c_int32), ("order", C.c_int32), ("reward_function", C.c_int32),
         ("rel_idx", C.c_int32 * MAX_DIM), ("make_denser", C.c_int32), ("has_p_noise", C.c_int32),
         ("p_noise", C.c_double), ("inertia", C.c_double), ("time_unit", C.c_double),
         ("state_space_max", C.c_double), ("action_space_max", C.c_double),

@@ -51,7 +51,7 @@ static void free_all(mdpp_env *h) {
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final, h->d_img_rec};
+                    h->d_img_state_final, h->d_img_rec, h->d_line_hist, h->d_ring64};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -95,6 +95,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
     h->d_P1 = h->d_init_cdf1 = h->d_noise_cdf1 = h->d_irr_state = nullptr;
+    h->d_line_hist = h->d_ring64 = nullptr;
     h->irr_ready = false;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = nullptr;
@@ -230,7 +231,17 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes <= 8";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
+        const bool line = cfg->reward_function == MDPP_CREWARD_MOVE_ALONG_A_LINE;
+        if ((cfg->reward_function != MDPP_CREWARD_MOVE_TO_A_POINT && !line) ||
+            (line && (cfg->n_rel > 4 || cfg->L < 1 || cfg->L > 64 || cfg->image))) {
+            g_create_err = "mdpp_create: move_along_a_line needs n_rel <= 4, 1 <= L <= 64 and no image observations";
+            free_all(h); delete h; return MDPP_EUNSUPPORTED;
+        }
         const size_t D = (size_t)cfg->D;
+        if (line) {
+            TRY(alloc_zero(h, &h->d_line_hist, (size_t)cfg->L * 4 * N * sizeof(float)));
+            if (cfg->delay > 0) TRY(alloc_zero(h, &h->d_ring64, (size_t)cfg->delay * N * sizeof(double)));
+        }
         TRY(alloc_zero(h, &h->d_sd, (size_t)(cfg->order + 1) * D * N * sizeof(float)));
         TRY(alloc_zero(h, &h->d_cur, D * N * sizeof(float)));
         TRY(alloc_zero(h, &h->d_meta, N * sizeof(uint2)));
@@ -280,7 +291,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
                 if (is_pow2(a.fact[k])) a.fact_pow2_mask |= 1u << k;
             }
             a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && cfg->n_boxes == 0 && a.rel_prefix &&
-                         a.bounded && cfg->delay == 0 && cfg->every_n == 1 && !cfg->image) ? 1u : 0u;
+                         a.bounded && cfg->delay == 0 && cfg->every_n == 1 && !cfg->image && !line) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
         }
         if (cfg->image) {   // scratch of one batch of img_chunk env steps: the states the pictures are made from
@@ -289,6 +300,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
+        a.line_L = line ? cfg->L : 0; a.line_hist = (float *)h->d_line_hist; a.ring64 = (double *)h->d_ring64;
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
@@ -873,7 +885,15 @@ extern "C" int mdpp_get_state_continuous(mdpp_env *h, float *derivs, float *cur,
             if (reached) reached[i] = (uint8_t)(me[2 * i + 1] & 1u);
         }
     }
-    if (ring && d > 0) {
+    if (ring && d > 0 && h->cargs.line_L) {          // move_along_a_line: a float64 delay line
+        std::vector<double> rg((size_t)d * N);
+        HIPCHK(h, hipMemcpy(rg.data(), h->d_ring64, rg.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++)
+            for (int j = 0; j < d; j++) {
+                ring[i * d + j] = rg[(size_t)((h->tick + j) % d) * N + i];
+                if (ring_is32) ring_is32[i * d + j] = 0;
+            }
+    } else if (ring && d > 0) {
         std::vector<uint32_t> rg((size_t)d * N);
         HIPCHK(h, hipMemcpy(rg.data(), h->d_ring, rg.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < N; i++)
@@ -891,6 +911,8 @@ extern "C" int mdpp_set_state_continuous(mdpp_env *h, const float *derivs, const
                                          const int32_t *steps, const double *ring,
                                          const uint8_t *ring_is32, const uint8_t *reached) {
     if (!h || h->cfg.kind != MDPP_KIND_CONTINUOUS || !derivs || !cur || !steps) return MDPP_EINVAL;
+    if (h->cargs.line_L)
+        return fail(h, MDPP_EUNSUPPORTED, "set_state_continuous: move_along_a_line keeps the last sequence_length states, which this call does not carry");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const size_t N = (size_t)h->cfg.num_envs, D = (size_t)h->cfg.D;

@@ -80,6 +80,175 @@ __device__ __forceinline__ void c_gather_rel(const ContinuousArgs &a, const floa
     }
 }
 
+// ---- reward_function move_along_a_line (:1864-1910, dist_of_pt_from_line :2546-2576) -------------
+// The last L states' relevant coordinates live in HBM, line_hist[(slot * 4 + j) * N + env] with
+// slot = s % L for the state reached after s transitions of the episode (s = 0: reset()).
+template <int DMAX>
+__device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint32_t s, const float (&rel)[DMAX]) {
+    const uint32_t slot = s % (uint32_t)a.line_L;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < DMAX && j < a.n_rel) a.line_hist[((size_t)slot * 4 + j) * a.N + i] = rel[j < DMAX ? j : 0];
+}
+
+// Reward after `steps` (>= L) transitions: minus the mean float64 distance of the L newest states from
+// the line through their mean along the dominant right-singular vector of the centred float32 data.
+// The reference takes that vector from LAPACK's float32 SVD; here it is the dominant eigenvector of
+// the 4x4 float64 scatter matrix (40 normalised squarings: B <- B B / tr), rounded to float32 like
+// LAPACK's output.  The two agree to float32 rounding divided by the gap between the two largest
+// singular values, which is the accuracy the reference's own reward has.
+__device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i, uint32_t steps) {
+    const int L = a.line_L, n = a.n_rel;
+    const size_t N = (size_t)a.N;
+    // slot of the oldest of the L newest states; walked with a wrap instead of a modulo per point
+    const uint32_t slot0 = (steps + 1u) % (uint32_t)L;
+    uint32_t slot = slot0;
+    float x[4];
+    auto next_pt = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = (j < n) ? a.line_hist[((size_t)slot * 4 + j) * N + i] : 0.0f;
+        slot = (slot + 1u == (uint32_t)L) ? 0u : slot + 1u;
+    };
+    // One pass over the points: (1) data_.mean(axis=0) the way numpy sums a contiguous float32 column
+    // (pairwise routine: 8 running sums while 8 more points are left, a fixed tree, the rest one by
+    // one; plain left-to-right below 8 points), divided by L in float32; (2) float64 raw moments for
+    // the scatter matrix about that mean: S = sum x x^T - m s^T - s m^T + L m m^T with s = sum x.
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, m[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[p][q] = 0.0;
+    auto moments = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            s1[p] += (double)x[p];
+#pragma unroll
+            for (int q = p; q < 4; q++) m[p][q] = fma((double)x[p], (double)x[q], m[p][q]);
+        }
+    };
+    float mean[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    if (L >= 8) {
+        float r[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            next_pt(); moments();
+#pragma unroll
+            for (int j = 0; j < 4; j++) r[q][j] = x[j];
+        }
+        for (k = 8; k < L - (L % 8); k += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                next_pt(); moments();
+#pragma unroll
+                for (int j = 0; j < 4; j++) r[q][j] += x[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            mean[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
+    }
+    for (; k < L; k++) {
+        next_pt(); moments();
+#pragma unroll
+        for (int j = 0; j < 4; j++) mean[j] += x[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) mean[j] = (j < n) ? mean[j] / (float)L : 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = p; q < 4; q++) {
+            const double mp = (double)mean[p], mq = (double)mean[q];
+            m[p][q] = m[p][q] - mp * s1[q] - s1[p] * mq + (double)L * mp * mq;
+            m[q][p] = m[p][q];
+        }
+    double v[4] = {1.0, 0.0, 0.0, 0.0};           // all points equal: LAPACK returns the identity, vv[0] = e0
+    double tr = m[0][0] + m[1][1] + m[2][2] + m[3][3];
+    if (tr > 0.0) {
+        // B <- B B, rescaled by a power of two (exact) so that tr(B) stays in [1/2, 1).  With eigenvalues
+        // mu_i of B, tr(B B) / tr(B)^2 = sum mu_i^2 / (sum mu_i)^2 reaches 1 when B has rank one: stop
+        // when every lane of the wave is there (6-10 squarings for a random walk, 40 at most)
+        auto pow2_inv = [](double t) __attribute__((always_inline)) -> double {   // 2^-(exponent of t)
+            const uint64_t e = ((uint64_t)__double_as_longlong(t) >> 52) & 0x7FFu;
+            return __longlong_as_double((long long)((2046ull - e - 1ull) << 52));
+        };
+        double sc = pow2_inv(tr);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) m[p][q] *= sc;
+        tr *= sc;
+        for (int it = 0; it < 40; it++) {
+            double sq[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = p; q < 4; q++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc = fma(m[p][r], m[r][q], acc);
+                    sq[p][q] = acc;
+                }
+            const double tr2 = sq[0][0] + sq[1][1] + sq[2][2] + sq[3][3];
+            const bool conv = (tr * tr - tr2) <= 2e-15 * tr * tr;
+            sc = pow2_inv(tr2);
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = p; q < 4; q++) { m[p][q] = sq[p][q] * sc; m[q][p] = m[p][q]; }
+            tr = tr2 * sc;
+            if (__builtin_amdgcn_ballot_w64(!conv) == 0) break;
+        }
+        // m ~ v v^T: the column with the largest diagonal entry, normalised
+        double best = m[0][0];
+        double c0 = m[0][0], c1 = m[1][0], c2 = m[2][0], c3 = m[3][0];
+#pragma unroll
+        for (int q = 1; q < 4; q++) {
+            const bool b = m[q][q] > best;
+            best = b ? m[q][q] : best;
+            c0 = b ? m[0][q] : c0; c1 = b ? m[1][q] : c1; c2 = b ? m[2][q] : c2; c3 = b ? m[3][q] : c3;
+        }
+        const double s = 1.0 / sqrt(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3);
+        v[0] = c0 * s; v[1] = c1 * s; v[2] = c2 * s; v[3] = c3 * s;
+    }
+    // line_end_pts = vv[0] * [-1, 1][:, None] + data_mean (float64 from here on)
+    double ptA[4], ab[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double vj = (double)(float)v[j], mj = (double)mean[j];
+        ptA[j] = vj * -1.0 + mj;
+        ab[j] = ptA[j] - (vj * 1.0 + mj);
+    }
+    double nab = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < n) nab = fma(ab[j], ab[j], nab);    // np.dot: a chain of FMAs
+    nab = sqrt(nab);
+    double total = 0.0;
+    slot = slot0;
+    for (int kk = 0; kk < L; kk++) {
+        double dot = 0.0, nap = 0.0;
+        next_pt();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < n) {
+                const double ap = ptA[j] - (double)x[j];
+                dot = fma(ab[j], ap, dot);
+                nap = fma(ap, ap, nap);
+            }
+        }
+        double dist = 0.0;
+        if (!(nab < 1e-13)) {
+            const double proj = dot / nab, na = sqrt(nap);
+            double sq = na * na - proj * proj;
+            sq = sq < 0.0 ? 0.0 : sq;
+            dist = sqrt(sq);
+        }
+        total += dist;
+    }
+    return 0.0 + -total / (double)L;
+}
+
 template <int DMAX, int OMAX, class G>
 __device__ __forceinline__ void c_reset_lane(const ContinuousArgs &a, G &sp, float (&sd)[OMAX + 1][DMAX],
                                              float (&cur)[DMAX], uint32_t &status) {
@@ -224,15 +393,20 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 #pragma unroll
                 for (int d = 0; d < DMAX; d++) sd[kk][d] = (kk == 0) ? nxt[d] : 0.0f;
         }
-        // ---- C5
+        // ---- C5 (the target latch exists for move_to_a_point only)
         c_gather_rel<DMAX>(a, nxt, rel);
-        const float dist_new = c_norm_rel<DMAX>(a, rel);
-        if (dist_new < a.radius32) flags |= 1u;
+        const float dist_new = a.line_L ? 0.0f : c_norm_rel<DMAX>(a, rel);
+        if (!a.line_L && dist_new < a.radius32) flags |= 1u;
         const bool in_box = (a.n_boxes > 0) && c_in_box<DMAX>(a, rel);
         steps += 1;
         // ---- C6
         CRew r;
-        if (a.make_denser) {
+        if (a.line_L) {
+            // gate (:1856): the state sequence_length transitions back must exist
+            c_line_put<DMAX>(a, i, steps, rel);
+            r.v = (steps >= (uint32_t)a.line_L) ? c_line_reward(a, i, steps) : 0.0;
+            r.is32 = false;
+        } else if (a.make_denser) {
             float relo[DMAX];
             c_gather_rel<DMAX>(a, cur, relo);
             const float dist_old = c_norm_rel<DMAX>(a, relo);
@@ -240,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         } else {
             r.v = (dist_new < a.radius32) ? 1.0 : 0.0;
         }
-        {
+        if (!a.line_L) {
             double acc = 0.0;
 #pragma unroll
             for (int d = 0; d < DMAX; d++)
@@ -250,7 +424,12 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             r.is32 = true;
         }
         // ---- C7
-        if (a.delay > 0) {
+        if (a.delay > 0 && a.line_L) {
+            double *slot = a.ring64 + (size_t)(tick % (uint32_t)a.delay) * N + i;
+            const double out = *slot;
+            *slot = r.v;
+            r.v = out;
+        } else if (a.delay > 0) {
             uint32_t *slot = a.ring + (size_t)(tick % (uint32_t)a.delay) * N + i;
             uint32_t bits = *slot;
             *slot = __float_as_uint((float)r.v);
@@ -290,7 +469,13 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
                 c_reset_lane<DMAX, OMAX>(a, sp_pcg, sd, cur, status);
             }
             steps = 0; flags = 0;
-            for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
+            if (a.line_L) {
+                c_gather_rel<DMAX>(a, cur, rel);
+                c_line_put<DMAX>(a, i, 0u, rel);
+                for (int dd = 0; dd < a.delay; dd++) a.ring64[(size_t)dd * N + i] = 0.0;
+            } else {
+                for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
+            }
         }
         // ---- outputs
         float *op = obs + o * D;
@@ -356,6 +541,14 @@ __global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, u
         }
     }
     a.meta[i] = make_uint2(0u, 0u);
+    if (a.line_L) {
+        float rel[DMAX];
+        c_gather_rel<DMAX>(a, cur, rel);
+        c_line_put<DMAX>(a, i, 0u, rel);
+        for (int dd = 0; dd < a.delay; dd++) a.ring64[(size_t)dd * N + i] = 0.0;
+        if (status) atomicOr(&a.status[i], status);
+        return;
+    }
     for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
     if (status) atomicOr(&a.status[i], status);
 }

@@ -86,6 +86,12 @@ struct ContinuousArgs {
     float *cur;                 // [D][N] last returned (noisy, clipped) state
     uint2 *meta;                // {steps, flags: bit0 reached_terminal}
     uint32_t *ring;             // [delay][N] float32 bit patterns (kRingPyZero = Python 0.0)
+    // reward_function move_along_a_line (0 = move_to_a_point): sequence_length, the last line_L states'
+    // relevant coordinates [slot = s % line_L][4][N] (s = transitions made when the state was
+    // reached), and a float64 delay line (these rewards are Python floats)
+    int32_t line_L;
+    float *line_hist;
+    double *ring64;             // [delay][N]
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
     uint32_t *status;
     // ---- precomputed on the host for the fused fast path (mdpp_continuous_fast.hip) ----
@@ -127,6 +133,7 @@ struct mdpp_env {
     // device allocations
     void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
     void *d_state, *d_ring, *d_status;
+    void *d_line_hist, *d_ring64;                             // continuous, move_along_a_line
     void *d_P1, *d_init_cdf1, *d_noise_cdf1, *d_irr_state;   // irrelevant sub-space
     bool irr_ready;
     void *d_sd, *d_cur, *d_meta;

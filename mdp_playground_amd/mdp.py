@@ -149,6 +149,7 @@ class ContinuousMDP(CommonParams):
     box_lo: np.ndarray = None                # float32 [K, n_rel] terminal hypercubes
     box_hi: np.ndarray = None
     image: dict | None = None                # ImageContinuous parameters (width, height, circle_radius), or None
+    reward_function: str = "move_to_a_point"  # or "move_along_a_line" (:1864-1910)
 
 
 @dataclass
@@ -443,15 +444,17 @@ def build_continuous(config) -> ContinuousMDP:
     common = _common(config, "continuous", sd)
     D = config["state_space_dim"]
     rf = config.get("reward_function", "move_to_a_point")
-    if rf != "move_to_a_point":
-        raise NotImplementedError("only reward_function='move_to_a_point' is built (SURVEY.md §8f)")
+    if rf not in ("move_to_a_point", "move_along_a_line"):
+        raise NotImplementedError("reward_function must be 'move_to_a_point' or 'move_along_a_line'")
+    line = rf == "move_along_a_line"
     image = None
     if config.get("image_representations", False):
         # ImageContinuous(feature_space, width, height, term_spaces, target_point, circle_radius=5)
         # (:770-778): RGB, relevant_indices left at its default [0, 1], at most 2 + 2 dimensions
         image = dict(width=config.get("image_width", 100), height=config.get("image_height", 100),
                      circle_radius=5)
-    _require(common["sequence_length"] == 1, "move_to_a_point needs sequence_length == 1")
+    if not line:
+        _require(common["sequence_length"] == 1, "move_to_a_point needs sequence_length == 1")   # :643
     if config.get("irrelevant_features", False):
         _require("relevant_indices" in config,
                  "Please provide dimensions of state space relevant to rewards.")
@@ -459,7 +462,15 @@ def build_continuous(config) -> ContinuousMDP:
     if image is not None and (D not in (2, 4) or len(rel) != 2):
         raise NotImplementedError("ImageContinuous observations: 2 relevant dimensions, and 2 or 4 state "
                                   "dimensions in all (the reference's picture is built from dims [0, 1] and [2, 3])")
-    if "target_point" in config:
+    if line:
+        # :1864-1910: the fit runs on the device for up to 4 relevant dimensions (a 4x4 scatter matrix
+        # kept in registers) and up to 64 states; no target, no target latch (:1719)
+        if len(rel) > 4 or common["sequence_length"] > 64:
+            raise NotImplementedError("move_along_a_line: at most 4 relevant dimensions and sequence_length <= 64")
+        if image is not None:
+            raise NotImplementedError("move_along_a_line with image observations is not built")
+        target = np.zeros(len(rel), dtype=np.float32)
+    elif "target_point" in config:
         target = np.array(config["target_point"], dtype=np.float32)
         _require(target.shape == (len(rel),),
                  "target_point should have dimensionality = relevant_state_space dimensionality")
@@ -492,7 +503,7 @@ def build_continuous(config) -> ContinuousMDP:
         make_denser=config.get("make_denser", True),
         action_loss_weight=config.get("action_loss_weight", 0.0),
         transition_noise=None if tn is None else float(tn), box_lo=box_lo, box_hi=box_hi, image=image,
-        **common)
+        reward_function=rf, **common)
 
 
 def build_grid(config) -> GridMDP:

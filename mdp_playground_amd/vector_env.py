@@ -264,6 +264,8 @@ class RLToyVectorEnv:
             # continuous MDPs carry no generated tables: per-env seeds only change the streams
             pass
         cfg.D, cfg.n_rel, cfg.order = m.D, len(m.relevant_indices), m.order
+        if m.reward_function == "move_along_a_line":
+            cfg.reward_function, cfg.L = capi.CREWARD_MOVE_ALONG_A_LINE, m.sequence_length
         for j, r in enumerate(m.relevant_indices):
             cfg.rel_idx[j] = int(r)
             cfg.target[j] = float(m.target_point[j])
@@ -488,7 +490,7 @@ class RLToyVectorEnv:
         if getattr(self, "_image", None) is not None:
             return "k_imagec_obs"
         fast = (self.rng == "numpy" and m.box_lo is None and np.isfinite(m.state_space_max)
-                and m.delay == 0 and m.reward_every_n_steps == 1
+                and m.delay == 0 and m.reward_every_n_steps == 1 and m.reward_function == "move_to_a_point"
                 and list(m.relevant_indices) == list(range(len(m.relevant_indices)))
                 and (m.D, m.order, len(m.relevant_indices)) in
                 {(12, 1, 4), (12, 2, 4), (2, 1, 2), (2, 2, 2), (4, 1, 4), (4, 2, 4), (8, 1, 8), (8, 2, 8),

@@ -355,6 +355,10 @@ struct ora_continuous {
     np_pcg64 env_rng;    /* self._np_random */
     np_pcg64 space_rng;  /* self.feature_space.np_random */
     int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
+    /* reward_function == "move_along_a_line" (:1864-1910) */
+    int line_L;                               /* sequence_length; 0 = move_to_a_point */
+    ora_line_fit_fn line_fit;
+    float lhist[ORA_MAX_LINE][ORA_MAX_DIM];   /* the last line_L states, oldest first */
 };
 
 ora_continuous *ora_c_create(int D, int n_rel, const int32_t *rel_idx, int order,
@@ -446,6 +450,58 @@ static float norm32(const float *x, int n) {
 /* reset(): :2250 ring, :2284-2307 rejection sampling from feature_space
  * (gymnasium Box.sample: uniform(low, high) per bounded dim, normal() when
  * unbounded), :2311-2323 derivatives / history, :2358-2369 counters. */
+/* move_along_a_line (:1864-1910): the last sequence_length states (relevant dimensions, float32)
+ * are fitted with a line through their mean along the first right-singular vector of the centred
+ * data (np.linalg.svd on float32: LAPACK sgesdd -- third-party arithmetic, obtained through the
+ * callback from the same numpy the reference uses, together with the float32 mean); the reward is
+ * minus the mean float64 distance of the points from that line (dist_of_pt_from_line, :2546-2576). */
+void ora_c_set_line_reward(ora_continuous *e, int L, ora_line_fit_fn fit) {
+    e->line_L = (L >= 1 && L <= ORA_MAX_LINE) ? L : 0;
+    e->line_fit = fit;
+}
+
+static void line_push(ora_continuous *e, const float *s) {
+    for (int k = 0; k + 1 < e->line_L; k++) memcpy(e->lhist[k], e->lhist[k + 1], sizeof(float) * e->D);
+    memcpy(e->lhist[e->line_L - 1], s, sizeof(float) * e->D);
+}
+
+/* numpy's scalar `x ** 2` is libm pow(x, 2.0), which is not always the correctly rounded x * x;
+ * called through a volatile pointer so that the compiler does not fold it into a multiplication */
+static double (*volatile libm_pow)(double, double) = pow;
+
+static double line_reward(ora_continuous *e) {
+    const int L = e->line_L, n = e->n_rel, D = e->D;
+    float pts[ORA_MAX_LINE * ORA_MAX_DIM];
+    double mean[ORA_MAX_DIM], v0[ORA_MAX_DIM], ptA[ORA_MAX_DIM], ptB[ORA_MAX_DIM];
+    for (int k = 0; k < L; k++) memcpy(pts + (size_t)k * D, e->lhist[k], sizeof(float) * D);
+    e->line_fit(pts, L, D, mean, v0);        /* float32 values, widened */
+    for (int j = 0; j < n; j++) {             /* vv[0] * linspace(-1, 1, 2)[:, None] + data_mean, float64 */
+        ptA[j] = v0[j] * -1.0 + mean[j];
+        ptB[j] = v0[j] * 1.0 + mean[j];
+    }
+    double total = 0.0;
+    for (int k = 0; k < L; k++) {
+        double ab[ORA_MAX_DIM], ap[ORA_MAX_DIM], dot = 0.0, nab = 0.0, nap = 0.0;
+        for (int j = 0; j < n; j++) {
+            ab[j] = ptA[j] - ptB[j];
+            ap[j] = ptA[j] - (double)pts[(size_t)k * D + e->rel[j]];
+        }
+        /* np.dot / np.linalg.norm on short float64 vectors: OpenBLAS ddot's scalar tail, a chain of
+         * fused multiply-adds (checked against numpy for n <= 8 in tests/test_np_random.py) */
+        for (int j = 0; j < n; j++) { dot = fma(ab[j], ap[j], dot); nab = fma(ab[j], ab[j], nab); nap = fma(ap[j], ap[j], nap); }
+        nab = sqrt(nab);
+        double dist = 0.0;
+        if (!(nab < 1e-13)) {
+            const double proj = dot / nab;
+            double sq = libm_pow(sqrt(nap), 2.0) - libm_pow(proj, 2.0);
+            if (sq < 0) sq = 0;
+            dist = sqrt(sq);
+        }
+        total += dist;
+    }
+    return 0.0 + -total / (double)L;
+}
+
 void ora_c_reset(ora_continuous *e, float *obs) {
     for (int i = 0; i < e->delay; i++) { e->ring[i].v = 0.0; e->ring[i].is32 = 0; }
     const int bounded = isfinite(e->smax);
@@ -462,6 +518,7 @@ void ora_c_reset(ora_continuous *e, float *obs) {
         for (int i = 0; i < e->D; i++) e->sd[k][i] = 0.0f;
     for (int i = 0; i < e->D; i++) { e->sd[0][i] = e->cur[i]; obs[i] = e->cur[i]; }
     e->steps = 0; e->reached = 0;
+    if (e->line_L) line_push(e, e->cur);       /* augmented_state = [NaN]*(len-1) + [curr_state], :2313-2323 */
 }
 
 void ora_c_set_philox(ora_continuous *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
@@ -522,19 +579,24 @@ void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
             for (int i = 0; i < D; i++) e->sd[k][i] = 0.0f;
         for (int i = 0; i < D; i++) e->sd[0][i] = nxt[i];
     }
-    /* C5: :1719-1725 */
-    float dist_new = norm32_rel_minus_target(e, nxt);
-    if (dist_new < e->radius32) e->reached = 1;
+    /* C5: :1719-1725 (the target latch exists for move_to_a_point only) */
+    float dist_new = e->line_L ? 0.0f : norm32_rel_minus_target(e, nxt);
+    if (!e->line_L && dist_new < e->radius32) e->reached = 1;
     e->steps += 1; /* :2058 */
     /* C6: :1912-1945 */
     rew_t r;
-    if (e->make_denser) {
+    if (e->line_L) {
+        /* :1864-1910; gate :1856: the state delay+sequence_length transitions back must exist */
+        line_push(e, nxt);
+        r.v = (e->steps >= e->line_L) ? line_reward(e) : 0.0;
+        r.is32 = 0;
+    } else if (e->make_denser) {
         float dist_old = norm32_rel_minus_target(e, e->cur);
         r.v = (double)(float)(-dist_new + dist_old);
     } else {
         r.v = (dist_new < e->radius32) ? 1.0 : 0.0;
     }
-    {
+    if (!e->line_L) {
         float pen = e->alw32 * norm32(a, D);
         r.v = (double)((float)r.v - pen);
         r.is32 = 1;

@@ -65,6 +65,7 @@ def lib():
                                     i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
         L.ora_c_destroy.argtypes = [vp]
         L.ora_c_set_image_quirk.argtypes = [vp, i32]
+        L.ora_c_set_line_reward.argtypes = [vp, i32, LINE_FIT_FN]
         L.ora_ig_render.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
         L.ora_ic_render.argtypes = [i32, i32, i32, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp]
         L.ora_c_set_rng.argtypes = [vp, vp, vp]
@@ -292,6 +293,11 @@ class GridOracle:
         return obs, rew, done.astype(bool), ro
 
 
+# what the reference's move_along_a_line reward gets from numpy / LAPACK (rl_toy_env.py:1865-1871)
+LINE_FIT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_double),
+                          C.POINTER(C.c_double))
+
+
 class ContinuousOracle:
     def __init__(self, D, relevant_indices, order, inertia, time_unit, state_space_max,
                  action_space_max, target_point, target_radius, make_denser,
@@ -323,6 +329,26 @@ class ContinuousOracle:
     def set_image_quirk(self, on=True):
         """image_representations=True: every step clips and zeroes the derivatives (mdpp_oracle.c C4)."""
         lib().ora_c_set_image_quirk(self.h, int(on))
+
+    def set_line_reward(self, sequence_length, delay=0):
+        """reward_function='move_along_a_line': the float32 mean and the first right-singular vector
+        come from numpy exactly as the reference computes them (rl_toy_env.py:1865-1871: an
+        (augmented_state_length, D) float32 array, rows [1 + delay:], columns relevant_indices, so
+        that the slice has the reference's memory layout and numpy sums it the same way)."""
+        rel = [int(x) for x in self._keep[0]]
+        L, D = int(sequence_length), self.D
+
+        def fit(pts, L_, D_, mean_out, v0_out):
+            states = np.ctypeslib.as_array(pts, shape=(L_ * D_,)).reshape(L_, D_)
+            considered = [np.full(D_, np.nan, np.float32)] * (1 + delay) + [states[k].copy() for k in range(L_)]
+            data_ = np.array(considered, dtype=np.float32)[1 + delay:1 + delay + L_, rel]
+            data_mean = data_.mean(axis=0)
+            uu, dd, vv = np.linalg.svd(data_ - data_mean)
+            for j in range(len(rel)):
+                mean_out[j] = float(data_mean[j])
+                v0_out[j] = float(vv[0][j])
+        self._line_cb = LINE_FIT_FN(fit)             # keep the thunk alive
+        lib().ora_c_set_line_reward(self.h, L, self._line_cb)
 
     def set_rng(self, env_words, space_words):
         a = np.ascontiguousarray(env_words, dtype=np.uint64)

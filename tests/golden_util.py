@@ -78,7 +78,7 @@ def continuous_params(cfg):
         inertia=cfg.get("inertia", 1.0), time_unit=cfg.get("time_unit", 1.0),
         state_space_max=cfg.get("state_space_max", np.inf),
         action_space_max=cfg.get("action_space_max", np.inf),
-        target_point=cfg["target_point"], target_radius=cfg.get("target_radius", 0.05),
+        target_point=cfg.get("target_point", [0.0] * len(rel)), target_radius=cfg.get("target_radius", 0.05),
         make_denser=cfg.get("make_denser", True),
         action_loss_weight=cfg.get("action_loss_weight", 0.0),
         transition_noise=cfg.get("transition_noise"), reward_noise=cfg.get("reward_noise"),
@@ -89,7 +89,11 @@ def continuous_params(cfg):
 
 
 def continuous_oracle_from_golden(name):
-    return ora.ContinuousOracle(**continuous_params(CASES[name]["config"]))
+    cfg = CASES[name]["config"]
+    o = ora.ContinuousOracle(**continuous_params(cfg))
+    if cfg.get("reward_function") == "move_along_a_line":
+        o.set_line_reward(cfg.get("sequence_length", 1), cfg.get("delay", 0))
+    return o
 
 
 def grid_params(cfg):

@@ -110,6 +110,8 @@ def _oracle_for(env, i):
                                  m.target_radius, m.make_denser, m.action_loss_weight,
                                  m.transition_noise, m.reward_noise, m.delay, m.reward_every_n_steps,
                                  m.reward_scale, m.reward_shift, m.term_state_reward, m.box_lo, m.box_hi)
+        if m.reward_function == "move_along_a_line":
+            o.set_line_reward(m.sequence_length, m.delay)
     return o
 
 
@@ -498,6 +500,20 @@ def test_grid_fast_rollout_kernel_vs_oracle(variant):
 
 
 # ----------------------------------------------------------------------------- continuous
+# move_along_a_line: the reference takes the line's direction from LAPACK's float32 SVD, so its reward
+# is only defined up to that library's rounding (its own tests compare with atol=1e-5, see
+# tests/test_mdp_playground.py:60-63); the device computes the direction in float64.  States,
+# terminal flags and everything else stay bit-exact.
+LINE_ATOL = 1e-5
+
+
+def _rewards_match(name, got, exp):
+    cfg = gu.CASES[name]["config"]
+    if cfg.get("reward_function") == "move_along_a_line":
+        return np.allclose(got, exp, rtol=0, atol=LINE_ATOL * cfg.get("reward_scale", 1.0))
+    return np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("name", gu.CONTINUOUS)
 def test_continuous_stepwise_vs_reference_golden(name):
     g = gu.load(name)
@@ -509,7 +525,7 @@ def test_continuous_stepwise_vs_reference_golden(name):
         obs, rew, term, trunc, _ = env.step(a)
         assert np.array_equal(obs.cpu().numpy().view(np.uint32), g["obs"][:, t].view(np.uint32)), (name, t)
         assert np.array_equal(term.cpu().numpy(), g["done"][:, t]), (name, t)
-        assert np.array_equal(rew.cpu().numpy(), g["reward"][:, t].astype(np.float32)), (name, t)
+        assert _rewards_match(name, rew.cpu().numpy(), g["reward"][:, t].astype(np.float32)), (name, t)
         ra = g["reset_after"][:, t]
         if ra.any():
             o, _ = env.reset(mask=torch.as_tensor(ra, device=env.device))
@@ -531,7 +547,55 @@ def test_continuous_fused_rollout_vs_reference_golden(name):
     exp[ra] = g["reset_obs"][ra]
     assert np.array_equal(obs.cpu().numpy().transpose(1, 0, 2).view(np.uint32), exp.view(np.uint32))
     assert np.array_equal(term.cpu().numpy().T, g["done"])
-    assert np.array_equal(rew.cpu().numpy().T, g["reward"].astype(np.float32))
+    assert _rewards_match(name, rew.cpu().numpy().T, g["reward"].astype(np.float32))
+    env.close()
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_continuous_line_reward_1024_envs_vs_oracle(rng):
+    """reward_function move_along_a_line on 1024 envs (5 relevant-of-6 dims would not fit: 3 of 6
+    here), random walks with straight stretches, delay, reward noise, terminal hypercubes, same-step
+    autoreset, fused rollout then single steps; every 9th env against its own oracle instance (which
+    gets mean and singular vector from numpy like the reference).  Everything but the reward is
+    bit-exact; the reward within LINE_ATOL, and within 1e-6 wherever the two largest singular
+    values are not close (the direction is then well-conditioned)."""
+    from oracle import oracle as ora
+    cfg = dict(gu.CASES["c_line_irr"]["config"], seed=21)
+    N, T, T1 = 1024, 60, 6
+    kw = dict(rng="philox", philox_seed=17) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    D = cfg["state_space_dim"]
+    g = np.random.default_rng(8)
+    acts = g.uniform(-1, 1, size=(T + T1, N, D)).astype(np.float32)
+    for t in range(1, T + T1):                      # straight stretches: repeat the previous action
+        keep = (t // 7) % 2 == 1
+        if keep:
+            acts[t] = acts[t - 1]
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts[:T], device=env.device))
+    obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    for t in range(T, T + T1):
+        o1, r1, d1, _, _ = env.step(torch.as_tensor(acts[t], device=env.device))
+        obs = np.concatenate([obs, o1.cpu().numpy()[None]]); rew = np.concatenate([rew, r1.cpu().numpy()[None]])
+        term = np.concatenate([term, d1.cpu().numpy()[None]])
+    worst = 0.0
+    for i in range(0, N, 9):
+        o = _oracle_for(env, i)
+        if rng == "philox":
+            o.set_philox(17, i)
+        else:
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert np.array_equal(o.reset(), init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        exp = eo.copy()
+        exp[ed] = ero[ed]
+        assert np.array_equal(obs[:, i].view(np.uint32), exp.view(np.uint32)), i
+        assert np.array_equal(term[:, i], ed), i
+        diff = np.abs(rew[:, i].astype(np.float64) - er)
+        worst = max(worst, float(diff.max()))
+        assert diff.max() <= LINE_ATOL * cfg["reward_scale"], (i, diff.max())
+        assert np.quantile(diff, 0.99) <= 1e-6, (i, np.quantile(diff, 0.99))
+    print("move_along_a_line: worst |reward - oracle| =", worst)
     env.close()
 
 

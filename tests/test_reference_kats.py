@@ -360,3 +360,21 @@ def test_discrete_custom_P_R_matrices():
     o.reset()
     acts = [4, 4, 2, 3, 4, 2, 4, 1, 0, int(np.random.default_rng(0).integers(5)), 4]
     assert [o.step(a)[1] for a in acts] == [0, 2, 2, 6, 6, 2, 0, 2, 6, 2, 2]
+
+
+def test_continuous_move_along_a_line_straight_walk():
+    """test_mdp_playground.py:31-71: reward_function move_along_a_line, sequence_length 10; twenty
+    steps of action [1, 1, 1, 1] from the seeded start stay on a line (reward 0 within the upstream
+    atol 1e-5) and end at the state upstream lists -- which also pins the unbounded Box's normal
+    sampling in reset()."""
+    cfg = dict(seed={"env": 0, "state_space": 10, "action_space": 11}, state_space_type="continuous",
+               action_space_type="continuous", state_space_dim=4, action_space_dim=4,
+               transition_dynamics_order=1, inertia=1, time_unit=1, delay=0, sequence_length=10,
+               reward_scale=1.0, reward_function="move_along_a_line")
+    m, o, s = _continuous(cfg)
+    assert m.reward_function == "move_along_a_line"
+    o.set_line_reward(m.sequence_length, m.delay)
+    for i in range(20):
+        s, r, _, _ = o.step(np.array([1, 1, 1, 1], np.float32))
+        np.testing.assert_allclose(0.0, r, atol=1e-5, err_msg=f"step {i}")
+    np.testing.assert_allclose(s, np.array([18.896662, 19.274975, 19.218195, 20.266975]), rtol=1e-7)

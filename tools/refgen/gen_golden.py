@@ -201,6 +201,22 @@ CASES = {
                     target_point=[0.0, 0.0], target_radius=0.8, reward_noise=0.1,
                     reward_every_n_steps=2, reward_function="move_to_a_point"),
         seeds=list(range(8)), T=200, reset="mixed"),
+    # --- reward_function move_along_a_line: random actions, then the same
+    # action repeated (the rewards of a straight walk are LAPACK-rounding-sized) -------------------
+    "c_line_4d": dict(       # the env of the reference's test_continuous_dynamics_move_along_a_line
+        config=dict(state_space_type="continuous", state_space_dim=4,
+                    transition_dynamics_order=1, inertia=1, time_unit=1, delay=0,
+                    sequence_length=10, reward_scale=1.0, action_space_max=1,
+                    reward_function="move_along_a_line"),
+        seeds=list(range(4)), T=140, reset="mixed", straight_window=14),
+    "c_line_irr": dict(
+        config=dict(state_space_type="continuous", state_space_dim=6, irrelevant_features=True,
+                    relevant_indices=[1, 3, 4], transition_dynamics_order=2, inertia=1.0,
+                    time_unit=0.5, state_space_max=8, action_space_max=1, delay=2,
+                    sequence_length=5, reward_noise=0.05, reward_scale=2.0, reward_shift=0.5,
+                    terminal_states=[[3.0, 3.0, 3.0]], term_state_edge=9.0, term_state_reward=-1.0,
+                    reward_function="move_along_a_line"),
+        seeds=list(range(4)), T=160, reset="mixed", straight_window=9, bad_action_every=29),
     # --- continuous + ImageContinuous observations: RGB pictures, and the
     # reference's quirk that every step takes the clip-and-zero-derivatives branch -----------------
     "ci_2d": dict(
@@ -357,6 +373,9 @@ def run_case(name, case):
                 D = env.state_space_dim
                 amax = env.action_space_max
                 a = arng.uniform(-amax, amax, D).astype(np.float32)
+                sw = case.get("straight_window")
+                if sw and (t // sw) % 2 == 1 and t % sw != 0:   # second window: repeat the last action
+                    a = r["action"][-1].copy()
                 bae = case.get("bad_action_every")
                 if bae and t % bae == bae - 1:
                     a[int(arng.integers(D))] = np.float32(amax * 1.5)
