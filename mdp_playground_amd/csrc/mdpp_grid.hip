@@ -230,7 +230,6 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
                                                               void *__restrict__ obs, float *__restrict__ reward,
                                                               uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                               void *__restrict__ final_obs) {
-    typedef int i32x2 __attribute__((ext_vector_type(2)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

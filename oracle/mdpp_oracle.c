@@ -471,7 +471,7 @@ static double (*volatile libm_pow)(double, double) = pow;
 
 static double line_reward(ora_continuous *e) {
     const int L = e->line_L, n = e->n_rel, D = e->D;
-    float pts[ORA_MAX_LINE * ORA_MAX_DIM];
+    float pts[ORA_MAX_LINE * ORA_MAX_DIM] = {0};
     double mean[ORA_MAX_DIM], v0[ORA_MAX_DIM], ptA[ORA_MAX_DIM], ptB[ORA_MAX_DIM];
     for (int k = 0; k < L; k++) memcpy(pts + (size_t)k * D, e->lhist[k], sizeof(float) * D);
     e->line_fit(pts, L, D, mean, v0);        /* float32 values, widened */

@@ -1136,6 +1136,81 @@ def test_edge_shapes_and_errors():
     env.close()
 
 
+MAX_DISCRETE = {
+    # S = 255 (the largest state id a history byte holds), 15 independent sets of 17 states
+    "s255": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=255,
+                 action_space_size=17, diameter=15, sequence_length=2, delay=3, reward_density=0.02, seed=1),
+    # L = 7: 8^7 sequence keys, the reward bitmask (256 KiB) stays in HBM; delay 32 = longest shift register
+    "l7": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8,
+               action_space_size=8, sequence_length=7, delay=32, reward_density=0.02,
+               terminal_state_density=0.125, seed=2),
+    # delay 40 > 32: sequence keys wait in the HBM ring instead of the shift register; P-noise on
+    "d40": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=16,
+                action_space_size=16, sequence_length=2, delay=40, transition_noise=0.1,
+                terminal_state_density=0.0625, reward_density=0.5, seed=3),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(MAX_DISCRETE))
+def test_discrete_maximum_sizes_vs_oracle(variant):
+    cfg = MAX_DISCRETE[variant]
+    N, T = 320, 150
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    A = cfg["action_space_size"]
+    acts = np.random.default_rng(4).integers(0, A, size=(T, N)).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
+    obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    paid = 0
+    for i in range(0, N, 9):
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert o.reset() == int(init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        exp = eo.copy()
+        exp[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], exp) and np.array_equal(term[:, i], ed), (variant, i)
+        assert np.array_equal(rew[:, i], er.astype(np.float32)), (variant, i)
+        paid += int((er != 0).sum())
+    assert paid > 0 or variant == "l7"          # (a 7-state sequence is rarely completed by random actions)
+    env.close()
+
+
+def test_continuous_maximum_sizes_vs_oracle():
+    """D = 32 (MDPP_MAX_DIM) with order 2, and order 4 (MDPP_MAX_ORDER) with 8 terminal hypercubes
+    (MDPP_MAX_BOXES), delay 5, both noises."""
+    big = dict(state_space_type="continuous", state_space_dim=32, relevant_indices=list(range(0, 32, 4)),
+               irrelevant_features=True, target_point=[0.5] * 8, target_radius=0.4, state_space_max=6,
+               action_space_max=1, transition_dynamics_order=2, inertia=1.5, time_unit=0.5, make_denser=True,
+               reward_function="move_to_a_point", reward_noise=0.1, delay=5, seed=4)
+    boxes = dict(state_space_type="continuous", state_space_dim=3, target_point=[0.0, 0.0, 0.0],
+                 target_radius=0.3, state_space_max=4, action_space_max=1, transition_dynamics_order=4,
+                 inertia=1.0, time_unit=0.7, make_denser=False, reward_function="move_to_a_point",
+                 transition_noise=0.02, terminal_states=[[x, y, z] for x in (-2.5, 2.5) for y in (-2.5, 2.5)
+                                                         for z in (-2.5, 2.5)],
+                 term_state_edge=2.0, term_state_reward=-2.0, reward_scale=0.5, seed=5)
+    for cfg in (big, boxes):
+        N, T, D = 192, 80, cfg["state_space_dim"]
+        env = _venv(num_envs=N, autoreset="same_step", **cfg)
+        acts = np.random.default_rng(9).uniform(-1, 1, size=(T, N, D)).astype(np.float32)
+        init = env._obs.cpu().numpy().copy()
+        obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
+        obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+        for i in range(0, N, 11):
+            o = _oracle_for(env, i)
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+            assert np.array_equal(o.reset(), init[i])
+            eo, er, ed, ero = o.rollout(acts[:, i], None)
+            exp = eo.copy()
+            exp[ed] = ero[ed]
+            assert np.array_equal(obs[:, i].view(np.uint32), exp.view(np.uint32)), (D, i)
+            assert np.array_equal(term[:, i], ed), (D, i)
+            assert np.array_equal(rew[:, i], er.astype(np.float32)), (D, i)
+        env.close()
+
+
 def test_device_normals_match_numpy_stream():
     """The device ziggurat (chord/tangent pre-test + exp fallback) makes numpy's decisions: the
     reward-noise stream of 4096 envs x 400 steps (1.6 M normals incl. wedge and tail cases) is
