@@ -97,6 +97,7 @@ __device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint
 // the 4x4 float64 scatter matrix (40 normalised squarings: B <- B B / tr), rounded to float32 like
 // LAPACK's output.  The two agree to float32 rounding divided by the gap between the two largest
 // singular values, which is the accuracy the reference's own reward has.
+template <bool CACHED>
 __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i, uint32_t steps) {
     const int L = a.line_L, n = a.n_rel;
     const size_t N = (size_t)a.N;
@@ -109,6 +110,19 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
         for (int j = 0; j < 4; j++) x[j] = (j < n) ? a.line_hist[((size_t)slot * 4 + j) * N + i] : 0.0f;
         slot = (slot + 1u == (uint32_t)L) ? 0u : slot + 1u;
     };
+    // CACHED (L <= 16): all points are fetched up front into registers -- 64 loads in flight instead
+    // of one L2 round trip per point in each of the two passes (points beyond L repeat the newest)
+    constexpr int kCache = 16;
+    float px[CACHED ? kCache : 1][4];
+    if (CACHED) {
+#pragma unroll
+        for (int k = 0; k < kCache; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) px[k][j] = (j < n) ? a.line_hist[((size_t)slot * 4 + j) * N + i] : 0.0f;
+            const uint32_t nx = (slot + 1u == (uint32_t)L) ? 0u : slot + 1u;
+            slot = (k + 1 < L) ? nx : slot;
+        }
+    }
     // One pass over the points: (1) data_.mean(axis=0) the way numpy sums a contiguous float32 column
     // (pairwise routine: 8 running sums while 8 more points are left, a fixed tree, the rest one by
     // one; plain left-to-right below 8 points), divided by L in float32; (2) float64 raw moments for
@@ -118,40 +132,63 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
     for (int p = 0; p < 4; p++)
 #pragma unroll
         for (int q = 0; q < 4; q++) m[p][q] = 0.0;
-    auto moments = [&]() __attribute__((always_inline)) {
+    auto moments = [&](const float (&y)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            s1[p] += (double)x[p];
+            s1[p] += (double)y[p];
 #pragma unroll
-            for (int q = p; q < 4; q++) m[p][q] = fma((double)x[p], (double)x[q], m[p][q]);
+            for (int q = p; q < 4; q++) m[p][q] = fma((double)y[p], (double)y[q], m[p][q]);
         }
     };
     float mean[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int k = 0;
-    if (L >= 8) {
+    if (CACHED) {
         float r[8][4];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            next_pt(); moments();
+        for (int q = 0; q < 8; q++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) r[q][j] = x[j];
-        }
-        for (k = 8; k < L - (L % 8); k += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                next_pt(); moments();
-#pragma unroll
-                for (int j = 0; j < 4; j++) r[q][j] += x[j];
-            }
-        }
+            for (int j = 0; j < 4; j++) r[q][j] = (L == kCache) ? px[q][j] + px[8 + q][j] : px[q][j];
+        const int tail0 = (L < 8) ? 0 : (L == kCache ? kCache : 8);      // first point summed one by one
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            mean[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
-    }
-    for (; k < L; k++) {
-        next_pt(); moments();
+            mean[j] = (L < 8) ? 0.0f
+                              : ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
 #pragma unroll
-        for (int j = 0; j < 4; j++) mean[j] += x[j];
+        for (int k = 0; k < kCache; k++) {
+            if (k < L) {                                   // (wave-uniform)
+                moments(px[k]);
+                if (k >= tail0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mean[j] += px[k][j];
+                }
+            }
+        }
+    } else {
+        int k = 0;
+        if (L >= 8) {
+            float r[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                next_pt(); moments(x);
+#pragma unroll
+                for (int j = 0; j < 4; j++) r[q][j] = x[j];
+            }
+            for (k = 8; k < L - (L % 8); k += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    next_pt(); moments(x);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) r[q][j] += x[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                mean[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
+        }
+        for (; k < L; k++) {
+            next_pt(); moments(x);
+#pragma unroll
+            for (int j = 0; j < 4; j++) mean[j] += x[j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) mean[j] = (j < n) ? mean[j] / (float)L : 0.0f;
@@ -224,15 +261,12 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
 #pragma unroll
     for (int j = 0; j < 4; j++) if (j < n) nab = fma(ab[j], ab[j], nab);    // np.dot: a chain of FMAs
     nab = sqrt(nab);
-    double total = 0.0;
-    slot = slot0;
-    for (int kk = 0; kk < L; kk++) {
+    auto dist_of = [&](const float (&y)[4]) __attribute__((always_inline)) -> double {
         double dot = 0.0, nap = 0.0;
-        next_pt();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j < n) {
-                const double ap = ptA[j] - (double)x[j];
+                const double ap = ptA[j] - (double)y[j];
                 dot = fma(ab[j], ap, dot);
                 nap = fma(ap, ap, nap);
             }
@@ -244,7 +278,19 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
             sq = sq < 0.0 ? 0.0 : sq;
             dist = sqrt(sq);
         }
-        total += dist;
+        return dist;
+    };
+    double total = 0.0;
+    if (CACHED) {
+#pragma unroll
+        for (int k = 0; k < kCache; k++)
+            if (k < L) total += dist_of(px[k]);
+    } else {
+        slot = slot0;
+        for (int kk = 0; kk < L; kk++) {
+            next_pt();
+            total += dist_of(x);
+        }
     }
     return 0.0 + -total / (double)L;
 }
@@ -404,7 +450,9 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         if (a.line_L) {
             // gate (:1856): the state sequence_length transitions back must exist
             c_line_put<DMAX>(a, i, steps, rel);
-            r.v = (steps >= (uint32_t)a.line_L) ? c_line_reward(a, i, steps) : 0.0;
+            r.v = 0.0;
+            if (steps >= (uint32_t)a.line_L)
+                r.v = a.line_L <= 16 ? c_line_reward<true>(a, i, steps) : c_line_reward<false>(a, i, steps);
             r.is32 = false;
         } else if (a.make_denser) {
             float relo[DMAX];
