@@ -14,6 +14,19 @@
 //   * what is left in the queue at the end of the launch is un-drawn (inverse LCG step), so the
 //     env stream is again exactly where the reference's would be.  Nothing else reads the env
 //     stream on this path (no reward noise), so the draws are consumed in stream order.
+// DUO: one wavefront per SIMD -- all a 65 536-env job gives a lane-per-env kernel -- leaves about
+// half of the SIMD's issue slots idle (profiles/r01_ablation_fast_kernel.txt).  With full 256-env
+// blocks and K >= 32 the step is therefore split over TWO waves per SIMD (512-thread workgroups),
+// like k_discrete_rollout_pipe does for the packed shapes:
+//   E  waves 0-3  state recurrence of both sub-spaces, sequence key, episode counters, terminal
+//                 test, same-step autoreset from the queue, the env's PCG64 stream; one 64-bit
+//                 record per env step into an LDS ring
+//   O  waves 4-7  reward-bitmask lookup, delay line, reward select and ALL global stores
+//   H  waves 8-11 (ROLES = 3, autoreset on) own the env's PCG64 stream for the launch and keep a small
+//                 LDS ring of pre-drawn start states filled; what the E lane did not take is un-drawn
+// Lane l of waves w, w + 4 (and w + 8) serves the same env; the rings are single-producer /
+// single-consumer with release / acquire counters at workgroup scope, polled once per 8 steps,
+// every spin bounded (MDPP_STATUS_INTERNAL instead of a hang).
 #include <stdlib.h>
 
 #include "mdpp_internal.hpp"
@@ -23,9 +36,17 @@ namespace mdpp {
 
 constexpr int kQQ = 4;                         // start states queued per lane
 constexpr int kQRsrc = 0x00020000;
+constexpr int kQDepth = 24;                    // E -> O ring depth in steps (multiple of the chunk of 8)
+constexpr uint32_t kQSpinLimit = 1u << 22;
+constexpr uint32_t kQStatusInternal = 0x80000000u;
 
-template <bool OBS64, bool IRR>
-__global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
+// record (E -> O), one per env step
+//   lo: [7:0] observation (after a possible reset)  [15:8] state reached  [23:16] irrelevant obs  [31:24] irrelevant reached
+//   hi: [0] terminated  [1] truncated  [2] reset happened  [3] history full (NaN gate)  [4] pay step  [31:5] sequence key
+// start states H -> E: one 64-bit word per env, three 16-bit entries (rel | irr << 8) and, in the top
+// 16 bits, the number of entries pushed so far (mod 2^16); E answers with the number it has taken
+template <bool OBS64, bool IRR, int ROLES>
+__global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
@@ -34,21 +55,29 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ float s_rsel[4];
+    __shared__ uint32_t s_prod[kBlock / 64], s_cons[kBlock / 64];   // steps published by E wave w / consumed by O wave w
+    __shared__ __align__(8) uint64_t s_start[ROLES == 3 ? kBlock : 1];   // H -> E
+    __shared__ uint32_t s_head[ROLES == 3 ? kBlock : 1];                 // E -> H
+    __shared__ uint32_t s_done;                                         // E waves that have finished
+    constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
+    constexpr int kThreads = ROLES * kBlock;
     const int tid = threadIdx.x;
+    const int role = DUO ? tid / kBlock : 0;        // 0 = E, 1 = O, 2 = H
+    const int l = DUO ? (tid & (kBlock - 1)) : tid, w = l >> 6;
     // shared MDP -> LDS (same carve as k_discrete_step) + the irrelevant sub-space's table and cdf
-    for (int k = tid; k < a.S * a.A; k += kBlock) lds[a.lds_P + k] = a.P[k];
-    for (int k = tid; k < a.S; k += kBlock) lds[a.lds_term + k] = a.is_term[k];
-    for (uint32_t k = tid; k < a.rbits_stride; k += kBlock) lds[a.lds_rew + k] = a.rbits[k];
+    for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
+    for (int k = tid; k < a.S; k += kThreads) lds[a.lds_term + k] = a.is_term[k];
+    for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k];
     // rho_0 as integer thresholds: cdf[j] <= u  <=>  ceil(cdf[j] * 2^53) <= r >> 11 (exact: u is
     // (r >> 11) * 2^-53), padded to a multiple of 8 with 2^64-1 so the search runs in unrolled blocks
     const uint32_t lds_P1 = a.lds_bytes, lds_T0 = (a.lds_bytes + (IRR ? (uint32_t)(a.S1 * a.A1) : 0u) + 15u) & ~15u;
     const uint32_t S8 = ((uint32_t)a.S + 7u) & ~7u, S18 = IRR ? (((uint32_t)a.S1 + 7u) & ~7u) : 0u;
     const uint32_t lds_T1 = lds_T0 + S8 * 8u;
-    for (uint32_t k = tid; k < S8; k += kBlock)
+    for (uint32_t k = tid; k < S8; k += kThreads)
         ((uint64_t *)(lds + lds_T0))[k] = k < (uint32_t)a.S ? (uint64_t)ceil(a.init_cdf[k] * 9007199254740992.0) : ~0ULL;
     if (IRR) {
-        for (int k = tid; k < a.S1 * a.A1; k += kBlock) lds[lds_P1 + k] = a.P1[k];
-        for (uint32_t k = tid; k < S18; k += kBlock)
+        for (int k = tid; k < a.S1 * a.A1; k += kThreads) lds[lds_P1 + k] = a.P1[k];
+        for (uint32_t k = tid; k < S18; k += kThreads)
             ((uint64_t *)(lds + lds_T1))[k] = k < (uint32_t)a.S1 ? (uint64_t)ceil(a.init_cdf1[k] * 9007199254740992.0) : ~0ULL;
     }
     if (tid < 4) {
@@ -59,12 +88,17 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
         if (tid & 1) r += a.term_add;
         s_rsel[tid] = (float)r;
     }
+    if (tid < kBlock / 64) { s_prod[tid] = 0; s_cons[tid] = 0; }
+    if (TRIO && tid < kBlock) { s_start[tid] = 0; s_head[tid] = 0; }
+    if (tid == 0) s_done = 0;
     __syncthreads();
+    // DUO: the record ring follows the tables in dynamic LDS
+    uint64_t *ring = (uint64_t *)(lds + ((lds_T1 + S18 * 8u + 15u) & ~15u));
     const uint8_t *P = lds + a.lds_P, *is_term = lds + a.lds_term, *rbits = lds + a.lds_rew, *P1 = lds + lds_P1;
     const uint64_t *T0 = (const uint64_t *)(lds + lds_T0), *T1 = (const uint64_t *)(lds + lds_T1);
 
-    const uint32_t i = blockIdx.x * kBlock + tid;
-    if (i >= (uint32_t)a.N) return;
+    const uint32_t i = blockIdx.x * kBlock + l;
+    if (!DUO && i >= (uint32_t)a.N) return;            // (DUO launches have full blocks only)
     const uint32_t N = (uint32_t)a.N, S = (uint32_t)a.S, A = (uint32_t)a.A, L = (uint32_t)a.L;
     const uint4 st = a.state[i];
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
@@ -119,7 +153,75 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
     };
     const bool autoreset = a.autoreset != 0, has_max = a.max_steps > 0;
     const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n, delay = (uint32_t)a.delay;
-    if (autoreset) refill();
+    const bool isE = !DUO || role == 0;
+    // =============================================================== H: start-state producer
+    if (TRIO && role == 2) {
+        uint64_t vals = 0;
+        uint32_t tail = 0, slot = 0;
+        for (;;) {
+            if (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == kBlock / 64) break;
+            const uint32_t head = __hip_atomic_load(&s_head[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t cnt = (tail - head) & 0xFFFFu;
+            const bool want = autoreset && cnt < 3u;
+            const uint64_t bw = __builtin_amdgcn_ballot_w64(want);
+            const bool urgent = __builtin_amdgcn_ballot_w64(want && cnt <= 1u) != 0;
+            if (__builtin_popcountll(bw) >= 16 || urgent) {
+                if (want) {
+                    const uint64_t c = draw_state();
+                    const uint32_t sh = slot * 16u;
+                    vals = (vals & ~(0xFFFFull << sh)) | (c << sh);
+                    slot = slot == 2u ? 0u : slot + 1u;
+                    tail = (tail + 1u) & 0xFFFFu;
+                    __hip_atomic_store(&s_start[l], vals | ((uint64_t)tail << 48), __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        // un-draw what the env lane did not use (its final count is net of what sat in its registers)
+        const uint32_t head = __hip_atomic_load(&s_head[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (uint32_t q = ((tail - head) & 0xFFFFu) * (IRR ? 2u : 1u); q > 0; q--) {
+            const uint64_t lo = g.s_lo - g.inc_lo;
+            const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
+            g.s_lo = lo * a.minv_lo;
+            g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+        }
+        g.store(a.env_s, i);
+        return;
+    }
+    // E's side of the start-state ring
+    uint32_t head16 = 0, hslot = 0;
+    auto pull = [&]() __attribute__((always_inline)) {
+        const uint64_t rt = __hip_atomic_load(&s_start[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t avail = ((uint32_t)(rt >> 48) - head16) & 0xFFFFu;
+        const uint32_t room = (uint32_t)kQQ - qn;
+        const uint32_t take = avail < room ? avail : room;
+#pragma unroll
+        for (uint32_t t = 0; t < 3; t++) {
+            if (t < take) {
+                const uint32_t e = (uint32_t)(rt >> (16u * hslot)) & 0xFFFFu;
+#pragma unroll
+                for (int q = 0; q < kQQ; q++) queue[q] = (qn == (uint32_t)q) ? e : queue[q];
+                qn++;
+                hslot = hslot == 2u ? 0u : hslot + 1u;
+            }
+        }
+        head16 = (head16 + take) & 0xFFFFu;
+        __hip_atomic_store(&s_head[l], head16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // every lane must hold a start state before a step may end its episode
+    auto ensure_start = [&]() __attribute__((always_inline)) {
+        if (!TRIO) { refill(); return; }
+        uint32_t spins = 0;
+        while (__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0) {
+            pull();
+            if (__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kQSpinLimit) { status |= kQStatusInternal; qn = 1; break; }
+        }
+    };
+    if (autoreset && isE && !TRIO) refill();
     uint32_t phase = steps % every_n;
 
     // rewards of the unit path: s_rsel[(paid << 1) | terminal], filled above.  An LDS table on
@@ -153,13 +255,10 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
             else __builtin_amdgcn_raw_buffer_store_b32(s0, rs, vobs, so * row_obs, 0);
         }
     };
-    u32x2 pre[kPre];
-#pragma unroll
-    for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
 
-    auto step = [&](const int k, const u32x2 act2) __attribute__((always_inline)) {
-        // every lane must hold a start state before the step may end its episode
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) refill();
+    // ---- E: one step of the state recurrence -> record
+    auto stepE = [&](const u32x2 act2) __attribute__((always_inline)) -> uint64_t {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
         int action = (int)act2.x;
         action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
         const bool bad = action < 0 || action >= (int)A;
@@ -172,14 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
         valid = min(valid + 1u, L + 1u);
         steps += 1;
         phase = (phase + 1 >= every_n) ? 0u : phase + 1;
-        uint32_t bit = (rbits[key >> 3] >> (key & 7u)) & 1u;
-        bit = valid > L ? bit : 0u;                                          // NaN gate: fewer than L transitions yet
-        const uint32_t outb = (ringbits >> ((delay - 1u) & 31u)) & 1u;      // D5 (shift register)
-        ringbits = delay > 0 ? ((ringbits << 1) | bit) : ringbits;
-        bit = delay > 0 ? outb : bit;
-        bit = phase != 0 ? 0u : bit;                                         // D6
         const bool done = is_term[nxt] != 0;                                 // D7
-        const float rout = s_rsel[(bit << 1) | (done ? 1u : 0u)];
         uint32_t bad1 = 0;
         if (IRR) {                                                           // :2063-2082
             int action1 = (int)act2.y;
@@ -191,10 +283,9 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
         status |= (bad || bad1) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
         const bool tr = has_max && steps >= max_steps;
         const bool need = autoreset && (done || tr);
-        const uint32_t so = (uint32_t)k;
-        if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
-            if (need) put_obs(r_fin, so, nxt, cur1);
-        }
+        uint32_t hi = (done ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |
+                      (phase == 0 ? 16u : 0u) | (key << 5);
+        uint32_t lo = (nxt << 8) | (cur1 << 24);
         // reset(): pop the next queued start state where the episode ended (:2250-2278)
         const uint32_t s0 = queue[0] & 0xFFu, s1 = queue[0] >> 8;
 #pragma unroll
@@ -205,38 +296,134 @@ __global__ __launch_bounds__(kBlock) void k_discrete_rollout_quiet(DiscreteArgs 
         valid = need ? 1u : valid;
         steps = need ? 0u : steps;
         phase = need ? 0u : phase;
-        ringbits = need ? 0u : ringbits;
         if (IRR) cur1 = need ? s1 : cur1;
-        put_obs(r_obs, so, need ? s0 : nxt, cur1);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so * N, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so * N, 0);
+        lo |= (need ? s0 : nxt) | (cur1 << 16);
+        return ((uint64_t)hi << 32) | lo;
     };
-    const int nfull = K / kPre;
-    for (int c = 0; c < nfull; c++) {
+    // ---- O: record -> reward, delay line, all global stores of step `so`
+    auto emitO = [&](const uint64_t rec, const uint32_t so) __attribute__((always_inline)) {
+        const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+        const uint32_t k2 = hi >> 5;
+        uint32_t bit = (rbits[k2 >> 3] >> (k2 & 7u)) & 1u;
+        bit = (hi & 8u) ? bit : 0u;                                          // NaN gate: fewer than L transitions yet
+        const uint32_t outb = (ringbits >> ((delay - 1u) & 31u)) & 1u;      // D5 (shift register)
+        ringbits = delay > 0 ? ((ringbits << 1) | bit) : ringbits;
+        bit = delay > 0 ? outb : bit;
+        bit = (hi & 16u) ? bit : 0u;                                         // D6
+        const uint32_t done = hi & 1u;
+        const float rout = s_rsel[(bit << 1) | done];
+        const bool need = (hi & 4u) != 0;
+        if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
+            if (need) put_obs(r_fin, so, (lo >> 8) & 0xFFu, lo >> 24);
+        }
+        ringbits = need ? 0u : ringbits;
+        put_obs(r_obs, so, lo & 0xFFu, (lo >> 16) & 0xFFu);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so * N, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((hi >> 1) & 1u), r_trunc, v1, so * N, 0);
+    };
+
+    if (!DUO) {
+        u32x2 pre[kPre];
 #pragma unroll
-        for (int u = 0; u < kPre; u++) {
-            const u32x2 act = pre[u];
-            pre[u] = load_act(c * kPre + kPre + u);
-            step(c * kPre + u, act);
+        for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
+        const int nfull = K / kPre;
+        for (int c = 0; c < nfull; c++) {
+#pragma unroll
+            for (int u = 0; u < kPre; u++) {
+                const u32x2 act = pre[u];
+                pre[u] = load_act(c * kPre + kPre + u);
+                emitO(stepE(act), (uint32_t)(c * kPre + u));
+            }
+        }
+        for (int k = nfull * kPre; k < K; k++) {
+            u32x2 act = pre[0];
+#pragma unroll
+            for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
+            emitO(stepE(act), (uint32_t)k);
+        }
+    } else if (role == 0) {
+        // -------------------------------------------------------------- E waves
+        u32x2 pre[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
+        const int nchunks = (K + kPre - 1) / kPre;
+        for (int c = 0; c < nchunks; c++) {
+            const int kbase = c * kPre;
+            if (kbase + kPre > kQDepth) {               // stay within the ring: at most kQDepth - 8 steps ahead of O
+                const uint32_t must = (uint32_t)(kbase + kPre - kQDepth);
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&s_cons[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < must) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kQSpinLimit) { status |= kQStatusInternal; break; }
+                }
+            }
+            if (TRIO && autoreset) pull();
+            if (kbase + kPre <= K) {
+#pragma unroll
+                for (int u = 0; u < kPre; u++) {
+                    const u32x2 act = pre[u];
+                    pre[u] = load_act(kbase + kPre + u);
+                    ring[((kbase + u) % kQDepth) * kBlock + l] = stepE(act);
+                }
+            } else {
+                for (int k = kbase; k < K; k++) {
+                    u32x2 act = pre[0];
+#pragma unroll
+                    for (int u = 1; u < kPre; u++) act = (k - kbase == u) ? pre[u] : act;
+                    ring[(k % kQDepth) * kBlock + l] = stepE(act);
+                }
+            }
+            if ((l & 63) == 0)
+                __hip_atomic_store(&s_prod[w], (uint32_t)min(kbase + kPre, K), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        // -------------------------------------------------------------- O waves
+        const int nchunks = (K + kPre - 1) / kPre;
+        for (int c = 0; c < nchunks; c++) {
+            const int kbase = c * kPre;
+            const uint32_t upto = (uint32_t)min(kbase + kPre, K);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&s_prod[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kQSpinLimit) { status |= kQStatusInternal; break; }
+            }
+            if (kbase + kPre <= K) {
+                uint64_t rec[kPre];
+#pragma unroll
+                for (int u = 0; u < kPre; u++) rec[u] = ring[((kbase + u) % kQDepth) * kBlock + l];
+#pragma unroll
+                for (int u = 0; u < kPre; u++) emitO(rec[u], (uint32_t)(kbase + u));
+            } else {
+                for (int k = kbase; k < K; k++) emitO(ring[(k % kQDepth) * kBlock + l], (uint32_t)k);
+            }
+            if ((l & 63) == 0)
+                __hip_atomic_store(&s_cons[w], upto, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    for (int k = nfull * kPre; k < K; k++) {
-        u32x2 act = pre[0];
-#pragma unroll
-        for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
-        step(k, act);
+    if (TRIO && role == 0) {
+        // tell H how many of its start states were really used, then that this wave is through
+        __hip_atomic_store(&s_head[l], (head16 - qn) & 0xFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((l & 63) == 0) __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (IRR) a.irr_state[i] = cur1;
+    } else if (isE) {
+        // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128)
+        for (uint32_t q = qn * (IRR ? 2u : 1u); q > 0; q--) {
+            const uint64_t lo = g.s_lo - g.inc_lo;
+            const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
+            g.s_lo = lo * a.minv_lo;
+            g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+        }
+        g.store(a.env_s, i);
+        if (IRR) a.irr_state[i] = cur1;
     }
-    // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128)
-    for (uint32_t q = qn * (IRR ? 2u : 1u); q > 0; q--) {
-        const uint64_t lo = g.s_lo - g.inc_lo;
-        const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
-        g.s_lo = lo * a.minv_lo;
-        g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+    if (!DUO) {
+        a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps, ringbits);
+    } else {
+        uint32_t *st32 = (uint32_t *)&a.state[i];
+        if (role == 0) { st32[0] = (uint32_t)hist; st32[1] = (uint32_t)(hist >> 32); st32[2] = steps; }
+        else st32[3] = ringbits;                        // the delay line belongs to the O lane
     }
-    g.store(a.env_s, i);
-    a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps, ringbits);
-    if (IRR) a.irr_state[i] = cur1;
     if (status) atomicOr(&a.status[i], status);
 }
 
@@ -252,9 +439,21 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     lds = ((lds + (a.irr ? (size_t)a.S1 * a.A1 : 0) + 15) & ~(size_t)15) + (size_t)((a.S + 7) & ~7) * 8 +
           (a.irr ? (size_t)((a.S1 + 7) & ~7) * 8 : 0);
     if (lds > 60 * 1024) return false;
+    // two waves per SIMD (E / O roles) when the blocks are full, the rollout is long enough to fill
+    // the ring, and tables + ring fit the 64 KiB a workgroup gets without opting in to more
+    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + (size_t)kQDepth * kBlock * 8;
+    const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo + 4096 <= 64 * 1024 && !getenv("MDPP_NO_DUO");
+    const bool trio = duo && a.autoreset && !getenv("MDPP_NO_TRIO");
     const int grid = (a.N + kBlock - 1) / kBlock;
-#define MDPP_Q_LAUNCH(O64, IR) hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR>), dim3(grid), dim3(kBlock), lds, s, a, K, \
-                                                  actions, obs, reward, term, trunc, final_obs)
+#define MDPP_Q_LAUNCH(O64, IR)                                                                                    \
+    do {                                                                                                          \
+        if (trio) hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR, 3>), dim3(grid), dim3(3 * kBlock),        \
+                                     lds_duo, s, a, K, actions, obs, reward, term, trunc, final_obs);             \
+        else if (duo) hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR, 2>), dim3(grid), dim3(2 * kBlock),    \
+                                         lds_duo, s, a, K, actions, obs, reward, term, trunc, final_obs);         \
+        else hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR, 1>), dim3(grid), dim3(kBlock), lds, s, a,      \
+                                K, actions, obs, reward, term, trunc, final_obs);                                 \
+    } while (0)
     if (a.irr) { if (a.obs_i32) MDPP_Q_LAUNCH(false, true); else MDPP_Q_LAUNCH(true, true); }
     else { if (a.obs_i32) MDPP_Q_LAUNCH(false, false); else MDPP_Q_LAUNCH(true, false); }
 #undef MDPP_Q_LAUNCH
