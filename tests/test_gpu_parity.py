@@ -187,7 +187,7 @@ def test_discrete_custom_matrices_2048_envs_vs_oracle(name, rng):
 QUIET = {
     "s20_l4_d3": (dict(state_space_size=20, action_space_size=20, sequence_length=4, delay=3,
                        reward_every_n_steps=2, reward_density=0.02, reward_scale=1.5, reward_shift=-0.25,
-                       term_state_reward=2.0), {}, 1000),
+                       term_state_reward=2.0), {}, 1024),          # full blocks: three roles (E / O / H waves)
     "diam2_s24_l3": (dict(state_space_size=24, action_space_size=12, diameter=2, sequence_length=3, delay=0,
                           terminal_state_density=0.25), {}, 777),
     "irr_8x5": (dict(state_space_size=[8, 5], action_space_size=[8, 5], irrelevant_features=True, delay=2,
@@ -195,7 +195,7 @@ QUIET = {
     "irr_i32_horizon": (dict(state_space_size=[6, 9], action_space_size=[6, 9], irrelevant_features=True,
                              sequence_length=1, dtype_s=np.int32), dict(max_episode_steps=7), 512),
     "s32_noreset": (dict(state_space_size=32, action_space_size=32, sequence_length=2, delay=1, reward_density=0.05),
-                    dict(autoreset="disabled"), 300),
+                    dict(autoreset="disabled"), 512),           # full blocks, no autoreset: two roles (E / O)
 }
 
 
@@ -203,8 +203,9 @@ QUIET = {
 def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
     """k_discrete_rollout_quiet (quiet discrete shapes beyond the specialised kernels: larger S and
     L, diameter 2, irrelevant sub-space): every 7th env against its oracle over launches of
-    different lengths — short ones go to the general kernel, long ones to the quiet kernel, on the
-    same state — incl. terminal observations and the env generator's state after every launch (the
+    different lengths — short ones go to the general kernel, long ones to the quiet kernel (one role
+    for ragged batches, two or three roles on full 256-env blocks), on the same state — incl.
+    terminal observations and the env generator's state after every launch (the
     queue of pre-drawn start states must be un-drawn exactly)."""
     from mdp_playground_amd import _capi as capi
     cfg_extra, env_kw, N = QUIET[variant]
