@@ -42,6 +42,7 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // step's instructions (profiles/r01_rng_microbench.txt) and one wave per SIMD leaves issue slots
 // idle, so running it beside the integrator nearly halves the step time.  Producer and consumer
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
+// The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
 constexpr uint32_t kCSpinLimit = 1u << 22;
 constexpr uint32_t kCStatusInternal = 0x80000000u;
@@ -75,6 +76,88 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         Pcg64 hg;
         hg.load(a.env_s, a.env_inc, i);
         uint32_t hstatus = 0;
+        if (a.park) {
+            // Lanes of a producer wave are allowed to drift apart by up to kNRing steps.  Every
+            // iteration makes ONE fast ziggurat attempt for every lane that is not parked (98.8 % of
+            // them succeed: one LDS store, next draw); a lane whose attempt fell outside its layer's
+            // rectangle is PARKED with its 64-bit word until kPark lanes wait (or the consumer does),
+            // and then the wedge / tail path -- an extra uniform, exp or log1p -- runs once for all of
+            // them (checked once per four attempts).  In lockstep, 54 % of a wave's draws have some lane on that path and all 64 pay
+            // for it (profiles/r01_rng_microbench.txt).  Per lane the stream is consumed in exactly
+            // numpy's order: a parked lane draws nothing until its own slow path has run.
+            constexpr uint32_t kPark = 5;            // 3-6 measure the same; 16 stalls the leading lanes at the ring limit
+            const uint32_t nd = (a.has_p_noise ? (uint32_t)D : 0u) + (a.has_r_noise ? 1u : 0u);
+            uint32_t kl = 0, jl = 0, pub = 0;        // this lane's step / draw within the step; steps published
+            uint64_t pr = 0;
+            bool parked = false;
+            uint32_t cons = 0, spins = 0;
+            auto put = [&](double x) __attribute__((always_inline)) {
+                const uint32_t d = a.has_p_noise ? jl : (uint32_t)D;
+                s_z[((size_t)(kl % (uint32_t)kNRing) * NPS + d) * kBlock + ln] = x;
+                jl += 1;
+                const bool wrap = jl == nd;
+                jl = wrap ? 0u : jl;
+                kl += wrap ? 1u : 0u;
+            };
+            uint32_t published = 0;
+            for (;;) {
+                cons = __hip_atomic_load(&s_cons[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t lim = min((uint32_t)K, cons + (uint32_t)kNRing);
+                const uint64_t bcan = __builtin_amdgcn_ballot_w64(!parked && kl < lim);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {            // four fast attempts per round of bookkeeping
+                    if (!parked && kl < lim) {
+                        uint64_t r = hg.next64();
+                        const uint64_t r0 = r;
+                        const int idx = (int)(r & 0xff);
+                        r >>= 8;
+                        const int sign = (int)(r & 0x1);
+                        const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+                        double x = (double)rabs * zig.wi[idx];
+                        x = sign ? -x : x;
+                        if (rabs < zig.ki[idx]) put(x);
+                        else { parked = true; pr = r0; }
+                    }
+                }
+                const uint64_t bpark = __builtin_amdgcn_ballot_w64(parked);
+                if (bpark != 0) {
+                    // (no "urgent" rule for a parked lane that holds the next step back: the producer is the
+                    // slower side, so the consumer is always waiting, and serving such lanes at once is the
+                    // lockstep behaviour again; the other lanes use the wait to run up to kNRing steps ahead)
+                    if ((uint32_t)__builtin_popcountll(bpark) >= kPark || bcan == 0) {
+                        if (parked) {
+                            uint64_t r = pr;
+                            const int idx = (int)(r & 0xff);
+                            r >>= 8;
+                            const int sign = (int)(r & 0x1);
+                            const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+                            double x = (double)rabs * zig.wi[idx];
+                            x = sign ? -x : x;
+                            if (idx == 0) put(np_zig_tail(hg, rabs));
+                            else if (((zig.fi[idx - 1] - zig.fi[idx]) * np_random(hg) + zig.fi[idx]) < exp(-0.5 * x * x)) put(x);
+                            parked = false;         // (a rejected wedge point: the draw starts over with a fresh word)
+                        }
+                    }
+                }
+                // publish the steps every lane has completed
+                while (pub < (uint32_t)K && __builtin_amdgcn_ballot_w64(kl <= pub) == 0) pub++;
+                if (pub != published) {
+                    if ((ln & 63) == 0)
+                        __hip_atomic_store(&s_prod[wv], pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    published = pub;
+                }
+                if (pub == (uint32_t)K) break;
+                if (bcan == 0 && bpark == 0) {       // ring full for every lane: wait for the consumer
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kCSpinLimit) { hstatus |= kCStatusInternal; break; }
+                } else {
+                    spins = 0;
+                }
+            }
+            hg.store(a.env_s, i);
+            if (hstatus) atomicOr(&a.status[i], hstatus);
+            return;
+        }
         for (int k = 0; k < K; k++) {
             if (k >= kNRing) {                  // wait until the consumer wave freed slot k % kNRing
                 uint32_t spins = 0;
@@ -388,9 +471,11 @@ static void launch_t(const ContinuousArgs &a, int K, const float *actions, float
         // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
         constexpr bool can_help = (size_t)kNRing * (D + 1) * kBlock * 8 <= 120 * 1024;
         const bool helper = can_help && K >= 16 && (a.N % kBlock) == 0 && !getenv("MDPP_NO_HELPER");
+        ContinuousArgs ap = a;
+        ap.park = getenv("MDPP_NO_PARK") ? 0 : 1;
         if (can_help && helper)
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help>), dim3(grid),
-                               dim3(2 * kBlock), 0, s, a, K, actions, obs, reward, term, trunc, final_obs);
+                               dim3(2 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
         else
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, false>), dim3(grid),
                                dim3(kBlock), 0, s, a, K, actions, obs, reward, term, trunc, final_obs);

@@ -95,6 +95,7 @@ struct ContinuousArgs {
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
     uint32_t *status;
     // ---- precomputed on the host for the fused fast path (mdpp_continuous_fast.hip) ----
+    int32_t park;               // helper waves park lanes that leave the ziggurat's fast path (mdpp_continuous_fast.hip)
     int32_t image_quirk;        // image observations: every step clips and zeroes the derivatives (see k_continuous_step C4)
     uint32_t fast_ok;           // PCG64, no hypercubes, relevant dims = a prefix, bounded, delay 0, every_n 1
     uint32_t inertia_pow2;      // inertia is a power of two: a / inertia == a * inv_inertia32 exactly
