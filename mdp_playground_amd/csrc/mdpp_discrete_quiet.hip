@@ -45,7 +45,14 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 //   hi: [0] terminated  [1] truncated  [2] reset happened  [3] history full (NaN gate)  [4] pay step  [31:5] sequence key
 // start states H -> E: one 64-bit word per env, three 16-bit entries (rel | irr << 8) and, in the top
 // 16 bits, the number of entries pushed so far (mod 2^16); E answers with the number it has taken
-template <bool OBS64, bool IRR, int ROLES>
+//
+// PN / RN: transition noise / reward noise (numpy streams).  PN: E draws one uniform per step from the
+// state space's stream and re-draws the next state from the categorical around the table's entry
+// (:1604-1622), searched as integer thresholds like rho_0.  RN: the reward noise comes from the ENV
+// stream, the one reset() draws from, and numpy's order is normal-of-the-step, then the reset draw:
+// so E owns that stream, draws the step's standard normal (ziggurat tables in LDS) and hands it to O
+// beside the record, start states are drawn at need instead of ahead, and there is no H role.
+template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN>
 __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
@@ -59,7 +66,12 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     __shared__ __align__(8) uint64_t s_start[ROLES == 3 ? kBlock : 1];   // H -> E
     __shared__ uint32_t s_head[ROLES == 3 ? kBlock : 1];                 // E -> H
     __shared__ uint32_t s_done;                                         // E waves that have finished
+    __shared__ uint64_t s_ki[RN ? 256 : 1];
+    __shared__ double s_wi[RN ? 256 : 1], s_fi[RN ? 256 : 1];
+    static_assert(!(IRR && (PN || RN)), "noise with an irrelevant sub-space runs on the general kernel");
+    static_assert(!(RN && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
+    constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = ROLES * kBlock;
     const int tid = threadIdx.x;
     const int role = DUO ? tid / kBlock : 0;        // 0 = E, 1 = O, 2 = H
@@ -68,11 +80,21 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
     for (int k = tid; k < a.S; k += kThreads) lds[a.lds_term + k] = a.is_term[k];
     for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k];
+    if (RN) zig_stage(s_ki, s_wi, s_fi, tid, kThreads);
+    const ZigLds zig{s_ki, s_wi, s_fi};
     // rho_0 as integer thresholds: cdf[j] <= u  <=>  ceil(cdf[j] * 2^53) <= r >> 11 (exact: u is
     // (r >> 11) * 2^-53), padded to a multiple of 8 with 2^64-1 so the search runs in unrolled blocks
     const uint32_t lds_P1 = a.lds_bytes, lds_T0 = (a.lds_bytes + (IRR ? (uint32_t)(a.S1 * a.A1) : 0u) + 15u) & ~15u;
     const uint32_t S8 = ((uint32_t)a.S + 7u) & ~7u, S18 = IRR ? (((uint32_t)a.S1 + 7u) & ~7u) : 0u;
     const uint32_t lds_T1 = lds_T0 + S8 * 8u;
+    const uint32_t lds_TN = lds_T1 + S18 * 8u;                 // PN: S rows of S8 thresholds of the noise categoricals
+    if (PN) {
+        for (uint32_t k = tid; k < (uint32_t)a.S * S8; k += kThreads) {
+            const uint32_t row = k / S8, col = k - row * S8;
+            ((uint64_t *)(lds + lds_TN))[k] =
+                col < (uint32_t)a.S ? (uint64_t)ceil(a.noise_cdf[row * (uint32_t)a.S + col] * 9007199254740992.0) : ~0ULL;
+        }
+    }
     for (uint32_t k = tid; k < S8; k += kThreads)
         ((uint64_t *)(lds + lds_T0))[k] = k < (uint32_t)a.S ? (uint64_t)ceil(a.init_cdf[k] * 9007199254740992.0) : ~0ULL;
     if (IRR) {
@@ -93,9 +115,11 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     if (tid == 0) s_done = 0;
     __syncthreads();
     // DUO: the record ring follows the tables in dynamic LDS
-    uint64_t *ring = (uint64_t *)(lds + ((lds_T1 + S18 * 8u + 15u) & ~15u));
+    uint64_t *ring = (uint64_t *)(lds + ((lds_TN + (PN ? (uint32_t)a.S * S8 * 8u : 0u) + 15u) & ~15u));
+    double *ringz = (double *)(ring + kDepth * kBlock);         // RN: the step's standard normal
     const uint8_t *P = lds + a.lds_P, *is_term = lds + a.lds_term, *rbits = lds + a.lds_rew, *P1 = lds + lds_P1;
     const uint64_t *T0 = (const uint64_t *)(lds + lds_T0), *T1 = (const uint64_t *)(lds + lds_T1);
+    const uint64_t *TN = (const uint64_t *)(lds + lds_TN);
 
     const uint32_t i = blockIdx.x * kBlock + l;
     if (!DUO && i >= (uint32_t)a.N) return;            // (DUO launches have full blocks only)
@@ -104,8 +128,9 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
     uint32_t steps = st.z, ringbits = st.w, status = 0;
     uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
-    Pcg64 g;
+    Pcg64 g, sp;
     g.load(a.env_s, a.env_inc, i);
+    if (PN) sp.load(a.sp_s, a.sp_inc, i);
     // sequence key over the last L states, carried: key' = (key - oldest * S^(L-1)) * S + new
     uint32_t spow = 1;
     for (uint32_t j = 1; j < L; j++) spow *= S;
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             if (++spins > kQSpinLimit) { status |= kQStatusInternal; qn = 1; break; }
         }
     };
-    if (autoreset && isE && !TRIO) refill();
+    if (autoreset && isE && !TRIO && !RN) refill();
     uint32_t phase = steps % every_n;
 
     // rewards of the unit path: s_rsel[(paid << 1) | terminal], filled above.  An LDS table on
@@ -257,14 +282,24 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     };
 
     // ---- E: one step of the state recurrence -> record
-    auto stepE = [&](const u32x2 act2) __attribute__((always_inline)) -> uint64_t {
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
+    auto stepE = [&](const u32x2 act2, double &z) __attribute__((always_inline)) -> uint64_t {
+        if (!RN && __builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
         int action = (int)act2.x;
         action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
         const bool bad = action < 0 || action >= (int)A;
         action = bad ? 0 : action;
         const uint32_t cur = (uint32_t)hist & 0xFFu;
-        const uint32_t nxt = P[cur * A + (uint32_t)action];                  // D1
+        uint32_t nxt = P[cur * A + (uint32_t)action];                        // D1
+        if (PN) {                                                            // D2 (:1604-1622)
+            const uint64_t m = sp.next64() >> 11;
+            const uint64_t *row = TN + nxt * S8;
+            uint32_t c = 0;
+            for (uint32_t b = 0; b < S8; b += 8) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) c += (row[b + j] <= m) ? 1u : 0u;
+            }
+            nxt = c;
+        }
         const uint32_t oldest = (uint32_t)(hist >> (8 * (L - 1))) & 0xFFu;   // leaves the L-window
         key = (key - (oldest == 0xFFu ? 0u : oldest) * spow) * S + nxt;     // D4 key, carried
         hist = (hist << 8) | nxt;                                            // D3
@@ -281,8 +316,13 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             cur1 = P1[cur1 * (uint32_t)a.A1 + (uint32_t)action1];
         }
         status |= (bad || bad1) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+        if (RN) z = np_standard_normal_lds(g, zig);                         // D6: drawn in reward_function, before any reset
         const bool tr = has_max && steps >= max_steps;
         const bool need = autoreset && (done || tr);
+        if (RN && __builtin_amdgcn_ballot_w64(need) != 0) {                  // reset(): drawn now, in stream order
+            if (need) { queue[0] = draw_state(); }
+            qn = need ? 1u : qn;
+        }
         uint32_t hi = (done ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |
                       (phase == 0 ? 16u : 0u) | (key << 5);
         uint32_t lo = (nxt << 8) | (cur1 << 24);
@@ -301,7 +341,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         return ((uint64_t)hi << 32) | lo;
     };
     // ---- O: record -> reward, delay line, all global stores of step `so`
-    auto emitO = [&](const uint64_t rec, const uint32_t so) __attribute__((always_inline)) {
+    auto emitO = [&](const uint64_t rec, const double z, const uint32_t so) __attribute__((always_inline)) {
         const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
         const uint32_t k2 = hi >> 5;
         uint32_t bit = (rbits[k2 >> 3] >> (k2 & 7u)) & 1u;
@@ -311,7 +351,17 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         bit = delay > 0 ? outb : bit;
         bit = (hi & 16u) ? bit : 0u;                                         // D6
         const uint32_t done = hi & 1u;
-        const float rout = s_rsel[(bit << 1) | done];
+        float rout;
+        if (RN) {                                                            // :1980-1990, :2107 in float64
+            double r = bit ? 1.0 : 0.0;
+            r += 0.0 + a.r_noise * z;
+            r *= a.scale;
+            r += a.shift;
+            if (done) r += a.term_add;
+            rout = (float)r;
+        } else {
+            rout = s_rsel[(bit << 1) | done];
+        }
         const bool need = (hi & 4u) != 0;
         if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
             if (need) put_obs(r_fin, so, (lo >> 8) & 0xFFu, lo >> 24);
@@ -333,14 +383,18 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             for (int u = 0; u < kPre; u++) {
                 const u32x2 act = pre[u];
                 pre[u] = load_act(c * kPre + kPre + u);
-                emitO(stepE(act), (uint32_t)(c * kPre + u));
+                double z = 0.0;
+                const uint64_t rec = stepE(act, z);
+                emitO(rec, z, (uint32_t)(c * kPre + u));
             }
         }
         for (int k = nfull * kPre; k < K; k++) {
             u32x2 act = pre[0];
 #pragma unroll
             for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
-            emitO(stepE(act), (uint32_t)k);
+            double z = 0.0;
+            const uint64_t rec = stepE(act, z);
+            emitO(rec, z, (uint32_t)k);
         }
     } else if (role == 0) {
         // -------------------------------------------------------------- E waves
@@ -350,8 +404,8 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         const int nchunks = (K + kPre - 1) / kPre;
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kPre;
-            if (kbase + kPre > kQDepth) {               // stay within the ring: at most kQDepth - 8 steps ahead of O
-                const uint32_t must = (uint32_t)(kbase + kPre - kQDepth);
+            if (kbase + kPre > kDepth) {                // stay within the ring: at most kDepth - 8 steps ahead of O
+                const uint32_t must = (uint32_t)(kbase + kPre - kDepth);
                 uint32_t spins = 0;
                 while (__hip_atomic_load(&s_cons[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < must) {
                     __builtin_amdgcn_s_sleep(1);
@@ -364,14 +418,18 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
                 for (int u = 0; u < kPre; u++) {
                     const u32x2 act = pre[u];
                     pre[u] = load_act(kbase + kPre + u);
-                    ring[((kbase + u) % kQDepth) * kBlock + l] = stepE(act);
+                    double z = 0.0;
+                    ring[((kbase + u) % kDepth) * kBlock + l] = stepE(act, z);
+                    if (RN) ringz[((kbase + u) % kDepth) * kBlock + l] = z;
                 }
             } else {
                 for (int k = kbase; k < K; k++) {
                     u32x2 act = pre[0];
 #pragma unroll
                     for (int u = 1; u < kPre; u++) act = (k - kbase == u) ? pre[u] : act;
-                    ring[(k % kQDepth) * kBlock + l] = stepE(act);
+                    double z = 0.0;
+                    ring[(k % kDepth) * kBlock + l] = stepE(act, z);
+                    if (RN) ringz[(k % kDepth) * kBlock + l] = z;
                 }
             }
             if ((l & 63) == 0)
@@ -390,17 +448,23 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             }
             if (kbase + kPre <= K) {
                 uint64_t rec[kPre];
+                double zz[kPre];
 #pragma unroll
-                for (int u = 0; u < kPre; u++) rec[u] = ring[((kbase + u) % kQDepth) * kBlock + l];
+                for (int u = 0; u < kPre; u++) {
+                    rec[u] = ring[((kbase + u) % kDepth) * kBlock + l];
+                    zz[u] = RN ? ringz[((kbase + u) % kDepth) * kBlock + l] : 0.0;
+                }
 #pragma unroll
-                for (int u = 0; u < kPre; u++) emitO(rec[u], (uint32_t)(kbase + u));
+                for (int u = 0; u < kPre; u++) emitO(rec[u], zz[u], (uint32_t)(kbase + u));
             } else {
-                for (int k = kbase; k < K; k++) emitO(ring[(k % kQDepth) * kBlock + l], (uint32_t)k);
+                for (int k = kbase; k < K; k++)
+                    emitO(ring[(k % kDepth) * kBlock + l], RN ? ringz[(k % kDepth) * kBlock + l] : 0.0, (uint32_t)k);
             }
             if ((l & 63) == 0)
                 __hip_atomic_store(&s_cons[w], upto, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    if (PN && isE) sp.store(a.sp_s, i);
     if (TRIO && role == 0) {
         // tell H how many of its start states were really used, then that this wave is through
         __hip_atomic_store(&s_head[l], (head16 - qn) & 0xFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -427,36 +491,62 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     if (status) atomicOr(&a.status[i], status);
 }
 
+template <bool O64, bool IR, int ROLES, bool PN, bool RN>
+static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t *actions, void *obs, float *reward,
+                         uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
+    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN>;
+    if (lds > 48 * 1024) {                        // tables + record ring beyond the default dynamic-LDS limit
+        static size_t allowed = 0;                // (per instantiation)
+        if (lds > allowed) {
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allowed = lds;
+        }
+    }
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ROLES * kBlock), lds, s, a, K, actions, obs, reward, term, trunc, final_obs);
+}
+
 // Serves the launch if the handle and the launch shape qualify; false = not taken.
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    if (a.philox || a.has_p_noise || a.has_r_noise || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds ||
-        a.fast_ok || K < 16 || getenv("MDPP_NO_QUIET"))
+    if (a.philox || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || getenv("MDPP_NO_QUIET"))
         return false;
+    const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
+    if ((pn || rn) && (a.irr || getenv("MDPP_NO_QUIET_NOISE"))) return false;
     const unsigned long long bytes = (unsigned long long)K * a.N * (a.irr ? 2 : 1) * 8ULL;
     if (bytes >= (1ULL << 32)) return false;                    // buffer descriptors address < 4 GiB per array
+    const size_t S8 = (size_t)((a.S + 7) & ~7);
     size_t lds = a.lds_bytes;
-    lds = ((lds + (a.irr ? (size_t)a.S1 * a.A1 : 0) + 15) & ~(size_t)15) + (size_t)((a.S + 7) & ~7) * 8 +
-          (a.irr ? (size_t)((a.S1 + 7) & ~7) * 8 : 0);
+    lds = ((lds + (a.irr ? (size_t)a.S1 * a.A1 : 0) + 15) & ~(size_t)15) + S8 * 8 + (a.irr ? (size_t)((a.S1 + 7) & ~7) * 8 : 0);
+    if (pn) lds += (size_t)a.S * S8 * 8;                        // thresholds of the S noise categoricals
     if (lds > 60 * 1024) return false;
-    // two waves per SIMD (E / O roles) when the blocks are full, the rollout is long enough to fill
-    // the ring, and tables + ring fit the 64 KiB a workgroup gets without opting in to more
-    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + (size_t)kQDepth * kBlock * 8;
-    const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo + 4096 <= 64 * 1024 && !getenv("MDPP_NO_DUO");
-    const bool trio = duo && a.autoreset && !getenv("MDPP_NO_TRIO");
-    const int grid = (a.N + kBlock - 1) / kBlock;
-#define MDPP_Q_LAUNCH(O64, IR)                                                                                    \
-    do {                                                                                                          \
-        if (trio) hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR, 3>), dim3(grid), dim3(3 * kBlock),        \
-                                     lds_duo, s, a, K, actions, obs, reward, term, trunc, final_obs);             \
-        else if (duo) hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR, 2>), dim3(grid), dim3(2 * kBlock),    \
-                                         lds_duo, s, a, K, actions, obs, reward, term, trunc, final_obs);         \
-        else hipLaunchKernelGGL((k_discrete_rollout_quiet<O64, IR, 1>), dim3(grid), dim3(kBlock), lds, s, a,      \
-                                K, actions, obs, reward, term, trunc, final_obs);                                 \
+    // two / three waves per SIMD (E / O / H roles) when the blocks are full and the rollout is long
+    // enough to fill the ring
+    const size_t depth = rn ? 16 : kQDepth;
+    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
+    const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !getenv("MDPP_NO_DUO");
+    const bool trio = duo && a.autoreset && !rn && !getenv("MDPP_NO_TRIO");
+    const int roles = trio ? 3 : duo ? 2 : 1;
+    const size_t l = roles == 1 ? lds : lds_duo;
+#define MDPP_Q_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
+#define MDPP_Q_ROLES(O64, IR, PN_, RN_)                                                           \
+    do {                                                                                          \
+        if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
+        else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_>(MDPP_Q_ARGS);                     \
+        else quiet_launch<O64, IR, 1, PN_, RN_>(MDPP_Q_ARGS);                                     \
     } while (0)
-    if (a.irr) { if (a.obs_i32) MDPP_Q_LAUNCH(false, true); else MDPP_Q_LAUNCH(true, true); }
-    else { if (a.obs_i32) MDPP_Q_LAUNCH(false, false); else MDPP_Q_LAUNCH(true, false); }
-#undef MDPP_Q_LAUNCH
+#define MDPP_Q_NOISE(O64)                                                                         \
+    do {                                                                                          \
+        if (a.irr) MDPP_Q_ROLES(O64, true, false, false);                                         \
+        else if (pn && rn) MDPP_Q_ROLES(O64, false, true, true);                                  \
+        else if (pn) MDPP_Q_ROLES(O64, false, true, false);                                       \
+        else if (rn) MDPP_Q_ROLES(O64, false, false, true);                                       \
+        else MDPP_Q_ROLES(O64, false, false, false);                                              \
+    } while (0)
+    if (a.obs_i32) MDPP_Q_NOISE(false); else MDPP_Q_NOISE(true);
+#undef MDPP_Q_NOISE
+#undef MDPP_Q_ROLES
+#undef MDPP_Q_ARGS
     return true;
 }
 

@@ -196,6 +196,16 @@ QUIET = {
                              sequence_length=1, dtype_s=np.int32), dict(max_episode_steps=7), 512),
     "s32_noreset": (dict(state_space_size=32, action_space_size=32, sequence_length=2, delay=1, reward_density=0.05),
                     dict(autoreset="disabled"), 512),           # full blocks, no autoreset: two roles (E / O)
+    # the noise variants: P-noise (three roles), reward noise (env stream shared with reset: two roles),
+    # both on a ragged batch (one role), reward noise with std 0 (still draws) and a horizon
+    "pn_s12": (dict(state_space_size=12, action_space_size=12, sequence_length=2, delay=1, transition_noise=0.25,
+                    reward_scale=2.0), {}, 768),
+    "rn_s8": (dict(state_space_size=8, action_space_size=8, sequence_length=3, delay=4, reward_noise=0.3,
+                   reward_shift=-0.5, term_state_reward=1.0), {}, 512),
+    "pn_rn_ragged": (dict(state_space_size=10, action_space_size=10, sequence_length=1, delay=0, transition_noise=0.1,
+                          reward_noise=1.5), {}, 700),
+    "pn_rn0_horizon": (dict(state_space_size=20, action_space_size=20, sequence_length=2, delay=2, transition_noise=0.4,
+                            reward_noise=0.0, reward_every_n_steps=1), dict(max_episode_steps=9), 256),
 }
 
 
@@ -243,6 +253,7 @@ def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
             obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(at))
             fin = None
         env_end = env.get_rng_streams(capi.STREAM_ENV)
+        sp_end = env.get_rng_streams(capi.STREAM_SPACE)
         for i, o, ep in oracles:
             for t in range(K):
                 st, rr, d = o.step(acts[t, i])
@@ -257,6 +268,7 @@ def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
                     ep[0] = 0
                 assert np.array_equal(obs[t, i], np.asarray(st)), (variant, K, i, t)
             assert np.array_equal(o.get_rng()[0][:4], env_end[i][:4]), (variant, K, i)
+            assert np.array_equal(o.get_rng()[1][:4], sp_end[i][:4]), (variant, K, i)
     env.close()
 
 
