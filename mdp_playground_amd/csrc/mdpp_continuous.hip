@@ -652,6 +652,7 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
         for (int k0 = 0; served && k0 < K;) {
             const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
             const size_t off = (size_t)k0 * a.N;
+            a.tick = h->tick + (uint32_t)k0;              // head of the delay ring for this piece
             served = launch_continuous_fast(a, kc, actions + off * a.D, obs + off * a.D, reward + off,
                                             term + off, trunc + off,
                                             final_obs ? final_obs + off * a.D : nullptr, s);

@@ -47,7 +47,12 @@ constexpr int kNRing = 4;                      // steps of normals buffered per 
 constexpr uint32_t kCSpinLimit = 1u << 22;
 constexpr uint32_t kCStatusInternal = 0x80000000u;
 
-template <int D, int ORDER, int NREL, bool NOISE, bool HELPER>
+// GEN: the general reward post-processing and episode ends -- delay line (C7, :1968-1973), every-n
+// mask (:1975), terminal hypercubes (C8, :945-952; reset() resamples out of them, :2284-2307).  With
+// these the reference's reward changes between np.float32 and Python-float arithmetic from step to
+// step (k_continuous_step's CRew); without them it is float32 throughout, and that path stays as lean
+// as it was.
+template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN>
 __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
@@ -225,6 +230,21 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         }
         return sqrtf((float)acc);
     };
+    // terminal hypercubes over the relevant (= first NREL) coordinates (:945-952)
+    auto in_boxes = [&](const float (&s)[D]) -> bool {
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < MDPP_MAX_BOXES; b++) {     // constant trip count: a run-time index into the
+            if (b < a.n_boxes) {                       // argument struct would put it in scratch memory
+                bool in = true;
+#pragma unroll
+                for (int j = 0; j < NREL; j++)
+                    in = in && (s[j] >= a.box_lo[b * NREL + j]) && (s[j] <= a.box_hi[b * NREL + j]);
+                any = any || in;
+            }
+        }
+        return any;
+    };
     // |x_d| <= bound for every d, false if any x_d is NaN: for non-negative floats the IEEE order
     // is the unsigned order of the bit patterns (inf above every finite value, NaN above inf)
     auto all_within = [&](const float (&v)[D], float bound) -> bool {
@@ -351,18 +371,49 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         } else {
             r = r - 0.0f;                       // alw * ||a|| == +0 exactly for an admitted action
         }
-        // ---- C7 (delay 0, every step pays: the reward stays np.float32 throughout)
-        if (NOISE && a.has_r_noise) {
-            if (HELPER) zi = D;
-            r = r + (float)(0.0 + a.r_noise * normal());
+        // ---- C7 (!GEN: delay 0, every step pays: the reward stays np.float32 throughout)
+        bool done = (flags & 1u) != 0;
+        if (!GEN) {
+            if (NOISE && a.has_r_noise) {
+                if (HELPER) zi = D;
+                r = r + (float)(0.0 + a.r_noise * normal());
+            }
+            if (HELPER && (ln & 63) == 0)   // this wave is done with the step's slot
+                __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            r = r * a.scale32;
+            r = r + a.shift32;
+            // ---- C8
+            r = done ? r + a.term_add32 : r;
+        } else {
+            double rv = (double)r;
+            bool is32 = true;
+            if (a.delay > 0) {                                                   // FIFO of float32 bit patterns
+                uint32_t *slot = a.ring + (size_t)((a.tick + (uint32_t)k) % (uint32_t)a.delay) * N + i;
+                const uint32_t bits = *slot;
+                *slot = __float_as_uint(r);
+                if (bits == kRingPyZero) { rv = 0.0; is32 = false; }
+                else { rv = (double)__uint_as_float(bits); is32 = true; }
+            }
+            if (steps % (uint32_t)a.every_n != 0) { rv = 0.0; is32 = false; }
+            if (NOISE && a.has_r_noise) {
+                if (HELPER) zi = D;
+                const double nz = 0.0 + a.r_noise * normal();
+                if (is32) rv = (double)((float)rv + (float)nz); else rv = rv + nz;
+            }
+            if (HELPER && (ln & 63) == 0)
+                __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (is32) {
+                rv = (double)((float)rv * a.scale32);
+                rv = (double)((float)rv + a.shift32);
+            } else {
+                rv = rv * a.scale;
+                rv = rv + a.shift;
+            }
+            // ---- C8: a terminal hypercube around the state ends the episode too
+            if (a.n_boxes > 0) done = done || in_boxes(nxt);
+            if (done) { if (is32) rv = (double)((float)rv + a.term_add32); else rv = rv + a.term_add; }
+            r = (float)rv;
         }
-        if (HELPER && (ln & 63) == 0)   // this wave is done with the step's slot
-            __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        r = r * a.scale32;
-        r = r + a.shift32;
-        // ---- C8
-        const bool done = (flags & 1u) != 0;
-        r = done ? r + a.term_add32 : r;
         const bool tr = has_max && steps >= max_steps;
         dist_prev = dist_new;
 #pragma unroll
@@ -377,9 +428,14 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                 }
                 Pcg64 sp;
                 sp.load(a.sp_s, a.sp_inc, i);
+                for (int tries = 0;; tries++) {
 #pragma unroll
-                for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));
+                    for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));
+                    if (!GEN || a.n_boxes == 0 || !in_boxes(cur)) break;     // :2284-2307 resample out of terminal cubes
+                    if (tries > 4096) { status |= 2u; break; }
+                }
                 sp.store(a.sp_s, i);
+                if (GEN) for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
 #pragma unroll
                 for (int kk = 0; kk <= ORDER; kk++)
 #pragma unroll
@@ -463,8 +519,8 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
     if (status) atomicOr(&a.status[i], status);
 }
 
-template <int D, int ORDER, int NREL>
-static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+template <int D, int ORDER, int NREL, bool GEN>
+static void launch_g(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.has_p_noise || a.has_r_noise) {
@@ -474,15 +530,24 @@ static void launch_t(const ContinuousArgs &a, int K, const float *actions, float
         ContinuousArgs ap = a;
         ap.park = getenv("MDPP_NO_PARK") ? 0 : 1;
         if (can_help && helper)
-            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help>), dim3(grid),
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN>), dim3(grid),
                                dim3(2 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
         else
-            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, false>), dim3(grid),
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, false, GEN>), dim3(grid),
                                dim3(kBlock), 0, s, a, K, actions, obs, reward, term, trunc, final_obs);
     } else {
-        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false, false>), dim3(grid), dim3(kBlock),
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false, false, GEN>), dim3(grid), dim3(kBlock),
                            0, s, a, K, actions, obs, reward, term, trunc, final_obs);
     }
+}
+
+template <int D, int ORDER, int NREL>
+static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+                     uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
+    if (a.delay > 0 || a.every_n != 1 || a.n_boxes > 0)
+        launch_g<D, ORDER, NREL, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+    else
+        launch_g<D, ORDER, NREL, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
 }
 
 // Returns false when the shape does not qualify (caller falls back to k_continuous_step).

@@ -1247,20 +1247,32 @@ def test_device_normals_match_numpy_stream():
     env.close()
 
 
-@pytest.mark.parametrize("name", ["c_cfg5", "c_cfg3"])
+CFAST_GEN = dict(delay=3, reward_every_n_steps=2, reward_scale=1.5, reward_shift=-0.25, term_state_reward=-1.0,
+                 target_radius=0.5, terminal_states=[[6.0, 6.0, 6.0, 6.0], [-5.0, 5.0, -5.0, 5.0]], term_state_edge=6.0)
+
+
+@pytest.mark.parametrize("name", ["c_cfg5", "c_cfg3", "c_cfg5+gen", "c_cfg3+gen"])
 def test_continuous_fast_kernel_shared_vs_oracle(name):
     """BASELINE cfg 3 / cfg 5 shapes at 512 envs (full 256-env blocks, 40 fused steps): with noise
     this runs the producer/consumer variant (helper waves draw the normals); every sampled env
-    must equal its oracle bit for bit, including the env stream's end state."""
-    cfg = _cfg(name, 23)
+    must equal its oracle bit for bit, including the env stream's end state.  "+gen": the same
+    with a reward delay, every-n 2, an affine map and two terminal hypercubes (the kernel's general
+    post-processing: the reward's float32 / Python-float typing of the reference, resets that
+    resample out of the cubes), across two launches so that the delay ring's head carries over."""
+    gen = name.endswith("+gen")
+    cfg = _cfg(name.split("+")[0], 23)
+    if gen:
+        cfg.update(CFAST_GEN)
     N, T = 512, 40
     env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=11, **cfg)
     rng = np.random.default_rng(6)
     acts = rng.uniform(-1, 1, size=(T, N, 12)).astype(np.float32)
     acts[7, 5, 3] = 2.0                      # one rejected action ("stay")
     init = env._obs.cpu().numpy().copy()
-    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
-    obs, rew, trunc = obs.cpu().numpy(), rew.cpu().numpy(), trunc.cpu().numpy()
+    assert env.rollout_kernel_name(T) == "k_continuous_rollout_fast"
+    at = torch.as_tensor(acts, device=env.device)
+    parts = [env.rollout(at[:17]), env.rollout(at[17:])]          # (17 steps: not a multiple of the delay)
+    obs, rew, term, trunc = (torch.cat([p[j] for p in parts]).cpu().numpy() for j in range(4))
     end_env = env.get_rng_streams(0)
     for i in list(range(0, N, 29)) + [5]:
         o = _oracle_for(env, i)

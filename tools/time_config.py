@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time fused rollouts of an arbitrary config (GPU box): env-steps/s and us per env-wave step.
-usage: python3 tools/time_config.py '<json config overrides>' [envs] [fuse] [launches]
-The overrides are applied to bench.py's cfg2 workload config."""
+usage: python3 tools/time_config.py '<json config overrides>' [envs] [fuse] [launches] [base workload]
+The overrides are applied to the config of bench.py's base workload (default cfg2)."""
 import json
 import os
 import sys
@@ -16,9 +16,10 @@ over = json.loads(sys.argv[1]) if len(sys.argv) > 1 else {}
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-cfg = dict(bench.WORKLOADS["cfg2"]["config"], **over)
+base = bench.WORKLOADS[sys.argv[5] if len(sys.argv) > 5 else "cfg2"]
+cfg = dict(base["config"], **over)
 env = RLToyVectorEnv(num_envs=N, autoreset="same_step", **cfg)
-wl = dict(kind="discrete", config=cfg)
+wl = dict(base, config=cfg)
 acts = bench.make_actions(wl, F, N, env.device, 1)
 out = env.alloc_rollout(F)
 for _ in range(3):
