@@ -329,6 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
                                                             float *__restrict__ final_obs) {
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
+    __shared__ double s_z[DMAX * kBlock];                    // this step's transition-noise normals, [d][lane]
     const bool any_noise = a.has_p_noise || a.has_r_noise;   // wave-uniform
     if (any_noise) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
     const ZigLds zig{s_ki, s_wi, s_fi};
@@ -354,6 +355,22 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     const bool need_env = a.has_p_noise || a.has_r_noise;
     if (!PHILOX && need_env) env_pcg.load(a.env_s, a.env_inc, i);
 
+    // [env][D] row-major, 16 B per lane per load when possible
+    auto load_action = [&](int k, float (&dst)[DMAX]) __attribute__((always_inline)) {
+        const float *ap = actions + ((long)k * N + i) * D;
+        if (DMAX % 4 == 0 && D == DMAX) {
+#pragma unroll
+            for (int q = 0; q < DMAX / 4; q++) {
+                float4 v = ((const float4 *)ap)[q];
+                dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) dst[d] = (d < D) ? ap[d] : 0.0f;
+        }
+    };
+    float nact[DMAX];
+    load_action(0, nact);
     for (int k = 0; k < K; k++) {
         const uint32_t tick = a.tick + (uint32_t)k;
         const long o = (long)k * N + i;
@@ -361,18 +378,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
             sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
         }
-        // ---- action: [env][D] row-major, 16 B per lane per load when possible
-        const float *ap = actions + o * D;
-        if (DMAX % 4 == 0 && D == DMAX) {
+        // ---- action: fetched one step ahead (with one wave per SIMD nothing else hides the load)
 #pragma unroll
-            for (int q = 0; q < DMAX / 4; q++) {
-                float4 v = ((const float4 *)ap)[q];
-                act[4 * q] = v.x; act[4 * q + 1] = v.y; act[4 * q + 2] = v.z; act[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < DMAX; d++) act[d] = (d < D) ? ap[d] : 0.0f;
-        }
+        for (int d = 0; d < DMAX; d++) act[d] = nact[d];
+        load_action(k + 1 < K ? k + 1 : k, nact);
         // ---- C1
         bool ok = true;
 #pragma unroll
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             for (int d = 0; d < DMAX; d++) {
 #pragma unroll
                 for (int kk = 0; kk <= OMAX; kk++)
-                    if (kk == n) sd[kk][d] = act[d] / a.inertia32;
+                    if (kk == n) sd[kk][d] = a.inertia_pow2 ? act[d] * a.inv_inertia32 : act[d] / a.inertia32;   // (exact for 2^k)
             }
 #pragma unroll
             for (int ii = 0; ii < OMAX; ii++) {
@@ -394,7 +403,9 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 #pragma unroll
                         for (int d = 0; d < DMAX; d++) {
                             float prod = sd[(ii + j + 1 <= OMAX) ? ii + j + 1 : OMAX][d] * a.tpow32[j + 1];
-                            double trm = (double)prod / a.fact[j + 1];
+                            // 1! and 2! are powers of two: multiplying by the reciprocal is the same float64
+                            const double trm = ((a.fact_pow2_mask >> (j + 1)) & 1u) ? (double)prod * a.inv_fact[j + 1]
+                                                                                    : (double)prod / a.fact[j + 1];
                             sd[ii][d] = (float)((double)sd[ii][d] + trm);
                         }
                     }
@@ -407,13 +418,19 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 #pragma unroll
             for (int d = 0; d < DMAX; d++) nxt[d] = cur[d];
         }
-        // ---- C3
+        // ---- C3.  The D normals are drawn in a ROLLED loop into this lane's LDS column and added from
+        // there: unrolled, D copies of the ziggurat make the loop body ~75 KB of code, and even a
+        // noise-free step then pays an instruction-cache miss per skipped copy (0.4 us per dimension).
+        if (a.has_p_noise) {
+#pragma unroll 1
+            for (int d = 0; d < D; d++)
+                s_z[d * kBlock + threadIdx.x] =
+                    0.0 + a.p_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+        }
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
             if (d < D) {
-                double nz = 0.0;
-                if (a.has_p_noise)
-                    nz = 0.0 + a.p_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                const double nz = a.has_p_noise ? s_z[d * kBlock + threadIdx.x] : 0.0;
                 nxt[d] = (float)((double)nxt[d] + nz);
             }
         }
