@@ -28,13 +28,13 @@ namespace mdpp {
 struct CRew { double v; bool is32; }; // np.float32 vs Python float, as the reference's `reward`
 
 template <int DMAX>
-__device__ __forceinline__ float c_norm_rel(const ContinuousArgs &a, const float (&rel)[DMAX]) {
+__device__ __forceinline__ float c_norm_rel(const ContinuousArgs &a, const float (&rel)[DMAX], const float (&target)[DMAX]) {
     // np.linalg.norm(rel - target): float32 products, float64 accumulate, one rounding, float32 sqrt
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < DMAX; j++) {
         if (j < a.n_rel) {
-            float d = rel[j] - a.target[j];
+            float d = rel[j] - target[j];
             float p = d * d;
             acc += (double)p;
         }
@@ -369,6 +369,19 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             for (int d = 0; d < DMAX; d++) dst[d] = (d < D) ? ap[d] : 0.0f;
         }
     };
+    // Per-dimension constants pinned in VECTOR registers.  Left to the compiler they are wave-uniform
+    // kernel arguments it keeps re-reading with scalar loads once the SGPR file is full: the step
+    // loop ran 102 s_load instructions per step and waited 58 % of its cycles (tools/pmc_sq.sh).
+    float tgt[DMAX], smax = a.smax32, amax = a.amax32, inertia = a.inertia32, inv_inertia = a.inv_inertia32, tpw[OMAX + 1];
+    double fct[OMAX + 1], ifct[OMAX + 1], pns = a.p_noise;
+#pragma unroll
+    for (int j = 0; j < DMAX; j++) { tgt[j] = (j < a.n_rel) ? a.target[j] : 0.0f; asm volatile("" : "+v"(tgt[j])); }
+#pragma unroll
+    for (int j = 0; j <= OMAX; j++) {
+        tpw[j] = a.tpow32[j]; fct[j] = a.fact[j]; ifct[j] = a.inv_fact[j];
+        asm volatile("" : "+v"(tpw[j]), "+v"(fct[j]), "+v"(ifct[j]));
+    }
+    asm volatile("" : "+v"(smax), "+v"(amax), "+v"(inertia), "+v"(inv_inertia), "+v"(pns));
     float nact[DMAX];
     load_action(0, nact);
     for (int k = 0; k < K; k++) {
@@ -386,14 +399,14 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         bool ok = true;
 #pragma unroll
         for (int d = 0; d < DMAX; d++)
-            if (d < D) ok = ok && (act[d] >= -a.amax32) && (act[d] <= a.amax32);
+            if (d < D) ok = ok && (act[d] >= -amax) && (act[d] <= amax);
         if (ok) {
             // ---- C2: lower orders first, each using the not-yet-updated higher ones
 #pragma unroll
             for (int d = 0; d < DMAX; d++) {
 #pragma unroll
                 for (int kk = 0; kk <= OMAX; kk++)
-                    if (kk == n) sd[kk][d] = a.inertia_pow2 ? act[d] * a.inv_inertia32 : act[d] / a.inertia32;   // (exact for 2^k)
+                    if (kk == n) sd[kk][d] = a.inertia_pow2 ? act[d] * inv_inertia : act[d] / inertia;   // (exact for 2^k)
             }
 #pragma unroll
             for (int ii = 0; ii < OMAX; ii++) {
@@ -402,10 +415,11 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
                     if (ii < n && j < n - ii) {
 #pragma unroll
                         for (int d = 0; d < DMAX; d++) {
-                            float prod = sd[(ii + j + 1 <= OMAX) ? ii + j + 1 : OMAX][d] * a.tpow32[j + 1];
+                            float prod = sd[(ii + j + 1 <= OMAX) ? ii + j + 1 : OMAX][d] * tpw[(j + 1 <= OMAX) ? j + 1 : OMAX];
                             // 1! and 2! are powers of two: multiplying by the reciprocal is the same float64
-                            const double trm = ((a.fact_pow2_mask >> (j + 1)) & 1u) ? (double)prod * a.inv_fact[j + 1]
-                                                                                    : (double)prod / a.fact[j + 1];
+                            const double trm = ((a.fact_pow2_mask >> (j + 1)) & 1u)
+                                                   ? (double)prod * ifct[(j + 1 <= OMAX) ? j + 1 : OMAX]
+                                                   : (double)prod / fct[(j + 1 <= OMAX) ? j + 1 : OMAX];
                             sd[ii][d] = (float)((double)sd[ii][d] + trm);
                         }
                     }
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 #pragma unroll 1
             for (int d = 0; d < D; d++)
                 s_z[d * kBlock + threadIdx.x] =
-                    0.0 + a.p_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                    0.0 + pns * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
         }
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         bool inside = true;
 #pragma unroll
         for (int d = 0; d < DMAX; d++)
-            if (d < D) inside = inside && (nxt[d] >= -a.smax32) && (nxt[d] <= a.smax32);
+            if (d < D) inside = inside && (nxt[d] >= -smax) && (nxt[d] <= smax);
         // image observations: the reference asks the ImageContinuous space whether it contains the
         // state VECTOR, which it never does (spaces/image_continuous.py:292-302 returns None), so every
         // step takes this branch: a clip that is the identity inside the box, and zeroed derivatives
@@ -447,8 +461,8 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 #pragma unroll
             for (int d = 0; d < DMAX; d++) {
                 float x = nxt[d];
-                if (x < -a.smax32) x = -a.smax32;
-                if (x > a.smax32) x = a.smax32;
+                if (x < -smax) x = -smax;
+                if (x > smax) x = smax;
                 nxt[d] = x;
             }
 #pragma unroll
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         }
         // ---- C5 (the target latch exists for move_to_a_point only)
         c_gather_rel<DMAX>(a, nxt, rel);
-        const float dist_new = a.line_L ? 0.0f : c_norm_rel<DMAX>(a, rel);
+        const float dist_new = a.line_L ? 0.0f : c_norm_rel<DMAX>(a, rel, tgt);
         if (!a.line_L && dist_new < a.radius32) flags |= 1u;
         const bool in_box = (a.n_boxes > 0) && c_in_box<DMAX>(a, rel);
         steps += 1;
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         } else if (a.make_denser) {
             float relo[DMAX];
             c_gather_rel<DMAX>(a, cur, relo);
-            const float dist_old = c_norm_rel<DMAX>(a, relo);
+            const float dist_old = c_norm_rel<DMAX>(a, relo, tgt);
             r.v = (double)(float)(-dist_new + dist_old);
         } else {
             r.v = (dist_new < a.radius32) ? 1.0 : 0.0;
