@@ -290,7 +290,10 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
                 a.inv_fact[k] = 1.0 / a.fact[k];
                 if (is_pow2(a.fact[k])) a.fact_pow2_mask |= 1u << k;
             }
-            a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && a.rel_prefix && a.bounded && !cfg->image && !line) ? 1u : 0u;
+            // (an unbounded box is fine as long as the actions are bounded: states then stay finite, which
+            // the fast kernel's clip relies on -- np.clip's NaN propagation lives in the general kernel)
+            a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && a.rel_prefix && !cfg->image && !line &&
+                         (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
         }
         if (cfg->image) {   // scratch of one batch of img_chunk env steps: the states the pictures are made from

@@ -429,8 +429,21 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                 Pcg64 sp;
                 sp.load(a.sp_s, a.sp_inc, i);
                 for (int tries = 0;; tries++) {
+                    if (a.bounded) {
 #pragma unroll
-                    for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));
+                        for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));
+                    } else if (D <= 4) {                      // unbounded Box: gymnasium samples a standard normal
+#pragma unroll
+                        for (int d = 0; d < D; d++) cur[d] = (float)(0.0 + 1.0 * np_standard_normal(sp));
+                    } else {
+                        // (a rolled loop through this lane's row of the wave's LDS tile: D inlined copies
+                        // of the sampler would be most of the kernel's code)
+                        float *row = s_tr + ((size_t)wv * 64 + (ln & 63)) * D;
+#pragma unroll 1
+                        for (int d = 0; d < D; d++) row[d] = (float)(0.0 + 1.0 * np_standard_normal(sp));
+#pragma unroll
+                        for (int d = 0; d < D; d++) cur[d] = row[d];
+                    }
                     if (!GEN || a.n_boxes == 0 || !in_boxes(cur)) break;     // :2284-2307 resample out of terminal cubes
                     if (tries > 4096) { status |= 2u; break; }
                 }

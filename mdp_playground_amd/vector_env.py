@@ -490,7 +490,8 @@ class RLToyVectorEnv:
         m = self.mdps[0]
         if getattr(self, "_image", None) is not None:
             return "k_imagec_obs"
-        fast = (self.rng == "numpy" and np.isfinite(m.state_space_max) and m.reward_function == "move_to_a_point"
+        fast = (self.rng == "numpy" and m.reward_function == "move_to_a_point"
+                and (np.isfinite(m.state_space_max) or np.isfinite(m.action_space_max))
                 and list(m.relevant_indices) == list(range(len(m.relevant_indices)))
                 and (m.D, m.order, len(m.relevant_indices)) in
                 {(12, 1, 4), (12, 2, 4), (2, 1, 2), (2, 2, 2), (4, 1, 4), (4, 2, 4), (8, 1, 8), (8, 2, 8),

@@ -1251,7 +1251,7 @@ CFAST_GEN = dict(delay=3, reward_every_n_steps=2, reward_scale=1.5, reward_shift
                  target_radius=0.5, terminal_states=[[6.0, 6.0, 6.0, 6.0], [-5.0, 5.0, -5.0, 5.0]], term_state_edge=6.0)
 
 
-@pytest.mark.parametrize("name", ["c_cfg5", "c_cfg3", "c_cfg5+gen", "c_cfg3+gen"])
+@pytest.mark.parametrize("name", ["c_cfg5", "c_cfg3", "c_cfg5+gen", "c_cfg3+gen", "c_cfg3+unbounded"])
 def test_continuous_fast_kernel_shared_vs_oracle(name):
     """BASELINE cfg 3 / cfg 5 shapes at 512 envs (full 256-env blocks, 40 fused steps): with noise
     this runs the producer/consumer variant (helper waves draw the normals); every sampled env
@@ -1263,6 +1263,9 @@ def test_continuous_fast_kernel_shared_vs_oracle(name):
     cfg = _cfg(name.split("+")[0], 23)
     if gen:
         cfg.update(CFAST_GEN)
+    if name.endswith("+unbounded"):                 # no state_space_max: reset() samples normals (rolled loop via LDS)
+        cfg.pop("state_space_max")
+        cfg["target_radius"] = 1.5
     N, T = 512, 40
     env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=11, **cfg)
     rng = np.random.default_rng(6)
