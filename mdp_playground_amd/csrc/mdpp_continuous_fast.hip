@@ -571,6 +571,7 @@ bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions
 #define MDPP_CF(DD, OO, RR) if (a.D == DD && a.order == OO && a.n_rel == RR) { launch_t<DD, OO, RR>(a, K, actions, obs, reward, term, trunc, final_obs, s); return true; }
     MDPP_CF(12, 1, 4) MDPP_CF(12, 2, 4) MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)
     MDPP_CF(8, 1, 8) MDPP_CF(8, 2, 8) MDPP_CF(12, 1, 12) MDPP_CF(12, 2, 12)
+    MDPP_CF(4, 1, 2) MDPP_CF(4, 2, 2) MDPP_CF(8, 1, 4) MDPP_CF(8, 2, 4)
 #undef MDPP_CF
     return false;
 }

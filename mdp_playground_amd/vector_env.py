@@ -495,7 +495,7 @@ class RLToyVectorEnv:
                 and list(m.relevant_indices) == list(range(len(m.relevant_indices)))
                 and (m.D, m.order, len(m.relevant_indices)) in
                 {(12, 1, 4), (12, 2, 4), (2, 1, 2), (2, 2, 2), (4, 1, 4), (4, 2, 4), (8, 1, 8), (8, 2, 8),
-                 (12, 1, 12), (12, 2, 12)})
+                 (12, 1, 12), (12, 2, 12), (4, 1, 2), (4, 2, 2), (8, 1, 4), (8, 2, 4)})
         return "k_continuous_rollout_fast" if fast else "k_continuous_step"
 
     def alloc_rollout(self, K):

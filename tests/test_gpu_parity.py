@@ -1296,6 +1296,37 @@ def test_continuous_fast_kernel_shared_vs_oracle(name):
     env.close()
 
 
+@pytest.mark.parametrize("D,nrel,order", [(4, 2, 1), (4, 2, 2), (8, 4, 1), (8, 4, 2), (8, 8, 2), (2, 2, 2)])
+def test_continuous_fast_kernel_other_shapes_vs_oracle(D, nrel, order):
+    """The other (D, relevant dims, order) instantiations of k_continuous_rollout_fast, with both noises,
+    a delay and truncation resets, on 256 envs against the oracle."""
+    cfg = dict(state_space_type="continuous", state_space_dim=D, relevant_indices=list(range(nrel)),
+               irrelevant_features=nrel < D, target_point=[0.5] * nrel, target_radius=0.3, state_space_max=6,
+               action_space_max=1, transition_dynamics_order=order, inertia=2.0, time_unit=0.5, make_denser=True,
+               reward_function="move_to_a_point", transition_noise=0.03, reward_noise=0.2, delay=2, seed=12)
+    N, T = 256, 48
+    env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=13, **cfg)
+    assert env.rollout_kernel_name(T) == "k_continuous_rollout_fast"
+    acts = np.random.default_rng(3).uniform(-1, 1, size=(T, N, D)).astype(np.float32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts, device=env.device)))
+    for i in range(0, N, 37):
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert np.array_equal(o.reset(), init[i])
+        n = 0
+        for t in range(T):
+            eo, er, _, ed = o.step(acts[t, i])
+            n += 1
+            tr = n >= 13
+            if ed or tr:
+                eo = o.reset()
+                n = 0
+            assert np.array_equal(obs[t, i], eo), (i, t)
+            assert rew[t, i] == np.float32(er) and bool(trunc[t, i]) == tr and bool(term[t, i]) == ed, (i, t)
+    env.close()
+
+
 @pytest.mark.parametrize("name,flag", [("d_cfg2", "MDPP_NO_PIPE"), ("c_cfg5", "MDPP_NO_HELPER")])
 def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     """The producer/consumer kernels (LDS rings between waves) against the single-role kernels of
