@@ -225,7 +225,11 @@ __global__ __launch_bounds__(kBlock) void k_grid_reset(GridArgs a, uint32_t rese
 constexpr int kGQ = 4;                        // start cells queued per lane
 constexpr int kGRsrc = 0x00020000;
 
-template <bool OBS64, bool G4, bool DENSE>
+// PN / RN: transition noise (a uniform from the env stream per admitted action; below the threshold
+// the action is re-drawn from the action space's stream until it differs, :1733-1749) and reward
+// noise (a normal from the env stream, :1980); reset() draws from the feature space's stream, so
+// the start-cell queue is untouched by either.
+template <bool OBS64, bool G4, bool DENSE, bool PN, bool RN>
 __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K, const int32_t *__restrict__ actions,
                                                               void *__restrict__ obs, float *__restrict__ reward,
                                                               uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
@@ -234,13 +238,24 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int G = G4 ? 4 : 2;
+    __shared__ uint64_t s_ki[RN ? 256 : 1];
+    __shared__ double s_wi[RN ? 256 : 1], s_fi[RN ? 256 : 1];
+    if (RN) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
+    const ZigLds zig{s_ki, s_wi, s_fi};
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= (uint32_t)a.N) return;
     const uint32_t N = (uint32_t)a.N;
     const uint4 st = a.state[i];
     uint32_t cells = st.x, steps = st.y, flags = st.z, status = 0;   // one byte per dimension
-    Pcg64 sp;
+    Pcg64 sp, env, actg;
+    Half32 acth{0, 0};
     sp.load(a.sp_s, a.sp_inc, i);
+    if (PN || RN) env.load(a.env_s, a.env_inc, i);
+    if (PN) {
+        actg.load(a.act_s, a.act_inc, i);
+        const uint2 hh = a.act_half[i];
+        acth = Half32{hh.x, hh.y};
+    }
     uint32_t queue[kGQ];                          // queued start cells, queue[0] next; qn of them valid
 #pragma unroll
     for (int q = 0; q < kGQ; q++) queue[q] = 0;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
 
     // straight-line step body: the run-time options (autoreset, reward_every_n_steps, episode limit)
     // are folded into selects rather than branches
-    auto step = [&](const int k, const i32x4 act) __attribute__((always_inline)) {
+    auto step = [&](const int k, i32x4 act) __attribute__((always_inline)) {
         // every lane must hold a start cell before the step may end its episode; the refill tops
         // all lanes up to kGQ, so this branch is taken once in several dozen steps
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) refill();
@@ -318,6 +333,22 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         const int nz = (act.x != 0) + (act.y != 0) + (G4 ? (act.z != 0) + (act.w != 0) : 0);
         const bool ok = a0 <= 2u && a1 <= 2u && (!G4 || (a2 <= 2u && a3 <= 2u)) && nz <= 1;
         status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+        if (PN) {
+            bool redraw = false;
+            if (ok) redraw = np_random(env) < a.p_noise;
+            if (__builtin_amdgcn_ballot_w64(redraw) != 0) {
+                if (redraw) {
+                    for (int tries = 0;; tries++) {
+                        const int ind = np_integers(actg, acth, 0, G);
+                        const int val = np_integers(actg, acth, 0, 3) - 1;
+                        const i32x4 cand{ind == 0 ? val : 0, ind == 1 ? val : 0, ind == 2 ? val : 0, ind == 3 ? val : 0};
+                        const bool same = cand.x == act.x && cand.y == act.y && (!G4 || (cand.z == act.z && cand.w == act.w));
+                        if (!same) { act = cand; break; }
+                        if (tries > 4096) { status |= MDPP_STATUS_INTERNAL; break; }
+                    }
+                }
+            }
+        }
         const int c0 = (int)(cells & 0xFFu), c1 = (int)((cells >> 8) & 0xFFu);
         const int c2 = (int)((cells >> 16) & 0xFFu), c3 = (int)(cells >> 24);
         const int n0 = ok ? min(max(c0 + act.x, 0), m0) : c0, n1 = ok ? min(max(c1 + act.y, 0), m1) : c1;
@@ -330,10 +361,12 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         else r += on_target ? 1.0 : 0.0;
         phase = (phase + 1 >= every_n) ? 0u : phase + 1;          // steps % every_n, carried
         r = phase != 0 ? 0.0 : r;
+        if (RN) r += 0.0 + a.r_noise * np_standard_normal_lds(env, zig);
         r *= a.scale;
         r += a.shift;
         const bool done = (flags & 1u) != 0;
-        r += done ? a.term_add : 0.0;             // r is not -0.0 here (a +0.0 shift was just added), so + 0.0 is the identity
+        if (RN) { if (done) r += a.term_add; }    // (with noise r can be -0.0: add only where the reference does)
+        else r += done ? a.term_add : 0.0;        // r is not -0.0 here (a +0.0 shift was just added), so + 0.0 is the identity
         const bool tr = has_max && steps >= max_steps;
         uint32_t nc = (uint32_t)n0 | ((uint32_t)n1 << 8) | ((uint32_t)n2 << 16) | ((uint32_t)n3 << 24);
         const uint32_t so = (uint32_t)k;
@@ -378,6 +411,11 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         sp.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
     }
     sp.store(a.sp_s, i);
+    if (PN || RN) env.store(a.env_s, i);
+    if (PN) {
+        actg.store(a.act_s, i);
+        a.act_half[i] = make_uint2(acth.has32, acth.u32);
+    }
     a.state[i] = make_uint4(cells, steps, flags, 0u);
     if (status) atomicOr(&a.status[i], status);
 }
@@ -389,14 +427,23 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)
-    if (!a.philox && !noise && !getenv("MDPP_NO_GFAST") &&
+    if (!a.philox && !(noise && getenv("MDPP_NO_GFAST_NOISE")) && !getenv("MDPP_NO_GFAST") &&
         (unsigned long long)K * a.N * a.G * 8ULL < (1ULL << 32)) {
-#define MDPP_GF_LAUNCH(O64, G4, DN) hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN>), dim3(grid), dim3(kBlock), 0, s, a, K, \
-                                                       actions, obs, reward, term, trunc, final_obs)
-#define MDPP_GF_DN(O64, G4) do { if (a.make_denser) MDPP_GF_LAUNCH(O64, G4, true); else MDPP_GF_LAUNCH(O64, G4, false); } while (0)
+        const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
+#define MDPP_GF_LAUNCH(O64, G4, DN, PN_, RN_) hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN, PN_, RN_>), dim3(grid), dim3(kBlock), \
+                                                                 0, s, a, K, actions, obs, reward, term, trunc, final_obs)
+#define MDPP_GF_NZ(O64, G4, DN)                                                  \
+    do {                                                                         \
+        if (pn && rn) MDPP_GF_LAUNCH(O64, G4, DN, true, true);                   \
+        else if (pn) MDPP_GF_LAUNCH(O64, G4, DN, true, false);                   \
+        else if (rn) MDPP_GF_LAUNCH(O64, G4, DN, false, true);                   \
+        else MDPP_GF_LAUNCH(O64, G4, DN, false, false);                          \
+    } while (0)
+#define MDPP_GF_DN(O64, G4) do { if (a.make_denser) MDPP_GF_NZ(O64, G4, true); else MDPP_GF_NZ(O64, G4, false); } while (0)
         if (a.obs_i32) { if (a.G == 4) MDPP_GF_DN(false, true); else MDPP_GF_DN(false, false); }
         else { if (a.G == 4) MDPP_GF_DN(true, true); else MDPP_GF_DN(true, false); }
 #undef MDPP_GF_DN
+#undef MDPP_GF_NZ
 #undef MDPP_GF_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { h->err = std::string("k_grid_rollout_fast launch: ") + hipGetErrorString(e); return MDPP_EHIP; }

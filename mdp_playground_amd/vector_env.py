@@ -485,8 +485,7 @@ class RLToyVectorEnv:
             if getattr(self, "_image", None) is not None:
                 return "k_imagec_obs"
             m = self.mdps[0]
-            quiet = self.rng == "numpy" and not m.transition_noise and m.reward_noise is None
-            return "k_grid_rollout_fast" if quiet else "k_grid_step"
+            return "k_grid_rollout_fast" if self.rng == "numpy" else "k_grid_step"
         m = self.mdps[0]
         if getattr(self, "_image", None) is not None:
             return "k_imagec_obs"

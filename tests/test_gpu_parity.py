@@ -452,6 +452,13 @@ GRID_FAST = {
     "dense_2d_horizon": (dict(grid_shape=(6, 6), make_denser=True, target_point=[0, 0]), dict(max_episode_steps=9), 1024),
     "dense_2d_noreset": (dict(grid_shape=(4, 9), make_denser=True, target_point=[3, 8], term_state_reward=1.0),
                          dict(autoreset="disabled"), 777),
+    # noise: the env stream (noise trigger, reward normal) and the action space's stream (re-drawn action)
+    "pn_dense_2d": (dict(grid_shape=(8, 8), make_denser=True, target_point=[5, 5], transition_noise=0.3,
+                         term_state_reward=-0.25), {}, 1000),
+    "rn_sparse_2d": (dict(grid_shape=(5, 7), make_denser=False, target_point=[2, 4], reward_noise=0.4,
+                          reward_scale=2.0, reward_shift=0.5), {}, 512),
+    "pn_rn_4d_every2": (dict(grid_shape=(6, 9), make_denser=True, target_point=[1, 7], irrelevant_features=True,
+                             transition_noise=0.2, reward_noise=0.1, reward_every_n_steps=2), dict(max_episode_steps=11), 640),
 }
 
 
@@ -495,6 +502,7 @@ def test_grid_fast_rollout_kernel_vs_oracle(variant):
             obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(at))
             fin = None
         sp_end = env.get_rng_streams(capi.STREAM_SPACE)
+        env_end, act_end = env.get_rng_streams(capi.STREAM_ENV), env.get_rng_streams(capi.STREAM_ACTION)
         for i, o, ep in oracles:
             for t in range(K):
                 st, rr, d = o.step(acts[t, i])
@@ -509,6 +517,8 @@ def test_grid_fast_rollout_kernel_vs_oracle(variant):
                     ep[0] = 0
                 assert np.array_equal(obs[t, i], st), (variant, K, i, t)
             assert np.array_equal(o.get_rng()[1][:4], sp_end[i][:4]), (variant, K, i)
+            assert np.array_equal(o.get_rng()[0][:4], env_end[i][:4]), (variant, K, i)
+            assert np.array_equal(o.get_rng()[2], act_end[i]), (variant, K, i)       # incl. the buffered 32-bit half
     env.close()
 
 
