@@ -125,9 +125,10 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE) {
             TRY(alloc_zero(h, &h->d_rng_half, N * 8));
             // scratch of one batch of img_chunk env steps: states in, transform records in between
-            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * 4));
-            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * 4));
-            TRY(alloc_zero(h, &h->d_img_rec, 2 * (size_t)h->img_chunk * N * 64));
+            const size_t sub = cfg->irrelevant ? 2 : 1;       // images per observation (one per sub-space)
+            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * 4 * sub));
+            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * 4 * sub));
+            TRY(alloc_zero(h, &h->d_img_rec, 2 * (size_t)h->img_chunk * N * 64 * sub));
         }
     } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
@@ -167,8 +168,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         h->rbits_stride = (h->nkeys + 7u) / 8u;
         const size_t T = (size_t)cfg->num_tables;
         if (cfg->irrelevant) {
-            if (cfg->S_irr < 2 || cfg->S_irr > 255 || cfg->A_irr < 1 || cfg->image) {
-                g_create_err = "mdpp_create: irrelevant sub-space needs 2 <= S_irr <= 255, A_irr >= 1, no image observations";
+            if (cfg->S_irr < 2 || cfg->S_irr > 255 || cfg->A_irr < 1) {
+                g_create_err = "mdpp_create: irrelevant sub-space needs 2 <= S_irr <= 255, A_irr >= 1";
                 free_all(h); delete h; return MDPP_EUNSUPPORTED;
             }
             TRY(alloc_zero(h, &h->d_P1, T * cfg->S_irr * cfg->A_irr));
@@ -633,11 +634,12 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
             // batches of up to img_chunk env steps: one state kernel (states only, a few bytes per
             // env step), one transform-draw kernel, one render kernel over steps x envs images
             // (W*H bytes each)
-            const size_t N = (size_t)h->cfg.num_envs, isz = (size_t)h->cfg.img_w * h->cfg.img_h;
+            const size_t N = (size_t)h->cfg.num_envs, aw = h->cfg.irrelevant ? 2 : 1;
+            const size_t isz = aw * h->cfg.img_w * h->cfg.img_h;
             for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
                 const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
                 const size_t off = (size_t)k0 * N;
-                rc = launch_discrete_step(h, kc, (const int32_t *)actions + off, h->d_img_state_out,
+                rc = launch_discrete_step(h, kc, (const int32_t *)actions + off * aw, h->d_img_state_out,
                                           reward + off, term + off, trunc + off, h->d_img_state_final, s);
                 if (rc) return rc;
                 rc = launch_image_obs(h, kc, (const int32_t *)h->d_img_state_out,
@@ -714,10 +716,12 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
     const mdpp_config &c = h->cfg;
     if (n_radii != c.img_r_max - c.img_r_min + 1 || n_cls_x < 1 || n_cls_y < 1)
         return fail(h, MDPP_EINVAL, "upload_image_templates: radii/classes do not match the config");
-    if ((size_t)c.S * n_radii * n_cls_x * n_cls_y >= (1u << 20) || c.img_r_max > 1023 || c.img_w > 65535 || c.img_h > 65535)
+    // templates cover the states of the larger sub-space (state s is drawn as an (s + 3)-gon in either)
+    const size_t S = (size_t)((c.irrelevant && c.S_irr > c.S) ? c.S_irr : c.S);
+    if (S * n_radii * n_cls_x * n_cls_y >= (1u << 20) || c.img_r_max > 1023 || c.img_w > 65535 || c.img_h > 65535)
         return fail(h, MDPP_EUNSUPPORTED, "upload_image_templates: more than 2^20 templates, R > 1023 or a side > 65535");
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t S = (size_t)c.S, W = (size_t)c.img_w, H = (size_t)c.img_h;
+    const size_t W = (size_t)c.img_w, H = (size_t)c.img_h;
     const size_t tb = S * n_radii * n_cls_x * n_cls_y * (size_t)c.img_tpl_size * c.img_tpl_size;
     for (size_t k = 0; k < S * n_radii * W; k++)
         if (cls_x[k] >= n_cls_x) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_x out of range");

@@ -50,7 +50,9 @@ struct ImgRec {
 static_assert(sizeof(ImgRec) == 64, "ImgRec is read as two s_load_dwordx8");
 
 struct ImageArgs {
-    int32_t N, W, H, S;
+    int32_t N, W, H, S;        // S: states the templates cover (max over the sub-spaces)
+    int32_t SUB;               // images per observation: 2 with an irrelevant sub-space (one image per sub-space,
+                               // concatenated along x, get_image_representation :272-288), else 1
     int32_t has_scale, has_shift, has_rotate, has_flip, sh_quant, ro_quant;
     int32_t r0, r_min, r_max, tpl, n_radii, n_cls_x, n_cls_y, autoreset;
     double log_min_r, log_max_r;
@@ -175,8 +177,11 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
                                                        const uint8_t *__restrict__ mask) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.N) return;
+    const int SUB = a.SUB;
     if (mask && !mask[i]) {
-        for (int k = 0; k < K; k++) a.rec0[(long)k * a.N + i].meta = a.rec1[(long)k * a.N + i].meta = 1u << 11; // skip
+        for (int k = 0; k < K; k++)
+            for (int q = 0; q < SUB; q++)
+                a.rec0[((long)k * a.N + i) * SUB + q].meta = a.rec1[((long)k * a.N + i) * SUB + q].meta = 1u << 11; // skip
         return;
     }
     // all the reset flags of the batch in one round trip
@@ -192,22 +197,27 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
     Half32 h{hh.x, hh.y};
     const ShiftBounds sb = shift_bounds(a, a.r0);
     for (int k = 0; k < K; k++) {
-        const long j = (long)k * a.N + i;
+        const long j0 = ((long)k * a.N + i) * SUB;
         const bool two = (twos >> k) & 1u;
-        const Xform x0 = draw_xform(a, sb, g, h);
-        Xform x1 = x0;
-        if (two) x1 = draw_xform(a, sb, g, h);
-        if (REC) {
-            if (two) {
-                make_rec(a, x0, state_final[j], false, &a.rec1[j]);
-                make_rec(a, x1, state_out[j], true, &a.rec0[j]);
+        // the step's observation first (one image per sub-space, relevant then irrelevant), then --
+        // where the step ended the episode -- the images of reset()'s observation, in the same order
+        Xform x0[2], x1[2];
+        for (int q = 0; q < SUB; q++) x0[q] = draw_xform(a, sb, g, h);
+        for (int q = 0; q < SUB; q++) { x1[q] = x0[q]; if (two) x1[q] = draw_xform(a, sb, g, h); }
+        for (int q = 0; q < SUB; q++) {
+            const long j = j0 + q;
+            if (REC) {
+                if (two) {
+                    make_rec(a, x0[q], state_final[j], false, &a.rec1[j]);
+                    make_rec(a, x1[q], state_out[j], true, &a.rec0[j]);
+                } else {
+                    make_rec(a, x0[q], state_out[j], false, &a.rec0[j]);
+                    a.rec1[j].meta = 1u << 11;                                      // skip
+                }
             } else {
-                make_rec(a, x0, state_out[j], false, &a.rec0[j]);
-                a.rec1[j].meta = 1u << 11;                                          // skip
+                const uint2 p0 = xf_pack(x0[q]), p1 = xf_pack(x1[q]);
+                *(u32x4 *)a.rec0[j].pad = u32x4{p0.x, p0.y, p1.x, p1.y | (two ? 0x80000000u : 0u)};
             }
-        } else {
-            const uint2 p0 = xf_pack(x0), p1 = xf_pack(x1);
-            *(u32x4 *)a.rec0[j].pad = u32x4{p0.x, p0.y, p1.x, p1.y | (two ? 0x80000000u : 0u)};
         }
     }
     g.store(a.rng_s, i);
@@ -473,7 +483,9 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         h->err = "launch_image_obs: K outside the record scratch"; return MDPP_EINVAL;
     }
     ImageArgs a;
-    a.N = c.num_envs; a.W = c.img_w; a.H = c.img_h; a.S = c.S;
+    a.N = c.num_envs; a.W = c.img_w; a.H = c.img_h;
+    a.S = (c.irrelevant && c.S_irr > c.S) ? c.S_irr : c.S;
+    a.SUB = c.irrelevant ? 2 : 1;
     a.has_scale = c.img_has_scale; a.has_shift = c.img_has_shift; a.has_rotate = c.img_has_rotate;
     a.has_flip = c.img_has_flip; a.sh_quant = c.img_sh_quant > 0 ? c.img_sh_quant : 1;
     a.ro_quant = c.img_ro_quant > 0 ? c.img_ro_quant : 1;
@@ -488,13 +500,13 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.rng_half = (uint2 *)h->d_rng_half;
     a.tplp_data = (const uint8_t *)h->d_img_tplp; a.tplp = c.img_tpl_size + 2 * kImgPad;
     a.rec0 = (ImgRec *)h->d_img_rec;
-    a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs;
+    a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs * a.SUB;
     static_assert(kBlock == 256, "render_fast packs four 64-byte template columns into a 256-byte LDS row");
     if (K == 1) {
         hipLaunchKernelGGL(k_image_draw<true>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
                            state_final, term, trunc, mask);
     } else {
-        const long M = (long)K * a.N;
+        const long M = (long)K * a.N * a.SUB;
         hipLaunchKernelGGL(k_image_draw<false>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
                            state_final, term, trunc, mask);
         hipLaunchKernelGGL(k_image_rec, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, M,
@@ -502,7 +514,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     }
     if (img_out) {
         const int per_block = kBlock / 64;
-        const long M = (long)K * a.N;
+        const long M = (long)K * a.N * a.SUB;
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
         if (h->img_fast_ok && !getenv("MDPP_NO_IMGFAST")) {
             // 40 KiB of LDS per workgroup: 4 resident workgroups per CU

@@ -282,8 +282,6 @@ def build_discrete(config) -> DiscreteMDP:
                  "Currently, 1st sub-state (and action) space is assumed to be relevant to rewards "
                  "and 2nd one is irrelevant. Please provide a list with sizes for the 2.")
         A, A_irr = (int(x) for x in config["action_space_size"])
-        if config.get("image_representations", False):
-            raise NotImplementedError("image observations of Tuple (irrelevant_features) spaces are not built")
     else:
         _require(isinstance(config["action_space_size"], int),
                  "Did you mean to turn irrelevant_features? If so, please set irrelevant_features = "
@@ -304,8 +302,10 @@ def build_discrete(config) -> DiscreteMDP:
     # sub-space the two state spaces are wrapped in a TupleExtended seeded with
     # seed_dict["state_space"] (:725-728), and gymnasium's Tuple.seed(int) (third-party, 0.29 / 1.x)
     # re-seeds every sub-space: subseeds = Generator(seed).integers(int32 max, size=len(spaces)).
+    # With image observations the observation space is the ImageMultiDiscrete instead (:707-717): no
+    # Tuple is built, and the two state spaces keep the seeds they were constructed with.
     space_seeds = (sd["relevant_state_space"], sd.get("irrelevant_state_space"))
-    if irrelevant:
+    if irrelevant and not config.get("image_representations", False):
         subseeds = new_generator(sd["state_space"]).integers(np.iinfo(np.int32).max, size=2)
         space_seeds = (int(subseeds[0]), int(subseeds[1]))
     space_rng = new_generator(space_seeds[0])

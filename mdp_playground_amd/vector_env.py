@@ -161,7 +161,9 @@ class RLToyVectorEnv:
                 raise NotImplementedError("image observations need rng='numpy'")
             from . import image_obs
             im = m.image
-            self._image = image_obs.build_templates(m.S, im)
+            # (with an irrelevant sub-space the observation is one image per sub-space, side by side
+            # along x; state s is an (s + 3)-gon in either, so the templates cover the larger one)
+            self._image = image_obs.build_templates(max(m.S, m.S_irr) if self._irr else m.S, im)
             cfg.image, cfg.img_w, cfg.img_h = 1, im["width"], im["height"]
             tr = im["transforms"]
             cfg.img_has_scale, cfg.img_has_shift = int("scale" in tr), int("shift" in tr)
@@ -174,7 +176,7 @@ class RLToyVectorEnv:
             cfg.img_tpl_size = self._image["tpl_size"]
             cfg.obs_dtype = capi.OBS_IMAGE_U8
             self._obs_torch_dtype = torch.uint8
-            self.single_observation_space = ImageSpace(im["width"], im["height"])
+            self.single_observation_space = ImageSpace((2 if self._irr else 1) * im["width"], im["height"])
         self.transition_matrix = m.P
         self.rewardable_sequences = m.rewardable_sequences
         self.reward_matrix = m.reward_matrix               # use_custom_mdp with matrices (:1259-1267)
@@ -344,7 +346,7 @@ class RLToyVectorEnv:
             return tuple(lead) + (len(self.mdps[0].grid_shape),)
         if getattr(self, "_image", None) is not None:
             im = self.mdps[0].image
-            return tuple(lead) + (im["width"], im["height"], 1)
+            return tuple(lead) + ((2 if getattr(self, "_irr", False) else 1) * im["width"], im["height"], 1)
         if getattr(self, "_irr", False):
             return tuple(lead) + (2,)
         return tuple(lead)

@@ -825,7 +825,7 @@ def test_image_observations_vs_reference_golden(name):
     """BASELINE cfg 4 shape (84x84 shift+rotate) and a 100x100 all-transforms case: every pixel of
     every observation equals what the reference (Pillow polygon + rotate) produced."""
     g = gu.load(name)
-    E, T = g["action"].shape
+    E, T = g["action"].shape[:2]          # (i_irr: action pairs, one image per sub-space side by side)
     env = _venv(autoreset="same_step", **_seeds_or_cfg(name))
     assert np.array_equal(env._obs.cpu().numpy(), g["init_obs"])
     for t in range(T):
@@ -855,7 +855,19 @@ IMG_CFGS = {
     "rot64": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=6,
                   action_space_size=6, delay=0, image_representations=True, image_width=64,
                   image_height=64, image_transforms="rotate,flip"),
+    # an irrelevant sub-space: two images per observation from one stream (relevant, then irrelevant)
+    "irr84": dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 11],
+                  action_space_size=[8, 11], irrelevant_features=True, delay=0, image_representations=True,
+                  image_width=84, image_height=84, image_transforms="shift,rotate", image_sh_quant=1, image_ro_quant=1),
 }
+
+
+def _img_actions(cfg, shape, seed):
+    r = np.random.default_rng(seed)
+    A = cfg["action_space_size"]
+    if isinstance(A, list):
+        return np.stack([r.integers(0, a, size=shape) for a in A], axis=-1).astype(np.int32)
+    return r.integers(0, A, size=shape).astype(np.int32)
 
 
 @pytest.mark.parametrize("name", sorted(IMG_CFGS))
@@ -869,8 +881,7 @@ def test_image_fused_rollout_equals_single_steps(name):
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     assert a.rollout_kernel_name(K) == ("k_image_obs" if name == "all100" else "k_image_obs_fast")
-    acts = torch.as_tensor(np.random.default_rng(2).integers(0, cfg["action_space_size"], size=(K, N)).astype(np.int32),
-                           device=a.device)
+    acts = torch.as_tensor(_img_actions(cfg, (K, N), 2), device=a.device)
     obs, rew, term, trunc = a.rollout(acts)
     assert term.any() and not term.all()
     for t in range(K):
@@ -888,20 +899,50 @@ def test_image_batch_vs_oracle(name):
     """A few thousand images (all states, hundreds of distinct angles/shifts) against the oracle's
     draw + Pillow-exact rotate restatement, for the observation, the terminal observation of a
     step that ends in a reset, and the first observation after it."""
-    from test_image_oracle import _render
+    from test_image_oracle import _render, _render_obs
     from mdp_playground_amd import _capi as capi, image_obs, mdp
     cfg = dict(IMG_CFGS[name], seed=9)
     N, T = 192, 12
     env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    m = mdp.build_mdp(cfg)
+    words = env.get_rng_streams(capi.STREAM_IMAGE).copy()
+    acts = _img_actions(cfg, (T, N), 4)
+    if m.irrelevant:
+        # (no integer-observation twin here: without images the reference re-seeds the two state spaces
+        # through the Tuple space, so the twin would be a different MDP.)  States after the step come
+        # from get_augmented_state(); the terminal observation's state is the terminal pair whose
+        # rendering, from the same stream position, equals it.
+        tpl = image_obs.build_templates(max(m.S, m.S_irr), m.image)
+        n_final = 0
+        for t in range(T):
+            obs, rew, term, trunc, info = env.step(torch.as_tensor(acts[t], device=env.device))
+            obs, fin, d = obs.cpu().numpy(), info["final_obs"].cpu().numpy(), term.cpu().numpy().astype(bool)
+            st = env.get_augmented_state()["curr_state"]
+            for i in range(N):
+                if d[i]:
+                    ok = False
+                    for s0 in m.terminal_states:
+                        for s1 in range(m.S_irr):
+                            w2 = words[i].copy()
+                            if np.array_equal(_render_obs(m.image, tpl, (int(s0), s1), w2), fin[i]):
+                                words[i] = w2
+                                ok = True
+                                break
+                        if ok:
+                            break
+                    assert ok, (name, t, i)
+                    n_final += 1
+                assert np.array_equal(_render_obs(m.image, tpl, st[i], words[i]), obs[i]), (name, t, i)
+        assert n_final > 50
+        assert np.array_equal(words, env.get_rng_streams(capi.STREAM_IMAGE))
+        env.close()
+        return
     twin_cfg = {k: v for k, v in cfg.items() if not k.startswith("image_")}
     twin = _venv(num_envs=N, autoreset="same_step", **twin_cfg)      # same states, integer observations
-    m = mdp.build_mdp(cfg)
     tpl = image_obs.build_templates(m.S, m.image)
     # stream position BEFORE the constructor's reset drew the first observation is not exported;
     # start from the current one: the next draws are those of step 0
-    words = env.get_rng_streams(capi.STREAM_IMAGE).copy()
     assert np.array_equal(twin._obs.cpu().numpy().shape, (N,))
-    acts = np.random.default_rng(4).integers(0, cfg["action_space_size"], size=(T, N)).astype(np.int32)
     n_final = 0
     for t in range(T):
         at = torch.as_tensor(acts[t], device=env.device)

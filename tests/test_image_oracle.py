@@ -35,27 +35,35 @@ def _render(im, t, state, rng_words):
     return ora.image_rotate_flip_transpose(src, angle, flip)[:, :, None]
 
 
+def _render_obs(im, t, state, rng_words):
+    """The observation of a (multi-)discrete state: one image per sub-space, drawn in order from the
+    same stream and concatenated along x (get_image_representation, image_multi_discrete.py:272-288)."""
+    subs = np.atleast_1d(state)
+    return np.concatenate([_render(im, t, int(s), rng_words) for s in subs], axis=0)
+
+
 @pytest.mark.parametrize("name", gu.IMAGE)
 def test_oracle_images_match_reference(name):
     g = gu.load(name)
-    E, T = g["action"].shape
+    E, T = g["action"].shape[:2]
     for e in range(E):
         m = mdp.build_mdp(gu.case_config(name, e))
-        t = image_obs.build_templates(m.S, m.image)
+        sizes = [m.S, m.S_irr] if m.irrelevant else [m.S]
+        t = image_obs.build_templates(max(sizes), m.image)
         words = ora.pcg_words(mdp.new_generator(m.image["seed"]))   # fresh image-space generator
-        init = _render(m.image, t, int(g["init_state"][e]), words)
+        init = _render_obs(m.image, t, g["init_state"][e], words)
         assert np.array_equal(init, g["init_obs"][e])
         assert np.array_equal(words, g["rng_image"][e])
         for step in range(T):
-            img = _render(m.image, t, int(g["curr_state"][e, step]), words)
+            img = _render_obs(m.image, t, g["curr_state"][e, step], words)
             assert np.array_equal(img, g["obs"][e, step]), (name, e, step)
             if g["reset_after"][e, step]:
                 # the fixture does not record the post-reset state: it is the one whose rendering
                 # reproduces reset_obs from the current stream position
                 ok = False
-                for s in range(m.S):
+                for s in np.ndindex(*sizes):
                     w2 = words.copy()
-                    if np.array_equal(_render(m.image, t, s, w2), g["reset_obs"][e, step]):
+                    if np.array_equal(_render_obs(m.image, t, s, w2), g["reset_obs"][e, step]):
                         words[:] = w2
                         ok = True
                         break

@@ -157,6 +157,13 @@ CASES = {
                     irrelevant_features=True, delay=0, sequence_length=3,
                     maximally_connected=False, transition_noise=0.1),
         seeds=list(range(4)), T=150, reset="on_done"),
+    # --- image observations of Tuple spaces: one polygon image per sub-space, side by side --------
+    "i_irr": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=[8, 11], action_space_size=[8, 11], irrelevant_features=True,
+                    delay=0, image_representations=True, image_width=84, image_height=84,
+                    image_transforms="shift,rotate,flip", image_sh_quant=2, image_ro_quant=3),
+        seeds=list(range(3)), T=24, reset="on_done"),
     # --- grid envs: 2-D, delay 0, sequence_length 1 (anything else raises
     # inside the reference's reward_function) --------------------------------------------------
     "g_dense": dict(      # the env of the reference's test_grid_env (:1057-1110)
