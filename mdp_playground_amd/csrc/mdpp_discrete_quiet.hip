@@ -68,7 +68,6 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     __shared__ uint32_t s_done;                                         // E waves that have finished
     __shared__ uint64_t s_ki[RN ? 256 : 1];
     __shared__ double s_wi[RN ? 256 : 1], s_fi[RN ? 256 : 1];
-    static_assert(!(IRR && (PN || RN)), "noise with an irrelevant sub-space runs on the general kernel");
     static_assert(!(RN && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
@@ -88,11 +87,20 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     const uint32_t S8 = ((uint32_t)a.S + 7u) & ~7u, S18 = IRR ? (((uint32_t)a.S1 + 7u) & ~7u) : 0u;
     const uint32_t lds_T1 = lds_T0 + S8 * 8u;
     const uint32_t lds_TN = lds_T1 + S18 * 8u;                 // PN: S rows of S8 thresholds of the noise categoricals
+    const uint32_t lds_TN1 = lds_TN + (PN ? (uint32_t)a.S * S8 * 8u : 0u);   // ... and S1 rows of S18 for the irrelevant sub-space
+    const uint32_t lds_end = lds_TN1 + ((PN && IRR) ? (uint32_t)a.S1 * S18 * 8u : 0u);
     if (PN) {
         for (uint32_t k = tid; k < (uint32_t)a.S * S8; k += kThreads) {
             const uint32_t row = k / S8, col = k - row * S8;
             ((uint64_t *)(lds + lds_TN))[k] =
                 col < (uint32_t)a.S ? (uint64_t)ceil(a.noise_cdf[row * (uint32_t)a.S + col] * 9007199254740992.0) : ~0ULL;
+        }
+        if (IRR) {
+            for (uint32_t k = tid; k < (uint32_t)a.S1 * S18; k += kThreads) {
+                const uint32_t row = k / S18, col = k - row * S18;
+                ((uint64_t *)(lds + lds_TN1))[k] =
+                    col < (uint32_t)a.S1 ? (uint64_t)ceil(a.noise_cdf1[row * (uint32_t)a.S1 + col] * 9007199254740992.0) : ~0ULL;
+            }
         }
     }
     for (uint32_t k = tid; k < S8; k += kThreads)
@@ -115,11 +123,11 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     if (tid == 0) s_done = 0;
     __syncthreads();
     // DUO: the record ring follows the tables in dynamic LDS
-    uint64_t *ring = (uint64_t *)(lds + ((lds_TN + (PN ? (uint32_t)a.S * S8 * 8u : 0u) + 15u) & ~15u));
+    uint64_t *ring = (uint64_t *)(lds + ((lds_end + 15u) & ~15u));
     double *ringz = (double *)(ring + kDepth * kBlock);         // RN: the step's standard normal
     const uint8_t *P = lds + a.lds_P, *is_term = lds + a.lds_term, *rbits = lds + a.lds_rew, *P1 = lds + lds_P1;
     const uint64_t *T0 = (const uint64_t *)(lds + lds_T0), *T1 = (const uint64_t *)(lds + lds_T1);
-    const uint64_t *TN = (const uint64_t *)(lds + lds_TN);
+    const uint64_t *TN = (const uint64_t *)(lds + lds_TN), *TN1 = (const uint64_t *)(lds + lds_TN1);
 
     const uint32_t i = blockIdx.x * kBlock + l;
     if (!DUO && i >= (uint32_t)a.N) return;            // (DUO launches have full blocks only)
@@ -128,9 +136,10 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
     uint32_t steps = st.z, ringbits = st.w, status = 0;
     uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
-    Pcg64 g, sp;
+    Pcg64 g, sp, sp1;
     g.load(a.env_s, a.env_inc, i);
     if (PN) sp.load(a.sp_s, a.sp_inc, i);
+    if (PN && IRR) sp1.load(a.sp1_s, a.sp1_inc, i);
     // sequence key over the last L states, carried: key' = (key - oldest * S^(L-1)) * S + new
     uint32_t spow = 1;
     for (uint32_t j = 1; j < L; j++) spow *= S;
@@ -314,6 +323,16 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             bad1 = (action1 < 0 || action1 >= a.A1) ? 1u : 0u;
             action1 = bad1 ? 0 : action1;
             cur1 = P1[cur1 * (uint32_t)a.A1 + (uint32_t)action1];
+            if (PN) {                                                        // its own P-noise stream (:2066-2080)
+                const uint64_t m1 = sp1.next64() >> 11;
+                const uint64_t *row = TN1 + cur1 * S18;
+                uint32_t c = 0;
+                for (uint32_t b = 0; b < S18; b += 8) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) c += (row[b + j] <= m1) ? 1u : 0u;
+                }
+                cur1 = c;
+            }
         }
         status |= (bad || bad1) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
         if (RN) z = np_standard_normal_lds(g, zig);                         // D6: drawn in reward_function, before any reset
@@ -465,6 +484,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         }
     }
     if (PN && isE) sp.store(a.sp_s, i);
+    if (PN && IRR && isE) sp1.store(a.sp1_s, i);
     if (TRIO && role == 0) {
         // tell H how many of its start states were really used, then that this wave is through
         __hip_atomic_store(&s_head[l], (head16 - qn) & 0xFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -512,13 +532,14 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     if (a.philox || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || getenv("MDPP_NO_QUIET"))
         return false;
     const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
-    if ((pn || rn) && (a.irr || getenv("MDPP_NO_QUIET_NOISE"))) return false;
+    if ((pn || rn) && getenv("MDPP_NO_QUIET_NOISE")) return false;
     const unsigned long long bytes = (unsigned long long)K * a.N * (a.irr ? 2 : 1) * 8ULL;
     if (bytes >= (1ULL << 32)) return false;                    // buffer descriptors address < 4 GiB per array
     const size_t S8 = (size_t)((a.S + 7) & ~7);
     size_t lds = a.lds_bytes;
     lds = ((lds + (a.irr ? (size_t)a.S1 * a.A1 : 0) + 15) & ~(size_t)15) + S8 * 8 + (a.irr ? (size_t)((a.S1 + 7) & ~7) * 8 : 0);
     if (pn) lds += (size_t)a.S * S8 * 8;                        // thresholds of the S noise categoricals
+    if (pn && a.irr) lds += (size_t)a.S1 * ((a.S1 + 7) & ~7) * 8;
     if (lds > 60 * 1024) return false;
     // two / three waves per SIMD (E / O / H roles) when the blocks are full and the rollout is long
     // enough to fill the ring
@@ -535,15 +556,15 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
         else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_>(MDPP_Q_ARGS);                     \
         else quiet_launch<O64, IR, 1, PN_, RN_>(MDPP_Q_ARGS);                                     \
     } while (0)
-#define MDPP_Q_NOISE(O64)                                                                         \
+#define MDPP_Q_NOISE(O64, IR)                                                                     \
     do {                                                                                          \
-        if (a.irr) MDPP_Q_ROLES(O64, true, false, false);                                         \
-        else if (pn && rn) MDPP_Q_ROLES(O64, false, true, true);                                  \
-        else if (pn) MDPP_Q_ROLES(O64, false, true, false);                                       \
-        else if (rn) MDPP_Q_ROLES(O64, false, false, true);                                       \
-        else MDPP_Q_ROLES(O64, false, false, false);                                              \
+        if (pn && rn) MDPP_Q_ROLES(O64, IR, true, true);                                          \
+        else if (pn) MDPP_Q_ROLES(O64, IR, true, false);                                          \
+        else if (rn) MDPP_Q_ROLES(O64, IR, false, true);                                          \
+        else MDPP_Q_ROLES(O64, IR, false, false);                                                 \
     } while (0)
-    if (a.obs_i32) MDPP_Q_NOISE(false); else MDPP_Q_NOISE(true);
+    if (a.irr) { if (a.obs_i32) MDPP_Q_NOISE(false, true); else MDPP_Q_NOISE(true, true); }
+    else { if (a.obs_i32) MDPP_Q_NOISE(false, false); else MDPP_Q_NOISE(true, false); }
 #undef MDPP_Q_NOISE
 #undef MDPP_Q_ROLES
 #undef MDPP_Q_ARGS

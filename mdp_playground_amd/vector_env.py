@@ -476,9 +476,7 @@ class RLToyVectorEnv:
             if not self.uses_fast_kernel:
                 # mirrors launch_discrete_quiet (mdpp_discrete_quiet.hip)
                 c = self._cfg
-                noisy = bool(c.has_transition_noise or c.has_reward_noise)
-                quiet = (self.rng == "numpy" and not self._per_env and c.unit_rewards and K >= 16
-                         and not (noisy and self._irr))
+                quiet = self.rng == "numpy" and not self._per_env and c.unit_rewards and K >= 16
                 return "k_discrete_rollout_quiet" if quiet else "k_discrete_step"
             if K >= 32 and full_blocks and self.autoreset == "same_step":
                 return "k_discrete_rollout_pipe"

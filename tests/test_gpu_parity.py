@@ -204,6 +204,10 @@ QUIET = {
                    reward_shift=-0.5, term_state_reward=1.0), {}, 512),
     "pn_rn_ragged": (dict(state_space_size=10, action_space_size=10, sequence_length=1, delay=0, transition_noise=0.1,
                           reward_noise=1.5), {}, 700),
+    "irr_pn_rn": (dict(state_space_size=[8, 6], action_space_size=[8, 6], irrelevant_features=True, delay=1,
+                       sequence_length=2, transition_noise=0.2, reward_noise=0.3), {}, 512),
+    "irr_pn_ragged": (dict(state_space_size=[6, 12], action_space_size=[6, 12], irrelevant_features=True, delay=0,
+                           sequence_length=1, transition_noise=0.35), {}, 333),
     "pn_rn0_horizon": (dict(state_space_size=20, action_space_size=20, sequence_length=2, delay=2, transition_noise=0.4,
                             reward_noise=0.0, reward_every_n_steps=1), dict(max_episode_steps=9), 256),
 }
@@ -269,6 +273,8 @@ def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
                 assert np.array_equal(obs[t, i], np.asarray(st)), (variant, K, i, t)
             assert np.array_equal(o.get_rng()[0][:4], env_end[i][:4]), (variant, K, i)
             assert np.array_equal(o.get_rng()[1][:4], sp_end[i][:4]), (variant, K, i)
+            if m.irrelevant:
+                assert np.array_equal(o.get_rng_irr()[:4], env.get_rng_streams(capi.STREAM_SPACE_IRR)[i][:4]), (variant, K, i)
     env.close()
 
 
