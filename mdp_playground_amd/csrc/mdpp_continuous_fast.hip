@@ -48,7 +48,8 @@ constexpr uint32_t kCSpinLimit = 1u << 22;
 constexpr uint32_t kCStatusInternal = 0x80000000u;
 
 // GEN: the general reward post-processing and episode ends -- delay line (C7, :1968-1973), every-n
-// mask (:1975), terminal hypercubes (C8, :945-952; reset() resamples out of them, :2284-2307).  With
+// mask (:1975), terminal hypercubes (C8, :945-952; reset() resamples out of them, :2284-2307), and
+// unbounded state boxes (reset() samples normals).  With
 // these the reference's reward changes between np.float32 and Python-float arithmetic from step to
 // step (k_continuous_step's CRew); without them it is float32 throughout, and that path stays as lean
 // as it was.
@@ -429,7 +430,9 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                 Pcg64 sp;
                 sp.load(a.sp_s, a.sp_inc, i);
                 for (int tries = 0;; tries++) {
-                    if (a.bounded) {
+                    // (unbounded boxes are served by the GEN instantiations, so that the plain kernels do not
+                    // carry the normal sampler)
+                    if (!GEN || a.bounded) {
 #pragma unroll
                         for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));
                     } else if (D <= 4) {                      // unbounded Box: gymnasium samples a standard normal
@@ -557,7 +560,7 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
 template <int D, int ORDER, int NREL>
 static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
-    if (a.delay > 0 || a.every_n != 1 || a.n_boxes > 0)
+    if (a.delay > 0 || a.every_n != 1 || a.n_boxes > 0 || !a.bounded)
         launch_g<D, ORDER, NREL, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
     else
         launch_g<D, ORDER, NREL, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
