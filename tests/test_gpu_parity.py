@@ -275,6 +275,7 @@ def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
             assert np.array_equal(o.get_rng()[1][:4], sp_end[i][:4]), (variant, K, i)
             if m.irrelevant:
                 assert np.array_equal(o.get_rng_irr()[:4], env.get_rng_streams(capi.STREAM_SPACE_IRR)[i][:4]), (variant, K, i)
+    assert int(env.status().sum()) == 0          # no bad action, and no bounded wait of the role hand-offs expired
     env.close()
 
 
