@@ -72,6 +72,9 @@ def load():
         raise MdppError(
             f"{LIB_PATH} is missing: build it with `python -m mdp_playground_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    # PyTorch-ROCm ships its own libamdhip64: load it first, so that the library binds to the HIP
+    # runtime the tensors live in (a second copy of the runtime in one process sees no device)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):
