@@ -58,6 +58,9 @@ static void free_all(mdpp_env *h) {
         if (h->d_rng_inc[s]) (void)hipFree(h->d_rng_inc[s]);
     }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    for (hipEvent_t e : {h->ev_entry, h->ev_side[0], h->ev_side[1], h->ev_render[0], h->ev_render[1]})
+        if (e) (void)hipEventDestroy(e);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
 }
 
@@ -106,6 +109,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) { h->d_rng_s[s] = h->d_rng_inc[s] = nullptr; h->streams_ready[s] = false; }
     h->tables_ready = false;
     h->ev0 = h->ev1 = nullptr;
+    h->side_stream = nullptr;
+    h->ev_entry = h->ev_side[0] = h->ev_side[1] = h->ev_render[0] = h->ev_render[1] = nullptr;
     const size_t N = (size_t)cfg->num_envs;
     int rc = MDPP_OK;
 #define TRY(x) do { rc = (x); if (rc != MDPP_OK) { g_create_err = h->err; free_all(h); delete h; return rc; } } while (0)
@@ -126,9 +131,13 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             TRY(alloc_zero(h, &h->d_rng_half, N * 8));
             // scratch of one batch of img_chunk env steps: states in, transform records in between
             const size_t sub = cfg->irrelevant ? 2 : 1;       // images per observation (one per sub-space)
-            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * 4 * sub));
-            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * 4 * sub));
-            TRY(alloc_zero(h, &h->d_img_rec, 2 * (size_t)h->img_chunk * N * 64 * sub));
+            // two sets of everything: batch b + 1 is prepared while batch b is rendered
+            TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * 4 * sub));
+            TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * 4 * sub));
+            TRY(alloc_zero(h, &h->d_img_rec, 2 * 2 * (size_t)h->img_chunk * N * 64 * sub));
+            TRYHIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&h->ev_entry, &h->ev_side[0], &h->ev_side[1], &h->ev_render[0], &h->ev_render[1]})
+                TRYHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
     } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
@@ -636,6 +645,37 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
             // (W*H bytes each)
             const size_t N = (size_t)h->cfg.num_envs, aw = h->cfg.irrelevant ? 2 : 1;
             const size_t isz = aw * h->cfg.img_w * h->cfg.img_h;
+            const int nb = (K + h->img_chunk - 1) / h->img_chunk;
+            if (nb >= 2 && h->side_stream && !getenv("MDPP_NO_IMG_OVERLAP")) {
+                // Pipelined: the state, draw and record kernels of batch b + 1 (latency-bound, a few
+                // dozen waves) run on the side stream while the persistent renderer of batch b owns
+                // the memory system.  The side stream starts behind everything already queued on `s`,
+                // every side batch is waited for by its renderer on `s` (so the work is joined back
+                // into `s`), and a scratch set is reused only after its renderer has finished.
+                hipStream_t s2 = h->side_stream;
+                const size_t sset = (size_t)h->img_chunk * N * aw;        // int32 per scratch set
+                HIPCHK(h, hipEventRecord(h->ev_entry, s));
+                HIPCHK(h, hipStreamWaitEvent(s2, h->ev_entry, 0));
+                for (int b = 0; b < nb; b++) {
+                    const int k0 = b * h->img_chunk, buf = b & 1;
+                    const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
+                    const size_t off = (size_t)k0 * N;
+                    int32_t *so = (int32_t *)h->d_img_state_out + buf * sset, *sf = (int32_t *)h->d_img_state_final + buf * sset;
+                    if (b >= 2) HIPCHK(h, hipStreamWaitEvent(s2, h->ev_render[buf], 0));
+                    rc = launch_discrete_step(h, kc, (const int32_t *)actions + off * aw, so, reward + off, term + off,
+                                              trunc + off, sf, s2);
+                    if (rc) return rc;
+                    rc = launch_image_obs(h, kc, so, sf, term + off, trunc + off, nullptr, nullptr, nullptr, s2, 1, buf);
+                    if (rc) return rc;
+                    HIPCHK(h, hipEventRecord(h->ev_side[buf], s2));
+                    HIPCHK(h, hipStreamWaitEvent(s, h->ev_side[buf], 0));
+                    rc = launch_image_obs(h, kc, so, sf, term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
+                                          final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s, 2, buf);
+                    if (rc) return rc;
+                    HIPCHK(h, hipEventRecord(h->ev_render[buf], s));
+                }
+                return MDPP_OK;
+            }
             for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
                 const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
                 const size_t off = (size_t)k0 * N;

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
 // draw only (the reference's reset()/step() consume the variates whether or not anyone looks).
 int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
-                     uint8_t *img_out, uint8_t *img_final, hipStream_t s) {
+                     uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase, int buf) {
     const mdpp_config &c = h->cfg;
     if (K < 1 || K > h->img_chunk || K > kImgChunk || (mask && K != 1)) {
         h->err = "launch_image_obs: K outside the record scratch"; return MDPP_EINVAL;
@@ -499,10 +499,12 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.rng_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_IMAGE];
     a.rng_half = (uint2 *)h->d_rng_half;
     a.tplp_data = (const uint8_t *)h->d_img_tplp; a.tplp = c.img_tpl_size + 2 * kImgPad;
-    a.rec0 = (ImgRec *)h->d_img_rec;
+    a.rec0 = (ImgRec *)h->d_img_rec + (size_t)buf * 2 * h->img_chunk * c.num_envs * a.SUB;
     a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs * a.SUB;
     static_assert(kBlock == 256, "render_fast packs four 64-byte template columns into a 256-byte LDS row");
-    if (K == 1) {
+    if (!(phase & 1)) {
+        // records of this batch were made earlier (side stream)
+    } else if (K == 1) {
         hipLaunchKernelGGL(k_image_draw<true>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
                            state_final, term, trunc, mask);
     } else {
@@ -512,13 +514,19 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         hipLaunchKernelGGL(k_image_rec, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, M,
                            state_out, state_final);
     }
-    if (img_out) {
+    if (img_out && (phase & 2)) {
         const int per_block = kBlock / 64;
         const long M = (long)K * a.N * a.SUB;
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
         if (h->img_fast_ok && !getenv("MDPP_NO_IMGFAST")) {
             // 40 KiB of LDS per workgroup: 4 resident workgroups per CU
-            const unsigned resident = 4u * (unsigned)h->num_cus;
+            // (phase 2 = the pipelined rollout: a few CUs keep a slot free, so that the next batch's state
+            // kernel, which needs a little LDS, can run beside this one)
+            // as many slots as the state kernel has workgroups (measured on cfg4, 32 of them: 16 reserved
+            // slots give no overlap at all, 32 and 64 the same +13 %, 128 less), at most 64
+            unsigned reserve = ((unsigned)a.N + kBlock - 1) / kBlock;
+            reserve = reserve < 8u ? 8u : (reserve > 64u ? 64u : reserve);
+            const unsigned resident = 4u * (unsigned)h->num_cus - (phase == 2 ? reserve : 0u);
             const dim3 grid(nblk < resident ? nblk : resident);
             const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);
             for (int pass = 0; pass < (img_final ? 2 : 1); pass++) {

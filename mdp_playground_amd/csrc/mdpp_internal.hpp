@@ -148,6 +148,10 @@ struct mdpp_env {
     uint32_t nkeys, rbits_stride;
     bool tables_ready, streams_ready[MDPP_NUM_STREAMS];
     hipEvent_t ev0, ev1;
+    // image rollouts: the next batch's state / draw / record kernels run on a side stream under the
+    // rendering of the current batch (two scratch sets, events both ways; mdpp_capi.hip)
+    hipStream_t side_stream;
+    hipEvent_t ev_entry, ev_side[2], ev_render[2];
     mdpp::DiscreteArgs dargs;
     mdpp::ContinuousArgs cargs;
     mdpp::GridArgs gargs;
@@ -174,7 +178,8 @@ int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
                      uint8_t *trunc, void *final_obs, hipStream_t s);
 int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
+// phase: 1 = draw + records only, 2 = render only, 3 = both; buf: scratch set (0 / 1)
 int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
-                     uint8_t *img_out, uint8_t *img_final, hipStream_t s);
+                     uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase = 3, int buf = 0);
 } // namespace mdpp
