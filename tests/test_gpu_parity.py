@@ -1417,13 +1417,15 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     a.close(); b.close()
 
 
-def test_rollout_is_graph_capturable():
+@pytest.mark.parametrize("what", ["states", "images"])
+def test_rollout_is_graph_capturable(what):
     """include/mdpp.h promises that nothing is allocated inside mdpp_step / mdpp_step_n: a fused
     rollout can be captured into a HIP graph and replayed.  (The handle's step counter travels by
     value, so a replayed graph is exact for numpy-stream handles with unit rewards — the counter only
-    feeds Philox keys and the key ring of non-unit rewards.)"""
-    cfg = _cfg("d_cfg2", 23)
-    N, K = 4096, 64
+    feeds Philox keys and the key ring of non-unit rewards.)  "images": the two-stream batch pipeline
+    of image rollouts forks to the handle's side stream and joins back inside the capture."""
+    cfg = _cfg("d_cfg2", 23) if what == "states" else dict(IMG_CFGS["cfg4"], seed=23)
+    N, K = (4096, 64) if what == "states" else (512, 40)
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     acts = torch.randint(0, 8, (K, N), device=a.device, dtype=torch.int32)
