@@ -4,7 +4,8 @@
  * DEVICE pointer owned by the caller (the Python layer passes torch tensors'
  * data_ptr()); every `*_host` pointer is host memory.  All work is enqueued on the
  * caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
- * stream) and is asynchronous with respect to the host.  The library owns only its
+ * stream) and is asynchronous with respect to the host (image rollouts additionally fork to a side
+ * stream owned by the handle and join back into the caller's stream before they return).  The library owns only its
  * per-env state and tables (freed by mdpp_destroy); nothing is allocated inside
  * mdpp_step / mdpp_step_n / mdpp_reset, so they can be captured into a HIP graph
  * (tests/test_gpu_parity.py::test_rollout_is_graph_capturable).  The handle's step counter
