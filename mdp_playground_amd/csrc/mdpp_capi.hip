@@ -135,9 +135,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * 4 * sub));
             TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * 4 * sub));
             TRY(alloc_zero(h, &h->d_img_rec, 2 * 2 * (size_t)h->img_chunk * N * 64 * sub));
-            TRYHIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-            for (hipEvent_t *e : {&h->ev_entry, &h->ev_side[0], &h->ev_side[1], &h->ev_render[0], &h->ev_render[1]})
-                TRYHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+
         }
     } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
@@ -154,6 +152,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         g_create_err = "mdpp_create: ImageContinuous observations need 2 or 4 bounded state dimensions, "
                        "width * height divisible by 16 and a disc radius of 1..15";
         free_all(h); delete h; return MDPP_EUNSUPPORTED;
+    }
+    if (cfg->image) {      // image rollouts pipeline their batches over a side stream (step_common)
+        TRYHIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&h->ev_entry, &h->ev_side[0], &h->ev_side[1], &h->ev_render[0], &h->ev_render[1]})
+            TRYHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     if (cfg->kind == MDPP_KIND_DISCRETE) {
         if (cfg->S < 2 || cfg->S > 255 || cfg->A < 1 || cfg->L < 1 || cfg->L > 7) {
@@ -307,8 +310,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             a.image_quirk = cfg->image ? 1 : 0;
         }
         if (cfg->image) {   // scratch of one batch of img_chunk env steps: the states the pictures are made from
-            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * D * sizeof(float)));
-            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * D * sizeof(float)));
+            TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * D * sizeof(float)));     // two sets (pipeline)
+            TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * D * sizeof(float)));
         }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
@@ -330,8 +333,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         TRY(alloc_zero(h, &h->d_state, N * sizeof(uint4)));
         if (cfg->image) {   // scratch of one batch of img_chunk env steps: the cells the pictures are made from
-            TRY(alloc_zero(h, &h->d_img_state_out, (size_t)h->img_chunk * N * cfg->grid_dims * 4));
-            TRY(alloc_zero(h, &h->d_img_state_final, (size_t)h->img_chunk * N * cfg->grid_dims * 4));
+            TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * cfg->grid_dims * 4));     // two sets (pipeline)
+            TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * cfg->grid_dims * 4));
             TRY(alloc_zero(h, &h->d_img_tpl, (size_t)(cfg->grid_dims / 2) * cfg->img_w * cfg->img_h / 16 * 2));   // grid-line bits
         }
         GridArgs &a = h->gargs;
@@ -630,6 +633,39 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
     return launch_continuous_reset(h, mask_dev, (float *)obs_dev, s);
 }
 
+// Image rollouts run as batches of up to img_chunk steps.  With two or more batches they form a
+// two-stage pipeline: `prepare` (the state kernel of batch b + 1, and for polygon images its draw and
+// record kernels: latency-bound, a few dozen waves) goes to the handle's side stream while `render`
+// of batch b owns the memory system on the caller's stream.  The side stream starts behind everything
+// already queued on `s`, every prepared batch is waited for by its renderer on `s` (so all work is
+// joined back into `s`, also under graph capture), and a scratch set (buf = b & 1) is reused only
+// after its renderer has finished.
+template <class Prepare, class Render>
+static int image_batches(mdpp_env *h, int K, hipStream_t s, Prepare prepare, Render render) {
+    const int nb = (K + h->img_chunk - 1) / h->img_chunk;
+    const bool overlap = nb >= 2 && h->side_stream && !getenv("MDPP_NO_IMG_OVERLAP");
+    hipStream_t s2 = overlap ? h->side_stream : s;
+    if (overlap) {
+        HIPCHK(h, hipEventRecord(h->ev_entry, s));
+        HIPCHK(h, hipStreamWaitEvent(s2, h->ev_entry, 0));
+    }
+    for (int b = 0; b < nb; b++) {
+        const int k0 = b * h->img_chunk, buf = overlap ? (b & 1) : 0;
+        const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
+        if (overlap && b >= 2) HIPCHK(h, hipStreamWaitEvent(s2, h->ev_render[buf], 0));
+        int rc = prepare(k0, kc, buf, s2);
+        if (rc) return rc;
+        if (overlap) {
+            HIPCHK(h, hipEventRecord(h->ev_side[buf], s2));
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_side[buf], 0));
+        }
+        rc = render(k0, kc, buf, s, overlap);
+        if (rc) return rc;
+        if (overlap) HIPCHK(h, hipEventRecord(h->ev_render[buf], s));
+    }
+    return MDPP_OK;
+}
+
 static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float *reward,
                        uint8_t *term, uint8_t *trunc, void *final_obs, void *stream) {
     if (!h) return MDPP_EINVAL;
@@ -645,50 +681,30 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
             // (W*H bytes each)
             const size_t N = (size_t)h->cfg.num_envs, aw = h->cfg.irrelevant ? 2 : 1;
             const size_t isz = aw * h->cfg.img_w * h->cfg.img_h;
-            const int nb = (K + h->img_chunk - 1) / h->img_chunk;
-            if (nb >= 2 && h->side_stream && !getenv("MDPP_NO_IMG_OVERLAP")) {
-                // Pipelined: the state, draw and record kernels of batch b + 1 (latency-bound, a few
-                // dozen waves) run on the side stream while the persistent renderer of batch b owns
-                // the memory system.  The side stream starts behind everything already queued on `s`,
-                // every side batch is waited for by its renderer on `s` (so the work is joined back
-                // into `s`), and a scratch set is reused only after its renderer has finished.
-                hipStream_t s2 = h->side_stream;
-                const size_t sset = (size_t)h->img_chunk * N * aw;        // int32 per scratch set
-                HIPCHK(h, hipEventRecord(h->ev_entry, s));
-                HIPCHK(h, hipStreamWaitEvent(s2, h->ev_entry, 0));
-                for (int b = 0; b < nb; b++) {
-                    const int k0 = b * h->img_chunk, buf = b & 1;
-                    const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
+            const size_t sset = (size_t)h->img_chunk * N * aw;            // int32 per scratch set
+            auto scratch = [&](int buf, int32_t **so, int32_t **sf) {
+                *so = (int32_t *)h->d_img_state_out + buf * sset;
+                *sf = (int32_t *)h->d_img_state_final + buf * sset;
+            };
+            return image_batches(
+                h, K, s,
+                [&](int k0, int kc, int buf, hipStream_t st) {
                     const size_t off = (size_t)k0 * N;
-                    int32_t *so = (int32_t *)h->d_img_state_out + buf * sset, *sf = (int32_t *)h->d_img_state_final + buf * sset;
-                    if (b >= 2) HIPCHK(h, hipStreamWaitEvent(s2, h->ev_render[buf], 0));
-                    rc = launch_discrete_step(h, kc, (const int32_t *)actions + off * aw, so, reward + off, term + off,
-                                              trunc + off, sf, s2);
-                    if (rc) return rc;
-                    rc = launch_image_obs(h, kc, so, sf, term + off, trunc + off, nullptr, nullptr, nullptr, s2, 1, buf);
-                    if (rc) return rc;
-                    HIPCHK(h, hipEventRecord(h->ev_side[buf], s2));
-                    HIPCHK(h, hipStreamWaitEvent(s, h->ev_side[buf], 0));
-                    rc = launch_image_obs(h, kc, so, sf, term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
-                                          final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s, 2, buf);
-                    if (rc) return rc;
-                    HIPCHK(h, hipEventRecord(h->ev_render[buf], s));
-                }
-                return MDPP_OK;
-            }
-            for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
-                const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
-                const size_t off = (size_t)k0 * N;
-                rc = launch_discrete_step(h, kc, (const int32_t *)actions + off * aw, h->d_img_state_out,
-                                          reward + off, term + off, trunc + off, h->d_img_state_final, s);
-                if (rc) return rc;
-                rc = launch_image_obs(h, kc, (const int32_t *)h->d_img_state_out,
-                                      (const int32_t *)h->d_img_state_final, term + off, trunc + off,
-                                      nullptr, (uint8_t *)obs + off * isz,
-                                      final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
-                if (rc) return rc;
-            }
-            return MDPP_OK;
+                    int32_t *so, *sf;
+                    scratch(buf, &so, &sf);
+                    int r = launch_discrete_step(h, kc, (const int32_t *)actions + off * aw, so, reward + off, term + off,
+                                                 trunc + off, sf, st);
+                    if (r) return r;
+                    return launch_image_obs(h, kc, so, sf, term + off, trunc + off, nullptr, nullptr, nullptr, st, 1, buf);
+                },
+                [&](int k0, int kc, int buf, hipStream_t st, bool overlap) {
+                    const size_t off = (size_t)k0 * N;
+                    int32_t *so, *sf;
+                    scratch(buf, &so, &sf);
+                    // (phase 2 leaves render slots free for the next batch's state kernel: only when pipelined)
+                    return launch_image_obs(h, kc, so, sf, term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
+                                            final_obs ? (uint8_t *)final_obs + off * isz : nullptr, st, overlap ? 2 : 6, buf);
+                });
         }
         return launch_discrete_step(h, K, (const int32_t *)actions, obs, reward, term, trunc, final_obs, s);
     }
@@ -697,35 +713,40 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
     if (h->cfg.kind == MDPP_KIND_GRID) {
         const size_t N = (size_t)h->cfg.num_envs, G = (size_t)h->cfg.grid_dims;
         const size_t isz = (G / 2) * h->cfg.img_w * h->cfg.img_h * 3;
-        for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
-            const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
-            const size_t off = (size_t)k0 * N;
-            rc = launch_grid_step(h, kc, (const int32_t *)actions + off * G, h->d_img_state_out, reward + off, term + off,
-                                  trunc + off, h->d_img_state_final, s);
-            if (rc) return rc;
-            rc = launch_imagec_obs(h, kc, h->d_img_state_out, h->d_img_state_final, term + off, trunc + off, nullptr,
-                                   (uint8_t *)obs + off * isz, final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
-            if (rc) return rc;
-        }
-        return MDPP_OK;
+        const size_t sset = (size_t)h->img_chunk * N * G;                 // int32 per scratch set
+        return image_batches(
+            h, K, s,
+            [&](int k0, int kc, int buf, hipStream_t st) {
+                const size_t off = (size_t)k0 * N;
+                return launch_grid_step(h, kc, (const int32_t *)actions + off * G, (int32_t *)h->d_img_state_out + buf * sset,
+                                        reward + off, term + off, trunc + off, (int32_t *)h->d_img_state_final + buf * sset, st);
+            },
+            [&](int k0, int kc, int buf, hipStream_t st, bool) {
+                const size_t off = (size_t)k0 * N;
+                return launch_imagec_obs(h, kc, (int32_t *)h->d_img_state_out + buf * sset,
+                                         (int32_t *)h->d_img_state_final + buf * sset, term + off, trunc + off, nullptr,
+                                         (uint8_t *)obs + off * isz, final_obs ? (uint8_t *)final_obs + off * isz : nullptr, st);
+            });
     }
     if (h->cfg.image) {
         // batches of up to img_chunk env steps: one state kernel, one render kernel over steps x envs
         // pictures (3 W H bytes per 2-D sub-space each)
         const size_t N = (size_t)h->cfg.num_envs, D = (size_t)h->cfg.D;
         const size_t isz = (size_t)(D > 2 ? 2 : 1) * h->cfg.img_w * h->cfg.img_h * 3;
-        for (int k0 = 0; k0 < K; k0 += h->img_chunk) {
-            const int kc = K - k0 < h->img_chunk ? K - k0 : h->img_chunk;
-            const size_t off = (size_t)k0 * N;
-            rc = launch_continuous_step(h, kc, (const float *)actions + off * D, (float *)h->d_img_state_out,
-                                        reward + off, term + off, trunc + off, (float *)h->d_img_state_final, s);
-            if (rc) return rc;
-            rc = launch_imagec_obs(h, kc, h->d_img_state_out, h->d_img_state_final,
-                                   term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
-                                   final_obs ? (uint8_t *)final_obs + off * isz : nullptr, s);
-            if (rc) return rc;
-        }
-        return MDPP_OK;
+        const size_t sset = (size_t)h->img_chunk * N * D;                 // floats per scratch set
+        return image_batches(
+            h, K, s,
+            [&](int k0, int kc, int buf, hipStream_t st) {
+                const size_t off = (size_t)k0 * N;
+                return launch_continuous_step(h, kc, (const float *)actions + off * D, (float *)h->d_img_state_out + buf * sset,
+                                              reward + off, term + off, trunc + off, (float *)h->d_img_state_final + buf * sset, st);
+            },
+            [&](int k0, int kc, int buf, hipStream_t st, bool) {
+                const size_t off = (size_t)k0 * N;
+                return launch_imagec_obs(h, kc, (float *)h->d_img_state_out + buf * sset, (float *)h->d_img_state_final + buf * sset,
+                                         term + off, trunc + off, nullptr, (uint8_t *)obs + off * isz,
+                                         final_obs ? (uint8_t *)final_obs + off * isz : nullptr, st);
+            });
     }
     return launch_continuous_step(h, K, (const float *)actions, (float *)obs, reward, term, trunc,
                                   (float *)final_obs, s);

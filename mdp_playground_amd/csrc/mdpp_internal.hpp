@@ -178,7 +178,8 @@ int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
                      uint8_t *trunc, void *final_obs, hipStream_t s);
 int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
-// phase: 1 = draw + records only, 2 = render only, 3 = both; buf: scratch set (0 / 1)
+// phase bits: 1 = draw + records, 2 = render (phase == 2 exactly: pipelined, the persistent grid leaves slots
+// free for the next batch's state kernel; 6 = render only on the full grid); buf: scratch set (0 / 1)
 int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase = 3, int buf = 0);
