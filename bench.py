@@ -221,7 +221,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8192)
     ap.add_argument("--warmup", type=int, default=1024)
-    ap.add_argument("--fuse", type=int, default=512, help="env steps per fused launch (mdpp_step_n)")
+    ap.add_argument("--fuse", type=int, default=None,
+                    help="env steps per fused launch (mdpp_step_n); default 512, and 2048 with more than one rank: "
+                         "every launch is followed by the path's one all-gather, whose host-side enqueue "
+                         "(events, stream switch, RCCL call) is of the order of a 512-step launch")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU")
     ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
@@ -257,7 +260,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     N = args.envs or wl["envs"]
-    F = max(1, min(args.fuse, args.steps, wl.get("fuse_max", args.fuse)))
+    fuse = args.fuse if args.fuse is not None else (2048 if world > 1 else 512)
+    F = max(1, min(fuse, args.steps, wl.get("fuse_max", fuse)))
     env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
                          autoreset="same_step", **wl["config"])
     acts = make_actions(wl, F, N, device, 12345 + rank)
