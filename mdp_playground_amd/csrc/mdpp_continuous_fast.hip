@@ -484,8 +484,9 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
             const uint32_t wbase = (i - (uint32_t)l) * (uint32_t)(D * 4);
 #pragma unroll
             for (int q = 0; q < V; q++)
-                __builtin_amdgcn_raw_buffer_store_b128(tile[q * 64 + l], r_obs, wbase + (uint32_t)(q * 64 + l) * 16u,
-                                                       so * (uint32_t)(D * 4), 0);
+                // (128-bit stores: whole offset in the VGPR, see mdpp_discrete_quiet.hip on the store-data hazard)
+                __builtin_amdgcn_raw_buffer_store_b128(tile[q * 64 + l], r_obs,
+                                                       wbase + (uint32_t)(q * 64 + l) * 16u + so * (uint32_t)(D * 4), 0, 0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             } else {                              // D = 4 rows are contiguous as they are; ragged last wave
 #pragma unroll
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                     __builtin_amdgcn_raw_buffer_store_b128(
                         u32x4{__float_as_uint(cur[4 * q]), __float_as_uint(cur[4 * q + 1]),
                               __float_as_uint(cur[4 * q + 2]), __float_as_uint(cur[4 * q + 3])},
-                        r_obs, vrow + 16u * q, so * (uint32_t)(D * 4), 0);
+                        r_obs, vrow + 16u * q + so * (uint32_t)(D * 4), 0, 0);
             }
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), r_rew, v4, so * 4u, 0);

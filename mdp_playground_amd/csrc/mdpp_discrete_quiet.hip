@@ -35,6 +35,10 @@
 namespace mdpp {
 
 constexpr int kQQ = 4;                         // start states queued per lane
+// 128-bit buffer stores carry their WHOLE offset in the VGPR.  With a register in the soffset field the
+// compiler's hazard recognizer assumes that the store-data hazard of > 64-bit stores (a VALU write to the
+// data registers right behind the store) does not exist and inserts no wait state; on gfx950 it does
+// exist: lanes 12-15 of every 16 stored the overwritten register (found by the role-split soak test).
 constexpr int kQRsrc = 0x00020000;
 constexpr int kQDepth = 24;                    // E -> O ring depth in steps (multiple of the chunk of 8)
 constexpr uint32_t kQSpinLimit = 1u << 22;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     };
     auto put_obs = [&](decltype(r_obs) rs, uint32_t so, uint32_t s0, uint32_t s1) __attribute__((always_inline)) {
         if (IRR) {
-            if (OBS64) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0, 0u, s1, 0u}, rs, vobs, so * row_obs, 0);
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0, 0u, s1, 0u}, rs, vobs + so * row_obs, 0, 0);   // (see kQRsrc)
             else __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, s1}, rs, vobs, so * row_obs, 0);
         } else {
             if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, 0u}, rs, vobs, so * row_obs, 0);

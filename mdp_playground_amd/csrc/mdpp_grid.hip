@@ -311,10 +311,11 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
     auto put_cells = [&](decltype(r_obs) rs, uint32_t so, uint32_t c) {
         const uint32_t c0 = c & 0xFFu, c1 = (c >> 8) & 0xFFu, c2 = (c >> 16) & 0xFFu, c3 = c >> 24;
         if (OBS64) {
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, 0u, c1, 0u}, rs, vobs, so * row_obs, 0);
-            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2, 0u, c3, 0u}, rs, vobs + 16u, so * row_obs, 0);
+            // (128-bit stores: whole offset in the VGPR, see mdpp_discrete_quiet.hip on the store-data hazard)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, 0u, c1, 0u}, rs, vobs + so * row_obs, 0, 0);
+            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2, 0u, c3, 0u}, rs, vobs + 16u + so * row_obs, 0, 0);
         } else {
-            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, c1, c2, c3}, rs, vobs, so * row_obs, 0);
+            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, c1, c2, c3}, rs, vobs + so * row_obs, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b64(u32x2{c0, c1}, rs, vobs, so * row_obs, 0);
         }
     };

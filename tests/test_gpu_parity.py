@@ -1385,19 +1385,35 @@ def test_continuous_fast_kernel_other_shapes_vs_oracle(D, nrel, order):
     env.close()
 
 
-@pytest.mark.parametrize("name,flag", [("d_cfg2", "MDPP_NO_PIPE"), ("c_cfg5", "MDPP_NO_HELPER")])
+SOAK_IRR = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 8],
+                action_space_size=[8, 8], irrelevant_features=True, delay=4, sequence_length=3)
+
+
+@pytest.mark.parametrize("name,flag", [("d_cfg2", "MDPP_NO_PIPE"), ("c_cfg5", "MDPP_NO_HELPER"), ("c_cfg5", "MDPP_NO_PARK"),
+                                       ("irr", "MDPP_NO_DUO"), ("irr+pn", "MDPP_NO_TRIO"), ("irr+pn+rn", "MDPP_NO_DUO")])
 def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     """The producer/consumer kernels (LDS rings between waves) against the single-role kernels of
-    the same arithmetic, full size, many launches: any lost or duplicated hand-off would show."""
+    the same arithmetic, full size, many launches: any lost or duplicated hand-off would show.
+    (c_cfg5 / MDPP_NO_PARK: the drifting producer lanes against the lockstep producer; irr*: the two-
+    and three-role forms of the quiet discrete kernel against the smaller ones.)"""
     import os
-    cfg = _cfg(name, 31)
+    if name.startswith("irr"):
+        cfg = dict(SOAK_IRR, seed=31)
+        if "+pn" in name:
+            cfg["transition_noise"] = 0.15
+        if "+rn" in name:
+            cfg["reward_noise"] = 0.25
+    else:
+        cfg = _cfg(name, 31)
     N, F, launches = 65536, 256, 12
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     g = torch.Generator(device=a.device)
     g.manual_seed(1)
     for j in range(launches):
-        if a.kind == "discrete":
+        if name.startswith("irr"):
+            acts = torch.randint(0, 8, (F, N, 2), generator=g, device=a.device, dtype=torch.int32)
+        elif a.kind == "discrete":
             acts = torch.randint(0, 8, (F, N), generator=g, device=a.device, dtype=torch.int32)
         else:
             acts = torch.rand((F, N, 12), generator=g, device=a.device) * 2 - 1
