@@ -1433,6 +1433,55 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("workload,over,flag,N,F", [
+    ("cfg2_noise", {}, "MDPP_NO_QUIET", 65536, 128),                      # noisy quiet kernel (two roles) vs general
+    ("cfg2_irr", {"transition_noise": 0.1}, "MDPP_NO_QUIET", 65536, 128),
+    ("grid", {}, "MDPP_NO_GFAST", 65536, 128),                            # int64 pairs: one 128-bit store per step
+    ("grid", {"irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "MDPP_NO_GFAST", 32768, 128),
+    ("cfg3", {}, "MDPP_NO_CFAST", 65536, 64),                             # transposed 128-bit stores
+    ("cfg3", {"delay": 2, "reward_every_n_steps": 2, "state_space_dim": 4, "relevant_indices": [0, 1, 2, 3]},
+     "MDPP_NO_CFAST", 65536, 64),
+    ("cfg5", {"delay": 3}, "MDPP_NO_CFAST", 32768, 48),
+    ("cfg4", {}, "MDPP_NO_IMGFAST", 2048, 40),                            # fast vs general renderer, pipelined batches
+])
+def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag, N, F):
+    """Every specialised rollout kernel against the general kernel of the same arithmetic, on EVERY env
+    of a large batch (the oracle tests sample envs): outputs, and the streams' end states.  A
+    lane-pattern fault such as the 128-bit store-data hazard shows up here."""
+    import os
+    import bench
+    from mdp_playground_amd import _capi as capi
+    wl = bench.WORKLOADS[workload]
+    cfg = dict(wl["config"], **over)
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    wl2 = dict(wl, config=cfg)
+    for j in range(3):
+        acts = bench.make_actions(wl2, F, N, a.device, 100 + j)
+        os.environ.pop(flag, None)
+        ra = a.rollout(acts)
+        torch.cuda.synchronize()
+        os.environ[flag] = "1"
+        try:
+            rb = b.rollout(acts)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop(flag, None)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (workload, j)
+    streams = [capi.STREAM_ENV, capi.STREAM_SPACE]
+    if a.kind == "grid":
+        streams.append(capi.STREAM_ACTION)
+    if a.kind == "discrete" and a._irr:
+        streams.append(capi.STREAM_SPACE_IRR)
+    if getattr(a, "_image", None) is not None and a.kind == "discrete":
+        streams.append(capi.STREAM_IMAGE)
+    for st in streams:
+        assert np.array_equal(a.get_rng_streams(st), b.get_rng_streams(st)), (workload, st)
+    assert (a.status() == 0).all() and (b.status() == 0).all()
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("what", ["states", "images"])
 def test_rollout_is_graph_capturable(what):
     """include/mdpp.h promises that nothing is allocated inside mdpp_step / mdpp_step_n: a fused
