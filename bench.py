@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/sec of the batched RLToyEnv.step() hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 8192 --warmup 1024
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            (starts its N ranks itself, as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): discrete 8 states x 8 actions, reward_delay 4,
 sequence_length 3, 65 536 env instances per GPU sharing one MDP, uniform random actions
 (synthetic, pre-generated on the device), same-step autoreset, numpy-exact PCG64 streams.
-A "step" is one env step of every instance of every rank.  Steps run as fused rollouts of
---fuse steps per launch (mdpp_step_n); with N > 1 each launch is followed by ONE RCCL
-all-gather that assembles the current global observation tensor on every rank (env ids are
-sharded contiguously, weak scaling; the gather overlaps the next launch).  The single-launch-per-step path (mdpp_step) is reported beside it.
 
-Rank 0 prints ONE JSON line: the driver contract plus `roofline` and `cpu_baseline`.
+ONE BENCH STEP = one pass of the hot path over one batch = ONE fused launch (mdpp_step_n) of
+--fuse (512, the same for every --gpus) env steps of every env instance of every rank, i.e.
+`--steps 20 --warmup 5` is 5 + 20 launches of 512 x 65 536 env steps per GPU.  `value` stays in
+env-steps/s (bench steps x fuse x envs x ranks / time), `ms_per_step` is per bench step (launch).
+With N > 1 each launch is followed by ONE RCCL all-gather that assembles the current global
+observation tensor on every rank (env ids are sharded contiguously, weak scaling; the gather
+overlaps the next launch); `collective_legs` reports the same launches without any collective,
+with that gather, and with a gather of every observation of the rollout ([K, N_local, ...]).
+The single-launch-per-step path (mdpp_step) is reported beside it.
+
+Rank 0 prints ONE JSON line: the driver contract plus `roofline` (HIP events around the timed
+launches; the measured copy / write ceilings of this device beside the 8 TB/s spec peak) and
+`cpu_baseline` (a pure-Python restatement of the reference step(), baseline/py_step.py; the C port
+of the oracle is reported as `cpu_baseline_port`).
 """
 import argparse
 import json
@@ -216,38 +226,72 @@ def cpu_baseline_all_cores(wl_name, seconds=4.0):
             "sample": f"{total} env-steps, one oracle process per core for {wall:.1f} s"}
 
 
+def hbm_ceilings(device, nbytes=1 << 30, reps=10):
+    """What the memory system of THIS device gives plain streaming kernels, measured live (SURVEY.md
+    §8d "report against both"): a device-to-device copy (read + write bytes) and a fill (write only)
+    of `nbytes`, torch's own kernels, HIP events."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    out = {}
+    for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("write", lambda: dst.fill_(7), nbytes)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        out[name + "_GBps"] = moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a
+    CHILD process (this process has not touched the GPU and never will), relay rank 0's JSON line and
+    the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=1024)
-    ap.add_argument("--fuse", type=int, default=None,
-                    help="env steps per fused launch (mdpp_step_n); default 512, and 2048 with more than one rank: "
-                         "every launch is followed by the path's one all-gather, whose host-side enqueue "
-                         "(events, stream switch, RCCL call) is of the order of a 512-step launch")
+    ap.add_argument("--steps", type=int, default=20, help="timed bench steps; ONE bench step = one fused launch of "
+                    "--fuse env steps of every env instance of every rank")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed bench steps (launches) before the timed ones")
+    ap.add_argument("--fuse", type=int, default=512, help="env steps per fused launch (mdpp_step_n), the same for every --gpus")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU")
     ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
+    ap.add_argument("--full-gather-steps", type=int, default=4,
+                    help="bench steps of the [K, N_local, ...] all-gather leg (multi-rank runs; 0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # all-core CPU line first: it forks one worker per core, which must happen before this
-    # process has initialised the GPU runtime
-    cpu_all = None
-    wl0 = WORKLOADS[args.workload]
-    if (rank == 0 and world == 1 and not args.no_cpu_baseline and wl0["kind"] == "discrete"
-            and not wl0["config"].get("image_representations")
-            and not wl0["config"].get("irrelevant_features")):
-        try:
-            cpu_all = cpu_baseline_all_cores(args.workload)
-        except Exception as e:          # a reported extra, never fatal
-            cpu_all = {"error": repr(e)}
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # CPU baselines first: they fork one worker per core, which must happen before this process has
+    # initialised the GPU runtime
+    wl = WORKLOADS[args.workload]
+    cpu_py = cpu_py_all = cpu_all = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -258,131 +302,112 @@ def main():
     from mdp_playground_amd import RLToyVectorEnv
     from mdp_playground_amd.dist import ObsGatherer
 
-    wl = WORKLOADS[args.workload]
     N = args.envs or wl["envs"]
-    fuse = args.fuse if args.fuse is not None else (2048 if world > 1 else 512)
-    F = max(1, min(fuse, args.steps, wl.get("fuse_max", fuse)))
+    F = max(1, min(args.fuse, wl.get("fuse_max", args.fuse)))
     env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
                          autoreset="same_step", **wl["config"])
     acts = make_actions(wl, F, N, device, 12345 + rank)
     outs = [env.alloc_rollout(F), env.alloc_rollout(F)]     # alternate, so a gather can trail a launch
-    out = outs[0]
-    # The collective of the path: after every rollout launch ONE all-gather of the
-    # local CURRENT observation shard ([N_local, ...], 512 KiB per rank for cfg2) gives every rank
-    # the concatenated observation tensor of all world*N envs.  It runs on its own stream and
-    # overlaps the next launch; the per-step observations of a fused rollout stay on their rank.
-    gathers, comm, ev_done = None, None, [None, None]
-    if dist is not None:
-        gathers = [ObsGatherer(o[0][-1], world, dist) for o in outs]
-        comm = torch.cuda.Stream(device=device)
-
-    def run(steps):
-        left, launches = steps, 0
-        cur = torch.cuda.current_stream(device)
-        while left > 0:
-            k = min(F, left)
-            j = launches & 1
-            if gathers is not None and ev_done[j] is not None:
-                cur.wait_event(ev_done[j])          # the gather that read this buffer two launches ago
-            if k == F:
-                env.rollout(acts, outs[j])
-            else:
-                env.rollout(acts[:k], tuple(t[:k] for t in outs[j]))
-            if gathers is not None:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ev)
-                    if k == F:
-                        gathers[j]()
-                    else:
-                        gathers[j].local = outs[j][0][k - 1]
-                        gathers[j]()
-                        gathers[j].local = outs[j][0][-1]
-                    ev_done[j] = torch.cuda.Event()
-                    ev_done[j].record(comm)
-            left -= k
-            launches += 1
-        if comm is not None:
-            cur.wait_stream(comm)
-        return launches
+    comm = torch.cuda.Stream(device=device) if dist is not None else None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    run(max(args.warmup, 1))
-    barrier()
-    if gathers is None:
-        env.timer_begin()
-    t0 = time.perf_counter()
-    launches = run(args.steps)
-    if gathers is None:
-        kernel_ms = env.timer_end()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if gathers is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # roofline leg without the collective: HIP events around plain launches on this rank
-        env.timer_begin()
-        launches_r = 0
-        for _ in range(8):
-            env.rollout(acts, out)
-            launches_r += 1
-        kernel_ms = env.timer_end() * (args.steps / (launches_r * F))
-    total_steps = world * N * args.steps
+    def run(steps, gathers):
+        """`steps` fused launches; with `gathers`, each launch is followed by ONE all-gather (on the comm
+        stream, overlapping the next launch) of the tensor gathers[j] was built on."""
+        cur = torch.cuda.current_stream(device)
+        ev_done = [None, None]
+        for it in range(steps):
+            j = it & 1
+            if gathers is not None and ev_done[j] is not None:
+                cur.wait_event(ev_done[j])          # the gather that read this buffer two launches ago
+            env.rollout(acts, outs[j])
+            if gathers is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    gathers[j]()
+                    ev_done[j] = torch.cuda.Event()
+                    ev_done[j].record(comm)
+        if gathers is not None:
+            cur.wait_stream(comm)
+
+    def timed(steps, gathers, events=False):
+        """EXACTLY `steps` launches between barrier + synchronize on both sides; max over ranks."""
+        barrier()
+        if events:
+            env.timer_begin()
+        t0 = time.perf_counter()
+        run(steps, gathers)
+        kernel_ms = env.timer_end() if events else None
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, kernel_ms
+
+    # ---- leg "none": no collective.  Its HIP-event time (launch stream) is the roofline leg.
+    run(max(args.warmup, 1), None)
+    el_none, kernel_ms = timed(args.steps, None, events=True)
+    legs = {"none": {"elapsed_s": el_none, "env_steps_per_s": world * N * F * args.steps / el_none}}
+    elapsed, collective = el_none, "none"
+    if dist is not None:
+        # ---- leg "last_row": the collective of the path (SURVEY.md §8e, north_star): after every launch ONE
+        # all-gather of the local CURRENT observation shard ([N_local, ...]: 512 KiB per rank for cfg2) gives
+        # every rank the concatenated observation tensor of all world * N envs
+        g_last = [ObsGatherer(o[0][-1], world, dist) for o in outs]
+        run(max(args.warmup, 1), g_last)
+        el_last, _ = timed(args.steps, g_last)
+        legs["last_row"] = {"elapsed_s": el_last, "env_steps_per_s": world * N * F * args.steps / el_last,
+                            "bytes_per_rank_per_launch": g_last[0].local.numel() * g_last[0].local.element_size()}
+        elapsed = el_last
+        collective = ("all_gather_into_tensor (RCCL, %d ranks) of the current observation shard after every launch, "
+                      "overlapped on a side stream" % dist.get_world_size())
+        del g_last
+        # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
+        full_bytes = outs[0][0].numel() * outs[0][0].element_size()
+        if args.full_gather_steps > 0 and full_bytes * world * 2 < (64 << 30):
+            g_full = [ObsGatherer(o[0], world, dist) for o in outs]
+            run(2, g_full)
+            ks = min(args.steps, args.full_gather_steps)
+            el_full, _ = timed(ks, g_full)
+            legs["full"] = {"elapsed_s": el_full, "steps": ks, "env_steps_per_s": world * N * F * ks / el_full,
+                            "bytes_per_rank_per_launch": full_bytes}
+            del g_full
+    total_steps = world * N * F * args.steps
     value = total_steps / elapsed
 
     # ---- roofline of the dominant kernel (fused rollout), per launch
-    per_launch_s = (kernel_ms / 1e3) / (args.steps / F)
+    per_launch_s = (kernel_ms / 1e3) / args.steps
     alg_bytes = wl["alg_bytes_fused"] * N * F
     achieved = alg_bytes / per_launch_s / 1e9
-    kname = env.rollout_kernel_name(F)
-    # HBM bytes per launch from PMC counters: collected offline with rocprofv3 --pmc (separate
-    # passes, gfx950 FETCH_SIZE correction applied) and committed under profiles/; only valid for
-    # the exact launch shape it was measured on.
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}.json")
-    if os.path.exists(tfile):
-        t = json.load(open(tfile))
-        if t.get("envs") == N and t.get("fuse") == F and "traffic_bytes_per_launch" in t:
-            traffic = t["traffic_bytes_per_launch"]
-        elif t.get("envs") == N and "traffic_bytes_per_env_step" in t:
-            # measured per env step over whole rollouts (tools/pmc_traffic.sh); per-step traffic of a
-            # fused rollout does not depend on the rollout length beyond the per-launch state I/O
-            traffic = int(round(t["traffic_bytes_per_env_step"] * N * F))
+    kname = env.rollout_kernel_name(F)          # what the library's dispatch launches (mdpp_kernel_name)
+    traffic, traffic_src = committed_traffic(args.workload, args.rng, N, F, kname)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                "alg_bytes_per_env_step": wl["alg_bytes_fused"],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
+                "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg_bytes,
                 "launch_us": per_launch_s * 1e6, "env_steps_per_launch": N * F}
 
     single = None
     if not args.no_single_step:
-        a1 = acts[0].contiguous()
-        for _ in range(50):
-            env.step(a1)
-        torch.cuda.synchronize(device)
-        n1 = 500
-        env.timer_begin()
-        t1 = time.perf_counter()
-        for _ in range(n1):
-            env.step(a1)
-        ms1 = env.timer_end()
-        torch.cuda.synchronize(device)
-        wall1 = time.perf_counter() - t1
-        b1 = wl["alg_bytes_step"] * N
-        single = {"env_steps_per_s": N * n1 / wall1, "launch_us_events": ms1 * 1e3 / n1,
-                  "alg_bytes_per_env_step": wl["alg_bytes_step"],
-                  "hbm_frac_events": b1 / (ms1 / 1e3 / n1) / 1e9 / HBM_PEAK_GBS}
+        single = single_step_leg(env, wl, acts, N, device)
+    if rank == 0:
+        peaks = hbm_ceilings(device)
+        roofline["peak_measured"] = peaks
+        roofline["frac_of_measured_copy"] = achieved / peaks["copy_GBps"]
+        roofline["frac_of_measured_write"] = achieved / peaks["write_GBps"]
 
-    cpu = None
+    cpu_port = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not (
             wl["kind"] == "continuous" and wl["config"].get("image_representations")):
-        cpu = cpu_baseline(wl)      # (the C port has no timed picture path for continuous envs)
+        cpu_port = cpu_baseline(wl)      # (the C port has no timed picture path for continuous envs)
     env.close()
 
     if rank == 0:
@@ -393,18 +418,108 @@ def main():
             "dtype": "u8" if wl["kind"] == "discrete" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: BASELINE.json configs "
                                    f"({json.dumps(wl['config'], sort_keys=True)}), "
-                                   f"{N} env instances per GPU, random actions, same-step autoreset, "
-                                   f"fused rollout of {F} steps per launch, rng={args.rng}",
-                       "envs_per_gpu": N, "fuse": F,
-                       "collective": ("all_gather of the current observation shard after every launch, "
-                                      "overlapped on a side stream") if gathers is not None else "none"},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
-            "single_step": single,
-            "launches": launches, "elapsed_s": elapsed,
+                                   f"{N} env instances per GPU, random actions, same-step autoreset, rng={args.rng}; "
+                                   f"ONE bench step = one fused launch of {F} env steps of every instance "
+                                   f"(= {world * N * F} env steps)",
+                       "envs_per_gpu": N, "fuse": F, "env_steps_per_bench_step": world * N * F,
+                       "collective": collective},
+            "roofline": roofline,
+            "cpu_baseline": cpu_py if cpu_py is not None else cpu_port,
+            "cpu_baseline_all_cores": cpu_py_all, "cpu_baseline_port": cpu_port,
+            "cpu_baseline_port_all_cores": cpu_all,
+            "single_step": single, "collective_legs": legs,
+            "launches": args.steps, "elapsed_s": elapsed,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def committed_traffic(workload, rng, N, F, kname):
+    """HBM bytes per launch from PMC counters.  They cannot be collected inside this process (rocprofv3
+    wraps the program), so they are collected offline with tools/pmc_traffic.sh (FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md) and committed
+    under profiles/; a record is used only for the launch shape AND kernel it was measured on."""
+    tag = workload if rng == "numpy" else f"{workload}_{rng}"
+    for rnd in ("r02", "r01"):
+        tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{tag}.json")
+        if not os.path.exists(tfile):
+            continue
+        t = json.load(open(tfile))
+        if t.get("envs") != N:
+            continue
+        kernels = " ".join(t.get("per_kernel_KB", {}))
+        if kernels and kname.split("<")[0] not in kernels:
+            continue
+        if t.get("fuse") == F and "traffic_bytes_per_launch" in t:
+            return t["traffic_bytes_per_launch"], os.path.basename(tfile)
+        if "traffic_bytes_per_env_step" in t:
+            # measured per env step over whole rollouts; the per-step traffic of a fused rollout does
+            # not depend on the rollout length beyond the per-launch state I/O (a few bytes per env)
+            return int(round(t["traffic_bytes_per_env_step"] * N * F)), os.path.basename(tfile)
+    return None, None
+
+
+def single_step_leg(env, wl, acts, N, device):
+    """The one-launch-per-step API (mdpp_step) and a replayed HIP graph of such steps."""
+    a1 = acts[0].contiguous()
+    for _ in range(50):
+        env.step(a1)
+    torch.cuda.synchronize(device)
+    n1 = 500
+    env.timer_begin()
+    t1 = time.perf_counter()
+    for _ in range(n1):
+        env.step(a1)
+    ms1 = env.timer_end()
+    torch.cuda.synchronize(device)
+    wall1 = time.perf_counter() - t1
+    b1 = wl["alg_bytes_step"] * N
+    single = {"env_steps_per_s": N * n1 / wall1, "launch_us_events": ms1 * 1e3 / n1,
+              "alg_bytes_per_env_step": wl["alg_bytes_step"],
+              "hbm_frac_events": b1 / (ms1 / 1e3 / n1) / 1e9 / HBM_PEAK_GBS}
+    if hasattr(env, "step_graph"):
+        try:
+            KG = 64
+            g = env.step_graph(acts[:KG].contiguous())
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize(device)
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t2 = time.perf_counter()
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize(device)
+            wall2 = time.perf_counter() - t2
+            single["graph"] = {"steps_per_graph": KG, "env_steps_per_s": N * KG * reps / wall2,
+                               "us_per_step_events": e0.elapsed_time(e1) * 1e3 / (KG * reps),
+                               "hbm_frac_events": b1 / (e0.elapsed_time(e1) * 1e-3 / (KG * reps)) / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:        # a reported extra, never fatal
+            single["graph"] = {"error": repr(e)}
+    return single
+
+
+def cpu_baselines_forked(workload):
+    """Everything that forks worker processes (must run before this process initialises the GPU):
+    the pure-Python restatement on 1 core and on all cores, and the C port on all cores."""
+    wl = WORKLOADS[workload]
+    cpu_py = cpu_py_all = cpu_all = None
+    try:
+        from baseline import bench_py
+        cpu_py, cpu_py_all = bench_py.measure(wl["config"], wl["kind"])
+    except Exception as e:          # a reported extra, never fatal
+        cpu_py = None
+        cpu_py_all = {"error": repr(e)}
+    if (wl["kind"] == "discrete" and not wl["config"].get("image_representations")
+            and not wl["config"].get("irrelevant_features")):
+        try:
+            cpu_all = cpu_baseline_all_cores(workload)
+        except Exception as e:
+            cpu_all = {"error": repr(e)}
+    return cpu_py, cpu_py_all, cpu_all
 
 
 if __name__ == "__main__":

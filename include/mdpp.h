@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 4
+#define MDPP_ABI_VERSION 5
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
@@ -47,7 +47,10 @@ enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_EST
 enum { MDPP_KIND_DISCRETE = 0, MDPP_KIND_CONTINUOUS = 1, MDPP_KIND_GRID = 2 };
 enum { MDPP_RNG_NUMPY_PCG64 = 0,   /* per-env numpy Generator(PCG64) streams: reference-exact */
        MDPP_RNG_PHILOX = 1 };      /* counter-based Philox4x32-10 keyed by (seed, global env id) */
-enum { MDPP_AUTORESET_DISABLED = 0, MDPP_AUTORESET_SAME_STEP = 1 };
+enum { MDPP_AUTORESET_DISABLED = 0,    /* the reference's own behaviour: keeps stepping after done */
+       MDPP_AUTORESET_SAME_STEP = 1,   /* gymnasium 0.29 SyncVectorEnv: the step that ends an episode returns the next episode's first obs */
+       MDPP_AUTORESET_NEXT_STEP = 2 }; /* gymnasium >= 1.0 vector envs: the step() AFTER the one that ended an episode ignores that env's
+                                          action, resets it and returns (first obs, reward 0, no flags); general kernels, no image observations */
 enum { MDPP_OBS_I64 = 0, MDPP_OBS_I32 = 1, MDPP_OBS_F32 = 2, MDPP_OBS_IMAGE_U8 = 3 };
 /* RNG streams, named after the generator object they mirror in the reference */
 enum { MDPP_STREAM_ENV = 0,        /* RLToyEnv._np_random: reset draw, reward noise, continuous P-noise */
@@ -61,6 +64,24 @@ enum { MDPP_STATUS_BAD_ACTION = 1u,     /* discrete: action out of range (refere
                                            continuous: action rejected by Box.contains -> "stay" (:1671) */
        MDPP_STATUS_RESET_GAVE_UP = 2u,  /* continuous reset(): 4096 draws all fell into terminal hypercubes */
        MDPP_STATUS_INTERNAL = 0x80000000u }; /* a bounded in-kernel wait expired (never expected) */
+
+/* Kernel-selection switches (mdpp_set_options): each bit takes one specialised rollout kernel (or
+ * one of its multi-wave forms) out of the dispatch, so that the same handle runs on the more general
+ * kernel of the same arithmetic.  Results never depend on them (tests compare both sides); they exist
+ * for those tests, for profiling and for ablations.  Per handle; nothing is read from the environment. */
+enum { MDPP_OPT_NO_PIPE = 1u << 0,         /* discrete: no three-role k_discrete_rollout_pipe */
+       MDPP_OPT_NO_HELPER = 1u << 1,       /* no helper (producer) waves in k_*_rollout_fast */
+       MDPP_OPT_NO_PARK = 1u << 2,         /* continuous helper waves draw in lockstep (no parked lanes) */
+       MDPP_OPT_NO_CFAST = 1u << 3,        /* continuous: k_continuous_step instead of k_continuous_rollout_fast */
+       MDPP_OPT_NO_QUIET = 1u << 4,        /* discrete: k_discrete_step instead of k_discrete_rollout_quiet */
+       MDPP_OPT_NO_QUIET_NOISE = 1u << 5,  /* ... only for handles with P- or reward noise */
+       MDPP_OPT_NO_DUO = 1u << 6,          /* k_discrete_rollout_quiet: one role only */
+       MDPP_OPT_NO_TRIO = 1u << 7,         /* k_discrete_rollout_quiet: at most two roles */
+       MDPP_OPT_NO_GFAST = 1u << 8,        /* grid: k_grid_step instead of k_grid_rollout_fast */
+       MDPP_OPT_NO_GFAST_NOISE = 1u << 9,  /* ... only for handles with noise */
+       MDPP_OPT_NO_IMGFAST = 1u << 10,     /* polygon images: k_image_obs instead of k_image_obs_fast */
+       MDPP_OPT_NO_IMG_OVERLAP = 1u << 11, /* image rollouts: no side-stream pipeline of the batches */
+       MDPP_OPT_NO_PHILOX_FAST = 1u << 12  /* Philox handles: general kernels only */ };
 
 /* what a discrete env's reward table is keyed by */
 enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences, rl_toy_env.py:1837-1841) */
@@ -224,6 +245,13 @@ int mdpp_get_state_continuous(mdpp_env *h, float *derivs_host, float *cur_host, 
 int mdpp_set_state_continuous(mdpp_env *h, const float *derivs_host, const float *cur_host,
                               const int32_t *steps_host, const double *ring_host,
                               const uint8_t *ring_is32_host, const uint8_t *reached_host);
+
+/* Kernel selection (see MDPP_OPT_*): disable_mask replaces the handle's current mask (0 = default dispatch). */
+int mdpp_set_options(mdpp_env *h, uint32_t disable_mask);
+/* Name (with template arguments) of the kernel mdpp_step_n(h, K, ...) would launch for this handle
+ * right now -- K = 1: mdpp_step -- decided by the same code that launches it, nothing is launched.
+ * Image handles: the renderer (the dominant kernel).  The string lives in the handle until the next call. */
+const char *mdpp_kernel_name(mdpp_env *h, int K);
 
 /* Per-env sticky status bits (MDPP_STATUS_*), cleared by the call. flags_host: uint32[N]. */
 int mdpp_status(mdpp_env *h, uint32_t *flags_host);

@@ -6,16 +6,20 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 4
+MDPP_ABI_VERSION = 5
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
 REWARD_SEQUENCES, REWARD_STATE_ACTION = 0, 1
 CREWARD_MOVE_TO_A_POINT, CREWARD_MOVE_ALONG_A_LINE = 0, 1
 RNG_NUMPY_PCG64, RNG_PHILOX = 0, 1
-AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1
+AUTORESET_DISABLED, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
 STREAM_ENV, STREAM_SPACE, STREAM_IMAGE, STREAM_SPACE_IRR, STREAM_ACTION = 0, 1, 2, 3, 4
 STATUS_BAD_ACTION = 1
+# MDPP_OPT_* kernel-selection switches (mdpp_set_options)
+OPTIONS = {"NO_PIPE": 1 << 0, "NO_HELPER": 1 << 1, "NO_PARK": 1 << 2, "NO_CFAST": 1 << 3, "NO_QUIET": 1 << 4,
+           "NO_QUIET_NOISE": 1 << 5, "NO_DUO": 1 << 6, "NO_TRIO": 1 << 7, "NO_GFAST": 1 << 8,
+           "NO_GFAST_NOISE": 1 << 9, "NO_IMGFAST": 1 << 10, "NO_IMG_OVERLAP": 1 << 11, "NO_PHILOX_FAST": 1 << 12}
 
 EXPORTS = [
     "mdpp_abi_version", "mdpp_create", "mdpp_destroy", "mdpp_last_error",
@@ -25,6 +29,7 @@ EXPORTS = [
     "mdpp_status", "mdpp_timer_begin", "mdpp_timer_end",
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
+    "mdpp_set_options", "mdpp_kernel_name",
 ]
 
 
@@ -105,6 +110,9 @@ def load():
     L.mdpp_get_state_grid.argtypes = [vp] * 4
     L.mdpp_set_state_grid.argtypes = [vp] * 4
     L.mdpp_status.argtypes = [vp, vp]
+    L.mdpp_set_options.argtypes = [vp, C.c_uint32]
+    L.mdpp_kernel_name.argtypes = [vp, i32]
+    L.mdpp_kernel_name.restype = C.c_char_p
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     if L.mdpp_abi_version() != MDPP_ABI_VERSION:

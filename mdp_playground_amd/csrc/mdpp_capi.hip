@@ -85,6 +85,10 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     if (cfg->num_envs <= 0) return fail(nullptr, MDPP_EINVAL, "mdpp_create: num_envs <= 0");
     if (cfg->delay < 0 || cfg->every_n < 1)
         return fail(nullptr, MDPP_EINVAL, "mdpp_create: need delay >= 0 and reward_every_n_steps >= 1");
+    if (cfg->autoreset < MDPP_AUTORESET_DISABLED || cfg->autoreset > MDPP_AUTORESET_NEXT_STEP)
+        return fail(nullptr, MDPP_EINVAL, "mdpp_create: unknown autoreset mode");
+    if (cfg->autoreset == MDPP_AUTORESET_NEXT_STEP && cfg->image)
+        return fail(nullptr, MDPP_EUNSUPPORTED, "mdpp_create: next-step autoreset is not available with image observations");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess)
         return fail(nullptr, MDPP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
@@ -95,6 +99,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->num_cus = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->num_cus = v; }
     h->tick = 0; h->reset_tick = 0;
+    h->opts = 0; h->kname[0] = 0;
     h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
     h->d_P1 = h->d_init_cdf1 = h->d_noise_cdf1 = h->d_irr_state = nullptr;
@@ -306,6 +311,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             // (an unbounded box is fine as long as the actions are bounded: states then stay finite, which
             // the fast kernel's clip relies on -- np.clip's NaN propagation lives in the general kernel)
             a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && a.rel_prefix && !cfg->image && !line &&
+                         cfg->autoreset != MDPP_AUTORESET_NEXT_STEP &&
                          (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
         }
@@ -396,6 +402,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         const mdpp_config &c = h->cfg;
         a.fast_ok = (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise &&
                      c.L <= 3 && c.S <= 16 && c.delay <= 32 && c.rng_mode == MDPP_RNG_NUMPY_PCG64 &&
+                     c.autoreset != MDPP_AUTORESET_NEXT_STEP &&
                      a.rew_in_lds && !c.irrelevant) ? 1u : 0u;   // (image handles: the state kernel of a batch)
         a.s_shift = 0xFFFFFFFFu;
         for (uint32_t b = 1; b < 8; b++) if ((1u << b) == (uint32_t)c.S) a.s_shift = b;
@@ -479,7 +486,7 @@ extern "C" int mdpp_get_state_grid(mdpp_env *h, int32_t *cells, int32_t *steps, 
     for (size_t i = 0; i < N; i++) {
         for (int d = 0; d < G; d++) cells[i * G + d] = (int32_t)((st[4 * i] >> (8 * d)) & 0xFF);
         steps[i] = (int32_t)st[4 * i + 1];
-        reached[i] = (uint8_t)(st[4 * i + 2] & 1u);
+        reached[i] = (uint8_t)(st[4 * i + 2] & 1u);                  // (bit 1: next-step autoreset pending)
     }
     return MDPP_OK;
 }
@@ -543,8 +550,10 @@ extern "C" int mdpp_seed_streams(mdpp_env *h, int stream, const uint64_t *words)
     HIPCHK(h, hipMemcpy(h->d_rng_inc[stream], inc.data(), N * 16, hipMemcpyHostToDevice));
     if ((stream == MDPP_STREAM_IMAGE || stream == MDPP_STREAM_ACTION) && h->d_rng_half)
         HIPCHK(h, hipMemcpy(h->d_rng_half, half.data(), N * 8, hipMemcpyHostToDevice));
-    if (stream == MDPP_STREAM_ENV && h->cfg.kind == MDPP_KIND_DISCRETE) {
-        // start states drawn ahead from the old stream are void: empty every env's queue
+    if (stream == MDPP_STREAM_ENV && h->cfg.kind == MDPP_KIND_DISCRETE && h->dargs.fast_ok) {
+        // start states drawn ahead from the old stream are void: empty every env's queue.  (Only the
+        // packed-nibble kernels keep a queue in word 1 of the record; for every other handle that word
+        // holds history bytes 4-7 and must survive a re-seed.)
         HIPCHK(h, hipDeviceSynchronize());
         HIPCHK(h, hipMemset2D((char *)h->d_state + 4, 16, 0, 4, N));
     }
@@ -583,6 +592,12 @@ extern "C" int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words) {
     return MDPP_OK;
 }
 
+extern "C" int mdpp_set_options(mdpp_env *h, uint32_t disable_mask) {
+    if (!h) return MDPP_EINVAL;
+    h->opts = disable_mask;
+    return MDPP_OK;
+}
+
 static int check_ready(mdpp_env *h, const char *what) {
     if (!h->tables_ready) return fail(h, MDPP_ESTATE, std::string(what) + ": tables not uploaded");
     if (h->cfg.rng_mode == MDPP_RNG_NUMPY_PCG64) {
@@ -608,6 +623,7 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
     if (!h) return MDPP_EINVAL;
     int rc = check_ready(h, "mdpp_reset");
     if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
         if (h->cfg.image) {
@@ -643,7 +659,7 @@ extern "C" int mdpp_reset(mdpp_env *h, const uint8_t *mask_dev, void *obs_dev, v
 template <class Prepare, class Render>
 static int image_batches(mdpp_env *h, int K, hipStream_t s, Prepare prepare, Render render) {
     const int nb = (K + h->img_chunk - 1) / h->img_chunk;
-    const bool overlap = nb >= 2 && h->side_stream && !getenv("MDPP_NO_IMG_OVERLAP");
+    const bool overlap = nb >= 2 && h->side_stream && !(h->opts & MDPP_OPT_NO_IMG_OVERLAP);
     hipStream_t s2 = overlap ? h->side_stream : s;
     if (overlap) {
         HIPCHK(h, hipEventRecord(h->ev_entry, s));
@@ -673,6 +689,7 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
     if (!actions || !obs || !reward || !term || !trunc) return fail(h, MDPP_EINVAL, "step: null buffer");
     int rc = check_ready(h, "mdpp_step");
     if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
         if (h->cfg.image) {
@@ -760,6 +777,24 @@ extern "C" int mdpp_step(mdpp_env *h, const void *actions, void *obs, float *rew
 extern "C" int mdpp_step_n(mdpp_env *h, int K, const void *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *stream) {
     return step_common(h, K, actions, obs, reward, term, trunc, nullptr, stream);
+}
+
+extern "C" const char *mdpp_kernel_name(mdpp_env *h, int K) {
+    if (!h) return "";
+    h->kname[0] = 0;
+    if (K < 1 || check_ready(h, "mdpp_kernel_name")) return h->kname;
+    if (h->cfg.image) {      // the renderer is the dominant kernel of an image rollout
+        snprintf(h->kname, sizeof h->kname, "%s", h->cfg.kind == MDPP_KIND_DISCRETE ? image_obs_kernel_name(h)
+                 : h->cfg.kind == MDPP_KIND_GRID ? "k_imagec_obs<GRID=1>" : "k_imagec_obs<GRID=0>");
+        return h->kname;
+    }
+    if (h->cfg.kind == MDPP_KIND_DISCRETE)
+        (void)launch_discrete_step(h, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->kname);
+    else if (h->cfg.kind == MDPP_KIND_GRID)
+        (void)launch_grid_step(h, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->kname);
+    else
+        (void)launch_continuous_step(h, K, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, h->kname);
+    return h->kname;
 }
 
 // Python round(v, 15) for |v| <= 1: correctly rounded decimal conversion, like Pillow's rotate().
@@ -878,7 +913,7 @@ extern "C" int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist, int32_t *step
                 uint32_t b = (uint32_t)((hb >> (8 * (L - j))) & 0xFF);
                 hist[i * (L + 1) + j] = (b == 0xFF) ? -1 : (int32_t)b;
             }
-        if (steps) steps[i] = (int32_t)st[4 * i + 2];
+        if (steps) steps[i] = (int32_t)(st[4 * i + 2] & 0x7FFFFFFFu);    // (bit 31: next-step autoreset pending)
         if (ring) {
             for (int j = 0; j < d; j++) { // ring[0] pays out next
                 double v;
@@ -897,25 +932,56 @@ extern "C" int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist, int32_t *step
 extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const int32_t *steps,
                                        const double *ring) {
     if (!h || h->cfg.kind != MDPP_KIND_DISCRETE || !hist || !steps) return MDPP_EINVAL;
-    if (ring && !h->cfg.unit_rewards)
-        return fail(h, MDPP_EUNSUPPORTED, "set_state_discrete: ring import needs unit_rewards (values are stored as sequence keys)");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const size_t N = (size_t)h->cfg.num_envs;
     const int L = h->cfg.L, d = h->cfg.delay;
     std::vector<uint32_t> st(4 * N);
     HIPCHK(h, hipMemcpy(st.data(), h->d_state, N * 16, hipMemcpyDeviceToHost));
+    // the kernels rely on: every entry a valid state id or a NaN slot, NaN slots a contiguous OLDEST
+    // prefix (what reset() + steps produce, rl_toy_env.py:2275-2278, :2050-2052), the newest entry valid
+    for (size_t i = 0; i < N; i++) {
+        bool seen_valid = false;
+        for (int j = 0; j <= L; j++) {
+            const int32_t v = hist[i * (L + 1) + j];
+            if (v >= h->cfg.S) return fail(h, MDPP_EINVAL, "set_state_discrete: state id out of range");
+            if (v >= 0) seen_valid = true;
+            else if (seen_valid) return fail(h, MDPP_EINVAL, "set_state_discrete: a NaN slot newer than a valid state");
+        }
+        if (!seen_valid) return fail(h, MDPP_EINVAL, "set_state_discrete: the current state is a NaN slot");
+    }
+    if (ring && !h->cfg.unit_rewards && d > 0) {
+        // the delay line of non-unit rewards holds sequence KEYS (values are looked up at pop time): a
+        // value is imported as any key that pays exactly that value, 0.0 as "no key"
+        const size_t T = (size_t)h->cfg.num_tables;
+        std::vector<double> rt(T * h->nkeys);
+        HIPCHK(h, hipMemcpy(rt.data(), h->d_rtable, rt.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> keys((size_t)d * N);
+        for (size_t i = 0; i < N; i++) {
+            const double *tab = &rt[(T == 1 ? 0 : i) * (size_t)h->nkeys];
+            for (int j = 0; j < d; j++) {
+                const double v = ring[i * d + j];
+                uint32_t key = kNoKey;
+                if (v != 0.0) {
+                    for (uint32_t k = 0; k < h->nkeys && key == kNoKey; k++) if (tab[k] == v) key = k;
+                    if (key == kNoKey)
+                        return fail(h, MDPP_EINVAL, "set_state_discrete: a reward_buffer value that no rewardable sequence pays");
+                }
+                keys[(size_t)((h->tick + j) % d) * N + i] = key;
+            }
+        }
+        HIPCHK(h, hipMemcpy(h->d_ring, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+    }
     for (size_t i = 0; i < N; i++) {
         uint64_t hb = ~0ULL;
         for (int j = 0; j <= L; j++) {
             int32_t v = hist[i * (L + 1) + j];
-            if (v >= h->cfg.S) return fail(h, MDPP_EINVAL, "set_state_discrete: state id out of range");
             hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v);
         }
         st[4 * i] = (uint32_t)hb;
         if (!h->dargs.fast_ok) st[4 * i + 1] = (uint32_t)(hb >> 32); // fast path: word 1 is the draw queue
         st[4 * i + 2] = (uint32_t)steps[i];
-        if (ring) {
+        if (ring && h->cfg.unit_rewards) {
             uint32_t bits = 0;
             for (int j = 0; j < d; j++) bits |= (ring[i * d + j] != 0.0 ? 1u : 0u) << (d - 1 - j);
             st[4 * i + 3] = bits;
@@ -1021,12 +1087,14 @@ extern "C" int mdpp_status(mdpp_env *h, uint32_t *flags) {
 
 extern "C" int mdpp_timer_begin(mdpp_env *h, void *stream) {
     if (!h) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventRecord(h->ev0, (hipStream_t)stream));
     return MDPP_OK;
 }
 
 extern "C" int mdpp_timer_end(mdpp_env *h, void *stream, float *ms) {
     if (!h || !ms) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventRecord(h->ev1, (hipStream_t)stream));
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));

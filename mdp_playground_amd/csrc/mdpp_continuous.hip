@@ -348,6 +348,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     for (int d = 0; d < DMAX; d++) cur[d] = (d < D) ? a.cur[(long)d * N + i] : 0.0f;
     uint2 meta = a.meta[i];
     uint32_t steps = meta.x, flags = meta.y, status = 0;
+    // next-step autoreset: "episode ended, reset at the next call" travels in bit 1 of the flags word
+    const bool next_step = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    bool pending = next_step && (flags & 2u) != 0;
+    flags &= ~2u;
 
     Pcg64 env_pcg, sp_pcg;
     Philox env_phx, sp_phx;
@@ -382,19 +386,55 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         asm volatile("" : "+v"(tpw[j]), "+v"(fct[j]), "+v"(ifct[j]));
     }
     asm volatile("" : "+v"(smax), "+v"(amax), "+v"(inertia), "+v"(inv_inertia), "+v"(pns));
+    // reset() of this lane (same-step autoreset after a finished episode; next-step: the call after it)
+    auto lane_reset = [&]() __attribute__((always_inline)) {
+        if (PHILOX) {
+            c_reset_lane<DMAX, OMAX>(a, sp_phx, sd, cur, status);
+        } else {
+            if (!sp_loaded) { sp_pcg.load(a.sp_s, a.sp_inc, i); sp_loaded = true; }
+            c_reset_lane<DMAX, OMAX>(a, sp_pcg, sd, cur, status);
+        }
+        steps = 0; flags = 0;
+        if (a.line_L) {
+            c_gather_rel<DMAX>(a, cur, rel);
+            c_line_put<DMAX>(a, i, 0u, rel);
+            for (int dd = 0; dd < a.delay; dd++) a.ring64[(size_t)dd * N + i] = 0.0;
+        } else {
+            for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
+        }
+    };
+    auto put_obs = [&](long o) __attribute__((always_inline)) {
+        float *op = obs + o * D;
+        if (DMAX % 4 == 0 && D == DMAX) {
+#pragma unroll
+            for (int q = 0; q < DMAX / 4; q++)
+                ((float4 *)op)[q] = make_float4(cur[4 * q], cur[4 * q + 1], cur[4 * q + 2], cur[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int d = 0; d < DMAX; d++) if (d < D) op[d] = cur[d];
+        }
+    };
     float nact[DMAX];
     load_action(0, nact);
     for (int k = 0; k < K; k++) {
-        const uint32_t tick = a.tick + (uint32_t)k;
+        const uint32_t tick = a.tick + (uint32_t)k;              // ring head (mod delay below)
+        const uint32_t ptick = (uint32_t)(a.ptick + (uint64_t)k);
         const long o = (long)k * N + i;
         if (PHILOX) {
-            env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
-            sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
+            env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_ENV);
+            sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_SPACE);
         }
         // ---- action: fetched one step ahead (with one wave per SIMD nothing else hides the load)
 #pragma unroll
         for (int d = 0; d < DMAX; d++) act[d] = nact[d];
         load_action(k + 1 < K ? k + 1 : k, nact);
+        if (pending) {               // next-step autoreset: this call is the env's reset(), :2284-2323
+            lane_reset();
+            put_obs(o);
+            reward[o] = 0.0f; term[o] = 0; trunc[o] = 0;
+            pending = false;
+            continue;
+        }
         // ---- C1
         bool ok = true;
 #pragma unroll
@@ -536,36 +576,16 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         for (int d = 0; d < DMAX; d++) cur[d] = nxt[d];
         const bool truncated = (a.max_steps > 0) && (steps >= (uint32_t)a.max_steps);
 
-        if (a.autoreset && (done || truncated)) {
+        if (next_step) pending = done || truncated;
+        if (a.autoreset == MDPP_AUTORESET_SAME_STEP && (done || truncated)) {
             if (final_obs) {
 #pragma unroll
                 for (int d = 0; d < DMAX; d++) if (d < D) final_obs[o * D + d] = nxt[d];
             }
-            if (PHILOX) {
-                c_reset_lane<DMAX, OMAX>(a, sp_phx, sd, cur, status);
-            } else {
-                if (!sp_loaded) { sp_pcg.load(a.sp_s, a.sp_inc, i); sp_loaded = true; }
-                c_reset_lane<DMAX, OMAX>(a, sp_pcg, sd, cur, status);
-            }
-            steps = 0; flags = 0;
-            if (a.line_L) {
-                c_gather_rel<DMAX>(a, cur, rel);
-                c_line_put<DMAX>(a, i, 0u, rel);
-                for (int dd = 0; dd < a.delay; dd++) a.ring64[(size_t)dd * N + i] = 0.0;
-            } else {
-                for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
-            }
+            lane_reset();
         }
         // ---- outputs
-        float *op = obs + o * D;
-        if (DMAX % 4 == 0 && D == DMAX) {
-#pragma unroll
-            for (int q = 0; q < DMAX / 4; q++)
-                ((float4 *)op)[q] = make_float4(cur[4 * q], cur[4 * q + 1], cur[4 * q + 2], cur[4 * q + 3]);
-        } else {
-#pragma unroll
-            for (int d = 0; d < DMAX; d++) if (d < D) op[d] = cur[d];
-        }
+        put_obs(o);
         reward[o] = (float)r.v;
         term[o] = done ? 1 : 0;
         trunc[o] = truncated ? 1 : 0;
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             if (k <= n && d < D) a.sd[((long)k * D + d) * N + i] = sd[k][d];
 #pragma unroll
     for (int d = 0; d < DMAX; d++) if (d < D) a.cur[(long)d * N + i] = cur[d];
-    a.meta[i] = make_uint2(steps, flags);
+    a.meta[i] = make_uint2(steps, flags | (pending ? 2u : 0u));
     if (!PHILOX) {
         if (need_env) env_pcg.store(a.env_s, i);
         if (sp_loaded) sp_pcg.store(a.sp_s, i);
@@ -636,8 +656,12 @@ __global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, u
 template <int DMAX, int OMAX>
 static void launch_step_t(const ContinuousArgs &a, int K, const float *actions, float *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, float *final_obs,
-                          hipStream_t s) {
+                          hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_continuous_step<DMAX=%d,OMAX=%d,PHILOX=%d>", DMAX, OMAX, a.philox != 0);
+        return;
+    }
     if (a.philox)
         hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, true>), dim3(grid), dim3(kBlock), 0, s, a,
                            K, actions, obs, reward, term, trunc, final_obs);
@@ -672,9 +696,11 @@ static void launch_reset_t(const ContinuousArgs &a, uint32_t reset_tick, const u
     } while (0)
 
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
-                           uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
+                           uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
     ContinuousArgs a = h->cargs;
-    a.tick = h->tick;
+    a.opts = h->opts;
+    a.ptick = h->tick;
+    a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     if (a.fast_ok) {
         // common shape: dedicated rollout kernel (mdpp_continuous_fast.hip); its buffer descriptors
         // address < 4 GiB per array, so long rollouts go out as several launches
@@ -683,32 +709,37 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
         for (int k0 = 0; served && k0 < K;) {
             const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
             const size_t off = (size_t)k0 * a.N;
-            a.tick = h->tick + (uint32_t)k0;              // head of the delay ring for this piece
+            a.ptick = h->tick + (uint64_t)k0;
+            a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u;   // head of the delay ring for this piece
             served = launch_continuous_fast(a, kc, actions + off * a.D, obs + off * a.D, reward + off,
                                             term + off, trunc + off,
-                                            final_obs ? final_obs + off * a.D : nullptr, s);
+                                            final_obs ? final_obs + off * a.D : nullptr, s, name_out);
+            if (served && name_out) return MDPP_OK;      // (the first piece names the launch)
             if (!served && k0 > 0) { h->err = "k_continuous_rollout_fast: inconsistent dispatch"; return MDPP_EHIP; }
             k0 += kc;
         }
         if (served) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { h->err = std::string("k_continuous_rollout_fast launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
-            h->tick += (uint32_t)K;
+            h->tick += (uint64_t)K;
             return MDPP_OK;
         }
+        a.ptick = h->tick;
+        a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     }
-#define CALL_STEP(DM, OM) launch_step_t<DM, OM>(a, K, actions, obs, reward, term, trunc, final_obs, s)
+#define CALL_STEP(DM, OM) launch_step_t<DM, OM>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)
     MDPP_C_DISPATCH(CALL_STEP);
 #undef CALL_STEP
+    if (name_out) return MDPP_OK;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_continuous_step launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
-    h->tick += (uint32_t)K;
+    h->tick += (uint64_t)K;
     return MDPP_OK;
 }
 
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s) {
     ContinuousArgs a = h->cargs;
-#define CALL_RESET(DM, OM) launch_reset_t<DM, OM>(a, h->reset_tick, mask, obs, s)
+#define CALL_RESET(DM, OM) launch_reset_t<DM, OM>(a, (uint32_t)h->reset_tick, mask, obs, s)
     MDPP_C_DISPATCH(CALL_RESET);
 #undef CALL_RESET
     hipError_t e = hipGetLastError();

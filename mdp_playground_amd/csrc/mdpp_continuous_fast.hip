@@ -538,14 +538,20 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
 
 template <int D, int ORDER, int NREL, bool GEN>
 static void launch_g(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
-                     uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
+                     uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
-    if (a.has_p_noise || a.has_r_noise) {
-        // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
-        constexpr bool can_help = (size_t)kNRing * (D + 1) * kBlock * 8 <= 120 * 1024;
-        const bool helper = can_help && K >= 16 && (a.N % kBlock) == 0 && !getenv("MDPP_NO_HELPER");
+    constexpr bool can_help = (size_t)kNRing * (D + 1) * kBlock * 8 <= 120 * 1024;
+    const bool noise = a.has_p_noise || a.has_r_noise;
+    // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
+    const bool helper = noise && can_help && K >= 16 && (a.N % kBlock) == 0 && !(a.opts & MDPP_OPT_NO_HELPER);
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d>", D, ORDER, NREL,
+                 noise, helper, GEN);
+        return;
+    }
+    if (noise) {
         ContinuousArgs ap = a;
-        ap.park = getenv("MDPP_NO_PARK") ? 0 : 1;
+        ap.park = (a.opts & MDPP_OPT_NO_PARK) ? 0 : 1;
         if (can_help && helper)
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN>), dim3(grid),
                                dim3(2 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
@@ -560,19 +566,19 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
 
 template <int D, int ORDER, int NREL>
 static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
-                     uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s) {
+                     uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
     if (a.delay > 0 || a.every_n != 1 || a.n_boxes > 0 || !a.bounded)
-        launch_g<D, ORDER, NREL, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+        launch_g<D, ORDER, NREL, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     else
-        launch_g<D, ORDER, NREL, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+        launch_g<D, ORDER, NREL, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
 }
 
 // Returns false when the shape does not qualify (caller falls back to k_continuous_step).
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs,
                             float *reward, uint8_t *term, uint8_t *trunc, float *final_obs,
-                            hipStream_t s) {
-    if (!a.fast_ok || getenv("MDPP_NO_CFAST")) return false;
-#define MDPP_CF(DD, OO, RR) if (a.D == DD && a.order == OO && a.n_rel == RR) { launch_t<DD, OO, RR>(a, K, actions, obs, reward, term, trunc, final_obs, s); return true; }
+                            hipStream_t s, char *name_out) {
+    if (!a.fast_ok || (a.opts & MDPP_OPT_NO_CFAST)) return false;
+#define MDPP_CF(DD, OO, RR) if (a.D == DD && a.order == OO && a.n_rel == RR) { launch_t<DD, OO, RR>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out); return true; }
     MDPP_CF(12, 1, 4) MDPP_CF(12, 2, 4) MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)
     MDPP_CF(8, 1, 8) MDPP_CF(8, 2, 8) MDPP_CF(12, 1, 12) MDPP_CF(12, 2, 12)
     MDPP_CF(4, 1, 2) MDPP_CF(4, 2, 2) MDPP_CF(8, 1, 4) MDPP_CF(8, 2, 4)

@@ -106,6 +106,12 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     uint4 st = a.state[i];
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;
     uint32_t steps = st.z, ringbits = st.w, status = 0;
+    // next-step autoreset (gymnasium >= 1.0 vector envs): an env whose episode ended is reset by the NEXT
+    // step() call, which ignores its action and returns the first observation with reward 0 and no flags.
+    // The "episode ended" flag travels in bit 31 of the step counter.
+    const bool next_step = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    bool pending = next_step && (steps >> 31) != 0;
+    steps &= 0x7FFFFFFFu;
     uint32_t phase = steps % (uint32_t)a.every_n; // steps % every_n, kept incrementally below
 
     // Streams live in registers for the whole launch.  The env stream is needed by reward noise
@@ -165,13 +171,34 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
         for (int u = 0; u < kPrefetch; u++) {
             const int k = k0 + u;
             if (k >= K) break;
-            const uint32_t tick = a.tick + (uint32_t)k;
+            const uint32_t tick = a.tick + (uint32_t)k;          // ring head (mod delay below)
+            const uint32_t ptick = (uint32_t)(a.ptick + (uint64_t)k);
             const long o = (long)k * N + i;
             int action = act[u];
             if (PHILOX) {
-                env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
-                sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
-                if (IRR) sp1_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, kPhiloxIrrStream);
+                env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_ENV);
+                sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_SPACE);
+                if (IRR) sp1_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, kPhiloxIrrStream);
+            }
+            if (pending) {           // next-step autoreset: this call is the env's reset(), :2250-2278
+                const uint32_t s0 = PHILOX ? d_reset_draw(a, t, env_phx) : d_reset_draw(a, t, env_pcg);
+                if (IRR) {
+                    const double u1 = PHILOX ? np_random(env_phx) : np_random(env_pcg);
+                    cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, u1);
+                }
+                hist = d_fresh_hist(s0);
+                steps = 0; phase = 0; ringbits = 0;
+                if (!UNIT)
+                    for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * N + i] = kNoKey;
+                if (a.obs_i32) ((int32_t *)obs)[o * AW] = (int32_t)s0;
+                else ((int64_t *)obs)[o * AW] = (int64_t)s0;
+                if (IRR) {
+                    if (a.obs_i32) ((int32_t *)obs)[o * AW + 1] = (int32_t)cur1;
+                    else ((int64_t *)obs)[o * AW + 1] = (int64_t)cur1;
+                }
+                reward[o] = 0.0f; term[o] = 0; trunc[o] = 0;
+                pending = false;
+                continue;
             }
             if (action < 0 && action >= -A) action += A;       // numpy negative indexing
             if (action < 0 || action >= A) { status |= MDPP_STATUS_BAD_ACTION; action = 0; }
@@ -241,7 +268,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             }
             const bool truncated = (a.max_steps > 0) && (steps >= (uint32_t)a.max_steps);
             uint32_t out_state = nxt;
-            if (a.autoreset && (done || truncated)) {
+            if (next_step) pending = done || truncated;
+            if (a.autoreset == MDPP_AUTORESET_SAME_STEP && (done || truncated)) {
                 // gymnasium "same-step" autoreset: report the terminal transition's reward/flags,
                 // hand back the first observation of the next episode (reset(), :2250-2278).
                 if (final_obs) {
@@ -275,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
         }
     }
 
-    a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps, ringbits);
+    a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps | (pending ? 0x80000000u : 0u), ringbits);
     if (!PHILOX) {
         if (use_env) env_pcg.store(a.env_s, i);
         if (use_sp) sp_pcg.store(a.sp_s, i);
@@ -336,10 +364,16 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint3
 template <bool PHILOX, bool NOISE>
 static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
-                          hipStream_t s) {
+                          hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
-    const bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds);
+    // (tables beyond the default dynamic-LDS limit -- a large action space -- are read from HBM / L2)
+    const bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds) && a.lds_bytes <= 48u * 1024u;
     const size_t lds = ldstab ? a.lds_bytes : 0;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_step<PHILOX=%d,NOISE=%d,UNIT=%d,LDSTAB=%d,IRR=%d>", PHILOX, NOISE,
+                 a.unit_rewards != 0, ldstab, a.irr != 0);
+        return;
+    }
 #define MDPP_D_LAUNCH(UNIT, LDSTAB, IRR)                                                               \
     hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB, IRR>), dim3(grid), dim3(kBlock), \
                        lds, s, a, K, actions, obs, reward, term, trunc, final_obs)
@@ -354,9 +388,11 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
 }
 
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
-                         uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
+                         uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     DiscreteArgs a = h->dargs;
-    a.tick = h->tick;
+    a.opts = h->opts;
+    a.ptick = h->tick;
+    a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     const bool noise = a.has_p_noise || a.has_r_noise;
     if (a.fast_ok) {
         // common shape: dedicated rollout kernel (mdpp_discrete_fast.hip); its buffer descriptors
@@ -367,28 +403,31 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
         for (int k0 = 0; k0 < K;) {
             const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
             const size_t off = (size_t)k0 * a.N;
-            a.tick = h->tick + (uint32_t)k0;
+            a.ptick = h->tick + (uint64_t)k0;
+            a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u;
             void *fo = final_obs ? (void *)((char *)final_obs + off * osz) : nullptr;
             // long rollouts of full blocks: three-role pipelined kernel (mdpp_discrete_pipe.hip)
             if (!launch_discrete_pipe(a, kc, actions + off, (char *)obs + off * osz, reward + off,
-                                      term + off, trunc + off, fo, s))
+                                      term + off, trunc + off, fo, s, name_out))
                 launch_discrete_fast(a, kc, actions + off, (char *)obs + off * osz, reward + off,
-                                     term + off, trunc + off, fo, s);
+                                     term + off, trunc + off, fo, s, name_out);
+            if (name_out) return MDPP_OK;     // (the first piece names the launch)
             k0 += kc;
         }
-    } else if (launch_discrete_quiet(a, K, actions, obs, reward, term, trunc, final_obs, s)) {
+    } else if (launch_discrete_quiet(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
         // quiet shapes beyond the specialised kernels (larger S / L, irrelevant sub-space):
         // mdpp_discrete_quiet.hip
     } else if (a.philox) {
-        if (noise) launch_step_t<true, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
-        else launch_step_t<true, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+        if (noise) launch_step_t<true, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+        else launch_step_t<true, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     } else {
-        if (noise) launch_step_t<false, true>(a, K, actions, obs, reward, term, trunc, final_obs, s);
-        else launch_step_t<false, false>(a, K, actions, obs, reward, term, trunc, final_obs, s);
+        if (noise) launch_step_t<false, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+        else launch_step_t<false, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     }
+    if (name_out) return MDPP_OK;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_discrete_step launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
-    h->tick += (uint32_t)K;
+    h->tick += (uint64_t)K;
     return MDPP_OK;
 }
 
@@ -396,9 +435,9 @@ int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream
     DiscreteArgs a = h->dargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox)
-        hipLaunchKernelGGL(k_discrete_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
+        hipLaunchKernelGGL(k_discrete_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
     else
-        hipLaunchKernelGGL(k_discrete_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
+        hipLaunchKernelGGL(k_discrete_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_discrete_reset launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->reset_tick += 1;

@@ -31,6 +31,8 @@
 // HBM traffic per env step: 4 B action in; 8 B obs + 4 B reward + 1 B + 1 B flags out.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_discrete_rollo
 // Returns false when the shape does not qualify (caller falls back to k_discrete_step).
 bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
-                          hipStream_t s) {
+                          hipStream_t s, char *name_out) {
     if (!a.fast_ok) return false;
 #ifdef MDPP_ABL_HALFWAVE
     const int grid = (a.N + kBlock / 2 - 1) / (kBlock / 2);
@@ -410,7 +412,11 @@ bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, 
 #endif
     const bool pow2 = a.s_shift != 0xFFFFFFFFu, dl = a.delay > 0, s8 = a.S <= 8;
     // helper waves pay off on long rollouts of full 256-env blocks
-    const bool helper = K >= 32 && (a.N % kBlock) == 0 && a.autoreset && !getenv("MDPP_NO_HELPER");
+    const bool helper = K >= 32 && (a.N % kBlock) == 0 && a.autoreset && !(a.opts & MDPP_OPT_NO_HELPER);
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_rollout_fast<OBS64=%d,POW2=%d,DELAY=%d,S8=%d,HELPER=%d>", !a.obs_i32, pow2, dl, s8, helper);
+        return true;
+    }
 #define MDPP_FAST_LAUNCH(O64, P2, DL, S8, HP)                                                   \
     hipLaunchKernelGGL((k_discrete_rollout_fast<O64, P2, DL, S8, HP>), dim3(grid),             \
                        dim3(HP ? 2 * kBlock : kBlock), 0, s, a, K, actions, obs, reward, term, \

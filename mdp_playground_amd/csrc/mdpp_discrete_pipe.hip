@@ -18,6 +18,8 @@
 // hanging.  Results are bit-identical to the single-role kernels (same tests).
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -361,10 +363,14 @@ __global__ __launch_bounds__(3 * kBlock) void k_discrete_rollout_pipe(DiscreteAr
 // Returns false when the shape does not qualify (caller uses k_discrete_rollout_fast).
 bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
-                          hipStream_t s) {
-    if (!a.fast_ok || K < 32 || (a.N % kBlock) != 0 || !a.autoreset || getenv("MDPP_NO_PIPE")) return false;
+                          hipStream_t s, char *name_out) {
+    if (!a.fast_ok || K < 32 || (a.N % kBlock) != 0 || !a.autoreset || (a.opts & MDPP_OPT_NO_PIPE)) return false;
     const int grid = a.N / kBlock;
     const bool pow2 = a.s_shift != 0xFFFFFFFFu, dl = a.delay > 0, s8 = a.S <= 8;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_rollout_pipe<OBS64=%d,POW2=%d,DELAY=%d,S8=%d>", !a.obs_i32, pow2, dl, s8);
+        return true;
+    }
 #define MDPP_PIPE_LAUNCH(O64, P2, DL, S8)                                                         \
     hipLaunchKernelGGL((k_discrete_rollout_pipe<O64, P2, DL, S8>), dim3(grid), dim3(3 * kBlock), \
                        0, s, a, K, actions, obs, reward, term, trunc, final_obs)

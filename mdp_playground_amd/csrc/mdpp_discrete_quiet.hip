@@ -29,6 +29,8 @@
 // every spin bounded (MDPP_STATUS_INTERNAL instead of a hang).
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -532,11 +534,12 @@ static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t
 
 // Serves the launch if the handle and the launch shape qualify; false = not taken.
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
-                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    if (a.philox || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || getenv("MDPP_NO_QUIET"))
+                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
+    if (a.autoreset == MDPP_AUTORESET_NEXT_STEP) return false;
+    if (a.philox || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
         return false;
     const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
-    if ((pn || rn) && getenv("MDPP_NO_QUIET_NOISE")) return false;
+    if ((pn || rn) && (a.opts & MDPP_OPT_NO_QUIET_NOISE)) return false;
     const unsigned long long bytes = (unsigned long long)K * a.N * (a.irr ? 2 : 1) * 8ULL;
     if (bytes >= (1ULL << 32)) return false;                    // buffer descriptors address < 4 GiB per array
     const size_t S8 = (size_t)((a.S + 7) & ~7);
@@ -549,9 +552,13 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     // enough to fill the ring
     const size_t depth = rn ? 16 : kQDepth;
     const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
-    const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !getenv("MDPP_NO_DUO");
-    const bool trio = duo && a.autoreset && !rn && !getenv("MDPP_NO_TRIO");
+    const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
+    const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = trio ? 3 : duo ? 2 : 1;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d>", !a.obs_i32, a.irr != 0, roles, pn, rn);
+        return true;
+    }
     const size_t l = roles == 1 ? lds : lds_duo;
 #define MDPP_Q_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
 #define MDPP_Q_ROLES(O64, IR, PN_, RN_)                                                           \

@@ -52,6 +52,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
     const uint4 st = a.state[i];
     int cell[4] = {(int)(st.x & 0xFF), (int)((st.x >> 8) & 0xFF), (int)((st.x >> 16) & 0xFF), (int)(st.x >> 24)};
     uint32_t steps = st.y, flags = st.z, status = 0;
+    // next-step autoreset: "episode ended, reset at the next call" travels in bit 1 of the flags word
+    const bool next_step = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    bool pending = next_step && (flags & 2u) != 0;
+    flags &= ~2u;
 
     Pcg64 env_pcg, sp_pcg, act_pcg;
     Philox env_phx, sp_phx, act_phx;
@@ -90,6 +94,15 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
     int pre[kGPrefetch][4];
 #pragma unroll
     for (int u = 0; u < kGPrefetch; u++) load_act(u, pre[u]);
+    // reset() of this lane (same-step autoreset after a finished episode; next-step: the call after it)
+    auto lane_reset = [&]() __attribute__((always_inline)) {
+        if (PHILOX) g_reset_lane(a, sp_phx, cell);
+        else {
+            if (!sp_loaded) { sp_pcg.load(a.sp_s, a.sp_inc, i); sp_loaded = true; }
+            g_reset_lane(a, sp_pcg, cell);
+        }
+        steps = 0; flags = 0;
+    };
 
     for (int k0 = 0; k0 < K; k0 += kGPrefetch) {
 #pragma unroll
@@ -98,13 +111,20 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
         if (k >= K) break;
         int act[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
         load_act(k + kGPrefetch, pre[u]);
-        const uint32_t tick = a.tick + (uint32_t)k;
+        const uint32_t tick = (uint32_t)(a.ptick + (uint64_t)k);
         const long o = (long)k * N + i;
         if (PHILOX) {
             env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
             sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_SPACE);
             act_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, kPhiloxActionStream);
             phx_h = Half32{0, 0};
+        }
+        if (pending) {               // next-step autoreset: this call is the env's reset(), :2325-2345
+            lane_reset();
+            put_obs(obs, o, cell);
+            reward[o] = 0.0f; term[o] = 0; trunc[o] = 0;
+            pending = false;
+            continue;
         }
         bool ok = true;
         int nz = 0;
@@ -158,14 +178,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
         const bool done = (flags & 1u) != 0;                  // :2102-2104
         if (done) r += a.term_add;
         const bool truncated = (a.max_steps > 0) && (steps >= (uint32_t)a.max_steps);
-        if (a.autoreset && (done || truncated)) {
+        if (next_step) pending = done || truncated;
+        if (a.autoreset == MDPP_AUTORESET_SAME_STEP && (done || truncated)) {
             if (final_obs) put_obs(final_obs, o, cell);
-            if (PHILOX) g_reset_lane(a, sp_phx, cell);
-            else {
-                if (!sp_loaded) { sp_pcg.load(a.sp_s, a.sp_inc, i); sp_loaded = true; }
-                g_reset_lane(a, sp_pcg, cell);
-            }
-            steps = 0; flags = 0;
+            lane_reset();
         }
         put_obs(obs, o, cell);
         reward[o] = (float)r;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
       }
     }
     a.state[i] = make_uint4((uint32_t)cell[0] | ((uint32_t)cell[1] << 8) | ((uint32_t)cell[2] << 16) |
-                                ((uint32_t)cell[3] << 24), steps, flags, 0u);
+                                ((uint32_t)cell[3] << 24), steps, flags | (pending ? 2u : 0u), 0u);
     if (!PHILOX) {
         if (need_env) env_pcg.store(a.env_s, i);
         if (sp_loaded) sp_pcg.store(a.sp_s, i);
@@ -422,15 +438,22 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
 }
 
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
-                     uint8_t *trunc, void *final_obs, hipStream_t s) {
+                     uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     GridArgs a = h->gargs;
-    a.tick = h->tick;
+    a.opts = h->opts;
+    a.ptick = h->tick;
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)
-    if (!a.philox && !(noise && getenv("MDPP_NO_GFAST_NOISE")) && !getenv("MDPP_NO_GFAST") &&
+    if (!a.philox && a.autoreset != MDPP_AUTORESET_NEXT_STEP && !(noise && (a.opts & MDPP_OPT_NO_GFAST_NOISE)) &&
+        !(a.opts & MDPP_OPT_NO_GFAST) &&
         (unsigned long long)K * a.N * a.G * 8ULL < (1ULL << 32)) {
         const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
+        if (name_out) {
+            snprintf(name_out, kNameLen, "k_grid_rollout_fast<OBS64=%d,G4=%d,DENSE=%d,PN=%d,RN=%d>", !a.obs_i32, a.G == 4,
+                     a.make_denser != 0, pn, rn);
+            return MDPP_OK;
+        }
 #define MDPP_GF_LAUNCH(O64, G4, DN, PN_, RN_) hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN, PN_, RN_>), dim3(grid), dim3(kBlock), \
                                                                  0, s, a, K, actions, obs, reward, term, trunc, final_obs)
 #define MDPP_GF_NZ(O64, G4, DN)                                                  \
@@ -448,7 +471,11 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
 #undef MDPP_GF_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { h->err = std::string("k_grid_rollout_fast launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
-        h->tick += (uint32_t)K;
+        h->tick += (uint64_t)K;
+        return MDPP_OK;
+    }
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_grid_step<PHILOX=%d,NOISE=%d>", a.philox != 0, noise);
         return MDPP_OK;
     }
 #define MDPP_G_LAUNCH(PH, NZ) hipLaunchKernelGGL((k_grid_step<PH, NZ>), dim3(grid), dim3(kBlock), 0, s, a, K, actions, \
@@ -458,15 +485,15 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
 #undef MDPP_G_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_grid_step launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
-    h->tick += (uint32_t)K;
+    h->tick += (uint64_t)K;
     return MDPP_OK;
 }
 
 int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
     GridArgs a = h->gargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
-    if (a.philox) hipLaunchKernelGGL(k_grid_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
-    else hipLaunchKernelGGL(k_grid_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
+    if (a.philox) hipLaunchKernelGGL(k_grid_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
+    else hipLaunchKernelGGL(k_grid_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_grid_reset launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->reset_tick += 1;

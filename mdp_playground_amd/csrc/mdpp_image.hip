@@ -518,7 +518,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         const int per_block = kBlock / 64;
         const long M = (long)K * a.N * a.SUB;
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
-        if (h->img_fast_ok && !getenv("MDPP_NO_IMGFAST")) {
+        if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST)) {
             // 40 KiB of LDS per workgroup: 4 resident workgroups per CU
             // (phase 2 = the pipelined rollout: a few CUs keep a slot free, so that the next batch's state
             // kernel, which needs a little LDS, can run beside this one)
@@ -546,6 +546,12 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_image_obs launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     return MDPP_OK;
+}
+
+const char *image_obs_kernel_name(const mdpp_env *h) {
+    if (!(h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST))) return "k_image_obs";
+    const int nst = (int)(((size_t)h->cfg.img_w * h->cfg.img_h / 16 + 63) / 64);
+    return nst == 7 ? "k_image_obs_fast<NST=7>" : nst == 4 ? "k_image_obs_fast<NST=4>" : "k_image_obs_fast<NST=0>";
 }
 
 } // namespace mdpp

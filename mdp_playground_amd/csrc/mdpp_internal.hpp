@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <string>
 
@@ -28,7 +29,9 @@ struct DiscreteArgs {
     int32_t autoreset, max_steps, obs_i32;
     int32_t philox;
     uint32_t nkeys;             // S^L
-    uint32_t tick;              // number of env steps taken by this handle before this launch
+    uint32_t tick;              // head of the delay ring at this launch: env steps taken so far mod delay
+    uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)
+    uint32_t opts;              // MDPP_OPT_* (host side: kernel selection only)
     uint64_t philox_seed;
     int64_t env_id_offset;
     double r_noise, scale, shift, term_add; // term_add = term_state_reward * reward_scale
@@ -70,7 +73,9 @@ struct ContinuousArgs {
     int32_t N, D, n_rel, order, delay, every_n;
     int32_t make_denser, has_p_noise, has_r_noise, bounded;
     int32_t autoreset, max_steps, philox, n_boxes, rel_prefix;
-    uint32_t tick;
+    uint32_t tick;              // head of the delay ring at this launch: env steps taken so far mod delay
+    uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)
+    uint32_t opts;              // MDPP_OPT_* (host side: kernel selection only)
     uint64_t philox_seed;
     int64_t env_id_offset;
     float inertia32, amax32, smax32, radius32, alw32, scale32, shift32, term_add32;
@@ -110,7 +115,8 @@ struct GridArgs {
     int32_t shape[4], target[2];
     int32_t make_denser, has_p_noise, has_r_noise, every_n;
     int32_t autoreset, max_steps, obs_i32, philox;
-    uint32_t tick;
+    uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)
+    uint32_t opts;              // MDPP_OPT_* (host side: kernel selection only)
     uint64_t philox_seed;
     int64_t env_id_offset;
     double p_noise, r_noise, scale, shift, term_add;
@@ -129,8 +135,10 @@ struct mdpp_env {
     int device;
     int num_cus;                // compute units of `device` (persistent-kernel grids)
     std::string err;
-    uint32_t tick;              // env steps taken so far (ring head, Philox counter)
-    uint32_t reset_tick;        // reset() calls so far (Philox counter)
+    uint64_t tick;              // env steps taken so far (ring head = tick mod delay; Philox counter)
+    uint64_t reset_tick;        // reset() calls so far (Philox counter)
+    uint32_t opts;              // MDPP_OPT_* kernel-selection switches (mdpp_set_options)
+    char kname[192];            // mdpp_kernel_name()
     // device allocations
     void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
     void *d_state, *d_ring, *d_status;
@@ -159,28 +167,32 @@ struct mdpp_env {
 
 namespace mdpp {
 // implemented in the kernel translation units
+// name_out != nullptr: a dry run -- the launcher writes the name of the kernel it would launch (at most
+// kNameLen bytes) and launches nothing
+constexpr int kNameLen = 192;
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
-                         uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
+                         uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
 bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
-                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
+                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
-                           uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
+                           uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
-                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
+                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
-                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s);
+                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
-                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s);
+                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_states, const uint8_t *term,
                       const uint8_t *trunc, const uint8_t *mask, uint8_t *img_out, uint8_t *img_final, hipStream_t s);
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,
-                     uint8_t *trunc, void *final_obs, hipStream_t s);
+                     uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
 // phase bits: 1 = draw + records, 2 = render (phase == 2 exactly: pipelined, the persistent grid leaves slots
 // free for the next batch's state kernel; 6 = render only on the full grid); buf: scratch set (0 / 1)
 int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase = 3, int buf = 0);
+const char *image_obs_kernel_name(const mdpp_env *h);    // the renderer launch_image_obs() uses
 } // namespace mdpp

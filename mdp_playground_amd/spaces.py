@@ -91,3 +91,30 @@ class BoxSpace:
 class ImageSpace(BoxSpace):
     def __init__(self, width, height):
         super().__init__(0, 255, (width, height, 1), dtype=np.uint8)
+
+
+class BatchedSpace:
+    """The space of a batch of `n` independent copies of `single` (what gymnasium's
+    vector.utils.batch_space builds for VectorEnv.observation_space / action_space): shape
+    (n,) + single.shape, sample() stacks n samples of the single space, contains() checks every row."""
+
+    def __init__(self, single, n):
+        self.single, self.n = single, int(n)
+        self.dtype = single.dtype
+        self.shape = None if single.shape is None else (self.n,) + tuple(single.shape)
+
+    def sample(self):
+        rows = [self.single.sample() for _ in range(self.n)]
+        if isinstance(self.single, TupleSpace):
+            return tuple(np.asarray(col) for col in zip(*rows))
+        return np.stack([np.asarray(r) for r in rows])
+
+    def contains(self, x):
+        if isinstance(self.single, TupleSpace):
+            return len(x) == len(self.single) and all(
+                len(col) == self.n and all(sp.contains(v) for v in col) for sp, col in zip(self.single.spaces, x))
+        x = np.asarray(x)
+        return x.shape[0] == self.n and all(self.single.contains(row) for row in x)
+
+    def __repr__(self):
+        return f"BatchedSpace({self.single!r}, {self.n})"

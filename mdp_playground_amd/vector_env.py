@@ -25,9 +25,10 @@ import torch
 
 from . import _capi as capi
 from . import mdp as mdp_mod
-from .spaces import BoxSpace, DiscreteSpace, ImageSpace, TupleSpace
+from .spaces import BatchedSpace, BoxSpace, DiscreteSpace, ImageSpace, TupleSpace
 
-_AUTORESET = {"disabled": capi.AUTORESET_DISABLED, "same_step": capi.AUTORESET_SAME_STEP}
+_AUTORESET = {"disabled": capi.AUTORESET_DISABLED, "same_step": capi.AUTORESET_SAME_STEP,
+              "next_step": capi.AUTORESET_NEXT_STEP}
 
 
 def _stack(arrs, dtype):
@@ -46,12 +47,14 @@ class RLToyVectorEnv:
             raise capi.MdppError("RLToyVectorEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
         if autoreset not in _AUTORESET:
-            raise ValueError("autoreset must be 'same_step' or 'disabled'")
+            raise ValueError("autoreset must be 'same_step', 'next_step' or 'disabled'")
         if rng not in ("numpy", "philox"):
             raise ValueError("rng must be 'numpy' or 'philox'")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.type != "cuda":
             raise capi.MdppError("device must be a cuda (ROCm) device")
+        if self.device.index is None:          # 'cuda' -> 'cuda:<current>': step() compares tensors' devices with it
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.config = copy.deepcopy(config)   # the reference mutates its config (:339,...); we do not
         if seeds is not None:
             if num_envs is not None and num_envs != len(seeds):
@@ -100,7 +103,7 @@ class RLToyVectorEnv:
         else:
             self._init_continuous(cfg)
         h = C.c_void_p()
-        rc = self._lib.mdpp_create(C.byref(cfg), self.device.index or 0, C.byref(h))
+        rc = self._lib.mdpp_create(C.byref(cfg), self.device.index, C.byref(h))
         capi.check(self._lib, None, rc, "mdpp_create")
         self._h = h
         self._cfg = cfg
@@ -180,11 +183,6 @@ class RLToyVectorEnv:
         self.transition_matrix = m.P
         self.rewardable_sequences = m.rewardable_sequences
         self.reward_matrix = m.reward_matrix               # use_custom_mdp with matrices (:1259-1267)
-        # mirrors DiscreteArgs.fast_ok (mdpp_capi.hip): which kernel serves this handle
-        self.uses_fast_kernel = bool(
-            not self._per_env and cfg.unit_rewards and not cfg.has_transition_noise
-            and not cfg.has_reward_noise and m.sequence_length <= 3 and m.S <= 16
-            and m.delay <= 32 and self.rng == "numpy" and not self._irr)
 
     def _upload_discrete(self):
         ms = self.mdps
@@ -316,8 +314,9 @@ class RLToyVectorEnv:
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
         self._term = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._trunc = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self.observation_space = self.single_observation_space
-        self.action_space = self.single_action_space
+        # batched spaces, as gymnasium's VectorEnv exposes them next to the single_* ones
+        self.observation_space = BatchedSpace(self.single_observation_space, N)
+        self.action_space = BatchedSpace(self.single_action_space, N)
         # everything step() passes on every call, prepared once (the call itself is the hot path)
         self._mdpp_step = self._lib.mdpp_step
         self._p_obs, self._p_final = self._obs.data_ptr(), self._final_obs.data_ptr()
@@ -436,6 +435,47 @@ class RLToyVectorEnv:
             self._seed_streams(seed, initial=False)
         return self._reset_all(mask), {}
 
+    def seed(self, seed=None):
+        """seed(seed) -> int, rl_toy_env.py:2379-2406: re-seeds the env generators (not the spaces') —
+        env i of the batch gets seed + i, like reset(seed=...) — and returns the seed; None draws one
+        from OS entropy as gymnasium's seeding.np_random does."""
+        if self.rng != "numpy":
+            raise capi.MdppError("seed() re-seeds numpy streams; this env uses rng='philox'")
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy)
+        if not isinstance(seed, int) or seed < 0:
+            raise TypeError("seed must be a non-negative python int")    # gymnasium.utils.seeding.np_random
+        self._seed_streams(seed, initial=False)
+        self.seed_ = seed
+        return seed
+
+    def step_graph(self, actions):
+        """A replayable HIP graph of K single steps (K = actions.shape[0] mdpp_step launches captured
+        once): the one-launch-per-step API without the per-call host cost.  actions: [K, N, ...] as for
+        rollout(); the tensor is read at every replay, so writing new actions into it between replays
+        steps with them.  Returns an object with .replay() and the output buffers
+        .obs/.reward/.terminated/.truncated ([K, N, ...]).  Exact for numpy-stream handles with unit
+        rewards (include/mdpp.h: the step counter travels by value into the captured launches)."""
+        K = int(actions.shape[0])
+        a = self._as_actions(actions, K)
+        obs, rew, term, trunc = self.alloc_rollout(K)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        g = torch.cuda.CUDAGraph()
+        step, h = self._lib.mdpp_step, self._h
+
+        def launches(stream):
+            for k in range(K):
+                rc = step(h, a[k].data_ptr(), obs[k].data_ptr(), rew[k].data_ptr(), term[k].data_ptr(),
+                          trunc[k].data_ptr(), None, stream)
+                if rc:
+                    capi.check(self._lib, h, rc, "mdpp_step")
+        with torch.cuda.graph(g, stream=side):
+            launches(side.cuda_stream)
+        g.actions, g.obs, g.reward = a, obs, rew
+        g.terminated, g.truncated = term.view(torch.bool), trunc.view(torch.bool)
+        return g
+
     def step(self, actions):
         """step(actions) -> (obs, reward, terminated, truncated, info), rl_toy_env.py:1992.
         Returned tensors alias preallocated device buffers (valid until the next call)."""
@@ -465,37 +505,19 @@ class RLToyVectorEnv:
         return obs, rew, term.view(torch.bool), trunc.view(torch.bool)
 
     def rollout_kernel_name(self, K):
-        """Name of the kernel mdpp_step_n(K) dispatches to (mirrors the C++ dispatch; for reports)."""
-        full_blocks = self.num_envs % 256 == 0
-        if self.kind == "discrete":
-            if getattr(self, "_image", None) is not None:
-                # mdpp_capi.hip img_fast_ok (shape part): dword rows, 16-byte chunks, padded template <= 64
-                W, H = int(self._cfg.img_w), int(self._cfg.img_h)
-                fast = H % 4 == 0 and (W * H) % 16 == 0 and self._image["tpl_size"] + 16 <= 64
-                return "k_image_obs_fast" if fast else "k_image_obs"
-            if not self.uses_fast_kernel:
-                # mirrors launch_discrete_quiet (mdpp_discrete_quiet.hip)
-                c = self._cfg
-                quiet = self.rng == "numpy" and not self._per_env and c.unit_rewards and K >= 16
-                return "k_discrete_rollout_quiet" if quiet else "k_discrete_step"
-            if K >= 32 and full_blocks and self.autoreset == "same_step":
-                return "k_discrete_rollout_pipe"
-            return "k_discrete_rollout_fast"
-        if self.kind == "grid":
-            if getattr(self, "_image", None) is not None:
-                return "k_imagec_obs"
-            m = self.mdps[0]
-            return "k_grid_rollout_fast" if self.rng == "numpy" else "k_grid_step"
-        m = self.mdps[0]
-        if getattr(self, "_image", None) is not None:
-            return "k_imagec_obs"
-        fast = (self.rng == "numpy" and m.reward_function == "move_to_a_point"
-                and (np.isfinite(m.state_space_max) or np.isfinite(m.action_space_max))
-                and list(m.relevant_indices) == list(range(len(m.relevant_indices)))
-                and (m.D, m.order, len(m.relevant_indices)) in
-                {(12, 1, 4), (12, 2, 4), (2, 1, 2), (2, 2, 2), (4, 1, 4), (4, 2, 4), (8, 1, 8), (8, 2, 8),
-                 (12, 1, 12), (12, 2, 12), (4, 1, 2), (4, 2, 2), (8, 1, 4), (8, 2, 4)})
-        return "k_continuous_rollout_fast" if fast else "k_continuous_step"
+        """Name (with template arguments) of the kernel mdpp_step_n(K) launches for this handle, as
+        decided by the library's own dispatch code (mdpp_kernel_name; nothing is launched)."""
+        name = self._lib.mdpp_kernel_name(self._h, int(K))
+        return name.decode() if name else ""
+
+    def set_kernel_options(self, *disable):
+        """Take specialised kernels out of the dispatch (names of capi.OPTIONS, e.g. "NO_PIPE"): the
+        handle then runs on the more general kernel of the same arithmetic.  Tests / profiling only;
+        results do not depend on it.  No arguments = default dispatch."""
+        mask = 0
+        for d in disable:
+            mask |= capi.OPTIONS[d]
+        capi.check(self._lib, self._h, self._lib.mdpp_set_options(self._h, mask), "mdpp_set_options")
 
     def alloc_rollout(self, K):
         N, dev = self.num_envs, self.device
@@ -578,8 +600,8 @@ class RLToyVectorEnv:
         if self.kind == "discrete":
             hist = np.ascontiguousarray(state["augmented_state"], dtype=np.int32)
             steps = np.ascontiguousarray(state["total_transitions_episode"], dtype=np.int32)
-            ring = state.get("reward_buffer")
-            ring = None if ring is None or not self._cfg.unit_rewards else np.ascontiguousarray(ring, np.float64)
+            ring = state.get("reward_buffer")       # (absent: the delay line stays as it is, like the reference)
+            ring = None if ring is None else np.ascontiguousarray(ring, np.float64)
             rc = self._lib.mdpp_set_state_discrete(self._h, capi.nptr(hist), capi.nptr(steps), capi.nptr(ring))
             capi.check(self._lib, self._h, rc, "mdpp_set_state_discrete")
             if self._irr:

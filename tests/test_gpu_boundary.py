@@ -1,0 +1,296 @@
+"""GPU tests of the drop-in boundary itself: autoreset modes, seed(), batched
+spaces, the per-handle kernel switches and kernel names, state import validation, the replayable
+graph of single steps.  Everything goes through the C ABI (RLToyVectorEnv -> libmdpp_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from test_gpu_parity import _oracle_for, _venv
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_oracle_streams(env, o, i):
+    from mdp_playground_amd import _capi as capi
+    if env.kind == "grid":
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i], env.seeded_streams[capi.STREAM_ACTION][i])
+    else:
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        if env.kind == "discrete" and env._irr:
+            o.set_rng_irr(env.seeded_streams[capi.STREAM_SPACE_IRR][i])
+
+
+def _rand_actions(env, T, rng):
+    N = env.num_envs
+    if env.kind == "discrete" and env._irr:
+        m = env.mdps[0]
+        return np.stack([rng.integers(0, m.A, size=(T, N)), rng.integers(0, m.A_irr, size=(T, N))], axis=2).astype(np.int32)
+    if env.kind == "discrete":
+        return rng.integers(0, env.mdps[0].A, size=(T, N)).astype(np.int32)
+    if env.kind == "grid":
+        G = len(env.mdps[0].grid_shape)
+        ac = np.zeros((T, N, G), np.int32)
+        np.put_along_axis(ac, rng.integers(0, G, size=(T, N, 1)), rng.integers(-1, 2, size=(T, N, 1)).astype(np.int32), axis=2)
+        return ac
+    return rng.uniform(-1, 1, size=(T, N, env.mdps[0].D)).astype(np.float32)
+
+
+def _oracle_step(o, kind, a):
+    if kind == "continuous":
+        ob, r, _, d = o.step(a)
+        return ob, r, d
+    return o.step(a if kind != "discrete" or np.ndim(a) else int(a))
+
+
+@pytest.mark.parametrize("name,max_steps", [("d_cfg2", 0), ("d_cfg2_noise", 7), ("d_irr_noise", 0), ("c_cfg5", 5),
+                                            ("c_sparse_term", 0), ("g_noise_sparse", 0)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_next_step_autoreset_vs_oracle_loop(name, max_steps, fused):
+    """autoreset="next_step" (gymnasium >= 1.0 vector envs): the call after an episode's last step
+    ignores that env's action, calls reset() and returns (first obs, 0.0, False, False) — against the
+    oracle driven by exactly that loop; noisy configs, so the streams must not move on the reset call."""
+    cfg = dict(gu.CASES[name]["config"], seed=13)
+    N, T = 384, 60
+    env = _venv(num_envs=N, autoreset="next_step", max_episode_steps=max_steps or None, **cfg)
+    assert "rollout" not in env.rollout_kernel_name(T)            # general kernels serve this mode
+    rng = np.random.default_rng(3)
+    acts = _rand_actions(env, T, rng)
+    init = env._obs.cpu().numpy().copy()
+    acts_t = torch.as_tensor(acts, device=env.device)
+    if fused:
+        obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(acts_t))
+    else:
+        outs = []
+        for t in range(T):
+            o_, r_, te_, tr_, info = env.step(acts_t[t])
+            assert "final_obs" not in info
+            outs.append((o_.cpu().numpy().copy(), r_.cpu().numpy().copy(), te_.cpu().numpy().copy(), tr_.cpu().numpy().copy()))
+        obs, rew, term, trunc = (np.stack(x) for x in zip(*outs))
+    assert (term | trunc).any()
+    for i in range(0, N, 5):
+        o = _oracle_for(env, i)
+        _set_oracle_streams(env, o, i)
+        assert np.array_equal(np.asarray(o.reset()), init[i])
+        pending, n = False, 0
+        for t in range(T):
+            if pending:
+                eo, er, ed, etr = o.reset(), 0.0, False, False
+                pending, n = False, 0
+            else:
+                eo, er, ed = _oracle_step(o, env.kind, acts[t, i])
+                n += 1
+                etr = bool(max_steps) and n >= max_steps
+                pending = ed or etr
+            assert np.array_equal(np.asarray(eo), obs[t, i]), (name, i, t)
+            assert rew[t, i] == np.float32(er) and bool(term[t, i]) == ed and bool(trunc[t, i]) == etr, (name, i, t)
+    assert (env.status() == 0).all()
+    env.close()
+
+
+def test_next_step_state_roundtrip_clears_nothing_it_should_not():
+    """get/set_augmented_state on a next_step handle: the pending flag is not part of the exported
+    counters (steps stay small), and an explicit reset() clears it."""
+    cfg = dict(gu.CASES["d_cfg2"]["config"], seed=2)
+    env = _venv(num_envs=256, autoreset="next_step", **cfg)
+    acts = torch.randint(0, 8, (40, 256), device=env.device, dtype=torch.int32)
+    _, _, term, _ = env.rollout(acts)
+    st = env.get_augmented_state()
+    assert st["total_transitions_episode"].max() < 64
+    env.reset()
+    o, r, te, tr, _ = env.step(acts[0])
+    # after an explicit reset nobody is pending: a pending env would return reward 0 and its reset obs
+    # with steps 0; here every env made one transition
+    assert (env.get_augmented_state()["total_transitions_episode"] == 1).all()
+    env.close()
+
+
+def test_next_step_refused_with_images():
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
+               image_representations=True, image_width=32, image_height=32, seed=0)
+    with pytest.raises(capi.MdppError):
+        _venv(num_envs=8, autoreset="next_step", **cfg)
+
+
+def test_seed_returns_seed_and_reseeds_env_streams():
+    """seed(s) -> s (rl_toy_env.py:2379-2406); env i continues from PCG64(SeedSequence(s + i))."""
+    from mdp_playground_amd import mdp as mdp_mod
+    cfg = dict(gu.CASES["d_cfg2_noise"]["config"], seed=4)
+    N, T = 128, 30
+    env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    assert env.seed(4242) == 4242
+    with pytest.raises(TypeError):
+        env.seed(-1)
+    assert isinstance(env.seed(), int)
+    assert env.seed(99) == 99
+    space_before = env.get_rng_streams(1)
+    ob, _ = env.reset()
+    ob = ob.cpu().numpy()
+    acts = np.random.default_rng(0).integers(0, 8, size=(T, N)).astype(np.int32)
+    obs, rew, term, _ = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts, device=env.device)))
+    for i in range(0, N, 9):
+        o = _oracle_for(env, i)
+        o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator(99 + i)), space_before[i])
+        assert o.reset() == ob[i]
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        eo[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], eo) and np.array_equal(rew[:, i], er.astype(np.float32)), i
+    env.close()
+
+
+def test_batched_spaces():
+    cfg = dict(gu.CASES["d_cfg2"]["config"], seed=1)
+    env = _venv(num_envs=16, **cfg)
+    assert env.observation_space.shape == (16,) and env.action_space.shape == (16,)
+    a = env.action_space.sample()
+    assert a.shape == (16,) and env.action_space.contains(a) and not env.action_space.contains(a + 100)
+    env.step(a)
+    assert env.single_action_space.n == 8
+    env.close()
+    env = _venv(num_envs=4, **dict(gu.CASES["c_cfg3"]["config"], seed=1))
+    assert env.observation_space.shape == (4, 12) and env.action_space.sample().shape == (4, 12)
+    assert env.observation_space.contains(env._obs.cpu().numpy())
+    env.close()
+
+
+def test_kernel_names_and_options():
+    """mdpp_kernel_name reports what the library's own dispatch launches; mdpp_set_options takes
+    specialised kernels out per handle (no process-global switches)."""
+    cfg = dict(gu.CASES["d_cfg2"]["config"], seed=1)
+    a = _venv(num_envs=65536, autoreset="same_step", **cfg)
+    b = _venv(num_envs=65536, autoreset="same_step", **cfg)
+    assert a.rollout_kernel_name(512) == "k_discrete_rollout_pipe<OBS64=1,POW2=1,DELAY=1,S8=1>"
+    assert a.rollout_kernel_name(16).startswith("k_discrete_rollout_fast<") and "HELPER=0" in a.rollout_kernel_name(16)
+    b.set_kernel_options("NO_PIPE")
+    assert b.rollout_kernel_name(512).startswith("k_discrete_rollout_fast<") and "HELPER=1" in b.rollout_kernel_name(512)
+    assert a.rollout_kernel_name(512).startswith("k_discrete_rollout_pipe<")       # a is unaffected
+    b.set_kernel_options("NO_PIPE", "NO_HELPER")
+    assert "HELPER=0" in b.rollout_kernel_name(512)
+    b.set_kernel_options()
+    assert b.rollout_kernel_name(512) == a.rollout_kernel_name(512)
+    a.close(); b.close()
+    c = _venv(num_envs=1000, autoreset="same_step", **cfg)                         # ragged batch: no pipe
+    assert c.rollout_kernel_name(512).startswith("k_discrete_rollout_fast<")
+    c.close()
+    d = _venv(num_envs=512, rng="philox", **cfg)
+    assert "k_discrete" in d.rollout_kernel_name(64)
+    d.close()
+
+
+@pytest.mark.parametrize("which", ["l4", "irr_l4"])
+def test_reseed_with_partial_mask_keeps_long_histories(which):
+    """reset(seed=s, mask=partial) re-seeds every env but resets only the masked ones: the unmasked
+    envs' history bytes 4-7 (sequence_length >= 4; general / quiet kernels) must survive the re-seed
+    (the queue word of the packed-nibble kernels is cleared only for those handles)."""
+    from mdp_playground_amd import mdp as mdp_mod
+    if which == "l4":
+        cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
+                   sequence_length=5, delay=2, reward_density=0.5, terminal_state_density=0.125, seed=3)
+    else:
+        cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 6],
+                   action_space_size=[8, 6], irrelevant_features=True, sequence_length=4, delay=1,
+                   reward_density=0.5, terminal_state_density=0.125, seed=3)
+    N, T = 256, 48
+    env = _venv(num_envs=N, autoreset="disabled", **cfg)
+    assert not env.rollout_kernel_name(T).startswith(("k_discrete_rollout_fast", "k_discrete_rollout_pipe"))
+    rng = np.random.default_rng(1)
+    acts1, acts2 = _rand_actions(env, 3, rng), _rand_actions(env, T, rng)     # 3 steps: histories still hold NaN slots
+    init = env._obs.cpu().numpy().copy()
+    seeded = {k: v.copy() for k, v in env.seeded_streams.items()}       # (reset(seed=) below replaces the record)
+    obs1, *_ = env.rollout(torch.as_tensor(acts1, device=env.device))
+    mask = rng.random(N) < 0.5
+    ob, _ = env.reset(seed=555, mask=torch.as_tensor(mask, device=env.device))
+    ob = ob.cpu().numpy()
+    obs2, rew2, term2, _ = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts2, device=env.device)))
+    env.seeded_streams = seeded
+    for i in range(0, N, 3):
+        o = _oracle_for(env, i)
+        _set_oracle_streams(env, o, i)
+        assert np.array_equal(np.asarray(o.reset()), init[i])
+        for t in range(3):
+            o.step(acts1[t, i])
+        w_sp = o.get_rng()[1]
+        o.set_rng(mdp_mod.pcg64_words(mdp_mod.new_generator(555 + i)), w_sp)      # seed: env stream only
+        if mask[i]:
+            assert np.array_equal(np.asarray(o.reset()), ob[i]), i
+        for t in range(T):
+            eo, er, ed = o.step(acts2[t, i])
+            assert np.array_equal(np.asarray(eo), obs2[t, i]), (i, t)
+            assert rew2[t, i] == np.float32(er) and bool(term2[t, i]) == ed, (i, t)
+    assert (env.status() == 0).all()
+    env.close()
+
+
+def test_set_state_validation_and_ring_import_of_non_unit_rewards():
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(gu.CASES["d_rdist"]["config"], seed=5)                 # non-unit rewards (reward_dist)
+    cfg["delay"] = 3
+    N = 256
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    acts = torch.as_tensor(np.random.default_rng(2).integers(0, a.mdps[0].A, size=(40, N)).astype(np.int32), device=a.device)
+    a.rollout(acts[:20])
+    st = a.get_augmented_state()
+    assert (st["reward_buffer"] != 0).any()                           # something is waiting in the delay line
+    assert len(np.unique(st["reward_buffer"])) > 2                    # ... and not only unit rewards
+    b.set_augmented_state(st)                                         # values -> keys that pay exactly those values
+    for s_ in (0, 1):
+        b._put_stream(s_, a.get_rng_streams(s_))
+    assert np.array_equal(b.get_augmented_state()["reward_buffer"], st["reward_buffer"])
+    ra, rb = a.rollout(acts[20:]), b.rollout(acts[20:])
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+    bad = dict(st, reward_buffer=st["reward_buffer"] + 0.123456)       # a value no sequence pays
+    with pytest.raises(capi.MdppError):
+        b.set_augmented_state(bad)
+    hist = st["augmented_state"].copy()
+    hist[0, 0], hist[0, 1] = 2, -1                                    # a NaN slot newer than a valid state
+    with pytest.raises(capi.MdppError):
+        b.set_augmented_state(dict(st, augmented_state=hist))
+    hist = st["augmented_state"].copy()
+    hist[3, :] = -1                                                   # no current state
+    with pytest.raises(capi.MdppError):
+        b.set_augmented_state(dict(st, augmented_state=hist))
+    a.close(); b.close()
+
+
+def test_step_graph_replays_single_steps():
+    """step_graph(K): K captured mdpp_step launches == K step() calls; new actions written into the
+    captured tensor are picked up by the next replay."""
+    cfg = dict(gu.CASES["d_cfg2"]["config"], seed=9)
+    N, K = 4096, 32
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    acts = torch.randint(0, 8, (K, N), device=a.device, dtype=torch.int32)
+    g = a.step_graph(acts)
+    for rep in range(3):
+        if rep:
+            g.actions.copy_(torch.randint(0, 8, (K, N), device=a.device, dtype=torch.int32))
+        g.replay()
+        torch.cuda.synchronize()
+        for t in range(K):
+            o, r, te, tr, _ = b.step(g.actions[t])
+            assert torch.equal(o, g.obs[t]) and torch.equal(r, g.reward[t]) and torch.equal(te, g.terminated[t]), (rep, t)
+    a.close(); b.close()
+
+
+def test_large_action_space_tables_fall_back_to_global_memory():
+    """S * A beyond the default dynamic-LDS limit: the step kernel reads the tables from HBM / L2
+    instead of failing its first launch."""
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=250, action_space_size=250,
+               sequence_length=1, delay=0, reward_density=0.1, terminal_state_density=0.05, seed=2)
+    N, T = 128, 20
+    env = _venv(num_envs=N, autoreset="same_step", **cfg)
+    assert "LDSTAB=0" in env.rollout_kernel_name(1)
+    acts = np.random.default_rng(4).integers(0, 250, size=(T, N)).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, _ = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts, device=env.device)))
+    for i in range(0, N, 11):
+        o = _oracle_for(env, i)
+        _set_oracle_streams(env, o, i)
+        assert o.reset() == int(init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        eo[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], eo) and np.array_equal(rew[:, i], er.astype(np.float32)), i
+    env.close()

@@ -229,7 +229,7 @@ def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         env = _venv(num_envs=N, **kw, **cfg)
-    assert not env.uses_fast_kernel
+    assert not env.rollout_kernel_name(64).startswith(("k_discrete_rollout_fast", "k_discrete_rollout_pipe"))
     m = env.mdps[0]
     horizon = env_kw.get("max_episode_steps", 0)
     auto = kw["autoreset"] == "same_step"
@@ -482,7 +482,7 @@ def test_grid_fast_rollout_kernel_vs_oracle(variant):
     kw = dict(autoreset="same_step")
     kw.update(env_kw)
     env = _venv(num_envs=N, **kw, **cfg)
-    assert env.rollout_kernel_name(8) == "k_grid_rollout_fast"
+    assert env.rollout_kernel_name(8).startswith("k_grid_rollout_fast<")
     G = len(env.mdps[0].grid_shape)
     horizon = env_kw.get("max_episode_steps", 0)
     auto = kw["autoreset"] == "same_step"
@@ -669,7 +669,7 @@ def test_discrete_fast_kernel_vs_oracle(variant, fused, N):
     the helper-wave variant (start states produced by partner waves through an LDS ring)."""
     cfg, kw, T = FAST_VARIANTS[variant]
     env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
-    assert env.uses_fast_kernel
+    assert env.rollout_kernel_name(1).startswith("k_discrete_rollout_fast")
     A = env.mdps[0].A
     acts = np.random.default_rng(3).integers(0, A, size=(T, N)).astype(np.int32)
     init = env._obs.cpu().numpy().copy()
@@ -887,7 +887,8 @@ def test_image_fused_rollout_equals_single_steps(name):
     N, K = 300, 40
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
-    assert a.rollout_kernel_name(K) == ("k_image_obs" if name == "all100" else "k_image_obs_fast")
+    assert a.rollout_kernel_name(K).startswith("k_image_obs" if name == "all100" else "k_image_obs_fast<")
+    assert (a.rollout_kernel_name(K) == "k_image_obs") == (name == "all100")
     acts = torch.as_tensor(_img_actions(cfg, (K, N), 2), device=a.device)
     obs, rew, term, trunc = a.rollout(acts)
     assert term.any() and not term.all()
@@ -1008,7 +1009,7 @@ def test_continuous_image_batch_vs_oracle_and_fused():
     N, K = 512, 40
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
-    assert a.rollout_kernel_name(K) == "k_imagec_obs"
+    assert a.rollout_kernel_name(K).startswith("k_imagec_obs<")
     acts = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, size=(K, N, 4)).astype(np.float32), device=a.device)
     obs, rew, term, trunc = a.rollout(acts)
     assert term.any()
@@ -1108,9 +1109,12 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     bit (two different launch shapes of the same arithmetic), (2) a strided sample of envs ==
     the oracle, (3) state export -> import -> continue reproduces the continuation."""
     cfg = _cfg(name, 17)
-    T = 24
+    T = 64                       # >= 32: the multi-wave (pipelined / helper-wave) kernels serve the fused launch
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    if name == "d_cfg2":         # the benchmarked kernel itself is what the oracle sees here
+        assert a.rollout_kernel_name(T).startswith("k_discrete_rollout_pipe<"), a.rollout_kernel_name(T)
+        assert a.rollout_kernel_name(1).startswith("k_discrete_rollout_fast<")
     rng = np.random.default_rng(0)
     from mdp_playground_amd import _capi as capi
     streams = [0, 1]
@@ -1161,6 +1165,46 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2)
     for e in (a, b, c):
         e.close()
+
+
+def test_bench_shape_pipe_kernel_vs_oracle_every_env():
+    """Exactly what `python bench.py --gpus 1 --steps 20 --warmup 5` launches (bench.WORKLOADS["cfg2"]: 65 536
+    envs, seed 0, fused launches of 512 steps, bench.make_actions(seed 12345)): k_discrete_rollout_pipe
+    against the oracle on EVERY env for the first launch, on every 16th env for the second launch
+    (state and streams carried across launches), and the env streams' end states."""
+    import bench
+    wl = bench.WORKLOADS["cfg2"]
+    N, F = wl["envs"], 512
+    env = _venv(num_envs=N, autoreset="same_step", **wl["config"])
+    assert env.rollout_kernel_name(F).startswith("k_discrete_rollout_pipe<"), env.rollout_kernel_name(F)
+    acts = bench.make_actions(wl, F, N, env.device, 12345)
+    init = env._obs.cpu().numpy().copy()
+    res = []
+    for _ in range(2):
+        obs, rew, term, trunc = env.rollout(acts)
+        assert not trunc.any()
+        res.append((obs.cpu().numpy().T.copy(), rew.cpu().numpy().T.copy(), term.cpu().numpy().T.copy()))
+    end = env.get_rng_streams(0)
+    acts_t = acts.cpu().numpy().T.copy()                     # [N, F]
+    from oracle import oracle as ora
+    m = env.mdps[0]
+    rt = m.reward_table()
+    for i in range(N):
+        o = ora.DiscreteOracle(m.S, m.A, m.sequence_length, m.delay, m.reward_every_n_steps, m.P, rt, m.terminal_states,
+                               m.init_dist, m.transition_noise, m.reward_noise, m.reward_scale, m.reward_shift,
+                               m.term_state_reward)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert o.reset() == int(init[i])
+        for launch in range(2 if i % 16 == 0 else 1):
+            eo, er, ed, ero = o.rollout(acts_t[i], None)
+            eo[ed] = ero[ed]
+            obs_h, rew_h, term_h = res[launch]
+            assert np.array_equal(obs_h[i], eo) and np.array_equal(term_h[i], ed), (i, launch)
+            assert np.array_equal(rew_h[i], er.astype(np.float32)), (i, launch)
+        if i % 16 == 0:
+            assert np.array_equal(o.get_rng()[0][:4], end[i][:4]), i
+    assert (env.status() == 0).all()
+    env.close()
 
 
 def test_edge_shapes_and_errors():
@@ -1330,7 +1374,7 @@ def test_continuous_fast_kernel_shared_vs_oracle(name):
     acts = rng.uniform(-1, 1, size=(T, N, 12)).astype(np.float32)
     acts[7, 5, 3] = 2.0                      # one rejected action ("stay")
     init = env._obs.cpu().numpy().copy()
-    assert env.rollout_kernel_name(T) == "k_continuous_rollout_fast"
+    assert env.rollout_kernel_name(T).startswith("k_continuous_rollout_fast<")
     at = torch.as_tensor(acts, device=env.device)
     parts = [env.rollout(at[:17]), env.rollout(at[17:])]          # (17 steps: not a multiple of the delay)
     obs, rew, term, trunc = (torch.cat([p[j] for p in parts]).cpu().numpy() for j in range(4))
@@ -1364,7 +1408,7 @@ def test_continuous_fast_kernel_other_shapes_vs_oracle(D, nrel, order):
                reward_function="move_to_a_point", transition_noise=0.03, reward_noise=0.2, delay=2, seed=12)
     N, T = 256, 48
     env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=13, **cfg)
-    assert env.rollout_kernel_name(T) == "k_continuous_rollout_fast"
+    assert env.rollout_kernel_name(T).startswith("k_continuous_rollout_fast<")
     acts = np.random.default_rng(3).uniform(-1, 1, size=(T, N, D)).astype(np.float32)
     init = env._obs.cpu().numpy().copy()
     obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts, device=env.device)))
@@ -1389,14 +1433,14 @@ SOAK_IRR = dict(state_space_type="discrete", action_space_type="discrete", state
                 action_space_size=[8, 8], irrelevant_features=True, delay=4, sequence_length=3)
 
 
-@pytest.mark.parametrize("name,flag", [("d_cfg2", "MDPP_NO_PIPE"), ("c_cfg5", "MDPP_NO_HELPER"), ("c_cfg5", "MDPP_NO_PARK"),
-                                       ("irr", "MDPP_NO_DUO"), ("irr+pn", "MDPP_NO_TRIO"), ("irr+pn+rn", "MDPP_NO_DUO")])
+@pytest.mark.parametrize("name,flag", [("d_cfg2", "NO_PIPE"), ("c_cfg5", "NO_HELPER"), ("c_cfg5", "NO_PARK"),
+                                       ("irr", "NO_DUO"), ("irr+pn", "NO_TRIO"), ("irr+pn+rn", "NO_DUO")])
 def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     """The producer/consumer kernels (LDS rings between waves) against the single-role kernels of
     the same arithmetic, full size, many launches: any lost or duplicated hand-off would show.
-    (c_cfg5 / MDPP_NO_PARK: the drifting producer lanes against the lockstep producer; irr*: the two-
-    and three-role forms of the quiet discrete kernel against the smaller ones.)"""
-    import os
+    (c_cfg5 / NO_PARK: the drifting producer lanes against the lockstep producer; irr*: the two-
+    and three-role forms of the quiet discrete kernel against the smaller ones.)  The single-role side
+    is selected per handle with mdpp_set_options (include/mdpp.h MDPP_OPT_*)."""
     if name.startswith("irr"):
         cfg = dict(SOAK_IRR, seed=31)
         if "+pn" in name:
@@ -1408,6 +1452,8 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     N, F, launches = 65536, 256, 12
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b.set_kernel_options(flag)
+    assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F) or flag == "NO_PARK", (a.rollout_kernel_name(F), flag)
     g = torch.Generator(device=a.device)
     g.manual_seed(1)
     for j in range(launches):
@@ -1417,15 +1463,9 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
             acts = torch.randint(0, 8, (F, N), generator=g, device=a.device, dtype=torch.int32)
         else:
             acts = torch.rand((F, N, 12), generator=g, device=a.device) * 2 - 1
-        os.environ.pop(flag, None)
         ra = a.rollout(acts)
+        rb = b.rollout(acts)
         torch.cuda.synchronize()
-        os.environ[flag] = "1"
-        try:
-            rb = b.rollout(acts)
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop(flag, None)
         for x, y in zip(ra, rb):
             assert torch.equal(x, y), (name, j)
     assert np.array_equal(a.get_rng_streams(0), b.get_rng_streams(0))
@@ -1434,39 +1474,34 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
 
 
 @pytest.mark.parametrize("workload,over,flag,N,F", [
-    ("cfg2_noise", {}, "MDPP_NO_QUIET", 65536, 128),                      # noisy quiet kernel (two roles) vs general
-    ("cfg2_irr", {"transition_noise": 0.1}, "MDPP_NO_QUIET", 65536, 128),
-    ("grid", {}, "MDPP_NO_GFAST", 65536, 128),                            # int64 pairs: one 128-bit store per step
-    ("grid", {"irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "MDPP_NO_GFAST", 32768, 128),
-    ("cfg3", {}, "MDPP_NO_CFAST", 65536, 64),                             # transposed 128-bit stores
+    ("cfg2_noise", {}, "NO_QUIET", 65536, 128),                      # noisy quiet kernel (two roles) vs general
+    ("cfg2_irr", {"transition_noise": 0.1}, "NO_QUIET", 65536, 128),
+    ("grid", {}, "NO_GFAST", 65536, 128),                            # int64 pairs: one 128-bit store per step
+    ("grid", {"irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "NO_GFAST", 32768, 128),
+    ("cfg3", {}, "NO_CFAST", 65536, 64),                             # transposed 128-bit stores
     ("cfg3", {"delay": 2, "reward_every_n_steps": 2, "state_space_dim": 4, "relevant_indices": [0, 1, 2, 3]},
-     "MDPP_NO_CFAST", 65536, 64),
-    ("cfg5", {"delay": 3}, "MDPP_NO_CFAST", 32768, 48),
-    ("cfg4", {}, "MDPP_NO_IMGFAST", 2048, 40),                            # fast vs general renderer, pipelined batches
+     "NO_CFAST", 65536, 64),
+    ("cfg5", {"delay": 3}, "NO_CFAST", 32768, 48),
+    ("cfg4", {}, "NO_IMGFAST", 2048, 40),                            # fast vs general renderer, pipelined batches
 ])
 def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag, N, F):
     """Every specialised rollout kernel against the general kernel of the same arithmetic, on EVERY env
     of a large batch (the oracle tests sample envs): outputs, and the streams' end states.  A
     lane-pattern fault such as the 128-bit store-data hazard shows up here."""
-    import os
     import bench
     from mdp_playground_amd import _capi as capi
     wl = bench.WORKLOADS[workload]
     cfg = dict(wl["config"], **over)
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b.set_kernel_options(flag)
+    assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F), (a.rollout_kernel_name(F), flag)
     wl2 = dict(wl, config=cfg)
     for j in range(3):
         acts = bench.make_actions(wl2, F, N, a.device, 100 + j)
-        os.environ.pop(flag, None)
         ra = a.rollout(acts)
+        rb = b.rollout(acts)
         torch.cuda.synchronize()
-        os.environ[flag] = "1"
-        try:
-            rb = b.rollout(acts)
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop(flag, None)
         for x, y in zip(ra, rb):
             assert torch.equal(x, y), (workload, j)
     streams = [capi.STREAM_ENV, capi.STREAM_SPACE]

@@ -1,4 +1,4 @@
-# usage: bash tools/pmc_sq.sh <workload> <fuse> [launches]   (GPU box; env vars such as MDPP_NO_CFAST pass through)
+# usage: bash tools/pmc_sq.sh <workload> <fuse> [launches]   [rng=philox] [disable=NO_CFAST,...]   (GPU box)
 # SQ instruction-mix counters of the workload's rollout kernels, per wave and env step.
 w=$1; F=$2; L=${3:-2}
 cd $GRAFT_REPO_ROOT
@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_IFETCH"; do
   t=$(echo $c | tr ' ' '_')
   rm -rf gpurun_out/sq_$t
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/sq_$t -- python3 tools/run_variant.py - $L $w $F > gpurun_out/sq_$t.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/sq_$t -- python3 tools/run_variant.py - $L $w $F ${@:4} > gpurun_out/sq_$t.log 2>&1
 done
 python3 - "$w" "$F" "$L" <<'PY'
 import csv, glob, sys

@@ -1,4 +1,4 @@
-# usage: bash tools/pmc_traffic.sh <workload> <fuse> [launches]  (GPU box)
+# usage: bash tools/pmc_traffic.sh <workload> <fuse> [launches] [rng=philox] [disable=...]  (GPU box)
 # HBM traffic of the fused rollouts of one workload: FETCH_SIZE and WRITE_SIZE in separate
 # rocprofv3 --pmc passes (MI355X_MICROARCH.md: they do not fit one pass), summed over every mdpp::
 # kernel, per env step.  Writes gpurun_out/traffic_<workload>.json.
@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${w}_$c
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${w}_$c -- python3 tools/run_variant.py - $L $w $F > gpurun_out/pmc_${w}_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${w}_$c -- python3 tools/run_variant.py - $L $w $F ${@:4} > gpurun_out/pmc_${w}_$c.log 2>&1
 done
 python3 - "$w" "$F" "$L" <<'PY'
 import csv, glob, json, sys
