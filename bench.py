@@ -273,6 +273,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU")
     ap.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
+    ap.add_argument("--disable", default="", help="comma-separated mdpp_set_options switches (include/mdpp.h MDPP_OPT_*, "
+                    "e.g. NO_HELPER): take specialised kernels out of the dispatch, for A/B timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
     ap.add_argument("--full-gather-steps", type=int, default=4,
@@ -306,6 +308,8 @@ def main():
     F = max(1, min(args.fuse, wl.get("fuse_max", args.fuse)))
     env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
                          autoreset="same_step", **wl["config"])
+    if args.disable:
+        env.set_kernel_options(*args.disable.split(","))
     acts = make_actions(wl, F, N, device, 12345 + rank)
     outs = [env.alloc_rollout(F), env.alloc_rollout(F)]     # alternate, so a gather can trail a launch
     comm = torch.cuda.Stream(device=device) if dist is not None else None
@@ -421,7 +425,8 @@ def main():
                                    f"{N} env instances per GPU, random actions, same-step autoreset, rng={args.rng}; "
                                    f"ONE bench step = one fused launch of {F} env steps of every instance "
                                    f"(= {world * N * F} env steps)",
-                       "envs_per_gpu": N, "fuse": F, "env_steps_per_bench_step": world * N * F,
+                       "envs_per_gpu": N, "fuse": F, "env_steps_per_bench_step": world * N * F, "rng": args.rng,
+                       "disabled_kernels": args.disable or None,
                        "collective": collective},
             "roofline": roofline,
             "cpu_baseline": cpu_py if cpu_py is not None else cpu_port,

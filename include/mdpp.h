@@ -253,6 +253,12 @@ int mdpp_set_options(mdpp_env *h, uint32_t disable_mask);
  * Image handles: the renderer (the dominant kernel).  The string lives in the handle until the next call. */
 const char *mdpp_kernel_name(mdpp_env *h, int K);
 
+/* Philox-mode streams made visible (diagnostics, offline reproduction of the noise): out_dev[e][j]
+ * (double, device) = the j-th standard normal of stream (seed, env_id0 + e, tick, stream id) -- a float32
+ * Box-Muller pair per 64-bit draw, see mdp_playground_amd/csrc/mdpp_rng.hpp.  Runs on the current device. */
+int mdpp_philox_normals(uint64_t seed, int64_t env_id0, uint64_t tick, uint32_t stream, int32_t n_envs,
+                        int32_t n_per_env, double *out_dev, void *hip_stream);
+
 /* Per-env sticky status bits (MDPP_STATUS_*), cleared by the call. flags_host: uint32[N]. */
 int mdpp_status(mdpp_env *h, uint32_t *flags_host);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "mdpp_status", "mdpp_timer_begin", "mdpp_timer_end",
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
-    "mdpp_set_options", "mdpp_kernel_name",
+    "mdpp_set_options", "mdpp_kernel_name", "mdpp_philox_normals",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     L.mdpp_set_options.argtypes = [vp, C.c_uint32]
     L.mdpp_kernel_name.argtypes = [vp, i32]
     L.mdpp_kernel_name.restype = C.c_char_p
+    L.mdpp_philox_normals.argtypes = [C.c_uint64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, vp, vp]
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     if L.mdpp_abi_version() != MDPP_ABI_VERSION:

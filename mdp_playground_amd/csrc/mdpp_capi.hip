@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "mdpp_internal.hpp"
+#include "mdpp_rng.hpp"
 
 using namespace mdpp;
 
@@ -310,7 +311,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             }
             // (an unbounded box is fine as long as the actions are bounded: states then stay finite, which
             // the fast kernel's clip relies on -- np.clip's NaN propagation lives in the general kernel)
-            a.fast_ok = (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64 && a.rel_prefix && !cfg->image && !line &&
+            a.fast_ok = (a.rel_prefix && !cfg->image && !line &&
                          cfg->autoreset != MDPP_AUTORESET_NEXT_STEP &&
                          (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
@@ -1073,6 +1074,23 @@ extern "C" int mdpp_set_state_continuous(mdpp_env *h, const float *derivs, const
         HIPCHK(h, hipMemcpy(h->d_ring, rg.data(), rg.size() * 4, hipMemcpyHostToDevice));
     }
     return MDPP_OK;
+}
+
+__global__ void k_philox_normals(uint64_t seed, int64_t env0, uint64_t tick, uint32_t stream, int n_envs, int n_per_env,
+                                 double *out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_envs) return;
+    mdpp::Philox g;
+    g.init(seed, (uint64_t)(env0 + e), tick, stream);
+    for (int j = 0; j < n_per_env; j++) out[e * n_per_env + j] = g.normal();
+}
+
+extern "C" int mdpp_philox_normals(uint64_t seed, int64_t env_id0, uint64_t tick, uint32_t stream, int32_t n_envs,
+                                   int32_t n_per_env, double *out_dev, void *hip_stream) {
+    if (!out_dev || n_envs < 1 || n_per_env < 1) return MDPP_EINVAL;
+    hipLaunchKernelGGL(k_philox_normals, dim3((n_envs + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)hip_stream, seed,
+                       env_id0, tick, stream, n_envs, n_per_env, out_dev);
+    return hipGetLastError() == hipSuccess ? MDPP_OK : MDPP_EHIP;
 }
 
 extern "C" int mdpp_status(mdpp_env *h, uint32_t *flags) {

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     load_action(0, nact);
     for (int k = 0; k < K; k++) {
         const uint32_t tick = a.tick + (uint32_t)k;              // ring head (mod delay below)
-        const uint32_t ptick = (uint32_t)(a.ptick + (uint64_t)k);
+        const uint64_t ptick = a.ptick + (uint64_t)k;
         const long o = (long)k * N + i;
         if (PHILOX) {
             env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_ENV);
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
 }
 
 template <int DMAX, int OMAX, bool PHILOX>
-__global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, uint32_t reset_tick,
+__global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, uint64_t reset_tick,
                                                              const uint8_t *__restrict__ mask,
                                                              float *__restrict__ obs) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -670,7 +670,7 @@ static void launch_step_t(const ContinuousArgs &a, int K, const float *actions, 
                            K, actions, obs, reward, term, trunc, final_obs);
 }
 template <int DMAX, int OMAX>
-static void launch_reset_t(const ContinuousArgs &a, uint32_t reset_tick, const uint8_t *mask,
+static void launch_reset_t(const ContinuousArgs &a, uint64_t reset_tick, const uint8_t *mask,
                            float *obs, hipStream_t s) {
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox)
@@ -739,7 +739,7 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
 
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s) {
     ContinuousArgs a = h->cargs;
-#define CALL_RESET(DM, OM) launch_reset_t<DM, OM>(a, (uint32_t)h->reset_tick, mask, obs, s)
+#define CALL_RESET(DM, OM) launch_reset_t<DM, OM>(a, h->reset_tick, mask, obs, s)
     MDPP_C_DISPATCH(CALL_RESET);
 #undef CALL_RESET
     hipError_t e = hipGetLastError();

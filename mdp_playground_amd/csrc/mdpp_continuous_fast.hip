@@ -19,6 +19,8 @@
 // Compile with -ffp-contract=off.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -44,6 +46,10 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
+#ifndef MDPP_PHILOX_PRODUCERS
+#define MDPP_PHILOX_PRODUCERS 2
+#endif
+constexpr int kPhiloxProducers = MDPP_PHILOX_PRODUCERS;   // producer waves per consumer wave, Philox streams (see NPROD)
 constexpr uint32_t kCSpinLimit = 1u << 22;
 constexpr uint32_t kCStatusInternal = 0x80000000u;
 
@@ -53,8 +59,14 @@ constexpr uint32_t kCStatusInternal = 0x80000000u;
 // these the reference's reward changes between np.float32 and Python-float arithmetic from step to
 // step (k_continuous_step's CRew); without them it is float32 throughout, and that path stays as lean
 // as it was.
-template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN>
-__global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
+// PHILOX: counter-based streams (mdpp_rng.hpp): a step's normals are a pure function of (seed, global env
+// id, tick), made as straight-line work -- by the producer waves (HELPER) or at the top of the step --
+// with no tables, no rejection loop and no stream state in HBM; reset() keys its own stream per step.
+// NPROD (PHILOX + HELPER): producer waves per consumer wave.  A counter-based stream has no serial
+// state, so step k's normals can be made by ANY wave: producer p makes the steps k = p (mod NPROD), and
+// two or three producers fill the SIMD's issue slots that one dependent Philox / Box-Muller chain leaves idle.
+template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1>
+__global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
                                                                     float *__restrict__ reward,
@@ -62,22 +74,93 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                                                                     uint8_t *__restrict__ trunc,
                                                                     float *__restrict__ final_obs) {
     static_assert(D % 4 == 0 || D == 2, "D must be 2 or a multiple of 4");
-    __shared__ uint64_t s_ki[NOISE ? 256 : 1];
-    __shared__ double s_wi[NOISE ? 256 : 1], s_fi[NOISE ? 256 : 1];
+    constexpr bool ZIG = NOISE && !PHILOX;      // numpy's ziggurat tables in LDS
+    __shared__ uint64_t s_ki[ZIG ? 256 : 1];
+    __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
     constexpr int NPS = D + 1;                  // normals per step slot (D transition + 1 reward)
-    __shared__ double s_z[HELPER ? kNRing * NPS * kBlock : 1];   // [slot][draw][lane]
-    __shared__ uint32_t s_prod[kBlock / 64], s_cons[kBlock / 64];
+    static_assert(NPROD == 1 || (PHILOX && HELPER), "several producers need counter-based streams");
+    typedef typename std::conditional<PHILOX, float, double>::type ZT;       // (Philox normals are float32 values)
+    __shared__ ZT s_z[HELPER ? kNRing * NPS * kBlock : 1];       // [slot][draw][lane]
+    __shared__ uint32_t s_prod[NPROD][kBlock / 64], s_cons[kBlock / 64];     // steps made by producer p / steps consumed
     __shared__ __align__(16) float s_tr[(D > 4 ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
     const int tid = threadIdx.x;
-    if (NOISE) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
-    if (HELPER && tid < kBlock / 64) { s_prod[tid] = 0; s_cons[tid] = 0; }
+    if (ZIG) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
+    if (HELPER && tid < kBlock / 64) {
+#pragma unroll
+        for (int p = 0; p < NPROD; p++) s_prod[p][tid] = 0;
+        s_cons[tid] = 0;
+    }
     if (NOISE) __syncthreads();
     const ZigLds zig{s_ki, s_wi, s_fi};
     const int ln = tid & (kBlock - 1), wv = ln >> 6;
     const uint32_t i = blockIdx.x * kBlock + ln;
     if (i >= (uint32_t)a.N) return;             // HELPER launches require N % kBlock == 0
     const uint32_t N = (uint32_t)a.N;
-    if (HELPER && tid >= kBlock) {
+    const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)
+    // this step's normals, PHILOX: P-noise of dimension d at [d], reward noise at [D]
+    auto philox_step = [&](int k, float (&z)[NPS]) __attribute__((always_inline)) {
+        const uint64_t tick = a.ptick + (uint64_t)k;
+        if (a.has_p_noise && a.has_r_noise) {
+            philox_normals<NPS>(a.philox_seed, genv, tick, MDPP_STREAM_ENV, z);
+        } else if (a.has_p_noise) {
+            float zz[D];
+            philox_normals<D>(a.philox_seed, genv, tick, MDPP_STREAM_ENV, zz);
+#pragma unroll
+            for (int d = 0; d < D; d++) z[d] = zz[d];
+            z[D] = 0.0f;
+        } else {
+            float zz[1];
+            philox_normals<1>(a.philox_seed, genv, tick, MDPP_STREAM_ENV, zz);
+#pragma unroll
+            for (int d = 0; d < D; d++) z[d] = 0.0f;
+            z[D] = zz[0];
+        }
+    };
+    if (HELPER && PHILOX && tid >= kBlock) {
+        // ---------------- producer lane, Philox: no stream state, every lane of the wave does the same work
+        uint32_t hstatus = 0;
+#ifdef MDPP_ABL_NOPROD
+        return;
+#endif
+        const int me = tid / kBlock - 1;        // producer index: this wave makes the steps k = me (mod NPROD)
+        uint32_t made = 0;
+        for (int k = me; k < K; k += NPROD) {
+            if (k >= kNRing) {                  // wait until the consumer wave freed slot k % kNRing
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&s_cons[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                       (uint32_t)(k - kNRing + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kCSpinLimit) { hstatus |= kCStatusInternal; break; }
+                }
+            }
+            // one Philox block -> two Box-Muller pairs -> four ring entries at a time (few live registers)
+            ZT *slot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
+            const uint64_t tick = a.ptick + (uint64_t)k;
+            const uint32_t k0 = (uint32_t)a.philox_seed, k1 = (uint32_t)(a.philox_seed >> 32) ^ (uint32_t)(tick >> 32);
+            const int first = a.has_p_noise ? 0 : D;            // ring index of the stream's first normal
+            const int nn = (a.has_p_noise ? D : 0) + (a.has_r_noise ? 1 : 0);
+#pragma unroll
+            for (int b = 0; b < (NPS + 3) / 4; b++) {
+                if (4 * b < nn) {
+                    uint32_t o[4];
+                    philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), (uint32_t)tick, (MDPP_STREAM_ENV << 24) + (uint32_t)b,
+                                  k0, k1, o);
+                    float zz[4];
+                    philox_box_muller(o[0], o[1], zz[0], zz[1]);
+                    if (4 * b + 2 < nn) philox_box_muller(o[2], o[3], zz[2], zz[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (4 * b + q < nn) slot[(first + 4 * b + q) * kBlock] = (ZT)zz[q];
+                }
+            }
+            made += 1;
+            if ((ln & 63) == 0)
+                __hip_atomic_store(&s_prod[me][wv], made, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (hstatus) atomicOr(&a.status[i], hstatus);
+        return;
+    }
+    if (HELPER && !PHILOX && tid >= kBlock) {
         // ---------------- producer lane: the env's noise stream for this launch -----------------
         Pcg64 hg;
         hg.load(a.env_s, a.env_inc, i);
@@ -149,7 +232,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                 while (pub < (uint32_t)K && __builtin_amdgcn_ballot_w64(kl <= pub) == 0) pub++;
                 if (pub != published) {
                     if ((ln & 63) == 0)
-                        __hip_atomic_store(&s_prod[wv], pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&s_prod[0][wv], pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     published = pub;
                 }
                 if (pub == (uint32_t)K) break;
@@ -173,14 +256,14 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                     if (++spins > kCSpinLimit) { hstatus |= kCStatusInternal; break; }
                 }
             }
-            double *slot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
+            ZT *slot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
             if (a.has_p_noise) {
 #pragma unroll
                 for (int d = 0; d < D; d++) slot[d * kBlock] = np_standard_normal_lds(hg, zig);
             }
             if (a.has_r_noise) slot[D * kBlock] = np_standard_normal_lds(hg, zig);
             if ((ln & 63) == 0)
-                __hip_atomic_store(&s_prod[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_prod[0][wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         hg.store(a.env_s, i);
         if (hstatus) atomicOr(&a.status[i], hstatus);
@@ -200,9 +283,10 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
     uint32_t steps = meta.x, flags = meta.y, status = 0;
 
     Pcg64 g;
-    if (NOISE && !HELPER) g.load(a.env_s, a.env_inc, i);
-    const double *zslot = s_z + ln;             // HELPER: this step's normals, set per step
+    if (ZIG && !HELPER) g.load(a.env_s, a.env_inc, i);
+    const ZT *zslot = s_z + ln;                 // HELPER: this step's normals, set per step
     int zi = 0;
+    float zf[NPS];                              // PHILOX without helper waves: this step's normals
 
     const uint32_t total = (uint32_t)K * N;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(D * 4), kCRsrc);
@@ -255,8 +339,16 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         return m <= __float_as_uint(bound);
     };
     auto normal = [&]() -> double {
-        if (HELPER) return zslot[(zi++) * kBlock];
-        return np_standard_normal_lds(g, zig);
+        if (HELPER) return (double)zslot[(zi++) * kBlock];
+        if constexpr (PHILOX) {
+            float v = 0.0f;
+#pragma unroll
+            for (int d = 0; d < NPS; d++) v = (d == zi) ? zf[d] : v;      // (zi is a compile-time constant after unrolling)
+            zi++;
+            return (double)v;
+        } else {
+            return np_standard_normal_lds(g, zig);
+        }
     };
 
     float dist_prev = norm_rel(cur);
@@ -291,13 +383,16 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         float nxt[D];
         if (HELPER) {
             uint32_t spins = 0;
-            while (__hip_atomic_load(&s_prod[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(k + 1)) {
+            // (producer k % NPROD has made k / NPROD + 1 steps once step k is in the ring)
+            while (__hip_atomic_load(&s_prod[k % NPROD][wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                   (uint32_t)(k / NPROD + 1)) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kCSpinLimit) { status |= kCStatusInternal; break; }
             }
             zslot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
             zi = a.has_p_noise ? 0 : D;
         }
+        if (NOISE && PHILOX && !HELPER) { philox_step(k, zf); zi = 0; }
         // ---- C1: Box.contains(action)
         const bool ok = all_within(act, amax);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
@@ -326,7 +421,14 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                     if (j >= ORDER - ii) continue;        // constant trip count: `ORDER - ii` as the bound defeats the unroller
                     const float hi = (ii + j + 1 == ORDER) ? nacc[d] : sd[(ii + j + 1 < ORDER) ? ii + j + 1 : ORDER][d];
                     const float prod = hi * a.tpow32[j + 1];
-                    if ((a.fact_pow2_mask >> (j + 1)) & 1u) acc = (float)((double)acc + (double)prod * a.inv_fact[j + 1]);
+                    // 1! and 2! are powers of two, so dividing by them is multiplying by 1 or 1/2 exactly -- known at
+                    // compile time for the orders this kernel is built for (a run-time test here became two scalar
+                    // branches around a float64 division per term: 72 of them per step at D = 12, order 2)
+                    // ... and the float64 detour folds away: prod / k! is prod or prod / 2, a 24-bit value, and
+                    // round32(round64(acc + prod / k!)) == round32(acc + prod / k!) for 24-bit operands (53 >= 2 * 24 + 2:
+                    // double rounding is innocuous for a sum), which is what one fma -- exact product, one rounding -- gives
+                    if constexpr (ORDER <= 2) acc = (j + 1 == 2) ? fmaf(prod, 0.5f, acc) : acc + prod;
+                    else if ((a.fact_pow2_mask >> (j + 1)) & 1u) acc = (float)((double)acc + (double)prod * a.inv_fact[j + 1]);
                     else acc = (float)((double)acc + (double)prod / a.fact[j + 1]);
                 }
                 sd[ii][d] = ok ? acc : sd[ii][d];        // rejected action: "stay", nothing moves
@@ -338,10 +440,12 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
 #pragma unroll
         for (int d = 0; d < D; d++) nxt[d] = ok ? sd[0][d] : cur[d];                  // "stay", :1671
         // ---- C3
+        if (NOISE && a.has_p_noise) {           // (the wave-uniform test outside the per-dimension loop)
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            if (NOISE && a.has_p_noise) nxt[d] = (float)((double)nxt[d] + (0.0 + a.p_noise * normal()));
-            else nxt[d] = nxt[d] + 0.0f;      // float32 += float64 zeros: only turns -0 into +0
+            for (int d = 0; d < D; d++) nxt[d] = (float)((double)nxt[d] + (0.0 + a.p_noise * normal()));
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; d++) nxt[d] = nxt[d] + 0.0f;      // float32 += float64 zeros: only turns -0 into +0
         }
         // ---- C4: one dimension outside the box clips the whole vector and zeroes every
         // derivative (:1694-1717).  Clipping an in-range coordinate is the identity, so the clip is
@@ -376,7 +480,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
         bool done = (flags & 1u) != 0;
         if (!GEN) {
             if (NOISE && a.has_r_noise) {
-                if (HELPER) zi = D;
+                if (HELPER || PHILOX) zi = D;
                 r = r + (float)(0.0 + a.r_noise * normal());
             }
             if (HELPER && (ln & 63) == 0)   // this wave is done with the step's slot
@@ -397,7 +501,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
             }
             if (steps % (uint32_t)a.every_n != 0) { rv = 0.0; is32 = false; }
             if (NOISE && a.has_r_noise) {
-                if (HELPER) zi = D;
+                if (HELPER || PHILOX) zi = D;
                 const double nz = 0.0 + a.r_noise * normal();
                 if (is32) rv = (double)((float)rv + (float)nz); else rv = rv + nz;
             }
@@ -427,8 +531,9 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
 #pragma unroll
                     for (int d = 0; d < D; d++) final_obs[((size_t)so + i) * D + d] = nxt[d];
                 }
-                Pcg64 sp;
-                sp.load(a.sp_s, a.sp_inc, i);
+                typename std::conditional<PHILOX, Philox, Pcg64>::type sp;
+                if constexpr (PHILOX) sp.init(a.philox_seed, genv, a.ptick + (uint64_t)k, MDPP_STREAM_SPACE);
+                else sp.load(a.sp_s, a.sp_inc, i);
                 for (int tries = 0;; tries++) {
                     // (unbounded boxes are served by the GEN instantiations, so that the plain kernels do not
                     // carry the normal sampler)
@@ -450,7 +555,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
                     if (!GEN || a.n_boxes == 0 || !in_boxes(cur)) break;     // :2284-2307 resample out of terminal cubes
                     if (tries > 4096) { status |= 2u; break; }
                 }
-                sp.store(a.sp_s, i);
+                if constexpr (!PHILOX) sp.store(a.sp_s, i);
                 if (GEN) for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
 #pragma unroll
                 for (int kk = 0; kk <= ORDER; kk++)
@@ -532,11 +637,11 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_continuous_rol
 #pragma unroll
     for (int d = 0; d < D; d++) a.cur[(size_t)d * N + i] = cur[d];
     a.meta[i] = make_uint2(steps, flags);
-    if (NOISE && !HELPER) g.store(a.env_s, i);
+    if (ZIG && !HELPER) g.store(a.env_s, i);
     if (status) atomicOr(&a.status[i], status);
 }
 
-template <int D, int ORDER, int NREL, bool GEN>
+template <int D, int ORDER, int NREL, bool GEN, bool PHILOX>
 static void launch_g(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
@@ -544,22 +649,28 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
     const bool noise = a.has_p_noise || a.has_r_noise;
     // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
     const bool helper = noise && can_help && K >= 16 && (a.N % kBlock) == 0 && !(a.opts & MDPP_OPT_NO_HELPER);
+    // Philox: several producer waves per consumer wave when the per-step draw count makes it worth it
+    const int nprod = (PHILOX && helper && D >= 8 && !(a.opts & MDPP_OPT_NO_TRIO)) ? kPhiloxProducers : 1;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d>", D, ORDER, NREL,
-                 noise, helper, GEN);
+        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d>", D,
+                 ORDER, NREL, noise, helper, GEN, PHILOX, helper ? nprod : 0);
         return;
     }
     if (noise) {
         ContinuousArgs ap = a;
         ap.park = (a.opts & MDPP_OPT_NO_PARK) ? 0 : 1;
-        if (can_help && helper)
-            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN>), dim3(grid),
+        if (can_help && helper && PHILOX && nprod > 1)
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN, PHILOX, PHILOX ? kPhiloxProducers : 1>),
+                               dim3(grid), dim3((1 + kPhiloxProducers) * kBlock), 0, s, ap, K, actions, obs, reward, term,
+                               trunc, final_obs);
+        else if (can_help && helper)
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN, PHILOX>), dim3(grid),
                                dim3(2 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
         else
-            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, false, GEN>), dim3(grid),
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, false, GEN, PHILOX>), dim3(grid),
                                dim3(kBlock), 0, s, a, K, actions, obs, reward, term, trunc, final_obs);
     } else {
-        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false, false, GEN>), dim3(grid), dim3(kBlock),
+        hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, false, false, GEN, PHILOX>), dim3(grid), dim3(kBlock),
                            0, s, a, K, actions, obs, reward, term, trunc, final_obs);
     }
 }
@@ -567,21 +678,28 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
 template <int D, int ORDER, int NREL>
 static void launch_t(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
-    if (a.delay > 0 || a.every_n != 1 || a.n_boxes > 0 || !a.bounded)
-        launch_g<D, ORDER, NREL, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
-    else
-        launch_g<D, ORDER, NREL, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    const bool gen = a.delay > 0 || a.every_n != 1 || a.n_boxes > 0 || !a.bounded;
+    if (a.philox) {
+        if (gen) launch_g<D, ORDER, NREL, true, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+        else launch_g<D, ORDER, NREL, false, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    } else {
+        if (gen) launch_g<D, ORDER, NREL, true, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+        else launch_g<D, ORDER, NREL, false, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    }
 }
 
 // Returns false when the shape does not qualify (caller falls back to k_continuous_step).
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs,
                             float *reward, uint8_t *term, uint8_t *trunc, float *final_obs,
                             hipStream_t s, char *name_out) {
-    if (!a.fast_ok || (a.opts & MDPP_OPT_NO_CFAST)) return false;
+    if (!a.fast_ok || (a.opts & MDPP_OPT_NO_CFAST) || (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST))) return false;
 #define MDPP_CF(DD, OO, RR) if (a.D == DD && a.order == OO && a.n_rel == RR) { launch_t<DD, OO, RR>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out); return true; }
-    MDPP_CF(12, 1, 4) MDPP_CF(12, 2, 4) MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)
+    MDPP_CF(12, 1, 4) MDPP_CF(12, 2, 4)
+#ifndef MDPP_CF_SHAPES_MIN          // (resource-usage / ablation builds compile the BASELINE shapes only)
+    MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)
     MDPP_CF(8, 1, 8) MDPP_CF(8, 2, 8) MDPP_CF(12, 1, 12) MDPP_CF(12, 2, 12)
     MDPP_CF(4, 1, 2) MDPP_CF(4, 2, 2) MDPP_CF(8, 1, 4) MDPP_CF(8, 2, 4)
+#endif
 #undef MDPP_CF
     return false;
 }

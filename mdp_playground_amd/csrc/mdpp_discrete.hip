@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             const int k = k0 + u;
             if (k >= K) break;
             const uint32_t tick = a.tick + (uint32_t)k;          // ring head (mod delay below)
-            const uint32_t ptick = (uint32_t)(a.ptick + (uint64_t)k);
+            const uint64_t ptick = a.ptick + (uint64_t)k;
             const long o = (long)k * N + i;
             int action = act[u];
             if (PHILOX) {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
 }
 
 template <bool PHILOX>
-__global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint32_t reset_tick,
+__global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint64_t reset_tick,
                                                            const uint8_t *__restrict__ mask,
                                                            void *__restrict__ obs) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -435,9 +435,9 @@ int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream
     DiscreteArgs a = h->dargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox)
-        hipLaunchKernelGGL(k_discrete_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
+        hipLaunchKernelGGL(k_discrete_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
     else
-        hipLaunchKernelGGL(k_discrete_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
+        hipLaunchKernelGGL(k_discrete_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_discrete_reset launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->reset_tick += 1;

@@ -31,6 +31,8 @@
 
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -58,7 +60,10 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // stream, the one reset() draws from, and numpy's order is normal-of-the-step, then the reset draw:
 // so E owns that stream, draws the step's standard normal (ziggurat tables in LDS) and hands it to O
 // beside the record, start states are drawn at need instead of ahead, and there is no H role.
-template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN>
+// PH: Philox streams (mdpp_rng.hpp): every step re-keys its generators by (seed, global env id, tick,
+// stream), nothing is loaded from or stored to HBM, start states are drawn at need (like RN: no queue, no
+// H role, nothing to un-draw), and the reward-noise normal is the Philox mode's Box-Muller one.
+template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false>
 __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
@@ -72,9 +77,11 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     __shared__ __align__(8) uint64_t s_start[ROLES == 3 ? kBlock : 1];   // H -> E
     __shared__ uint32_t s_head[ROLES == 3 ? kBlock : 1];                 // E -> H
     __shared__ uint32_t s_done;                                         // E waves that have finished
-    __shared__ uint64_t s_ki[RN ? 256 : 1];
-    __shared__ double s_wi[RN ? 256 : 1], s_fi[RN ? 256 : 1];
-    static_assert(!(RN && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
+    constexpr bool ZIG = RN && !PH;                 // numpy's ziggurat tables
+    constexpr bool ATNEED = RN || PH;               // start states drawn when an episode ends, not ahead
+    __shared__ uint64_t s_ki[ZIG ? 256 : 1];
+    __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
+    static_assert(!(ATNEED && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = ROLES * kBlock;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
     for (int k = tid; k < a.S; k += kThreads) lds[a.lds_term + k] = a.is_term[k];
     for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k];
-    if (RN) zig_stage(s_ki, s_wi, s_fi, tid, kThreads);
+    if (ZIG) zig_stage(s_ki, s_wi, s_fi, tid, kThreads);
     const ZigLds zig{s_ki, s_wi, s_fi};
     // rho_0 as integer thresholds: cdf[j] <= u  <=>  ceil(cdf[j] * 2^53) <= r >> 11 (exact: u is
     // (r >> 11) * 2^-53), padded to a multiple of 8 with 2^64-1 so the search runs in unrolled blocks
@@ -142,10 +149,14 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
     uint32_t steps = st.z, ringbits = st.w, status = 0;
     uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
-    Pcg64 g, sp, sp1;
-    g.load(a.env_s, a.env_inc, i);
-    if (PN) sp.load(a.sp_s, a.sp_inc, i);
-    if (PN && IRR) sp1.load(a.sp1_s, a.sp1_inc, i);
+    typedef typename std::conditional<PH, Philox, Pcg64>::type Gen;
+    Gen g, sp, sp1;
+    const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);         // global env id (Philox key)
+    if constexpr (!PH) {
+        g.load(a.env_s, a.env_inc, i);
+        if (PN) sp.load(a.sp_s, a.sp_inc, i);
+        if (PN && IRR) sp1.load(a.sp1_s, a.sp1_inc, i);
+    }
     // sequence key over the last L states, carried: key' = (key - oldest * S^(L-1)) * S + new
     uint32_t spow = 1;
     for (uint32_t j = 1; j < L; j++) spow *= S;
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n, delay = (uint32_t)a.delay;
     const bool isE = !DUO || role == 0;
     // =============================================================== H: start-state producer
-    if (TRIO && role == 2) {
+    if constexpr (TRIO) if (role == 2) {
         uint64_t vals = 0;
         uint32_t tail = 0, slot = 0;
         for (;;) {
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             if (++spins > kQSpinLimit) { status |= kQStatusInternal; qn = 1; break; }
         }
     };
-    if (autoreset && isE && !TRIO && !RN) refill();
+    if (autoreset && isE && !TRIO && !ATNEED) refill();
     uint32_t phase = steps % every_n;
 
     // rewards of the unit path: s_rsel[(paid << 1) | terminal], filled above.  An LDS table on
@@ -297,8 +308,14 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     };
 
     // ---- E: one step of the state recurrence -> record
-    auto stepE = [&](const u32x2 act2, double &z) __attribute__((always_inline)) -> uint64_t {
-        if (!RN && __builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
+    auto stepE = [&](const u32x2 act2, double &z, const int kstep) __attribute__((always_inline)) -> uint64_t {
+        if constexpr (PH) {          // this step's streams (a block is only computed when something is drawn)
+            const uint64_t tick = a.ptick + (uint64_t)kstep;
+            g.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
+            if (PN) sp.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
+            if (PN && IRR) sp1.init(a.philox_seed, genv, tick, kPhiloxIrrStream);
+        }
+        if (!ATNEED && __builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
         int action = (int)act2.x;
         action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
         const bool bad = action < 0 || action >= (int)A;
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         if (RN) z = np_standard_normal_lds(g, zig);                         // D6: drawn in reward_function, before any reset
         const bool tr = has_max && steps >= max_steps;
         const bool need = autoreset && (done || tr);
-        if (RN && __builtin_amdgcn_ballot_w64(need) != 0) {                  // reset(): drawn now, in stream order
+        if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
             if (need) { queue[0] = draw_state(); }
             qn = need ? 1u : qn;
         }
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
                 const u32x2 act = pre[u];
                 pre[u] = load_act(c * kPre + kPre + u);
                 double z = 0.0;
-                const uint64_t rec = stepE(act, z);
+                const uint64_t rec = stepE(act, z, c * kPre + u);
                 emitO(rec, z, (uint32_t)(c * kPre + u));
             }
         }
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
 #pragma unroll
             for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
             double z = 0.0;
-            const uint64_t rec = stepE(act, z);
+            const uint64_t rec = stepE(act, z, k);
             emitO(rec, z, (uint32_t)k);
         }
     } else if (role == 0) {
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
                     const u32x2 act = pre[u];
                     pre[u] = load_act(kbase + kPre + u);
                     double z = 0.0;
-                    ring[((kbase + u) % kDepth) * kBlock + l] = stepE(act, z);
+                    ring[((kbase + u) % kDepth) * kBlock + l] = stepE(act, z, kbase + u);
                     if (RN) ringz[((kbase + u) % kDepth) * kBlock + l] = z;
                 }
             } else {
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
 #pragma unroll
                     for (int u = 1; u < kPre; u++) act = (k - kbase == u) ? pre[u] : act;
                     double z = 0.0;
-                    ring[(k % kDepth) * kBlock + l] = stepE(act, z);
+                    ring[(k % kDepth) * kBlock + l] = stepE(act, z, k);
                     if (RN) ringz[(k % kDepth) * kBlock + l] = z;
                 }
             }
@@ -489,22 +506,26 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
                 __hip_atomic_store(&s_cons[w], upto, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    if (PN && isE) sp.store(a.sp_s, i);
-    if (PN && IRR && isE) sp1.store(a.sp1_s, i);
+    if constexpr (!PH) {
+        if (PN && isE) sp.store(a.sp_s, i);
+        if (PN && IRR && isE) sp1.store(a.sp1_s, i);
+    }
     if (TRIO && role == 0) {
         // tell H how many of its start states were really used, then that this wave is through
         __hip_atomic_store(&s_head[l], (head16 - qn) & 0xFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((l & 63) == 0) __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (IRR) a.irr_state[i] = cur1;
     } else if (isE) {
-        // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128)
-        for (uint32_t q = qn * (IRR ? 2u : 1u); q > 0; q--) {
-            const uint64_t lo = g.s_lo - g.inc_lo;
-            const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
-            g.s_lo = lo * a.minv_lo;
-            g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+        if constexpr (!PH) {
+            // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128)
+            for (uint32_t q = qn * (IRR ? 2u : 1u); q > 0; q--) {
+                const uint64_t lo = g.s_lo - g.inc_lo;
+                const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
+                g.s_lo = lo * a.minv_lo;
+                g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+            }
+            g.store(a.env_s, i);
         }
-        g.store(a.env_s, i);
         if (IRR) a.irr_state[i] = cur1;
     }
     if (!DUO) {
@@ -517,10 +538,10 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     if (status) atomicOr(&a.status[i], status);
 }
 
-template <bool O64, bool IR, int ROLES, bool PN, bool RN>
+template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false>
 static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN>;
+    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH>;
     if (lds > 48 * 1024) {                        // tables + record ring beyond the default dynamic-LDS limit
         static size_t allowed = 0;                // (per instantiation)
         if (lds > allowed) {
@@ -536,8 +557,10 @@ static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     if (a.autoreset == MDPP_AUTORESET_NEXT_STEP) return false;
-    if (a.philox || !a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
+    if (!a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
         return false;
+    if (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
+    const bool ph = a.philox != 0;
     const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
     if ((pn || rn) && (a.opts & MDPP_OPT_NO_QUIET_NOISE)) return false;
     const unsigned long long bytes = (unsigned long long)K * a.N * (a.irr ? 2 : 1) * 8ULL;
@@ -553,17 +576,22 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const size_t depth = rn ? 16 : kQDepth;
     const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
-    const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
+    const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = trio ? 3 : duo ? 2 : 1;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d>", !a.obs_i32, a.irr != 0, roles, pn, rn);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d>", !a.obs_i32, a.irr != 0,
+                 roles, pn, rn, ph);
         return true;
     }
     const size_t l = roles == 1 ? lds : lds_duo;
 #define MDPP_Q_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
 #define MDPP_Q_ROLES(O64, IR, PN_, RN_)                                                           \
     do {                                                                                          \
-        if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
+        if (ph) {                                                                                 \
+            if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_, true>(MDPP_Q_ARGS);                \
+            else quiet_launch<O64, IR, 1, PN_, RN_, true>(MDPP_Q_ARGS);                           \
+        }                                                                                         \
+        else if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
         else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_>(MDPP_Q_ARGS);                     \
         else quiet_launch<O64, IR, 1, PN_, RN_>(MDPP_Q_ARGS);                                     \
     } while (0)

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
         if (k >= K) break;
         int act[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
         load_act(k + kGPrefetch, pre[u]);
-        const uint32_t tick = (uint32_t)(a.ptick + (uint64_t)k);
+        const uint64_t tick = a.ptick + (uint64_t)k;
         const long o = (long)k * N + i;
         if (PHILOX) {
             env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
 }
 
 template <bool PHILOX>
-__global__ __launch_bounds__(kBlock) void k_grid_reset(GridArgs a, uint32_t reset_tick,
+__global__ __launch_bounds__(kBlock) void k_grid_reset(GridArgs a, uint64_t reset_tick,
                                                        const uint8_t *__restrict__ mask, void *__restrict__ obs) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.N) return;
@@ -492,8 +492,8 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
 int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
     GridArgs a = h->gargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
-    if (a.philox) hipLaunchKernelGGL(k_grid_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
-    else hipLaunchKernelGGL(k_grid_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, (uint32_t)h->reset_tick, mask, obs);
+    if (a.philox) hipLaunchKernelGGL(k_grid_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
+    else hipLaunchKernelGGL(k_grid_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_grid_reset launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->reset_tick += 1;

@@ -6,7 +6,8 @@
 //              np.random.Generator does in rl_toy_env.py (reset :2255, noise :403/:413,
 //              DiscreteExtended.sample spaces/discrete_extended.py:17).
 //   * Philox — stateless Philox4x32-10 keyed by (seed, global env id, tick, stream): no RNG
-//              bytes in HBM, results independent of how envs are sharded over GPUs.
+//              bytes in HBM, results independent of how envs are sharded over GPUs; its own
+//              (Box-Muller) Gaussians, see below.
 // The distributions on top (uniform double, ziggurat normal, Lemire bounded integers) follow
 // numpy/random/src/distributions/distributions.c so both generators share one code path.
 #pragma once
@@ -58,40 +59,142 @@ __device__ __forceinline__ uint32_t next32(G &g, Half32 &h) {
     return (uint32_t)n;
 }
 
+// ---- Philox mode (the build's own counter-based streams; NOT in the reference) -------------------
+// A stream is keyed by (seed, GLOBAL env id, 64-bit tick, stream id) and is a sequence of 32-bit words:
+// block b of the stream = Philox4x32-10 (Salmon et al., SC'11) of counter (env lo, env hi, tick lo,
+// stream << 24 | b) under key (seed lo, seed hi ^ tick hi); next64() hands out words (0,1) then (2,3).
+// Uniform doubles, bounded integers and the categorical search sit on next64() exactly like numpy's
+// (shared code below).  GAUSSIANS are this mode's own: a float32 Box-Muller pair per 64-bit draw
+// (philox_box_muller: the form GPU libraries use for float normals), fixed consumption, no rejection
+// loop, no tables -- every lane of a wave does the same work.  The pair's second normal is kept for
+// the stream's next normal draw.  The transform uses only IEEE-exact operations (conversions, fma,
+// multiply, add, correctly rounded sqrtf, bit operations), so the oracle's C restatement
+// (oracle/np_random.c philox_box_muller) produces the same bits.
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t y0 = h1 ^ c1 ^ k0, y1 = l1, y2 = h0 ^ c3 ^ k1, y3 = l0;
+        c0 = y0; c1 = y1; c2 = y2; c3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// Two independent N(0, 1) float32 variates from two 32-bit words (Box-Muller):
+//   r = sqrt(-2 ln u1), u1 = max(w0, 1/2) * 2^-32 in (0, 1];  theta = 2 pi (w1 * 2^-32)
+//   z0 = r cos(theta), z1 = r sin(theta).
+// ln on [sqrt(1/2), sqrt(2)) and sin / cos on [0, pi/4] are the Cephes single-precision polynomials
+// (Moshier, logf.c / sinf.c), evaluated with fma; relative error of z about 2^-22.  |z| <= 6.8.
+__device__ __forceinline__ void philox_box_muller(uint32_t w0, uint32_t w1, float &z0, float &z1) {
+    float f = (float)w0;                                    // round to nearest
+    if (w0 == 0u) f = 0.5f;
+    const uint32_t b = __float_as_uint(f);
+    int e = (int)(b >> 23) - 127;                           // f = m 2^e, m in [1, 2)
+    float m = __uint_as_float((b & 0x7FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m *= 0.5f; e += 1; }
+    const float x = m - 1.0f;
+    const float xx = x * x;
+    float y = 7.0376836292E-2f;
+    y = fmaf(y, x, -1.1514610310E-1f);
+    y = fmaf(y, x, 1.1676998740E-1f);
+    y = fmaf(y, x, -1.2420140846E-1f);
+    y = fmaf(y, x, 1.4249322787E-1f);
+    y = fmaf(y, x, -1.6668057665E-1f);
+    y = fmaf(y, x, 2.0000714765E-1f);
+    y = fmaf(y, x, -2.4999993993E-1f);
+    y = fmaf(y, x, 3.3333331174E-1f);
+    y = (y * x) * xx;
+    y = fmaf(-0.5f, xx, y);
+    const float fe = (float)(e - 32);
+    float l = fmaf(fe, 0.693359375f, fmaf(fe, -2.12194440e-4f, x + y));   // ln u1
+    l = fminf(l, 0.0f);
+    const float r = sqrtf(-2.0f * l);          // correctly rounded (hipcc default; __fsqrt_rn is the native approximation)
+    const uint32_t q = w1 >> 30;
+    const float a = (float)(w1 & 0x3FFFFFFFu) * (1.0f / 1073741824.0f);   // angle within the quadrant / (pi/2), [0, 1]
+    const bool swap = a > 0.5f;
+    const float t = (swap ? 1.0f - a : a) * 1.57079632679489662f;        // [0, pi/4]
+    const float tt = t * t;
+    float sn = fmaf(-1.9515295891E-4f, tt, 8.3321608736E-3f);
+    sn = fmaf(sn, tt, -1.6666654611E-1f);
+    sn = fmaf(sn * tt, t, t);
+    float cs = fmaf(2.443315711809948E-5f, tt, -1.388731625493765E-3f);
+    cs = fmaf(cs, tt, 4.166664568298827E-2f);
+    cs = fmaf(cs * tt, tt, fmaf(-0.5f, tt, 1.0f));
+    const float s1 = swap ? cs : sn, c1 = swap ? sn : cs;                // sin, cos of the in-quadrant angle
+    const float cq = (q == 0u) ? c1 : (q == 1u) ? -s1 : (q == 2u) ? -c1 : s1;
+    const float sq = (q == 0u) ? s1 : (q == 1u) ? c1 : (q == 2u) ? -s1 : -c1;
+    z0 = r * cq;
+    z1 = r * sq;
+}
+
 struct Philox {
-    uint32_t k0, k1;         // key = seed
-    uint32_t c0, c1, c2, c3; // counter = (env id lo/hi, tick, stream | block)
+    uint32_t k0, k1;         // key
+    uint32_t c0, c1, c2, c3; // counter = (env id lo/hi, tick lo, stream << 24 | block)
     uint32_t spare_lo, spare_hi;
     uint32_t have_spare;
+    float z_spare;           // second normal of the last Box-Muller pair
+    uint32_t have_z;
 
-    __device__ __forceinline__ void init(uint64_t seed, uint64_t env, uint32_t tick, uint32_t stream) {
-        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
-        c0 = (uint32_t)env; c1 = (uint32_t)(env >> 32); c2 = tick; c3 = stream << 24;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(tick >> 32);
+        c0 = (uint32_t)env; c1 = (uint32_t)(env >> 32); c2 = (uint32_t)tick; c3 = stream << 24;
         have_spare = 0; spare_lo = spare_hi = 0;
+        have_z = 0; z_spare = 0.0f;
     }
     __device__ __forceinline__ uint64_t next64() {
         if (have_spare) { have_spare = 0; return ((uint64_t)spare_hi << 32) | spare_lo; }
-        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, a = k0, b = k1;
-#pragma unroll
-        for (int r = 0; r < 10; r++) {
-            uint32_t h0 = __umulhi(0xD2511F53u, x0), l0 = 0xD2511F53u * x0;
-            uint32_t h1 = __umulhi(0xCD9E8D57u, x2), l1 = 0xCD9E8D57u * x2;
-            uint32_t y0 = h1 ^ x1 ^ a, y1 = l1, y2 = h0 ^ x3 ^ b, y3 = l0;
-            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
-            a += 0x9E3779B9u; b += 0xBB67AE85u;
-        }
+        uint32_t o[4];
+        philox4x32_10(c0, c1, c2, c3, k0, k1, o);
         c3 += 1; // next block of this (env, tick, stream)
-        spare_lo = x2; spare_hi = x3; have_spare = 1;
-        return ((uint64_t)x1 << 32) | x0;
+        spare_lo = o[2]; spare_hi = o[3]; have_spare = 1;
+        return ((uint64_t)o[1] << 32) | o[0];
+    }
+    __device__ __forceinline__ double normal() {
+        if (have_z) { have_z = 0; return (double)z_spare; }
+        const uint64_t r = next64();
+        float z0;
+        philox_box_muller((uint32_t)r, (uint32_t)(r >> 32), z0, z_spare);
+        have_z = 1;
+        return (double)z0;
     }
 };
+
+// The first NN standard normals of Philox stream (seed, env, tick, stream), all at once: the same values
+// Philox::normal() hands out one by one (pair p = words (0,1) / (2,3) of block p / 2), but as
+// independent straight-line work -- ceil(NN / 4) blocks, ceil(NN / 2) Box-Muller pairs -- for the fused
+// rollout kernels, where a step's draw count is known in advance.
+template <int NN>
+__device__ __forceinline__ void philox_normals(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, float (&z)[NN]) {
+    constexpr int NPAIR = (NN + 1) / 2, NBLK = (NPAIR + 1) / 2;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(tick >> 32);
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        uint32_t o[4];
+        philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)tick, (stream << 24) + (uint32_t)b, k0, k1, o);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int pr = 2 * b + h;
+            if (pr < NPAIR) {
+                float z0, z1;
+                philox_box_muller(o[2 * h], o[2 * h + 1], z0, z1);
+                z[2 * pr] = z0;
+                if (2 * pr + 1 < NN) z[2 * pr + 1] = z1;
+            }
+        }
+    }
+}
 
 template <class G>
 __device__ __forceinline__ double np_random(G &g) { // Generator.random()
     return (double)(g.next64() >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// random_standard_normal: 256-layer ziggurat
+// random_standard_normal: 256-layer ziggurat (numpy streams); Philox streams: their own Box-Muller normal
+__device__ __forceinline__ double np_standard_normal(Philox &g) { return g.normal(); }
 template <class G>
 __device__ __forceinline__ double np_standard_normal(G &g) {
     const double nor_r = 3.6541528853610087963519472518;
@@ -179,6 +282,7 @@ __device__ __forceinline__ double np_zig_tail(G &g, uint64_t rabs) {
 // SIMD (tools/bench_rng.hip, profiles/r01_rng_microbench.txt) this plain form (412 ns per draw per
 // wave) beats both a wave-uniform restructuring of the wedge path and a chord/tangent pre-test
 // that avoids exp() (530-750 ns): the rejection branches are short and rarely re-entered.
+__device__ __forceinline__ double np_standard_normal_lds(Philox &g, const ZigLds &) { return g.normal(); }
 template <class G>
 __device__ __forceinline__ double np_standard_normal_lds(G &g, const ZigLds &z) {
     for (;;) {

@@ -29,7 +29,7 @@ struct ora_discrete {
     int steps;               /* total_transitions_episode */
     np_pcg64 env_rng;        /* self._np_random */
     np_pcg64 space_rng;      /* self.observation_spaces[0].np_random */
-    int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
+    int philox; uint64_t ph_seed, ph_env; uint64_t tick, reset_tick;
     /* irrelevant sub-space (irrelevant_features=True), rl_toy_env.py:2028-2035, :2063-2092 */
     int irr, S1, A1, irr_state;
     int32_t *P1;
@@ -108,7 +108,7 @@ int64_t ora_d_reset(ora_discrete *e) {
     return s0;
 }
 
-void ora_d_set_philox(ora_discrete *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
+void ora_d_set_philox(ora_discrete *e, uint64_t seed, uint64_t env_id, uint64_t tick, uint64_t reset_tick) {
     e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
 }
 void ora_d_philox_explicit_reset(ora_discrete *e) {
@@ -224,7 +224,7 @@ struct ora_grid {
     np_pcg64 env_rng;        /* self._np_random: noise trigger (:1736), reward noise */
     np_pcg64 space_rng;      /* self.feature_space.np_random: reset() sample (:2326) */
     np_pcg64 action_rng;     /* self.action_space.np_random: the noisy action (:1738) */
-    int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
+    int philox; uint64_t ph_seed, ph_env; uint64_t tick, reset_tick;
 };
 
 ora_grid *ora_g_create(int G, const int32_t *shape, const int32_t *target, int make_denser,
@@ -247,7 +247,7 @@ void ora_g_set_rng(ora_grid *e, const uint64_t env[6], const uint64_t space[6], 
 void ora_g_get_rng(const ora_grid *e, uint64_t env[6], uint64_t space[6], uint64_t action[6]) {
     np_pcg64_store(&e->env_rng, env); np_pcg64_store(&e->space_rng, space); np_pcg64_store(&e->action_rng, action);
 }
-void ora_g_set_philox(ora_grid *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
+void ora_g_set_philox(ora_grid *e, uint64_t seed, uint64_t env_id, uint64_t tick, uint64_t reset_tick) {
     e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
 }
 void ora_g_philox_explicit_reset(ora_grid *e) {
@@ -354,7 +354,7 @@ struct ora_continuous {
     int steps, reached;
     np_pcg64 env_rng;    /* self._np_random */
     np_pcg64 space_rng;  /* self.feature_space.np_random */
-    int philox; uint64_t ph_seed, ph_env; uint32_t tick, reset_tick;
+    int philox; uint64_t ph_seed, ph_env; uint64_t tick, reset_tick;
     /* reward_function == "move_along_a_line" (:1864-1910) */
     int line_L;                               /* sequence_length; 0 = move_to_a_point */
     ora_line_fit_fn line_fit;
@@ -521,7 +521,7 @@ void ora_c_reset(ora_continuous *e, float *obs) {
     if (e->line_L) line_push(e, e->cur);       /* augmented_state = [NaN]*(len-1) + [curr_state], :2313-2323 */
 }
 
-void ora_c_set_philox(ora_continuous *e, uint64_t seed, uint64_t env_id, uint32_t tick, uint32_t reset_tick) {
+void ora_c_set_philox(ora_continuous *e, uint64_t seed, uint64_t env_id, uint64_t tick, uint64_t reset_tick) {
     e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
 }
 void ora_c_philox_explicit_reset(ora_continuous *e) {

@@ -1,6 +1,7 @@
 /* ORACLE — TEST INFRASTRUCTURE ONLY (see np_random.h for scope and sources). */
 #include "np_random.h"
 #include <math.h>
+#include <string.h>
 #include "np_ziggurat_tables.inc"
 
 static const uint64_t ki_double[256] = NPZ_KI_INIT;
@@ -23,12 +24,62 @@ void np_pcg64_store(const np_pcg64 *g, uint64_t w[6]) {
     w[4] = g->has32; w[5] = g->u32;
 }
 
-void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint32_t tick, uint32_t stream) {
+void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
     g->philox = 1;
-    g->k0 = (uint32_t)seed; g->k1 = (uint32_t)(seed >> 32);
-    g->c0 = (uint32_t)env; g->c1 = (uint32_t)(env >> 32); g->c2 = tick; g->c3 = stream << 24;
+    g->k0 = (uint32_t)seed; g->k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(tick >> 32);
+    g->c0 = (uint32_t)env; g->c1 = (uint32_t)(env >> 32); g->c2 = (uint32_t)tick; g->c3 = stream << 24;
     g->have_spare = 0; g->spare_lo = g->spare_hi = 0;
     g->has32 = 0; g->u32 = 0;
+    g->have_z = 0; g->z_spare = 0.0f;
+}
+
+/* Box-Muller pair in float32 from two 32-bit words: the Philox mode's Gaussian (not numpy's).
+ * Same operation sequence as the device's philox_box_muller (mdpp_rng.hpp): RN conversions, fmaf,
+ * multiply, add, correctly rounded sqrtf, bit operations -- nothing whose result depends on the
+ * math library.  ln on [sqrt(1/2), sqrt(2)) and sin / cos on [0, pi/4]: Cephes single-precision
+ * polynomials (Moshier, logf.c / sinf.c). */
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+void np_philox_box_muller(uint32_t w0, uint32_t w1, float *z0, float *z1) {
+    float f = (float)w0;
+    if (w0 == 0u) f = 0.5f;
+    const uint32_t b = f2u(f);
+    int e = (int)(b >> 23) - 127;
+    float m = u2f((b & 0x7FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m *= 0.5f; e += 1; }
+    const float x = m - 1.0f;
+    const float xx = x * x;
+    float y = 7.0376836292E-2f;
+    y = fmaf(y, x, -1.1514610310E-1f);
+    y = fmaf(y, x, 1.1676998740E-1f);
+    y = fmaf(y, x, -1.2420140846E-1f);
+    y = fmaf(y, x, 1.4249322787E-1f);
+    y = fmaf(y, x, -1.6668057665E-1f);
+    y = fmaf(y, x, 2.0000714765E-1f);
+    y = fmaf(y, x, -2.4999993993E-1f);
+    y = fmaf(y, x, 3.3333331174E-1f);
+    y = (y * x) * xx;
+    y = fmaf(-0.5f, xx, y);
+    const float fe = (float)(e - 32);
+    float l = fmaf(fe, 0.693359375f, fmaf(fe, -2.12194440e-4f, x + y));
+    l = fminf(l, 0.0f);
+    const float r = sqrtf(-2.0f * l);
+    const uint32_t q = w1 >> 30;
+    const float a = (float)(w1 & 0x3FFFFFFFu) * (1.0f / 1073741824.0f);
+    const int swap = a > 0.5f;
+    const float t = (swap ? 1.0f - a : a) * 1.57079632679489662f;
+    const float tt = t * t;
+    float sn = fmaf(-1.9515295891E-4f, tt, 8.3321608736E-3f);
+    sn = fmaf(sn, tt, -1.6666654611E-1f);
+    sn = fmaf(sn * tt, t, t);
+    float cs = fmaf(2.443315711809948E-5f, tt, -1.388731625493765E-3f);
+    cs = fmaf(cs, tt, 4.166664568298827E-2f);
+    cs = fmaf(cs * tt, tt, fmaf(-0.5f, tt, 1.0f));
+    const float s1 = swap ? cs : sn, c1 = swap ? sn : cs;
+    const float cq = (q == 0u) ? c1 : (q == 1u) ? -s1 : (q == 2u) ? -c1 : s1;
+    const float sq = (q == 0u) ? s1 : (q == 1u) ? c1 : (q == 2u) ? -s1 : -c1;
+    *z0 = r * cq;
+    *z1 = r * sq;
 }
 
 /* Philox4x32-10: one block gives two 64-bit draws (words 0-1, then words 2-3). */
@@ -72,6 +123,14 @@ double np_random(np_pcg64 *g) {
 }
 
 double np_standard_normal(np_pcg64 *g) {
+    if (g->philox) {                         /* Philox mode: Box-Muller pairs, second one kept */
+        if (g->have_z) { g->have_z = 0; return (double)g->z_spare; }
+        const uint64_t r = np_next64(g);
+        float z0;
+        np_philox_box_muller((uint32_t)r, (uint32_t)(r >> 32), &z0, &g->z_spare);
+        g->have_z = 1;
+        return (double)z0;
+    }
     for (;;) {
         uint64_t r = np_next64(g);
         int idx = (int)(r & 0xff);
@@ -131,4 +190,15 @@ int np_choice_cdf(np_pcg64 *g, const double *cdf, int n) {
         if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+
+/* out[e][j] = j-th standard normal of Philox stream (seed, env0 + e, tick, stream): the counterpart of
+ * the library's mdpp_philox_normals, for the device-vs-oracle bit test. */
+void np_philox_normals(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream, int n_envs, int n_per_env,
+                       double *out) {
+    for (int e = 0; e < n_envs; e++) {
+        np_pcg64 g;
+        np_philox_init(&g, seed, env0 + (uint64_t)e, tick, stream);
+        for (int j = 0; j < n_per_env; j++) out[(size_t)e * n_per_env + j] = np_standard_normal(&g);
+    }
 }

@@ -30,13 +30,21 @@ typedef struct {
     uint32_t has32;          /* numpy's pcg64_state.has_uint32 */
     uint32_t u32;            /* numpy's pcg64_state.uinteger */
     /* Alternative bit generator of the build (NOT in the reference): stateless Philox4x32-10
-     * (Salmon et al., SC'11) keyed by (seed, global env id, tick, stream).  Same next64()
-     * interface, so every distribution above it is shared.  philox != 0 selects it. */
+     * (Salmon et al., SC'11) keyed by (seed, global env id, 64-bit tick, stream).  Same next64()
+     * interface, so the uniform / integer / categorical distributions above it are shared; its
+     * Gaussians are a float32 Box-Muller pair per 64-bit draw (philox_box_muller, the mirror of
+     * mdp_playground_amd/csrc/mdpp_rng.hpp: IEEE-exact operations only, so both sides give the same
+     * bits).  philox != 0 selects it. */
     uint32_t philox;
     uint32_t k0, k1, c0, c1, c2, c3, spare_lo, spare_hi, have_spare;
+    float z_spare;
+    uint32_t have_z;
 } np_pcg64;
 
-void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint32_t tick, uint32_t stream);
+void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream);
+void np_philox_box_muller(uint32_t w0, uint32_t w1, float *z0, float *z1);
+void np_philox_normals(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream, int n_envs, int n_per_env,
+                       double *out);
 
 void np_pcg64_load(np_pcg64 *g, const uint64_t w[6]);
 void np_pcg64_store(const np_pcg64 *g, uint64_t w[6]);

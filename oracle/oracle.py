@@ -55,7 +55,7 @@ def lib():
         L.ora_g_destroy.argtypes = [vp]
         L.ora_g_set_rng.argtypes = [vp, vp, vp, vp]
         L.ora_g_get_rng.argtypes = [vp, vp, vp, vp]
-        L.ora_g_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_g_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.ora_g_philox_explicit_reset.argtypes = [vp]
         L.ora_g_reset.argtypes = [vp, vp]
         L.ora_g_step.argtypes = [vp, vp, vp, vp, vp]
@@ -74,8 +74,8 @@ def lib():
         L.ora_c_step.argtypes = [vp] * 6
         L.ora_c_get_derivs.argtypes = [vp, vp]
         L.ora_c_rollout.argtypes = [vp, i32] + [vp] * 6
-        L.ora_d_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
-        L.ora_c_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ora_d_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ora_c_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
         L.ora_d_philox_explicit_reset.argtypes = [vp]
         L.ora_c_philox_explicit_reset.argtypes = [vp]
         L.ora_i_draw.argtypes = [vp] * 7
@@ -90,6 +90,8 @@ def lib():
         L.np_standard_normal.argtypes = [vp]
         L.np_integers.restype = C.c_int64
         L.np_integers.argtypes = [vp, C.c_int64, C.c_int64]
+        L.np_philox_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, i32, i32, vp]
+        L.np_philox_box_muller.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
         _lib = L
     return _lib
 
@@ -113,12 +115,20 @@ class NpPCG64(C.Structure):
                 ("inc_hi", C.c_uint64), ("has32", C.c_uint32), ("u32", C.c_uint32),
                 ("philox", C.c_uint32), ("k0", C.c_uint32), ("k1", C.c_uint32),
                 ("c0", C.c_uint32), ("c1", C.c_uint32), ("c2", C.c_uint32), ("c3", C.c_uint32),
-                ("spare_lo", C.c_uint32), ("spare_hi", C.c_uint32), ("have_spare", C.c_uint32)]
+                ("spare_lo", C.c_uint32), ("spare_hi", C.c_uint32), ("have_spare", C.c_uint32),
+                ("z_spare", C.c_float), ("have_z", C.c_uint32)]
 
     @classmethod
     def from_words(cls, w):
         w = [int(x) for x in w]
         return cls(w[0], w[1], w[2], w[3], w[4], w[5])
+
+
+def philox_normals(seed, env0, tick, stream, n_envs, n_per_env):
+    """[n_envs, n_per_env] standard normals of the Philox-mode streams (seed, env0 + e, tick, stream)."""
+    out = np.zeros((n_envs, n_per_env), np.float64)
+    lib().np_philox_normals(int(seed), int(env0), int(tick), int(stream), n_envs, n_per_env, _p(out))
+    return out
 
 
 def rtable_from_sequences(S, L, keys, vals):

@@ -741,9 +741,9 @@ def test_discrete_fast_kernel_masked_reset_and_reseed():
 # ----------------------------------------------------------------------------- Philox streams
 @pytest.mark.parametrize("fused", [True, False])
 def test_discrete_philox_vs_oracle(fused):
-    """rng='philox': stateless Philox4x32-10 keyed by (seed, GLOBAL env id, tick, stream).  Integer
-    draws are exact; the ziggurat tail uses log1p/exp whose device and glibc versions may differ in
-    the last ulp, hence allclose on rewards."""
+    """rng='philox': stateless Philox4x32-10 keyed by (seed, GLOBAL env id, tick, stream).  Its
+    Gaussians are float32 Box-Muller pairs built from IEEE-exact operations only (mdpp_rng.hpp
+    philox_box_muller == oracle/np_random.c np_philox_box_muller), so rewards are bit-exact too."""
     cfg = dict(gu.CASES["d_cfg2_noise"]["config"], seed=6)
     N, T, off = 700, 50, 4096
     env = _venv(num_envs=N, autoreset="same_step", rng="philox", env_id_offset=off, philox_seed=99, **cfg)
@@ -765,8 +765,27 @@ def test_discrete_philox_vs_oracle(fused):
         eo[ed] = ero[ed]
         assert np.array_equal(obs[:, i], eo), i
         assert np.array_equal(term[:, i], ed), i
-        assert np.allclose(rew[:, i], er.astype(np.float32), rtol=1e-6, atol=1e-6), i
+        assert np.array_equal(rew[:, i], er.astype(np.float32)), i
     env.close()
+
+
+def test_philox_box_muller_device_equals_oracle_bit_for_bit():
+    """The Philox mode's Gaussian on 2^22 stream positions (incl. the first block of many envs and long
+    streams of a few): device == oracle/np_random.c, every bit."""
+    import ctypes as C
+    from mdp_playground_amd import _capi as capi
+    from oracle import oracle as ora
+    lib = capi.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for seed, env0, tick, stream, ne, npe in ((1234567890123, 0, 0, 0, 65536, 14), (99, 1 << 40, (1 << 33) + 5, 4, 64, 8192)):
+        out = torch.empty((ne, npe), dtype=torch.float64, device=dev)
+        rc = lib.mdpp_philox_normals(seed, env0, tick, stream, ne, npe, C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0
+        got = out.cpu().numpy()
+        exp = ora.philox_normals(seed, env0, tick, stream, ne, npe)
+        assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+        assert abs(got.mean()) < 0.01 and abs(got.std() - 1.0) < 0.01
 
 
 def test_continuous_philox_vs_oracle_and_sharding_invariance():
@@ -786,8 +805,8 @@ def test_continuous_philox_vs_oracle_and_sharding_invariance():
         assert np.array_equal(o.reset(), init[i])
         eo, er, ed, ero = o.rollout(acts[:, i], None)
         eo[ed] = ero[ed]
-        assert np.allclose(obs[:, i], eo, rtol=1e-6, atol=0), i
-        assert np.allclose(rew[:, i], er.astype(np.float32), rtol=1e-5, atol=1e-5), i
+        assert np.array_equal(obs[:, i], eo), i
+        assert np.array_equal(rew[:, i], er.astype(np.float32)), i
     env.close()
     half = N // 2
     parts = []
@@ -1483,6 +1502,12 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
      "NO_CFAST", 65536, 64),
     ("cfg5", {"delay": 3}, "NO_CFAST", 32768, 48),
     ("cfg4", {}, "NO_IMGFAST", 2048, 40),                            # fast vs general renderer, pipelined batches
+    # Philox streams: the fused kernels (normals made by producer waves / at the top of the step) vs the general ones
+    ("cfg5", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 64),
+    ("cfg5", {"rng": "philox"}, "NO_HELPER", 65536, 64),
+    ("cfg5", {"rng": "philox", "delay": 3, "terminal_states": [[5.0, 5.0, 5.0, 5.0]], "term_state_edge": 6.0},
+     "NO_PHILOX_FAST", 32768, 48),
+    ("cfg3", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 64),
 ])
 def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag, N, F):
     """Every specialised rollout kernel against the general kernel of the same arithmetic, on EVERY env
@@ -1491,9 +1516,11 @@ def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag
     import bench
     from mdp_playground_amd import _capi as capi
     wl = bench.WORKLOADS[workload]
+    over = dict(over)
+    rng = over.pop("rng", "numpy")
     cfg = dict(wl["config"], **over)
-    a = _venv(num_envs=N, autoreset="same_step", **cfg)
-    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    a = _venv(num_envs=N, autoreset="same_step", rng=rng, **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", rng=rng, **cfg)
     b.set_kernel_options(flag)
     assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F), (a.rollout_kernel_name(F), flag)
     wl2 = dict(wl, config=cfg)
@@ -1504,7 +1531,7 @@ def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag
         torch.cuda.synchronize()
         for x, y in zip(ra, rb):
             assert torch.equal(x, y), (workload, j)
-    streams = [capi.STREAM_ENV, capi.STREAM_SPACE]
+    streams = [capi.STREAM_ENV, capi.STREAM_SPACE] if rng == "numpy" else []       # (Philox: no stream state)
     if a.kind == "grid":
         streams.append(capi.STREAM_ACTION)
     if a.kind == "discrete" and a._irr:

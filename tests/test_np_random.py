@@ -109,3 +109,33 @@ def test_float32_norm_semantics():
             for v in x:
                 acc += np.float64(f(v * v))
             assert np.sqrt(f(acc)) == np.linalg.norm(x)
+
+
+def test_philox_mode_normals_are_standard_normal():
+    """The Philox mode's own Gaussian (float32 Box-Muller pairs, oracle/np_random.c): moments, a
+    Kolmogorov-Smirnov test against N(0, 1), independence of the pair's two halves, tails, and pinned
+    bit patterns (any change of the transform on either side shows here or in the GPU bit test)."""
+    import scipy.stats as st
+    z = ora.philox_normals(20261002, 0, 0, 0, 4096, 512).ravel()
+    assert z.dtype == np.float64 and np.all(z == z.astype(np.float32))          # float32 values
+    assert abs(z.mean()) < 3e-3 and abs(z.std() - 1.0) < 3e-3
+    assert abs(st.skew(z)) < 0.01 and abs(st.kurtosis(z)) < 0.02
+    assert st.kstest(z[:200000], "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 3e-3                       # cos / sin halves of a pair
+    assert 4.5 < np.abs(z).max() < 6.9
+    assert abs((np.abs(z) > 3.0).mean() - 2 * st.norm.sf(3.0)) < 2e-4
+    # streams are keyed: another env / tick / stream id gives other numbers, the same key the same
+    a = ora.philox_normals(5, 7, 9, 1, 1, 8)
+    assert np.array_equal(a, ora.philox_normals(5, 7, 9, 1, 1, 8))
+    for other in ((5, 8, 9, 1), (5, 7, 10, 1), (5, 7, 9, 2), (6, 7, 9, 1), (5, 7, 9 + (1 << 32), 1)):
+        assert not np.array_equal(a, ora.philox_normals(*other, 1, 8))
+    import ctypes as C
+    z0, z1 = C.c_float(), C.c_float()
+    for w0, w1 in ((0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (1, 0x40000000), (0x80000000, 0x20000000)):
+        ora.lib().np_philox_box_muller(w0, w1, C.byref(z0), C.byref(z1))
+        r2 = z0.value ** 2 + z1.value ** 2
+        u1 = max(w0, 0.5) / 2.0 ** 32
+        assert abs(r2 - (-2.0 * np.log(u1))) <= 2e-6 * max(r2, 1.0), (w0, w1)
+        th = 2 * np.pi * w1 / 2.0 ** 32
+        assert abs(z0.value - np.sqrt(r2) * np.cos(th)) < 3e-6 * max(np.sqrt(r2), 1) and \
+            abs(z1.value - np.sqrt(r2) * np.sin(th)) < 3e-6 * max(np.sqrt(r2), 1), (w0, w1)
