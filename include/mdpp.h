@@ -267,6 +267,54 @@ int mdpp_status(mdpp_env *h, uint32_t *flags_host);
 int mdpp_timer_begin(mdpp_env *h, void *stream);
 int mdpp_timer_end(mdpp_env *h, void *stream, float *ms_out);
 
+/* ---- GymEnvWrapper-style post-processor ---------------------------------------
+ * What the reference's mdp_playground/envs/gym_env_wrapper.py does around ANY inner env, for a batch of N
+ * independent instances whose (obs, reward, done) the caller supplies as device tensors -- from
+ * libmdpp_hip's own envs or from any other batched simulator.  Instance i is one GymEnvWrapper object:
+ * one generator (the wrapper's _np_random, seeded by mdpp_post_seed_streams or a Philox stream), one reward
+ * FIFO.  Replaces, per entry point:
+ *   mdpp_post_actions   discrete action noise                                   gym_env_wrapper.py:354-366
+ *   mdpp_post_step(_n)  continuous observation noise :367-373, :400-402; image canvas + shift :404-405,
+ *                       :523-618; reward delay / flush on done / terminal reward / noise / scale / shift :407-432
+ *   mdpp_post_reset     reset(): buffer refilled with zeros, image of the first observation :441-486
+ * Rewards are float64 in and out (the reference computes them as Python floats).  Upstream's `done` branch
+ * raises TypeError (list * float, :410); what is implemented is its evident numpy meaning, see INTEGRATION.md. */
+typedef struct mdpp_post mdpp_post;
+typedef struct {
+    int32_t abi_version;        /* MDPP_ABI_VERSION */
+    int32_t num_envs;
+    int64_t env_id_offset;      /* global id of local instance 0 (Philox keys) */
+    int32_t rng_mode;           /* MDPP_RNG_* */
+    uint64_t philox_seed;
+    int32_t continuous;         /* config["state_space_type"] == "continuous" */
+    int32_t n_actions;          /* discrete: env.action_space.n */
+    int32_t obs_dim, obs_f64;   /* continuous: length of an observation and its dtype (0 float32, 1 float64) */
+    int32_t delay;              /* 0..128 */
+    int32_t has_transition_noise; double transition_noise;   /* discrete: P(action replaced), continuous: std of the obs noise */
+    int32_t has_reward_noise; double reward_noise;
+    double reward_scale, reward_shift, term_state_reward;
+    int32_t autoreset;          /* 1: the caller's env resets itself at done -> the buffer is refilled with zeros after a done step */
+    /* image_transforms (discrete envs with uint8 [H][W][C] observations): canvas uint8 [W + 2 pad][H + 2 pad][C] */
+    int32_t image, img_h, img_w, img_c, img_pad, img_has_shift, img_sh_quant;
+} mdpp_post_config;
+int mdpp_post_create(const mdpp_post_config *cfg, int device, mdpp_post **out);
+void mdpp_post_destroy(mdpp_post *h);
+const char *mdpp_post_last_error(const mdpp_post *h);
+int mdpp_post_seed_streams(mdpp_post *h, const uint64_t *words_host);   /* uint64 [N][6], as mdpp_seed_streams */
+int mdpp_post_get_streams(mdpp_post *h, uint64_t *words_host);
+int mdpp_post_get_reward_buffer(mdpp_post *h, double *ring_host);       /* double [N][delay], [0] pays out next */
+/* mask_dev NULL = every instance.  Image handles: obs_in uint8 [N][H][W][C] -> obs_out uint8 [N][W+2p][H+2p][C]
+ * (instances outside the mask untouched); others: both NULL. */
+int mdpp_post_reset(mdpp_post *h, const uint8_t *mask_dev, const void *obs_in_dev, void *obs_out_dev, void *stream);
+/* the actions the inner envs receive: int32 [N] -> int32 [N] (may alias) */
+int mdpp_post_actions(mdpp_post *h, const int32_t *actions_in_dev, int32_t *actions_out_dev, void *stream);
+/* obs_in / obs_out: continuous float32|float64 [K][N][obs_dim]; image uint8 [K][N][H][W][C] -> [K][N][W+2p][H+2p][C];
+ * otherwise NULL (observations pass through).  reward double [K][N], done uint8 [K][N] (terminated). */
+int mdpp_post_step(mdpp_post *h, const void *obs_in_dev, const double *reward_in_dev, const uint8_t *done_dev,
+                   void *obs_out_dev, double *reward_out_dev, void *stream);
+int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, const double *reward_in_dev, const uint8_t *done_dev,
+                     void *obs_out_dev, double *reward_out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

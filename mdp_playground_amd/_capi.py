@@ -30,6 +30,8 @@ EXPORTS = [
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
     "mdpp_set_options", "mdpp_kernel_name", "mdpp_philox_normals",
+    "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
+    "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
 ]
 
 
@@ -58,6 +60,18 @@ class MdppConfig(C.Structure):
         ("img_has_flip", C.c_int32), ("img_sh_quant", C.c_int32), ("img_ro_quant", C.c_int32),
         ("img_r0", C.c_int32), ("img_r_min", C.c_int32), ("img_r_max", C.c_int32),
         ("img_log_min_r", C.c_double), ("img_log_max_r", C.c_double), ("img_tpl_size", C.c_int32),
+    ]
+
+
+class MdppPostConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("num_envs", C.c_int32), ("env_id_offset", C.c_int64), ("rng_mode", C.c_int32),
+        ("philox_seed", C.c_uint64), ("continuous", C.c_int32), ("n_actions", C.c_int32), ("obs_dim", C.c_int32),
+        ("obs_f64", C.c_int32), ("delay", C.c_int32), ("has_transition_noise", C.c_int32),
+        ("transition_noise", C.c_double), ("has_reward_noise", C.c_int32), ("reward_noise", C.c_double),
+        ("reward_scale", C.c_double), ("reward_shift", C.c_double), ("term_state_reward", C.c_double),
+        ("autoreset", C.c_int32), ("image", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
+        ("img_c", C.c_int32), ("img_pad", C.c_int32), ("img_has_shift", C.c_int32), ("img_sh_quant", C.c_int32),
     ]
 
 
@@ -114,6 +128,18 @@ def load():
     L.mdpp_kernel_name.argtypes = [vp, i32]
     L.mdpp_kernel_name.restype = C.c_char_p
     L.mdpp_philox_normals.argtypes = [C.c_uint64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, vp, vp]
+    L.mdpp_post_create.argtypes = [C.POINTER(MdppPostConfig), i32, C.POINTER(vp)]
+    L.mdpp_post_destroy.argtypes = [vp]
+    L.mdpp_post_destroy.restype = None
+    L.mdpp_post_last_error.argtypes = [vp]
+    L.mdpp_post_last_error.restype = C.c_char_p
+    L.mdpp_post_seed_streams.argtypes = [vp, vp]
+    L.mdpp_post_get_streams.argtypes = [vp, vp]
+    L.mdpp_post_get_reward_buffer.argtypes = [vp, vp]
+    L.mdpp_post_reset.argtypes = [vp] * 5
+    L.mdpp_post_actions.argtypes = [vp] * 4
+    L.mdpp_post_step.argtypes = [vp] * 7
+    L.mdpp_post_step_n.argtypes = [vp, i32] + [vp] * 6
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     if L.mdpp_abi_version() != MDPP_ABI_VERSION:

@@ -1,0 +1,453 @@
+// Batched GymEnvWrapper-style post-processor: what the reference's
+// mdp_playground/envs/gym_env_wrapper.py does around ANY inner env, applied to caller-supplied
+// (action | obs, reward, done) tensors of N independent env instances, one lane per instance:
+//   mdpp_post_actions   discrete action noise                               gym_env_wrapper.py:354-366
+//   mdpp_post_step_n    continuous observation noise :367-373, :400-402; image padding / shift
+//                       :404-405, :523-618; reward delay, flush-on-done, terminal reward, noise, scale,
+//                       shift :407-432
+//   mdpp_post_reset     reset(): reward buffer refilled with zeros, image of the first observation :441-486
+// Instance i owns ONE generator -- the wrapper's _np_random -- (numpy PCG64 state in HBM, or a Philox
+// stream keyed per call) and a reward FIFO `ring[delay][N]` (float64, like the reference's list of
+// Python floats) with a per-instance head, because a `done` step neither pushes nor pops (:407-414).
+// Everything is HBM/latency-bound scalar work except the image path, which writes (W + 2 pad) x
+// (H + 2 pad) x C bytes per instance and step: k_post_image moves dwords, transposing through the
+// read side (the canvas is returned as [x][y][c], :616).
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mdpp_internal.hpp"
+#include "mdpp_rng.hpp"
+
+using namespace mdpp;
+
+struct mdpp_post {
+    mdpp_post_config cfg;
+    int device;
+    std::string err;
+    uint64_t tick, reset_tick;
+    void *d_rng_s, *d_rng_inc, *d_half, *d_ring, *d_head, *d_noise_cdf, *d_shift;
+    size_t shift_cap;           // image placements held by d_shift (K * N of the largest call so far)
+    bool seeded;
+};
+
+static std::string g_post_create_err;
+
+namespace {
+
+constexpr uint32_t kPhiloxPostAction = 6, kPhiloxPostStep = 7, kPhiloxPostReset = 8;
+
+struct PostArgs {
+    int32_t N, continuous, n_actions, obs_dim, obs_f64, delay, has_p, has_r, autoreset;
+    int32_t image, H, W, C, pad, has_shift, sh_quant, philox;
+    double p_noise, r_noise, scale, shift, term;
+    uint64_t philox_seed, tick;
+    int64_t env_id_offset;
+    ulonglong2 *rng_s, *rng_inc;
+    uint2 *half;
+    double *ring;               // [delay][N]
+    uint32_t *head;             // [N] FIFO front
+    const double *noise_cdf;    // [n][n]
+    short2 *place;              // [K][N] (top, left) of the image inside the canvas
+};
+
+// numpy's pairwise summation (loops_utils.h.src), n <= 128: what np.sum does to the flushed buffer
+__device__ double post_pairwise_sum(const double *a, int n) {
+    if (n < 8) { double res = 0.; for (int i = 0; i < n; i++) res += a[i]; return res; }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// get_transformed_image's placement (:560-611): draws the shift, returns (top, left)
+template <class G>
+__device__ __forceinline__ short2 post_place(const PostArgs &a, G &g, Half32 &h) {
+    const int tot_w = a.W + 2 * a.pad, tot_h = a.H + 2 * a.pad;
+    int shift_w = tot_w / 2, shift_h = tot_h / 2;
+    if (a.has_shift) {
+        const int max_w = (tot_w - a.W) / 2, max_h = (tot_h - a.W) / 2;       // R = width, :558
+        int aw = np_integers(g, h, -max_w + 1, max_w);
+        int ah = np_integers(g, h, -max_h + 1, max_h);
+        aw = (aw / a.sh_quant) * a.sh_quant;                                  // int(a / q) * q: truncation
+        ah = (ah / a.sh_quant) * a.sh_quant;
+        shift_w += aw; shift_h += ah;
+    }
+    return make_short2((short)(shift_h - a.H / 2), (short)(shift_w - a.W / 2));
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_post_actions(PostArgs a, const int32_t *__restrict__ in,
+                                                         int32_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.N) return;
+    int act = in[i];
+    if (act < 0 || act >= a.n_actions) { out[i] = act; return; }             // (the reference would raise IndexError)
+    typename std::conditional<PHILOX, Philox, Pcg64>::type g;
+    if constexpr (PHILOX) g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.tick, kPhiloxPostAction);
+    else g.load(a.rng_s, a.rng_inc, i);
+    const double u = np_random(g);                                            // choice(n, size=1, p=probs), :364
+    out[i] = searchsorted_right(a.noise_cdf + (size_t)act * a.n_actions, a.n_actions, u);
+    if constexpr (!PHILOX) g.store(a.rng_s, i);
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const void *__restrict__ obs_in,
+                                                      const double *__restrict__ reward_in,
+                                                      const uint8_t *__restrict__ done_in, void *__restrict__ obs_out,
+                                                      double *__restrict__ reward_out) {
+    __shared__ uint64_t s_ki[256];
+    __shared__ double s_wi[256], s_fi[256];
+    const bool normals = !PHILOX && ((a.continuous && a.has_p) || a.has_r);
+    if (normals) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
+    const ZigLds zig{s_ki, s_wi, s_fi};
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.N) return;
+    const long N = a.N;
+    typename std::conditional<PHILOX, Philox, Pcg64>::type g;
+    Half32 hf{0, 0};
+    const bool draws = (a.continuous && a.has_p) || a.has_r || (a.image && a.has_shift);
+    if constexpr (!PHILOX) {
+        if (draws) { g.load(a.rng_s, a.rng_inc, i); const uint2 hh = a.half[i]; hf = Half32{hh.x, hh.y}; }
+    }
+    uint32_t head = a.delay > 0 ? a.head[i] : 0u;
+    for (int k = 0; k < K; k++) {
+        const long o = (long)k * N + i;
+        if constexpr (PHILOX) {
+            g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.tick + (uint64_t)k, kPhiloxPostStep);
+            hf = Half32{0, 0};
+        }
+        if (a.continuous) {                                                   // :367-373, :400-402
+            for (int d = 0; d < a.obs_dim; d++) {
+                const double nz = a.has_p ? 0.0 + a.p_noise * np_standard_normal_lds(g, zig) : 0.0;
+                if (a.obs_f64) ((double *)obs_out)[o * a.obs_dim + d] = ((const double *)obs_in)[o * a.obs_dim + d] + nz;
+                else ((float *)obs_out)[o * a.obs_dim + d] = (float)((double)((const float *)obs_in)[o * a.obs_dim + d] + nz);
+            }
+        }
+        if (a.image) a.place[o] = post_place(a, g, hf);                      // :404-405 (pixels: k_post_image)
+        double reward = reward_in[o];
+        const bool done = done_in[o] != 0;
+        if (done) {                                                           // :407-414
+            double tmp[128];
+            for (int j = 0; j < a.delay; j++) {
+                const uint32_t slot = head + (uint32_t)j < (uint32_t)a.delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)a.delay;
+                tmp[j] = a.ring[(size_t)slot * N + i] * a.scale + a.shift;
+            }
+            reward += post_pairwise_sum(tmp, a.delay);
+            reward += a.term * a.scale;
+            if (a.autoreset) {                                                // the caller's env reset itself: reset(), :456
+                for (int j = 0; j < a.delay; j++) a.ring[(size_t)j * N + i] = 0.0;
+                head = 0;
+            }
+        } else if (a.delay > 0) {                                             // :415-420
+            double *slot = a.ring + (size_t)head * N + i;
+            const double out = *slot;
+            *slot = reward;
+            reward = out;
+            head = head + 1u == (uint32_t)a.delay ? 0u : head + 1u;
+        }
+        const double nz = a.has_r ? 0.0 + a.r_noise * np_standard_normal_lds(g, zig) : 0.0;   // :426
+        reward += nz;                                                         // :430-432
+        reward *= a.scale;
+        reward += a.shift;
+        reward_out[o] = reward;
+    }
+    if (a.delay > 0) a.head[i] = head;
+    if constexpr (!PHILOX) {
+        if (draws) { g.store(a.rng_s, i); a.half[i] = make_uint2(hf.has32, hf.u32); }
+    }
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_post_reset(PostArgs a, uint64_t reset_tick, const uint8_t *__restrict__ mask) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.N) return;
+    if (mask && !mask[i]) { if (a.image) a.place[i] = make_short2(-32768, 0); return; }
+    for (int j = 0; j < a.delay; j++) a.ring[(size_t)j * a.N + i] = 0.0;      // :456
+    if (a.delay > 0) a.head[i] = 0;
+    if (a.image) {                                                            // :481-482
+        typename std::conditional<PHILOX, Philox, Pcg64>::type g;
+        Half32 hf{0, 0};
+        if constexpr (PHILOX) g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), reset_tick, kPhiloxPostReset);
+        else if (a.has_shift) { g.load(a.rng_s, a.rng_inc, i); const uint2 hh = a.half[i]; hf = Half32{hh.x, hh.y}; }
+        a.place[i] = post_place(a, g, hf);
+        if constexpr (!PHILOX) {
+            if (a.has_shift) { g.store(a.rng_s, i); a.half[i] = make_uint2(hf.has32, hf.u32); }
+        }
+    }
+}
+
+// canvas[x][y][c] = image[y - top][x - left][c] inside the placed image, else 0: one dword of the canvas
+// per lane, consecutive lanes consecutive dwords (1 KiB per wave store); M images of in_bytes / out_bytes
+__global__ __launch_bounds__(kBlock) void k_post_image(PostArgs a, long M, const short2 *__restrict__ place,
+                                                       const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+    const int tot_w = a.W + 2 * a.pad, tot_h = a.H + 2 * a.pad, C = a.C;
+    const long out_bytes = (long)tot_w * tot_h * C, in_bytes = (long)a.H * a.W * C;
+    const long dwords = out_bytes / 4;                 // (create() checks divisibility)
+    const long total = M * dwords;
+    for (long q = (long)blockIdx.x * kBlock + threadIdx.x; q < total; q += (long)gridDim.x * kBlock) {
+        const long img = q / dwords;
+        const short2 pl = place[img];
+        if (pl.x == -32768) continue;                  // not reset: leave the caller's buffer alone
+        const uint32_t b0 = (uint32_t)(q - img * dwords) * 4u;
+        const uint8_t *src = in + img * in_bytes;
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t b = b0 + (uint32_t)j;
+            const uint32_t pix = b / (uint32_t)C, c = b - pix * (uint32_t)C;
+            const int x = (int)(pix / (uint32_t)tot_h), y = (int)(pix - (uint32_t)x * (uint32_t)tot_h);
+            const int sy = y - pl.x, sx = x - pl.y;
+            uint32_t byte = 0;
+            if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) byte = src[((long)sy * a.W + sx) * C + c];
+            v |= byte << (8 * j);
+        }
+        ((uint32_t *)(out + img * out_bytes))[q - img * dwords] = v;
+    }
+}
+
+int pfail(mdpp_post *h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_post_create_err = msg;
+    return code;
+}
+
+#define PHIP(h, expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return pfail(h, MDPP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+PostArgs make_args(const mdpp_post *h) {
+    const mdpp_post_config &c = h->cfg;
+    PostArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = c.num_envs; a.continuous = c.continuous; a.n_actions = c.n_actions; a.obs_dim = c.obs_dim; a.obs_f64 = c.obs_f64;
+    a.delay = c.delay; a.has_p = c.has_transition_noise; a.has_r = c.has_reward_noise; a.autoreset = c.autoreset;
+    a.image = c.image; a.H = c.img_h; a.W = c.img_w; a.C = c.img_c; a.pad = c.img_pad; a.has_shift = c.img_has_shift;
+    a.sh_quant = c.img_sh_quant > 0 ? c.img_sh_quant : 1;
+    a.philox = c.rng_mode == MDPP_RNG_PHILOX;
+    a.p_noise = c.transition_noise; a.r_noise = c.reward_noise; a.scale = c.reward_scale; a.shift = c.reward_shift;
+    a.term = c.term_state_reward;
+    a.philox_seed = c.philox_seed; a.tick = h->tick; a.env_id_offset = c.env_id_offset;
+    a.rng_s = (ulonglong2 *)h->d_rng_s; a.rng_inc = (ulonglong2 *)h->d_rng_inc; a.half = (uint2 *)h->d_half;
+    a.ring = (double *)h->d_ring; a.head = (uint32_t *)h->d_head; a.noise_cdf = (const double *)h->d_noise_cdf;
+    a.place = (short2 *)h->d_shift;
+    return a;
+}
+
+int ensure_place(mdpp_post *h, size_t count) {
+    if (count <= h->shift_cap) return MDPP_OK;
+    if (h->d_shift) (void)hipFree(h->d_shift);
+    h->d_shift = nullptr; h->shift_cap = 0;
+    PHIP(h, hipMalloc(&h->d_shift, count * sizeof(short2)));
+    h->shift_cap = count;
+    return MDPP_OK;
+}
+
+int post_ready(mdpp_post *h, const char *what) {
+    if (h->cfg.rng_mode == MDPP_RNG_NUMPY_PCG64 && !h->seeded) return pfail(h, MDPP_ESTATE, std::string(what) + ": stream not seeded");
+    return MDPP_OK;
+}
+
+} // namespace
+
+extern "C" const char *mdpp_post_last_error(const mdpp_post *h) { return h ? h->err.c_str() : g_post_create_err.c_str(); }
+
+extern "C" void mdpp_post_destroy(mdpp_post *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void *p : {h->d_rng_s, h->d_rng_inc, h->d_half, h->d_ring, h->d_head, h->d_noise_cdf, h->d_shift})
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int mdpp_post_create(const mdpp_post_config *cfg, int device, mdpp_post **out) {
+    if (!cfg || !out) return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: null argument");
+    if (cfg->abi_version != MDPP_ABI_VERSION) return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: abi_version mismatch");
+    if (cfg->num_envs <= 0) return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: num_envs <= 0");
+    if (cfg->delay < 0 || cfg->delay > 128)
+        return pfail(nullptr, MDPP_EUNSUPPORTED, "mdpp_post_create: need 0 <= delay <= 128 (the flush on done sums the buffer like np.sum, blocked up to 128)");
+    if (cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 && cfg->rng_mode != MDPP_RNG_PHILOX)
+        return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: unknown rng_mode");
+    if (cfg->continuous && (cfg->obs_dim < 1 || cfg->image))
+        return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: continuous needs obs_dim >= 1 and no image transforms (:135-138)");
+    if (!cfg->continuous && cfg->has_transition_noise &&
+        (cfg->n_actions < 2 || !(cfg->transition_noise >= 0.0 && cfg->transition_noise <= 1.0)))
+        return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: discrete transition_noise must be in [0, 1] and n_actions >= 2 (:105-109)");
+    if (cfg->image) {
+        const long ob = (long)(cfg->img_w + 2 * cfg->img_pad) * (cfg->img_h + 2 * cfg->img_pad) * cfg->img_c;
+        if (cfg->img_h < 2 || cfg->img_h != cfg->img_w || cfg->img_h % 2 || cfg->img_c < 1 || cfg->img_pad < 0 ||
+            cfg->img_h + 2 * cfg->img_pad > 16384 || ob % 4)
+            return pfail(nullptr, MDPP_EUNSUPPORTED, "mdpp_post_create: images must be square (:531) with an even side, and the "
+                                                     "padded canvas a multiple of 4 bytes");
+        if (cfg->img_has_shift && cfg->img_pad < 1)
+            return pfail(nullptr, MDPP_EINVAL, "mdpp_post_create: shift needs image_padding >= 1");
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return pfail(nullptr, MDPP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    mdpp_post *h = new mdpp_post();
+    h->cfg = *cfg; h->device = device; h->tick = 0; h->reset_tick = 0; h->seeded = false;
+    h->d_rng_s = h->d_rng_inc = h->d_half = h->d_ring = h->d_head = h->d_noise_cdf = h->d_shift = nullptr;
+    h->shift_cap = 0;
+    const size_t N = (size_t)cfg->num_envs;
+    auto alloc0 = [&](void **p, size_t bytes) {
+        if (hipMalloc(p, bytes ? bytes : 16) != hipSuccess) return false;
+        return hipMemset(*p, 0, bytes ? bytes : 16) == hipSuccess;
+    };
+    bool ok = true;
+    if (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64)
+        ok = alloc0(&h->d_rng_s, N * 16) && alloc0(&h->d_rng_inc, N * 16) && alloc0(&h->d_half, N * 8);
+    ok = ok && alloc0(&h->d_ring, (size_t)cfg->delay * N * 8) && alloc0(&h->d_head, N * 4);
+    if (ok && !cfg->continuous && cfg->has_transition_noise && cfg->transition_noise != 0.0) {
+        // row a = cumsum(probs) / cumsum(probs)[-1] of probs = noise / (n - 1), probs[a] = 1 - noise (:356-361), as numpy's choice forms it
+        const int n = cfg->n_actions;
+        std::vector<double> cdf((size_t)n * n);
+        for (int a = 0; a < n; a++) {
+            double acc = 0.0;
+            for (int j = 0; j < n; j++) {
+                const double p = (j == a) ? 1 - cfg->transition_noise : 1.0 * cfg->transition_noise / (double)(n - 1);
+                acc += p; cdf[(size_t)a * n + j] = acc;
+            }
+            const double last = cdf[(size_t)a * n + n - 1];
+            for (int j = 0; j < n; j++) cdf[(size_t)a * n + j] /= last;
+        }
+        ok = hipMalloc(&h->d_noise_cdf, cdf.size() * 8) == hipSuccess &&
+             hipMemcpy(h->d_noise_cdf, cdf.data(), cdf.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { g_post_create_err = "mdpp_post_create: device allocation failed"; mdpp_post_destroy(h); return MDPP_ENOMEM; }
+    *out = h;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_seed_streams(mdpp_post *h, const uint64_t *words) {
+    if (!h || !words) return MDPP_EINVAL;
+    if (h->cfg.rng_mode != MDPP_RNG_NUMPY_PCG64) return pfail(h, MDPP_ESTATE, "post_seed_streams: handle is in Philox mode");
+    PHIP(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.num_envs;
+    std::vector<uint64_t> st(2 * N), inc(2 * N);
+    std::vector<uint32_t> half(2 * N);
+    for (size_t i = 0; i < N; i++) {
+        st[2 * i] = words[6 * i]; st[2 * i + 1] = words[6 * i + 1];
+        inc[2 * i] = words[6 * i + 2]; inc[2 * i + 1] = words[6 * i + 3];
+        half[2 * i] = (uint32_t)words[6 * i + 4]; half[2 * i + 1] = (uint32_t)words[6 * i + 5];
+    }
+    PHIP(h, hipDeviceSynchronize());
+    PHIP(h, hipMemcpy(h->d_rng_s, st.data(), N * 16, hipMemcpyHostToDevice));
+    PHIP(h, hipMemcpy(h->d_rng_inc, inc.data(), N * 16, hipMemcpyHostToDevice));
+    PHIP(h, hipMemcpy(h->d_half, half.data(), N * 8, hipMemcpyHostToDevice));
+    h->seeded = true;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_get_streams(mdpp_post *h, uint64_t *words) {
+    if (!h || !words) return MDPP_EINVAL;
+    if (h->cfg.rng_mode != MDPP_RNG_NUMPY_PCG64) return pfail(h, MDPP_ESTATE, "post_get_streams: handle is in Philox mode");
+    PHIP(h, hipSetDevice(h->device));
+    PHIP(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    std::vector<uint64_t> st(2 * N), inc(2 * N);
+    std::vector<uint32_t> half(2 * N);
+    PHIP(h, hipMemcpy(st.data(), h->d_rng_s, N * 16, hipMemcpyDeviceToHost));
+    PHIP(h, hipMemcpy(inc.data(), h->d_rng_inc, N * 16, hipMemcpyDeviceToHost));
+    PHIP(h, hipMemcpy(half.data(), h->d_half, N * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        words[6 * i] = st[2 * i]; words[6 * i + 1] = st[2 * i + 1];
+        words[6 * i + 2] = inc[2 * i]; words[6 * i + 3] = inc[2 * i + 1];
+        words[6 * i + 4] = half[2 * i]; words[6 * i + 5] = half[2 * i + 1];
+    }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_get_reward_buffer(mdpp_post *h, double *ring_host) {
+    if (!h || !ring_host) return MDPP_EINVAL;
+    PHIP(h, hipSetDevice(h->device));
+    PHIP(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs, d = (size_t)h->cfg.delay;
+    if (d == 0) return MDPP_OK;
+    std::vector<double> rg(d * N);
+    std::vector<uint32_t> head(N);
+    PHIP(h, hipMemcpy(rg.data(), h->d_ring, rg.size() * 8, hipMemcpyDeviceToHost));
+    PHIP(h, hipMemcpy(head.data(), h->d_head, N * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++)
+        for (size_t j = 0; j < d; j++) ring_host[i * d + j] = rg[((head[i] + j) % d) * N + i];   // [0] pays out next
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_reset(mdpp_post *h, const uint8_t *mask_dev, const void *obs_in_dev, void *obs_out_dev, void *stream) {
+    if (!h) return MDPP_EINVAL;
+    int rc = post_ready(h, "mdpp_post_reset");
+    if (rc) return rc;
+    if (h->cfg.image && (!obs_in_dev || !obs_out_dev)) return pfail(h, MDPP_EINVAL, "mdpp_post_reset: image handles need the first observations");
+    PHIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->cfg.image) { rc = ensure_place(h, (size_t)h->cfg.num_envs); if (rc) return rc; }
+    PostArgs a = make_args(h);
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    if (a.philox) hipLaunchKernelGGL(k_post_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask_dev);
+    else hipLaunchKernelGGL(k_post_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask_dev);
+    if (h->cfg.image) {
+        const long dwords = (long)(a.W + 2 * a.pad) * (a.H + 2 * a.pad) * a.C / 4;
+        const long blocks = ((long)a.N * dwords + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_post_image, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s, a, (long)a.N,
+                           a.place, (const uint8_t *)obs_in_dev, (uint8_t *)obs_out_dev);
+    }
+    PHIP(h, hipGetLastError());
+    h->reset_tick += 1;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_actions(mdpp_post *h, const int32_t *in_dev, int32_t *out_dev, void *stream) {
+    if (!h || !in_dev || !out_dev) return MDPP_EINVAL;
+    int rc = post_ready(h, "mdpp_post_actions");
+    if (rc) return rc;
+    if (h->cfg.continuous) return pfail(h, MDPP_EINVAL, "mdpp_post_actions: continuous actions pass through unchanged (:367-373 adds noise to observations)");
+    PHIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = (size_t)h->cfg.num_envs;
+    if (!h->d_noise_cdf) {                                   // `if self.transition_noise:` false: identity
+        if (in_dev != out_dev) PHIP(h, hipMemcpyAsync(out_dev, in_dev, N * 4, hipMemcpyDeviceToDevice, s));
+        return MDPP_OK;
+    }
+    PostArgs a = make_args(h);
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    if (a.philox) hipLaunchKernelGGL(k_post_actions<true>, dim3(grid), dim3(kBlock), 0, s, a, in_dev, out_dev);
+    else hipLaunchKernelGGL(k_post_actions<false>, dim3(grid), dim3(kBlock), 0, s, a, in_dev, out_dev);
+    PHIP(h, hipGetLastError());
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, const double *reward_in_dev,
+                                const uint8_t *done_dev, void *obs_out_dev, double *reward_out_dev, void *stream) {
+    if (!h || K < 1 || !reward_in_dev || !done_dev || !reward_out_dev) return MDPP_EINVAL;
+    int rc = post_ready(h, "mdpp_post_step");
+    if (rc) return rc;
+    if ((h->cfg.continuous || h->cfg.image) && (!obs_in_dev || !obs_out_dev))
+        return pfail(h, MDPP_EINVAL, "mdpp_post_step: this handle transforms observations: obs_in / obs_out needed");
+    PHIP(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->cfg.image) { rc = ensure_place(h, (size_t)K * h->cfg.num_envs); if (rc) return rc; }
+    PostArgs a = make_args(h);
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    if (a.philox) hipLaunchKernelGGL(k_post_step<true>, dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, reward_in_dev, done_dev, obs_out_dev, reward_out_dev);
+    else hipLaunchKernelGGL(k_post_step<false>, dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, reward_in_dev, done_dev, obs_out_dev, reward_out_dev);
+    if (h->cfg.image) {
+        const long M = (long)K * a.N;
+        const long dwords = (long)(a.W + 2 * a.pad) * (a.H + 2 * a.pad) * a.C / 4;
+        const long blocks = (M * dwords + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_post_image, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s, a, M, a.place,
+                           (const uint8_t *)obs_in_dev, (uint8_t *)obs_out_dev);
+    }
+    PHIP(h, hipGetLastError());
+    h->tick += (uint64_t)K;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_post_step(mdpp_post *h, const void *obs_in_dev, const double *reward_in_dev, const uint8_t *done_dev,
+                              void *obs_out_dev, double *reward_out_dev, void *stream) {
+    return mdpp_post_step_n(h, 1, obs_in_dev, reward_in_dev, done_dev, obs_out_dev, reward_out_dev, stream);
+}

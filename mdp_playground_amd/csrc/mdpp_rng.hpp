@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t next32(G &g, Half32 &h) {
 // loop, no tables -- every lane of a wave does the same work.  The pair's second normal is kept for
 // the stream's next normal draw.  The transform uses only IEEE-exact operations (conversions, fma,
 // multiply, add, correctly rounded sqrtf, bit operations), so the oracle's C restatement
-// (oracle/np_random.c philox_box_muller) produces the same bits.
+// (np_philox_box_muller in the test oracle) produces the same bits.
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&o)[4]) {

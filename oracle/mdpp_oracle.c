@@ -822,3 +822,127 @@ void ora_ig_render(int W, int H, int R, const uint8_t *disc, int G, const int32_
         }
     }
 }
+
+/* ======================================================================
+ * GymEnvWrapper-style post-processor, gym_env_wrapper.py:350-439, :441-486, :523-618
+ * ==================================================================== */
+struct ora_post {
+    int continuous, n_actions, obs_dim, obs_f64, delay;
+    int has_p, has_r;
+    double p_noise, r_noise, scale, shift, term;
+    double *noise_cdf;            /* [n][n]: row a = cdf of the categorical around action a (:356-364) */
+    int image, H, W, C, pad, has_shift, sh_quant;
+    double *ring; int ring_n;     /* self.reward_buffer (a list: append at the end, pop the front) */
+    np_pcg64 rng;
+    int philox; uint64_t ph_seed, ph_env, tick, reset_tick;
+};
+
+/* numpy's pairwise summation of a contiguous float64 vector (loops_utils.h.src, n <= 128) == np.sum */
+double ora_np_pairwise_sum(const double *a, int n) {
+    if (n < 8) { double res = 0.; for (int i = 0; i < n; i++) res += a[i]; return res; }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+ora_post *ora_p_create(int continuous, int n_actions, int obs_dim, int obs_f64, int delay,
+                       int has_p_noise, double p_noise, int has_r_noise, double r_noise,
+                       double scale, double shift, double term_state_reward,
+                       int image, int H, int W, int C, int pad, int has_shift, int sh_quant) {
+    ora_post *e = (ora_post *)calloc(1, sizeof *e);
+    e->continuous = continuous; e->n_actions = n_actions; e->obs_dim = obs_dim; e->obs_f64 = obs_f64;
+    e->delay = delay; e->has_p = has_p_noise; e->p_noise = p_noise; e->has_r = has_r_noise; e->r_noise = r_noise;
+    e->scale = scale; e->shift = shift; e->term = term_state_reward;
+    e->image = image; e->H = H; e->W = W; e->C = C; e->pad = pad; e->has_shift = has_shift; e->sh_quant = sh_quant;
+    e->ring = (double *)calloc((size_t)(delay > 0 ? delay : 1), sizeof(double));
+    e->ring_n = delay;
+    if (!continuous && has_p_noise && p_noise != 0.0) {        /* `if self.transition_noise:` (:355) */
+        const int n = n_actions;
+        e->noise_cdf = (double *)malloc(sizeof(double) * (size_t)n * n);
+        double *p = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int a = 0; a < n; a++) {                            /* :356-361 */
+            for (int j = 0; j < n; j++) p[j] = 1.0 * p_noise / (double)(n - 1);
+            p[a] = 1 - p_noise;
+            np_build_cdf(p, n, e->noise_cdf + (size_t)a * n);
+        }
+        free(p);
+    }
+    return e;
+}
+void ora_p_destroy(ora_post *e) { if (e) { free(e->ring); free(e->noise_cdf); free(e); } }
+void ora_p_set_rng(ora_post *e, const uint64_t w[6]) { np_pcg64_load(&e->rng, w); }
+void ora_p_get_rng(const ora_post *e, uint64_t w[6]) { np_pcg64_store(&e->rng, w); }
+void ora_p_set_philox(ora_post *e, uint64_t seed, uint64_t env_id, uint64_t tick, uint64_t reset_tick) {
+    e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
+}
+
+/* get_transformed_image, :523-618 (only "shift" does anything upstream; square RGB images) */
+static void post_image(ora_post *e, const uint8_t *in, uint8_t *out) {
+    const int H = e->H, W = e->W, C = e->C, pad = e->pad;
+    const int tot_w = W + 2 * pad, tot_h = H + 2 * pad;
+    int shift_w = (int)(tot_w / 2.0), shift_h = (int)(tot_h / 2.0);          /* :560-561 */
+    if (e->has_shift) {                                                      /* :584-594 */
+        const int R = W;
+        const long max_w = (tot_w - R) / 2, max_h = (tot_h - R) / 2;
+        long aw = np_integers(&e->rng, -max_w + 1, max_w);
+        long ah = np_integers(&e->rng, -max_h + 1, max_h);
+        aw = (aw / e->sh_quant) * e->sh_quant;                               /* int(a / q) * q: truncation */
+        ah = (ah / e->sh_quant) * e->sh_quant;
+        shift_w += (int)aw; shift_h += (int)ah;
+    }
+    const int top = shift_h - H / 2, left = shift_w - W / 2;                 /* :604-611 */
+    memset(out, 0, (size_t)tot_w * tot_h * C);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < C; c++)                                      /* canvas[row][col] then transpose(1, 0, 2), :616 */
+                out[((size_t)(left + x) * tot_h + (top + y)) * C + c] = in[((size_t)y * W + x) * C + c];
+}
+
+void ora_p_reset(ora_post *e, const uint8_t *img_in, uint8_t *img_out) {
+    for (int i = 0; i < e->delay; i++) e->ring[i] = 0.0;                     /* :456 */
+    e->ring_n = e->delay;
+    if (e->philox) { np_philox_init(&e->rng, e->ph_seed, e->ph_env, e->reset_tick, 8); e->reset_tick += 1; }
+    if (e->image) post_image(e, img_in, img_out);                            /* :481-482 */
+}
+
+int ora_p_action(ora_post *e, int action) {
+    if (e->philox) np_philox_init(&e->rng, e->ph_seed, e->ph_env, e->tick, 6);
+    if (e->continuous || !e->noise_cdf) return action;
+    return np_choice_cdf(&e->rng, e->noise_cdf + (size_t)action * e->n_actions, e->n_actions);   /* :364 */
+}
+
+void ora_p_step(ora_post *e, const void *obs_in, double reward, int done, void *obs_out, double *reward_out) {
+    if (e->philox) { np_philox_init(&e->rng, e->ph_seed, e->ph_env, e->tick, 7); e->tick += 1; }
+    if (e->continuous) {
+        /* :367-373 noise drawn before the inner step (it does not touch this generator), added to a copy
+         * of the observation in its own dtype :400-402; without noise `next_obs += 0.0` */
+        for (int d = 0; d < e->obs_dim; d++) {
+            const double nz = e->has_p ? 0.0 + e->p_noise * np_standard_normal(&e->rng) : 0.0;
+            if (e->obs_f64) ((double *)obs_out)[d] = ((const double *)obs_in)[d] + nz;
+            else ((float *)obs_out)[d] = (float)((double)((const float *)obs_in)[d] + nz);
+        }
+    }
+    if (e->image) post_image(e, (const uint8_t *)obs_in, (uint8_t *)obs_out);   /* :404-405 */
+    if (done) {                                                              /* :407-414 */
+        double tmp[128];
+        for (int i = 0; i < e->ring_n; i++) tmp[i] = e->ring[i] * e->scale + e->shift;
+        reward += ora_np_pairwise_sum(tmp, e->ring_n);
+        reward += e->term * e->scale;
+    } else {                                                                 /* :415-420 */
+        if (e->delay > 0) {
+            const double out = e->ring[0];
+            memmove(e->ring, e->ring + 1, sizeof(double) * (size_t)(e->delay - 1));
+            e->ring[e->delay - 1] = reward;
+            reward = out;
+        }
+    }
+    const double nz = e->has_r ? 0.0 + e->r_noise * np_standard_normal(&e->rng) : 0.0;   /* :426 */
+    reward += nz;                                                            /* :430-432 */
+    reward *= e->scale;
+    reward += e->shift;
+    *reward_out = reward;
+}

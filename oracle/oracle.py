@@ -90,6 +90,18 @@ def lib():
         L.np_standard_normal.argtypes = [vp]
         L.np_integers.restype = C.c_int64
         L.np_integers.argtypes = [vp, C.c_int64, C.c_int64]
+        L.ora_p_create.restype = vp
+        L.ora_p_create.argtypes = [i32] * 6 + [f64, i32, f64, f64, f64, f64] + [i32] * 7
+        L.ora_p_destroy.argtypes = [vp]
+        L.ora_p_set_rng.argtypes = [vp, vp]
+        L.ora_p_get_rng.argtypes = [vp, vp]
+        L.ora_p_set_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ora_p_reset.argtypes = [vp, vp, vp]
+        L.ora_p_action.argtypes = [vp, i32]
+        L.ora_p_action.restype = i32
+        L.ora_p_step.argtypes = [vp, vp, f64, i32, vp, vp]
+        L.ora_np_pairwise_sum.argtypes = [vp, i32]
+        L.ora_np_pairwise_sum.restype = f64
         L.np_philox_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, i32, i32, vp]
         L.np_philox_box_muller.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
         _lib = L
@@ -122,6 +134,75 @@ class NpPCG64(C.Structure):
     def from_words(cls, w):
         w = [int(x) for x in w]
         return cls(w[0], w[1], w[2], w[3], w[4], w[5])
+
+
+class PostOracle:
+    """One GymEnvWrapper instance's post-processing (gym_env_wrapper.py:350-439, :441-486, :523-618) of an
+    inner env's (obs, reward, done); config keys as the wrapper's."""
+
+    def __init__(self, state_space_type, n_actions=0, obs_dim=0, obs_dtype=np.float32, delay=0,
+                 transition_noise=None, reward_noise=None, reward_scale=1.0, reward_shift=0.0, term_state_reward=0.0,
+                 image_shape=None, image_transforms=None, image_padding=20, image_sh_quant=1):
+        self.cont = state_space_type == "continuous"
+        self.obs_dtype = np.dtype(obs_dtype)
+        self.obs_dim = int(obs_dim)
+        self.image = image_transforms is not None and bool(image_transforms)
+        self.shape = tuple(image_shape) if self.image else None
+        H, W, Cc = self.shape if self.image else (0, 0, 0)
+        self.pad = int(image_padding)
+        self.h = lib().ora_p_create(int(self.cont), int(n_actions), self.obs_dim, int(self.obs_dtype == np.float64),
+                                    int(delay), int(transition_noise is not None), float(transition_noise or 0.0),
+                                    int(reward_noise is not None), float(reward_noise or 0.0), float(reward_scale),
+                                    float(reward_shift), float(term_state_reward), int(self.image), H, W, Cc, self.pad,
+                                    int(self.image and "shift" in image_transforms), int(image_sh_quant or 1))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_p_destroy(self.h)
+            self.h = None
+
+    def set_rng(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        lib().ora_p_set_rng(self.h, _p(w))
+
+    def get_rng(self):
+        w = np.zeros(6, np.uint64)
+        lib().ora_p_get_rng(self.h, _p(w))
+        return w
+
+    def set_philox(self, seed, env_id, tick=0, reset_tick=0):
+        lib().ora_p_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
+
+    def _img_out(self):
+        H, W, Cc = self.shape
+        return np.zeros((W + 2 * self.pad, H + 2 * self.pad, Cc), np.uint8)
+
+    def reset(self, obs=None):
+        if not self.image:
+            lib().ora_p_reset(self.h, None, None)
+            return obs
+        src = np.ascontiguousarray(obs, dtype=np.uint8)
+        out = self._img_out()
+        lib().ora_p_reset(self.h, _p(src), _p(out))
+        return out
+
+    def action(self, a):
+        return int(lib().ora_p_action(self.h, int(a)))
+
+    def step(self, obs, reward, done):
+        r = C.c_double()
+        if self.cont:
+            src = np.ascontiguousarray(obs, dtype=self.obs_dtype)
+            out = np.zeros_like(src)
+            lib().ora_p_step(self.h, _p(src), float(reward), int(bool(done)), _p(out), C.byref(r))
+            return out, r.value
+        if self.image:
+            src = np.ascontiguousarray(obs, dtype=np.uint8)
+            out = self._img_out()
+            lib().ora_p_step(self.h, _p(src), float(reward), int(bool(done)), _p(out), C.byref(r))
+            return out, r.value
+        lib().ora_p_step(self.h, None, float(reward), int(bool(done)), None, C.byref(r))
+        return obs, r.value
 
 
 def philox_normals(seed, env0, tick, stream, n_envs, n_per_env):

@@ -1,0 +1,166 @@
+"""GPU parity of the batched post-processor (mdpp_post_*, mdp_playground_amd/post.py) — SURVEY.md §8f
+rank 4 — against (1) the goldens the reference's GymEnvWrapper produced (tests/golden/w_*.npz) and (2)
+the oracle on freshly seeded inputs at sizes the oracle finishes in seconds.  Bit-exact everywhere:
+noisy actions, observation floats / pixels, float64 rewards, generator end states."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from test_post_oracle_golden import WCASES, make_post_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _post(case, g, num_envs, **kw):
+    from mdp_playground_amd.post import VectorPostProcessor
+    cfg = dict(case["config"])
+    args = dict(n_actions=6)
+    if case["kind"] == "continuous":
+        args = dict(obs_shape=g["base_obs"].shape[2:], obs_dtype=g["base_obs"].dtype)
+    elif case["kind"] == "image":
+        args.update(obs_shape=g["base_obs"].shape[2:])
+    return VectorPostProcessor(num_envs, **args, **kw, **cfg)
+
+
+def _bits(t):
+    return t.cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("name", sorted(WCASES))
+def test_post_vs_gym_env_wrapper_goldens(name):
+    case, g = WCASES[name], gu.load(name)
+    E, T = g["base_reward"].shape
+    post = _post(case, g, E, seed=case["seeds"][0])
+    assert np.array_equal(post.get_streams(), g["rng0"])            # the constructor's draws, :93-104
+    dev = post.device
+    ob0 = post.reset(torch.as_tensor(g["init_base_obs"], device=dev) if case["kind"] == "image" else None)
+    if case["kind"] == "image":
+        assert _bits(ob0) == g["init_obs"].tobytes()
+    cur = None if case["kind"] != "image" else ob0.clone()
+    for t in range(T):
+        if case["kind"] != "continuous":
+            a = post.actions(torch.as_tensor(g["action"][:, t].astype(np.int32), device=dev))
+            assert np.array_equal(a.cpu().numpy(), g["action_env"][:, t]), (name, t)
+        obs_in = None if case["kind"] == "discrete" else torch.as_tensor(np.ascontiguousarray(g["base_obs"][:, t]), device=dev)
+        obs, rew = post.step(obs_in, torch.as_tensor(g["base_reward"][:, t], device=dev),
+                             torch.as_tensor(g["base_done"][:, t], device=dev))
+        if case["kind"] != "discrete":
+            assert _bits(obs) == np.ascontiguousarray(g["obs"][:, t]).tobytes(), (name, t)
+        assert np.array_equal(rew.cpu().numpy().view(np.uint64), g["reward"][:, t].view(np.uint64)), (name, t)
+        ra = g["reset_after"][:, t]
+        if ra.any():
+            if case["kind"] == "image":
+                cur = obs.clone()
+                out = post.reset(torch.as_tensor(np.ascontiguousarray(g["reset_base_obs"][:, t]), device=dev), mask=ra, out=cur)
+                got = out.cpu().numpy()
+                assert np.array_equal(got[ra], g["reset_obs"][:, t][ra]), (name, t)
+                assert np.array_equal(got[~ra], g["obs"][:, t][~ra]), (name, t)          # untouched outside the mask
+            else:
+                post.reset(mask=ra)
+    assert np.array_equal(post.get_streams(), g["rng_end"])
+    post.close()
+
+
+@pytest.mark.parametrize("kind,rng", [("discrete", "numpy"), ("continuous", "numpy"), ("image", "numpy"),
+                                      ("discrete", "philox"), ("continuous", "philox"), ("image", "philox")])
+def test_post_fused_steps_vs_oracle_at_scale(kind, rng):
+    """4 096 instances, K = 24 fused steps in one call (+ a second call: state carried), random inner-env
+    outputs incl. done steps with same-step autoreset of the buffer; every 37th instance against the oracle."""
+    from mdp_playground_amd.post import VectorPostProcessor
+    from oracle import oracle as ora
+    N, K = 4096, 24
+    r = np.random.default_rng(5)
+    cfg = dict(state_space_type="continuous" if kind == "continuous" else "discrete", delay=5, reward_noise=0.3,
+               reward_scale=1.5, reward_shift=0.25, term_state_reward=-3.0, seed=77)
+    okw = dict(state_space_type=cfg["state_space_type"], delay=5, reward_noise=0.3, reward_scale=1.5, reward_shift=0.25,
+               term_state_reward=-3.0)
+    args = {}
+    if kind == "continuous":
+        cfg["transition_noise"] = 0.2
+        args = dict(obs_shape=(7,), obs_dtype=np.float32)
+        okw.update(transition_noise=0.2, obs_dim=7, obs_dtype=np.float32)
+        base_obs = r.normal(size=(2, K, N, 7)).astype(np.float32)
+    elif kind == "image":
+        cfg.update(image_transforms="shift", image_padding=5, image_sh_quant=3, transition_noise=0.3)
+        args = dict(obs_shape=(10, 10, 3), n_actions=5)
+        okw.update(transition_noise=0.3, n_actions=5, image_shape=(10, 10, 3), image_transforms="shift", image_padding=5,
+                   image_sh_quant=3)
+        base_obs = r.integers(0, 256, size=(2, K, N, 10, 10, 3)).astype(np.uint8)
+    else:
+        cfg["transition_noise"] = 0.3
+        args = dict(n_actions=5)
+        okw.update(transition_noise=0.3, n_actions=5)
+        base_obs = None
+    post = VectorPostProcessor(N, rng=rng, autoreset=True, env_id_offset=1000, **args, **cfg)
+    dev = post.device
+    base_rew = r.integers(-8, 9, size=(2, K, N)) / 4.0
+    base_done = r.random((2, K, N)) < 0.08
+    acts = r.integers(0, 5, size=(N,)).astype(np.int32)
+    start = post.get_streams() if rng == "numpy" else None
+    if kind == "image":
+        first = r.integers(0, 256, size=(N, 10, 10, 3)).astype(np.uint8)
+        ob0 = post.reset(torch.as_tensor(first, device=dev)).cpu().numpy()
+    else:
+        post.reset()
+    a_env = post.actions(torch.as_tensor(acts, device=dev)).cpu().numpy() if kind != "continuous" else None
+    outs = []
+    for c in range(2):
+        oi = None if base_obs is None else torch.as_tensor(base_obs[c], device=dev)
+        o, rw = post.step(oi, torch.as_tensor(base_rew[c], device=dev), torch.as_tensor(base_done[c], device=dev))
+        outs.append((None if o is None else o.cpu().numpy(), rw.cpu().numpy()))
+    end = post.get_streams() if rng == "numpy" else None
+    for i in range(0, N, 37):
+        o = ora.PostOracle(**okw)
+        if rng == "numpy":
+            o.set_rng(start[i])
+        else:
+            o.set_philox(77, 1000 + i)
+        if kind == "image":
+            assert np.array_equal(o.reset(first[i]), ob0[i]), i
+        else:
+            o.reset()
+        if kind != "continuous":
+            assert o.action(int(acts[i])) == int(a_env[i]), i
+        for c in range(2):
+            for k in range(K):
+                eo, er = o.step(None if base_obs is None else base_obs[c, k, i], base_rew[c, k, i], base_done[c, k, i])
+                if base_obs is not None:
+                    assert np.array_equal(eo, outs[c][0][k, i]), (i, c, k)
+                assert np.float64(er).view(np.uint64) == outs[c][1][k, i].view(np.uint64), (i, c, k)
+                if base_done[c, k, i]:
+                    import ctypes
+                    ora.lib().ora_p_reset(o.h, None, None) if kind != "image" else _oracle_ring_reset(o)
+        if rng == "numpy":
+            assert np.array_equal(o.get_rng(), end[i]), i
+    post.close()
+
+
+def _oracle_ring_reset(o):
+    """autoreset=True refills the buffer after a done step without drawing an image (the caller resets its
+    observations itself): the oracle's reset() minus its image draw."""
+    w = o.get_rng()
+    o.reset(np.zeros(o.shape, np.uint8))
+    o.set_rng(w)
+
+
+def test_post_chained_behind_the_vector_env():
+    """RLToyVectorEnv (the reference's RLToyEnv, batched) -> VectorPostProcessor (its GymEnvWrapper): both on
+    the device, no host round trip; sanity of shapes / dtypes and of the delay line across the chain."""
+    from mdp_playground_amd import RLToyVectorEnv
+    from mdp_playground_amd.post import VectorPostProcessor
+    N = 512
+    env = RLToyVectorEnv(num_envs=N, autoreset="disabled", state_space_type="discrete", action_space_type="discrete",
+                         state_space_size=8, action_space_size=8, delay=0, sequence_length=1, reward_density=0.5, seed=3)
+    post = VectorPostProcessor(N, n_actions=8, state_space_type="discrete", delay=2, reward_scale=2.0, seed=11)
+    post.reset()
+    rews = []
+    for t in range(12):
+        a = torch.randint(0, 8, (N,), device=env.device, dtype=torch.int32)
+        obs, r, term, trunc, _ = env.step(post.actions(a))
+        _, r2 = post.step(None, r, torch.zeros_like(term))
+        rews.append((r.double().cpu().numpy(), r2.cpu().numpy()))
+    for t in range(2, 12):
+        assert np.array_equal(rews[t][1], rews[t - 2][0] * 2.0)
+    assert (rews[0][1] == 0).all() and (rews[1][1] == 0).all()
+    env.close(); post.close()
