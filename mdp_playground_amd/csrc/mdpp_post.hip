@@ -28,7 +28,8 @@ struct mdpp_post {
     int device;
     std::string err;
     uint64_t tick, reset_tick;
-    void *d_rng_s, *d_rng_inc, *d_half, *d_ring, *d_head, *d_noise_cdf, *d_shift;
+    void *d_rng_s, *d_rng_inc, *d_half, *d_ring, *d_head, *d_noise_cdf, *d_shift, *d_xyc;
+    int num_cus;
     size_t shift_cap;           // image placements held by d_shift (K * N of the largest call so far)
     bool seeded;
 };
@@ -52,18 +53,6 @@ struct PostArgs {
     const double *noise_cdf;    // [n][n]
     short2 *place;              // [K][N] (top, left) of the image inside the canvas
 };
-
-// numpy's pairwise summation (loops_utils.h.src), n <= 128: what np.sum does to the flushed buffer
-__device__ double post_pairwise_sum(const double *a, int n) {
-    if (n < 8) { double res = 0.; for (int i = 0; i < n; i++) res += a[i]; return res; }
-    double r[8];
-    for (int j = 0; j < 8; j++) r[j] = a[j];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += a[i];
-    return res;
-}
 
 // get_transformed_image's placement (:560-611): draws the shift, returns (top, left)
 template <class G>
@@ -96,13 +85,21 @@ __global__ __launch_bounds__(kBlock) void k_post_actions(PostArgs a, const int32
     if constexpr (!PHILOX) g.store(a.rng_s, i);
 }
 
-template <bool PHILOX>
+// LDSRING: the instance's reward FIFO lives in LDS for the call (delay <= kPostLdsDelay: [delay][256] doubles),
+// loaded once and written back at the end -- otherwise every step is a dependent HBM read-modify-write of its
+// slot, and with one wave per SIMD that round trip IS the step time (2.1 us per step measured).
+constexpr int kPostLdsDelay = 16;
+constexpr int kPostPre = 8;              // reward / done inputs in flight per lane
+constexpr int kPostUB = 8;               // k_post_image_lds: loads in flight per lane
+
+template <bool PHILOX, bool LDSRING>
 __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const void *__restrict__ obs_in,
                                                       const double *__restrict__ reward_in,
                                                       const uint8_t *__restrict__ done_in, void *__restrict__ obs_out,
                                                       double *__restrict__ reward_out) {
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
+    __shared__ double s_ring[LDSRING ? kPostLdsDelay * kBlock : 1];
     const bool normals = !PHILOX && ((a.continuous && a.has_p) || a.has_r);
     if (normals) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
     const ZigLds zig{s_ki, s_wi, s_fi};
@@ -116,8 +113,30 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
         if (draws) { g.load(a.rng_s, a.rng_inc, i); const uint2 hh = a.half[i]; hf = Half32{hh.x, hh.y}; }
     }
     uint32_t head = a.delay > 0 ? a.head[i] : 0u;
-    for (int k = 0; k < K; k++) {
+    // ring slot j of this lane: LDS column (conflict-free: consecutive lanes, consecutive banks) or HBM
+    double *ringp = LDSRING ? s_ring + threadIdx.x : a.ring + i;
+    const size_t rstride = LDSRING ? (size_t)kBlock : (size_t)N;
+    if (LDSRING) for (int j = 0; j < a.delay; j++) s_ring[j * kBlock + threadIdx.x] = a.ring[(size_t)j * N + i];
+    double pre_r[kPostPre];
+    uint8_t pre_d[kPostPre];
+#pragma unroll
+    for (int u = 0; u < kPostPre; u++) {
+        const long oo = (long)(u < K ? u : K - 1) * N + i;
+        pre_r[u] = reward_in[oo]; pre_d[u] = done_in[oo];
+    }
+    for (int k0 = 0; k0 < K; k0 += kPostPre) {
+#pragma unroll
+      for (int u = 0; u < kPostPre; u++) {
+        const int k = k0 + u;
+        if (k >= K) break;
         const long o = (long)k * N + i;
+        double reward = pre_r[u];
+        const bool done = pre_d[u] != 0;
+        {
+            const int kn = k + kPostPre;
+            const long oo = (long)(kn < K ? kn : K - 1) * N + i;
+            pre_r[u] = reward_in[oo]; pre_d[u] = done_in[oo];
+        }
         if constexpr (PHILOX) {
             g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.tick + (uint64_t)k, kPhiloxPostStep);
             hf = Half32{0, 0};
@@ -130,22 +149,35 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
             }
         }
         if (a.image) a.place[o] = post_place(a, g, hf);                      // :404-405 (pixels: k_post_image)
-        double reward = reward_in[o];
-        const bool done = done_in[o] != 0;
         if (done) {                                                           // :407-414
-            double tmp[128];
-            for (int j = 0; j < a.delay; j++) {
-                const uint32_t slot = head + (uint32_t)j < (uint32_t)a.delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)a.delay;
-                tmp[j] = a.ring[(size_t)slot * N + i] * a.scale + a.shift;
+            // np.sum(buffer * scale + shift) in numpy's pairwise order, read straight from the FIFO (a private
+            // array here would live in scratch memory, and some lane of a wave is done on most steps)
+            auto val = [&](int j) __attribute__((always_inline)) -> double {
+                const uint32_t sl = head + (uint32_t)j < (uint32_t)a.delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)a.delay;
+                return ringp[(size_t)sl * rstride] * a.scale + a.shift;
+            };
+            double sum;
+            if (a.delay < 8) {
+                sum = 0.;
+                for (int j = 0; j < a.delay; j++) sum += val(j);
+            } else {
+                double r0 = val(0), r1 = val(1), r2 = val(2), r3 = val(3), r4 = val(4), r5 = val(5), r6 = val(6), r7 = val(7);
+                int j;
+                for (j = 8; j < a.delay - (a.delay % 8); j += 8) {
+                    r0 += val(j); r1 += val(j + 1); r2 += val(j + 2); r3 += val(j + 3);
+                    r4 += val(j + 4); r5 += val(j + 5); r6 += val(j + 6); r7 += val(j + 7);
+                }
+                sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                for (; j < a.delay; j++) sum += val(j);
             }
-            reward += post_pairwise_sum(tmp, a.delay);
+            reward += sum;
             reward += a.term * a.scale;
             if (a.autoreset) {                                                // the caller's env reset itself: reset(), :456
-                for (int j = 0; j < a.delay; j++) a.ring[(size_t)j * N + i] = 0.0;
+                for (int j = 0; j < a.delay; j++) ringp[(size_t)j * rstride] = 0.0;
                 head = 0;
             }
         } else if (a.delay > 0) {                                             // :415-420
-            double *slot = a.ring + (size_t)head * N + i;
+            double *slot = ringp + (size_t)head * rstride;
             const double out = *slot;
             *slot = reward;
             reward = out;
@@ -156,7 +188,9 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
         reward *= a.scale;
         reward += a.shift;
         reward_out[o] = reward;
+      }
     }
+    if (LDSRING) for (int j = 0; j < a.delay; j++) a.ring[(size_t)j * N + i] = s_ring[j * kBlock + threadIdx.x];
     if (a.delay > 0) a.head[i] = head;
     if constexpr (!PHILOX) {
         if (draws) { g.store(a.rng_s, i); a.half[i] = make_uint2(hf.has32, hf.u32); }
@@ -182,8 +216,83 @@ __global__ __launch_bounds__(kBlock) void k_post_reset(PostArgs a, uint64_t rese
     }
 }
 
-// canvas[x][y][c] = image[y - top][x - left][c] inside the placed image, else 0: one dword of the canvas
-// per lane, consecutive lanes consecutive dwords (1 KiB per wave store); M images of in_bytes / out_bytes
+// canvas[x][y][c] = image[y - top][x - left][c] inside the placed image, else 0.  One workgroup per image:
+// the source image is staged in LDS TRANSPOSED ([sx][sy][c], rows at an odd dword pitch: byte scatter on the
+// way in, 21 K byte writes for 84 x 84 x 3), so that a canvas row x is one LDS row shifted by top * C bytes
+// between two runs of zeros: every canvas dword is two LDS dwords through a byte funnel shift
+// (v_alignbyte) plus a range mask -- about 20 instructions, where gathering its four bytes one by one took
+// about 100 and made the kernel issue-bound at 0.2 of the HBM roofline.  Stores go front to back, 1 KiB
+// contiguous per wave instruction.  Which (x, byte of the row) a canvas dword starts at is the same for every
+// image of a handle: table `xr` (x << 16 | row byte), made once at create().
+__global__ __launch_bounds__(kBlock) void k_post_image_lds(PostArgs a, long M, const short2 *__restrict__ place,
+                                                           const uint32_t *__restrict__ xr, const uint8_t *__restrict__ in,
+                                                           uint8_t *__restrict__ out) {
+    extern __shared__ __align__(16) uint8_t s_img[];
+    const int tot_w = a.W + 2 * a.pad, tot_h = a.H + 2 * a.pad, C = a.C;
+    const long out_bytes = (long)tot_w * tot_h * C, in_bytes = (long)a.H * a.W * C;
+    const int dwords = (int)(out_bytes / 4), in_dw = (int)(in_bytes / 4);
+    const int colb = a.H * C;                           // bytes of one transposed row (one source column)
+    const int pitch = (((colb + 3) / 4 + 2) | 1) * 4;   // odd dword pitch, one spare dword behind the data (the funnel reads it)
+    for (long img = blockIdx.x; img < M; img += gridDim.x) {
+        const short2 pl = place[img];
+        if (pl.x == -32768) continue;                  // (wave-uniform: one image per workgroup)
+        const uint32_t *src = (const uint32_t *)(in + img * in_bytes);
+        __syncthreads();                               // the previous image's readers are done
+        // (kPostUB loads in flight per lane: one at a time, the loop is a chain of HBM round trips -- 50 us per image)
+        for (int q0 = threadIdx.x; q0 < in_dw; q0 += kBlock * kPostUB) {
+            uint32_t v[kPostUB], m[kPostUB];
+#pragma unroll
+            for (int u = 0; u < kPostUB; u++) {
+                const int q = q0 + u * kBlock;
+                v[u] = q < in_dw ? src[q] : 0u;
+                m[u] = q < in_dw ? xr[dwords + q] : 0u; // (sx << 18 | sy << 4 | c) of the source dword's first byte
+            }
+#pragma unroll
+            for (int u = 0; u < kPostUB; u++) {
+                if (q0 + u * kBlock >= in_dw) break;
+                const int sy = (int)((m[u] >> 4) & 0x3FFFu);
+                int sx = (int)(m[u] >> 18), c = (int)(m[u] & 15u);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    s_img[sx * pitch + sy * C + c] = (uint8_t)(v[u] >> (8 * j));
+                    c += 1;
+                    if (c == C) { c = 0; sx += 1; }    // (a dword never crosses a source row: row_bytes % 4 == 0)
+                }
+            }
+        }
+        // the spare dword behind every transposed row reads as zero
+        for (int r = threadIdx.x; r < a.W; r += kBlock) {
+            *(uint32_t *)(s_img + r * pitch + ((colb + 3) & ~3)) = 0u;
+            if (colb & 3) for (int t = colb; t < ((colb + 3) & ~3); t++) s_img[r * pitch + t] = 0;
+        }
+        __syncthreads();
+        uint32_t *dst = (uint32_t *)(out + img * out_bytes);
+        const int shift_b = pl.x * C;                  // canvas row byte of the image's first byte
+        for (int q0 = threadIdx.x; q0 < dwords; q0 += kBlock * kPostUB) {
+            uint32_t t[kPostUB];
+#pragma unroll
+            for (int u = 0; u < kPostUB; u++) t[u] = q0 + u * kBlock < dwords ? xr[q0 + u * kBlock] : 0u;
+#pragma unroll
+            for (int u = 0; u < kPostUB; u++) {
+                const int q = q0 + u * kBlock;
+                if (q >= dwords) break;
+                const int sx = (int)(t[u] >> 16) - pl.y, rel = (int)(t[u] & 0xFFFFu) - shift_b;   // byte of the transposed row this dword starts at
+                uint32_t v = 0;
+                if (sx >= 0 && sx < a.W && rel > -4 && rel < colb) {
+                    const int base = rel >> 2;          // (arithmetic shift: -1 for rel in -3..-1)
+                    const uint8_t *rowp = s_img + sx * pitch;
+                    const uint32_t lo = base >= 0 ? *(const uint32_t *)(rowp + base * 4) : 0u;
+                    const uint32_t hi = *(const uint32_t *)(rowp + (base + 1) * 4);
+                    v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(rel & 3));
+                    // bytes before the image (rel + j < 0) are zero through `lo`; bytes behind it through the zeroed spare
+                }
+                dst[q] = v;
+            }
+        }
+    }
+}
+
+// general form (any size): one dword of the canvas per lane, source bytes gathered from HBM / L2
 __global__ __launch_bounds__(kBlock) void k_post_image(PostArgs a, long M, const short2 *__restrict__ place,
                                                        const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
     const int tot_w = a.W + 2 * a.pad, tot_h = a.H + 2 * a.pad, C = a.C;
@@ -249,6 +358,26 @@ int ensure_place(mdpp_post *h, size_t count) {
     return MDPP_OK;
 }
 
+int launch_post_image(mdpp_post *h, const PostArgs &a, long M, const void *in, void *out, hipStream_t s) {
+    if (h->d_xyc) {
+        const size_t lds = ((size_t)a.W * ((((a.H * a.C + 3) / 4 + 2) | 1) * 4) + 15) & ~(size_t)15;
+        static size_t allowed = 48 * 1024;
+        if (lds > allowed) {
+            (void)hipFuncSetAttribute((const void *)k_post_image_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allowed = lds;
+        }
+        const long resident = (long)h->num_cus * (lds > 40 * 1024 ? 2 : lds > 24 * 1024 ? 4 : 6);
+        hipLaunchKernelGGL(k_post_image_lds, dim3((unsigned)(M < resident ? M : resident)), dim3(kBlock), lds, s, a, M, a.place,
+                           (const uint32_t *)h->d_xyc, (const uint8_t *)in, (uint8_t *)out);
+    } else {
+        const long dwords = (long)(a.W + 2 * a.pad) * (a.H + 2 * a.pad) * a.C / 4;
+        const long blocks = (M * dwords + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_post_image, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s, a, M, a.place,
+                           (const uint8_t *)in, (uint8_t *)out);
+    }
+    return MDPP_OK;
+}
+
 int post_ready(mdpp_post *h, const char *what) {
     if (h->cfg.rng_mode == MDPP_RNG_NUMPY_PCG64 && !h->seeded) return pfail(h, MDPP_ESTATE, std::string(what) + ": stream not seeded");
     return MDPP_OK;
@@ -261,7 +390,7 @@ extern "C" const char *mdpp_post_last_error(const mdpp_post *h) { return h ? h->
 extern "C" void mdpp_post_destroy(mdpp_post *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    for (void *p : {h->d_rng_s, h->d_rng_inc, h->d_half, h->d_ring, h->d_head, h->d_noise_cdf, h->d_shift})
+    for (void *p : {h->d_rng_s, h->d_rng_inc, h->d_half, h->d_ring, h->d_head, h->d_noise_cdf, h->d_shift, h->d_xyc})
         if (p) (void)hipFree(p);
     delete h;
 }
@@ -292,7 +421,9 @@ extern "C" int mdpp_post_create(const mdpp_post_config *cfg, int device, mdpp_po
     if (e != hipSuccess) return pfail(nullptr, MDPP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     mdpp_post *h = new mdpp_post();
     h->cfg = *cfg; h->device = device; h->tick = 0; h->reset_tick = 0; h->seeded = false;
-    h->d_rng_s = h->d_rng_inc = h->d_half = h->d_ring = h->d_head = h->d_noise_cdf = h->d_shift = nullptr;
+    h->d_rng_s = h->d_rng_inc = h->d_half = h->d_ring = h->d_head = h->d_noise_cdf = h->d_shift = h->d_xyc = nullptr;
+    h->num_cus = 256;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->num_cus = v; }
     h->shift_cap = 0;
     const size_t N = (size_t)cfg->num_envs;
     auto alloc0 = [&](void **p, size_t bytes) {
@@ -318,6 +449,26 @@ extern "C" int mdpp_post_create(const mdpp_post_config *cfg, int device, mdpp_po
         }
         ok = hipMalloc(&h->d_noise_cdf, cdf.size() * 8) == hipSuccess &&
              hipMemcpy(h->d_noise_cdf, cdf.data(), cdf.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok && cfg->image && (cfg->img_w * cfg->img_c) % 4 == 0 && ((cfg->img_h + 2 * cfg->img_pad) * cfg->img_c) % 4 == 0 &&
+        (size_t)cfg->img_w * ((((cfg->img_h * cfg->img_c + 3) / 4 + 2) | 1) * 4) <= 60 * 1024 &&
+        (cfg->img_h + 2 * cfg->img_pad) * cfg->img_c < 65536 && cfg->img_w + 2 * cfg->img_pad < 16384 && cfg->img_c <= 16) {
+        // where every canvas dword starts: (x << 16 | byte within the canvas row of th * C bytes), canvas [x][y][c].
+        // (a dword may run over into the next row x + 1 only if th * C % 4 != 0: excluded below)
+        const int tw = cfg->img_w + 2 * cfg->img_pad, th = cfg->img_h + 2 * cfg->img_pad, C = cfg->img_c;
+        const size_t ndw = (size_t)tw * th * C / 4, sdw = (size_t)cfg->img_h * cfg->img_w * C / 4;
+        std::vector<uint32_t> xyc(ndw + sdw);
+        for (size_t q = 0; q < ndw; q++) {
+            const size_t b = 4 * q;
+            xyc[q] = ((uint32_t)(b / ((size_t)th * C)) << 16) | (uint32_t)(b % ((size_t)th * C));
+        }
+        // ... followed by where every SOURCE dword starts: (sx << 18 | sy << 4 | c), source [sy][sx][c]
+        for (size_t q = 0; q < sdw; q++) {
+            const size_t b = 4 * q, sy = b / ((size_t)cfg->img_w * C), rb = b % ((size_t)cfg->img_w * C);
+            xyc[ndw + q] = ((uint32_t)(rb / C) << 18) | ((uint32_t)sy << 4) | (uint32_t)(rb % C);
+        }
+        ok = hipMalloc(&h->d_xyc, xyc.size() * 4) == hipSuccess &&
+             hipMemcpy(h->d_xyc, xyc.data(), xyc.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { g_post_create_err = "mdpp_post_create: device allocation failed"; mdpp_post_destroy(h); return MDPP_ENOMEM; }
     *out = h;
@@ -390,12 +541,7 @@ extern "C" int mdpp_post_reset(mdpp_post *h, const uint8_t *mask_dev, const void
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox) hipLaunchKernelGGL(k_post_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask_dev);
     else hipLaunchKernelGGL(k_post_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask_dev);
-    if (h->cfg.image) {
-        const long dwords = (long)(a.W + 2 * a.pad) * (a.H + 2 * a.pad) * a.C / 4;
-        const long blocks = ((long)a.N * dwords + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_post_image, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s, a, (long)a.N,
-                           a.place, (const uint8_t *)obs_in_dev, (uint8_t *)obs_out_dev);
-    }
+    if (h->cfg.image) launch_post_image(h, a, (long)a.N, obs_in_dev, obs_out_dev, s);
     PHIP(h, hipGetLastError());
     h->reset_tick += 1;
     return MDPP_OK;
@@ -433,15 +579,13 @@ extern "C" int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, con
     if (h->cfg.image) { rc = ensure_place(h, (size_t)K * h->cfg.num_envs); if (rc) return rc; }
     PostArgs a = make_args(h);
     const int grid = (a.N + kBlock - 1) / kBlock;
-    if (a.philox) hipLaunchKernelGGL(k_post_step<true>, dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, reward_in_dev, done_dev, obs_out_dev, reward_out_dev);
-    else hipLaunchKernelGGL(k_post_step<false>, dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, reward_in_dev, done_dev, obs_out_dev, reward_out_dev);
-    if (h->cfg.image) {
-        const long M = (long)K * a.N;
-        const long dwords = (long)(a.W + 2 * a.pad) * (a.H + 2 * a.pad) * a.C / 4;
-        const long blocks = (M * dwords + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_post_image, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(kBlock), 0, s, a, M, a.place,
-                           (const uint8_t *)obs_in_dev, (uint8_t *)obs_out_dev);
-    }
+    const bool ldsring = a.delay >= 1 && a.delay <= kPostLdsDelay;
+#define MDPP_POST_LAUNCH(PH, LR) hipLaunchKernelGGL((k_post_step<PH, LR>), dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, \
+                                                    reward_in_dev, done_dev, obs_out_dev, reward_out_dev)
+    if (a.philox) { if (ldsring) MDPP_POST_LAUNCH(true, true); else MDPP_POST_LAUNCH(true, false); }
+    else { if (ldsring) MDPP_POST_LAUNCH(false, true); else MDPP_POST_LAUNCH(false, false); }
+#undef MDPP_POST_LAUNCH
+    if (h->cfg.image) launch_post_image(h, a, (long)K * a.N, obs_in_dev, obs_out_dev, s);
     PHIP(h, hipGetLastError());
     h->tick += (uint64_t)K;
     return MDPP_OK;
