@@ -46,6 +46,9 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
+#ifndef MDPP_CONSUMER_PRIO
+#define MDPP_CONSUMER_PRIO 2
+#endif
 #ifndef MDPP_PHILOX_PRODUCERS
 #define MDPP_PHILOX_PRODUCERS 2
 #endif
@@ -271,6 +274,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     }
     constexpr int kCAhead = NOISE ? kCAheadNoise : kCAheadQuiet;
     constexpr int V = (D == 2) ? 1 : D / 4;      // 16-byte pieces per action / observation row
+    // Several producers per consumer: the consumer wave is the critical path (one dependent chain per step, while
+    // the producers have a whole step of slack each), so its instructions go first whenever they are ready
+    if (HELPER && NPROD > 1) __builtin_amdgcn_s_setprio(MDPP_CONSUMER_PRIO);
 
     float sd[ORDER + 1][D], cur[D];
 #pragma unroll
@@ -411,6 +417,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
 #pragma unroll
             for (int d = 0; d < D; d++) nacc[d] = act[d] / a.inertia32;
         }
+        // (the whole wave's actions admitted -- the normal case: no per-element selects; otherwise a lane whose
+        // action was rejected keeps every derivative, :1671-1679)
+        auto integrate = [&](auto all_admitted) __attribute__((always_inline)) {
+        constexpr bool ALL = decltype(all_admitted)::value;
 #pragma unroll
         for (int ii = 0; ii < ORDER; ii++) {
 #pragma unroll
@@ -431,14 +441,16 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                     else if ((a.fact_pow2_mask >> (j + 1)) & 1u) acc = (float)((double)acc + (double)prod * a.inv_fact[j + 1]);
                     else acc = (float)((double)acc + (double)prod / a.fact[j + 1]);
                 }
-                sd[ii][d] = ok ? acc : sd[ii][d];        // rejected action: "stay", nothing moves
+                sd[ii][d] = (ALL || ok) ? acc : sd[ii][d];        // rejected action: "stay", nothing moves
             }
         }
 #pragma unroll
-        for (int d = 0; d < D; d++) sd[ORDER][d] = ok ? nacc[d] : sd[ORDER][d];
-        status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+        for (int d = 0; d < D; d++) sd[ORDER][d] = (ALL || ok) ? nacc[d] : sd[ORDER][d];
 #pragma unroll
-        for (int d = 0; d < D; d++) nxt[d] = ok ? sd[0][d] : cur[d];                  // "stay", :1671
+        for (int d = 0; d < D; d++) nxt[d] = (ALL || ok) ? sd[0][d] : cur[d];                  // "stay", :1671
+        };
+        if (all_ok) integrate(std::true_type{}); else integrate(std::false_type{});
+        status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
         // ---- C3
         if (NOISE && a.has_p_noise) {           // (the wave-uniform test outside the per-dimension loop)
 #pragma unroll
