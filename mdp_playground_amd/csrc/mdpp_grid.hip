@@ -18,6 +18,8 @@
 // flags}; PCG64 streams as ulonglong2 per env; the action stream also carries numpy's buffered
 // 32-bit half.  Algorithmic bytes per env step of a fused rollout: 4 G (actions) + 8 G (int64
 // observation) + 4 (reward) + 2 (flags) = 30 B for a plain 2-D grid.
+#include <type_traits>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 #include <cstdlib>
@@ -245,7 +247,9 @@ constexpr int kGRsrc = 0x00020000;
 // the action is re-drawn from the action space's stream until it differs, :1733-1749) and reward
 // noise (a normal from the env stream, :1980); reset() draws from the feature space's stream, so
 // the start-cell queue is untouched by either.
-template <bool OBS64, bool G4, bool DENSE, bool PN, bool RN>
+// PH: Philox streams -- every step re-keys its three generators by (seed, global env id, tick, stream), start
+// cells are drawn when an episode ends (no queue, nothing to un-draw), nothing is loaded from or stored to HBM.
+template <bool OBS64, bool G4, bool DENSE, bool PN, bool RN, bool PH = false>
 __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K, const int32_t *__restrict__ actions,
                                                               void *__restrict__ obs, float *__restrict__ reward,
                                                               uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
@@ -254,23 +258,28 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int G = G4 ? 4 : 2;
-    __shared__ uint64_t s_ki[RN ? 256 : 1];
-    __shared__ double s_wi[RN ? 256 : 1], s_fi[RN ? 256 : 1];
-    if (RN) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
+    constexpr bool ZIG = RN && !PH;
+    __shared__ uint64_t s_ki[ZIG ? 256 : 1];
+    __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
+    if (ZIG) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
     const ZigLds zig{s_ki, s_wi, s_fi};
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= (uint32_t)a.N) return;
     const uint32_t N = (uint32_t)a.N;
     const uint4 st = a.state[i];
     uint32_t cells = st.x, steps = st.y, flags = st.z, status = 0;   // one byte per dimension
-    Pcg64 sp, env, actg;
+    typedef typename std::conditional<PH, Philox, Pcg64>::type Gen;
+    Gen sp, env, actg;
     Half32 acth{0, 0};
-    sp.load(a.sp_s, a.sp_inc, i);
-    if (PN || RN) env.load(a.env_s, a.env_inc, i);
-    if (PN) {
-        actg.load(a.act_s, a.act_inc, i);
-        const uint2 hh = a.act_half[i];
-        acth = Half32{hh.x, hh.y};
+    const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)
+    if constexpr (!PH) {
+        sp.load(a.sp_s, a.sp_inc, i);
+        if (PN || RN) env.load(a.env_s, a.env_inc, i);
+        if (PN) {
+            actg.load(a.act_s, a.act_inc, i);
+            const uint2 hh = a.act_half[i];
+            acth = Half32{hh.x, hh.y};
+        }
     }
     uint32_t queue[kGQ];                          // queued start cells, queue[0] next; qn of them valid
 #pragma unroll
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
             }
         }
     };
-    if (a.autoreset) refill();
+    if (a.autoreset && !PH) refill();
 
     const uint32_t total = (uint32_t)K * N;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(G * 4), kGRsrc);
@@ -344,7 +353,13 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
     auto step = [&](const int k, i32x4 act) __attribute__((always_inline)) {
         // every lane must hold a start cell before the step may end its episode; the refill tops
         // all lanes up to kGQ, so this branch is taken once in several dozen steps
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) refill();
+        if constexpr (PH) {
+            const uint64_t tick = a.ptick + (uint64_t)k;
+            env.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
+            sp.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
+            actg.init(a.philox_seed, genv, tick, kPhiloxActionStream);
+            acth = Half32{0, 0};
+        } else if (__builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) refill();
         // GridActionSpace.contains: every entry in {-1, 0, 1}, at most one non-zero
         const uint32_t a0 = (uint32_t)(act.x + 1), a1 = (uint32_t)(act.y + 1), a2 = (uint32_t)(act.z + 1), a3 = (uint32_t)(act.w + 1);
         const int nz = (act.x != 0) + (act.y != 0) + (G4 ? (act.z != 0) + (act.w != 0) : 0);
@@ -391,6 +406,12 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
             if (need) put_cells(r_fin, so, nc);
         }
+        if constexpr (PH) {                       // reset(): drawn now from this step's feature-space stream
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                if (need) queue[0] = draw_cell();
+                qn = need ? 1u : qn;
+            }
+        }
         // pop the next queued start cell where the episode ended
         nc = need ? queue[0] : nc;
 #pragma unroll
@@ -420,18 +441,20 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         for (int u = 1; u < kPre; u++) act = (k - nfull * kPre == u) ? pre[u] : act;
         step(k, act);
     }
-    // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128), G uniforms per queued cell
-    for (uint32_t q = qn * (uint32_t)G; q > 0; q--) {
-        const uint64_t lo = sp.s_lo - sp.inc_lo;
-        const uint64_t hi = sp.s_hi - sp.inc_hi - (sp.s_lo < sp.inc_lo ? 1ULL : 0ULL);
-        sp.s_lo = lo * a.minv_lo;
-        sp.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
-    }
-    sp.store(a.sp_s, i);
-    if (PN || RN) env.store(a.env_s, i);
-    if (PN) {
-        actg.store(a.act_s, i);
-        a.act_half[i] = make_uint2(acth.has32, acth.u32);
+    if constexpr (!PH) {
+        // un-draw what was not used: s_prev = (s - inc) * M^-1 (mod 2^128), G uniforms per queued cell
+        for (uint32_t q = qn * (uint32_t)G; q > 0; q--) {
+            const uint64_t lo = sp.s_lo - sp.inc_lo;
+            const uint64_t hi = sp.s_hi - sp.inc_hi - (sp.s_lo < sp.inc_lo ? 1ULL : 0ULL);
+            sp.s_lo = lo * a.minv_lo;
+            sp.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+        }
+        sp.store(a.sp_s, i);
+        if (PN || RN) env.store(a.env_s, i);
+        if (PN) {
+            actg.store(a.act_s, i);
+            a.act_half[i] = make_uint2(acth.has32, acth.u32);
+        }
     }
     a.state[i] = make_uint4(cells, steps, flags, 0u);
     if (status) atomicOr(&a.status[i], status);
@@ -445,17 +468,22 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)
-    if (!a.philox && a.autoreset != MDPP_AUTORESET_NEXT_STEP && !(noise && (a.opts & MDPP_OPT_NO_GFAST_NOISE)) &&
-        !(a.opts & MDPP_OPT_NO_GFAST) &&
+    if (!(a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) && a.autoreset != MDPP_AUTORESET_NEXT_STEP &&
+        !(noise && (a.opts & MDPP_OPT_NO_GFAST_NOISE)) && !(a.opts & MDPP_OPT_NO_GFAST) &&
         (unsigned long long)K * a.N * a.G * 8ULL < (1ULL << 32)) {
         const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
         if (name_out) {
-            snprintf(name_out, kNameLen, "k_grid_rollout_fast<OBS64=%d,G4=%d,DENSE=%d,PN=%d,RN=%d>", !a.obs_i32, a.G == 4,
-                     a.make_denser != 0, pn, rn);
+            snprintf(name_out, kNameLen, "k_grid_rollout_fast<OBS64=%d,G4=%d,DENSE=%d,PN=%d,RN=%d,PHILOX=%d>", !a.obs_i32, a.G == 4,
+                     a.make_denser != 0, pn, rn, a.philox != 0);
             return MDPP_OK;
         }
-#define MDPP_GF_LAUNCH(O64, G4, DN, PN_, RN_) hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN, PN_, RN_>), dim3(grid), dim3(kBlock), \
-                                                                 0, s, a, K, actions, obs, reward, term, trunc, final_obs)
+#define MDPP_GF_LAUNCH(O64, G4, DN, PN_, RN_)                                                                                   \
+    do {                                                                                                                        \
+        if (a.philox) hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN, PN_, RN_, true>), dim3(grid), dim3(kBlock), 0, s, a, \
+                                         K, actions, obs, reward, term, trunc, final_obs);                                      \
+        else hipLaunchKernelGGL((k_grid_rollout_fast<O64, G4, DN, PN_, RN_, false>), dim3(grid), dim3(kBlock), 0, s, a, K,      \
+                                actions, obs, reward, term, trunc, final_obs);                                                  \
+    } while (0)
 #define MDPP_GF_NZ(O64, G4, DN)                                                  \
     do {                                                                         \
         if (pn && rn) MDPP_GF_LAUNCH(O64, G4, DN, true, true);                   \
