@@ -1524,9 +1524,10 @@ def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag
     over = dict(over)
     rng = over.pop("rng", "numpy")
     cfg = dict(wl["config"], **over)
+    cfg = {k: v for k, v in cfg.items() if v is not None}       # (None: drop the key from the workload's config)
     a = _venv(num_envs=N, autoreset="same_step", rng=rng, **cfg)
     b = _venv(num_envs=N, autoreset="same_step", rng=rng, **cfg)
-    b.set_kernel_options(flag)
+    b.set_kernel_options(*flag.split(","))
     assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F), (a.rollout_kernel_name(F), flag)
     wl2 = dict(wl, config=cfg)
     for j in range(3):

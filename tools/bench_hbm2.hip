@@ -1,0 +1,101 @@
+// Which part of the discrete rollout's write pattern costs what (GPU box):
+//   hipcc --offload-arch=gfx950 -O3 tools/bench_hbm2.hip -o gpurun_out/bench_hbm2 && ./gpurun_out/bench_hbm2
+// K rows of N envs; MODE bit 0: int64 obs, bit 1: float reward, bit 2: term bytes, bit 3: trunc bytes,
+// bit 4: the two byte arrays written as DWORDS by every 4th lane (bytes of 4 neighbours gathered by DPP).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+template <int MODE>
+__global__ void k(uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = (uint32_t)i;
+    for (int k = 0; k < K; k++) {
+        const size_t o = (size_t)k * N + i;
+        s = s * 1664525u + 1013904223u;
+        if (MODE & 1) obs[o] = s & 7u;
+        if (MODE & 2) rew[o] = (float)(s >> 31);
+        const uint32_t t = (s >> 8) & 1u, u = (s >> 9) & 1u;
+        if (MODE & 16) {
+            // gather the bytes of lanes 4j..4j+3 into lane 4j
+            uint32_t tt = t | (u << 16);
+            tt |= __shfl_down(tt, 1) << 8;          // lanes 0,2: bytes of (l, l+1)
+            const uint32_t hi = __shfl_down(tt, 2);
+            if ((threadIdx.x & 3) == 0) {
+                const uint32_t lo16 = (tt & 0xFFFFu) | ((hi & 0xFFFFu) << 16);
+                const uint32_t hi16 = (tt >> 16) | (hi & 0xFFFF0000u);
+                if (MODE & 4) *(uint32_t *)(term + o) = lo16;
+                if (MODE & 8) *(uint32_t *)(trunc + o) = hi16;
+            }
+        } else {
+            if (MODE & 4) term[o] = (uint8_t)t;
+            if (MODE & 8) trunc[o] = (uint8_t)u;
+        }
+    }
+}
+
+// the full pattern of a fused discrete rollout: int32 action reads prefetched 8 steps ahead + the four output rows
+template <int PRE>
+__global__ void k_full(const int32_t *act, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = (uint32_t)i;
+    int pre[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; u++) pre[u] = act[(size_t)u * N + i];
+    for (int k0 = 0; k0 < K; k0 += PRE) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) {
+            const int k = k0 + u;
+            const size_t o = (size_t)k * N + i;
+            const int a = pre[u];
+            const int kn = k + PRE < K ? k + PRE : K - 1;
+            pre[u] = act[(size_t)kn * N + i];
+            s = s * 1664525u + 1013904223u + (uint32_t)a;
+            obs[o] = s & 7u;
+            rew[o] = (float)(s >> 31);
+            term[o] = (uint8_t)((s >> 8) & 1u);
+            trunc[o] = (uint8_t)((s >> 9) & 1u);
+        }
+    }
+}
+
+template <int MODE>
+void run(const char *name, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, double bytes_per) {
+    const int N = 65536, K = 512, reps = 10;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int w = 0; w < 2; w++) {
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k<MODE>, dim3(N / 256), dim3(256), 0, 0, obs, rew, term, trunc, N, K);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("%-46s %5.1f B/env-step %8.1f GB/s  %7.1f us per 512-step launch\n", name, bytes_per,
+           bytes_per * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
+}
+
+int main() {
+    uint64_t *obs; float *rew; uint8_t *term, *trunc;
+    const size_t n = 65536ull * 512;
+    hipMalloc(&obs, n * 8); hipMalloc(&rew, n * 4); hipMalloc(&term, n); hipMalloc(&trunc, n);
+    run<1>("obs int64", obs, rew, term, trunc, 8);
+    run<3>("obs + reward", obs, rew, term, trunc, 12);
+    run<7>("obs + reward + term bytes", obs, rew, term, trunc, 13);
+    run<15>("obs + reward + term + trunc bytes", obs, rew, term, trunc, 14);
+    run<31>("obs + reward + flags as dwords of 4 lanes", obs, rew, term, trunc, 14);
+    {
+        int32_t *act; hipMalloc(&act, n * 4); hipMemset(act, 1, n * 4);
+        const int N = 65536, K = 512, reps = 10;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float ms = 0;
+        for (int w = 0; w < 2; w++) {
+            hipEventRecord(e0);
+            for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_full<8>, dim3(N / 256), dim3(256), 0, 0, act, obs, rew, term, trunc, N, K);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        }
+        printf("%-46s %5.1f B/env-step %8.1f GB/s  %7.1f us per 512-step launch\n", "actions (8 ahead) + all four outputs", 18.0,
+               18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
+    }
+    run<12>("term + trunc bytes only", obs, rew, term, trunc, 2);
+    run<28>("flags as dwords only", obs, rew, term, trunc, 2);
+    return 0;
+}
