@@ -25,8 +25,14 @@
 
 namespace mdpp {
 
-constexpr int kChunk = 8;          // steps between hand-off polls; also the action prefetch distance
-constexpr int kDepth = 32;         // E->O ring depth in steps (multiple of kChunk)
+#ifndef MDPP_PIPE_CHUNK
+#define MDPP_PIPE_CHUNK 8
+#endif
+#ifndef MDPP_PIPE_DEPTH
+#define MDPP_PIPE_DEPTH 32
+#endif
+constexpr int kChunk = MDPP_PIPE_CHUNK;   // steps between hand-off polls; also the action prefetch distance
+constexpr int kDepth = MDPP_PIPE_DEPTH;   // E->O ring depth in steps (multiple of kChunk)
 constexpr int kPRsrc = 0x00020000;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kStatusInternal = 0x80000000u;

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Build variants of k_discrete_rollout_pipe (macro knobs) and time them on the bench workload (GPU box).
+usage: python3 tools/ablate_pipe.py "NAME:-DMDPP_PIPE_CHUNK=16 -DMDPP_PIPE_DEPTH=64" ..."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+CSRC = os.path.join(ROOT, "mdp_playground_amd", "csrc")
+sys.path.insert(0, ROOT)
+from mdp_playground_amd import build as B  # noqa: E402
+
+
+def main():
+    outdir = os.path.join(ROOT, "gpurun_out", "ablate_pipe")
+    os.makedirs(outdir, exist_ok=True)
+    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in B.SOURCES if s != "mdpp_discrete_pipe.hip"]
+    variants = [("base", "")] + [tuple(v.split(":", 1)) for v in sys.argv[1:]]
+    for name, flags in variants:
+        obj = os.path.join(outdir, f"pipe_{name}.o")
+        so = os.path.join(outdir, f"libmdpp_{name}.so")
+        subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(CSRC, "mdpp_discrete_pipe.hip"), "-o", obj])
+        subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-o", so] + objs + [obj])
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); import torch\n"
+                f"from mdp_playground_amd import _capi; _capi.LIB_PATH = {so!r}\n"
+                "from mdp_playground_amd import RLToyVectorEnv; import bench\n"
+                "wl = bench.WORKLOADS['cfg2']; N, F = wl['envs'], 512\n"
+                "env = RLToyVectorEnv(num_envs=N, autoreset='same_step', **wl['config'])\n"
+                "acts = bench.make_actions(wl, F, N, env.device, 12345); out = env.alloc_rollout(F)\n"
+                "for _ in range(5): env.rollout(acts, out)\n"
+                "torch.cuda.synchronize(); best = 1e9\n"
+                "for rep in range(3):\n"
+                "    env.timer_begin()\n"
+                "    for _ in range(20): env.rollout(acts, out)\n"
+                "    best = min(best, env.timer_end() / 20)\n"
+                f"print({name!r}, env.rollout_kernel_name(F), '%.1f us per launch' % (best * 1e3), '%.3f of 8 TB/s' % (18 * N * F / (best * 1e-3) / 8e12))\n")
+        subprocess.check_call([sys.executable, "-c", code])
+
+
+if __name__ == "__main__":
+    main()
