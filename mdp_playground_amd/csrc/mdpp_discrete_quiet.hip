@@ -45,6 +45,7 @@ constexpr int kQQ = 4;                         // start states queued per lane
 // exist: lanes 12-15 of every 16 stored the overwritten register (found by the role-split soak test).
 constexpr int kQRsrc = 0x00020000;
 constexpr int kQDepth = 24;                    // E -> O ring depth in steps (multiple of the chunk of 8)
+constexpr int kHD = 16;                        // Philox producers -> E ring depth in steps
 constexpr uint32_t kQSpinLimit = 1u << 22;
 constexpr uint32_t kQStatusInternal = 0x80000000u;
 
@@ -63,8 +64,14 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // PH: Philox streams (mdpp_rng.hpp): every step re-keys its generators by (seed, global env id, tick,
 // stream), nothing is loaded from or stored to HBM, start states are drawn at need (like RN: no queue, no
 // H role, nothing to un-draw), and the reward-noise normal is the Philox mode's Box-Muller one.
-template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false>
-__global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
+// NPH (PH, two roles, no irrelevant sub-space): Philox producer waves.  A counter-based stream has no serial
+// state, so everything random about step k -- the P-noise uniform, the reward-noise normal, the start state
+// a reset at that step would draw -- is a pure function of (seed, env, tick) and is made AHEAD of the step by
+// NPH extra waves per SIMD (producer p takes the steps k = p mod NPH) into an LDS ring; the E wave, whose
+// dependent chain is the step time, then runs no generator at all (two Philox blocks and a Box-Muller pair
+// per step on E were 0.15 of the HBM roofline on cfg2 + noise).
+template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0>
+__global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
@@ -82,9 +89,14 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     __shared__ uint64_t s_ki[ZIG ? 256 : 1];
     __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
     static_assert(!(ATNEED && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
+    static_assert(NPH == 0 || (PH && ROLES == 2 && !IRR), "Philox producers: two roles, one sub-space");
+    // producers -> E: per env and step {P-noise uniform (53 bits) | start state << 56} and the reward normal
+    __shared__ __align__(8) uint64_t s_hm[NPH ? kHD * kBlock : 1];
+    __shared__ float s_hz[(NPH && RN) ? kHD * kBlock : 1];
+    __shared__ uint32_t s_hprod[NPH ? NPH : 1][kBlock / 64];            // steps made by producer p for wave w
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
-    constexpr int kThreads = ROLES * kBlock;
+    constexpr int kThreads = (ROLES + NPH) * kBlock;
     const int tid = threadIdx.x;
     const int role = DUO ? tid / kBlock : 0;        // 0 = E, 1 = O, 2 = H
     const int l = DUO ? (tid & (kBlock - 1)) : tid, w = l >> 6;
@@ -131,7 +143,10 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         if (tid & 1) r += a.term_add;
         s_rsel[tid] = (float)r;
     }
-    if (tid < kBlock / 64) { s_prod[tid] = 0; s_cons[tid] = 0; }
+    if (tid < kBlock / 64) {
+        s_prod[tid] = 0; s_cons[tid] = 0;
+        if (NPH) for (int p = 0; p < NPH; p++) s_hprod[p][tid] = 0;
+    }
     if (TRIO && tid < kBlock) { s_start[tid] = 0; s_head[tid] = 0; }
     if (tid == 0) s_done = 0;
     __syncthreads();
@@ -202,6 +217,43 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             }
         }
     };
+    if constexpr (NPH > 0) if (role >= 2) {
+        // =========================================================== Philox producer (see NPH above)
+        const int me = role - 2;
+        uint32_t made = 0, hstatus = 0;
+        for (int k = me; k < K; k += NPH) {
+            const uint64_t tick = a.ptick + (uint64_t)k;
+            uint64_t m_sp = 0;
+            if (PN) {                                            // this step's P-noise uniform, state-space stream
+                Philox gs;
+                gs.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
+                m_sp = gs.next64() >> 11;
+            }
+            Philox ge;                                           // env stream: reward normal, then the reset draw
+            ge.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
+            float z = 0.0f;
+            if (RN) z = (float)ge.normal();
+            const uint64_t mr = ge.next64() >> 11;
+            uint32_t s0 = 0;
+            for (uint32_t b = 0; b < S8; b += 8) {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8; jj++) s0 += (T0[b + jj] <= mr) ? 1u : 0u;
+            }
+            if (k >= kHD) {                                      // slot k % kHD: E must be through step k - kHD
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&s_prod[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(k - kHD + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kQSpinLimit) { hstatus |= kQStatusInternal; break; }
+                }
+            }
+            s_hm[(k % kHD) * kBlock + l] = m_sp | ((uint64_t)s0 << 56);
+            if (RN) s_hz[(k % kHD) * kBlock + l] = z;
+            made += 1;
+            if ((l & 63) == 0) __hip_atomic_store(&s_hprod[me][w], made, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (hstatus) atomicOr(&a.status[i], hstatus);
+        return;
+    }
     const bool autoreset = a.autoreset != 0, has_max = a.max_steps > 0;
     const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n, delay = (uint32_t)a.delay;
     const bool isE = !DUO || role == 0;
@@ -309,7 +361,9 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
 
     // ---- E: one step of the state recurrence -> record
     auto stepE = [&](const u32x2 act2, double &z, const int kstep) __attribute__((always_inline)) -> uint64_t {
-        if constexpr (PH) {          // this step's streams (a block is only computed when something is drawn)
+        uint64_t hent = 0;           // NPH: what the producers made for this step
+        if constexpr (NPH > 0) hent = s_hm[(kstep % kHD) * kBlock + l];
+        if constexpr (PH && NPH == 0) {          // this step's streams (a block is only computed when something is drawn)
             const uint64_t tick = a.ptick + (uint64_t)kstep;
             g.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
             if (PN) sp.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
@@ -323,7 +377,9 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
         const uint32_t cur = (uint32_t)hist & 0xFFu;
         uint32_t nxt = P[cur * A + (uint32_t)action];                        // D1
         if (PN) {                                                            // D2 (:1604-1622)
-            const uint64_t m = sp.next64() >> 11;
+            uint64_t m;
+            if constexpr (NPH > 0) m = hent & ((1ull << 53) - 1ull);
+            else m = sp.next64() >> 11;
             const uint64_t *row = TN + nxt * S8;
             uint32_t c = 0;
             for (uint32_t b = 0; b < S8; b += 8) {
@@ -358,11 +414,15 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
             }
         }
         status |= (bad || bad1) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
-        if (RN) z = np_standard_normal_lds(g, zig);                         // D6: drawn in reward_function, before any reset
+        if (RN) {                                                           // D6: drawn in reward_function, before any reset
+            if constexpr (NPH > 0) z = (double)s_hz[(kstep % kHD) * kBlock + l];
+            else z = np_standard_normal_lds(g, zig);
+        }
         const bool tr = has_max && steps >= max_steps;
         const bool need = autoreset && (done || tr);
         if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
-            if (need) { queue[0] = draw_state(); }
+            if constexpr (NPH > 0) { queue[0] = need ? (uint32_t)(hent >> 56) : queue[0]; }
+            else if (need) { queue[0] = draw_state(); }
             qn = need ? 1u : qn;
         }
         uint32_t hi = (done ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |
@@ -455,6 +515,18 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
                 }
             }
             if (TRIO && autoreset) pull();
+            if constexpr (NPH > 0) {                    // the producers must be through this chunk's steps
+                const int upto = min(kbase + kPre, K);
+#pragma unroll
+                for (int p = 0; p < NPH; p++) {
+                    const uint32_t want = upto > p ? (uint32_t)((upto - p + NPH - 1) / NPH) : 0u;
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(&s_hprod[p][w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kQSpinLimit) { status |= kQStatusInternal; break; }
+                    }
+                }
+            }
             if (kbase + kPre <= K) {
 #pragma unroll
                 for (int u = 0; u < kPre; u++) {
@@ -538,10 +610,10 @@ __global__ __launch_bounds__(ROLES * kBlock) void k_discrete_rollout_quiet(Discr
     if (status) atomicOr(&a.status[i], status);
 }
 
-template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false>
+template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0>
 static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH>;
+    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH>;
     if (lds > 48 * 1024) {                        // tables + record ring beyond the default dynamic-LDS limit
         static size_t allowed = 0;                // (per instantiation)
         if (lds > allowed) {
@@ -550,7 +622,7 @@ static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t
         }
     }
     const int grid = (a.N + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(ROLES * kBlock), lds, s, a, K, actions, obs, reward, term, trunc, final_obs);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((ROLES + NPH) * kBlock), lds, s, a, K, actions, obs, reward, term, trunc, final_obs);
 }
 
 // Serves the launch if the handle and the launch shape qualify; false = not taken.
@@ -578,9 +650,11 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = trio ? 3 : duo ? 2 : 1;
+    // Philox handles in two roles without an irrelevant sub-space: two producer waves on top (see NPH)
+    const int nph = (ph && duo && !a.irr && a.autoreset && lds_duo + 56 * 1024 <= 150 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO)) ? 2 : 0;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d>", !a.obs_i32, a.irr != 0,
-                 roles, pn, rn, ph);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d,NPH=%d>", !a.obs_i32,
+                 a.irr != 0, roles, pn, rn, ph, nph);
         return true;
     }
     const size_t l = roles == 1 ? lds : lds_duo;
@@ -588,7 +662,8 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
 #define MDPP_Q_ROLES(O64, IR, PN_, RN_)                                                           \
     do {                                                                                          \
         if (ph) {                                                                                 \
-            if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_, true>(MDPP_Q_ARGS);                \
+            if (nph == 2) { if constexpr (!IR) quiet_launch<O64, IR, 2, PN_, RN_, true, 2>(MDPP_Q_ARGS); } \
+            else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_, true>(MDPP_Q_ARGS);           \
             else quiet_launch<O64, IR, 1, PN_, RN_, true>(MDPP_Q_ARGS);                           \
         }                                                                                         \
         else if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
