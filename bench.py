@@ -453,8 +453,8 @@ def committed_traffic(workload, rng, N, F, kname):
         t = json.load(open(tfile))
         if t.get("envs") != N:
             continue
-        kernels = " ".join(t.get("per_kernel_KB", {}))
-        if kernels and kname.split("<")[0] not in kernels:
+        kernels = " ".join(t.get("per_kernel_KB", {})) + " " + str(t.get("kernel", ""))
+        if kname.split("<")[0] not in kernels:      # measured on another kernel (or the record does not say)
             continue
         if t.get("fuse") == F and "traffic_bytes_per_launch" in t:
             return t["traffic_bytes_per_launch"], os.path.basename(tfile)
