@@ -277,6 +277,7 @@ def main():
                     "e.g. NO_HELPER): take specialised kernels out of the dispatch, for A/B timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live PMC traffic measurement (two child rocprofv3 runs)")
     ap.add_argument("--full-gather-steps", type=int, default=4,
                     help="bench steps of the [K, N_local, ...] all-gather leg (multi-rank runs; 0 = skip)")
     args = ap.parse_args()
@@ -294,6 +295,9 @@ def main():
     cpu_py = cpu_py_all = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
+    pmc = None
+    if rank == 0 and world == 1 and not args.no_pmc:
+        pmc = live_traffic(args.workload, args.rng, args.envs or wl["envs"], max(1, min(args.fuse, wl.get("fuse_max", args.fuse))))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -394,6 +398,8 @@ def main():
     achieved = alg_bytes / per_launch_s / 1e9
     kname = env.rollout_kernel_name(F)          # what the library's dispatch launches (mdpp_kernel_name)
     traffic, traffic_src = committed_traffic(args.workload, args.rng, N, F, kname)
+    if pmc is not None and kname.split("<")[0] in pmc[1]:      # measured in this run, on the kernel that was timed
+        traffic, traffic_src = pmc[0], pmc[2]
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg_bytes,
@@ -438,6 +444,51 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def live_traffic(workload, rng, N, F, launches=4, timeout=150):
+    """HBM bytes per launch of the dominant kernel from PMC counters, measured NOW: two child rocprofv3 runs
+    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: they do not fit one pass) of tools/run_variant.py, which
+    launches the same fused rollouts; read bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B read requests at
+    64 B, MI355X_MICROARCH.md), write bytes = WRITE_SIZE KB.  Returns (bytes per launch, kernel, note) or None
+    when rocprofv3 is not usable here (the committed record is used instead)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="mdpp_pmc_", dir="/tmp")
+    per_kernel = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "run_variant.py"), "-", str(launches), workload, str(F), f"rng={rng}",
+                   f"envs={N}"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"].split("(")[0]
+                    if row["Counter_Name"] == counter and "mdpp::" in k and "reset" not in k:
+                        d = per_kernel.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "calls": 0})
+                        d[counter] += float(row["Counter_Value"])
+                        if counter == "WRITE_SIZE":
+                            d["calls"] += 1
+        if not per_kernel:
+            return None
+        k, d = max(per_kernel.items(), key=lambda kv: kv[1]["FETCH_SIZE"] * 2 + kv[1]["WRITE_SIZE"])
+        calls = max(d["calls"], 1)
+        return int(round((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 / calls)), k, \
+            f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, x2 on FETCH_SIZE), {calls} launches, in this run"
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def committed_traffic(workload, rng, N, F, kname):

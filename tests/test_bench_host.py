@@ -35,3 +35,11 @@ def test_self_launch_spawns_a_child_torchrun(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_live_traffic_gives_up_without_profiler(monkeypatch):
+    """No rocprofv3 (or no GPU under it) -> None, and the bench line falls back to the committed record."""
+    import shutil
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert bench.live_traffic("cfg2", "numpy", 65536, 512) is None

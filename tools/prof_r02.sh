@@ -5,10 +5,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02
 for w in cfg2_noise cfg3 cfg4 cfg5 grid cfg2_irr line img_cont; do
-  python3 bench.py --workload $w --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > gpurun_out/r02/bench_$w.json
+  python3 bench.py --workload $w --no-cpu-baseline --no-pmc 2>/dev/null | grep '^{"metric"' > gpurun_out/r02/bench_$w.json
 done
 for w in cfg2 cfg2_noise cfg3 cfg5 grid; do
-  python3 bench.py --workload $w --rng philox --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > gpurun_out/r02/bench_${w}_philox.json
+  python3 bench.py --workload $w --rng philox --no-cpu-baseline --no-pmc 2>/dev/null | grep '^{"metric"' > gpurun_out/r02/bench_${w}_philox.json
 done
 for w in cfg5 cfg2_noise; do
   rm -rf gpurun_out/prof_${w}_philox
