@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libmdpp_hip.so")
-SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_fast.hip", "mdpp_discrete_pipe.hip",
+SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_fast.hip", "mdpp_discrete_pipe.hip", "mdpp_discrete_lean.hip",
            "mdpp_discrete_quiet.hip",
            "mdpp_continuous.hip",
            "mdpp_continuous_fast.hip", "mdpp_image.hip", "mdpp_grid.hip", "mdpp_imagec.hip", "mdpp_post.hip"]

@@ -585,7 +585,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         if (D == 2) {
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[0]), __float_as_uint(cur[1])},
-                                                  r_obs, vrow, so * (uint32_t)(D * 4), 0);
+                                                  r_obs, vrow, so * (uint32_t)(D * 4), MDPP_ST_NT);
         } else {
             if (V > 1 && full_wave) {
             // rows of D floats -> the wave's 64 rows as one contiguous block, through a wave-private
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             for (int q = 0; q < V; q++)
                 // (128-bit stores: whole offset in the VGPR, see mdpp_discrete_quiet.hip on the store-data hazard)
                 __builtin_amdgcn_raw_buffer_store_b128(tile[q * 64 + l], r_obs,
-                                                       wbase + (uint32_t)(q * 64 + l) * 16u + so * (uint32_t)(D * 4), 0, 0);
+                                                       wbase + (uint32_t)(q * 64 + l) * 16u + so * (uint32_t)(D * 4), 0, MDPP_ST_NT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             } else {                              // D = 4 rows are contiguous as they are; ragged last wave
 #pragma unroll
@@ -611,12 +611,12 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                     __builtin_amdgcn_raw_buffer_store_b128(
                         u32x4{__float_as_uint(cur[4 * q]), __float_as_uint(cur[4 * q + 1]),
                               __float_as_uint(cur[4 * q + 2]), __float_as_uint(cur[4 * q + 3])},
-                        r_obs, vrow + 16u * q + so * (uint32_t)(D * 4), 0, 0);
+                        r_obs, vrow + 16u * q + so * (uint32_t)(D * 4), 0, MDPP_ST_NT);
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), r_rew, v4, so * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), r_rew, v4, so * 4u, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so, MDPP_ST_NT);
     };
 
     const int nfull = K / kCAhead;

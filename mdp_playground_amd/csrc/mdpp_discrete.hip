@@ -407,7 +407,10 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
             a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u;
             void *fo = final_obs ? (void *)((char *)final_obs + off * osz) : nullptr;
             // long rollouts of full blocks: three-role pipelined kernel (mdpp_discrete_pipe.hip)
-            if (!launch_discrete_pipe(a, kc, actions + off, (char *)obs + off * osz, reward + off,
+            // (at most 8 states: its leaner re-encoding, mdpp_discrete_lean.hip)
+            if (!launch_discrete_lean(a, kc, actions + off, (char *)obs + off * osz, reward + off,
+                                      term + off, trunc + off, fo, s, name_out) &&
+                !launch_discrete_pipe(a, kc, actions + off, (char *)obs + off * osz, reward + off,
                                       term + off, trunc + off, fo, s, name_out))
                 launch_discrete_fast(a, kc, actions + off, (char *)obs + off * osz, reward + off,
                                      term + off, trunc + off, fo, s, name_out);

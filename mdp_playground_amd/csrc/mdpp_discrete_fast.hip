@@ -288,8 +288,8 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_discrete_rollo
         }
         if (__builtin_expect(want_final, 0)) {
             if (need) {
-                if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{nxt, 0u}, r_fin, v8, so * 8u, 0);
-                else __builtin_amdgcn_raw_buffer_store_b32(nxt, r_fin, v4, so * 4u, 0);
+                if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{nxt, 0u}, r_fin, v8, so * 8u, MDPP_ST_NT);
+                else __builtin_amdgcn_raw_buffer_store_b32(nxt, r_fin, v4, so * 4u, MDPP_ST_NT);
             }
         }
         {   // same-step autoreset (reset(), :2250-2278) as selects
@@ -303,10 +303,10 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_discrete_rollo
             e.qc = e.qc - (need ? 1u : 0u);
         }
 #ifndef MDPP_ABL_NOSTORE
-        if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{e.cur, 0u}, r_obs, v8, so * 8u, 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(e.cur, r_obs, v4, so * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)tr, r_trunc, v1, so, 0);
+        if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{e.cur, 0u}, r_obs, v8, so * 8u, MDPP_ST_NT);
+        else __builtin_amdgcn_raw_buffer_store_b32(e.cur, r_obs, v4, so * 4u, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)tr, r_trunc, v1, so, MDPP_ST_NT);
 #else
         e.status ^= (e.cur + done + tr) & 0x100u;
 #endif
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_discrete_rollo
         const float rout = done ? r_t : r_nt;
         if (DELAY) e.ring = (p.flags & 4u) ? 0u : e.ring;
 #ifndef MDPP_ABL_NOSTORE
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, p.so * 4u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, p.so * 4u, MDPP_ST_NT);
 #else
         e.status ^= __float_as_uint(rout) & 0x100u;
 #endif

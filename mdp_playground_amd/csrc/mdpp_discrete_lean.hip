@@ -1,0 +1,565 @@
+// Four-role pipelined rollout for discrete shapes with at most 8 states: the work of
+// k_discrete_rollout_pipe (mdpp_discrete_pipe.hip) re-encoded so that one env step costs about a
+// third of its vector instructions, with the output stores marked non-temporal.  Same arithmetic
+// and the same results as that kernel and as k_discrete_rollout_fast (reference
+// rl_toy_env.py:1992-2125, reset :2250-2278); the same tests hold all three against the oracle.
+//
+// A 1024-thread workgroup steps 256 envs, lane l of waves w, w+4, w+8, w+12 serving the same env:
+//   E   waves 0-3    state recurrence, same-step autoreset from the queue of pre-drawn start states;
+//                    three (four) dwords per env step into LDS rings
+//   O1  waves 4-7    reward path: reward bit, delay line, reward value; stores `reward`
+//   O2  waves 8-11   stores `obs`, `terminated`, `truncated` (and final_obs)
+//   H   waves 12-15  own the envs' PCG64 streams for the launch and keep an LDS ring of pre-drawn
+//                    rho_0 start states filled; un-draw what was not used at the end
+// Hand-offs and spin bounds as in mdpp_discrete_pipe.hip (single-producer rings, monotonic counters,
+// release/acquire at workgroup scope, polled once per kChunk steps).
+//
+// The encoding:
+//   * history register: one nibble per state, newest lowest, bit 3 = "is a state" (0 = NaN).  A
+//     transition is v_perm_b32 (byte `cur` of the action's 8-byte column) + v_lshl_or_b32; a reset
+//     replaces the register with (s0 | 8), which also restarts the NaN prefix
+//   * column byte = next state | 8 | is_terminal << 7: the terminal test is a compare of the byte
+//     just fetched (bit 7 lands on a history bit that is set anyway)
+//   * reward bit and NaN gate (:1822) in ONE lookup: a 65 536-bit LDS table indexed by the four
+//     low nibbles, zero wherever one of the L + 1 nibbles it needs is not a state
+//   * truncation: the step counter is biased so that bit 16 is set exactly when steps >= max_steps;
+//     byte 2 of the counter is the `truncated` byte
+//   * reward_every_n_steps: a down-counter in units of 16 that indexes the reward-value table
+//     (only its row 0 hands out the bit), so the gate (:1975-1976) costs no instruction in O1
+//   * the queue of pre-drawn start states keeps bit 3 of every nibble it holds, so "queue empty"
+//     is a test of its low nibble and no count is kept
+//   * reward value: one LDS read of a table indexed by (steps to the next pay step, delayed bit, terminated)
+//   * "reset happened" = the history words before and after it differ
+// What the measurements said (profiles/r02_ablation_lean_kernel.txt): with the default cache policy
+// the time was set by the stores, whoever issued them (147 us per 512-step launch of 65 536 envs with
+// one, two or three storing waves per SIMD); marked nt they cost 10 us on top of the 95 us the
+// recurrence + start-state draws take, 106 us = 5.7 TB/s.
+#include <stdlib.h>
+
+#include <stdio.h>
+
+#include "mdpp_internal.hpp"
+#include "mdpp_rng.hpp"
+
+namespace mdpp {
+
+#ifndef MDPP_LEAN_CHUNK
+#define MDPP_LEAN_CHUNK 8
+#endif
+#ifndef MDPP_LEAN_DEPTH
+#define MDPP_LEAN_DEPTH 32
+#endif
+#ifndef MDPP_LEAN_AHEAD
+#define MDPP_LEAN_AHEAD 4
+#endif
+#ifndef MDPP_LEAN_PRIO_E
+#define MDPP_LEAN_PRIO_E 3
+#endif
+#ifndef MDPP_LEAN_PRIO_O
+#define MDPP_LEAN_PRIO_O 2
+#endif
+#ifndef MDPP_LEAN_ST_AUX
+#define MDPP_LEAN_ST_AUX MDPP_ST_NT
+#endif
+#ifndef MDPP_LEAN_LD_AUX
+#define MDPP_LEAN_LD_AUX 0
+#endif
+#ifndef MDPP_LEAN_HSLEEP
+#define MDPP_LEAN_HSLEEP 8
+#endif
+namespace lean {
+constexpr int kChunk = MDPP_LEAN_CHUNK;   // steps between hand-off polls; also the action prefetch distance
+constexpr int kDepth = MDPP_LEAN_DEPTH;   // E->O ring depth in steps (multiple of kChunk)
+constexpr int kAhead = MDPP_LEAN_AHEAD;   // action prefetch distance in chunks
+constexpr int kPRsrc = 0x00020000;
+constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr uint32_t kStatusInternal = 0x80000000u;
+constexpr uint32_t kQueueCap = 6;
+constexpr int kRoles = 4;                 // E, O1 (reward path), O2 (observation / flag stores), H
+constexpr uint32_t kSelPad = 0x0c0c0c00u; // v_perm_b32 selector bytes 1-3: constant 0x00
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t wg_load_acq(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wg_store_rel(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+} // namespace lean
+using namespace lean;
+
+template <bool OBS64, bool DELAY, bool HASMAX, bool EVN>
+__global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(DiscreteArgs a, int K,
+                                                                      const int32_t *__restrict__ actions,
+                                                                      void *__restrict__ obs,
+                                                                      float *__restrict__ reward,
+                                                                      uint8_t *__restrict__ term,
+                                                                      uint8_t *__restrict__ trunc,
+                                                                      void *__restrict__ final_obs) {
+    __shared__ __align__(16) uint32_t lds_A[kDepth][kBlock];  // E -> O: history before a reset
+    __shared__ __align__(16) uint32_t lds_B[kDepth][kBlock];  //         history after it
+    __shared__ __align__(16) uint32_t lds_C[kDepth][kBlock];  //         byte 0 terminated, byte 2 truncated
+    __shared__ __align__(16) uint32_t lds_D[EVN ? kDepth : 1][kBlock];  //   (every_n > 1) 16 x steps to the next pay step
+    __shared__ __align__(16) uint32_t lds_V[2048];            // reward bit & NaN gate, by the 4 low nibbles
+    __shared__ __align__(16) uint2 lds_col[16];               // action a, byte s: P[s][a] | 8 | is_term[P[s][a]] << 7
+    __shared__ __align__(16) uint32_t lds_R[128];             // 4096 reward bits by key (staging for lds_V)
+    __shared__ __align__(16) uint64_t lds_T[8];               // rho_0 thresholds
+    __shared__ __align__(16) float lds_rsel[EVN ? 4 * 64 : 4]; // reward by (steps to pay step, bit, terminated)
+    __shared__ __align__(16) uint64_t lds_ring[kBlock];       // H -> E: {8 nibbles, #pushed}
+    __shared__ uint32_t lds_head[kBlock];                     // E -> H: #popped
+    __shared__ uint32_t lds_prod[kBlock / 64];                // steps published by E wave w
+    __shared__ __align__(8) uint32_t lds_cons[kBlock / 64][2]; // steps consumed by the O1 / O2 wave w
+    __shared__ uint32_t lds_done;                             // E waves that have finished
+    const int tid = threadIdx.x;
+    const int role = tid / kBlock;                  // 0 = E, 1 = O1, 2 = O2, 3 = H
+    const int l = tid & (kBlock - 1);               // env slot inside the block
+    const int w = l >> 6;
+    const uint32_t S = (uint32_t)a.S, L = (uint32_t)a.L;
+    if (tid < 16) {
+        uint64_t cs = 0;
+        if (tid < a.A)
+            for (uint32_t s = 0; s < S; s++) {
+                const uint32_t nx = a.P[s * a.A + tid] & 7u;
+                cs |= (uint64_t)(nx | 8u | ((uint32_t)((a.term_mask >> nx) & 1ULL) << 7)) << (8 * s);
+            }
+        lds_col[tid] = make_uint2((uint32_t)cs, (uint32_t)(cs >> 32));
+        if (tid < 8) lds_T[tid] = a.init_thr[tid];
+        if (!EVN && tid < 4) lds_rsel[tid] = a.rsel[tid];
+    }
+    if (EVN)                                                  // only pay steps hand out the bit (:1975-1976)
+        for (int k = tid; k < 4 * a.every_n; k += kRoles * kBlock) lds_rsel[k] = a.rsel[k < 4 ? k : (k & 1)];
+    for (uint32_t k = tid; k < 128; k += kRoles * kBlock) {
+        uint32_t wd = 0;
+        for (int b = 0; b < 4; b++) {
+            uint32_t byte = 4 * k + b;
+            if (byte < a.rbits_stride) wd |= (uint32_t)a.rbits[byte] << (8 * b);
+        }
+        lds_R[k] = wd;
+    }
+    if (tid < kBlock) { lds_ring[tid] = 0; lds_head[tid] = 0; }
+    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; }
+    if (tid == 0) lds_done = 0;
+    __syncthreads();
+    {   // lds_V: dword d holds indices 32 d .. 32 d + 31; nibble j of an index = (d * 32 + b) >> 4 j.
+        // Non-zero only where nibbles 0..L all carry bit 3: nibbles 1..L are fixed by d.
+        uint32_t dmask = 0;
+        for (uint32_t j = 1; j <= L; j++) dmask |= 1u << (4 * j - 2);
+        for (uint32_t d = tid; d < 2048; d += kRoles * kBlock) {
+            uint32_t wd = 0;
+            if ((d & dmask) == dmask) {
+                for (uint32_t b = 8; b < 32; b++) {
+                    if (!(b & 8u)) continue;
+                    const uint32_t idx = d * 32u + b;
+                    uint32_t key = 0, pw = 1;
+                    for (uint32_t j = 0; j < L; j++) { key += ((idx >> (4 * j)) & 7u) * pw; pw *= S; }
+                    if (key < a.nkeys) wd |= ((lds_R[key >> 5] >> (key & 31u)) & 1u) << b;
+                }
+            }
+            lds_V[d] = wd;
+        }
+    }
+    __syncthreads();
+
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Give every XCD one contiguous eighth of the
+    // envs, so that what its L2 writes back per output row is one contiguous range, not every eighth
+    // 256-env piece of it.
+#ifdef MDPP_ABL_NOXCD
+    const uint32_t eblk = blockIdx.x;
+#else
+    const uint32_t eblk = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+#endif
+    const uint32_t i = eblk * kBlock + l;           // N % kBlock == 0 is a launch precondition
+    const uint32_t N = (uint32_t)a.N;
+    const uint32_t A = (uint32_t)a.A;
+    constexpr int kMinLanes = 16;
+    uint32_t status = 0;
+
+    // =============================================================== H: start-state producer
+    if (role == 3) {
+#ifdef MDPP_ABL_NOH
+        return;
+#endif
+        Pcg64 g;
+        g.load(a.env_s, a.env_inc, i);
+        auto draw = [&](Pcg64 &gg) -> uint32_t {
+            const uint64_t m = gg.next64() >> 11;
+            uint32_t s0 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
+            return s0;
+        };
+        uint32_t vals = 0, tail = 0;
+        for (;;) {
+            if (wg_load_acq(&lds_done) == kBlock / 64) break;
+            const uint32_t head = wg_load_acq(&lds_head[l]);
+            const uint32_t cnt = tail - head;
+            const bool want = cnt < 8;
+            const uint64_t bw = __builtin_amdgcn_ballot_w64(want);
+            const bool urgent = __builtin_amdgcn_ballot_w64(want && cnt <= 2) != 0;
+            if (__builtin_popcountll(bw) >= kMinLanes || urgent) {
+                Pcg64 n = g;
+                const uint32_t s0 = draw(n) | 8u;
+                if (want) {
+                    const uint32_t sh = (tail & 7u) * 4u;
+                    g = n;
+                    vals = (vals & ~(0xFu << sh)) | (s0 << sh);
+                    tail += 1;
+                }
+                __hip_atomic_store(&lds_ring[l], (uint64_t)vals | ((uint64_t)tail << 32), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __builtin_amdgcn_s_sleep(MDPP_LEAN_HSLEEP);
+            }
+        }
+        // un-draw what the env lane did not take: s_prev = (s - inc) * M^-1 (mod 2^128)
+        const uint32_t head = wg_load_acq(&lds_head[l]);
+        for (uint32_t q = tail - head; q > 0; q--) {
+            uint64_t lo = g.s_lo - g.inc_lo;
+            uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
+            g.s_lo = lo * a.minv_lo;
+            g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+        }
+        g.store(a.env_s, i);
+        return;
+    }
+
+    const uint32_t total = (uint32_t)K * N;
+    const int nchunks = (K + kChunk - 1) / kChunk;
+
+    // =============================================================== O1: reward path
+    if (role == 1) {
+        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O);
+        auto r_rew = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kPRsrc);
+        const uint32_t v4 = i * 4u;
+        const uint32_t dsh = (uint32_t)(a.delay > 0 ? a.delay - 1 : 0);
+        uint32_t ring = ((const uint32_t *)&a.state[i])[3];
+        const uint8_t *rselb = (const uint8_t *)lds_rsel;
+
+        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t rd, uint32_t so) {
+            uint32_t bit = lds_V[(ra >> 5) & 2047u] >> (ra & 31u);                   // reward bit, NaN-gated (:1822)
+            uint32_t out;
+            if (DELAY) {                                                             // FIFO (:1970-1973)
+                out = (ring >> dsh) & 1u;
+                ring = (ring << 1) | (bit & 1u);
+                ring = (ra != rb) ? 0u : ring;                                       // reset clears it (:2250)
+            } else {
+                out = bit & 1u;
+            }
+            const uint32_t tb = HASMAX ? (rc & 1u) : rc;
+            const float rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
+                                   : *(const float *)(rselb + (((out << 1) | tb) << 2));
+#if defined(MDPP_ABL_NOSTORE) || defined(MDPP_ABL_NOREW)
+            status ^= __float_as_uint(rout) & 0x100u;
+#else
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * 4u, MDPP_LEAN_ST_AUX);
+#endif
+        };
+        for (int c = 0; c < nchunks; c++) {
+            const int kbase = c * kChunk;
+            const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
+            uint32_t spins = 0;
+#ifdef MDPP_ABL_FREEO
+            while (false) {
+#else
+            while (wg_load_acq(&lds_prod[w]) < upto) {
+#endif
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+            }
+            if (kbase + kChunk <= K) {
+                uint32_t ra[kChunk], rb[kChunk], rc[kChunk], rd[kChunk];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    ra[u] = lds_A[(kbase + u) % kDepth][l];
+                    rb[u] = DELAY ? lds_B[(kbase + u) % kDepth][l] : 0u;
+                    rc[u] = lds_C[(kbase + u) % kDepth][l];
+                    rd[u] = EVN ? lds_D[(kbase + u) % kDepth][l] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], rd[u], (uint32_t)(kbase + u) * N);
+            } else {
+                for (int k = kbase; k < K; k++)
+                    emit(lds_A[k % kDepth][l], lds_B[k % kDepth][l], lds_C[k % kDepth][l],
+                         EVN ? lds_D[k % kDepth][l] : 0u, (uint32_t)k * N);
+            }
+            if ((l & 63) == 0) wg_store_rel(&lds_cons[w][0], upto);
+        }
+        ((uint32_t *)&a.state[i])[3] = ring;
+        if (status) atomicOr(&a.status[i], status);
+        return;
+    }
+
+    // =============================================================== O2: observation, terminated, truncated
+    if (role == 2) {
+        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O);
+        auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u), kPRsrc);
+        auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
+        auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
+        auto r_fin = __builtin_amdgcn_make_buffer_rsrc(final_obs ? final_obs : obs, 0,
+                                                       total * (OBS64 ? 8u : 4u), kPRsrc);
+        const bool want_final = final_obs != nullptr;
+        const uint32_t v1 = i, v4 = i * 4u, v8 = i * 8u;
+        auto emit = [&](uint32_t rb, uint32_t rc, uint32_t so) {
+            const uint32_t o = rb & 7u;
+#ifdef MDPP_ABL_NOSTORE
+            status ^= (o + rc) & 0x100u;
+            return;
+#endif
+#ifdef MDPP_ABL_NOOBS
+            status ^= o & 0x100u;
+#else
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{o, 0u}, r_obs, v8, so * 8u, MDPP_LEAN_ST_AUX);
+            else __builtin_amdgcn_raw_buffer_store_b32(o, r_obs, v4, so * 4u, MDPP_LEAN_ST_AUX);
+#endif
+#ifdef MDPP_ABL_NOBYTES
+            status ^= rc & 0x100u;
+#else
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rc, r_term, v1, so, MDPP_LEAN_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b8(HASMAX ? (uint8_t)(rc >> 16) : (uint8_t)0, r_trunc, v1, so, MDPP_LEAN_ST_AUX);
+#endif
+        };
+        auto emit_final = [&](uint32_t ra, uint32_t rb, uint32_t so) {       // state reached, where a reset replaced it
+            if (ra != rb) {
+                const uint32_t nx = ra & 7u;
+                if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{nx, 0u}, r_fin, v8, so * 8u, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(nx, r_fin, v4, so * 4u, 0);
+            }
+        };
+        for (int c = 0; c < nchunks; c++) {
+            const int kbase = c * kChunk;
+            const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
+            uint32_t spins = 0;
+#ifdef MDPP_ABL_FREEO
+            while (false) {
+#else
+            while (wg_load_acq(&lds_prod[w]) < upto) {
+#endif
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+            }
+            if (kbase + kChunk <= K) {
+                uint32_t rb[kChunk], rc[kChunk];
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    rb[u] = lds_B[(kbase + u) % kDepth][l];
+                    rc[u] = lds_C[(kbase + u) % kDepth][l];
+                }
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) emit(rb[u], rc[u], (uint32_t)(kbase + u) * N);
+                if (__builtin_expect(want_final, 0)) {
+#pragma unroll
+                    for (int u = 0; u < kChunk; u++) emit_final(lds_A[(kbase + u) % kDepth][l], rb[u], (uint32_t)(kbase + u) * N);
+                }
+            } else {
+                for (int k = kbase; k < K; k++) {
+                    emit(lds_B[k % kDepth][l], lds_C[k % kDepth][l], (uint32_t)k * N);
+                    if (want_final) emit_final(lds_A[k % kDepth][l], lds_B[k % kDepth][l], (uint32_t)k * N);
+                }
+            }
+            if ((l & 63) == 0) wg_store_rel(&lds_cons[w][1], upto);
+        }
+        if (status) atomicOr(&a.status[i], status);
+        return;
+    }
+
+    // =============================================================== E: state recurrence
+    __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_E);   // the serial recurrence is the critical path; H is filler work
+    // hist: bytes newest first, 0xFF = NaN  ->  nibbles newest first, bit 3 = is a state
+    uint32_t k2, qv, cnt, steps0, last_reset = 0, ph = 0;
+    const uint32_t ph_full = 16u * (uint32_t)a.every_n;
+    {
+        uint4 st = a.state[i];
+        k2 = 0;
+        for (int j = 3; j >= 0; j--) {
+            const uint32_t b = (st.x >> (8 * j)) & 0xFFu;
+            k2 = (k2 << 4) | (b == 0xFFu ? 0u : ((b & 7u) | 8u));
+        }
+        const uint32_t qc = (st.y >> 24) & 7u;
+        qv = (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u));
+        steps0 = st.z;
+        const uint32_t ms = (uint32_t)a.max_steps;
+        cnt = HASMAX ? (0x10000u - ms) + (steps0 < ms ? steps0 : ms) : 0u;
+        if (EVN) ph = ph_full - 16u * (steps0 % (uint32_t)a.every_n);
+    }
+    const uint32_t c0 = HASMAX ? 0x10000u - (uint32_t)a.max_steps : 0u;
+    auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * 4u, kPRsrc);
+    const uint32_t v4 = i * 4u;
+    uint32_t head_local = 0;
+    uint32_t sel = (k2 & 7u) | kSelPad;
+
+    auto pull = [&]() {
+        const uint64_t rt = __hip_atomic_load(&lds_ring[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t vals = (uint32_t)rt, tail = (uint32_t)(rt >> 32);
+        const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x88888888u);
+        const uint32_t avail = tail - head_local, room = kQueueCap - qc;
+        const uint32_t take = avail < room ? avail : room;
+        const uint32_t rot = __builtin_amdgcn_alignbit(vals, vals, (head_local & 7u) * 4u);
+        const uint32_t m = (1u << (4u * take)) - 1u;
+        qv |= (rot & m) << (4u * qc);
+        head_local += take;
+        __hip_atomic_store(&lds_head[l], head_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto column = [&](int action) -> uint2 {
+        uint32_t ua = (uint32_t)action;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(ua >= A) != 0, 0)) {
+            ua = (uint32_t)(action + ((action >> 31) & (int)A));
+            const bool bad = ua >= A;
+            status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+            ua = bad ? 0u : ua;
+        }
+        return lds_col[ua];
+    };
+    auto stepE = [&](const uint2 &col, int k) {
+        const uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);              // D1: P[cur][a] | 8 | terminal << 7
+        const uint32_t tb = entry >> 7;                                               // D7: is_terminal[next]
+        const uint32_t k2n = (k2 << 4) | entry;       // (bit 7 of the sum is set anyway: the nibble below was a state)
+        bool need = entry > 0x7Fu;
+        uint32_t rc = tb;
+        if (HASMAX) {
+            cnt += 1;
+            need = need || cnt >= 0x10000u;
+            rc = __builtin_amdgcn_perm(cnt, tb, 0x0c060c00u);                          // byte 0 terminated, byte 2 truncated
+        }
+#ifdef MDPP_ABL_NORESET
+        need = false;
+#endif
+        uint32_t s0v = qv & 0xFu;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
+            uint32_t spins = 0;
+            while (__builtin_amdgcn_ballot_w64(need && (qv & 0xFu) == 0u) != 0) {
+                pull();
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; qv |= 8u; break; }
+            }
+            s0v = qv & 0xFu;
+        }
+        if (EVN) {
+            ph -= 16u;
+            lds_D[k % kDepth][l] = ph;
+            ph = (need || ph == 0u) ? ph_full : ph;
+        }
+        k2 = need ? s0v : k2n;
+        qv = need ? (qv >> 4) : qv;
+        if (HASMAX) cnt = need ? c0 : cnt;
+        else last_reset = need ? (uint32_t)(k + 1) : last_reset;
+        sel = (k2 & 7u) | kSelPad;
+        lds_A[k % kDepth][l] = k2n;
+        lds_B[k % kDepth][l] = k2;
+        lds_C[k % kDepth][l] = rc;
+    };
+
+    auto load_act = [&](int k) -> int {
+        const uint32_t kk = (uint32_t)min(k, K - 1);
+#ifdef MDPP_ABL_NOLOAD
+        return (int)((kk * 7u + i) & 7u);
+#endif
+        return __builtin_amdgcn_raw_buffer_load_b32(r_act, v4, kk * N * 4u, MDPP_LEAN_LD_AUX);
+    };
+    // Actions are fetched kAhead chunks ahead of their use, columns one chunk ahead.  The buffers rotate
+    // by NAME (the chunk loop is unrolled kAhead times): copying a register whose load is still in
+    // flight makes the wave wait for it, which would put one HBM latency into every chunk.
+    static_assert(kAhead % 2 == 0, "the column double buffer alternates with the chunk index");
+    int actq[kAhead][kChunk];       // slot (m - 1) % kAhead holds the actions of chunk m
+    uint2 colq[2][kChunk];          // slot m & 1 holds the columns of chunk m
+#pragma unroll
+    for (int u = 0; u < kChunk; u++) colq[0][u] = column(load_act(u));
+#pragma unroll
+    for (int q = 0; q < kAhead; q++)
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) actq[q][u] = load_act((q + 1) * kChunk + u);
+
+    const int nfull = K / kChunk;   // full chunks; a ragged tail (K % kChunk steps) follows the loop
+    auto wait_room = [&](int kend) {                // do not run more than kDepth steps ahead of the O wave
+        if (kend > kDepth) {
+            const uint32_t must = (uint32_t)(kend - kDepth);
+            uint32_t spins = 0;
+            for (;;) {
+                const uint64_t cc = __hip_atomic_load((const uint64_t *)&lds_cons[w][0], __ATOMIC_ACQUIRE,
+                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (min((uint32_t)cc, (uint32_t)(cc >> 32)) >= must) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+            }
+        }
+    };
+    // one full chunk: slot j's actions -> next chunk's columns, (re)fill slot j, step, publish
+    auto chunkE = [&](int c, int j, bool refill) {
+        const int kbase = c * kChunk;
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) colq[(j + 1) & 1][u] = column(actq[j][u]);
+        if (refill) {
+#pragma unroll
+            for (int u = 0; u < kChunk; u++) actq[j][u] = load_act(kbase + (kAhead + 1) * kChunk + u);
+        }
+        wait_room(kbase + kChunk);
+        pull();
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) stepE(colq[j & 1][u], kbase + u);
+        if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)(kbase + kChunk));
+    };
+    // (single-exit loop body, no global load in an inner loop: the compiler then counts its vmcnt waits
+    //  exactly, vmcnt(8 (kAhead - 1) + ...), instead of waiting for every load in flight)
+    const int ngrp = nfull / kAhead;
+    for (int g = 0; g < ngrp; g++) {
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) chunkE(g * kAhead + j, j, true);
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead - 1; j++)
+        if (ngrp * kAhead + j < nfull) chunkE(ngrp * kAhead + j, j, false);
+    if (K % kChunk) {               // (no global load inside the loop above: its waits stay counted, not vmcnt(0))
+        const int kbase = nfull * kChunk;
+        int ta[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) ta[u] = load_act(kbase + u);
+        wait_room(kbase + kChunk);
+        pull();
+#pragma unroll
+        for (int u = 0; u < kChunk; u++)
+            if (kbase + u < K) stepE(column(ta[u]), kbase + u);
+        if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)K);
+    }
+
+    // back to the handle's state words: hist bytes, queue nibbles + count, episode steps
+    uint32_t hist = 0;
+    for (int j = 3; j >= 0; j--) {
+        const uint32_t nb = (k2 >> (4 * j)) & 0xFu;
+        hist = (hist << 8) | ((nb & 8u) ? (nb & 7u) : 0xFFu);
+    }
+    const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x00888888u);
+    uint32_t steps;
+    if (HASMAX) steps = cnt - c0;
+    else steps = last_reset ? (uint32_t)K - last_reset : steps0 + (uint32_t)K;
+    uint32_t *st = (uint32_t *)&a.state[i];
+    st[0] = hist; st[1] = (qv & 0x00777777u) | (qc << 24); st[2] = steps;   // word 3 (delay line) belongs to the O lane
+    if ((l & 63) == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (status) atomicOr(&a.status[i], status);
+}
+
+// Returns false when the shape does not qualify (caller tries k_discrete_rollout_pipe, then _fast).
+bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                          float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                          hipStream_t s, char *name_out) {
+    if (!a.fast_ok || K < 32 || (a.N % kBlock) != 0 || !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
+        return false;
+    if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
+    const int grid = a.N / kBlock;
+    const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d>", !a.obs_i32, dl, hm, evn);
+        return true;
+    }
+#define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                          \
+    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV>), dim3(grid), dim3(kRoles * kBlock), \
+                       0, s, a, K, actions, obs, reward, term, trunc, final_obs)
+#define MDPP_LEAN_L3(O64, DL, HM) do { if (evn) MDPP_LEAN_LAUNCH(O64, DL, HM, true); else MDPP_LEAN_LAUNCH(O64, DL, HM, false); } while (0)
+#define MDPP_LEAN_L2(O64, DL) do { if (hm) MDPP_LEAN_L3(O64, DL, true); else MDPP_LEAN_L3(O64, DL, false); } while (0)
+    if (a.obs_i32) { if (dl) MDPP_LEAN_L2(false, true); else MDPP_LEAN_L2(false, false); }
+    else { if (dl) MDPP_LEAN_L2(true, true); else MDPP_LEAN_L2(true, false); }
+#undef MDPP_LEAN_L2
+#undef MDPP_LEAN_L3
+#undef MDPP_LEAN_LAUNCH
+    return true;
+}
+
+} // namespace mdpp

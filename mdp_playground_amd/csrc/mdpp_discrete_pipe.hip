@@ -185,19 +185,19 @@ __global__ __launch_bounds__(3 * kBlock) void k_discrete_rollout_pipe(DiscreteAr
             if (__builtin_expect(want_final, 0)) {
                 if (rec & 0x400u) {
                     const uint32_t nx = (rec >> 4) & 0xFu;
-                    if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(pu32x2{nx, 0u}, r_fin, v8, so * 8u, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b32(nx, r_fin, v4, so * 4u, 0);
+                    if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(pu32x2{nx, 0u}, r_fin, v8, so * 8u, MDPP_ST_NT);
+                    else __builtin_amdgcn_raw_buffer_store_b32(nx, r_fin, v4, so * 4u, MDPP_ST_NT);
                 }
             }
 #ifdef MDPP_ABL_NOSTORE
             status ^= (o + __float_as_uint(rout)) & 0x100u;
             return;
 #endif
-            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(pu32x2{o, 0u}, r_obs, v8, so * 8u, 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(o, r_obs, v4, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * 4u, 0);
-            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rec >> 8) & 1u), r_term, v1, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rec >> 9) & 1u), r_trunc, v1, so, 0);
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(pu32x2{o, 0u}, r_obs, v8, so * 8u, MDPP_ST_NT);
+            else __builtin_amdgcn_raw_buffer_store_b32(o, r_obs, v4, so * 4u, MDPP_ST_NT);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * 4u, MDPP_ST_NT);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rec >> 8) & 1u), r_term, v1, so, MDPP_ST_NT);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rec >> 9) & 1u), r_trunc, v1, so, MDPP_ST_NT);
         };
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kChunk;

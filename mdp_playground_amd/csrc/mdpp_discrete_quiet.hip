@@ -351,11 +351,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     };
     auto put_obs = [&](decltype(r_obs) rs, uint32_t so, uint32_t s0, uint32_t s1) __attribute__((always_inline)) {
         if (IRR) {
-            if (OBS64) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0, 0u, s1, 0u}, rs, vobs + so * row_obs, 0, 0);   // (see kQRsrc)
-            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, s1}, rs, vobs, so * row_obs, 0);
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0, 0u, s1, 0u}, rs, vobs + so * row_obs, 0, MDPP_ST_NT);   // (see kQRsrc)
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, s1}, rs, vobs, so * row_obs, MDPP_ST_NT);
         } else {
-            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, 0u}, rs, vobs, so * row_obs, 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(s0, rs, vobs, so * row_obs, 0);
+            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{s0, 0u}, rs, vobs, so * row_obs, MDPP_ST_NT);
+            else __builtin_amdgcn_raw_buffer_store_b32(s0, rs, vobs, so * row_obs, MDPP_ST_NT);
         }
     };
 
@@ -470,9 +470,9 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
         ringbits = need ? 0u : ringbits;
         put_obs(r_obs, so, lo & 0xFFu, (lo >> 16) & 0xFFu);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so * N, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((hi >> 1) & 1u), r_trunc, v1, so * N, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so * N, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((hi >> 1) & 1u), r_trunc, v1, so * N, MDPP_ST_NT);
     };
 
     if (!DUO) {

@@ -337,11 +337,11 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         const uint32_t c0 = c & 0xFFu, c1 = (c >> 8) & 0xFFu, c2 = (c >> 16) & 0xFFu, c3 = c >> 24;
         if (OBS64) {
             // (128-bit stores: whole offset in the VGPR, see mdpp_discrete_quiet.hip on the store-data hazard)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, 0u, c1, 0u}, rs, vobs + so * row_obs, 0, 0);
-            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2, 0u, c3, 0u}, rs, vobs + 16u + so * row_obs, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, 0u, c1, 0u}, rs, vobs + so * row_obs, 0, MDPP_ST_NT);
+            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c2, 0u, c3, 0u}, rs, vobs + 16u + so * row_obs, 0, MDPP_ST_NT);
         } else {
-            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, c1, c2, c3}, rs, vobs + so * row_obs, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{c0, c1}, rs, vobs, so * row_obs, 0);
+            if (G4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0, c1, c2, c3}, rs, vobs + so * row_obs, 0, MDPP_ST_NT);
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{c0, c1}, rs, vobs, so * row_obs, MDPP_ST_NT);
         }
     };
     i32x4 pre[kPre];
@@ -422,9 +422,9 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         phase = need ? 0u : phase;
         cells = nc;
         put_cells(r_obs, so, nc);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)r), r_rew, v4, so * N * 4u, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so * N, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so * N, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)r), r_rew, v4, so * N * 4u, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so * N, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so * N, MDPP_ST_NT);
     };
     const int nfull = K / kPre;
     for (int c = 0; c < nfull; c++) {

@@ -10,6 +10,14 @@
 
 namespace mdpp {
 
+// Cache policy of the rollout kernels' OUTPUT stores (aux of the raw-buffer store builtins; 2 = nt).  Every
+// output row is written once and never read by the kernel; left at the default policy the write-back
+// traffic of these rows throttled the whole memory pipeline of the CU (cfg2 fused rollout: 147 -> 106 us
+// per launch with nt, profiles/r02_ablation_lean_kernel.txt).  NOT for the picture kernels: their 16-byte
+// stores of whole pictures ran 0.51 -> 0.44 (polygon pictures) and 0.54 -> 0.18 (continuous pictures) with nt.
+#ifndef MDPP_ST_NT
+#define MDPP_ST_NT 2
+#endif
 constexpr int kBlock = 256;         // 4 wavefronts of 64 lanes; one lane per env instance
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 constexpr uint32_t kRingPyZero = 0x7FC0DE1Au; // float32 ring slot holding Python's float 0.0
@@ -181,6 +189,8 @@ int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStr
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
+                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
+bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);

@@ -1132,7 +1132,7 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     if name == "d_cfg2":         # the benchmarked kernel itself is what the oracle sees here
-        assert a.rollout_kernel_name(T).startswith("k_discrete_rollout_pipe<"), a.rollout_kernel_name(T)
+        assert a.rollout_kernel_name(T).startswith("k_discrete_rollout_lean<"), a.rollout_kernel_name(T)
         assert a.rollout_kernel_name(1).startswith("k_discrete_rollout_fast<")
     rng = np.random.default_rng(0)
     from mdp_playground_amd import _capi as capi
@@ -1186,16 +1186,20 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
         e.close()
 
 
-def test_bench_shape_pipe_kernel_vs_oracle_every_env():
+@pytest.mark.parametrize("kernel", ["lean", "pipe"])
+def test_bench_shape_kernel_vs_oracle_every_env(kernel):
     """Exactly what `python bench.py --gpus 1 --steps 20 --warmup 5` launches (bench.WORKLOADS["cfg2"]: 65 536
-    envs, seed 0, fused launches of 512 steps, bench.make_actions(seed 12345)): k_discrete_rollout_pipe
+    envs, seed 0, fused launches of 512 steps, bench.make_actions(seed 12345)): k_discrete_rollout_lean (and
+    k_discrete_rollout_pipe, which serves the shapes lean does not, selected with NO_LEAN)
     against the oracle on EVERY env for the first launch, on every 16th env for the second launch
     (state and streams carried across launches), and the env streams' end states."""
     import bench
     wl = bench.WORKLOADS["cfg2"]
     N, F = wl["envs"], 512
     env = _venv(num_envs=N, autoreset="same_step", **wl["config"])
-    assert env.rollout_kernel_name(F).startswith("k_discrete_rollout_pipe<"), env.rollout_kernel_name(F)
+    if kernel == "pipe":
+        env.set_kernel_options("NO_LEAN")
+    assert env.rollout_kernel_name(F).startswith(f"k_discrete_rollout_{kernel}<"), env.rollout_kernel_name(F)
     acts = bench.make_actions(wl, F, N, env.device, 12345)
     init = env._obs.cpu().numpy().copy()
     res = []
@@ -1448,11 +1452,88 @@ def test_continuous_fast_kernel_other_shapes_vs_oracle(D, nrel, order):
     env.close()
 
 
+LEAN_SHAPES = {
+    # S <= 8, every L / delay / truncation branch of k_discrete_rollout_lean, one non-power-of-two S, int32 obs
+    "l3_d4": (dict(state_space_size=8, action_space_size=8, delay=4, sequence_length=3), None, "int64"),
+    "l1_d0": (dict(state_space_size=8, action_space_size=8, delay=0, sequence_length=1, terminal_state_density=0.25), None, "int64"),
+    "l2_d1_max": (dict(state_space_size=8, action_space_size=5, delay=1, sequence_length=2, terminal_state_density=0.25,
+                       reward_every_n_steps=1), 13, "int64"),
+    "l2_d3_every5": (dict(state_space_size=8, action_space_size=8, delay=3, sequence_length=2, reward_every_n_steps=5), None, "int64"),
+    "s5_l3_d2_max": (dict(state_space_size=5, action_space_size=3, delay=2, sequence_length=3), 7, "int32"),
+    "s6_l2_d0_max": (dict(state_space_size=6, action_space_size=6, delay=0, sequence_length=2, terminal_state_density=0.34), 40, "int64"),
+    "s3_l1_d32": (dict(state_space_size=3, action_space_size=2, delay=32, sequence_length=1), 9, "int32"),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(LEAN_SHAPES))
+def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape):
+    """k_discrete_rollout_lean (nibble history, v_perm transitions, one gated reward-bit table; see
+    mdpp_discrete_lean.hip) on 1024 envs, several launches with a ragged last chunk: every output and the
+    stream end states equal the pipelined and the single-role kernels of the old encoding, a strided
+    sample equals the oracle step for step, and single steps continue from the state it leaves."""
+    extra, max_steps, odt = LEAN_SHAPES[shape]
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", seed=23, **extra)
+    N, launches = 1024, 3
+    Ks = [40, 32, 77]
+    kw = dict(num_envs=N, autoreset="same_step", **cfg)
+    if max_steps:
+        kw["max_episode_steps"] = max_steps
+    if odt == "int32":
+        kw["dtype_o"] = np.int32
+    envs = [_venv(**kw) for _ in range(3)]
+    envs[1].set_kernel_options("NO_LEAN")
+    envs[2].set_kernel_options("NO_PIPE", "NO_HELPER")
+    assert envs[0].rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), envs[0].rollout_kernel_name(64)
+    assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_pipe<")
+    assert envs[2].rollout_kernel_name(64).startswith("k_discrete_rollout_fast<")
+    A = cfg["action_space_size"]
+    rng = np.random.default_rng(5)
+    init = envs[0]._obs.cpu().numpy().copy()
+    outs = []
+    for j in range(launches):
+        acts = rng.integers(0, A, size=(Ks[j], N)).astype(np.int32)
+        acts[3, 5] = -1                                   # negative index wraps (numpy semantics)
+        ta = torch.as_tensor(acts, device=envs[0].device)
+        res = [tuple(x.cpu().numpy() for x in e.rollout(ta)) for e in envs]
+        for r in res[1:]:
+            for x, y in zip(res[0], r):
+                assert np.array_equal(x, y), (shape, j)
+        outs.append((acts, res[0]))
+    st = [e.get_rng_streams(0) for e in envs]
+    assert np.array_equal(st[0], st[1]) and np.array_equal(st[0], st[2])
+    # single steps from the state the lean kernel left == single steps from the state the old kernels left
+    acts = torch.as_tensor(rng.integers(0, A, size=(N,)).astype(np.int32), device=envs[0].device)
+    for _ in range(6):
+        r = [tuple(x.cpu().numpy() for x in e.step(acts)[:4]) for e in envs]
+        for q in r[1:]:
+            for x, y in zip(r[0], q):
+                assert np.array_equal(x, y), shape
+    for i in range(0, N, 97):
+        o = _oracle_for(envs[0], i)
+        o.set_rng(envs[0].seeded_streams[0][i], envs[0].seeded_streams[1][i])
+        assert np.array_equal(o.reset(), init[i])
+        n = 0
+        for acts_j, (obs, rew, term, trunc) in outs:
+            for t in range(acts_j.shape[0]):
+                a_t = int(acts_j[t, i])
+                eo, er, ed = o.step(a_t if a_t >= 0 else a_t + A)
+                n += 1
+                tr = bool(max_steps) and n >= max_steps
+                if ed or tr:
+                    eo = o.reset()
+                    n = 0
+                assert int(obs[t, i]) == int(eo), (shape, i, t)
+                assert rew[t, i] == np.float32(er) and bool(trunc[t, i]) == tr and bool(term[t, i]) == bool(ed), (shape, i, t)
+    for e in envs:
+        assert (e.status() == 0).all()
+        e.close()
+
+
 SOAK_IRR = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 8],
                 action_space_size=[8, 8], irrelevant_features=True, delay=4, sequence_length=3)
 
 
-@pytest.mark.parametrize("name,flag", [("d_cfg2", "NO_PIPE"), ("c_cfg5", "NO_HELPER"), ("c_cfg5", "NO_PARK"),
+@pytest.mark.parametrize("name,flag", [("d_cfg2", "NO_PIPE"), ("d_cfg2", "NO_LEAN"), ("c_cfg5", "NO_HELPER"), ("c_cfg5", "NO_PARK"),
                                        ("irr", "NO_DUO"), ("irr+pn", "NO_TRIO"), ("irr+pn+rn", "NO_DUO")])
 def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     """The producer/consumer kernels (LDS rings between waves) against the single-role kernels of

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Build variants of k_discrete_rollout_pipe (macro knobs) and time them on the bench workload (GPU box).
-usage: python3 tools/ablate_pipe.py "NAME:-DMDPP_PIPE_CHUNK=16 -DMDPP_PIPE_DEPTH=64" ..."""
+"""Build variants of k_discrete_rollout_pipe / _lean (macro knobs) and time them on the bench workload (GPU box).
+usage: python3 tools/ablate_pipe.py [--file mdpp_discrete_lean.hip] "NAME:-DMDPP_PIPE_CHUNK=16 -DMDPP_PIPE_DEPTH=64" ..."""
 import os
 import subprocess
 import sys
@@ -12,14 +12,18 @@ from mdp_playground_amd import build as B  # noqa: E402
 
 
 def main():
+    src = "mdpp_discrete_pipe.hip"
+    if len(sys.argv) > 2 and sys.argv[1] == "--file":
+        src = sys.argv[2]
+        del sys.argv[1:3]
     outdir = os.path.join(ROOT, "gpurun_out", "ablate_pipe")
     os.makedirs(outdir, exist_ok=True)
-    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in B.SOURCES if s != "mdpp_discrete_pipe.hip"]
+    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in B.SOURCES if s != src]
     variants = [("base", "")] + [tuple(v.split(":", 1)) for v in sys.argv[1:]]
     for name, flags in variants:
         obj = os.path.join(outdir, f"pipe_{name}.o")
         so = os.path.join(outdir, f"libmdpp_{name}.so")
-        subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(CSRC, "mdpp_discrete_pipe.hip"), "-o", obj])
+        subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(CSRC, src), "-o", obj])
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-o", so] + objs + [obj])
         code = (f"import sys; sys.path.insert(0, {ROOT!r}); import torch\n"
                 f"from mdp_playground_amd import _capi; _capi.LIB_PATH = {so!r}\n"
