@@ -342,6 +342,9 @@ __global__ __launch_bounds__(kBlock) void k_image_obs(ImageArgs a, long M, const
 //  * waves are persistent: each walks images j, j + (waves in the grid), ... and has the next
 //    image's record (scalar loads) and template (4 dwordx4 per lane) in flight while it evaluates
 //    the current one; the stores of an image drain while the next one is evaluated.
+#ifndef MDPP_IMG_ST_AUX
+#define MDPP_IMG_ST_AUX 0
+#endif
 struct TplRegs { u32x4 v[4]; };          // a padded template (<= 64 rows x 64 B), 4 chunks per lane
 
 __device__ __forceinline__ TplRegs load_tpl(const ImageArgs &a, uint32_t tix, int lane) {
@@ -432,7 +435,7 @@ __device__ __forceinline__ void render_fast_store(const ImageArgs &a, const ColR
 #ifdef MDPP_IMG_ABL_NOSTORE
         if (v.x == 0x12345678u)
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, c * 16, 0, 0);   // beyond the descriptor: dropped
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, c * 16, 0, MDPP_IMG_ST_AUX);   // beyond the descriptor: dropped
     };
     if (NST > 0) {
 #pragma unroll

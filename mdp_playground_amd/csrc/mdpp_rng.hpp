@@ -75,8 +75,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 product each (v_mad_u64_u32: one quarter-rate instruction where
+        // __umulhi + * are two)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         const uint32_t y0 = h1 ^ c1 ^ k0, y1 = l1, y2 = h0 ^ c3 ^ k1, y3 = l0;
         c0 = y0; c1 = y1; c2 = y2; c3 = y3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

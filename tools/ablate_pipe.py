@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build variants of k_discrete_rollout_pipe / _lean (macro knobs) and time them on the bench workload (GPU box).
-usage: python3 tools/ablate_pipe.py [--file mdpp_discrete_lean.hip] "NAME:-DMDPP_PIPE_CHUNK=16 -DMDPP_PIPE_DEPTH=64" ..."""
+usage: python3 tools/ablate_pipe.py [--file mdpp_discrete_lean.hip] [--workload cfg4] "NAME:-DMDPP_PIPE_CHUNK=16 -DMDPP_PIPE_DEPTH=64" ..."""
 import os
 import subprocess
 import sys
@@ -13,8 +13,12 @@ from mdp_playground_amd import build as B  # noqa: E402
 
 def main():
     src = "mdpp_discrete_pipe.hip"
-    if len(sys.argv) > 2 and sys.argv[1] == "--file":
-        src = sys.argv[2]
+    wname, alg = "cfg2", 18
+    while len(sys.argv) > 2 and sys.argv[1] in ("--file", "--workload"):
+        if sys.argv[1] == "--file":
+            src = sys.argv[2]
+        else:
+            wname = sys.argv[2]
         del sys.argv[1:3]
     outdir = os.path.join(ROOT, "gpurun_out", "ablate_pipe")
     os.makedirs(outdir, exist_ok=True)
@@ -28,7 +32,7 @@ def main():
         code = (f"import sys; sys.path.insert(0, {ROOT!r}); import torch\n"
                 f"from mdp_playground_amd import _capi; _capi.LIB_PATH = {so!r}\n"
                 "from mdp_playground_amd import RLToyVectorEnv; import bench\n"
-                "wl = bench.WORKLOADS['cfg2']; N, F = wl['envs'], 512\n"
+                f"wl = bench.WORKLOADS[{wname!r}]; N = wl['envs']; F = min(512, wl.get('fuse_max', 512))\n"
                 "env = RLToyVectorEnv(num_envs=N, autoreset='same_step', **wl['config'])\n"
                 "acts = bench.make_actions(wl, F, N, env.device, 12345); out = env.alloc_rollout(F)\n"
                 "for _ in range(5): env.rollout(acts, out)\n"
@@ -37,7 +41,7 @@ def main():
                 "    env.timer_begin()\n"
                 "    for _ in range(20): env.rollout(acts, out)\n"
                 "    best = min(best, env.timer_end() / 20)\n"
-                f"print({name!r}, env.rollout_kernel_name(F), '%.1f us per launch' % (best * 1e3), '%.3f of 8 TB/s' % (18 * N * F / (best * 1e-3) / 8e12))\n")
+                f"print({name!r}, env.rollout_kernel_name(F), '%.1f us per launch' % (best * 1e3), '%.3f of 8 TB/s' % (wl['alg_bytes_fused'] * N * F / (best * 1e-3) / 8e12))\n")
         subprocess.check_call([sys.executable, "-c", code])
 
 
