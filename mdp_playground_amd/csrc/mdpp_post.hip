@@ -92,13 +92,18 @@ constexpr int kPostLdsDelay = 16;
 constexpr int kPostPre = 8;              // reward / done inputs in flight per lane
 constexpr int kPostUB = 8;               // k_post_image_lds: loads in flight per lane
 
-template <bool PHILOX, bool LDSRING>
+// RING = 2: delay <= 8 -- the FIFO is eight registers in pay-out order (a shift per step, no memory round
+// trip in the step at all: the LDS form spent most of a step waiting on its dependent ds_read / ds_write);
+// RING = 1: the LDS form (delay <= 16); RING = 0: slots in HBM.
+constexpr int kPostRegDelay = 8;
+template <bool PHILOX, int RING>
 __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const void *__restrict__ obs_in,
                                                       const double *__restrict__ reward_in,
                                                       const uint8_t *__restrict__ done_in, void *__restrict__ obs_out,
                                                       double *__restrict__ reward_out) {
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
+    constexpr bool LDSRING = RING == 1, REGRING = RING == 2;
     __shared__ double s_ring[LDSRING ? kPostLdsDelay * kBlock : 1];
     const bool normals = !PHILOX && ((a.continuous && a.has_p) || a.has_r);
     if (normals) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
@@ -117,6 +122,15 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
     double *ringp = LDSRING ? s_ring + threadIdx.x : a.ring + i;
     const size_t rstride = LDSRING ? (size_t)kBlock : (size_t)N;
     if (LDSRING) for (int j = 0; j < a.delay; j++) s_ring[j * kBlock + threadIdx.x] = a.ring[(size_t)j * N + i];
+    double rq[kPostRegDelay];            // REGRING: rq[0] pays out next
+    if (REGRING) {
+#pragma unroll
+        for (int j = 0; j < kPostRegDelay; j++) {
+            const uint32_t sl = head + (uint32_t)j < (uint32_t)a.delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)a.delay;
+            rq[j] = j < a.delay ? a.ring[(size_t)sl * N + i] : 0.0;
+        }
+        head = 0;
+    }
     double pre_r[kPostPre];
     uint8_t pre_d[kPostPre];
 #pragma unroll
@@ -124,15 +138,12 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
         const long oo = (long)(u < K ? u : K - 1) * N + i;
         pre_r[u] = reward_in[oo]; pre_d[u] = done_in[oo];
     }
-    for (int k0 = 0; k0 < K; k0 += kPostPre) {
-#pragma unroll
-      for (int u = 0; u < kPostPre; u++) {
-        const int k = k0 + u;
-        if (k >= K) break;
+    // one instance step; slot u of the prefetch buffers holds step k and is refilled with step k + kPostPre
+    auto step = [&](const int k, const int u, const bool refill) __attribute__((always_inline)) {
         const long o = (long)k * N + i;
         double reward = pre_r[u];
         const bool done = pre_d[u] != 0;
-        {
+        if (refill) {
             const int kn = k + kPostPre;
             const long oo = (long)(kn < K ? kn : K - 1) * N + i;
             pre_r[u] = reward_in[oo]; pre_d[u] = done_in[oo];
@@ -157,7 +168,18 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
                 return ringp[(size_t)sl * rstride] * a.scale + a.shift;
             };
             double sum;
-            if (a.delay < 8) {
+            if (REGRING) {
+                if (a.delay < 8) {
+                    sum = 0.;
+#pragma unroll
+                    for (int j = 0; j < kPostRegDelay - 1; j++) sum = j < a.delay ? sum + (rq[j] * a.scale + a.shift) : sum;
+                } else {
+                    double v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = rq[j] * a.scale + a.shift;
+                    sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                }
+            } else if (a.delay < 8) {
                 sum = 0.;
                 for (int j = 0; j < a.delay; j++) sum += val(j);
             } else {
@@ -173,9 +195,22 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
             reward += sum;
             reward += a.term * a.scale;
             if (a.autoreset) {                                                // the caller's env reset itself: reset(), :456
-                for (int j = 0; j < a.delay; j++) ringp[(size_t)j * rstride] = 0.0;
+                if (REGRING) {
+#pragma unroll
+                    for (int j = 0; j < kPostRegDelay; j++) rq[j] = 0.0;
+                } else {
+                    for (int j = 0; j < a.delay; j++) ringp[(size_t)j * rstride] = 0.0;
+                }
                 head = 0;
             }
+        } else if (REGRING) {                                                 // :415-420, FIFO as a shift register
+            const double out = rq[0];
+#pragma unroll
+            for (int j = 0; j < kPostRegDelay; j++) {
+                const double nxt = j + 1 < kPostRegDelay ? rq[j + 1] : 0.0;
+                rq[j] = j + 1 == a.delay ? reward : nxt;
+            }
+            reward = out;
         } else if (a.delay > 0) {                                             // :415-420
             double *slot = ringp + (size_t)head * rstride;
             const double out = *slot;
@@ -187,10 +222,23 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
         reward += nz;                                                         // :430-432
         reward *= a.scale;
         reward += a.shift;
-        reward_out[o] = reward;
-      }
+        __builtin_nontemporal_store(reward, &reward_out[o]);                 // (written once, not read here)
+    };
+    // Single-exit loop over full groups, the ragged tail outside it: with a `break` in the unrolled body the
+    // compiler waits for EVERY load in flight at the loop head (s_waitcnt vmcnt(0)) and the prefetch is void.
+    const int kfull = K - K % kPostPre;
+    for (int k0 = 0; k0 < kfull; k0 += kPostPre) {
+#pragma unroll
+        for (int u = 0; u < kPostPre; u++) step(k0 + u, u, true);
     }
+#pragma unroll
+    for (int u = 0; u < kPostPre - 1; u++)
+        if (kfull + u < K) step(kfull + u, u, false);
     if (LDSRING) for (int j = 0; j < a.delay; j++) a.ring[(size_t)j * N + i] = s_ring[j * kBlock + threadIdx.x];
+    if (REGRING) {
+#pragma unroll
+        for (int j = 0; j < kPostRegDelay; j++) if (j < a.delay) a.ring[(size_t)j * N + i] = rq[j];
+    }
     if (a.delay > 0) a.head[i] = head;
     if constexpr (!PHILOX) {
         if (draws) { g.store(a.rng_s, i); a.half[i] = make_uint2(hf.has32, hf.u32); }
@@ -579,11 +627,11 @@ extern "C" int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, con
     if (h->cfg.image) { rc = ensure_place(h, (size_t)K * h->cfg.num_envs); if (rc) return rc; }
     PostArgs a = make_args(h);
     const int grid = (a.N + kBlock - 1) / kBlock;
-    const bool ldsring = a.delay >= 1 && a.delay <= kPostLdsDelay;
+    const int ring = a.delay >= 1 && a.delay <= kPostRegDelay ? 2 : (a.delay >= 1 && a.delay <= kPostLdsDelay ? 1 : 0);
 #define MDPP_POST_LAUNCH(PH, LR) hipLaunchKernelGGL((k_post_step<PH, LR>), dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, \
                                                     reward_in_dev, done_dev, obs_out_dev, reward_out_dev)
-    if (a.philox) { if (ldsring) MDPP_POST_LAUNCH(true, true); else MDPP_POST_LAUNCH(true, false); }
-    else { if (ldsring) MDPP_POST_LAUNCH(false, true); else MDPP_POST_LAUNCH(false, false); }
+    if (a.philox) { if (ring == 2) MDPP_POST_LAUNCH(true, 2); else if (ring == 1) MDPP_POST_LAUNCH(true, 1); else MDPP_POST_LAUNCH(true, 0); }
+    else { if (ring == 2) MDPP_POST_LAUNCH(false, 2); else if (ring == 1) MDPP_POST_LAUNCH(false, 1); else MDPP_POST_LAUNCH(false, 0); }
 #undef MDPP_POST_LAUNCH
     if (h->cfg.image) launch_post_image(h, a, (long)K * a.N, obs_in_dev, obs_out_dev, s);
     PHIP(h, hipGetLastError());

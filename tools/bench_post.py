@@ -13,13 +13,14 @@ import torch  # noqa: E402
 from mdp_playground_amd.post import VectorPostProcessor  # noqa: E402
 
 WORKLOADS = {
-    # reward in 8 + done 1 + reward out 8 + FIFO slot read 8 + write 8
-    "post_disc": dict(N=65536, K=256, alg=33, args=dict(n_actions=8),
+    # reward in 8 + done 1 + reward out 8 (the FIFO of delayed rewards lives in registers / LDS for the call since
+    # round 2: its slots are not HBM traffic any more; round-2 lines before that counted 33 B)
+    "post_disc": dict(N=65536, K=256, alg=17, args=dict(n_actions=8),
                       cfg=dict(state_space_type="discrete", delay=4, reward_scale=2.0, reward_shift=-1.0, seed=0)),
-    "post_disc_noise": dict(N=65536, K=256, alg=33, args=dict(n_actions=8),
+    "post_disc_noise": dict(N=65536, K=256, alg=17, args=dict(n_actions=8),
                             cfg=dict(state_space_type="discrete", delay=4, reward_noise=0.1, reward_scale=2.0, seed=0)),
     # + observations float32[12] in and out
-    "post_cont_noise": dict(N=65536, K=128, alg=33 + 96, args=dict(obs_shape=(12,), obs_dtype=np.float32),
+    "post_cont_noise": dict(N=65536, K=128, alg=17 + 96, args=dict(obs_shape=(12,), obs_dtype=np.float32),
                             cfg=dict(state_space_type="continuous", delay=4, transition_noise=0.05, reward_noise=0.05, seed=0)),
     # Atari-sized frames: 84 x 84 x 3 in, 124 x 124 x 3 out (image_padding 20), shift drawn per frame
     "post_img": dict(N=4096, K=8, alg=17 + 84 * 84 * 3 + 124 * 124 * 3, args=dict(n_actions=6, obs_shape=(84, 84, 3)),
