@@ -497,8 +497,8 @@ def committed_traffic(workload, rng, N, F, kname):
     WRITE_SIZE in separate passes, gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md) and committed
     under profiles/; a record is used only for the launch shape AND kernel it was measured on."""
     tag = workload if rng == "numpy" else f"{workload}_{rng}"
-    for rnd in ("r02", "r01"):
-        tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{tag}.json")
+    for name in (f"r02_traffic_{tag}.json", f"r02_traffic_{tag}_pipe.json", f"r01_traffic_{tag}.json"):
+        tfile = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tfile):
             continue
         t = json.load(open(tfile))

@@ -11,7 +11,7 @@ def test_committed_traffic_is_keyed_by_shape_and_kernel():
     t, src = bench.committed_traffic("cfg2", "numpy", 65536, 512, "k_discrete_rollout_lean<OBS64=1,DELAY=1,HASMAX=0,EVN=1>")
     assert src == "r02_traffic_cfg2.json" and 6.0e8 < t < 6.4e8                 # 18.5 B x 65 536 x 512
     t, src = bench.committed_traffic("cfg2", "numpy", 65536, 512, "k_discrete_rollout_pipe<OBS64=1,POW2=1,DELAY=1,S8=1>")
-    assert src == "r01_traffic_cfg2.json" and 6.0e8 < t < 6.3e8                 # the round-1 record of that kernel
+    assert src == "r02_traffic_cfg2_pipe.json" and 6.0e8 < t < 6.3e8            # the record of that kernel
     assert bench.committed_traffic("cfg2", "numpy", 65536, 512, "k_discrete_step<PHILOX=0>")[0] is None     # another kernel
     assert bench.committed_traffic("cfg2", "numpy", 4096, 512, "k_discrete_rollout_pipe<>")[0] is None      # another batch
     t5, src5 = bench.committed_traffic("cfg5", "philox", 65536, 512, "k_continuous_rollout_fast<D=12,...>")
