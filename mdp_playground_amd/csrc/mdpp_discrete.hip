@@ -394,7 +394,36 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
     a.ptick = h->tick;
     a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     const bool noise = a.has_p_noise || a.has_r_noise;
-    if (a.fast_ok) {
+    // Philox handles of the common shape: k_discrete_rollout_lean with its H waves on Philox blocks
+    // (mdpp_discrete_lean.hip); pieces it does not take (a short last one) go to the quiet kernel
+    bool lean_philox = false;
+    if (!a.fast_ok && a.philox && a.shape_ok) {
+        const long long kmax = ((1LL << 32) - 1) / (8LL * a.N);
+        char dry[kNameLen];
+        const int k_first = (int)(K < kmax ? K : kmax);
+        if (kmax >= 32 && launch_discrete_lean(a, k_first, actions, obs, reward, term, trunc, nullptr, s, dry)) {
+            lean_philox = true;
+            const size_t osz = a.obs_i32 ? 4 : 8;
+            for (int k0 = 0; k0 < K;) {
+                const int kc = (int)((K - k0) < kmax ? (K - k0) : kmax);
+                const size_t off = (size_t)k0 * a.N;
+                a.ptick = h->tick + (uint64_t)k0;
+                a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u;
+                const size_t aoff = off;      // (shape_ok: no irrelevant sub-space, one action per env step)
+                if (!launch_discrete_lean(a, kc, actions + aoff, (char *)obs + off * osz, reward + off, term + off,
+                                          trunc + off, nullptr, s, name_out) &&
+                    !launch_discrete_quiet(a, kc, actions + aoff, (char *)obs + off * osz, reward + off, term + off,
+                                           trunc + off, nullptr, s, name_out)) {
+                    h->err = "k_discrete_rollout_lean: no kernel for the last piece of the rollout";
+                    return MDPP_EUNSUPPORTED;
+                }
+                if (name_out) return MDPP_OK;
+                k0 += kc;
+            }
+        }
+    }
+    if (lean_philox) {
+    } else if (a.fast_ok) {
         // common shape: dedicated rollout kernel (mdpp_discrete_fast.hip); its buffer descriptors
         // address < 4 GiB per output array, so very long rollouts go out as several launches
         const long long kmax = ((1LL << 32) - 1) / (8LL * a.N);

@@ -75,6 +75,7 @@ constexpr int kPRsrc = 0x00020000;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kStatusInternal = 0x80000000u;
 constexpr uint32_t kQueueCap = 6;
+constexpr int kHChunks = 8;               // Philox streams: H runs up to this many chunks ahead of E
 constexpr int kRoles = 4;                 // E, O1 (reward path), O2 (observation / flag stores), H
 constexpr uint32_t kSelPad = 0x0c0c0c00u; // v_perm_b32 selector bytes 1-3: constant 0x00
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -88,7 +89,7 @@ __device__ __forceinline__ void wg_store_rel(uint32_t *p, uint32_t v) {
 } // namespace lean
 using namespace lean;
 
-template <bool OBS64, bool DELAY, bool HASMAX, bool EVN>
+template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX>
 __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(DiscreteArgs a, int K,
                                                                       const int32_t *__restrict__ actions,
                                                                       void *__restrict__ obs,
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ uint32_t lds_prod[kBlock / 64];                // steps published by E wave w
     __shared__ __align__(8) uint32_t lds_cons[kBlock / 64][2]; // steps consumed by the O1 / O2 wave w
     __shared__ uint32_t lds_done;                             // E waves that have finished
+    __shared__ __align__(16) uint32_t lds_s0[PHILOX ? kHChunks : 1][kBlock];   // Philox: H -> E, the chunk's 8 start states
+    __shared__ uint32_t lds_hprod[kBlock / 64];               // Philox: chunks published by H wave w
     const int tid = threadIdx.x;
     const int role = tid / kBlock;                  // 0 = E, 1 = O1, 2 = O2, 3 = H
     const int l = tid & (kBlock - 1);               // env slot inside the block
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         lds_R[k] = wd;
     }
     if (tid < kBlock) { lds_ring[tid] = 0; lds_head[tid] = 0; }
-    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; }
+    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; }
     if (tid == 0) lds_done = 0;
     __syncthreads();
     {   // lds_V: dword d holds indices 32 d .. 32 d + 31; nibble j of an index = (d * 32 + b) >> 4 j.
@@ -179,6 +182,38 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NOH
         return;
 #endif
+        if constexpr (PHILOX) {
+            // Philox streams: the start state a reset at tick t draws is a function of (seed, env, t) alone
+            // (first 64 bits of block 0 of the env stream, as in k_discrete_step / _quiet), so H makes the one
+            // of EVERY tick, a chunk of 8 at a time (independent blocks), packed as 8 nibbles | 8
+            const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);
+            const int nch = (K + kChunk - 1) / kChunk;
+            for (int c = 0; c < nch; c++) {
+                if (c >= kHChunks) {                             // slot c % kHChunks: E must be through chunk c - kHChunks
+                    const uint32_t must = (uint32_t)min((c - kHChunks + 1) * kChunk, K);
+                    uint32_t spins = 0;
+                    while (wg_load_acq(&lds_prod[w]) < must) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+                    }
+                }
+                uint32_t pk = 0;
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    Philox ge;
+                    ge.init(a.philox_seed, genv, a.ptick + (uint64_t)(c * kChunk + u), MDPP_STREAM_ENV);
+                    const uint64_t m = ge.next64() >> 11;
+                    uint32_t s0 = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
+                    pk |= (s0 | 8u) << (4 * u);
+                }
+                lds_s0[c % kHChunks][l] = pk;
+                if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)(c + 1));
+            }
+            if (status) atomicOr(&a.status[i], status);
+            return;
+        }
         Pcg64 g;
         g.load(a.env_s, a.env_inc, i);
         auto draw = [&](Pcg64 &gg) -> uint32_t {
@@ -374,8 +409,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const uint32_t b = (st.x >> (8 * j)) & 0xFFu;
             k2 = (k2 << 4) | (b == 0xFFu ? 0u : ((b & 7u) | 8u));
         }
-        const uint32_t qc = (st.y >> 24) & 7u;
-        qv = (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u));
+        const uint32_t qc = PHILOX ? 0u : (st.y >> 24) & 7u;
+        qv = PHILOX ? 0u : (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u));
         steps0 = st.z;
         const uint32_t ms = (uint32_t)a.max_steps;
         cnt = HASMAX ? (0x10000u - ms) + (steps0 < ms ? steps0 : ms) : 0u;
@@ -384,10 +419,19 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     const uint32_t c0 = HASMAX ? 0x10000u - (uint32_t)a.max_steps : 0u;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * 4u, kPRsrc);
     const uint32_t v4 = i * 4u;
-    uint32_t head_local = 0;
+    uint32_t head_local = 0, s0c = 0;
     uint32_t sel = (k2 & 7u) | kSelPad;
 
-    auto pull = [&]() {
+    auto pull = [&](int c) {
+        if constexpr (PHILOX) {                     // this chunk's start states, made by the H wave
+            uint32_t spins = 0;
+            while (wg_load_acq(&lds_hprod[w]) < (uint32_t)(c + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+            }
+            s0c = lds_s0[c % kHChunks][l];
+            return;
+        }
         const uint64_t rt = __hip_atomic_load(&lds_ring[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t vals = (uint32_t)rt, tail = (uint32_t)(rt >> 32);
         const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x88888888u);
@@ -423,11 +467,11 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NORESET
         need = false;
 #endif
-        uint32_t s0v = qv & 0xFu;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
+        uint32_t s0v = PHILOX ? (s0c >> (4 * (k % kChunk))) & 0xFu : qv & 0xFu;
+        if (!PHILOX && __builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
             uint32_t spins = 0;
             while (__builtin_amdgcn_ballot_w64(need && (qv & 0xFu) == 0u) != 0) {
-                pull();
+                pull(0);
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; qv |= 8u; break; }
             }
@@ -439,7 +483,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             ph = (need || ph == 0u) ? ph_full : ph;
         }
         k2 = need ? s0v : k2n;
-        qv = need ? (qv >> 4) : qv;
+        if (!PHILOX) qv = need ? (qv >> 4) : qv;
         if (HASMAX) cnt = need ? c0 : cnt;
         else last_reset = need ? (uint32_t)(k + 1) : last_reset;
         sel = (k2 & 7u) | kSelPad;
@@ -492,7 +536,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             for (int u = 0; u < kChunk; u++) actq[j][u] = load_act(kbase + (kAhead + 1) * kChunk + u);
         }
         wait_room(kbase + kChunk);
-        pull();
+        pull(c);
 #pragma unroll
         for (int u = 0; u < kChunk; u++) stepE(colq[j & 1][u], kbase + u);
         if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)(kbase + kChunk));
@@ -513,7 +557,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #pragma unroll
         for (int u = 0; u < kChunk; u++) ta[u] = load_act(kbase + u);
         wait_room(kbase + kChunk);
-        pull();
+        pull(nfull);
 #pragma unroll
         for (int u = 0; u < kChunk; u++)
             if (kbase + u < K) stepE(column(ta[u]), kbase + u);
@@ -531,7 +575,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     if (HASMAX) steps = cnt - c0;
     else steps = last_reset ? (uint32_t)K - last_reset : steps0 + (uint32_t)K;
     uint32_t *st = (uint32_t *)&a.state[i];
-    st[0] = hist; st[1] = (qv & 0x00777777u) | (qc << 24); st[2] = steps;   // word 3 (delay line) belongs to the O lane
+    st[0] = hist; st[2] = steps;                    // word 3 (delay line) belongs to the O1 lane
+    if (!PHILOX) st[1] = (qv & 0x00777777u) | (qc << 24);   // (Philox handles: word 1 is older history, unused at L <= 3)
     if ((l & 63) == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (status) atomicOr(&a.status[i], status);
 }
@@ -540,18 +585,24 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                           hipStream_t s, char *name_out) {
-    if (!a.fast_ok || K < 32 || (a.N % kBlock) != 0 || !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
+    const bool ph = a.philox != 0;
+    if (!(ph ? (a.shape_ok && !(a.opts & MDPP_OPT_NO_PHILOX_FAST)) : a.fast_ok) || K < 32 || (a.N % kBlock) != 0 ||
+        !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
     if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
     const int grid = a.N / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d>", !a.obs_i32, dl, hm, evn);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d>", !a.obs_i32, dl, hm, evn, ph);
         return true;
     }
-#define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                          \
-    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV>), dim3(grid), dim3(kRoles * kBlock), \
-                       0, s, a, K, actions, obs, reward, term, trunc, final_obs)
+#define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                                   \
+    do {                                                                                                   \
+        if (ph) hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, true>), dim3(grid), dim3(kRoles * kBlock), \
+                                   0, s, a, K, actions, obs, reward, term, trunc, final_obs);              \
+        else hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, false>), dim3(grid), dim3(kRoles * kBlock), \
+                                0, s, a, K, actions, obs, reward, term, trunc, final_obs);                 \
+    } while (0)
 #define MDPP_LEAN_L3(O64, DL, HM) do { if (evn) MDPP_LEAN_LAUNCH(O64, DL, HM, true); else MDPP_LEAN_LAUNCH(O64, DL, HM, false); } while (0)
 #define MDPP_LEAN_L2(O64, DL) do { if (hm) MDPP_LEAN_L3(O64, DL, true); else MDPP_LEAN_L3(O64, DL, false); } while (0)
     if (a.obs_i32) { if (dl) MDPP_LEAN_L2(false, true); else MDPP_LEAN_L2(false, false); }

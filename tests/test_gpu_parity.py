@@ -1465,8 +1465,9 @@ LEAN_SHAPES = {
 }
 
 
+@pytest.mark.parametrize("rng_mode", ["numpy", "philox"])
 @pytest.mark.parametrize("shape", sorted(LEAN_SHAPES))
-def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape):
+def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
     """k_discrete_rollout_lean (nibble history, v_perm transitions, one gated reward-bit table; see
     mdpp_discrete_lean.hip) on 1024 envs, several launches with a ragged last chunk: every output and the
     stream end states equal the pipelined and the single-role kernels of the old encoding, a strided
@@ -1475,17 +1476,24 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape):
     cfg = dict(state_space_type="discrete", action_space_type="discrete", seed=23, **extra)
     N, launches = 1024, 3
     Ks = [40, 32, 77]
-    kw = dict(num_envs=N, autoreset="same_step", **cfg)
+    kw = dict(num_envs=N, autoreset="same_step", rng=rng_mode, **cfg)
     if max_steps:
         kw["max_episode_steps"] = max_steps
     if odt == "int32":
         kw["dtype_o"] = np.int32
     envs = [_venv(**kw) for _ in range(3)]
-    envs[1].set_kernel_options("NO_LEAN")
-    envs[2].set_kernel_options("NO_PIPE", "NO_HELPER")
     assert envs[0].rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), envs[0].rollout_kernel_name(64)
-    assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_pipe<")
-    assert envs[2].rollout_kernel_name(64).startswith("k_discrete_rollout_fast<")
+    if rng_mode == "numpy":
+        envs[1].set_kernel_options("NO_LEAN")
+        envs[2].set_kernel_options("NO_PIPE", "NO_HELPER")
+        assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_pipe<")
+        assert envs[2].rollout_kernel_name(64).startswith("k_discrete_rollout_fast<")
+    else:       # Philox streams: the H waves make every tick's start state; against the quiet and the general kernel
+        assert envs[0].rollout_kernel_name(64).endswith("PHILOX=1>")
+        envs[1].set_kernel_options("NO_LEAN")
+        envs[2].set_kernel_options("NO_PHILOX_FAST")
+        assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_quiet<")
+        assert envs[2].rollout_kernel_name(64).startswith("k_discrete_step<")
     A = cfg["action_space_size"]
     rng = np.random.default_rng(5)
     init = envs[0]._obs.cpu().numpy().copy()
@@ -1499,8 +1507,9 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape):
             for x, y in zip(res[0], r):
                 assert np.array_equal(x, y), (shape, j)
         outs.append((acts, res[0]))
-    st = [e.get_rng_streams(0) for e in envs]
-    assert np.array_equal(st[0], st[1]) and np.array_equal(st[0], st[2])
+    if rng_mode == "numpy":
+        st = [e.get_rng_streams(0) for e in envs]
+        assert np.array_equal(st[0], st[1]) and np.array_equal(st[0], st[2])
     # single steps from the state the lean kernel left == single steps from the state the old kernels left
     acts = torch.as_tensor(rng.integers(0, A, size=(N,)).astype(np.int32), device=envs[0].device)
     for _ in range(6):
@@ -1508,7 +1517,7 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape):
         for q in r[1:]:
             for x, y in zip(r[0], q):
                 assert np.array_equal(x, y), shape
-    for i in range(0, N, 97):
+    for i in (range(0, N, 97) if rng_mode == "numpy" else []):      # (Philox: the general kernel above is held to the oracle elsewhere)
         o = _oracle_for(envs[0], i)
         o.set_rng(envs[0].seeded_streams[0][i], envs[0].seeded_streams[1][i])
         assert np.array_equal(o.reset(), init[i])
@@ -1590,7 +1599,8 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
      "NO_PHILOX_FAST", 32768, 48),
     ("cfg3", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 64),
     ("cfg2_noise", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),
-    ("cfg2", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),
+    ("cfg2", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),     # lean kernel, H waves on Philox blocks, vs general
+    ("cfg2", {"rng": "philox"}, "NO_LEAN", 65536, 128),            # ... vs the quiet kernel's producer waves
     ("cfg2_irr", {"rng": "philox", "transition_noise": 0.1, "reward_noise": 0.2}, "NO_PHILOX_FAST", 32768, 64),
     ("grid", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),
     ("grid", {"rng": "philox", "irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "NO_PHILOX_FAST", 32768, 128),
