@@ -171,8 +171,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #else
     const uint32_t eblk = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 #endif
-    const uint32_t i = eblk * kBlock + l;           // N % kBlock == 0 is a launch precondition
+    const uint32_t i = eblk * kBlock + l;
     const uint32_t N = (uint32_t)a.N;
+    if (i >= N) {                                   // ragged last block: its spare lanes leave (every wave that stays keeps
+        // lane 0, which publishes the hand-off counters; no barrier follows); an E wave that leaves entirely counts as done
+        if (role == 0 && (l & 63) == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
     const uint32_t A = (uint32_t)a.A;
     constexpr int kMinLanes = 16;
     uint32_t status = 0;
@@ -586,11 +591,11 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                           hipStream_t s, char *name_out) {
     const bool ph = a.philox != 0;
-    if (!(ph ? (a.shape_ok && !(a.opts & MDPP_OPT_NO_PHILOX_FAST)) : a.fast_ok) || K < 32 || (a.N % kBlock) != 0 ||
+    if (!(ph ? (a.shape_ok && !(a.opts & MDPP_OPT_NO_PHILOX_FAST)) : a.fast_ok) || K < 32 || a.N < kBlock ||
         !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
     if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
-    const int grid = a.N / kBlock;
+    const int grid = (a.N + kBlock - 1) / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
     if (name_out) {
         snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d>", !a.obs_i32, dl, hm, evn, ph);

@@ -172,8 +172,13 @@ def test_kernel_names_and_options():
     b.set_kernel_options()
     assert b.rollout_kernel_name(512) == a.rollout_kernel_name(512)
     a.close(); b.close()
-    c = _venv(num_envs=1000, autoreset="same_step", **cfg)                         # ragged batch: no pipe
+    c = _venv(num_envs=1000, autoreset="same_step", **cfg)                         # ragged batch: lean takes it, pipe does not
+    assert c.rollout_kernel_name(512).startswith("k_discrete_rollout_lean<")
+    c.set_kernel_options("NO_LEAN")
     assert c.rollout_kernel_name(512).startswith("k_discrete_rollout_fast<")
+    d = _venv(num_envs=200, autoreset="same_step", **cfg)                          # less than one block: single-role kernel
+    assert d.rollout_kernel_name(512).startswith("k_discrete_rollout_fast<")
+    d.close()
     c.close()
     d = _venv(num_envs=512, rng="philox", **cfg)
     assert "k_discrete" in d.rollout_kernel_name(64)
