@@ -397,8 +397,8 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
     // Philox handles of the common shape: k_discrete_rollout_lean with its H waves on Philox blocks
     // (mdpp_discrete_lean.hip); pieces it does not take (a short last one) go to the quiet kernel
     bool lean_philox = false;
-    if (!a.fast_ok && a.philox && a.shape_ok) {
-        const long long kmax = ((1LL << 32) - 1) / (8LL * a.N);
+    if (!a.fast_ok && ((a.philox && a.shape_ok) || a.shape_ok_irr)) {
+        const long long kmax = ((1LL << 32) - 1) / ((a.irr ? 16LL : 8LL) * a.N);
         char dry[kNameLen];
         const int k_first = (int)(K < kmax ? K : kmax);
         if (kmax >= 32 && launch_discrete_lean(a, k_first, actions, obs, reward, term, trunc, nullptr, s, dry)) {
@@ -409,11 +409,10 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
                 const size_t off = (size_t)k0 * a.N;
                 a.ptick = h->tick + (uint64_t)k0;
                 a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u;
-                const size_t aoff = off;      // (shape_ok: no irrelevant sub-space, one action per env step)
-                if (!launch_discrete_lean(a, kc, actions + aoff, (char *)obs + off * osz, reward + off, term + off,
-                                          trunc + off, nullptr, s, name_out) &&
-                    !launch_discrete_quiet(a, kc, actions + aoff, (char *)obs + off * osz, reward + off, term + off,
-                                           trunc + off, nullptr, s, name_out)) {
+                const size_t aoff = off * (a.irr ? 2 : 1);     // (an irrelevant sub-space: action pairs, observation pairs)
+                char *op = (char *)obs + off * osz * (a.irr ? 2 : 1);
+                if (!launch_discrete_lean(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, nullptr, s, name_out) &&
+                    !launch_discrete_quiet(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, nullptr, s, name_out)) {
                     h->err = "k_discrete_rollout_lean: no kernel for the last piece of the rollout";
                     return MDPP_EUNSUPPORTED;
                 }

@@ -38,6 +38,8 @@
 
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -79,6 +81,7 @@ constexpr int kHChunks = 8;               // Philox streams: H runs up to this m
 constexpr int kRoles = 4;                 // E, O1 (reward path), O2 (observation / flag stores), H
 constexpr uint32_t kSelPad = 0x0c0c0c00u; // v_perm_b32 selector bytes 1-3: constant 0x00
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t wg_load_acq(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -89,7 +92,7 @@ __device__ __forceinline__ void wg_store_rel(uint32_t *p, uint32_t v) {
 } // namespace lean
 using namespace lean;
 
-template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX>
+template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX, bool IRR>
 __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(DiscreteArgs a, int K,
                                                                       const int32_t *__restrict__ actions,
                                                                       void *__restrict__ obs,
@@ -111,8 +114,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ uint32_t lds_prod[kBlock / 64];                // steps published by E wave w
     __shared__ __align__(8) uint32_t lds_cons[kBlock / 64][2]; // steps consumed by the O1 / O2 wave w
     __shared__ uint32_t lds_done;                             // E waves that have finished
-    __shared__ __align__(16) uint32_t lds_s0[PHILOX ? kHChunks : 1][kBlock];   // Philox: H -> E, the chunk's 8 start states
+    typedef typename std::conditional<IRR, uint64_t, uint32_t>::type S0Word;   // a nibble per tick; with an irrelevant sub-space two
+    __shared__ __align__(16) S0Word lds_s0[PHILOX ? kHChunks : 1][kBlock];     // Philox: H -> E, the chunk's 8 start states
+    __shared__ __align__(16) uint2 lds_col1[IRR ? 16 : 1];    // irrelevant sub-space: action a1, byte s1: P1[s1][a1]
+    __shared__ __align__(16) uint64_t lds_T1[IRR ? 8 : 1];    // its rho_0 thresholds
     __shared__ uint32_t lds_hprod[kBlock / 64];               // Philox: chunks published by H wave w
+    constexpr int kEN = IRR ? 2 : 1;                // nibbles per start-state entry (relevant, irrelevant)
     const int tid = threadIdx.x;
     const int role = tid / kBlock;                  // 0 = E, 1 = O1, 2 = O2, 3 = H
     const int l = tid & (kBlock - 1);               // env slot inside the block
@@ -127,6 +134,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             }
         lds_col[tid] = make_uint2((uint32_t)cs, (uint32_t)(cs >> 32));
         if (tid < 8) lds_T[tid] = a.init_thr[tid];
+        if (IRR) {                                              // (:2028-2035, :2063-2082, reset :2259-2264)
+            uint64_t c1 = 0;
+            if (tid < a.A1)
+                for (int s1 = 0; s1 < a.S1; s1++) c1 |= (uint64_t)(a.P1[s1 * a.A1 + tid] & 7u) << (8 * s1);
+            lds_col1[tid] = make_uint2((uint32_t)c1, (uint32_t)(c1 >> 32));
+            if (tid < 8) lds_T1[tid] = tid < a.S1 ? (uint64_t)ceil(a.init_cdf1[tid] * 9007199254740992.0) : ~0ULL;
+        }
         if (!EVN && tid < 4) lds_rsel[tid] = a.rsel[tid];
     }
     if (EVN)                                                  // only pay steps hand out the bit (:1975-1976)
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                         if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
                     }
                 }
-                uint32_t pk = 0;
+                S0Word pk = 0;
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
                     Philox ge;
@@ -211,7 +225,14 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     uint32_t s0 = 0;
 #pragma unroll
                     for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
-                    pk |= (s0 | 8u) << (4 * u);
+                    if (IRR) {                                   // the irrelevant start state: the same block's second half
+                        const uint64_t m1 = ge.next64() >> 11;
+                        uint32_t s1 = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) s1 += (lds_T1[j] <= m1) ? 1u : 0u;
+                        s0 |= (s1 | 8u) << 4;
+                    }
+                    pk |= (S0Word)(s0 | 8u) << (kEN * 4 * u);
                 }
                 lds_s0[c % kHChunks][l] = pk;
                 if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)(c + 1));
@@ -226,6 +247,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             uint32_t s0 = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
+            if (IRR) {                                           // relevant, then irrelevant, like reset() (:2255-2264)
+                const uint64_t m1 = gg.next64() >> 11;
+                uint32_t s1 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) s1 += (lds_T1[j] <= m1) ? 1u : 0u;
+                s0 |= (s1 | 8u) << 4;
+            }
             return s0;
         };
         uint32_t vals = 0, tail = 0;
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             if (wg_load_acq(&lds_done) == kBlock / 64) break;
             const uint32_t head = wg_load_acq(&lds_head[l]);
             const uint32_t cnt = tail - head;
-            const bool want = cnt < 8;
+            const bool want = cnt + (uint32_t)kEN <= 8u;
             const uint64_t bw = __builtin_amdgcn_ballot_w64(want);
             const bool urgent = __builtin_amdgcn_ballot_w64(want && cnt <= 2) != 0;
             if (__builtin_popcountll(bw) >= kMinLanes || urgent) {
@@ -242,8 +270,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 if (want) {
                     const uint32_t sh = (tail & 7u) * 4u;
                     g = n;
-                    vals = (vals & ~(0xFu << sh)) | (s0 << sh);
-                    tail += 1;
+                    vals = (vals & ~((IRR ? 0xFFu : 0xFu) << sh)) | (s0 << sh);
+                    tail += (uint32_t)kEN;                       // (in nibbles = in draws of the stream)
                 }
                 __hip_atomic_store(&lds_ring[l], (uint64_t)vals | ((uint64_t)tail << 32), __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -285,7 +313,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             } else {
                 out = bit & 1u;
             }
-            const uint32_t tb = HASMAX ? (rc & 1u) : rc;
+            const uint32_t tb = (HASMAX || IRR) ? (rc & 1u) : rc;
             const float rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
                                    : *(const float *)(rselb + (((out << 1) | tb) << 2));
 #if defined(MDPP_ABL_NOSTORE) || defined(MDPP_ABL_NOREW)
@@ -332,13 +360,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // =============================================================== O2: observation, terminated, truncated
     if (role == 2) {
         __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O);
-        auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u), kPRsrc);
+        auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
         auto r_fin = __builtin_amdgcn_make_buffer_rsrc(final_obs ? final_obs : obs, 0,
                                                        total * (OBS64 ? 8u : 4u), kPRsrc);
         const bool want_final = final_obs != nullptr;
-        const uint32_t v1 = i, v4 = i * 4u, v8 = i * 8u;
+        const uint32_t v1 = i, v4 = i * 4u, v8 = i * 8u, v16 = i * 16u;
         auto emit = [&](uint32_t rb, uint32_t rc, uint32_t so) {
             const uint32_t o = rb & 7u;
 #ifdef MDPP_ABL_NOSTORE
@@ -348,7 +376,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NOOBS
             status ^= o & 0x100u;
 #else
-            if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{o, 0u}, r_obs, v8, so * 8u, MDPP_LEAN_ST_AUX);
+            if (IRR) {
+                const uint32_t o1 = (rc >> 8) & 7u;
+                // (128-bit stores: the whole offset in the VGPR, see the store-data hazard note in mdpp_discrete_quiet.hip)
+                if (OBS64) __builtin_amdgcn_raw_buffer_store_b128(u32x4{o, 0u, o1, 0u}, r_obs, v16 + so * 16u, 0, MDPP_LEAN_ST_AUX);
+                else __builtin_amdgcn_raw_buffer_store_b64(u32x2{o, o1}, r_obs, v8, so * 8u, MDPP_LEAN_ST_AUX);
+            } else if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{o, 0u}, r_obs, v8, so * 8u, MDPP_LEAN_ST_AUX);
             else __builtin_amdgcn_raw_buffer_store_b32(o, r_obs, v4, so * 4u, MDPP_LEAN_ST_AUX);
 #endif
 #ifdef MDPP_ABL_NOBYTES
@@ -414,18 +447,21 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const uint32_t b = (st.x >> (8 * j)) & 0xFFu;
             k2 = (k2 << 4) | (b == 0xFFu ? 0u : ((b & 7u) | 8u));
         }
-        const uint32_t qc = PHILOX ? 0u : (st.y >> 24) & 7u;
-        qv = PHILOX ? 0u : (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u));
+        const uint32_t qc = (PHILOX || IRR) ? 0u : (st.y >> 24) & 7u;
+        qv = (PHILOX || IRR) ? 0u : (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u));
         steps0 = st.z;
         const uint32_t ms = (uint32_t)a.max_steps;
         cnt = HASMAX ? (0x10000u - ms) + (steps0 < ms ? steps0 : ms) : 0u;
         if (EVN) ph = ph_full - 16u * (steps0 % (uint32_t)a.every_n);
     }
     const uint32_t c0 = HASMAX ? 0x10000u - (uint32_t)a.max_steps : 0u;
-    auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * 4u, kPRsrc);
-    const uint32_t v4 = i * 4u;
-    uint32_t head_local = 0, s0c = 0;
+    auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * 4u * (uint32_t)kEN, kPRsrc);
+    const uint32_t v4 = i * 4u * (uint32_t)kEN;
+    uint32_t head_local = 0;
+    S0Word s0c = 0;
     uint32_t sel = (k2 & 7u) | kSelPad;
+    uint32_t c1 = IRR ? (a.irr_state[i] & 7u) : 0u;                 // the irrelevant part of curr_state
+    const uint32_t A1 = IRR ? (uint32_t)a.A1 : 1u;
 
     auto pull = [&](int c) {
         if constexpr (PHILOX) {                     // this chunk's start states, made by the H wave
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         const uint64_t rt = __hip_atomic_load(&lds_ring[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t vals = (uint32_t)rt, tail = (uint32_t)(rt >> 32);
         const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x88888888u);
-        const uint32_t avail = tail - head_local, room = kQueueCap - qc;
+        const uint32_t avail = tail - head_local, room = kQueueCap - qc;       // (IRR: both even, entries are nibble pairs)
         const uint32_t take = avail < room ? avail : room;
         const uint32_t rot = __builtin_amdgcn_alignbit(vals, vals, (head_local & 7u) * 4u);
         const uint32_t m = (1u << (4u * take)) - 1u;
@@ -448,7 +484,11 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         head_local += take;
         __hip_atomic_store(&lds_head[l], head_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    auto column = [&](int action) -> uint2 {
+    typedef typename std::conditional<IRR, uint2, int>::type Act;      // (action, irrelevant action)
+    typedef typename std::conditional<IRR, uint4, uint2>::type Col;    // their columns
+    auto column = [&](Act act) -> Col {
+        int action;
+        if constexpr (IRR) action = (int)act.x; else action = act;
         uint32_t ua = (uint32_t)action;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(ua >= A) != 0, 0)) {
             ua = (uint32_t)(action + ((action >> 31) & (int)A));
@@ -456,9 +496,22 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
             ua = bad ? 0u : ua;
         }
-        return lds_col[ua];
+        if constexpr (IRR) {
+            const int action1 = (int)act.y;
+            uint32_t ub = (uint32_t)action1;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(ub >= A1) != 0, 0)) {
+                ub = (uint32_t)(action1 + ((action1 >> 31) & (int)A1));
+                const bool bad = ub >= A1;
+                status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+                ub = bad ? 0u : ub;
+            }
+            const uint2 ca = lds_col[ua], cb = lds_col1[ub];
+            return make_uint4(ca.x, ca.y, cb.x, cb.y);
+        } else {
+            return lds_col[ua];
+        }
     };
-    auto stepE = [&](const uint2 &col, int k) {
+    auto stepE = [&](const Col &col, int k) {
         const uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);              // D1: P[cur][a] | 8 | terminal << 7
         const uint32_t tb = entry >> 7;                                               // D7: is_terminal[next]
         const uint32_t k2n = (k2 << 4) | entry;       // (bit 7 of the sum is set anyway: the nibble below was a state)
@@ -472,7 +525,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NORESET
         need = false;
 #endif
-        uint32_t s0v = PHILOX ? (s0c >> (4 * (k % kChunk))) & 0xFu : qv & 0xFu;
+        uint32_t s0v = PHILOX ? (uint32_t)(s0c >> (kEN * 4 * (k % kChunk))) & (IRR ? 0xFFu : 0xFu) : qv & (IRR ? 0xFFu : 0xFu);
         if (!PHILOX && __builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
             uint32_t spins = 0;
             while (__builtin_amdgcn_ballot_w64(need && (qv & 0xFu) == 0u) != 0) {
@@ -480,7 +533,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; qv |= 8u; break; }
             }
-            s0v = qv & 0xFu;
+            s0v = qv & (IRR ? 0xFFu : 0xFu);
+        }
+        if constexpr (IRR) {                                     // the irrelevant sub-space steps on its own table
+            const uint32_t n1 = __builtin_amdgcn_perm(col.w, col.z, c1 | kSelPad);
+            c1 = need ? ((s0v >> 4) & 7u) : n1;
+            rc |= c1 << 8;                                       // byte 1: the irrelevant observation
+            s0v &= 0xFu;
         }
         if (EVN) {
             ph -= 16u;
@@ -488,7 +547,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             ph = (need || ph == 0u) ? ph_full : ph;
         }
         k2 = need ? s0v : k2n;
-        if (!PHILOX) qv = need ? (qv >> 4) : qv;
+        if (!PHILOX) qv = need ? (qv >> (4 * kEN)) : qv;
         if (HASMAX) cnt = need ? c0 : cnt;
         else last_reset = need ? (uint32_t)(k + 1) : last_reset;
         sel = (k2 & 7u) | kSelPad;
@@ -497,23 +556,29 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         lds_C[k % kDepth][l] = rc;
     };
 
-    auto load_act = [&](int k) -> int {
+    auto load_act = [&](int k) -> Act {
         const uint32_t kk = (uint32_t)min(k, K - 1);
+        if constexpr (IRR) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_act, v4, kk * N * 8u, MDPP_LEAN_LD_AUX);
+            return make_uint2(v.x, v.y);
+        } else {
 #ifdef MDPP_ABL_NOLOAD
-        return (int)((kk * 7u + i) & 7u);
+            return (int)((kk * 7u + i) & 7u);
 #endif
-        return __builtin_amdgcn_raw_buffer_load_b32(r_act, v4, kk * N * 4u, MDPP_LEAN_LD_AUX);
+            return __builtin_amdgcn_raw_buffer_load_b32(r_act, v4, kk * N * 4u, MDPP_LEAN_LD_AUX);
+        }
     };
     // Actions are fetched kAhead chunks ahead of their use, columns one chunk ahead.  The buffers rotate
     // by NAME (the chunk loop is unrolled kAhead times): copying a register whose load is still in
     // flight makes the wave wait for it, which would put one HBM latency into every chunk.
-    static_assert(kAhead % 2 == 0, "the column double buffer alternates with the chunk index");
-    int actq[kAhead][kChunk];       // slot (m - 1) % kAhead holds the actions of chunk m
-    uint2 colq[2][kChunk];          // slot m & 1 holds the columns of chunk m
+    constexpr int kAh = IRR ? 2 : kAhead;      // (action pairs: half the depth, for registers)
+    static_assert(kAh % 2 == 0, "the column double buffer alternates with the chunk index");
+    Act actq[kAh][kChunk];       // slot (m - 1) % kAhead holds the actions of chunk m
+    Col colq[2][kChunk];            // slot m & 1 holds the columns of chunk m
 #pragma unroll
     for (int u = 0; u < kChunk; u++) colq[0][u] = column(load_act(u));
 #pragma unroll
-    for (int q = 0; q < kAhead; q++)
+    for (int q = 0; q < kAh; q++)
 #pragma unroll
         for (int u = 0; u < kChunk; u++) actq[q][u] = load_act((q + 1) * kChunk + u);
 
@@ -538,7 +603,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         for (int u = 0; u < kChunk; u++) colq[(j + 1) & 1][u] = column(actq[j][u]);
         if (refill) {
 #pragma unroll
-            for (int u = 0; u < kChunk; u++) actq[j][u] = load_act(kbase + (kAhead + 1) * kChunk + u);
+            for (int u = 0; u < kChunk; u++) actq[j][u] = load_act(kbase + (kAh + 1) * kChunk + u);
         }
         wait_room(kbase + kChunk);
         pull(c);
@@ -548,17 +613,17 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     };
     // (single-exit loop body, no global load in an inner loop: the compiler then counts its vmcnt waits
     //  exactly, vmcnt(8 (kAhead - 1) + ...), instead of waiting for every load in flight)
-    const int ngrp = nfull / kAhead;
+    const int ngrp = nfull / kAh;
     for (int g = 0; g < ngrp; g++) {
 #pragma unroll
-        for (int j = 0; j < kAhead; j++) chunkE(g * kAhead + j, j, true);
+        for (int j = 0; j < kAh; j++) chunkE(g * kAh + j, j, true);
     }
 #pragma unroll
-    for (int j = 0; j < kAhead - 1; j++)
-        if (ngrp * kAhead + j < nfull) chunkE(ngrp * kAhead + j, j, false);
+    for (int j = 0; j < kAh - 1; j++)
+        if (ngrp * kAh + j < nfull) chunkE(ngrp * kAh + j, j, false);
     if (K % kChunk) {               // (no global load inside the loop above: its waits stay counted, not vmcnt(0))
         const int kbase = nfull * kChunk;
-        int ta[kChunk];
+        Act ta[kChunk];
 #pragma unroll
         for (int u = 0; u < kChunk; u++) ta[u] = load_act(kbase + u);
         wait_room(kbase + kChunk);
@@ -576,12 +641,18 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         hist = (hist << 8) | ((nb & 8u) ? (nb & 7u) : 0xFFu);
     }
     const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x00888888u);
+    if (IRR) {
+        // word 1 of the state is not a queue for these handles: what sits in the register queue goes back to the H
+        // lane (it un-draws everything not taken), and the irrelevant state goes to its own array
+        if (!PHILOX) __hip_atomic_store(&lds_head[l], head_local - qc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        a.irr_state[i] = c1;
+    }
     uint32_t steps;
     if (HASMAX) steps = cnt - c0;
     else steps = last_reset ? (uint32_t)K - last_reset : steps0 + (uint32_t)K;
     uint32_t *st = (uint32_t *)&a.state[i];
     st[0] = hist; st[2] = steps;                    // word 3 (delay line) belongs to the O1 lane
-    if (!PHILOX) st[1] = (qv & 0x00777777u) | (qc << 24);   // (Philox handles: word 1 is older history, unused at L <= 3)
+    if (!PHILOX && !IRR) st[1] = (qv & 0x00777777u) | (qc << 24);   // (Philox / IRR handles: word 1 is older history, unused at L <= 3)
     if ((l & 63) == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (status) atomicOr(&a.status[i], status);
 }
@@ -590,28 +661,35 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                           hipStream_t s, char *name_out) {
-    const bool ph = a.philox != 0;
-    if (!(ph ? (a.shape_ok && !(a.opts & MDPP_OPT_NO_PHILOX_FAST)) : a.fast_ok) || K < 32 || a.N < kBlock ||
+    const bool ph = a.philox != 0, irr = a.irr != 0;
+    const bool shape = irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
+    if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
         !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
     if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
+    if (irr && (a.S1 > 8 || a.A1 > 16 || final_obs != nullptr || (8ULL * 2 * a.N * (unsigned long long)K) >= (1ULL << 32)))
+        return false;
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d>", !a.obs_i32, dl, hm, evn, ph);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d>", !a.obs_i32, dl, hm, evn, ph, irr);
         return true;
     }
+#define MDPP_LEAN_GO(O64, DL, HM, EV, PH, IR)                                                                \
+    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, PH, IR>), dim3(grid), dim3(kRoles * kBlock), \
+                       0, s, a, K, actions, obs, reward, term, trunc, final_obs)
 #define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                                   \
     do {                                                                                                   \
-        if (ph) hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, true>), dim3(grid), dim3(kRoles * kBlock), \
-                                   0, s, a, K, actions, obs, reward, term, trunc, final_obs);              \
-        else hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, false>), dim3(grid), dim3(kRoles * kBlock), \
-                                0, s, a, K, actions, obs, reward, term, trunc, final_obs);                 \
+        if (ph && irr) MDPP_LEAN_GO(O64, DL, HM, EV, true, true);                                          \
+        else if (ph) MDPP_LEAN_GO(O64, DL, HM, EV, true, false);                                           \
+        else if (irr) MDPP_LEAN_GO(O64, DL, HM, EV, false, true);                                          \
+        else MDPP_LEAN_GO(O64, DL, HM, EV, false, false);                                                  \
     } while (0)
 #define MDPP_LEAN_L3(O64, DL, HM) do { if (evn) MDPP_LEAN_LAUNCH(O64, DL, HM, true); else MDPP_LEAN_LAUNCH(O64, DL, HM, false); } while (0)
 #define MDPP_LEAN_L2(O64, DL) do { if (hm) MDPP_LEAN_L3(O64, DL, true); else MDPP_LEAN_L3(O64, DL, false); } while (0)
     if (a.obs_i32) { if (dl) MDPP_LEAN_L2(false, true); else MDPP_LEAN_L2(false, false); }
     else { if (dl) MDPP_LEAN_L2(true, true); else MDPP_LEAN_L2(true, false); }
+#undef MDPP_LEAN_GO
 #undef MDPP_LEAN_L2
 #undef MDPP_LEAN_L3
 #undef MDPP_LEAN_LAUNCH

@@ -160,7 +160,7 @@ def test_kernel_names_and_options():
     cfg = dict(gu.CASES["d_cfg2"]["config"], seed=1)
     a = _venv(num_envs=65536, autoreset="same_step", **cfg)
     b = _venv(num_envs=65536, autoreset="same_step", **cfg)
-    assert a.rollout_kernel_name(512) == "k_discrete_rollout_lean<OBS64=1,DELAY=1,HASMAX=0,EVN=1,PHILOX=0>"
+    assert a.rollout_kernel_name(512) == "k_discrete_rollout_lean<OBS64=1,DELAY=1,HASMAX=0,EVN=1,PHILOX=0,IRR=0>"
     b.set_kernel_options("NO_LEAN")
     assert b.rollout_kernel_name(512) == "k_discrete_rollout_pipe<OBS64=1,POW2=1,DELAY=1,S8=1>"
     assert a.rollout_kernel_name(16).startswith("k_discrete_rollout_fast<") and "HELPER=0" in a.rollout_kernel_name(16)

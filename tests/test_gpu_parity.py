@@ -1462,6 +1462,10 @@ LEAN_SHAPES = {
     "s5_l3_d2_max": (dict(state_space_size=5, action_space_size=3, delay=2, sequence_length=3), 7, "int32"),
     "s6_l2_d0_max": (dict(state_space_size=6, action_space_size=6, delay=0, sequence_length=2, terminal_state_density=0.34), 40, "int64"),
     "s3_l1_d32": (dict(state_space_size=3, action_space_size=2, delay=32, sequence_length=1), 9, "int32"),
+    # an irrelevant sub-space (action / observation pairs, start states drawn in pairs)
+    "irr_l3_d4": (dict(state_space_size=[8, 8], action_space_size=[8, 5], irrelevant_features=True, delay=4, sequence_length=3), None, "int64"),
+    "irr_s5_l2_max": (dict(state_space_size=[5, 7], action_space_size=[3, 4], irrelevant_features=True, delay=1, sequence_length=2,
+                           terminal_state_density=0.4), 11, "int32"),
 }
 
 
@@ -1483,18 +1487,25 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
         kw["dtype_o"] = np.int32
     envs = [_venv(**kw) for _ in range(3)]
     assert envs[0].rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), envs[0].rollout_kernel_name(64)
-    if rng_mode == "numpy":
+    if rng_mode == "numpy" and "irr" in shape:          # an irrelevant sub-space: against the quiet and the general kernel
+        assert envs[0].rollout_kernel_name(64).endswith("IRR=1>")
+        envs[1].set_kernel_options("NO_LEAN")
+        envs[2].set_kernel_options("NO_LEAN", "NO_QUIET")
+        assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_quiet<")
+        assert envs[2].rollout_kernel_name(64).startswith("k_discrete_step<")
+    elif rng_mode == "numpy":
         envs[1].set_kernel_options("NO_LEAN")
         envs[2].set_kernel_options("NO_PIPE", "NO_HELPER")
         assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_pipe<" if N % 256 == 0 else "k_discrete_rollout_fast<")
         assert envs[2].rollout_kernel_name(64).startswith("k_discrete_rollout_fast<")
     else:       # Philox streams: the H waves make every tick's start state; against the quiet and the general kernel
-        assert envs[0].rollout_kernel_name(64).endswith("PHILOX=1>")
+        assert "PHILOX=1" in envs[0].rollout_kernel_name(64)
         envs[1].set_kernel_options("NO_LEAN")
         envs[2].set_kernel_options("NO_PHILOX_FAST")
         assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_quiet<")
         assert envs[2].rollout_kernel_name(64).startswith("k_discrete_step<")
-    A = cfg["action_space_size"]
+    irr = isinstance(cfg["action_space_size"], list)
+    A, A1 = (cfg["action_space_size"] if irr else (cfg["action_space_size"], None))
     rng = np.random.default_rng(5)
     init = envs[0]._obs.cpu().numpy().copy()
     outs = []
@@ -1504,6 +1515,10 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
         if j == 1 and rng_mode == "philox":
             acts[9, 70] = A + 3                           # out of range: flagged, stepped as action 0 by every kernel
             acts[11, N - 1] = -A - 1                      # (the last env of the ragged block)
+        if irr:
+            acts1 = rng.integers(0, A1, size=(Ks[j], N)).astype(np.int32)
+            acts1[4, 6] = -2
+            acts = np.stack([acts, acts1], axis=2)
         ta = torch.as_tensor(acts, device=envs[0].device)
         res = [tuple(x.cpu().numpy() for x in e.rollout(ta)) for e in envs]
         for r in res[1:]:
@@ -1514,7 +1529,10 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
         st = [e.get_rng_streams(0) for e in envs]
         assert np.array_equal(st[0], st[1]) and np.array_equal(st[0], st[2])
     # single steps from the state the lean kernel left == single steps from the state the old kernels left
-    acts = torch.as_tensor(rng.integers(0, A, size=(N,)).astype(np.int32), device=envs[0].device)
+    one = rng.integers(0, A, size=(N,)).astype(np.int32)
+    if irr:
+        one = np.stack([one, rng.integers(0, A1, size=(N,)).astype(np.int32)], axis=1)
+    acts = torch.as_tensor(one, device=envs[0].device)
     for _ in range(6):
         r = [tuple(x.cpu().numpy() for x in e.step(acts)[:4]) for e in envs]
         for q in r[1:]:
@@ -1523,18 +1541,23 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
     for i in (range(0, N, 97) if rng_mode == "numpy" else []):      # (Philox: the general kernel above is held to the oracle elsewhere)
         o = _oracle_for(envs[0], i)
         o.set_rng(envs[0].seeded_streams[0][i], envs[0].seeded_streams[1][i])
-        assert np.array_equal(o.reset(), init[i])
+        assert np.array_equal(np.asarray(o.reset()), init[i])
         n = 0
         for acts_j, (obs, rew, term, trunc) in outs:
             for t in range(acts_j.shape[0]):
-                a_t = int(acts_j[t, i])
-                eo, er, ed = o.step(a_t if a_t >= 0 else a_t + A)
+                if irr:
+                    a_t = [int(x) for x in acts_j[t, i]]
+                    a_t = [a_t[0] if a_t[0] >= 0 else a_t[0] + A, a_t[1] if a_t[1] >= 0 else a_t[1] + A1]
+                    eo, er, ed = o.step(np.asarray(a_t, dtype=np.int32))
+                else:
+                    a_t = int(acts_j[t, i])
+                    eo, er, ed = o.step(a_t if a_t >= 0 else a_t + A)
                 n += 1
                 tr = bool(max_steps) and n >= max_steps
                 if ed or tr:
-                    eo = o.reset()
+                    eo = o.reset(explicit=False) if irr else o.reset()
                     n = 0
-                assert int(obs[t, i]) == int(eo), (shape, i, t)
+                assert np.array_equal(np.asarray(obs[t, i]), np.asarray(eo)), (shape, i, t)
                 assert rew[t, i] == np.float32(er) and bool(trunc[t, i]) == tr and bool(term[t, i]) == bool(ed), (shape, i, t)
     for e in envs:
         st = e.status()
@@ -1550,7 +1573,7 @@ SOAK_IRR = dict(state_space_type="discrete", action_space_type="discrete", state
 
 
 @pytest.mark.parametrize("name,flag", [("d_cfg2", "NO_PIPE"), ("d_cfg2", "NO_LEAN"), ("c_cfg5", "NO_HELPER"), ("c_cfg5", "NO_PARK"),
-                                       ("irr", "NO_DUO"), ("irr+pn", "NO_TRIO"), ("irr+pn+rn", "NO_DUO")])
+                                       ("irr", "NO_LEAN"), ("irr", "NO_LEAN,NO_DUO"), ("irr+pn", "NO_TRIO"), ("irr+pn+rn", "NO_DUO")])
 def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     """The producer/consumer kernels (LDS rings between waves) against the single-role kernels of
     the same arithmetic, full size, many launches: any lost or duplicated hand-off would show.
@@ -1568,7 +1591,7 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     N, F, launches = 65536, 256, 12
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
-    b.set_kernel_options(flag)
+    b.set_kernel_options(*flag.split(","))          # (irr: the lean kernel against the three-role / single-role quiet kernel)
     assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F) or flag == "NO_PARK", (a.rollout_kernel_name(F), flag)
     g = torch.Generator(device=a.device)
     g.manual_seed(1)
