@@ -40,6 +40,10 @@
 
 #include <type_traits>
 
+#ifndef MDPP_LEAN_TU_NEXT
+#define MDPP_LEAN_TU_NEXT 0        // 1: this translation unit holds the next-step autoreset instantiations
+#endif
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -65,6 +69,9 @@ namespace mdpp {
 #endif
 #ifndef MDPP_LEAN_LD_AUX
 #define MDPP_LEAN_LD_AUX 0
+#endif
+#ifndef MDPP_LEAN_HMIN
+#define MDPP_LEAN_HMIN 16
 #endif
 #ifndef MDPP_LEAN_HSLEEP
 #define MDPP_LEAN_HSLEEP 8
@@ -92,7 +99,7 @@ __device__ __forceinline__ void wg_store_rel(uint32_t *p, uint32_t v) {
 } // namespace lean
 using namespace lean;
 
-template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX, bool IRR>
+template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX, bool IRR, bool NEXT>
 __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(DiscreteArgs a, int K,
                                                                       const int32_t *__restrict__ actions,
                                                                       void *__restrict__ obs,
@@ -120,6 +127,11 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ __align__(16) uint64_t lds_T1[IRR ? 8 : 1];    // its rho_0 thresholds
     __shared__ uint32_t lds_hprod[kBlock / 64];               // Philox: chunks published by H wave w
     constexpr int kEN = IRR ? 2 : 1;                // nibbles per start-state entry (relevant, irrelevant)
+    // gymnasium's next-step autoreset: the call after an episode's last step IS the reset (action ignored, reward 0,
+    // no flags); the pending flag travels in bit 31 of the step counter like in k_discrete_step
+    // (a template flag, instantiated in its own translation unit, mdpp_discrete_lean_next.hip: as a run-time
+    //  flag its selects cost the same-step mode 9 us of 106 per launch)
+    constexpr bool nextmode = NEXT;
     const int tid = threadIdx.x;
     const int role = tid / kBlock;                  // 0 = E, 1 = O1, 2 = O2, 3 = H
     const int l = tid & (kBlock - 1);               // env slot inside the block
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         return;
     }
     const uint32_t A = (uint32_t)a.A;
-    constexpr int kMinLanes = 16;
+    constexpr int kMinLanes = MDPP_LEAN_HMIN;       // H draws for the whole wave once this many lanes have room (or one runs low)
     uint32_t status = 0;
 
     // =============================================================== H: start-state producer
@@ -314,8 +326,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 out = bit & 1u;
             }
             const uint32_t tb = (HASMAX || IRR) ? (rc & 1u) : rc;
-            const float rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
-                                   : *(const float *)(rselb + (((out << 1) | tb) << 2));
+            float rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
+                             : *(const float *)(rselb + (((out << 1) | tb) << 2));
+            if (nextmode) rout = (ra != rb) ? 0.0f : rout;                           // the reset call returns reward 0
 #if defined(MDPP_ABL_NOSTORE) || defined(MDPP_ABL_NOREW)
             status ^= __float_as_uint(rout) & 0x100u;
 #else
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
                     ra[u] = lds_A[(kbase + u) % kDepth][l];
-                    rb[u] = DELAY ? lds_B[(kbase + u) % kDepth][l] : 0u;
+                    rb[u] = lds_B[(kbase + u) % kDepth][l];
                     rc[u] = lds_C[(kbase + u) % kDepth][l];
                     rd[u] = EVN ? lds_D[(kbase + u) % kDepth][l] : 0u;
                 }
@@ -438,7 +451,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // =============================================================== E: state recurrence
     __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_E);   // the serial recurrence is the critical path; H is filler work
     // hist: bytes newest first, 0xFF = NaN  ->  nibbles newest first, bit 3 = is a state
-    uint32_t k2, qv, cnt, steps0, last_reset = 0, ph = 0;
+    uint32_t k2, qv, cnt, steps0, last_reset = 0, ph = 0, badq[2] = {0u, 0u};
+    bool pend = false;                              // next-step mode: the episode ended on the previous step
     const uint32_t ph_full = 16u * (uint32_t)a.every_n;
     {
         uint4 st = a.state[i];
@@ -447,9 +461,11 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const uint32_t b = (st.x >> (8 * j)) & 0xFFu;
             k2 = (k2 << 4) | (b == 0xFFu ? 0u : ((b & 7u) | 8u));
         }
-        const uint32_t qc = (PHILOX || IRR) ? 0u : (st.y >> 24) & 7u;
-        qv = (PHILOX || IRR) ? 0u : (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u));
-        steps0 = st.z;
+        const bool own_q = !PHILOX && !IRR && !nextmode;   // word 1 of the state is this kernel's draw queue (fast_ok handles)
+        const uint32_t qc = own_q ? (st.y >> 24) & 7u : 0u;
+        qv = own_q ? (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u)) : 0u;
+        steps0 = st.z & 0x7FFFFFFFu;
+        pend = nextmode && (st.z >> 31) != 0u;
         const uint32_t ms = (uint32_t)a.max_steps;
         cnt = HASMAX ? (0x10000u - ms) + (steps0 < ms ? steps0 : ms) : 0u;
         if (EVN) ph = ph_full - 16u * (steps0 % (uint32_t)a.every_n);
@@ -486,14 +502,15 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     };
     typedef typename std::conditional<IRR, uint2, int>::type Act;      // (action, irrelevant action)
     typedef typename std::conditional<IRR, uint4, uint2>::type Col;    // their columns
-    auto column = [&](Act act) -> Col {
+    auto column = [&](Act act, uint32_t &badm, int u) -> Col {
         int action;
         if constexpr (IRR) action = (int)act.x; else action = act;
         uint32_t ua = (uint32_t)action;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(ua >= A) != 0, 0)) {
             ua = (uint32_t)(action + ((action >> 31) & (int)A));
             const bool bad = ua >= A;
-            status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+            // (next-step mode: an action the reset call ignores is not an error; decided at the step)
+            if (nextmode) badm |= bad ? (1u << u) : 0u; else status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
             ua = bad ? 0u : ua;
         }
         if constexpr (IRR) {
@@ -502,7 +519,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(ub >= A1) != 0, 0)) {
                 ub = (uint32_t)(action1 + ((action1 >> 31) & (int)A1));
                 const bool bad = ub >= A1;
-                status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+                if (nextmode) badm |= bad ? (1u << u) : 0u; else status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
                 ub = bad ? 0u : ub;
             }
             const uint2 ca = lds_col[ua], cb = lds_col1[ub];
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             return lds_col[ua];
         }
     };
-    auto stepE = [&](const Col &col, int k) {
+    auto stepE = [&](const Col &col, int k, uint32_t badbit) {
         const uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);              // D1: P[cur][a] | 8 | terminal << 7
         const uint32_t tb = entry >> 7;                                               // D7: is_terminal[next]
         const uint32_t k2n = (k2 << 4) | entry;       // (bit 7 of the sum is set anyway: the nibble below was a state)
@@ -525,6 +542,15 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NORESET
         need = false;
 #endif
+        uint32_t rec_a = k2n;
+        if (nextmode) {
+            const bool ended = need && !pend;
+            need = pend;                                         // reset now: this call is reset() (:2250-2278) ...
+            rc = pend ? 0u : rc;                                 // ... which returns no flags,
+            rec_a = pend ? 0u : k2n;                             // no reward (history word 0: O1 sees a reset, pays 0.0)
+            status |= (badbit != 0u && !pend) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+            pend = ended;
+        }
         uint32_t s0v = PHILOX ? (uint32_t)(s0c >> (kEN * 4 * (k % kChunk))) & (IRR ? 0xFFu : 0xFu) : qv & (IRR ? 0xFFu : 0xFu);
         if (!PHILOX && __builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
             uint32_t spins = 0;
@@ -551,7 +577,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         if (HASMAX) cnt = need ? c0 : cnt;
         else last_reset = need ? (uint32_t)(k + 1) : last_reset;
         sel = (k2 & 7u) | kSelPad;
-        lds_A[k % kDepth][l] = k2n;
+        lds_A[k % kDepth][l] = rec_a;
         lds_B[k % kDepth][l] = k2;
         lds_C[k % kDepth][l] = rc;
     };
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     Act actq[kAh][kChunk];       // slot (m - 1) % kAhead holds the actions of chunk m
     Col colq[2][kChunk];            // slot m & 1 holds the columns of chunk m
 #pragma unroll
-    for (int u = 0; u < kChunk; u++) colq[0][u] = column(load_act(u));
+    for (int u = 0; u < kChunk; u++) colq[0][u] = column(load_act(u), badq[0], u);
 #pragma unroll
     for (int q = 0; q < kAh; q++)
 #pragma unroll
@@ -599,8 +625,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // one full chunk: slot j's actions -> next chunk's columns, (re)fill slot j, step, publish
     auto chunkE = [&](int c, int j, bool refill) {
         const int kbase = c * kChunk;
+        badq[(j + 1) & 1] = 0u;
 #pragma unroll
-        for (int u = 0; u < kChunk; u++) colq[(j + 1) & 1][u] = column(actq[j][u]);
+        for (int u = 0; u < kChunk; u++) colq[(j + 1) & 1][u] = column(actq[j][u], badq[(j + 1) & 1], u);
         if (refill) {
 #pragma unroll
             for (int u = 0; u < kChunk; u++) actq[j][u] = load_act(kbase + (kAh + 1) * kChunk + u);
@@ -608,7 +635,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         wait_room(kbase + kChunk);
         pull(c);
 #pragma unroll
-        for (int u = 0; u < kChunk; u++) stepE(colq[j & 1][u], kbase + u);
+        for (int u = 0; u < kChunk; u++) stepE(colq[j & 1][u], kbase + u, (badq[j & 1] >> u) & 1u);
         if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)(kbase + kChunk));
     };
     // (single-exit loop body, no global load in an inner loop: the compiler then counts its vmcnt waits
@@ -630,7 +657,11 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         pull(nfull);
 #pragma unroll
         for (int u = 0; u < kChunk; u++)
-            if (kbase + u < K) stepE(column(ta[u]), kbase + u);
+            if (kbase + u < K) {
+                uint32_t bm = 0;
+                const Col cc = column(ta[u], bm, 0);
+                stepE(cc, kbase + u, bm);
+            }
         if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)K);
     }
 
@@ -641,28 +672,44 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         hist = (hist << 8) | ((nb & 8u) ? (nb & 7u) : 0xFFu);
     }
     const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x00888888u);
-    if (IRR) {
+    const bool own_q = !PHILOX && !IRR && !nextmode;
+    if (!own_q && !PHILOX) {
         // word 1 of the state is not a queue for these handles: what sits in the register queue goes back to the H
-        // lane (it un-draws everything not taken), and the irrelevant state goes to its own array
-        if (!PHILOX) __hip_atomic_store(&lds_head[l], head_local - qc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        a.irr_state[i] = c1;
+        // lane (it un-draws everything not taken)
+        __hip_atomic_store(&lds_head[l], head_local - qc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (IRR) a.irr_state[i] = c1;                   // the irrelevant state has its own array
     uint32_t steps;
     if (HASMAX) steps = cnt - c0;
     else steps = last_reset ? (uint32_t)K - last_reset : steps0 + (uint32_t)K;
     uint32_t *st = (uint32_t *)&a.state[i];
-    st[0] = hist; st[2] = steps;                    // word 3 (delay line) belongs to the O1 lane
-    if (!PHILOX && !IRR) st[1] = (qv & 0x00777777u) | (qc << 24);   // (Philox / IRR handles: word 1 is older history, unused at L <= 3)
+    st[0] = hist; st[2] = steps | (pend ? 0x80000000u : 0u);        // word 3 (delay line) belongs to the O1 lane
+    if (own_q) st[1] = (qv & 0x00777777u) | (qc << 24);   // (other handles: word 1 is older history, unused at L <= 3)
     if ((l & 63) == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (status) atomicOr(&a.status[i], status);
 }
 
 // Returns false when the shape does not qualify (caller tries k_discrete_rollout_pipe, then _fast).
+#if MDPP_LEAN_TU_NEXT
+bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                               float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                               hipStream_t s, char *name_out) {
+    constexpr bool kNext = true;
+    if (a.autoreset != MDPP_AUTORESET_NEXT_STEP) return false;
+#else
+bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                               float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                               hipStream_t s, char *name_out);
 bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                           hipStream_t s, char *name_out) {
+    constexpr bool kNext = false;
+    if (a.autoreset == MDPP_AUTORESET_NEXT_STEP)
+        return launch_discrete_lean_next(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+#endif
     const bool ph = a.philox != 0, irr = a.irr != 0;
-    const bool shape = irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
+    const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? (a.lean_next_ok != 0 && final_obs == nullptr)
+                       : irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
     if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
         !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
@@ -672,11 +719,11 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d>", !a.obs_i32, dl, hm, evn, ph, irr);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d,NEXT=%d>", !a.obs_i32, dl, hm, evn, ph, irr, kNext);
         return true;
     }
 #define MDPP_LEAN_GO(O64, DL, HM, EV, PH, IR)                                                                \
-    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, PH, IR>), dim3(grid), dim3(kRoles * kBlock), \
+    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, PH, IR, kNext>), dim3(grid), dim3(kRoles * kBlock), \
                        0, s, a, K, actions, obs, reward, term, trunc, final_obs)
 #define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                                   \
     do {                                                                                                   \

@@ -1488,7 +1488,7 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
     envs = [_venv(**kw) for _ in range(3)]
     assert envs[0].rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), envs[0].rollout_kernel_name(64)
     if rng_mode == "numpy" and "irr" in shape:          # an irrelevant sub-space: against the quiet and the general kernel
-        assert envs[0].rollout_kernel_name(64).endswith("IRR=1>")
+        assert "IRR=1" in envs[0].rollout_kernel_name(64)
         envs[1].set_kernel_options("NO_LEAN")
         envs[2].set_kernel_options("NO_LEAN", "NO_QUIET")
         assert envs[1].rollout_kernel_name(64).startswith("k_discrete_rollout_quiet<")
@@ -1566,6 +1566,53 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
         else:
             assert (st == 0).all()
         e.close()
+
+
+@pytest.mark.parametrize("rng_mode", ["numpy", "philox"])
+@pytest.mark.parametrize("shape", sorted(LEAN_SHAPES))
+def test_lean_rollout_kernel_next_step_autoreset_vs_general_kernel(shape, rng_mode):
+    """autoreset="next_step" on the lean kernel (the pending flag in bit 31 of the step counter, the reset call's
+    zero reward through a zeroed history word) against k_discrete_step, which the oracle-loop test of
+    test_gpu_boundary.py holds to the oracle: fused launches, single steps in between (the flag crosses kernels
+    both ways), an out-of-range action on some steps (an error only where the call is not a reset), stream ends."""
+    extra, max_steps, odt = LEAN_SHAPES[shape]
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", seed=29, **extra)
+    N = 1000
+    kw = dict(num_envs=N, autoreset="next_step", rng=rng_mode, **cfg)
+    if max_steps:
+        kw["max_episode_steps"] = max_steps
+    if odt == "int32":
+        kw["dtype_o"] = np.int32
+    a, b = _venv(**kw), _venv(**kw)
+    b.set_kernel_options("NO_LEAN")
+    assert a.rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), a.rollout_kernel_name(64)
+    assert b.rollout_kernel_name(64).startswith("k_discrete_step<"), b.rollout_kernel_name(64)
+    irr = isinstance(cfg["action_space_size"], list)
+    A, A1 = (cfg["action_space_size"] if irr else (cfg["action_space_size"], None))
+    rng = np.random.default_rng(9)
+
+    def actions(K):
+        x = rng.integers(0, A, size=(K, N)).astype(np.int32)
+        x[rng.integers(0, K, size=40), rng.integers(0, N, size=40)] = A + 1      # out of range here and there
+        if irr:
+            x = np.stack([x, rng.integers(0, A1, size=(K, N)).astype(np.int32)], axis=2)
+        return torch.as_tensor(x, device=a.device)
+    ended = 0
+    for K in (45, 1, 1, 64, 1, 33):
+        acts = actions(K)
+        if K == 1:
+            ra, rb = a.step(acts[0])[:4], b.step(acts[0])[:4]
+        else:
+            ra, rb = a.rollout(acts), b.rollout(acts)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (shape, K)
+        ended += int((ra[2] | ra[3]).sum())
+    assert ended > 0
+    sa, sb = a.status(), b.status()                 # (reading clears)
+    assert np.array_equal(sa, sb) and (sa != 0).any()
+    if rng_mode == "numpy":
+        assert np.array_equal(a.get_rng_streams(0), b.get_rng_streams(0))
+    a.close(); b.close()
 
 
 SOAK_IRR = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 8],
