@@ -107,10 +107,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                                                                       uint8_t *__restrict__ term,
                                                                       uint8_t *__restrict__ trunc,
                                                                       void *__restrict__ final_obs) {
-    __shared__ __align__(16) uint32_t lds_A[kDepth][kBlock];  // E -> O: history before a reset
-    __shared__ __align__(16) uint32_t lds_B[kDepth][kBlock];  //         history after it
-    __shared__ __align__(16) uint32_t lds_C[kDepth][kBlock];  //         byte 0 terminated, byte 2 truncated
-    __shared__ __align__(16) uint32_t lds_D[EVN ? kDepth : 1][kBlock];  //   (every_n > 1) 16 x steps to the next pay step
+    // E -> O, three dwords per env step in ONE array (constant 32 KB apart: two of them go out as one ds_write2st64):
+    //   A history before a reset   B history after it   C byte 0: the column entry (bit 7 terminated), byte 1 the
+    //   irrelevant observation, byte 2 truncated
+    __shared__ __align__(16) uint32_t lds_rec[3][kDepth][kBlock];
     __shared__ __align__(16) uint32_t lds_V[2048];            // reward bit & NaN gate, by the 4 low nibbles
     __shared__ __align__(16) uint2 lds_col[16];               // action a, byte s: P[s][a] | 8 | is_term[P[s][a]] << 7
     __shared__ __align__(16) uint32_t lds_R[128];             // 4096 reward bits by key (staging for lds_V)
@@ -187,16 +187,20 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             lds_V[d] = wd;
         }
     }
+    // (the episode step count at launch, for the O1 lane's every-n phase: read BEFORE the barrier -- the E lane
+    //  writes the word back at the end of the launch, and with K <= kDepth it could get there before O1 starts)
+    uint32_t steps_at_launch = 0;
+    {
+        const uint32_t eb0 = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+        const uint32_t i0 = eb0 * kBlock + l;
+        if (EVN && role == 1 && i0 < (uint32_t)a.N) steps_at_launch = ((const uint32_t *)&a.state[i0])[2] & 0x7FFFFFFFu;
+    }
     __syncthreads();
 
     // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Give every XCD one contiguous eighth of the
     // envs, so that what its L2 writes back per output row is one contiguous range, not every eighth
     // 256-env piece of it.
-#ifdef MDPP_ABL_NOXCD
-    const uint32_t eblk = blockIdx.x;
-#else
     const uint32_t eblk = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-#endif
     const uint32_t i = eblk * kBlock + l;
     const uint32_t N = (uint32_t)a.N;
     if (i >= N) {                                   // ragged last block: its spare lanes leave (every wave that stays keeps
@@ -315,7 +319,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         uint32_t ring = ((const uint32_t *)&a.state[i])[3];
         const uint8_t *rselb = (const uint8_t *)lds_rsel;
 
-        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t rd, uint32_t so) {
+        // reward_every_n_steps (:1975-1976): 16 x (steps to the next pay step), the row index of the reward-value table
+        const uint32_t ph_full = 16u * (uint32_t)a.every_n;
+        uint32_t ph = EVN ? ph_full - 16u * (steps_at_launch % (uint32_t)a.every_n) : 0u;
+        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so) {
             uint32_t bit = lds_V[(ra >> 5) & 2047u] >> (ra & 31u);                   // reward bit, NaN-gated (:1822)
             uint32_t out;
             if (DELAY) {                                                             // FIFO (:1970-1973)
@@ -325,7 +332,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             } else {
                 out = bit & 1u;
             }
-            const uint32_t tb = (HASMAX || IRR) ? (rc & 1u) : rc;
+            const uint32_t tb = (rc >> 7) & 1u;
+            uint32_t rd = 0;
+            if (EVN) {
+                ph -= 16u;
+                rd = ph;
+                ph = (ra != rb || ph == 0u) ? ph_full : ph;
+            }
             float rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
                              : *(const float *)(rselb + (((out << 1) | tb) << 2));
             if (nextmode) rout = (ra != rb) ? 0.0f : rout;                           // the reset call returns reward 0
@@ -348,20 +361,18 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
             if (kbase + kChunk <= K) {
-                uint32_t ra[kChunk], rb[kChunk], rc[kChunk], rd[kChunk];
+                uint32_t ra[kChunk], rb[kChunk], rc[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    ra[u] = lds_A[(kbase + u) % kDepth][l];
-                    rb[u] = lds_B[(kbase + u) % kDepth][l];
-                    rc[u] = lds_C[(kbase + u) % kDepth][l];
-                    rd[u] = EVN ? lds_D[(kbase + u) % kDepth][l] : 0u;
+                    ra[u] = lds_rec[0][(kbase + u) % kDepth][l];
+                    rb[u] = lds_rec[1][(kbase + u) % kDepth][l];
+                    rc[u] = lds_rec[2][(kbase + u) % kDepth][l];
                 }
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], rd[u], (uint32_t)(kbase + u) * N);
+                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N);
             } else {
                 for (int k = kbase; k < K; k++)
-                    emit(lds_A[k % kDepth][l], lds_B[k % kDepth][l], lds_C[k % kDepth][l],
-                         EVN ? lds_D[k % kDepth][l] : 0u, (uint32_t)k * N);
+                    emit(lds_rec[0][k % kDepth][l], lds_rec[1][k % kDepth][l], lds_rec[2][k % kDepth][l], (uint32_t)k * N);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][0], upto);
         }
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NOBYTES
             status ^= rc & 0x100u;
 #else
-            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)rc, r_term, v1, so, MDPP_LEAN_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rc >> 7) & 1u), r_term, v1, so, MDPP_LEAN_ST_AUX);
             __builtin_amdgcn_raw_buffer_store_b8(HASMAX ? (uint8_t)(rc >> 16) : (uint8_t)0, r_trunc, v1, so, MDPP_LEAN_ST_AUX);
 #endif
         };
@@ -427,19 +438,19 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 uint32_t rb[kChunk], rc[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    rb[u] = lds_B[(kbase + u) % kDepth][l];
-                    rc[u] = lds_C[(kbase + u) % kDepth][l];
+                    rb[u] = lds_rec[1][(kbase + u) % kDepth][l];
+                    rc[u] = lds_rec[2][(kbase + u) % kDepth][l];
                 }
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) emit(rb[u], rc[u], (uint32_t)(kbase + u) * N);
                 if (__builtin_expect(want_final, 0)) {
 #pragma unroll
-                    for (int u = 0; u < kChunk; u++) emit_final(lds_A[(kbase + u) % kDepth][l], rb[u], (uint32_t)(kbase + u) * N);
+                    for (int u = 0; u < kChunk; u++) emit_final(lds_rec[0][(kbase + u) % kDepth][l], rb[u], (uint32_t)(kbase + u) * N);
                 }
             } else {
                 for (int k = kbase; k < K; k++) {
-                    emit(lds_B[k % kDepth][l], lds_C[k % kDepth][l], (uint32_t)k * N);
-                    if (want_final) emit_final(lds_A[k % kDepth][l], lds_B[k % kDepth][l], (uint32_t)k * N);
+                    emit(lds_rec[1][k % kDepth][l], lds_rec[2][k % kDepth][l], (uint32_t)k * N);
+                    if (want_final) emit_final(lds_rec[0][k % kDepth][l], lds_rec[1][k % kDepth][l], (uint32_t)k * N);
                 }
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][1], upto);
@@ -451,9 +462,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // =============================================================== E: state recurrence
     __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_E);   // the serial recurrence is the critical path; H is filler work
     // hist: bytes newest first, 0xFF = NaN  ->  nibbles newest first, bit 3 = is a state
-    uint32_t k2, qv, cnt, steps0, last_reset = 0, ph = 0, badq[2] = {0u, 0u};
+    uint32_t k2, qv, cnt, steps0, last_reset = 0, badq[2] = {0u, 0u};
     bool pend = false;                              // next-step mode: the episode ended on the previous step
-    const uint32_t ph_full = 16u * (uint32_t)a.every_n;
     {
         uint4 st = a.state[i];
         k2 = 0;
@@ -468,7 +478,6 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         pend = nextmode && (st.z >> 31) != 0u;
         const uint32_t ms = (uint32_t)a.max_steps;
         cnt = HASMAX ? (0x10000u - ms) + (steps0 < ms ? steps0 : ms) : 0u;
-        if (EVN) ph = ph_full - 16u * (steps0 % (uint32_t)a.every_n);
     }
     const uint32_t c0 = HASMAX ? 0x10000u - (uint32_t)a.max_steps : 0u;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * 4u * (uint32_t)kEN, kPRsrc);
@@ -530,14 +539,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     };
     auto stepE = [&](const Col &col, int k, uint32_t badbit) {
         const uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);              // D1: P[cur][a] | 8 | terminal << 7
-        const uint32_t tb = entry >> 7;                                               // D7: is_terminal[next]
         const uint32_t k2n = (k2 << 4) | entry;       // (bit 7 of the sum is set anyway: the nibble below was a state)
-        bool need = entry > 0x7Fu;
-        uint32_t rc = tb;
+        bool need = entry > 0x7Fu;                                                    // D7: is_terminal[next]
+        uint32_t rc = entry;                          // (O1 / O2 take bit 7 out)
         if (HASMAX) {
             cnt += 1;
             need = need || cnt >= 0x10000u;
-            rc = __builtin_amdgcn_perm(cnt, tb, 0x0c060c00u);                          // byte 0 terminated, byte 2 truncated
+            rc = __builtin_amdgcn_perm(cnt, entry, 0x0c060c00u);                       // byte 0 the entry, byte 2 truncated
         }
 #ifdef MDPP_ABL_NORESET
         need = false;
@@ -567,19 +575,14 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             rc |= c1 << 8;                                       // byte 1: the irrelevant observation
             s0v &= 0xFu;
         }
-        if (EVN) {
-            ph -= 16u;
-            lds_D[k % kDepth][l] = ph;
-            ph = (need || ph == 0u) ? ph_full : ph;
-        }
         k2 = need ? s0v : k2n;
         if (!PHILOX) qv = need ? (qv >> (4 * kEN)) : qv;
         if (HASMAX) cnt = need ? c0 : cnt;
         else last_reset = need ? (uint32_t)(k + 1) : last_reset;
         sel = (k2 & 7u) | kSelPad;
-        lds_A[k % kDepth][l] = rec_a;
-        lds_B[k % kDepth][l] = k2;
-        lds_C[k % kDepth][l] = rc;
+        lds_rec[0][k % kDepth][l] = rec_a;
+        lds_rec[1][k % kDepth][l] = k2;
+        lds_rec[2][k % kDepth][l] = rc;
     };
 
     auto load_act = [&](int k) -> Act {
