@@ -64,7 +64,9 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
     if (mask && !mask[j % a.N]) return;
     if (term && !(term[j] | trunc[j])) return;
     const int npix = a.n_sub * a.W * a.H, ngroup = npix >> 4;      // W * H % 16 == 0 (host-checked)
-    uint32_t *codes = lds_codes + (size_t)wave * ngroup;
+    const int ngpad = (ngroup + 3) & ~3;                                 // (the slab behind the codes stays 16-byte aligned)
+    uint32_t *codes = lds_codes + (size_t)wave * (ngpad + 768);          // (+ the wave's 3 KiB store slab)
+    uint32_t *slab = codes + ngpad;
     for (int g = lane; g < ngroup; g += 64) codes[g] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const float *st = (const float *)states_v + (size_t)j * a.D;
@@ -117,7 +119,12 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
     // phase 2: 16 pixels -> 48 bytes per lane
     const size_t isz = (size_t)npix * 3;
     const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)j * isz), 0, (int)isz, 0x00020000);
+#ifdef MDPP_IMGC_DIRECT
     for (int g = lane; g < ngroup; g += 64) {
+#else
+    for (int g0 = 0; g0 < ngroup; g0 += 64) {                      // (every lane takes part in every round's stores)
+        const int g = min(g0 + lane, ngroup - 1);
+#endif
         const uint32_t c = codes[g];
         const uint32_t ln = GRID ? (uint32_t)a.lines[g] : 0u;       // white where no shape covers the line
         u32x4 o0, o1, o2;
@@ -143,9 +150,25 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
             o1 = u32x4{d[4], d[5], d[6], d[7]};
             o2 = u32x4{d[8], d[9], d[10], d[11]};
         }
+#ifdef MDPP_IMGC_DIRECT
         __builtin_amdgcn_raw_buffer_store_b128(o0, r_out, g * 48, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o1, r_out, g * 48 + 16, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o2, r_out, g * 48 + 32, 0, 0);
+#else
+        // The lane's 48 bytes go through a 3 KiB LDS slab of the wave, so that every store instruction writes 1 KiB
+        // CONTIGUOUS (lane l: bytes 16 l ..) instead of 16 bytes out of every 48
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // (the slab's previous round has been read)
+        u32x4 *sl = (u32x4 *)slab;
+        sl[lane * 3] = o0; sl[lane * 3 + 1] = o1; sl[lane * 3 + 2] = o2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const int base = g0 * 48;                                      // first byte of this round of 64 groups
+        const int nb = min(64, ngroup - g0) * 48;                      // bytes of this round
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int off = k * 1024 + lane * 16;
+            if (off < nb) __builtin_amdgcn_raw_buffer_store_b128(sl[k * 64 + lane], r_out, base + off, 0, 0);
+        }
+#endif
     }
 }
 
@@ -178,7 +201,7 @@ int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_
     for (int r = 0; r < 32; r++) a.disc_rows[r] = h->imgc_disc_rows[r];
     const long M = (long)K * a.N;
     const int per_block = kBlock / 64;
-    const size_t lds = (size_t)per_block * ((size_t)a.n_sub * a.W * a.H / 16) * 4;
+    const size_t lds = (size_t)per_block * ((((size_t)a.n_sub * a.W * a.H / 16 + 3) & ~(size_t)3) + 768) * 4;
     if (lds > 64 * 1024) { h->err = "k_imagec_obs: image too large for the LDS colour map"; return MDPP_EUNSUPPORTED; }
     const dim3 grd((unsigned)((M + per_block - 1) / per_block));
 #define MDPP_IC_LAUNCH(GR, st, te, tr, im) hipLaunchKernelGGL((k_imagec_obs<GR>), grd, dim3(kBlock), lds, s, a, M, st, te, tr, mask, im)
