@@ -315,7 +315,10 @@ def main():
     if args.disable:
         env.set_kernel_options(*args.disable.split(","))
     acts = make_actions(wl, F, N, device, 12345 + rank)
-    outs = [env.alloc_rollout(F), env.alloc_rollout(F)]     # alternate, so a gather can trail a launch
+    # rotate, so a gather can trail a launch; three with a collective: launch k + 1 must not wait for the gather
+    # of launch k - 1, which cannot run beside a rollout that holds every CU (it slips in between two launches)
+    outs = [env.alloc_rollout(F) for _ in range(3 if dist is not None else 2)]
+    NB = len(outs)
     comm = torch.cuda.Stream(device=device) if dist is not None else None
 
     def barrier():
@@ -327,11 +330,11 @@ def main():
         """`steps` fused launches; with `gathers`, each launch is followed by ONE all-gather (on the comm
         stream, overlapping the next launch) of the tensor gathers[j] was built on."""
         cur = torch.cuda.current_stream(device)
-        ev_done = [None, None]
+        ev_done = [None] * NB
         for it in range(steps):
-            j = it & 1
+            j = it % NB
             if gathers is not None and ev_done[j] is not None:
-                cur.wait_event(ev_done[j])          # the gather that read this buffer two launches ago
+                cur.wait_event(ev_done[j])          # the gather that read this buffer NB launches ago
             env.rollout(acts, outs[j])
             if gathers is not None:
                 ev = torch.cuda.Event()
@@ -381,7 +384,7 @@ def main():
         del g_last
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()
-        if args.full_gather_steps > 0 and full_bytes * world * 2 < (64 << 30):
+        if args.full_gather_steps > 0 and full_bytes * world * NB < (64 << 30):
             g_full = [ObsGatherer(o[0], world, dist) for o in outs]
             run(2, g_full)
             ks = min(args.steps, args.full_gather_steps)
