@@ -96,7 +96,8 @@ constexpr int kPostUB = 8;               // k_post_image_lds: loads in flight pe
 // trip in the step at all: the LDS form spent most of a step waiting on its dependent ds_read / ds_write);
 // RING = 1: the LDS form (delay <= 16); RING = 0: slots in HBM.
 constexpr int kPostRegDelay = 8;
-template <bool PHILOX, int RING>
+// DC > 0: the delay as a compile-time constant (register FIFO: the shift and the flush sum lose their selects)
+template <bool PHILOX, int RING, int DC>
 __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const void *__restrict__ obs_in,
                                                       const double *__restrict__ reward_in,
                                                       const uint8_t *__restrict__ done_in, void *__restrict__ obs_out,
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     constexpr bool LDSRING = RING == 1, REGRING = RING == 2;
+    const int delay = DC > 0 ? DC : a.delay;
     __shared__ double s_ring[LDSRING ? kPostLdsDelay * kBlock : 1];
     const bool normals = !PHILOX && ((a.continuous && a.has_p) || a.has_r);
     if (normals) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
@@ -117,17 +119,17 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
     if constexpr (!PHILOX) {
         if (draws) { g.load(a.rng_s, a.rng_inc, i); const uint2 hh = a.half[i]; hf = Half32{hh.x, hh.y}; }
     }
-    uint32_t head = a.delay > 0 ? a.head[i] : 0u;
+    uint32_t head = delay > 0 ? a.head[i] : 0u;
     // ring slot j of this lane: LDS column (conflict-free: consecutive lanes, consecutive banks) or HBM
     double *ringp = LDSRING ? s_ring + threadIdx.x : a.ring + i;
     const size_t rstride = LDSRING ? (size_t)kBlock : (size_t)N;
-    if (LDSRING) for (int j = 0; j < a.delay; j++) s_ring[j * kBlock + threadIdx.x] = a.ring[(size_t)j * N + i];
+    if (LDSRING) for (int j = 0; j < delay; j++) s_ring[j * kBlock + threadIdx.x] = a.ring[(size_t)j * N + i];
     double rq[kPostRegDelay];            // REGRING: rq[0] pays out next
     if (REGRING) {
 #pragma unroll
         for (int j = 0; j < kPostRegDelay; j++) {
-            const uint32_t sl = head + (uint32_t)j < (uint32_t)a.delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)a.delay;
-            rq[j] = j < a.delay ? a.ring[(size_t)sl * N + i] : 0.0;
+            const uint32_t sl = head + (uint32_t)j < (uint32_t)delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)delay;
+            rq[j] = j < delay ? a.ring[(size_t)sl * N + i] : 0.0;
         }
         head = 0;
     }
@@ -164,33 +166,33 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
             // np.sum(buffer * scale + shift) in numpy's pairwise order, read straight from the FIFO (a private
             // array here would live in scratch memory, and some lane of a wave is done on most steps)
             auto val = [&](int j) __attribute__((always_inline)) -> double {
-                const uint32_t sl = head + (uint32_t)j < (uint32_t)a.delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)a.delay;
+                const uint32_t sl = head + (uint32_t)j < (uint32_t)delay ? head + (uint32_t)j : head + (uint32_t)j - (uint32_t)delay;
                 return ringp[(size_t)sl * rstride] * a.scale + a.shift;
             };
             double sum;
             if (REGRING) {
-                if (a.delay < 8) {
+                if (delay < 8) {
                     sum = 0.;
 #pragma unroll
-                    for (int j = 0; j < kPostRegDelay - 1; j++) sum = j < a.delay ? sum + (rq[j] * a.scale + a.shift) : sum;
+                    for (int j = 0; j < kPostRegDelay - 1; j++) sum = j < delay ? sum + (rq[j] * a.scale + a.shift) : sum;
                 } else {
                     double v[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] = rq[j] * a.scale + a.shift;
                     sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 }
-            } else if (a.delay < 8) {
+            } else if (delay < 8) {
                 sum = 0.;
-                for (int j = 0; j < a.delay; j++) sum += val(j);
+                for (int j = 0; j < delay; j++) sum += val(j);
             } else {
                 double r0 = val(0), r1 = val(1), r2 = val(2), r3 = val(3), r4 = val(4), r5 = val(5), r6 = val(6), r7 = val(7);
                 int j;
-                for (j = 8; j < a.delay - (a.delay % 8); j += 8) {
+                for (j = 8; j < delay - (delay % 8); j += 8) {
                     r0 += val(j); r1 += val(j + 1); r2 += val(j + 2); r3 += val(j + 3);
                     r4 += val(j + 4); r5 += val(j + 5); r6 += val(j + 6); r7 += val(j + 7);
                 }
                 sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                for (; j < a.delay; j++) sum += val(j);
+                for (; j < delay; j++) sum += val(j);
             }
             reward += sum;
             reward += a.term * a.scale;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
 #pragma unroll
                     for (int j = 0; j < kPostRegDelay; j++) rq[j] = 0.0;
                 } else {
-                    for (int j = 0; j < a.delay; j++) ringp[(size_t)j * rstride] = 0.0;
+                    for (int j = 0; j < delay; j++) ringp[(size_t)j * rstride] = 0.0;
                 }
                 head = 0;
             }
@@ -208,15 +210,15 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
 #pragma unroll
             for (int j = 0; j < kPostRegDelay; j++) {
                 const double nxt = j + 1 < kPostRegDelay ? rq[j + 1] : 0.0;
-                rq[j] = j + 1 == a.delay ? reward : nxt;
+                rq[j] = j + 1 == delay ? reward : nxt;
             }
             reward = out;
-        } else if (a.delay > 0) {                                             // :415-420
+        } else if (delay > 0) {                                             // :415-420
             double *slot = ringp + (size_t)head * rstride;
             const double out = *slot;
             *slot = reward;
             reward = out;
-            head = head + 1u == (uint32_t)a.delay ? 0u : head + 1u;
+            head = head + 1u == (uint32_t)delay ? 0u : head + 1u;
         }
         const double nz = a.has_r ? 0.0 + a.r_noise * np_standard_normal_lds(g, zig) : 0.0;   // :426
         reward += nz;                                                         // :430-432
@@ -234,12 +236,12 @@ __global__ __launch_bounds__(kBlock) void k_post_step(PostArgs a, int K, const v
 #pragma unroll
     for (int u = 0; u < kPostPre - 1; u++)
         if (kfull + u < K) step(kfull + u, u, false);
-    if (LDSRING) for (int j = 0; j < a.delay; j++) a.ring[(size_t)j * N + i] = s_ring[j * kBlock + threadIdx.x];
+    if (LDSRING) for (int j = 0; j < delay; j++) a.ring[(size_t)j * N + i] = s_ring[j * kBlock + threadIdx.x];
     if (REGRING) {
 #pragma unroll
-        for (int j = 0; j < kPostRegDelay; j++) if (j < a.delay) a.ring[(size_t)j * N + i] = rq[j];
+        for (int j = 0; j < kPostRegDelay; j++) if (j < delay) a.ring[(size_t)j * N + i] = rq[j];
     }
-    if (a.delay > 0) a.head[i] = head;
+    if (delay > 0) a.head[i] = head;
     if constexpr (!PHILOX) {
         if (draws) { g.store(a.rng_s, i); a.half[i] = make_uint2(hf.has32, hf.u32); }
     }
@@ -628,10 +630,18 @@ extern "C" int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, con
     PostArgs a = make_args(h);
     const int grid = (a.N + kBlock - 1) / kBlock;
     const int ring = a.delay >= 1 && a.delay <= kPostRegDelay ? 2 : (a.delay >= 1 && a.delay <= kPostLdsDelay ? 1 : 0);
-#define MDPP_POST_LAUNCH(PH, LR) hipLaunchKernelGGL((k_post_step<PH, LR>), dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, \
-                                                    reward_in_dev, done_dev, obs_out_dev, reward_out_dev)
-    if (a.philox) { if (ring == 2) MDPP_POST_LAUNCH(true, 2); else if (ring == 1) MDPP_POST_LAUNCH(true, 1); else MDPP_POST_LAUNCH(true, 0); }
-    else { if (ring == 2) MDPP_POST_LAUNCH(false, 2); else if (ring == 1) MDPP_POST_LAUNCH(false, 1); else MDPP_POST_LAUNCH(false, 0); }
+#define MDPP_POST_LAUNCH(PH, LR, DC) hipLaunchKernelGGL((k_post_step<PH, LR, DC>), dim3(grid), dim3(kBlock), 0, s, a, K, obs_in_dev, \
+                                                        reward_in_dev, done_dev, obs_out_dev, reward_out_dev)
+#define MDPP_POST_REG(PH)                                                                        \
+    switch (a.delay) {                                                                           \
+    case 1: MDPP_POST_LAUNCH(PH, 2, 1); break; case 2: MDPP_POST_LAUNCH(PH, 2, 2); break;        \
+    case 3: MDPP_POST_LAUNCH(PH, 2, 3); break; case 4: MDPP_POST_LAUNCH(PH, 2, 4); break;        \
+    case 5: MDPP_POST_LAUNCH(PH, 2, 5); break; case 6: MDPP_POST_LAUNCH(PH, 2, 6); break;        \
+    case 7: MDPP_POST_LAUNCH(PH, 2, 7); break; default: MDPP_POST_LAUNCH(PH, 2, 8); break;       \
+    }
+    if (a.philox) { if (ring == 2) { MDPP_POST_REG(true); } else if (ring == 1) MDPP_POST_LAUNCH(true, 1, 0); else MDPP_POST_LAUNCH(true, 0, 0); }
+    else { if (ring == 2) { MDPP_POST_REG(false); } else if (ring == 1) MDPP_POST_LAUNCH(false, 1, 0); else MDPP_POST_LAUNCH(false, 0, 0); }
+#undef MDPP_POST_REG
 #undef MDPP_POST_LAUNCH
     if (h->cfg.image) launch_post_image(h, a, (long)K * a.N, obs_in_dev, obs_out_dev, s);
     PHIP(h, hipGetLastError());
