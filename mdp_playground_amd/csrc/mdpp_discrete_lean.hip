@@ -6,7 +6,7 @@
 //
 // A 1024-thread workgroup steps 256 envs, lane l of waves w, w+4, w+8, w+12 serving the same env:
 //   E   waves 0-3    state recurrence, same-step autoreset from the queue of pre-drawn start states;
-//                    three (four) dwords per env step into LDS rings
+//                    three dwords per env step into an LDS ring (13 instructions per step)
 //   O1  waves 4-7    reward path: reward bit, delay line, reward value; stores `reward`
 //   O2  waves 8-11   stores `obs`, `terminated`, `truncated` (and final_obs)
 //   H   waves 12-15  own the envs' PCG64 streams for the launch and keep an LDS ring of pre-drawn
@@ -24,8 +24,8 @@
 //     low nibbles, zero wherever one of the L + 1 nibbles it needs is not a state
 //   * truncation: the step counter is biased so that bit 16 is set exactly when steps >= max_steps;
 //     byte 2 of the counter is the `truncated` byte
-//   * reward_every_n_steps: a down-counter in units of 16 that indexes the reward-value table
-//     (only its row 0 hands out the bit), so the gate (:1975-1976) costs no instruction in O1
+//   * reward_every_n_steps: a down-counter in units of 16, kept by the O1 lane, that indexes the
+//     reward-value table (only its row 0 hands out the bit): the gate (:1975-1976) is part of the lookup
 //   * the queue of pre-drawn start states keeps bit 3 of every nibble it holds, so "queue empty"
 //     is a test of its low nibble and no count is kept
 //   * reward value: one LDS read of a table indexed by (steps to the next pay step, delayed bit, terminated)
