@@ -67,6 +67,9 @@ namespace mdpp {
 #ifndef MDPP_LEAN_ST_AUX
 #define MDPP_LEAN_ST_AUX MDPP_ST_NT
 #endif
+#ifndef MDPP_LEAN_ST_AUX_BYTES
+#define MDPP_LEAN_ST_AUX_BYTES MDPP_LEAN_ST_AUX
+#endif
 #ifndef MDPP_LEAN_LD_AUX
 #define MDPP_LEAN_LD_AUX 0
 #endif
@@ -411,8 +414,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NOBYTES
             status ^= rc & 0x100u;
 #else
-            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rc >> 7) & 1u), r_term, v1, so, MDPP_LEAN_ST_AUX);
-            __builtin_amdgcn_raw_buffer_store_b8(HASMAX ? (uint8_t)(rc >> 16) : (uint8_t)0, r_trunc, v1, so, MDPP_LEAN_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rc >> 7) & 1u), r_term, v1, so, MDPP_LEAN_ST_AUX_BYTES);
+            __builtin_amdgcn_raw_buffer_store_b8(HASMAX ? (uint8_t)(rc >> 16) : (uint8_t)0, r_trunc, v1, so, MDPP_LEAN_ST_AUX_BYTES);
 #endif
         };
         auto emit_final = [&](uint32_t ra, uint32_t rb, uint32_t so) {       // state reached, where a reset replaced it
