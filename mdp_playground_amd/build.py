@@ -60,7 +60,10 @@ def build(force=False, verbose=False):
         return r.stdout
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        # the long compiles first (template-heavy kernels: 1.5-3 min each), as many at once as there are cores to spare
+        heavy = ("mdpp_continuous_fast", "mdpp_discrete_lean", "mdpp_discrete_quiet", "mdpp_grid", "mdpp_continuous.")
+        jobs.sort(key=lambda c: next((k for k, h in enumerate(heavy) if h in c[-3]), len(heavy)))
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4) - 1, 7))) as ex:
             for out in ex.map(run, jobs):
                 if verbose and out.strip():
                     print(out)
