@@ -311,8 +311,10 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             }
             // (an unbounded box is fine as long as the actions are bounded: states then stay finite, which
             // the fast kernel's clip relies on -- np.clip's NaN propagation lives in the general kernel)
-            a.fast_ok = (a.rel_prefix && !cfg->image && !line &&
-                         cfg->autoreset != MDPP_AUTORESET_NEXT_STEP &&
+            // (next-step autoreset: without noise or with Philox streams -- numpy noise streams are drawn ahead per step)
+            const bool next_ok = cfg->autoreset != MDPP_AUTORESET_NEXT_STEP || cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 ||
+                                 (!cfg->has_transition_noise && !cfg->has_reward_noise);
+            a.fast_ok = (a.rel_prefix && !cfg->image && !line && next_ok &&
                          (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
         }

@@ -287,6 +287,12 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     for (int d = 0; d < D; d++) cur[d] = a.cur[(size_t)d * N + i];
     uint2 meta = a.meta[i];
     uint32_t steps = meta.x, flags = meta.y, status = 0;
+    // gymnasium's next-step autoreset (the call after an episode's last step IS the reset: action ignored, reward 0, no
+    // flags); "episode ended" travels in bit 1 of the flags word like in k_continuous_step.  Served here without noise or
+    // with Philox streams: numpy noise streams are drawn ahead per step, and a reset call must not move them.
+    const bool nextmode = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    bool pend = nextmode && (flags & 2u) != 0u;
+    flags &= ~2u;
 
     Pcg64 g;
     if (ZIG && !HELPER) g.load(a.env_s, a.env_inc, i);
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         for (int d = 0; d < D; d++) nxt[d] = (ALL || ok) ? sd[0][d] : cur[d];                  // "stay", :1671
         };
         if (all_ok) integrate(std::true_type{}); else integrate(std::false_type{});
-        status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+        status |= (ok || pend) ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;      // (an action the reset call ignores is no error)
         // ---- C3
         if (NOISE && a.has_p_noise) {           // (the wave-uniform test outside the per-dimension loop)
 #pragma unroll
@@ -531,15 +537,23 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             if (done) { if (is32) rv = (double)((float)rv + a.term_add32); else rv = rv + a.term_add; }
             r = (float)rv;
         }
-        const bool tr = has_max && steps >= max_steps;
+        bool tr = has_max && steps >= max_steps;
         dist_prev = dist_new;
 #pragma unroll
         for (int d = 0; d < D; d++) cur[d] = nxt[d];
         // ---- episode end: same-step autoreset (reset(), :2284-2323), rare
-        const bool need = autoreset && (done || tr);
+        bool need = autoreset && (done || tr);
+        if (nextmode) {                  // ... or the reset one call later: whatever this lane just computed is dropped
+            const bool ended = (done || tr) && !pend;
+            need = pend;
+            r = pend ? 0.0f : r;
+            done = pend ? false : done;
+            tr = pend ? false : tr;
+            pend = ended;
+        }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0, 0)) {
             if (need) {
-                if (final_obs) {
+                if (final_obs && !nextmode) {
 #pragma unroll
                     for (int d = 0; d < D; d++) final_obs[((size_t)so + i) * D + d] = nxt[d];
                 }
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         for (int d = 0; d < D; d++) a.sd[((size_t)k * D + d) * N + i] = sd[k][d];
 #pragma unroll
     for (int d = 0; d < D; d++) a.cur[(size_t)d * N + i] = cur[d];
-    a.meta[i] = make_uint2(steps, flags);
+    a.meta[i] = make_uint2(steps, flags | (pend ? 2u : 0u));
     if (ZIG && !HELPER) g.store(a.env_s, i);
     if (status) atomicOr(&a.status[i], status);
 }

@@ -268,6 +268,11 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
     const uint32_t N = (uint32_t)a.N;
     const uint4 st = a.state[i];
     uint32_t cells = st.x, steps = st.y, flags = st.z, status = 0;   // one byte per dimension
+    // next-step autoreset (bit 1 of the flags word, as in k_grid_step): the call after an episode's last step is the
+    // reset -- action ignored, nothing drawn from the noise streams, reward 0, no flags
+    const bool nextmode = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    bool pend = nextmode && (flags & 2u) != 0u;
+    flags &= ~2u;
     typedef typename std::conditional<PH, Philox, Pcg64>::type Gen;
     Gen sp, env, actg;
     Half32 acth{0, 0};
@@ -364,10 +369,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         const uint32_t a0 = (uint32_t)(act.x + 1), a1 = (uint32_t)(act.y + 1), a2 = (uint32_t)(act.z + 1), a3 = (uint32_t)(act.w + 1);
         const int nz = (act.x != 0) + (act.y != 0) + (G4 ? (act.z != 0) + (act.w != 0) : 0);
         const bool ok = a0 <= 2u && a1 <= 2u && (!G4 || (a2 <= 2u && a3 <= 2u)) && nz <= 1;
-        status |= ok ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
+        status |= (ok || pend) ? 0u : (uint32_t)MDPP_STATUS_BAD_ACTION;
         if (PN) {
             bool redraw = false;
-            if (ok) redraw = np_random(env) < a.p_noise;
+            if (ok && !pend) redraw = np_random(env) < a.p_noise;
             if (__builtin_amdgcn_ballot_w64(redraw) != 0) {
                 if (redraw) {
                     for (int tries = 0;; tries++) {
@@ -393,17 +398,25 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         else r += on_target ? 1.0 : 0.0;
         phase = (phase + 1 >= every_n) ? 0u : phase + 1;          // steps % every_n, carried
         r = phase != 0 ? 0.0 : r;
-        if (RN) r += 0.0 + a.r_noise * np_standard_normal_lds(env, zig);
+        if (RN) { if (!pend) r += 0.0 + a.r_noise * np_standard_normal_lds(env, zig); }
         r *= a.scale;
         r += a.shift;
-        const bool done = (flags & 1u) != 0;
+        bool done = (flags & 1u) != 0;
         if (RN) { if (done) r += a.term_add; }    // (with noise r can be -0.0: add only where the reference does)
         else r += done ? a.term_add : 0.0;        // r is not -0.0 here (a +0.0 shift was just added), so + 0.0 is the identity
-        const bool tr = has_max && steps >= max_steps;
+        bool tr = has_max && steps >= max_steps;
         uint32_t nc = (uint32_t)n0 | ((uint32_t)n1 << 8) | ((uint32_t)n2 << 16) | ((uint32_t)n3 << 24);
         const uint32_t so = (uint32_t)k;
-        const bool need = autoreset && (done || tr);
-        if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
+        bool need = autoreset && (done || tr);
+        if (nextmode) {                           // the reset one call later: what this lane just computed is dropped
+            const bool ended = (done || tr) && !pend;
+            need = pend;
+            r = pend ? 0.0 : r;
+            done = pend ? false : done;
+            tr = pend ? false : tr;
+            pend = ended;
+        }
+        if (final_obs && !nextmode && __builtin_amdgcn_ballot_w64(need) != 0) {
             if (need) put_cells(r_fin, so, nc);
         }
         if constexpr (PH) {                       // reset(): drawn now from this step's feature-space stream
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
             a.act_half[i] = make_uint2(acth.has32, acth.u32);
         }
     }
-    a.state[i] = make_uint4(cells, steps, flags, 0u);
+    a.state[i] = make_uint4(cells, steps, flags | (pend ? 2u : 0u), 0u);
     if (status) atomicOr(&a.status[i], status);
 }
 
@@ -468,7 +481,7 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)
-    if (!(a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) && a.autoreset != MDPP_AUTORESET_NEXT_STEP &&
+    if (!(a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) &&
         !(noise && (a.opts & MDPP_OPT_NO_GFAST_NOISE)) && !(a.opts & MDPP_OPT_NO_GFAST) &&
         (unsigned long long)K * a.N * a.G * 8ULL < (1ULL << 32)) {
         const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;

@@ -53,9 +53,12 @@ def test_next_step_autoreset_vs_oracle_loop(name, max_steps, fused):
     cfg = dict(gu.CASES[name]["config"], seed=13)
     N, T = 384, 60
     env = _venv(num_envs=N, autoreset="next_step", max_episode_steps=max_steps or None, **cfg)
-    if name == "d_cfg2":                                           # at most 8 states, no noise: the lean rollout kernel takes this mode
-        assert env.rollout_kernel_name(T).startswith("k_discrete_rollout_lean<"), env.rollout_kernel_name(T)
-    else:                                                          # general kernels serve it
+    fused_kernel = {"d_cfg2": "k_discrete_rollout_lean<",          # at most 8 states, no noise
+                    "c_sparse_term": "k_continuous_rollout_fast<",  # no noise (numpy noise streams are drawn ahead per step)
+                    "g_noise_sparse": "k_grid_rollout_fast<"}.get(name)
+    if fused_kernel:
+        assert env.rollout_kernel_name(T).startswith(fused_kernel), env.rollout_kernel_name(T)
+    else:                                                          # general kernels serve the mode
         assert "rollout" not in env.rollout_kernel_name(T)
     rng = np.random.default_rng(3)
     acts = _rand_actions(env, T, rng)

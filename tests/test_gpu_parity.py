@@ -1681,6 +1681,13 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     ("cfg2_irr", {"rng": "philox", "transition_noise": 0.1, "reward_noise": 0.2}, "NO_PHILOX_FAST", 32768, 64),
     ("grid", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),
     ("grid", {"rng": "philox", "irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "NO_PHILOX_FAST", 32768, 128),
+    # next-step autoreset on the fused kernels (pending flag in the flags word; a reset call draws nothing from the noise streams)
+    ("cfg3", {"autoreset": "next_step", "max_episode_steps": 7}, "NO_CFAST", 16384, 64),
+    ("cfg3", {"autoreset": "next_step", "max_episode_steps": 5, "delay": 2, "target_radius": 6.0}, "NO_CFAST", 16384, 64),
+    ("cfg5", {"rng": "philox", "autoreset": "next_step", "max_episode_steps": 5}, "NO_PHILOX_FAST", 16384, 64),
+    ("grid", {"autoreset": "next_step"}, "NO_GFAST", 16384, 128),
+    ("grid", {"autoreset": "next_step", "transition_noise": 0.2, "reward_noise": 0.1, "max_episode_steps": 11}, "NO_GFAST", 16384, 128),
+    ("grid", {"rng": "philox", "autoreset": "next_step", "transition_noise": 0.2}, "NO_PHILOX_FAST", 16384, 128),
 ])
 def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag, N, F):
     """Every specialised rollout kernel against the general kernel of the same arithmetic, on EVERY env
@@ -1691,13 +1698,15 @@ def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag
     wl = bench.WORKLOADS[workload]
     over = dict(over)
     rng = over.pop("rng", "numpy")
+    ekw = dict(autoreset=over.pop("autoreset", "same_step"), max_episode_steps=over.pop("max_episode_steps", None))
     cfg = dict(wl["config"], **over)
     cfg = {k: v for k, v in cfg.items() if v is not None}       # (None: drop the key from the workload's config)
-    a = _venv(num_envs=N, autoreset="same_step", rng=rng, **cfg)
-    b = _venv(num_envs=N, autoreset="same_step", rng=rng, **cfg)
+    a = _venv(num_envs=N, rng=rng, **ekw, **cfg)
+    b = _venv(num_envs=N, rng=rng, **ekw, **cfg)
     b.set_kernel_options(*flag.split(","))
     assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F), (a.rollout_kernel_name(F), flag)
     wl2 = dict(wl, config=cfg)
+    ended = 0
     for j in range(3):
         acts = bench.make_actions(wl2, F, N, a.device, 100 + j)
         ra = a.rollout(acts)
@@ -1705,6 +1714,9 @@ def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag
         torch.cuda.synchronize()
         for x, y in zip(ra, rb):
             assert torch.equal(x, y), (workload, j)
+        ended += int((ra[2] | ra[3]).sum())
+    if ekw["autoreset"] == "next_step":
+        assert ended > 0                                         # (some episodes ended: the reset calls were exercised)
     streams = [capi.STREAM_ENV, capi.STREAM_SPACE] if rng == "numpy" else []       # (Philox: no stream state)
     if a.kind == "grid":
         streams.append(capi.STREAM_ACTION)
