@@ -162,7 +162,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const uint32_t N = (uint32_t)a.N, S = (uint32_t)a.S, A = (uint32_t)a.A, L = (uint32_t)a.L;
     const uint4 st = a.state[i];
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
-    uint32_t steps = st.z, ringbits = st.w, status = 0;
+    // next-step autoreset: "episode ended, reset at the next call" travels in bit 31 of the step counter (k_discrete_step);
+    // the reset call ignores the action, draws nothing from the noise streams and returns (start state, 0.0, no flags)
+    const bool nextmode = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    uint32_t steps = st.z & 0x7FFFFFFFu, ringbits = st.w, status = 0;
+    bool pend = nextmode && (st.z >> 31) != 0u;
     uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
     typedef typename std::conditional<PH, Philox, Pcg64>::type Gen;
     Gen g, sp, sp1;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (PN) {                                                            // D2 (:1604-1622)
             uint64_t m;
             if constexpr (NPH > 0) m = hent & ((1ull << 53) - 1ull);
-            else m = sp.next64() >> 11;
+            else { m = 0; if (!pend) m = sp.next64() >> 11; }
             const uint64_t *row = TN + nxt * S8;
             uint32_t c = 0;
             for (uint32_t b = 0; b < S8; b += 8) {
@@ -403,7 +407,8 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             action1 = bad1 ? 0 : action1;
             cur1 = P1[cur1 * (uint32_t)a.A1 + (uint32_t)action1];
             if (PN) {                                                        // its own P-noise stream (:2066-2080)
-                const uint64_t m1 = sp1.next64() >> 11;
+                uint64_t m1 = 0;
+                if (!pend) m1 = sp1.next64() >> 11;
                 const uint64_t *row = TN1 + cur1 * S18;
                 uint32_t c = 0;
                 for (uint32_t b = 0; b < S18; b += 8) {
@@ -413,19 +418,27 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                 cur1 = c;
             }
         }
-        status |= (bad || bad1) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+        status |= ((bad || bad1) && !pend) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
         if (RN) {                                                           // D6: drawn in reward_function, before any reset
             if constexpr (NPH > 0) z = (double)s_hz[(kstep % kHD) * kBlock + l];
-            else z = np_standard_normal_lds(g, zig);
+            else { z = 0.0; if (!pend) z = np_standard_normal_lds(g, zig); }
         }
-        const bool tr = has_max && steps >= max_steps;
-        const bool need = autoreset && (done || tr);
+        bool tr = has_max && steps >= max_steps;
+        bool need = autoreset && (done || tr);
+        bool done_out = done;
+        if (nextmode) {                           // the reset one call later: what this lane just computed is dropped
+            const bool ended = (done || tr) && !pend;
+            need = pend;
+            done_out = pend ? false : done;
+            tr = pend ? false : tr;
+            pend = ended;
+        }
         if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
             if constexpr (NPH > 0) { queue[0] = need ? (uint32_t)(hent >> 56) : queue[0]; }
             else if (need) { queue[0] = draw_state(); }
             qn = need ? 1u : qn;
         }
-        uint32_t hi = (done ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |
+        uint32_t hi = (done_out ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |
                       (phase == 0 ? 16u : 0u) | (key << 5);
         uint32_t lo = (nxt << 8) | (cur1 << 24);
         // reset(): pop the next queued start state where the episode ended (:2250-2278)
@@ -465,7 +478,8 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             rout = s_rsel[(bit << 1) | done];
         }
         const bool need = (hi & 4u) != 0;
-        if (final_obs && __builtin_amdgcn_ballot_w64(need) != 0) {
+        if (nextmode) rout = need ? 0.0f : rout;                             // the reset call pays 0.0
+        if (final_obs && !nextmode && __builtin_amdgcn_ballot_w64(need) != 0) {
             if (need) put_obs(r_fin, so, (lo >> 8) & 0xFFu, lo >> 24);
         }
         ringbits = need ? 0u : ringbits;
@@ -601,10 +615,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (IRR) a.irr_state[i] = cur1;
     }
     if (!DUO) {
-        a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps, ringbits);
+        a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps | (pend ? 0x80000000u : 0u), ringbits);
     } else {
         uint32_t *st32 = (uint32_t *)&a.state[i];
-        if (role == 0) { st32[0] = (uint32_t)hist; st32[1] = (uint32_t)(hist >> 32); st32[2] = steps; }
+        if (role == 0) { st32[0] = (uint32_t)hist; st32[1] = (uint32_t)(hist >> 32); st32[2] = steps | (pend ? 0x80000000u : 0u); }
         else st32[3] = ringbits;                        // the delay line belongs to the O lane
     }
     if (status) atomicOr(&a.status[i], status);
@@ -628,7 +642,6 @@ static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t
 // Serves the launch if the handle and the launch shape qualify; false = not taken.
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
-    if (a.autoreset == MDPP_AUTORESET_NEXT_STEP) return false;
     if (!a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
         return false;
     if (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
@@ -651,7 +664,11 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = trio ? 3 : duo ? 2 : 1;
     // Philox handles in two roles without an irrelevant sub-space: two producer waves on top (see NPH)
-    const int nph = (ph && duo && !a.irr && a.autoreset && lds_duo + 56 * 1024 <= 150 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO)) ? 2 : 0;
+    // (not with next-step autoreset + reward noise: a reset call draws its start state from the FIRST words of the
+    //  tick's block, a terminal step from the words after the reward normal -- the producers cannot tell which)
+    const bool next_rn = a.autoreset == MDPP_AUTORESET_NEXT_STEP && rn;
+    const int nph = (ph && duo && !a.irr && a.autoreset && !next_rn && lds_duo + 56 * 1024 <= 150 * 1024 &&
+                     !(a.opts & MDPP_OPT_NO_TRIO)) ? 2 : 0;
     if (name_out) {
         snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d,NPH=%d>", !a.obs_i32,
                  a.irr != 0, roles, pn, rn, ph, nph);

@@ -55,7 +55,9 @@ def test_next_step_autoreset_vs_oracle_loop(name, max_steps, fused):
     env = _venv(num_envs=N, autoreset="next_step", max_episode_steps=max_steps or None, **cfg)
     fused_kernel = {"d_cfg2": "k_discrete_rollout_lean<",          # at most 8 states, no noise
                     "c_sparse_term": "k_continuous_rollout_fast<",  # no noise (numpy noise streams are drawn ahead per step)
-                    "g_noise_sparse": "k_grid_rollout_fast<"}.get(name)
+                    "g_noise_sparse": "k_grid_rollout_fast<",
+                    "d_cfg2_noise": "k_discrete_rollout_quiet<",    # inline draws, skipped on a reset call
+                    "d_irr_noise": "k_discrete_rollout_quiet<"}.get(name)
     if fused_kernel:
         assert env.rollout_kernel_name(T).startswith(fused_kernel), env.rollout_kernel_name(T)
     else:                                                          # general kernels serve the mode

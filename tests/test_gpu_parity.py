@@ -1584,7 +1584,7 @@ def test_lean_rollout_kernel_next_step_autoreset_vs_general_kernel(shape, rng_mo
     if odt == "int32":
         kw["dtype_o"] = np.int32
     a, b = _venv(**kw), _venv(**kw)
-    b.set_kernel_options("NO_LEAN")
+    b.set_kernel_options("NO_LEAN", "NO_QUIET")
     assert a.rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), a.rollout_kernel_name(64)
     assert b.rollout_kernel_name(64).startswith("k_discrete_step<"), b.rollout_kernel_name(64)
     irr = isinstance(cfg["action_space_size"], list)
@@ -1682,6 +1682,9 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     ("grid", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),
     ("grid", {"rng": "philox", "irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "NO_PHILOX_FAST", 32768, 128),
     # next-step autoreset on the fused kernels (pending flag in the flags word; a reset call draws nothing from the noise streams)
+    ("cfg2_noise", {"autoreset": "next_step", "max_episode_steps": 9}, "NO_QUIET", 16384, 128),       # (two roles)
+    ("cfg2_noise", {"rng": "philox", "autoreset": "next_step"}, "NO_PHILOX_FAST", 16384, 128),         # (Philox producers)
+    ("cfg2_irr", {"autoreset": "next_step", "state_space_size": [8, 11], "action_space_size": [8, 11]}, "NO_QUIET", 16384, 128),  # (three roles)
     ("cfg3", {"autoreset": "next_step", "max_episode_steps": 7}, "NO_CFAST", 16384, 64),
     ("cfg3", {"autoreset": "next_step", "max_episode_steps": 5, "delay": 2, "target_radius": 6.0}, "NO_CFAST", 16384, 64),
     ("cfg5", {"rng": "philox", "autoreset": "next_step", "max_episode_steps": 5}, "NO_PHILOX_FAST", 16384, 64),
