@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // (a template flag, instantiated in its own translation unit, mdpp_discrete_lean_next.hip: as a run-time
     //  flag its selects cost the same-step mode 9 us of 106 per launch)
     constexpr bool nextmode = NEXT;
+    const bool ar = a.autoreset != 0;               // autoreset "disabled" (the reference's own behaviour): no resets, H idle
     const int tid = threadIdx.x;
     const int role = tid / kBlock;                  // 0 = E, 1 = O1, 2 = O2, 3 = H
     const int l = tid & (kBlock - 1);               // env slot inside the block
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NOH
         return;
 #endif
+        if (!ar) return;
         if constexpr (PHILOX) {
             // Philox streams: the start state a reset at tick t draws is a function of (seed, env, t) alone
             // (first 64 bits of block 0 of the env stream, as in k_discrete_step / _quiet), so H makes the one
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     const uint32_t A1 = IRR ? (uint32_t)a.A1 : 1u;
 
     auto pull = [&](int c) {
+        if (!ar) return;                            // (no resets: nothing is drawn, the H lanes have left)
         if constexpr (PHILOX) {                     // this chunk's start states, made by the H wave
             uint32_t spins = 0;
             while (wg_load_acq(&lds_hprod[w]) < (uint32_t)(c + 1)) {
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NORESET
         need = false;
 #endif
+        need = need && ar;
         uint32_t rec_a = k2n;
         if (nextmode) {
             const bool ended = need && !pend;
@@ -717,8 +721,9 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
     const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? (a.lean_next_ok != 0 && final_obs == nullptr)
                        : irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
     if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
-        !a.autoreset || (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
+        (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
+    if (!a.autoreset && a.max_steps > 0) return false;      // (the biased step counter saturates only through resets)
     if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
     if (irr && (a.S1 > 8 || a.A1 > 16 || final_obs != nullptr || (8ULL * 2 * a.N * (unsigned long long)K) >= (1ULL << 32)))
         return false;

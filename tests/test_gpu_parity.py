@@ -1569,6 +1569,41 @@ def test_lean_rollout_kernel_vs_oracle_and_other_kernels(shape, rng_mode):
 
 
 @pytest.mark.parametrize("rng_mode", ["numpy", "philox"])
+@pytest.mark.parametrize("shape", ["l3_d4", "l1_d0", "irr_l3_d4"])
+def test_lean_rollout_kernel_without_autoreset_vs_single_role_kernel(shape, rng_mode):
+    """autoreset="disabled" (what the reference itself does: it keeps stepping from the terminal state until the caller
+    resets): the lean kernel with its H lanes idle against the kernel the golden parity tests run on, masked resets
+    by the caller in between, stream end states."""
+    extra, _, _ = LEAN_SHAPES[shape]
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", seed=31, **extra)
+    N = 2048
+    a = _venv(num_envs=N, autoreset="disabled", rng=rng_mode, **cfg)
+    b = _venv(num_envs=N, autoreset="disabled", rng=rng_mode, **cfg)
+    b.set_kernel_options("NO_LEAN", "NO_PIPE", "NO_QUIET")
+    assert a.rollout_kernel_name(64).startswith("k_discrete_rollout_lean<"), a.rollout_kernel_name(64)
+    assert not b.rollout_kernel_name(64).startswith("k_discrete_rollout_lean<")
+    irr = isinstance(cfg["action_space_size"], list)
+    A, A1 = (cfg["action_space_size"] if irr else (cfg["action_space_size"], None))
+    g = torch.Generator(device=a.device)
+    g.manual_seed(3)
+    for K in (40, 33, 64):
+        acts = torch.randint(0, A, (K, N), generator=g, device=a.device, dtype=torch.int32)
+        if irr:
+            acts = torch.stack([acts, torch.randint(0, A1, (K, N), generator=g, device=a.device, dtype=torch.int32)], dim=2)
+        ra, rb = a.rollout(acts), b.rollout(acts)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (shape, K)
+        assert bool(ra[2][-1].any())                              # terminal envs keep reporting terminated
+        mask = ra[2][-1].clone()
+        oa, ob = a.reset(mask=mask)[0], b.reset(mask=mask)[0]
+        assert torch.equal(oa, ob)
+    if rng_mode == "numpy":
+        assert np.array_equal(a.get_rng_streams(0), b.get_rng_streams(0))
+    assert (a.status() == 0).all() and (b.status() == 0).all()
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("rng_mode", ["numpy", "philox"])
 @pytest.mark.parametrize("shape", sorted(LEAN_SHAPES))
 def test_lean_rollout_kernel_next_step_autoreset_vs_general_kernel(shape, rng_mode):
     """autoreset="next_step" on the lean kernel (the pending flag in bit 31 of the step counter, the reset call's
