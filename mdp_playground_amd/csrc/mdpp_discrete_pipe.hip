@@ -317,47 +317,62 @@ __global__ __launch_bounds__(3 * kBlock) void k_discrete_rollout_pipe(DiscreteAr
         const uint32_t kk = (uint32_t)min(k, K - 1);
         return __builtin_amdgcn_raw_buffer_load_b32(r_act, v4, kk * N * 4u, 0);
     };
-    int act1[kChunk];
-    uint64_t col0[kChunk];
+    // Actions are fetched kPipeAhead chunks ahead of their use, columns one chunk ahead.  The buffers rotate by
+    // NAME (chunk loop unrolled kPipeAhead times, single exit, no global load in an inner loop): a copy of a
+    // register whose load is in flight makes the wave wait for the load, and a `break` in the unrolled body makes
+    // it wait for every load at the loop head (found on k_discrete_rollout_lean, profiles/r02_ablation_lean_kernel.txt)
+    constexpr int kPipeAhead = 2;
+    int actq[kPipeAhead][kChunk];   // slot (m - 1) % kPipeAhead holds the actions of chunk m
+    uint64_t colq[2][kChunk];       // slot m & 1 holds the columns of chunk m
 #pragma unroll
-    for (int u = 0; u < kChunk; u++) act1[u] = load_act(u);
+    for (int u = 0; u < kChunk; u++) colq[0][u] = column(load_act(u));
 #pragma unroll
-    for (int u = 0; u < kChunk; u++) col0[u] = column(act1[u]);
+    for (int q = 0; q < kPipeAhead; q++)
 #pragma unroll
-    for (int u = 0; u < kChunk; u++) act1[u] = load_act(kChunk + u);
-
-    for (int c = 0; c < nchunks; c++) {
-        const int kbase = c * kChunk;
-        // do not run more than kDepth - kChunk steps ahead of the O wave
-        if (kbase + kChunk > kDepth) {
-            const uint32_t must = (uint32_t)(kbase + kChunk - kDepth);
+        for (int u = 0; u < kChunk; u++) actq[q][u] = load_act((q + 1) * kChunk + u);
+    auto wait_room = [&](int kend) {                // do not run more than kDepth steps ahead of the O wave
+        if (kend > kDepth) {
+            const uint32_t must = (uint32_t)(kend - kDepth);
             uint32_t spins = 0;
             while (wg_load_acq(&lds_cons[w]) < must) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
         }
-        int act2[kChunk];
+    };
+    auto chunkE = [&](int c, int j, bool refill) {
+        const int kbase = c * kChunk;
 #pragma unroll
-        for (int u = 0; u < kChunk; u++) act2[u] = load_act(kbase + 2 * kChunk + u);
-        uint64_t col1[kChunk];
+        for (int u = 0; u < kChunk; u++) colq[(j + 1) & 1][u] = column(actq[j][u]);
+        if (refill) {
 #pragma unroll
-        for (int u = 0; u < kChunk; u++) col1[u] = column(act1[u]);
-        if (autoreset) pull();
-        if (kbase + kChunk <= K) {
-#pragma unroll
-            for (int u = 0; u < kChunk; u++) stepE(col0[u], kbase + u);
-        } else {
-            for (int k = kbase; k < K; k++) {
-                uint64_t cc = col0[0];
-#pragma unroll
-                for (int u = 1; u < kChunk; u++) cc = (k - kbase == u) ? col0[u] : cc;
-                stepE(cc, k);
-            }
+            for (int u = 0; u < kChunk; u++) actq[j][u] = load_act(kbase + (kPipeAhead + 1) * kChunk + u);
         }
-        if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)min(kbase + kChunk, K));
+        wait_room(kbase + kChunk);
+        if (autoreset) pull();
 #pragma unroll
-        for (int u = 0; u < kChunk; u++) { col0[u] = col1[u]; act1[u] = act2[u]; }
+        for (int u = 0; u < kChunk; u++) stepE(colq[j & 1][u], kbase + u);
+        if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)(kbase + kChunk));
+    };
+    const int nfull = K / kChunk, ngrp = nfull / kPipeAhead;
+    for (int g = 0; g < ngrp; g++) {
+#pragma unroll
+        for (int j = 0; j < kPipeAhead; j++) chunkE(g * kPipeAhead + j, j, true);
+    }
+#pragma unroll
+    for (int j = 0; j < kPipeAhead - 1; j++)
+        if (ngrp * kPipeAhead + j < nfull) chunkE(ngrp * kPipeAhead + j, j, false);
+    if (K % kChunk) {               // the ragged tail, outside the loop
+        const int kbase = nfull * kChunk;
+        int ta[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; u++) ta[u] = load_act(kbase + u);
+        wait_room(kbase + kChunk);
+        if (autoreset) pull();
+#pragma unroll
+        for (int u = 0; u < kChunk; u++)
+            if (kbase + u < K) stepE(column(ta[u]), kbase + u);
+        if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)K);
     }
 
     uint32_t *st = (uint32_t *)&a.state[i];
