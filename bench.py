@@ -449,7 +449,7 @@ def main():
         dist.destroy_process_group()
 
 
-def live_traffic(workload, rng, N, F, launches=4, timeout=150):
+def live_traffic(workload, rng, N, F, launches=4, timeout=75):
     """HBM bytes per launch of the dominant kernel from PMC counters, measured NOW: two child rocprofv3 runs
     (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: they do not fit one pass) of tools/run_variant.py, which
     launches the same fused rollouts; read bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B read requests at
