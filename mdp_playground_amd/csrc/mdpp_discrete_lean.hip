@@ -8,7 +8,7 @@
 //   E   waves 0-3    state recurrence, same-step autoreset from the queue of pre-drawn start states;
 //                    three dwords per env step into an LDS ring (13 instructions per step)
 //   O1  waves 4-7    reward path: reward bit, delay line, reward value; stores `reward`
-//   O2  waves 8-11   stores `obs`, `terminated`, `truncated` (and final_obs)
+//   O2  waves 8-11   stores `obs`, `terminated`, `truncated`
 //   H   waves 12-15  own the envs' PCG64 streams for the launch and keep an LDS ring of pre-drawn
 //                    rho_0 start states filled; un-draw what was not used at the end
 // Hand-offs and spin bounds as in mdpp_discrete_pipe.hip (single-producer rings, monotonic counters,
@@ -392,9 +392,6 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
-        auto r_fin = __builtin_amdgcn_make_buffer_rsrc(final_obs ? final_obs : obs, 0,
-                                                       total * (OBS64 ? 8u : 4u), kPRsrc);
-        const bool want_final = final_obs != nullptr;
         const uint32_t v1 = i, v4 = i * 4u, v8 = i * 8u, v16 = i * 16u;
         auto emit = [&](uint32_t rb, uint32_t rc, uint32_t so) {
             const uint32_t o = rb & 7u;
@@ -420,13 +417,6 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             __builtin_amdgcn_raw_buffer_store_b8(HASMAX ? (uint8_t)(rc >> 16) : (uint8_t)0, r_trunc, v1, so, MDPP_LEAN_ST_AUX_BYTES);
 #endif
         };
-        auto emit_final = [&](uint32_t ra, uint32_t rb, uint32_t so) {       // state reached, where a reset replaced it
-            if (ra != rb) {
-                const uint32_t nx = ra & 7u;
-                if (OBS64) __builtin_amdgcn_raw_buffer_store_b64(u32x2{nx, 0u}, r_fin, v8, so * 8u, 0);
-                else __builtin_amdgcn_raw_buffer_store_b32(nx, r_fin, v4, so * 4u, 0);
-            }
-        };
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kChunk;
             const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
@@ -448,15 +438,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 }
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) emit(rb[u], rc[u], (uint32_t)(kbase + u) * N);
-                if (__builtin_expect(want_final, 0)) {
-#pragma unroll
-                    for (int u = 0; u < kChunk; u++) emit_final(lds_rec[0][(kbase + u) % kDepth][l], rb[u], (uint32_t)(kbase + u) * N);
-                }
             } else {
-                for (int k = kbase; k < K; k++) {
-                    emit(lds_rec[1][k % kDepth][l], lds_rec[2][k % kDepth][l], (uint32_t)k * N);
-                    if (want_final) emit_final(lds_rec[0][k % kDepth][l], lds_rec[1][k % kDepth][l], (uint32_t)k * N);
-                }
+                for (int k = kbase; k < K; k++) emit(lds_rec[1][k % kDepth][l], lds_rec[2][k % kDepth][l], (uint32_t)k * N);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][1], upto);
         }
@@ -718,14 +701,15 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
         return launch_discrete_lean_next(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
 #endif
     const bool ph = a.philox != 0, irr = a.irr != 0;
-    const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? (a.lean_next_ok != 0 && final_obs == nullptr)
+    if (final_obs) return false;        // (rollouts of K >= 32 steps never ask for final observations: mdpp_step does, K = 1)
+    const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? a.lean_next_ok != 0
                        : irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
     if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
         (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
     if (!a.autoreset && a.max_steps > 0) return false;      // (the biased step counter saturates only through resets)
     if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
-    if (irr && (a.S1 > 8 || a.A1 > 16 || final_obs != nullptr || (8ULL * 2 * a.N * (unsigned long long)K) >= (1ULL << 32)))
+    if (irr && (a.S1 > 8 || a.A1 > 16 || (8ULL * 2 * a.N * (unsigned long long)K) >= (1ULL << 32)))
         return false;
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
