@@ -462,6 +462,11 @@ def live_traffic(workload, rng, N, F, launches=4, timeout=75):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    # Never from inside a profiled run: a child `rocprofv3 --pmc` would inherit the tracing environment of the
+    # `rocprofv3 --kernel-trace ... -- python bench.py` above it (counters + trace domains in one process).
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None
     tmp = tempfile.mkdtemp(prefix="mdpp_pmc_", dir="/tmp")
     per_kernel = {}
     try:

@@ -45,3 +45,18 @@ def test_live_traffic_gives_up_without_profiler(monkeypatch):
     import bench
     monkeypatch.setattr(shutil, "which", lambda name: None)
     assert bench.live_traffic("cfg2", "numpy", 65536, 512) is None
+
+
+def test_live_traffic_is_skipped_inside_a_profiled_run(monkeypatch):
+    """Under `rocprofv3 ... -- python bench.py` no child `rocprofv3 --pmc` is started (it would inherit the tracing
+    environment): the line then carries the committed record."""
+    import shutil
+    import subprocess
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not spawn")))
+    monkeypatch.setenv("ROCPROFILER_OUTPUT_PATH", "/tmp/x")
+    assert bench.live_traffic("cfg2", "numpy", 65536, 512) is None
+    monkeypatch.delenv("ROCPROFILER_OUTPUT_PATH")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.live_traffic("cfg2", "numpy", 65536, 512) is None
