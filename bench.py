@@ -14,16 +14,26 @@ ONE BENCH STEP = one pass of the hot path over one batch = ONE fused launch (mdp
 --fuse (512, the same for every --gpus) env steps of every env instance of every rank, i.e.
 `--steps 20 --warmup 5` is 5 + 20 launches of 512 x 65 536 env steps per GPU.  `value` stays in
 env-steps/s (bench steps x fuse x envs x ranks / time), `ms_per_step` is per bench step (launch).
-With N > 1 each launch is followed by ONE RCCL all-gather that assembles the current global
-observation tensor on every rank (env ids are sharded contiguously, weak scaling; the gather
-overlaps the next launch); `collective_legs` reports the same launches without any collective,
-with that gather, and with a gather of every observation of the rollout ([K, N_local, ...]).
+
+`value` is the SAME experiment for every --gpus, one rank included: each launch is followed by ONE RCCL
+all-gather that assembles the current global observation tensor on every rank (env ids are sharded contiguously,
+weak scaling; the gather runs on a side stream and overlaps the next launch) -- a plain one-GPU run makes a
+one-rank RCCL group of its own.  `value_none` is the same launches without any collective, `value_last_row` the
+leg with it (= `value`); `collective_legs` adds a gather of every observation of the rollout ([K, N_local, ...]).
+
+Reads are honest: the timed launches cycle through >= 4 distinct action tensors, >= 512 MiB together (above the
+256 MiB Infinity Cache); `roofline.frac` is that leg, `roofline.frac_replayed` the same launches replaying one
+tensor (what rounds 1-2 reported).
+
+`workloads`: after the cfg2 leg the other BASELINE configs run under the same clock on one GPU -- cfg3, cfg4, cfg5
+(numpy-exact and Philox streams) and cfg2 on Philox streams, >= 10 fused launches each, HIP events on the launch
+stream: {name: {env_steps_per_s, launch_us, frac, kernel, traffic}}.
 The single-launch-per-step path (mdpp_step) is reported beside it.
 
 Rank 0 prints ONE JSON line: the driver contract plus `roofline` (HIP events around the timed
-launches; the measured copy / write ceilings of this device beside the 8 TB/s spec peak) and
-`cpu_baseline` (a pure-Python restatement of the reference step(), baseline/py_step.py; the C port
-of the oracle is reported as `cpu_baseline_port`).
+launches; PMC traffic from two child rocprofv3 passes of the same launches; the measured copy / write ceilings of
+this device beside the 8 TB/s spec peak) and `cpu_baseline` (a pure-Python restatement of the reference step(),
+baseline/py_step.py; the C port of the oracle is reported as `cpu_baseline_port`).
 """
 import argparse
 import json
@@ -247,6 +257,57 @@ def hbm_ceilings(device, nbytes=1 << 30, reps=10):
     return out
 
 
+def action_rotation(wl, F, N, device, seed, min_total=512 << 20, min_n=4, max_n=32):
+    """Distinct pre-generated action tensors, cycled through the launches.  Together they are larger than the
+    256 MiB Infinity Cache (>= 512 MiB, at least 4 tensors), so the action reads of a launch come from HBM and
+    not from what the previous replay of the same tensor left in the cache."""
+    first = make_actions(wl, F, N, device, seed)
+    nbytes = first.numel() * first.element_size()
+    n = min(max_n, max(min_n, -(-min_total // nbytes)))
+    return [first] + [make_actions(wl, F, N, device, seed + 1000 * j) for j in range(1, n)]
+
+
+# the other BASELINE.json configs (and cfg2 on the RNG north_star names), timed in the same run after the cfg2 leg
+EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5", "numpy"), ("cfg5", "philox"))
+
+
+def leg_name(workload, rng):
+    return workload if rng == "numpy" else f"{workload}_{rng}"
+
+
+def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345):
+    """One more workload under the same clock: `warmup` untimed + `launches` timed fused rollouts (HIP events on
+    the launch stream around the timed ones, rotating action tensors), everything resident in HBM."""
+    from mdp_playground_amd import RLToyVectorEnv
+    wl = WORKLOADS[name]
+    N = wl["envs"]
+    F = max(1, min(fuse, wl.get("fuse_max", fuse)))
+    env = RLToyVectorEnv(num_envs=N, device=device, rng=rng, autoreset="same_step", **wl["config"])
+    acts = action_rotation(wl, F, N, device, seed)
+    out = env.alloc_rollout(F)
+    for it in range(max(warmup, 1)):
+        env.rollout(acts[it % len(acts)], out)
+    torch.cuda.synchronize(device)
+    env.timer_begin()
+    t0 = time.perf_counter()
+    for it in range(launches):
+        env.rollout(acts[(warmup + it) % len(acts)], out)
+    ms = env.timer_end()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    bad = int((env.status() != 0).sum())
+    kname = env.rollout_kernel_name(F)
+    env.close()
+    per_launch_s = ms / 1e3 / launches
+    alg = wl["alg_bytes_fused"] * N * F
+    achieved = alg / per_launch_s / 1e9
+    return {"env_steps_per_s": N * F * launches / wall, "launch_us": per_launch_s * 1e6, "launches": launches,
+            "frac": achieved / HBM_PEAK_GBS, "achieved_GBps": achieved, "kernel": kname, "rng": rng,
+            "envs": N, "fuse": F, "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg,
+            "action_tensors": len(acts), "action_bytes_rotated": len(acts) * acts[0].numel() * acts[0].element_size(),
+            "envs_with_status_bits": bad, "traffic": None, "traffic_source": None}
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a
     CHILD process (this process has not touched the GPU and never will), relay rank 0's JSON line and
@@ -261,6 +322,33 @@ def self_launch(args, argv):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, env=env)
     raise SystemExit(r.returncode)
+
+
+def init_collective(device, world, no_collective):
+    """The process group of the run: RCCL (backend "nccl").  Launched by torch.distributed.run it joins that
+    job; a plain one-GPU run makes a ONE-rank group of its own, so that N = 1 times the same code path
+    (launch + all-gather on a side stream) as N > 1 and a 1 -> 8 curve compares like with like."""
+    if no_collective:
+        return None, "disabled (--no-collective)"
+    import torch.distributed as dist
+    try:
+        if "RANK" in os.environ:
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            if world != 1:
+                raise RuntimeError("no launcher")
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                    device_id=device)
+        return dist, None
+    except Exception as e:              # a one-rank run still has its `none` leg
+        if world > 1:
+            raise
+        return None, f"unavailable: {e!r}"
 
 
 def main():
@@ -278,8 +366,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live PMC traffic measurement (two child rocprofv3 runs)")
+    ap.add_argument("--no-collective", action="store_true", help="one-GPU runs: no RCCL group, `value` = the leg without a collective")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the legs of the other BASELINE configs (`workloads`)")
+    ap.add_argument("--workload-steps", type=int, default=10, help="timed launches of each `workloads` leg")
     ap.add_argument("--full-gather-steps", type=int, default=4,
-                    help="bench steps of the [K, N_local, ...] all-gather leg (multi-rank runs; 0 = skip)")
+                    help="bench steps of the [K, N_local, ...] all-gather leg (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -292,32 +383,36 @@ def main():
     # CPU baselines first: they fork one worker per core, which must happen before this process has
     # initialised the GPU runtime
     wl = WORKLOADS[args.workload]
+    N = args.envs or wl["envs"]
+    F = max(1, min(args.fuse, wl.get("fuse_max", args.fuse)))
+    extra = []
+    if world == 1 and args.workload == "cfg2" and args.rng == "numpy" and not args.no_workloads and not args.disable \
+            and args.envs is None:
+        extra = list(EXTRA_LEGS)
     cpu_py = cpu_py_all = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
     pmc = None
     if rank == 0 and world == 1 and not args.no_pmc:
-        pmc = live_traffic(args.workload, args.rng, args.envs or wl["envs"], max(1, min(args.fuse, wl.get("fuse_max", args.fuse))))
+        specs = [(args.workload, args.rng, N, F)] + [
+            (w, r, WORKLOADS[w]["envs"], max(1, min(args.fuse, WORKLOADS[w].get("fuse_max", args.fuse)))) for w, r in extra]
+        pmc = live_traffic_all(specs)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: RCCL, even for N = 1
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+    dist, no_coll_why = init_collective(device, world, args.no_collective)
 
     from mdp_playground_amd import RLToyVectorEnv
     from mdp_playground_amd.dist import ObsGatherer
 
-    N = args.envs or wl["envs"]
-    F = max(1, min(args.fuse, wl.get("fuse_max", args.fuse)))
     env = RLToyVectorEnv(num_envs=N, device=device, env_id_offset=rank * N, rng=args.rng,
                          autoreset="same_step", **wl["config"])
     if args.disable:
         env.set_kernel_options(*args.disable.split(","))
-    acts = make_actions(wl, F, N, device, 12345 + rank)
-    # rotate, so a gather can trail a launch; three with a collective: launch k + 1 must not wait for the gather
-    # of launch k - 1, which cannot run beside a rollout that holds every CU (it slips in between two launches)
-    outs = [env.alloc_rollout(F) for _ in range(3 if dist is not None else 2)]
+    acts = action_rotation(wl, F, N, device, 12345 + rank)
+    NA = len(acts)
+    # output buffers rotate, so a gather can trail a launch; four with a collective: launch k + 1 must not wait for
+    # the gather of launch k - 2, which slips in between two launches (a rollout holds every CU)
+    outs = [env.alloc_rollout(F) for _ in range(4 if dist is not None else 2)]
     NB = len(outs)
     comm = torch.cuda.Stream(device=device) if dist is not None else None
 
@@ -326,16 +421,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def run(steps, gathers):
+    launched = [0]
+
+    def run(steps, gathers, rotate=True):
         """`steps` fused launches; with `gathers`, each launch is followed by ONE all-gather (on the comm
         stream, overlapping the next launch) of the tensor gathers[j] was built on."""
         cur = torch.cuda.current_stream(device)
         ev_done = [None] * NB
         for it in range(steps):
             j = it % NB
-            if gathers is not None and ev_done[j] is not None:
-                cur.wait_event(ev_done[j])          # the gather that read this buffer NB launches ago
-            env.rollout(acts, outs[j])
+            # the gather that read this buffer NB launches ago: asked on the host first -- when it has completed
+            # (the usual case) no wait goes into the launch stream, and launches stay back to back
+            if gathers is not None and ev_done[j] is not None and not ev_done[j].query():
+                cur.wait_event(ev_done[j])
+            env.rollout(acts[launched[0] % NA] if rotate else acts[0], outs[j])
+            launched[0] += 1
             if gathers is not None:
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -347,45 +447,49 @@ def main():
         if gathers is not None:
             cur.wait_stream(comm)
 
-    def timed(steps, gathers, events=False):
+    def timed(steps, gathers, events=False, rotate=True):
         """EXACTLY `steps` launches between barrier + synchronize on both sides; max over ranks."""
         barrier()
         if events:
             env.timer_begin()
         t0 = time.perf_counter()
-        run(steps, gathers)
+        run(steps, gathers, rotate)
         kernel_ms = env.timer_end() if events else None
         torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
         barrier()
-        if dist is not None:
+        if dist is not None and world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, kernel_ms
 
-    # ---- leg "none": no collective.  Its HIP-event time (launch stream) is the roofline leg.
+    # ---- leg "none": no collective.  Its HIP-event time (launch stream) is the roofline leg: every launch reads a
+    # different action tensor (NA of them, > the Infinity Cache together)
     run(max(args.warmup, 1), None)
     el_none, kernel_ms = timed(args.steps, None, events=True)
     legs = {"none": {"elapsed_s": el_none, "env_steps_per_s": world * N * F * args.steps / el_none}}
-    elapsed, collective = el_none, "none"
+    # the same launches replaying ONE action tensor (what rounds 1-2 timed): its reads may be cache hits
+    run(2, None, rotate=False)
+    _, replay_ms = timed(args.steps, None, events=True, rotate=False)
+    elapsed, collective = el_none, "none" + (f" ({no_coll_why})" if no_coll_why else "")
     if dist is not None:
-        # ---- leg "last_row": the collective of the path (SURVEY.md §8e, north_star): after every launch ONE
+        # ---- leg "last_row" = `value`: the collective of the path (SURVEY.md §8e, north_star): after every launch ONE
         # all-gather of the local CURRENT observation shard ([N_local, ...]: 512 KiB per rank for cfg2) gives
         # every rank the concatenated observation tensor of all world * N envs
-        g_last = [ObsGatherer(o[0][-1], world, dist) for o in outs]
+        g_last = [ObsGatherer(o[0][-1], world, dist, always_collective=True) for o in outs]
         run(max(args.warmup, 1), g_last)
         el_last, _ = timed(args.steps, g_last)
         legs["last_row"] = {"elapsed_s": el_last, "env_steps_per_s": world * N * F * args.steps / el_last,
                             "bytes_per_rank_per_launch": g_last[0].local.numel() * g_last[0].local.element_size()}
         elapsed = el_last
-        collective = ("all_gather_into_tensor (RCCL, %d ranks) of the current observation shard after every launch, "
-                      "overlapped on a side stream" % dist.get_world_size())
+        collective = ("all_gather_into_tensor (RCCL, %d rank%s) of the current observation shard after every launch, "
+                      "overlapped on a side stream" % (dist.get_world_size(), "" if world == 1 else "s"))
         del g_last
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()
         if args.full_gather_steps > 0 and full_bytes * world * NB < (64 << 30):
-            g_full = [ObsGatherer(o[0], world, dist) for o in outs]
+            g_full = [ObsGatherer(o[0], world, dist, always_collective=True) for o in outs]
             run(2, g_full)
             ks = min(args.steps, args.full_gather_steps)
             el_full, _ = timed(ks, g_full)
@@ -399,18 +503,45 @@ def main():
     per_launch_s = (kernel_ms / 1e3) / args.steps
     alg_bytes = wl["alg_bytes_fused"] * N * F
     achieved = alg_bytes / per_launch_s / 1e9
+    replayed = alg_bytes / ((replay_ms / 1e3) / args.steps) / 1e9
     kname = env.rollout_kernel_name(F)          # what the library's dispatch launches (mdpp_kernel_name)
     traffic, traffic_src = committed_traffic(args.workload, args.rng, N, F, kname)
-    if pmc is not None and kname.split("<")[0] in pmc[1]:      # measured in this run, on the kernel that was timed
-        traffic, traffic_src = pmc[0], pmc[2]
+    main_pmc = (pmc or {}).get(leg_name(args.workload, args.rng))
+    if main_pmc is not None and kname.split("<")[0] in main_pmc["kernels"]:   # measured in this run, on the kernel that was timed
+        traffic, traffic_src = main_pmc["bytes_per_launch"], main_pmc["note"]
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg_bytes,
-                "launch_us": per_launch_s * 1e6, "env_steps_per_launch": N * F}
+                "launch_us": per_launch_s * 1e6, "env_steps_per_launch": N * F,
+                "action_tensors": NA, "action_bytes_rotated": NA * acts[0].numel() * acts[0].element_size(),
+                "frac_replayed": replayed / HBM_PEAK_GBS, "launch_us_replayed": replay_ms * 1e3 / args.steps,
+                "reads": f"`frac`: the launches cycle through {NA} distinct action tensors "
+                         f"({NA * acts[0].numel() * acts[0].element_size() >> 20} MiB together, above the 256 MiB "
+                         "Infinity Cache); `frac_replayed`: the same launches replaying one tensor"}
 
     single = None
     if not args.no_single_step:
-        single = single_step_leg(env, wl, acts, N, device)
+        single = single_step_leg(env, wl, acts[0], N, device)
+    env.close()
+    del outs, acts
+
+    # ---- the other BASELINE configs under the same clock (one GPU; not part of `value`)
+    workloads = None
+    if extra and rank == 0:
+        workloads = {}
+        for w, r in extra:
+            key = leg_name(w, r)
+            try:
+                leg = workload_leg(w, r, device, args.fuse, max(args.workload_steps, 10), 3)
+                rec = (pmc or {}).get(key)
+                if rec is not None and leg["kernel"].split("<")[0] in rec["kernels"]:
+                    leg["traffic"], leg["traffic_source"] = rec["bytes_per_launch"], rec["note"]
+                else:
+                    leg["traffic"], leg["traffic_source"] = committed_traffic(w, r, leg["envs"], leg["fuse"], leg["kernel"])
+                workloads[key] = leg
+            except Exception as e:          # reported extras, never fatal for the contract line
+                workloads[key] = {"error": repr(e)}
+            torch.cuda.empty_cache()
     if rank == 0:
         peaks = hbm_ceilings(device)
         roofline["peak_measured"] = peaks
@@ -421,9 +552,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not (
             wl["kind"] == "continuous" and wl["config"].get("image_representations")):
         cpu_port = cpu_baseline(wl)      # (the C port has no timed picture path for continuous envs)
-    env.close()
 
     if rank == 0:
+        v_none = legs["none"]["env_steps_per_s"]
+        v_last = legs["last_row"]["env_steps_per_s"] if "last_row" in legs else None
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
@@ -436,12 +568,15 @@ def main():
                                    f"(= {world * N * F} env steps)",
                        "envs_per_gpu": N, "fuse": F, "env_steps_per_bench_step": world * N * F, "rng": args.rng,
                        "disabled_kernels": args.disable or None,
-                       "collective": collective},
+                       "collective": collective,
+                       "value_is": "the `last_row` leg (launch + the path's all-gather) for every --gpus, one rank included"
+                                   if v_last is not None else "the `none` leg (no process group in this run)"},
+            "value_none": v_none, "value_last_row": v_last,
             "roofline": roofline,
             "cpu_baseline": cpu_py if cpu_py is not None else cpu_port,
             "cpu_baseline_all_cores": cpu_py_all, "cpu_baseline_port": cpu_port,
             "cpu_baseline_port_all_cores": cpu_all,
-            "single_step": single, "collective_legs": legs,
+            "single_step": single, "collective_legs": legs, "workloads": workloads,
             "launches": args.steps, "elapsed_s": elapsed,
         }
         print(json.dumps(line), flush=True)
@@ -449,54 +584,79 @@ def main():
         dist.destroy_process_group()
 
 
-def live_traffic(workload, rng, N, F, launches=4, timeout=75):
-    """HBM bytes per launch of the dominant kernel from PMC counters, measured NOW: two child rocprofv3 runs
-    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: they do not fit one pass) of tools/run_variant.py, which
-    launches the same fused rollouts; read bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B read requests at
-    64 B, MI355X_MICROARCH.md), write bytes = WRITE_SIZE KB.  Returns (bytes per launch, kernel, note) or None
-    when rocprofv3 is not usable here (the committed record is used instead)."""
+def _pmc_blocked():
+    """Never from inside a profiled run: a child `rocprofv3 --pmc` would inherit the tracing environment of the
+    `rocprofv3 --kernel-trace ... -- python bench.py` above it (counters + trace domains in one process)."""
+    return any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+
+
+def live_traffic_all(specs, launches=3, timeout=150):
+    """HBM bytes per fused launch from PMC counters, measured NOW, for every (workload, rng, envs, fuse) of `specs`:
+    two child rocprofv3 runs (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: they do not fit one pass; no trace domain
+    beside them) of tools/pmc_workloads.py, which launches the same fused rollouts workload after workload with a
+    marker dispatch between them; read bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B read requests at 64 B,
+    MI355X_MICROARCH.md), write bytes = WRITE_SIZE KB, summed over every mdpp:: kernel of the rollout call (reset
+    kernels excluded).  Returns {leg name: {"bytes_per_launch", "kernels", "note"}} or None when rocprofv3 is not
+    usable here (the committed record is used instead)."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
-    if shutil.which("rocprofv3") is None:
-        return None
-    # Never from inside a profiled run: a child `rocprofv3 --pmc` would inherit the tracing environment of the
-    # `rocprofv3 --kernel-trace ... -- python bench.py` above it (counters + trace domains in one process).
-    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ) or \
-            "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+    if shutil.which("rocprofv3") is None or _pmc_blocked():
         return None
     tmp = tempfile.mkdtemp(prefix="mdpp_pmc_", dir="/tmp")
-    per_kernel = {}
+    seg = [{"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "kernels": {}} for _ in specs]
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "tools", "run_variant.py"), "-", str(launches), workload, str(F), f"rng={rng}",
-                   f"envs={N}"]
+                   os.path.join(ROOT, "tools", "pmc_workloads.py"), str(launches)] + \
+                  [f"{w}:{r}:{n}:{f}" for w, r, n, f in specs]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=timeout)
             if r.returncode != 0:
                 return None
+            rows = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    k = row["Kernel_Name"].split("(")[0]
-                    if row["Counter_Name"] == counter and "mdpp::" in k and "reset" not in k:
-                        d = per_kernel.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "calls": 0})
-                        d[counter] += float(row["Counter_Value"])
-                        if counter == "WRITE_SIZE":
-                            d["calls"] += 1
-        if not per_kernel:
-            return None
-        k, d = max(per_kernel.items(), key=lambda kv: kv[1]["FETCH_SIZE"] * 2 + kv[1]["WRITE_SIZE"])
-        calls = max(d["calls"], 1)
-        return int(round((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 / calls)), k, \
-            f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, x2 on FETCH_SIZE), {calls} launches, in this run"
+                rows += [row for row in csv.DictReader(open(f)) if row.get("Counter_Name") == counter]
+            rows.sort(key=lambda row: int(row.get("Dispatch_Id") or 0))
+            k = 0
+            for row in rows:
+                name = row["Kernel_Name"].split("(")[0]
+                if "k_philox_normals" in name:          # the marker: next workload
+                    k += 1
+                    continue
+                if k >= len(specs) or "mdpp::" not in name or "reset" in name:
+                    continue
+                seg[k][counter] += float(row["Counter_Value"])
+                seg[k]["kernels"].setdefault(name, 0)
+                if counter == "WRITE_SIZE":
+                    seg[k]["kernels"][name] += 1
+            if k != len(specs):
+                return None
+        res = {}
+        for (w, r, n, f), s in zip(specs, seg):
+            if not s["kernels"]:
+                continue
+            res[leg_name(w, r)] = {
+                "bytes_per_launch": int(round((2.0 * s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0 / launches)),
+                "kernels": " ".join(s["kernels"]),
+                "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, x2 on FETCH_SIZE), every mdpp:: "
+                        f"kernel of {launches} fused launches, in this run"}
+        return res or None
     except Exception:
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_traffic(workload, rng, N, F, launches=3, timeout=75):
+    """One workload's record of live_traffic_all: (bytes per launch, kernels, note) or None."""
+    res = live_traffic_all([(workload, rng, N, F)], launches, timeout)
+    rec = (res or {}).get(leg_name(workload, rng))
+    return None if rec is None else (rec["bytes_per_launch"], rec["kernels"], rec["note"])
 
 
 def committed_traffic(workload, rng, N, F, kname):
@@ -505,7 +665,7 @@ def committed_traffic(workload, rng, N, F, kname):
     WRITE_SIZE in separate passes, gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md) and committed
     under profiles/; a record is used only for the launch shape AND kernel it was measured on."""
     tag = workload if rng == "numpy" else f"{workload}_{rng}"
-    for name in (f"r02_traffic_{tag}.json", f"r02_traffic_{tag}_pipe.json", f"r01_traffic_{tag}.json"):
+    for name in (f"r03_traffic_{tag}.json", f"r02_traffic_{tag}.json", f"r02_traffic_{tag}_pipe.json", f"r01_traffic_{tag}.json"):
         tfile = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tfile):
             continue

@@ -247,6 +247,24 @@ int mdpp_set_state_continuous(mdpp_env *h, const float *derivs_host, const float
                               const int32_t *steps_host, const double *ring_host,
                               const uint8_t *ring_is32_host, const uint8_t *reached_host);
 
+/* HIP graphs of single steps (RLToyVectorEnv.step_graph).  mdpp_step hands the handle's step counter to its
+ * launch by value (ring head = counter mod delay for delay lines kept in memory; Philox keys), so a captured
+ * launch replays with the counter it was captured with.
+ * mdpp_graph_replay_exact: 1 when a graph of K captured mdpp_step launches replays exactly for this handle
+ * (numpy streams, and either no delay line in memory or K a multiple of the delay), 0 when it does not, < 0 on error.
+ * mdpp_tick: adds `advance` (may be negative) to the step counter and returns the new value in *tick_out (may be
+ * NULL): the capture advances the counter although nothing ran (take it back with -K), a replay runs K steps the
+ * counter has not seen (add K). */
+int mdpp_graph_replay_exact(mdpp_env *h, int K);
+int mdpp_tick(mdpp_env *h, int64_t advance, uint64_t *tick_out);
+
+/* MDPP_AUTORESET_NEXT_STEP: the per-env flag "the episode ended on the previous call, the next call is the reset"
+ * (gymnasium >= 1.0 vector envs; the reference itself never autoresets).  mdpp_get_state_* leave it out and
+ * mdpp_set_state_* clear it; a checkpoint taken between the two calls carries it through these (uint8[N], host).
+ * Call mdpp_set_reset_pending AFTER mdpp_set_state_*. */
+int mdpp_get_reset_pending(mdpp_env *h, uint8_t *pending_host);
+int mdpp_set_reset_pending(mdpp_env *h, const uint8_t *pending_host);
+
 /* Kernel selection (see MDPP_OPT_*): disable_mask replaces the handle's current mask (0 = default dispatch). */
 int mdpp_set_options(mdpp_env *h, uint32_t disable_mask);
 /* Name (with template arguments) of the kernel mdpp_step_n(h, K, ...) would launch for this handle

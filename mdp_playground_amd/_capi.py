@@ -30,6 +30,7 @@ EXPORTS = [
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
     "mdpp_set_options", "mdpp_kernel_name", "mdpp_philox_normals",
+    "mdpp_graph_replay_exact", "mdpp_tick", "mdpp_get_reset_pending", "mdpp_set_reset_pending",
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
 ]
@@ -127,6 +128,10 @@ def load():
     L.mdpp_set_options.argtypes = [vp, C.c_uint32]
     L.mdpp_kernel_name.argtypes = [vp, i32]
     L.mdpp_kernel_name.restype = C.c_char_p
+    L.mdpp_graph_replay_exact.argtypes = [vp, i32]
+    L.mdpp_tick.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
+    L.mdpp_get_reset_pending.argtypes = [vp, vp]
+    L.mdpp_set_reset_pending.argtypes = [vp, vp]
     L.mdpp_philox_normals.argtypes = [C.c_uint64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, vp, vp]
     L.mdpp_post_create.argtypes = [C.POINTER(MdppPostConfig), i32, C.POINTER(vp)]
     L.mdpp_post_destroy.argtypes = [vp]

@@ -607,6 +607,69 @@ extern "C" int mdpp_set_options(mdpp_env *h, uint32_t disable_mask) {
     return MDPP_OK;
 }
 
+// ---- HIP graphs of single steps: the host-side step counter ---------------------------------------------
+// mdpp_step hands the counter (`tick`) to its launch BY VALUE: the head of a delay line kept in memory is
+// tick mod delay, and Philox streams are keyed by it.  A captured launch therefore replays with the value it was
+// captured with.
+extern "C" int mdpp_graph_replay_exact(mdpp_env *h, int K) {
+    if (!h || K < 1) return MDPP_EINVAL;
+    if (h->cfg.rng_mode == MDPP_RNG_PHILOX) return 0;             // every replay would re-draw the same noise and resets
+    const int d = h->cfg.delay;
+    const bool ring_in_memory = d > 0 && (h->cfg.kind == MDPP_KIND_CONTINUOUS ||
+                                          (h->cfg.kind == MDPP_KIND_DISCRETE && !h->cfg.unit_rewards));
+    if (ring_in_memory && K % d != 0) return 0;                   // replay r would start at ring slot (tick0 + r K) mod delay
+    return 1;
+}
+
+extern "C" int mdpp_tick(mdpp_env *h, int64_t advance, uint64_t *tick_out) {
+    if (!h) return MDPP_EINVAL;
+    if (advance < 0 && (uint64_t)(-advance) > h->tick) return fail(h, MDPP_EINVAL, "mdpp_tick: the counter would become negative");
+    h->tick = (uint64_t)((int64_t)h->tick + advance);
+    if (tick_out) *tick_out = h->tick;
+    return MDPP_OK;
+}
+
+// ---- next-step autoreset: the "episode ended on the previous call" flag of every env ---------------------
+// (bit 31 of the discrete step counter, bit 1 of the grid / continuous flag words; the state getters mask it out)
+static int pending_word(const mdpp_env *h, void **buf, size_t *stride_words, size_t *word, uint32_t *bit) {
+    if (h->cfg.kind == MDPP_KIND_DISCRETE) { *buf = h->d_state; *stride_words = 4; *word = 2; *bit = 0x80000000u; }
+    else if (h->cfg.kind == MDPP_KIND_GRID) { *buf = h->d_state; *stride_words = 4; *word = 2; *bit = 2u; }
+    else { *buf = h->d_meta; *stride_words = 2; *word = 1; *bit = 2u; }
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_get_reset_pending(mdpp_env *h, uint8_t *pending) {
+    if (!h || !pending) return MDPP_EINVAL;
+    void *buf; size_t sw, wd; uint32_t bit;
+    pending_word(h, &buf, &sw, &wd, &bit);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    std::vector<uint32_t> st(sw * N);
+    HIPCHK(h, hipMemcpy(st.data(), buf, st.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) pending[i] = (st[sw * i + wd] & bit) ? 1 : 0;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_set_reset_pending(mdpp_env *h, const uint8_t *pending) {
+    if (!h || !pending) return MDPP_EINVAL;
+    const size_t N = (size_t)h->cfg.num_envs;
+    if (h->cfg.autoreset != MDPP_AUTORESET_NEXT_STEP) {
+        for (size_t i = 0; i < N; i++)
+            if (pending[i]) return fail(h, MDPP_EINVAL, "set_reset_pending: the handle does not use next-step autoreset");
+        return MDPP_OK;
+    }
+    void *buf; size_t sw, wd; uint32_t bit;
+    pending_word(h, &buf, &sw, &wd, &bit);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    std::vector<uint32_t> st(sw * N);
+    HIPCHK(h, hipMemcpy(st.data(), buf, st.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) st[sw * i + wd] = (st[sw * i + wd] & ~bit) | (pending[i] ? bit : 0u);
+    HIPCHK(h, hipMemcpy(buf, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    return MDPP_OK;
+}
+
 static int check_ready(mdpp_env *h, const char *what) {
     if (!h->tables_ready) return fail(h, MDPP_ESTATE, std::string(what) + ": tables not uploaded");
     if (h->cfg.rng_mode == MDPP_RNG_NUMPY_PCG64) {

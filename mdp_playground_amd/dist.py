@@ -27,8 +27,9 @@ class ObsGatherer:
     tensor in global env-id order; for rollout buffers [K, N_local, ...] use
     `out.transpose(0, 1).flatten(1, 2)` for [K, N_global, ...]."""
 
-    def __init__(self, local: torch.Tensor, world: int, dist_module=None, group=None):
+    def __init__(self, local: torch.Tensor, world: int, dist_module=None, group=None, always_collective=False):
         self.local = local
+        self.always_collective = bool(always_collective)   # one rank: still go through the backend (bench, tests)
         self.world = int(world)
         self.dist = dist_module
         self.group = group
@@ -38,7 +39,7 @@ class ObsGatherer:
         self.out = self._flat.view((self.world,) + tuple(local.shape))
 
     def __call__(self) -> torch.Tensor:
-        if self.world == 1 or self.dist is None:
+        if self.dist is None or (self.world == 1 and not self.always_collective):
             self.out[0].copy_(self.local)
             return self.out
         self.dist.all_gather_into_tensor(self._flat, self.local, group=self.group)
@@ -50,7 +51,7 @@ class ShardedVectorEnv:
     gathered observations from step()/rollout().  Rewards/flags stay local (each rank acts on
     its own shard); pass gather_all=True to gather them too."""
 
-    def __init__(self, total_envs, rank, world, dist_module=None, device=None, **kwargs):
+    def __init__(self, total_envs, rank, world, dist_module=None, device=None, always_collective=False, **kwargs):
         from .vector_env import RLToyVectorEnv
         self.rank, self.world, self.dist = rank, world, dist_module
         lo, hi = shard_bounds(total_envs, rank, world)
@@ -58,7 +59,9 @@ class ShardedVectorEnv:
             raise ValueError("total_envs must divide evenly over the ranks (all_gather needs equal shards)")
         self.lo, self.hi = lo, hi
         self.env = RLToyVectorEnv(num_envs=hi - lo, device=device, env_id_offset=lo, **kwargs)
-        self._g_obs = ObsGatherer(self.env._obs, world, dist_module)
+        self._always = bool(always_collective)
+        self._g_obs = ObsGatherer(self.env._obs, world, dist_module, always_collective=self._always)
+        self._g_last = {}
 
     def reset(self, seed=None):
         obs, info = self.env.reset(seed=seed)
@@ -67,6 +70,19 @@ class ShardedVectorEnv:
     def step(self, local_actions):
         obs, rew, term, trunc, info = self.env.step(local_actions)
         return self._g_obs().flatten(0, 1), rew, term, trunc, info
+
+    def rollout(self, local_actions, out=None):
+        """K fused steps of this rank's shard in one launch, then ONE all-gather of the rollout's LAST observation
+        row: (obs_local [K, N_local, ...], reward, terminated, truncated, obs_global [N_global, ...]).  Per-step
+        observations stay on their rank (gathering all of them is bound by the xGMI links)."""
+        obs, rew, term, trunc = self.env.rollout(local_actions, out)
+        key = (obs.data_ptr(), tuple(obs.shape))
+        g = self._g_last.get(key)
+        if g is None:
+            if len(self._g_last) > 8:
+                self._g_last.clear()
+            g = self._g_last[key] = ObsGatherer(obs[-1], self.world, self.dist, always_collective=self._always)
+        return obs, rew, term, trunc, g().flatten(0, 1)
 
     def close(self):
         self.env.close()

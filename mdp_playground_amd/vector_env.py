@@ -453,10 +453,22 @@ class RLToyVectorEnv:
         """A replayable HIP graph of K single steps (K = actions.shape[0] mdpp_step launches captured
         once): the one-launch-per-step API without the per-call host cost.  actions: [K, N, ...] as for
         rollout(); the tensor is read at every replay, so writing new actions into it between replays
-        steps with them.  Returns an object with .replay() and the output buffers
-        .obs/.reward/.terminated/.truncated ([K, N, ...]).  Exact for numpy-stream handles with unit
-        rewards (include/mdpp.h: the step counter travels by value into the captured launches)."""
+        steps with them.  Returns a StepGraph with .replay() and the output buffers
+        .obs/.reward/.terminated/.truncated ([K, N, ...]).
+
+        The handle's step counter travels BY VALUE into the captured launches (include/mdpp.h), so only handles
+        for which a replay is exact are accepted: numpy streams, and a delay line that is either kept in the
+        state record (discrete unit rewards) or whose length divides K.  Anything else raises MdppError
+        (Philox keys would repeat; the ring head of a delay line in memory would be the captured one)."""
         K = int(actions.shape[0])
+        ok = self._lib.mdpp_graph_replay_exact(self._h, K)
+        if ok < 0:
+            capi.check(self._lib, self._h, ok, "mdpp_graph_replay_exact")
+        if ok == 0:
+            raise capi.MdppError(
+                "step_graph: a captured graph of %d steps does not replay exactly for this handle (rng='philox' "
+                "keys its draws by the step counter; a delay line kept in memory needs K %% delay == 0, delay = %d). "
+                "Use rollout() (one fused launch) instead." % (K, self._cfg.delay))
         a = self._as_actions(actions, K)
         obs, rew, term, trunc = self.alloc_rollout(K)
         side = torch.cuda.Stream(device=self.device)
@@ -470,11 +482,17 @@ class RLToyVectorEnv:
                           trunc[k].data_ptr(), None, stream)
                 if rc:
                     capi.check(self._lib, h, rc, "mdpp_step")
-        with torch.cuda.graph(g, stream=side):
-            launches(side.cuda_stream)
-        g.actions, g.obs, g.reward = a, obs, rew
-        g.terminated, g.truncated = term.view(torch.bool), trunc.view(torch.bool)
-        return g
+        tick0 = C.c_uint64()
+        capi.check(self._lib, h, self._lib.mdpp_tick(h, 0, C.byref(tick0)), "mdpp_tick")
+        try:
+            with torch.cuda.graph(g, stream=side):
+                launches(side.cuda_stream)
+        finally:
+            # the capture advanced the counter although nothing ran
+            now = C.c_uint64()
+            self._lib.mdpp_tick(h, 0, C.byref(now))
+            self._lib.mdpp_tick(h, int(tick0.value) - int(now.value), None)
+        return StepGraph(self, g, K, int(tick0.value), a, obs, rew, term, trunc)
 
     def step(self, actions):
         """step(actions) -> (obs, reward, terminated, truncated, info), rl_toy_env.py:1992.
@@ -554,7 +572,17 @@ class RLToyVectorEnv:
     # ------------------------------------------------------------------ state access
     def get_augmented_state(self):
         """Batched get_augmented_state() (rl_toy_env.py:2127) plus what the reference leaves out:
-        reward ring, step counters, reached flags.  Host numpy arrays (synchronises)."""
+        reward ring, step counters, reached flags, and with autoreset="next_step" the per-env flag
+        "the next call is the reset" (`reset_pending`).  Host numpy arrays (synchronises)."""
+        st = self._get_augmented_state()
+        if self.autoreset == "next_step":
+            pend = np.zeros(self.num_envs, np.uint8)
+            rc = self._lib.mdpp_get_reset_pending(self._h, capi.nptr(pend))
+            capi.check(self._lib, self._h, rc, "mdpp_get_reset_pending")
+            st["reset_pending"] = pend.astype(bool)
+        return st
+
+    def _get_augmented_state(self):
         N = self.num_envs
         if self.kind == "discrete":
             L, d = self._cfg.L, self._cfg.delay
@@ -596,7 +624,18 @@ class RLToyVectorEnv:
                 "reached_terminal": reached.astype(bool)}
 
     def set_augmented_state(self, state):
-        """Inverse of get_augmented_state() (rl_toy_env.py:2168)."""
+        """Inverse of get_augmented_state() (rl_toy_env.py:2168).  `reset_pending` (next-step autoreset) is
+        restored when present and cleared when absent."""
+        self._set_augmented_state(state)
+        pend = state.get("reset_pending") if isinstance(state, dict) else None
+        pend = np.zeros(self.num_envs, np.uint8) if pend is None else np.ascontiguousarray(pend, dtype=np.uint8)
+        if pend.shape != (self.num_envs,):
+            raise ValueError("reset_pending must have shape (num_envs,)")
+        if self.autoreset == "next_step" or pend.any():
+            rc = self._lib.mdpp_set_reset_pending(self._h, capi.nptr(pend))
+            capi.check(self._lib, self._h, rc, "mdpp_set_reset_pending")
+
+    def _set_augmented_state(self, state):
         if self.kind == "discrete":
             hist = np.ascontiguousarray(state["augmented_state"], dtype=np.int32)
             steps = np.ascontiguousarray(state["total_transitions_episode"], dtype=np.int32)
@@ -663,6 +702,28 @@ class RLToyVectorEnv:
             self.close()
         except Exception:
             pass
+
+
+class StepGraph:
+    """What RLToyVectorEnv.step_graph() returns: a captured HIP graph of K mdpp_step launches.  replay() runs
+    the K steps on the current stream and advances the handle's step counter by K, as K step() calls would."""
+
+    def __init__(self, env, graph, K, tick0, actions, obs, reward, term, trunc):
+        self._env, self._g, self.K, self._tick0 = env, graph, K, tick0
+        self.actions, self.obs, self.reward = actions, obs, reward
+        self.terminated, self.truncated = term.view(torch.bool), trunc.view(torch.bool)
+
+    def replay(self):
+        env = self._env
+        d = int(env._cfg.delay)
+        now = C.c_uint64()
+        capi.check(env._lib, env._h, env._lib.mdpp_tick(env._h, 0, C.byref(now)), "mdpp_tick")
+        ring_in_memory = d > 0 and (env.kind == "continuous" or (env.kind == "discrete" and not env._cfg.unit_rewards))
+        if ring_in_memory and (int(now.value) - self._tick0) % d != 0:
+            raise capi.MdppError("StepGraph.replay: %d steps were taken outside the graph since its capture; the delay line "
+                                 "(length %d) would be read at the captured ring head" % (int(now.value) - self._tick0, d))
+        self._g.replay()
+        capi.check(env._lib, env._h, env._lib.mdpp_tick(env._h, self.K, None), "mdpp_tick")
 
 
 def make_vec(env_id="RLToyVec-v0", num_envs=1, **kwargs):

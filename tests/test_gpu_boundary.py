@@ -113,6 +113,55 @@ def test_next_step_state_roundtrip_clears_nothing_it_should_not():
     env.close()
 
 
+@pytest.mark.parametrize("name", ["d_cfg2", "d_cfg2_noise", "c_sparse_term", "g_noise_sparse"])
+def test_next_step_checkpoint_between_the_last_step_and_the_reset_call(name):
+    """a checkpoint taken right after a terminal step (next-step autoreset: the NEXT call is the reset)
+    carries the per-env pending flag through get/set_augmented_state: a rollout split by a checkpoint into a fresh
+    env equals the unsplit one, at every split point of a stretch in which episodes end."""
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(gu.CASES[name]["config"], seed=21)
+    N, T = 256, 24
+    mk = lambda: _venv(num_envs=N, autoreset="next_step", max_episode_steps=5, **cfg)   # noqa: E731
+    ref = mk()
+    acts = torch.as_tensor(_rand_actions(ref, T, np.random.default_rng(8)), device=ref.device)
+    want = [x.clone() for x in ref.rollout(acts)]
+    streams = [capi.STREAM_ENV, capi.STREAM_SPACE] + ([capi.STREAM_ACTION] if ref.kind == "grid" else [])
+    seen_pending = False
+    for split in (5, 6, 11, 17):
+        a, b = mk(), mk()
+        head = a.rollout(acts[:split])
+        st = a.get_augmented_state()
+        assert st["reset_pending"].dtype == bool and st["reset_pending"].shape == (N,)
+        seen_pending = seen_pending or bool(st["reset_pending"].any())
+        b.set_augmented_state(st)
+        for s_ in streams:
+            b._put_stream(s_, a.get_rng_streams(s_))
+        tail = b.rollout(acts[split:])
+        for w, h, t in zip(want, head, tail):
+            assert torch.equal(w[:split], h) and torch.equal(w[split:], t), (name, split)
+        # without the flag the restored env keeps stepping from the terminal state: the export must matter
+        if st["reset_pending"].any():
+            c = mk()
+            c.set_augmented_state({k: v for k, v in st.items() if k != "reset_pending"})
+            assert not c.get_augmented_state()["reset_pending"].any()
+            c.close()
+        a.close(); b.close()
+    assert seen_pending
+    ref.close()
+
+
+def test_reset_pending_refused_without_next_step_autoreset():
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(gu.CASES["d_cfg2"]["config"], seed=2)
+    env = _venv(num_envs=64, autoreset="same_step", **cfg)
+    st = env.get_augmented_state()
+    assert "reset_pending" not in st
+    env.set_augmented_state(st)
+    with pytest.raises(capi.MdppError):
+        env.set_augmented_state(dict(st, reset_pending=np.ones(64, bool)))
+    env.close()
+
+
 def test_next_step_refused_with_images():
     from mdp_playground_amd import _capi as capi
     cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
@@ -288,6 +337,46 @@ def test_step_graph_replays_single_steps():
             o, r, te, tr, _ = b.step(g.actions[t])
             assert torch.equal(o, g.obs[t]) and torch.equal(r, g.reward[t]) and torch.equal(te, g.terminated[t]), (rep, t)
     a.close(); b.close()
+
+
+def test_step_graph_counts_its_steps_and_refuses_inexact_handles():
+    """the step counter travels by value into captured launches.  (1) The capture does not advance it and a
+    replay advances it by K: plain steps after replays use the right delay-line slot (continuous env, delay 2, K = 4).
+    (2) Philox handles and delay lines in memory whose length does not divide K are refused.  (3) A replay after a
+    number of plain steps that moves the ring head is refused."""
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(gu.CASES["c_order3_delay3"]["config"], seed=5)
+    d = int(cfg["delay"])
+    N, K = 512, 2 * d
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    rng = np.random.default_rng(3)
+    acts = torch.as_tensor(_rand_actions(a, K, rng), device=a.device)
+    g = a.step_graph(acts)
+    for rep in range(3):
+        if rep:
+            g.actions.copy_(torch.as_tensor(_rand_actions(a, K, rng), device=a.device))
+        g.replay()
+        torch.cuda.synchronize()
+        for t in range(K):
+            o, r, te, tr, _ = b.step(g.actions[t])
+            assert torch.equal(o, g.obs[t]) and torch.equal(r, g.reward[t]) and torch.equal(te, g.terminated[t]), (rep, t)
+        # plain steps between replays: a whole number of ring turns keeps the graph usable
+        for t in range(d):
+            x = torch.as_tensor(_rand_actions(a, 1, rng)[0], device=a.device)
+            oa, ra, _, _, _ = a.step(x)
+            ob, rb, _, _, _ = b.step(x)
+            assert torch.equal(oa, ob) and torch.equal(ra, rb), (rep, t)
+    a.step(acts[0])                                         # one more: the ring head no longer matches the captured one
+    with pytest.raises(capi.MdppError):
+        g.replay()
+    with pytest.raises(capi.MdppError):
+        a.step_graph(acts[:d + 1])                          # K % delay != 0
+    a.close(); b.close()
+    p = _venv(num_envs=N, autoreset="same_step", rng="philox", **dict(gu.CASES["d_cfg2"]["config"], seed=9))
+    with pytest.raises(capi.MdppError):
+        p.step_graph(torch.zeros((4, N), dtype=torch.int32, device=p.device))
+    p.close()
 
 
 def test_large_action_space_tables_fall_back_to_global_memory():

@@ -988,6 +988,60 @@ def test_image_batch_vs_oracle(name):
     env.close(); twin.close()
 
 
+def test_cfg4_at_bench_size_fast_vs_general_renderer_and_oracle():
+    """BASELINE configs[3] at ITS size: 8 192 envs x 32 fused steps = two pipelined batches of 16.  The
+    persistent fast renderer leaves workgroup slots free for the next batch's state kernel as a function of the batch
+    size (32 of 1 024 here), so the size it is benchmarked at is the size it is checked at: every pixel of every
+    image against the general renderer (k_image_obs, NO_IMGFAST), the pipeline against the unpipelined launch order
+    (NO_IMG_OVERLAP), and a strided sample of envs against the oracle's draw + Pillow-exact rotation."""
+    import bench
+    from test_image_oracle import _render
+    from mdp_playground_amd import _capi as capi, image_obs, mdp
+    wl = bench.WORKLOADS["cfg4"]
+    cfg, N, K = wl["config"], wl["envs"], 32
+    assert N == 8192
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    c = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b.set_kernel_options("NO_IMGFAST")
+    c.set_kernel_options("NO_IMG_OVERLAP")
+    assert a.rollout_kernel_name(K).startswith("k_image_obs_fast<") and b.rollout_kernel_name(K) == "k_image_obs"
+    twin = _venv(num_envs=N, autoreset="same_step", **{k: v for k, v in cfg.items() if not k.startswith("image_")})
+    words0 = a.get_rng_streams(capi.STREAM_IMAGE).copy()
+    acts = bench.make_actions(wl, K, N, a.device, 77)
+    oa, ra, ta, _ = a.rollout(acts)
+    ob, rb, tb, _ = b.rollout(acts)
+    oc, rc, tc, _ = c.rollout(acts)
+    st, rs, ts, _ = twin.rollout(acts)
+    torch.cuda.synchronize()
+    assert tuple(oa.shape) == (K, N, 84, 84, 1)
+    for k in range(K):                                    # (row by row: a whole-tensor compare allocates another 1.8 GB)
+        assert torch.equal(oa[k], ob[k]), k
+        assert torch.equal(oa[k], oc[k]), k
+    assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ra, rc) and torch.equal(ta, tc)
+    assert torch.equal(ra, rs) and torch.equal(ta, ts) and ta.any() and not ta.all()
+    for s_ in (capi.STREAM_IMAGE, capi.STREAM_ENV):
+        assert np.array_equal(a.get_rng_streams(s_), b.get_rng_streams(s_))
+        assert np.array_equal(a.get_rng_streams(s_), c.get_rng_streams(s_))
+    # the oracle on every 257th env: the state sequence from the integer-observation twin; a step that ends in a
+    # reset draws the terminal observation first (not rendered by a rollout, and with shift + rotate its draw count
+    # does not depend on the state), then the first observation of the next episode
+    m = mdp.build_mdp(cfg)
+    tpl = image_obs.build_templates(m.S, m.image)
+    st_h, term_h = st.cpu().numpy(), ta.cpu().numpy().astype(bool)
+    end = a.get_rng_streams(capi.STREAM_IMAGE)
+    for i in range(3, N, 257):
+        w = words0[i].copy()
+        got = oa[:, i].cpu().numpy()
+        for k in range(K):
+            if term_h[k, i]:
+                _render(m.image, tpl, 0, w)
+            assert np.array_equal(_render(m.image, tpl, int(st_h[k, i]), w), got[k]), (i, k)
+        assert np.array_equal(w, end[i]), i
+    for e in (a, b, c, twin):
+        e.close()
+
+
 # ----------------------------------------------------------------------------- ImageContinuous
 @pytest.mark.parametrize("name", gu.IMAGE_CONT)
 def test_continuous_image_observations_vs_reference_golden(name):
