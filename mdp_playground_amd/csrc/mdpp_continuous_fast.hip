@@ -149,8 +149,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                     philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), (uint32_t)tick, (MDPP_STREAM_ENV << 24) + (uint32_t)b,
                                   k0, k1, o);
                     float zz[4];
-                    philox_box_muller(o[0], o[1], zz[0], zz[1]);
-                    if (4 * b + 2 < nn) philox_box_muller(o[2], o[3], zz[2], zz[3]);
+                    // (both pairs of a block as packed float32 work; nn is wave-uniform)
+                    if (4 * b + 2 < nn) philox_box_muller2(o, zz[0], zz[1], zz[2], zz[3]);
+                    else philox_box_muller(o[0], o[1], zz[0], zz[1]);
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (4 * b + q < nn) slot[(first + 4 * b + q) * kBlock] = (ZT)zz[q];

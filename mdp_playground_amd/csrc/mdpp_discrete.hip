@@ -181,10 +181,16 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (IRR) sp1_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, kPhiloxIrrStream);
             }
             if (pending) {           // next-step autoreset: this call is the env's reset(), :2250-2278
-                const uint32_t s0 = PHILOX ? d_reset_draw(a, t, env_phx) : d_reset_draw(a, t, env_pcg);
-                if (IRR) {
-                    const double u1 = PHILOX ? np_random(env_phx) : np_random(env_pcg);
-                    cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, u1);
+                uint32_t s0;
+                if (PHILOX) {        // one word of the start-state streams per tick (mdpp_rng.hpp)
+                    const uint64_t ge_ = (uint64_t)(a.env_id_offset + i);
+                    s0 = (uint32_t)searchsorted_right(t.init_cdf, a.S, philox_start_uniform(
+                        philox_start_m31(a.philox_seed, ge_, ptick, kPhiloxStartStream)));
+                    if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, philox_start_uniform(
+                        philox_start_m31(a.philox_seed, ge_, ptick, kPhiloxStartIrrStream)));
+                } else {
+                    s0 = d_reset_draw(a, t, env_pcg);
+                    if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(env_pcg));
                 }
                 hist = d_fresh_hist(s0);
                 steps = 0; phase = 0; ringbits = 0;
@@ -280,10 +286,16 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                         else ((int64_t *)final_obs)[o * AW + 1] = (int64_t)cur1;
                     }
                 }
-                const uint32_t s0 = PHILOX ? d_reset_draw(a, t, env_phx) : d_reset_draw(a, t, env_pcg);
-                if (IRR) {
-                    const double u1 = PHILOX ? np_random(env_phx) : np_random(env_pcg);
-                    cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, u1);
+                uint32_t s0;
+                if (PHILOX) {        // one word of the start-state streams per tick (mdpp_rng.hpp)
+                    const uint64_t ge_ = (uint64_t)(a.env_id_offset + i);
+                    s0 = (uint32_t)searchsorted_right(t.init_cdf, a.S, philox_start_uniform(
+                        philox_start_m31(a.philox_seed, ge_, ptick, kPhiloxStartStream)));
+                    if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, philox_start_uniform(
+                        philox_start_m31(a.philox_seed, ge_, ptick, kPhiloxStartIrrStream)));
+                } else {
+                    s0 = d_reset_draw(a, t, env_pcg);
+                    if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(env_pcg));
                 }
                 hist = d_fresh_hist(s0);
                 steps = 0; phase = 0; ringbits = 0;

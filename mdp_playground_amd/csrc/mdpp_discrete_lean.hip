@@ -223,11 +223,22 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #endif
         if (!ar) return;
         if constexpr (PHILOX) {
-            // Philox streams: the start state a reset at tick t draws is a function of (seed, env, t) alone
-            // (first 64 bits of block 0 of the env stream, as in k_discrete_step / _quiet), so H makes the one
-            // of EVERY tick, a chunk of 8 at a time (independent blocks), packed as 8 nibbles | 8
+            // Philox streams: the start state a reset at tick t draws is a function of (seed, env, t) alone -- ONE 32-bit
+            // word of the start-state stream, four ticks to a block (mdpp_rng.hpp philox_start_*, as in k_discrete_step /
+            // _quiet) --, so H makes the one of EVERY tick, a chunk of 8 at a time: two blocks (three when the launch
+            // does not start on a multiple of four ticks), 31-bit thresholds in scalar registers; packed as 8 nibbles | 8
             const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);
             const int nch = (K + kChunk - 1) / kChunk;
+            static_assert(kChunk == 8, "two start-state blocks per chunk");
+            uint32_t thr[8], thr1[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {                        // ceil(cdf 2^31) from ceil(cdf 2^53); padding: never reached
+                const uint64_t t53 = lds_T[j];
+                thr[j] = __builtin_amdgcn_readfirstlane(t53 > (1ULL << 53) ? 0x80000000u : (uint32_t)((t53 + 0x3FFFFFULL) >> 22));
+                const uint64_t u53 = IRR ? lds_T1[j] : ~0ULL;
+                thr1[j] = __builtin_amdgcn_readfirstlane(u53 > (1ULL << 53) ? 0x80000000u : (uint32_t)((u53 + 0x3FFFFFULL) >> 22));
+            }
+            const uint32_t r4 = (uint32_t)a.ptick & 3u;            // the launch's offset inside its first block (wave-uniform)
             for (int c = 0; c < nch; c++) {
                 if (c >= kHChunks) {                             // slot c % kHChunks: E must be through chunk c - kHChunks
                     const uint32_t must = (uint32_t)min((c - kHChunks + 1) * kChunk, K);
@@ -237,20 +248,32 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                         if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
                     }
                 }
+                const uint64_t b0 = (a.ptick + (uint64_t)(c * kChunk)) >> 2;
+                auto words = [&](uint32_t stream, uint32_t (&wd)[kChunk]) {
+                    uint32_t o0[4], o1[4], o2[4] = {0u, 0u, 0u, 0u};
+                    philox_start_block(a.philox_seed, genv, b0, stream, o0);
+                    philox_start_block(a.philox_seed, genv, b0 + 1, stream, o1);
+                    if (r4 != 0u) philox_start_block(a.philox_seed, genv, b0 + 2, stream, o2);
+                    const uint32_t all[12] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3], o2[0], o2[1], o2[2], o2[3]};
+#pragma unroll
+                    for (int u = 0; u < kChunk; u++)
+                        wd[u] = r4 == 0u ? all[u] : r4 == 1u ? all[u + 1] : r4 == 2u ? all[u + 2] : all[u + 3];
+                };
+                uint32_t wd[kChunk], wd1[kChunk];
+                words(kPhiloxStartStream, wd);
+                if (IRR) words(kPhiloxStartIrrStream, wd1);
                 S0Word pk = 0;
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    Philox ge;
-                    ge.init(a.philox_seed, genv, a.ptick + (uint64_t)(c * kChunk + u), MDPP_STREAM_ENV);
-                    const uint64_t m = ge.next64() >> 11;
+                    const uint32_t m = wd[u] >> 1;
                     uint32_t s0 = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
-                    if (IRR) {                                   // the irrelevant start state: the same block's second half
-                        const uint64_t m1 = ge.next64() >> 11;
+                    for (int j = 0; j < 8; j++) s0 += (thr[j] <= m) ? 1u : 0u;
+                    if (IRR) {
+                        const uint32_t m1 = wd1[u] >> 1;
                         uint32_t s1 = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) s1 += (lds_T1[j] <= m1) ? 1u : 0u;
+                        for (int j = 0; j < 8; j++) s1 += (thr1[j] <= m1) ? 1u : 0u;
                         s0 |= (s1 | 8u) << 4;
                     }
                     pk |= (S0Word)(s0 | 8u) << (kEN * 4 * u);

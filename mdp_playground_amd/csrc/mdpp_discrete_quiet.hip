@@ -190,9 +190,29 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 #pragma unroll
     for (int q = 0; q < kQQ; q++) queue[q] = 0;
     uint32_t qn = 0;
-    auto draw_state = [&]() __attribute__((always_inline)) -> uint32_t {
+    auto draw_state = [&](const uint64_t tick = 0) __attribute__((always_inline)) -> uint32_t {
         // self._np_random.choice(S, p=rho_0): searchsorted(cdf, u, 'right') (:2255); then the
         // irrelevant start state the same way (:2259-2264)
+        if constexpr (PH) {
+            // Philox streams: one word of the start-state stream(s) of this tick, a 31-bit uniform (mdpp_rng.hpp):
+            // cdf[j] <= m31 2^-31  <=>  ceil(cdf[j] 2^53) <= m31 << 22
+            const uint64_t m = (uint64_t)philox_start_m31(a.philox_seed, genv, tick, kPhiloxStartStream) << 22;
+            uint32_t s0 = 0;
+            for (uint32_t b = 0; b < S8; b += 8) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) s0 += (T0[b + j] <= m) ? 1u : 0u;
+            }
+            if (IRR) {
+                const uint64_t m1 = (uint64_t)philox_start_m31(a.philox_seed, genv, tick, kPhiloxStartIrrStream) << 22;
+                uint32_t s1 = 0;
+                for (uint32_t b = 0; b < S18; b += 8) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) s1 += (T1[b + j] <= m1) ? 1u : 0u;
+                }
+                s0 |= s1 << 8;
+            }
+            return s0;
+        }
         const uint64_t m = g.next64() >> 11;
         uint32_t s0 = 0;
         for (uint32_t b = 0; b < S8; b += 8) {
@@ -233,11 +253,14 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                 gs.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
                 m_sp = gs.next64() >> 11;
             }
-            Philox ge;                                           // env stream: reward normal, then the reset draw
-            ge.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
             float z = 0.0f;
-            if (RN) z = (float)ge.normal();
-            const uint64_t mr = ge.next64() >> 11;
+            if (RN) {                                            // env stream: the reward normal
+                Philox ge;
+                ge.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
+                z = (float)ge.normal();
+            }
+            // the start state a reset at this tick takes: one word of the start-state stream (mdpp_rng.hpp)
+            const uint64_t mr = (uint64_t)philox_start_m31(a.philox_seed, genv, tick, kPhiloxStartStream) << 22;
             uint32_t s0 = 0;
             for (uint32_t b = 0; b < S8; b += 8) {
 #pragma unroll
@@ -435,7 +458,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
         if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
             if constexpr (NPH > 0) { queue[0] = need ? (uint32_t)(hent >> 56) : queue[0]; }
-            else if (need) { queue[0] = draw_state(); }
+            else if (need) { queue[0] = draw_state(a.ptick + (uint64_t)kstep); }
             qn = need ? 1u : qn;
         }
         uint32_t hi = (done_out ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |

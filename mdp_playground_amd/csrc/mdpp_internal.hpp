@@ -25,6 +25,9 @@ constexpr uint32_t kRingPyZero = 0x7FC0DE1Au; // float32 ring slot holding Pytho
 constexpr uint32_t kPhiloxResetStream = 3;    // an explicit reset(), keyed by the reset tick
 constexpr uint32_t kPhiloxIrrStream = 4;      // P-noise of the irrelevant sub-space
 constexpr uint32_t kPhiloxActionStream = 5;   // grid: the re-drawn noisy action
+// (6-8: the post-processor's streams, mdpp_post.hip)
+constexpr uint32_t kPhiloxStartStream = 9;    // discrete: start state of an in-rollout reset, one word per tick (mdpp_rng.hpp)
+constexpr uint32_t kPhiloxStartIrrStream = 10; // ... of the irrelevant sub-space
 
 // ---- discrete: kernel arguments (passed by value; wave-uniform => SGPRs) -------------------
 struct DiscreteArgs {

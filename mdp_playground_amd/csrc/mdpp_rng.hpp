@@ -79,7 +79,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         // __umulhi + * are two)
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-        const uint32_t y0 = h1 ^ c1 ^ k0, y1 = l1, y2 = h0 ^ c3 ^ k1, y3 = l0;
+        // (three-input xor: one v_bitop3_b32, truth table 0x96, where the compiler emits two v_xor_b32)
+        const uint32_t y0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96), y1 = l1;
+        const uint32_t y2 = __builtin_amdgcn_bitop3_b32(h0, c3, k1, 0x96), y3 = l0;
         c0 = y0; c1 = y1; c2 = y2; c3 = y3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -126,11 +128,69 @@ __device__ __forceinline__ void philox_box_muller(uint32_t w0, uint32_t w1, floa
     float cs = fmaf(2.443315711809948E-5f, tt, -1.388731625493765E-3f);
     cs = fmaf(cs, tt, 4.166664568298827E-2f);
     cs = fmaf(cs * tt, tt, fmaf(-0.5f, tt, 1.0f));
-    const float s1 = swap ? cs : sn, c1 = swap ? sn : cs;                // sin, cos of the in-quadrant angle
-    const float cq = (q == 0u) ? c1 : (q == 1u) ? -s1 : (q == 2u) ? -c1 : s1;
-    const float sq = (q == 0u) ? s1 : (q == 1u) ? c1 : (q == 2u) ? -s1 : -c1;
-    z0 = r * cq;
-    z1 = r * sq;
+    // sin, cos of the in-quadrant angle are (sn, cs), exchanged when the angle was reflected at pi/4; quadrant q
+    // rotates (cos, sin) -> (-sin, cos) q times: an odd q exchanges them once more, cos is negative for q = 1, 2
+    // and sin for q = 2, 3 (bit 31 of w1 + 2^30, and of w1).  Two selects and two sign-bit flips.
+    const bool xsw = swap != ((q & 1u) != 0u);
+    const float cq = xsw ? sn : cs, sq = xsw ? cs : sn;
+    z0 = __uint_as_float(__float_as_uint(r * cq) ^ ((w1 + 0x40000000u) & 0x80000000u));
+    z1 = __uint_as_float(__float_as_uint(r * sq) ^ (w1 & 0x80000000u));
+}
+
+// Two Box-Muller pairs at once from the four words of one Philox block: the same operations per pair as
+// philox_box_muller -- the same bits -- with the polynomial evaluations as packed float32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes per instruction, each an IEEE operation).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void philox_box_muller2(const uint32_t (&w)[4], float &z0, float &z1, float &z2, float &z3) {
+    f32x2 f = {(float)w[0], (float)w[2]};
+    if (w[0] == 0u) f.x = 0.5f;
+    if (w[2] == 0u) f.y = 0.5f;
+    const uint32_t b0 = __float_as_uint(f.x), b1 = __float_as_uint(f.y);
+    int e0 = (int)(b0 >> 23) - 127, e1 = (int)(b1 >> 23) - 127;
+    f32x2 m = {__uint_as_float((b0 & 0x7FFFFFu) | 0x3F800000u), __uint_as_float((b1 & 0x7FFFFFu) | 0x3F800000u)};
+    const bool big0 = m.x > 1.41421356f, big1 = m.y > 1.41421356f;
+    const f32x2 mh = m * 0.5f;
+    m.x = big0 ? mh.x : m.x; m.y = big1 ? mh.y : m.y;
+    e0 += big0 ? 1 : 0; e1 += big1 ? 1 : 0;
+    const f32x2 x = m - 1.0f;
+    const f32x2 xx = x * x;
+    auto K = [](float c) -> f32x2 { return f32x2{c, c}; };
+    f32x2 y = K(7.0376836292E-2f);
+    y = __builtin_elementwise_fma(y, x, K(-1.1514610310E-1f));
+    y = __builtin_elementwise_fma(y, x, K(1.1676998740E-1f));
+    y = __builtin_elementwise_fma(y, x, K(-1.2420140846E-1f));
+    y = __builtin_elementwise_fma(y, x, K(1.4249322787E-1f));
+    y = __builtin_elementwise_fma(y, x, K(-1.6668057665E-1f));
+    y = __builtin_elementwise_fma(y, x, K(2.0000714765E-1f));
+    y = __builtin_elementwise_fma(y, x, K(-2.4999993993E-1f));
+    y = __builtin_elementwise_fma(y, x, K(3.3333331174E-1f));
+    y = (y * x) * xx;
+    y = __builtin_elementwise_fma(K(-0.5f), xx, y);
+    const f32x2 fe = {(float)(e0 - 32), (float)(e1 - 32)};
+    f32x2 l = __builtin_elementwise_fma(fe, K(0.693359375f), __builtin_elementwise_fma(fe, K(-2.12194440e-4f), x + y));
+    l.x = fminf(l.x, 0.0f); l.y = fminf(l.y, 0.0f);
+    const f32x2 l2 = l * -2.0f;
+    const f32x2 r = {sqrtf(l2.x), sqrtf(l2.y)};
+    f32x2 a = {(float)(w[1] & 0x3FFFFFFFu), (float)(w[3] & 0x3FFFFFFFu)};
+    a = a * (1.0f / 1073741824.0f);
+    const bool swap0 = a.x > 0.5f, swap1 = a.y > 0.5f;
+    const f32x2 ar = 1.0f - a;
+    f32x2 t = {swap0 ? ar.x : a.x, swap1 ? ar.y : a.y};
+    t = t * 1.57079632679489662f;
+    const f32x2 tt = t * t;
+    f32x2 sn = __builtin_elementwise_fma(K(-1.9515295891E-4f), tt, K(8.3321608736E-3f));
+    sn = __builtin_elementwise_fma(sn, tt, K(-1.6666654611E-1f));
+    sn = __builtin_elementwise_fma(sn * tt, t, t);
+    f32x2 cs = __builtin_elementwise_fma(K(2.443315711809948E-5f), tt, K(-1.388731625493765E-3f));
+    cs = __builtin_elementwise_fma(cs, tt, K(4.166664568298827E-2f));
+    cs = __builtin_elementwise_fma(cs * tt, tt, __builtin_elementwise_fma(K(-0.5f), tt, K(1.0f)));
+    const bool x0 = swap0 != (((w[1] >> 30) & 1u) != 0u), x1 = swap1 != (((w[3] >> 30) & 1u) != 0u);
+    const f32x2 cq = {x0 ? sn.x : cs.x, x1 ? sn.y : cs.y}, sq = {x0 ? cs.x : sn.x, x1 ? cs.y : sn.y};
+    const f32x2 pc = r * cq, ps = r * sq;
+    z0 = __uint_as_float(__float_as_uint(pc.x) ^ ((w[1] + 0x40000000u) & 0x80000000u));
+    z1 = __uint_as_float(__float_as_uint(ps.x) ^ (w[1] & 0x80000000u));
+    z2 = __uint_as_float(__float_as_uint(pc.y) ^ ((w[3] + 0x40000000u) & 0x80000000u));
+    z3 = __uint_as_float(__float_as_uint(ps.y) ^ (w[3] & 0x80000000u));
 }
 
 struct Philox {
@@ -177,18 +237,42 @@ __device__ __forceinline__ void philox_normals(uint64_t seed, uint64_t env, uint
     for (int b = 0; b < NBLK; b++) {
         uint32_t o[4];
         philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)tick, (stream << 24) + (uint32_t)b, k0, k1, o);
+        if (2 * b + 1 < NPAIR) {                 // both pairs of the block: packed
+            float zz[4];
+            philox_box_muller2(o, zz[0], zz[1], zz[2], zz[3]);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int pr = 2 * b + h;
-            if (pr < NPAIR) {
-                float z0, z1;
-                philox_box_muller(o[2 * h], o[2 * h + 1], z0, z1);
-                z[2 * pr] = z0;
-                if (2 * pr + 1 < NN) z[2 * pr + 1] = z1;
-            }
+            for (int q = 0; q < 4; q++)
+                if (4 * b + q < NN) z[4 * b + q] = zz[q];
+        } else {
+            float z0, z1;
+            philox_box_muller(o[0], o[1], z0, z1);
+            z[4 * b] = z0;
+            if (4 * b + 1 < NN) z[4 * b + 1] = z1;
         }
     }
 }
+
+// ---- Philox mode, discrete envs: the start state of an in-rollout reset ---------------------------------
+// (same-step autoreset: the step at tick t ended the episode; next-step autoreset: call t IS the reset.)
+// A reset needs ONE categorical draw, so it gets one 32-bit word, and a block serves four ticks:
+//   w(t) = word (t & 3) of block 0 of stream (seed, env, t >> 2, stream id)      [stream ids: mdpp_internal.hpp]
+//   s0   = searchsorted(cdf, (w >> 1) * 2^-31, 'right') = #{ j : ceil(cdf[j] 2^31) <= (w >> 1) }
+// (round 2 spent a whole block per env and tick on it -- first 64 bits of the env stream's block -- although only
+//  a quarter of the ticks reset: cfg2 ran at half the rate of the numpy streams.)  An explicit reset() keeps its
+// own stream keyed by the reset count (kPhiloxResetStream, 53-bit uniform).
+__device__ __forceinline__ void philox_start_block(uint64_t seed, uint64_t env, uint64_t blk, uint32_t stream,
+                                                   uint32_t (&o)[4]) {
+    philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)blk, stream << 24, (uint32_t)seed,
+                  (uint32_t)(seed >> 32) ^ (uint32_t)(blk >> 32), o);
+}
+__device__ __forceinline__ uint32_t philox_start_m31(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
+    uint32_t o[4];
+    philox_start_block(seed, env, tick >> 2, stream, o);
+    const uint32_t q = (uint32_t)tick & 3u;
+    const uint32_t w = q == 0u ? o[0] : q == 1u ? o[1] : q == 2u ? o[2] : o[3];
+    return w >> 1;
+}
+__device__ __forceinline__ double philox_start_uniform(uint32_t m31) { return (double)m31 * (1.0 / 2147483648.0); }
 
 template <class G>
 __device__ __forceinline__ double np_random(G &g) { // Generator.random()

@@ -30,6 +30,7 @@ struct ora_discrete {
     np_pcg64 env_rng;        /* self._np_random */
     np_pcg64 space_rng;      /* self.observation_spaces[0].np_random */
     int philox; uint64_t ph_seed, ph_env; uint64_t tick, reset_tick;
+    int ph_explicit;         /* Philox mode: the next reset() is a call of its own (stream 3), not the end of a step */
     /* irrelevant sub-space (irrelevant_features=True), rl_toy_env.py:2028-2035, :2063-2092 */
     int irr, S1, A1, irr_state;
     int32_t *P1;
@@ -99,12 +100,22 @@ void ora_d_get_rng(const ora_discrete *e, uint64_t a[6], uint64_t b[6]) {
 
 /* reset(): rl_toy_env.py:2250 (ring cleared), :2255-2257 (choice from rho_0 on the
  * env RNG), :2275-2278 (NaN-filled history), :2358-2369 (counters). */
+/* Philox streams (the build's own, not the reference's): a reset that ends a step of a rollout takes the start-state
+ * word of that step's tick (stream 9; the irrelevant sub-space stream 10); an explicit reset() draws 53-bit uniforms
+ * from stream 3 keyed by the reset count. */
+#define ORA_PHILOX_START 9
+#define ORA_PHILOX_START_IRR 10
 int64_t ora_d_reset(ora_discrete *e) {
     for (int i = 0; i < e->delay; i++) e->ring[i] = 0.0;
-    int s0 = np_choice_cdf(&e->env_rng, e->init_cdf, e->S);
+    int s0;
+    if (e->philox && !e->ph_explicit)
+        s0 = np_philox_start_state(e->ph_seed, e->ph_env, e->tick - 1, ORA_PHILOX_START, e->init_cdf, e->S);
+    else
+        s0 = np_choice_cdf(&e->env_rng, e->init_cdf, e->S);
     for (int i = 0; i < e->L; i++) e->hist[i] = -1;
     e->hist[e->L] = s0;
     e->steps = 0;
+    e->ph_explicit = 0;
     return s0;
 }
 
@@ -114,6 +125,7 @@ void ora_d_set_philox(ora_discrete *e, uint64_t seed, uint64_t env_id, uint64_t 
 void ora_d_philox_explicit_reset(ora_discrete *e) {
     np_philox_init(&e->env_rng, e->ph_seed, e->ph_env, e->reset_tick, 3);
     e->reset_tick += 1;
+    e->ph_explicit = 1;
 }
 
 void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8_t *done) {
@@ -169,8 +181,13 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
  * same env generator (:2259-2264); step() moves the irrelevant part with its own table and its own
  * P-noise generator after the reward was computed (:2063-2082).  obs = (relevant, irrelevant). */
 void ora_d_reset2(ora_discrete *e, int64_t out[2]) {
+    const int in_step = e->philox && !e->ph_explicit;
     out[0] = ora_d_reset(e);
-    e->irr_state = np_choice_cdf(&e->env_rng, e->init_cdf1, e->S1);
+    if (in_step)
+        e->irr_state = np_philox_start_state(e->ph_seed, e->ph_env, e->tick - 1, ORA_PHILOX_START_IRR, e->init_cdf1, e->S1);
+    else
+        e->irr_state = np_choice_cdf(&e->env_rng, e->init_cdf1, e->S1);
+    e->ph_explicit = 0;
     out[1] = e->irr_state;
 }
 

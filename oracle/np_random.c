@@ -192,6 +192,21 @@ int np_choice_cdf(np_pcg64 *g, const double *cdf, int n) {
     return lo;
 }
 
+/* Philox mode, discrete envs: the start state an in-rollout reset at tick t draws -- the build's own definition
+ * (mdp_playground_amd/csrc/mdpp_rng.hpp philox_start_*; NOT in the reference): one 32-bit word per tick, word (t & 3) of
+ * block 0 of stream (seed, env, t >> 2, stream id), and a 31-bit uniform u = (w >> 1) 2^-31 searched in the cdf like
+ * numpy's choice (searchsorted 'right'). */
+int np_philox_start_state(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, const double *cdf, int n) {
+    np_pcg64 g;
+    np_philox_init(&g, seed, env, tick >> 2, stream);
+    const uint64_t a = np_next64(&g), b = np_next64(&g);        /* words (0, 1), then (2, 3) of block 0 */
+    const uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    const double u = (double)(w[tick & 3] >> 1) * (1.0 / 2147483648.0);
+    int c = 0;
+    for (int i = 0; i < n; i++) c += (cdf[i] <= u) ? 1 : 0;
+    return c;
+}
+
 /* out[e][j] = j-th standard normal of Philox stream (seed, env0 + e, tick, stream): the counterpart of
  * the library's mdpp_philox_normals, for the device-vs-oracle bit test. */
 void np_philox_normals(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream, int n_envs, int n_per_env,

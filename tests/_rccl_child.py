@@ -34,8 +34,10 @@ for name, c, rng in (("cfg2", cfg, "numpy"), ("cfg2", cfg, "philox"), ("cfg5", c
     pl = RLToyVectorEnv(num_envs=N, device=dev, autoreset="same_step", rng=rng, **c)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
+    assert torch.equal(sh.env._obs, pl._obs), name           # (the constructors' reset())
     o_s, _ = sh.reset()
-    assert o_s.shape[0] == N and torch.equal(o_s, pl._obs), name
+    o_p, _ = pl.reset()
+    assert o_s.shape[0] == N and torch.equal(o_s, o_p), name
     for t in range(T):
         if c is cfg:
             a = torch.randint(0, 8, (N,), generator=g, device=dev, dtype=torch.int32)

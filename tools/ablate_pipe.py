@@ -29,17 +29,18 @@ def main():
         so = os.path.join(outdir, f"libmdpp_{name}.so")
         subprocess.check_call([B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(CSRC, src), "-o", obj])
         subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-o", so] + objs + [obj])
+        rng = os.environ.get("ABL_RNG", "numpy")
         code = (f"import sys; sys.path.insert(0, {ROOT!r}); import torch\n"
                 f"from mdp_playground_amd import _capi; _capi.LIB_PATH = {so!r}\n"
                 "from mdp_playground_amd import RLToyVectorEnv; import bench\n"
                 f"wl = bench.WORKLOADS[{wname!r}]; N = wl['envs']; F = min(512, wl.get('fuse_max', 512))\n"
-                "env = RLToyVectorEnv(num_envs=N, autoreset='same_step', **wl['config'])\n"
-                "acts = bench.make_actions(wl, F, N, env.device, 12345); out = env.alloc_rollout(F)\n"
-                "for _ in range(5): env.rollout(acts, out)\n"
+                f"env = RLToyVectorEnv(num_envs=N, autoreset='same_step', rng={rng!r}, **wl['config'])\n"
+                "acts = bench.action_rotation(wl, F, N, env.device, 12345); out = env.alloc_rollout(F)\n"
+                "for j in range(5): env.rollout(acts[j % len(acts)], out)\n"
                 "torch.cuda.synchronize(); best = 1e9\n"
                 "for rep in range(3):\n"
                 "    env.timer_begin()\n"
-                "    for _ in range(20): env.rollout(acts, out)\n"
+                "    for j in range(20): env.rollout(acts[j % len(acts)], out)\n"
                 "    best = min(best, env.timer_end() / 20)\n"
                 f"print({name!r}, env.rollout_kernel_name(F), '%.1f us per launch' % (best * 1e3), '%.3f of 8 TB/s' % (wl['alg_bytes_fused'] * N * F / (best * 1e-3) / 8e12))\n")
         subprocess.check_call([sys.executable, "-c", code])
