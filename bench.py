@@ -422,6 +422,7 @@ def main():
         torch.cuda.synchronize(device)
 
     launched = [0]
+    host_enqueue = [0.0]
 
     def run(steps, gathers, rotate=True):
         """`steps` fused launches; with `gathers`, each launch is followed by ONE all-gather (on the comm
@@ -454,6 +455,7 @@ def main():
             env.timer_begin()
         t0 = time.perf_counter()
         run(steps, gathers, rotate)
+        host_enqueue[0] = time.perf_counter() - t0      # the host's share: everything is asynchronous up to here
         kernel_ms = env.timer_end() if events else None
         torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
@@ -468,7 +470,8 @@ def main():
     # different action tensor (NA of them, > the Infinity Cache together)
     run(max(args.warmup, 1), None)
     el_none, kernel_ms = timed(args.steps, None, events=True)
-    legs = {"none": {"elapsed_s": el_none, "env_steps_per_s": world * N * F * args.steps / el_none}}
+    legs = {"none": {"elapsed_s": el_none, "env_steps_per_s": world * N * F * args.steps / el_none,
+                     "host_enqueue_s": host_enqueue[0]}}
     # the same launches replaying ONE action tensor (what rounds 1-2 timed): its reads may be cache hits
     run(2, None, rotate=False)
     _, replay_ms = timed(args.steps, None, events=True, rotate=False)
@@ -481,6 +484,7 @@ def main():
         run(max(args.warmup, 1), g_last)
         el_last, _ = timed(args.steps, g_last)
         legs["last_row"] = {"elapsed_s": el_last, "env_steps_per_s": world * N * F * args.steps / el_last,
+                            "host_enqueue_s": host_enqueue[0],
                             "bytes_per_rank_per_launch": g_last[0].local.numel() * g_last[0].local.element_size()}
         elapsed = el_last
         collective = ("all_gather_into_tensor (RCCL, %d rank%s) of the current observation shard after every launch, "

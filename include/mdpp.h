@@ -334,6 +334,17 @@ int mdpp_post_step(mdpp_post *h, const void *obs_in_dev, const double *reward_in
 int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, const double *reward_in_dev, const uint8_t *done_dev,
                      void *obs_out_dev, double *reward_out_dev, void *stream);
 
+/* Episode statistics of a block of per-step outputs (what RLlib reports per training iteration and the reference's
+ * callbacks write to the stats CSV, config_processor.py:275-407; mdp_playground_amd/stats_csv.py EpisodeStats): for
+ * every instance the running return (double [N]) and length (int64 [N]) are carried through the K rows of
+ * reward [K][N] (float32, or float64 when reward_is_f64) with end flags ended | ended2 (uint8 [K][N]; ended2 may be
+ * NULL), and over the episodes that end inside the block *sum_ret, *sum_len, *count (device scalars) grow by the sum of
+ * their returns, the sum of their lengths and their number.  Deterministic (no atomics).  scratch_dev: at least
+ * 24 * ceil(N / 256) bytes.  Runs on the current device. */
+int mdpp_episode_stats(int32_t K, int32_t N, const void *reward_dev, int32_t reward_is_f64, const uint8_t *ended_dev,
+                       const uint8_t *ended2_dev, double *ret_dev, int64_t *len_dev, double *sum_ret_dev,
+                       int64_t *sum_len_dev, int64_t *count_dev, void *scratch_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,7 @@ EXPORTS = [
     "mdpp_graph_replay_exact", "mdpp_tick", "mdpp_get_reset_pending", "mdpp_set_reset_pending",
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
+    "mdpp_episode_stats",
 ]
 
 
@@ -145,6 +146,7 @@ def load():
     L.mdpp_post_actions.argtypes = [vp] * 4
     L.mdpp_post_step.argtypes = [vp] * 7
     L.mdpp_post_step_n.argtypes = [vp, i32] + [vp] * 6
+    L.mdpp_episode_stats.argtypes = [i32, i32, vp, i32] + [vp] * 9
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     if L.mdpp_abi_version() != MDPP_ABI_VERSION:

@@ -413,7 +413,9 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
         const long long kmax = ((1LL << 32) - 1) / ((a.irr ? 16LL : 8LL) * a.N);
         char dry[kNameLen];
         const int k_first = (int)(K < kmax ? K : kmax);
-        if (kmax >= 32 && launch_discrete_lean(a, k_first, actions, obs, reward, term, trunc, nullptr, s, dry)) {
+        // (final observations are forwarded piece by piece like in the fast_ok branch below: the lean kernel declines a
+        //  launch that asks for them, the quiet and general kernels write them -- ADVICE r2: nothing is dropped silently)
+        if (kmax >= 32 && launch_discrete_lean(a, k_first, actions, obs, reward, term, trunc, final_obs, s, dry)) {
             lean_philox = true;
             const size_t osz = a.obs_i32 ? 4 : 8;
             for (int k0 = 0; k0 < K;) {
@@ -423,11 +425,12 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
                 a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u;
                 const size_t aoff = off * (a.irr ? 2 : 1);     // (an irrelevant sub-space: action pairs, observation pairs)
                 char *op = (char *)obs + off * osz * (a.irr ? 2 : 1);
-                if (!launch_discrete_lean(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, nullptr, s, name_out) &&
-                    !launch_discrete_quiet(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, nullptr, s, name_out)) {
+                void *fo = final_obs ? (void *)((char *)final_obs + off * osz * (a.irr ? 2 : 1)) : nullptr;
+                if (!launch_discrete_lean(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out) &&
+                    !launch_discrete_quiet(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out)) {
                     // (a short last piece of a next-step handle: the general kernel; these shapes have no noise)
-                    if (a.philox) launch_step_t<true, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, nullptr, s, name_out);
-                    else launch_step_t<false, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, nullptr, s, name_out);
+                    if (a.philox) launch_step_t<true, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
+                    else launch_step_t<false, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
                 }
                 if (name_out) return MDPP_OK;
                 k0 += kc;

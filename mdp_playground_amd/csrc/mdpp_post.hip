@@ -28,6 +28,7 @@ struct mdpp_post {
     int device;
     std::string err;
     uint64_t tick, reset_tick;
+    uint64_t action_tick;       // mdpp_post_actions calls so far (Philox counter of the action-noise stream)
     void *d_rng_s, *d_rng_inc, *d_half, *d_ring, *d_head, *d_noise_cdf, *d_shift, *d_xyc;
     int num_cus;
     size_t shift_cap;           // image placements held by d_shift (K * N of the largest call so far)
@@ -44,7 +45,7 @@ struct PostArgs {
     int32_t N, continuous, n_actions, obs_dim, obs_f64, delay, has_p, has_r, autoreset;
     int32_t image, H, W, C, pad, has_shift, sh_quant, philox;
     double p_noise, r_noise, scale, shift, term;
-    uint64_t philox_seed, tick;
+    uint64_t philox_seed, tick, action_tick;
     int64_t env_id_offset;
     ulonglong2 *rng_s, *rng_inc;
     uint2 *half;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void k_post_actions(PostArgs a, const int32
     int act = in[i];
     if (act < 0 || act >= a.n_actions) { out[i] = act; return; }             // (the reference would raise IndexError)
     typename std::conditional<PHILOX, Philox, Pcg64>::type g;
-    if constexpr (PHILOX) g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.tick, kPhiloxPostAction);
+    if constexpr (PHILOX) g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.action_tick, kPhiloxPostAction);
     else g.load(a.rng_s, a.rng_inc, i);
     const double u = np_random(g);                                            // choice(n, size=1, p=probs), :364
     out[i] = searchsorted_right(a.noise_cdf + (size_t)act * a.n_actions, a.n_actions, u);
@@ -392,7 +393,7 @@ PostArgs make_args(const mdpp_post *h) {
     a.philox = c.rng_mode == MDPP_RNG_PHILOX;
     a.p_noise = c.transition_noise; a.r_noise = c.reward_noise; a.scale = c.reward_scale; a.shift = c.reward_shift;
     a.term = c.term_state_reward;
-    a.philox_seed = c.philox_seed; a.tick = h->tick; a.env_id_offset = c.env_id_offset;
+    a.philox_seed = c.philox_seed; a.tick = h->tick; a.action_tick = h->action_tick; a.env_id_offset = c.env_id_offset;
     a.rng_s = (ulonglong2 *)h->d_rng_s; a.rng_inc = (ulonglong2 *)h->d_rng_inc; a.half = (uint2 *)h->d_half;
     a.ring = (double *)h->d_ring; a.head = (uint32_t *)h->d_head; a.noise_cdf = (const double *)h->d_noise_cdf;
     a.place = (short2 *)h->d_shift;
@@ -470,7 +471,7 @@ extern "C" int mdpp_post_create(const mdpp_post_config *cfg, int device, mdpp_po
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return pfail(nullptr, MDPP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     mdpp_post *h = new mdpp_post();
-    h->cfg = *cfg; h->device = device; h->tick = 0; h->reset_tick = 0; h->seeded = false;
+    h->cfg = *cfg; h->device = device; h->tick = 0; h->reset_tick = 0; h->action_tick = 0; h->seeded = false;
     h->d_rng_s = h->d_rng_inc = h->d_half = h->d_ring = h->d_head = h->d_noise_cdf = h->d_shift = h->d_xyc = nullptr;
     h->num_cus = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) h->num_cus = v; }
@@ -605,11 +606,15 @@ extern "C" int mdpp_post_actions(mdpp_post *h, const int32_t *in_dev, int32_t *o
     PHIP(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t N = (size_t)h->cfg.num_envs;
+    // (Philox streams: the action noise is keyed by the number of mdpp_post_actions calls, not by the step counter --
+    //  a block of K action rows processed before one fused step_n(K) gets K different draws per instance)
     if (!h->d_noise_cdf) {                                   // `if self.transition_noise:` false: identity
         if (in_dev != out_dev) PHIP(h, hipMemcpyAsync(out_dev, in_dev, N * 4, hipMemcpyDeviceToDevice, s));
+        h->action_tick += 1;
         return MDPP_OK;
     }
     PostArgs a = make_args(h);
+    h->action_tick += 1;
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox) hipLaunchKernelGGL(k_post_actions<true>, dim3(grid), dim3(kBlock), 0, s, a, in_dev, out_dev);
     else hipLaunchKernelGGL(k_post_actions<false>, dim3(grid), dim3(kBlock), 0, s, a, in_dev, out_dev);
@@ -652,4 +657,95 @@ extern "C" int mdpp_post_step_n(mdpp_post *h, int K, const void *obs_in_dev, con
 extern "C" int mdpp_post_step(mdpp_post *h, const void *obs_in_dev, const double *reward_in_dev, const uint8_t *done_dev,
                               void *obs_out_dev, double *reward_out_dev, void *stream) {
     return mdpp_post_step_n(h, 1, obs_in_dev, reward_in_dev, done_dev, obs_out_dev, reward_out_dev, stream);
+}
+
+// ---- episode statistics (episode_reward_mean / episode_len_mean of RLlib's result dict, config_processor.py:275-407) ----
+// One lane per instance walks the K rows of a [K][N] block of per-step rewards and end flags: running return and
+// length per instance, and over the episodes that ended inside the block the sum of returns, the sum of lengths
+// and their number.  Two launches, no atomics: per-block partial sums in a fixed tree order, then one lane adds
+// the partials in block order -- the result does not depend on scheduling.
+namespace {
+constexpr int kStatsPre = 8;
+template <bool F64>
+__global__ __launch_bounds__(kBlock) void k_episode_stats(int K, int N, const void *__restrict__ reward,
+                                                          const uint8_t *__restrict__ e1, const uint8_t *__restrict__ e2,
+                                                          double *__restrict__ ret, long long *__restrict__ len,
+                                                          double *__restrict__ part_ret, long long *__restrict__ part_len,
+                                                          long long *__restrict__ part_cnt) {
+    __shared__ double s_r[kBlock];
+    __shared__ long long s_l[kBlock], s_c[kBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double sret = 0.0;
+    long long slen = 0, cnt = 0;
+    if (i < N) {
+        double r = ret[i];
+        long long l = len[i];
+        auto rew = [&](int k) -> double {
+            const size_t o = (size_t)k * N + i;
+            return F64 ? ((const double *)reward)[o] : (double)((const float *)reward)[o];
+        };
+        auto fl = [&](int k) -> bool {
+            const size_t o = (size_t)k * N + i;
+            return (e1[o] | (e2 ? e2[o] : (uint8_t)0)) != 0;
+        };
+        int k = 0;
+        for (; k + kStatsPre <= K; k += kStatsPre) {            // kStatsPre rows in flight per lane
+            double rv[kStatsPre];
+            bool ev[kStatsPre];
+#pragma unroll
+            for (int u = 0; u < kStatsPre; u++) { rv[u] = rew(k + u); ev[u] = fl(k + u); }
+#pragma unroll
+            for (int u = 0; u < kStatsPre; u++) {
+                r += rv[u]; l += 1;
+                sret += ev[u] ? r : 0.0; slen += ev[u] ? l : 0; cnt += ev[u] ? 1 : 0;
+                r = ev[u] ? 0.0 : r; l = ev[u] ? 0 : l;
+            }
+        }
+        for (; k < K; k++) {
+            const bool e = fl(k);
+            r += rew(k); l += 1;
+            sret += e ? r : 0.0; slen += e ? l : 0; cnt += e ? 1 : 0;
+            r = e ? 0.0 : r; l = e ? 0 : l;
+        }
+        ret[i] = r; len[i] = l;
+    }
+    s_r[threadIdx.x] = sret; s_l[threadIdx.x] = slen; s_c[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            s_r[threadIdx.x] += s_r[threadIdx.x + st]; s_l[threadIdx.x] += s_l[threadIdx.x + st]; s_c[threadIdx.x] += s_c[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part_ret[blockIdx.x] = s_r[0]; part_len[blockIdx.x] = s_l[0]; part_cnt[blockIdx.x] = s_c[0]; }
+}
+
+__global__ void k_episode_stats_final(int nblocks, const double *part_ret, const long long *part_len, const long long *part_cnt,
+                                      double *sum_ret, long long *sum_len, long long *count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double r = *sum_ret;
+    long long l = *sum_len, c = *count;
+    for (int b = 0; b < nblocks; b++) { r += part_ret[b]; l += part_len[b]; c += part_cnt[b]; }
+    *sum_ret = r; *sum_len = l; *count = c;
+}
+} // namespace
+
+extern "C" int mdpp_episode_stats(int32_t K, int32_t N, const void *reward_dev, int32_t reward_is_f64, const uint8_t *ended_dev,
+                                  const uint8_t *ended2_dev, double *ret_dev, int64_t *len_dev, double *sum_ret_dev,
+                                  int64_t *sum_len_dev, int64_t *count_dev, void *scratch_dev, void *stream) {
+    if (K < 1 || N < 1 || !reward_dev || !ended_dev || !ret_dev || !len_dev || !sum_ret_dev || !sum_len_dev || !count_dev || !scratch_dev)
+        return MDPP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (N + kBlock - 1) / kBlock;
+    double *part_ret = (double *)scratch_dev;
+    long long *part_len = (long long *)(part_ret + grid), *part_cnt = part_len + grid;
+    if (reward_is_f64)
+        hipLaunchKernelGGL(k_episode_stats<true>, dim3(grid), dim3(kBlock), 0, s, K, N, reward_dev, ended_dev, ended2_dev, ret_dev,
+                           (long long *)len_dev, part_ret, part_len, part_cnt);
+    else
+        hipLaunchKernelGGL(k_episode_stats<false>, dim3(grid), dim3(kBlock), 0, s, K, N, reward_dev, ended_dev, ended2_dev, ret_dev,
+                           (long long *)len_dev, part_ret, part_len, part_cnt);
+    hipLaunchKernelGGL(k_episode_stats_final, dim3(1), dim3(64), 0, s, grid, part_ret, part_len, part_cnt, sum_ret_dev,
+                       (long long *)sum_len_dev, (long long *)count_dev);
+    return hipGetLastError() == hipSuccess ? MDPP_OK : MDPP_EHIP;
 }

@@ -8,7 +8,7 @@ mdp_playground/analysis/analysis.py:15-330 (`MDPP_Analysis.load_data`) is the co
 format: space-separated, `#` comment lines, the header's column names split on ", ", the last three
 columns timesteps_total / episode_reward_mean / episode_len_mean with timesteps_total restarting at
 every run.  Host-side and tiny; the per-episode reductions over batched device tensors are in
-EpisodeStats below (torch ops on the device, no kernel of its own)."""
+EpisodeStats below (one kernel per call on device tensors)."""
 from __future__ import annotations
 
 import os
@@ -19,12 +19,16 @@ METRICS = ("timesteps_total", "episode_reward_mean", "episode_len_mean")
 EVAL_SEPARATOR = "#HACK STRING EVAL\n"
 
 
-def format_value(v):
-    """A varied-config value as `on_train_result` writes it (:287-301): floats "%.2e", lists
-    "[e1,e2,]" with float elements "%.2e", everything else str() without spaces."""
+def format_value(v, config_type="env"):
+    """A varied-config value as `on_train_result` writes it, by the type of config it belongs to:
+    "env" (:287-301): floats "%.2e", lists "[e1,e2,]" with float elements "%.2e", everything else str() without
+    spaces; "agent" (:303-343): floats "%.2e", everything else -- lists included, e.g. fcnet_hiddens "[256,256]" --
+    str() without spaces; "model" (:344-349): str() without spaces for every value."""
+    if config_type == "model":
+        return str(v).replace(" ", "")
     if isinstance(v, float):
         return "%.2e" % v
-    if isinstance(v, list):
+    if isinstance(v, list) and config_type == "env":
         s = "["
         for e in v:
             s += "%.2e" % e if isinstance(e, float) else str(e)
@@ -34,10 +38,17 @@ def format_value(v):
 
 
 class StatsWriter:
-    """Appends to <prefix>.csv / <prefix>_eval.csv exactly what the reference's Ray callbacks append."""
+    """Appends to <prefix>.csv / <prefix>_eval.csv what the reference's Ray callbacks append (value formats per
+    config type: format_value)."""
 
-    def __init__(self, stats_file_prefix, columns, algorithm, write_header=True):
+    def __init__(self, stats_file_prefix, columns, algorithm, write_header=True, column_types=None):
+        """column_types: {column: "env" | "agent" | "model"} -- which config a varied column belongs to (the
+        reference formats values per type, format_value); columns not named are env columns."""
         self.prefix, self.columns, self.algorithm = stats_file_prefix, list(columns), str(algorithm)
+        self.column_types = dict(column_types or {})
+        for c, t in self.column_types.items():
+            if t not in ("env", "agent", "model"):
+                raise ValueError(f"column_types[{c!r}] must be 'env', 'agent' or 'model'")
         if write_header:                                        # init_stats_file, :241-259
             with open(self.prefix + ".csv", "a") as f:
                 f.write("# training_iteration, algorithm, ")
@@ -51,7 +62,7 @@ class StatsWriter:
         with open(self.prefix + ".csv", "a") as f:
             f.write(str(training_iteration) + " " + self.algorithm + " ")
             for c in self.columns:
-                f.write(format_value(config_values[c]) + " ")
+                f.write(format_value(config_values[c], self.column_types.get(c, "env")) + " ")
             f.write(str(timesteps_total) + " " + "%.2e" % episode_reward_mean + " " + "%.2e" % episode_len_mean + "\n")
         if evaluation:                                          # :378-385
             with open(self.prefix + "_eval.csv", "a") as f:
@@ -137,34 +148,70 @@ def load_stats(dir_name, exp_name, num_metrics=3, load_eval=False, normalise_epi
 
 class EpisodeStats:
     """episode_reward_mean / episode_len_mean of a batch of env instances from the per-step tensors a
-    vector env returns (reward[N], terminated | truncated [N]): running per-instance return and length,
-    and the sums over the episodes that finished since the last pop() (what RLlib reports per training
-    iteration).  Plain torch ops on the tensors' device."""
+    vector env returns (reward[N] or [K, N], terminated / truncated of the same shape): running per-instance
+    return and length, and the sums over the episodes that finished since the last pop() (what RLlib reports
+    per training iteration).  Device tensors go through ONE kernel per call (mdpp_episode_stats: a lane per
+    instance walks the K rows; a [512, 65 536] rollout is two launches, not 4 000 torch ops); host tensors
+    through plain torch ops."""
 
     def __init__(self, num_envs, device):
         import torch
         self._t = torch
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
         self.ret = torch.zeros(num_envs, dtype=torch.float64, device=device)
         self.len = torch.zeros(num_envs, dtype=torch.int64, device=device)
         self.sum_ret = torch.zeros((), dtype=torch.float64, device=device)
         self.sum_len = torch.zeros((), dtype=torch.int64, device=device)
         self.count = torch.zeros((), dtype=torch.int64, device=device)
         self.timesteps_total = 0
+        self._lib = self._scratch = None
+        if self.device.type == "cuda":
+            from . import _capi
+            self._lib = _capi.load()          # (raises when the HIP library is missing: no fallback for device tensors)
+            self._scratch = torch.empty(3 * ((self.num_envs + 255) // 256), dtype=torch.float64, device=device)
 
-    def update(self, reward, ended):
-        """reward [N] or [K, N]; ended = terminated | truncated, same shape."""
+    def update(self, reward, ended, ended2=None):
+        """reward [N] or [K, N] (float32 / float64); ended (and optionally ended2, e.g. terminated and truncated:
+        an episode ends where either is set), same shape."""
+        t = self._t
         if reward.dim() == 1:
             reward, ended = reward[None], ended[None]
-        for k in range(reward.shape[0]):
-            self.ret += reward[k].to(self._t.float64)
-            self.len += 1
-            e = ended[k].to(self._t.bool)
-            self.sum_ret += (self.ret * e).sum()
-            self.sum_len += (self.len * e).sum()
-            self.count += e.sum()
-            self.ret.masked_fill_(e, 0.0)
-            self.len.masked_fill_(e, 0)
-        self.timesteps_total += int(reward.shape[0] * reward.shape[1])
+            ended2 = None if ended2 is None else ended2[None]
+        K, N = int(reward.shape[0]), int(reward.shape[1])
+        if N != self.num_envs:
+            raise ValueError(f"expected {self.num_envs} instances, got {N}")
+        if self._lib is not None:
+            if reward.dtype not in (t.float32, t.float64):
+                reward = reward.to(t.float64)
+            r = reward.contiguous()
+            e1 = ended.contiguous().view(t.uint8) if ended.dtype == t.bool else ended.to(t.uint8).contiguous()
+            e2 = None
+            if ended2 is not None:
+                e2 = ended2.contiguous().view(t.uint8) if ended2.dtype == t.bool else ended2.to(t.uint8).contiguous()
+            if r.device != self.device or e1.device != self.device:
+                raise ValueError("EpisodeStats.update: tensors must live on the device the statistics were made for")
+            from . import _capi
+            with t.cuda.device(self.device):
+                rc = self._lib.mdpp_episode_stats(
+                    K, N, r.data_ptr(), int(r.dtype == t.float64), e1.data_ptr(), None if e2 is None else e2.data_ptr(),
+                    self.ret.data_ptr(), self.len.data_ptr(), self.sum_ret.data_ptr(), self.sum_len.data_ptr(),
+                    self.count.data_ptr(), self._scratch.data_ptr(), t.cuda.current_stream(self.device).cuda_stream)
+            if rc:
+                raise _capi.MdppError(f"mdpp_episode_stats failed ({rc})")
+        else:
+            for k in range(K):
+                self.ret += reward[k].to(t.float64)
+                self.len += 1
+                e = ended[k].to(t.bool)
+                if ended2 is not None:
+                    e = e | ended2[k].to(t.bool)
+                self.sum_ret += (self.ret * e).sum()
+                self.sum_len += (self.len * e).sum()
+                self.count += e.sum()
+                self.ret.masked_fill_(e, 0.0)
+                self.len.masked_fill_(e, 0)
+        self.timesteps_total += K * N
 
     def pop(self):
         """-> (timesteps_total, episode_reward_mean, episode_len_mean) over the episodes finished since the

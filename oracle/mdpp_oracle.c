@@ -356,6 +356,8 @@ typedef struct { double v; int is32; } rew_t; /* np.float32 vs Python float */
 struct ora_continuous {
     int D, n_rel, order, make_denser, has_p_noise, has_r_noise, delay, every_n, n_boxes;
     int image_quirk;
+    int target64;            /* the DEFAULT target_point: float64 zeros of length state_space_dim (:652-654) */
+    double radius;
     int rel[ORA_MAX_DIM];
     float inertia32, amax32, smax32, radius32, alw32;
     float tpow32[ORA_MAX_ORDER + 1];  /* float32(time_unit ** k) */
@@ -394,6 +396,7 @@ ora_continuous *ora_c_create(int D, int n_rel, const int32_t *rel_idx, int order
     e->amax = action_max; e->smax = state_max;
     e->amax32 = (float)action_max; e->smax32 = (float)state_max;
     e->radius32 = (float)target_radius; e->alw32 = (float)action_loss_weight;
+    e->radius = target_radius;
     double f = 1.0;
     for (int k = 1; k <= order; k++) {
         f *= (double)k;
@@ -414,6 +417,12 @@ ora_continuous *ora_c_create(int D, int n_rel, const int32_t *rel_idx, int order
 }
 
 void ora_c_set_image_quirk(ora_continuous *e, int on) { e->image_quirk = on; }
+/* No "target_point" in the config: the reference falls back to np.zeros(shape=(state_space_dim,)) -- FLOAT64, and
+ * of the full state dimension, so it only broadcasts when every dimension is relevant (:652-654).  The float32 state
+ * minus that target is a float64 vector: np.linalg.norm, the target latch (:1719-1725) and a dense reward (:1926-1929)
+ * are float64 (np.float64 behaves like a Python float in what follows); a sparse reward is the Python float 1.0 / 0.0
+ * and turns np.float32 at `reward -= action_loss_weight * norm(action)` as with an explicit target. */
+void ora_c_set_target64(ora_continuous *e) { e->target64 = 1; }
 
 void ora_c_destroy(ora_continuous *e) {
     if (!e) return;
@@ -457,6 +466,18 @@ static float norm32_rel_minus_target(const ora_continuous *e, const float *s) {
         acc += (double)p;
     }
     return sqrtf((float)acc);
+}
+/* np.linalg.norm of (float32 state - float64 zeros) = sqrt(x.dot(x)) in float64: cblas_ddot; for n < 16 OpenBLAS's
+ * x86_64 ddot runs its scalar tail, a sequential sum (every product of two float32-valued doubles is exact, so an
+ * fma chain and multiply-then-add give the same bits; checked against numpy for n <= 12, mismatches from n = 16 on:
+ * the host builder refuses the default target for state_space_dim >= 16). */
+static double norm64_rel(const ora_continuous *e, const float *s) {
+    double acc = 0.0;
+    for (int j = 0; j < e->n_rel; j++) {
+        double d = (double)s[e->rel[j]] - 0.0;
+        acc += d * d;
+    }
+    return sqrt(acc);
 }
 static float norm32(const float *x, int n) {
     double acc = 0.0;
@@ -598,7 +619,9 @@ void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
     }
     /* C5: :1719-1725 (the target latch exists for move_to_a_point only) */
     float dist_new = e->line_L ? 0.0f : norm32_rel_minus_target(e, nxt);
-    if (!e->line_L && dist_new < e->radius32) e->reached = 1;
+    double dist_new64 = e->target64 ? norm64_rel(e, nxt) : 0.0;
+    const int within = e->target64 ? (dist_new64 < e->radius) : (dist_new < e->radius32);
+    if (!e->line_L && within) e->reached = 1;
     e->steps += 1; /* :2058 */
     /* C6: :1912-1945 */
     rew_t r;
@@ -607,16 +630,19 @@ void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
         line_push(e, nxt);
         r.v = (e->steps >= e->line_L) ? line_reward(e) : 0.0;
         r.is32 = 0;
+    } else if (e->make_denser && e->target64) {
+        r.v = -dist_new64;                       /* np.float64 (:1926) */
+        r.v = r.v + norm64_rel(e, e->cur);       /* :1929 */
     } else if (e->make_denser) {
         float dist_old = norm32_rel_minus_target(e, e->cur);
         r.v = (double)(float)(-dist_new + dist_old);
     } else {
-        r.v = (dist_new < e->radius32) ? 1.0 : 0.0;
+        r.v = within ? 1.0 : 0.0;
     }
     if (!e->line_L) {
-        float pen = e->alw32 * norm32(a, D);
-        r.v = (double)((float)r.v - pen);
-        r.is32 = 1;
+        float pen = e->alw32 * norm32(a, D);     /* Python float * np.float32 -> np.float32 */
+        if (e->make_denser && e->target64) { r.v = r.v - (double)pen; r.is32 = 0; }   /* np.float64 - np.float32 */
+        else { r.v = (double)((float)r.v - pen); r.is32 = 1; }
     }
     /* C7: :1968-1990 */
     if (e->delay > 0) {
@@ -851,7 +877,7 @@ struct ora_post {
     int image, H, W, C, pad, has_shift, sh_quant;
     double *ring; int ring_n;     /* self.reward_buffer (a list: append at the end, pop the front) */
     np_pcg64 rng;
-    int philox; uint64_t ph_seed, ph_env, tick, reset_tick;
+    int philox; uint64_t ph_seed, ph_env, tick, reset_tick, action_tick;
 };
 
 /* numpy's pairwise summation of a contiguous float64 vector (loops_utils.h.src, n <= 128) == np.sum */
@@ -895,6 +921,7 @@ void ora_p_set_rng(ora_post *e, const uint64_t w[6]) { np_pcg64_load(&e->rng, w)
 void ora_p_get_rng(const ora_post *e, uint64_t w[6]) { np_pcg64_store(&e->rng, w); }
 void ora_p_set_philox(ora_post *e, uint64_t seed, uint64_t env_id, uint64_t tick, uint64_t reset_tick) {
     e->philox = 1; e->ph_seed = seed; e->ph_env = env_id; e->tick = tick; e->reset_tick = reset_tick;
+    e->action_tick = tick;
 }
 
 /* get_transformed_image, :523-618 (only "shift" does anything upstream; square RGB images) */
@@ -927,7 +954,8 @@ void ora_p_reset(ora_post *e, const uint8_t *img_in, uint8_t *img_out) {
 }
 
 int ora_p_action(ora_post *e, int action) {
-    if (e->philox) np_philox_init(&e->rng, e->ph_seed, e->ph_env, e->tick, 6);
+    /* (Philox streams: keyed by the number of action calls, so that K calls before one fused K-step call differ) */
+    if (e->philox) { np_philox_init(&e->rng, e->ph_seed, e->ph_env, e->action_tick, 6); e->action_tick += 1; }
     if (e->continuous || !e->noise_cdf) return action;
     return np_choice_cdf(&e->rng, e->noise_cdf + (size_t)action * e->n_actions, e->n_actions);   /* :364 */
 }

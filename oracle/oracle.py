@@ -65,6 +65,7 @@ def lib():
                                     i32, f64, i32, f64, i32, i32, f64, f64, f64, i32, vp, vp])
         L.ora_c_destroy.argtypes = [vp]
         L.ora_c_set_image_quirk.argtypes = [vp, i32]
+        L.ora_c_set_target64.argtypes = [vp]
         L.ora_c_set_line_reward.argtypes = [vp, i32, LINE_FIT_FN]
         L.ora_ig_render.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
         L.ora_ic_render.argtypes = [i32, i32, i32, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp]
@@ -420,6 +421,11 @@ class ContinuousOracle:
     def set_image_quirk(self, on=True):
         """image_representations=True: every step clips and zeroes the derivatives (mdpp_oracle.c C4)."""
         lib().ora_c_set_image_quirk(self.h, int(on))
+
+    def set_target64(self):
+        """No target_point in the config: the reference's float64 zeros of length state_space_dim (:652-654), i.e.
+        float64 distances, target latch and dense reward (mdpp_oracle.c ora_c_set_target64)."""
+        lib().ora_c_set_target64(self.h)
 
     def set_line_reward(self, sequence_length, delay=0):
         """reward_function='move_along_a_line': the float32 mean and the first right-singular vector

@@ -93,6 +93,8 @@ def continuous_oracle_from_golden(name):
     o = ora.ContinuousOracle(**continuous_params(cfg))
     if cfg.get("reward_function") == "move_along_a_line":
         o.set_line_reward(cfg.get("sequence_length", 1), cfg.get("delay", 0))
+    elif "target_point" not in cfg:
+        o.set_target64()
     return o
 
 

@@ -104,6 +104,11 @@ def test_post_fused_steps_vs_oracle_at_scale(kind, rng):
     else:
         post.reset()
     a_env = post.actions(torch.as_tensor(acts, device=dev)).cpu().numpy() if kind != "continuous" else None
+    # a second block of actions before any step: Philox streams key the action noise by the number of
+    # actions() calls, so the second row is not the first row's draw again
+    a_env2 = post.actions(torch.as_tensor(acts, device=dev)).cpu().numpy() if kind != "continuous" else None
+    if kind != "continuous":
+        assert (a_env2 != a_env).any()
     outs = []
     for c in range(2):
         oi = None if base_obs is None else torch.as_tensor(base_obs[c], device=dev)
@@ -122,6 +127,7 @@ def test_post_fused_steps_vs_oracle_at_scale(kind, rng):
             o.reset()
         if kind != "continuous":
             assert o.action(int(acts[i])) == int(a_env[i]), i
+            assert o.action(int(acts[i])) == int(a_env2[i]), i
         for c in range(2):
             for k in range(K):
                 eo, er = o.step(None if base_obs is None else base_obs[c, k, i], base_rew[c, k, i], base_done[c, k, i])
@@ -192,3 +198,35 @@ def test_post_chained_behind_the_vector_env():
         assert np.array_equal(rews[t][1], rews[t - 2][0] * 2.0)
     assert (rews[0][1] == 0).all() and (rews[1][1] == 0).all()
     env.close(); post.close()
+
+
+def test_episode_stats_kernel_equals_the_host_loop():
+    """stats_csv.EpisodeStats on device tensors (mdpp_episode_stats: one kernel over [K, N]) against the same class on
+    host tensors (plain torch ops, step by step): running returns / lengths bit-equal, counts equal, the sums of
+    returns equal up to the order of a float64 summation; float32 env rewards and float64 post-processor rewards,
+    one or two end-flag rows, state carried across calls, a ragged batch."""
+    from mdp_playground_amd.stats_csv import EpisodeStats
+    dev = torch.device("cuda", 0)
+    r = np.random.default_rng(3)
+    for N, K, dt in ((65536, 512, np.float32), (1000, 37, np.float64)):
+        d, h = EpisodeStats(N, dev), EpisodeStats(N, "cpu")
+        for call in range(2):
+            rew = (r.integers(-8, 9, size=(K, N)) / 4.0).astype(dt)
+            term = r.random((K, N)) < 0.03
+            trunc = r.random((K, N)) < 0.01
+            if call == 0:
+                d.update(torch.as_tensor(rew, device=dev), torch.as_tensor(term, device=dev), torch.as_tensor(trunc, device=dev))
+                h.update(torch.as_tensor(rew), torch.as_tensor(term), torch.as_tensor(trunc))
+            else:
+                d.update(torch.as_tensor(rew, device=dev), torch.as_tensor(term | trunc, device=dev).to(torch.uint8))
+                h.update(torch.as_tensor(rew), torch.as_tensor(term | trunc))
+            assert torch.equal(d.ret.cpu(), h.ret) and torch.equal(d.len.cpu(), h.len), (N, call)
+            assert int(d.count.item()) == int(h.count.item()) and int(d.sum_len.item()) == int(h.sum_len.item())
+            assert abs(float(d.sum_ret.item()) - float(h.sum_ret.item())) <= 1e-9 * max(1.0, abs(float(h.sum_ret.item())))
+        td, th = d.pop(), h.pop()
+        assert td[0] == th[0] == 2 * K * N and td[2] == th[2] and abs(td[1] - th[1]) < 1e-9
+    # a single row ([N] tensors), as a step() loop would feed it
+    d = EpisodeStats(256, dev)
+    d.update(torch.ones(256, device=dev), torch.zeros(256, dtype=torch.bool, device=dev))
+    d.update(torch.ones(256, device=dev), torch.ones(256, dtype=torch.bool, device=dev))
+    assert d.pop() == (512, 2.0, 2.0)

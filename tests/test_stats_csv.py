@@ -65,3 +65,21 @@ def test_episode_stats_reductions():
     # finished episodes: env2 (0.5, len 1), env0 (2.0, len 2), env2 (1.0, len 2), env0 (2.0, len 2), env1 (8.0, len 4)
     assert ts == 12 and abs(rmean - (0.5 + 2.0 + 1.0 + 2.0 + 8.0) / 5) < 1e-12 and abs(lmean - 11 / 5) < 1e-12
     assert np.isnan(es.pop()[1])
+
+
+def test_value_formats_per_config_type(tmp_path):
+    """the reference formats a varied value by the config it belongs to (config_processor.py:287-349):
+    env lists "[a,b,]" with "%.2e" floats; agent lists and everything non-float str() without spaces; model values
+    str() without spaces even when they are floats."""
+    assert stats_csv.format_value([0.25, 3], "env") == "[2.50e-01,3,]"
+    assert stats_csv.format_value([256, 256], "agent") == "[256,256]"
+    assert stats_csv.format_value(0.001, "agent") == "1.00e-03"
+    assert stats_csv.format_value([[16, [8, 8], 4], [32, [4, 4], 2]], "model") == "[[16,[8,8],4],[32,[4,4],2]]"
+    assert stats_csv.format_value(0.5, "model") == "0.5"
+    prefix = str(tmp_path / "run")
+    w = stats_csv.StatsWriter(prefix, ["delay", "fcnet_hiddens", "conv_filters"], "DQN",
+                              column_types={"fcnet_hiddens": "agent", "conv_filters": "model"})
+    w.write_train_row(1, {"delay": 2, "fcnet_hiddens": [256, 256], "conv_filters": [[16, [8, 8], 4]]}, 1000, 1.5, 20.0)
+    lines = open(prefix + ".csv").read().splitlines()
+    assert lines[0] == "# training_iteration, algorithm, delay, fcnet_hiddens, conv_filters, timesteps_total, episode_reward_mean, episode_len_mean"
+    assert lines[1] == "1 DQN 2 [256,256] [[16,[8,8],4]] 1000 1.50e+00 2.00e+01"

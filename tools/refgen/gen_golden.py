@@ -208,6 +208,20 @@ CASES = {
                     target_point=[0.0, 0.0], target_radius=0.8, reward_noise=0.1,
                     reward_every_n_steps=2, reward_function="move_to_a_point"),
         seeds=list(range(8)), T=200, reset="mixed"),
+    # --- the DEFAULT target_point (:652-654): float64 zeros of length state_space_dim -- usable when every dimension is
+    # relevant -- which promotes distances, the target latch and a dense reward to float64 (np.float64 throughout)
+    "c_default_target": dict(
+        config=dict(state_space_type="continuous", state_space_dim=4, transition_dynamics_order=2,
+                    inertia=1.0, time_unit=0.5, state_space_max=3, action_space_max=1, make_denser=True,
+                    target_radius=0.6, delay=2, reward_noise=0.1, reward_scale=1.5, reward_shift=-0.25,
+                    term_state_reward=2.0, action_loss_weight=0.05, reward_function="move_to_a_point"),
+        seeds=list(range(4)), T=200, reset="mixed", bad_action_every=31),
+    "c_default_target_sparse": dict(
+        config=dict(state_space_type="continuous", state_space_dim=2, transition_dynamics_order=1,
+                    inertia=1.0, time_unit=1.0, state_space_max=2, action_space_max=1, make_denser=False,
+                    target_radius=0.9, reward_every_n_steps=2, transition_noise=0.05, reward_noise=0.2,
+                    action_loss_weight=0.1, reward_function="move_to_a_point"),
+        seeds=list(range(4)), T=200, reset="mixed"),
     # --- reward_function move_along_a_line: random actions, then the same
     # action repeated (the rewards of a straight walk are LAPACK-rounding-sized) -------------------
     "c_line_4d": dict(       # the env of the reference's test_continuous_dynamics_move_along_a_line
