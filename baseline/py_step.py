@@ -150,7 +150,8 @@ class PyContinuousEnv:
         f32 = np.float32
         self.s_low, self.s_high = np.full(D, -state_space_max, f32), np.full(D, state_space_max, f32)
         self.a_low, self.a_high = np.full(D, -action_space_max, f32), np.full(D, action_space_max, f32)
-        self.target_point = np.array(target_point, dtype=f32)
+        # (no target_point: float64 zeros of length state_space_dim, rl_toy_env.py:652-654)
+        self.target_point = np.zeros(shape=(D,)) if target_point is None else np.array(target_point, dtype=f32)
         self.target_radius, self.make_denser = target_radius, make_denser
         self.action_loss_weight = action_loss_weight
         self.transition_noise, self.reward_noise = transition_noise, reward_noise
@@ -265,7 +266,7 @@ def from_mdp(m, env_rng, space_rng, space_irr_rng=None):
     if m.kind == "continuous" and m.reward_function == "move_to_a_point":
         return PyContinuousEnv(m.D, m.relevant_indices, order=m.order, inertia=m.inertia, time_unit=m.time_unit,
                                state_space_max=m.state_space_max, action_space_max=m.action_space_max,
-                               target_point=m.target_point, target_radius=m.target_radius,
+                               target_point=None if m.target_default else m.target_point, target_radius=m.target_radius,
                                make_denser=m.make_denser, action_loss_weight=m.action_loss_weight,
                                transition_noise=m.transition_noise, reward_noise=m.reward_noise, delay=m.delay,
                                reward_every_n_steps=m.reward_every_n_steps, reward_scale=m.reward_scale,

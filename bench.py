@@ -332,8 +332,15 @@ def init_collective(device, world, no_collective):
         return None, "disabled (--no-collective)"
     import torch.distributed as dist
     try:
+        # the collectives' stream at high priority: its hardware queue is then not one the launch stream can share
+        # (streams of one priority are spread over a few hardware queues; a shared queue serialises gather and launch)
+        opts = None
+        try:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:
+            pass
         if "RANK" in os.environ:
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, pg_options=opts)
         else:
             if world != 1:
                 raise RuntimeError("no launcher")
@@ -343,7 +350,7 @@ def init_collective(device, world, no_collective):
                 port = sk.getsockname()[1]
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                    device_id=device)
+                                    device_id=device, pg_options=opts)
         return dist, None
     except Exception as e:              # a one-rank run still has its `none` leg
         if world > 1:
@@ -414,7 +421,6 @@ def main():
     # the gather of launch k - 2, which slips in between two launches (a rollout holds every CU)
     outs = [env.alloc_rollout(F) for _ in range(4 if dist is not None else 2)]
     NB = len(outs)
-    comm = torch.cuda.Stream(device=device) if dist is not None else None
 
     def barrier():
         if dist is not None:
@@ -425,28 +431,24 @@ def main():
     host_enqueue = [0.0]
 
     def run(steps, gathers, rotate=True):
-        """`steps` fused launches; with `gathers`, each launch is followed by ONE all-gather (on the comm
-        stream, overlapping the next launch) of the tensor gathers[j] was built on."""
-        cur = torch.cuda.current_stream(device)
-        ev_done = [None] * NB
+        """`steps` fused launches; with `gathers`, each launch is followed by ONE all-gather of the tensor gathers[j]
+        was built on, started asynchronously (ObsGatherer.start): the backend's stream waits for the launch that fills
+        it and runs the collective beside the next launch; nothing is inserted into the launch stream."""
+        works = [None] * NB
         for it in range(steps):
             j = it % NB
             # the gather that read this buffer NB launches ago: asked on the host first -- when it has completed
             # (the usual case) no wait goes into the launch stream, and launches stay back to back
-            if gathers is not None and ev_done[j] is not None and not ev_done[j].query():
-                cur.wait_event(ev_done[j])
+            if gathers is not None and works[j] is not None and not works[j].is_completed():
+                works[j].wait()
             env.rollout(acts[launched[0] % NA] if rotate else acts[0], outs[j])
             launched[0] += 1
             if gathers is not None:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(ev)
-                    gathers[j]()
-                    ev_done[j] = torch.cuda.Event()
-                    ev_done[j].record(comm)
+                works[j] = gathers[j].start()
         if gathers is not None:
-            cur.wait_stream(comm)
+            for w in works:
+                if w is not None:
+                    w.wait()                        # (the current stream waits for the collective's stream)
 
     def timed(steps, gathers, events=False, rotate=True):
         """EXACTLY `steps` launches between barrier + synchronize on both sides; max over ranks."""
@@ -487,8 +489,8 @@ def main():
                             "host_enqueue_s": host_enqueue[0],
                             "bytes_per_rank_per_launch": g_last[0].local.numel() * g_last[0].local.element_size()}
         elapsed = el_last
-        collective = ("all_gather_into_tensor (RCCL, %d rank%s) of the current observation shard after every launch, "
-                      "overlapped on a side stream" % (dist.get_world_size(), "" if world == 1 else "s"))
+        collective = ("all_gather_into_tensor (RCCL, %d rank%s, async_op) of the current observation shard after every "
+                      "launch, on the backend's high-priority stream beside the next launch" % (dist.get_world_size(), "" if world == 1 else "s"))
         del g_last
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 5
+#define MDPP_ABI_VERSION 6
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
@@ -163,6 +163,11 @@ typedef struct {
     int32_t img_r_min, img_r_max; /* radii that can occur (scale transform), templates cover [r_min, r_max] */
     double img_log_min_r, img_log_max_r;
     int32_t img_tpl_size;       /* templates are (2*tpl_half+1)^2 bitmaps */
+
+    /* ---- ABI 6 ---- */
+    int32_t target_f64;         /* continuous, move_to_a_point, no "target_point" in the config: the reference's default,
+                                   np.zeros(shape=(state_space_dim,)) -- float64, every dimension relevant
+                                   (rl_toy_env.py:652-654): distances, the target latch and a dense reward are float64 */
 } mdpp_config;
 
 /* Lifetime */

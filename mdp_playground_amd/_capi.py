@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 5
+MDPP_ABI_VERSION = 6
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
 REWARD_SEQUENCES, REWARD_STATE_ACTION = 0, 1
@@ -62,6 +62,7 @@ class MdppConfig(C.Structure):
         ("img_has_flip", C.c_int32), ("img_sh_quant", C.c_int32), ("img_ro_quant", C.c_int32),
         ("img_r0", C.c_int32), ("img_r_min", C.c_int32), ("img_r_max", C.c_int32),
         ("img_log_min_r", C.c_double), ("img_log_max_r", C.c_double), ("img_tpl_size", C.c_int32),
+        ("target_f64", C.c_int32),
     ]
 
 

@@ -257,10 +257,17 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         const size_t D = (size_t)cfg->D;
-        if (line) {
-            TRY(alloc_zero(h, &h->d_line_hist, (size_t)cfg->L * 4 * N * sizeof(float)));
-            if (cfg->delay > 0) TRY(alloc_zero(h, &h->d_ring64, (size_t)cfg->delay * N * sizeof(double)));
+        if (cfg->target_f64) {      // (ddot's summation order is the sequential one below 16 elements only)
+            bool all_rel = !line && cfg->n_rel == cfg->D && cfg->D < 16;
+            for (int j = 0; all_rel && j < cfg->n_rel; j++) all_rel = cfg->rel_idx[j] == j && cfg->target[j] == 0.0f;
+            if (!all_rel) {
+                g_create_err = "mdpp_create: target_f64 (the default target_point) needs move_to_a_point, every dimension relevant, state_space_dim < 16";
+                free_all(h); delete h; return MDPP_EUNSUPPORTED;
+            }
         }
+        const bool rew64 = line || (cfg->target_f64 && cfg->make_denser);
+        if (line) TRY(alloc_zero(h, &h->d_line_hist, (size_t)cfg->L * 4 * N * sizeof(float)));
+        if (rew64 && cfg->delay > 0) TRY(alloc_zero(h, &h->d_ring64, (size_t)cfg->delay * N * sizeof(double)));
         TRY(alloc_zero(h, &h->d_sd, (size_t)(cfg->order + 1) * D * N * sizeof(float)));
         TRY(alloc_zero(h, &h->d_cur, D * N * sizeof(float)));
         TRY(alloc_zero(h, &h->d_meta, N * sizeof(uint2)));
@@ -314,7 +321,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             // (next-step autoreset: without noise or with Philox streams -- numpy noise streams are drawn ahead per step)
             const bool next_ok = cfg->autoreset != MDPP_AUTORESET_NEXT_STEP || cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 ||
                                  (!cfg->has_transition_noise && !cfg->has_reward_noise);
-            a.fast_ok = (a.rel_prefix && !cfg->image && !line && next_ok &&
+            a.fast_ok = (a.rel_prefix && !cfg->image && !line && !cfg->target_f64 && next_ok &&
                          (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
         }
@@ -325,6 +332,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
         a.line_L = line ? cfg->L : 0; a.line_hist = (float *)h->d_line_hist; a.ring64 = (double *)h->d_ring64;
+        a.target64 = cfg->target_f64 ? 1 : 0; a.rew64 = rew64 ? 1 : 0; a.radius = cfg->target_radius;
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
@@ -1090,7 +1098,7 @@ extern "C" int mdpp_get_state_continuous(mdpp_env *h, float *derivs, float *cur,
             if (reached) reached[i] = (uint8_t)(me[2 * i + 1] & 1u);
         }
     }
-    if (ring && d > 0 && h->cargs.line_L) {          // move_along_a_line: a float64 delay line
+    if (ring && d > 0 && h->cargs.rew64) {           // move_along_a_line / the default float64 target: a float64 delay line
         std::vector<double> rg((size_t)d * N);
         HIPCHK(h, hipMemcpy(rg.data(), h->d_ring64, rg.size() * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < N; i++)
@@ -1134,7 +1142,12 @@ extern "C" int mdpp_set_state_continuous(mdpp_env *h, const float *derivs, const
     HIPCHK(h, hipMemcpy(h->d_sd, sd.data(), sd.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_cur, cu.data(), cu.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_meta, me.data(), N * 8, hipMemcpyHostToDevice));
-    if (ring && d > 0) {
+    if (ring && d > 0 && h->cargs.rew64) {          // the default float64 target with a dense reward: a float64 delay line
+        std::vector<double> rg((size_t)d * N);
+        for (size_t i = 0; i < N; i++)
+            for (int j = 0; j < d; j++) rg[(size_t)((h->tick + j) % d) * N + i] = ring[i * d + j];
+        HIPCHK(h, hipMemcpy(h->d_ring64, rg.data(), rg.size() * 8, hipMemcpyHostToDevice));
+    } else if (ring && d > 0) {
         std::vector<uint32_t> rg((size_t)d * N);
         for (size_t i = 0; i < N; i++)
             for (int j = 0; j < d; j++) {

@@ -42,6 +42,22 @@ __device__ __forceinline__ float c_norm_rel(const ContinuousArgs &a, const float
     return sqrtf((float)acc);
 }
 
+// The default target (float64 zeros over every dimension, :652-654): np.linalg.norm(float32 state - float64 zeros) is
+// sqrt(x.dot(x)) in float64 -- cblas_ddot, whose scalar tail sums sequentially below 16 elements; every product of two
+// float32-valued doubles is exact, so no fused multiply-add can change a bit (n_rel == D here).
+template <int DMAX>
+__device__ __forceinline__ double c_norm64(const ContinuousArgs &a, const float (&s)[DMAX]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < DMAX; j++) {
+        if (j < a.n_rel) {
+            const double d = (double)s[j] - 0.0;
+            acc += d * d;
+        }
+    }
+    return sqrt(acc);
+}
+
 template <int DMAX>
 __device__ __forceinline__ bool c_in_box(const ContinuousArgs &a, const float (&rel)[DMAX]) {
     bool any = false;
@@ -83,12 +99,18 @@ __device__ __forceinline__ void c_gather_rel(const ContinuousArgs &a, const floa
 // ---- reward_function move_along_a_line (:1864-1910, dist_of_pt_from_line :2546-2576) -------------
 // The last L states' relevant coordinates live in HBM, line_hist[(slot * 4 + j) * N + env] with
 // slot = s % L for the state reached after s transitions of the episode (s = 0: reset()).
+// `lds_line` (rollouts with L <= 16, round 3): the lane's L points mirrored in LDS for the launch, float4 [slot][lane];
+// the HBM copy stays the truth between launches (write-through), the per-step fit reads LDS instead of making 64 L2
+// round trips per step.
 template <int DMAX>
-__device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint32_t s, const float (&rel)[DMAX]) {
+__device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint32_t s, const float (&rel)[DMAX],
+                                           float4 *lds_line = nullptr) {
     const uint32_t slot = s % (uint32_t)a.line_L;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        if (j < DMAX && j < a.n_rel) a.line_hist[((size_t)slot * 4 + j) * a.N + i] = rel[j < DMAX ? j : 0];
+        if (j < DMAX && j < a.n_rel) { v[j] = rel[j < DMAX ? j : 0]; a.line_hist[((size_t)slot * 4 + j) * a.N + i] = v[j]; }
+    if (lds_line) lds_line[slot * kBlock + threadIdx.x] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // Reward after `steps` (>= L) transitions: minus the mean float64 distance of the L newest states from
@@ -98,7 +120,7 @@ __device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint
 // LAPACK's output.  The two agree to float32 rounding divided by the gap between the two largest
 // singular values, which is the accuracy the reference's own reward has.
 template <bool CACHED>
-__device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i, uint32_t steps) {
+__device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i, uint32_t steps, const float4 *lds_line = nullptr) {
     const int L = a.line_L, n = a.n_rel;
     const size_t N = (size_t)a.N;
     // slot of the oldest of the L newest states; walked with a wrap instead of a modulo per point
@@ -117,8 +139,13 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
     if (CACHED) {
 #pragma unroll
         for (int k = 0; k < kCache; k++) {
+            if (lds_line) {                                  // (wave-uniform) one ds_read_b128 per point
+                const float4 q = lds_line[slot * kBlock + threadIdx.x];
+                px[k][0] = q.x; px[k][1] = q.y; px[k][2] = q.z; px[k][3] = q.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) px[k][j] = (j < n) ? a.line_hist[((size_t)slot * 4 + j) * N + i] : 0.0f;
+                for (int j = 0; j < 4; j++) px[k][j] = (j < n) ? a.line_hist[((size_t)slot * 4 + j) * N + i] : 0.0f;
+            }
             const uint32_t nx = (slot + 1u == (uint32_t)L) ? 0u : slot + 1u;
             slot = (k + 1 < L) ? nx : slot;
         }
@@ -228,7 +255,9 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
                     sq[p][q] = acc;
                 }
             const double tr2 = sq[0][0] + sq[1][1] + sq[2][2] + sq[3][3];
-            const bool conv = (tr * tr - tr2) <= 2e-15 * tr * tr;
+            // (tr^2 - tr2 = 2 sum_{i<j} mu_i mu_j ~ 2 mu_1 mu_2: the relative weight of everything but the dominant
+            //  direction; the vector is rounded to float32 below, 1e-12 is five digits beyond that)
+            const bool conv = (tr * tr - tr2) <= 2e-12 * tr * tr;
             sc = pow2_inv(tr2);
 #pragma unroll
             for (int p = 0; p < 4; p++)
@@ -260,7 +289,12 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
     double nab = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; j++) if (j < n) nab = fma(ab[j], ab[j], nab);    // np.dot: a chain of FMAs
-    nab = sqrt(nab);
+    // dist_of_pt_from_line (:2546-2576): proj = dot / |ab|, dist = sqrt(|ap|^2 - proj^2), with |ap| taken as
+    // sqrt(dot(ap, ap)) and squared again there.  Here |ap|^2 is the dot product itself and dot^2 / |ab|^2 uses one
+    // reciprocal per step: one square root per point instead of two and a division -- a difference of an ulp or two of
+    // float64 in a reward that is defined to ~1e-7 by its float32 singular vector (tests: LINE_ATOL).
+    const bool degenerate = sqrt(nab) < 1e-13;
+    const double inv_nab2 = 1.0 / nab;
     auto dist_of = [&](const float (&y)[4]) __attribute__((always_inline)) -> double {
         double dot = 0.0, nap = 0.0;
 #pragma unroll
@@ -271,14 +305,9 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
                 nap = fma(ap, ap, nap);
             }
         }
-        double dist = 0.0;
-        if (!(nab < 1e-13)) {
-            const double proj = dot / nab, na = sqrt(nap);
-            double sq = na * na - proj * proj;
-            sq = sq < 0.0 ? 0.0 : sq;
-            dist = sqrt(sq);
-        }
-        return dist;
+        double sq = nap - (dot * dot) * inv_nab2;
+        sq = sq < 0.0 ? 0.0 : sq;
+        return degenerate ? 0.0 : sqrt(sq);
     };
     double total = 0.0;
     if (CACHED) {
@@ -330,6 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     __shared__ double s_z[DMAX * kBlock];                    // this step's transition-noise normals, [d][lane]
+    extern __shared__ __align__(16) float4 s_line[];         // move_along_a_line, L <= 16: [L][lane] (launch_step_t sizes it)
     const bool any_noise = a.has_p_noise || a.has_r_noise;   // wave-uniform
     if (any_noise) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
     const ZigLds zig{s_ki, s_wi, s_fi};
@@ -353,6 +383,16 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     bool pending = next_step && (flags & 2u) != 0;
     flags &= ~2u;
 
+    float4 *lds_line = nullptr;
+    if (a.line_L && a.line_lds) {                            // this lane's L points: HBM -> LDS once per launch
+        lds_line = s_line;
+        for (int sl = 0; sl < a.line_L; sl++) {
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = (j < a.n_rel) ? a.line_hist[((size_t)sl * 4 + j) * N + i] : 0.0f;
+            s_line[sl * kBlock + threadIdx.x] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+    }
     Pcg64 env_pcg, sp_pcg;
     Philox env_phx, sp_phx;
     bool sp_loaded = false;
@@ -397,7 +437,9 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         steps = 0; flags = 0;
         if (a.line_L) {
             c_gather_rel<DMAX>(a, cur, rel);
-            c_line_put<DMAX>(a, i, 0u, rel);
+            c_line_put<DMAX>(a, i, 0u, rel, lds_line);
+        }
+        if (a.rew64) {
             for (int dd = 0; dd < a.delay; dd++) a.ring64[(size_t)dd * N + i] = 0.0;
         } else {
             for (int dd = 0; dd < a.delay; dd++) a.ring[(size_t)dd * N + i] = kRingPyZero;
@@ -512,38 +554,45 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
         }
         // ---- C5 (the target latch exists for move_to_a_point only)
         c_gather_rel<DMAX>(a, nxt, rel);
-        const float dist_new = a.line_L ? 0.0f : c_norm_rel<DMAX>(a, rel, tgt);
-        if (!a.line_L && dist_new < a.radius32) flags |= 1u;
+        const float dist_new = (a.line_L || a.target64) ? 0.0f : c_norm_rel<DMAX>(a, rel, tgt);
+        const double dist_new64 = a.target64 ? c_norm64<DMAX>(a, rel) : 0.0;
+        const bool within = a.target64 ? (dist_new64 < a.radius) : (dist_new < a.radius32);
+        if (!a.line_L && within) flags |= 1u;
         const bool in_box = (a.n_boxes > 0) && c_in_box<DMAX>(a, rel);
         steps += 1;
         // ---- C6
         CRew r;
         if (a.line_L) {
             // gate (:1856): the state sequence_length transitions back must exist
-            c_line_put<DMAX>(a, i, steps, rel);
+            c_line_put<DMAX>(a, i, steps, rel, lds_line);
             r.v = 0.0;
             if (steps >= (uint32_t)a.line_L)
-                r.v = a.line_L <= 16 ? c_line_reward<true>(a, i, steps) : c_line_reward<false>(a, i, steps);
+                r.v = a.line_L <= 16 ? c_line_reward<true>(a, i, steps, lds_line) : c_line_reward<false>(a, i, steps);
             r.is32 = false;
+        } else if (a.make_denser && a.target64) {
+            float relo[DMAX];
+            c_gather_rel<DMAX>(a, cur, relo);
+            r.v = -dist_new64;                            // np.float64 (:1926)
+            r.v = r.v + c_norm64<DMAX>(a, relo);          // :1929
         } else if (a.make_denser) {
             float relo[DMAX];
             c_gather_rel<DMAX>(a, cur, relo);
             const float dist_old = c_norm_rel<DMAX>(a, relo, tgt);
             r.v = (double)(float)(-dist_new + dist_old);
         } else {
-            r.v = (dist_new < a.radius32) ? 1.0 : 0.0;
+            r.v = within ? 1.0 : 0.0;
         }
         if (!a.line_L) {
             double acc = 0.0;
 #pragma unroll
             for (int d = 0; d < DMAX; d++)
                 if (d < D) { float p = act[d] * act[d]; acc += (double)p; }
-            float pen = a.alw32 * sqrtf((float)acc);
-            r.v = (double)((float)r.v - pen);
-            r.is32 = true;
+            float pen = a.alw32 * sqrtf((float)acc);      // Python float * np.float32 -> np.float32
+            if (a.rew64) { r.v = r.v - (double)pen; r.is32 = false; }      // np.float64 - np.float32
+            else { r.v = (double)((float)r.v - pen); r.is32 = true; }
         }
         // ---- C7
-        if (a.delay > 0 && a.line_L) {
+        if (a.delay > 0 && a.rew64) {
             double *slot = a.ring64 + (size_t)(tick % (uint32_t)a.delay) * N + i;
             const double out = *slot;
             *slot = r.v;
@@ -644,6 +693,8 @@ __global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, u
         float rel[DMAX];
         c_gather_rel<DMAX>(a, cur, rel);
         c_line_put<DMAX>(a, i, 0u, rel);
+    }
+    if (a.rew64) {
         for (int dd = 0; dd < a.delay; dd++) a.ring64[(size_t)dd * N + i] = 0.0;
         if (status) atomicOr(&a.status[i], status);
         return;
@@ -662,12 +713,21 @@ static void launch_step_t(const ContinuousArgs &a, int K, const float *actions, 
         snprintf(name_out, kNameLen, "k_continuous_step<DMAX=%d,OMAX=%d,PHILOX=%d>", DMAX, OMAX, a.philox != 0);
         return;
     }
-    if (a.philox)
-        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, true>), dim3(grid), dim3(kBlock), 0, s, a,
+    // move_along_a_line with L <= 16, rollouts: the L points of every lane mirrored in (dynamic) LDS for the launch
+    ContinuousArgs al = a;
+    al.line_lds = (a.line_L > 0 && a.line_L <= 16 && K >= 4) ? 1 : 0;
+    const size_t lds = al.line_lds ? (size_t)a.line_L * kBlock * sizeof(float4) : 0;
+    if (a.philox) {
+        if (lds > 32 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, true>), dim3(grid), dim3(kBlock), lds, s, al,
                            K, actions, obs, reward, term, trunc, final_obs);
-    else
-        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, false>), dim3(grid), dim3(kBlock), 0, s, a,
+    } else {
+        if (lds > 32 * 1024)
+            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, false>), dim3(grid), dim3(kBlock), lds, s, al,
                            K, actions, obs, reward, term, trunc, final_obs);
+    }
 }
 template <int DMAX, int OMAX>
 static void launch_reset_t(const ContinuousArgs &a, uint64_t reset_tick, const uint8_t *mask,

@@ -109,8 +109,13 @@ struct ContinuousArgs {
     // relevant coordinates [slot = s % line_L][4][N] (s = transitions made when the state was
     // reached), and a float64 delay line (these rewards are Python floats)
     int32_t line_L;
+    int32_t line_lds;           // this launch mirrors the L points of every lane in dynamic LDS (set by launch_step_t)
     float *line_hist;
     double *ring64;             // [delay][N]
+    // the reference's DEFAULT target_point, float64 zeros over every dimension (:652-654): float64 distances, target
+    // latch and dense reward; rew64 = the reward is float64 throughout (line reward, or default target + make_denser)
+    int32_t target64, rew64;
+    double radius;
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
     uint32_t *status;
     // ---- precomputed on the host for the fused fast path (mdpp_continuous_fast.hip) ----

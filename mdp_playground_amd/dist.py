@@ -45,6 +45,17 @@ class ObsGatherer:
         self.dist.all_gather_into_tensor(self._flat, self.local, group=self.group)
         return self.out
 
+    def start(self):
+        """The same gather, asynchronous with respect to the CURRENT stream: the backend's own stream waits for what
+        the current stream has enqueued so far (the rollout that fills `local`) and runs the collective beside
+        whatever the current stream does next; nothing is put back into the current stream.  Returns the Work handle
+        (`.is_completed()`, `.wait()`; `self.out` holds the result once it is done), or None when no backend is
+        involved (the copy then runs on the current stream)."""
+        if self.dist is None or (self.world == 1 and not self.always_collective):
+            self.out[0].copy_(self.local)
+            return None
+        return self.dist.all_gather_into_tensor(self._flat, self.local, group=self.group, async_op=True)
+
 
 class ShardedVectorEnv:
     """Convenience wrapper: builds this rank's shard of a `total_envs` job and returns globally

@@ -142,6 +142,7 @@ class ContinuousMDP(CommonParams):
     state_space_max: float = np.inf
     action_space_max: float = np.inf
     target_point: np.ndarray = None          # float32 [n_rel]
+    target_default: bool = False             # no target_point in the config: float64 zeros (:652-654), float64 reward path
     target_radius: float = 0.05
     make_denser: bool = True
     action_loss_weight: float = 0.0
@@ -475,9 +476,25 @@ def build_continuous(config) -> ContinuousMDP:
         _require(target.shape == (len(rel),),
                  "target_point should have dimensionality = relevant_state_space dimensionality")
     else:
-        # The reference falls back to float64 zeros of length state_space_dim (:654), which
-        # silently promotes the reward arithmetic to float64; require the explicit form instead.
-        raise NotImplementedError("please pass target_point explicitly (float32 semantics)")
+        # The reference's default (:652-654): np.zeros(shape=(state_space_dim,)) -- FLOAT64 and of the full state
+        # dimension.  `state[relevant_indices] - target_point` then only broadcasts when every dimension is relevant
+        # (the reference raises ValueError at its first step otherwise), and it is a float64 vector: distances, the
+        # target latch and a dense reward are float64 (ContinuousMDP.target_default; kernels: target64).
+        if len(rel) != D and len(rel) != 1:
+            raise ValueError("operands could not be broadcast together: the default target_point has state_space_dim = "
+                             f"{D} entries, the relevant state {len(rel)} (pass target_point)")
+        if len(rel) == 1 and D != 1:
+            raise NotImplementedError("default target_point with one relevant dimension of several (the reference "
+                                      "broadcasts it against all state_space_dim zeros): pass target_point")
+        if D >= 16:
+            raise NotImplementedError("default (float64) target_point: state_space_dim < 16 on the device "
+                                      "(numpy's float64 dot changes its summation order from 16 elements on)")
+        if image is not None:
+            raise NotImplementedError("default target_point with image observations: pass target_point")
+        target = np.zeros(len(rel), dtype=np.float32)
+        target_default = True
+    if not (not line and "target_point" not in config):
+        target_default = False
     tn = config.get("transition_noise", None)
     if callable(tn):
         raise NotImplementedError("callable transition_noise runs on the host only")
@@ -499,7 +516,7 @@ def build_continuous(config) -> ContinuousMDP:
         time_unit=config.get("time_unit", 1.0),
         state_space_max=config.get("state_space_max", np.inf),
         action_space_max=config.get("action_space_max", np.inf),
-        target_point=target, target_radius=config.get("target_radius", 0.05),
+        target_point=target, target_default=target_default, target_radius=config.get("target_radius", 0.05),
         make_denser=config.get("make_denser", True),
         action_loss_weight=config.get("action_loss_weight", 0.0),
         transition_noise=None if tn is None else float(tn), box_lo=box_lo, box_hi=box_hi, image=image,

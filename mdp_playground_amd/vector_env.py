@@ -270,6 +270,7 @@ class RLToyVectorEnv:
             cfg.rel_idx[j] = int(r)
             cfg.target[j] = float(m.target_point[j])
         cfg.make_denser = int(bool(m.make_denser))
+        cfg.target_f64 = int(bool(m.target_default))      # the default target_point: float64 zeros (:652-654)
         cfg.has_p_noise = int(m.transition_noise is not None)
         cfg.p_noise = float(m.transition_noise or 0.0)
         cfg.inertia, cfg.time_unit = float(m.inertia), float(m.time_unit)

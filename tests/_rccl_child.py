@@ -72,6 +72,13 @@ assert t.item() == 1.5
 loc = torch.arange(12, dtype=torch.float32, device=dev).view(3, 4)
 gth = ObsGatherer(loc, 1, dist, always_collective=True)
 assert torch.equal(gth().flatten(0, 1), loc)
+# the asynchronous form bench.py uses: the backend's stream runs the gather beside the caller's next launch
+loc.mul_(2.0)
+w = gth.start()
+assert w is not None
+w.wait()
+torch.cuda.synchronize()
+assert w.is_completed() and torch.equal(gth.out.flatten(0, 1), loc)
 torch.cuda.synchronize()
 dist.barrier()
 dist.destroy_process_group()

@@ -38,6 +38,10 @@ def _worker(rank, world, port, total, ret):
     # single-step layout: [N_local, D] -> [N_global, D]
     g1 = ObsGatherer(local[0].contiguous(), world, dist)
     ok = ok and torch.equal(g1().flatten(0, 1), (torch.arange(total, dtype=torch.float32) * 1000)[:, None].expand(total, D))
+    # the asynchronous form (ObsGatherer.start -> Work): what bench.py's collective leg uses
+    w = g1.start()
+    w.wait()
+    ok = ok and torch.equal(g1.out.flatten(0, 1), (torch.arange(total, dtype=torch.float32) * 1000)[:, None].expand(total, D))
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -112,6 +112,8 @@ def _oracle_for(env, i):
                                  m.reward_scale, m.reward_shift, m.term_state_reward, m.box_lo, m.box_hi)
         if m.reward_function == "move_along_a_line":
             o.set_line_reward(m.sequence_length, m.delay)
+        elif m.target_default:
+            o.set_target64()
     return o
 
 
@@ -579,6 +581,61 @@ def test_continuous_fused_rollout_vs_reference_golden(name):
     assert np.array_equal(term.cpu().numpy().T, g["done"])
     assert _rewards_match(name, rew.cpu().numpy().T, g["reward"].astype(np.float32))
     env.close()
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+@pytest.mark.parametrize("dense", [True, False])
+def test_default_target_point_2048_envs_vs_oracle(rng, dense):
+    """No target_point in the config: the reference's float64 zeros over every dimension
+    (rl_toy_env.py:652-654) -- float64 distances, target latch and (dense) float64 reward through the delay line,
+    noise and the affine map; a sparse reward turns np.float32 at the action penalty.  Fused rollout with same-step
+    autoreset, then single steps, every 7th env against the oracle: states bit-exact, rewards equal as float32,
+    a get/set_augmented_state round trip of the float64 delay line."""
+    cfg = dict(gu.CASES["c_default_target" if dense else "c_default_target_sparse"]["config"], seed=12)
+    cfg.update(delay=3, target_radius=1.2)
+    N, T, T1 = 2048, 50, 5
+    kw = dict(rng="philox", philox_seed=23) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=17, **kw, **cfg)
+    assert env.mdps[0].target_default and "rollout" not in env.rollout_kernel_name(T)      # the general kernel
+    D = cfg["state_space_dim"]
+    acts = np.random.default_rng(4).uniform(-1, 1, size=(T + T1, N, D)).astype(np.float32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts[:T], device=env.device)))
+    st = env.get_augmented_state()
+    assert st["reward_buffer"].shape == (N, 3) and not st["reward_buffer_is32"].any() if dense else True
+    twin = _venv(num_envs=N, autoreset="same_step", max_episode_steps=17, **kw, **cfg)
+    twin._lib.mdpp_tick(twin._h, T, None)                 # the step counter first: Philox keys, and the head of the delay line
+    twin.set_augmented_state(st)
+    if rng == "numpy":
+        for s_ in (0, 1):
+            twin._put_stream(s_, env.get_rng_streams(s_))
+    tail = []
+    for t in range(T, T + T1):
+        a = torch.as_tensor(acts[t], device=env.device)
+        o1, r1, d1, tr1, _ = env.step(a)
+        o2, r2, d2, tr2, _ = twin.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), t
+        tail.append((o1.cpu().numpy().copy(), r1.cpu().numpy().copy(), d1.cpu().numpy().copy()))
+    assert term.any() and trunc.any()
+    for i in range(0, N, 7):
+        o = _oracle_for(env, i)
+        if rng == "philox":
+            o.set_philox(23, i)
+        else:
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert np.array_equal(o.reset(), init[i])
+        n = 0
+        for t in range(T + T1):
+            eo, er, _, ed = o.step(acts[t, i])
+            n += 1
+            etr = n >= 17
+            if ed or etr:
+                eo = o.reset(explicit=False)
+                n = 0
+            go, gr, gd = (obs[t, i], rew[t, i], term[t, i]) if t < T else (tail[t - T][0][i], tail[t - T][1][i], tail[t - T][2][i])
+            assert np.array_equal(np.asarray(eo).view(np.uint32), go.view(np.uint32)), (i, t)
+            assert np.float32(er) == gr and bool(ed) == bool(gd), (i, t, er, gr)
+    env.close(); twin.close()
 
 
 @pytest.mark.parametrize("rng", ["numpy", "philox"])

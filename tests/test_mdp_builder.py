@@ -75,3 +75,20 @@ def test_error_behaviour_matches_reference():
                        "sequence_length": 0, "seed": 0})
     with pytest.raises(AssertionError):
         mdp.build_mdp({"state_space_type": "discrete", "action_space_size": [8, 8], "seed": 0})
+
+
+def test_default_target_point_follows_the_reference():
+    """No target_point: float64 zeros of length state_space_dim (rl_toy_env.py:652-654) -- taken (target_default) when
+    every dimension is relevant; with fewer relevant dimensions the reference cannot broadcast `state[rel] - target`
+    and raises ValueError at its first step: raised at construction here."""
+    import pytest
+    from mdp_playground_amd import mdp
+    base = dict(state_space_type="continuous", state_space_dim=4, state_space_max=3, action_space_max=1,
+                reward_function="move_to_a_point", seed=0)
+    m = mdp.build_mdp(base)
+    assert m.target_default and m.relevant_indices == [0, 1, 2, 3] and not np.any(m.target_point)
+    assert not mdp.build_mdp(dict(base, target_point=[0, 0, 0, 0])).target_default
+    with pytest.raises(ValueError):
+        mdp.build_mdp(dict(base, irrelevant_features=True, relevant_indices=[0, 1]))
+    with pytest.raises(NotImplementedError):
+        mdp.build_mdp(dict(base, state_space_dim=16))

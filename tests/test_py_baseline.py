@@ -53,7 +53,8 @@ def test_py_continuous_matches_reference_goldens(name):
         env = py_step.PyContinuousEnv(
             p["D"], p["relevant_indices"], order=p["order"], inertia=p["inertia"], time_unit=p["time_unit"],
             state_space_max=p["state_space_max"], action_space_max=p["action_space_max"],
-            target_point=p["target_point"], target_radius=p["target_radius"], make_denser=p["make_denser"],
+            target_point=p["target_point"] if "target_point" in gu.CASES[name]["config"] else None,
+            target_radius=p["target_radius"], make_denser=p["make_denser"],
             action_loss_weight=p["action_loss_weight"], transition_noise=p["transition_noise"],
             reward_noise=p["reward_noise"], delay=p["delay"], reward_every_n_steps=p["every_n"],
             reward_scale=p["reward_scale"], reward_shift=p["reward_shift"], term_state_reward=p["term_state_reward"],

@@ -59,6 +59,36 @@ __global__ void k_full(const int32_t *act, uint64_t *obs, float *rew, uint8_t *t
     }
 }
 
+// round 3: the same pattern with non-temporal stores (what the rollout kernels use) -- NT -- and, in main(), with the
+// launches cycling through four action tensors (537 MB > the 256 MiB Infinity Cache: reads come from HBM)
+template <int PRE, bool NT>
+__global__ void k_full2(const int32_t *act, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = (uint32_t)i;
+    int pre[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; u++) pre[u] = act[(size_t)u * N + i];
+    for (int k0 = 0; k0 < K; k0 += PRE) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) {
+            const int k = k0 + u;
+            const size_t o = (size_t)k * N + i;
+            const int a = pre[u];
+            const int kn = k + PRE < K ? k + PRE : K - 1;
+            pre[u] = act[(size_t)kn * N + i];
+            s = s * 1664525u + 1013904223u + (uint32_t)a;
+            if (NT) {
+                __builtin_nontemporal_store((uint64_t)(s & 7u), obs + o);
+                __builtin_nontemporal_store((float)(s >> 31), rew + o);
+                __builtin_nontemporal_store((uint8_t)((s >> 8) & 1u), term + o);
+                __builtin_nontemporal_store((uint8_t)((s >> 9) & 1u), trunc + o);
+            } else {
+                obs[o] = s & 7u; rew[o] = (float)(s >> 31); term[o] = (uint8_t)((s >> 8) & 1u); trunc[o] = (uint8_t)((s >> 9) & 1u);
+            }
+        }
+    }
+}
+
 template <int MODE>
 void run(const char *name, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, double bytes_per) {
     const int N = 65536, K = 512, reps = 10;
@@ -94,6 +124,33 @@ int main() {
         }
         printf("%-46s %5.1f B/env-step %8.1f GB/s  %7.1f us per 512-step launch\n", "actions (8 ahead) + all four outputs", 18.0,
                18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
+    }
+    {
+        const int N = 65536, K = 512, reps = 12, NA = 4;
+        int32_t *acts[NA];
+        for (int q = 0; q < NA; q++) { hipMalloc(&acts[q], n * 4); hipMemset(acts[q], 1 + q, n * 4); }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int variant = 0; variant < 6; variant++) {
+            const bool nt = variant & 1, rot = variant >= 2;
+            const int pre = variant >= 4 ? 16 : 8;
+            float ms = 0;
+            for (int w = 0; w < 2; w++) {
+                hipEventRecord(e0);
+                for (int r = 0; r < reps; r++) {
+                    const int32_t *a = acts[rot ? r % NA : 0];
+                    if (pre == 16) {
+                        if (nt) hipLaunchKernelGGL((k_full2<16, true>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K);
+                        else hipLaunchKernelGGL((k_full2<16, false>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K);
+                    } else {
+                        if (nt) hipLaunchKernelGGL((k_full2<8, true>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K);
+                        else hipLaunchKernelGGL((k_full2<8, false>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K);
+                    }
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("bare pattern: %-9s stores, %-8s action tensor, %2d steps ahead   %8.1f GB/s  %7.1f us per 512-step launch\n",
+                   nt ? "nt" : "default", rot ? "rotating" : "one", pre, 18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
+        }
     }
     run<12>("term + trunc bytes only", obs, rew, term, trunc, 2);
     run<28>("flags as dwords only", obs, rew, term, trunc, 2);
