@@ -211,7 +211,9 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             const uint32_t cur = (uint32_t)hist & 0xFFu;
             uint32_t nxt = t.P[cur * A + action];                                   // D1
             if (NOISE && a.has_p_noise) {                                           // D2
-                double uu = PHILOX ? np_random(sp_phx) : np_random(sp_pcg);
+                // (Philox streams: the P-noise uniform is the env stream's FIRST 64-bit draw of the tick and the reward normal its
+                //  second -- both halves of one block; numpy streams: the state space's own generator, as in the reference)
+                double uu = PHILOX ? np_random(env_phx) : np_random(sp_pcg);
                 nxt = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, uu);
             }
             hist = (hist << 8) | nxt;                                               // D3

@@ -245,22 +245,28 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         // =========================================================== Philox producer (see NPH above)
         const int me = role - 2;
         uint32_t made = 0, hstatus = 0;
+        uint64_t sblk = ~0ULL;
+        uint32_t sw[4] = {0u, 0u, 0u, 0u};
         for (int k = me; k < K; k += NPH) {
             const uint64_t tick = a.ptick + (uint64_t)k;
+            // one block of the env stream per tick: its first 64-bit draw is the P-noise uniform, the next the reward
+            // normal's Box-Muller pair (the order k_discrete_step draws them in)
             uint64_t m_sp = 0;
-            if (PN) {                                            // this step's P-noise uniform, state-space stream
-                Philox gs;
-                gs.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
-                m_sp = gs.next64() >> 11;
-            }
             float z = 0.0f;
-            if (RN) {                                            // env stream: the reward normal
+            {
                 Philox ge;
                 ge.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
-                z = (float)ge.normal();
+                if (PN) m_sp = ge.next64() >> 11;
+                if (RN) z = (float)ge.normal();
             }
-            // the start state a reset at this tick takes: one word of the start-state stream (mdpp_rng.hpp)
-            const uint64_t mr = (uint64_t)philox_start_m31(a.philox_seed, genv, tick, kPhiloxStartStream) << 22;
+            // the start state a reset at this tick takes: one word of the start-state stream (mdpp_rng.hpp); the block
+            // serves four ticks, two of them this producer's
+            if ((tick >> 2) != sblk) {                           // (wave-uniform)
+                sblk = tick >> 2;
+                philox_start_block(a.philox_seed, genv, sblk, kPhiloxStartStream, sw);
+            }
+            const uint32_t tq = (uint32_t)tick & 3u;
+            const uint64_t mr = (uint64_t)((tq == 0u ? sw[0] : tq == 1u ? sw[1] : tq == 2u ? sw[2] : sw[3]) >> 1) << 22;
             uint32_t s0 = 0;
             for (uint32_t b = 0; b < S8; b += 8) {
 #pragma unroll
@@ -406,7 +412,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (PN) {                                                            // D2 (:1604-1622)
             uint64_t m;
             if constexpr (NPH > 0) m = hent & ((1ull << 53) - 1ull);
-            else { m = 0; if (!pend) m = sp.next64() >> 11; }
+            else {
+                m = 0;
+                if constexpr (PH) { if (!pend) m = g.next64() >> 11; }      // the env stream's first draw of the tick (k_discrete_step)
+                else { if (!pend) m = sp.next64() >> 11; }
+            }
             const uint64_t *row = TN + nxt * S8;
             uint32_t c = 0;
             for (uint32_t b = 0; b < S8; b += 8) {

@@ -93,6 +93,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 //   z0 = r cos(theta), z1 = r sin(theta).
 // ln on [sqrt(1/2), sqrt(2)) and sin / cos on [0, pi/4] are the Cephes single-precision polynomials
 // (Moshier, logf.c / sinf.c), evaluated with fma; relative error of z about 2^-22.  |z| <= 6.8.
+// Correctly rounded float32 square root of x in [0, 2^7) that is zero or a normal number (here: -2 ln u1 <= 44.4, and
+// never denormal: its smallest non-zero value is -2 ln(1 - 2^-32) = 4.7e-10): v_sqrt_f32 (<= 1 ulp) stepped one ulp down /
+// up where the exact fma residual says so -- the compiler's own sequence for sqrtf without its denormal scaling and
+// special-case selects (6 instructions fewer per root, 7 roots per cfg5 step).  Same bits as IEEE sqrtf on that range.
+__device__ __forceinline__ float philox_sqrtf(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float r = (rd <= 0.0f) ? sd : s;
+    r = (ru > 0.0f) ? su : r;
+    return r;
+}
+
 __device__ __forceinline__ void philox_box_muller(uint32_t w0, uint32_t w1, float &z0, float &z1) {
     float f = (float)w0;                                    // round to nearest
     if (w0 == 0u) f = 0.5f;
@@ -116,7 +129,7 @@ __device__ __forceinline__ void philox_box_muller(uint32_t w0, uint32_t w1, floa
     const float fe = (float)(e - 32);
     float l = fmaf(fe, 0.693359375f, fmaf(fe, -2.12194440e-4f, x + y));   // ln u1
     l = fminf(l, 0.0f);
-    const float r = sqrtf(-2.0f * l);          // correctly rounded (hipcc default; __fsqrt_rn is the native approximation)
+    const float r = philox_sqrtf(-2.0f * l);   // correctly rounded
     const uint32_t q = w1 >> 30;
     const float a = (float)(w1 & 0x3FFFFFFFu) * (1.0f / 1073741824.0f);   // angle within the quadrant / (pi/2), [0, 1]
     const bool swap = a > 0.5f;
@@ -170,7 +183,7 @@ __device__ __forceinline__ void philox_box_muller2(const uint32_t (&w)[4], float
     f32x2 l = __builtin_elementwise_fma(fe, K(0.693359375f), __builtin_elementwise_fma(fe, K(-2.12194440e-4f), x + y));
     l.x = fminf(l.x, 0.0f); l.y = fminf(l.y, 0.0f);
     const f32x2 l2 = l * -2.0f;
-    const f32x2 r = {sqrtf(l2.x), sqrtf(l2.y)};
+    const f32x2 r = {philox_sqrtf(l2.x), philox_sqrtf(l2.y)};
     f32x2 a = {(float)(w[1] & 0x3FFFFFFFu), (float)(w[3] & 0x3FFFFFFFu)};
     a = a * (1.0f / 1073741824.0f);
     const bool swap0 = a.x > 0.5f, swap1 = a.y > 0.5f;

@@ -144,7 +144,9 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
         for (int i = 0; i < S; i++) probs[i] = 1.0 * e->p_noise / (double)(S - 1);
         probs[nxt] = 1 - e->p_noise;
         np_build_cdf(probs, S, cdf);
-        nxt = np_choice_cdf(&e->space_rng, cdf, S);
+        /* (Philox streams, the build's own: the P-noise uniform is the env stream's first 64-bit draw of the tick, the
+         *  reward normal its second -- one block; numpy streams: the state space's generator, as the reference) */
+        nxt = np_choice_cdf(e->philox ? &e->env_rng : &e->space_rng, cdf, S);
     }
     /* D3: history shift, :2050-2052; :2058 */
     for (int i = 0; i < L; i++) e->hist[i] = e->hist[i + 1];

@@ -89,6 +89,44 @@ __global__ void k_full2(const int32_t *act, uint64_t *obs, float *rew, uint8_t *
     }
 }
 
+// round 3: would WIDER action reads help?  One wave of the 256-env block fetches the block's whole 1 KiB action row with
+// one 16-byte load per lane (instead of four waves x 4 bytes per lane), LD: 0 plain, 1 non-temporal loads; stores nt.
+template <int PRE, int WIDE, int LD>
+__global__ void k_full3(const int32_t *act, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = (uint32_t)i;
+    const bool loader = !WIDE || threadIdx.x < 64;
+    typedef int v4 __attribute__((ext_vector_type(4)));
+    v4 pre4[PRE]; int pre[PRE];
+    auto ld = [&](int k) {
+        if (WIDE) {
+            const v4 *p = (const v4 *)(act + (size_t)k * N + blockIdx.x * 256) + threadIdx.x;
+            return LD ? __builtin_nontemporal_load(p) : *p;
+        } else {
+            const int *p = act + (size_t)k * N + i;
+            const int x = LD ? __builtin_nontemporal_load(p) : *p;
+            return v4{x, 0, 0, 0};
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PRE; u++) { pre4[u] = v4{0, 0, 0, 0}; if (loader) pre4[u] = ld(u); }
+    for (int k0 = 0; k0 < K; k0 += PRE) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) {
+            const int k = k0 + u;
+            const size_t o = (size_t)k * N + i;
+            const v4 a = pre4[u];
+            const int kn = k + PRE < K ? k + PRE : K - 1;
+            if (loader) pre4[u] = ld(kn);
+            s = s * 1664525u + 1013904223u + (uint32_t)(a.x + a.y + a.z + a.w);
+            __builtin_nontemporal_store((uint64_t)(s & 7u), obs + o);
+            __builtin_nontemporal_store((float)(s >> 31), rew + o);
+            __builtin_nontemporal_store((uint8_t)((s >> 8) & 1u), term + o);
+            __builtin_nontemporal_store((uint8_t)((s >> 9) & 1u), trunc + o);
+        }
+    }
+}
+
 template <int MODE>
 void run(const char *name, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, double bytes_per) {
     const int N = 65536, K = 512, reps = 10;
@@ -150,6 +188,31 @@ int main() {
             }
             printf("bare pattern: %-9s stores, %-8s action tensor, %2d steps ahead   %8.1f GB/s  %7.1f us per 512-step launch\n",
                    nt ? "nt" : "default", rot ? "rotating" : "one", pre, 18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
+        }
+    }
+    {
+        const int N = 65536, K = 512, reps = 12, NA = 4;
+        int32_t *acts[NA];
+        for (int q = 0; q < NA; q++) { hipMalloc(&acts[q], n * 4); hipMemset(acts[q], 1 + q, n * 4); }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int variant = 0; variant < 4; variant++) {
+            float ms = 0;
+            for (int w = 0; w < 2; w++) {
+                hipEventRecord(e0);
+                for (int r = 0; r < reps; r++) {
+                    const int32_t *a = acts[r % NA];
+                    switch (variant) {
+                    case 0: hipLaunchKernelGGL((k_full3<8, 0, 0>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    case 1: hipLaunchKernelGGL((k_full3<8, 0, 1>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    case 2: hipLaunchKernelGGL((k_full3<8, 1, 0>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    default: hipLaunchKernelGGL((k_full3<8, 1, 1>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    }
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("bare pattern (nt stores, rotating actions): %s reads, %s loads   %8.1f GB/s  %7.1f us per 512-step launch\n",
+                   (variant & 2) ? "16 B per lane of one wave" : "4 B per lane", (variant & 1) ? "nt" : "plain",
+                   18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
         }
     }
     run<12>("term + trunc bytes only", obs, rew, term, trunc, 2);
