@@ -9,13 +9,13 @@ import bench
 
 def test_committed_traffic_is_keyed_by_shape_and_kernel():
     t, src = bench.committed_traffic("cfg2", "numpy", 65536, 512, "k_discrete_rollout_lean<OBS64=1,DELAY=1,HASMAX=0,EVN=1>")
-    assert src == "r02_traffic_cfg2.json" and 6.0e8 < t < 6.4e8                 # 18.5 B x 65 536 x 512
+    assert src == "r03_traffic_cfg2.json" and 6.0e8 < t < 6.4e8                 # 18.6 B x 65 536 x 512 (the newest record)
     t, src = bench.committed_traffic("cfg2", "numpy", 65536, 512, "k_discrete_rollout_pipe<OBS64=1,POW2=1,DELAY=1,S8=1>")
     assert src == "r02_traffic_cfg2_pipe.json" and 6.0e8 < t < 6.3e8            # the record of that kernel
     assert bench.committed_traffic("cfg2", "numpy", 65536, 512, "k_discrete_step<PHILOX=0>")[0] is None     # another kernel
     assert bench.committed_traffic("cfg2", "numpy", 4096, 512, "k_discrete_rollout_pipe<>")[0] is None      # another batch
     t5, src5 = bench.committed_traffic("cfg5", "philox", 65536, 512, "k_continuous_rollout_fast<D=12,...>")
-    assert src5 == "r02_traffic_cfg5_philox.json" and abs(t5 / (65536 * 512) - 104.8) < 1.0
+    assert src5 == "r03_traffic_cfg5_philox.json" and abs(t5 / (65536 * 512) - 104.8) < 1.0
 
 
 def test_self_launch_spawns_a_child_torchrun(monkeypatch):
