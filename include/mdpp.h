@@ -165,6 +165,8 @@ typedef struct {
     int32_t img_tpl_size;       /* templates are (2*tpl_half+1)^2 bitmaps */
 
     /* ---- ABI 6 ---- */
+    int32_t episode_stats;      /* 1: keep the reference's per-episode noise statistics per env (mdpp_get_episode_stats); such
+                                   handles run on the general kernels */
     int32_t target_f64;         /* continuous, move_to_a_point, no "target_point" in the config: the reference's default,
                                    np.zeros(shape=(state_space_dim,)) -- float64, every dimension relevant
                                    (rl_toy_env.py:652-654): distances, the target latch and a dense reward are float64 */
@@ -269,6 +271,16 @@ int mdpp_tick(mdpp_env *h, int64_t advance, uint64_t *tick_out);
  * Call mdpp_set_reset_pending AFTER mdpp_set_state_*. */
 int mdpp_get_reset_pending(mdpp_env *h, uint8_t *pending_host);
 int mdpp_set_reset_pending(mdpp_env *h, const uint8_t *pending_host);
+
+/* cfg.episode_stats: what the reference accumulates per env object and logs at every reset() (rl_toy_env.py:2231-2247,
+ * cleared :2360-2369).  Rows of `current_host` (double [nk][N], the running episode): 0 total_abs_noise_in_reward_episode
+ * (:1984), 1 total_reward_episode (:1985: the reward after the delay line and the every-n mask, before noise, scale and shift;
+ * accumulated in float32 where the reference's reward is np.float32), 2 total_noisy_transitions_episode (discrete :1620, grid
+ * :1746; 0 for continuous envs), 3 .. 3 + D - 1 total_abs_noise_in_transition_episode per dimension (continuous :1686);
+ * nk = 3, or 3 + D for continuous envs.  `last_host` (double [nk + 1][N]): the same rows of the episode the latest reset()
+ * of each env ended -- in-rollout autoresets and mdpp_reset alike -- and in row nk its total_transitions_episode.  Either
+ * pointer may be NULL.  Synchronises the device. */
+int mdpp_get_episode_stats(mdpp_env *h, double *current_host, double *last_host);
 
 /* Kernel selection (see MDPP_OPT_*): disable_mask replaces the handle's current mask (0 = default dispatch). */
 int mdpp_set_options(mdpp_env *h, uint32_t disable_mask);

@@ -31,6 +31,7 @@ EXPORTS = [
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
     "mdpp_set_options", "mdpp_kernel_name", "mdpp_philox_normals",
     "mdpp_graph_replay_exact", "mdpp_tick", "mdpp_get_reset_pending", "mdpp_set_reset_pending",
+    "mdpp_get_episode_stats",
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
     "mdpp_episode_stats",
@@ -62,7 +63,7 @@ class MdppConfig(C.Structure):
         ("img_has_flip", C.c_int32), ("img_sh_quant", C.c_int32), ("img_ro_quant", C.c_int32),
         ("img_r0", C.c_int32), ("img_r_min", C.c_int32), ("img_r_max", C.c_int32),
         ("img_log_min_r", C.c_double), ("img_log_max_r", C.c_double), ("img_tpl_size", C.c_int32),
-        ("target_f64", C.c_int32),
+        ("episode_stats", C.c_int32), ("target_f64", C.c_int32),
     ]
 
 
@@ -132,6 +133,7 @@ def load():
     L.mdpp_kernel_name.restype = C.c_char_p
     L.mdpp_graph_replay_exact.argtypes = [vp, i32]
     L.mdpp_tick.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
+    L.mdpp_get_episode_stats.argtypes = [vp, vp, vp]
     L.mdpp_get_reset_pending.argtypes = [vp, vp]
     L.mdpp_set_reset_pending.argtypes = [vp, vp]
     L.mdpp_philox_normals.argtypes = [C.c_uint64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, vp, vp]

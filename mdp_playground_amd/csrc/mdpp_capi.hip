@@ -52,7 +52,7 @@ static void free_all(mdpp_env *h) {
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final, h->d_img_rec, h->d_line_hist, h->d_ring64};
+                    h->d_img_state_final, h->d_img_rec, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -105,6 +105,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
     h->d_P1 = h->d_init_cdf1 = h->d_noise_cdf1 = h->d_irr_state = nullptr;
     h->d_line_hist = h->d_ring64 = nullptr;
+    h->d_est_cur = h->d_est_last = nullptr; h->est_nk = 0;
     h->irr_ready = false;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = nullptr;
@@ -124,6 +125,12 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     TRYHIP(hipEventCreate(&h->ev0));
     TRYHIP(hipEventCreate(&h->ev1));
     TRY(alloc_zero(h, &h->d_status, N * sizeof(uint32_t)));
+    if (cfg->episode_stats) {       // per-episode noise statistics (EpisodeStatsDev): running episode + the one a reset() ended
+        if (cfg->image) { g_create_err = "mdpp_create: episode_stats with image observations is not built"; free_all(h); delete h; return MDPP_EUNSUPPORTED; }
+        h->est_nk = 3 + (cfg->kind == MDPP_KIND_CONTINUOUS ? cfg->D : 0);
+        TRY(alloc_zero(h, &h->d_est_cur, (size_t)h->est_nk * N * sizeof(double)));
+        TRY(alloc_zero(h, &h->d_est_last, (size_t)(h->est_nk + 1) * N * sizeof(double)));
+    }
     if (cfg->rng_mode == MDPP_RNG_NUMPY_PCG64) {
         for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
             if (s == MDPP_STREAM_IMAGE && !(cfg->image && cfg->kind == MDPP_KIND_DISCRETE)) continue;
@@ -133,23 +140,21 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             TRY(alloc_zero(h, &h->d_rng_inc[s], N * 16));
         }
         if (cfg->kind == MDPP_KIND_GRID) TRY(alloc_zero(h, &h->d_rng_half, N * 8));   // action stream's 32-bit half
-        if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE) {
-            TRY(alloc_zero(h, &h->d_rng_half, N * 8));
-            // scratch of one batch of img_chunk env steps: states in, transform records in between
-            const size_t sub = cfg->irrelevant ? 2 : 1;       // images per observation (one per sub-space)
-            // two sets of everything: batch b + 1 is prepared while batch b is rendered
-            TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * 4 * sub));
-            TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * 4 * sub));
-            TRY(alloc_zero(h, &h->d_img_rec, 2 * 2 * (size_t)h->img_chunk * N * 64 * sub));
-
-        }
+        if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE) TRY(alloc_zero(h, &h->d_rng_half, N * 8));
     } else if (cfg->rng_mode != MDPP_RNG_PHILOX) {
         g_create_err = "mdpp_create: unknown rng_mode"; free_all(h); delete h; return MDPP_EINVAL;
     }
+    if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE) {      // (either RNG mode)
+        // scratch of one batch of img_chunk env steps: states in, transform records in between
+        const size_t sub = cfg->irrelevant ? 2 : 1;       // images per observation (one per sub-space)
+        // two sets of everything: batch b + 1 is prepared while batch b is rendered
+        TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * 4 * sub));
+        TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * 4 * sub));
+        TRY(alloc_zero(h, &h->d_img_rec, 2 * 2 * (size_t)h->img_chunk * N * 64 * sub));
+    }
 
-    if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE &&
-        (cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 || cfg->img_w < 1 || cfg->img_h < 1 || cfg->img_tpl_size < 1)) {
-        g_create_err = "mdpp_create: image observations of a discrete env need numpy PCG64 streams";
+    if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE && (cfg->img_w < 1 || cfg->img_h < 1 || cfg->img_tpl_size < 1)) {
+        g_create_err = "mdpp_create: image observations of a discrete env need img_w, img_h, img_tpl_size >= 1";
         free_all(h); delete h; return MDPP_EUNSUPPORTED;
     }
     if (cfg->image && cfg->kind == MDPP_KIND_CONTINUOUS &&
@@ -239,6 +244,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
+        a.est = mdpp::EpisodeStatsDev{(double *)h->d_est_cur, (double *)h->d_est_last, h->est_nk};
         a.irr = cfg->irrelevant ? 1 : 0; a.S1 = cfg->S_irr; a.A1 = cfg->A_irr;
         a.P1 = (const uint8_t *)h->d_P1; a.init_cdf1 = (const double *)h->d_init_cdf1;
         a.noise_cdf1 = (const double *)h->d_noise_cdf1; a.irr_state = (uint32_t *)h->d_irr_state;
@@ -333,6 +339,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.ring = (uint32_t *)h->d_ring;
         a.line_L = line ? cfg->L : 0; a.line_hist = (float *)h->d_line_hist; a.ring64 = (double *)h->d_ring64;
         a.target64 = cfg->target_f64 ? 1 : 0; a.rew64 = rew64 ? 1 : 0; a.radius = cfg->target_radius;
+        a.est = mdpp::EpisodeStatsDev{(double *)h->d_est_cur, (double *)h->d_est_last, h->est_nk};
+        if (cfg->episode_stats) a.fast_ok = 0;
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
@@ -374,6 +382,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.act_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ACTION]; a.act_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ACTION];
         a.act_half = (uint2 *)h->d_rng_half;
         a.status = (uint32_t *)h->d_status;
+        a.est = mdpp::EpisodeStatsDev{(double *)h->d_est_cur, (double *)h->d_est_last, h->est_nk};
         a.minv_lo = (uint64_t)pcg_mult_inverse(); a.minv_hi = (uint64_t)(pcg_mult_inverse() >> 64);
         h->tables_ready = true;      // a grid env has no tables
     } else {
@@ -421,6 +430,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         a.lean_next_ok = (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise &&
                           c.L <= 3 && c.S <= 8 && c.delay <= 32 && c.autoreset == MDPP_AUTORESET_NEXT_STEP &&
                           a.rew_in_lds && !c.image) ? 1u : 0u;
+        if (c.episode_stats) a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = 0u;   // (general kernel keeps the statistics)
         a.s_shift = 0xFFFFFFFFu;
         for (uint32_t b = 1; b < 8; b++) if ((1u << b) == (uint32_t)c.S) a.s_shift = b;
         a.key_mask = h->nkeys - 1u;
@@ -612,6 +622,17 @@ extern "C" int mdpp_get_streams(mdpp_env *h, int stream, uint64_t *words) {
 extern "C" int mdpp_set_options(mdpp_env *h, uint32_t disable_mask) {
     if (!h) return MDPP_EINVAL;
     h->opts = disable_mask;
+    return MDPP_OK;
+}
+
+extern "C" int mdpp_get_episode_stats(mdpp_env *h, double *current, double *last) {
+    if (!h) return MDPP_EINVAL;
+    if (!h->d_est_cur) return fail(h, MDPP_ESTATE, "get_episode_stats: the handle was not created with episode_stats");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs;
+    if (current) HIPCHK(h, hipMemcpy(current, h->d_est_cur, (size_t)h->est_nk * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (last) HIPCHK(h, hipMemcpy(last, h->d_est_last, (size_t)(h->est_nk + 1) * N * sizeof(double), hipMemcpyDeviceToHost));
     return MDPP_OK;
 }
 

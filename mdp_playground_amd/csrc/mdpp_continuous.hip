@@ -434,6 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             if (!sp_loaded) { sp_pcg.load(a.sp_s, a.sp_inc, i); sp_loaded = true; }
             c_reset_lane<DMAX, OMAX>(a, sp_pcg, sd, cur, status);
         }
+        if (a.est.cur) est_roll(a.est, N, i, steps);               // reset(): :2231-2247, :2360-2369
         steps = 0; flags = 0;
         if (a.line_L) {
             c_gather_rel<DMAX>(a, cur, rel);
@@ -522,6 +523,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             for (int d = 0; d < D; d++)
                 s_z[d * kBlock + threadIdx.x] =
                     0.0 + pns * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+            if (a.est.cur) {                                       // total_abs_noise_in_transition_episode, :1686
+#pragma unroll 1
+                for (int d = 0; d < D; d++) est_add(a.est, N, i, 3 + d, fabs(s_z[d * kBlock + threadIdx.x]));
+            }
         }
 #pragma unroll
         for (int d = 0; d < DMAX; d++) {
@@ -605,8 +610,17 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             else { r.v = (double)__uint_as_float(bits); r.is32 = true; }
         }
         if (steps % (uint32_t)a.every_n != 0) { r.v = 0.0; r.is32 = false; }
+        if (a.est.cur) {
+            // total_reward_episode += reward (:1985): an np.float32 reward makes the running sum np.float32 (int 0 + float32,
+            // then float32 + float32, and float32 + a Python 0.0 stays float32); float64 rewards (line reward, default
+            // target) sum in float64
+            double &acc = a.est.cur[(size_t)1 * N + i];
+            if (a.rew64) acc += r.v;
+            else if (r.is32) acc = (double)((float)acc + (float)r.v);
+        }
         if (a.has_r_noise) {
             double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+            if (a.est.cur) est_add(a.est, N, i, 0, fabs(nz));      // total_abs_noise_in_reward_episode, :1984
             if (r.is32) r.v = (double)((float)r.v + (float)nz); else r.v = r.v + nz;
         }
         if (r.is32) {
@@ -688,6 +702,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, u
             if (obs) obs[i * D + d] = cur[d];
         }
     }
+    if (a.est.cur) est_roll(a.est, a.N, i, a.meta[i].x);
     a.meta[i] = make_uint2(0u, 0u);
     if (a.line_L) {
         float rel[DMAX];

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                     if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(env_pcg));
                 }
                 hist = d_fresh_hist(s0);
+                if (a.est.cur) est_roll(a.est, N, i, steps);                        // reset(): :2231-2247, :2360-2369
                 steps = 0; phase = 0; ringbits = 0;
                 if (!UNIT)
                     for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * N + i] = kNoKey;
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 // (Philox streams: the P-noise uniform is the env stream's FIRST 64-bit draw of the tick and the reward normal its
                 //  second -- both halves of one block; numpy streams: the state space's own generator, as in the reference)
                 double uu = PHILOX ? np_random(env_phx) : np_random(sp_pcg);
-                nxt = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, uu);
+                const uint32_t noisy = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, uu);
+                if (a.est.cur && noisy != nxt) est_add(a.est, N, i, 2, 1.0);        // total_noisy_transitions_episode, :1620
+                nxt = noisy;
             }
             hist = (hist << 8) | nxt;                                               // D3
             steps += 1;
@@ -237,9 +240,12 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                     bit = out;
                 }
                 if (phase != 0) bit = 0;                                            // D6
+                if (a.est.cur && bit) est_add(a.est, N, i, 1, 1.0);                 // total_reward_episode, :1985
                 if (NOISE && a.has_r_noise) {
                     double r = bit ? 1.0 : 0.0;
-                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                    const double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                    if (a.est.cur) est_add(a.est, N, i, 0, fabs(nz));               // total_abs_noise_in_reward_episode, :1984
+                    r += nz;
                     r *= a.scale;
                     r += a.shift;
                     if (done) r += a.term_add;
@@ -256,8 +262,12 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 }
                 double r = (key != kNoKey) ? t.rtable[key] : 0.0;
                 if (phase != 0) r = 0.0;
-                if (NOISE && a.has_r_noise)
-                    r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                if (a.est.cur) est_add(a.est, N, i, 1, r);                          // total_reward_episode, :1985
+                if (NOISE && a.has_r_noise) {
+                    const double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                    if (a.est.cur) est_add(a.est, N, i, 0, fabs(nz));               // :1984
+                    r += nz;
+                }
                 r *= a.scale;
                 r += a.shift;
                 if (done) r += a.term_add;
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                     if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(env_pcg));
                 }
                 hist = d_fresh_hist(s0);
+                if (a.est.cur) est_roll(a.est, N, i, steps);                        // reset(): :2231-2247, :2360-2369
                 steps = 0; phase = 0; ringbits = 0;
                 if (!UNIT)
                     for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * N + i] = kNoKey;
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint6
         }
     }
     if (a.irr) a.irr_state[i] = s1;
+    if (a.est.cur) est_roll(a.est, a.N, i, a.state[i].z & 0x7FFFFFFFu);
     uint64_t hist = d_fresh_hist(s0);
     a.state[i] = make_uint4((uint32_t)hist, a.fast_ok ? queue : (uint32_t)(hist >> 32), 0u, 0u);
     if (!a.unit_rewards)
@@ -463,7 +475,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
             if (name_out) return MDPP_OK;     // (the first piece names the launch)
             k0 += kc;
         }
-    } else if (launch_discrete_quiet(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
+    } else if (!a.est.cur && launch_discrete_quiet(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
         // quiet shapes beyond the specialised kernels (larger S / L, irrelevant sub-space):
         // mdpp_discrete_quiet.hip
     } else if (a.philox) {

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
             if (!sp_loaded) { sp_pcg.load(a.sp_s, a.sp_inc, i); sp_loaded = true; }
             g_reset_lane(a, sp_pcg, cell);
         }
+        if (a.est.cur) est_roll(a.est, N, i, steps);                       // reset(): :2231-2247, :2360-2369
         steps = 0; flags = 0;
     };
 
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
                         if (!same) {
 #pragma unroll
                             for (int d = 0; d < 4; d++) act[d] = (d == ind) ? val - 1 : 0;
+                            if (a.est.cur) est_add(a.est, N, i, 2, 1.0);      // total_noisy_transitions_episode, :1746
                             break;
                         }
                         if (tries > 4096) { status |= MDPP_STATUS_INTERNAL; break; }
@@ -173,8 +175,12 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
                           (abs(cell[0] - a.target[0]) + abs(cell[1] - a.target[1])));
         else if (on_target) r += 1.0;                         // :1962-1965
         if (a.every_n != 1 && steps % (uint32_t)a.every_n != 0) r = 0.0;   // :1975-1978
-        if (NOISE && a.has_r_noise)
-            r += 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+        if (a.est.cur) est_add(a.est, N, i, 1, r);                         // total_reward_episode, :1985
+        if (NOISE && a.has_r_noise) {
+            const double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+            if (a.est.cur) est_add(a.est, N, i, 0, fabs(nz));              // total_abs_noise_in_reward_episode, :1984
+            r += nz;
+        }
         r *= a.scale;
         r += a.shift;
         const bool done = (flags & 1u) != 0;                  // :2102-2104
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_reset(GridArgs a, uint64_t rese
         g_reset_lane(a, g, cell);
         g.store(a.sp_s, i);
     }
+    if (a.est.cur) est_roll(a.est, a.N, i, a.state[i].y);
     a.state[i] = make_uint4((uint32_t)cell[0] | ((uint32_t)cell[1] << 8) | ((uint32_t)cell[2] << 16) |
                                 ((uint32_t)cell[3] << 24), 0u, 0u, 0u);
     if (obs)
@@ -481,7 +488,7 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)
-    if (!(a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) &&
+    if (!a.est.cur && !(a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) &&
         !(noise && (a.opts & MDPP_OPT_NO_GFAST_NOISE)) && !(a.opts & MDPP_OPT_NO_GFAST) &&
         (unsigned long long)K * a.N * a.G * 8ULL < (1ULL << 32)) {
         const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;

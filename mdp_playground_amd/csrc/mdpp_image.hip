@@ -29,6 +29,7 @@
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mdpp {
 
@@ -65,6 +66,12 @@ struct ImageArgs {
     const int32_t *rot;        // [360][6] = a0 a1 a2 a3 a4 a5
     ulonglong2 *rng_s, *rng_inc;
     uint2 *rng_half;           // {has_uint32, uinteger}
+    // Philox streams (round 3): the transforms of tick t come from stream (seed, global env id, t, MDPP_STREAM_IMAGE) in the
+    // order the reference draws them (the step's images, then reset()'s where the step ended the episode); an explicit
+    // reset() from stream kPhiloxResetImageStream keyed by the reset count
+    int32_t philox, is_reset;
+    uint64_t philox_seed, ptick;
+    int64_t env_id_offset;
     ImgRec *rec0, *rec1;       // [M]: the image that goes to img_out / the terminal observation of a
                                // step that ends in a reset (img_final)
 };
@@ -84,7 +91,8 @@ __device__ __forceinline__ ShiftBounds shift_bounds(const ImageArgs &a, int R) {
     return ShiftBounds{(int)(-mw + 1), (int)mw, (int)(-mh + 1), (int)mh};   // Generator.integers truncates toward 0
 }
 
-__device__ __forceinline__ Xform draw_xform(const ImageArgs &a, const ShiftBounds &fixed, Pcg64 &g, Half32 &h) {
+template <class G>
+__device__ __forceinline__ Xform draw_xform(const ImageArgs &a, const ShiftBounds &fixed, G &g, Half32 &h) {
     Xform x;
     x.R = a.r0;
     x.cx = a.W / 2; x.cy = a.H / 2;              // int(width / 2)
@@ -169,7 +177,8 @@ constexpr int kImgChunk = 16;            // env steps per batch (mdpp_env::img_c
 // REC: build the records right here (K = 1: one launch less); otherwise only leave the drawn
 // transforms in the records' pad words for k_image_rec, so that the per-image table lookups and
 // stores run one lane per IMAGE instead of serially per env (60 us -> a few us for 16 steps).
-template <bool REC>
+constexpr uint32_t kPhiloxResetImageStream = 11;   // an explicit reset()'s image transforms (keyed by the reset count)
+template <bool REC, bool PHILOX = false>
 __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const int32_t *__restrict__ state_out,
                                                        const int32_t *__restrict__ state_final,
                                                        const uint8_t *__restrict__ term,
@@ -191,14 +200,22 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
         for (int k = 0; k < kImgChunk; k++)
             if (k < K) twos |= (uint32_t)((term[(long)k * a.N + i] | trunc[(long)k * a.N + i]) != 0) << k;
     }
-    Pcg64 g;
-    g.load(a.rng_s, a.rng_inc, i);
-    const uint2 hh = a.rng_half[i];
-    Half32 h{hh.x, hh.y};
+    typename std::conditional<PHILOX, Philox, Pcg64>::type g;
+    Half32 h{0u, 0u};
+    if constexpr (!PHILOX) {
+        g.load(a.rng_s, a.rng_inc, i);
+        const uint2 hh = a.rng_half[i];
+        h = Half32{hh.x, hh.y};
+    }
     const ShiftBounds sb = shift_bounds(a, a.r0);
     for (int k = 0; k < K; k++) {
         const long j0 = ((long)k * a.N + i) * SUB;
         const bool two = (twos >> k) & 1u;
+        if constexpr (PHILOX) {                  // this tick's stream; its buffered 32-bit half starts empty
+            g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.ptick + (uint64_t)k,
+                   a.is_reset ? kPhiloxResetImageStream : (uint32_t)MDPP_STREAM_IMAGE);
+            h = Half32{0u, 0u};
+        }
         // the step's observation first (one image per sub-space, relevant then irrelevant), then --
         // where the step ended the episode -- the images of reset()'s observation, in the same order
         Xform x0[2], x1[2];
@@ -220,8 +237,10 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
             }
         }
     }
-    g.store(a.rng_s, i);
-    a.rng_half[i] = make_uint2(h.has32, h.u32);
+    if constexpr (!PHILOX) {
+        g.store(a.rng_s, i);
+        a.rng_half[i] = make_uint2(h.has32, h.u32);
+    }
 }
 
 // One lane per image: transforms (pad words of rec0) -> records.  mask is nullptr here (K > 1).
@@ -502,18 +521,26 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.rng_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_IMAGE];
     a.rng_half = (uint2 *)h->d_rng_half;
     a.tplp_data = (const uint8_t *)h->d_img_tplp; a.tplp = c.img_tpl_size + 2 * kImgPad;
+    a.philox = c.rng_mode == MDPP_RNG_PHILOX; a.philox_seed = c.philox_seed; a.env_id_offset = c.env_id_offset;
+    // (the state kernel / reset kernel of this batch ran just before and has advanced the handle's counters)
+    a.is_reset = term == nullptr;
+    a.ptick = a.is_reset ? h->reset_tick - 1 : h->tick - (uint64_t)K;
     a.rec0 = (ImgRec *)h->d_img_rec + (size_t)buf * 2 * h->img_chunk * c.num_envs * a.SUB;
     a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs * a.SUB;
     static_assert(kBlock == 256, "render_fast packs four 64-byte template columns into a 256-byte LDS row");
     if (!(phase & 1)) {
         // records of this batch were made earlier (side stream)
     } else if (K == 1) {
-        hipLaunchKernelGGL(k_image_draw<true>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
-                           state_final, term, trunc, mask);
+        if (a.philox) hipLaunchKernelGGL((k_image_draw<true, true>), dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
+                                         state_final, term, trunc, mask);
+        else hipLaunchKernelGGL((k_image_draw<true, false>), dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
+                                state_final, term, trunc, mask);
     } else {
         const long M = (long)K * a.N * a.SUB;
-        hipLaunchKernelGGL(k_image_draw<false>, dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
-                           state_final, term, trunc, mask);
+        if (a.philox) hipLaunchKernelGGL((k_image_draw<false, true>), dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
+                                         state_final, term, trunc, mask);
+        else hipLaunchKernelGGL((k_image_draw<false, false>), dim3((a.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, K, state_out,
+                                state_final, term, trunc, mask);
         hipLaunchKernelGGL(k_image_rec, dim3((unsigned)((M + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a, M,
                            state_out, state_final);
     }

@@ -29,6 +29,27 @@ constexpr uint32_t kPhiloxActionStream = 5;   // grid: the re-drawn noisy action
 constexpr uint32_t kPhiloxStartStream = 9;    // discrete: start state of an in-rollout reset, one word per tick (mdpp_rng.hpp)
 constexpr uint32_t kPhiloxStartIrrStream = 10; // ... of the irrelevant sub-space
 
+// ---- per-episode noise statistics (cfg.episode_stats; general kernels only) ------------------------------------
+// What the reference accumulates per env object and logs at every reset() (rl_toy_env.py:2231-2247; cleared
+// :2360-2369): row 0 total_abs_noise_in_reward_episode (:1984), row 1 total_reward_episode (:1985: the reward after the
+// delay line and the every-n mask, before noise / scale / shift), row 2 total_noisy_transitions_episode (discrete :1620,
+// grid :1746), rows 3.. total_abs_noise_in_transition_episode per dimension (continuous :1686).  cur [nk][N] is the running
+// episode, last [nk + 1][N] the episode a reset() ended (row nk: its total_transitions_episode).  cur == nullptr: off.
+struct EpisodeStatsDev {
+    double *cur, *last;
+    int32_t nk;
+};
+__device__ __forceinline__ void est_add(const EpisodeStatsDev &e, long N, long i, int k, double v) {
+    e.cur[(size_t)k * N + i] += v;
+}
+__device__ __forceinline__ void est_roll(const EpisodeStatsDev &e, long N, long i, uint32_t steps) {   // reset(): log, then clear
+    for (int k = 0; k < e.nk; k++) {
+        e.last[(size_t)k * N + i] = e.cur[(size_t)k * N + i];
+        e.cur[(size_t)k * N + i] = 0.0;
+    }
+    e.last[(size_t)e.nk * N + i] = (double)steps;
+}
+
 // ---- discrete: kernel arguments (passed by value; wave-uniform => SGPRs) -------------------
 struct DiscreteArgs {
     int32_t N;
@@ -62,6 +83,7 @@ struct DiscreteArgs {
     uint32_t *ring_keys;        // [delay][N] keys awaiting payout (unit_rewards == 0)
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc; // PCG64 streams
     uint32_t *status;
+    EpisodeStatsDev est;
     // ---- irrelevant sub-space (cfg.irrelevant; general kernel only) ----
     int32_t irr, S1, A1;
     const uint8_t *P1;          // [T][S1][A1]
@@ -118,6 +140,7 @@ struct ContinuousArgs {
     double radius;
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc;
     uint32_t *status;
+    EpisodeStatsDev est;
     // ---- precomputed on the host for the fused fast path (mdpp_continuous_fast.hip) ----
     int32_t park;               // helper waves park lanes that leave the ziggurat's fast path (mdpp_continuous_fast.hip)
     int32_t image_quirk;        // image observations: every step clips and zeroes the derivatives (see k_continuous_step C4)
@@ -144,6 +167,7 @@ struct GridArgs {
     uint2 *act_half;            // numpy's buffered 32-bit half of the action stream
     uint64_t minv_lo, minv_hi;  // inverse of the PCG64 LCG multiplier mod 2^128 (un-drawing queued reset cells)
     uint32_t *status;
+    EpisodeStatsDev est;
 };
 
 } // namespace mdpp
@@ -162,6 +186,8 @@ struct mdpp_env {
     void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
     void *d_state, *d_ring, *d_status;
     void *d_line_hist, *d_ring64;                             // continuous, move_along_a_line
+    void *d_est_cur, *d_est_last;                             // cfg.episode_stats: EpisodeStatsDev rows
+    int32_t est_nk;
     void *d_P1, *d_init_cdf1, *d_noise_cdf1, *d_irr_state;   // irrelevant sub-space
     bool irr_ready;
     void *d_sd, *d_cur, *d_meta;

@@ -40,7 +40,7 @@ class RLToyVectorEnv:
 
     def __init__(self, num_envs=None, device=None, *, seeds=None, rng="numpy",
                  autoreset="same_step", max_episode_steps=None, env_id_offset=0,
-                 philox_seed=None, **config):
+                 philox_seed=None, episode_stats=False, **config):
         self._lib = capi.load()
         self._h = None
         if not torch.cuda.is_available():
@@ -95,6 +95,10 @@ class RLToyVectorEnv:
         cfg.reward_scale = float(m.reward_scale)
         cfg.reward_shift = float(m.reward_shift)
         cfg.term_state_reward = float(m.term_state_reward)
+        # the reference's per-episode noise statistics (logged at every reset(), rl_toy_env.py:2231-2247), per env;
+        # such handles run on the general kernels
+        self.episode_stats = bool(episode_stats)
+        cfg.episode_stats = int(self.episode_stats)
         self._irr = False
         if m.kind == "discrete":
             self._init_discrete(cfg)
@@ -160,8 +164,6 @@ class RLToyVectorEnv:
                 seed=m.seed_dict.get("action_space"))
         self._image = None
         if m.image is not None:
-            if self.rng != "numpy":
-                raise NotImplementedError("image observations need rng='numpy'")
             from . import image_obs
             im = m.image
             # (with an irrelevant sub-space the observation is one image per sub-space, side by side
@@ -669,6 +671,37 @@ class RLToyVectorEnv:
         rc = self._lib.mdpp_set_state_continuous(self._h, capi.nptr(sd), capi.nptr(cur), capi.nptr(steps),
                                                  capi.nptr(ring), capi.nptr(is32), capi.nptr(reached))
         capi.check(self._lib, self._h, rc, "mdpp_set_state_continuous")
+
+    def get_episode_stats(self):
+        """The reference's per-episode statistics (attributes of every env object, logged at each reset() and cleared,
+        rl_toy_env.py:2231-2247, :2360-2369), per env instance, for handles made with ``episode_stats=True``: a dict
+        with the running episode's ``total_abs_noise_in_reward_episode``, ``total_reward_episode``,
+        ``total_noisy_transitions_episode`` (discrete, grid), ``total_abs_noise_in_transition_episode`` ([N, D],
+        continuous), ``total_transitions_episode``, and under ``"last_episode"`` the same for the episode each env's
+        latest reset() ended (what the reference logs).  Host numpy arrays (synchronises)."""
+        if not self.episode_stats:
+            raise capi.MdppError("get_episode_stats: construct the env with episode_stats=True")
+        N = self.num_envs
+        D = self.mdps[0].D if self.kind == "continuous" else 0
+        nk = 3 + D
+        cur = np.zeros((nk, N), np.float64)
+        last = np.zeros((nk + 1, N), np.float64)
+        rc = self._lib.mdpp_get_episode_stats(self._h, capi.nptr(cur), capi.nptr(last))
+        capi.check(self._lib, self._h, rc, "mdpp_get_episode_stats")
+
+        def rows(a, transitions):
+            d = {"total_abs_noise_in_reward_episode": a[0].copy(), "total_reward_episode": a[1].copy(),
+                 "total_transitions_episode": transitions}
+            if self.kind == "continuous":
+                # (total_reward_episode of a continuous env is the reference's np.float32 running sum wherever its reward
+                #  is np.float32 -- held here as the float64 of exactly that value)
+                d["total_abs_noise_in_transition_episode"] = np.ascontiguousarray(a[3:3 + D].T)
+            else:
+                d["total_noisy_transitions_episode"] = a[2].astype(np.int64)
+            return d
+        out = rows(cur, np.asarray(self._get_augmented_state()["total_transitions_episode"], dtype=np.int64))
+        out["last_episode"] = rows(last, last[nk].astype(np.int64))
+        return out
 
     def get_rng_streams(self, stream=capi.STREAM_ENV):
         words = np.zeros((self.num_envs, 6), np.uint64)

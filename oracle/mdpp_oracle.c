@@ -31,6 +31,10 @@ struct ora_discrete {
     np_pcg64 space_rng;      /* self.observation_spaces[0].np_random */
     int philox; uint64_t ph_seed, ph_env; uint64_t tick, reset_tick;
     int ph_explicit;         /* Philox mode: the next reset() is a call of its own (stream 3), not the end of a step */
+    /* per-episode noise statistics (:1620, :1984-1985; logged at reset :2231-2247, cleared :2360-2369):
+     * [0] total_abs_noise_in_reward_episode, [1] total_reward_episode, [2] total_noisy_transitions_episode; st_last: the
+     * episode the latest reset() ended, [3] its total_transitions_episode */
+    double st[3], st_last[4];
     /* irrelevant sub-space (irrelevant_features=True), rl_toy_env.py:2028-2035, :2063-2092 */
     int irr, S1, A1, irr_state;
     int32_t *P1;
@@ -105,7 +109,13 @@ void ora_d_get_rng(const ora_discrete *e, uint64_t a[6], uint64_t b[6]) {
  * from stream 3 keyed by the reset count. */
 #define ORA_PHILOX_START 9
 #define ORA_PHILOX_START_IRR 10
+void ora_d_get_stats(const ora_discrete *e, double cur[3], double last[4]) {
+    for (int k = 0; k < 3; k++) cur[k] = e->st[k];
+    for (int k = 0; k < 4; k++) last[k] = e->st_last[k];
+}
 int64_t ora_d_reset(ora_discrete *e) {
+    for (int k = 0; k < 3; k++) { e->st_last[k] = e->st[k]; e->st[k] = 0.0; }
+    e->st_last[3] = (double)e->steps;
     for (int i = 0; i < e->delay; i++) e->ring[i] = 0.0;
     int s0;
     if (e->philox && !e->ph_explicit)
@@ -146,7 +156,9 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
         np_build_cdf(probs, S, cdf);
         /* (Philox streams, the build's own: the P-noise uniform is the env stream's first 64-bit draw of the tick, the
          *  reward normal its second -- one block; numpy streams: the state space's generator, as the reference) */
-        nxt = np_choice_cdf(e->philox ? &e->env_rng : &e->space_rng, cdf, S);
+        const int noisy = np_choice_cdf(e->philox ? &e->env_rng : &e->space_rng, cdf, S);
+        if (noisy != nxt) e->st[2] += 1.0;              /* :1620 */
+        nxt = noisy;
     }
     /* D3: history shift, :2050-2052; :2058 */
     for (int i = 0; i < L; i++) e->hist[i] = e->hist[i + 1];
@@ -170,7 +182,12 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
     }
     /* D6: every-n mask, noise, affine, :1975-1990 */
     if (e->steps % e->every_n != 0) r = 0.0;
-    if (e->has_r_noise) r += 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+    e->st[1] += r;                                       /* :1985 */
+    if (e->has_r_noise) {
+        const double nz = 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+        e->st[0] += fabs(nz);                            /* :1984 */
+        r += nz;
+    }
     r *= e->scale;
     r += e->shift;
     /* D7: :2102-2109 */
@@ -240,6 +257,7 @@ struct ora_grid {
     int make_denser, has_p_noise, has_r_noise, every_n;
     double p_noise, r_noise, scale, shift, term_reward;
     int state[4], steps, reached;
+    double st[3], st_last[4]; /* per-episode noise statistics, as in ora_discrete ([2]: :1746) */
     np_pcg64 env_rng;        /* self._np_random: noise trigger (:1736), reward noise */
     np_pcg64 space_rng;      /* self.feature_space.np_random: reset() sample (:2326) */
     np_pcg64 action_rng;     /* self.action_space.np_random: the noisy action (:1738) */
@@ -279,12 +297,18 @@ void ora_g_philox_explicit_reset(ora_grid *e) {
  * reference; the terminal-state resampling loop never triggers (Box(int64).contains(float64 array)
  * is False under gymnasium's dtype check, :973-982). */
 void ora_g_reset(ora_grid *e, int64_t *obs) {
+    for (int k = 0; k < 3; k++) { e->st_last[k] = e->st[k]; e->st[k] = 0.0; }
+    e->st_last[3] = (double)e->steps;
     for (int i = 0; i < e->G; i++) {
         double v = 0.0 + ((double)(e->shape[i] + 1) - 0.0) * np_random(&e->space_rng);
         e->state[i] = (int)floor(v);
         obs[i] = e->state[i];
     }
     e->steps = 0; e->reached = 0;
+}
+void ora_g_get_stats(const ora_grid *e, double cur[3], double last[4]) {
+    for (int k = 0; k < 3; k++) cur[k] = e->st[k];
+    for (int k = 0; k < 4; k++) last[k] = e->st_last[k];
 }
 
 void ora_g_step(ora_grid *e, const int32_t *action, int64_t *obs, double *reward, uint8_t *done) {
@@ -309,7 +333,7 @@ void ora_g_step(ora_grid *e, const int32_t *action, int64_t *obs, double *reward
                     int na[4] = {0, 0, 0, 0}, same = 1;
                     na[ind] = val - 1;
                     for (int i = 0; i < G; i++) if (na[i] != a[i]) same = 0;
-                    if (!same) { for (int i = 0; i < G; i++) a[i] = na[i]; break; }
+                    if (!same) { for (int i = 0; i < G; i++) a[i] = na[i]; e->st[2] += 1.0; break; }   /* :1746 */
                 }
             }
         }
@@ -329,7 +353,12 @@ void ora_g_step(ora_grid *e, const int32_t *action, int64_t *obs, double *reward
         r += (double)(d_old - d_new);
     } else if (e->state[0] == e->target[0] && e->state[1] == e->target[1]) r += 1.0;  /* :1962-1965 */
     if (e->steps % e->every_n != 0) r = 0.0;                             /* :1975-1978 */
-    if (e->has_r_noise) r += 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+    e->st[1] += r;                                                       /* :1985 */
+    if (e->has_r_noise) {
+        const double nz = 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+        e->st[0] += fabs(nz);                                            /* :1984 */
+        r += nz;
+    }
     r *= e->scale;
     r += e->shift;
     uint8_t d = (uint8_t)e->reached;                                     /* :2102-2104 */
@@ -373,6 +402,11 @@ struct ora_continuous {
     float cur[ORA_MAX_DIM];                   /* curr_state == augmented_state[-1] */
     rew_t ring[ORA_MAX_DELAY];
     int steps, reached;
+    /* per-episode noise statistics (:1686, :1984-1985; logged at reset :2231-2247, cleared :2360-2369): [0]
+     * total_abs_noise_in_reward_episode, [1] total_reward_episode (np.float32 running sum where the reward is np.float32:
+     * int 0 + float32 -> float32, float32 + Python 0.0 -> float32; float64 for the line reward / default target), [2] unused,
+     * [3 + d] total_abs_noise_in_transition_episode[d]; st_last: the episode the latest reset() ended, [3 + D] its transitions */
+    double st[3 + ORA_MAX_DIM], st_last[4 + ORA_MAX_DIM];
     np_pcg64 env_rng;    /* self._np_random */
     np_pcg64 space_rng;  /* self.feature_space.np_random */
     int philox; uint64_t ph_seed, ph_env; uint64_t tick, reset_tick;
@@ -542,7 +576,13 @@ static double line_reward(ora_continuous *e) {
     return 0.0 + -total / (double)L;
 }
 
+void ora_c_get_stats(const ora_continuous *e, double *cur /* [3 + D] */, double *last /* [4 + D] */) {
+    for (int k = 0; k < 3 + e->D; k++) { cur[k] = e->st[k]; last[k] = e->st_last[k]; }
+    last[3 + e->D] = e->st_last[3 + e->D];
+}
 void ora_c_reset(ora_continuous *e, float *obs) {
+    for (int k = 0; k < 3 + e->D; k++) { e->st_last[k] = e->st[k]; e->st[k] = 0.0; }
+    e->st_last[3 + e->D] = (double)e->steps;
     for (int i = 0; i < e->delay; i++) { e->ring[i].v = 0.0; e->ring[i].is32 = 0; }
     const int bounded = isfinite(e->smax);
     const double lo = (double)(-e->smax32), range = (double)e->smax32 - (double)(-e->smax32);
@@ -599,6 +639,7 @@ void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
     /* C3: :1682-1691 (D normals from the env RNG, or float64 zeros) */
     for (int i = 0; i < D; i++) {
         double nz = e->has_p_noise ? 0.0 + e->p_noise * np_standard_normal(&e->env_rng) : 0.0;
+        e->st[3 + i] += fabs(nz);                        /* :1686 */
         nxt[i] = (float)((double)nxt[i] + nz);
     }
     /* C4: :1694-1717 */
@@ -654,8 +695,12 @@ void ora_c_step(ora_continuous *e, const float *a, float *obs, double *reward,
         r = out;
     }
     if (e->steps % e->every_n != 0) { r.v = 0.0; r.is32 = 0; }
+    /* :1985 */
+    if (e->line_L || (e->target64 && e->make_denser)) e->st[1] += r.v;
+    else if (r.is32) e->st[1] = (double)((float)e->st[1] + (float)r.v);
     if (e->has_r_noise) {
         double nz = 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+        e->st[0] += fabs(nz);                            /* :1984 */
         if (r.is32) r.v = (double)((float)r.v + (float)nz); else r.v = r.v + nz;
     }
     if (r.is32) {
@@ -696,9 +741,24 @@ void ora_c_rollout(ora_continuous *e, int T, const float *actions, const uint8_t
  * ==================================================================== */
 static long floordiv(long a, long b) { long q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) q--; return q; }
 
+static void i_draw_with(const ora_image_cfg *c, np_pcg64 *gp, int *R, int *cx, int *cy, int *angle, int *flip);
 void ora_i_draw(const ora_image_cfg *c, uint64_t rngw[6], int *R, int *cx, int *cy,
                 int *angle, int *flip) {
     np_pcg64 g; np_pcg64_load(&g, rngw);
+    i_draw_with(c, &g, R, cx, cy, angle, flip);
+    np_pcg64_store(&g, rngw);
+}
+/* Philox streams (the build's own): the transforms of the `n` images drawn at one tick -- the step's observation, one
+ * image per sub-space, then, where the step ended the episode, the images of reset()'s observation -- come in that order
+ * from stream (seed, env, tick, stream id): id 2 for steps, id 11 for an explicit reset() (keyed by the reset count).
+ * out: n rows of {R, cx, cy, angle, flip}. */
+void ora_i_draw_philox(const ora_image_cfg *c, uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, int n, int *out) {
+    np_pcg64 g;
+    np_philox_init(&g, seed, env, tick, stream);
+    for (int k = 0; k < n; k++) i_draw_with(c, &g, &out[5 * k], &out[5 * k + 1], &out[5 * k + 2], &out[5 * k + 3], &out[5 * k + 4]);
+}
+static void i_draw_with(const ora_image_cfg *c, np_pcg64 *gp, int *R, int *cx, int *cy, int *angle, int *flip) {
+    np_pcg64 g = *gp;
     int r = c->R0;
     *cx = (int)(c->W / 2.0); *cy = (int)(c->H / 2.0);
     if (c->has_scale) { /* :149-169 */
@@ -723,7 +783,7 @@ void ora_i_draw(const ora_image_cfg *c, uint64_t rngw[6], int *R, int *cx, int *
         if (np_integers(&g, 0, 2) == 0) *flip = (np_integers(&g, 0, 2) == 0) ? 1 : 2;
     }
     *R = r;
-    np_pcg64_store(&g, rngw);
+    *gp = g;
 }
 
 static double round15(double v) { /* Python round(v, 15) for |v| <= 1 */

@@ -66,6 +66,9 @@ def lib():
         L.ora_c_destroy.argtypes = [vp]
         L.ora_c_set_image_quirk.argtypes = [vp, i32]
         L.ora_c_set_target64.argtypes = [vp]
+        L.ora_c_get_stats.argtypes = [vp, vp, vp]
+        L.ora_d_get_stats.argtypes = [vp, vp, vp]
+        L.ora_g_get_stats.argtypes = [vp, vp, vp]
         L.ora_c_set_line_reward.argtypes = [vp, i32, LINE_FIT_FN]
         L.ora_ig_render.argtypes = [i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]
         L.ora_ic_render.argtypes = [i32, i32, i32, vp, i32, vp, C.c_float, vp, i32, vp, vp, vp]
@@ -80,6 +83,7 @@ def lib():
         L.ora_d_philox_explicit_reset.argtypes = [vp]
         L.ora_c_philox_explicit_reset.argtypes = [vp]
         L.ora_i_draw.argtypes = [vp] * 7
+        L.ora_i_draw_philox.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, i32, vp]
         L.ora_i_rotate_flip_transpose.argtypes = [i32, i32, vp, i32, i32, vp]
         for name in ("np_next64", "np_next32"):
             getattr(L, name).argtypes = [vp]
@@ -261,6 +265,14 @@ class DiscreteOracle:
         lib().ora_d_get_rng(self.h, _p(a), _p(b))
         return a, b
 
+    def get_stats(self):
+        """(current [3], last [4]): total_abs_noise_in_reward_episode, total_reward_episode,
+        total_noisy_transitions_episode of the running episode / of the episode the latest reset() ended (+ its
+        total_transitions_episode), rl_toy_env.py:2231-2247."""
+        cur, last = np.zeros(3), np.zeros(4)
+        lib().ora_d_get_stats(self.h, _p(cur), _p(last))
+        return cur, last
+
     def set_philox(self, seed, env_id, tick=0, reset_tick=0):
         self._philox = True
         lib().ora_d_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
@@ -353,6 +365,11 @@ class GridOracle:
         w = [np.zeros(6, np.uint64) for _ in range(3)]
         lib().ora_g_get_rng(self.h, _p(w[0]), _p(w[1]), _p(w[2]))
         return w
+
+    def get_stats(self):
+        cur, last = np.zeros(3), np.zeros(4)
+        lib().ora_g_get_stats(self.h, _p(cur), _p(last))
+        return cur, last
 
     def set_philox(self, seed, env_id, tick=0, reset_tick=0):
         self._philox = True
@@ -458,6 +475,12 @@ class ContinuousOracle:
         lib().ora_c_get_rng(self.h, _p(a), _p(b))
         return a, b
 
+    def get_stats(self):
+        """(current [3 + D], last [4 + D]): rows as mdpp_get_episode_stats (include/mdpp.h)."""
+        cur, last = np.zeros(3 + self.D), np.zeros(4 + self.D)
+        lib().ora_c_get_stats(self.h, _p(cur), _p(last))
+        return cur, last
+
     def set_philox(self, seed, env_id, tick=0, reset_tick=0):
         self._philox = True
         lib().ora_c_set_philox(self.h, int(seed), int(env_id), int(tick), int(reset_tick))
@@ -558,6 +581,13 @@ def image_grid_render(W, H, R, grid_shape, cells, target, terminal_cells):
     out = np.zeros(((G // 2) * W, H, 3), np.uint8)
     lib().ora_ig_render(W, H, R, _p(disc), G, _p(sh), _p(cells), _p(tg), len(tc), _p(tc), _p(lines), _p(out))
     return out
+
+
+def image_draw_philox(cfg, seed, env, tick, stream, n):
+    """Philox streams: the transforms (R, cx, cy, angle, flip) of the n images drawn at one tick, in order."""
+    out = np.zeros((n, 5), np.int32)
+    lib().ora_i_draw_philox(C.byref(cfg), int(seed), int(env), int(tick), int(stream), int(n), _p(out))
+    return [tuple(int(v) for v in row) for row in out]
 
 
 def image_draw(cfg, rng_words):

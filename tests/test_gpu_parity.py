@@ -1045,6 +1045,79 @@ def test_image_batch_vs_oracle(name):
     env.close(); twin.close()
 
 
+@pytest.mark.parametrize("name", ["cfg4", "all100", "irr"])
+def test_image_observations_on_philox_streams_vs_oracle(name):
+    """rng="philox" with polygon image observations (VERDICT r2 "missing"): the transforms of tick t come from stream
+    (seed, global env id, t, image) in the reference's draw order -- the step's images, then reset()'s where the step ended
+    the episode -- and an explicit reset() from its own stream keyed by the reset count.  Against the oracle's Philox
+    restatement + Pillow-exact rotation on 160 envs x 12 single steps (observations and terminal observations), then a
+    fused rollout == the same steps one by one; env ids offset, so the key is the GLOBAL id."""
+    from test_image_oracle import _cfg_struct
+    from oracle import oracle as ora
+    from mdp_playground_amd import image_obs, mdp
+    cfg = dict(IMG_CFGS[name], seed=9)
+    N, T, off = 160, 12, 5000
+    kw = dict(rng="philox", philox_seed=77, env_id_offset=off)
+    env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    m = mdp.build_mdp(cfg)
+    SUB = 2 if m.irrelevant else 1
+    tpl = image_obs.build_templates(max(m.S, m.S_irr) if m.irrelevant else m.S, m.image)
+    cs = _cfg_struct(m.image, tpl)
+
+    def render(state, xf):
+        R, cx, cy, angle, flip = xf
+        ri = R - tpl["r_min"]
+        tp = tpl["tpl"][state, ri, tpl["cls_x"][state, ri, cx], tpl["cls_y"][state, ri, cy]]
+        W, H, half = m.image["width"], m.image["height"], tpl["tpl_size"] // 2
+        src = np.zeros((H, W), np.uint8)
+        for ty in range(tpl["tpl_size"]):
+            y = ty - half + cy
+            if 0 <= y < H:
+                x0 = cx - half
+                lo, hi = max(0, -x0), min(tpl["tpl_size"], W - x0)
+                if lo < hi:
+                    src[y, x0 + lo:x0 + hi] = tp[ty, lo:hi]
+        return ora.image_rotate_flip_transpose(src, angle, flip)[:, :, None]
+
+    def render_obs(states, xfs):
+        return np.concatenate([render(int(s_), xf) for s_, xf in zip(np.atleast_1d(states), xfs)], axis=0)
+
+    # the constructor's reset(): explicit-reset stream (id 11), reset count 0
+    st0 = env.get_augmented_state()["curr_state"]
+    first = env._obs.cpu().numpy()
+    for i in range(0, N, 7):
+        xfs = ora.image_draw_philox(cs, 77, off + i, 0, 11, SUB)
+        assert np.array_equal(render_obs(st0[i], xfs), first[i]), (name, i)
+    acts = _img_actions(cfg, (T + 20, N), 4)
+    b = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    n_final = 0
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(torch.as_tensor(acts[t], device=env.device))
+        obs, fin, d = obs.cpu().numpy(), info["final_obs"].cpu().numpy(), term.cpu().numpy().astype(bool)
+        st = env.get_augmented_state()["curr_state"]
+        for i in range(0, N, 7):
+            xfs = ora.image_draw_philox(cs, 77, off + i, t, 2, 2 * SUB if d[i] else SUB)
+            if d[i]:
+                # the terminal observation's state is not exported: it is the terminal state (pair) whose rendering
+                # with the first SUB transforms equals final_obs
+                cands = [(s0,) for s0 in m.terminal_states] if SUB == 1 else \
+                        [(s0, s1) for s0 in m.terminal_states for s1 in range(m.S_irr)]
+                assert any(np.array_equal(render_obs(c, xfs[:SUB]), fin[i]) for c in cands), (name, t, i)
+                n_final += 1
+                assert np.array_equal(render_obs(st[i], xfs[SUB:]), obs[i]), (name, t, i)
+            else:
+                assert np.array_equal(render_obs(st[i], xfs), obs[i]), (name, t, i)
+    assert n_final > 10
+    # a fused rollout (batches of 16 steps) == single steps, on twin envs
+    o1 = env.rollout(torch.as_tensor(acts[T:], device=env.device))
+    for t in range(T):
+        b.step(torch.as_tensor(acts[t], device=b.device))
+    for k in range(20):
+        o, r, te, tr, _ = b.step(torch.as_tensor(acts[T + k], device=b.device))
+        assert torch.equal(o, o1[0][k]) and torch.equal(r, o1[1][k]) and torch.equal(te, o1[2][k]), (name, k)
+    env.close(); b.close()
+
+
 def test_cfg4_at_bench_size_fast_vs_general_renderer_and_oracle():
     """BASELINE configs[3] at ITS size: 8 192 envs x 32 fused steps = two pipelined batches of 16.  The
     persistent fast renderer leaves workgroup slots free for the next batch's state kernel as a function of the batch

@@ -108,3 +108,40 @@ def test_continuous_rollouts_bit_exact(name):
                 (name, e, t, r, g["reward"][e, t])
             if ra[t]:
                 assert np.array_equal(o.reset(), g["reset_obs"][e, t])
+
+
+@pytest.mark.parametrize("name", ["d_stats", "g_stats", "c_stats"])
+def test_episode_statistics_match_the_reference(name):
+    """The env object's per-episode noise statistics (total_abs_noise_in_reward_episode, total_reward_episode,
+    total_noisy_transitions_episode, total_abs_noise_in_transition_episode; logged at every reset() and cleared,
+    rl_toy_env.py:2231-2247, :2360-2369) after every step of reference-generated trajectories: float64 bit patterns,
+    and at every reset() the figures it logged (the oracle's `last`)."""
+    g = gu.load(name)
+    E, T = g["action"].shape[:2]
+    fresh = lambda s: ora.pcg_words(np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(s)))))  # noqa: E731
+    for e in range(E):
+        sd = g["seed_dict"][e]
+        if name.startswith("d_"):
+            o = gu.discrete_oracle_from_golden(name, g, e)
+            o.set_rng(fresh(sd[0]), g["rng_space"][e])
+        elif name.startswith("g_"):
+            o = gu.grid_oracle_from_golden(name)
+            o.set_rng(fresh(sd[0]), fresh(sd[5]), g["rng_action"][e])
+        else:
+            o = gu.continuous_oracle_from_golden(name)
+            o.set_rng(fresh(sd[0]), fresh(sd[5]))
+        o.reset()
+        ra = g["reset_after"][e]
+        for t in range(T):
+            o.step(g["action"][e, t] if not name.startswith("d_") else int(g["action"][e, t]))
+            cur, _ = o.get_stats()
+            want = g["stats"][e, t]
+            got = np.concatenate([cur[:3], [want[3]], cur[3:]]) if name.startswith("c_") else np.concatenate([cur, [want[3]]])
+            if name.startswith("c_"):
+                got[2] = want[2]                     # (noisy transitions: not kept for continuous envs; the reference leaves 0)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (name, e, t, got, want)
+            if ra[t]:
+                o.reset()
+                _, last = o.get_stats()
+                assert np.array_equal(last[:2], want[:2]) and last[-1] == want[3], (name, e, t)
+                assert not np.any(o.get_stats()[0])

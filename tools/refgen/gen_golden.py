@@ -222,6 +222,18 @@ CASES = {
                     target_radius=0.9, reward_every_n_steps=2, transition_noise=0.05, reward_noise=0.2,
                     action_loss_weight=0.1, reward_function="move_to_a_point"),
         seeds=list(range(4)), T=200, reset="mixed"),
+    # --- the env object's per-episode noise statistics (logged at every reset(), :2231-2247) recorded per step ------
+    "d_stats": dict(config=dict(CFG2N, reward_every_n_steps=2), seeds=list(range(4)), T=160, reset="mixed", stats=True),
+    "g_stats": dict(
+        config=dict(state_space_type="grid", grid_shape=(5, 7), reward_function="move_to_a_point",
+                    make_denser=True, target_point=[2, 3], transition_noise=0.3, reward_noise=0.2,
+                    reward_scale=1.5, term_state_reward=1.5),
+        seeds=list(range(4)), T=160, reset="mixed", stats=True),
+    "c_stats": dict(
+        config=dict(BASE_C, state_space_dim=4, irrelevant_features=False, relevant_indices=[0, 1, 2, 3],
+                    target_radius=1.5, state_space_max=4, transition_dynamics_order=2, time_unit=0.5,
+                    transition_noise=0.05, reward_noise=0.1, delay=1, reward_every_n_steps=2, reward_scale=2.0),
+        seeds=list(range(4)), T=160, reset="mixed", stats=True),
     # --- reward_function move_along_a_line: random actions, then the same
     # action repeated (the rewards of a straight walk are LAPACK-rounding-sized) -------------------
     "c_line_4d": dict(       # the env of the reference's test_continuous_dynamics_move_along_a_line
@@ -305,6 +317,11 @@ def run_case(name, case):
     T = case["T"]
     rec = {k: [] for k in ("obs", "reward", "done", "action", "reset_after",
                            "reset_obs", "curr_state")}
+    if case.get("stats"):
+        # the env object's per-episode noise statistics after every step (before any reset() of that step):
+        # total_abs_noise_in_reward_episode, total_reward_episode, total_noisy_transitions_episode,
+        # total_transitions_episode, [total_abs_noise_in_transition_episode per dimension] (:2360-2369)
+        rec["stats"] = []
     tables = {k: [] for k in ("P", "terminal_states", "init_dist", "rew_keys",
                               "rew_vals", "rng_env", "rng_space", "rng_image",
                               "init_obs", "init_state", "seed_dict", "sd",
@@ -409,6 +426,12 @@ def run_case(name, case):
             r["reward"].append(np.float64(rew))
             r["done"].append(bool(done))
             r["curr_state"].append(np.array(env.curr_state).copy())
+            if "stats" in rec:
+                row = [float(env.total_abs_noise_in_reward_episode), float(env.total_reward_episode),
+                       float(env.total_noisy_transitions_episode), float(env.total_transitions_episode)]
+                if kind == "continuous":
+                    row += [float(x) for x in env.total_abs_noise_in_transition_episode]
+                r["stats"].append(np.array(row, dtype=np.float64))
             if kind == "continuous":
                 sdrec.append(np.stack([np.array(x, dtype=np.float32)
                                        for x in env.state_derivatives]))
