@@ -382,7 +382,10 @@ def _build_discrete_custom(config) -> DiscreteMDP:
         raise NotImplementedError("use_custom_mdp with callables runs on the host only; the device "
                                   "path takes transition_function / reward_function as S x A arrays")
     if config.get("irrelevant_features", False):
-        raise NotImplementedError("use_custom_mdp with irrelevant_features is not built")
+        # the reference wraps the given state_space_size in a one-element list for custom MDPs (:586-587) and then reads
+        # state_space_size[1] for the irrelevant sub-space (:685): RLToyEnv.__init__ itself raises IndexError
+        raise IndexError("list index out of range (use_custom_mdp with irrelevant_features: the reference's constructor "
+                         "fails the same way, rl_toy_env.py:586-587 / :685)")
     sd, _env_rng = _seed_dict(config)
     common = _common(config, "discrete", sd)
     _require(isinstance(config["action_space_size"], int),

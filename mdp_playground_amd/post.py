@@ -13,8 +13,9 @@ consumed in the same order, so outputs are bit-identical to the reference's unde
     obs, reward = post.step(base_obs, base_reward, base_done)
 
 Differences from upstream, all documented in INTEGRATION.md: the `done` branch (:407-414) raises
-TypeError upstream (list * float); implemented is its numpy meaning.  Callable noise functions,
-Atari preprocessing and the nested irrelevant-features toy env are host-side composition, not here.
+TypeError upstream (list * float); implemented is its numpy meaning.  Callable noise functions and
+Atari preprocessing are host-side composition, not here; the nested irrelevant-features toy env is
+`IrrelevantToyEnvWrapper` below (two batched envs side by side on the device).
 """
 from __future__ import annotations
 
@@ -212,3 +213,63 @@ class VectorPostProcessor:
             self.close()
         except Exception:
             pass
+
+
+class IrrelevantToyEnvWrapper:
+    """The wrapper's nested irrelevant toy env (gym_env_wrapper.py:214-270, :378-396, :476-486): config key
+    "irrelevant_features" holds an RLToyEnv config; its env steps beside the wrapped env on the second part of every
+    action and contributes the second part of every observation -- nothing else (its reward and done are ignored, it is
+    only ever reset together with the wrapped env).  Batched: `env` is any batched env on the device with
+    reset(seed=None, mask=None) -> (obs, info) and step(actions) -> (obs, reward, terminated, truncated, info) -- e.g. an
+    RLToyVectorEnv with autoreset="disabled" -- and the toy env an `RLToyVectorEnv(num_envs, **irrelevant_features)`.
+
+    discrete (:379-383): actions int32 [N, 2] = (wrapped, toy); observations [N, 2]
+    continuous (:384-396): actions float32 [N, Da + Db], the first Da (`env_action_dim`) for the wrapped env;
+        observations [N, Do + Db], concatenated.
+    autoreset=True: instances whose wrapped env reports terminated | truncated are reset (both envs) in the same call,
+    the returned observation is the new episode's first (info["final_obs"]: the terminal one)."""
+
+    def __init__(self, env, num_envs, irrelevant_features, *, state_space_type, env_action_dim=None, autoreset=False,
+                 device=None, **toy_kwargs):
+        from .vector_env import RLToyVectorEnv
+        if state_space_type not in ("discrete", "continuous"):
+            raise ValueError("state_space_type must be 'discrete' or 'continuous'")
+        self.env, self.num_envs, self.continuous = env, int(num_envs), state_space_type == "continuous"
+        self.autoreset = bool(autoreset)
+        toy_kwargs.setdefault("autoreset", "disabled")            # it keeps stepping after its own `done` (:380, :391)
+        self.irr_toy_env = RLToyVectorEnv(num_envs=self.num_envs, device=device, **toy_kwargs, **irrelevant_features)
+        if self.continuous and env_action_dim is None:
+            raise ValueError("continuous: env_action_dim (action dimensions of the wrapped env) is needed")
+        self.env_action_dim = env_action_dim
+
+    def _join(self, o, o_irr):
+        if self.continuous:
+            return torch.cat((o, o_irr.to(o.dtype)), dim=1)
+        return torch.stack((o.to(torch.int64), o_irr.to(torch.int64)), dim=1)
+
+    def reset(self, seed=None, mask=None):
+        kw = {} if mask is None else {"mask": mask}
+        o, info = self.env.reset(seed=seed, **kw)
+        o_irr, info_irr = self.irr_toy_env.reset(seed=seed, **kw)
+        return self._join(o, o_irr), (info, info_irr)
+
+    def step(self, actions):
+        if self.continuous:
+            a0, a1 = actions[:, :self.env_action_dim].contiguous(), actions[:, self.env_action_dim:].contiguous()
+        else:
+            a0, a1 = actions[:, 0].contiguous(), actions[:, 1].contiguous()
+        o, r, term, trunc, info = self.env.step(a0)
+        o_irr, _, _, _, _ = self.irr_toy_env.step(a1)
+        obs = self._join(o, o_irr)
+        if self.autoreset:
+            ended = term | trunc
+            info = dict(info or {}, final_obs=obs)
+            if bool(ended.any()):
+                fresh, _ = self.reset(mask=ended)
+                obs = torch.where(ended.view(-1, *([1] * (obs.dim() - 1))), fresh, obs)
+        return obs, r, term, trunc, info
+
+    def close(self):
+        self.irr_toy_env.close()
+        if hasattr(self.env, "close"):
+            self.env.close()
