@@ -802,6 +802,14 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
         a.ptick = h->tick;
         a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     }
+    // move_along_a_line in its common shape: the dedicated rollout kernel (mdpp_continuous_line.hip)
+    if (launch_continuous_line(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
+        if (name_out) return MDPP_OK;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { h->err = std::string("k_continuous_line_rollout launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+        h->tick += (uint64_t)K;
+        return MDPP_OK;
+    }
 #define CALL_STEP(DM, OM) launch_step_t<DM, OM>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)
     MDPP_C_DISPATCH(CALL_STEP);
 #undef CALL_STEP

@@ -231,6 +231,8 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
+bool launch_continuous_line(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_states, const uint8_t *term,
                       const uint8_t *trunc, const uint8_t *mask, uint8_t *img_out, uint8_t *img_final, hipStream_t s);
 int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward, uint8_t *term,

@@ -639,6 +639,61 @@ def test_default_target_point_2048_envs_vs_oracle(rng, dense):
 
 
 @pytest.mark.parametrize("rng", ["numpy", "philox"])
+@pytest.mark.parametrize("shape", ["d4_o1_l10", "d2_o2_l16", "d4_o2_l3"])
+def test_line_rollout_kernel_vs_general_kernel_and_oracle(shape, rng):
+    """k_continuous_line_rollout (round 3: the line reward's common shape -- every dimension relevant, no noise, delay 0 --
+    with the window in LDS and its moments carried) against k_continuous_step (NO_CFAST) on EVERY env of 16 384: states,
+    flags, truncations and post-reset states bit-equal, rewards within 1e-6 (running moments against recomputed ones: a few
+    float64 ulps before the float32 rounding); launches of different lengths, state carried across them and handed between
+    the two kernels through the HBM history; a sample of envs against the oracle within the upstream tolerance."""
+    D, order, L = {"d4_o1_l10": (4, 1, 10), "d2_o2_l16": (2, 2, 16), "d4_o2_l3": (4, 2, 3)}[shape]
+    cfg = dict(state_space_type="continuous", state_space_dim=D, transition_dynamics_order=order, inertia=1, time_unit=0.5 if order == 2 else 1,
+               delay=0, sequence_length=L, reward_scale=1.5, reward_shift=0.25, action_space_max=1, state_space_max=6,
+               reward_function="move_along_a_line", seed=8)
+    N = 16384
+    kw = dict(rng="philox", philox_seed=29) if rng == "philox" else {}
+    a = _venv(num_envs=N, autoreset="same_step", max_episode_steps=37, **kw, **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", max_episode_steps=37, **kw, **cfg)
+    b.set_kernel_options("NO_CFAST")
+    assert a.rollout_kernel_name(64).startswith("k_continuous_line_rollout<") and b.rollout_kernel_name(64).startswith("k_continuous_step<")
+    g = torch.Generator(device=a.device)
+    g.manual_seed(3)
+    init = a._obs.cpu().numpy().copy()
+    all_acts, all_out = [], []
+    for j, K in enumerate((64, 7, 33, 50)):
+        acts = torch.rand((K, N, D), generator=g, device=a.device) * 2.4 - 1.2       # (some actions outside the box: "stay")
+        oa, ra, ta, tra = a.rollout(acts)
+        if j == 2:                        # hand the envs over: b runs this launch on the line kernel, a on the general one
+            a.set_kernel_options("NO_CFAST"); b.set_kernel_options()
+        ob, rb, tb, trb = b.rollout(acts)
+        if j == 2:
+            a.set_kernel_options(); b.set_kernel_options("NO_CFAST")
+        assert torch.equal(oa, ob) and torch.equal(ta, tb) and torch.equal(tra, trb), (shape, j)
+        assert float((ra - rb).abs().max()) <= 1e-6, (shape, j, float((ra - rb).abs().max()))
+        all_acts.append(acts.cpu().numpy()); all_out.append((oa.cpu().numpy(), ra.cpu().numpy(), tra.cpu().numpy()))
+    assert any(o[2].any() for o in all_out)
+    acts = np.concatenate(all_acts); obs = np.concatenate([o[0] for o in all_out]); rew = np.concatenate([o[1] for o in all_out])
+    trn = np.concatenate([o[2] for o in all_out])
+    for i in range(5, N, 1637):
+        o = _oracle_for(a, i)
+        if rng == "philox":
+            o.set_philox(29, i)
+        else:
+            o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i])
+        assert np.array_equal(o.reset(), init[i])
+        n = 0
+        for t in range(acts.shape[0]):
+            eo, er, _, ed = o.step(acts[t, i])
+            n += 1
+            if n >= 37:
+                assert trn[t, i]
+                eo = o.reset(explicit=False); n = 0
+            assert np.array_equal(np.asarray(eo).view(np.uint32), obs[t, i].view(np.uint32)), (shape, i, t)
+            assert abs(float(rew[t, i]) - er) <= LINE_ATOL * 1.5, (shape, i, t, rew[t, i], er)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
 def test_continuous_line_reward_1024_envs_vs_oracle(rng):
     """reward_function move_along_a_line on 1024 envs (5 relevant-of-6 dims would not fit: 3 of 6
     here), random walks with straight stretches, delay, reward noise, terminal hypercubes, same-step
