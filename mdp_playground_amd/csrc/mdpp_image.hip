@@ -69,6 +69,7 @@ struct ImageArgs {
     // Philox streams (round 3): the transforms of tick t come from stream (seed, global env id, t, MDPP_STREAM_IMAGE) in the
     // order the reference draws them (the step's images, then reset()'s where the step ended the episode); an explicit
     // reset() from stream kPhiloxResetImageStream keyed by the reset count
+    int32_t coldw;             // fast renderer: dwords of image columns per wave in LDS (host: the widest box + slack)
     int32_t philox, is_reset;
     uint64_t philox_seed, ptick;
     int64_t env_id_offset;
@@ -471,9 +472,12 @@ __device__ __forceinline__ void render_fast_store(const ImageArgs &a, const ColR
 template <int NST>
 __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, const ImgRec *__restrict__ rec,
                                                            uint8_t *__restrict__ img) {
-    __shared__ __align__(16) uint8_t lds[64 * 256];
-    __shared__ __align__(16) uint32_t lds_cols[kBlock / 64][kImgColDw];
+    // LDS, sized by the launch (round 3): tplp template rows of 256 B, then coldw dwords of image columns per wave -- for
+    // 84 x 84 images at R = 20 that is 14.25 + 4 x 4.4 KiB = 31.75 KiB, FIVE workgroups per CU where the fixed 16 + 24 KiB
+    // of rounds 1-2 allowed four: more waves whose evaluation and store phases interleave
+    extern __shared__ __align__(16) uint8_t lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;
     const int nw = (int)gridDim.x * (kBlock / 64);
     long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
     if (j >= M) return;
@@ -487,9 +491,9 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
         const RecRegs nxt = load_rec(rec + (more ? jn : j));
         const TplRegs tp = load_tpl(a, nxt.lo[7] >> 12, lane);
         ColRange cr{0, 0};
-        if (!skip) cr = render_fast_eval(a, cur, lds, lds_cols[wave], wave, lane);
+        if (!skip) cr = render_fast_eval(a, cur, lds, lds_col, wave, lane);
         stage_tpl(a, tp, lds, wave, lane);
-        if (!skip) render_fast_store<NST>(a, cr, lds_cols[wave], img + (size_t)j * isz, lane);
+        if (!skip) render_fast_store<NST>(a, cr, lds_col, img + (size_t)j * isz, lane);
         if (!more) break;
         j = jn; cur = nxt;
     }
@@ -549,22 +553,33 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         const long M = (long)K * a.N * a.SUB;
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
         if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST)) {
-            // 40 KiB of LDS per workgroup: 4 resident workgroups per CU
+            // LDS per workgroup: the template rows + four column buffers wide enough for the widest box (make_rec: at most
+            // 2 R + 13 columns) plus chunk-alignment slack; as many resident workgroups per CU as 160 KiB hold (at most 8)
+            const int span_dw = (2 * c.img_r_max + 13) * (c.img_h / 4) + 8;
+            a.coldw = (span_dw + 3) & ~3;
+            if (a.coldw > kImgColDw) a.coldw = kImgColDw;
+            const size_t lds_bytes = (size_t)a.tplp * 256 + (size_t)(kBlock / 64) * a.coldw * 4;
+            unsigned per_cu = (unsigned)((160u * 1024u) / ((lds_bytes + 511) & ~(size_t)511));
+            per_cu = per_cu < 1u ? 1u : (per_cu > 8u ? 8u : per_cu);
+#ifdef MDPP_IMG_WG_PER_CU
+            per_cu = MDPP_IMG_WG_PER_CU;
+#endif
+            // (the comment below: rounds 1-2 had 40 KiB per workgroup, 4 resident workgroups per CU)
             // (phase 2 = the pipelined rollout: a few CUs keep a slot free, so that the next batch's state
             // kernel, which needs a little LDS, can run beside this one)
             // as many slots as the state kernel has workgroups (measured on cfg4, 32 of them: 16 reserved
             // slots give no overlap at all, 32 and 64 the same +13 %, 128 less), at most 64
             unsigned reserve = ((unsigned)a.N + kBlock - 1) / kBlock;
             reserve = reserve < 8u ? 8u : (reserve > 64u ? 64u : reserve);
-            const unsigned resident = 4u * (unsigned)h->num_cus - (phase == 2 ? reserve : 0u);
+            const unsigned resident = per_cu * (unsigned)h->num_cus - (phase == 2 ? reserve : 0u);
             const dim3 grid(nblk < resident ? nblk : resident);
             const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);
             for (int pass = 0; pass < (img_final ? 2 : 1); pass++) {
                 const ImgRec *rec = pass ? a.rec1 : a.rec0;
                 uint8_t *img = pass ? img_final : img_out;
-                if (nst == 7) hipLaunchKernelGGL(k_image_obs_fast<7>, grid, dim3(kBlock), 0, s, a, M, rec, img);   // 84 x 84
-                else if (nst == 4) hipLaunchKernelGGL(k_image_obs_fast<4>, grid, dim3(kBlock), 0, s, a, M, rec, img); // 64 x 64
-                else hipLaunchKernelGGL(k_image_obs_fast<0>, grid, dim3(kBlock), 0, s, a, M, rec, img);
+                if (nst == 7) hipLaunchKernelGGL(k_image_obs_fast<7>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img);   // 84 x 84
+                else if (nst == 4) hipLaunchKernelGGL(k_image_obs_fast<4>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img); // 64 x 64
+                else hipLaunchKernelGGL(k_image_obs_fast<0>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img);
             }
         } else {
             const size_t lds = (size_t)per_block * (((size_t)a.tpl * a.tpl + 15) & ~(size_t)15);

@@ -57,8 +57,11 @@ def run(src, wname, rng, names):
                 "    best = min(best, env.timer_end() / 20)\n"
                 f"print({name!r}, env.rollout_kernel_name(F), '%.1f us per launch' % (best * 1e3), "
                 "'%.3f of 8 TB/s' % (wl['alg_bytes_fused'] * N * F / (best * 1e-3) / 8e12), flush=True)\n")
-        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        print(r.stdout.strip() if r.returncode == 0 else f"{name} FAILED: {r.stderr[-800:]}", flush=True)
+        try:                # (a variant that removes a producer role can spin to its bound on every step: give up after 2 minutes)
+            r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+            print(r.stdout.strip() if r.returncode == 0 else f"{name} FAILED: {r.stderr[-800:]}", flush=True)
+        except subprocess.TimeoutExpired:
+            print(f"{name} TIMED OUT after 120 s", flush=True)
         if name != "shipped":
             os.remove(so)
 
