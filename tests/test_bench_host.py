@@ -60,3 +60,71 @@ def test_live_traffic_is_skipped_inside_a_profiled_run(monkeypatch):
     monkeypatch.delenv("ROCPROFILER_OUTPUT_PATH")
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
     assert bench.live_traffic("cfg2", "numpy", 65536, 512) is None
+
+
+def test_live_traffic_all_splits_counter_rows_at_the_marker_dispatches(monkeypatch, tmp_path):
+    """bench.live_traffic_all: the two child rocprofv3 passes run every workload in ONE process with a marker dispatch
+    (k_philox_normals) after each; the counter rows, read in dispatch order, are split into one segment per workload,
+    mdpp:: kernels only, reset kernels excluded, FETCH_SIZE counted twice (gfx950), KB -> bytes per launch."""
+    import shutil
+    import subprocess
+    import types
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    for k in list(__import__("os").environ):
+        if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    specs = [("cfg2", "numpy", 65536, 512), ("cfg3", "numpy", 65536, 512)]
+    launches = 3
+
+    def fake_run(cmd, **kw):
+        counter = cmd[cmd.index("--pmc") + 1]
+        out = cmd[cmd.index("-d") + 1]
+        d = __import__("os").path.join(out, "host", "1234")
+        __import__("os").makedirs(d)
+        rows, did = [], 0
+
+        def row(name, val):
+            nonlocal did
+            did += 1
+            rows.append(f'{did},"{name}",{counter},{val}')
+        per = {"FETCH_SIZE": (100.0, 1000.0), "WRITE_SIZE": (400.0, 2000.0)}[counter]
+        for w in range(sum(1 for c in cmd if c.count(":") == 3)):                                  # one segment per workload spec
+            row("void mdpp::k_discrete_reset<false>(mdpp::DiscreteArgs)", 5.0)              # constructor reset: excluded
+            row("void at::native::vectorized_elementwise_kernel<4>(int)", 77.0)             # torch kernel: excluded
+            for _ in range(launches):
+                row(("void mdpp::k_discrete_rollout_lean<true>(mdpp::DiscreteArgs, int)", "void mdpp::k_continuous_rollout_fast<12, 1>(mdpp::ContinuousArgs)")[w], per[w])
+            row("mdpp::k_philox_normals(unsigned long, long)", 0.0)                         # the marker
+        with open(__import__("os").path.join(d, "1234_counter_collection.csv"), "w") as f:
+            f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n" + "\n".join(reversed(rows)) + "\n")   # (file order != dispatch order)
+        return types.SimpleNamespace(returncode=0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    res = bench.live_traffic_all(specs, launches=launches)
+    assert set(res) == {"cfg2", "cfg3"}
+    assert res["cfg2"]["bytes_per_launch"] == int((2 * 100.0 + 400.0) * 1024)
+    assert res["cfg3"]["bytes_per_launch"] == int((2 * 1000.0 + 2000.0) * 1024)
+    assert "k_discrete_rollout_lean" in res["cfg2"]["kernels"] and "reset" not in res["cfg2"]["kernels"]
+    one = bench.live_traffic("cfg2", "numpy", 65536, 512, launches=launches)
+    assert one[0] == res["cfg2"]["bytes_per_launch"]
+
+
+def test_action_rotation_is_larger_than_the_infinity_cache():
+    """>= 4 distinct tensors, >= 512 MiB together, capped at 32 tensors (sizes only: the tensors need a device)."""
+    import torch
+    made = []
+
+    def fake_make(wl, K, N, device, seed):
+        made.append(seed)
+        return torch.empty(0, dtype=torch.int32).new_empty((K, N), device="meta")
+    import pytest
+    mp = pytest.MonkeyPatch()
+    mp.setattr(bench, "make_actions", fake_make)
+    try:
+        a = bench.action_rotation(bench.WORKLOADS["cfg2"], 512, 65536, "meta", 7)
+        assert len(a) == 4 and len(set(made)) == 4 and sum(x.numel() * 4 for x in a) >= 512 << 20
+        made.clear()
+        a = bench.action_rotation(bench.WORKLOADS["cfg4"], 512, 8192, "meta", 7)
+        assert len(a) == 32 and len(set(made)) == 32
+    finally:
+        mp.undo()
+    assert bench.leg_name("cfg5", "philox") == "cfg5_philox" and bench.leg_name("cfg2", "numpy") == "cfg2"
