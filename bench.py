@@ -324,13 +324,16 @@ def self_launch(args, argv):
     raise SystemExit(r.returncode)
 
 
-def init_collective(device, world, no_collective):
+def init_collective(device, world, no_collective, backend="nccl"):
     """The process group of the run: RCCL (backend "nccl").  Launched by torch.distributed.run it joins that
     job; a plain one-GPU run makes a ONE-rank group of its own, so that N = 1 times the same code path
     (launch + all-gather on a side stream) as N > 1 and a 1 -> 8 curve compares like with like."""
     if no_collective:
         return None, "disabled (--no-collective)"
     import torch.distributed as dist
+    if backend == "gloo":               # (tests: several ranks on ONE GPU, the rank logic of the multi-rank path)
+        dist.init_process_group(backend="gloo")
+        return dist, None
     try:
         # the collectives' stream at high priority: its hardware queue is then not one the launch stream can share
         # (streams of one priority are spread over a few hardware queues; a shared queue serialises gather and launch)
@@ -376,6 +379,8 @@ def main():
     ap.add_argument("--no-collective", action="store_true", help="one-GPU runs: no RCCL group, `value` = the leg without a collective")
     ap.add_argument("--no-workloads", action="store_true", help="skip the legs of the other BASELINE configs (`workloads`)")
     ap.add_argument("--workload-steps", type=int, default=10, help="timed launches of each `workloads` leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only for tests that run several ranks on one GPU (RCCL is the product path)")
     ap.add_argument("--full-gather-steps", type=int, default=4,
                     help="bench steps of the [K, N_local, ...] all-gather leg (0 = skip)")
     args = ap.parse_args()
@@ -404,9 +409,10 @@ def main():
         specs = [(args.workload, args.rng, N, F)] + [
             (w, r, WORKLOADS[w]["envs"], max(1, min(args.fuse, WORKLOADS[w].get("fuse_max", args.fuse)))) for w, r in extra]
         pmc = live_traffic_all(specs)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist, no_coll_why = init_collective(device, world, args.no_collective)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist, no_coll_why = init_collective(device, world, args.no_collective, args.backend)
 
     from mdp_playground_amd import RLToyVectorEnv
     from mdp_playground_amd.dist import ObsGatherer
@@ -489,8 +495,9 @@ def main():
                             "host_enqueue_s": host_enqueue[0],
                             "bytes_per_rank_per_launch": g_last[0].local.numel() * g_last[0].local.element_size()}
         elapsed = el_last
-        collective = ("all_gather_into_tensor (RCCL, %d rank%s, async_op) of the current observation shard after every "
-                      "launch, on the backend's high-priority stream beside the next launch" % (dist.get_world_size(), "" if world == 1 else "s"))
+        collective = ("all_gather_into_tensor (%s, %d rank%s, async_op) of the current observation shard after every "
+                      "launch, on the backend's high-priority stream beside the next launch"
+                      % ("RCCL" if args.backend == "nccl" else args.backend, dist.get_world_size(), "" if world == 1 else "s"))
         del g_last
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()

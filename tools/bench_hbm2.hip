@@ -127,6 +127,44 @@ __global__ void k_full3(const int32_t *act, uint64_t *obs, float *rew, uint8_t *
     }
 }
 
+// the same again in the code shape of k_full2 (plain int prefetch registers): WIDE = one wave of the block fetches the whole
+// 1 KiB action row (16 B per lane), the other three waves load nothing
+template <int PRE, bool WIDE>
+__global__ void k_full4(const int32_t *act, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = (uint32_t)i;
+    typedef int v4 __attribute__((ext_vector_type(4)));
+    int pre[PRE]; v4 prew[PRE];
+    const bool loader = threadIdx.x < 64;
+    const v4 *row0 = (const v4 *)(act + blockIdx.x * 256) + (threadIdx.x & 63);
+#pragma unroll
+    for (int u = 0; u < PRE; u++) {
+        if (WIDE) { prew[u] = v4{0, 0, 0, 0}; if (loader) prew[u] = *(const v4 *)((const int *)row0 + (size_t)u * N); pre[u] = 0; }
+        else pre[u] = act[(size_t)u * N + i];
+    }
+    for (int k0 = 0; k0 < K; k0 += PRE) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) {
+            const int k = k0 + u;
+            const size_t o = (size_t)k * N + i;
+            int a;
+            const int kn = k + PRE < K ? k + PRE : K - 1;
+            if (WIDE) {
+                a = prew[u].x ^ prew[u].y ^ prew[u].z ^ prew[u].w;
+                if (loader) prew[u] = *(const v4 *)((const int *)row0 + (size_t)kn * N);
+            } else {
+                a = pre[u];
+                pre[u] = act[(size_t)kn * N + i];
+            }
+            s = s * 1664525u + 1013904223u + (uint32_t)a;
+            __builtin_nontemporal_store((uint64_t)(s & 7u), obs + o);
+            __builtin_nontemporal_store((float)(s >> 31), rew + o);
+            __builtin_nontemporal_store((uint8_t)((s >> 8) & 1u), term + o);
+            __builtin_nontemporal_store((uint8_t)((s >> 9) & 1u), trunc + o);
+        }
+    }
+}
+
 template <int MODE>
 void run(const char *name, uint64_t *obs, float *rew, uint8_t *term, uint8_t *trunc, double bytes_per) {
     const int N = 65536, K = 512, reps = 10;
@@ -212,6 +250,32 @@ int main() {
             }
             printf("bare pattern (nt stores, rotating actions): %s reads, %s loads   %8.1f GB/s  %7.1f us per 512-step launch\n",
                    (variant & 2) ? "16 B per lane of one wave" : "4 B per lane", (variant & 1) ? "nt" : "plain",
+                   18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
+        }
+    }
+    {
+        const int N = 65536, K = 512, reps = 12, NA = 4;
+        int32_t *acts[NA];
+        for (int q = 0; q < NA; q++) { hipMalloc(&acts[q], n * 4); hipMemset(acts[q], 1 + q, n * 4); }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int round = 0; round < 2; round++)
+        for (int variant = 0; variant < 4; variant++) {
+            float ms = 0;
+            for (int w = 0; w < 2; w++) {
+                hipEventRecord(e0);
+                for (int r = 0; r < reps; r++) {
+                    const int32_t *a = acts[r % NA];
+                    switch (variant) {
+                    case 0: hipLaunchKernelGGL((k_full4<8, false>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    case 1: hipLaunchKernelGGL((k_full4<8, true>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    case 2: hipLaunchKernelGGL((k_full4<16, false>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    default: hipLaunchKernelGGL((k_full4<16, true>), dim3(N / 256), dim3(256), 0, 0, a, obs, rew, term, trunc, N, K); break;
+                    }
+                }
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("bare pattern 4 (nt stores, rotating actions): %-28s %2d ahead   %8.1f GB/s  %7.1f us per 512-step launch\n",
+                   (variant & 1) ? "16 B per lane of one wave" : "4 B per lane", variant >= 2 ? 16 : 8,
                    18.0 * N * K * reps / 1e9 / (ms / 1e3), ms * 1e3 / reps);
         }
     }
