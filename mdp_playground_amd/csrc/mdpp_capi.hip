@@ -88,8 +88,6 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         return fail(nullptr, MDPP_EINVAL, "mdpp_create: need delay >= 0 and reward_every_n_steps >= 1");
     if (cfg->autoreset < MDPP_AUTORESET_DISABLED || cfg->autoreset > MDPP_AUTORESET_NEXT_STEP)
         return fail(nullptr, MDPP_EINVAL, "mdpp_create: unknown autoreset mode");
-    if (cfg->autoreset == MDPP_AUTORESET_NEXT_STEP && cfg->image)
-        return fail(nullptr, MDPP_EUNSUPPORTED, "mdpp_create: next-step autoreset is not available with image observations");
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess)
         return fail(nullptr, MDPP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));

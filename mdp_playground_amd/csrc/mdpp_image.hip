@@ -517,7 +517,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.ro_quant = c.img_ro_quant > 0 ? c.img_ro_quant : 1;
     a.r0 = c.img_r0; a.r_min = c.img_r_min; a.r_max = c.img_r_max; a.tpl = c.img_tpl_size;
     a.n_radii = h->img_n_radii; a.n_cls_x = h->img_n_cls_x; a.n_cls_y = h->img_n_cls_y;
-    a.autoreset = c.autoreset;
+    a.autoreset = c.autoreset == MDPP_AUTORESET_SAME_STEP;   // (next-step: a reset call draws one observation like any step)
     a.log_min_r = c.img_log_min_r; a.log_max_r = c.img_log_max_r;
     a.tpl_data = (const uint8_t *)h->d_img_tpl; a.cls_x = (const int16_t *)h->d_img_clsx;
     a.cls_y = (const int16_t *)h->d_img_clsy; a.rot = (const int32_t *)h->d_img_rot;

@@ -162,14 +162,6 @@ def test_reset_pending_refused_without_next_step_autoreset():
     env.close()
 
 
-def test_next_step_refused_with_images():
-    from mdp_playground_amd import _capi as capi
-    cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
-               image_representations=True, image_width=32, image_height=32, seed=0)
-    with pytest.raises(capi.MdppError):
-        _venv(num_envs=8, autoreset="next_step", **cfg)
-
-
 def test_seed_returns_seed_and_reseeds_env_streams():
     """seed(s) -> s (rl_toy_env.py:2379-2406); env i continues from PCG64(SeedSequence(s + i))."""
     from mdp_playground_amd import mdp as mdp_mod

@@ -1354,6 +1354,138 @@ def test_grid_image_fused_equals_single_steps_and_oracle():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+@pytest.mark.parametrize("name", ["cfg4", "all100", "irr84"])
+def test_polygon_images_with_next_step_autoreset_vs_oracle(name, rng):
+    """gymnasium's next-step autoreset with polygon image observations: the call after an episode's last step is reset()
+    alone -- it draws ONE observation's transforms from the image stream like any step (reset() -> get_image_representation,
+    rl_toy_env.py:2237; image_multi_discrete.py:272-288), reward 0, flags False, no terminal observation.  160 envs x 14
+    single steps against the oracle's draw + Pillow-exact rotation, then a fused rollout == the same steps one by one."""
+    from test_image_oracle import _render_obs, _cfg_struct
+    from oracle import oracle as ora
+    from mdp_playground_amd import _capi as capi, image_obs, mdp
+    cfg = dict(IMG_CFGS[name], seed=9)
+    N, T = 160, 14
+    kw = dict(rng="philox", philox_seed=31, env_id_offset=700) if rng == "philox" else {}
+    env = _venv(num_envs=N, autoreset="next_step", **kw, **cfg)
+    b = _venv(num_envs=N, autoreset="next_step", **kw, **cfg)
+    m = mdp.build_mdp(cfg)
+    SUB = 2 if m.irrelevant else 1
+    tpl = image_obs.build_templates(max(m.S, m.S_irr) if m.irrelevant else m.S, m.image)
+    words = env.get_rng_streams(capi.STREAM_IMAGE).copy() if rng == "numpy" else None
+    acts = _img_actions(cfg, (T + 20, N), 4)
+    pending = np.zeros(N, bool)
+    n_reset = 0
+    if rng == "philox":
+        cs = _cfg_struct(m.image, tpl)
+        W, H, ts = m.image["width"], m.image["height"], tpl["tpl_size"]
+
+        def render(state, xf):
+            R, cx, cy, angle, flip = xf
+            ri = R - tpl["r_min"]
+            tp = tpl["tpl"][state, ri, tpl["cls_x"][state, ri, cx], tpl["cls_y"][state, ri, cy]]
+            src = np.zeros((H, W), np.uint8)
+            for ty in range(ts):
+                y = ty - ts // 2 + cy
+                x0 = cx - ts // 2
+                lo, hi = max(0, -x0), min(ts, W - x0)
+                if 0 <= y < H and lo < hi:
+                    src[y, x0 + lo:x0 + hi] = tp[ty, lo:hi]
+            return ora.image_rotate_flip_transpose(src, angle, flip)[:, :, None]
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(torch.as_tensor(acts[t], device=env.device))
+        assert "final_obs" not in info
+        obs, rew, d = obs.cpu().numpy(), rew.cpu().numpy(), (term | trunc).cpu().numpy().astype(bool)
+        assert not d[pending].any() and not rew[pending].any()             # a reset call: reward 0, flags False
+        n_reset += int(pending.sum())
+        st = env.get_augmented_state()["curr_state"]
+        for i in range(0, N, 3 if rng == "numpy" else 7):
+            if rng == "numpy":
+                assert np.array_equal(_render_obs(m.image, tpl, st[i], words[i]), obs[i]), (name, t, i)
+            else:
+                xfs = ora.image_draw_philox(cs, 31, 700 + i, t, 2, SUB)
+                pic = np.concatenate([render(int(s_), xf) for s_, xf in zip(np.atleast_1d(st[i]), xfs)], axis=0)
+                assert np.array_equal(pic, obs[i]), (name, t, i)
+        pending = d
+    assert n_reset > 10
+    if rng == "numpy":
+        got = env.get_rng_streams(capi.STREAM_IMAGE)
+        assert np.array_equal(words[::3], got[::3])
+    # fused (batches of 16 steps) == single steps
+    for t in range(T):
+        b.step(torch.as_tensor(acts[t], device=b.device))
+    o1, r1, t1, _ = env.rollout(torch.as_tensor(acts[T:], device=env.device))
+    for k in range(20):
+        o, r, te, tr, _ = b.step(torch.as_tensor(acts[T + k], device=b.device))
+        assert torch.equal(o, o1[k]) and torch.equal(r, r1[k]) and torch.equal(te, t1[k]), (name, k)
+    env.close(); b.close()
+
+
+def test_continuous_and_grid_images_with_next_step_autoreset_vs_oracle():
+    """The same mode for the continuous and the grid pictures (no image stream there): the picture of a reset call is the
+    new episode's start state's."""
+    from oracle import oracle as ora
+    cfg = dict(state_space_type="continuous", state_space_dim=4, relevant_indices=[0, 1],
+               transition_dynamics_order=1, inertia=1.0, time_unit=1.0, state_space_max=4, action_space_max=1,
+               make_denser=True, target_point=[1.5, -2.0], target_radius=0.7,
+               terminal_states=[[-2.0, 2.0], [3.0, 0.0]], term_state_edge=1.5, transition_noise=0.1,
+               reward_function="move_to_a_point", image_representations=True, image_width=64, image_height=80, seed=4)
+    N, K = 256, 40
+    a = _venv(num_envs=N, autoreset="next_step", **cfg)
+    acts = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, size=(K, N, 4)).astype(np.float32), device=a.device)
+    obs, rew, term, trunc = a.rollout(acts)
+    obs_h, term_h, rew_h, acts_h = obs.cpu().numpy(), term.cpu().numpy(), rew.cpu().numpy(), acts.cpu().numpy()
+    m = a.mdps[0]
+    n_reset = 0
+    for i in range(0, N, 4):
+        o = _oracle_for(a, i)
+        o.set_image_quirk(True)
+        o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i])
+        o.reset()
+        pend = False
+        for t in range(K):
+            if pend:
+                st, r, d = o.reset(), 0.0, False
+                n_reset += 1
+            else:
+                st, r, is32, d = o.step(acts_h[t, i])
+            assert d == bool(term_h[t, i]) and np.float32(r) == rew_h[t, i], (i, t)
+            pic = ora.image_continuous_render(64, 80, 5, st, 4.0, cfg["target_point"], m.box_lo, m.box_hi)
+            assert np.array_equal(pic, obs_h[t, i]), (i, t)
+            pend = d
+    assert n_reset > 10
+    a.close()
+    cfg = dict(state_space_type="grid", grid_shape=(6, 5), reward_function="move_to_a_point", make_denser=True,
+               target_point=[2, 3], irrelevant_features=True, transition_noise=0.2, terminal_states=[[0, 0], [5, 4]],
+               image_representations=True, image_width=48, image_height=64, seed=8)
+    N, K = 192, 40
+    a = _venv(num_envs=N, autoreset="next_step", **cfg)
+    r = np.random.default_rng(6)
+    acts = np.zeros((K, N, 4), np.int32)
+    np.put_along_axis(acts, r.integers(0, 4, size=(K, N, 1)), r.integers(-1, 2, size=(K, N, 1)).astype(np.int32), axis=2)
+    obs, rew, term, trunc = a.rollout(torch.as_tensor(acts, device=a.device))
+    obs_h, term_h = obs.cpu().numpy(), term.cpu().numpy()
+    m = a.mdps[0]
+    n_reset = 0
+    for i in range(0, N, 6):
+        o = _oracle_for(a, i)
+        o.set_rng(a.seeded_streams[0][i], a.seeded_streams[1][i], a.seeded_streams[4][i])
+        o.reset()
+        pend = False
+        for t in range(K):
+            if pend:
+                st, d = o.reset(), False
+                n_reset += 1
+            else:
+                st, r_, d = o.step(acts[t, i])
+            assert d == bool(term_h[t, i]), (i, t)
+            pic = ora.image_grid_render(48, 64, 5, m.grid_shape, st, cfg["target_point"], cfg["terminal_states"])
+            assert np.array_equal(pic, obs_h[t, i]), (i, t)
+            pend = d
+    assert n_reset > 5
+    a.close()
+
+
 # ----------------------------------------------------------------------------- BASELINE full sizes
 def _cfg(name, seed):
     return dict(gu.CASES[name]["config"], seed=seed)
