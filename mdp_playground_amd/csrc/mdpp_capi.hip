@@ -124,7 +124,6 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     TRYHIP(hipEventCreate(&h->ev1));
     TRY(alloc_zero(h, &h->d_status, N * sizeof(uint32_t)));
     if (cfg->episode_stats) {       // per-episode noise statistics (EpisodeStatsDev): running episode + the one a reset() ended
-        if (cfg->image) { g_create_err = "mdpp_create: episode_stats with image observations is not built"; free_all(h); delete h; return MDPP_EUNSUPPORTED; }
         h->est_nk = 3 + (cfg->kind == MDPP_KIND_CONTINUOUS ? cfg->D : 0);
         TRY(alloc_zero(h, &h->d_est_cur, (size_t)h->est_nk * N * sizeof(double)));
         TRY(alloc_zero(h, &h->d_est_last, (size_t)(h->est_nk + 1) * N * sizeof(double)));

@@ -40,6 +40,8 @@ def centre_range(params, R, size):
         return [c0]
     m = size / 2 - R
     lo, hi = int(-m + 1), int(m)            # Generator.integers truncates float bounds toward 0
+    if lo >= hi:                            # (the reference's Generator.integers(low, high) raises ValueError: low >= high)
+        raise ValueError(f"image transform 'shift': a polygon of radius {R} leaves no shift inside {size} pixels")
     q = params["sh_quant"]
     return sorted({c0 + (v // q) * q for v in range(lo, hi)})
 

@@ -469,3 +469,63 @@ def test_episode_stats_fused_rollout_vs_oracle(name, rng):
     env.close()
     with pytest.raises(Exception):
         _venv(num_envs=8, **cfg).get_episode_stats()
+
+
+def test_episode_stats_with_image_observations():
+    """episode_stats on handles with image observations (the state kernel of every batch keeps them): a polygon-image env and
+    a grid-picture env hold the statistics of their integer-observation twins, a continuous-picture env the oracle's (with
+    the reference's image-mode clipping, rl_toy_env.py:1601-1622), through fused rollouts with same-step autoreset."""
+    T = 40
+    dcfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
+                delay=1, sequence_length=2, reward_density=0.25, terminal_state_density=0.25, transition_noise=0.2,
+                reward_noise=0.5, seed=12)
+    gcfg = dict(state_space_type="grid", grid_shape=(6, 5), reward_function="move_to_a_point", make_denser=True,
+                target_point=[2, 3], transition_noise=0.2, terminal_states=[[0, 0], [5, 4]], seed=8)
+    for cfg, img in ((dcfg, dict(image_representations=True, image_width=64, image_height=64, image_transforms="shift,rotate")),
+                     (gcfg, dict(image_representations=True, image_width=48, image_height=64))):
+        N = 512
+        a = _venv(num_envs=N, autoreset="same_step", max_episode_steps=17, episode_stats=True, **cfg, **img)
+        b = _venv(num_envs=N, autoreset="same_step", max_episode_steps=17, episode_stats=True, **cfg)
+        acts = torch.as_tensor(_rand_actions(b, T, np.random.default_rng(2)), device=a.device)
+        ra, rb = a.rollout(acts), b.rollout(acts)
+        assert torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2]) and ra[2].any()
+        sa, sb = a.get_episode_stats(), b.get_episode_stats()
+        for k in sb:
+            if k == "last_episode":
+                for k2 in sb[k]:
+                    assert np.array_equal(np.asarray(sa[k][k2]).view(np.uint64), np.asarray(sb[k][k2]).view(np.uint64)), (k, k2)
+            else:
+                assert np.array_equal(np.asarray(sa[k]).view(np.uint64), np.asarray(sb[k]).view(np.uint64)), k
+        assert np.asarray(sb["last_episode"]["total_transitions_episode"]).any()
+        a.close(); b.close()
+    ccfg = dict(state_space_type="continuous", state_space_dim=4, relevant_indices=[0, 1], transition_dynamics_order=2,
+                inertia=1.0, time_unit=1.0, state_space_max=4, action_space_max=1, make_denser=True,
+                target_point=[1.5, -2.0], target_radius=0.7, terminal_states=[[-2.0, 2.0], [3.0, 0.0]], term_state_edge=1.5,
+                transition_noise=0.1, reward_noise=0.05, reward_function="move_to_a_point", image_representations=True,
+                image_width=32, image_height=40, seed=4)
+    N = 256
+    env = _venv(num_envs=N, autoreset="same_step", max_episode_steps=17, episode_stats=True, **ccfg)
+    acts = _rand_actions(env, T, np.random.default_rng(6))
+    obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(torch.as_tensor(acts, device=env.device)))
+    st = env.get_episode_stats()
+    cur, last = _stats_rows(st, "continuous", 4), _stats_rows(st["last_episode"], "continuous", 4)
+    assert term.any()
+    for i in range(0, N, 5):
+        o = _oracle_for(env, i)
+        o.set_image_quirk(True)
+        _set_oracle_streams(env, o, i)
+        o.reset()
+        n = 0
+        for t in range(T):
+            _, er, ed = _oracle_step(o, "continuous", acts[t, i])
+            n += 1
+            assert np.float32(er) == rew[t, i] and bool(ed) == bool(term[t, i]), (i, t)
+            if ed or n >= 17:
+                o.reset(explicit=False)
+                n = 0
+        oc, ol = o.get_stats()
+        want_cur = np.concatenate([oc[:2], [0.0], [n], oc[3:]])
+        want_last = np.concatenate([ol[:2], [0.0], [ol[-1]], ol[3:-1]])
+        assert np.array_equal(cur[i].view(np.uint64), want_cur.view(np.uint64)), (i, cur[i], want_cur)
+        assert np.array_equal(last[i].view(np.uint64), want_last.view(np.uint64)), (i, last[i], want_last)
+    env.close()

@@ -160,3 +160,12 @@ def test_oracle_grid_images_match_reference(name):
 def test_grid_line_mask_host_equals_oracle_helper():
     for shape in [(8, 8), (4, 6, 4, 6)]:
         assert np.array_equal(image_obs.grid_line_mask(96, 80, list(shape)), ora.grid_line_mask(96, 80, list(shape)))
+
+
+def test_shift_with_a_polygon_wider_than_the_image_raises_like_the_reference():
+    """shift draws np_random.integers(-(W/2 - R) + 1, W/2 - R) (image_multi_discrete.py:172-175): with the default radius 20
+    in a 32-pixel image low >= high and the reference's first observation raises ValueError; so does the template builder."""
+    m = mdp.build_mdp(dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
+                           image_representations=True, image_width=32, image_height=32, image_transforms="shift", seed=0))
+    with pytest.raises(ValueError, match="shift"):
+        image_obs.build_templates(m.S, m.image)
