@@ -215,6 +215,9 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.every_n = cfg->every_n; a.shared_tables = (cfg->num_tables == 1); a.unit_rewards = cfg->unit_rewards;
         a.rew_sa = rew_sa ? 1 : 0;
         a.has_p_noise = cfg->has_transition_noise; a.has_r_noise = cfg->has_reward_noise;
+        a.pn_T = cfg->has_transition_noise ? philox_pnoise_threshold(cfg->transition_noise) : 0u;
+        a.pn_M = philox_pnoise_magic(a.pn_T, (uint32_t)cfg->S);
+        a.pn_M1 = cfg->irrelevant ? philox_pnoise_magic(a.pn_T, (uint32_t)cfg->S_irr) : 0ull;
         a.autoreset = cfg->autoreset; a.max_steps = cfg->max_episode_steps;
         a.obs_i32 = (cfg->obs_dtype == MDPP_OBS_I32 || cfg->image);
         a.philox = (cfg->rng_mode == MDPP_RNG_PHILOX);

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     // and by every in-kernel reset(); with 2 of 8 states terminal some lane of a wave resets on
     // almost every step, so it is loaded up front rather than inside the divergent branch.
     Pcg64 env_pcg, sp_pcg, sp1_pcg;
-    Philox env_phx, sp_phx, sp1_phx;
+    PhiloxTickWords pn_w, pn_w1;           // Philox streams: the current four ticks' noise words / normals (mdpp_rng.hpp)
+    PhiloxTickNormals rn_z;
+    const uint64_t genv = (uint64_t)(a.env_id_offset + i);
     const bool use_env = (NOISE && a.has_r_noise) || a.autoreset;
     const bool use_sp = NOISE && a.has_p_noise;
     if (!PHILOX) {
@@ -175,11 +177,6 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             const uint64_t ptick = a.ptick + (uint64_t)k;
             const long o = (long)k * N + i;
             int action = act[u];
-            if (PHILOX) {
-                env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_ENV);
-                sp_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_SPACE);
-                if (IRR) sp1_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, kPhiloxIrrStream);
-            }
             if (pending) {           // next-step autoreset: this call is the env's reset(), :2250-2278
                 uint32_t s0;
                 if (PHILOX) {        // one word of the start-state streams per tick (mdpp_rng.hpp)
@@ -212,10 +209,11 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             const uint32_t cur = (uint32_t)hist & 0xFFu;
             uint32_t nxt = t.P[cur * A + action];                                   // D1
             if (NOISE && a.has_p_noise) {                                           // D2
-                // (Philox streams: the P-noise uniform is the env stream's FIRST 64-bit draw of the tick and the reward normal its
-                //  second -- both halves of one block; numpy streams: the state space's own generator, as in the reference)
-                double uu = PHILOX ? np_random(env_phx) : np_random(sp_pcg);
-                const uint32_t noisy = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, uu);
+                // (Philox streams: one word of the tick decides "noisy" and which other state, mdpp_rng.hpp philox_pnoise_*;
+                //  numpy streams: the state space's own generator and the categorical's cdf, as in the reference)
+                uint32_t noisy;
+                if (PHILOX) noisy = philox_pnoise_state(pn_w.word(a.philox_seed, genv, ptick, kPhiloxPNoiseStream), a.pn_T, a.pn_M, nxt);
+                else noisy = (uint32_t)searchsorted_right(t.noise_cdf + (size_t)nxt * S, S, np_random(sp_pcg));
                 if (a.est.cur && noisy != nxt) est_add(a.est, N, i, 2, 1.0);        // total_noisy_transitions_episode, :1620
                 nxt = noisy;
             }
@@ -243,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (a.est.cur && bit) est_add(a.est, N, i, 1, 1.0);                 // total_reward_episode, :1985
                 if (NOISE && a.has_r_noise) {
                     double r = bit ? 1.0 : 0.0;
-                    const double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                    const double nz = 0.0 + a.r_noise * (PHILOX ? (double)rn_z.normal(a.philox_seed, genv, ptick, kPhiloxRNoiseStream) : np_standard_normal_lds(env_pcg, zig));
                     if (a.est.cur) est_add(a.est, N, i, 0, fabs(nz));               // total_abs_noise_in_reward_episode, :1984
                     r += nz;
                     r *= a.scale;
@@ -264,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (phase != 0) r = 0.0;
                 if (a.est.cur) est_add(a.est, N, i, 1, r);                          // total_reward_episode, :1985
                 if (NOISE && a.has_r_noise) {
-                    const double nz = 0.0 + a.r_noise * (PHILOX ? np_standard_normal_lds(env_phx, zig) : np_standard_normal_lds(env_pcg, zig));
+                    const double nz = 0.0 + a.r_noise * (PHILOX ? (double)rn_z.normal(a.philox_seed, genv, ptick, kPhiloxRNoiseStream) : np_standard_normal_lds(env_pcg, zig));
                     if (a.est.cur) est_add(a.est, N, i, 0, fabs(nz));               // :1984
                     r += nz;
                 }
@@ -279,8 +277,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (action1 < 0 || action1 >= a.A1) { status |= MDPP_STATUS_BAD_ACTION; action1 = 0; }
                 uint32_t nxt1 = P1[cur1 * a.A1 + action1];
                 if (NOISE && a.has_p_noise) {
-                    double uu = PHILOX ? np_random(sp1_phx) : np_random(sp1_pcg);
-                    nxt1 = (uint32_t)searchsorted_right(a.noise_cdf1 + (size_t)nxt1 * a.S1, a.S1, uu);
+                    if (PHILOX) nxt1 = philox_pnoise_state(pn_w1.word(a.philox_seed, genv, ptick, kPhiloxIrrStream), a.pn_T, a.pn_M1, nxt1);
+                    else nxt1 = (uint32_t)searchsorted_right(a.noise_cdf1 + (size_t)nxt1 * a.S1, a.S1, np_random(sp1_pcg));
                 }
                 cur1 = nxt1;
             }

@@ -45,7 +45,7 @@ constexpr int kQQ = 4;                         // start states queued per lane
 // exist: lanes 12-15 of every 16 stored the overwritten register (found by the role-split soak test).
 constexpr int kQRsrc = 0x00020000;
 constexpr int kQDepth = 24;                    // E -> O ring depth in steps (multiple of the chunk of 8)
-constexpr int kHD = 16;                        // Philox producers -> E ring depth in steps
+constexpr int kHD = 32;                        // Philox producers -> E ring depth in steps
 constexpr uint32_t kQSpinLimit = 1u << 22;
 constexpr uint32_t kQStatusInternal = 0x80000000u;
 
@@ -61,15 +61,17 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // stream, the one reset() draws from, and numpy's order is normal-of-the-step, then the reset draw:
 // so E owns that stream, draws the step's standard normal (ziggurat tables in LDS) and hands it to O
 // beside the record, start states are drawn at need instead of ahead, and there is no H role.
-// PH: Philox streams (mdpp_rng.hpp): every step re-keys its generators by (seed, global env id, tick,
-// stream), nothing is loaded from or stored to HBM, start states are drawn at need (like RN: no queue, no
-// H role, nothing to un-draw), and the reward-noise normal is the Philox mode's Box-Muller one.
+// PH: Philox streams (mdpp_rng.hpp): everything random about tick t is one word (or one float32 normal) of a block
+// keyed by (seed, global env id, t >> 2, stream) -- the transition-noise word (philox_pnoise_*: "noisy" and which
+// other state, no cdf), the reward normal, the start state --, nothing is loaded from or stored to HBM, start
+// states are drawn at need (like RN: no queue, no H role, nothing to un-draw).
 // NPH (PH, two roles, no irrelevant sub-space): Philox producer waves.  A counter-based stream has no serial
 // state, so everything random about step k -- the P-noise uniform, the reward-noise normal, the start state
 // a reset at that step would draw -- is a pure function of (seed, env, tick) and is made AHEAD of the step by
-// NPH extra waves per SIMD (producer p takes the steps k = p mod NPH) into an LDS ring; the E wave, whose
-// dependent chain is the step time, then runs no generator at all (two Philox blocks and a Box-Muller pair
-// per step on E were 0.15 of the HBM roofline on cfg2 + noise).
+// NPH extra waves per SIMD (producer p takes the four-tick blocks b = p mod NPH: three Philox blocks and two packed
+// Box-Muller pairs per four env steps) into an LDS ring; the E wave, whose dependent chain is the step time, then
+// runs no generator at all (two Philox blocks and a Box-Muller pair per step on E were 0.15 of the HBM roofline
+// on cfg2 + noise; one block + one pair per step on the producers 0.24).
 template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0>
 __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
@@ -90,10 +92,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
     static_assert(!(ATNEED && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
     static_assert(NPH == 0 || (PH && ROLES == 2 && !IRR), "Philox producers: two roles, one sub-space");
-    // producers -> E: per env and step {P-noise uniform (53 bits) | start state << 56} and the reward normal
-    __shared__ __align__(8) uint64_t s_hm[NPH ? kHD * kBlock : 1];
+    // producers -> E: per env and step {other-state index j | noisy << 8 | start state << 16} and the reward normal
+    __shared__ __align__(8) uint32_t s_hm[NPH ? kHD * kBlock : 1];
     __shared__ float s_hz[(NPH && RN) ? kHD * kBlock : 1];
-    __shared__ uint32_t s_hprod[NPH ? NPH : 1][kBlock / 64];            // steps made by producer p for wave w
+    __shared__ uint32_t s_t31[NPH ? 256 : 1];                           // rho_0 as 31-bit thresholds (producers)
+    __shared__ uint32_t s_hprod[NPH ? NPH : 1][kBlock / 64];            // producer p has made every step < this of its blocks, for wave w
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = (ROLES + NPH) * kBlock;
@@ -112,9 +115,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const uint32_t S8 = ((uint32_t)a.S + 7u) & ~7u, S18 = IRR ? (((uint32_t)a.S1 + 7u) & ~7u) : 0u;
     const uint32_t lds_T1 = lds_T0 + S8 * 8u;
     const uint32_t lds_TN = lds_T1 + S18 * 8u;                 // PN: S rows of S8 thresholds of the noise categoricals
-    const uint32_t lds_TN1 = lds_TN + (PN ? (uint32_t)a.S * S8 * 8u : 0u);   // ... and S1 rows of S18 for the irrelevant sub-space
-    const uint32_t lds_end = lds_TN1 + ((PN && IRR) ? (uint32_t)a.S1 * S18 * 8u : 0u);
-    if (PN) {
+    constexpr bool PNC = PN && !PH;                             // (Philox streams need no cdf: philox_pnoise_*)
+    const uint32_t lds_TN1 = lds_TN + (PNC ? (uint32_t)a.S * S8 * 8u : 0u);   // ... and S1 rows of S18 for the irrelevant sub-space
+    const uint32_t lds_end = lds_TN1 + ((PNC && IRR) ? (uint32_t)a.S1 * S18 * 8u : 0u);
+    if (PNC) {
         for (uint32_t k = tid; k < (uint32_t)a.S * S8; k += kThreads) {
             const uint32_t row = k / S8, col = k - row * S8;
             ((uint64_t *)(lds + lds_TN))[k] =
@@ -130,6 +134,9 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     }
     for (uint32_t k = tid; k < S8; k += kThreads)
         ((uint64_t *)(lds + lds_T0))[k] = k < (uint32_t)a.S ? (uint64_t)ceil(a.init_cdf[k] * 9007199254740992.0) : ~0ULL;
+    if (NPH)       // cdf[j] <= m31 2^-31  <=>  ceil(cdf[j] 2^31) <= m31; padding never counts
+        for (uint32_t k = tid; k < 256u; k += kThreads)
+            s_t31[k] = k < (uint32_t)a.S ? (uint32_t)(((uint64_t)ceil(a.init_cdf[k] * 9007199254740992.0) + 0x3FFFFFull) >> 22) : 0x80000000u;
     if (IRR) {
         for (int k = tid; k < a.S1 * a.A1; k += kThreads) lds[lds_P1 + k] = a.P1[k];
         for (uint32_t k = tid; k < S18; k += kThreads)
@@ -170,6 +177,9 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
     typedef typename std::conditional<PH, Philox, Pcg64>::type Gen;
     Gen g, sp, sp1;
+    PhiloxTickWords pnw, pnw1;             // PH without producers: the current four ticks' noise words / normals
+    PhiloxTickNormals rnz;
+    const uint64_t pn_M = a.pn_M, pn_M1 = a.pn_M1;
     const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);         // global env id (Philox key)
     if constexpr (!PH) {
         g.load(a.env_s, a.env_inc, i);
@@ -244,45 +254,58 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     if constexpr (NPH > 0) if (role >= 2) {
         // =========================================================== Philox producer (see NPH above)
         const int me = role - 2;
-        uint32_t made = 0, hstatus = 0;
-        uint64_t sblk = ~0ULL;
-        uint32_t sw[4] = {0u, 0u, 0u, 0u};
-        for (int k = me; k < K; k += NPH) {
-            const uint64_t tick = a.ptick + (uint64_t)k;
-            // one block of the env stream per tick: its first 64-bit draw is the P-noise uniform, the next the reward
-            // normal's Box-Muller pair (the order k_discrete_step draws them in)
-            uint64_t m_sp = 0;
-            float z = 0.0f;
-            {
-                Philox ge;
-                ge.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
-                if (PN) m_sp = ge.next64() >> 11;
-                if (RN) z = (float)ge.normal();
-            }
-            // the start state a reset at this tick takes: one word of the start-state stream (mdpp_rng.hpp); the block
-            // serves four ticks, two of them this producer's
-            if ((tick >> 2) != sblk) {                           // (wave-uniform)
-                sblk = tick >> 2;
-                philox_start_block(a.philox_seed, genv, sblk, kPhiloxStartStream, sw);
-            }
-            const uint32_t tq = (uint32_t)tick & 3u;
-            const uint64_t mr = (uint64_t)((tq == 0u ? sw[0] : tq == 1u ? sw[1] : tq == 2u ? sw[2] : sw[3]) >> 1) << 22;
-            uint32_t s0 = 0;
-            for (uint32_t b = 0; b < S8; b += 8) {
+        uint32_t hstatus = 0;
+        const uint64_t G0 = a.ptick >> 2;
+        const int nG = (int)(((a.ptick + (uint64_t)K - 1u) >> 2) - G0) + 1;
+        const bool small = S <= 8u;                              // rho_0 thresholds in scalar registers
+        uint32_t t31[8];
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8; jj++) s0 += (T0[b + jj] <= mr) ? 1u : 0u;
+        for (int j = 0; j < 8; j++) t31[j] = __builtin_amdgcn_readfirstlane(s_t31[j]);
+        const bool want_start = a.autoreset != 0;
+        for (int r = me; r < nG; r += NPH) {
+            const uint64_t blk = G0 + (uint64_t)r;
+            const int kfirst = (int)((int64_t)(blk << 2) - (int64_t)a.ptick);      // step of the block's word 0 (may be < 0)
+            const int k_hi = min(K, kfirst + 4);
+            uint32_t pw[4] = {0u, 0u, 0u, 0u}, sw[4] = {0u, 0u, 0u, 0u};
+            float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (PN) philox_start_block(a.philox_seed, genv, blk, kPhiloxPNoiseStream, pw);
+            if (RN) {
+                uint32_t o[4];
+                philox_start_block(a.philox_seed, genv, blk, kPhiloxRNoiseStream, o);
+                philox_box_muller2(o, z[0], z[1], z[2], z[3]);
             }
-            if (k >= kHD) {                                      // slot k % kHD: E must be through step k - kHD
+            if (want_start) philox_start_block(a.philox_seed, genv, blk, kPhiloxStartStream, sw);
+            if (k_hi > kHD) {                                    // slots k % kHD: E must be through step k_hi - 1 - kHD
                 uint32_t spins = 0;
-                while (__hip_atomic_load(&s_prod[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(k - kHD + 1)) {
+                while (__hip_atomic_load(&s_prod[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(k_hi - kHD)) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > kQSpinLimit) { hstatus |= kQStatusInternal; break; }
                 }
             }
-            s_hm[(k % kHD) * kBlock + l] = m_sp | ((uint64_t)s0 << 56);
-            if (RN) s_hz[(k % kHD) * kBlock + l] = z;
-            made += 1;
-            if ((l & 63) == 0) __hip_atomic_store(&s_hprod[me][w], made, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k = kfirst + q;
+                if (k < 0 || k >= K) continue;                   // (wave-uniform)
+                uint32_t ent = 0;
+                if (PN) ent = philox_pnoise_index(pw[q], a.pn_T, pn_M);
+                if (want_start) {
+                    const uint32_t m31 = sw[q] >> 1;
+                    uint32_t s0 = 0;
+                    if (small) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) s0 += (t31[j] <= m31) ? 1u : 0u;
+                    } else {
+                        for (uint32_t b = 0; b < S8; b += 8) {
+#pragma unroll
+                            for (uint32_t jj = 0; jj < 8; jj++) s0 += (s_t31[b + jj] <= m31) ? 1u : 0u;
+                        }
+                    }
+                    ent |= s0 << 16;
+                }
+                s_hm[(k % kHD) * kBlock + l] = ent;
+                if (RN) s_hz[(k % kHD) * kBlock + l] = z[q];
+            }
+            if ((l & 63) == 0) __hip_atomic_store(&s_hprod[me][w], (uint32_t)k_hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (hstatus) atomicOr(&a.status[i], hstatus);
         return;
@@ -394,14 +417,9 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 
     // ---- E: one step of the state recurrence -> record
     auto stepE = [&](const u32x2 act2, double &z, const int kstep) __attribute__((always_inline)) -> uint64_t {
-        uint64_t hent = 0;           // NPH: what the producers made for this step
+        uint32_t hent = 0;           // NPH: what the producers made for this step
         if constexpr (NPH > 0) hent = s_hm[(kstep % kHD) * kBlock + l];
-        if constexpr (PH && NPH == 0) {          // this step's streams (a block is only computed when something is drawn)
-            const uint64_t tick = a.ptick + (uint64_t)kstep;
-            g.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
-            if (PN) sp.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
-            if (PN && IRR) sp1.init(a.philox_seed, genv, tick, kPhiloxIrrStream);
-        }
+        const uint64_t ptick = a.ptick + (uint64_t)kstep;        // (Philox streams)
         if (!ATNEED && __builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
         int action = (int)act2.x;
         action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
@@ -409,14 +427,15 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         action = bad ? 0 : action;
         const uint32_t cur = (uint32_t)hist & 0xFFu;
         uint32_t nxt = P[cur * A + (uint32_t)action];                        // D1
-        if (PN) {                                                            // D2 (:1604-1622)
-            uint64_t m;
-            if constexpr (NPH > 0) m = hent & ((1ull << 53) - 1ull);
-            else {
-                m = 0;
-                if constexpr (PH) { if (!pend) m = g.next64() >> 11; }      // the env stream's first draw of the tick (k_discrete_step)
-                else { if (!pend) m = sp.next64() >> 11; }
-            }
+        if constexpr (PN && PH) {                                            // D2, Philox streams: mdpp_rng.hpp philox_pnoise_*
+            uint32_t ent = hent;
+            if constexpr (NPH == 0) ent = philox_pnoise_index(pnw.word(a.philox_seed, genv, ptick, kPhiloxPNoiseStream), a.pn_T, pn_M);
+            const uint32_t j = ent & 0xFFu;
+            nxt = (ent & 0x100u) ? j + (j >= nxt ? 1u : 0u) : nxt;          // (a reset call's result is dropped below)
+        }
+        if constexpr (PN && !PH) {                                           // D2 (:1604-1622)
+            uint64_t m = 0;
+            if (!pend) m = sp.next64() >> 11;
             const uint64_t *row = TN + nxt * S8;
             uint32_t c = 0;
             for (uint32_t b = 0; b < S8; b += 8) {
@@ -439,7 +458,12 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             bad1 = (action1 < 0 || action1 >= a.A1) ? 1u : 0u;
             action1 = bad1 ? 0 : action1;
             cur1 = P1[cur1 * (uint32_t)a.A1 + (uint32_t)action1];
-            if (PN) {                                                        // its own P-noise stream (:2066-2080)
+            if constexpr (PN && PH) {
+                const uint32_t ent = philox_pnoise_index(pnw1.word(a.philox_seed, genv, ptick, kPhiloxIrrStream), a.pn_T, pn_M1);
+                const uint32_t j = ent & 0xFFu;
+                cur1 = (ent & 0x100u) ? j + (j >= cur1 ? 1u : 0u) : cur1;
+            }
+            if constexpr (PN && !PH) {                                       // its own P-noise stream (:2066-2080)
                 uint64_t m1 = 0;
                 if (!pend) m1 = sp1.next64() >> 11;
                 const uint64_t *row = TN1 + cur1 * S18;
@@ -454,6 +478,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         status |= ((bad || bad1) && !pend) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
         if (RN) {                                                           // D6: drawn in reward_function, before any reset
             if constexpr (NPH > 0) z = (double)s_hz[(kstep % kHD) * kBlock + l];
+            else if constexpr (PH) z = (double)rnz.normal(a.philox_seed, genv, ptick, kPhiloxRNoiseStream);
             else { z = 0.0; if (!pend) z = np_standard_normal_lds(g, zig); }
         }
         bool tr = has_max && steps >= max_steps;
@@ -467,7 +492,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             pend = ended;
         }
         if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
-            if constexpr (NPH > 0) { queue[0] = need ? (uint32_t)(hent >> 56) : queue[0]; }
+            if constexpr (NPH > 0) { queue[0] = need ? (hent >> 16) : queue[0]; }
             else if (need) { queue[0] = draw_state(a.ptick + (uint64_t)kstep); }
             qn = need ? 1u : qn;
         }
@@ -562,11 +587,16 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                 }
             }
             if (TRIO && autoreset) pull();
-            if constexpr (NPH > 0) {                    // the producers must be through this chunk's steps
+            if constexpr (NPH > 0) {                    // the producers must be through this chunk's four-tick blocks
                 const int upto = min(kbase + kPre, K);
+                const uint64_t G0 = a.ptick >> 2;
+                const int r_last = (int)(((a.ptick + (uint64_t)upto - 1u) >> 2) - G0);
 #pragma unroll
                 for (int p = 0; p < NPH; p++) {
-                    const uint32_t want = upto > p ? (uint32_t)((upto - p + NPH - 1) / NPH) : 0u;
+                    if (r_last < p) continue;
+                    const int r_p = r_last - ((r_last - p) % NPH);          // producer p's last block that starts before `upto`
+                    const int64_t hi = (int64_t)((G0 + (uint64_t)r_p + 1u) << 2) - (int64_t)a.ptick;
+                    const uint32_t want = (uint32_t)(hi < (int64_t)K ? hi : (int64_t)K);
                     uint32_t spins = 0;
                     while (__hip_atomic_load(&s_hprod[p][w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
                         __builtin_amdgcn_s_sleep(1);
@@ -686,8 +716,9 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const size_t S8 = (size_t)((a.S + 7) & ~7);
     size_t lds = a.lds_bytes;
     lds = ((lds + (a.irr ? (size_t)a.S1 * a.A1 : 0) + 15) & ~(size_t)15) + S8 * 8 + (a.irr ? (size_t)((a.S1 + 7) & ~7) * 8 : 0);
-    if (pn) lds += (size_t)a.S * S8 * 8;                        // thresholds of the S noise categoricals
-    if (pn && a.irr) lds += (size_t)a.S1 * ((a.S1 + 7) & ~7) * 8;
+    const bool ph_ = a.philox != 0;
+    if (pn && !ph_) lds += (size_t)a.S * S8 * 8;                // thresholds of the S noise categoricals (numpy streams)
+    if (pn && !ph_ && a.irr) lds += (size_t)a.S1 * ((a.S1 + 7) & ~7) * 8;
     if (lds > 60 * 1024) return false;
     // two / three waves per SIMD (E / O / H roles) when the blocks are full and the rollout is long
     // enough to fill the ring
@@ -697,10 +728,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = trio ? 3 : duo ? 2 : 1;
     // Philox handles in two roles without an irrelevant sub-space: two producer waves on top (see NPH)
-    // (not with next-step autoreset + reward noise: a reset call draws its start state from the FIRST words of the
-    //  tick's block, a terminal step from the words after the reward normal -- the producers cannot tell which)
-    const bool next_rn = a.autoreset == MDPP_AUTORESET_NEXT_STEP && rn;
-    const int nph = (ph && duo && !a.irr && a.autoreset && !next_rn && lds_duo + 56 * 1024 <= 150 * 1024 &&
+    const int nph = (ph && duo && !a.irr && a.autoreset && lds_duo + 72 * 1024 <= 150 * 1024 &&
                      !(a.opts & MDPP_OPT_NO_TRIO)) ? 2 : 0;
     if (name_out) {
         snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d,NPH=%d>", !a.obs_i32,

@@ -28,6 +28,8 @@ constexpr uint32_t kPhiloxActionStream = 5;   // grid: the re-drawn noisy action
 // (6-8: the post-processor's streams, mdpp_post.hip)
 constexpr uint32_t kPhiloxStartStream = 9;    // discrete: start state of an in-rollout reset, one word per tick (mdpp_rng.hpp)
 constexpr uint32_t kPhiloxStartIrrStream = 10; // ... of the irrelevant sub-space
+constexpr uint32_t kPhiloxPNoiseStream = 12;  // discrete: transition noise, one word per tick (mdpp_rng.hpp)
+constexpr uint32_t kPhiloxRNoiseStream = 13;  // discrete: reward noise, one float32 normal per tick (four per block)
 
 // ---- per-episode noise statistics (cfg.episode_stats; general kernels only) ------------------------------------
 // What the reference accumulates per env object and logs at every reset() (rl_toy_env.py:2231-2247; cleared
@@ -60,6 +62,8 @@ struct DiscreteArgs {
     int32_t has_p_noise, has_r_noise;
     int32_t autoreset, max_steps, obs_i32;
     int32_t philox;
+    uint32_t pn_T;              // Philox streams: transition-noise threshold ceil(p 2^32) (mdpp_rng.hpp philox_pnoise_*)
+    uint64_t pn_M, pn_M1;       // ... and ceil(2^64 (S - 1) / T) for the relevant / the irrelevant sub-space
     uint32_t nkeys;             // S^L
     uint32_t tick;              // head of the delay ring at this launch: env steps taken so far mod delay
     uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)

@@ -287,6 +287,71 @@ __device__ __forceinline__ uint32_t philox_start_m31(uint64_t seed, uint64_t env
 }
 __device__ __forceinline__ double philox_start_uniform(uint32_t m31) { return (double)m31 * (1.0 / 2147483648.0); }
 
+// ---- Philox mode, discrete envs: transition noise and reward noise, one word per tick each ----------------
+// (round 3, second re-key: a block of the env stream per env and tick -- a 53-bit uniform searched in the S-entry
+//  categorical's cdf in 64-bit arithmetic, and a Box-Muller pair of which one normal was used -- made cfg2 + noise
+//  VALU-bound at 0.24 of the HBM roofline.)  Like the start state, each draw of a tick is ONE word of a block
+// that serves four ticks, w(t, id) = word (t & 3) of block 0 of stream (seed, env, t >> 2, id):
+//   transition noise (:1604-1622: the table's next state n keeps mass 1 - p, every other state gets p / (S - 1)):
+//     T = ceil(p 2^32) (at most 2^32 - 1);  w(t, 12) >= T: the step is not noisy;  otherwise the re-drawn state is the
+//     j-th of the S - 1 OTHER states in ascending order, j = floor(w (S - 1) / T)   -- the same distribution
+//     from one word, without a cdf; the irrelevant sub-space the same with stream id 4 and its own S;
+//   reward noise (:1980-1984): the four float32 Box-Muller normals of block (t >> 2) of stream id 13
+//     (pairs (w0, w1) and (w2, w3), philox_box_muller2), normal t & 3 is tick t's.
+__device__ __forceinline__ uint32_t philox_word_of(const uint32_t (&o)[4], uint64_t tick) {
+    const uint32_t q = (uint32_t)tick & 3u;
+    return q == 0u ? o[0] : q == 1u ? o[1] : q == 2u ? o[2] : o[3];
+}
+struct PhiloxTickWords {          // the block of the current four ticks, kept while a K-step loop stays inside it
+    uint64_t blk = ~0ULL;
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+    __device__ __forceinline__ uint32_t word(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
+        if ((tick >> 2) != blk) {              // (wave-uniform: every lane is at the same tick)
+            blk = tick >> 2;
+            philox_start_block(seed, env, blk, stream, o);
+        }
+        return philox_word_of(o, tick);
+    }
+};
+struct PhiloxTickNormals {
+    uint64_t blk = ~0ULL;
+    float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    __device__ __forceinline__ float normal(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
+        if ((tick >> 2) != blk) {
+            blk = tick >> 2;
+            uint32_t o[4];
+            philox_start_block(seed, env, blk, stream, o);
+            philox_box_muller2(o, z[0], z[1], z[2], z[3]);
+        }
+        const uint32_t q = (uint32_t)tick & 3u;
+        return q == 0u ? z[0] : q == 1u ? z[1] : q == 2u ? z[2] : z[3];
+    }
+};
+__host__ __device__ inline uint32_t philox_pnoise_threshold(double p) {
+    const double t = ceil(p * 4294967296.0);
+    return t >= 4294967295.0 ? 4294967295u : (t <= 0.0 ? 0u : (uint32_t)t);
+}
+// floor(w (S - 1) / T) for every w < T as the top word of a 32 x 64-bit product: M = ceil(2^64 (S - 1) / T) (division
+// by an invariant with 64 fraction bits: the product is too large by less than 2^-32, and a non-integer w (S - 1) / T is
+// at least 1 / T > 2^-32 below the next integer).  0 = no noise (S < 2, or T <= S - 1: p < 6e-8).
+inline uint64_t philox_pnoise_magic(uint32_t T, uint32_t S) {
+    if (S < 2u || T <= S - 1u) return 0ull;
+    const unsigned __int128 num = (unsigned __int128)(S - 1u) << 64;
+    return (uint64_t)((num + T - 1u) / T);
+}
+// j | noisy << 8: `noisy` = the tick's word w is below T, j = index of the re-drawn state among the S - 1 others
+__device__ __forceinline__ uint32_t philox_pnoise_index(uint32_t w, uint32_t T, uint64_t M) {
+    const uint64_t t = (uint64_t)w * (uint32_t)(M >> 32) + (uint64_t)__umulhi(w, (uint32_t)M);
+    const uint32_t j = (uint32_t)(t >> 32);
+    return (w < T && M != 0ull) ? (j | 0x100u) : 0u;
+}
+// the state a step lands in: `nxt` (the table's) unless the tick's word says noisy
+__device__ __forceinline__ uint32_t philox_pnoise_state(uint32_t w, uint32_t T, uint64_t M, uint32_t nxt) {
+    const uint32_t e = philox_pnoise_index(w, T, M);
+    const uint32_t j = e & 0xFFu;
+    return (e & 0x100u) ? j + (j >= nxt ? 1u : 0u) : nxt;
+}
+
 template <class G>
 __device__ __forceinline__ double np_random(G &g) { // Generator.random()
     return (double)(g.next64() >> 11) * (1.0 / 9007199254740992.0);

@@ -471,8 +471,9 @@ def build_continuous(config) -> ContinuousMDP:
         # kept in registers) and up to 64 states; no target, no target latch (:1719)
         if len(rel) > 4 or common["sequence_length"] > 64:
             raise NotImplementedError("move_along_a_line: at most 4 relevant dimensions and sequence_length <= 64")
-        if image is not None:
-            raise NotImplementedError("move_along_a_line with image observations is not built")
+        if image is not None:     # :767-775 hands self.target_point to ImageContinuous; only move_to_a_point sets it (:650)
+            raise AttributeError("'RLToyEnv' object has no attribute 'target_point' (the reference's constructor fails for "
+                                 "move_along_a_line with image_representations)")
         target = np.zeros(len(rel), dtype=np.float32)
     elif "target_point" in config:
         target = np.array(config["target_point"], dtype=np.float32)

@@ -109,6 +109,8 @@ void ora_d_get_rng(const ora_discrete *e, uint64_t a[6], uint64_t b[6]) {
  * from stream 3 keyed by the reset count. */
 #define ORA_PHILOX_START 9
 #define ORA_PHILOX_START_IRR 10
+#define ORA_PHILOX_PNOISE 12     /* transition noise, one word per tick (irrelevant sub-space: id 4) */
+#define ORA_PHILOX_RNOISE 13     /* reward noise, one float32 normal per tick */
 void ora_d_get_stats(const ora_discrete *e, double cur[3], double last[4]) {
     for (int k = 0; k < 3; k++) cur[k] = e->st[k];
     for (int k = 0; k < 4; k++) last[k] = e->st_last[k];
@@ -140,23 +142,23 @@ void ora_d_philox_explicit_reset(ora_discrete *e) {
 
 void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8_t *done) {
     const int S = e->S, L = e->L;
-    if (e->philox) {
-        np_philox_init(&e->env_rng, e->ph_seed, e->ph_env, e->tick, 0);
-        np_philox_init(&e->space_rng, e->ph_seed, e->ph_env, e->tick, 1);
-        e->tick += 1;
-    }
+    const uint64_t t0 = e->tick;              /* Philox streams: this step's tick */
+    if (e->philox) e->tick += 1;
     /* D1: table lookup, :1603 */
     const int prev = e->hist[L];
     int nxt = e->P[prev * e->A + action];
     /* D2: categorical P-noise on the state-space RNG, :1604-1622 + discrete_extended.py:11-23 */
     if (e->has_p_noise) {
-        double cdf[256], probs[256];
-        for (int i = 0; i < S; i++) probs[i] = 1.0 * e->p_noise / (double)(S - 1);
-        probs[nxt] = 1 - e->p_noise;
-        np_build_cdf(probs, S, cdf);
-        /* (Philox streams, the build's own: the P-noise uniform is the env stream's first 64-bit draw of the tick, the
-         *  reward normal its second -- one block; numpy streams: the state space's generator, as the reference) */
-        const int noisy = np_choice_cdf(e->philox ? &e->env_rng : &e->space_rng, cdf, S);
+        int noisy;
+        if (e->philox) {     /* the build's own streams: one word of the tick, no cdf (np_random.c np_philox_pnoise_state) */
+            noisy = np_philox_pnoise_state(np_philox_tick_word(e->ph_seed, e->ph_env, t0, ORA_PHILOX_PNOISE), e->p_noise, S, nxt);
+        } else {             /* numpy streams: the state space's generator, as the reference */
+            double cdf[256], probs[256];
+            for (int i = 0; i < S; i++) probs[i] = 1.0 * e->p_noise / (double)(S - 1);
+            probs[nxt] = 1 - e->p_noise;
+            np_build_cdf(probs, S, cdf);
+            noisy = np_choice_cdf(&e->space_rng, cdf, S);
+        }
         if (noisy != nxt) e->st[2] += 1.0;              /* :1620 */
         nxt = noisy;
     }
@@ -184,7 +186,9 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
     if (e->steps % e->every_n != 0) r = 0.0;
     e->st[1] += r;                                       /* :1985 */
     if (e->has_r_noise) {
-        const double nz = 0.0 + e->r_noise * np_standard_normal(&e->env_rng);
+        const double zn = e->philox ? (double)np_philox_tick_normal(e->ph_seed, e->ph_env, t0, ORA_PHILOX_RNOISE)
+                                    : np_standard_normal(&e->env_rng);
+        const double nz = 0.0 + e->r_noise * zn;
         e->st[0] += fabs(nz);                            /* :1984 */
         r += nz;
     }
@@ -213,8 +217,9 @@ void ora_d_reset2(ora_discrete *e, int64_t out[2]) {
 void ora_d_step2(ora_discrete *e, int action, int action_irr, int64_t obs[2], double *reward, uint8_t *done) {
     ora_d_step(e, action, &obs[0], reward, done);
     int nxt = e->P1[e->irr_state * e->A1 + action_irr];
-    if (e->has_p_noise) {
-        if (e->philox) np_philox_init(&e->space1_rng, e->ph_seed, e->ph_env, e->tick - 1, 4);
+    if (e->has_p_noise && e->philox) {
+        nxt = np_philox_pnoise_state(np_philox_tick_word(e->ph_seed, e->ph_env, e->tick - 1, 4), e->p_noise, e->S1, nxt);
+    } else if (e->has_p_noise) {
         double cdf[256], probs[256];
         for (int i = 0; i < e->S1; i++) probs[i] = 1.0 * e->p_noise / (double)(e->S1 - 1);
         probs[nxt] = 1 - e->p_noise;

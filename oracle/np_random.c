@@ -207,6 +207,37 @@ int np_philox_start_state(uint64_t seed, uint64_t env, uint64_t tick, uint32_t s
     return c;
 }
 
+/* Philox mode, discrete envs: what a tick draws for its noise -- the build's own definitions (mdpp_rng.hpp, "transition
+ * noise and reward noise, one word per tick each"; NOT in the reference, which draws from its numpy generators): word
+ * (t & 3) of block 0 of stream (seed, env, t >> 2, stream id). */
+uint32_t np_philox_tick_word(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
+    np_pcg64 g;
+    np_philox_init(&g, seed, env, tick >> 2, stream);
+    const uint64_t a = np_next64(&g), b = np_next64(&g);        /* words (0, 1), then (2, 3) of block 0 */
+    const uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    return w[tick & 3];
+}
+/* Transition noise (rl_toy_env.py:1604-1622: the table's next state keeps mass 1 - p, each of the S - 1 others gets
+ * p / (S - 1)): with T = ceil(p 2^32) the step is noisy iff the tick's word w < T, and the re-drawn state is the j-th of the
+ * other states in ascending order, j = floor(w (S - 1) / T).  (T <= S - 1, p < 6e-8: no noise.) */
+int np_philox_pnoise_state(uint32_t w, double p, int S, int nxt) {
+    double t = ceil(p * 4294967296.0);
+    const uint32_t T = t >= 4294967295.0 ? 4294967295u : (t <= 0.0 ? 0u : (uint32_t)t);
+    if (S < 2 || T <= (uint32_t)(S - 1) || w >= T) return nxt;
+    const int j = (int)(((uint64_t)w * (uint64_t)(S - 1)) / T);
+    return j + (j >= nxt ? 1 : 0);
+}
+/* Reward noise: the four float32 Box-Muller normals of the block -- pairs (w0, w1), (w2, w3) --, normal (t & 3) is tick t's. */
+float np_philox_tick_normal(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream) {
+    np_pcg64 g;
+    np_philox_init(&g, seed, env, tick >> 2, stream);
+    const uint64_t a = np_next64(&g), b = np_next64(&g);
+    float z[4];
+    np_philox_box_muller((uint32_t)a, (uint32_t)(a >> 32), &z[0], &z[1]);
+    np_philox_box_muller((uint32_t)b, (uint32_t)(b >> 32), &z[2], &z[3]);
+    return z[tick & 3];
+}
+
 /* out[e][j] = j-th standard normal of Philox stream (seed, env0 + e, tick, stream): the counterpart of
  * the library's mdpp_philox_normals, for the device-vs-oracle bit test. */
 void np_philox_normals(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream, int n_envs, int n_per_env,

@@ -45,6 +45,9 @@ void np_philox_init(np_pcg64 *g, uint64_t seed, uint64_t env, uint64_t tick, uin
 void np_philox_box_muller(uint32_t w0, uint32_t w1, float *z0, float *z1);
 void np_philox_normals(uint64_t seed, uint64_t env0, uint64_t tick, uint32_t stream, int n_envs, int n_per_env,
                        double *out);
+uint32_t np_philox_tick_word(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream);
+int np_philox_pnoise_state(uint32_t w, double p, int S, int nxt);
+float np_philox_tick_normal(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream);
 int np_philox_start_state(uint64_t seed, uint64_t env, uint64_t tick, uint32_t stream, const double *cdf, int n);
 
 void np_pcg64_load(np_pcg64 *g, const uint64_t w[6]);

@@ -881,6 +881,85 @@ def test_discrete_philox_vs_oracle(fused):
     env.close()
 
 
+@pytest.mark.parametrize("shape", ["s8", "s37_l2", "s255", "irr", "p_tiny", "p_big"])
+def test_discrete_philox_noise_words_unaligned_ticks_vs_general_kernel_and_oracle(shape):
+    """Philox streams, discrete noise: one word (one normal) per tick out of a block that serves four ticks
+    (mdpp_rng.hpp philox_pnoise_*, PhiloxTickNormals; oracle/np_random.c np_philox_tick_*).  Launches that start and end
+    inside a block (3 single steps, then rollouts of 50, 37 and 64 steps), small and large state spaces (the re-drawn
+    state's index is a 32 x 64-bit product: exact floor(w (S - 1) / T) up to S = 255), noise probabilities from 1e-9 (below
+    the threshold's resolution: never noisy) to 0.97, an irrelevant sub-space with its own noise words: the fused kernel
+    (producer waves make the blocks) == the general kernel on every env, and every 11th env == the oracle."""
+    base = dict(state_space_type="discrete", action_space_type="discrete", delay=1, sequence_length=2, reward_density=0.25,
+                terminal_state_density=0.25, transition_noise=0.1, reward_noise=0.3, seed=5)
+    cfg = dict(base, **{
+        "s8": dict(state_space_size=8, action_space_size=8),
+        "s37_l2": dict(state_space_size=37, action_space_size=5, reward_density=0.05, terminal_state_density=0.1),
+        "s255": dict(state_space_size=255, action_space_size=3, sequence_length=1, reward_density=0.1, terminal_state_density=0.05),
+        "irr": dict(state_space_size=[8, 6], action_space_size=[8, 6], irrelevant_features=True),
+        "p_tiny": dict(state_space_size=8, action_space_size=8, transition_noise=1e-9),
+        "p_big": dict(state_space_size=5, action_space_size=5, transition_noise=0.97),
+    }[shape])
+    N, off = 1024, 300
+    kw = dict(rng="philox", philox_seed=1234, env_id_offset=off, autoreset="same_step", max_episode_steps=19)
+    a = _venv(num_envs=N, **kw, **cfg)
+    b = _venv(num_envs=N, **kw, **cfg)
+    b.set_kernel_options("NO_PHILOX_FAST")
+    assert a.rollout_kernel_name(50) != b.rollout_kernel_name(50)
+    m = a.mdps[0]
+    rs = np.random.default_rng(8)
+    T = 3 + 50 + 37 + 64
+
+    def acts_of(n):
+        if shape == "irr":
+            return np.stack([rs.integers(0, m.A, size=(n, N)), rs.integers(0, m.A_irr, size=(n, N))], axis=2).astype(np.int32)
+        return rs.integers(0, m.A, size=(n, N)).astype(np.int32)
+    acts = acts_of(T)
+    init = a._obs.cpu().numpy().copy()
+    outs = []
+    for t in range(3):
+        ra = a.step(torch.as_tensor(acts[t], device=a.device))
+        rb = b.step(torch.as_tensor(acts[t], device=a.device))
+        for x, y in zip(ra[:4], rb[:4]):
+            assert torch.equal(x, y), (shape, t)
+        outs.append([x.cpu().numpy()[None] for x in ra[:4]])
+    t0 = 3
+    for n in (50, 37, 64):
+        at = torch.as_tensor(acts[t0:t0 + n], device=a.device)
+        ra, rb = a.rollout(at), b.rollout(at)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), (shape, t0)
+        outs.append([x.cpu().numpy() for x in ra])
+        t0 += n
+    obs, rew, term, trunc = (np.concatenate([o[j] for o in outs], axis=0) for j in range(4))
+    assert (a.status() == 0).all() and (b.status() == 0).all()
+    noisy_seen = 0
+    for i in range(0, N, 11):
+        o = _oracle_for(a, i)
+        o.set_philox(1234, off + i)
+        first = o.reset()
+        assert np.array_equal(np.asarray(first), init[i])
+        n = 0
+        for t in range(T):
+            if shape == "irr":
+                eo, er, ed = o.step(acts[t, i])
+            else:
+                eo, er, ed = o.step(int(acts[t, i]))
+            n += 1
+            assert np.float32(er) == rew[t, i] and bool(ed) == bool(term[t, i]), (shape, i, t)
+            tr = n >= 19
+            assert tr == bool(trunc[t, i]), (shape, i, t)
+            if ed or tr:
+                eo = o.reset(explicit=False)
+                n = 0
+            assert np.array_equal(np.asarray(eo), obs[t, i]), (shape, i, t)
+        noisy_seen += int(o.get_stats()[0][2] + o.get_stats()[1][2])
+    if shape == "p_tiny":
+        assert noisy_seen == 0
+    elif shape != "irr":
+        assert noisy_seen > 0
+    a.close(); b.close()
+
+
 def test_philox_box_muller_device_equals_oracle_bit_for_bit():
     """The Philox mode's Gaussian on 2^22 stream positions (incl. the first block of many envs and long
     streams of a few): device == oracle/np_random.c, every bit."""

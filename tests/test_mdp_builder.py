@@ -104,3 +104,14 @@ def test_custom_mdp_with_irrelevant_features_fails_like_the_reference():
         mdp.build_mdp(dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[2, 2],
                            action_space_size=[2, 2], irrelevant_features=True, use_custom_mdp=True,
                            transition_function=P, reward_function=R, seed=0))
+
+
+def test_line_reward_with_image_observations_fails_like_the_reference():
+    """rl_toy_env.py:767-775 passes self.target_point to ImageContinuous, which only move_to_a_point configs define
+    (:650-654): the reference's constructor raises AttributeError; so does the builder (checked against the reference when
+    tests/golden was generated: tools/refgen/gen_golden.py with such a case stops in RLToyEnv.__init__)."""
+    with pytest.raises(AttributeError):
+        mdp.build_mdp(dict(state_space_type="continuous", state_space_dim=2, transition_dynamics_order=1, inertia=1.0,
+                           time_unit=1.0, state_space_max=5, action_space_max=1, delay=0, sequence_length=6,
+                           reward_function="move_along_a_line", image_representations=True, image_width=48,
+                           image_height=40, seed=0))
