@@ -430,7 +430,10 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         a.lean_next_ok = (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise &&
                           c.L <= 3 && c.S <= 8 && c.delay <= 32 && c.autoreset == MDPP_AUTORESET_NEXT_STEP &&
                           a.rew_in_lds && !c.image) ? 1u : 0u;
-        if (c.episode_stats) a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = 0u;   // (general kernel keeps the statistics)
+        a.shape_ok_noise = (T == 1 && c.unit_rewards && (c.has_transition_noise || c.has_reward_noise) &&
+                            c.rng_mode == MDPP_RNG_PHILOX && c.L <= 3 && c.S <= 8 && c.S >= 2 && c.delay <= 32 &&
+                            c.autoreset != MDPP_AUTORESET_NEXT_STEP && a.rew_in_lds && !c.irrelevant && !c.image) ? 1u : 0u;
+        if (c.episode_stats) a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = a.shape_ok_noise = 0u;   // (general kernel keeps the statistics)
         a.s_shift = 0xFFFFFFFFu;
         for (uint32_t b = 1; b < 8; b++) if ((1u << b) == (uint32_t)c.S) a.s_shift = b;
         a.key_mask = h->nkeys - 1u;

@@ -46,6 +46,9 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
+#ifndef MDPP_PRODUCER_PRIO
+#define MDPP_PRODUCER_PRIO 0
+#endif
 #ifndef MDPP_CONSUMER_PRIO
 #define MDPP_CONSUMER_PRIO 2
 #endif
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         return;
 #endif
         const int me = tid / kBlock - 1;        // producer index: this wave makes the steps k = me (mod NPROD)
+        if (NPROD > 1) __builtin_amdgcn_s_setprio(MDPP_PRODUCER_PRIO);
         uint32_t made = 0;
         for (int k = me; k < K; k += NPROD) {
             if (k >= kNRing) {                  // wait until the consumer wave freed slot k % kNRing

@@ -421,7 +421,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
     // Philox handles of the common shape: k_discrete_rollout_lean with its H waves on Philox blocks
     // (mdpp_discrete_lean.hip); pieces it does not take (a short last one) go to the quiet kernel
     bool lean_philox = false;
-    if (!a.fast_ok && ((a.philox && a.shape_ok) || a.shape_ok_irr || a.lean_next_ok)) {
+    if (!a.fast_ok && ((a.philox && (a.shape_ok || a.shape_ok_noise)) || a.shape_ok_irr || a.lean_next_ok)) {
         const long long kmax = ((1LL << 32) - 1) / ((a.irr ? 16LL : 8LL) * a.N);
         char dry[kNameLen];
         const int k_first = (int)(K < kmax ? K : kmax);
@@ -440,8 +440,9 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
                 void *fo = final_obs ? (void *)((char *)final_obs + off * osz * (a.irr ? 2 : 1)) : nullptr;
                 if (!launch_discrete_lean(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out) &&
                     !launch_discrete_quiet(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out)) {
-                    // (a short last piece of a next-step handle: the general kernel; these shapes have no noise)
-                    if (a.philox) launch_step_t<true, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
+                    // (a short last piece of a next-step handle: the general kernel)
+                    if (a.philox && noise) launch_step_t<true, true>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
+                    else if (a.philox) launch_step_t<true, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
                     else launch_step_t<false, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
                 }
                 if (name_out) return MDPP_OK;

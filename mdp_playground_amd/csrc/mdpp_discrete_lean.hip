@@ -30,6 +30,12 @@
 //     is a test of its low nibble and no count is kept
 //   * reward value: one LDS read of a table indexed by (steps to the next pay step, delayed bit, terminated)
 //   * "reset happened" = the history words before and after it differ
+// NZ (Philox streams only; bit 0 transition noise, bit 1 reward noise; mdpp_discrete_lean_noise.hip): everything random
+// about tick t is one word / one float32 normal of a block that serves four ticks (mdpp_rng.hpp philox_pnoise_*,
+// PhiloxTickNormals).  H makes the chunk's eight transition-noise nibbles (noisy << 3 | index of the re-drawn state among
+// the others) beside its start states; the E lane applies one with seven instructions and re-encodes the column byte
+// with a v_perm_b32 of a constant; the O1 lane makes its own eight normals per chunk (two blocks, two packed Box-Muller
+// pairs) and forms the reward in float64 in the reference's order (:1980-1990, :2107).
 // What the measurements said (profiles/r02_ablation_lean_kernel.txt): with the default cache policy
 // the time was set by the stores, whoever issued them (147 us per 512-step launch of 65 536 envs with
 // one, two or three storing waves per SIMD); marked nt they cost 10 us on top of the 95 us the
@@ -42,6 +48,9 @@
 
 #ifndef MDPP_LEAN_TU_NEXT
 #define MDPP_LEAN_TU_NEXT 0        // 1: this translation unit holds the next-step autoreset instantiations
+#endif
+#ifndef MDPP_LEAN_TU_NOISE
+#define MDPP_LEAN_TU_NOISE 0       // 1: ... the transition- / reward-noise instantiations (Philox streams)
 #endif
 
 #include "mdpp_internal.hpp"
@@ -58,11 +67,19 @@ namespace mdpp {
 #ifndef MDPP_LEAN_AHEAD
 #define MDPP_LEAN_AHEAD 4
 #endif
+#if defined(MDPP_LEAN_PRIO_E) || defined(MDPP_LEAN_PRIO_O) || defined(MDPP_LEAN_PRIO_H)
+#define MDPP_LEAN_PRIO_FORCED 1    // (tools/ablate.py: the same priorities for every variant)
+#else
+#define MDPP_LEAN_PRIO_FORCED 0
+#endif
 #ifndef MDPP_LEAN_PRIO_E
 #define MDPP_LEAN_PRIO_E 3
 #endif
 #ifndef MDPP_LEAN_PRIO_O
 #define MDPP_LEAN_PRIO_O 2
+#endif
+#ifndef MDPP_LEAN_PRIO_H
+#define MDPP_LEAN_PRIO_H 0
 #endif
 #ifndef MDPP_LEAN_ST_AUX
 #define MDPP_LEAN_ST_AUX MDPP_ST_NT
@@ -99,10 +116,39 @@ __device__ __forceinline__ uint32_t wg_load_acq(const uint32_t *p) {
 __device__ __forceinline__ void wg_store_rel(uint32_t *p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// the words of the chunk's eight ticks: blocks b0, b0 + 1 (and b0 + 2 when the launch is r4 ticks into its first block)
+__device__ __forceinline__ void chunk_words(uint64_t seed, uint64_t genv, uint64_t b0, uint32_t r4, uint32_t stream,
+                                            uint32_t (&wd)[MDPP_LEAN_CHUNK]) {
+    uint32_t o0[4], o1[4], o2[4] = {0u, 0u, 0u, 0u};
+    philox_start_block(seed, genv, b0, stream, o0);
+    philox_start_block(seed, genv, b0 + 1, stream, o1);
+    if (r4 != 0u) philox_start_block(seed, genv, b0 + 2, stream, o2);
+    const uint32_t all[12] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3], o2[0], o2[1], o2[2], o2[3]};
+#pragma unroll
+    for (int u = 0; u < MDPP_LEAN_CHUNK; u++)
+        wd[u] = r4 == 0u ? all[u] : r4 == 1u ? all[u + 1] : r4 == 2u ? all[u + 2] : all[u + 3];
+}
+// ... and their reward normals (four per block: PhiloxTickNormals)
+__device__ __forceinline__ void chunk_normals(uint64_t seed, uint64_t genv, uint64_t b0, uint32_t r4, uint32_t stream,
+                                              float (&z)[MDPP_LEAN_CHUNK]) {
+    float all[12] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t o[4];
+    philox_start_block(seed, genv, b0, stream, o);
+    philox_box_muller2(o, all[0], all[1], all[2], all[3]);
+    philox_start_block(seed, genv, b0 + 1, stream, o);
+    philox_box_muller2(o, all[4], all[5], all[6], all[7]);
+    if (r4 != 0u) {
+        philox_start_block(seed, genv, b0 + 2, stream, o);
+        philox_box_muller2(o, all[8], all[9], all[10], all[11]);
+    }
+#pragma unroll
+    for (int u = 0; u < MDPP_LEAN_CHUNK; u++)
+        z[u] = r4 == 0u ? all[u] : r4 == 1u ? all[u + 1] : r4 == 2u ? all[u + 2] : all[u + 3];
+}
 } // namespace lean
 using namespace lean;
 
-template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX, bool IRR, bool NEXT>
+template <bool OBS64, bool DELAY, bool HASMAX, bool EVN, bool PHILOX, bool IRR, bool NEXT, int NZ = 0>
 __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(DiscreteArgs a, int K,
                                                                       const int32_t *__restrict__ actions,
                                                                       void *__restrict__ obs,
@@ -129,6 +175,17 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ __align__(16) uint2 lds_col1[IRR ? 16 : 1];    // irrelevant sub-space: action a1, byte s1: P1[s1][a1]
     __shared__ __align__(16) uint64_t lds_T1[IRR ? 8 : 1];    // its rho_0 thresholds
     __shared__ uint32_t lds_hprod[kBlock / 64];               // Philox: chunks published by H wave w
+    constexpr bool PN = (NZ & 1) != 0, RN = (NZ & 2) != 0;
+    // Wave priorities (s_setprio).  numpy streams: the serial recurrence (E) first, the H wave's PCG64 draws are filler work.
+    // Philox streams: the waves that make Philox blocks are the long stages and go first -- H (start states, and with PN
+    // the transition-noise words), with RN the O1 wave (normals) -- and the E wave, now the shortest stage, last:
+    // cfg2 128 -> 122 us per launch, + transition noise 195 -> 144, + reward noise 181 -> 167, both 227 -> 184
+    // (profiles/r03_ablation_lean_priorities.txt).
+    constexpr int kPrioE = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_E : 1;
+    constexpr int kPrioO = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_O : (PN ? 2 : 3);
+    constexpr int kPrioH = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_H : (PN ? 3 : 2);
+    static_assert(NZ == 0 || (PHILOX && !IRR && !NEXT), "noise on the lean kernel: Philox streams, one sub-space, same-step autoreset");
+    __shared__ __align__(16) uint32_t lds_pn[PN ? kHChunks : 1][kBlock];       // H -> E: the chunk's 8 transition-noise nibbles
     constexpr int kEN = IRR ? 2 : 1;                // nibbles per start-state entry (relevant, irrelevant)
     // gymnasium's next-step autoreset: the call after an episode's last step IS the reset (action ignored, reward 0,
     // no flags); the pending flag travels in bit 31 of the step counter like in k_discrete_step
@@ -221,7 +278,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #ifdef MDPP_ABL_NOH
         return;
 #endif
-        if (!ar) return;
+        if (!ar && !PN) return;
+        __builtin_amdgcn_s_setprio(kPrioH);
         if constexpr (PHILOX) {
             // Philox streams: the start state a reset at tick t draws is a function of (seed, env, t) alone -- ONE 32-bit
             // word of the start-state stream, four ticks to a block (mdpp_rng.hpp philox_start_*, as in k_discrete_step /
@@ -249,16 +307,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     }
                 }
                 const uint64_t b0 = (a.ptick + (uint64_t)(c * kChunk)) >> 2;
-                auto words = [&](uint32_t stream, uint32_t (&wd)[kChunk]) {
-                    uint32_t o0[4], o1[4], o2[4] = {0u, 0u, 0u, 0u};
-                    philox_start_block(a.philox_seed, genv, b0, stream, o0);
-                    philox_start_block(a.philox_seed, genv, b0 + 1, stream, o1);
-                    if (r4 != 0u) philox_start_block(a.philox_seed, genv, b0 + 2, stream, o2);
-                    const uint32_t all[12] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3], o2[0], o2[1], o2[2], o2[3]};
-#pragma unroll
-                    for (int u = 0; u < kChunk; u++)
-                        wd[u] = r4 == 0u ? all[u] : r4 == 1u ? all[u + 1] : r4 == 2u ? all[u + 2] : all[u + 3];
-                };
+                auto words = [&](uint32_t stream, uint32_t (&wd)[kChunk]) { chunk_words(a.philox_seed, genv, b0, r4, stream, wd); };
                 uint32_t wd[kChunk], wd1[kChunk];
                 words(kPhiloxStartStream, wd);
                 if (IRR) words(kPhiloxStartIrrStream, wd1);
@@ -279,6 +328,16 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     pk |= (S0Word)(s0 | 8u) << (kEN * 4 * u);
                 }
                 lds_s0[c % kHChunks][l] = pk;
+                if constexpr (PN) {                              // noisy << 3 | j (S <= 8: j <= 6), mdpp_rng.hpp philox_pnoise_index
+                    uint32_t wp[kChunk], pn = 0;
+                    words(kPhiloxPNoiseStream, wp);
+#pragma unroll
+                    for (int u = 0; u < kChunk; u++) {
+                        const uint32_t e = philox_pnoise_index(wp[u], a.pn_T, a.pn_M);
+                        pn |= ((e & 7u) | ((e >> 5) & 8u)) << (4 * u);
+                    }
+                    lds_pn[c % kHChunks][l] = pn;
+                }
                 if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)(c + 1));
             }
             if (status) atomicOr(&a.status[i], status);
@@ -340,7 +399,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== O1: reward path
     if (role == 1) {
-        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O);
+        __builtin_amdgcn_s_setprio(kPrioO);
         auto r_rew = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kPRsrc);
         const uint32_t v4 = i * 4u;
         const uint32_t dsh = (uint32_t)(a.delay > 0 ? a.delay - 1 : 0);
@@ -350,7 +409,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         // reward_every_n_steps (:1975-1976): 16 x (steps to the next pay step), the row index of the reward-value table
         const uint32_t ph_full = 16u * (uint32_t)a.every_n;
         uint32_t ph = EVN ? ph_full - 16u * (steps_at_launch % (uint32_t)a.every_n) : 0u;
-        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so) {
+        const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);
+        const uint32_t r4 = (uint32_t)a.ptick & 3u;
+        float zc[kChunk] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};         // RN: the chunk's reward normals
+        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, float z) {
             uint32_t bit = lds_V[(ra >> 5) & 2047u] >> (ra & 31u);                   // reward bit, NaN-gated (:1822)
             uint32_t out;
             if (DELAY) {                                                             // FIFO (:1970-1973)
@@ -367,8 +429,18 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 rd = ph;
                 ph = (ra != rb || ph == 0u) ? ph_full : ph;
             }
-            float rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
-                             : *(const float *)(rselb + (((out << 1) | tb) << 2));
+            float rout;
+            if constexpr (RN) {                                                      // :1975-1990, :2107 in float64
+                double r = (out != 0u && (!EVN || rd == 0u)) ? 1.0 : 0.0;
+                r += 0.0 + a.r_noise * (double)z;
+                r *= a.scale;
+                r += a.shift;
+                if (tb) r += a.term_add;
+                rout = (float)r;
+            } else {
+                rout = EVN ? *(const float *)(rselb + (rd | (out << 3) | (tb << 2)))
+                           : *(const float *)(rselb + (((out << 1) | tb) << 2));
+            }
             if (nextmode) rout = (ra != rb) ? 0.0f : rout;                           // the reset call returns reward 0
 #if defined(MDPP_ABL_NOSTORE) || defined(MDPP_ABL_NOREW)
             status ^= __float_as_uint(rout) & 0x100u;
@@ -379,6 +451,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kChunk;
             const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
+            if constexpr (RN)       // (before the wait: independent of E)
+                chunk_normals(a.philox_seed, genv, (a.ptick + (uint64_t)kbase) >> 2, r4, kPhiloxRNoiseStream, zc);
             uint32_t spins = 0;
 #ifdef MDPP_ABL_FREEO
             while (false) {
@@ -397,10 +471,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     rc[u] = lds_rec[2][(kbase + u) % kDepth][l];
                 }
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N);
+                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N, zc[u]);
             } else {
-                for (int k = kbase; k < K; k++)
-                    emit(lds_rec[0][k % kDepth][l], lds_rec[1][k % kDepth][l], lds_rec[2][k % kDepth][l], (uint32_t)k * N);
+#pragma unroll
+                for (int u = 0; u < kChunk; u++)
+                    if (kbase + u < K)
+                        emit(lds_rec[0][(kbase + u) % kDepth][l], lds_rec[1][(kbase + u) % kDepth][l],
+                             lds_rec[2][(kbase + u) % kDepth][l], (uint32_t)(kbase + u) * N, zc[u]);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][0], upto);
         }
@@ -411,7 +488,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== O2: observation, terminated, truncated
     if (role == 2) {
-        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O);
+        __builtin_amdgcn_s_setprio(kPrioO);
         auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
@@ -471,7 +548,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     }
 
     // =============================================================== E: state recurrence
-    __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_E);   // the serial recurrence is the critical path; H is filler work
+    __builtin_amdgcn_s_setprio(kPrioE);   // the serial recurrence is the critical path; H is filler work
     // hist: bytes newest first, 0xFF = NaN  ->  nibbles newest first, bit 3 = is a state
     uint32_t k2, qv, cnt, steps0, last_reset = 0, badq[2] = {0u, 0u};
     bool pend = false;                              // next-step mode: the episode ended on the previous step
@@ -499,8 +576,16 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     uint32_t c1 = IRR ? (a.irr_state[i] & 7u) : 0u;                 // the irrelevant part of curr_state
     const uint32_t A1 = IRR ? (uint32_t)a.A1 : 1u;
 
+    uint32_t pnc = 0;                               // PN: this chunk's transition-noise nibbles
+    // PN: byte s of {enc_lo, enc_hi} = s | 8 | is_terminal[s] << 7, the column byte of a re-drawn state
+    uint32_t enc_lo = 0, enc_hi = 0;
+    if constexpr (PN) {
+        uint64_t enc = 0;
+        for (uint32_t s_ = 0; s_ < 8u; s_++) enc |= (uint64_t)(s_ | 8u | ((uint32_t)((a.term_mask >> s_) & 1ULL) << 7)) << (8 * s_);
+        enc_lo = (uint32_t)enc; enc_hi = (uint32_t)(enc >> 32);
+    }
     auto pull = [&](int c) {
-        if (!ar) return;                            // (no resets: nothing is drawn, the H lanes have left)
+        if (!ar && !PN) return;                     // (no resets: nothing is drawn, the H lanes have left)
         if constexpr (PHILOX) {                     // this chunk's start states, made by the H wave
             uint32_t spins = 0;
             while (wg_load_acq(&lds_hprod[w]) < (uint32_t)(c + 1)) {
@@ -508,6 +593,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
             s0c = lds_s0[c % kHChunks][l];
+            if constexpr (PN) pnc = lds_pn[c % kHChunks][l];
             return;
         }
         const uint64_t rt = __hip_atomic_load(&lds_ring[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -550,7 +636,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         }
     };
     auto stepE = [&](const Col &col, int k, uint32_t badbit) {
-        const uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);              // D1: P[cur][a] | 8 | terminal << 7
+        uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);                    // D1: P[cur][a] | 8 | terminal << 7
+        if constexpr (PN) {                                                           // D2 (:1604-1622), philox_pnoise_*
+            const uint32_t nib = (pnc >> (4 * (k % kChunk))) & 0xFu, j = nib & 7u, nx = entry & 7u;
+            const uint32_t ns = nib > 7u ? j + (j >= nx ? 1u : 0u) : nx;
+            entry = __builtin_amdgcn_perm(enc_hi, enc_lo, ns | kSelPad);
+        }
         const uint32_t k2n = (k2 << 4) | entry;       // (bit 7 of the sum is set anyway: the nibble below was a state)
         bool need = entry > 0x7Fu;                                                    // D7: is_terminal[next]
         uint32_t rc = entry;                          // (O1 / O2 take bit 7 out)
@@ -712,24 +803,40 @@ bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *acti
                                hipStream_t s, char *name_out) {
     constexpr bool kNext = true;
     if (a.autoreset != MDPP_AUTORESET_NEXT_STEP) return false;
+    const int nz = 0;
+#elif MDPP_LEAN_TU_NOISE
+bool launch_discrete_lean_noise(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                                float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                                hipStream_t s, char *name_out) {
+    constexpr bool kNext = false;
+    const int nz = (a.has_p_noise ? 1 : 0) | (a.has_r_noise ? 2 : 0);
+    if (nz == 0 || a.autoreset == MDPP_AUTORESET_NEXT_STEP || !a.philox || a.irr) return false;
 #else
 bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                                float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                                hipStream_t s, char *name_out);
+bool launch_discrete_lean_noise(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                                float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                                hipStream_t s, char *name_out);
 bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                           hipStream_t s, char *name_out) {
     constexpr bool kNext = false;
     if (a.autoreset == MDPP_AUTORESET_NEXT_STEP)
         return launch_discrete_lean_next(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    if (a.has_p_noise || a.has_r_noise)
+        return launch_discrete_lean_noise(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    const int nz = 0;
 #endif
     const bool ph = a.philox != 0, irr = a.irr != 0;
     if (final_obs) return false;        // (rollouts of K >= 32 steps never ask for final observations: mdpp_step does, K = 1)
     const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? a.lean_next_ok != 0
+                       : nz ? a.shape_ok_noise != 0
                        : irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
     if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
         (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
+    if (nz && (a.opts & MDPP_OPT_NO_QUIET_NOISE)) return false;
     if (!a.autoreset && a.max_steps > 0) return false;      // (the biased step counter saturates only through resets)
     if (a.S > 8 || a.A > 16 || a.every_n > 64 || a.max_steps >= 65536) return false;
     if (irr && (a.S1 > 8 || a.A1 > 16 || (8ULL * 2 * a.N * (unsigned long long)K) >= (1ULL << 32)))
@@ -737,9 +844,24 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d,NEXT=%d>", !a.obs_i32, dl, hm, evn, ph, irr, kNext);
+        if (nz)
+            snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d,NEXT=%d,PN=%d,RN=%d>",
+                     !a.obs_i32, dl, hm, evn, ph, irr, kNext, nz & 1, (nz >> 1) & 1);
+        else
+            snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d,NEXT=%d>", !a.obs_i32, dl, hm, evn, ph, irr, kNext);
         return true;
     }
+#if MDPP_LEAN_TU_NOISE
+#define MDPP_LEAN_GO(O64, DL, HM, EV, NZ_)                                                                   \
+    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, true, false, false, NZ_>), dim3(grid), dim3(kRoles * kBlock), \
+                       0, s, a, K, actions, obs, reward, term, trunc, final_obs)
+#define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                                   \
+    do {                                                                                                   \
+        if (nz == 3) MDPP_LEAN_GO(O64, DL, HM, EV, 3);                                                     \
+        else if (nz == 2) MDPP_LEAN_GO(O64, DL, HM, EV, 2);                                                \
+        else MDPP_LEAN_GO(O64, DL, HM, EV, 1);                                                             \
+    } while (0)
+#else
 #define MDPP_LEAN_GO(O64, DL, HM, EV, PH, IR)                                                                \
     hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, PH, IR, kNext>), dim3(grid), dim3(kRoles * kBlock), \
                        0, s, a, K, actions, obs, reward, term, trunc, final_obs)
@@ -750,6 +872,7 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
         else if (irr) MDPP_LEAN_GO(O64, DL, HM, EV, false, true);                                          \
         else MDPP_LEAN_GO(O64, DL, HM, EV, false, false);                                                  \
     } while (0)
+#endif
 #define MDPP_LEAN_L3(O64, DL, HM) do { if (evn) MDPP_LEAN_LAUNCH(O64, DL, HM, true); else MDPP_LEAN_LAUNCH(O64, DL, HM, false); } while (0)
 #define MDPP_LEAN_L2(O64, DL) do { if (hm) MDPP_LEAN_L3(O64, DL, true); else MDPP_LEAN_L3(O64, DL, false); } while (0)
     if (a.obs_i32) { if (dl) MDPP_LEAN_L2(false, true); else MDPP_LEAN_L2(false, false); }

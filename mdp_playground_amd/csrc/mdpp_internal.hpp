@@ -99,6 +99,7 @@ struct DiscreteArgs {
     uint32_t fast_ok;           // shape qualifies: shared LDS tables, unit rewards, no noise, L <= 3, S <= 16
     uint32_t shape_ok;          // fast_ok without its "numpy streams" condition (Philox handles: k_discrete_rollout_lean)
     uint32_t shape_ok_irr;      // the same shape with an irrelevant sub-space of at most 8 states (k_discrete_rollout_lean<IRR>)
+    uint32_t shape_ok_noise;    // the lean shape (at most 8 states) with transition and / or reward noise on Philox streams (k_discrete_rollout_lean<..., NZ>)
     uint32_t lean_next_ok;      // ... with next-step autoreset (at most 8 states, with or without the irrelevant sub-space)
     uint32_t s_shift;           // log2(S) when S is a power of two, else 0xFFFFFFFF
     uint32_t key_mask;          // S^L - 1 (power-of-two S)

@@ -2160,7 +2160,11 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     ("cfg5", {"rng": "philox", "delay": 3, "terminal_states": [[5.0, 5.0, 5.0, 5.0]], "term_state_edge": 6.0},
      "NO_PHILOX_FAST", 32768, 48),
     ("cfg3", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 64),
-    ("cfg2_noise", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),
+    ("cfg2_noise", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),   # lean kernel with noise (H: noise nibbles, O1: normals) vs general
+    ("cfg2_noise", {"rng": "philox"}, "NO_LEAN", 65536, 128),          # ... vs the quiet kernel's producer waves
+    ("cfg2_noise", {"rng": "philox", "reward_noise": None, "max_episode_steps": 13}, "NO_LEAN", 32768, 128),     # transition noise only
+    ("cfg2_noise", {"rng": "philox", "transition_noise": None, "reward_every_n_steps": 3, "delay": 0}, "NO_LEAN", 32768, 128),  # reward noise only
+    ("cfg2_noise", {"rng": "philox", "autoreset": "disabled", "terminal_state_density": 0.0}, "NO_LEAN", 32768, 128),    # (H makes the noise without resets)
     ("cfg2", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 128),     # lean kernel, H waves on Philox blocks, vs general
     ("cfg2", {"rng": "philox"}, "NO_LEAN", 65536, 128),            # ... vs the quiet kernel's producer waves
     ("cfg2_irr", {"rng": "philox", "transition_noise": 0.1, "reward_noise": 0.2}, "NO_PHILOX_FAST", 32768, 64),

@@ -2,7 +2,8 @@
 """Macro-knob variants of ONE kernel source, compiled in the build container and timed on the GPU box.
 
     python3 tools/ablate.py build <source.hip> "NAME:-DFLAG=1 -DOTHER" ...      (here: hipcc cross-compiles, in parallel)
-    python3 tools/ablate.py run   <source.hip> [workload] [rng] NAME ...         (GPU box: link + time, HIP events)
+    python3 tools/ablate.py run   <source.hip> [workload] [rng] NAME ...         (GPU box: link + time, HIP events;
+                                                                                 key=value: config overrides, None drops a key)
 
 Objects live in build/ablate/ (git-ignored, but they travel with the gpurun snapshot).  `run` times 3 x 20 fused
 launches of the bench workload with the bench's rotating action tensors and prints the best average per launch."""
@@ -36,6 +37,8 @@ def build(src, variants):
 
 
 def run(src, wname, rng, names):
+    over = {n.split("=", 1)[0]: eval(n.split("=", 1)[1]) for n in names if "=" in n}      # config overrides: key=python-literal
+    names = [n for n in names if "=" not in n]
     objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in B.SOURCES if s != src]
     for name in names:
         so = os.path.join(OUT, f"libmdpp__{name}.so")
@@ -47,7 +50,8 @@ def run(src, wname, rng, names):
                 f"from mdp_playground_amd import _capi; _capi.LIB_PATH = {so!r}\n"
                 "from mdp_playground_amd import RLToyVectorEnv; import bench\n"
                 f"wl = bench.WORKLOADS[{wname!r}]; N = wl['envs']; F = min(512, wl.get('fuse_max', 512))\n"
-                f"env = RLToyVectorEnv(num_envs=N, autoreset='same_step', rng={rng!r}, **wl['config'])\n"
+                f"cfg = dict(wl['config'], **{over!r}); cfg = {{k: v for k, v in cfg.items() if v is not None}}\n"
+                f"env = RLToyVectorEnv(num_envs=N, autoreset='same_step', rng={rng!r}, **cfg)\n"
                 "acts = bench.action_rotation(wl, F, N, env.device, 12345); out = env.alloc_rollout(F)\n"
                 "for j in range(5): env.rollout(acts[j % len(acts)], out)\n"
                 "torch.cuda.synchronize(); best = 1e9\n"

@@ -1,72 +1,57 @@
-// Micro-benchmark of the Philox-mode building blocks (GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I mdp_playground_amd/csrc tools/bench_philox.hip -o gpurun_out/bench_philox
-// ns per call per wave with 1, 2 and 4 waves per SIMD (256 blocks of 256 / 512 / 1024 threads).
+// Cost of one Philox4x32-10 block and of one packed Box-Muller evaluation (4 normals) per wave64, in SIMD cycles:
+//   hipcc --offload-arch=gfx950 -O3 -w -I include -I mdp_playground_amd/csrc tools/bench_philox.hip -o build/bench_philox && build/bench_philox
+// (grid = 256 CUs x 4 SIMDs x W waves; every lane runs R dependent rounds; cycles = elapsed x 2.4 GHz / (R x W))
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdint.h>
+#include "mdpp.h"
 #include "mdpp_rng.hpp"
 using namespace mdpp;
 
-template <int ROUNDS>
-__device__ __forceinline__ void philox_block(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                             uint32_t (&o)[4]) {
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        uint32_t y0 = h1 ^ c1 ^ k0, y1 = l1, y2 = h0 ^ c3 ^ k1, y3 = l0;
-        c0 = y0; c1 = y1; c2 = y2; c3 = y3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
-
 template <int MODE>
-__global__ void k(uint32_t *out, int iters) {
-    uint32_t acc = 0, c = threadIdx.x + blockIdx.x * 1024;
-    float facc = 0.f;
-    for (int i = 0; i < iters; i++) {
-        uint32_t w[4];
-        if (MODE == 0) { philox_block<10>(c, i, 7, 9, 1, 2, w); acc ^= w[0] ^ w[1] ^ w[2] ^ w[3]; }
-        if (MODE == 1) { philox_block<7>(c, i, 7, 9, 1, 2, w); acc ^= w[0] ^ w[1] ^ w[2] ^ w[3]; }
-        if (MODE == 2) {  // Philox-10 + two Box-Muller pairs
-            philox_block<10>(c, i, 7, 9, 1, 2, w);
+__global__ __launch_bounds__(256) void k(uint32_t *out, int R, uint32_t seed) {
+    uint32_t c0 = threadIdx.x + blockIdx.x * 256, acc = 0;
+    float fz = 0.0f;
+    for (int r = 0; r < R; r++) {
+        uint32_t o[4];
+        if (MODE == 0 || MODE == 2) philox4x32_10(c0, 1u, (uint32_t)r, 2u, seed, 77u, o);
+        else { o[0] = c0 * 3u + r; o[1] = c0 ^ r; o[2] = c0 + 5u * r; o[3] = c0 - r; }
+        if (MODE >= 1) {
             float z0, z1, z2, z3;
-            philox_box_muller(w[0], w[1], z0, z1);
-            philox_box_muller(w[2], w[3], z2, z3);
-            facc += z0 + z1 + z2 + z3;
+            philox_box_muller2(o, z0, z1, z2, z3);
+            fz += z0 + z1 + z2 + z3;
         }
-        if (MODE == 3) {  // Box-Muller pair only (inputs from a cheap LCG)
-            acc = acc * 1664525u + 1013904223u;
-            float z0, z1;
-            philox_box_muller(acc, acc ^ (c * 2654435761u), z0, z1);
-            facc += z0 + z1;
-        }
-        if (MODE == 4) { acc = __umulhi(acc | 1u, 0xD2511F53u) ^ (acc * 0xCD9E8D57u); }   // dependent mul_hi + mul_lo
+        acc ^= o[0] ^ o[1] ^ o[2] ^ o[3];
+        c0 += acc & 1u;
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = acc + (uint32_t)facc;
+    out[threadIdx.x + blockIdx.x * 256] = acc + __float_as_uint(fz);
 }
 
 template <int MODE>
-void run(const char *name, uint32_t *d, int iters) {
-    for (int threads : {256, 512, 1024}) {
-        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-        hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, d, iters);
-        hipEventRecord(a);
-        hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, d, iters);
-        hipEventRecord(b); hipEventSynchronize(b);
-        float ms; hipEventElapsedTime(&ms, a, b);
-        printf("%-44s %d wave(s)/SIMD  %8.1f ns per call per wave  (%6.1f ns per call per SIMD)\n", name, threads / 256,
-               ms * 1e6 / iters, ms * 1e6 / iters / (threads / 256));
-    }
+static void run(const char *what, int wavesPerSimd) {
+    const int R = 4096, blocks = 256 * wavesPerSimd;       // 256 threads = 4 waves = one per SIMD of a CU
+    uint32_t *d;
+    hipMalloc(&d, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, 256>>>(d, R, 1u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<MODE><<<blocks, 256>>>(d, R, 2u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s waves/SIMD %d: %7.1f us, %6.1f SIMD cycles per wave-iteration at 2.4 GHz\n", what, wavesPerSimd, ms * 1e3,
+           ms * 1e-3 * 2.4e9 / ((double)R * wavesPerSimd));
+    hipFree(d);
 }
 
 int main() {
-    uint32_t *d; hipMalloc(&d, 256 * 1024 * 4);
-    int iters = 20000;
-    run<4>("dependent v_mul_hi_u32 + v_mul_lo_u32", d, iters);
-    run<0>("Philox4x32-10 block (4 words)", d, iters);
-    run<1>("Philox4x32-7 block (4 words)", d, iters);
-    run<3>("float32 Box-Muller pair (2 normals)", d, iters);
-    run<2>("Philox4x32-10 + 2 Box-Muller pairs (4 normals)", d, iters);
+    for (int w : {1, 2, 4}) {
+        run<0>("philox block", w);
+        run<1>("box-muller x4 (packed)", w);
+        run<2>("block + box-muller x4", w);
+    }
     return 0;
 }

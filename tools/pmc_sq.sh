@@ -3,7 +3,12 @@
 w=$1; F=$2; L=${3:-2}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_IFETCH"; do
+# (SQ_MORE=1: where the issue cycles go -- active cycles per unit, integer / float64 / transcendental instruction counts)
+sets=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_IFETCH")
+if [ -n "$SQ_MORE" ]; then
+  sets+=("SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64" "SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_FMA_F32")
+fi
+for c in "${sets[@]}"; do
   t=$(echo $c | tr ' ' '_')
   rm -rf gpurun_out/sq_$t
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/sq_$t -- python3 tools/run_variant.py - $L $w $F ${@:4} > gpurun_out/sq_$t.log 2>&1
