@@ -46,6 +46,12 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
+#ifndef MDPP_NP_PRODUCER_PRIO
+#define MDPP_NP_PRODUCER_PRIO 3    // numpy streams: the helper wave (13 numpy-exact normals per step) is the long stage: 2 737 -> 2 410 us per cfg5 launch
+#endif
+#ifndef MDPP_NP_CONSUMER_PRIO
+#define MDPP_NP_CONSUMER_PRIO 0
+#endif
 #ifndef MDPP_PRODUCER_PRIO
 #define MDPP_PRODUCER_PRIO 0
 #endif
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         // ---------------- producer lane: the env's noise stream for this launch -----------------
         Pcg64 hg;
         hg.load(a.env_s, a.env_inc, i);
+        __builtin_amdgcn_s_setprio(MDPP_NP_PRODUCER_PRIO);
         uint32_t hstatus = 0;
         if (a.park) {
             // Lanes of a producer wave are allowed to drift apart by up to kNRing steps.  Every
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     // Several producers per consumer: the consumer wave is the critical path (one dependent chain per step, while
     // the producers have a whole step of slack each), so its instructions go first whenever they are ready
     if (HELPER && NPROD > 1) __builtin_amdgcn_s_setprio(MDPP_CONSUMER_PRIO);
+    if (HELPER && !PHILOX) __builtin_amdgcn_s_setprio(MDPP_NP_CONSUMER_PRIO);
 
     float sd[ORDER + 1][D], cur[D];
 #pragma unroll

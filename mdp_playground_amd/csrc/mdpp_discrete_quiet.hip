@@ -38,6 +38,15 @@
 
 namespace mdpp {
 
+#ifndef MDPP_Q_PRIO_E
+#define MDPP_Q_PRIO_E 0
+#endif
+#ifndef MDPP_Q_PRIO_O
+#define MDPP_Q_PRIO_O 0
+#endif
+#ifndef MDPP_Q_PRIO_H
+#define MDPP_Q_PRIO_H 0
+#endif
 constexpr int kQQ = 4;                         // start states queued per lane
 // 128-bit buffer stores carry their WHOLE offset in the VGPR.  With a register in the soffset field the
 // compiler's hazard recognizer assumes that the store-data hazard of > 64-bit stores (a VALU write to the
@@ -254,6 +263,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     if constexpr (NPH > 0) if (role >= 2) {
         // =========================================================== Philox producer (see NPH above)
         const int me = role - 2;
+        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
         uint32_t hstatus = 0;
         const uint64_t G0 = a.ptick >> 2;
         const int nG = (int)(((a.ptick + (uint64_t)K - 1u) >> 2) - G0) + 1;
@@ -315,6 +325,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const bool isE = !DUO || role == 0;
     // =============================================================== H: start-state producer
     if constexpr (TRIO) if (role == 2) {
+        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
         uint64_t vals = 0;
         uint32_t tail = 0, slot = 0;
         for (;;) {
@@ -572,6 +583,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
     } else if (role == 0) {
         // -------------------------------------------------------------- E waves
+        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_E);
         u32x2 pre[kPre];
 #pragma unroll
         for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
@@ -628,6 +640,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
     } else {
         // -------------------------------------------------------------- O waves
+        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_O);
         const int nchunks = (K + kPre - 1) / kPre;
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kPre;

@@ -1,3 +1,4 @@
-echo "== cfg5 philox"; timeout 400 python tools/ablate.py run mdpp_continuous_fast.hip cfg5 philox c2p0 c0p2 c1p3 c0p0 c3p1
-echo "== shipped"; for w in "cfg2 numpy" "cfg2 philox" "cfg2_noise philox"; do timeout 100 python tools/ablate.py run mdpp_discrete_lean.hip $w shipped; done
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "unaligned_ticks or specialised or discrete_philox or lean" 2>&1 | tail -4
+echo "== cfg2_noise philox, quiet producers"; timeout 400 python tools/ablate.py run mdpp_discrete_quiet.hip cfg2_noise philox disable=NO_LEAN q000 qh3e1o2 qh2e1o3 qh0e3o2 qh0e3o0 qh0e0o3
+echo "== cfg2_noise numpy (quiet E/O)"; timeout 400 python tools/ablate.py run mdpp_discrete_quiet.hip cfg2_noise numpy q000 qh0e3o2 qh0e3o0 qh0e0o3
+echo "== cfg2_irr numpy (quiet trio)"; timeout 400 python tools/ablate.py run mdpp_discrete_quiet.hip cfg2_irr numpy disable=NO_LEAN q000 qh3e1o2 qh0e3o2 qh0e3o0 qh2e1o3
+echo "== cfg5 numpy"; timeout 400 python tools/ablate.py run mdpp_continuous_fast.hip cfg5 numpy np00 np30 np03 np21

@@ -37,7 +37,8 @@ def build(src, variants):
 
 
 def run(src, wname, rng, names):
-    over = {n.split("=", 1)[0]: eval(n.split("=", 1)[1]) for n in names if "=" in n}      # config overrides: key=python-literal
+    disable = [n.split("=", 1)[1] for n in names if n.startswith("disable=")]           # disable=NO_LEAN,...: kernel options
+    over = {n.split("=", 1)[0]: eval(n.split("=", 1)[1]) for n in names if "=" in n and not n.startswith("disable=")}   # key=python-literal
     names = [n for n in names if "=" not in n]
     objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in B.SOURCES if s != src]
     for name in names:
@@ -52,6 +53,7 @@ def run(src, wname, rng, names):
                 f"wl = bench.WORKLOADS[{wname!r}]; N = wl['envs']; F = min(512, wl.get('fuse_max', 512))\n"
                 f"cfg = dict(wl['config'], **{over!r}); cfg = {{k: v for k, v in cfg.items() if v is not None}}\n"
                 f"env = RLToyVectorEnv(num_envs=N, autoreset='same_step', rng={rng!r}, **cfg)\n"
+                f"env.set_kernel_options(*{disable!r}[0].split(',')) if {disable!r} else None\n"
                 "acts = bench.action_rotation(wl, F, N, env.device, 12345); out = env.alloc_rollout(F)\n"
                 "for j in range(5): env.rollout(acts[j % len(acts)], out)\n"
                 "torch.cuda.synchronize(); best = 1e9\n"

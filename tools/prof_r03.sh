@@ -13,7 +13,7 @@ rm -rf gpurun_out/prof_r03
 for w in cfg2 cfg3 cfg4 cfg5; do
   bash tools/pmc_traffic.sh $w 512 3 > /dev/null 2>&1; cp gpurun_out/traffic_$w.json $o/r03_traffic_$w.json
 done
-for w in cfg2 cfg5; do
+for w in cfg2 cfg5 cfg2_noise; do
   bash tools/pmc_traffic.sh $w 512 3 rng=philox > /dev/null 2>&1; cp gpurun_out/traffic_$w.json $o/r03_traffic_${w}_philox.json
 done
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc 2>/dev/null | grep '^{"metric"' > $o/r03_bench_torchrun1.json
