@@ -109,6 +109,12 @@ def lib():
         L.ora_np_pairwise_sum.restype = f64
         L.np_philox_normals.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, i32, i32, vp]
         L.np_philox_box_muller.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
+        L.np_philox_tick_word.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.np_philox_tick_word.restype = C.c_uint32
+        L.np_philox_pnoise_state.argtypes = [C.c_uint32, C.c_double, C.c_int, C.c_int]
+        L.np_philox_pnoise_state.restype = C.c_int
+        L.np_philox_tick_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.np_philox_tick_normal.restype = C.c_float
         _lib = L
     return _lib
 
@@ -215,6 +221,21 @@ def philox_normals(seed, env0, tick, stream, n_envs, n_per_env):
     out = np.zeros((n_envs, n_per_env), np.float64)
     lib().np_philox_normals(int(seed), int(env0), int(tick), int(stream), n_envs, n_per_env, _p(out))
     return out
+
+
+def philox_tick_word(seed, env, tick, stream):
+    """Philox mode, discrete envs: the 32-bit word tick `tick` draws from stream `stream` (np_random.c np_philox_tick_word)."""
+    return int(lib().np_philox_tick_word(int(seed), int(env), int(tick), int(stream)))
+
+
+def philox_pnoise_state(w, p, S, nxt):
+    """... and the state a step lands in when the table says `nxt` (np_philox_pnoise_state)."""
+    return int(lib().np_philox_pnoise_state(int(w), float(p), int(S), int(nxt)))
+
+
+def philox_tick_normal(seed, env, tick, stream):
+    """... and its reward-noise normal (float32)."""
+    return float(lib().np_philox_tick_normal(int(seed), int(env), int(tick), int(stream)))
 
 
 def rtable_from_sequences(S, L, keys, vals):

@@ -139,3 +139,58 @@ def test_philox_mode_normals_are_standard_normal():
         th = 2 * np.pi * w1 / 2.0 ** 32
         assert abs(z0.value - np.sqrt(r2) * np.cos(th)) < 3e-6 * max(np.sqrt(r2), 1) and \
             abs(z1.value - np.sqrt(r2) * np.sin(th)) < 3e-6 * max(np.sqrt(r2), 1), (w0, w1)
+
+
+def test_philox_noise_words_of_discrete_envs():
+    """Philox mode, discrete envs (the build's own definitions, mdpp_rng.hpp "one word per tick"): the word of tick t is word
+    t & 3 of the block four ticks share; the transition-noise rule is noisy iff w < ceil(p 2^32), re-drawn state = the
+    floor(w (S - 1) / T)-th of the other states -- P(noisy) = p, the others equally likely, like the reference's categorical
+    (rl_toy_env.py:1604-1622); the reward normal of tick t is normal t & 3 of the block's two Box-Muller pairs."""
+    seed, env = 99, 1234
+    for t in range(16):
+        blk = ora.philox_normals(seed, env, t >> 2, 13, 1, 4)[0]
+        assert np.float32(ora.philox_tick_normal(seed, env, t, 13)) == np.float32(blk[t & 3])
+    ws = np.array([ora.philox_tick_word(seed, env, t, 12) for t in range(4000)], dtype=np.uint64)
+    assert len(set(ws.tolist())) > 3990 and abs(ws.mean() / 2 ** 32 - 0.5) < 0.02
+    S, p, nxt = 5, 0.3, 2
+    T = int(np.ceil(p * 2 ** 32))
+    rng = np.random.default_rng(0)
+    w = rng.integers(0, 2 ** 32, size=200000, dtype=np.uint64)
+    got = np.array([ora.philox_pnoise_state(int(x), p, S, nxt) for x in w[:20000]])
+    want = np.where(w[:20000] >= T, nxt, 0)
+    j = (w[:20000].astype(object) * (S - 1)) // T                      # exact integers
+    want = np.where(w[:20000] >= T, nxt, np.array([int(v) + (int(v) >= nxt) for v in j]))
+    assert np.array_equal(got, want)
+    assert abs((got != nxt).mean() - p) < 0.01
+    others = got[got != nxt]
+    counts = np.bincount(others, minlength=S)
+    assert counts[nxt] == 0 and (np.abs(counts[[0, 1, 3, 4]] / len(others) - 0.25) < 0.02).all()
+    # boundaries: w = T - 1 is the last noisy word and lands on the last other state; w = T is quiet; S = 255 stays in range
+    assert ora.philox_pnoise_state(T - 1, p, S, nxt) == 4 and ora.philox_pnoise_state(T, p, S, nxt) == nxt
+    assert ora.philox_pnoise_state(0, p, S, 0) == 1 and ora.philox_pnoise_state(0, p, S, 3) == 0
+    T9 = int(np.ceil(0.9 * 2 ** 32))
+    assert ora.philox_pnoise_state(T9 - 1, 0.9, 255, 254) == 253 and ora.philox_pnoise_state(T9 - 1, 0.9, 255, 0) == 254
+    assert ora.philox_pnoise_state(3, 1e-9, 8, 5) == 5                   # T = 5 <= S - 1: never noisy
+
+
+def test_philox_noise_index_by_invariant_multiplication_is_the_exact_quotient():
+    """The device forms floor(w (S - 1) / T) as the top 32 bits of w x M, M = ceil(2^64 (S - 1) / T) (mdpp_rng.hpp
+    philox_pnoise_magic / philox_pnoise_index; the oracle divides).  The arithmetic restated with Python integers: equal for
+    every w next to a quotient boundary and for random w, over noise probabilities from 1e-6 to 1 - 1e-9 and 2 to 255 states."""
+    rng = np.random.default_rng(1)
+    for p in (1e-6, 0.01, 0.1, 1.0 / 3.0, 0.5, 0.97, 1.0 - 1e-9):
+        T = min(int(np.ceil(p * 2 ** 32)), 2 ** 32 - 1)
+        for S in (2, 3, 8, 37, 255):
+            if T <= S - 1:
+                continue
+            M = -((-(S - 1) << 64) // T)                                  # ceil
+            assert M < 2 ** 64
+            ws = set(int(x) for x in rng.integers(0, T, size=500))
+            for k in range(0, S):
+                b = -((-k * T) // (S - 1))                                  # first w whose quotient is k
+                ws.update(x for x in (b - 1, b, b + 1) if 0 <= x < T)
+            ws.update((0, T - 1))
+            for w in ws:
+                top = (w * (M >> 32) + ((w * (M & 0xFFFFFFFF)) >> 32)) >> 32     # the device's two multiplies
+                assert top == (w * (S - 1)) // T == (w * M) >> 64, (p, S, w)
+                assert top <= S - 2
