@@ -169,7 +169,7 @@ __device__ __forceinline__ Xform xf_unpack(uint2 v) {
     return x;
 }
 
-constexpr int kImgChunk = 16;            // env steps per batch (mdpp_env::img_chunk)
+constexpr int kImgChunk = 64;            // most env steps per batch (mdpp_env::img_chunk; one bit per step in `twos`)
 
 // One lane per env, K <= kImgChunk steps of a batch (time-major [K][N] arrays): the serial part.
 // An env that is reset in a step (autoreset && (term | trunc)) draws twice there, like the
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
         return;
     }
     // all the reset flags of the batch in one round trip
-    uint32_t twos = 0;
+    uint64_t twos = 0;
     if (a.autoreset && term) {
 #pragma unroll
         for (int k = 0; k < kImgChunk; k++)
-            if (k < K) twos |= (uint32_t)((term[(long)k * a.N + i] | trunc[(long)k * a.N + i]) != 0) << k;
+            if (k < K) twos |= (uint64_t)((term[(long)k * a.N + i] | trunc[(long)k * a.N + i]) != 0) << k;
     }
     typename std::conditional<PHILOX, Philox, Pcg64>::type g;
     Half32 h{0u, 0u};
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
     const ShiftBounds sb = shift_bounds(a, a.r0);
     for (int k = 0; k < K; k++) {
         const long j0 = ((long)k * a.N + i) * SUB;
-        const bool two = (twos >> k) & 1u;
+        const bool two = (twos >> k) & 1ull;
         if constexpr (PHILOX) {                  // this tick's stream; its buffered 32-bit half starts empty
             g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.ptick + (uint64_t)k,
                    a.is_reset ? kPhiloxResetImageStream : (uint32_t)MDPP_STREAM_IMAGE);

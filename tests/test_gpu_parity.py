@@ -1089,12 +1089,13 @@ def _img_actions(cfg, shape, seed):
 
 @pytest.mark.parametrize("name", sorted(IMG_CFGS))
 def test_image_fused_rollout_equals_single_steps(name):
-    """mdpp_step_n on an image env runs batches of 16 steps (state kernel, serial draw kernel,
-    per-image record kernel, persistent render kernel); mdpp_step runs one step with the draw and
-    the records fused.  Same arithmetic, different launch shapes: bit-identical images, rewards,
-    flags and RNG end states.  K = 40 spans two full batches and a ragged one."""
+    """mdpp_step_n on an image env runs batches of up to 32 steps (state kernel, serial draw kernel,
+    per-image record kernel, persistent render kernel), a long rollout starting with batches of 8 and 16; mdpp_step runs
+    one step with the draw and the records fused.  Same arithmetic, different launch shapes: bit-identical images,
+    rewards, flags and RNG end states.  K = 140: batches of 8, 16, 32, 32, 32 and a ragged one of 20 (cfg4; 40 elsewhere:
+    one full batch and a ragged one)."""
     cfg = dict(IMG_CFGS[name], seed=5)
-    N, K = 300, 40
+    N, K = (96, 140) if name == "cfg4" else (300, 40)
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     assert a.rollout_kernel_name(K).startswith("k_image_obs" if name == "all100" else "k_image_obs_fast<")
