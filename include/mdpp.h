@@ -46,11 +46,18 @@ enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_EST
 
 enum { MDPP_KIND_DISCRETE = 0, MDPP_KIND_CONTINUOUS = 1, MDPP_KIND_GRID = 2 };
 enum { MDPP_RNG_NUMPY_PCG64 = 0,   /* per-env numpy Generator(PCG64) streams: reference-exact */
-       MDPP_RNG_PHILOX = 1 };      /* counter-based Philox4x32-10 keyed by (seed, global env id) */
+       MDPP_RNG_PHILOX = 1 };      /* counter-based Philox4x32-10 keyed by (seed, global env id, tick, stream id): no reference for
+                                      this mode, its draws are defined in mdp_playground_amd/csrc/mdpp_rng.hpp and restated in
+                                      oracle/np_random.c.  Stream ids: 0-4 the MDPP_STREAM_* below (whole blocks per tick:
+                                      continuous / grid noise, image transforms; 4 also the irrelevant sub-space's transition
+                                      noise), 3 an explicit reset(), 5 grid noisy action, 6-8 the post-processor, 9 / 10 the
+                                      start state of an in-rollout reset (relevant / irrelevant), 11 an explicit reset()'s image,
+                                      12 discrete transition noise, 13 discrete reward noise -- ids 4 (discrete), 9, 10, 12, 13
+                                      take ONE word (one float32 normal) per tick from a block that serves four ticks */
 enum { MDPP_AUTORESET_DISABLED = 0,    /* the reference's own behaviour: keeps stepping after done */
        MDPP_AUTORESET_SAME_STEP = 1,   /* gymnasium 0.29 SyncVectorEnv: the step that ends an episode returns the next episode's first obs */
        MDPP_AUTORESET_NEXT_STEP = 2 }; /* gymnasium >= 1.0 vector envs: the step() AFTER the one that ended an episode ignores that env's
-                                          action, resets it and returns (first obs, reward 0, no flags); general kernels, no image observations */
+                                          action, resets it and returns (first obs, reward 0, no flags) */
 enum { MDPP_OBS_I64 = 0, MDPP_OBS_I32 = 1, MDPP_OBS_F32 = 2, MDPP_OBS_IMAGE_U8 = 3 };
 /* RNG streams, named after the generator object they mirror in the reference */
 enum { MDPP_STREAM_ENV = 0,        /* RLToyEnv._np_random: reset draw, reward noise, continuous P-noise */
