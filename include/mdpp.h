@@ -100,7 +100,7 @@ enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences
 enum { MDPP_CREWARD_MOVE_TO_A_POINT = 0,    /* rl_toy_env.py:1912-1945 */
        MDPP_CREWARD_MOVE_ALONG_A_LINE = 1 }; /* :1864-1910: minus the mean distance of the last L states from
                                                 the line fitted through them (first right-singular vector);
-                                                n_rel <= 4, L <= 64, no image observations */
+                                                n_rel <= 8 (state_space_dim <= 12 beyond 4), L <= 64, no image observations */
 
 typedef struct mdpp_env mdpp_env;
 

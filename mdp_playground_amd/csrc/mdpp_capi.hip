@@ -261,8 +261,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         const bool line = cfg->reward_function == MDPP_CREWARD_MOVE_ALONG_A_LINE;
         if ((cfg->reward_function != MDPP_CREWARD_MOVE_TO_A_POINT && !line) ||
-            (line && (cfg->n_rel > 4 || cfg->L < 1 || cfg->L > 64 || cfg->image))) {
-            g_create_err = "mdpp_create: move_along_a_line needs n_rel <= 4, 1 <= L <= 64 and no image observations";
+            (line && (cfg->n_rel > 8 || (cfg->n_rel > 4 && cfg->D > 12) || cfg->L < 1 || cfg->L > 64 || cfg->image))) {
+            g_create_err = "mdpp_create: move_along_a_line needs n_rel <= 8 (state_space_dim <= 12 beyond 4), 1 <= L <= 64 and no image observations";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         const size_t D = (size_t)cfg->D;
@@ -275,7 +275,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             }
         }
         const bool rew64 = line || (cfg->target_f64 && cfg->make_denser);
-        if (line) TRY(alloc_zero(h, &h->d_line_hist, (size_t)cfg->L * 4 * N * sizeof(float)));
+        const size_t line_nl = cfg->n_rel > 4 ? 8 : 4;          // row width of the history of relevant coordinates
+        if (line) TRY(alloc_zero(h, &h->d_line_hist, (size_t)cfg->L * line_nl * N * sizeof(float)));
         if (rew64 && cfg->delay > 0) TRY(alloc_zero(h, &h->d_ring64, (size_t)cfg->delay * N * sizeof(double)));
         TRY(alloc_zero(h, &h->d_sd, (size_t)(cfg->order + 1) * D * N * sizeof(float)));
         TRY(alloc_zero(h, &h->d_cur, D * N * sizeof(float)));
@@ -340,7 +341,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
-        a.line_L = line ? cfg->L : 0; a.line_hist = (float *)h->d_line_hist; a.ring64 = (double *)h->d_ring64;
+        a.line_L = line ? cfg->L : 0; a.line_NL = cfg->n_rel > 4 ? 8 : 4; a.line_hist = (float *)h->d_line_hist; a.ring64 = (double *)h->d_ring64;
         a.target64 = cfg->target_f64 ? 1 : 0; a.rew64 = rew64 ? 1 : 0; a.radius = cfg->target_radius;
         a.est = mdpp::EpisodeStatsDev{(double *)h->d_est_cur, (double *)h->d_est_last, h->est_nk};
         if (cfg->episode_stats) a.fast_ok = 0;

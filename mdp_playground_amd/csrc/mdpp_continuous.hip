@@ -20,6 +20,10 @@
 // Data layout (HBM): per-env state is struct-of-arrays, sd[k][d][env] / cur[d][env] float32, so
 // that consecutive lanes touch consecutive addresses; actions/observations are the caller's
 // [env][D] row-major tensors and are read/written as float4 per lane when D % 4 == 0.
+#ifndef MDPP_CONT_TU_LINE8
+#define MDPP_CONT_TU_LINE8 0       // 1: this translation unit holds k_continuous_step<..., NL = 8> (mdpp_continuous_line8.hip)
+#endif
+
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
@@ -102,14 +106,17 @@ __device__ __forceinline__ void c_gather_rel(const ContinuousArgs &a, const floa
 // `lds_line` (rollouts with L <= 16, round 3): the lane's L points mirrored in LDS for the launch, float4 [slot][lane];
 // the HBM copy stays the truth between launches (write-through), the per-step fit reads LDS instead of making 64 L2
 // round trips per step.
+// Rows of line_hist are 4 floats wide (a.line_NL = 4: at most 4 relevant dimensions, the LDS mirror is a float4) or 8
+// (5 to 8 relevant dimensions: k_continuous_step<..., NL = 8>, mdpp_continuous_line8.hip).
 template <int DMAX>
 __device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint32_t s, const float (&rel)[DMAX],
                                            float4 *lds_line = nullptr) {
     const uint32_t slot = s % (uint32_t)a.line_L;
-    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const size_t NL = (size_t)a.line_NL;
+    float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (j < DMAX && j < a.n_rel) { v[j] = rel[j < DMAX ? j : 0]; a.line_hist[((size_t)slot * 4 + j) * a.N + i] = v[j]; }
+    for (int j = 0; j < 8; j++)
+        if (j < DMAX && j < a.n_rel) { v[j] = rel[j < DMAX ? j : 0]; a.line_hist[((size_t)slot * NL + j) * a.N + i] = v[j]; }
     if (lds_line) lds_line[slot * kBlock + threadIdx.x] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -119,24 +126,25 @@ __device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint
 // the 4x4 float64 scatter matrix (40 normalised squarings: B <- B B / tr), rounded to float32 like
 // LAPACK's output.  The two agree to float32 rounding divided by the gap between the two largest
 // singular values, which is the accuracy the reference's own reward has.
-template <bool CACHED>
+template <bool CACHED, int NL = 4>
 __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i, uint32_t steps, const float4 *lds_line = nullptr) {
     const int L = a.line_L, n = a.n_rel;
     const size_t N = (size_t)a.N;
     // slot of the oldest of the L newest states; walked with a wrap instead of a modulo per point
     const uint32_t slot0 = (steps + 1u) % (uint32_t)L;
     uint32_t slot = slot0;
-    float x[4];
+    static_assert(NL == 4 || (NL == 8 && !CACHED), "8-wide rows: the uncached walk");
+    float x[NL];
     auto next_pt = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = (j < n) ? a.line_hist[((size_t)slot * 4 + j) * N + i] : 0.0f;
+        for (int j = 0; j < NL; j++) x[j] = (j < n) ? a.line_hist[((size_t)slot * NL + j) * N + i] : 0.0f;
         slot = (slot + 1u == (uint32_t)L) ? 0u : slot + 1u;
     };
     // CACHED (L <= 16): all points are fetched up front into registers -- 64 loads in flight instead
     // of one L2 round trip per point in each of the two passes (points beyond L repeat the newest)
     constexpr int kCache = 16;
-    float px[CACHED ? kCache : 1][4];
-    if (CACHED) {
+    float px[CACHED ? kCache : 1][NL];
+    if constexpr (CACHED) {
 #pragma unroll
         for (int k = 0; k < kCache; k++) {
             if (lds_line) {                                  // (wave-uniform) one ds_read_b128 per point
@@ -154,21 +162,25 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
     // (pairwise routine: 8 running sums while 8 more points are left, a fixed tree, the rest one by
     // one; plain left-to-right below 8 points), divided by L in float32; (2) float64 raw moments for
     // the scatter matrix about that mean: S = sum x x^T - m s^T - s m^T + L m m^T with s = sum x.
-    double s1[4] = {0.0, 0.0, 0.0, 0.0}, m[4][4];
+    double s1[NL], m[NL][NL];
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+    for (int p = 0; p < NL; p++) {
+        s1[p] = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) m[p][q] = 0.0;
-    auto moments = [&](const float (&y)[4]) __attribute__((always_inline)) {
+        for (int q = 0; q < NL; q++) m[p][q] = 0.0;
+    }
+    auto moments = [&](const float (&y)[NL]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < NL; p++) {
             s1[p] += (double)y[p];
 #pragma unroll
-            for (int q = p; q < 4; q++) m[p][q] = fma((double)y[p], (double)y[q], m[p][q]);
+            for (int q = p; q < NL; q++) m[p][q] = fma((double)y[p], (double)y[q], m[p][q]);
         }
     };
-    float mean[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (CACHED) {
+    float mean[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) mean[j] = 0.0f;
+    if constexpr (CACHED) {
         float r[8][4];
 #pragma unroll
         for (int q = 0; q < 8; q++)
@@ -192,43 +204,45 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
     } else {
         int k = 0;
         if (L >= 8) {
-            float r[8][4];
+            float r[8][NL];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 next_pt(); moments(x);
 #pragma unroll
-                for (int j = 0; j < 4; j++) r[q][j] = x[j];
+                for (int j = 0; j < NL; j++) r[q][j] = x[j];
             }
             for (k = 8; k < L - (L % 8); k += 8) {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     next_pt(); moments(x);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) r[q][j] += x[j];
+                    for (int j = 0; j < NL; j++) r[q][j] += x[j];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < NL; j++)
                 mean[j] = ((r[0][j] + r[1][j]) + (r[2][j] + r[3][j])) + ((r[4][j] + r[5][j]) + (r[6][j] + r[7][j]));
         }
         for (; k < L; k++) {
             next_pt(); moments(x);
 #pragma unroll
-            for (int j = 0; j < 4; j++) mean[j] += x[j];
+            for (int j = 0; j < NL; j++) mean[j] += x[j];
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) mean[j] = (j < n) ? mean[j] / (float)L : 0.0f;
+    for (int j = 0; j < NL; j++) mean[j] = (j < n) ? mean[j] / (float)L : 0.0f;
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+    for (int p = 0; p < NL; p++)
 #pragma unroll
-        for (int q = p; q < 4; q++) {
+        for (int q = p; q < NL; q++) {
             const double mp = (double)mean[p], mq = (double)mean[q];
             m[p][q] = m[p][q] - mp * s1[q] - s1[p] * mq + (double)L * mp * mq;
             m[q][p] = m[p][q];
         }
-    double v[4] = {1.0, 0.0, 0.0, 0.0};           // all points equal: LAPACK returns the identity, vv[0] = e0
-    double tr = m[0][0] + m[1][1] + m[2][2] + m[3][3];
+    double v[NL];                                 // all points equal: LAPACK returns the identity, vv[0] = e0
+    double tr = 0.0;
+#pragma unroll
+    for (int p = 0; p < NL; p++) { v[p] = p == 0 ? 1.0 : 0.0; tr += m[p][p]; }
     if (tr > 0.0) {
         // B <- B B, rescaled by a power of two (exact) so that tr(B) stays in [1/2, 1).  With eigenvalues
         // mu_i of B, tr(B B) / tr(B)^2 = sum mu_i^2 / (sum mu_i)^2 reaches 1 when B has rank one: stop
@@ -239,66 +253,73 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
         };
         double sc = pow2_inv(tr);
 #pragma unroll
-        for (int p = 0; p < 4; p++)
+        for (int p = 0; p < NL; p++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) m[p][q] *= sc;
+            for (int q = 0; q < NL; q++) m[p][q] *= sc;
         tr *= sc;
         for (int it = 0; it < 40; it++) {
-            double sq[4][4];
+            double sq[NL][NL];
+            double tr2 = 0.0;
 #pragma unroll
-            for (int p = 0; p < 4; p++)
+            for (int p = 0; p < NL; p++)
 #pragma unroll
-                for (int q = p; q < 4; q++) {
+                for (int q = p; q < NL; q++) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) acc = fma(m[p][r], m[r][q], acc);
+                    for (int r = 0; r < NL; r++) acc = fma(m[p][r], m[r][q], acc);
                     sq[p][q] = acc;
+                    if (q == p) tr2 += acc;
                 }
-            const double tr2 = sq[0][0] + sq[1][1] + sq[2][2] + sq[3][3];
             // (tr^2 - tr2 = 2 sum_{i<j} mu_i mu_j ~ 2 mu_1 mu_2: the relative weight of everything but the dominant
             //  direction; the vector is rounded to float32 below, 1e-12 is five digits beyond that)
             const bool conv = (tr * tr - tr2) <= 2e-12 * tr * tr;
             sc = pow2_inv(tr2);
 #pragma unroll
-            for (int p = 0; p < 4; p++)
+            for (int p = 0; p < NL; p++)
 #pragma unroll
-                for (int q = p; q < 4; q++) { m[p][q] = sq[p][q] * sc; m[q][p] = m[p][q]; }
+                for (int q = p; q < NL; q++) { m[p][q] = sq[p][q] * sc; m[q][p] = m[p][q]; }
             tr = tr2 * sc;
             if (__builtin_amdgcn_ballot_w64(!conv) == 0) break;
         }
         // m ~ v v^T: the column with the largest diagonal entry, normalised
-        double best = m[0][0];
-        double c0 = m[0][0], c1 = m[1][0], c2 = m[2][0], c3 = m[3][0];
+        double best = m[0][0], col[NL];
 #pragma unroll
-        for (int q = 1; q < 4; q++) {
+        for (int p = 0; p < NL; p++) col[p] = m[p][0];
+#pragma unroll
+        for (int q = 1; q < NL; q++) {
             const bool b = m[q][q] > best;
             best = b ? m[q][q] : best;
-            c0 = b ? m[0][q] : c0; c1 = b ? m[1][q] : c1; c2 = b ? m[2][q] : c2; c3 = b ? m[3][q] : c3;
+#pragma unroll
+            for (int p = 0; p < NL; p++) col[p] = b ? m[p][q] : col[p];
         }
-        const double s = 1.0 / sqrt(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3);
-        v[0] = c0 * s; v[1] = c1 * s; v[2] = c2 * s; v[3] = c3 * s;
+        double nn = 0.0;
+#pragma unroll
+        for (int p = 0; p < NL; p++) nn += col[p] * col[p];
+        const double s = 1.0 / sqrt(nn);
+#pragma unroll
+        for (int p = 0; p < NL; p++) v[p] = col[p] * s;
     }
     // line_end_pts = vv[0] * [-1, 1][:, None] + data_mean (float64 from here on)
-    double ptA[4], ab[4];
+    double ptA[NL], ab[NL];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NL; j++) {
         const double vj = (double)(float)v[j], mj = (double)mean[j];
         ptA[j] = vj * -1.0 + mj;
         ab[j] = ptA[j] - (vj * 1.0 + mj);
     }
     double nab = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (j < n) nab = fma(ab[j], ab[j], nab);    // np.dot: a chain of FMAs
+    for (int j = 0; j < NL; j++) if (j < n) nab = fma(ab[j], ab[j], nab);    // np.dot: a chain of FMAs
     // dist_of_pt_from_line (:2546-2576): proj = dot / |ab|, dist = sqrt(|ap|^2 - proj^2), with |ap| taken as
     // sqrt(dot(ap, ap)) and squared again there.  Here |ap|^2 is the dot product itself and dot^2 / |ab|^2 uses one
     // reciprocal per step: one square root per point instead of two and a division -- a difference of an ulp or two of
     // float64 in a reward that is defined to ~1e-7 by its float32 singular vector (tests: LINE_ATOL).
     const bool degenerate = sqrt(nab) < 1e-13;
     const double inv_nab2 = 1.0 / nab;
-    auto dist_of = [&](const float (&y)[4]) __attribute__((always_inline)) -> double {
+    auto dist_of = [&](const float (&y)[NL]) __attribute__((always_inline)) -> double {
         double dot = 0.0, nap = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NL; j++) {
             if (j < n) {
                 const double ap = ptA[j] - (double)y[j];
                 dot = fma(ab[j], ap, dot);
@@ -310,7 +331,7 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
         return degenerate ? 0.0 : sqrt(sq);
     };
     double total = 0.0;
-    if (CACHED) {
+    if constexpr (CACHED) {
 #pragma unroll
         for (int k = 0; k < kCache; k++)
             if (k < L) total += dist_of(px[k]);
@@ -348,7 +369,7 @@ __device__ __forceinline__ void c_reset_lane(const ContinuousArgs &a, G &sp, flo
         for (int d = 0; d < DMAX; d++) sd[k][d] = (k == 0) ? cur[d] : 0.0f;
 }
 
-template <int DMAX, int OMAX, bool PHILOX>
+template <int DMAX, int OMAX, bool PHILOX, int NL = 4>
 __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, int K,
                                                             const float *__restrict__ actions,
                                                             float *__restrict__ obs,
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     flags &= ~2u;
 
     float4 *lds_line = nullptr;
-    if (a.line_L && a.line_lds) {                            // this lane's L points: HBM -> LDS once per launch
+    if (NL == 4 && a.line_L && a.line_lds) {                 // this lane's L points: HBM -> LDS once per launch
         lds_line = s_line;
         for (int sl = 0; sl < a.line_L; sl++) {
             float q[4];
@@ -571,8 +592,10 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             // gate (:1856): the state sequence_length transitions back must exist
             c_line_put<DMAX>(a, i, steps, rel, lds_line);
             r.v = 0.0;
-            if (steps >= (uint32_t)a.line_L)
-                r.v = a.line_L <= 16 ? c_line_reward<true>(a, i, steps, lds_line) : c_line_reward<false>(a, i, steps);
+            if (steps >= (uint32_t)a.line_L) {
+                if constexpr (NL == 4) r.v = a.line_L <= 16 ? c_line_reward<true, 4>(a, i, steps, lds_line) : c_line_reward<false, 4>(a, i, steps);
+                else r.v = c_line_reward<false, NL>(a, i, steps);
+            }
             r.is32 = false;
         } else if (a.make_denser && a.target64) {
             float relo[DMAX];
@@ -719,31 +742,45 @@ __global__ __launch_bounds__(kBlock) void k_continuous_reset(ContinuousArgs a, u
 }
 
 // ---- dispatch on (padded D, padded order) -------------------------------------------------
-template <int DMAX, int OMAX>
+template <int DMAX, int OMAX, int NL = 4>
 static void launch_step_t(const ContinuousArgs &a, int K, const float *actions, float *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, float *final_obs,
                           hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_continuous_step<DMAX=%d,OMAX=%d,PHILOX=%d>", DMAX, OMAX, a.philox != 0);
+        if (NL == 4) snprintf(name_out, kNameLen, "k_continuous_step<DMAX=%d,OMAX=%d,PHILOX=%d>", DMAX, OMAX, a.philox != 0);
+        else snprintf(name_out, kNameLen, "k_continuous_step<DMAX=%d,OMAX=%d,PHILOX=%d,NL=%d>", DMAX, OMAX, a.philox != 0, NL);
         return;
     }
-    // move_along_a_line with L <= 16, rollouts: the L points of every lane mirrored in (dynamic) LDS for the launch
+    // move_along_a_line with L <= 16 (rows of 4), rollouts: the L points of every lane mirrored in (dynamic) LDS for the launch
     ContinuousArgs al = a;
-    al.line_lds = (a.line_L > 0 && a.line_L <= 16 && K >= 4) ? 1 : 0;
+    al.line_lds = (NL == 4 && a.line_L > 0 && a.line_L <= 16 && K >= 4) ? 1 : 0;
     const size_t lds = al.line_lds ? (size_t)a.line_L * kBlock * sizeof(float4) : 0;
     if (a.philox) {
         if (lds > 32 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, true>), dim3(grid), dim3(kBlock), lds, s, al,
+            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, true, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, true, NL>), dim3(grid), dim3(kBlock), lds, s, al,
                            K, actions, obs, reward, term, trunc, final_obs);
     } else {
         if (lds > 32 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, false>), dim3(grid), dim3(kBlock), lds, s, al,
+            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, false, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, false, NL>), dim3(grid), dim3(kBlock), lds, s, al,
                            K, actions, obs, reward, term, trunc, final_obs);
     }
 }
+#if MDPP_CONT_TU_LINE8
+// move_along_a_line with 5 to 8 relevant dimensions (state_space_dim <= 12): rows of 8, an 8 x 8 scatter matrix in registers
+bool launch_continuous_step_line8(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+                                  uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
+    if (a.line_NL != 8 || a.D > 12 || a.order > 4) return false;
+    if (a.order <= 1) launch_step_t<12, 1, 8>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    else if (a.order <= 2) launch_step_t<12, 2, 8>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    else launch_step_t<12, 4, 8>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    return true;
+}
+#else
+bool launch_continuous_step_line8(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
+                                  uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out);
 template <int DMAX, int OMAX>
 static void launch_reset_t(const ContinuousArgs &a, uint64_t reset_tick, const uint8_t *mask,
                            float *obs, hipStream_t s) {
@@ -810,9 +847,16 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
         h->tick += (uint64_t)K;
         return MDPP_OK;
     }
+    if (a.line_L && a.line_NL == 8) {
+        if (!launch_continuous_step_line8(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
+            h->err = "k_continuous_step<NL=8>: move_along_a_line with 5 to 8 relevant dimensions needs state_space_dim <= 12";
+            return MDPP_EUNSUPPORTED;
+        }
+    } else {
 #define CALL_STEP(DM, OM) launch_step_t<DM, OM>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)
-    MDPP_C_DISPATCH(CALL_STEP);
+        MDPP_C_DISPATCH(CALL_STEP);
 #undef CALL_STEP
+    }
     if (name_out) return MDPP_OK;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("k_continuous_step launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
@@ -830,5 +874,6 @@ int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStr
     h->reset_tick += 1;
     return MDPP_OK;
 }
+#endif   // !MDPP_CONT_TU_LINE8
 
 } // namespace mdpp

@@ -133,9 +133,10 @@ struct ContinuousArgs {
     uint2 *meta;                // {steps, flags: bit0 reached_terminal}
     uint32_t *ring;             // [delay][N] float32 bit patterns (kRingPyZero = Python 0.0)
     // reward_function move_along_a_line (0 = move_to_a_point): sequence_length, the last line_L states'
-    // relevant coordinates [slot = s % line_L][4][N] (s = transitions made when the state was
+    // relevant coordinates [slot = s % line_L][line_NL][N] (s = transitions made when the state was
     // reached), and a float64 delay line (these rewards are Python floats)
     int32_t line_L;
+    int32_t line_NL;            // row width of line_hist: 4 (at most 4 relevant dimensions) or 8
     int32_t line_lds;           // this launch mirrors the L points of every lane in dynamic LDS (set by launch_step_t)
     float *line_hist;
     double *ring64;             // [delay][N]

@@ -467,10 +467,12 @@ def build_continuous(config) -> ContinuousMDP:
         raise NotImplementedError("ImageContinuous observations: 2 relevant dimensions, and 2 or 4 state "
                                   "dimensions in all (the reference's picture is built from dims [0, 1] and [2, 3])")
     if line:
-        # :1864-1910: the fit runs on the device for up to 4 relevant dimensions (a 4x4 scatter matrix
-        # kept in registers) and up to 64 states; no target, no target latch (:1719)
-        if len(rel) > 4 or common["sequence_length"] > 64:
-            raise NotImplementedError("move_along_a_line: at most 4 relevant dimensions and sequence_length <= 64")
+        # :1864-1910: the fit runs on the device for up to 8 relevant dimensions (a scatter matrix kept in registers: 4 x 4,
+        # or 8 x 8 in its own kernel instantiation for 5 to 8, which needs state_space_dim <= 12) and up to 64 states;
+        # no target, no target latch (:1719)
+        if len(rel) > 8 or (len(rel) > 4 and D > 12) or common["sequence_length"] > 64:
+            raise NotImplementedError("move_along_a_line: at most 8 relevant dimensions (state_space_dim <= 12 beyond 4) "
+                                      "and sequence_length <= 64")
         if image is not None:     # :767-775 hands self.target_point to ImageContinuous; only move_to_a_point sets it (:650)
             raise AttributeError("'RLToyEnv' object has no attribute 'target_point' (the reference's constructor fails for "
                                  "move_along_a_line with image_representations)")

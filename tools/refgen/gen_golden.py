@@ -250,6 +250,13 @@ CASES = {
                     terminal_states=[[3.0, 3.0, 3.0]], term_state_edge=9.0, term_state_reward=-1.0,
                     reward_function="move_along_a_line"),
         seeds=list(range(4)), T=160, reset="mixed", straight_window=9, bad_action_every=29),
+    "c_line_6of8": dict(     # six relevant dimensions (rows of 8 in the line history, the 8 x 8 scatter matrix)
+        config=dict(state_space_type="continuous", state_space_dim=8, irrelevant_features=True,
+                    relevant_indices=[0, 2, 3, 4, 6, 7], transition_dynamics_order=1, inertia=1.0,
+                    time_unit=1.0, state_space_max=6, action_space_max=1, delay=1,
+                    sequence_length=7, reward_scale=1.5,
+                    reward_function="move_along_a_line"),
+        seeds=list(range(3)), T=120, reset="mixed", straight_window=11),
     # --- continuous + ImageContinuous observations: RGB pictures, and the
     # reference's quirk that every step takes the clip-and-zero-derivatives branch -----------------
     "ci_2d": dict(
