@@ -81,6 +81,9 @@ namespace mdpp {
 #ifndef MDPP_LEAN_PRIO_H
 #define MDPP_LEAN_PRIO_H 0
 #endif
+#ifndef MDPP_LEAN_PRIO_O2
+#define MDPP_LEAN_PRIO_O2 -1       // (>= 0: the O2 waves' own priority; tools/ablate.py)
+#endif
 #ifndef MDPP_LEAN_ST_AUX
 #define MDPP_LEAN_ST_AUX MDPP_ST_NT
 #endif
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== O2: observation, terminated, truncated
     if (role == 2) {
-        __builtin_amdgcn_s_setprio(kPrioO);
+        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O2 >= 0 ? MDPP_LEAN_PRIO_O2 : kPrioO);
         auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
