@@ -298,7 +298,9 @@ const char *mdpp_kernel_name(mdpp_env *h, int K);
 
 /* Philox-mode streams made visible (diagnostics, offline reproduction of the noise): out_dev[e][j]
  * (double, device) = the j-th standard normal of stream (seed, env_id0 + e, tick, stream id) -- a float32
- * Box-Muller pair per 64-bit draw, see mdp_playground_amd/csrc/mdpp_rng.hpp.  Runs on the current device. */
+ * Box-Muller pair per 64-bit draw, see mdp_playground_amd/csrc/mdpp_rng.hpp.  Runs on the current device.
+ * (The reward noise of a DISCRETE env at tick t is normal t & 3 of stream (seed, env, t >> 2, 13): call with tick = t >> 2,
+ *  stream = 13, n_per_env = 4.) */
 int mdpp_philox_normals(uint64_t seed, int64_t env_id0, uint64_t tick, uint32_t stream, int32_t n_envs,
                         int32_t n_per_env, double *out_dev, void *hip_stream);
 
