@@ -320,12 +320,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     const uint32_t m = wd[u] >> 1;
                     uint32_t s0 = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) s0 += (thr[j] <= m) ? 1u : 0u;
+                    for (int j = 0; j < 7; j++) s0 += (thr[j] <= m) ? 1u : 0u;       // (entry 7: cdf 1.0 or padding, 2^31 > m)
                     if (IRR) {
                         const uint32_t m1 = wd1[u] >> 1;
                         uint32_t s1 = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) s1 += (thr1[j] <= m1) ? 1u : 0u;
+                        for (int j = 0; j < 7; j++) s1 += (thr1[j] <= m1) ? 1u : 0u;
                         s0 |= (s1 | 8u) << 4;
                     }
                     pk |= (S0Word)(s0 | 8u) << (kEN * 4 * u);
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);
         const uint32_t r4 = (uint32_t)a.ptick & 3u;
         float zc[kChunk] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};         // RN: the chunk's reward normals
+        const bool plain = a.scale == 1.0 && a.shift == 0.0;                        // (wave-uniform)
         auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, float z) {
             uint32_t bit = lds_V[(ra >> 5) & 2047u] >> (ra & 31u);                   // reward bit, NaN-gated (:1822)
             uint32_t out;
@@ -436,8 +437,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             if constexpr (RN) {                                                      // :1975-1990, :2107 in float64
                 double r = (out != 0u && (!EVN || rd == 0u)) ? 1.0 : 0.0;
                 r += 0.0 + a.r_noise * (double)z;
-                r *= a.scale;
-                r += a.shift;
+                if (!plain) {                // (scale 1, shift 0: r * 1.0 and r + 0.0 are r -- it is never -0.0 here)
+                    r *= a.scale;
+                    r += a.shift;
+                }
                 if (tb) r += a.term_add;
                 rout = (float)r;
             } else {

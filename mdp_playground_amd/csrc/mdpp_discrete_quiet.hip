@@ -303,7 +303,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                     uint32_t s0 = 0;
                     if (small) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) s0 += (t31[j] <= m31) ? 1u : 0u;
+                        for (int j = 0; j < 7; j++) s0 += (t31[j] <= m31) ? 1u : 0u;     // (entry 7: cdf 1.0 or padding)
                     } else {
                         for (uint32_t b = 0; b < S8; b += 8) {
 #pragma unroll
