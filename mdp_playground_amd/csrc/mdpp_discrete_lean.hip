@@ -278,8 +278,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== H: start-state producer
     if (role == 3) {
-#ifdef MDPP_ABL_NOH
-        return;
+#if defined(MDPP_ABL_NOH) && defined(MDPP_ABL_NORESET)
+        return;         // (only together with NORESET: without the H waves every reset spins to its bound -- minutes per launch)
 #endif
         if (!ar && !PN) return;
         __builtin_amdgcn_s_setprio(kPrioH);
