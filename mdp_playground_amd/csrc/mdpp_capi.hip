@@ -110,7 +110,6 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     // env steps per batch of an image rollout: 32 (cfg4: 7 740 -> 7 440 us per 512 steps against 16: fewer kernel tails; 64 is
     // slower again, the first batch's serial draw kernel is not hidden) while the scratch of two batches stays below 1 GiB
     h->img_chunk = (size_t)cfg->num_envs * (cfg->irrelevant ? 2 : 1) <= 65536 ? 32 : 16;
-    if (const char *e = getenv("MDPP_IMG_CHUNK")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) h->img_chunk = v; }   // (tuning)
     h->img_ready = false; h->img_fast_ok = false; h->img_lines_ready = false;
     for (int r = 0; r < 32; r++) h->imgc_disc_rows[r] = 0;
     h->img_n_radii = h->img_n_cls_x = h->img_n_cls_y = 0;
