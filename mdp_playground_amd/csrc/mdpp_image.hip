@@ -567,10 +567,14 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
             // (the comment below: rounds 1-2 had 40 KiB per workgroup, 4 resident workgroups per CU)
             // (phase 2 = the pipelined rollout: a few CUs keep a slot free, so that the next batch's state
             // kernel, which needs a little LDS, can run beside this one)
-            // as many slots as the state kernel has workgroups (measured on cfg4, 32 of them: 16 reserved
-            // slots give no overlap at all, 32 and 64 the same +13 %, 128 less), at most 64
-            unsigned reserve = ((unsigned)a.N + kBlock - 1) / kBlock;
-            reserve = reserve < 8u ? 8u : (reserve > 64u ? 64u : reserve);
+            // a few slots (rounds 1-2, 40 KiB of LDS per workgroup, four per CU: as many as the state kernel has workgroups --
+            // 16 gave no overlap at all, 32 and 64 the same +13 %; round 3, LDS sized by the launch, five per CU for cfg4 and
+            // batches of 32 steps: 7 385 / 7 672 us per launch with 32 reserved slots, 7 227 / 7 551 with 8, 7 289 / 7 660
+            // with none, on two boxes)
+            unsigned reserve = 8u;
+#ifdef MDPP_IMG_RESERVE
+            reserve = MDPP_IMG_RESERVE;
+#endif
             const unsigned resident = per_cu * (unsigned)h->num_cus - (phase == 2 ? reserve : 0u);
             const dim3 grid(nblk < resident ? nblk : resident);
             const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);

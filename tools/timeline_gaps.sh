@@ -2,7 +2,7 @@
 # k_discrete_rollout_lean launch, the gap to the next one and what ran in between (the legs: none, replay, last_row, full)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 rm -rf gpurun_out/tl
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --gpus 1 --steps 12 --warmup 3 --no-cpu-baseline --no-pmc --no-workloads > gpurun_out/tl.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 bench.py --gpus 1 --steps ${TL_STEPS:-12} --warmup 3 --no-cpu-baseline --no-pmc --no-workloads ${TL_ARGS} > gpurun_out/tl.log 2>&1
 python3 - <<'PY'
 import csv, glob
 ev = []
@@ -13,7 +13,9 @@ for f in glob.glob("gpurun_out/tl/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "MEMCPY " + r.get("Direction", ""), ""))
 ev.sort()
-lean = [k for k, e in enumerate(ev) if "rollout_lean" in e[2]]
+import os
+pat = os.environ.get("TL_KERNEL", "rollout_lean")
+lean = [k for k, e in enumerate(ev) if pat in e[2]]
 print("lean kernels:", len(lean))
 # gaps between consecutive lean kernels, grouped
 gaps = []
