@@ -415,6 +415,11 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     DiscreteArgs a = h->dargs;
     a.opts = h->opts;
+    // image handles: this is the state kernel of a batch of the image pipeline, which runs BESIDE the persistent renderer of the
+    // previous batch (mdpp_capi.hip image_batches).  The role-split kernels want most of a CU's LDS and wait for the renderer's
+    // workgroups to leave (k_discrete_rollout_pipe: 38 us alone, 308 us average beside the renderer, and the batch's draw and
+    // record kernels queue behind it); the single-role kernel needs a kilobyte and always fits.
+    if (h->cfg.image) a.opts |= MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN;
     a.ptick = h->tick;
     a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     const bool noise = a.has_p_noise || a.has_r_noise;
