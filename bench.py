@@ -368,8 +368,6 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="timed bench steps; ONE bench step = one fused launch of "
                     "--fuse env steps of every env instance of every rank")
     ap.add_argument("--warmup", type=int, default=5, help="untimed bench steps (launches) before the timed ones")
-    ap.add_argument("--no-stream-probe", action="store_true", help="run the legs on the current (default) stream instead of the "
-                    "quickest of five candidate launch streams (see 'the launch stream' in main)")
     ap.add_argument("--fuse", type=int, default=512, help="env steps per fused launch (mdpp_step_n), the same for every --gpus")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="env instances per GPU")
@@ -477,31 +475,10 @@ def main():
             elapsed = float(t.item())
         return elapsed, kernel_ms
 
-    # ---- the launch stream.  Streams share a few hardware queues, and a launch stream that shares one with the backend's
-    # collective stream serialises every gather with the next launch (the default stream did in the probe of round 3:
-    # + 175 us per launch on one box, + 10 on another; a stream apart + 4-7).  Which torch stream maps to which queue cannot
-    # be asked, so it is measured: a few launches + gathers on each candidate, the quickest one runs every leg.
-    stream_probe = None
-    if dist is not None and not args.no_stream_probe:
-        cands = [("default", torch.cuda.current_stream(device))] + [(f"side{k}", torch.cuda.Stream(device)) for k in range(3)] + \
-                [("high_priority", torch.cuda.Stream(device, priority=-1))]
-        g_probe = [ObsGatherer(o[0][-1], world, dist, always_collective=True) for o in outs]
-        stream_probe = {}
-        for name, st in cands:
-            with torch.cuda.stream(st):
-                run(3, g_probe)
-                torch.cuda.synchronize(device)
-                env.timer_begin()
-                run(8, g_probe)
-                stream_probe[name] = env.timer_end() * 1e3 / 8
-                torch.cuda.synchronize(device)
-        if world > 1:      # (every rank may pick its own stream; the probe's collectives were the same on all of them)
-            dist.barrier()
-        best = min(stream_probe, key=stream_probe.get)
-        torch.cuda.set_stream(dict(cands)[best])
-        stream_probe = {"picked": best, "us_per_launch_with_gather": {k: round(v, 1) for k, v in stream_probe.items()}}
-        del g_probe
-
+    # (Every leg runs on the default stream.  A probe that picked "the quickest of five candidate launch streams" was tried in
+    # round 3 and taken out again: the candidates measured the same with the collective, and a picked stream that happened to
+    # share a hardware queue with an image handle's side stream serialised cfg4's prepare and render stages -- 7.4 or 8.4 ms per
+    # launch from run to run.)
     # ---- leg "none": no collective.  Its HIP-event time (launch stream) is the roofline leg: every launch reads a
     # different action tensor (NA of them, > the Infinity Cache together)
     run(max(args.warmup, 1), None)
@@ -610,7 +587,6 @@ def main():
                        "envs_per_gpu": N, "fuse": F, "env_steps_per_bench_step": world * N * F, "rng": args.rng,
                        "disabled_kernels": args.disable or None,
                        "collective": collective,
-                       "launch_stream": stream_probe,
                        "value_is": "the `last_row` leg (launch + the path's all-gather) for every --gpus, one rank included"
                                    if v_last is not None else "the `none` leg (no process group in this run)"},
             "value_none": v_none, "value_last_row": v_last,

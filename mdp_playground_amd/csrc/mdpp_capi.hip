@@ -164,7 +164,17 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         free_all(h); delete h; return MDPP_EUNSUPPORTED;
     }
     if (cfg->image) {      // image rollouts pipeline their batches over a side stream (step_common)
-        TRYHIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        // (at the highest priority: streams of one priority share a few hardware queues, and a side stream that lands in the
+        //  caller's queue serialises the two pipeline stages -- 7.4 or 8.4 ms per cfg4 launch from run to run when bench.py
+        //  ran its legs on a non-default stream; the queues of another priority are not the caller's unless it asks for them)
+        {
+            int lo = 0, hi = 0;
+            TRYHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+#ifdef MDPP_ABL_SIDE_NORMAL
+            hi = 0;
+#endif
+            TRYHIP(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, hi));
+        }
         for (hipEvent_t *e : {&h->ev_entry, &h->ev_side[0], &h->ev_side[1], &h->ev_render[0], &h->ev_render[1]})
             TRYHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }

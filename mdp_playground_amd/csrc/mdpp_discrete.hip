@@ -419,7 +419,9 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
     // previous batch (mdpp_capi.hip image_batches).  The role-split kernels want most of a CU's LDS and wait for the renderer's
     // workgroups to leave (k_discrete_rollout_pipe: 38 us alone, 308 us average beside the renderer, and the batch's draw and
     // record kernels queue behind it); the single-role kernel needs a kilobyte and always fits.
+#ifndef MDPP_ABL_IMG_STATE_PIPE
     if (h->cfg.image) a.opts |= MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN;
+#endif
     a.ptick = h->tick;
     a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     const bool noise = a.has_p_noise || a.has_r_noise;
