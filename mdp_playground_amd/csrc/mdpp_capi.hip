@@ -52,7 +52,7 @@ static void free_all(mdpp_env *h) {
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final, h->d_img_rec, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last};
+                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -106,7 +106,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_est_cur = h->d_est_last = nullptr; h->est_nk = 0;
     h->irr_ready = false;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
-    h->d_img_state_out = h->d_img_state_final = h->d_img_rec = nullptr;
+    h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
     // env steps per batch of an image rollout: 32 (cfg4: 7 740 -> 7 440 us per 512 steps against 16: fewer kernel tails; 64 is
     // slower again, the first batch's serial draw kernel is not hidden) while the scratch of two batches stays below 1 GiB
     h->img_chunk = (size_t)cfg->num_envs * (cfg->irrelevant ? 2 : 1) <= 65536 ? 32 : 16;
@@ -150,6 +150,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * 4 * sub));
         TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * 4 * sub));
         TRY(alloc_zero(h, &h->d_img_rec, 2 * 2 * (size_t)h->img_chunk * N * 64 * sub));
+        TRY(alloc_zero(h, &h->d_img_ctr, 2 * 2 * 64 * 128));     // [scratch set][render launch][kImgCtrs] counters, 128 B apart
     }
 
     if (cfg->image && cfg->kind == MDPP_KIND_DISCRETE && (cfg->img_w < 1 || cfg->img_h < 1 || cfg->img_tpl_size < 1)) {

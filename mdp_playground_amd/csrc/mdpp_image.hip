@@ -70,6 +70,8 @@ struct ImageArgs {
     // order the reference draws them (the step's images, then reset()'s where the step ended the episode); an explicit
     // reset() from stream kPhiloxResetImageStream keyed by the reset count
     int32_t coldw;             // fast renderer: dwords of image columns per wave in LDS (host: the widest box + slack)
+    uint32_t *work_ctr;        // fast renderer: [2][kImgCtrs x 32] work counters of this batch's two render launches, one per group of waves,
+                               // 128 B apart (zeroed by k_image_draw)
     int32_t philox, is_reset;
     uint64_t philox_seed, ptick;
     int64_t env_id_offset;
@@ -169,6 +171,10 @@ __device__ __forceinline__ Xform xf_unpack(uint2 v) {
     return x;
 }
 
+#ifndef MDPP_IMG_CTRS
+#define MDPP_IMG_CTRS 32
+#endif
+constexpr int kImgCtrs = MDPP_IMG_CTRS;   // work counters of the fast renderer (k_image_obs_fast; at most 64: mdpp_capi.hip sizes the array)
 constexpr int kImgChunk = 64;            // most env steps per batch (mdpp_env::img_chunk; one bit per step in `twos`)
 
 // One lane per env, K <= kImgChunk steps of a batch (time-major [K][N] arrays): the serial part.
@@ -186,6 +192,8 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
                                                        const uint8_t *__restrict__ trunc,
                                                        const uint8_t *__restrict__ mask) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (a.work_ctr)                                      // (the renderer of this batch runs after this kernel)
+        for (long k = i; k < 2L * kImgCtrs * 32; k += (long)gridDim.x * kBlock) a.work_ctr[k] = 0u;
     if (i >= a.N) return;
     const int SUB = a.SUB;
     if (mask && !mask[i]) {
@@ -471,17 +479,71 @@ __device__ __forceinline__ void render_fast_store(const ImageArgs &a, const ColR
 // under the evaluation of the next.
 template <int NST>
 __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, const ImgRec *__restrict__ rec,
-                                                           uint8_t *__restrict__ img) {
+                                                           uint8_t *__restrict__ img, uint32_t *__restrict__ ctr) {
     // LDS, sized by the launch (round 3): tplp template rows of 256 B, then coldw dwords of image columns per wave -- for
     // 84 x 84 images at R = 20 that is 14.25 + 4 x 4.4 KiB = 31.75 KiB, FIVE workgroups per CU where the fixed 16 + 24 KiB
     // of rounds 1-2 allowed four: more waves whose evaluation and store phases interleave
     extern __shared__ __align__(16) uint8_t lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;
+    // Work distribution (round 3): a wave CLAIMS its next image from a counter instead of walking j, j + (waves in the grid),
+    // ...: the next batch's state / draw / record kernels run beside this kernel on a few CUs, images differ in cost, and with
+    // a static split the slowest wave sets the kernel's duration (a 32-step render: 427 us alone, 465-475 us beside them).
+    // cfg4 on one box: static 7 770 us per launch; claims of 1 / 2 / 4 / 8 images 6 960 / 7 380 / 7 620 / 7 720 (consecutive
+    // images in one wave cost more than the coarser balance saves); 8 / 16 / 32 / 64 counters 7 110 / 6 930 / 6 910 / 6 950.
+#ifndef MDPP_IMG_DYNAMIC
+#define MDPP_IMG_DYNAMIC 1
+#endif
+#ifndef MDPP_IMG_CLAIM
+#define MDPP_IMG_CLAIM 1
+#endif
+    constexpr long kImgClaim = MDPP_IMG_CLAIM;
+    const size_t isz = (size_t)a.W * a.H;
+#if MDPP_IMG_DYNAMIC
+    // One counter per group of waves (wave id mod kImgCtrs: its waves sit on CUs all over the chip), each over its own
+    // contiguous slice of the images: a single counter saturates -- 65 536 same-address atomics per batch took as long as the
+    // rendering itself.  The claim's result stays in a vector register until it is needed, a whole chunk later.
+    const long wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
+    const long grp = wid % kImgCtrs;
+    const long per = (M + kImgCtrs - 1) / kImgCtrs;
+    const long g0 = grp * per;
+    M = g0 + per < M ? g0 + per : M;             // (from here on: the end of this group's slice)
+    uint32_t *const gctr = ctr + grp * 32;
+    uint32_t pend = 0;
+    auto claim_issue = [&]() __attribute__((always_inline)) { if (lane == 0) pend = atomicAdd(gctr, (uint32_t)kImgClaim); };
+    auto claim_take = [&]() __attribute__((always_inline)) -> long {
+        return g0 + (long)(uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+    };
+    claim_issue();
+    long base = claim_take();
+    if (base >= M) return;
+    claim_issue();                               // (one chunk ahead)
+    long j = base;
+    RecRegs cur = load_rec(rec + j);
+    stage_tpl(a, load_tpl(a, cur.lo[7] >> 12, lane), lds, wave, lane);
+    for (;;) {
+        const bool last_of_chunk = j + 1 >= base + kImgClaim || j + 1 >= M;
+        long jn = j + 1;
+        if (last_of_chunk) {                     // (wave-uniform)
+            jn = claim_take();
+            base = jn;
+            if (jn < M) claim_issue();
+        }
+        const bool more = jn < M;
+        const bool skip = cur.lo[7] & (1u << 11);
+        const RecRegs nxt = load_rec(rec + (more ? jn : j));
+        const TplRegs tp = load_tpl(a, nxt.lo[7] >> 12, lane);
+        ColRange cr{0, 0};
+        if (!skip) cr = render_fast_eval(a, cur, lds, lds_col, wave, lane);
+        stage_tpl(a, tp, lds, wave, lane);
+        if (!skip) render_fast_store<NST>(a, cr, lds_col, img + (size_t)j * isz, lane);
+        if (!more) break;
+        j = jn; cur = nxt;
+    }
+#else
     const int nw = (int)gridDim.x * (kBlock / 64);
     long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
     if (j >= M) return;
-    const size_t isz = (size_t)a.W * a.H;
     RecRegs cur = load_rec(rec + j);
     stage_tpl(a, load_tpl(a, cur.lo[7] >> 12, lane), lds, wave, lane);
     for (;;) {
@@ -497,6 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
         if (!more) break;
         j = jn; cur = nxt;
     }
+#endif
 }
 
 // K steps x N envs, arrays time-major; mask (reset only, K = 1) selects envs.  img_out == nullptr:
@@ -531,6 +594,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.ptick = a.is_reset ? h->reset_tick - 1 : h->tick - (uint64_t)K;
     a.rec0 = (ImgRec *)h->d_img_rec + (size_t)buf * 2 * h->img_chunk * c.num_envs * a.SUB;
     a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs * a.SUB;
+    a.work_ctr = (uint32_t *)h->d_img_ctr + (size_t)buf * 2 * kImgCtrs * 32;
     static_assert(kBlock == 256, "render_fast packs four 64-byte template columns into a 256-byte LDS row");
     if (!(phase & 1)) {
         // records of this batch were made earlier (side stream)
@@ -581,9 +645,10 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
             for (int pass = 0; pass < (img_final ? 2 : 1); pass++) {
                 const ImgRec *rec = pass ? a.rec1 : a.rec0;
                 uint8_t *img = pass ? img_final : img_out;
-                if (nst == 7) hipLaunchKernelGGL(k_image_obs_fast<7>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img);   // 84 x 84
-                else if (nst == 4) hipLaunchKernelGGL(k_image_obs_fast<4>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img); // 64 x 64
-                else hipLaunchKernelGGL(k_image_obs_fast<0>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img);
+                uint32_t *ctr = a.work_ctr + pass * kImgCtrs * 32;
+                if (nst == 7) hipLaunchKernelGGL(k_image_obs_fast<7>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img, ctr);   // 84 x 84
+                else if (nst == 4) hipLaunchKernelGGL(k_image_obs_fast<4>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img, ctr); // 64 x 64
+                else hipLaunchKernelGGL(k_image_obs_fast<0>, grid, dim3(kBlock), lds_bytes, s, a, M, rec, img, ctr);
             }
         } else {
             const size_t lds = (size_t)per_block * (((size_t)a.tpl * a.tpl + 15) & ~(size_t)15);

@@ -200,6 +200,7 @@ struct mdpp_env {
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
     void *d_img_tpl, *d_img_tplp, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;
     void *d_img_rec;            // ImgRec [2][img_chunk][N] per-image records (mdpp_image.hip), 64 B each
+    void *d_img_ctr;            // uint32 [2][2]: the fast renderer's work counters (scratch set x render launch)
     int32_t img_chunk;          // env steps per state-kernel + draw + render batch
     uint32_t imgc_disc_rows[32]; // continuous image observations: the disc raster, one bitmask per row
     bool img_ready, img_fast_ok, img_lines_ready;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
