@@ -107,9 +107,17 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->irr_ready = false;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
-    // env steps per batch of an image rollout: 32 (cfg4: 7 740 -> 7 440 us per 512 steps against 16: fewer kernel tails; 64 is
-    // slower again, the first batch's serial draw kernel is not hidden) while the scratch of two batches stays below 1 GiB
-    h->img_chunk = (size_t)cfg->num_envs * (cfg->irrelevant ? 2 : 1) <= 65536 ? 32 : 16;
+    // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
+    // 7 740 us per 512 steps with batches of 16, 7 440 with 32; with the renderer's waves claiming their images, 7 250 / 6 830 /
+    // 6 660 with 16 / 32 / 64: fewer kernel tails and hand-overs; a long rollout starts with batches of 8 and 16 because
+    // nothing hides the first batch's serial draw kernel, image_batches)
+    {
+        const size_t imgs = (size_t)cfg->num_envs * (cfg->irrelevant ? 2 : 1);
+        h->img_chunk = imgs <= 32768 ? 64 : imgs <= 65536 ? 32 : 16;
+    }
+#ifdef MDPP_ABL_IMG_CHUNK
+    h->img_chunk = MDPP_ABL_IMG_CHUNK;
+#endif
     h->img_ready = false; h->img_fast_ok = false; h->img_lines_ready = false;
     for (int r = 0; r < 32; r++) h->imgc_disc_rows[r] = 0;
     h->img_n_radii = h->img_n_cls_x = h->img_n_cls_y = 0;

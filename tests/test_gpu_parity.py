@@ -1162,13 +1162,13 @@ def _img_actions(cfg, shape, seed):
 
 @pytest.mark.parametrize("name", sorted(IMG_CFGS))
 def test_image_fused_rollout_equals_single_steps(name):
-    """mdpp_step_n on an image env runs batches of up to 32 steps (state kernel, serial draw kernel,
-    per-image record kernel, persistent render kernel), a long rollout starting with batches of 8 and 16; mdpp_step runs
-    one step with the draw and the records fused.  Same arithmetic, different launch shapes: bit-identical images,
-    rewards, flags and RNG end states.  K = 140: batches of 8, 16, 32, 32, 32 and a ragged one of 20 (cfg4; 40 elsewhere:
-    one full batch and a ragged one)."""
+    """mdpp_step_n on an image env runs batches of up to 64 steps (state kernel, serial draw kernel, per-image record
+    kernel, persistent render kernel whose waves claim their images from counters), a long rollout starting with batches of 8
+    and 16; mdpp_step runs one step with the draw and the records fused.  Same arithmetic, different launch shapes:
+    bit-identical images, rewards, flags and RNG end states.  K = 300: batches of 8, 16, 64, 64, 64, 64 and a ragged one of
+    20 (cfg4; 40 elsewhere: one ragged batch)."""
     cfg = dict(IMG_CFGS[name], seed=5)
-    N, K = (96, 140) if name == "cfg4" else (300, 40)
+    N, K = (48, 300) if name == "cfg4" else (300, 40)
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     assert a.rollout_kernel_name(K).startswith("k_image_obs" if name == "all100" else "k_image_obs_fast<")
@@ -1327,16 +1327,16 @@ def test_image_observations_on_philox_streams_vs_oracle(name):
 
 
 def test_cfg4_at_bench_size_fast_vs_general_renderer_and_oracle():
-    """BASELINE configs[3] at ITS size: 8 192 envs x 32 fused steps = two pipelined batches of 16.  The
-    persistent fast renderer leaves workgroup slots free for the next batch's state kernel as a function of the batch
-    size (32 of 1 024 here), so the size it is benchmarked at is the size it is checked at: every pixel of every
+    """BASELINE configs[3] at ITS size: 8 192 envs x 80 fused steps = two pipelined batches (64 + 16).  The
+    persistent fast renderer's grid, the slots it leaves free and the counters its waves claim their images from depend on
+    the batch size, so the size it is benchmarked at is the size it is checked at: every pixel of every
     image against the general renderer (k_image_obs, NO_IMGFAST), the pipeline against the unpipelined launch order
     (NO_IMG_OVERLAP), and a strided sample of envs against the oracle's draw + Pillow-exact rotation."""
     import bench
     from test_image_oracle import _render
     from mdp_playground_amd import _capi as capi, image_obs, mdp
     wl = bench.WORKLOADS["cfg4"]
-    cfg, N, K = wl["config"], wl["envs"], 32
+    cfg, N, K = wl["config"], wl["envs"], 80
     assert N == 8192
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
