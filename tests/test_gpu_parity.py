@@ -1163,10 +1163,10 @@ def _img_actions(cfg, shape, seed):
 @pytest.mark.parametrize("name", sorted(IMG_CFGS))
 def test_image_fused_rollout_equals_single_steps(name):
     """mdpp_step_n on an image env runs batches of up to 64 steps (state kernel, serial draw kernel, per-image record
-    kernel, persistent render kernel whose waves claim their images from counters), a long rollout starting with batches of 8
-    and 16; mdpp_step runs one step with the draw and the records fused.  Same arithmetic, different launch shapes:
-    bit-identical images, rewards, flags and RNG end states.  K = 300: batches of 8, 16, 64, 64, 64, 64 and a ragged one of
-    20 (cfg4; 40 elsewhere: one ragged batch)."""
+    kernel, persistent render kernel whose waves claim their images from counters), a long rollout starting with batches of 8,
+    16 and 32; mdpp_step runs one step with the draw and the records fused.  Same arithmetic, different launch shapes:
+    bit-identical images, rewards, flags and RNG end states.  K = 300: batches of 8, 16, 32, 64, 64, 64 and a ragged one of
+    52 (cfg4; 40 elsewhere: one ragged batch)."""
     cfg = dict(IMG_CFGS[name], seed=5)
     N, K = (48, 300) if name == "cfg4" else (300, 40)
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
