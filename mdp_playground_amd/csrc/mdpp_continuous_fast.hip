@@ -46,6 +46,12 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
+#ifndef MDPP_NP_PARK
+#define MDPP_NP_PARK 3             // (3-6 measure within 1 %, 8 and 12 stall the leading lanes at the ring limit)
+#endif
+#ifndef MDPP_NP_ATTEMPTS
+#define MDPP_NP_ATTEMPTS 8         // fast attempts per round of bookkeeping: 2 / 4 / 6 / 8 / 10 / 13 -> 2 745 / 2 420 / 2 304 / 2 272 / 2 293 / 2 480 us per cfg5 launch
+#endif
 #ifndef MDPP_NP_PRODUCER_PRIO
 #define MDPP_NP_PRODUCER_PRIO 3    // numpy streams: the helper wave (13 numpy-exact normals per step) is the long stage: 2 737 -> 2 410 us per cfg5 launch
 #endif
@@ -186,10 +192,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             // them succeed: one LDS store, next draw); a lane whose attempt fell outside its layer's
             // rectangle is PARKED with its 64-bit word until kPark lanes wait (or the consumer does),
             // and then the wedge / tail path -- an extra uniform, exp or log1p -- runs once for all of
-            // them (checked once per four attempts).  In lockstep, 54 % of a wave's draws have some lane on that path and all 64 pay
+            // them (checked once per MDPP_NP_ATTEMPTS attempts).  In lockstep, 54 % of a wave's draws have some lane on that path and all 64 pay
             // for it (profiles/r01_rng_microbench.txt).  Per lane the stream is consumed in exactly
             // numpy's order: a parked lane draws nothing until its own slow path has run.
-            constexpr uint32_t kPark = 5;            // 3-6 measure the same; 16 stalls the leading lanes at the ring limit
+            constexpr uint32_t kPark = MDPP_NP_PARK;
             const uint32_t nd = (a.has_p_noise ? (uint32_t)D : 0u) + (a.has_r_noise ? 1u : 0u);
             uint32_t kl = 0, jl = 0, pub = 0;        // this lane's step / draw within the step; steps published
             uint64_t pr = 0;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                 const uint32_t lim = min((uint32_t)K, cons + (uint32_t)kNRing);
                 const uint64_t bcan = __builtin_amdgcn_ballot_w64(!parked && kl < lim);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {            // four fast attempts per round of bookkeeping
+                for (int u = 0; u < MDPP_NP_ATTEMPTS; u++) {   // fast attempts per round of bookkeeping
                     if (!parked && kl < lim) {
                         uint64_t r = hg.next64();
                         const uint64_t r0 = r;
