@@ -46,6 +46,9 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
 constexpr int kNRing = 4;                      // steps of normals buffered per env
+#ifndef MDPP_NP_BATCH
+#define MDPP_NP_BATCH 1
+#endif
 #ifndef MDPP_NP_PARK
 #define MDPP_NP_PARK 3             // (3-6 measure within 1 %, 8 and 12 stall the leading lanes at the ring limit)
 #endif
@@ -214,6 +217,46 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                 cons = __hip_atomic_load(&s_cons[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t lim = min((uint32_t)K, cons + (uint32_t)kNRing);
                 const uint64_t bcan = __builtin_amdgcn_ballot_w64(!parked && kl < lim);
+#if MDPP_NP_BATCH
+                // One round = up to MDPP_NP_ATTEMPTS fast attempts per lane, made as a batch: the words of the next states first
+                // (they do not depend on what the attempts decide), then all table lookups at once (one LDS round trip instead of
+                // one per attempt), then the accepted prefix is stored; the stream stops behind the first rejected word, which
+                // parks the lane.  Per lane the stream is consumed in numpy's order exactly as in the attempt-by-attempt form.
+                if (bcan != 0) {
+                    constexpr int NB = MDPP_NP_ATTEMPTS;
+                    uint32_t allowed = 0;
+                    if (!parked && kl < lim) { const uint32_t rem = (lim - kl) * nd - jl; allowed = rem < (uint32_t)NB ? rem : (uint32_t)NB; }
+                    uint64_t wd[NB], slo[NB], shi[NB];
+                    Pcg64 t = hg;
+#pragma unroll
+                    for (int u = 0; u < NB; u++) { wd[u] = t.next64(); slo[u] = t.s_lo; shi[u] = t.s_hi; }
+                    double xs[NB];
+                    bool ok[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; u++) {
+                        uint64_t r = wd[u];
+                        const int idx = (int)(r & 0xff);
+                        r >>= 8;
+                        const int sign = (int)(r & 0x1);
+                        const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+                        const double x = (double)rabs * zig.wi[idx];
+                        xs[u] = sign ? -x : x;
+                        ok[u] = rabs < zig.ki[idx];
+                    }
+                    uint32_t nacc = allowed;
+                    bool rej = false;
+#pragma unroll
+                    for (int u = NB - 1; u >= 0; u--)                     // (descending: the FIRST rejection wins)
+                        if ((uint32_t)u < allowed && !ok[u]) { nacc = (uint32_t)u; rej = true; pr = wd[u]; }
+                    const uint32_t consumed = rej ? nacc + 1u : allowed;
+#pragma unroll
+                    for (int u = 0; u < NB; u++) {
+                        if ((uint32_t)u < nacc) put(xs[u]);
+                        if (consumed == (uint32_t)(u + 1)) { hg.s_lo = slo[u]; hg.s_hi = shi[u]; }
+                    }
+                    parked = parked || rej;
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < MDPP_NP_ATTEMPTS; u++) {   // fast attempts per round of bookkeeping
                     if (!parked && kl < lim) {
@@ -229,6 +272,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                         else { parked = true; pr = r0; }
                     }
                 }
+#endif
                 const uint64_t bpark = __builtin_amdgcn_ballot_w64(parked);
                 if (bpark != 0) {
                     // (no "urgent" rule for a parked lane that holds the next step back: the producer is the
