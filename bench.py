@@ -45,10 +45,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the host driver only supports dmabuf IPC (RCCL, CUDA-tensor sharing): must be in the environment before the HIP runtime
+# reads it, i.e. before anything touches the GPU (setting it after torch.cuda.set_device had no effect)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import statistics  # noqa: E402
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0    # what the guide measures for a float4 copy kernel on MI355X (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -238,11 +245,24 @@ def cpu_baseline_all_cores(wl_name, seconds=4.0):
 
 def hbm_ceilings(device, nbytes=1 << 30, reps=10):
     """What the memory system of THIS device gives plain streaming kernels, measured live (SURVEY.md
-    §8d "report against both"): a device-to-device copy (read + write bytes) and a fill (write only)
-    of `nbytes`, torch's own kernels, HIP events."""
+    §8d "report against both"), two ways: the library's own 16-bytes-per-lane grid-stride kernels (mdpp_probe_hbm: the
+    float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s, a fill, a read) -- `copy_GBps`, `write_GBps`, `read_GBps` --
+    and torch's copy_ / fill_ kernels (`torch_copy_GBps`, `torch_write_GBps`: what round 3 called the ceiling; torch's
+    copy runs 20 % under the float4 one), HIP events around `reps` launches over `nbytes`."""
+    import ctypes
+    from mdp_playground_amd import _capi
     src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
     dst = torch.empty_like(src)
     out = {}
+    lib = _capi.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    for name, mode, moved in (("copy", 0, 2 * nbytes), ("write", 1, nbytes), ("read", 2, nbytes)):
+        ms = ctypes.c_float(0.0)
+        rc = lib.mdpp_probe_hbm(mode, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nbytes, reps, stream,
+                                ctypes.byref(ms))
+        if rc == 0 and ms.value > 0:
+            out[name + "_GBps"] = moved * reps / (ms.value * 1e-3) / 1e9
+    torch_out = {}
     for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("write", lambda: dst.fill_(7), nbytes)):
         for _ in range(3):
             fn()
@@ -252,8 +272,11 @@ def hbm_ceilings(device, nbytes=1 << 30, reps=10):
             fn()
         e1.record()
         e1.synchronize()
-        out[name + "_GBps"] = moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        torch_out[name] = moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
+    out["torch_copy_GBps"], out["torch_write_GBps"] = torch_out["copy"], torch_out["write"]
+    out.setdefault("copy_GBps", torch_out["copy"])
+    out.setdefault("write_GBps", torch_out["write"])
     return out
 
 
@@ -276,7 +299,7 @@ def leg_name(workload, rng):
     return workload if rng == "numpy" else f"{workload}_{rng}"
 
 
-def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345):
+def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=5):
     """One more workload under the same clock: `warmup` untimed + `launches` timed fused rollouts (HIP events on
     the launch stream around the timed ones, rotating action tensors), everything resident in HBM."""
     from mdp_playground_amd import RLToyVectorEnv
@@ -289,21 +312,28 @@ def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345):
     for it in range(max(warmup, 1)):
         env.rollout(acts[it % len(acts)], out)
     torch.cuda.synchronize(device)
-    env.timer_begin()
-    t0 = time.perf_counter()
-    for it in range(launches):
-        env.rollout(acts[(warmup + it) % len(acts)], out)
-    ms = env.timer_end()
-    torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t0
+    us, walls, n = [], [], warmup
+    for _ in range(max(repeats, 1)):            # R repeats of `launches` launches: the median is reported
+        env.timer_begin()
+        t0 = time.perf_counter()
+        for it in range(launches):
+            env.rollout(acts[(n + it) % len(acts)], out)
+        ms = env.timer_end()
+        torch.cuda.synchronize(device)
+        walls.append(time.perf_counter() - t0)
+        us.append(ms * 1e3 / launches)
+        n += launches
     bad = int((env.status() != 0).sum())
     kname = env.rollout_kernel_name(F)
     env.close()
-    per_launch_s = ms / 1e3 / launches
+    per_launch_s = statistics.median(us) * 1e-6
+    wall = statistics.median(walls)
     alg = wl["alg_bytes_fused"] * N * F
     achieved = alg / per_launch_s / 1e9
     return {"env_steps_per_s": N * F * launches / wall, "launch_us": per_launch_s * 1e6, "launches": launches,
-            "frac": achieved / HBM_PEAK_GBS, "achieved_GBps": achieved, "kernel": kname, "rng": rng,
+            "repeats": len(us), "launch_us_runs": {"min": min(us), "median": statistics.median(us), "max": max(us)},
+            "frac": achieved / HBM_PEAK_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+            "achieved_GBps": achieved, "kernel": kname, "rng": rng,
             "envs": N, "fuse": F, "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg,
             "action_tensors": len(acts), "action_bytes_rotated": len(acts) * acts[0].numel() * acts[0].element_size(),
             "envs_with_status_bits": bad, "traffic": None, "traffic_source": None}
@@ -352,7 +382,6 @@ def init_collective(device, world, no_collective, backend="nccl"):
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                     device_id=device, pg_options=opts)
         return dist, None
@@ -382,6 +411,11 @@ def main():
     ap.add_argument("--workload-steps", type=int, default=10, help="timed launches of each `workloads` leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only for tests that run several ranks on one GPU (RCCL is the product path)")
+    ap.add_argument("--repeats", type=int, default=5, help="every timed leg is repeated this many times; the MEDIAN repeat is "
+                    "reported (`value`, `ms_per_step`, `roofline.launch_us`), all repeats in `*_runs`")
+    ap.add_argument("--only-leg", default=None, choices=["rotating", "replayed"],
+                    help="profiling: time only this form of the main workload's launches (no collective, no other legs), so that a "
+                    "rocprofv3 --kernel-trace --stats of the run holds ONE leg per kernel (profiles/r04_kernel_stats_<leg>.csv)")
     ap.add_argument("--full-gather-steps", type=int, default=4,
                     help="bench steps of the [K, N_local, ...] all-gather leg (0 = skip)")
     args = ap.parse_args()
@@ -399,11 +433,13 @@ def main():
     N = args.envs or wl["envs"]
     F = max(1, min(args.fuse, wl.get("fuse_max", args.fuse)))
     extra = []
+    if args.only_leg is not None:       # a profiling run of one leg of the main kernel: nothing else on the device
+        args.no_workloads = args.no_cpu_baseline = args.no_pmc = args.no_single_step = args.no_collective = True
     if world == 1 and args.workload == "cfg2" and args.rng == "numpy" and not args.no_workloads and not args.disable \
             and args.envs is None:
         extra = list(EXTRA_LEGS)
     cpu_py = cpu_py_all = cpu_all = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:      # (rank 0 of a multi-rank run too: it has not touched the GPU yet)
         cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
     pmc = None
     if rank == 0 and world == 1 and not args.no_pmc:
@@ -479,30 +515,80 @@ def main():
     # round 3 and taken out again: the candidates measured the same with the collective, and a picked stream that happened to
     # share a hardware queue with an image handle's side stream serialised cfg4's prepare and render stages -- 7.4 or 8.4 ms per
     # launch from run to run.)
+    R = max(1, args.repeats)
+
+    def timed_reps(steps, gathers, events=False, rotate=True):
+        """R back-to-back repeats of timed(): [(elapsed_s, kernel_ms)]; the MEDIAN repeat is what a leg reports
+        (one 2.9 ms sample decided `value` in round 3; box noise is +-5 %)."""
+        return [timed(steps, gathers, events, rotate) for _ in range(R)]
+
+    def leg_record(reps, steps):
+        els = [e for e, _ in reps]
+        med = statistics.median(els)
+        return med, {"elapsed_s": med, "env_steps_per_s": world * N * F * steps / med,
+                     "elapsed_s_runs": els, "env_steps_per_s_runs": [world * N * F * steps / e for e in els]}
+
     # ---- leg "none": no collective.  Its HIP-event time (launch stream) is the roofline leg: every launch reads a
     # different action tensor (NA of them, > the Infinity Cache together)
-    run(max(args.warmup, 1), None)
-    el_none, kernel_ms = timed(args.steps, None, events=True)
-    legs = {"none": {"elapsed_s": el_none, "env_steps_per_s": world * N * F * args.steps / el_none,
-                     "host_enqueue_s": host_enqueue[0]}}
+    legs = {}
+    kernel_us_runs = replay_us_runs = None
+    el_none = None
+    if args.only_leg in (None, "rotating"):
+        run(max(args.warmup, 1), None)
+        reps = timed_reps(args.steps, None, events=True)
+        el_none, legs["none"] = leg_record(reps, args.steps)
+        legs["none"]["host_enqueue_s"] = host_enqueue[0]
+        kernel_us_runs = [k * 1e3 / args.steps for _, k in reps]
     # the same launches replaying ONE action tensor (what rounds 1-2 timed): its reads may be cache hits
-    run(2, None, rotate=False)
-    _, replay_ms = timed(args.steps, None, events=True, rotate=False)
+    if args.only_leg in (None, "replayed"):
+        run(2, None, rotate=False)
+        reps = timed_reps(args.steps, None, events=True, rotate=False)
+        replay_us_runs = [k * 1e3 / args.steps for _, k in reps]
+        if el_none is None:
+            el_none, legs["none"] = leg_record(reps, args.steps)
+            kernel_us_runs = replay_us_runs
     elapsed, collective = el_none, "none" + (f" ({no_coll_why})" if no_coll_why else "")
-    if dist is not None:
+    diag = None
+    if dist is not None and args.only_leg is None:
         # ---- leg "last_row" = `value`: the collective of the path (SURVEY.md §8e, north_star): after every launch ONE
         # all-gather of the local CURRENT observation shard ([N_local, ...]: 512 KiB per rank for cfg2) gives
         # every rank the concatenated observation tensor of all world * N envs
         g_last = [ObsGatherer(o[0][-1], world, dist, always_collective=True) for o in outs]
         run(max(args.warmup, 1), g_last)
-        el_last, _ = timed(args.steps, g_last)
-        legs["last_row"] = {"elapsed_s": el_last, "env_steps_per_s": world * N * F * args.steps / el_last,
-                            "host_enqueue_s": host_enqueue[0],
-                            "bytes_per_rank_per_launch": g_last[0].local.numel() * g_last[0].local.element_size()}
+        reps = timed_reps(args.steps, g_last)
+        el_last, legs["last_row"] = leg_record(reps, args.steps)
+        legs["last_row"]["host_enqueue_s"] = host_enqueue[0]
+        legs["last_row"]["bytes_per_rank_per_launch"] = g_last[0].local.numel() * g_last[0].local.element_size()
         elapsed = el_last
         collective = ("all_gather_into_tensor (%s, %d rank%s, async_op) of the current observation shard after every "
                       "launch, on the backend's high-priority stream beside the next launch"
                       % ("RCCL" if args.backend == "nccl" else args.backend, dist.get_world_size(), "" if world == 1 else "s"))
+        # ---- what a scaling line needs to explain itself (VERDICT r3 item 3b): per rank, the launch alone (HIP events on
+        # the launch stream, from the `none` leg), the collective alone (G back-to-back gathers between events, nothing
+        # else on the device) and what the collective adds per launch when it runs beside the rollouts; min / max over ranks
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        G = 20
+        barrier()
+        e0.record()
+        for j in range(G):
+            g_last[j % NB].start().wait()
+        e1.record()
+        e1.synchronize()
+        gather_us = e0.elapsed_time(e1) * 1e3 / G
+        barrier()
+        mine = {"launch_us": statistics.median(kernel_us_runs), "gather_alone_us": gather_us,
+                "launch_plus_gather_us": el_last * 1e6 / args.steps,
+                "added_per_launch_us": (el_last - el_none) * 1e6 / args.steps}
+        if world > 1:
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+        else:
+            allv = [mine]
+        diag = {k: {"min": min(v[k] for v in allv), "max": max(v[k] for v in allv)} for k in mine}
+        diag["per_rank"] = allv
+        diag["note"] = ("launch_us: HIP events on the launch stream, no collective; gather_alone_us: the all-gather with nothing "
+                        "else running (events around %d of them); added_per_launch_us: (last_row - none) / launches -- what is "
+                        "left of the gather after overlap (the rollout grid holds every CU: a gather can only run between launches)" % G)
         del g_last
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()
@@ -517,11 +603,11 @@ def main():
     total_steps = world * N * F * args.steps
     value = total_steps / elapsed
 
-    # ---- roofline of the dominant kernel (fused rollout), per launch
-    per_launch_s = (kernel_ms / 1e3) / args.steps
+    # ---- roofline of the dominant kernel (fused rollout), per launch: the median repeat
+    launch_us = statistics.median(kernel_us_runs)
+    per_launch_s = launch_us * 1e-6
     alg_bytes = wl["alg_bytes_fused"] * N * F
     achieved = alg_bytes / per_launch_s / 1e9
-    replayed = alg_bytes / ((replay_ms / 1e3) / args.steps) / 1e9
     kname = env.rollout_kernel_name(F)          # what the library's dispatch launches (mdpp_kernel_name)
     traffic, traffic_src = committed_traffic(args.workload, args.rng, N, F, kname)
     main_pmc = (pmc or {}).get(leg_name(args.workload, args.rng))
@@ -530,12 +616,21 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg_bytes,
-                "launch_us": per_launch_s * 1e6, "env_steps_per_launch": N * F,
+                "launch_us": launch_us, "env_steps_per_launch": N * F,
+                "launch_us_runs": {"min": min(kernel_us_runs), "median": launch_us, "max": max(kernel_us_runs), "repeats": R},
+                "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                "achievable": f"{HBM_ACHIEVABLE_GBS:.0f} GB/s: the float4 copy of MI355X_MICROARCH.md; `peak_measured` is this device's own",
                 "action_tensors": NA, "action_bytes_rotated": NA * acts[0].numel() * acts[0].element_size(),
-                "frac_replayed": replayed / HBM_PEAK_GBS, "launch_us_replayed": replay_ms * 1e3 / args.steps,
                 "reads": f"`frac`: the launches cycle through {NA} distinct action tensors "
                          f"({NA * acts[0].numel() * acts[0].element_size() >> 20} MiB together, above the 256 MiB "
                          "Infinity Cache); `frac_replayed`: the same launches replaying one tensor"}
+    if replay_us_runs is not None:
+        rus = statistics.median(replay_us_runs)
+        roofline["frac_replayed"] = alg_bytes / (rus * 1e-6) / 1e9 / HBM_PEAK_GBS
+        roofline["launch_us_replayed"] = rus
+        roofline["launch_us_replayed_runs"] = {"min": min(replay_us_runs), "median": rus, "max": max(replay_us_runs)}
+    if args.only_leg is not None:
+        roofline["only_leg"] = args.only_leg
 
     single = None
     if not args.no_single_step:
@@ -567,7 +662,7 @@ def main():
         roofline["frac_of_measured_write"] = achieved / peaks["write_GBps"]
 
     cpu_port = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not (
+    if rank == 0 and not args.no_cpu_baseline and not (
             wl["kind"] == "continuous" and wl["config"].get("image_representations")):
         cpu_port = cpu_baseline(wl)      # (the C port has no timed picture path for continuous envs)
 
@@ -590,6 +685,12 @@ def main():
                        "value_is": "the `last_row` leg (launch + the path's all-gather) for every --gpus, one rank included"
                                    if v_last is not None else "the `none` leg (no process group in this run)"},
             "value_none": v_none, "value_last_row": v_last,
+            "value_runs": legs["last_row" if v_last is not None else "none"]["env_steps_per_s_runs"], "repeats": R,
+            "value_is_median_of_runs": True,
+            # False: `value` is NOT the leg with the path's collective (no process group could be made) -- do not
+            # compare it with lines where it is
+            "collective_ok": v_last is not None,
+            "multi_rank_diagnostics": diag,
             "roofline": roofline,
             "cpu_baseline": cpu_py if cpu_py is not None else cpu_port,
             "cpu_baseline_all_cores": cpu_py_all, "cpu_baseline_port": cpu_port,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 6
+#define MDPP_ABI_VERSION 7
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
@@ -260,6 +260,14 @@ int mdpp_get_state_continuous(mdpp_env *h, float *derivs_host, float *cur_host, 
 int mdpp_set_state_continuous(mdpp_env *h, const float *derivs_host, const float *cur_host,
                               const int32_t *steps_host, const double *ring_host,
                               const uint8_t *ring_is32_host, const uint8_t *reached_host);
+/* reward_function = move_along_a_line (rl_toy_env.py:1864-1910): the window of the line fit -- the relevant coordinates
+ * of the last sequence_length states of every env, which the reference keeps in `augmented_state` and returns from
+ * get_augmented_state() (:2147-2156) --, oldest first, float32 [N][L][n_rel] on the host; slots older than the running
+ * episode are NaN like the reference's NaN-filled list.  mdpp_set_state_continuous on such a handle restores the step
+ * counters but not this window: stepping is refused (MDPP_EUNSUPPORTED) until mdpp_set_line_history has been called
+ * AFTER it (the slot of a state depends on the step counter).  ABI 7. */
+int mdpp_get_line_history(mdpp_env *h, float *hist_host);
+int mdpp_set_line_history(mdpp_env *h, const float *hist_host);
 
 /* HIP graphs of single steps (RLToyVectorEnv.step_graph).  mdpp_step hands the handle's step counter to its
  * launch by value (ring head = counter mod delay for delay lines kept in memory; Philox keys), so a captured
@@ -311,6 +319,13 @@ int mdpp_status(mdpp_env *h, uint32_t *flags_host);
  * begin/end bracket any number of launches; returns elapsed milliseconds. */
 int mdpp_timer_begin(mdpp_env *h, void *stream);
 int mdpp_timer_end(mdpp_env *h, void *stream, float *ms_out);
+
+/* What the memory system of the current device gives plain streaming kernels (no handle; nothing of the reference):
+ * `reps` launches of a 16-bytes-per-lane grid-stride kernel over `nbytes` on `stream`, HIP events around them ->
+ * *ms_out (all reps).  mode 0: copy src -> dst (2 x nbytes moved per launch; the float4 copy MI355X_MICROARCH.md
+ * measures at 6.29 TB/s), 1: fill dst (src unused), 2: read src (dst: a device pointer to 4 scratch bytes).
+ * bench.py prices `roofline.frac` beside these (`peak_measured`).  ABI 7. */
+int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size_t nbytes, int reps, void *stream, float *ms_out);
 
 /* ---- GymEnvWrapper-style post-processor ---------------------------------------
  * What the reference's mdp_playground/envs/gym_env_wrapper.py does around ANY inner env, for a batch of N

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 6
+MDPP_ABI_VERSION = 7
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
 REWARD_SEQUENCES, REWARD_STATE_ACTION = 0, 1
@@ -31,10 +31,10 @@ EXPORTS = [
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
     "mdpp_set_options", "mdpp_kernel_name", "mdpp_philox_normals",
     "mdpp_graph_replay_exact", "mdpp_tick", "mdpp_get_reset_pending", "mdpp_set_reset_pending",
-    "mdpp_get_episode_stats",
+    "mdpp_get_episode_stats", "mdpp_get_line_history", "mdpp_set_line_history",
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
-    "mdpp_episode_stats",
+    "mdpp_episode_stats", "mdpp_probe_hbm",
 ]
 
 
@@ -134,6 +134,8 @@ def load():
     L.mdpp_graph_replay_exact.argtypes = [vp, i32]
     L.mdpp_tick.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
     L.mdpp_get_episode_stats.argtypes = [vp, vp, vp]
+    L.mdpp_get_line_history.argtypes = [vp, vp]
+    L.mdpp_set_line_history.argtypes = [vp, vp]
     L.mdpp_get_reset_pending.argtypes = [vp, vp]
     L.mdpp_set_reset_pending.argtypes = [vp, vp]
     L.mdpp_philox_normals.argtypes = [C.c_uint64, C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, vp, vp]
@@ -150,6 +152,7 @@ def load():
     L.mdpp_post_step.argtypes = [vp] * 7
     L.mdpp_post_step_n.argtypes = [vp, i32] + [vp] * 6
     L.mdpp_episode_stats.argtypes = [i32, i32, vp, i32] + [vp] * 9
+    L.mdpp_probe_hbm.argtypes = [i32, vp, vp, C.c_size_t, i32, vp, C.POINTER(C.c_float)]
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     if L.mdpp_abi_version() != MDPP_ABI_VERSION:

@@ -105,6 +105,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_line_hist = h->d_ring64 = nullptr;
     h->d_est_cur = h->d_est_last = nullptr; h->est_nk = 0;
     h->irr_ready = false;
+    h->line_hist_stale = false;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
     // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
@@ -827,6 +828,8 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
     if (!actions || !obs || !reward || !term || !trunc) return fail(h, MDPP_EINVAL, "step: null buffer");
     int rc = check_ready(h, "mdpp_step");
     if (rc) return rc;
+    if (h->line_hist_stale)
+        return fail(h, MDPP_EUNSUPPORTED, "step: mdpp_set_state_continuous on a move_along_a_line handle must be followed by mdpp_set_line_history (the window of the line fit)");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (h->cfg.kind == MDPP_KIND_DISCRETE) {
@@ -1182,8 +1185,9 @@ extern "C" int mdpp_set_state_continuous(mdpp_env *h, const float *derivs, const
                                          const int32_t *steps, const double *ring,
                                          const uint8_t *ring_is32, const uint8_t *reached) {
     if (!h || h->cfg.kind != MDPP_KIND_CONTINUOUS || !derivs || !cur || !steps) return MDPP_EINVAL;
-    if (h->cargs.line_L)
-        return fail(h, MDPP_EUNSUPPORTED, "set_state_continuous: move_along_a_line keeps the last sequence_length states, which this call does not carry");
+    // move_along_a_line fits the last sequence_length states, which this call does not carry: stepping is refused
+    // until mdpp_set_line_history() has restored them for the restored step counters
+    if (h->cargs.line_L) h->line_hist_stale = true;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const size_t N = (size_t)h->cfg.num_envs, D = (size_t)h->cfg.D;
@@ -1215,6 +1219,58 @@ extern "C" int mdpp_set_state_continuous(mdpp_env *h, const float *derivs, const
             }
         HIPCHK(h, hipMemcpy(h->d_ring, rg.data(), rg.size() * 4, hipMemcpyHostToDevice));
     }
+    return MDPP_OK;
+}
+
+// move_along_a_line: the window of the line fit -- the relevant coordinates of the last L = sequence_length states of
+// every env (rl_toy_env.py:1865-1872 reads them from augmented_state) --, oldest first, [N][L][n_rel] float32 on the
+// host.  Slots older than the running episode (fewer than L - 1 transitions since its reset) hold NaN, as the
+// reference's NaN-filled list does.  Device layout: line_hist[slot = s % L][NL][N], s = transitions made when the
+// state was reached (mdpp_continuous.hip c_line_put), so the export reads the per-env step counters.
+extern "C" int mdpp_get_line_history(mdpp_env *h, float *hist) {
+    if (!h || h->cfg.kind != MDPP_KIND_CONTINUOUS || !hist) return MDPP_EINVAL;
+    if (!h->cargs.line_L) return fail(h, MDPP_EUNSUPPORTED, "get_line_history: reward_function is not move_along_a_line");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs, L = (size_t)h->cargs.line_L, NL = (size_t)h->cargs.line_NL, nr = (size_t)h->cfg.n_rel;
+    std::vector<float> lh(L * NL * N);
+    std::vector<uint32_t> me(2 * N);
+    HIPCHK(h, hipMemcpy(lh.data(), h->d_line_hist, lh.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(me.data(), h->d_meta, N * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        const size_t steps = me[2 * i];
+        for (size_t j = 0; j < L; j++) {                    // j-th oldest of the L newest: reached after steps - (L - 1) + j transitions
+            const bool live = steps + j + 1 >= L;
+            const size_t slot = (steps + 1 + j) % L;
+            for (size_t c = 0; c < nr; c++)
+                hist[(i * L + j) * nr + c] = live ? lh[(slot * NL + c) * N + i] : __builtin_nanf("");
+        }
+    }
+    return MDPP_OK;
+}
+
+// Inverse of mdpp_get_line_history for the step counters the handle holds NOW: call it after mdpp_set_state_continuous.
+extern "C" int mdpp_set_line_history(mdpp_env *h, const float *hist) {
+    if (!h || h->cfg.kind != MDPP_KIND_CONTINUOUS || !hist) return MDPP_EINVAL;
+    if (!h->cargs.line_L) return fail(h, MDPP_EUNSUPPORTED, "set_line_history: reward_function is not move_along_a_line");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)h->cfg.num_envs, L = (size_t)h->cargs.line_L, NL = (size_t)h->cargs.line_NL, nr = (size_t)h->cfg.n_rel;
+    std::vector<float> lh(L * NL * N, 0.0f);
+    std::vector<uint32_t> me(2 * N);
+    HIPCHK(h, hipMemcpy(me.data(), h->d_meta, N * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        const size_t steps = me[2 * i];
+        for (size_t j = 0; j < L; j++) {
+            const size_t slot = (steps + 1 + j) % L;
+            for (size_t c = 0; c < nr; c++) {
+                const float v = hist[(i * L + j) * nr + c];
+                lh[(slot * NL + c) * N + i] = (v == v) ? v : 0.0f;      // (slots before the episode are never read: steps < L gates the fit)
+            }
+        }
+    }
+    HIPCHK(h, hipMemcpy(h->d_line_hist, lh.data(), lh.size() * 4, hipMemcpyHostToDevice));
+    h->line_hist_stale = false;
     return MDPP_OK;
 }
 
@@ -1259,4 +1315,54 @@ extern "C" int mdpp_timer_end(mdpp_env *h, void *stream, float *ms) {
     HIPCHK(h, hipEventSynchronize(h->ev1));
     HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
     return MDPP_OK;
+}
+
+// ---- what the memory system gives plain streaming kernels (bench.py: the ceiling `roofline.frac` is priced beside) ----
+// 16 bytes per lane, grid-stride, 8 workgroups of 256 lanes per CU: the float4 copy MI355X_MICROARCH.md measures at
+// 6.29 TB/s, a fill and a read of the same shape.
+namespace mdpp {
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void k_probe_fill(uint4 *__restrict__ d, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint4 v = make_uint4(threadIdx.x, blockIdx.x, 3u, 4u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
+}
+__global__ __launch_bounds__(256) void k_probe_read(const uint4 *__restrict__ s, size_t n, uint32_t *out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 v = s[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345u) out[0] = acc;          // (keeps the loads alive)
+}
+} // namespace mdpp
+
+extern "C" int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size_t nbytes, int reps, void *stream, float *ms_out) {
+    if (!ms_out || reps < 1 || nbytes < 16 || mode < 0 || mode > 2) return MDPP_EINVAL;
+    if ((mode != 2 && !dst_dev) || (mode != 1 && !src_dev)) return MDPP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return MDPP_EHIP;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t n = nbytes / 16;
+    const dim3 grid((unsigned)(cus * 8)), block(256);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MDPP_EHIP;
+    auto launch = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(mdpp::k_probe_copy, grid, block, 0, s, (const uint4 *)src_dev, (uint4 *)dst_dev, n);
+        else if (mode == 1) hipLaunchKernelGGL(mdpp::k_probe_fill, grid, block, 0, s, (uint4 *)dst_dev, n);
+        else hipLaunchKernelGGL(mdpp::k_probe_read, grid, block, 0, s, (const uint4 *)src_dev, n, (uint32_t *)dst_dev);
+    };
+    for (int w = 0; w < 2; w++) launch();
+    int rc = MDPP_OK;
+    if (hipEventRecord(e0, s) != hipSuccess) rc = MDPP_EHIP;
+    for (int r = 0; r < reps; r++) launch();
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+        hipEventElapsedTime(ms_out, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = MDPP_EHIP;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
 }

@@ -70,6 +70,25 @@ constexpr int kNRing = 4;                      // steps of normals buffered per 
 #ifndef MDPP_PHILOX_PRODUCERS
 #define MDPP_PHILOX_PRODUCERS 2
 #endif
+#ifndef MDPP_WK_ATTEMPTS
+#define MDPP_WK_ATTEMPTS 8         // walker: fast ziggurat attempts per round
+#endif
+#ifndef MDPP_WK_GEN_BATCH
+#define MDPP_WK_GEN_BATCH 4        // generator: words per window check (divides kWRing)
+#endif
+#ifndef MDPP_WK_PARK
+#define MDPP_WK_PARK 8             // walker: parked lanes that trigger a wedge / tail pass
+#endif
+#ifndef MDPP_WK_GEN_PRIO
+#define MDPP_WK_GEN_PRIO 1
+#endif
+#ifndef MDPP_WK_WALKER_PRIO
+#define MDPP_WK_WALKER_PRIO 2
+#endif
+#ifndef MDPP_WK_CONSUMER_PRIO
+#define MDPP_WK_CONSUMER_PRIO 3
+#endif
+constexpr int kWRing = 32;         // WALK: raw words / normals buffered per env (powers of two: ring index = count & 31)
 constexpr int kPhiloxProducers = MDPP_PHILOX_PRODUCERS;   // producer waves per consumer wave, Philox streams (see NPROD)
 constexpr uint32_t kCSpinLimit = 1u << 22;
 constexpr uint32_t kCStatusInternal = 0x80000000u;
@@ -86,6 +105,19 @@ constexpr uint32_t kCStatusInternal = 0x80000000u;
 // NPROD (PHILOX + HELPER): producer waves per consumer wave.  A counter-based stream has no serial
 // state, so step k's normals can be made by ANY wave: producer p makes the steps k = p (mod NPROD), and
 // two or three producers fill the SIMD's issue slots that one dependent Philox / Box-Muller chain leaves idle.
+// WALK (numpy streams + HELPER, NPROD == 2): three roles on three waves per SIMD instead of producer + consumer.  The helper
+// wave of rounds 1-3 walked ONE sequential PCG64 stream per lane AND decided the ziggurat's data-dependent consumption in
+// the same dependent chain (1 300 vector + 830 scalar instructions per step, profiles/r02_cfg5_sq.txt).  The two halves do
+// not depend on each other the way that code made them:
+//   * the stream's 64-bit WORDS are a function of the position alone -- a generator wave (waves 8-11) makes them in order,
+//     branch-free, into a per-lane LDS ring indexed by stream position (window of kWRing words ahead of the walker);
+//   * the WALKER (waves 4-7) reads words at its lane's position, runs batches of fast ziggurat attempts on them (the
+//     accepted prefix goes to the normals ring, the first rejected word parks the lane; wedge / tail passes run for all
+//     parked lanes at once and take their uniforms from the same ring), and never touches generator state -- so a
+//     rejection no longer needs saved states to rewind to;
+//   * the consumer (waves 0-3) reads a step's normals at the top of the step and frees the slots at once.
+// Per lane the stream is consumed in exactly numpy's order; the generator un-draws the words the walker did not take at
+// the end of the launch (inverse LCG steps), so the stored stream state is the reference's.
 template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1>
 __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
@@ -96,20 +128,30 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                                                                     float *__restrict__ final_obs) {
     static_assert(D % 4 == 0 || D == 2, "D must be 2 or a multiple of 4");
     constexpr bool ZIG = NOISE && !PHILOX;      // numpy's ziggurat tables in LDS
-    __shared__ uint64_t s_ki[ZIG ? 256 : 1];
-    __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
+    constexpr bool WALK = HELPER && !PHILOX && NPROD == 2;
+    __shared__ uint64_t s_ki[ZIG && !WALK ? 256 : 1];
+    __shared__ double s_wi[ZIG && !WALK ? 256 : 1], s_fi[ZIG ? 256 : 1];
+    __shared__ ulonglong2 s_kw[WALK ? 256 : 1];                 // WALK: {ki, wi} side by side (one 16-byte lookup per attempt)
     constexpr int NPS = D + 1;                  // normals per step slot (D transition + 1 reward)
-    static_assert(NPROD == 1 || (PHILOX && HELPER), "several producers need counter-based streams");
+    static_assert(NPROD == 1 || HELPER, "several helper waves need HELPER");
+    static_assert(NPROD == 1 || PHILOX || NPROD == 2, "numpy streams: generator + walker");
     typedef typename std::conditional<PHILOX, float, double>::type ZT;       // (Philox normals are float32 values)
-    __shared__ ZT s_z[HELPER ? kNRing * NPS * kBlock : 1];       // [slot][draw][lane]
+    __shared__ ZT s_z[HELPER ? (WALK ? kWRing : kNRing * NPS) * kBlock : 1];       // [slot][draw][lane]; WALK: [normal count & 31][lane]
+    __shared__ uint64_t s_raw[WALK ? kWRing * kBlock : 1];       // WALK: [stream position & 31][lane]
+    __shared__ uint32_t s_gp[WALK ? kBlock : 1], s_rp[WALK ? kBlock : 1], s_done[kBlock / 64];   // words made / taken per lane
     __shared__ uint32_t s_prod[NPROD][kBlock / 64], s_cons[kBlock / 64];     // steps made by producer p / steps consumed
     __shared__ __align__(16) float s_tr[(D > 4 ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
     const int tid = threadIdx.x;
-    if (ZIG) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
+    if (ZIG && !WALK) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
+    if (WALK) {
+        for (int k = tid; k < 256; k += 3 * kBlock) { s_kw[k] = make_ulonglong2(d_zig_ki[k], __double_as_longlong(d_zig_wi[k])); s_fi[k] = d_zig_fi[k]; }
+        if (tid < kBlock) { s_gp[tid] = 0; s_rp[tid] = 0; }
+    }
     if (HELPER && tid < kBlock / 64) {
 #pragma unroll
         for (int p = 0; p < NPROD; p++) s_prod[p][tid] = 0;
         s_cons[tid] = 0;
+        s_done[tid] = 0;
     }
     if (NOISE) __syncthreads();
     const ZigLds zig{s_ki, s_wi, s_fi};
@@ -183,7 +225,174 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         if (hstatus) atomicOr(&a.status[i], hstatus);
         return;
     }
-    if (HELPER && !PHILOX && tid >= kBlock) {
+    if constexpr (WALK) {
+        if (tid >= 2 * kBlock) {
+            // ---------------- generator lane: the words of the env's noise stream, in order, by position -----------------
+            // Word p of the launch goes to s_raw[p & 31][lane]; a batch is made when it fits the lane's window (the walker
+            // has taken s_rp[lane] words: positions below s_rp + kWRing are free).  No data-dependent control flow.
+            Pcg64 hg;
+            hg.load(a.env_s, a.env_inc, i);
+            Pcg64Limbs lg;
+            lg.from(hg);
+            __builtin_amdgcn_s_setprio(MDPP_WK_GEN_PRIO);
+            constexpr uint32_t UG = MDPP_WK_GEN_BATCH;
+            static_assert(kWRing % MDPP_WK_GEN_BATCH == 0, "a batch must not wrap");
+            uint32_t p = 0, spins = 0, hstatus = 0;
+            uint64_t *rawl = s_raw + ln;
+            for (;;) {
+                const uint32_t rp = __hip_atomic_load(&s_rp[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__hip_atomic_load(&s_done[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+                const bool go = p + UG <= rp + (uint32_t)kWRing;
+                if (__builtin_amdgcn_ballot_w64(go) != 0) {
+                    if (go) {
+                        uint64_t *dst = rawl + (size_t)(p & (uint32_t)(kWRing - 1)) * kBlock;
+#pragma unroll
+                        for (uint32_t u = 0; u < UG; u++) dst[u * kBlock] = lg.next64();
+                        p += UG;
+                    }
+                    __hip_atomic_store(&s_gp[ln], p, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    spins = 0;
+                } else {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kCSpinLimit) { hstatus |= kCStatusInternal; break; }
+                }
+            }
+            // un-draw what the walker did not take: s_prev = (s - inc) * M^-1 (mod 2^128)
+            lg.to(hg);
+            const uint32_t taken = __hip_atomic_load(&s_rp[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t MINV_HI = 0x07dda22b93979860ULL, MINV_LO = 0x98abc8b0716eac8dULL;
+            for (uint32_t q = p - taken; q > 0; q--) {
+                const uint64_t lo = hg.s_lo - hg.inc_lo;
+                const uint64_t hi = hg.s_hi - hg.inc_hi - (hg.s_lo < hg.inc_lo ? 1ULL : 0ULL);
+                hg.s_lo = lo * MINV_LO;
+                hg.s_hi = __umul64hi(lo, MINV_LO) + lo * MINV_HI + hi * MINV_LO;
+            }
+            hg.store(a.env_s, i);
+            if (hstatus) atomicOr(&a.status[i], hstatus);
+            return;
+        }
+        if (tid >= kBlock) {
+            // ---------------- walker lane: numpy's ziggurat over the words of the ring, in numpy's order -----------------
+            // One round = up to NB fast attempts on the next NB words (98.8 % of attempts succeed: one table lookup, one
+            // compare).  The accepted prefix goes to the normals ring; the first rejected word parks the lane with that
+            // word.  When kPark lanes wait (or nothing else can be done) the wedge / tail path runs once for all of them
+            // and takes its uniforms from the ring like numpy takes them from the stream.  Lanes drift apart by what
+            // their rejections consumed; both rings are per lane, so nobody waits for anybody's position.
+            __builtin_amdgcn_s_setprio(MDPP_WK_WALKER_PRIO);
+            constexpr int NB = MDPP_WK_ATTEMPTS;
+            constexpr uint32_t kPark = MDPP_WK_PARK;
+            const uint32_t nd = (a.has_p_noise ? (uint32_t)D : 0u) + (a.has_r_noise ? 1u : 0u);
+            const uint32_t total = (uint32_t)K * nd;
+            uint32_t n = 0, rp = 0, pub = 0, published = 0, thr = nd, spins = 0, hstatus = 0;
+            bool parked = false;
+            uint64_t pr = 0;
+            // ring slots as BYTE offsets: slot (c & 31) of this lane is at ((c << 11) & 0xf800) | lane * 8 -- an add and one
+            // v_and_or_b32 per access (both rings are 64 KiB: the masked count and the lane never share a bit)
+            const char *rawb = (const char *)s_raw;
+            char *zb = (char *)s_z;
+            const uint32_t lane8 = (uint32_t)ln * 8u;
+            constexpr uint32_t SM = (uint32_t)(kWRing - 1) << 11;
+            auto raw_at = [&](uint32_t c11) __attribute__((always_inline)) -> uint64_t {      // c11 = count << 11
+                return *(const uint64_t *)(rawb + ((c11 & SM) | lane8));
+            };
+            auto z_put = [&](uint32_t c11, double v) __attribute__((always_inline)) { *(double *)(zb + ((c11 & SM) | lane8)) = v; };
+            for (;;) {
+                const uint32_t cons = __hip_atomic_load(&s_cons[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t nlim = min(total, cons * nd + (uint32_t)kWRing);
+                const uint32_t gp = __hip_atomic_load(&s_gp[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool can = !parked && n < nlim && rp < gp;
+                const uint64_t bcan = __builtin_amdgcn_ballot_w64(can);
+                bool progress = false;
+                if (bcan != 0) {
+                    const uint32_t allowed = can ? min(min(nlim - n, gp - rp), (uint32_t)NB) : 0u;
+                    uint64_t wd[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; u++) wd[u] = raw_at((rp << 11) + ((uint32_t)u << 11));
+                    ulonglong2 kw[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; u++) kw[u] = s_kw[(uint32_t)wd[u] & 0xffu];
+                    uint32_t bad = 1u << allowed;
+                    double xs[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; u++) {
+                        const uint64_t rabs = (wd[u] >> 9) & 0x000fffffffffffffULL;
+                        // (double)rabs, exactly: 2^52 + rabs has rabs as its mantissa
+                        const double t = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
+                        const double x = t * __longlong_as_double((long long)kw[u].y);
+                        // sign = bit 8 of the word -> bit 63 (x, or -x: numpy's `if (sign & 0x1) x = -x`)
+                        xs[u] = __longlong_as_double((long long)((uint64_t)__double_as_longlong(x) ^
+                                                                 ((uint64_t)((uint32_t)wd[u] & 0x100u) << 55)));
+                        bad |= (rabs < kw[u].x) ? 0u : (1u << u);
+                    }
+                    const uint32_t m = (uint32_t)__builtin_ctz(bad);        // accepted prefix (<= allowed)
+                    const bool rej = m < allowed;
+#pragma unroll
+                    for (int u = 0; u < NB; u++)
+                        if ((uint32_t)u < m) z_put((n << 11) + ((uint32_t)u << 11), xs[u]);
+                    if (__builtin_amdgcn_ballot_w64(rej) != 0) {
+                        if (rej) pr = raw_at((rp + m) << 11);
+                    }
+                    n += m;
+                    rp += m + (rej ? 1u : 0u);
+                    parked = parked || rej;
+                    progress = true;
+                }
+                const uint64_t bpark = __builtin_amdgcn_ballot_w64(parked);
+                if (bpark != 0 && ((uint32_t)__builtin_popcountll(bpark) >= kPark || bcan == 0)) {
+                    if (parked) {
+                        const uint32_t idx = (uint32_t)pr & 0xffu;
+                        const uint64_t rabs = (pr >> 9) & 0x000fffffffffffffULL;
+                        if (idx == 0) {                 // tail: two uniforms per try (np_zig_tail), the lane stays parked until one is accepted
+                            if (rp + 2u <= gp) {
+                                const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
+                                const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
+                                const double u2 = (double)(raw_at((rp + 1u) << 11) >> 11) * (1.0 / 9007199254740992.0);
+                                rp += 2u;
+                                const double xx = -nor_inv_r * log1p(-u1);
+                                const double yy = -log1p(-u2);
+                                if (yy + yy > xx * xx) {
+                                    z_put(n << 11, ((rabs >> 8) & 0x1) ? -(nor_r + xx) : nor_r + xx);
+                                    n += 1u;
+                                    parked = false;
+                                }
+                                progress = true;
+                            }
+                        } else if (rp < gp) {           // wedge: one uniform; a rejected point starts the draw over with a fresh word
+                            double x = (double)rabs * __longlong_as_double((long long)s_kw[idx].y);
+                            x = ((uint32_t)pr & 0x100u) ? -x : x;
+                            const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
+                            rp += 1u;
+                            if (((s_fi[idx - 1] - s_fi[idx]) * u1 + s_fi[idx]) < exp(-0.5 * x * x)) {
+                                z_put(n << 11, x);
+                                n += 1u;
+                            }
+                            parked = false;
+                            progress = true;
+                        }
+                    }
+                }
+                // what this lane has taken (the generator's window) and the steps every lane has completed
+                __hip_atomic_store(&s_rp[ln], rp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (pub < (uint32_t)K && __builtin_amdgcn_ballot_w64(n < thr) == 0) { pub++; thr += nd; }
+                if (pub != published) {
+                    if ((ln & 63) == 0)
+                        __hip_atomic_store(&s_prod[0][wv], pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    published = pub;
+                }
+                if (pub == (uint32_t)K) break;
+                if (__builtin_amdgcn_ballot_w64(progress) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kCSpinLimit) { hstatus |= kCStatusInternal; break; }
+                } else {
+                    spins = 0;
+                }
+            }
+            if ((ln & 63) == 0) __hip_atomic_store(&s_done[wv], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hstatus) atomicOr(&a.status[i], hstatus);
+            return;
+        }
+    }
+    if (HELPER && !PHILOX && !WALK && tid >= kBlock) {
         // ---------------- producer lane: the env's noise stream for this launch -----------------
         Pcg64 hg;
         hg.load(a.env_s, a.env_inc, i);
@@ -339,7 +548,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     // Several producers per consumer: the consumer wave is the critical path (one dependent chain per step, while
     // the producers have a whole step of slack each), so its instructions go first whenever they are ready
     if (HELPER && NPROD > 1) __builtin_amdgcn_s_setprio(MDPP_CONSUMER_PRIO);
-    if (HELPER && !PHILOX) __builtin_amdgcn_s_setprio(MDPP_NP_CONSUMER_PRIO);
+    if (HELPER && !PHILOX) __builtin_amdgcn_s_setprio(WALK ? MDPP_WK_CONSUMER_PRIO : MDPP_NP_CONSUMER_PRIO);
 
     float sd[ORDER + 1][D], cur[D];
 #pragma unroll
@@ -362,6 +571,8 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     const ZT *zslot = s_z + ln;                 // HELPER: this step's normals, set per step
     int zi = 0;
     float zf[NPS];                              // PHILOX without helper waves: this step's normals
+    double zn[WALK ? NPS : 1];                  // WALK: this step's normals, packed in draw order (nd of them)
+    const uint32_t wk_nd = (a.has_p_noise ? (uint32_t)D : 0u) + (a.has_r_noise ? 1u : 0u);
 
     const uint32_t total = (uint32_t)K * N;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(D * 4), kCRsrc);
@@ -414,6 +625,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         return m <= __float_as_uint(bound);
     };
     auto normal = [&]() -> double {
+        if constexpr (WALK) {
+            double v = 0.0;
+#pragma unroll
+            for (int d = 0; d < NPS; d++) v = (d == zi) ? zn[d] : v;      // (zi is a compile-time constant after unrolling)
+            zi++;
+            return v;
+        }
         if (HELPER) return (double)zslot[(zi++) * kBlock];
         if constexpr (PHILOX) {
             float v = 0.0f;
@@ -459,13 +677,24 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         if (HELPER) {
             uint32_t spins = 0;
             // (producer k % NPROD has made k / NPROD + 1 steps once step k is in the ring)
-            while (__hip_atomic_load(&s_prod[k % NPROD][wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   (uint32_t)(k / NPROD + 1)) {
+            // (WALK: the walker publishes whole steps in s_prod[0])
+            while (__hip_atomic_load(&s_prod[WALK ? 0 : k % NPROD][wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                   (uint32_t)(WALK ? k + 1 : k / NPROD + 1)) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kCSpinLimit) { status |= kCStatusInternal; break; }
             }
-            zslot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
-            zi = a.has_p_noise ? 0 : D;
+            if constexpr (WALK) {
+                // the step's normals at once, then the slots are free again (the walker runs up to kWRing normals ahead)
+                const uint32_t nb = (uint32_t)k * wk_nd;
+#pragma unroll
+                for (int j = 0; j < NPS; j++) zn[j] = (double)s_z[(size_t)((nb + (uint32_t)j) & (uint32_t)(kWRing - 1)) * kBlock + ln];
+                if ((ln & 63) == 0)
+                    __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                zi = 0;
+            } else {
+                zslot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
+                zi = a.has_p_noise ? 0 : D;
+            }
         }
         if (NOISE && PHILOX && !HELPER) { philox_step(k, zf); zi = 0; }
         // ---- C1: Box.contains(action)
@@ -562,9 +791,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         if (!GEN) {
             if (NOISE && a.has_r_noise) {
                 if (HELPER || PHILOX) zi = D;
-                r = r + (float)(0.0 + a.r_noise * normal());
+                if constexpr (WALK) r = r + (float)(0.0 + a.r_noise * (a.has_p_noise ? zn[D] : zn[0]));
+                else r = r + (float)(0.0 + a.r_noise * normal());
             }
-            if (HELPER && (ln & 63) == 0)   // this wave is done with the step's slot
+            if (HELPER && !WALK && (ln & 63) == 0)   // this wave is done with the step's slot
                 __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             r = r * a.scale32;
             r = r + a.shift32;
@@ -583,10 +813,12 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             if (steps % (uint32_t)a.every_n != 0) { rv = 0.0; is32 = false; }
             if (NOISE && a.has_r_noise) {
                 if (HELPER || PHILOX) zi = D;
-                const double nz = 0.0 + a.r_noise * normal();
+                double zr;
+                if constexpr (WALK) zr = a.has_p_noise ? zn[D] : zn[0]; else zr = normal();
+                const double nz = 0.0 + a.r_noise * zr;
                 if (is32) rv = (double)((float)rv + (float)nz); else rv = rv + nz;
             }
-            if (HELPER && (ln & 63) == 0)
+            if (HELPER && !WALK && (ln & 63) == 0)
                 __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (is32) {
                 rv = (double)((float)rv * a.scale32);
@@ -739,7 +971,9 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
     // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
     const bool helper = noise && can_help && K >= 16 && (a.N % kBlock) == 0 && !(a.opts & MDPP_OPT_NO_HELPER);
     // Philox: several producer waves per consumer wave when the per-step draw count makes it worth it
-    const int nprod = (PHILOX && helper && D >= 8 && !(a.opts & MDPP_OPT_NO_TRIO)) ? kPhiloxProducers : 1;
+    // numpy streams: generator + walker waves (WALK) under the same conditions
+    const bool walk = !PHILOX && helper && D >= 8 && !(a.opts & (MDPP_OPT_NO_TRIO | MDPP_OPT_NO_PARK));
+    const int nprod = (PHILOX && helper && D >= 8 && !(a.opts & MDPP_OPT_NO_TRIO)) ? kPhiloxProducers : (walk ? 2 : 1);
     if (name_out) {
         snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d>", D,
                  ORDER, NREL, noise, helper, GEN, PHILOX, helper ? nprod : 0);
@@ -752,6 +986,9 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN, PHILOX, PHILOX ? kPhiloxProducers : 1>),
                                dim3(grid), dim3((1 + kPhiloxProducers) * kBlock), 0, s, ap, K, actions, obs, reward, term,
                                trunc, final_obs);
+        else if (can_help && helper && walk)
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help && D >= 8, GEN, false, (can_help && D >= 8 && !PHILOX) ? 2 : 1>), dim3(grid),
+                               dim3(3 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
         else if (can_help && helper)
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN, PHILOX>), dim3(grid),
                                dim3(2 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);

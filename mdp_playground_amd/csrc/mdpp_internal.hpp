@@ -196,6 +196,7 @@ struct mdpp_env {
     int32_t est_nk;
     void *d_P1, *d_init_cdf1, *d_noise_cdf1, *d_irr_state;   // irrelevant sub-space
     bool irr_ready;
+    bool line_hist_stale;       // move_along_a_line: set_state_continuous restored the step counters, the fit's window not yet
     void *d_sd, *d_cur, *d_meta;
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
     void *d_img_tpl, *d_img_tplp, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;

@@ -266,8 +266,10 @@ class RLToyVectorEnv:
             # continuous MDPs carry no generated tables: per-env seeds only change the streams
             pass
         cfg.D, cfg.n_rel, cfg.order = m.D, len(m.relevant_indices), m.order
+        self._line_L = 0
         if m.reward_function == "move_along_a_line":
             cfg.reward_function, cfg.L = capi.CREWARD_MOVE_ALONG_A_LINE, m.sequence_length
+            self._line_L = int(m.sequence_length)
         for j, r in enumerate(m.relevant_indices):
             cfg.rel_idx[j] = int(r)
             cfg.target[j] = float(m.target_point[j])
@@ -622,7 +624,14 @@ class RLToyVectorEnv:
         rc = self._lib.mdpp_get_state_continuous(self._h, capi.nptr(sd), capi.nptr(cur), capi.nptr(steps),
                                                  capi.nptr(ring), capi.nptr(is32), capi.nptr(reached))
         capi.check(self._lib, self._h, rc, "mdpp_get_state_continuous")
-        return {"curr_state": cur, "curr_obs": cur, "augmented_state": cur, "state_derivatives": sd,
+        aug = cur
+        if self._line_L:
+            # move_along_a_line: what the reference's augmented_state is read for (rl_toy_env.py:1865-1872, :2147-2156) --
+            # the last sequence_length states' relevant coordinates, oldest first, NaN before the episode's reset
+            aug = np.zeros((N, self._line_L, self._cfg.n_rel), np.float32)
+            rc = self._lib.mdpp_get_line_history(self._h, capi.nptr(aug))
+            capi.check(self._lib, self._h, rc, "mdpp_get_line_history")
+        return {"curr_state": cur, "curr_obs": cur, "augmented_state": aug, "state_derivatives": sd,
                 "total_transitions_episode": steps, "reward_buffer": ring, "reward_buffer_is32": is32,
                 "reached_terminal": reached.astype(bool)}
 
@@ -671,6 +680,13 @@ class RLToyVectorEnv:
         rc = self._lib.mdpp_set_state_continuous(self._h, capi.nptr(sd), capi.nptr(cur), capi.nptr(steps),
                                                  capi.nptr(ring), capi.nptr(is32), capi.nptr(reached))
         capi.check(self._lib, self._h, rc, "mdpp_set_state_continuous")
+        if self._line_L:
+            aug = np.ascontiguousarray(state["augmented_state"], dtype=np.float32)
+            if aug.shape != (self.num_envs, self._line_L, self._cfg.n_rel):
+                raise ValueError("move_along_a_line: augmented_state must be the [num_envs, sequence_length, n_relevant] history "
+                                 "get_augmented_state() returns")
+            rc = self._lib.mdpp_set_line_history(self._h, capi.nptr(aug))
+            capi.check(self._lib, self._h, rc, "mdpp_set_line_history")
 
     def get_episode_stats(self):
         """The reference's per-episode statistics (attributes of every env object, logged at each reset() and cleared,

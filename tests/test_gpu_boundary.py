@@ -529,3 +529,51 @@ def test_episode_stats_with_image_observations():
         assert np.array_equal(cur[i].view(np.uint64), want_cur.view(np.uint64)), (i, cur[i], want_cur)
         assert np.array_equal(last[i].view(np.uint64), want_last.view(np.uint64)), (i, last[i], want_last)
     env.close()
+
+
+@pytest.mark.parametrize("name", ["c_line_4d", "c_line_irr", "c_line_6of8"])
+def test_line_reward_checkpoint_carries_the_window_of_the_fit(name):
+    """move_along_a_line fits the last sequence_length states.  get_augmented_state() returns that window
+    (the part of the reference's augmented_state list the reward reads, rl_toy_env.py:1865-1872, :2147-2156; NaN before
+    the episode's reset), set_augmented_state() restores it into a fresh twin at every split point of a rollout, and
+    the twin continues bit for bit like the uninterrupted handle -- the first L rewards after the restore included.
+    Restoring the counters WITHOUT the window makes stepping fail loudly instead of fitting a stale one."""
+    from mdp_playground_amd import RLToyVectorEnv, _capi
+    import golden_util as gu
+    cfg = dict(gu.CASES[name]["config"], seed=3)
+    N, D = 192, cfg["state_space_dim"]
+    L = cfg["sequence_length"]
+    mk = lambda: RLToyVectorEnv(num_envs=N, autoreset="same_step", max_episode_steps=2 * L + 3, **cfg)   # noqa: E731
+    env = mk()
+    acts = torch.as_tensor(np.random.default_rng(5).uniform(-1, 1, size=(4 * L + 9, N, D)).astype(np.float32), device=env.device)
+    for split in (1, L - 1, L, 2 * L + 4, 3 * L + 1):
+        a, b = mk(), mk()
+        for t in range(split):
+            a.step(acts[t])
+        st = a.get_augmented_state()
+        n_rel = a._cfg.n_rel
+        assert st["augmented_state"].shape == (N, L, n_rel)
+        steps = st["total_transitions_episode"]
+        live = np.arange(L)[None, :] + steps[:, None] + 1 >= L
+        assert np.array_equal(~np.isnan(st["augmented_state"]).any(axis=2), live)           # NaN exactly before the episode
+        rel = list(a.mdps[0].relevant_indices)
+        assert np.array_equal(st["augmented_state"][:, -1], st["curr_state"][:, rel])       # newest = the current state
+        b._lib.mdpp_tick(b._h, split, None)
+        b.set_augmented_state(st)
+        for s_ in (0, 1):
+            b._put_stream(s_, a.get_rng_streams(s_))
+        for t in range(split, split + L + 3):
+            ra, rb = a.step(acts[t]), b.step(acts[t])
+            for x, y in zip(ra[:4], rb[:4]):
+                assert torch.equal(x, y), (name, split, t)
+        # counters without the window: refused
+        c = mk()
+        rc = c._lib.mdpp_set_state_continuous(c._h, _capi.nptr(np.ascontiguousarray(st["state_derivatives"], np.float32)),
+                                             _capi.nptr(np.ascontiguousarray(st["curr_state"], np.float32)),
+                                             _capi.nptr(np.ascontiguousarray(steps, np.int32)), None, None, None)
+        assert rc == 0
+        with pytest.raises(_capi.MdppError, match="set_line_history"):
+            c.step(acts[0])
+        for e in (a, b, c):
+            e.close()
+    env.close()
