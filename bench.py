@@ -710,6 +710,28 @@ def _pmc_blocked():
         "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
 
 
+def _run_group(cmd, timeout, **kw):
+    """subprocess.run for a child that has children of its own (rocprofv3 -> python): its own session, and on a timeout
+    the whole process group is ended, not only the direct child.  Returns the exit code, -999 on a timeout."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True, **kw)
+    try:
+        return p.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return -999
+
+
 def live_traffic_all(specs, launches=3, timeout=150):
     """HBM bytes per fused launch from PMC counters, measured NOW, for every (workload, rng, envs, fuse) of `specs`:
     two child rocprofv3 runs (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: they do not fit one pass; no trace domain
@@ -733,9 +755,7 @@ def live_traffic_all(specs, launches=3, timeout=150):
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "tools", "pmc_workloads.py"), str(launches)] + \
                   [f"{w}:{r}:{n}:{f}" for w, r, n, f in specs]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=timeout)
-            if r.returncode != 0:
+            if _run_group(cmd, timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp")) != 0:
                 return None
             rows = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):

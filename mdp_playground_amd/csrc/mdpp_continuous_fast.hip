@@ -77,16 +77,16 @@ constexpr int kNRing = 4;                      // steps of normals buffered per 
 #define MDPP_WK_GEN_BATCH 4        // generator: words per window check (divides kWRing)
 #endif
 #ifndef MDPP_WK_PARK
-#define MDPP_WK_PARK 8             // walker: parked lanes that trigger a wedge / tail pass
-#endif
+#define MDPP_WK_PARK 1             // walker: parked lanes that trigger a wedge / tail pass.  1 / 2 / 4 / 6 / 8 / 12 / 16 -> 1 518 / 1 554 / 1 648 /
+#endif                             // 1 714 / 1 869 / 2 196 / 2 457 us per cfg5 launch: a waiting lane holds the consumer's step back, the pass is cheap
 #ifndef MDPP_WK_GEN_PRIO
-#define MDPP_WK_GEN_PRIO 1
+#define MDPP_WK_GEN_PRIO 1         // (gen 1, walker 3, consumer 2: 1 475 us; all 0: 1 528; consumer first: 1 522 -- profiles/r04_ablation_walk.txt)
 #endif
 #ifndef MDPP_WK_WALKER_PRIO
-#define MDPP_WK_WALKER_PRIO 2
+#define MDPP_WK_WALKER_PRIO 3
 #endif
 #ifndef MDPP_WK_CONSUMER_PRIO
-#define MDPP_WK_CONSUMER_PRIO 3
+#define MDPP_WK_CONSUMER_PRIO 2
 #endif
 constexpr int kWRing = 32;         // WALK: raw words / normals buffered per env (powers of two: ring index = count & 31)
 constexpr int kPhiloxProducers = MDPP_PHILOX_PRODUCERS;   // producer waves per consumer wave, Philox streams (see NPROD)
@@ -226,10 +226,21 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         return;
     }
     if constexpr (WALK) {
+        // ring slots as BYTE offsets: slot (c & 31) of this lane is at ((c << 11) & 0xf800) + lane * 8
+        const uint32_t lane8 = (uint32_t)ln * 8u;
+        constexpr uint32_t SM = (uint32_t)(kWRing - 1) << 11;
+        char *rawb = (char *)s_raw;
+        char *zb = (char *)s_z;
+        auto raw_at = [&](uint32_t c11) __attribute__((always_inline)) -> uint64_t {          // c11 = count << 11
+            return *(const uint64_t *)(rawb + ((c11 & SM) | lane8));
+        };
         if (tid >= 2 * kBlock) {
             // ---------------- generator lane: the words of the env's noise stream, in order, by position -----------------
             // Word p of the launch goes to s_raw[p & 31][lane]; a batch is made when it fits the lane's window (the walker
             // has taken s_rp[lane] words: positions below s_rp + kWRing are free).  No data-dependent control flow.
+#ifdef MDPP_ABL_WK_NOGEN
+            return;
+#endif
             Pcg64 hg;
             hg.load(a.env_s, a.env_inc, i);
             Pcg64Limbs lg;
@@ -238,14 +249,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             constexpr uint32_t UG = MDPP_WK_GEN_BATCH;
             static_assert(kWRing % MDPP_WK_GEN_BATCH == 0, "a batch must not wrap");
             uint32_t p = 0, spins = 0, hstatus = 0;
-            uint64_t *rawl = s_raw + ln;
             for (;;) {
                 const uint32_t rp = __hip_atomic_load(&s_rp[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__hip_atomic_load(&s_done[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
                 const bool go = p + UG <= rp + (uint32_t)kWRing;
                 if (__builtin_amdgcn_ballot_w64(go) != 0) {
                     if (go) {
-                        uint64_t *dst = rawl + (size_t)(p & (uint32_t)(kWRing - 1)) * kBlock;
+                        uint64_t *dst = (uint64_t *)(rawb + (((p << 11) & SM) | lane8));
 #pragma unroll
                         for (uint32_t u = 0; u < UG; u++) dst[u * kBlock] = lg.next64();
                         p += UG;
@@ -272,12 +282,20 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             return;
         }
         if (tid >= kBlock) {
+#ifdef MDPP_ABL_WK_NOWALK
+            return;
+#endif
             // ---------------- walker lane: numpy's ziggurat over the words of the ring, in numpy's order -----------------
             // One round = up to NB fast attempts on the next NB words (98.8 % of attempts succeed: one table lookup, one
             // compare).  The accepted prefix goes to the normals ring; the first rejected word parks the lane with that
             // word.  When kPark lanes wait (or nothing else can be done) the wedge / tail path runs once for all of them
             // and takes its uniforms from the ring like numpy takes them from the stream.  Lanes drift apart by what
             // their rejections consumed; both rings are per lane, so nobody waits for anybody's position.
+            // The wedge test `y < exp(-x^2 / 2)` is decided by a float32 estimate of the right-hand side (v_exp_f32,
+            // relative error < 2e-6) wherever y is further than 1e-5 (relative) from it -- all but about one wedge point in
+            // 10^5 --; the others take the float64 exp() as before, so every decision is the one exp() gives.  (exp() for
+            // every pass was most of the 590 us that the passes cost a 1 860 us cfg5 launch; a variant that handed the
+            // passes to the generator wave made lanes wait longer than the 2.5 steps of normals the ring holds: 2 740 us.)
             __builtin_amdgcn_s_setprio(MDPP_WK_WALKER_PRIO);
             constexpr int NB = MDPP_WK_ATTEMPTS;
             constexpr uint32_t kPark = MDPP_WK_PARK;
@@ -286,23 +304,18 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             uint32_t n = 0, rp = 0, pub = 0, published = 0, thr = nd, spins = 0, hstatus = 0;
             bool parked = false;
             uint64_t pr = 0;
-            // ring slots as BYTE offsets: slot (c & 31) of this lane is at ((c << 11) & 0xf800) | lane * 8 -- an add and one
-            // v_and_or_b32 per access (both rings are 64 KiB: the masked count and the lane never share a bit)
-            const char *rawb = (const char *)s_raw;
-            char *zb = (char *)s_z;
-            const uint32_t lane8 = (uint32_t)ln * 8u;
-            constexpr uint32_t SM = (uint32_t)(kWRing - 1) << 11;
-            auto raw_at = [&](uint32_t c11) __attribute__((always_inline)) -> uint64_t {      // c11 = count << 11
-                return *(const uint64_t *)(rawb + ((c11 & SM) | lane8));
-            };
             auto z_put = [&](uint32_t c11, double v) __attribute__((always_inline)) { *(double *)(zb + ((c11 & SM) | lane8)) = v; };
             for (;;) {
                 const uint32_t cons = __hip_atomic_load(&s_cons[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MDPP_ABL_WK_NOCONS
+                const uint32_t nlim = total + (cons & 1u);
+#else
                 const uint32_t nlim = min(total, cons * nd + (uint32_t)kWRing);
+#endif
                 const uint32_t gp = __hip_atomic_load(&s_gp[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bool progress = false;
                 const bool can = !parked && n < nlim && rp < gp;
                 const uint64_t bcan = __builtin_amdgcn_ballot_w64(can);
-                bool progress = false;
                 if (bcan != 0) {
                     const uint32_t allowed = can ? min(min(nlim - n, gp - rp), (uint32_t)NB) : 0u;
                     uint64_t wd[NB];
@@ -322,7 +335,11 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                         // sign = bit 8 of the word -> bit 63 (x, or -x: numpy's `if (sign & 0x1) x = -x`)
                         xs[u] = __longlong_as_double((long long)((uint64_t)__double_as_longlong(x) ^
                                                                  ((uint64_t)((uint32_t)wd[u] & 0x100u) << 55)));
+#ifndef MDPP_ABL_WK_NOSLOW
                         bad |= (rabs < kw[u].x) ? 0u : (1u << u);
+#else
+                        bad |= (rabs < kw[u].x + 0x7fffffffffffffffULL) ? 0u : (1u << u);
+#endif
                     }
                     const uint32_t m = (uint32_t)__builtin_ctz(bad);        // accepted prefix (<= allowed)
                     const bool rej = m < allowed;
@@ -335,38 +352,54 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                     n += m;
                     rp += m + (rej ? 1u : 0u);
                     parked = parked || rej;
-                    progress = true;
+                    progress = can;
                 }
                 const uint64_t bpark = __builtin_amdgcn_ballot_w64(parked);
                 if (bpark != 0 && ((uint32_t)__builtin_popcountll(bpark) >= kPark || bcan == 0)) {
-                    if (parked) {
-                        const uint32_t idx = (uint32_t)pr & 0xffu;
-                        const uint64_t rabs = (pr >> 9) & 0x000fffffffffffffULL;
-                        if (idx == 0) {                 // tail: two uniforms per try (np_zig_tail), the lane stays parked until one is accepted
-                            if (rp + 2u <= gp) {
-                                const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
-                                const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
-                                const double u2 = (double)(raw_at((rp + 1u) << 11) >> 11) * (1.0 / 9007199254740992.0);
-                                rp += 2u;
-                                const double xx = -nor_inv_r * log1p(-u1);
-                                const double yy = -log1p(-u2);
-                                if (yy + yy > xx * xx) {
-                                    z_put(n << 11, ((rabs >> 8) & 0x1) ? -(nor_r + xx) : nor_r + xx);
-                                    n += 1u;
-                                    parked = false;
-                                }
-                                progress = true;
-                            }
-                        } else if (rp < gp) {           // wedge: one uniform; a rejected point starts the draw over with a fresh word
-                            double x = (double)rabs * __longlong_as_double((long long)s_kw[idx].y);
+                    const uint32_t idx = (uint32_t)pr & 0xffu;
+                    const bool tail = idx == 0u;
+                    const bool act = parked && rp + (tail ? 2u : 1u) <= gp;     // (the uniforms it takes are in the ring)
+                    // wedge lanes first: one uniform; a rejected point starts the draw over with a fresh word
+                    if (__builtin_amdgcn_ballot_w64(act && !tail) != 0) {
+                        bool sure = true, accf = false;
+                        double x = 0.0, y = 0.0;
+                        if (act && !tail) {
+                            const uint64_t rabs = (pr >> 9) & 0x000fffffffffffffULL;
+                            x = (double)rabs * __longlong_as_double((long long)s_kw[idx].y);
                             x = ((uint32_t)pr & 0x100u) ? -x : x;
                             const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
                             rp += 1u;
-                            if (((s_fi[idx - 1] - s_fi[idx]) * u1 + s_fi[idx]) < exp(-0.5 * x * x)) {
-                                z_put(n << 11, x);
-                                n += 1u;
-                            }
+                            y = (s_fi[idx - 1] - s_fi[idx]) * u1 + s_fi[idx];
+                            // exp(-x^2 / 2) = 2^t, t = -x^2 log2(e) / 2 in (-9.7, 0]: t rounded to float32 is off by < 5e-7
+                            // (6.6e-7 relative in the result), v_exp_f32 by one ulp
+                            const float e32 = __builtin_amdgcn_exp2f((float)(x * x * -0.72134752044448170368));
+                            const double e = (double)e32;
+                            accf = y < e;
+                            sure = fabs(y - e) > 1.0e-5 * e;
+                        }
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sure) != 0, 0)) {
+                            if (!sure) accf = y < exp(-0.5 * x * x);
+                        }
+                        if (act && !tail) {
+                            if (accf) { z_put(n << 11, x); n += 1u; }
                             parked = false;
+                            progress = true;
+                        }
+                    }
+                    // tail lanes (layer 0, |x| > 3.654: 3 in 10^4 draws): two uniforms per try, the lane stays parked until one is accepted
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(act && tail) != 0, 0)) {
+                        if (act && tail) {
+                            const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
+                            const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
+                            const double u2 = (double)(raw_at((rp + 1u) << 11) >> 11) * (1.0 / 9007199254740992.0);
+                            rp += 2u;
+                            const double xx = -nor_inv_r * log1p(-u1);
+                            const double yy = -log1p(-u2);
+                            if (yy + yy > xx * xx) {
+                                z_put(n << 11, ((pr >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx);
+                                n += 1u;
+                                parked = false;
+                            }
                             progress = true;
                         }
                     }
@@ -387,6 +420,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                     spins = 0;
                 }
             }
+            __hip_atomic_store(&s_rp[ln], rp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((ln & 63) == 0) __hip_atomic_store(&s_done[wv], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (hstatus) atomicOr(&a.status[i], hstatus);
             return;
@@ -543,6 +577,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         if (hstatus) atomicOr(&a.status[i], hstatus);
         return;
     }
+#ifdef MDPP_ABL_WK_NOCONS
+    if (WALK) return;
+#endif
     constexpr int kCAhead = NOISE ? kCAheadNoise : kCAheadQuiet;
     constexpr int V = (D == 2) ? 1 : D / 4;      // 16-byte pieces per action / observation row
     // Several producers per consumer: the consumer wave is the critical path (one dependent chain per step, while
@@ -571,8 +608,8 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     const ZT *zslot = s_z + ln;                 // HELPER: this step's normals, set per step
     int zi = 0;
     float zf[NPS];                              // PHILOX without helper waves: this step's normals
-    double zn[WALK ? NPS : 1];                  // WALK: this step's normals, packed in draw order (nd of them)
     const uint32_t wk_nd = (a.has_p_noise ? (uint32_t)D : 0u) + (a.has_r_noise ? 1u : 0u);
+    uint32_t wk_nb = 0;                         // WALK: count of this step's first normal (ring slot = count & 31; wave-uniform)
 
     const uint32_t total = (uint32_t)K * N;
     auto r_act = __builtin_amdgcn_make_buffer_rsrc((void *)actions, 0, total * (uint32_t)(D * 4), kCRsrc);
@@ -625,13 +662,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         return m <= __float_as_uint(bound);
     };
     auto normal = [&]() -> double {
-        if constexpr (WALK) {
-            double v = 0.0;
-#pragma unroll
-            for (int d = 0; d < NPS; d++) v = (d == zi) ? zn[d] : v;      // (zi is a compile-time constant after unrolling)
-            zi++;
-            return v;
-        }
+        // WALK: normals are packed in draw order, slot = (count of the step's first normal + zi) & 31 -- scalar arithmetic;
+        // read where they are used (holding a step's 13 doubles in registers spilled the step loop at 168 registers)
+        if constexpr (WALK) return (double)s_z[(size_t)((wk_nb + (uint32_t)(zi++)) & (uint32_t)(kWRing - 1)) * kBlock + ln];
         if (HELPER) return (double)zslot[(zi++) * kBlock];
         if constexpr (PHILOX) {
             float v = 0.0f;
@@ -678,18 +711,16 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             uint32_t spins = 0;
             // (producer k % NPROD has made k / NPROD + 1 steps once step k is in the ring)
             // (WALK: the walker publishes whole steps in s_prod[0])
+#ifdef MDPP_ABL_WK_NOWAIT
+            if (!WALK)
+#endif
             while (__hip_atomic_load(&s_prod[WALK ? 0 : k % NPROD][wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
                    (uint32_t)(WALK ? k + 1 : k / NPROD + 1)) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kCSpinLimit) { status |= kCStatusInternal; break; }
             }
             if constexpr (WALK) {
-                // the step's normals at once, then the slots are free again (the walker runs up to kWRing normals ahead)
-                const uint32_t nb = (uint32_t)k * wk_nd;
-#pragma unroll
-                for (int j = 0; j < NPS; j++) zn[j] = (double)s_z[(size_t)((nb + (uint32_t)j) & (uint32_t)(kWRing - 1)) * kBlock + ln];
-                if ((ln & 63) == 0)
-                    __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                wk_nb = (uint32_t)k * wk_nd;
                 zi = 0;
             } else {
                 zslot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
@@ -791,10 +822,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         if (!GEN) {
             if (NOISE && a.has_r_noise) {
                 if (HELPER || PHILOX) zi = D;
-                if constexpr (WALK) r = r + (float)(0.0 + a.r_noise * (a.has_p_noise ? zn[D] : zn[0]));
-                else r = r + (float)(0.0 + a.r_noise * normal());
+                if (WALK) zi = a.has_p_noise ? D : 0;
+                r = r + (float)(0.0 + a.r_noise * normal());
             }
-            if (HELPER && !WALK && (ln & 63) == 0)   // this wave is done with the step's slot
+            if (HELPER && (ln & 63) == 0)   // this wave is done with the step's slot
                 __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             r = r * a.scale32;
             r = r + a.shift32;
@@ -813,12 +844,11 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             if (steps % (uint32_t)a.every_n != 0) { rv = 0.0; is32 = false; }
             if (NOISE && a.has_r_noise) {
                 if (HELPER || PHILOX) zi = D;
-                double zr;
-                if constexpr (WALK) zr = a.has_p_noise ? zn[D] : zn[0]; else zr = normal();
-                const double nz = 0.0 + a.r_noise * zr;
+                if (WALK) zi = a.has_p_noise ? D : 0;
+                const double nz = 0.0 + a.r_noise * normal();
                 if (is32) rv = (double)((float)rv + (float)nz); else rv = rv + nz;
             }
-            if (HELPER && !WALK && (ln & 63) == 0)
+            if (HELPER && (ln & 63) == 0)
                 __hip_atomic_store(&s_cons[wv], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (is32) {
                 rv = (double)((float)rv * a.scale32);

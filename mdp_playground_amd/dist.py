@@ -72,7 +72,10 @@ class ShardedVectorEnv:
         self.env = RLToyVectorEnv(num_envs=hi - lo, device=device, env_id_offset=lo, **kwargs)
         self._always = bool(always_collective)
         self._g_obs = ObsGatherer(self.env._obs, world, dist_module, always_collective=self._always)
-        self._g_last = {}
+        # rollouts: ONE persistent staging row and gather output (a gatherer cached per rollout buffer pinned
+        # up to nine whole [K, N, ...] buffers, and env.rollout(out=None) allocates a fresh one per call)
+        self._last = torch.empty_like(self.env._obs)
+        self._g_last = ObsGatherer(self._last, world, dist_module, always_collective=self._always)
 
     def reset(self, seed=None):
         obs, info = self.env.reset(seed=seed)
@@ -85,15 +88,11 @@ class ShardedVectorEnv:
     def rollout(self, local_actions, out=None):
         """K fused steps of this rank's shard in one launch, then ONE all-gather of the rollout's LAST observation
         row: (obs_local [K, N_local, ...], reward, terminated, truncated, obs_global [N_global, ...]).  Per-step
-        observations stay on their rank (gathering all of them is bound by the xGMI links)."""
+        observations stay on their rank (gathering all of them is bound by the xGMI links).
+        `obs_global` is a view of this object's one gather buffer: the next rollout() overwrites it."""
         obs, rew, term, trunc = self.env.rollout(local_actions, out)
-        key = (obs.data_ptr(), tuple(obs.shape))
-        g = self._g_last.get(key)
-        if g is None:
-            if len(self._g_last) > 8:
-                self._g_last.clear()
-            g = self._g_last[key] = ObsGatherer(obs[-1], self.world, self.dist, always_collective=self._always)
-        return obs, rew, term, trunc, g().flatten(0, 1)
+        self._last.copy_(obs[-1])
+        return obs, rew, term, trunc, self._g_last().flatten(0, 1)
 
     def close(self):
         self.env.close()

@@ -1754,6 +1754,55 @@ def test_bench_shape_kernel_vs_oracle_every_env(kernel):
     env.close()
 
 
+@pytest.mark.timeout(1500)
+def test_bench_shape_cfg5_kernel_vs_oracle_every_env():
+    """the cfg5 leg of the bench line (bench.WORKLOADS["cfg5"]: 65 536 envs, fused launches of 512 steps,
+    bench.make_actions(seed 12345), numpy-exact streams) is the kernel whose stream consumption is data dependent --
+    generator, walker and consumer waves (k_continuous_rollout_fast<..., NPROD=2>), lanes drifting apart by what their
+    ziggurat rejections consumed.  Against the oracle on EVERY env for one launch: float32 states bit for bit, rewards,
+    flags, and the end states of both streams of every env (the generator un-draws what the walker did not take); a
+    second launch (state and streams carried over) on every 64th env."""
+    import bench
+    wl = bench.WORKLOADS["cfg5"]
+    N, F = wl["envs"], 512
+    env = _venv(num_envs=N, autoreset="same_step", **wl["config"])
+    kname = env.rollout_kernel_name(F)
+    assert kname.startswith("k_continuous_rollout_fast<") and "PHILOX=0" in kname and "NPROD=2" in kname, kname
+    acts = bench.make_actions(wl, F, N, env.device, 12345)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(acts)
+    assert not trunc.any()
+    end1 = (env.get_rng_streams(0), env.get_rng_streams(1))
+    obs2, rew2, term2, _ = env.rollout(acts)
+    end2 = (env.get_rng_streams(0), env.get_rng_streams(1))
+    assert (env.status() == 0).all()
+    B = 2048                                    # envs per host block (actions + observations: 100 MB a block)
+    for b0 in range(0, N, B):
+        a_h = acts[:, b0:b0 + B].cpu().numpy()
+        o_h, r_h, t_h = obs[:, b0:b0 + B].cpu().numpy(), rew[:, b0:b0 + B].cpu().numpy(), term[:, b0:b0 + B].cpu().numpy()
+        o2_h, r2_h, t2_h = obs2[:, b0:b0 + B].cpu().numpy(), rew2[:, b0:b0 + B].cpu().numpy(), term2[:, b0:b0 + B].cpu().numpy()
+        for j in range(B):
+            i = b0 + j
+            o = _oracle_for(env, i)
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+            assert np.array_equal(o.reset(), init[i]), i
+            a_i = np.ascontiguousarray(a_h[:, j])
+            eo, er, ed, ero = o.rollout(a_i, None)
+            eo[ed] = ero[ed]
+            assert np.array_equal(o_h[:, j].view(np.uint32), eo.view(np.uint32)), i
+            assert np.array_equal(t_h[:, j], ed) and np.array_equal(r_h[:, j], er.astype(np.float32)), i
+            ge, gs = o.get_rng()
+            assert np.array_equal(ge[:4], end1[0][i][:4]) and np.array_equal(gs[:4], end1[1][i][:4]), i
+            if i % 64 == 0:
+                eo, er, ed, ero = o.rollout(a_i, None)
+                eo[ed] = ero[ed]
+                assert np.array_equal(o2_h[:, j].view(np.uint32), eo.view(np.uint32)), i
+                assert np.array_equal(t2_h[:, j], ed) and np.array_equal(r2_h[:, j], er.astype(np.float32)), i
+                ge, gs = o.get_rng()
+                assert np.array_equal(ge[:4], end2[0][i][:4]) and np.array_equal(gs[:4], end2[1][i][:4]), i
+    env.close()
+
+
 def test_edge_shapes_and_errors():
     cfg = _cfg("d_cfg2", 1)
     # ragged sizes: 1 env, and a batch that is not a multiple of the wave or block size
