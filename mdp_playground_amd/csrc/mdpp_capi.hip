@@ -417,6 +417,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     return MDPP_OK;
 }
 
+static inline bool t_fits53(uint64_t t) { return t <= (1ULL << 53) - 1; }
+
 extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const double *rtable,
                                            const uint8_t *rbits, const uint8_t *is_term,
                                            const double *init_cdf, const double *noise_cdf) {
@@ -456,7 +458,28 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         a.shape_ok_noise = (T == 1 && c.unit_rewards && (c.has_transition_noise || c.has_reward_noise) &&
                             c.rng_mode == MDPP_RNG_PHILOX && c.L <= 3 && c.S <= 8 && c.S >= 2 && c.delay <= 32 &&
                             c.autoreset != MDPP_AUTORESET_NEXT_STEP && a.rew_in_lds && !c.irrelevant && !c.image) ? 1u : 0u;
-        if (c.episode_stats) a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = a.shape_ok_noise = 0u;   // (general kernel keeps the statistics)
+        // numpy streams: the lean kernel serves the noisy shape when the S transition-noise categoricals have the
+        // row-independent threshold form (DiscreteArgs::pn_TL / pn_TU)
+        a.shape_ok_noise_np = (T == 1 && c.unit_rewards && (c.has_transition_noise || c.has_reward_noise) &&
+                               c.rng_mode == MDPP_RNG_NUMPY_PCG64 && c.L <= 3 && c.S <= 8 && c.S >= 2 && c.delay <= 32 &&
+                               c.autoreset != MDPP_AUTORESET_NEXT_STEP && a.rew_in_lds && !c.irrelevant && !c.image) ? 1u : 0u;
+        for (int j = 0; j < 8; j++) a.pn_TL[j] = a.pn_TU[j] = ~0ULL;
+        if (a.shape_ok_noise_np && c.has_transition_noise) {
+            bool same = true;
+            for (size_t j = 0; j < S; j++) {
+                uint64_t tl = 0, tu = 0;
+                bool hl = false, hu = false;
+                for (size_t n = 0; n < S; n++) {
+                    const uint64_t t = (uint64_t)ceil(ldexp(noise_cdf[n * S + j], 53));
+                    if (n > j) { if (hl && tl != t) same = false; tl = t; hl = true; }
+                    else { if (hu && tu != t) same = false; tu = t; hu = true; }
+                }
+                if (t_fits53(tl) && hl) a.pn_TL[j] = tl << 11;
+                if (hu) a.pn_TU[j] = tu > (1ULL << 53) - 1 ? ~0ULL : tu << 11;      // (cdf 1.0: never reached by a 53-bit draw)
+            }
+            if (!same) a.shape_ok_noise_np = 0u;
+        }
+        if (c.episode_stats) a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = a.shape_ok_noise = a.shape_ok_noise_np = 0u;   // (general kernel keeps the statistics)
         a.s_shift = 0xFFFFFFFFu;
         for (uint32_t b = 1; b < 8; b++) if ((1u << b) == (uint32_t)c.S) a.s_shift = b;
         a.key_mask = h->nkeys - 1u;

@@ -428,7 +428,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
     // Philox handles of the common shape: k_discrete_rollout_lean with its H waves on Philox blocks
     // (mdpp_discrete_lean.hip); pieces it does not take (a short last one) go to the quiet kernel
     bool lean_philox = false;
-    if (!a.fast_ok && ((a.philox && (a.shape_ok || a.shape_ok_noise)) || a.shape_ok_irr || a.lean_next_ok)) {
+    if (!a.fast_ok && ((a.philox && (a.shape_ok || a.shape_ok_noise)) || a.shape_ok_noise_np || a.shape_ok_irr || a.lean_next_ok)) {
         const long long kmax = ((1LL << 32) - 1) / ((a.irr ? 16LL : 8LL) * a.N);
         char dry[kNameLen];
         const int k_first = (int)(K < kmax ? K : kmax);
@@ -450,6 +450,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
                     // (a short last piece of a next-step handle: the general kernel)
                     if (a.philox && noise) launch_step_t<true, true>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
                     else if (a.philox) launch_step_t<true, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
+                    else if (noise) launch_step_t<false, true>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
                     else launch_step_t<false, false>(a, kc, actions + aoff, op, reward + off, term + off, trunc + off, fo, s, name_out);
                 }
                 if (name_out) return MDPP_OK;

@@ -36,6 +36,22 @@
 // the others) beside its start states; the E lane applies one with seven instructions and re-encodes the column byte
 // with a v_perm_b32 of a constant; the O1 lane makes its own eight normals per chunk (two blocks, two packed Box-Muller
 // pairs) and forms the reward in float64 in the reference's order (:1980-1990, :2107).
+// NZ on NUMPY streams (round 4; mdpp_discrete_lean_npnoise.hip): the reference's own draws, bit for bit, without putting a
+// generator on the E lane (k_discrete_rollout_quiet<PN, RN> runs both PCG64 streams, the categorical search and the
+// ziggurat inside the recurrence: 607 us per cfg2 launch).  The H wave owns both streams:
+//   * transition noise (:1604-1622) takes exactly one word of the state space's stream per step, so H makes the chunk's
+//     eight words ahead like the Philox form; the categorical around table entry n is searched ONCE for all n -- with
+//     a = #{j : TL[j] <= r}, b = #{j : TU[j] <= r} the re-drawn state is min(a, n) + max(b - n, 0) (DiscreteArgs::pn_TL:
+//     exact whenever the rows' thresholds agree, which the host checks) -- and E applies the byte (a | b << 4);
+//   * reward noise (:1980-1984) and reset() (:2255) share the ENV stream: per step one ziggurat normal (1, 2 or more
+//     words), then one word if the episode ended -- only E knows where a step's draws start.  H therefore evaluates
+//     EVERY position p of the stream as if a draw started there: meta[p] = {the start state word p would give a reset,
+//     kind: normal accepted at once / wedge point accepted (2 words) / wedge point rejected (2 words, the draw starts
+//     over) / tail (count in the high byte)} and x[p] = that draw's value, into 16-position rings per lane; the
+//     ziggurat's slow path uses a COPY of the generator (its words are evaluated again as positions of their own).  E
+//     walks positions: reads meta[p], meta[p + 1], meta[p + 2] (fetched one step ahead), copies x[p] into the step's
+//     record for O1, and moves on by the draw's words (+ 1 if the episode ended); H runs up to 16 positions ahead of the
+//     position E publishes and un-draws what E did not reach at the end of the launch.
 // What the measurements said (profiles/r02_ablation_lean_kernel.txt): with the default cache policy
 // the time was set by the stores, whoever issued them (147 us per 512-step launch of 65 536 envs with
 // one, two or three storing waves per SIMD); marked nt they cost 10 us on top of the 95 us the
@@ -50,7 +66,7 @@
 #define MDPP_LEAN_TU_NEXT 0        // 1: this translation unit holds the next-step autoreset instantiations
 #endif
 #ifndef MDPP_LEAN_TU_NOISE
-#define MDPP_LEAN_TU_NOISE 0       // 1: ... the transition- / reward-noise instantiations (Philox streams)
+#define MDPP_LEAN_TU_NOISE 0       // 1: ... the transition- / reward-noise instantiations (Philox streams); 2: on numpy streams
 #endif
 
 #include "mdpp_internal.hpp"
@@ -108,6 +124,10 @@ constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kStatusInternal = 0x80000000u;
 constexpr uint32_t kQueueCap = 6;
 constexpr int kHChunks = 8;               // Philox streams: H runs up to this many chunks ahead of E
+constexpr int kHChunksNp = 4;             // numpy transition noise: ... this many (LDS)
+constexpr int kXR = 16;                   // numpy reward noise: stream positions H evaluates ahead of E (per lane)
+constexpr int kXB = 4;                    // ... per batch (divides kXR)
+constexpr int kDepthNp = 16;              // ... and the E->O ring depth of these instantiations (records carry the normal)
 constexpr int kRoles = 4;                 // E, O1 (reward path), O2 (observation / flag stores), H
 constexpr uint32_t kSelPad = 0x0c0c0c00u; // v_perm_b32 selector bytes 1-3: constant 0x00
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -162,7 +182,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // E -> O, three dwords per env step in ONE array (constant 32 KB apart: two of them go out as one ds_write2st64):
     //   A history before a reset   B history after it   C byte 0: the column entry (bit 7 terminated), byte 1 the
     //   irrelevant observation, byte 2 truncated
-    __shared__ __align__(16) uint32_t lds_rec[3][kDepth][kBlock];
+    constexpr bool PN = (NZ & 1) != 0, RN = (NZ & 2) != 0;
+    constexpr bool NPN = PN && !PHILOX, NRN = RN && !PHILOX;          // noise on numpy streams
+    constexpr int KD = NRN ? kDepthNp : kDepth;                       // E->O ring depth in steps
+    __shared__ __align__(16) uint32_t lds_rec[3][KD][kBlock];
     __shared__ __align__(16) uint32_t lds_V[2048];            // reward bit & NaN gate, by the 4 low nibbles
     __shared__ __align__(16) uint2 lds_col[16];               // action a, byte s: P[s][a] | 8 | is_term[P[s][a]] << 7
     __shared__ __align__(16) uint32_t lds_R[128];             // 4096 reward bits by key (staging for lds_V)
@@ -178,7 +201,6 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ __align__(16) uint2 lds_col1[IRR ? 16 : 1];    // irrelevant sub-space: action a1, byte s1: P1[s1][a1]
     __shared__ __align__(16) uint64_t lds_T1[IRR ? 8 : 1];    // its rho_0 thresholds
     __shared__ uint32_t lds_hprod[kBlock / 64];               // Philox: chunks published by H wave w
-    constexpr bool PN = (NZ & 1) != 0, RN = (NZ & 2) != 0;
     // Wave priorities (s_setprio).  numpy streams: the serial recurrence (E) first, the H wave's PCG64 draws are filler work.
     // Philox streams: the waves that make Philox blocks are the long stages and go first -- H (start states, and with PN
     // the transition-noise words), with RN the O1 wave (normals) -- and the E wave, now the shortest stage, last:
@@ -187,8 +209,16 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     constexpr int kPrioE = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_E : 1;
     constexpr int kPrioO = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_O : (PN ? 2 : 3);
     constexpr int kPrioH = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_H : (PN ? 3 : 2);
-    static_assert(NZ == 0 || (PHILOX && !IRR && !NEXT), "noise on the lean kernel: Philox streams, one sub-space, same-step autoreset");
-    __shared__ __align__(16) uint32_t lds_pn[PN ? kHChunks : 1][kBlock];       // H -> E: the chunk's 8 transition-noise nibbles
+    static_assert(NZ == 0 || (!IRR && !NEXT), "noise on the lean kernel: one sub-space, same-step autoreset");
+    __shared__ __align__(16) uint32_t lds_pn[(PN && PHILOX) ? kHChunks : 1][kBlock];       // H -> E: the chunk's 8 transition-noise nibbles
+    // numpy streams (header): transition-noise bytes of a chunk; per stream position the draw's value and {start state, kind, words}
+    __shared__ __align__(16) uint32_t lds_pn2[NPN ? kHChunksNp : 1][2][kBlock];
+    __shared__ __align__(16) double lds_x[NRN ? kXR : 1][kBlock];
+    __shared__ uint16_t lds_meta[NRN ? kXR : 1][kBlock];
+    __shared__ __align__(16) double lds_rx[NRN ? KD : 1][kBlock];      // E -> O1: the step's normal
+    __shared__ uint32_t lds_hhead[NRN ? kBlock : 1], lds_epos[NRN ? kBlock : 1];   // positions made by H / reached by E
+    __shared__ ulonglong2 lds_kw[NRN ? 256 : 1];                       // ziggurat {ki, wi}
+    __shared__ double lds_fi[NRN ? 256 : 1];
     constexpr int kEN = IRR ? 2 : 1;                // nibbles per start-state entry (relevant, irrelevant)
     // gymnasium's next-step autoreset: the call after an episode's last step IS the reset (action ignored, reward 0,
     // no flags); the pending flag travels in bit 31 of the step counter like in k_discrete_step
@@ -229,7 +259,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         }
         lds_R[k] = wd;
     }
-    if (tid < kBlock) { lds_ring[tid] = 0; lds_head[tid] = 0; }
+    if (tid < kBlock) { lds_ring[tid] = 0; lds_head[tid] = 0; if (NRN) { lds_hhead[tid] = 0; lds_epos[tid] = 0; } }
+    if (NRN)
+        for (int k = tid; k < 256; k += kRoles * kBlock) { lds_kw[k] = make_ulonglong2(d_zig_ki[k], (unsigned long long)__double_as_longlong(d_zig_wi[k])); lds_fi[k] = d_zig_fi[k]; }
     if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; }
     if (tid == 0) lds_done = 0;
     __syncthreads();
@@ -281,7 +313,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #if defined(MDPP_ABL_NOH) && defined(MDPP_ABL_NORESET)
         return;         // (only together with NORESET: without the H waves every reset spins to its bound -- minutes per launch)
 #endif
-        if (!ar && !PN) return;
+        if (!ar && !PN && !NRN) return;
         __builtin_amdgcn_s_setprio(kPrioH);
         if constexpr (PHILOX) {
             // Philox streams: the start state a reset at tick t draws is a function of (seed, env, t) alone -- ONE 32-bit
@@ -342,6 +374,170 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     lds_pn[c % kHChunks][l] = pn;
                 }
                 if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)(c + 1));
+            }
+            if (status) atomicOr(&a.status[i], status);
+            return;
+        }
+        if constexpr (NPN || NRN) {
+            // ---- numpy streams with noise (header): H owns the state space's stream (transition noise, one word per step, made a
+            // chunk ahead) and the env stream (RN: every position evaluated as a draw's start; else: the start-state queue)
+            Pcg64 g;
+            g.load(a.env_s, a.env_inc, i);
+            Pcg64LimbsLo ge;
+            ge.from(g);
+            Pcg64 sp;
+            Pcg64LimbsLo gs;
+            if (PN) { sp.load(a.sp_s, a.sp_inc, i); gs.from(sp); }
+            const int nch = (K + kChunk - 1) / kChunk;
+            int c = 0;                              // transition-noise chunks made
+            uint32_t hq = 0;                        // RN: positions made
+            uint32_t vals = 0, tail = 0, spins = 0; // !RN: the start-state queue (as on quiet handles)
+            // start state of a reset whose word is r: #{j : ceil(cdf[j] 2^53) <= r >> 11}
+            auto start_of = [&](uint64_t r) __attribute__((always_inline)) -> uint32_t {
+                const uint64_t m = r >> 11;
+                uint32_t s0 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) s0 += (a.init_thr[j] <= m) ? 1u : 0u;
+                return s0;
+            };
+            for (;;) {
+                if (wg_load_acq(&lds_done) == kBlock / 64) break;
+                bool did = false;
+                if constexpr (NPN) {
+                    if (c < nch && (c < kHChunksNp || wg_load_acq(&lds_prod[w]) >= (uint32_t)min((c - kHChunksNp + 1) * kChunk, K))) {
+                        uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                        for (int u = 0; u < kChunk; u++) {
+                            const uint64_t r = gs.next64();
+                            uint32_t na = 0, nb = 0;
+#pragma unroll
+                            for (int j = 0; j < 7; j++) na += (a.pn_TL[j] <= r) ? 1u : 0u;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) nb += (a.pn_TU[j] <= r) ? 1u : 0u;
+                            pk[u >> 2] |= (na | (nb << 4)) << (8 * (u & 3));
+                        }
+                        lds_pn2[c % kHChunksNp][0][l] = pk[0];
+                        lds_pn2[c % kHChunksNp][1][l] = pk[1];
+                        c += 1;
+                        if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)c);
+                        did = true;
+                    }
+                }
+                if constexpr (NRN) {
+                    const uint32_t epos = __hip_atomic_load(&lds_epos[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const bool go = hq + (uint32_t)kXB <= epos + (uint32_t)kXR;
+                    if (__builtin_amdgcn_ballot_w64(go) != 0) {
+                        uint32_t rej = 0;
+                        uint64_t wdv[kXB];
+                        uint32_t sv[kXB][4];
+                        if (go) {
+#pragma unroll
+                            for (int u = 0; u < kXB; u++) {
+                                const uint64_t wd = ge.next64();
+                                wdv[u] = wd;
+                                sv[u][0] = ge.s0; sv[u][1] = ge.s1; sv[u][2] = ge.s2; sv[u][3] = ge.s3;
+                                const ulonglong2 kw = lds_kw[(uint32_t)wd & 0xffu];
+                                const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
+                                const double t = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
+                                const double x = t * __longlong_as_double((long long)kw.y);
+                                const double xs = __longlong_as_double((long long)((uint64_t)__double_as_longlong(x) ^
+                                                                                     ((uint64_t)((uint32_t)wd & 0x100u) << 55)));
+                                const bool ok = rabs < kw.x;
+                                rej |= ok ? 0u : (1u << u);
+                                const uint32_t slot = (hq + (uint32_t)u) & (uint32_t)(kXR - 1);
+                                lds_x[slot][l] = xs;
+                                lds_meta[slot][l] = (uint16_t)(start_of(wd) | (ok ? 0u : (2u << 3)));   // (rejected: patched below)
+                            }
+                        }
+                        // the ziggurat's slow path for the rejected words of the batch, on a copy of the generator
+                        while (__builtin_amdgcn_ballot_w64(rej != 0u) != 0) {
+                            if (rej != 0u) {
+                                const uint32_t j = (uint32_t)__builtin_ctz(rej);
+                                rej &= rej - 1u;
+                                Pcg64LimbsLo t = ge;
+                                uint64_t wd = 0;
+#pragma unroll
+                                for (int u = 0; u < kXB; u++)
+                                    if (j == (uint32_t)u) { t.s0 = sv[u][0]; t.s1 = sv[u][1]; t.s2 = sv[u][2]; t.s3 = sv[u][3]; wd = wdv[u]; }
+                                const uint32_t idx = (uint32_t)wd & 0xffu;
+                                const uint32_t slot = (hq + j) & (uint32_t)(kXR - 1);
+                                const uint32_t ss = lds_meta[slot][l] & 7u;
+                                if (idx == 0u) {            // tail: two uniforms per try (np_zig_tail)
+                                    const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
+                                    uint32_t cnt = 1u;
+                                    double val = 0.0;
+                                    for (;;) {
+                                        const double u1 = (double)(t.next64() >> 11) * (1.0 / 9007199254740992.0);
+                                        const double u2 = (double)(t.next64() >> 11) * (1.0 / 9007199254740992.0);
+                                        cnt += 2u;
+                                        const double xx = -nor_inv_r * log1p(-u1);
+                                        const double yy = -log1p(-u2);
+                                        if (yy + yy > xx * xx) { val = ((wd >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx; break; }
+                                        if (cnt > 250u) { status |= kStatusInternal; break; }
+                                    }
+                                    lds_x[slot][l] = val;
+                                    lds_meta[slot][l] = (uint16_t)(ss | (3u << 3) | (cnt << 8));
+                                } else {                    // wedge: one uniform; a rejected point starts the draw over two words on
+                                    const double x = lds_x[slot][l];
+                                    const double u1 = (double)(t.next64() >> 11) * (1.0 / 9007199254740992.0);
+                                    const double y = (lds_fi[idx - 1] - lds_fi[idx]) * u1 + lds_fi[idx];
+                                    // exp(-x^2 / 2) by a float32 estimate (relative error < 2e-6); float64 exp() within 1e-5 of it
+                                    const double e = (double)__builtin_amdgcn_exp2f((float)(x * x * -0.72134752044448170368));
+                                    bool acc = y < e;
+                                    if (!(fabs(y - e) > 1.0e-5 * e)) acc = y < exp(-0.5 * x * x);
+                                    lds_meta[slot][l] = (uint16_t)(ss | ((acc ? 1u : 2u) << 3));
+                                }
+                            }
+                        }
+                        if (go) hq += (uint32_t)kXB;
+                        __hip_atomic_store(&lds_hhead[l], hq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        did = true;
+                    }
+                } else if (ar) {
+                    // (transition noise only: resets draw their start states from the env stream ahead of need, as without noise)
+                    const uint32_t head = wg_load_acq(&lds_head[l]);
+                    const uint32_t cnt = tail - head;
+                    const bool want = cnt + 1u <= 8u;
+                    const uint64_t bw = __builtin_amdgcn_ballot_w64(want);
+                    const bool urgent = __builtin_amdgcn_ballot_w64(want && cnt <= 2) != 0;
+                    if (__builtin_popcountll(bw) >= kMinLanes || urgent) {
+                        Pcg64LimbsLo n = ge;
+                        const uint32_t s0 = start_of(n.next64()) | 8u;
+                        if (want) {
+                            const uint32_t sh = (tail & 7u) * 4u;
+                            ge = n;
+                            vals = (vals & ~(0xFu << sh)) | (s0 << sh);
+                            tail += 1u;
+                        }
+                        __hip_atomic_store(&lds_ring[l], (uint64_t)vals | ((uint64_t)tail << 32), __ATOMIC_RELEASE,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                        did = true;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(did) == 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit * 4u) { status |= kStatusInternal; break; }
+                } else {
+                    spins = 0;
+                }
+            }
+            // un-draw what was made and not used: s_prev = (s - inc) * M^-1 (mod 2^128)
+            auto undraw = [&](Pcg64 &gg, uint32_t q) {
+                for (; q > 0; q--) {
+                    uint64_t lo = gg.s_lo - gg.inc_lo;
+                    uint64_t hi = gg.s_hi - gg.inc_hi - (gg.s_lo < gg.inc_lo ? 1ULL : 0ULL);
+                    gg.s_lo = lo * a.minv_lo;
+                    gg.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+                }
+            };
+            ge.to(g);
+            if (NRN) undraw(g, hq - __hip_atomic_load(&lds_epos[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            else undraw(g, tail - wg_load_acq(&lds_head[l]));
+            g.store(a.env_s, i);
+            if (PN) {
+                gs.to(sp);
+                undraw(sp, (uint32_t)(c * kChunk) - (uint32_t)K);       // (the last chunk may be ragged)
+                sp.store(a.sp_s, i);
             }
             if (status) atomicOr(&a.status[i], status);
             return;
@@ -416,7 +612,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         const uint32_t r4 = (uint32_t)a.ptick & 3u;
         float zc[kChunk] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};         // RN: the chunk's reward normals
         const bool plain = a.scale == 1.0 && a.shift == 0.0;                        // (wave-uniform)
-        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, float z) {
+        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, double z) {
             uint32_t bit = lds_V[(ra >> 5) & 2047u] >> (ra & 31u);                   // reward bit, NaN-gated (:1822)
             uint32_t out;
             if (DELAY) {                                                             // FIFO (:1970-1973)
@@ -436,7 +632,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             float rout;
             if constexpr (RN) {                                                      // :1975-1990, :2107 in float64
                 double r = (out != 0u && (!EVN || rd == 0u)) ? 1.0 : 0.0;
-                r += 0.0 + a.r_noise * (double)z;
+                r += 0.0 + a.r_noise * z;
                 if (!plain) {                // (scale 1, shift 0: r * 1.0 and r + 0.0 are r -- it is never -0.0 here)
                     r *= a.scale;
                     r += a.shift;
@@ -457,7 +653,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kChunk;
             const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
-            if constexpr (RN)       // (before the wait: independent of E)
+            if constexpr (RN && PHILOX)       // (before the wait: independent of E)
                 chunk_normals(a.philox_seed, genv, (a.ptick + (uint64_t)kbase) >> 2, r4, kPhiloxRNoiseStream, zc);
             uint32_t spins = 0;
 #ifdef MDPP_ABL_FREEO
@@ -472,18 +668,22 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 uint32_t ra[kChunk], rb[kChunk], rc[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    ra[u] = lds_rec[0][(kbase + u) % kDepth][l];
-                    rb[u] = lds_rec[1][(kbase + u) % kDepth][l];
-                    rc[u] = lds_rec[2][(kbase + u) % kDepth][l];
+                    ra[u] = lds_rec[0][(kbase + u) % KD][l];
+                    rb[u] = lds_rec[1][(kbase + u) % KD][l];
+                    rc[u] = lds_rec[2][(kbase + u) % KD][l];
                 }
+                double zd[kChunk];
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N, zc[u]);
+                for (int u = 0; u < kChunk; u++) zd[u] = NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u];    // (numpy streams: the normal E found)
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N, zd[u]);
             } else {
 #pragma unroll
                 for (int u = 0; u < kChunk; u++)
                     if (kbase + u < K)
-                        emit(lds_rec[0][(kbase + u) % kDepth][l], lds_rec[1][(kbase + u) % kDepth][l],
-                             lds_rec[2][(kbase + u) % kDepth][l], (uint32_t)(kbase + u) * N, zc[u]);
+                        emit(lds_rec[0][(kbase + u) % KD][l], lds_rec[1][(kbase + u) % KD][l],
+                             lds_rec[2][(kbase + u) % KD][l], (uint32_t)(kbase + u) * N,
+                             NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u]);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][0], upto);
         }
@@ -539,13 +739,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 uint32_t rb[kChunk], rc[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
-                    rb[u] = lds_rec[1][(kbase + u) % kDepth][l];
-                    rc[u] = lds_rec[2][(kbase + u) % kDepth][l];
+                    rb[u] = lds_rec[1][(kbase + u) % KD][l];
+                    rc[u] = lds_rec[2][(kbase + u) % KD][l];
                 }
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) emit(rb[u], rc[u], (uint32_t)(kbase + u) * N);
             } else {
-                for (int k = kbase; k < K; k++) emit(lds_rec[1][k % kDepth][l], lds_rec[2][k % kDepth][l], (uint32_t)k * N);
+                for (int k = kbase; k < K; k++) emit(lds_rec[1][k % KD][l], lds_rec[2][k % KD][l], (uint32_t)k * N);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][1], upto);
         }
@@ -565,7 +765,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const uint32_t b = (st.x >> (8 * j)) & 0xFFu;
             k2 = (k2 << 4) | (b == 0xFFu ? 0u : ((b & 7u) | 8u));
         }
-        const bool own_q = !PHILOX && !IRR && !nextmode;   // word 1 of the state is this kernel's draw queue (fast_ok handles)
+        const bool own_q = !PHILOX && !IRR && !nextmode && NZ == 0;   // word 1 of the state is this kernel's draw queue (fast_ok handles)
         const uint32_t qc = own_q ? (st.y >> 24) & 7u : 0u;
         qv = own_q ? (st.y & 0x00777777u) | (0x00888888u & ((1u << (4u * qc)) - 1u)) : 0u;
         steps0 = st.z & 0x7FFFFFFFu;
@@ -582,7 +782,31 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     uint32_t c1 = IRR ? (a.irr_state[i] & 7u) : 0u;                 // the irrelevant part of curr_state
     const uint32_t A1 = IRR ? (uint32_t)a.A1 : 1u;
 
-    uint32_t pnc = 0;                               // PN: this chunk's transition-noise nibbles
+    uint32_t pnc = 0, pnc_hi = 0;                   // PN: this chunk's transition-noise nibbles (numpy streams: bytes a | b << 4)
+    // NRN: the env stream by position (header).  ep = position of the next draw; (m0, m1, m2, xv) = meta[ep .. ep + 2], x[ep],
+    // fetched at the end of the previous step; hh = positions H has made, as last read
+    uint32_t ep = 0, hh = 0, m0 = 0, m1 = 0, m2 = 0;
+    double xv = 0.0;
+    auto ensure = [&](uint32_t upto) __attribute__((always_inline)) {       // positions < upto are made
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(upto > hh) != 0, 0)) {
+            uint32_t spins = 0;
+            hh = __hip_atomic_load(&lds_hhead[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__builtin_amdgcn_ballot_w64(upto > hh) != 0) {
+                __hip_atomic_store(&lds_epos[l], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (H's window follows E)
+                __builtin_amdgcn_s_sleep(1);
+                hh = __hip_atomic_load(&lds_hhead[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; hh = upto; break; }
+            }
+        }
+    };
+    auto fetch = [&]() __attribute__((always_inline)) {
+        ensure(ep + 3u);
+        m0 = lds_meta[ep & (uint32_t)(kXR - 1)][l];
+        m1 = lds_meta[(ep + 1u) & (uint32_t)(kXR - 1)][l];
+        m2 = lds_meta[(ep + 2u) & (uint32_t)(kXR - 1)][l];
+        xv = lds_x[ep & (uint32_t)(kXR - 1)][l];
+    };
+    if constexpr (NRN) fetch();
     // PN: byte s of {enc_lo, enc_hi} = s | 8 | is_terminal[s] << 7, the column byte of a re-drawn state
     uint32_t enc_lo = 0, enc_hi = 0;
     if constexpr (PN) {
@@ -592,6 +816,17 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     }
     auto pull = [&](int c) {
         if (!ar && !PN) return;                     // (no resets: nothing is drawn, the H lanes have left)
+        if (NPN && c >= 0) {                        // this chunk's transition-noise bytes, made by the H wave from the space stream
+            uint32_t spins = 0;
+            while (wg_load_acq(&lds_hprod[w]) < (uint32_t)(c + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+            }
+            pnc = lds_pn2[c % kHChunksNp][0][l];
+            pnc_hi = lds_pn2[c % kHChunksNp][1][l];
+        }
+        if constexpr (NRN) return;                  // (start states come with the positions)
+        if (!PHILOX && !ar) return;
         if constexpr (PHILOX) {                     // this chunk's start states, made by the H wave
             uint32_t spins = 0;
             while (wg_load_acq(&lds_hprod[w]) < (uint32_t)(c + 1)) {
@@ -643,9 +878,14 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     };
     auto stepE = [&](const Col &col, int k, uint32_t badbit) {
         uint32_t entry = __builtin_amdgcn_perm(col.y, col.x, sel);                    // D1: P[cur][a] | 8 | terminal << 7
-        if constexpr (PN) {                                                           // D2 (:1604-1622), philox_pnoise_*
+        if constexpr (PN && PHILOX) {                                                 // D2 (:1604-1622), philox_pnoise_*
             const uint32_t nib = (pnc >> (4 * (k % kChunk))) & 0xFu, j = nib & 7u, nx = entry & 7u;
             const uint32_t ns = nib > 7u ? j + (j >= nx ? 1u : 0u) : nx;
+            entry = __builtin_amdgcn_perm(enc_hi, enc_lo, ns | kSelPad);
+        }
+        if constexpr (NPN) {                                                          // ... on the space stream's word: min(a, n) + max(b - n, 0)
+            const uint32_t by = (((k % kChunk) < 4 ? pnc : pnc_hi) >> (8 * (k & 3))) & 0xFFu, nx = entry & 7u;
+            const uint32_t ns = min(by & 15u, nx) + (uint32_t)max((int)(by >> 4) - (int)nx, 0);
             entry = __builtin_amdgcn_perm(enc_hi, enc_lo, ns | kSelPad);
         }
         const uint32_t k2n = (k2 << 4) | entry;       // (bit 7 of the sum is set anyway: the nibble below was a state)
@@ -670,10 +910,37 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             pend = ended;
         }
         uint32_t s0v = PHILOX ? (uint32_t)(s0c >> (kEN * 4 * (k % kChunk))) & (IRR ? 0xFFu : 0xFu) : qv & (IRR ? 0xFFu : 0xFu);
-        if (!PHILOX && __builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
+        if constexpr (NRN) {
+            // this step's draws on the env stream: the normal that starts at position ep, then -- if the episode ended -- one word
+            uint32_t kind = (m0 >> 3) & 3u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(kind >= 2u) != 0, 0)) {
+                uint32_t guard = 0;
+                while (__builtin_amdgcn_ballot_w64(kind == 2u) != 0) {          // wedge point rejected: the draw starts over two words on
+                    const bool red = kind == 2u;
+                    ep += red ? 2u : 0u;
+                    uint32_t o0 = m0, o1 = m1, o2 = m2;
+                    double ox = xv;
+                    fetch();
+                    if (!red) { m0 = o0; m1 = o1; m2 = o2; xv = ox; }
+                    kind = (m0 >> 3) & 3u;
+                    if (++guard > 64u) { status |= kStatusInternal; break; }
+                }
+            }
+            uint32_t cntw = kind == 0u ? 1u : 2u, ssm = kind == 0u ? m1 : m2;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(kind == 3u) != 0, 0)) {   // tail: its words are counted in the high byte
+                const uint32_t tc = m0 >> 8;
+                ensure(kind == 3u ? ep + tc + 1u : ep);
+                if (kind == 3u) { cntw = tc; ssm = lds_meta[(ep + tc) & (uint32_t)(kXR - 1)][l]; }
+            }
+            lds_rx[k % KD][l] = xv;
+            s0v = (ssm & 7u) | 8u;
+            ep += cntw + (need ? 1u : 0u);
+            fetch();
+        }
+        if (!PHILOX && !NRN && __builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
             uint32_t spins = 0;
             while (__builtin_amdgcn_ballot_w64(need && (qv & 0xFu) == 0u) != 0) {
-                pull(0);
+                pull(-1);                                        // (the queue only: not the chunk's noise bytes)
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; qv |= 8u; break; }
             }
@@ -686,13 +953,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             s0v &= 0xFu;
         }
         k2 = need ? s0v : k2n;
-        if (!PHILOX) qv = need ? (qv >> (4 * kEN)) : qv;
+        if (!PHILOX && !NRN) qv = need ? (qv >> (4 * kEN)) : qv;
         if (HASMAX) cnt = need ? c0 : cnt;
         else last_reset = need ? (uint32_t)(k + 1) : last_reset;
         sel = (k2 & 7u) | kSelPad;
-        lds_rec[0][k % kDepth][l] = rec_a;
-        lds_rec[1][k % kDepth][l] = k2;
-        lds_rec[2][k % kDepth][l] = rc;
+        lds_rec[0][k % KD][l] = rec_a;
+        lds_rec[1][k % KD][l] = k2;
+        lds_rec[2][k % KD][l] = rc;
     };
 
     auto load_act = [&](int k) -> Act {
@@ -723,8 +990,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     const int nfull = K / kChunk;   // full chunks; a ragged tail (K % kChunk steps) follows the loop
     auto wait_room = [&](int kend) {                // do not run more than kDepth steps ahead of the O wave
-        if (kend > kDepth) {
-            const uint32_t must = (uint32_t)(kend - kDepth);
+        if (kend > KD) {
+            const uint32_t must = (uint32_t)(kend - KD);
             uint32_t spins = 0;
             for (;;) {
                 const uint64_t cc = __hip_atomic_load((const uint64_t *)&lds_cons[w][0], __ATOMIC_ACQUIRE,
@@ -749,6 +1016,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         pull(c);
 #pragma unroll
         for (int u = 0; u < kChunk; u++) stepE(colq[j & 1][u], kbase + u, (badq[j & 1] >> u) & 1u);
+        if (NRN) __hip_atomic_store(&lds_epos[l], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((l & 63) == 0) wg_store_rel(&lds_prod[w], (uint32_t)(kbase + kChunk));
     };
     // (single-exit loop body, no global load in an inner loop: the compiler then counts its vmcnt waits
@@ -785,8 +1053,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         hist = (hist << 8) | ((nb & 8u) ? (nb & 7u) : 0xFFu);
     }
     const uint32_t qc = (uint32_t)__builtin_popcount(qv & 0x00888888u);
-    const bool own_q = !PHILOX && !IRR && !nextmode;
-    if (!own_q && !PHILOX) {
+    const bool own_q = !PHILOX && !IRR && !nextmode && NZ == 0;
+    if (NRN) __hip_atomic_store(&lds_epos[l], ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (H un-draws what lies beyond)
+    if (!own_q && !PHILOX && !NRN) {
         // word 1 of the state is not a queue for these handles: what sits in the register queue goes back to the H
         // lane (it un-draws everything not taken)
         __hip_atomic_store(&lds_head[l], head_local - qc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -810,13 +1079,20 @@ bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *acti
     constexpr bool kNext = true;
     if (a.autoreset != MDPP_AUTORESET_NEXT_STEP) return false;
     const int nz = 0;
-#elif MDPP_LEAN_TU_NOISE
+#elif MDPP_LEAN_TU_NOISE == 1
 bool launch_discrete_lean_noise(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                                 float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                                 hipStream_t s, char *name_out) {
     constexpr bool kNext = false;
     const int nz = (a.has_p_noise ? 1 : 0) | (a.has_r_noise ? 2 : 0);
     if (nz == 0 || a.autoreset == MDPP_AUTORESET_NEXT_STEP || !a.philox || a.irr) return false;
+#elif MDPP_LEAN_TU_NOISE == 2
+bool launch_discrete_lean_npnoise(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                                  float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                                  hipStream_t s, char *name_out) {
+    constexpr bool kNext = false;
+    const int nz = (a.has_p_noise ? 1 : 0) | (a.has_r_noise ? 2 : 0);
+    if (nz == 0 || a.autoreset == MDPP_AUTORESET_NEXT_STEP || a.philox || a.irr) return false;
 #else
 bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                                float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
@@ -824,12 +1100,17 @@ bool launch_discrete_lean_next(const DiscreteArgs &a, int K, const int32_t *acti
 bool launch_discrete_lean_noise(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                                 float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                                 hipStream_t s, char *name_out);
+bool launch_discrete_lean_npnoise(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
+                                  float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
+                                  hipStream_t s, char *name_out);
 bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, void *obs,
                           float *reward, uint8_t *term, uint8_t *trunc, void *final_obs,
                           hipStream_t s, char *name_out) {
     constexpr bool kNext = false;
     if (a.autoreset == MDPP_AUTORESET_NEXT_STEP)
         return launch_discrete_lean_next(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    if ((a.has_p_noise || a.has_r_noise) && !a.philox)
+        return launch_discrete_lean_npnoise(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     if (a.has_p_noise || a.has_r_noise)
         return launch_discrete_lean_noise(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     const int nz = 0;
@@ -837,6 +1118,7 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
     const bool ph = a.philox != 0, irr = a.irr != 0;
     if (final_obs) return false;        // (rollouts of K >= 32 steps never ask for final observations: mdpp_step does, K = 1)
     const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? a.lean_next_ok != 0
+                       : (nz && !ph) ? a.shape_ok_noise_np != 0
                        : nz ? a.shape_ok_noise != 0
                        : irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
     if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
@@ -859,7 +1141,7 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
     }
 #if MDPP_LEAN_TU_NOISE
 #define MDPP_LEAN_GO(O64, DL, HM, EV, NZ_)                                                                   \
-    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, true, false, false, NZ_>), dim3(grid), dim3(kRoles * kBlock), \
+    hipLaunchKernelGGL((k_discrete_rollout_lean<O64, DL, HM, EV, MDPP_LEAN_TU_NOISE == 1, false, false, NZ_>), dim3(grid), dim3(kRoles * kBlock), \
                        0, s, a, K, actions, obs, reward, term, trunc, final_obs)
 #define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                                   \
     do {                                                                                                   \

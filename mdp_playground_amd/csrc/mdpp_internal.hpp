@@ -101,6 +101,13 @@ struct DiscreteArgs {
     uint32_t shape_ok_irr;      // the same shape with an irrelevant sub-space of at most 8 states (k_discrete_rollout_lean<IRR>)
     uint32_t shape_ok_noise;    // the lean shape (at most 8 states) with transition and / or reward noise on Philox streams (k_discrete_rollout_lean<..., NZ>)
     uint32_t lean_next_ok;      // ... with next-step autoreset (at most 8 states, with or without the irrelevant sub-space)
+    uint32_t shape_ok_noise_np; // the lean shape with transition and / or reward noise on NUMPY streams (k_discrete_rollout_lean<..., PHILOX=0, NZ>)
+    // transition noise on numpy streams, row-independent form of the S categoricals (:1604-1622): with m = r >> 11 the 53-bit
+    // draw, the state re-drawn around table entry n is  min(a, n) + max(b - n, 0),  a = #{j <= S - 2 : pn_TL[j] <= r},
+    // b = #{j <= S - 1 : pn_TU[j] <= r}  (thresholds pre-shifted by 11: compared with the 64-bit word itself).  Valid when
+    // ceil(cdf_n[j] 2^53) is the same for every row n > j (TL) and for every row n <= j (TU): checked on the host, else
+    // shape_ok_noise_np stays 0 and the general / quiet kernels search the row's own thresholds.
+    uint64_t pn_TL[8], pn_TU[8];
     uint32_t s_shift;           // log2(S) when S is a power of two, else 0xFFFFFFFF
     uint32_t key_mask;          // S^L - 1 (power-of-two S)
     uint32_t spow;              // S^(L-1)

@@ -51,63 +51,47 @@ struct Pcg64 {
 // state as four 32-bit limbs, the 128-bit product as six 32 x 32 -> 64 multiply-adds chained through their 64-bit
 // addends plus four low products -- 23 vector instructions and 8 for the output permutation, where the compiler's
 // expansion of the 64-bit arithmetic above takes 38 + 8 (it rebuilds every {x, 0} addend pair with moves and spends a
-// multiply-add on each).  Temporaries are fixed registers (v150-v157: an {x, 0} pair needs two consecutive registers
-// of which only the low one is rewritten, which a constraint cannot say); the generator role keeps < 40 registers live.
-struct Pcg64Limbs {
-    uint32_t s0, s1, s2, s3, i0, i1, i2, i3;
-    __device__ __forceinline__ void from(const Pcg64 &g) {
-        s0 = (uint32_t)g.s_lo; s1 = (uint32_t)(g.s_lo >> 32); s2 = (uint32_t)g.s_hi; s3 = (uint32_t)(g.s_hi >> 32);
-        i0 = (uint32_t)g.inc_lo; i1 = (uint32_t)(g.inc_lo >> 32); i2 = (uint32_t)g.inc_hi; i3 = (uint32_t)(g.inc_hi >> 32);
-    }
-    __device__ __forceinline__ void to(Pcg64 &g) const {
-        g.s_lo = ((uint64_t)s1 << 32) | s0; g.s_hi = ((uint64_t)s3 << 32) | s2;
-    }
-    __device__ __forceinline__ uint64_t next64() {
-        const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
-        uint32_t o0, o1, o2, o3;
-        // (gfx940+: a VALU instruction that reads VCC needs two wait states after the VALU instruction that wrote it --
-        //  the compiler pads its own code, inline assembly is not padded: the carry chain is interleaved with the
-        //  independent low products, s_nop where nothing is left to interleave)
-        asm volatile(
-            "v_mov_b32 v151, 0\n\t"
-            "v_mad_u64_u32 v[152:153], vcc, %[s0], %[m0], 0\n\t"            // p = s0 m0             (limb 0 = p.lo)
-            "v_mov_b32 v150, v153\n\t"
-            "v_mad_u64_u32 v[154:155], vcc, %[s0], %[m1], v[150:151]\n\t"   // q = s0 m1 + p.hi
-            "v_mov_b32 v150, v154\n\t"
-            "v_mad_u64_u32 v[156:157], vcc, %[s1], %[m0], v[150:151]\n\t"   // t = s1 m0 + q.lo      (limb 1 = t.lo)
-            "v_mov_b32 v150, v155\n\t"
-            "v_mad_u64_u32 v[154:155], vcc, %[s1], %[m1], v[150:151]\n\t"   // H = s1 m1 + q.hi
-            "v_add_co_u32 v154, vcc, v154, v157\n\t"                        //     + t.hi
-            "v_mul_lo_u32 v150, %[s0], %[m3]\n\t"
-            "v_mul_lo_u32 v157, %[s1], %[m2]\n\t"
-            "v_addc_co_u32 v155, vcc, 0, v155, vcc\n\t"
-            "v_mad_u64_u32 v[154:155], vcc, %[s0], %[m2], v[154:155]\n\t"   //     + s0 m2 + s2 m0   (mod 2^64)
-            "v_mad_u64_u32 v[154:155], vcc, %[s2], %[m0], v[154:155]\n\t"
-            "v_add3_u32 v155, v155, v150, v157\n\t"                         // limb 3 += lo(s0 m3 + s1 m2 + s2 m1 + s3 m0)
-            "v_add_co_u32 %[o0], vcc, v152, %[i0]\n\t"                      // + inc, carries through the four limbs
-            "v_mul_lo_u32 v150, %[s2], %[m1]\n\t"
-            "v_mul_lo_u32 v157, %[s3], %[m0]\n\t"
-            "v_addc_co_u32 %[o1], vcc, v156, %[i1], vcc\n\t"
-            "v_add3_u32 v155, v155, v150, v157\n\t"
-            "s_nop 0\n\t"
-            "v_addc_co_u32 %[o2], vcc, v154, %[i2], vcc\n\t"
-            "s_nop 1\n\t"
-            "v_addc_co_u32 %[o3], vcc, v155, %[i3], vcc\n\t"
-            : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3)
-            : [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
-              [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3)
-            : "vcc", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157");
-        s0 = o0; s1 = o1; s2 = o2; s3 = o3;
-        // XSL-RR: rotr64(hi ^ lo, hi >> 58) as a conditional swap of the halves (bit 5 of the count = the state's top
-        // bit) and two funnel shifts (v_alignbit_b32 takes the low five bits of the count)
-        const uint32_t xl = s0 ^ s2, xh = s1 ^ s3;
-        const bool sw = (int32_t)s3 < 0;
-        const uint32_t a = sw ? xh : xl, b = sw ? xl : xh;
-        const uint32_t rot = s3 >> 26;
-        const uint32_t ol = __builtin_amdgcn_alignbit(b, a, rot), oh = __builtin_amdgcn_alignbit(a, b, rot);
-        return ((uint64_t)oh << 32) | ol;
-    }
-};
+// multiply-add on each).  Temporaries are fixed registers (an {x, 0} pair needs two consecutive registers of which only the
+// low one is rewritten, which a constraint cannot say; the body is mdpp_pcg64_limbs.inc, included per register range);
+// the roles that use it keep few registers live.
+#define MDPP_LIMBS_NAME Pcg64Limbs       /* kernels of up to 768 threads (168 registers per lane) */
+#define MDPP_R_Z0 "150"
+#define MDPP_R_Z1 "151"
+#define MDPP_R_P0 "152"
+#define MDPP_R_P1 "153"
+#define MDPP_R_Q0 "154"
+#define MDPP_R_Q1 "155"
+#define MDPP_R_T0 "156"
+#define MDPP_R_T1 "157"
+#include "mdpp_pcg64_limbs.inc"
+#undef MDPP_LIMBS_NAME
+#undef MDPP_R_Z0
+#undef MDPP_R_Z1
+#undef MDPP_R_P0
+#undef MDPP_R_P1
+#undef MDPP_R_Q0
+#undef MDPP_R_Q1
+#undef MDPP_R_T0
+#undef MDPP_R_T1
+#define MDPP_LIMBS_NAME Pcg64LimbsLo     /* the 1024-thread role-split kernels (128 registers per lane) */
+#define MDPP_R_Z0 "112"
+#define MDPP_R_Z1 "113"
+#define MDPP_R_P0 "114"
+#define MDPP_R_P1 "115"
+#define MDPP_R_Q0 "116"
+#define MDPP_R_Q1 "117"
+#define MDPP_R_T0 "118"
+#define MDPP_R_T1 "119"
+#include "mdpp_pcg64_limbs.inc"
+#undef MDPP_LIMBS_NAME
+#undef MDPP_R_Z0
+#undef MDPP_R_Z1
+#undef MDPP_R_P0
+#undef MDPP_R_P1
+#undef MDPP_R_Q0
+#undef MDPP_R_Q1
+#undef MDPP_R_T0
+#undef MDPP_R_T1
 
 // numpy's pcg64_next32 buffers the high half of a 64-bit draw (has_uint32 / uinteger).
 struct Half32 {

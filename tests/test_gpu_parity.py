@@ -2268,7 +2268,12 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
 
 
 @pytest.mark.parametrize("workload,over,flag,N,F", [
-    ("cfg2_noise", {}, "NO_QUIET", 65536, 128),                      # noisy quiet kernel (two roles) vs general
+    ("cfg2_noise", {}, "NO_LEAN,NO_QUIET", 65536, 128),              # numpy streams: lean kernel with noise (H: both streams, by position) vs general
+    ("cfg2_noise", {}, "NO_LEAN", 65536, 128),                       # ... vs the noisy quiet kernel (two roles)
+    ("cfg2_noise", {"reward_noise": None, "max_episode_steps": 13}, "NO_LEAN", 32768, 128),          # transition noise only (start-state queue + noise bytes)
+    ("cfg2_noise", {"transition_noise": None, "reward_every_n_steps": 3, "delay": 0}, "NO_LEAN", 32768, 128),   # reward noise only
+    ("cfg2_noise", {"autoreset": "disabled", "terminal_state_density": 0.0}, "NO_LEAN,NO_QUIET", 32768, 128),   # (no resets: H still makes the noise)
+    ("cfg2_noise", {"transition_noise": 0.5}, "NO_QUIET", 32768, 128),   # (rows' thresholds differ: the lean kernel declines, quiet vs general)
     ("cfg2_irr", {"transition_noise": 0.1}, "NO_QUIET", 65536, 128),
     ("grid", {}, "NO_GFAST", 65536, 128),                            # int64 pairs: one 128-bit store per step
     ("grid", {"irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "NO_GFAST", 32768, 128),
