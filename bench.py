@@ -292,7 +292,7 @@ def action_rotation(wl, F, N, device, seed, min_total=512 << 20, min_n=4, max_n=
 
 # the other BASELINE.json configs (and cfg2 on the RNG north_star names), timed in the same run after the cfg2 leg
 EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5", "numpy"), ("cfg5", "philox"),
-              ("cfg2_noise", "philox"))        # (+ cfg2 with both noises on the north_star RNG: VERDICT r2 item 6)
+              ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"))   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
 
 
 def leg_name(workload, rng):

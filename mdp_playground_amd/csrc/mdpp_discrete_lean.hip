@@ -47,7 +47,7 @@
 //     words), then one word if the episode ended -- only E knows where a step's draws start.  H therefore evaluates
 //     EVERY position p of the stream as if a draw started there: meta[p] = {the start state word p would give a reset,
 //     kind: normal accepted at once / wedge point accepted (2 words) / wedge point rejected (2 words, the draw starts
-//     over) / tail (count in the high byte)} and x[p] = that draw's value, into 16-position rings per lane; the
+//     over) / tail (count in the high byte, the start state behind its words in bits 5-7)} and x[p] = that draw's value, into 16-position rings per lane; the
 //     ziggurat's slow path uses a COPY of the generator (its words are evaluated again as positions of their own).  E
 //     walks positions: reads meta[p], meta[p + 1], meta[p + 2] (fetched one step ahead), copies x[p] into the step's
 //     record for O1, and moves on by the draw's words (+ 1 if the episode ended); H runs up to 16 positions ahead of the
@@ -126,7 +126,7 @@ constexpr uint32_t kQueueCap = 6;
 constexpr int kHChunks = 8;               // Philox streams: H runs up to this many chunks ahead of E
 constexpr int kHChunksNp = 4;             // numpy transition noise: ... this many (LDS)
 constexpr int kXR = 16;                   // numpy reward noise: stream positions H evaluates ahead of E (per lane)
-constexpr int kXB = 4;                    // ... per batch (divides kXR)
+constexpr int kXB = 4;                    // ... per batch (divides kXR; 8 with kXR = 16 leaves E too little lead: 497 -> 586 us)
 constexpr int kDepthNp = 16;              // ... and the E->O ring depth of these instantiations (records carry the normal)
 constexpr int kRoles = 4;                 // E, O1 (reward path), O2 (observation / flag stores), H
 constexpr uint32_t kSelPad = 0x0c0c0c00u; // v_perm_b32 selector bytes 1-3: constant 0x00
@@ -206,9 +206,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // the transition-noise words), with RN the O1 wave (normals) -- and the E wave, now the shortest stage, last:
     // cfg2 128 -> 122 us per launch, + transition noise 195 -> 144, + reward noise 181 -> 167, both 227 -> 184
     // (profiles/r03_ablation_lean_priorities.txt).
-    constexpr int kPrioE = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_E : 1;
-    constexpr int kPrioO = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_O : (PN ? 2 : 3);
-    constexpr int kPrioH = (MDPP_LEAN_PRIO_FORCED || !PHILOX) ? MDPP_LEAN_PRIO_H : (PN ? 3 : 2);
+    // numpy streams with noise: H (both generators) is the long stage: E 3 O 2 H 0 -> 497 us per cfg2 + noise launch, E 2 O 1 H 3 -> 420
+    // (profiles/r04_ablation_npnoise.txt)
+    constexpr bool kNpNoise = !PHILOX && NZ != 0;
+    constexpr int kPrioE = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_E : kNpNoise ? 2 : !PHILOX ? MDPP_LEAN_PRIO_E : 1;
+    constexpr int kPrioO = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_O : kNpNoise ? 1 : !PHILOX ? MDPP_LEAN_PRIO_O : (PN ? 2 : 3);
+    constexpr int kPrioH = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_H : kNpNoise ? 3 : !PHILOX ? MDPP_LEAN_PRIO_H : (PN ? 3 : 2);
     static_assert(NZ == 0 || (!IRR && !NEXT), "noise on the lean kernel: one sub-space, same-step autoreset");
     __shared__ __align__(16) uint32_t lds_pn[(PN && PHILOX) ? kHChunks : 1][kBlock];       // H -> E: the chunk's 8 transition-noise nibbles
     // numpy streams (header): transition-noise bytes of a chunk; per stream position the draw's value and {start state, kind, words}
@@ -217,6 +220,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ uint16_t lds_meta[NRN ? kXR : 1][kBlock];
     __shared__ __align__(16) double lds_rx[NRN ? KD : 1][kBlock];      // E -> O1: the step's normal
     __shared__ uint32_t lds_hhead[NRN ? kBlock : 1], lds_epos[NRN ? kBlock : 1];   // positions made by H / reached by E
+    // the two categorical searches of H by the word's top bits: byte = the answer where the bucket holds no threshold, 0xFF
+    // where it does (then the thresholds are counted: a few lanes per thousand)
+    __shared__ uint8_t lds_sstab[(NRN || NPN) ? 2048 : 1];            // start state by r >> 53
+    __shared__ uint8_t lds_pntab[NPN ? 4096 : 1];                     // a | b << 4 by r >> 52
     __shared__ ulonglong2 lds_kw[NRN ? 256 : 1];                       // ziggurat {ki, wi}
     __shared__ double lds_fi[NRN ? 256 : 1];
     constexpr int kEN = IRR ? 2 : 1;                // nibbles per start-state entry (relevant, irrelevant)
@@ -260,6 +267,26 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         lds_R[k] = wd;
     }
     if (tid < kBlock) { lds_ring[tid] = 0; lds_head[tid] = 0; if (NRN) { lds_hhead[tid] = 0; lds_epos[tid] = 0; } }
+    if (NRN || NPN) {
+        for (uint32_t k = tid; k < 2048u; k += kRoles * kBlock) {
+            const uint64_t lo = (uint64_t)k << 53, hi = lo + ((1ULL << 53) - 1ULL);       // the bucket's words
+            uint32_t c0 = 0, c1 = 0;
+            for (int j = 0; j < 8; j++) {
+                const uint64_t t = a.init_thr[j] > (1ULL << 53) - 1ULL ? ~0ULL : a.init_thr[j] << 11;
+                c0 += (t <= lo) ? 1u : 0u; c1 += (t <= hi) ? 1u : 0u;
+            }
+            lds_sstab[k] = (uint8_t)(c0 == c1 ? c0 : 0xFFu);
+        }
+    }
+    if (NPN) {
+        for (uint32_t k = tid; k < 4096u; k += kRoles * kBlock) {
+            const uint64_t lo = (uint64_t)k << 52, hi = lo + ((1ULL << 52) - 1ULL);
+            uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            for (int j = 0; j < 7; j++) { a0 += (a.pn_TL[j] <= lo) ? 1u : 0u; a1 += (a.pn_TL[j] <= hi) ? 1u : 0u; }
+            for (int j = 0; j < 8; j++) { b0 += (a.pn_TU[j] <= lo) ? 1u : 0u; b1 += (a.pn_TU[j] <= hi) ? 1u : 0u; }
+            lds_pntab[k] = (uint8_t)((a0 == a1 && b0 == b1) ? (a0 | (b0 << 4)) : 0xFFu);
+        }
+    }
     if (NRN)
         for (int k = tid; k < 256; k += kRoles * kBlock) { lds_kw[k] = make_ulonglong2(d_zig_ki[k], (unsigned long long)__double_as_longlong(d_zig_wi[k])); lds_fi[k] = d_zig_fi[k]; }
     if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; }
@@ -391,13 +418,23 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const int nch = (K + kChunk - 1) / kChunk;
             int c = 0;                              // transition-noise chunks made
             uint32_t hq = 0;                        // RN: positions made
+            uint64_t look = 0;                      // RN: the word of position hq (the generator runs one word ahead)
+            if (NRN) look = ge.next64();
             uint32_t vals = 0, tail = 0, spins = 0; // !RN: the start-state queue (as on quiet handles)
             // start state of a reset whose word is r: #{j : ceil(cdf[j] 2^53) <= r >> 11}
             auto start_of = [&](uint64_t r) __attribute__((always_inline)) -> uint32_t {
-                const uint64_t m = r >> 11;
-                uint32_t s0 = 0;
+#ifdef MDPP_ABL_NP_NOSS
+                return (uint32_t)(r >> 61) % 6u;
+#endif
+                uint32_t s0 = lds_sstab[(uint32_t)(r >> 53)];
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(s0 == 0xFFu) != 0, 0)) {
+                    if (s0 == 0xFFu) {
+                        const uint64_t m = r >> 11;
+                        s0 = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) s0 += (a.init_thr[j] <= m) ? 1u : 0u;
+                        for (int j = 0; j < 8; j++) s0 += (a.init_thr[j] <= m) ? 1u : 0u;
+                    }
+                }
                 return s0;
             };
             for (;;) {
@@ -409,12 +446,21 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #pragma unroll
                         for (int u = 0; u < kChunk; u++) {
                             const uint64_t r = gs.next64();
-                            uint32_t na = 0, nb = 0;
+                            uint32_t by = lds_pntab[(uint32_t)(r >> 52)];
+#ifdef MDPP_ABL_NP_NOPNC
+                            by = 7u | ((uint32_t)(r >> 63) << 4);
+#endif
+                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(by == 0xFFu) != 0, 0)) {
+                                if (by == 0xFFu) {
+                                    uint32_t na = 0, nb = 0;
 #pragma unroll
-                            for (int j = 0; j < 7; j++) na += (a.pn_TL[j] <= r) ? 1u : 0u;
+                                    for (int j = 0; j < 7; j++) na += (a.pn_TL[j] <= r) ? 1u : 0u;
 #pragma unroll
-                            for (int j = 0; j < 8; j++) nb += (a.pn_TU[j] <= r) ? 1u : 0u;
-                            pk[u >> 2] |= (na | (nb << 4)) << (8 * (u & 3));
+                                    for (int j = 0; j < 8; j++) nb += (a.pn_TU[j] <= r) ? 1u : 0u;
+                                    by = na | (nb << 4);
+                                }
+                            }
+                            pk[u >> 2] |= by << (8 * (u & 3));
                         }
                         lds_pn2[c % kHChunksNp][0][l] = pk[0];
                         lds_pn2[c % kHChunksNp][1][l] = pk[1];
@@ -427,64 +473,85 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     const uint32_t epos = __hip_atomic_load(&lds_epos[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const bool go = hq + (uint32_t)kXB <= epos + (uint32_t)kXR;
                     if (__builtin_amdgcn_ballot_w64(go) != 0) {
+                        // The generator runs ONE word ahead (`look` = the word of position hq): the uniform a wedge point of
+                        // position p takes is word p + 1, which the batch has in hand -- no copy of the generator, no saved states
                         uint32_t rej = 0;
-                        uint64_t wdv[kXB];
-                        uint32_t sv[kXB][4];
+                        uint64_t wdv[kXB + 1];
                         if (go) {
+                            wdv[0] = look;
 #pragma unroll
                             for (int u = 0; u < kXB; u++) {
-                                const uint64_t wd = ge.next64();
-                                wdv[u] = wd;
-                                sv[u][0] = ge.s0; sv[u][1] = ge.s1; sv[u][2] = ge.s2; sv[u][3] = ge.s3;
+                                const uint64_t wd = wdv[u];
+                                wdv[u + 1] = ge.next64();
                                 const ulonglong2 kw = lds_kw[(uint32_t)wd & 0xffu];
                                 const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
                                 const double t = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
                                 const double x = t * __longlong_as_double((long long)kw.y);
                                 const double xs = __longlong_as_double((long long)((uint64_t)__double_as_longlong(x) ^
                                                                                      ((uint64_t)((uint32_t)wd & 0x100u) << 55)));
+#ifdef MDPP_ABL_NP_NOSLOW
+                                const bool ok = rabs < kw.x + 0x7fffffffffffffffULL;
+#else
                                 const bool ok = rabs < kw.x;
+#endif
                                 rej |= ok ? 0u : (1u << u);
                                 const uint32_t slot = (hq + (uint32_t)u) & (uint32_t)(kXR - 1);
                                 lds_x[slot][l] = xs;
                                 lds_meta[slot][l] = (uint16_t)(start_of(wd) | (ok ? 0u : (2u << 3)));   // (rejected: patched below)
                             }
+                            look = wdv[kXB];
                         }
-                        // the ziggurat's slow path for the rejected words of the batch, on a copy of the generator
+                        // the ziggurat's slow path for the rejected words of the batch
                         while (__builtin_amdgcn_ballot_w64(rej != 0u) != 0) {
                             if (rej != 0u) {
                                 const uint32_t j = (uint32_t)__builtin_ctz(rej);
                                 rej &= rej - 1u;
-                                Pcg64LimbsLo t = ge;
-                                uint64_t wd = 0;
+                                uint64_t wd = 0, wn = 0;            // the rejected word and the one behind it
 #pragma unroll
                                 for (int u = 0; u < kXB; u++)
-                                    if (j == (uint32_t)u) { t.s0 = sv[u][0]; t.s1 = sv[u][1]; t.s2 = sv[u][2]; t.s3 = sv[u][3]; wd = wdv[u]; }
+                                    if (j == (uint32_t)u) { wd = wdv[u]; wn = wdv[u + 1]; }
                                 const uint32_t idx = (uint32_t)wd & 0xffu;
                                 const uint32_t slot = (hq + j) & (uint32_t)(kXR - 1);
                                 const uint32_t ss = lds_meta[slot][l] & 7u;
-                                if (idx == 0u) {            // tail: two uniforms per try (np_zig_tail)
+                                if (__builtin_expect(idx == 0u, 0)) {   // tail: two uniforms per try (np_zig_tail), 3 in 10^4 draws
                                     const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
-                                    uint32_t cnt = 1u;
+                                    // its words: what the batch still holds behind position j, then a copy of the generator
+                                    Pcg64LimbsLo t = ge;
+                                    uint32_t have = (uint32_t)kXB - j, cnt = 1u;
+                                    auto word = [&]() -> uint64_t {
+                                        uint64_t r = 0;
+                                        if (have != 0u) {
+#pragma unroll
+                                            for (int u = 1; u <= kXB; u++) if ((uint32_t)kXB - have + 1u == (uint32_t)u) r = wdv[u];
+                                            have -= 1u;
+                                        } else {
+                                            r = t.next64();
+                                        }
+                                        cnt += 1u;
+                                        return r;
+                                    };
                                     double val = 0.0;
                                     for (;;) {
-                                        const double u1 = (double)(t.next64() >> 11) * (1.0 / 9007199254740992.0);
-                                        const double u2 = (double)(t.next64() >> 11) * (1.0 / 9007199254740992.0);
-                                        cnt += 2u;
+                                        const double u1 = (double)(word() >> 11) * (1.0 / 9007199254740992.0);
+                                        const double u2 = (double)(word() >> 11) * (1.0 / 9007199254740992.0);
                                         const double xx = -nor_inv_r * log1p(-u1);
                                         const double yy = -log1p(-u2);
                                         if (yy + yy > xx * xx) { val = ((wd >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx; break; }
                                         if (cnt > 250u) { status |= kStatusInternal; break; }
                                     }
                                     lds_x[slot][l] = val;
-                                    lds_meta[slot][l] = (uint16_t)(ss | (3u << 3) | (cnt << 8));
+                                    // (bits 5-7: the start state of the word BEHIND the tail's words -- E must not have to
+                                    //  find it in the ring, a long tail reaches beyond the window H keeps ahead of E)
+                                    const uint32_t words = cnt, ssb = start_of(word());
+                                    lds_meta[slot][l] = (uint16_t)(ss | (3u << 3) | (ssb << 5) | (words << 8));
                                 } else {                    // wedge: one uniform; a rejected point starts the draw over two words on
                                     const double x = lds_x[slot][l];
-                                    const double u1 = (double)(t.next64() >> 11) * (1.0 / 9007199254740992.0);
+                                    const double u1 = (double)(wn >> 11) * (1.0 / 9007199254740992.0);
                                     const double y = (lds_fi[idx - 1] - lds_fi[idx]) * u1 + lds_fi[idx];
                                     // exp(-x^2 / 2) by a float32 estimate (relative error < 2e-6); float64 exp() within 1e-5 of it
                                     const double e = (double)__builtin_amdgcn_exp2f((float)(x * x * -0.72134752044448170368));
                                     bool acc = y < e;
-                                    if (!(fabs(y - e) > 1.0e-5 * e)) acc = y < exp(-0.5 * x * x);
+                                    if (__builtin_expect(!(fabs(y - e) > 1.0e-5 * e), 0)) acc = y < exp(-0.5 * x * x);
                                     lds_meta[slot][l] = (uint16_t)(ss | ((acc ? 1u : 2u) << 3));
                                 }
                             }
@@ -531,7 +598,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 }
             };
             ge.to(g);
-            if (NRN) undraw(g, hq - __hip_atomic_load(&lds_epos[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (NRN) undraw(g, hq + 1u - __hip_atomic_load(&lds_epos[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // (+ the word in hand)
             else undraw(g, tail - wg_load_acq(&lds_head[l]));
             g.store(a.env_s, i);
             if (PN) {
@@ -927,14 +994,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 }
             }
             uint32_t cntw = kind == 0u ? 1u : 2u, ssm = kind == 0u ? m1 : m2;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(kind == 3u) != 0, 0)) {   // tail: its words are counted in the high byte
-                const uint32_t tc = m0 >> 8;
-                ensure(kind == 3u ? ep + tc + 1u : ep);
-                if (kind == 3u) { cntw = tc; ssm = lds_meta[(ep + tc) & (uint32_t)(kXR - 1)][l]; }
-            }
+            // tail: its words are counted in the high byte, the start state of the word behind them is in bits 5-7
+            if (kind == 3u) { cntw = m0 >> 8; ssm = m0 >> 5; }
             lds_rx[k % KD][l] = xv;
             s0v = (ssm & 7u) | 8u;
             ep += cntw + (need ? 1u : 0u);
+            __hip_atomic_store(&lds_epos[l], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (H's window follows E)
             fetch();
         }
         if (!PHILOX && !NRN && __builtin_expect(__builtin_amdgcn_ballot_w64(need && s0v == 0u) != 0, 0)) {
@@ -1163,8 +1228,13 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
 #endif
 #define MDPP_LEAN_L3(O64, DL, HM) do { if (evn) MDPP_LEAN_LAUNCH(O64, DL, HM, true); else MDPP_LEAN_LAUNCH(O64, DL, HM, false); } while (0)
 #define MDPP_LEAN_L2(O64, DL) do { if (hm) MDPP_LEAN_L3(O64, DL, true); else MDPP_LEAN_L3(O64, DL, false); } while (0)
+#ifdef MDPP_LEAN_SHAPES_MIN       // (ablation builds: the bench shape only)
+    if (a.obs_i32 || !dl || hm || !evn) return false;
+    MDPP_LEAN_LAUNCH(true, true, false, true);
+#else
     if (a.obs_i32) { if (dl) MDPP_LEAN_L2(false, true); else MDPP_LEAN_L2(false, false); }
     else { if (dl) MDPP_LEAN_L2(true, true); else MDPP_LEAN_L2(true, false); }
+#endif
 #undef MDPP_LEAN_GO
 #undef MDPP_LEAN_L2
 #undef MDPP_LEAN_L3
