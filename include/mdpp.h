@@ -273,11 +273,21 @@ int mdpp_set_line_history(mdpp_env *h, const float *hist_host);
  * launch by value (ring head = counter mod delay for delay lines kept in memory; Philox keys), so a captured
  * launch replays with the counter it was captured with.
  * mdpp_graph_replay_exact: 1 when a graph of K captured mdpp_step launches replays exactly for this handle
- * (numpy streams, and either no delay line in memory or K a multiple of the delay), 0 when it does not, < 0 on error.
+ * (numpy streams, and either no delay line in memory or K a multiple of the delay), 2 when it does through the
+ * device-side offset below, 0 when it does not (image observations with such a counter dependence), < 0 on error.
  * mdpp_tick: adds `advance` (may be negative) to the step counter and returns the new value in *tick_out (may be
  * NULL): the capture advances the counter although nothing ran (take it back with -K), a replay runs K steps the
  * counter has not seen (add K). */
 int mdpp_graph_replay_exact(mdpp_env *h, int K);
+/* ABI 7 -- graphs that replay exactly for EVERY handle without image observations (Philox streams, any delay line):
+ * mdpp_graph_replay_exact returns 2 where a by-value capture would not be exact but this protocol is:
+ *   mdpp_graph_capture(h, 1);  capture the K mdpp_step launches;  mdpp_graph_capture(h, 0);  mdpp_tick(h, -K, NULL);
+ *   per replay:  mdpp_graph_set_tick_offset(h, counter_now - counter_at_capture, stream);  launch the graph on `stream`;
+ *                mdpp_tick(h, K, NULL).
+ * Launches made in capture mode add the device word that mdpp_graph_set_tick_offset writes to the step counter they
+ * were captured with (ring head of a delay line in memory, Philox keys), first thing in the kernel. */
+int mdpp_graph_capture(mdpp_env *h, int on);
+int mdpp_graph_set_tick_offset(mdpp_env *h, int64_t offset, void *stream);
 int mdpp_tick(mdpp_env *h, int64_t advance, uint64_t *tick_out);
 
 /* MDPP_AUTORESET_NEXT_STEP: the per-env flag "the episode ended on the previous call, the next call is the reset"

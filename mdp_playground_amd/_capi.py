@@ -30,7 +30,7 @@ EXPORTS = [
     "mdpp_upload_discrete_irrelevant", "mdpp_get_state_irrelevant", "mdpp_set_state_irrelevant",
     "mdpp_get_state_grid", "mdpp_set_state_grid", "mdpp_upload_image_disc", "mdpp_upload_image_lines",
     "mdpp_set_options", "mdpp_kernel_name", "mdpp_philox_normals",
-    "mdpp_graph_replay_exact", "mdpp_tick", "mdpp_get_reset_pending", "mdpp_set_reset_pending",
+    "mdpp_graph_replay_exact", "mdpp_graph_capture", "mdpp_graph_set_tick_offset", "mdpp_tick", "mdpp_get_reset_pending", "mdpp_set_reset_pending",
     "mdpp_get_episode_stats", "mdpp_get_line_history", "mdpp_set_line_history",
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
@@ -132,6 +132,8 @@ def load():
     L.mdpp_kernel_name.argtypes = [vp, i32]
     L.mdpp_kernel_name.restype = C.c_char_p
     L.mdpp_graph_replay_exact.argtypes = [vp, i32]
+    L.mdpp_graph_capture.argtypes = [vp, i32]
+    L.mdpp_graph_set_tick_offset.argtypes = [vp, C.c_int64, vp]
     L.mdpp_tick.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
     L.mdpp_get_episode_stats.argtypes = [vp, vp, vp]
     L.mdpp_get_line_history.argtypes = [vp, vp]

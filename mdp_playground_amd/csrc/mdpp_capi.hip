@@ -52,7 +52,7 @@ static void free_all(mdpp_env *h) {
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last};
+                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -106,6 +106,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_est_cur = h->d_est_last = nullptr; h->est_nk = 0;
     h->irr_ready = false;
     h->line_hist_stale = false;
+    h->graph_capture = false;
+    h->d_tick_off = nullptr;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
     // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
@@ -134,6 +136,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     TRYHIP(hipEventCreate(&h->ev0));
     TRYHIP(hipEventCreate(&h->ev1));
     TRY(alloc_zero(h, &h->d_status, N * sizeof(uint32_t)));
+    TRY(alloc_zero(h, &h->d_tick_off, sizeof(uint64_t)));
     if (cfg->episode_stats) {       // per-episode noise statistics (EpisodeStatsDev): running episode + the one a reset() ended
         h->est_nk = 3 + (cfg->kind == MDPP_KIND_CONTINUOUS ? cfg->D : 0);
         TRY(alloc_zero(h, &h->d_est_cur, (size_t)h->est_nk * N * sizeof(double)));
@@ -691,12 +694,37 @@ extern "C" int mdpp_get_episode_stats(mdpp_env *h, double *current, double *last
 // captured with.
 extern "C" int mdpp_graph_replay_exact(mdpp_env *h, int K) {
     if (!h || K < 1) return MDPP_EINVAL;
-    if (h->cfg.rng_mode == MDPP_RNG_PHILOX) return 0;             // every replay would re-draw the same noise and resets
     const int d = h->cfg.delay;
     const bool ring_in_memory = d > 0 && (h->cfg.kind == MDPP_KIND_CONTINUOUS ||
                                           (h->cfg.kind == MDPP_KIND_DISCRETE && !h->cfg.unit_rewards));
-    if (ring_in_memory && K % d != 0) return 0;                   // replay r would start at ring slot (tick0 + r K) mod delay
-    return 1;
+    // by value: numpy streams (a Philox key would repeat), and no ring head that moves between replays
+    if (h->cfg.rng_mode != MDPP_RNG_PHILOX && !(ring_in_memory && K % d != 0)) return 1;
+    // otherwise: through the device-side offset (mdpp_graph_capture / mdpp_graph_set_tick_offset) -- every step and rollout
+    // kernel reads it; the image pipelines (their draw kernels take the counter by value, side streams) do not
+    return h->cfg.image ? 0 : 2;
+}
+
+namespace mdpp {
+__global__ void k_set_tick_offset(uint64_t *p, uint64_t v) { *p = v; }
+}
+
+// Capture mode: launches made while it is on carry a pointer to the handle's device word `tick offset` and add it to
+// the step counter they were given by value (mdpp_internal.hpp tick_from_device).
+extern "C" int mdpp_graph_capture(mdpp_env *h, int on) {
+    if (!h) return MDPP_EINVAL;
+    if (on && h->cfg.image) return fail(h, MDPP_EUNSUPPORTED, "mdpp_graph_capture: handles with image observations take the step counter by value");
+    h->graph_capture = on != 0;
+    return MDPP_OK;
+}
+
+// offset = (step counter now) - (step counter when the graph was captured), enqueued on `stream` BEFORE the graph launch.
+extern "C" int mdpp_graph_set_tick_offset(mdpp_env *h, int64_t offset, void *stream) {
+    if (!h || !h->d_tick_off) return MDPP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(mdpp::k_set_tick_offset, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint64_t *)h->d_tick_off, (uint64_t)offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("k_set_tick_offset: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    return MDPP_OK;
 }
 
 extern "C" int mdpp_tick(mdpp_env *h, int64_t advance, uint64_t *tick_out) {
@@ -1344,22 +1372,35 @@ extern "C" int mdpp_timer_end(mdpp_env *h, void *stream, float *ms) {
 // 16 bytes per lane, grid-stride, 8 workgroups of 256 lanes per CU: the float4 copy MI355X_MICROARCH.md measures at
 // 6.29 TB/s, a fill and a read of the same shape.
 namespace mdpp {
-__global__ __launch_bounds__(256) void k_probe_copy(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
-}
-__global__ __launch_bounds__(256) void k_probe_fill(uint4 *__restrict__ d, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const uint4 v = make_uint4(threadIdx.x, blockIdx.x, 3u, 4u);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
-}
-__global__ __launch_bounds__(256) void k_probe_read(const uint4 *__restrict__ s, size_t n, uint32_t *out) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    uint32_t acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint4 v = s[i];
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+typedef unsigned int pu4 __attribute__((ext_vector_type(4)));
+// (a workgroup takes contiguous 16 KiB tiles -- four 16-byte pieces per lane, 4 KiB apart -- tile after tile, grid-stride)
+__global__ __launch_bounds__(256) void k_probe_copy(const pu4 *__restrict__ s, pu4 *__restrict__ d, size_t n) {
+    const size_t ntile = n / 1024;
+    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const size_t i = t * 1024 + threadIdx.x;
+        const pu4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+        d[i] = a; d[i + 256] = b; d[i + 512] = c; d[i + 768] = e;
     }
+    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void k_probe_fill(pu4 *__restrict__ d, size_t n) {
+    const pu4 v = pu4{threadIdx.x, blockIdx.x, 3u, 4u};
+    const size_t ntile = n / 1024;
+    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const size_t i = t * 1024 + threadIdx.x;
+        d[i] = v; d[i + 256] = v; d[i + 512] = v; d[i + 768] = v;
+    }
+    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = v;
+}
+__global__ __launch_bounds__(256) void k_probe_read(const pu4 *__restrict__ s, size_t n, uint32_t *out) {
+    uint32_t acc = 0;
+    const size_t ntile = n / 1024;
+    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const size_t i = t * 1024 + threadIdx.x;
+        const pu4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ e.x ^ e.y ^ e.z ^ e.w;
+    }
+    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const pu4 v = s[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     if (acc == 0x12345u) out[0] = acc;          // (keeps the loads alive)
 }
 } // namespace mdpp
@@ -1376,9 +1417,9 @@ extern "C" int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MDPP_EHIP;
     auto launch = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(mdpp::k_probe_copy, grid, block, 0, s, (const uint4 *)src_dev, (uint4 *)dst_dev, n);
-        else if (mode == 1) hipLaunchKernelGGL(mdpp::k_probe_fill, grid, block, 0, s, (uint4 *)dst_dev, n);
-        else hipLaunchKernelGGL(mdpp::k_probe_read, grid, block, 0, s, (const uint4 *)src_dev, n, (uint32_t *)dst_dev);
+        if (mode == 0) hipLaunchKernelGGL(mdpp::k_probe_copy, grid, block, 0, s, (const mdpp::pu4 *)src_dev, (mdpp::pu4 *)dst_dev, n);
+        else if (mode == 1) hipLaunchKernelGGL(mdpp::k_probe_fill, grid, block, 0, s, (mdpp::pu4 *)dst_dev, n);
+        else hipLaunchKernelGGL(mdpp::k_probe_read, grid, block, 0, s, (const mdpp::pu4 *)src_dev, n, (uint32_t *)dst_dev);
     };
     for (int w = 0; w < 2; w++) launch();
     int rc = MDPP_OK;

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
                                                             uint8_t *__restrict__ term,
                                                             uint8_t *__restrict__ trunc,
                                                             float *__restrict__ final_obs) {
+    tick_from_device(a);
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     __shared__ double s_z[DMAX * kBlock];                    // this step's transition-noise normals, [d][lane]
@@ -812,6 +813,7 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
     ContinuousArgs a = h->cargs;
     a.opts = h->opts;
     a.ptick = h->tick;
+    a.dtick = h->graph_capture ? (const uint64_t *)h->d_tick_off : nullptr;     // (launches being captured into a HIP graph)
     a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     if (a.fast_ok) {
         // common shape: dedicated rollout kernel (mdpp_continuous_fast.hip); its buffer descriptors

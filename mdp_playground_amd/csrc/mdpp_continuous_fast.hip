@@ -126,6 +126,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                                                                     uint8_t *__restrict__ term,
                                                                     uint8_t *__restrict__ trunc,
                                                                     float *__restrict__ final_obs) {
+    tick_from_device(a);
     static_assert(D % 4 == 0 || D == 2, "D must be 2 or a multiple of 4");
     constexpr bool ZIG = NOISE && !PHILOX;      // numpy's ziggurat tables in LDS
     constexpr bool WALK = HELPER && !PHILOX && NPROD == 2;

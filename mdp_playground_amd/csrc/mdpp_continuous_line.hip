@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_line_rollout(ContinuousAr
                                                                     uint8_t *__restrict__ term,
                                                                     uint8_t *__restrict__ trunc,
                                                                     float *__restrict__ final_obs) {
+    tick_from_device(a);
     static_assert(D == 2 || D == 4, "every dimension relevant: 2 or 4");
     extern __shared__ __align__(16) float4 s_pts[];            // [L][kBlock]
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                                                           uint8_t *__restrict__ term,
                                                           uint8_t *__restrict__ trunc,
                                                           void *__restrict__ final_obs) {
+    tick_from_device(a);
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ uint64_t s_ki[NOISE ? 256 : 1];
     __shared__ double s_wi[NOISE ? 256 : 1], s_fi[NOISE ? 256 : 1];
@@ -423,6 +424,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
     if (h->cfg.image) a.opts |= MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN;
 #endif
     a.ptick = h->tick;
+    a.dtick = h->graph_capture ? (const uint64_t *)h->d_tick_off : nullptr;     // (launches being captured into a HIP graph)
     a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // Philox handles of the common shape: k_discrete_rollout_lean with its H waves on Philox blocks

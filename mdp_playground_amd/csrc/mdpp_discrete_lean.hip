@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                                                                       uint8_t *__restrict__ term,
                                                                       uint8_t *__restrict__ trunc,
                                                                       void *__restrict__ final_obs) {
+    tick_from_device(a);
     // E -> O, three dwords per env step in ONE array (constant 32 KB apart: two of them go out as one ds_write2st64):
     //   A history before a reset   B history after it   C byte 0: the column entry (bit 7 terminated), byte 1 the
     //   irrelevant observation, byte 2 truncated

@@ -87,6 +87,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                                                                    void *__restrict__ obs, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                                    void *__restrict__ final_obs) {
+    tick_from_device(a);
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __align__(16) unsigned char lds[];

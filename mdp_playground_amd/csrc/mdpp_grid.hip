@@ -43,6 +43,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
                                                       void *__restrict__ obs, float *__restrict__ reward,
                                                       uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                       void *__restrict__ final_obs) {
+    tick_from_device(a);
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     if (NOISE && a.has_r_noise) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
                                                               void *__restrict__ obs, float *__restrict__ reward,
                                                               uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                               void *__restrict__ final_obs) {
+    tick_from_device(a);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -485,6 +487,7 @@ int launch_grid_step(mdpp_env *h, int K, const int32_t *actions, void *obs, floa
     GridArgs a = h->gargs;
     a.opts = h->opts;
     a.ptick = h->tick;
+    a.dtick = h->graph_capture ? (const uint64_t *)h->d_tick_off : nullptr;     // (launches being captured into a HIP graph)
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool noise = a.has_p_noise || a.has_r_noise;
     // quiet numpy-stream handles: the fused rollout kernel (< 4 GiB per output array per launch)

@@ -67,6 +67,7 @@ struct DiscreteArgs {
     uint32_t nkeys;             // S^L
     uint32_t tick;              // head of the delay ring at this launch: env steps taken so far mod delay
     uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)
+    const uint64_t *dtick;      // launches captured into a HIP graph: device word added to ptick at run time (tick_from_device)
     uint32_t opts;              // MDPP_OPT_* (host side: kernel selection only)
     uint64_t philox_seed;
     int64_t env_id_offset;
@@ -123,6 +124,7 @@ struct ContinuousArgs {
     int32_t autoreset, max_steps, philox, n_boxes, rel_prefix;
     uint32_t tick;              // head of the delay ring at this launch: env steps taken so far mod delay
     uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)
+    const uint64_t *dtick;      // launches captured into a HIP graph: device word added to ptick at run time (tick_from_device)
     uint32_t opts;              // MDPP_OPT_* (host side: kernel selection only)
     uint64_t philox_seed;
     int64_t env_id_offset;
@@ -164,6 +166,17 @@ struct ContinuousArgs {
     double inv_fact[MDPP_MAX_ORDER + 1];
 };
 
+// A launch captured into a HIP graph replays with the argument values it was captured with -- the step counter among
+// them (Philox keys; the head of a delay line kept in memory).  In capture mode (mdpp_graph_capture) the launches carry a
+// pointer to a device word instead: the difference between the counter NOW and the counter at capture, written by
+// mdpp_graph_set_tick_offset before a replay; every step / rollout kernel adds it first thing (wave-uniform scalar load).
+__device__ __forceinline__ void tick_from_device(DiscreteArgs &a) {
+    if (a.dtick) { a.ptick += *a.dtick; a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u; }
+}
+__device__ __forceinline__ void tick_from_device(ContinuousArgs &a) {
+    if (a.dtick) { a.ptick += *a.dtick; a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u; }
+}
+
 // ---- grid (mdpp_grid.hip) ----
 struct GridArgs {
     int32_t N, G;               // envs; state dimensions (2 or 4)
@@ -171,6 +184,7 @@ struct GridArgs {
     int32_t make_denser, has_p_noise, has_r_noise, every_n;
     int32_t autoreset, max_steps, obs_i32, philox;
     uint64_t ptick;             // env steps taken by this handle before this launch (Philox counter)
+    const uint64_t *dtick;      // launches captured into a HIP graph: device word added to ptick at run time (tick_from_device)
     uint32_t opts;              // MDPP_OPT_* (host side: kernel selection only)
     uint64_t philox_seed;
     int64_t env_id_offset;
@@ -182,6 +196,10 @@ struct GridArgs {
     uint32_t *status;
     EpisodeStatsDev est;
 };
+
+__device__ __forceinline__ void tick_from_device(GridArgs &a) {
+    if (a.dtick) a.ptick += *a.dtick;
+}
 
 } // namespace mdpp
 
@@ -203,6 +221,8 @@ struct mdpp_env {
     int32_t est_nk;
     void *d_P1, *d_init_cdf1, *d_noise_cdf1, *d_irr_state;   // irrelevant sub-space
     bool irr_ready;
+    bool graph_capture;         // mdpp_graph_capture(h, 1): launches take the step counter's offset from d_tick_off
+    void *d_tick_off;           // uint64: counter now - counter at capture (mdpp_graph_set_tick_offset)
     bool line_hist_stale;       // move_along_a_line: set_state_continuous restored the step counters, the fit's window not yet
     void *d_sd, *d_cur, *d_meta;
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;

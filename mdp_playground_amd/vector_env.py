@@ -461,19 +461,21 @@ class RLToyVectorEnv:
         steps with them.  Returns a StepGraph with .replay() and the output buffers
         .obs/.reward/.terminated/.truncated ([K, N, ...]).
 
-        The handle's step counter travels BY VALUE into the captured launches (include/mdpp.h), so only handles
-        for which a replay is exact are accepted: numpy streams, and a delay line that is either kept in the
-        state record (discrete unit rewards) or whose length divides K.  Anything else raises MdppError
-        (Philox keys would repeat; the ring head of a delay line in memory would be the captured one)."""
+        The handle's step counter travels BY VALUE into captured launches (include/mdpp.h).  Where that would not replay
+        exactly -- Philox streams key their draws by the counter, a delay line kept in memory starts at counter mod delay --
+        the launches are captured in the library's capture mode instead: they add a device word to the counter, which
+        replay() sets to (counter now - counter at capture) right before the graph (mdpp_graph_capture /
+        mdpp_graph_set_tick_offset, round 4).  Only image handles with such a dependence still raise MdppError."""
         K = int(actions.shape[0])
         ok = self._lib.mdpp_graph_replay_exact(self._h, K)
         if ok < 0:
             capi.check(self._lib, self._h, ok, "mdpp_graph_replay_exact")
         if ok == 0:
             raise capi.MdppError(
-                "step_graph: a captured graph of %d steps does not replay exactly for this handle (rng='philox' "
-                "keys its draws by the step counter; a delay line kept in memory needs K %% delay == 0, delay = %d). "
-                "Use rollout() (one fused launch) instead." % (K, self._cfg.delay))
+                "step_graph: a captured graph of %d steps does not replay exactly for this handle (image observations: "
+                "rng='philox' keys its draws by the step counter; a delay line kept in memory needs K %% delay == 0, "
+                "delay = %d). Use rollout() (one fused launch) instead." % (K, self._cfg.delay))
+        by_offset = ok == 2
         a = self._as_actions(actions, K)
         obs, rew, term, trunc = self.alloc_rollout(K)
         side = torch.cuda.Stream(device=self.device)
@@ -490,14 +492,18 @@ class RLToyVectorEnv:
         tick0 = C.c_uint64()
         capi.check(self._lib, h, self._lib.mdpp_tick(h, 0, C.byref(tick0)), "mdpp_tick")
         try:
+            if by_offset:
+                capi.check(self._lib, h, self._lib.mdpp_graph_capture(h, 1), "mdpp_graph_capture")
             with torch.cuda.graph(g, stream=side):
                 launches(side.cuda_stream)
         finally:
+            if by_offset:
+                self._lib.mdpp_graph_capture(h, 0)
             # the capture advanced the counter although nothing ran
             now = C.c_uint64()
             self._lib.mdpp_tick(h, 0, C.byref(now))
             self._lib.mdpp_tick(h, int(tick0.value) - int(now.value), None)
-        return StepGraph(self, g, K, int(tick0.value), a, obs, rew, term, trunc)
+        return StepGraph(self, g, K, int(tick0.value), a, obs, rew, term, trunc, by_offset)
 
     def step(self, actions):
         """step(actions) -> (obs, reward, terminated, truncated, info), rl_toy_env.py:1992.
@@ -758,8 +764,8 @@ class StepGraph:
     """What RLToyVectorEnv.step_graph() returns: a captured HIP graph of K mdpp_step launches.  replay() runs
     the K steps on the current stream and advances the handle's step counter by K, as K step() calls would."""
 
-    def __init__(self, env, graph, K, tick0, actions, obs, reward, term, trunc):
-        self._env, self._g, self.K, self._tick0 = env, graph, K, tick0
+    def __init__(self, env, graph, K, tick0, actions, obs, reward, term, trunc, by_offset=False):
+        self._env, self._g, self.K, self._tick0, self._by_offset = env, graph, K, tick0, by_offset
         self.actions, self.obs, self.reward = actions, obs, reward
         self.terminated, self.truncated = term.view(torch.bool), trunc.view(torch.bool)
 
@@ -768,10 +774,16 @@ class StepGraph:
         d = int(env._cfg.delay)
         now = C.c_uint64()
         capi.check(env._lib, env._h, env._lib.mdpp_tick(env._h, 0, C.byref(now)), "mdpp_tick")
-        ring_in_memory = d > 0 and (env.kind == "continuous" or (env.kind == "discrete" and not env._cfg.unit_rewards))
-        if ring_in_memory and (int(now.value) - self._tick0) % d != 0:
-            raise capi.MdppError("StepGraph.replay: %d steps were taken outside the graph since its capture; the delay line "
-                                 "(length %d) would be read at the captured ring head" % (int(now.value) - self._tick0, d))
+        if self._by_offset:
+            # the captured launches add this to the counter they were captured with (in stream order before the graph)
+            stream = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)
+            capi.check(env._lib, env._h, env._lib.mdpp_graph_set_tick_offset(env._h, int(now.value) - self._tick0, stream),
+                       "mdpp_graph_set_tick_offset")
+        else:
+            ring_in_memory = d > 0 and (env.kind == "continuous" or (env.kind == "discrete" and not env._cfg.unit_rewards))
+            if ring_in_memory and (int(now.value) - self._tick0) % d != 0:
+                raise capi.MdppError("StepGraph.replay: %d steps were taken outside the graph since its capture; the delay line "
+                                     "(length %d) would be read at the captured ring head" % (int(now.value) - self._tick0, d))
         self._g.replay()
         capi.check(env._lib, env._h, env._lib.mdpp_tick(env._h, self.K, None), "mdpp_tick")
 

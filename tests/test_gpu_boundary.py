@@ -362,13 +362,61 @@ def test_step_graph_counts_its_steps_and_refuses_inexact_handles():
     a.step(acts[0])                                         # one more: the ring head no longer matches the captured one
     with pytest.raises(capi.MdppError):
         g.replay()
-    with pytest.raises(capi.MdppError):
-        a.step_graph(acts[:d + 1])                          # K % delay != 0
+    assert a._lib.mdpp_graph_replay_exact(a._h, d + 1) == 2   # K % delay != 0: exact through the device-side offset (below)
     a.close(); b.close()
-    p = _venv(num_envs=N, autoreset="same_step", rng="philox", **dict(gu.CASES["d_cfg2"]["config"], seed=9))
+    # image observations whose draws are keyed by the counter: still refused
+    icfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8, delay=0,
+                image_representations=True, image_width=84, image_height=84, image_transforms="shift,rotate", seed=0)
+    p = _venv(num_envs=256, autoreset="same_step", rng="philox", **icfg)
+    assert p._lib.mdpp_graph_replay_exact(p._h, 4) == 0
     with pytest.raises(capi.MdppError):
-        p.step_graph(torch.zeros((4, N), dtype=torch.int32, device=p.device))
+        p.step_graph(torch.zeros((4, 256), dtype=torch.int32, device=p.device))
     p.close()
+
+
+@pytest.mark.parametrize("case", ["cfg2-philox", "cfg2noise-philox", "cfg3delay3-numpy", "cfg5-philox", "cfg5-numpy-delay2",
+                                  "custom-reward-delay", "grid-philox"])
+def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
+    """step() is the API RL code calls; a replayed graph of K single steps is exact for EVERY handle without
+    image observations.  Launches captured in the library's capture mode add a device word to the step counter they were
+    captured with (Philox keys, the head of a delay line in memory); replay() sets it to (counter now - counter at
+    capture).  Replays interleaved with plain steps -- any number of them, so the ring head and the Philox ticks move --
+    equal a twin stepped call by call, bit for bit."""
+    import bench
+    if case == "cfg2-philox":
+        cfg, kw = dict(bench.WORKLOADS["cfg2"]["config"]), dict(rng="philox", philox_seed=3)
+    elif case == "cfg2noise-philox":
+        cfg, kw = dict(bench.WORKLOADS["cfg2_noise"]["config"]), dict(rng="philox", philox_seed=4)
+    elif case == "cfg3delay3-numpy":
+        cfg, kw = dict(bench.WORKLOADS["cfg3"]["config"], delay=3), {}
+    elif case == "cfg5-philox":
+        cfg, kw = dict(bench.WORKLOADS["cfg5"]["config"]), dict(rng="philox", philox_seed=5)
+    elif case == "cfg5-numpy-delay2":
+        cfg, kw = dict(bench.WORKLOADS["cfg5"]["config"], delay=2), {}
+    elif case == "custom-reward-delay":          # float rewards: the discrete delay line lives in memory (keys awaiting payout)
+        cfg, kw = dict(gu.CASES["d_rdist"]["config"], seed=2, delay=3), {}
+    else:
+        cfg, kw = dict(bench.WORKLOADS["grid"]["config"], transition_noise=0.2, reward_noise=0.1), dict(rng="philox", philox_seed=6)
+    N, K = 1024, 5
+    a = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    assert a._lib.mdpp_graph_replay_exact(a._h, K) == 2, case
+    rng = np.random.default_rng(7)
+    g = a.step_graph(torch.as_tensor(_rand_actions(a, K, rng), device=a.device))
+    for rep in range(4):
+        g.actions.copy_(torch.as_tensor(_rand_actions(a, K, rng), device=a.device))
+        g.replay()
+        torch.cuda.synchronize()
+        for t in range(K):
+            o, r, te, tr, _ = b.step(g.actions[t])
+            assert torch.equal(o, g.obs[t]) and torch.equal(r, g.reward[t]), (case, rep, t)
+            assert torch.equal(te, g.terminated[t]) and torch.equal(tr, g.truncated[t]), (case, rep, t)
+        for t in range(rep + 1):                 # plain steps in between: 1, 2, 3 ... (never a multiple of every delay)
+            x = torch.as_tensor(_rand_actions(a, 1, rng)[0], device=a.device)
+            ra, rb = a.step(x), b.step(x)
+            assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2]), (case, rep, t)
+    assert int(a.status().sum()) == 0
+    a.close(); b.close()
 
 
 def test_large_action_space_tables_fall_back_to_global_memory():

@@ -1,2 +1,7 @@
-timeout 1500 python3 tools/ablate_npnoise.py 5 6 7 8 9 10 11 12 13 > gpurun_out/ablate_np3.log 2>&1
-grep -v amdgpu.ids gpurun_out/ablate_np3.log
+python3 - > gpurun_out/probe.log 2>&1 <<'PY'
+import sys; sys.path.insert(0, '.')
+import torch, bench
+print(bench.hbm_ceilings(torch.device('cuda:0')))
+print(bench.hbm_ceilings(torch.device('cuda:0'), nbytes=4<<30))
+PY
+grep -v amdgpu gpurun_out/probe.log
