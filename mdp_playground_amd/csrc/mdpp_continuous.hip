@@ -377,7 +377,8 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
                                                             uint8_t *__restrict__ term,
                                                             uint8_t *__restrict__ trunc,
                                                             float *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
+    const uint32_t rhead0 = ring_head_now(a, ptick0);    // ... and the head of a delay line kept in memory
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     __shared__ double s_z[DMAX * kBlock];                    // this step's transition-noise normals, [d][lane]
@@ -482,8 +483,8 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
     float nact[DMAX];
     load_action(0, nact);
     for (int k = 0; k < K; k++) {
-        const uint32_t tick = a.tick + (uint32_t)k;              // ring head (mod delay below)
-        const uint64_t ptick = a.ptick + (uint64_t)k;
+        const uint32_t tick = rhead0 + (uint32_t)k;              // ring head (mod delay below)
+        const uint64_t ptick = ptick0 + (uint64_t)k;
         const long o = (long)k * N + i;
         if (PHILOX) {
             env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), ptick, MDPP_STREAM_ENV);

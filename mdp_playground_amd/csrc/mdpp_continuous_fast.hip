@@ -126,7 +126,8 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                                                                     uint8_t *__restrict__ term,
                                                                     uint8_t *__restrict__ trunc,
                                                                     float *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
+    const uint32_t rhead0 = ring_head_now(a, ptick0);    // ... and the head of a delay line kept in memory
     static_assert(D % 4 == 0 || D == 2, "D must be 2 or a multiple of 4");
     constexpr bool ZIG = NOISE && !PHILOX;      // numpy's ziggurat tables in LDS
     constexpr bool WALK = HELPER && !PHILOX && NPROD == 2;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)
     // this step's normals, PHILOX: P-noise of dimension d at [d], reward noise at [D]
     auto philox_step = [&](int k, float (&z)[NPS]) __attribute__((always_inline)) {
-        const uint64_t tick = a.ptick + (uint64_t)k;
+        const uint64_t tick = ptick0 + (uint64_t)k;
         if (a.has_p_noise && a.has_r_noise) {
             philox_normals<NPS>(a.philox_seed, genv, tick, MDPP_STREAM_ENV, z);
         } else if (a.has_p_noise) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             }
             // one Philox block -> two Box-Muller pairs -> four ring entries at a time (few live registers)
             ZT *slot = s_z + (size_t)(k % kNRing) * NPS * kBlock + ln;
-            const uint64_t tick = a.ptick + (uint64_t)k;
+            const uint64_t tick = ptick0 + (uint64_t)k;
             const uint32_t k0 = (uint32_t)a.philox_seed, k1 = (uint32_t)(a.philox_seed >> 32) ^ (uint32_t)(tick >> 32);
             const int first = a.has_p_noise ? 0 : D;            // ring index of the stream's first normal
             const int nn = (a.has_p_noise ? D : 0) + (a.has_r_noise ? 1 : 0);
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             double rv = (double)r;
             bool is32 = true;
             if (a.delay > 0) {                                                   // FIFO of float32 bit patterns
-                uint32_t *slot = a.ring + (size_t)((a.tick + (uint32_t)k) % (uint32_t)a.delay) * N + i;
+                uint32_t *slot = a.ring + (size_t)((rhead0 + (uint32_t)k) % (uint32_t)a.delay) * N + i;
                 const uint32_t bits = *slot;
                 *slot = __float_as_uint(r);
                 if (bits == kRingPyZero) { rv = 0.0; is32 = false; }
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                     for (int d = 0; d < D; d++) final_obs[((size_t)so + i) * D + d] = nxt[d];
                 }
                 typename std::conditional<PHILOX, Philox, Pcg64>::type sp;
-                if constexpr (PHILOX) sp.init(a.philox_seed, genv, a.ptick + (uint64_t)k, MDPP_STREAM_SPACE);
+                if constexpr (PHILOX) sp.init(a.philox_seed, genv, ptick0 + (uint64_t)k, MDPP_STREAM_SPACE);
                 else sp.load(a.sp_s, a.sp_inc, i);
                 for (int tries = 0;; tries++) {
                     // (unbounded boxes are served by the GEN instantiations, so that the plain kernels do not

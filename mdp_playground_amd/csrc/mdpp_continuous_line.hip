@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_line_rollout(ContinuousAr
                                                                     uint8_t *__restrict__ term,
                                                                     uint8_t *__restrict__ trunc,
                                                                     float *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
     static_assert(D == 2 || D == 4, "every dimension relevant: 2 or 4");
     extern __shared__ __align__(16) float4 s_pts[];            // [L][kBlock]
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void k_continuous_line_rollout(ContinuousAr
                     for (int d = 0; d < D; d++) final_obs[((size_t)so + i) * D + d] = nxt[d];
                 }
                 typename std::conditional<PHILOX, Philox, Pcg64>::type sp;
-                if constexpr (PHILOX) sp.init(a.philox_seed, (uint64_t)(a.env_id_offset + (int64_t)i), a.ptick + (uint64_t)k, MDPP_STREAM_SPACE);
+                if constexpr (PHILOX) sp.init(a.philox_seed, (uint64_t)(a.env_id_offset + (int64_t)i), ptick0 + (uint64_t)k, MDPP_STREAM_SPACE);
                 else sp.load(a.sp_s, a.sp_inc, i);
 #pragma unroll
                 for (int d = 0; d < D; d++) cur[d] = (float)(a.reset_lo + a.reset_range * np_random(sp));

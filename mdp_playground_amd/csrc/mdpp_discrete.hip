@@ -57,7 +57,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                                                           uint8_t *__restrict__ term,
                                                           uint8_t *__restrict__ trunc,
                                                           void *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
+    const uint32_t rhead0 = ring_head_now(a, ptick0);    // ... and the head of a delay line kept in memory
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ uint64_t s_ki[NOISE ? 256 : 1];
     __shared__ double s_wi[NOISE ? 256 : 1], s_fi[NOISE ? 256 : 1];
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
         for (int u = 0; u < kPrefetch; u++) {
             const int k = k0 + u;
             if (k >= K) break;
-            const uint32_t tick = a.tick + (uint32_t)k;          // ring head (mod delay below)
-            const uint64_t ptick = a.ptick + (uint64_t)k;
+            const uint32_t tick = rhead0 + (uint32_t)k;          // ring head (mod delay below)
+            const uint64_t ptick = ptick0 + (uint64_t)k;
             const long o = (long)k * N + i;
             int action = act[u];
             if (pending) {           // next-step autoreset: this call is the env's reset(), :2250-2278

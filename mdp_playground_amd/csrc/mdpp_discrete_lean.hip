@@ -112,6 +112,9 @@ namespace mdpp {
 #ifndef MDPP_LEAN_HMIN
 #define MDPP_LEAN_HMIN 16
 #endif
+#ifndef MDPP_LEAN_H_LIMBS
+#define MDPP_LEAN_H_LIMBS 0        // (the limb form of PCG64 on the numpy H wave: 137 us per cfg2 launch either way -- H is not what bounds it)
+#endif
 #ifndef MDPP_LEAN_HSLEEP
 #define MDPP_LEAN_HSLEEP 8
 #endif
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                                                                       uint8_t *__restrict__ term,
                                                                       uint8_t *__restrict__ trunc,
                                                                       void *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
     // E -> O, three dwords per env step in ONE array (constant 32 KB apart: two of them go out as one ds_write2st64):
     //   A history before a reset   B history after it   C byte 0: the column entry (bit 7 terminated), byte 1 the
     //   irrelevant observation, byte 2 truncated
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 const uint64_t u53 = IRR ? lds_T1[j] : ~0ULL;
                 thr1[j] = __builtin_amdgcn_readfirstlane(u53 > (1ULL << 53) ? 0x80000000u : (uint32_t)((u53 + 0x3FFFFFULL) >> 22));
             }
-            const uint32_t r4 = (uint32_t)a.ptick & 3u;            // the launch's offset inside its first block (wave-uniform)
+            const uint32_t r4 = (uint32_t)ptick0 & 3u;            // the launch's offset inside its first block (wave-uniform)
             for (int c = 0; c < nch; c++) {
                 if (c >= kHChunks) {                             // slot c % kHChunks: E must be through chunk c - kHChunks
                     const uint32_t must = (uint32_t)min((c - kHChunks + 1) * kChunk, K);
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                         if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
                     }
                 }
-                const uint64_t b0 = (a.ptick + (uint64_t)(c * kChunk)) >> 2;
+                const uint64_t b0 = (ptick0 + (uint64_t)(c * kChunk)) >> 2;
                 auto words = [&](uint32_t stream, uint32_t (&wd)[kChunk]) { chunk_words(a.philox_seed, genv, b0, r4, stream, wd); };
                 uint32_t wd[kChunk], wd1[kChunk];
                 words(kPhiloxStartStream, wd);
@@ -612,7 +615,14 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         }
         Pcg64 g;
         g.load(a.env_s, a.env_inc, i);
+#if MDPP_LEAN_H_LIMBS
+        // (the hand-scheduled limb form of the generator: 31 instead of 46 vector instructions per word on the filler wave)
+        Pcg64LimbsLo gl;
+        gl.from(g);
+        auto draw = [&](Pcg64LimbsLo &gg) -> uint32_t {
+#else
         auto draw = [&](Pcg64 &gg) -> uint32_t {
+#endif
             const uint64_t m = gg.next64() >> 11;
             uint32_t s0 = 0;
 #pragma unroll
@@ -635,11 +645,19 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const uint64_t bw = __builtin_amdgcn_ballot_w64(want);
             const bool urgent = __builtin_amdgcn_ballot_w64(want && cnt <= 2) != 0;
             if (__builtin_popcountll(bw) >= kMinLanes || urgent) {
+#if MDPP_LEAN_H_LIMBS
+                Pcg64LimbsLo n = gl;
+#else
                 Pcg64 n = g;
+#endif
                 const uint32_t s0 = draw(n) | 8u;
                 if (want) {
                     const uint32_t sh = (tail & 7u) * 4u;
+#if MDPP_LEAN_H_LIMBS
+                    gl = n;
+#else
                     g = n;
+#endif
                     vals = (vals & ~((IRR ? 0xFFu : 0xFu) << sh)) | (s0 << sh);
                     tail += (uint32_t)kEN;                       // (in nibbles = in draws of the stream)
                 }
@@ -650,6 +668,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             }
         }
         // un-draw what the env lane did not take: s_prev = (s - inc) * M^-1 (mod 2^128)
+#if MDPP_LEAN_H_LIMBS
+        gl.to(g);
+#endif
         const uint32_t head = wg_load_acq(&lds_head[l]);
         for (uint32_t q = tail - head; q > 0; q--) {
             uint64_t lo = g.s_lo - g.inc_lo;
@@ -677,7 +698,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         const uint32_t ph_full = 16u * (uint32_t)a.every_n;
         uint32_t ph = EVN ? ph_full - 16u * (steps_at_launch % (uint32_t)a.every_n) : 0u;
         const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);
-        const uint32_t r4 = (uint32_t)a.ptick & 3u;
+        const uint32_t r4 = (uint32_t)ptick0 & 3u;
         float zc[kChunk] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};         // RN: the chunk's reward normals
         const bool plain = a.scale == 1.0 && a.shift == 0.0;                        // (wave-uniform)
         auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, double z) {
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             const int kbase = c * kChunk;
             const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
             if constexpr (RN && PHILOX)       // (before the wait: independent of E)
-                chunk_normals(a.philox_seed, genv, (a.ptick + (uint64_t)kbase) >> 2, r4, kPhiloxRNoiseStream, zc);
+                chunk_normals(a.philox_seed, genv, (ptick0 + (uint64_t)kbase) >> 2, r4, kPhiloxRNoiseStream, zc);
             uint32_t spins = 0;
 #ifdef MDPP_ABL_FREEO
             while (false) {

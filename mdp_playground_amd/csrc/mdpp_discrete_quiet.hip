@@ -87,7 +87,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                                                                    void *__restrict__ obs, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                                    void *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __align__(16) unsigned char lds[];
@@ -266,8 +266,8 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         const int me = role - 2;
         __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
         uint32_t hstatus = 0;
-        const uint64_t G0 = a.ptick >> 2;
-        const int nG = (int)(((a.ptick + (uint64_t)K - 1u) >> 2) - G0) + 1;
+        const uint64_t G0 = ptick0 >> 2;
+        const int nG = (int)(((ptick0 + (uint64_t)K - 1u) >> 2) - G0) + 1;
         const bool small = S <= 8u;                              // rho_0 thresholds in scalar registers
         uint32_t t31[8];
 #pragma unroll
@@ -275,7 +275,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         const bool want_start = a.autoreset != 0;
         for (int r = me; r < nG; r += NPH) {
             const uint64_t blk = G0 + (uint64_t)r;
-            const int kfirst = (int)((int64_t)(blk << 2) - (int64_t)a.ptick);      // step of the block's word 0 (may be < 0)
+            const int kfirst = (int)((int64_t)(blk << 2) - (int64_t)ptick0);      // step of the block's word 0 (may be < 0)
             const int k_hi = min(K, kfirst + 4);
             uint32_t pw[4] = {0u, 0u, 0u, 0u}, sw[4] = {0u, 0u, 0u, 0u};
             float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -431,7 +431,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     auto stepE = [&](const u32x2 act2, double &z, const int kstep) __attribute__((always_inline)) -> uint64_t {
         uint32_t hent = 0;           // NPH: what the producers made for this step
         if constexpr (NPH > 0) hent = s_hm[(kstep % kHD) * kBlock + l];
-        const uint64_t ptick = a.ptick + (uint64_t)kstep;        // (Philox streams)
+        const uint64_t ptick = ptick0 + (uint64_t)kstep;        // (Philox streams)
         if (!ATNEED && __builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
         int action = (int)act2.x;
         action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
@@ -505,7 +505,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
         if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
             if constexpr (NPH > 0) { queue[0] = need ? (hent >> 16) : queue[0]; }
-            else if (need) { queue[0] = draw_state(a.ptick + (uint64_t)kstep); }
+            else if (need) { queue[0] = draw_state(ptick0 + (uint64_t)kstep); }
             qn = need ? 1u : qn;
         }
         uint32_t hi = (done_out ? 1u : 0u) | (tr ? 2u : 0u) | (need ? 4u : 0u) | (valid > L ? 8u : 0u) |
@@ -602,13 +602,13 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             if (TRIO && autoreset) pull();
             if constexpr (NPH > 0) {                    // the producers must be through this chunk's four-tick blocks
                 const int upto = min(kbase + kPre, K);
-                const uint64_t G0 = a.ptick >> 2;
-                const int r_last = (int)(((a.ptick + (uint64_t)upto - 1u) >> 2) - G0);
+                const uint64_t G0 = ptick0 >> 2;
+                const int r_last = (int)(((ptick0 + (uint64_t)upto - 1u) >> 2) - G0);
 #pragma unroll
                 for (int p = 0; p < NPH; p++) {
                     if (r_last < p) continue;
                     const int r_p = r_last - ((r_last - p) % NPH);          // producer p's last block that starts before `upto`
-                    const int64_t hi = (int64_t)((G0 + (uint64_t)r_p + 1u) << 2) - (int64_t)a.ptick;
+                    const int64_t hi = (int64_t)((G0 + (uint64_t)r_p + 1u) << 2) - (int64_t)ptick0;
                     const uint32_t want = (uint32_t)(hi < (int64_t)K ? hi : (int64_t)K);
                     uint32_t spins = 0;
                     while (__hip_atomic_load(&s_hprod[p][w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {

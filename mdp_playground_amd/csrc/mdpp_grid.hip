@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
                                                       void *__restrict__ obs, float *__restrict__ reward,
                                                       uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                       void *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
     __shared__ uint64_t s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     if (NOISE && a.has_r_noise) { zig_stage(s_ki, s_wi, s_fi, threadIdx.x, kBlock); __syncthreads(); }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_step(GridArgs a, int K, const i
         if (k >= K) break;
         int act[4] = {pre[u][0], pre[u][1], pre[u][2], pre[u][3]};
         load_act(k + kGPrefetch, pre[u]);
-        const uint64_t tick = a.ptick + (uint64_t)k;
+        const uint64_t tick = ptick0 + (uint64_t)k;
         const long o = (long)k * N + i;
         if (PHILOX) {
             env_phx.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick, MDPP_STREAM_ENV);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
                                                               void *__restrict__ obs, float *__restrict__ reward,
                                                               uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                               void *__restrict__ final_obs) {
-    tick_from_device(a);
+    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_rollout_fast(GridArgs a, int K,
         // every lane must hold a start cell before the step may end its episode; the refill tops
         // all lanes up to kGQ, so this branch is taken once in several dozen steps
         if constexpr (PH) {
-            const uint64_t tick = a.ptick + (uint64_t)k;
+            const uint64_t tick = ptick0 + (uint64_t)k;
             env.init(a.philox_seed, genv, tick, MDPP_STREAM_ENV);
             sp.init(a.philox_seed, genv, tick, MDPP_STREAM_SPACE);
             actg.init(a.philox_seed, genv, tick, kPhiloxActionStream);

@@ -169,12 +169,15 @@ struct ContinuousArgs {
 // A launch captured into a HIP graph replays with the argument values it was captured with -- the step counter among
 // them (Philox keys; the head of a delay line kept in memory).  In capture mode (mdpp_graph_capture) the launches carry a
 // pointer to a device word instead: the difference between the counter NOW and the counter at capture, written by
-// mdpp_graph_set_tick_offset before a replay; every step / rollout kernel adds it first thing (wave-uniform scalar load).
-__device__ __forceinline__ void tick_from_device(DiscreteArgs &a) {
-    if (a.dtick) { a.ptick += *a.dtick; a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u; }
-}
-__device__ __forceinline__ void tick_from_device(ContinuousArgs &a) {
-    if (a.dtick) { a.ptick += *a.dtick; a.tick = a.delay > 0 ? (uint32_t)(a.ptick % (uint64_t)a.delay) : 0u; }
+// mdpp_graph_set_tick_offset before a replay; every step / rollout kernel reads its counter through tick_now() /
+// ring_head_now() (a wave-uniform scalar load).  (NOT by patching the argument struct inside the kernel: a write to a
+// by-value kernel argument makes the compiler copy the whole struct to private memory -- the cfg2 rollout went from 129 to
+// 195 us per launch with exactly that.)
+template <class A>
+__device__ __forceinline__ uint64_t tick_now(const A &a) { return a.ptick + (a.dtick ? *a.dtick : 0ULL); }
+template <class A>
+__device__ __forceinline__ uint32_t ring_head_now(const A &a, uint64_t ptick) {
+    return a.dtick ? (a.delay > 0 ? (uint32_t)(ptick % (uint64_t)a.delay) : 0u) : a.tick;
 }
 
 // ---- grid (mdpp_grid.hip) ----
@@ -196,10 +199,6 @@ struct GridArgs {
     uint32_t *status;
     EpisodeStatsDev est;
 };
-
-__device__ __forceinline__ void tick_from_device(GridArgs &a) {
-    if (a.dtick) a.ptick += *a.dtick;
-}
 
 } // namespace mdpp
 
