@@ -410,17 +410,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             return;
         }
         if constexpr (NPN || NRN) {
-            // ---- numpy streams with noise (header): H owns the state space's stream (transition noise, one word per step, made a
-            // chunk ahead) and the env stream (RN: every position evaluated as a draw's start; else: the start-state queue)
+            // ---- numpy streams with noise (header): H owns the env stream (RN: every position evaluated as a draw's start; else:
+            // the start-state queue).  The state space's stream (transition noise) is the O2 wave's: H was the long chain
+            // (68 vector instructions per wave and step at 66 % of the issue cycles, profiles/r04_cfg2_noise_sq.txt)
             Pcg64 g;
             g.load(a.env_s, a.env_inc, i);
             Pcg64LimbsLo ge;
             ge.from(g);
-            Pcg64 sp;
-            Pcg64LimbsLo gs;
-            if (PN) { sp.load(a.sp_s, a.sp_inc, i); gs.from(sp); }
-            const int nch = (K + kChunk - 1) / kChunk;
-            int c = 0;                              // transition-noise chunks made
             uint32_t hq = 0;                        // RN: positions made
             uint64_t look = 0;                      // RN: the word of position hq (the generator runs one word ahead)
             if (NRN) look = ge.next64();
@@ -444,35 +440,6 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             for (;;) {
                 if (wg_load_acq(&lds_done) == kBlock / 64) break;
                 bool did = false;
-                if constexpr (NPN) {
-                    if (c < nch && (c < kHChunksNp || wg_load_acq(&lds_prod[w]) >= (uint32_t)min((c - kHChunksNp + 1) * kChunk, K))) {
-                        uint32_t pk[2] = {0u, 0u};
-#pragma unroll
-                        for (int u = 0; u < kChunk; u++) {
-                            const uint64_t r = gs.next64();
-                            uint32_t by = lds_pntab[(uint32_t)(r >> 52)];
-#ifdef MDPP_ABL_NP_NOPNC
-                            by = 7u | ((uint32_t)(r >> 63) << 4);
-#endif
-                            if (__builtin_expect(__builtin_amdgcn_ballot_w64(by == 0xFFu) != 0, 0)) {
-                                if (by == 0xFFu) {
-                                    uint32_t na = 0, nb = 0;
-#pragma unroll
-                                    for (int j = 0; j < 7; j++) na += (a.pn_TL[j] <= r) ? 1u : 0u;
-#pragma unroll
-                                    for (int j = 0; j < 8; j++) nb += (a.pn_TU[j] <= r) ? 1u : 0u;
-                                    by = na | (nb << 4);
-                                }
-                            }
-                            pk[u >> 2] |= by << (8 * (u & 3));
-                        }
-                        lds_pn2[c % kHChunksNp][0][l] = pk[0];
-                        lds_pn2[c % kHChunksNp][1][l] = pk[1];
-                        c += 1;
-                        if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)c);
-                        did = true;
-                    }
-                }
                 if constexpr (NRN) {
                     const uint32_t epos = __hip_atomic_load(&lds_epos[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const bool go = hq + (uint32_t)kXB <= epos + (uint32_t)kXR;
@@ -605,11 +572,6 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             if (NRN) undraw(g, hq + 1u - __hip_atomic_load(&lds_epos[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));   // (+ the word in hand)
             else undraw(g, tail - wg_load_acq(&lds_head[l]));
             g.store(a.env_s, i);
-            if (PN) {
-                gs.to(sp);
-                undraw(sp, (uint32_t)(c * kChunk) - (uint32_t)K);       // (the last chunk may be ragged)
-                sp.store(a.sp_s, i);
-            }
             if (status) atomicOr(&a.status[i], status);
             return;
         }
@@ -783,7 +745,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== O2: observation, terminated, truncated
     if (role == 2) {
-        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O2 >= 0 ? MDPP_LEAN_PRIO_O2 : kPrioO);
+        // (numpy transition noise: this wave runs the state space's generator -- a long stage like H)
+        // (3 beside an H wave that only keeps the start-state queue, 2 beside one that evaluates the env stream: 159 / 306 us per
+        //  cfg2 launch with transition noise / both noises, against 202 / 313 at the O waves' priority)
+        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O2 >= 0 ? MDPP_LEAN_PRIO_O2 : (NPN && !MDPP_LEAN_PRIO_FORCED) ? (NRN ? 2 : 3) : kPrioO);
         auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
@@ -812,6 +777,40 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             __builtin_amdgcn_raw_buffer_store_b8(HASMAX ? (uint8_t)(rc >> 16) : (uint8_t)0, r_trunc, v1, so, MDPP_LEAN_ST_AUX_BYTES);
 #endif
         };
+        // numpy transition noise (header): this wave owns the state space's stream and makes the noise bytes of chunk pc --
+        // one word per step -- up to kHChunksNp chunks ahead of the chunk E has finished (slot pc % kHChunksNp is free then)
+        Pcg64 sp;
+        Pcg64LimbsLo gs;
+        int pc = 0;
+        if constexpr (NPN) { sp.load(a.sp_s, a.sp_inc, i); gs.from(sp); }
+        auto make_pn = [&](int upto_chunk) __attribute__((always_inline)) {
+            for (; pc < nchunks && pc < upto_chunk; pc++) {
+                uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    const uint64_t r = gs.next64();
+                    uint32_t by = lds_pntab[(uint32_t)(r >> 52)];
+#ifdef MDPP_ABL_NP_NOPNC
+                    by = 7u | ((uint32_t)(r >> 63) << 4);
+#endif
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(by == 0xFFu) != 0, 0)) {
+                        if (by == 0xFFu) {
+                            uint32_t na = 0, nb = 0;
+#pragma unroll
+                            for (int j = 0; j < 7; j++) na += (a.pn_TL[j] <= r) ? 1u : 0u;
+#pragma unroll
+                            for (int j = 0; j < 8; j++) nb += (a.pn_TU[j] <= r) ? 1u : 0u;
+                            by = na | (nb << 4);
+                        }
+                    }
+                    pk[u >> 2] |= by << (8 * (u & 3));
+                }
+                lds_pn2[pc % kHChunksNp][0][l] = pk[0];
+                lds_pn2[pc % kHChunksNp][1][l] = pk[1];
+                if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)(pc + 1));
+            }
+        };
+        if constexpr (NPN) make_pn(kHChunksNp);
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kChunk;
             const uint32_t upto = (uint32_t)min(kbase + kChunk, K);
@@ -824,6 +823,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
+            if constexpr (NPN) make_pn(c + 1 + kHChunksNp);          // (E is through chunk c)
             if (kbase + kChunk <= K) {
                 uint32_t rb[kChunk], rc[kChunk];
 #pragma unroll
@@ -837,6 +837,16 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 for (int k = kbase; k < K; k++) emit(lds_rec[1][k % KD][l], lds_rec[2][k % KD][l], (uint32_t)k * N);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][1], upto);
+        }
+        if constexpr (NPN) {                        // un-draw the words of a ragged last chunk: s_prev = (s - inc) * M^-1 (mod 2^128)
+            gs.to(sp);
+            for (uint32_t q = (uint32_t)(pc * kChunk) - (uint32_t)K; q > 0; q--) {
+                uint64_t lo = sp.s_lo - sp.inc_lo;
+                uint64_t hi = sp.s_hi - sp.inc_hi - (sp.s_lo < sp.inc_lo ? 1ULL : 0ULL);
+                sp.s_lo = lo * a.minv_lo;
+                sp.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+            }
+            sp.store(a.sp_s, i);
         }
         if (status) atomicOr(&a.status[i], status);
         return;

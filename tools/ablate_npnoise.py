@@ -23,6 +23,12 @@ VARIANTS = [
     ("prio E 3 O 0 H 3", "-DMDPP_LEAN_PRIO_E=3 -DMDPP_LEAN_PRIO_O=0 -DMDPP_LEAN_PRIO_H=3"),
     ("prio E 1 O 0 H 3, O2 2", "-DMDPP_LEAN_PRIO_E=1 -DMDPP_LEAN_PRIO_O=0 -DMDPP_LEAN_PRIO_H=3 -DMDPP_LEAN_PRIO_O2=2"),
     ("prio E 2 O 2 H 3", "-DMDPP_LEAN_PRIO_E=2 -DMDPP_LEAN_PRIO_O=2 -DMDPP_LEAN_PRIO_H=3"),
+    ("O2 at priority 2", "-DMDPP_LEAN_PRIO_O2=2"),
+    ("O2 at priority 1", "-DMDPP_LEAN_PRIO_O2=1"),
+    ("E 3, O1 1, O2 3, H 3", "-DMDPP_LEAN_PRIO_E=3 -DMDPP_LEAN_PRIO_O=1 -DMDPP_LEAN_PRIO_H=3 -DMDPP_LEAN_PRIO_O2=3"),
+    ("E 1, O1 0, O2 3, H 3", "-DMDPP_LEAN_PRIO_E=1 -DMDPP_LEAN_PRIO_O=0 -DMDPP_LEAN_PRIO_H=3 -DMDPP_LEAN_PRIO_O2=3"),
+    ("E 2, O1 1, O2 2, H 3", "-DMDPP_LEAN_PRIO_E=2 -DMDPP_LEAN_PRIO_O=1 -DMDPP_LEAN_PRIO_H=3 -DMDPP_LEAN_PRIO_O2=2"),
+    ("E 2, O1 1, O2 3, H 2", "-DMDPP_LEAN_PRIO_E=2 -DMDPP_LEAN_PRIO_O=1 -DMDPP_LEAN_PRIO_H=2 -DMDPP_LEAN_PRIO_O2=3"),
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-DMDPP_LEAN_SHAPES_MIN"]
 sys.path.insert(0, ROOT)
