@@ -330,6 +330,31 @@ int mdpp_status(mdpp_env *h, uint32_t *flags_host);
 int mdpp_timer_begin(mdpp_env *h, void *stream);
 int mdpp_timer_end(mdpp_env *h, void *stream, float *ms_out);
 
+/* ---- peer-copy gather of the observation shards (ABI 7; SURVEY.md 8e "Collective") ----------------------------------
+ * The path's one collective -- every rank gets the concatenated current-observation tensor -- as device-to-device copies
+ * on the copy engines instead of a collective KERNEL: the rollout kernels hold every compute unit, so an RCCL all-gather
+ * can only run between two launches, a copy engine runs beside them.  No counterpart in the reference (one process, one
+ * env); `dist.PeerGatherer` is the binding, `ObsGatherer` (RCCL all_gather_into_tensor) stays the default and `value`.
+ *   mdpp_peer_create   a buffer [slots][world][shard_bytes] on `device` (+ one 64-bit flag per slot and rank)
+ *   mdpp_peer_handle   its hipIpcMemHandle_t (MDPP_PEER_HANDLE_BYTES bytes); exchange them over any channel
+ *   mdpp_peer_open     maps the other ranks' buffers: `handles` = world x MDPP_PEER_HANDLE_BYTES bytes in rank order
+ *   mdpp_peer_push     behind what `stream` has enqueued: shard_dev (shard_bytes on this device) -> row `rank` of slot
+ *                      `slot` of EVERY rank's buffer, then `seq` into this rank's flag there (side stream of the handle)
+ *   mdpp_peer_wait     `stream` waits until every rank's flag of `slot` is >= seq (a one-wave kernel polling device
+ *                      memory, bounded: a timeout sets a status bit per missing rank -- mdpp_peer_status -- never hangs)
+ *   mdpp_peer_buffer   device pointer of slot `slot`: [world][shard_bytes], rank-major = global env-id order */
+#define MDPP_PEER_HANDLE_BYTES 64
+typedef struct mdpp_peer mdpp_peer;
+int mdpp_peer_create(int device, int world, int rank, size_t shard_bytes, int slots, mdpp_peer **out);
+int mdpp_peer_handle(mdpp_peer *p, void *handle_out);
+int mdpp_peer_open(mdpp_peer *p, const void *handles);
+int mdpp_peer_push(mdpp_peer *p, int slot, const void *shard_dev, uint64_t seq, void *stream);
+int mdpp_peer_wait(mdpp_peer *p, int slot, uint64_t seq, void *stream);
+void *mdpp_peer_buffer(mdpp_peer *p, int slot);
+int mdpp_peer_status(mdpp_peer *p, uint32_t *status_out, int *finegrained_out);
+const char *mdpp_peer_last_error(mdpp_peer *p);
+int mdpp_peer_destroy(mdpp_peer *p);
+
 /* What the memory system of the current device gives plain streaming kernels (no handle; nothing of the reference):
  * `reps` launches of a 16-bytes-per-lane grid-stride kernel over `nbytes` on `stream`, HIP events around them ->
  * *ms_out (all reps).  mode 0: copy src -> dst (2 x nbytes moved per launch; the float4 copy MI355X_MICROARCH.md

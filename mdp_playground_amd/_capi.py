@@ -16,6 +16,7 @@ AUTORESET_DISABLED, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 OBS_I64, OBS_I32, OBS_F32, OBS_IMAGE_U8 = 0, 1, 2, 3
 STREAM_ENV, STREAM_SPACE, STREAM_IMAGE, STREAM_SPACE_IRR, STREAM_ACTION = 0, 1, 2, 3, 4
 STATUS_BAD_ACTION = 1
+PEER_HANDLE_BYTES = 64
 # MDPP_OPT_* kernel-selection switches (mdpp_set_options)
 OPTIONS = {"NO_PIPE": 1 << 0, "NO_HELPER": 1 << 1, "NO_PARK": 1 << 2, "NO_CFAST": 1 << 3, "NO_QUIET": 1 << 4,
            "NO_QUIET_NOISE": 1 << 5, "NO_DUO": 1 << 6, "NO_TRIO": 1 << 7, "NO_GFAST": 1 << 8,
@@ -35,6 +36,8 @@ EXPORTS = [
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
     "mdpp_episode_stats", "mdpp_probe_hbm",
+    "mdpp_peer_create", "mdpp_peer_handle", "mdpp_peer_open", "mdpp_peer_push", "mdpp_peer_wait", "mdpp_peer_buffer",
+    "mdpp_peer_status", "mdpp_peer_last_error", "mdpp_peer_destroy",
 ]
 
 
@@ -155,6 +158,17 @@ def load():
     L.mdpp_post_step_n.argtypes = [vp, i32] + [vp] * 6
     L.mdpp_episode_stats.argtypes = [i32, i32, vp, i32] + [vp] * 9
     L.mdpp_probe_hbm.argtypes = [i32, vp, vp, C.c_size_t, i32, vp, C.POINTER(C.c_float)]
+    L.mdpp_peer_create.argtypes = [i32, i32, i32, C.c_size_t, i32, C.POINTER(vp)]
+    L.mdpp_peer_handle.argtypes = [vp, vp]
+    L.mdpp_peer_open.argtypes = [vp, vp]
+    L.mdpp_peer_push.argtypes = [vp, i32, vp, C.c_uint64, vp]
+    L.mdpp_peer_wait.argtypes = [vp, i32, C.c_uint64, vp]
+    L.mdpp_peer_buffer.argtypes = [vp, i32]
+    L.mdpp_peer_buffer.restype = vp
+    L.mdpp_peer_status.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(i32)]
+    L.mdpp_peer_last_error.argtypes = [vp]
+    L.mdpp_peer_last_error.restype = C.c_char_p
+    L.mdpp_peer_destroy.argtypes = [vp]
     L.mdpp_timer_begin.argtypes = [vp, vp]
     L.mdpp_timer_end.argtypes = [vp, vp, C.POINTER(C.c_float)]
     if L.mdpp_abi_version() != MDPP_ABI_VERSION:

@@ -96,3 +96,91 @@ class ShardedVectorEnv:
 
     def close(self):
         self.env.close()
+
+
+class _DevBuf:
+    """A device buffer the library owns, seen through __cuda_array_interface__ (torch.as_tensor makes a view, no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PeerGatherer:
+    """The same gather as ObsGatherer -- every rank gets all ranks' shards of `local`, rank-major -- as device-to-device
+    copies on the copy engines instead of a collective kernel (include/mdpp.h "mdpp_peer_*"): the rollout kernels hold
+    every compute unit, so RCCL's all-gather kernel runs BETWEEN two launches; a peer copy runs beside them.
+
+    One process per rank; the buffers' hipIpc handles are exchanged once through `dist_module.all_gather_object`.
+    start() pushes the current contents of `local` (behind what the current stream has enqueued) into every rank's
+    buffer; wait() makes the current stream wait until every rank's shard of that push has landed here; `out` is the
+    [world, *local.shape] tensor (a view of the library's buffer).  Pushes alternate over `slots` buffers, so a new
+    push does not overwrite what a peer may still be reading.  A rank that never arrives shows up as a status bit
+    (status()), not as a hang."""
+
+    _ITEM = {1: "|u1", 2: "<u2", 4: "<u4", 8: "<u8"}
+
+    def __init__(self, local: torch.Tensor, world: int, rank: int, dist_module=None, slots: int = 2):
+        import ctypes as C
+        from . import _capi as capi
+        if not local.is_contiguous():
+            raise ValueError("PeerGatherer: the local shard must be contiguous")
+        self._capi, self._lib, self._C = capi, capi.load(), C
+        self.local, self.world, self.rank, self.slots = local, int(world), int(rank), int(slots)
+        self.nbytes = local.numel() * local.element_size()
+        self._h = C.c_void_p()
+        dev = local.device.index or 0
+        rc = self._lib.mdpp_peer_create(dev, self.world, self.rank, self.nbytes, self.slots, C.byref(self._h))
+        if rc:
+            raise capi.MdppError(f"mdpp_peer_create failed ({rc})")
+        mine = (C.c_uint8 * capi.PEER_HANDLE_BYTES)()
+        self._check(self._lib.mdpp_peer_handle(self._h, mine), "mdpp_peer_handle")
+        if self.world > 1:
+            if dist_module is None:
+                raise ValueError("PeerGatherer: world > 1 needs a process group to exchange the handles")
+            allh = [None] * self.world
+            dist_module.all_gather_object(allh, bytes(mine))
+            blob = (C.c_uint8 * (capi.PEER_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(allh))
+            self._check(self._lib.mdpp_peer_open(self._h, blob), "mdpp_peer_open")
+        self._seq, self._slot = 0, 0
+        typestr = self._ITEM[local.element_size()]
+        self._views = []
+        for s in range(self.slots):
+            ptr = self._lib.mdpp_peer_buffer(self._h, s)
+            raw = torch.as_tensor(_DevBuf(ptr, (self.world * local.numel(),), typestr), device=local.device)
+            self._views.append(raw.view(local.dtype).view((self.world,) + tuple(local.shape)))
+        self.out = self._views[0]
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self._lib.mdpp_peer_last_error(self._h)
+            raise self._capi.MdppError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.local.device).cuda_stream)
+
+    def start(self):
+        """Push the shard (asynchronous with respect to the current stream); returns the ticket wait() takes."""
+        self._seq += 1
+        self._slot = self._seq % self.slots
+        self._check(self._lib.mdpp_peer_push(self._h, self._slot, self.local.data_ptr(), self._seq, self._stream()), "mdpp_peer_push")
+        return (self._slot, self._seq)
+
+    def wait(self, ticket=None):
+        slot, seq = ticket if ticket is not None else (self._slot, self._seq)
+        self._check(self._lib.mdpp_peer_wait(self._h, slot, seq, self._stream()), "mdpp_peer_wait")
+        self.out = self._views[slot]
+        return self.out
+
+    def __call__(self):
+        return self.wait(self.start())
+
+    def status(self):
+        st, fg = self._C.c_uint32(0), self._C.c_int(0)
+        self._check(self._lib.mdpp_peer_status(self._h, self._C.byref(st), self._C.byref(fg)), "mdpp_peer_status")
+        return int(st.value), bool(fg.value)
+
+    def close(self):
+        if self._h:
+            self._views, self.out = [], None
+            self._lib.mdpp_peer_destroy(self._h)
+            self._h = None
