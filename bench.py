@@ -491,7 +491,7 @@ def main():
         if gathers is not None:
             for w in works:
                 if w is not None:
-                    w.wait()                        # (the current stream waits for the collective's stream)
+                    getattr(w, "finish", w.wait)()  # (the current stream waits for the collective's stream / the peers' shards)
 
     def timed(steps, gathers, events=False, rotate=True):
         """EXACTLY `steps` launches between barrier + synchronize on both sides; max over ranks."""
@@ -590,6 +590,50 @@ def main():
                         "else running (events around %d of them); added_per_launch_us: (last_row - none) / launches -- what is "
                         "left of the gather after overlap (the rollout grid holds every CU: a gather can only run between launches)" % G)
         del g_last
+        # ---- leg "peer_copy" (reported beside `value`, never `value`): the same exchange without a collective KERNEL -- every
+        # rank's buffer mapped into the others with hipIpc handles, the shard copied device to device on a side stream after
+        # every launch (copy engines; the rollout grid holds every compute unit, an RCCL gather can only run between
+        # launches), a bounded flag wait at the end (include/mdpp.h mdpp_peer_*, dist.PeerGatherer)
+        try:
+            from mdp_playground_amd.dist import PeerGatherer
+
+            class _PeerWork:                        # (the interface run() expects of a collective's Work handle)
+                def __init__(self, g, ticket):
+                    self.g, self.ticket = g, ticket
+
+                def is_completed(self):
+                    return False
+
+                def wait(self):                     # buffer reuse: this rank's copies have left
+                    self.g.fence(self.ticket)
+
+                def finish(self):                   # end of the leg: every rank's shard has arrived
+                    self.g.wait(self.ticket)
+
+            class _PeerStart:
+                def __init__(self, g):
+                    self.g = g
+
+                def start(self):
+                    return _PeerWork(self.g, self.g.start())
+
+            peers = [PeerGatherer(o[0][-1], world, rank, dist, slots=2) for o in outs]
+            g_peer = [_PeerStart(g) for g in peers]
+            run(max(args.warmup, 1), g_peer)
+            reps = timed_reps(args.steps, g_peer)
+            el_peer, legs["peer_copy"] = leg_record(reps, args.steps)
+            st = [g.status() for g in peers]
+            legs["peer_copy"].update({"host_enqueue_s": host_enqueue[0], "bytes_per_rank_per_launch": peers[0].nbytes,
+                                      "timeouts": sum(1 for x in st if x[0]), "finegrained_buffers": bool(st[0][1]),
+                                      "what": "hipIpc-mapped buffers, hipMemcpyAsync device to device on a side stream per launch, "
+                                              "flag wait at the end of the timed region"})
+            if diag is not None:
+                diag["peer_copy_added_per_launch_us"] = (el_peer - el_none) * 1e6 / args.steps
+            for g in peers:
+                g.close()
+            del peers, g_peer
+        except Exception as e:                      # a reported extra, never fatal for the contract line
+            legs["peer_copy"] = {"error": repr(e)}
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()
         if args.full_gather_steps > 0 and full_bytes * world * NB < (64 << 30):
@@ -685,6 +729,7 @@ def main():
                        "value_is": "the `last_row` leg (launch + the path's all-gather) for every --gpus, one rank included"
                                    if v_last is not None else "the `none` leg (no process group in this run)"},
             "value_none": v_none, "value_last_row": v_last,
+            "value_peer_copy": legs.get("peer_copy", {}).get("env_steps_per_s"),
             "value_runs": legs["last_row" if v_last is not None else "none"]["env_steps_per_s_runs"], "repeats": R,
             "value_is_median_of_runs": True,
             # False: `value` is NOT the leg with the path's collective (no process group could be made) -- do not

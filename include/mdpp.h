@@ -340,6 +340,8 @@ int mdpp_timer_end(mdpp_env *h, void *stream, float *ms_out);
  *   mdpp_peer_open     maps the other ranks' buffers: `handles` = world x MDPP_PEER_HANDLE_BYTES bytes in rank order
  *   mdpp_peer_push     behind what `stream` has enqueued: shard_dev (shard_bytes on this device) -> row `rank` of slot
  *                      `slot` of EVERY rank's buffer, then `seq` into this rank's flag there (side stream of the handle)
+ *   mdpp_peer_fence    `stream` waits (an event) until THIS rank's copies of the slot's latest push have left: the shard
+ *                      buffer may be overwritten after that
  *   mdpp_peer_wait     `stream` waits until every rank's flag of `slot` is >= seq (a one-wave kernel polling device
  *                      memory, bounded: a timeout sets a status bit per missing rank -- mdpp_peer_status -- never hangs)
  *   mdpp_peer_buffer   device pointer of slot `slot`: [world][shard_bytes], rank-major = global env-id order */
@@ -349,6 +351,7 @@ int mdpp_peer_create(int device, int world, int rank, size_t shard_bytes, int sl
 int mdpp_peer_handle(mdpp_peer *p, void *handle_out);
 int mdpp_peer_open(mdpp_peer *p, const void *handles);
 int mdpp_peer_push(mdpp_peer *p, int slot, const void *shard_dev, uint64_t seq, void *stream);
+int mdpp_peer_fence(mdpp_peer *p, int slot, void *stream);
 int mdpp_peer_wait(mdpp_peer *p, int slot, uint64_t seq, void *stream);
 void *mdpp_peer_buffer(mdpp_peer *p, int slot);
 int mdpp_peer_status(mdpp_peer *p, uint32_t *status_out, int *finegrained_out);

@@ -36,7 +36,7 @@ EXPORTS = [
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
     "mdpp_episode_stats", "mdpp_probe_hbm",
-    "mdpp_peer_create", "mdpp_peer_handle", "mdpp_peer_open", "mdpp_peer_push", "mdpp_peer_wait", "mdpp_peer_buffer",
+    "mdpp_peer_create", "mdpp_peer_handle", "mdpp_peer_open", "mdpp_peer_push", "mdpp_peer_fence", "mdpp_peer_wait", "mdpp_peer_buffer",
     "mdpp_peer_status", "mdpp_peer_last_error", "mdpp_peer_destroy",
 ]
 
@@ -162,6 +162,7 @@ def load():
     L.mdpp_peer_handle.argtypes = [vp, vp]
     L.mdpp_peer_open.argtypes = [vp, vp]
     L.mdpp_peer_push.argtypes = [vp, i32, vp, C.c_uint64, vp]
+    L.mdpp_peer_fence.argtypes = [vp, i32, vp]
     L.mdpp_peer_wait.argtypes = [vp, i32, C.c_uint64, vp]
     L.mdpp_peer_buffer.argtypes = [vp, i32]
     L.mdpp_peer_buffer.restype = vp

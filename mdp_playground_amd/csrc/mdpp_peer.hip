@@ -27,14 +27,16 @@ struct mdpp_peer {
     std::vector<uint8_t *> peer;   // peer[r] = rank r's buffer as mapped here (peer[rank] = buf)
     hipStream_t side;
     hipEvent_t ev;
-    uint64_t *d_seq;               // [slots] the sequence number to publish (source of the flag copies)
+    std::vector<hipEvent_t> ev_push;   // per slot: this rank's copies of the slot's latest push are done
+    uint64_t *h_seq;               // pinned host ring [kSeqRing]: the sequence numbers in flight (sources of the flag copies --
+                                   // a copy from host memory, not a kernel: a kernel could not start beside a rollout that holds every register)
     uint32_t *d_status;            // != 0: a wait ran into its bound
     bool opened, finegrained;
     std::string err;
 };
 
 namespace {
-__global__ void k_peer_set_seq(uint64_t *p, uint64_t v) { *p = v; }
+constexpr int kSeqRing = 256;
 // lane r polls rank r's flag of the slot (system scope: the writers are other devices' copy engines)
 __global__ void k_peer_wait(const uint64_t *flags, int world, uint64_t seq, uint32_t *status, uint32_t max_spins) {
     const int r = threadIdx.x;
@@ -57,9 +59,10 @@ extern "C" int mdpp_peer_create(int device, int world, int rank, size_t shard_by
     if (!out || world < 1 || world > 64 || rank < 0 || rank >= world || shard_bytes == 0 || slots < 1) return MDPP_EINVAL;
     mdpp_peer *p = new mdpp_peer();
     p->device = device; p->world = world; p->rank = rank; p->slots = slots; p->shard = shard_bytes;
-    p->buf = nullptr; p->side = nullptr; p->ev = nullptr; p->d_seq = nullptr; p->d_status = nullptr;
+    p->buf = nullptr; p->side = nullptr; p->ev = nullptr; p->h_seq = nullptr; p->d_status = nullptr;
     p->opened = false; p->finegrained = false;
     p->peer.assign((size_t)world, nullptr);
+    p->ev_push.assign((size_t)slots, nullptr);
     if (hipSetDevice(device) != hipSuccess) { delete p; return MDPP_EHIP; }
     p->flags_off = ((size_t)slots * world * shard_bytes + 255) & ~(size_t)255;
     const size_t bytes = p->flags_off + (size_t)slots * world * sizeof(uint64_t);
@@ -69,9 +72,10 @@ extern "C" int mdpp_peer_create(int device, int world, int rank, size_t shard_by
     bool ok = hipMemset(p->buf, 0, bytes) == hipSuccess &&
               hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) == hipSuccess &&
-              hipMalloc((void **)&p->d_seq, (size_t)slots * sizeof(uint64_t)) == hipSuccess &&
+              hipHostMalloc((void **)&p->h_seq, (size_t)kSeqRing * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&p->d_status, sizeof(uint32_t)) == hipSuccess &&
               hipMemset(p->d_status, 0, sizeof(uint32_t)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    for (int k = 0; ok && k < slots; k++) ok = hipEventCreateWithFlags(&p->ev_push[(size_t)k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { mdpp_peer_destroy(p); return MDPP_EHIP; }
     p->peer[(size_t)rank] = p->buf;
     *out = p;
@@ -116,12 +120,23 @@ extern "C" int mdpp_peer_push(mdpp_peer *p, int slot, const void *shard_dev, uin
         const int r = (p->rank + 1 + k) % p->world;                   // (start with the neighbour: the ranks' copies fan out over different links)
         PCHK(p, hipMemcpyAsync(p->peer[(size_t)r] + row, shard_dev, p->shard, hipMemcpyDeviceToDevice, p->side));
     }
-    hipLaunchKernelGGL(k_peer_set_seq, dim3(1), dim3(1), 0, p->side, p->d_seq + slot, seq);
+    uint64_t *src = p->h_seq + (seq % (uint64_t)kSeqRing);             // (stable until the copies have run: at most kSeqRing pushes in flight)
+    *src = seq;
     const size_t fo = p->flags_off + ((size_t)slot * p->world + (size_t)p->rank) * sizeof(uint64_t);
     for (int k = 0; k < p->world; k++) {                               // (same stream: a flag lands behind its data)
         const int r = (p->rank + 1 + k) % p->world;
-        PCHK(p, hipMemcpyAsync(p->peer[(size_t)r] + fo, p->d_seq + slot, sizeof(uint64_t), hipMemcpyDeviceToDevice, p->side));
+        PCHK(p, hipMemcpyAsync(p->peer[(size_t)r] + fo, src, sizeof(uint64_t), hipMemcpyDefault, p->side));
     }
+    PCHK(p, hipEventRecord(p->ev_push[(size_t)slot], p->side));
+    return MDPP_OK;
+}
+
+// `stream` waits (an event, no kernel) until THIS rank's copies of the slot's latest push have left: the shard buffer may
+// be overwritten after that.
+extern "C" int mdpp_peer_fence(mdpp_peer *p, int slot, void *stream) {
+    if (!p || slot < 0 || slot >= p->slots) return MDPP_EINVAL;
+    PCHK(p, hipSetDevice(p->device));
+    PCHK(p, hipStreamWaitEvent((hipStream_t)stream, p->ev_push[(size_t)slot], 0));
     return MDPP_OK;
 }
 
@@ -157,7 +172,8 @@ extern "C" int mdpp_peer_destroy(mdpp_peer *p) {
         if (r != p->rank && p->peer[(size_t)r]) (void)hipIpcCloseMemHandle(p->peer[(size_t)r]);
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->ev) (void)hipEventDestroy(p->ev);
-    if (p->d_seq) (void)hipFree(p->d_seq);
+    for (hipEvent_t e : p->ev_push) if (e) (void)hipEventDestroy(e);
+    if (p->h_seq) (void)hipHostFree(p->h_seq);
     if (p->d_status) (void)hipFree(p->d_status);
     if (p->buf) (void)hipFree(p->buf);
     delete p;

@@ -165,6 +165,12 @@ class PeerGatherer:
         self._check(self._lib.mdpp_peer_push(self._h, self._slot, self.local.data_ptr(), self._seq, self._stream()), "mdpp_peer_push")
         return (self._slot, self._seq)
 
+    def fence(self, ticket=None):
+        """The current stream waits (an event, no kernel) until this rank's copies of that push have left: `local` may be
+        overwritten after it."""
+        slot, _ = ticket if ticket is not None else (self._slot, self._seq)
+        self._check(self._lib.mdpp_peer_fence(self._h, slot, self._stream()), "mdpp_peer_fence")
+
     def wait(self, ticket=None):
         slot, seq = ticket if ticket is not None else (self._slot, self._seq)
         self._check(self._lib.mdpp_peer_wait(self._h, slot, seq, self._stream()), "mdpp_peer_wait")

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from mdp_playground_amd import RLToyVectorEnv  # noqa: E402
-from mdp_playground_amd.dist import ShardedVectorEnv, shard_bounds  # noqa: E402
+from mdp_playground_amd.dist import PeerGatherer, ShardedVectorEnv, shard_bounds  # noqa: E402
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -52,11 +52,20 @@ for name, c, rng in (("cfg2", cfg, "numpy"), ("cfg2", cfg, "philox"), ("cfg5", c
         acts = torch.randint(0, 8, (K, N), generator=g, device=dev, dtype=torch.int32)
     else:
         acts = torch.rand((K, N, 12), generator=g, device=dev) * 2 - 1
-    for rep in range(2):                                       # twice: the gather buffer is reused
+    # the same gather as peer copies through the C-ABI (mdpp_peer_*: each rank's buffer mapped into the other PROCESS with
+    # hipIpc handles, device-to-device copies on a side stream, a bounded flag wait) -- two processes, one device here
+    pg = PeerGatherer(sh._last, world, rank, dist, slots=2)             # (rollout() leaves its last observation row there)
+    for rep in range(3):                                       # (more pushes than slots: the buffers are reused)
         ob, rw, te, tr, glob = sh.rollout(acts[:, lo:hi].contiguous())
         ob2, rw2, te2, tr2 = whole.rollout(acts)
         assert torch.equal(ob, ob2[:, lo:hi]) and torch.equal(rw, rw2[:, lo:hi]) and torch.equal(te, te2[:, lo:hi]), (name, rng)
         assert torch.equal(glob, ob2[-1]), (name, rng, "gathered last row")
+        peer = pg.wait(pg.start()).flatten(0, 1)
+        torch.cuda.synchronize()
+        assert pg.status()[0] == 0, (name, rng, "a rank's shard never arrived")
+        assert torch.equal(peer, ob2[-1]), (name, rng, "peer-copy gather")
+        dist.barrier()                                         # (nobody pushes into a slot a peer is still comparing)
+    pg.close()
     assert int(sh.env.status().sum()) == 0
     sh.close(); whole.close()
     dist.barrier()

@@ -39,7 +39,9 @@ def test_bench_multi_rank_path_with_two_ranks_on_one_gpu(spawn_fresh):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["envs_per_gpu"] == 4096 and d["config"]["env_steps_per_bench_step"] == 2 * 4096 * 64
-    assert set(d["collective_legs"]) == {"none", "last_row", "full"}
+    assert set(d["collective_legs"]) == {"none", "last_row", "peer_copy", "full"}
+    pc = d["collective_legs"]["peer_copy"]
+    assert "error" not in pc and pc["timeouts"] == 0 and pc["env_steps_per_s"] > 0 and d["value_peer_copy"] == pc["env_steps_per_s"]
     assert d["value"] == d["value_last_row"] == d["collective_legs"]["last_row"]["env_steps_per_s"] > 0
     assert d["value_none"] == d["collective_legs"]["none"]["env_steps_per_s"] >= 0.5 * d["value"]
     assert abs(d["value"] - 2 * 4096 * 64 * 4 / d["elapsed_s"]) <= 1e-6 * d["value"]
