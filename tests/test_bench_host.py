@@ -55,6 +55,7 @@ def test_live_traffic_is_skipped_inside_a_profiled_run(monkeypatch):
     import bench
     monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not spawn")))
+    monkeypatch.setattr(bench, "_run_group", lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not spawn")))
     monkeypatch.setenv("ROCPROFILER_OUTPUT_PATH", "/tmp/x")
     assert bench.live_traffic("cfg2", "numpy", 65536, 512) is None
     monkeypatch.delenv("ROCPROFILER_OUTPUT_PATH")
@@ -98,7 +99,7 @@ def test_live_traffic_all_splits_counter_rows_at_the_marker_dispatches(monkeypat
         with open(__import__("os").path.join(d, "1234_counter_collection.csv"), "w") as f:
             f.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n" + "\n".join(reversed(rows)) + "\n")   # (file order != dispatch order)
         return types.SimpleNamespace(returncode=0)
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "_run_group", lambda cmd, timeout, **kw: fake_run(cmd, **kw).returncode)   # (the child rocprofv3 passes)
     res = bench.live_traffic_all(specs, launches=launches)
     assert set(res) == {"cfg2", "cfg3"}
     assert res["cfg2"]["bytes_per_launch"] == int((2 * 100.0 + 400.0) * 1024)
