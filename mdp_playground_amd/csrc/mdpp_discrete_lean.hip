@@ -112,6 +112,9 @@ namespace mdpp {
 #ifndef MDPP_LEAN_HMIN
 #define MDPP_LEAN_HMIN 16
 #endif
+#ifndef MDPP_LEAN_PHILOX_PN_O2
+#define MDPP_LEAN_PHILOX_PN_O2 1   // Philox transition noise: the chunk's noise nibbles are made by the O2 wave (1) / the H wave (0)
+#endif
 #ifndef MDPP_LEAN_H_LIMBS
 #define MDPP_LEAN_H_LIMBS 0        // (the limb form of PCG64 on the numpy H wave: 137 us per cfg2 launch either way -- H is not what bounds it)
 #endif
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ __align__(16) uint2 lds_col1[IRR ? 16 : 1];    // irrelevant sub-space: action a1, byte s1: P1[s1][a1]
     __shared__ __align__(16) uint64_t lds_T1[IRR ? 8 : 1];    // its rho_0 thresholds
     __shared__ uint32_t lds_hprod[kBlock / 64];               // Philox: chunks published by H wave w
+    __shared__ uint32_t lds_pprod[kBlock / 64];               // Philox transition noise made by the O2 wave: chunks published
     // Wave priorities (s_setprio).  numpy streams: the serial recurrence (E) first, the H wave's PCG64 draws are filler work.
     // Philox streams: the waves that make Philox blocks are the long stages and go first -- H (start states, and with PN
     // the transition-noise words), with RN the O1 wave (normals) -- and the E wave, now the shortest stage, last:
@@ -213,9 +217,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // numpy streams with noise: H (both generators) is the long stage: E 3 O 2 H 0 -> 497 us per cfg2 + noise launch, E 2 O 1 H 3 -> 420
     // (profiles/r04_ablation_npnoise.txt)
     constexpr bool kNpNoise = !PHILOX && NZ != 0;
+    // Philox streams with noise (round 4, the transition-noise nibbles made by the O2 wave): E last, the three waves that make
+    // Philox blocks level -- E 1, O1 2, H 2, O2 2 (3 without reward noise): 191 -> 168 us both noises, 143 -> 138 transition
+    // noise alone (24 combinations: profiles/r04_ablation_lean_philox_noise.txt)
+    constexpr bool kPhNoise = PHILOX && NZ != 0 && MDPP_LEAN_PHILOX_PN_O2;
     constexpr int kPrioE = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_E : kNpNoise ? 2 : !PHILOX ? MDPP_LEAN_PRIO_E : 1;
-    constexpr int kPrioO = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_O : kNpNoise ? 1 : !PHILOX ? MDPP_LEAN_PRIO_O : (PN ? 2 : 3);
-    constexpr int kPrioH = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_H : kNpNoise ? 3 : !PHILOX ? MDPP_LEAN_PRIO_H : (PN ? 3 : 2);
+    constexpr int kPrioO = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_O : kNpNoise ? 1 : !PHILOX ? MDPP_LEAN_PRIO_O : kPhNoise ? 2 : (PN ? 2 : 3);
+    constexpr int kPrioH = MDPP_LEAN_PRIO_FORCED ? MDPP_LEAN_PRIO_H : kNpNoise ? 3 : !PHILOX ? MDPP_LEAN_PRIO_H : kPhNoise ? 2 : (PN ? 3 : 2);
     static_assert(NZ == 0 || (!IRR && !NEXT), "noise on the lean kernel: one sub-space, same-step autoreset");
     __shared__ __align__(16) uint32_t lds_pn[(PN && PHILOX) ? kHChunks : 1][kBlock];       // H -> E: the chunk's 8 transition-noise nibbles
     // numpy streams (header): transition-noise bytes of a chunk; per stream position the draw's value and {start state, kind, words}
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     }
     if (NRN)
         for (int k = tid; k < 256; k += kRoles * kBlock) { lds_kw[k] = make_ulonglong2(d_zig_ki[k], (unsigned long long)__double_as_longlong(d_zig_wi[k])); lds_fi[k] = d_zig_fi[k]; }
-    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; }
+    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; lds_pprod[tid] = 0; }
     if (tid == 0) lds_done = 0;
     __syncthreads();
     {   // lds_V: dword d holds indices 32 d .. 32 d + 31; nibble j of an index = (d * 32 + b) >> 4 j.
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     pk |= (S0Word)(s0 | 8u) << (kEN * 4 * u);
                 }
                 lds_s0[c % kHChunks][l] = pk;
-                if constexpr (PN) {                              // noisy << 3 | j (S <= 8: j <= 6), mdpp_rng.hpp philox_pnoise_index
+                if constexpr (PN && !MDPP_LEAN_PHILOX_PN_O2) {   // noisy << 3 | j (S <= 8: j <= 6), mdpp_rng.hpp philox_pnoise_index
                     uint32_t wp[kChunk], pn = 0;
                     words(kPhiloxPNoiseStream, wp);
 #pragma unroll
@@ -748,7 +756,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         // (numpy transition noise: this wave runs the state space's generator -- a long stage like H)
         // (3 beside an H wave that only keeps the start-state queue, 2 beside one that evaluates the env stream: 159 / 306 us per
         //  cfg2 launch with transition noise / both noises, against 202 / 313 at the O waves' priority)
-        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O2 >= 0 ? MDPP_LEAN_PRIO_O2 : (NPN && !MDPP_LEAN_PRIO_FORCED) ? (NRN ? 2 : 3) : kPrioO);
+        __builtin_amdgcn_s_setprio(MDPP_LEAN_PRIO_O2 >= 0 ? MDPP_LEAN_PRIO_O2 : (NPN && !MDPP_LEAN_PRIO_FORCED) ? (NRN ? 2 : 3)
+                                   : (PN && PHILOX && MDPP_LEAN_PHILOX_PN_O2 && !MDPP_LEAN_PRIO_FORCED) ? (RN ? 2 : 3) : kPrioO);
         auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
@@ -810,6 +819,26 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 if ((l & 63) == 0) wg_store_rel(&lds_hprod[w], (uint32_t)(pc + 1));
             }
         };
+        // Philox transition noise: the chunk's eight nibbles (noisy << 3 | index among the other states) are a function of
+        // (seed, env, tick) alone -- made here, up to kHChunks chunks ahead of the chunk E has finished, instead of on the
+        // H wave, whose chain (start states AND noise words: four Philox blocks per chunk) set the pace
+        constexpr bool PPN = PN && PHILOX && MDPP_LEAN_PHILOX_PN_O2;
+        const uint64_t genv2 = (uint64_t)(a.env_id_offset + (int64_t)i);
+        int ppc = 0;
+        auto make_ppn = [&](int upto_chunk) __attribute__((always_inline)) {
+            for (; ppc < nchunks && ppc < upto_chunk; ppc++) {
+                uint32_t wp[kChunk], pn = 0;
+                chunk_words(a.philox_seed, genv2, (ptick0 + (uint64_t)(ppc * kChunk)) >> 2, (uint32_t)ptick0 & 3u, kPhiloxPNoiseStream, wp);
+#pragma unroll
+                for (int u = 0; u < kChunk; u++) {
+                    const uint32_t e = philox_pnoise_index(wp[u], a.pn_T, a.pn_M);
+                    pn |= ((e & 7u) | ((e >> 5) & 8u)) << (4 * u);
+                }
+                lds_pn[ppc % kHChunks][l] = pn;
+                if ((l & 63) == 0) wg_store_rel(&lds_pprod[w], (uint32_t)(ppc + 1));
+            }
+        };
+        if constexpr (PPN) make_ppn(kHChunks);
         if constexpr (NPN) make_pn(kHChunksNp);
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kChunk;
@@ -824,6 +853,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
             if constexpr (NPN) make_pn(c + 1 + kHChunksNp);          // (E is through chunk c)
+            if constexpr (PPN) make_ppn(c + 1 + kHChunks);
             if (kbase + kChunk <= K) {
                 uint32_t rb[kChunk], rc[kChunk];
 #pragma unroll
@@ -933,7 +963,16 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
             s0c = lds_s0[c % kHChunks][l];
-            if constexpr (PN) pnc = lds_pn[c % kHChunks][l];
+            if constexpr (PN) {
+                if (MDPP_LEAN_PHILOX_PN_O2) {
+                    spins = 0;
+                    while (wg_load_acq(&lds_pprod[w]) < (uint32_t)(c + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
+                    }
+                }
+                pnc = lds_pn[c % kHChunks][l];
+            }
             return;
         }
         const uint64_t rt = __hip_atomic_load(&lds_ring[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -1,9 +1,4 @@
-timeout 1500 python3 -m pytest tests/test_gpu_dist.py -x -q -m gpu > gpurun_out/t6.log 2>&1
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-workloads --no-single-step 2>/dev/null | grep '^{"metric"' > gpurun_out/bench_peer.json
-tail -n 12 gpurun_out/t6.log
-python3 - <<'PY'
-import json
-d=json.loads(open("gpurun_out/bench_peer.json").read())
-print({k:(v.get("env_steps_per_s"), v.get("error"), v.get("timeouts")) for k,v in d["collective_legs"].items()})
-print({k:v for k,v in d["multi_rank_diagnostics"].items() if k not in ("per_rank","note")})
-PY
+timeout 900 python3 tools/soak_noise.py 6 philox > gpurun_out/soakp.log 2>&1; echo "soak rc=$?" >> gpurun_out/soakp.log
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "specialised_kernels_equal_general or lean_rollout_kernel or philox" > gpurun_out/t7.log 2>&1
+for o in '{}' '{"reward_noise": null}' '{"transition_noise": null}'; do MDPP_RNG=philox timeout 300 python3 tools/time_config.py "$o" 65536 512 20 cfg2_noise 2>/dev/null | tail -1; done
+tail -n 7 gpurun_out/soakp.log | cut -c1-220; tail -n 3 gpurun_out/t7.log

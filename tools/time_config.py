@@ -18,7 +18,7 @@ F = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 base = bench.WORKLOADS[sys.argv[5] if len(sys.argv) > 5 else "cfg2"]
 cfg = dict(base["config"], **over)
-env = RLToyVectorEnv(num_envs=N, autoreset="same_step", **cfg)
+env = RLToyVectorEnv(num_envs=N, autoreset="same_step", rng=os.environ.get("MDPP_RNG", "numpy"), **cfg)
 wl = dict(base, config=cfg)
 acts = bench.make_actions(wl, F, N, env.device, 1)
 out = env.alloc_rollout(F)
