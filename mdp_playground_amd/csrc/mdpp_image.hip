@@ -422,10 +422,22 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
         const int A2 = a2 - ((cx - half_p) << 16) + ((wave * 64) << 16);
         const int A5 = a5 - ((cy - half_p) << 16);
         const int nb = bw * bhq;
-        const uint32_t inv = 65536u / (uint32_t)bhq + 1u;   // k / bhq == (k * inv) >> 16 here (k < 2^16 / bhq)
-        const int kx = (int)(((uint32_t)lane * inv) >> 16);
-        int x = X0 + kx, y = 4 * (Q0 + (lane - kx * bhq));        // y = first pixel row of the dword
-        const int d64 = 64 / bhq, r64 = 4 * (64 - d64 * bhq), yend = 4 * Q1, ywrap = 4 * bhq;
+        // Which way the 64 lanes of an iteration walk the box (round 4).  A template row is 256 B = all 64 LDS banks once, so
+        // source pixels in ONE COLUMN of the template sit in one bank: at rotations near 0 / 180 degrees lanes that walk DOWN
+        // an image column read down a template column (13-way bank conflicts on every ds_read_u8: 16.3 us per step of 8 192
+        // images with angles {0, 180} against 11.3 with {90, 270}); near 90 / 270 the same happens to lanes that walk ALONG an
+        // image row.  So the walk follows the map: x fastest where |d xs / d x| >= |d xs / d y|, y fastest otherwise -- the
+        // lanes of an iteration then read along template rows either way (wave-uniform choice, no per-pixel cost).
+#ifndef MDPP_IMG_WALK
+#define MDPP_IMG_WALK 1
+#endif
+        const bool xfast = MDPP_IMG_WALK && (a0 < 0 ? -a0 : a0) >= (a1 < 0 ? -a1 : a1);
+        const int span = xfast ? bw : bhq;                          // lanes per line of the walk
+        const uint32_t inv = 65536u / (uint32_t)span + 1u;         // k / span == (k * inv) >> 16 here (k < 2^16 / span)
+        const int kq = (int)(((uint32_t)lane * inv) >> 16), kr = lane - kq * span;
+        int x = X0 + (xfast ? kr : kq), y = 4 * (Q0 + (xfast ? kq : kr));        // y = first pixel row of the dword
+        const int d64 = 64 / span, r64 = 64 - d64 * span;
+        const int yend = 4 * Q1, ywrap = 4 * bhq;
         for (int k = lane; k < nb; k += 64) {
             const float ddx = (float)x - fcx, ddy = (float)y + 1.5f - fcy;
 #ifndef MDPP_IMG_ABL_ZERO
@@ -442,8 +454,13 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
                 lds_col[__mul24(x, HQ) + (y >> 2) - B0] = word;
             }
 #endif
-            x += d64; y += r64;
-            if (y >= yend) { y -= ywrap; x += 1; }
+            if (xfast) {
+                y += 4 * d64; x += r64;
+                if (x >= X1) { x -= bw; y += 4; }
+            } else {
+                x += d64; y += 4 * r64;
+                if (y >= yend) { y -= ywrap; x += 1; }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
