@@ -617,21 +617,44 @@ def main():
                 def start(self):
                     return _PeerWork(self.g, self.g.start())
 
-            peers = [PeerGatherer(o[0][-1], world, rank, dist, slots=2) for o in outs]
-            g_peer = [_PeerStart(g) for g in peers]
-            run(max(args.warmup, 1), g_peer)
-            reps = timed_reps(args.steps, g_peer)
-            el_peer, legs["peer_copy"] = leg_record(reps, args.steps)
-            st = [g.status() for g in peers]
-            legs["peer_copy"].update({"host_enqueue_s": host_enqueue[0], "bytes_per_rank_per_launch": peers[0].nbytes,
-                                      "timeouts": sum(1 for x in st if x[0]), "finegrained_buffers": bool(st[0][1]),
-                                      "what": "hipIpc-mapped buffers, hipMemcpyAsync device to device on a side stream per launch, "
-                                              "flag wait at the end of the timed region"})
-            if diag is not None:
-                diag["peer_copy_added_per_launch_us"] = (el_peer - el_none) * 1e6 / args.steps
+            def all_ranks_ok(flag):                 # (the leg has collectives inside: every rank takes it, or none does)
+                if world == 1:
+                    return bool(flag)
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+
+            peers, why = [], None
+            try:                                    # local half: buffers + handles
+                peers = [PeerGatherer(o[0][-1], world, rank, dist, slots=2, defer_exchange=True) for o in outs]
+            except Exception as e:
+                why = repr(e)
+            ok = all_ranks_ok(why is None)
+            if ok and world > 1:
+                try:                                # collective half: exchange the handles, map the peers' buffers
+                    for g in peers:
+                        g.exchange(dist)
+                except Exception as e:
+                    why = repr(e)
+                ok = all_ranks_ok(why is None)
+            if ok:
+                g_peer = [_PeerStart(g) for g in peers]
+                run(max(args.warmup, 1), g_peer)
+                reps = timed_reps(args.steps, g_peer)
+                el_peer, legs["peer_copy"] = leg_record(reps, args.steps)
+                st = [g.status() for g in peers]
+                legs["peer_copy"].update({"host_enqueue_s": host_enqueue[0], "bytes_per_rank_per_launch": peers[0].nbytes,
+                                          "timeouts": sum(1 for x in st if x[0]), "finegrained_buffers": bool(st[0][1]),
+                                          "what": "hipIpc-mapped buffers, hipMemcpyAsync device to device on a side stream per launch, "
+                                                  "flag wait at the end of the timed region"})
+                if diag is not None:
+                    diag["peer_copy_added_per_launch_us"] = (el_peer - el_none) * 1e6 / args.steps
+                del g_peer
+            else:
+                legs["peer_copy"] = {"error": why or "the set-up failed on another rank"}
             for g in peers:
                 g.close()
-            del peers, g_peer
+            del peers
         except Exception as e:                      # a reported extra, never fatal for the contract line
             legs["peer_copy"] = {"error": repr(e)}
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch

@@ -71,7 +71,7 @@ constexpr int kNRing = 4;                      // steps of normals buffered per 
 #define MDPP_PHILOX_PRODUCERS 2
 #endif
 #ifndef MDPP_WK_ATTEMPTS
-#define MDPP_WK_ATTEMPTS 8         // walker: fast ziggurat attempts per round
+#define MDPP_WK_ATTEMPTS 7         // walker: fast ziggurat attempts per round (4 / 5 / 6 / 7 / 8 / 10 / 12 / 16 -> 1 604 / 1 465 / 1 479 / 1 443 / 1 506 / 1 520 / 1 570 / 1 709 us)
 #endif
 #ifndef MDPP_WK_GEN_BATCH
 #define MDPP_WK_GEN_BATCH 4        // generator: words per window check (divides kWRing)

@@ -119,7 +119,7 @@ class PeerGatherer:
 
     _ITEM = {1: "|u1", 2: "<u2", 4: "<u4", 8: "<u8"}
 
-    def __init__(self, local: torch.Tensor, world: int, rank: int, dist_module=None, slots: int = 2):
+    def __init__(self, local: torch.Tensor, world: int, rank: int, dist_module=None, slots: int = 2, defer_exchange: bool = False):
         import ctypes as C
         from . import _capi as capi
         if not local.is_contiguous():
@@ -134,13 +134,11 @@ class PeerGatherer:
             raise capi.MdppError(f"mdpp_peer_create failed ({rc})")
         mine = (C.c_uint8 * capi.PEER_HANDLE_BYTES)()
         self._check(self._lib.mdpp_peer_handle(self._h, mine), "mdpp_peer_handle")
-        if self.world > 1:
+        self._mine, self._opened = bytes(mine), self.world == 1
+        if self.world > 1 and not defer_exchange:
             if dist_module is None:
                 raise ValueError("PeerGatherer: world > 1 needs a process group to exchange the handles")
-            allh = [None] * self.world
-            dist_module.all_gather_object(allh, bytes(mine))
-            blob = (C.c_uint8 * (capi.PEER_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(allh))
-            self._check(self._lib.mdpp_peer_open(self._h, blob), "mdpp_peer_open")
+            self.exchange(dist_module)
         self._seq, self._slot = 0, 0
         typestr = self._ITEM[local.element_size()]
         self._views = []
@@ -149,6 +147,18 @@ class PeerGatherer:
             raw = torch.as_tensor(_DevBuf(ptr, (self.world * local.numel(),), typestr), device=local.device)
             self._views.append(raw.view(local.dtype).view((self.world,) + tuple(local.shape)))
         self.out = self._views[0]
+
+    def exchange(self, dist_module):
+        """The COLLECTIVE half of the set-up (every rank must call it): all_gather_object of the buffers' handles, then
+        each rank maps the others' buffers.  `defer_exchange=True` in the constructor leaves it to the caller, who can
+        first agree across ranks that every local half succeeded (bench.py: a rank that failed alone must not leave the
+        others inside a collective)."""
+        C, capi = self._C, self._capi
+        allh = [None] * self.world
+        dist_module.all_gather_object(allh, self._mine)
+        blob = (C.c_uint8 * (capi.PEER_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(allh))
+        self._check(self._lib.mdpp_peer_open(self._h, blob), "mdpp_peer_open")
+        self._opened = True
 
     def _check(self, rc, what):
         if rc:

@@ -33,6 +33,16 @@ VARIANTS = [
     ("park 1, prio all 0", "-DMDPP_WK_PARK=1 -DMDPP_WK_GEN_PRIO=0 -DMDPP_WK_WALKER_PRIO=0 -DMDPP_WK_CONSUMER_PRIO=0"),
     ("park 1, gen batch 8", "-DMDPP_WK_PARK=1 -DMDPP_WK_GEN_BATCH=8"),
     ("park 1, gen batch 2", "-DMDPP_WK_PARK=1 -DMDPP_WK_GEN_BATCH=2"),
+    ("attempts 10", "-DMDPP_WK_ATTEMPTS=10"),
+    ("attempts 12", "-DMDPP_WK_ATTEMPTS=12"),
+    ("attempts 16", "-DMDPP_WK_ATTEMPTS=16"),
+    ("attempts 12, gen batch 8", "-DMDPP_WK_ATTEMPTS=12 -DMDPP_WK_GEN_BATCH=8"),
+    ("attempts 6", "-DMDPP_WK_ATTEMPTS=6"),
+    ("attempts 5", "-DMDPP_WK_ATTEMPTS=5"),
+    ("attempts 7", "-DMDPP_WK_ATTEMPTS=7"),
+    ("attempts 4 (park 1)", "-DMDPP_WK_ATTEMPTS=4"),
+    ("attempts 6, gen batch 2", "-DMDPP_WK_ATTEMPTS=6 -DMDPP_WK_GEN_BATCH=2"),
+    ("attempts 6, gen batch 8", "-DMDPP_WK_ATTEMPTS=6 -DMDPP_WK_GEN_BATCH=8"),
     ("park 2", "-DMDPP_WK_PARK=2"),
     ("park 6", "-DMDPP_WK_PARK=6"),
     ("park 12", "-DMDPP_WK_PARK=12"),
