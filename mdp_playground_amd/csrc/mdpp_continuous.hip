@@ -757,18 +757,15 @@ static void launch_step_t(const ContinuousArgs &a, int K, const float *actions, 
     // move_along_a_line with L <= 16 (rows of 4), rollouts: the L points of every lane mirrored in (dynamic) LDS for the launch
     ContinuousArgs al = a;
     al.line_lds = (NL == 4 && a.line_L > 0 && a.line_L <= 16 && K >= 4) ? 1 : 0;
-    const size_t lds = al.line_lds ? (size_t)a.line_L * kBlock * sizeof(float4) : 0;
-    if (a.philox) {
-        if (lds > 32 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, true, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    size_t lds = al.line_lds ? (size_t)a.line_L * kBlock * sizeof(float4) : 0;
+    const void *kern = a.philox ? (const void *)k_continuous_step<DMAX, OMAX, true, NL> : (const void *)k_continuous_step<DMAX, OMAX, false, NL>;
+    if (!dynamic_lds_ok(kern, lds)) { al.line_lds = 0; lds = 0; }        // (no room: the points stay in HBM)
+    if (a.philox)
         hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, true, NL>), dim3(grid), dim3(kBlock), lds, s, al,
                            K, actions, obs, reward, term, trunc, final_obs);
-    } else {
-        if (lds > 32 * 1024)
-            (void)hipFuncSetAttribute((const void *)k_continuous_step<DMAX, OMAX, false, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else
         hipLaunchKernelGGL((k_continuous_step<DMAX, OMAX, false, NL>), dim3(grid), dim3(kBlock), lds, s, al,
                            K, actions, obs, reward, term, trunc, final_obs);
-    }
 }
 #if MDPP_CONT_TU_LINE8
 // move_along_a_line with 5 to 8 relevant dimensions (state_space_dim <= 12): rows of 8, an 8 x 8 scatter matrix in registers

@@ -414,8 +414,7 @@ bool launch_continuous_line(const ContinuousArgs &a, int K, const float *actions
     const size_t lds = (size_t)a.line_L * kBlock * sizeof(float4);
 #define MDPP_LINE_GO(DD, OO, PH)                                                                                              \
     do {                                                                                                                      \
-        if (lds > 32 * 1024)                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)k_continuous_line_rollout<DD, OO, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (!dynamic_lds_ok((const void *)k_continuous_line_rollout<DD, OO, PH>, lds)) return false;   /* -> k_continuous_step */ \
         hipLaunchKernelGGL((k_continuous_line_rollout<DD, OO, PH>), dim3(grid), dim3(kBlock), lds, s, a, K, actions, obs, reward, \
                            term, trunc, final_obs);                                                                           \
     } while (0)

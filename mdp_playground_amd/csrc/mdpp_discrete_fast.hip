@@ -71,7 +71,6 @@ __global__ __launch_bounds__(HELPER ? 2 * kBlock : kBlock) void k_discrete_rollo
                                                                   uint8_t *__restrict__ term,
                                                                   uint8_t *__restrict__ trunc,
                                                                   void *__restrict__ final_obs) {
-    const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
     __shared__ __align__(16) uint64_t lds_col[16]; // column a of P: nibble s = P[s][a]
     __shared__ __align__(16) uint32_t lds_R[128];  // 4096 reward bits (16^3)
     __shared__ __align__(16) uint64_t lds_T[16];   // rho_0 thresholds (read only by refill rounds)

@@ -180,6 +180,21 @@ __device__ __forceinline__ uint32_t ring_head_now(const A &a, uint64_t ptick) {
     return a.dtick ? (a.delay > 0 ? (uint32_t)(ptick % (uint64_t)a.delay) : 0u) : a.tick;
 }
 
+// A kernel that asks for more than the default 32 KiB of dynamic LDS: raise its limit, and say whether the launch can go
+// ahead (static + dynamic LDS within what a workgroup may have; the attribute call succeeded).  false = the caller takes
+// its path without the LDS mirror.
+inline bool dynamic_lds_ok(const void *kernel, size_t dyn_bytes) {
+    if (dyn_bytes <= 32 * 1024) return true;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) { (void)hipGetLastError(); return false; }
+    int dev = 0, max_lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (fa.sharedSizeBytes + dyn_bytes > (size_t)max_lds) return false;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
 // ---- grid (mdpp_grid.hip) ----
 struct GridArgs {
     int32_t N, G;               // envs; state dimensions (2 or 4)
