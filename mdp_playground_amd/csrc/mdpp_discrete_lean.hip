@@ -121,6 +121,9 @@ namespace mdpp {
 #ifndef MDPP_LEAN_HSLEEP
 #define MDPP_LEAN_HSLEEP 8
 #endif
+#ifndef MDPP_LEAN_ROWS
+#define MDPP_LEAN_ROWS 3           // whole-row stores (header): bit 0 obs and flags, bit 1 the rewards too, bit 2 also in the noise instantiations
+#endif
 namespace lean {
 constexpr int kChunk = MDPP_LEAN_CHUNK;   // steps between hand-off polls; also the action prefetch distance
 constexpr int kDepth = MDPP_LEAN_DEPTH;   // E->O ring depth in steps (multiple of kChunk)
@@ -203,6 +206,20 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ uint32_t lds_prod[kBlock / 64];                // steps published by E wave w
     __shared__ __align__(8) uint32_t lds_cons[kBlock / 64][2]; // steps consumed by the O1 / O2 wave w
     __shared__ uint32_t lds_done;                             // E waves that have finished
+    // Whole-row stores (MDPP_LEAN_ROWS; tools/bench_store.hip: the same bytes leave 10 % faster when one wave writes the
+    // workgroup's whole piece of an output row -- obs 2 KiB, reward 1 KiB, flags 256 B -- than when every wave writes its
+    // own 64 envs of every row): of a chunk's 8 rows the O waves w take rows w and w + 4, for all 256 envs of the block.
+    // The O2 wave reads the other E waves' records (E waits for ALL four O2 waves before it reuses a ring slot); the O1
+    // wave -- its reward path carries state from step to step -- computes its own envs' 8 rewards as before and hands
+    // them to the O2 waves through lds_rw (kRB chunks deep), which store them too.  Blocks with spare lanes (N % 256)
+    // keep the per-lane stores.
+    constexpr bool ROWS2 = (MDPP_LEAN_ROWS & 1) != 0 && !IRR && (NZ == 0 || (MDPP_LEAN_ROWS & 4) != 0);   // (noise: the O waves are long stages there -- no gain, measured)
+    // (rewards through the O2 waves: numpy streams only -- with Philox streams, where E runs at the lowest priority, 124-128 us per cfg2
+    //  launch became 132-133; numpy streams 115-120 -> 112-118; without whole-row stores 129-137, all on one lease)
+    constexpr bool ROWS1 = (MDPP_LEAN_ROWS & 2) != 0 && ROWS2 && !PHILOX && !NRN;
+    constexpr int kRB = 4;                                    // chunks of staged rewards (the O1 waves run this far ahead of the stores)
+    __shared__ __align__(16) float lds_rw[ROWS1 ? kRB : 1][kChunk][ROWS1 ? kBlock : 4];
+    __shared__ __align__(16) uint32_t lds_rprod[kBlock / 64], lds_rcons[kBlock / 64];   // chunks staged by O1 wave w / stored by O2 wave w
     typedef typename std::conditional<IRR, uint64_t, uint32_t>::type S0Word;   // a nibble per tick; with an irrelevant sub-space two
     __shared__ __align__(16) S0Word lds_s0[PHILOX ? kHChunks : 1][kBlock];     // Philox: H -> E, the chunk's 8 start states
     __shared__ __align__(16) uint2 lds_col1[IRR ? 16 : 1];    // irrelevant sub-space: action a1, byte s1: P1[s1][a1]
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     }
     if (NRN)
         for (int k = tid; k < 256; k += kRoles * kBlock) { lds_kw[k] = make_ulonglong2(d_zig_ki[k], (unsigned long long)__double_as_longlong(d_zig_wi[k])); lds_fi[k] = d_zig_fi[k]; }
-    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; lds_pprod[tid] = 0; }
+    if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; lds_pprod[tid] = 0; lds_rprod[tid] = 0; lds_rcons[tid] = 0; }
     if (tid == 0) lds_done = 0;
     __syncthreads();
     {   // lds_V: dword d holds indices 32 d .. 32 d + 31; nibble j of an index = (d * 32 + b) >> 4 j.
@@ -338,6 +355,15 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     const uint32_t eblk = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t i = eblk * kBlock + l;
     const uint32_t N = (uint32_t)a.N;
+    const bool rows = ROWS2 && (N % (uint32_t)kBlock) == 0u;       // (every wave of every block is there)
+    const uint32_t blk0 = eblk * kBlock, ln = (uint32_t)l & 63u;
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane(w);
+    // min over the four waves' counters (two 64-bit LDS reads)
+    auto min4 = [&](const uint32_t *p) -> uint32_t {
+        const uint64_t x = __hip_atomic_load((const uint64_t *)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t y = __hip_atomic_load((const uint64_t *)p + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return min(min((uint32_t)x, (uint32_t)(x >> 32)), min((uint32_t)y, (uint32_t)(y >> 32)));
+    };
     if (i >= N) {                                   // ragged last block: its spare lanes leave (every wave that stays keeps
         // lane 0, which publishes the hand-off counters; no barrier follows); an E wave that leaves entirely counts as done
         if (role == 0 && (l & 63) == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -671,7 +697,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         const uint32_t r4 = (uint32_t)ptick0 & 3u;
         float zc[kChunk] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};         // RN: the chunk's reward normals
         const bool plain = a.scale == 1.0 && a.shift == 0.0;                        // (wave-uniform)
-        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, double z) {
+        auto emit = [&](uint32_t ra, uint32_t rb, uint32_t rc, uint32_t so, double z, float *stage) {
             uint32_t bit = lds_V[(ra >> 5) & 2047u] >> (ra & 31u);                   // reward bit, NaN-gated (:1822)
             uint32_t out;
             if (DELAY) {                                                             // FIFO (:1970-1973)
@@ -703,6 +729,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                            : *(const float *)(rselb + (((out << 1) | tb) << 2));
             }
             if (nextmode) rout = (ra != rb) ? 0.0f : rout;                           // the reset call returns reward 0
+            if (stage) { *stage = rout; return; }
 #if defined(MDPP_ABL_NOSTORE) || defined(MDPP_ABL_NOREW)
             status ^= __float_as_uint(rout) & 0x100u;
 #else
@@ -723,6 +750,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }
+            const bool rowc = ROWS1 && rows && kbase + kChunk <= K;                  // (wave-uniform)
             if (kbase + kChunk <= K) {
                 uint32_t ra[kChunk], rb[kChunk], rc[kChunk];
 #pragma unroll
@@ -734,17 +762,28 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 double zd[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) zd[u] = NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u];    // (numpy streams: the normal E found)
+                if (rowc && c >= kRB) {                     // the staging rows of chunk c - kRB: stored by all four O2 waves
+                    uint32_t sp2 = 0;
+                    while (min4(lds_rcons) < (uint32_t)(c - kRB + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++sp2 > kSpinLimit) { status |= kStatusInternal; break; }
+                    }
+                }
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N, zd[u]);
+                for (int u = 0; u < kChunk; u++)
+                    emit(ra[u], rb[u], rc[u], (uint32_t)(kbase + u) * N, zd[u], rowc ? &lds_rw[ROWS1 ? (c % kRB) : 0][u][ROWS1 ? l : 0] : nullptr);
             } else {
 #pragma unroll
                 for (int u = 0; u < kChunk; u++)
                     if (kbase + u < K)
                         emit(lds_rec[0][(kbase + u) % KD][l], lds_rec[1][(kbase + u) % KD][l],
                              lds_rec[2][(kbase + u) % KD][l], (uint32_t)(kbase + u) * N,
-                             NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u]);
+                             NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u], nullptr);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][0], upto);
+            if constexpr (ROWS1) {
+                if (rowc && (l & 63) == 0) wg_store_rel(&lds_rprod[w], (uint32_t)(c + 1));
+            }
         }
         ((uint32_t *)&a.state[i])[3] = ring;
         if (status) atomicOr(&a.status[i], status);
@@ -760,6 +799,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                                    : (PN && PHILOX && MDPP_LEAN_PHILOX_PN_O2 && !MDPP_LEAN_PRIO_FORCED) ? (RN ? 2 : 3) : kPrioO);
         auto r_obs = __builtin_amdgcn_make_buffer_rsrc(obs, 0, total * (OBS64 ? 8u : 4u) * (uint32_t)kEN, kPRsrc);
         auto r_term = __builtin_amdgcn_make_buffer_rsrc((void *)term, 0, total, kPRsrc);
+        auto r_rew2 = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kPRsrc);
         auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kPRsrc);
         const uint32_t v1 = i, v4 = i * 4u, v8 = i * 8u, v16 = i * 16u;
         auto emit = [&](uint32_t rb, uint32_t rc, uint32_t so) {
@@ -854,7 +894,55 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             }
             if constexpr (NPN) make_pn(c + 1 + kHChunksNp);          // (E is through chunk c)
             if constexpr (PPN) make_ppn(c + 1 + kHChunks);
-            if (kbase + kChunk <= K) {
+            if (ROWS2 && rows && kbase + kChunk <= K) {
+                // rows w and w + 4 of the chunk, the block's 256 envs (header "whole-row stores"): all four E waves are through it
+                uint32_t sp2 = 0;
+                while (min4(lds_prod) < upto) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++sp2 > kSpinLimit) { status |= kStatusInternal; break; }
+                }
+                if constexpr (ROWS1) {              // ... and all four O1 waves have staged its rewards
+                    while (min4(lds_rprod) < (uint32_t)(c + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++sp2 > kSpinLimit) { status |= kStatusInternal; break; }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < kChunk / 4; h++) {
+                    const uint32_t kk = (uint32_t)kbase + ws + 4u * (uint32_t)h, slot = kk % (uint32_t)KD;
+#if !defined(MDPP_ABL_NOSTORE) && !defined(MDPP_ABL_NOREW)
+                    if constexpr (ROWS1) {          // (whole offset in the VGPR: mdpp_discrete_quiet.hip's hazard note)
+                        const u32x4 v = *(const u32x4 *)&lds_rw[c % kRB][ws + 4u * (uint32_t)h][4u * ln];
+                        __builtin_amdgcn_raw_buffer_store_b128(v, r_rew2, (blk0 + 4u * ln) * 4u + kk * N * 4u, 0, MDPP_LEAN_ST_AUX);
+                    }
+#endif
+#ifdef MDPP_ABL_NOSTORE
+                    status ^= lds_rec[1][slot][l] & 0x100u;
+                    continue;
+#endif
+#ifndef MDPP_ABL_NOOBS
+                    if (OBS64) {                    // lane ln: envs 2 ln, 2 ln + 1 and 128 + 2 ln, 129 + 2 ln -- each store 1 KiB in one piece
+                        const u32x2 b0 = *(const u32x2 *)&lds_rec[1][slot][2u * ln];
+                        const u32x2 b1 = *(const u32x2 *)&lds_rec[1][slot][128u + 2u * ln];
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{b0.x & 7u, 0u, b0.y & 7u, 0u}, r_obs, (blk0 + 2u * ln) * 8u + kk * N * 8u, 0, MDPP_LEAN_ST_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{b1.x & 7u, 0u, b1.y & 7u, 0u}, r_obs, (blk0 + 128u + 2u * ln) * 8u + kk * N * 8u, 0, MDPP_LEAN_ST_AUX);
+                    } else {
+                        const u32x4 b = *(const u32x4 *)&lds_rec[1][slot][4u * ln];
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{b.x & 7u, b.y & 7u, b.z & 7u, b.w & 7u}, r_obs, (blk0 + 4u * ln) * 4u + kk * N * 4u, 0, MDPP_LEAN_ST_AUX);
+                    }
+#endif
+#ifndef MDPP_ABL_NOBYTES
+                    const u32x4 c4 = *(const u32x4 *)&lds_rec[2][slot][4u * ln];
+                    // byte j of the flag words = the flag of env 4 ln + j: bit 7 of byte 0 / byte 2 of its record
+                    const uint32_t t01 = __builtin_amdgcn_perm(c4.y, c4.x, 0x0c0c0400u), t23 = __builtin_amdgcn_perm(c4.w, c4.z, 0x04000c0cu);
+                    const uint32_t tw = ((t01 | t23) >> 7) & 0x01010101u;
+                    __builtin_amdgcn_raw_buffer_store_b32(tw, r_term, blk0 + 4u * ln, kk * N, MDPP_LEAN_ST_AUX_BYTES);
+                    uint32_t uw = 0u;
+                    if (HASMAX) uw = __builtin_amdgcn_perm(c4.y, c4.x, 0x0c0c0602u) | __builtin_amdgcn_perm(c4.w, c4.z, 0x06020c0cu);
+                    __builtin_amdgcn_raw_buffer_store_b32(uw, r_trunc, blk0 + 4u * ln, kk * N, MDPP_LEAN_ST_AUX_BYTES);
+#endif
+                }
+            } else if (kbase + kChunk <= K) {
                 uint32_t rb[kChunk], rc[kChunk];
 #pragma unroll
                 for (int u = 0; u < kChunk; u++) {
@@ -866,7 +954,10 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             } else {
                 for (int k = kbase; k < K; k++) emit(lds_rec[1][k % KD][l], lds_rec[2][k % KD][l], (uint32_t)k * N);
             }
-            if ((l & 63) == 0) wg_store_rel(&lds_cons[w][1], upto);
+            if ((l & 63) == 0) {
+                wg_store_rel(&lds_cons[w][1], upto);
+                if (ROWS1) wg_store_rel(&lds_rcons[w], (uint32_t)(c + 1));
+            }
         }
         if constexpr (NPN) {                        // un-draw the words of a ragged last chunk: s_prev = (s - inc) * M^-1 (mod 2^128)
             gs.to(sp);
@@ -1132,7 +1223,12 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             for (;;) {
                 const uint64_t cc = __hip_atomic_load((const uint64_t *)&lds_cons[w][0], __ATOMIC_ACQUIRE,
                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (min((uint32_t)cc, (uint32_t)(cc >> 32)) >= must) break;
+                uint32_t have = min((uint32_t)cc, (uint32_t)(cc >> 32));
+                if (rows) {                         // whole-row stores: every O2 wave reads this wave's records
+#pragma unroll
+                    for (int j = 0; j < kBlock / 64; j++) have = min(have, wg_load_acq(&lds_cons[j][1]));
+                }
+                if (have >= must) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }
             }

@@ -1,0 +1,176 @@
+// What the WIDTH of the per-lane stores does to the write rate of the discrete rollout's output pattern (GPU box):
+//   hipcc --offload-arch=gfx950 -O3 tools/bench_store.hip -o gpurun_out/bench_store && ./gpurun_out/bench_store
+// K rows of N envs, one lane per env, one wave per SIMD (256 workgroups of 256 lanes), an LCG step per row instead of the env's
+// arithmetic.  The four output rows of a step -- int64 obs, float reward, term bytes, trunc bytes -- are written either as the
+// rollout does today (one element per lane and step) or TRANSPOSED inside groups of g lanes over g steps, so that one store
+// instruction carries g elements per lane: lane r of a group writes the group's g envs of row k0 + r.  The bytes and the
+// addresses written are the same; only the shape of the store instructions changes.  (Values are junk: timing only.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT, class T>
+__device__ __forceinline__ void st(T *p, T v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// one stream: element size E bytes, G lanes grouped (G elements per lane and store, one store per G steps)
+template <int E, int G, bool NT>
+__device__ __forceinline__ void put(uint8_t *base, int N, int i, int k, uint32_t s) {
+    if (G == 1) {
+        uint8_t *p = base + ((size_t)k * N + i) * E;
+        if (E == 8) st<NT>((u32x2 *)p, u32x2{s & 7u, 0u});
+        else if (E == 4) st<NT>((uint32_t *)p, s);
+        else st<NT>(p, (uint8_t)(s & 1u));
+        return;
+    }
+    if ((k % G) != G - 1) return;
+    const int r = i % G, j0 = i - r, k0 = k - (G - 1);
+    uint8_t *p = base + ((size_t)(k0 + r) * N + j0) * E;
+    constexpr int W = E * G;
+    if (W == 16) st<NT>((u32x4 *)p, u32x4{s, s >> 1, s >> 2, s >> 3});
+    else if (W == 8) st<NT>((u32x2 *)p, u32x2{s, s >> 1});
+    else if (W == 4) st<NT>((uint32_t *)p, s);
+    else if (W == 32) { st<NT>((u32x4 *)p, u32x4{s, s >> 1, s >> 2, s >> 3}); st<NT>((u32x4 *)p + 1, u32x4{s, s >> 1, s >> 2, s >> 3}); }
+}
+
+// the workgroup's 256 envs x 4 steps transposed (through LDS in a real kernel): wave w writes the workgroup's whole piece of
+// row k0 + w -- obs 2 KiB (two 16-byte stores per lane), reward 1 KiB (one), flags 256 B each (4 bytes per lane)
+template <bool NT>
+__device__ __forceinline__ void put_block(uint8_t *obs, uint8_t *rew, uint8_t *term, uint8_t *trunc, int N, int k, uint32_t s) {
+    if ((k & 3) != 3) return;
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63, b0 = blockIdx.x * 256;
+    const size_t row = (size_t)(k - 3 + w) * N + b0;
+    st<NT>((u32x4 *)(obs + row * 8 + ln * 16), u32x4{s, 0u, s >> 3, 0u});
+    st<NT>((u32x4 *)(obs + row * 8 + 1024 + ln * 16), u32x4{s >> 1, 0u, s >> 4, 0u});
+    st<NT>((u32x4 *)(rew + row * 4 + ln * 16), u32x4{s, s >> 1, s >> 2, s >> 3});
+    st<NT>((uint32_t *)(term + row + ln * 4), s >> 8);
+    st<NT>((uint32_t *)(trunc + row + ln * 4), s >> 9);
+}
+
+template <int OG, int RG, int FG, bool NT, int PRE>
+__global__ __launch_bounds__(256) void k(const int32_t *act, uint8_t *obs, uint8_t *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s = (uint32_t)i;
+    int pre[PRE > 0 ? PRE : 1];
+    if (PRE > 0) {
+#pragma unroll
+        for (int u = 0; u < PRE; u++) pre[u] = act[(size_t)u * N + i];
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int k = k0 + u;
+            int a = 0;
+            if (PRE > 0) {
+                a = pre[u % PRE];
+                const int kn = k + PRE < K ? k + PRE : K - 1;
+                pre[u % PRE] = act[(size_t)kn * N + i];
+            }
+            s = s * 1664525u + 1013904223u + (uint32_t)a;
+            if (OG == 0) { put_block<NT>(obs, rew, term, trunc, N, k, s); continue; }
+            put<8, OG ? OG : 1, NT>(obs, N, i, k, s);
+            put<4, RG, NT>(rew, N, i, k, s >> 3);
+            put<1, FG, NT>(term, N, i, k, s >> 8);
+            put<1, FG, NT>(trunc, N, i, k, s >> 9);
+        }
+    }
+}
+
+// plain fills of one buffer: SHAPE 0 one 16-byte store per lane, one-shot grid; 1 four stores per lane 4 KiB apart (16 KiB per
+// workgroup), one-shot grid; 2 the same tiles, persistent grid of 8 workgroups per CU (mdpp_probe_hbm's fill)
+template <int SHAPE, bool NT>
+__global__ __launch_bounds__(256) void k_fill(u32x4 *d, size_t n) {
+    const u32x4 v = u32x4{threadIdx.x, blockIdx.x, 3u, 4u};
+    if (SHAPE == 0) { const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; if (i < n) st<NT>(d + i, v); return; }
+    const size_t ntile = n / 1024;
+    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const size_t i = t * 1024 + threadIdx.x;
+        st<NT>(d + i, v); st<NT>(d + i + 256, v); st<NT>(d + i + 512, v); st<NT>(d + i + 768, v);
+    }
+}
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static int N = 65536, K = 512;
+static uint8_t *d_obs, *d_rew, *d_term, *d_trunc;
+static int32_t *d_act[4];
+
+template <int OG, int RG, int FG, bool NT, int PRE>
+static void run(const char *label, bool rotate) {
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k<OG, RG, FG, NT, PRE>), dim3(N / 256), dim3(256), 0, 0, d_act[rotate ? w & 3 : 0], d_obs, d_rew, d_term, d_trunc, N, K);
+        CHK(hipEventRecord(e0, 0));
+        const int L = 20;
+        for (int w = 0; w < L; w++) hipLaunchKernelGGL((k<OG, RG, FG, NT, PRE>), dim3(N / 256), dim3(256), 0, 0, d_act[rotate ? w & 3 : 0], d_obs, d_rew, d_term, d_trunc, N, K);
+        CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / L < best) best = ms / L;
+    }
+    const double bytes = (double)N * K * (14.0 + (PRE > 0 ? 4.0 : 0.0));
+    printf("  obs x%-2d rew x%-2d flags x%-2d %-7s %-22s %8.1f us per launch  %7.1f GB/s\n", OG, RG, FG, NT ? "nt" : "default", label, best * 1e3, bytes / (best * 1e-3) / 1e9);
+    fflush(stdout);
+    CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+}
+
+template <int SHAPE, bool NT>
+static void fill(u32x4 *d, size_t nbytes) {
+    const size_t n = nbytes / 16;
+    const unsigned grid = SHAPE == 0 ? (unsigned)(n / 256) : SHAPE == 1 ? (unsigned)(n / 1024) : 2048u;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_fill<SHAPE, NT>), dim3(grid), dim3(256), 0, 0, d, n);
+    CHK(hipEventRecord(e0, 0));
+    for (int w = 0; w < 10; w++) hipLaunchKernelGGL((k_fill<SHAPE, NT>), dim3(grid), dim3(256), 0, 0, d, n);
+    CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  fill %zu MiB, shape %d, %-7s %7.1f GB/s\n", nbytes >> 20, SHAPE, NT ? "nt" : "default", (double)nbytes * 10 / (ms * 1e-3) / 1e9);
+    CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+}
+
+template <int OG, int RG, int FG>
+static void all() {
+    run<OG, RG, FG, true, 0>("no reads", false);
+    run<OG, RG, FG, false, 0>("no reads", false);
+    run<OG, RG, FG, true, 8>("reads, one tensor", false);
+    run<OG, RG, FG, true, 8>("reads, rotating", true);
+    run<OG, RG, FG, false, 8>("reads, rotating", true);
+}
+
+int main() {
+    const size_t tot = (size_t)N * K;
+    CHK(hipMalloc(&d_obs, tot * 8)); CHK(hipMalloc(&d_rew, tot * 4)); CHK(hipMalloc(&d_term, tot)); CHK(hipMalloc(&d_trunc, tot));
+    for (int j = 0; j < 4; j++) { CHK(hipMalloc(&d_act[j], tot * 4)); CHK(hipMemset(d_act[j], j, tot * 4)); }
+    {
+        u32x4 *big; CHK(hipMalloc(&big, (size_t)1 << 30));
+        printf("fills (shape 0: one 16-byte store per lane, one-shot; 1: 16 KiB tiles, one-shot; 2: 16 KiB tiles, persistent grid)\n");
+        fill<0, false>(big, (size_t)1 << 30); fill<0, true>(big, (size_t)1 << 30);
+        fill<1, false>(big, (size_t)1 << 30); fill<1, true>(big, (size_t)1 << 30);
+        fill<2, false>(big, (size_t)1 << 30); fill<2, true>(big, (size_t)1 << 30);
+        CHK(hipFree(big));
+    }
+    printf("N %d envs, K %d rows per launch; x g = g elements per lane and store (g lanes x g steps transposed)\n", N, K);
+    all<1, 1, 1>();
+    all<1, 2, 1>();
+    all<1, 4, 1>();
+    all<1, 4, 4>();
+    all<1, 4, 8>();
+    all<1, 4, 16>();
+    all<2, 4, 8>();
+    all<2, 4, 16>();
+    all<2, 2, 8>();
+    all<1, 1, 8>();
+    all<1, 1, 16>();
+    all<4, 4, 16>();
+    printf("obs x0 = the workgroup's 256 envs x 4 steps transposed: each wave writes one whole row piece\n");
+    all<0, 4, 4>();
+    return 0;
+}
