@@ -118,8 +118,14 @@ namespace mdpp {
 #ifndef MDPP_LEAN_H_LIMBS
 #define MDPP_LEAN_H_LIMBS 0        // (the limb form of PCG64 on the numpy H wave: 137 us per cfg2 launch either way -- H is not what bounds it)
 #endif
+#ifndef MDPP_LEAN_H_SSTAB
+#define MDPP_LEAN_H_SSTAB 0        // numpy H wave without noise: start state by the word's top 11 bits from lds_sstab (1) / eight compares (0)
+#endif
 #ifndef MDPP_LEAN_HSLEEP
 #define MDPP_LEAN_HSLEEP 8
+#endif
+#ifndef MDPP_LEAN_XCD_CONTIG
+#define MDPP_LEAN_XCD_CONTIG 1     // every XCD steps one contiguous eighth of the envs (0: blocks in launch order, round-robin over the XCDs)
 #endif
 #ifndef MDPP_LEAN_ROWS
 #define MDPP_LEAN_ROWS 3           // whole-row stores (header): bit 0 obs and flags, bit 1 the rewards too, bit 2 also in the noise instantiations
@@ -251,7 +257,8 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ uint32_t lds_hhead[NRN ? kBlock : 1], lds_epos[NRN ? kBlock : 1];   // positions made by H / reached by E
     // the two categorical searches of H by the word's top bits: byte = the answer where the bucket holds no threshold, 0xFF
     // where it does (then the thresholds are counted: a few lanes per thousand)
-    __shared__ uint8_t lds_sstab[(NRN || NPN) ? 2048 : 1];            // start state by r >> 53
+    constexpr bool HSS = MDPP_LEAN_H_SSTAB && !PHILOX && NZ == 0 && !IRR;
+    __shared__ uint8_t lds_sstab[(NRN || NPN || HSS) ? 2048 : 1];     // start state by r >> 53
     __shared__ uint8_t lds_pntab[NPN ? 4096 : 1];                     // a | b << 4 by r >> 52
     __shared__ ulonglong2 lds_kw[NRN ? 256 : 1];                       // ziggurat {ki, wi}
     __shared__ double lds_fi[NRN ? 256 : 1];
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         lds_R[k] = wd;
     }
     if (tid < kBlock) { lds_ring[tid] = 0; lds_head[tid] = 0; if (NRN) { lds_hhead[tid] = 0; lds_epos[tid] = 0; } }
-    if (NRN || NPN) {
+    if (NRN || NPN || HSS) {
         for (uint32_t k = tid; k < 2048u; k += kRoles * kBlock) {
             const uint64_t lo = (uint64_t)k << 53, hi = lo + ((1ULL << 53) - 1ULL);       // the bucket's words
             uint32_t c0 = 0, c1 = 0;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     //  writes the word back at the end of the launch, and with K <= kDepth it could get there before O1 starts)
     uint32_t steps_at_launch = 0;
     {
-        const uint32_t eb0 = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+        const uint32_t eb0 = (MDPP_LEAN_XCD_CONTIG && (gridDim.x & 7u) == 0u) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
         const uint32_t i0 = eb0 * kBlock + l;
         if (EVN && role == 1 && i0 < (uint32_t)a.N) steps_at_launch = ((const uint32_t *)&a.state[i0])[2] & 0x7FFFFFFFu;
     }
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Give every XCD one contiguous eighth of the
     // envs, so that what its L2 writes back per output row is one contiguous range, not every eighth
     // 256-env piece of it.
-    const uint32_t eblk = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t eblk = (MDPP_LEAN_XCD_CONTIG && (gridDim.x & 7u) == 0u) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t i = eblk * kBlock + l;
     const uint32_t N = (uint32_t)a.N;
     const bool rows = ROWS2 && (N % (uint32_t)kBlock) == 0u;       // (every wave of every block is there)
@@ -619,10 +626,22 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 #else
         auto draw = [&](Pcg64 &gg) -> uint32_t {
 #endif
-            const uint64_t m = gg.next64() >> 11;
+            const uint64_t r0 = gg.next64();
+            const uint64_t m = r0 >> 11;
             uint32_t s0 = 0;
+            if constexpr (HSS) {                                 // (the bucket's answer; 0xFF = a threshold inside it: count)
+                s0 = lds_sstab[(uint32_t)(r0 >> 53)];
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(s0 == 0xFFu) != 0, 0)) {
+                    if (s0 == 0xFFu) {
+                        s0 = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
+                        for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) s0 += (lds_T[j] <= m) ? 1u : 0u;
+            }
             if (IRR) {                                           // relevant, then irrelevant, like reset() (:2255-2264)
                 const uint64_t m1 = gg.next64() >> 11;
                 uint32_t s1 = 0;
