@@ -702,6 +702,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== O1: reward path
     if (role == 1) {
+#ifdef MDPP_ABL_NOO1
+        return;
+#endif
         __builtin_amdgcn_s_setprio(kPrioO);
         auto r_rew = __builtin_amdgcn_make_buffer_rsrc((void *)reward, 0, total * 4u, kPRsrc);
         const uint32_t v4 = i * 4u;
@@ -811,6 +814,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
 
     // =============================================================== O2: observation, terminated, truncated
     if (role == 2) {
+#ifdef MDPP_ABL_NOO2
+        return;
+#endif
         // (numpy transition noise: this wave runs the state space's generator -- a long stage like H)
         // (3 beside an H wave that only keeps the start-state queue, 2 beside one that evaluates the env stream: 159 / 306 us per
         //  cfg2 launch with transition noise / both noises, against 202 / 313 at the O waves' priority)
@@ -1243,10 +1249,20 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 const uint64_t cc = __hip_atomic_load((const uint64_t *)&lds_cons[w][0], __ATOMIC_ACQUIRE,
                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
                 uint32_t have = min((uint32_t)cc, (uint32_t)(cc >> 32));
+#ifdef MDPP_ABL_NOO1
+                have = (uint32_t)(cc >> 32);
+#endif
+#ifdef MDPP_ABL_NOO2
+                have = (uint32_t)cc;
+#ifdef MDPP_ABL_NOO1
+                have = must;
+#endif
+#else
                 if (rows) {                         // whole-row stores: every O2 wave reads this wave's records
 #pragma unroll
                     for (int j = 0; j < kBlock / 64; j++) have = min(have, wg_load_acq(&lds_cons[j][1]));
                 }
+#endif
                 if (have >= must) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kSpinLimit) { status |= kStatusInternal; break; }

@@ -95,6 +95,64 @@ __global__ __launch_bounds__(256) void k_fill(u32x4 *d, size_t n) {
     }
 }
 
+// The rollout kernel's own shape without its arithmetic: 1024-thread workgroups, waves 0-3 ("E") load the block's actions 4 B per
+// lane, AH chunks of 8 steps ahead, and publish a chunk counter; waves 8-11 ("O2") wait for it and write rows w and w + 4 of the
+// chunk for the block's 256 envs (obs 2 x 16 B per lane, reward 16 B, flags 4 B each); the other eight waves leave at once.
+template <int AH, bool NT>
+__global__ __launch_bounds__(1024) void k_lean_like(const int32_t *act, uint8_t *obs, uint8_t *rew, uint8_t *term, uint8_t *trunc, int N, int K) {
+    __shared__ uint32_t prod[4];
+    __shared__ uint32_t ring[32][256];
+    const int role = threadIdx.x >> 8, l = threadIdx.x & 255, w = l >> 6, ln = l & 63;
+    const uint32_t eblk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int i = eblk * 256 + l;
+    if (threadIdx.x < 4) prod[threadIdx.x] = 0;
+    __syncthreads();
+    if (role == 0) {
+        int q[AH][8];
+#pragma unroll
+        for (int c = 0; c < AH; c++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[c][u] = act[(size_t)(c * 8 + u) * N + i];
+        uint32_t s = (uint32_t)i;
+        for (int c0 = 0; c0 < K / 8; c0 += AH) {
+#pragma unroll
+            for (int j = 0; j < AH; j++) {
+                const int c = c0 + j;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    s = s * 1664525u + 1013904223u + (uint32_t)q[j][u];
+                    ring[(c * 8 + u) & 31][l] = s;
+                    const int kn = (c + AH) * 8 + u;
+                    q[j][u] = act[(size_t)(kn < K ? kn : K - 1) * N + i];
+                }
+                if (ln == 0) __hip_atomic_store(&prod[w], (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
+    if (role != 2) return;
+    for (int c = 0; c < K / 8; c++) {
+        for (;;) {
+            uint32_t m = 0xFFFFFFFFu;
+            for (int j = 0; j < 4; j++) { const uint32_t p = __hip_atomic_load(&prod[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); m = p < m ? p : m; }
+            if (m >= (uint32_t)(c + 1)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = c * 8 + w + 4 * h;
+            const size_t row = (size_t)k * N + eblk * 256;
+            const uint32_t a0 = ring[k & 31][2 * ln], a1 = ring[k & 31][2 * ln + 1], b0 = ring[k & 31][128 + 2 * ln], b1 = ring[k & 31][129 + 2 * ln];
+            st<NT>((u32x4 *)(obs + row * 8 + ln * 16), u32x4{a0 & 7u, 0u, a1 & 7u, 0u});
+            st<NT>((u32x4 *)(obs + row * 8 + 1024 + ln * 16), u32x4{b0 & 7u, 0u, b1 & 7u, 0u});
+            const u32x4 r4 = *(const u32x4 *)&ring[k & 31][4 * ln];
+            st<NT>((u32x4 *)(rew + row * 4 + ln * 16), r4);
+            st<NT>((uint32_t *)(term + row + ln * 4), (r4.x >> 7) & 0x01010101u);
+            st<NT>((uint32_t *)(trunc + row + ln * 4), (r4.y >> 9) & 0x01010101u);
+        }
+    }
+}
+
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static int N = 65536, K = 512;
@@ -136,6 +194,26 @@ static void fill(u32x4 *d, size_t nbytes) {
     CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
 }
 
+template <int AH, bool NT>
+static void lean_like(bool rotate) {
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL((k_lean_like<AH, NT>), dim3(N / 256), dim3(1024), 0, 0, d_act[rotate ? w & 3 : 0], d_obs, d_rew, d_term, d_trunc, N, K);
+        CHK(hipEventRecord(e0, 0));
+        const int L = 20;
+        for (int w = 0; w < L; w++) hipLaunchKernelGGL((k_lean_like<AH, NT>), dim3(N / 256), dim3(1024), 0, 0, d_act[rotate ? w & 3 : 0], d_obs, d_rew, d_term, d_trunc, N, K);
+        CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms / L < best) best = ms / L;
+    }
+    printf("  rollout-shaped (E waves load %d chunks ahead, O2 waves store rows) %-7s %-18s %8.1f us per launch  %7.1f GB/s\n", AH, NT ? "nt" : "default",
+           rotate ? "reads, rotating" : "reads, one tensor", best * 1e3, (double)N * K * 18.0 / (best * 1e-3) / 1e9);
+    fflush(stdout);
+    CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+}
+
 template <int OG, int RG, int FG>
 static void all() {
     run<OG, RG, FG, true, 0>("no reads", false);
@@ -158,6 +236,14 @@ int main() {
         CHK(hipFree(big));
     }
     printf("N %d envs, K %d rows per launch; x g = g elements per lane and store (g lanes x g steps transposed)\n", N, K);
+    if (getenv("LEAN_ONLY")) {
+        for (int r = 0; r < 2; r++) {
+            lean_like<4, true>(true); lean_like<4, true>(false); lean_like<4, false>(true);
+            lean_like<2, true>(true); lean_like<8, true>(true);
+            all<0, 4, 4>();
+        }
+        return 0;
+    }
     all<1, 1, 1>();
     all<1, 2, 1>();
     all<1, 4, 1>();
