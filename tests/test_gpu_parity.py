@@ -2268,6 +2268,12 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
 
 
 @pytest.mark.parametrize("workload,over,flag,N,F", [
+    # whole-row stores of the lean kernel (one wave writes the block's piece of a row; the flag bytes of four envs packed with
+    # v_perm_b32, rewards staged through LDS): the TimeLimit byte, int32 observations, F with a ragged last chunk, next-step mode
+    ("cfg2", {"max_episode_steps": 13}, "NO_LEAN", 65536, 132),
+    ("cfg2", {"max_episode_steps": 13, "dtype_o": np.int32, "delay": 0}, "NO_LEAN,NO_PIPE", 32768, 128),
+    ("cfg2", {"autoreset": "next_step", "max_episode_steps": 9}, "NO_LEAN", 32768, 132),
+    ("cfg2", {"rng": "philox", "max_episode_steps": 13, "reward_every_n_steps": 1}, "NO_LEAN", 32768, 132),
     ("cfg2_noise", {}, "NO_LEAN,NO_QUIET", 65536, 128),              # numpy streams: lean kernel with noise (H: both streams, by position) vs general
     ("cfg2_noise", {}, "NO_LEAN", 65536, 128),                       # ... vs the noisy quiet kernel (two roles)
     ("cfg2_noise", {"reward_noise": None, "max_episode_steps": 13}, "NO_LEAN", 32768, 128),          # transition noise only (start-state queue + noise bytes)
