@@ -29,6 +29,12 @@ namespace mdpp {
 #ifndef MDPP_CAHEAD
 #define MDPP_CAHEAD 4
 #endif
+#ifndef MDPP_CONT_ROWS
+#define MDPP_CONT_ROWS 1           // rewards and flags leave as whole rows of the workgroup (see "whole-row stores" in the kernel)
+#endif
+#ifndef MDPP_CBUFS
+#define MDPP_CBUFS 1               // noise-free rollouts: action rows in flight = MDPP_CBUFS x MDPP_CAHEAD (buffers rotated by NAME: a
+#endif                             // single loop over 8 or more rows is past the compiler's unroll budget and lands in scratch)
 constexpr int kCAheadQuiet = MDPP_CAHEAD, kCAheadNoise = 1; // noisy steps take microseconds: one row ahead hides the load, and a
                                                             // deeper ring would not unroll (step body too large) -> scratch
 constexpr int kCRsrc = 0x00020000;
@@ -143,6 +149,20 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     __shared__ uint32_t s_gp[WALK ? kBlock : 1], s_rp[WALK ? kBlock : 1], s_done[kBlock / 64];   // words made / taken per lane
     __shared__ uint32_t s_prod[NPROD][kBlock / 64], s_cons[kBlock / 64];     // steps made by producer p / steps consumed
     __shared__ __align__(16) float s_tr[(D > 4 ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
+    // Whole-row stores of the small outputs (round 4).  A lane's reward is 4 bytes and its flags one byte each: stored per lane,
+    // a wave instruction writes 256 / 64 / 64 bytes -- 6 of the step's 102 bytes that took 8-19 % of a cfg3 launch (573-630 us
+    // without them against 685-706).  Without helper waves: the rewards and flags of a GROUP of four steps are staged in LDS
+    // (three buffers), and wave w writes the block's whole piece of row k0 + w of a group -- 1 KiB of rewards (16 B per lane),
+    // 256 B of each flag array (4 B per lane) -- one group LATER, when the other three waves have long staged theirs: per-wave
+    // counters (groups staged / groups stored), no barrier (a barrier per group took back most of the gain: 662 -> 641 us).
+    constexpr bool CROWS = MDPP_CONT_ROWS && !HELPER;
+    constexpr int kRS = kBlock / 64;            // steps per group = waves per workgroup
+    constexpr int kRBufs = 3;
+    __shared__ __align__(16) float s_rw[CROWS ? kRBufs * kRS * kBlock : 4];
+    __shared__ __align__(16) uint8_t s_tw[CROWS ? kRBufs * kRS * kBlock : 4], s_uw[CROWS ? kRBufs * kRS * kBlock : 4];
+    __shared__ __align__(16) uint32_t s_rprod[kBlock / 64], s_rcons[kBlock / 64];
+    if (CROWS && threadIdx.x < kBlock / 64) { s_rprod[threadIdx.x] = 0; s_rcons[threadIdx.x] = 0; }
+    if (CROWS) __syncthreads();
     const int tid = threadIdx.x;
     if (ZIG && !WALK) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
     if (WALK) {
@@ -621,6 +641,8 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     auto r_trunc = __builtin_amdgcn_make_buffer_rsrc((void *)trunc, 0, total, kCRsrc);
     const uint32_t v1 = i, v4 = i * 4u, vrow = i * (uint32_t)(D * 4);
     const bool full_wave = (i - (i & 63u)) + 64u <= N;     // all 64 lanes of this wave own an env
+    const bool crows = CROWS && (N % (uint32_t)kBlock) == 0u;            // whole-row stores: every wave of every block is there
+    const int k_rows = K - K % kRS;                        // ... for the steps in whole groups (the rest: per-lane stores)
     const uint32_t row_bytes = N * (uint32_t)(D * 4);
 
     const float amax = a.amax32, smax = a.smax32, radius = a.radius32;
@@ -702,10 +724,42 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         }
     };
 
-    float pre[kCAhead][D];
+    constexpr int kCBufs = NOISE ? 1 : MDPP_CBUFS;
+    static_assert(kCBufs >= 1 && kCBufs <= 3, "one to three named buffers");
+    float pre[kCAhead][D], pre1[kCBufs > 1 ? kCAhead : 1][D], pre2[kCBufs > 2 ? kCAhead : 1][D];
 #pragma unroll
     for (int u = 0; u < kCAhead; u++) load_row(u, pre[u]);
+    if constexpr (kCBufs > 1) {
+#pragma unroll
+        for (int u = 0; u < kCAhead; u++) load_row(kCAhead + u, pre1[u]);
+    }
+    if constexpr (kCBufs > 2) {
+#pragma unroll
+        for (int u = 0; u < kCAhead; u++) load_row(2 * kCAhead + u, pre2[u]);
+    }
 
+    auto rmin4 = [&](const uint32_t *p) -> uint32_t {
+        const uint64_t x = __hip_atomic_load((const uint64_t *)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t y = __hip_atomic_load((const uint64_t *)p + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return min(min((uint32_t)x, (uint32_t)(x >> 32)), min((uint32_t)y, (uint32_t)(y >> 32)));
+    };
+    static_assert(kBlock / 64 == 4, "four per-wave counters");
+    // this wave's row (w) of group gg, the block's 256 envs: all four waves have staged the group
+    auto flush_rows = [&](int gg) __attribute__((always_inline)) {
+        uint32_t spins = 0;
+        while (rmin4(s_rprod) < (uint32_t)(gg + 1)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kCSpinLimit) { status |= kCStatusInternal; break; }
+        }
+        const uint32_t wvu = (uint32_t)__builtin_amdgcn_readfirstlane(wv), l64 = (uint32_t)ln & 63u;
+        const uint32_t src = ((uint32_t)(gg % kRBufs) * kRS + wvu) * kBlock + 4u * l64;
+        const uint32_t row = ((uint32_t)(gg * kRS) + wvu) * N + (i - (uint32_t)ln) + 4u * l64;
+        // (128-bit store: whole offset in the VGPR, see mdpp_discrete_quiet.hip on the store-data hazard)
+        __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4 *)&s_rw[CROWS ? src : 0], r_rew, row * 4u, 0, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b32(*(const uint32_t *)&s_tw[CROWS ? src : 0], r_term, row, 0, MDPP_ST_NT);
+        __builtin_amdgcn_raw_buffer_store_b32(*(const uint32_t *)&s_uw[CROWS ? src : 0], r_trunc, row, 0, MDPP_ST_NT);
+        if (l64 == 0) __hip_atomic_store(&s_rcons[wv], (uint32_t)(gg + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     auto step = [&](const float (&act)[D], int k) {
         const uint32_t so = (uint32_t)k * N;
         float nxt[D];
@@ -955,34 +1009,68 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                         r_obs, vrow + 16u * q + so * (uint32_t)(D * 4), 0, MDPP_ST_NT);
             }
         }
+#ifdef MDPP_ABL_NORF
+        status ^= (__float_as_uint(r) + (done ? 1 : 0) + (tr ? 1 : 0)) & 0x100u;
+        return;
+#endif
+        if constexpr (CROWS) {
+            if (crows && k < k_rows) {                  // (wave-uniform)
+                const int grp = k / kRS, slot = k & (kRS - 1);
+                if (slot == 0 && grp >= kRBufs) {       // the buffer held group grp - 3: stored by all four waves?
+                    uint32_t spins = 0;
+                    while (rmin4(s_rcons) < (uint32_t)(grp - kRBufs + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kCSpinLimit) { status |= kCStatusInternal; break; }
+                    }
+                }
+                const int at = ((grp % kRBufs) * kRS + slot) * kBlock + ln;
+                s_rw[at] = r; s_tw[at] = (uint8_t)(done ? 1 : 0); s_uw[at] = (uint8_t)(tr ? 1 : 0);
+                if (slot == kRS - 1) {
+                    if ((ln & 63) == 0) __hip_atomic_store(&s_rprod[wv], (uint32_t)(grp + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (grp >= 1) flush_rows(grp - 1);
+                }
+                return;
+            }
+        }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), r_rew, v4, so * 4u, MDPP_ST_NT);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), r_term, v1, so, MDPP_ST_NT);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(tr ? 1 : 0), r_trunc, v1, so, MDPP_ST_NT);
     };
 
-    const int nfull = K / kCAhead;
-    for (int c = 0; c < nfull; c++) {
+    // chunk c from buffer `buf`, which is refilled with chunk c + kCBufs
+    auto chunk = [&](float (&buf)[kCAhead][D], int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < kCAhead; u++) {
             float act[D];
 #pragma unroll
-            for (int d = 0; d < D; d++) act[d] = pre[u][d];
-            load_row(c * kCAhead + kCAhead + u, pre[u]);   // refill this slot for the next chunk
+            for (int d = 0; d < D; d++) act[d] = buf[u][d];
+            load_row((c + kCBufs) * kCAhead + u, buf[u]);
             step(act, c * kCAhead + u);
         }
+    };
+    const int nfull = K / kCAhead, ngrp = nfull / kCBufs;
+    for (int gq = 0; gq < ngrp; gq++) {
+        chunk(pre, gq * kCBufs);
+        if constexpr (kCBufs > 1) chunk(pre1, gq * kCBufs + 1);
+        if constexpr (kCBufs > 2) chunk(pre2, gq * kCBufs + 2);
     }
-    for (int k = nfull * kCAhead; k < K; k++) {
+    // the last full chunks and the ragged tail: rows already in the buffers (loads past the end were clamped)
+    for (int k = ngrp * kCBufs * kCAhead; k < K; k++) {
         float act[D];
-        const int u = k - nfull * kCAhead;
+        const int rel = k - ngrp * kCBufs * kCAhead, b = rel / kCAhead, u = rel % kCAhead;
 #pragma unroll
         for (int uu = 0; uu < kCAhead; uu++)
             if (uu == u) {
 #pragma unroll
-                for (int d = 0; d < D; d++) act[d] = pre[uu][d];
+                for (int d = 0; d < D; d++)
+                    act[d] = (kCBufs > 2 && b == 2) ? pre2[kCBufs > 2 ? uu : 0][d] : (kCBufs > 1 && b == 1) ? pre1[kCBufs > 1 ? uu : 0][d] : pre[uu][d];
             }
         step(act, k);
     }
 
+    if constexpr (CROWS) {
+        if (crows && k_rows > 0) flush_rows(k_rows / kRS - 1);          // (the last group)
+    }
 #pragma unroll
     for (int k = 0; k <= ORDER; k++)
 #pragma unroll
