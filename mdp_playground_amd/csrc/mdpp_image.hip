@@ -374,6 +374,13 @@ __global__ __launch_bounds__(kBlock) void k_image_obs(ImageArgs a, long M, const
 #define MDPP_IMG_ST_AUX 0
 #endif
 struct TplRegs { u32x4 v[4]; };          // a padded template (<= 64 rows x 64 B), 4 chunks per lane
+// LDS accesses by INTEGER address (round 4): indexing the dynamic LDS array costs a v_add_u32 of its (link-time) base per access --
+// four per evaluated dword here; an address-space-3 pointer made from an integer is used as it is
+typedef __attribute__((address_space(3))) const uint8_t *lds_u8p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
+#ifndef MDPP_IMG_LEAN_LOOP
+#define MDPP_IMG_LEAN_LOOP 1       // the trimmed evaluation loop (integer LDS addresses, integer near test in half pixels, byte-address columns)
+#endif
 
 __device__ __forceinline__ TplRegs load_tpl(const ImageArgs &a, uint32_t tix, int lane) {
     const u32x4 *gt = (const u32x4 *)(a.tplp_data + (size_t)tix * ((size_t)a.tplp * 64));
@@ -409,6 +416,17 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
     const int X0 = (int)(r.hi[2] & 0xFFFFu), X1 = (int)(r.hi[2] >> 16);
     const int Q0 = (int)(r.hi[3] & 0xFFFFu), Q1 = (int)(r.hi[3] >> 16);
     const float rr = (float)R + 4.5f, rr2 = rr * rr;          // near radius of the general renderer
+    (void)rr2;
+    // ... in integers (MDPP_IMG_LEAN_LOOP): doubled coordinates against the centre rounded to half pixels (off by <= 0.36 px), radius
+    // R + 5 -- a superset of the float test's dwords inside the same bounding box, and every pixel of a dword it lets through
+    // still lies within R + 5.36 + 1.5 of the centre: inside the zero border (R + 8) after the map's rounding
+    int ncx2, ncy2;                              // (scalar registers; through asm: the compiler folds a readfirstlane of a uniform value away
+    {                                            //  and keeps the value in a vector register, which costs the loop two instructions per test)
+        const int vx = -(int)rintf(2.0f * fcx), vy = 3 - (int)rintf(2.0f * fcy);
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ncx2) : "v"(vx));
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ncy2) : "v"(vy));
+    }
+    const int rr2i = (2 * R + 10) * (2 * R + 10);
     const int HQ = a.H >> 2;
     const int bw = X1 - X0, bhq = Q1 - Q0;
     // LDS columns hold image dwords [B0, B1), 16-byte chunks [C0, C1)
@@ -420,7 +438,15 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
         // bx >> 16 = xs - (cx - half_p) + 64 wave, by >> 16 = ys - (cy - half_p)
         const int half_p = a.tplp >> 1;
         const int A2 = a2 - ((cx - half_p) << 16) + ((wave * 64) << 16);
-        const int A5 = a5 - ((cy - half_p) << 16);
+        int A5 = a5 - ((cy - half_p) << 16);
+        // (integer LDS addresses: the template rows start at LDS offset lbase -- 0 for this kernel, which has no static LDS; a
+        //  multiple of 256 folds into the row accumulator)
+        const uint32_t lbase = (uint32_t)(uintptr_t)(lds_u8p)lds;
+        if (MDPP_IMG_LEAN_LOOP) {
+            if (__builtin_expect((lbase & 255u) != 0u || lbase > 0xC000u, 0)) __builtin_trap();
+            A5 += (int)(lbase >> 8) << 16;
+        }
+        const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32p)lds_col - 4u * (uint32_t)B0, HQ4 = 4u * (uint32_t)HQ;
         const int nb = bw * bhq;
         // Which way the 64 lanes of an iteration walk the box (round 4).  A template row is 256 B = all 64 LDS banks once, so
         // source pixels in ONE COLUMN of the template sit in one bank: at rotations near 0 / 180 degrees lanes that walk DOWN
@@ -439,8 +465,25 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
         const int d64 = 64 / span, r64 = 64 - d64 * span;
         const int yend = 4 * Q1, ywrap = 4 * bhq;
         for (int k = lane; k < nb; k += 64) {
-            const float ddx = (float)x - fcx, ddy = (float)y + 1.5f - fcy;
 #ifndef MDPP_IMG_ABL_ZERO
+#if MDPP_IMG_LEAN_LOOP
+            const int dx2 = 2 * x + ncx2, dy2 = 2 * y + ncy2;        // (v_lshl_add_u32 with a scalar)
+            if (dx2 * dx2 + dy2 * dy2 <= rr2i) {          // (plain multiplies: __mul24 sign-extends its operands from 24 bits first, two shifts each)
+                const int bx = A2 + __mul24(a0, x) + __mul24(a1, y);      // |a_i| <= 2^16, x, y < 2^23
+                const int by = A5 + __mul24(a3, x) + __mul24(a4, y);
+                uint32_t px[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    // byte 2 of each accumulator = its integer part (< 256): address = uy * 256 + ux
+                    const uint32_t addr = __builtin_amdgcn_perm((uint32_t)(by + b * a4), (uint32_t)(bx + b * a1), 0x0c0c0602u);
+                    px[b] = *(lds_u8p)(uintptr_t)addr;
+                }
+                const uint32_t word = (px[0] | (px[1] << 8)) | ((px[2] | (px[3] << 8)) << 16);
+                // (y is a multiple of 4: the dword's byte address in the columns is x * 4 HQ + y)
+                *(lds_u32p)(uintptr_t)(__umul24((uint32_t)x, HQ4) + (uint32_t)y + cbase) = word;
+            }
+#else
+            const float ddx = (float)x - fcx, ddy = (float)y + 1.5f - fcy;
             if (ddx * ddx + ddy * ddy <= rr2) {
                 const int bx = A2 + __mul24(a0, x) + __mul24(a1, y);      // |a_i| <= 2^16, x, y < 2^23
                 const int by = A5 + __mul24(a3, x) + __mul24(a4, y);
@@ -453,6 +496,7 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
                 }
                 lds_col[__mul24(x, HQ) + (y >> 2) - B0] = word;
             }
+#endif
 #endif
             if (xfast) {
                 y += 4 * d64; x += r64;
