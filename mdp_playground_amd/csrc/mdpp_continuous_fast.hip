@@ -139,13 +139,15 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     constexpr bool WALK = HELPER && !PHILOX && NPROD == 2;
     __shared__ uint64_t s_ki[ZIG && !WALK ? 256 : 1];
     __shared__ double s_wi[ZIG && !WALK ? 256 : 1], s_fi[ZIG ? 256 : 1];
-    __shared__ ulonglong2 s_kw[WALK ? 256 : 1];                 // WALK: {ki, wi} side by side (one 16-byte lookup per attempt)
+    __shared__ ulonglong2 s_kw[WALK ? 256 : 1];                 // WALK: {ki, wi * 2^52} side by side (one 16-byte lookup per attempt)
     constexpr int NPS = D + 1;                  // normals per step slot (D transition + 1 reward)
     static_assert(NPROD == 1 || HELPER, "several helper waves need HELPER");
     static_assert(NPROD == 1 || PHILOX || NPROD == 2, "numpy streams: generator + walker");
     typedef typename std::conditional<PHILOX, float, double>::type ZT;       // (Philox normals are float32 values)
-    __shared__ ZT s_z[HELPER ? (WALK ? kWRing : kNRing * NPS) * kBlock : 1];       // [slot][draw][lane]; WALK: [normal count & 31][lane]
-    __shared__ uint64_t s_raw[WALK ? kWRing * kBlock : 1];       // WALK: [stream position & 31][lane]
+    // (WALK: both rings are 64 KiB and 64 KiB-aligned -- a slot's byte address is then ONE v_and_or_b32 of the count, the ring mask
+    //  and a per-lane constant)
+    __shared__ __attribute__((aligned(WALK ? 65536 : 16))) ZT s_z[HELPER ? (WALK ? kWRing : kNRing * NPS) * kBlock : 1];       // [slot][draw][lane]; WALK: [normal count & 31][lane]
+    __shared__ __attribute__((aligned(WALK ? 65536 : 16))) uint64_t s_raw[WALK ? kWRing * kBlock : 1];       // WALK: [stream position & 31][lane]
     __shared__ uint32_t s_gp[WALK ? kBlock : 1], s_rp[WALK ? kBlock : 1], s_done[kBlock / 64];   // words made / taken per lane
     __shared__ uint32_t s_prod[NPROD][kBlock / 64], s_cons[kBlock / 64];     // steps made by producer p / steps consumed
     __shared__ __align__(16) float s_tr[(D > 4 ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     const int tid = threadIdx.x;
     if (ZIG && !WALK) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
     if (WALK) {
-        for (int k = tid; k < 256; k += 3 * kBlock) { s_kw[k] = make_ulonglong2(d_zig_ki[k], __double_as_longlong(d_zig_wi[k])); s_fi[k] = d_zig_fi[k]; }
+        for (int k = tid; k < 256; k += 3 * kBlock) { s_kw[k] = make_ulonglong2(d_zig_ki[k], __double_as_longlong(d_zig_wi[k]) + (52LL << 52));   /* {ki, W = wi * 2^52 (exact)} */ s_fi[k] = d_zig_fi[k]; }
         if (tid < kBlock) { s_gp[tid] = 0; s_rp[tid] = 0; }
     }
     if (HELPER && tid < kBlock / 64) {
@@ -252,10 +254,17 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         const uint32_t lane8 = (uint32_t)ln * 8u;
         constexpr uint32_t SM = (uint32_t)(kWRing - 1) << 11;
         char *rawb = (char *)s_raw;
-        char *zb = (char *)s_z;
+        typedef __attribute__((address_space(3))) const uint64_t *lds_cu64p;
+        typedef __attribute__((address_space(3))) double *lds_f64p;
+        // (integer LDS addresses: ring base | lane * 8 in one register; the bases have their low 16 bits clear)
+        const uint32_t raw0 = (uint32_t)(uintptr_t)(lds_cu64p)s_raw | lane8, z0 = (uint32_t)(uintptr_t)(lds_f64p)s_z | lane8;
         auto raw_at = [&](uint32_t c11) __attribute__((always_inline)) -> uint64_t {          // c11 = count << 11
-            return *(const uint64_t *)(rawb + ((c11 & SM) | lane8));
+            return *(lds_cu64p)(uintptr_t)((c11 & SM) | raw0);
         };
+        // ... as two 32-bit halves (a 64-bit value invites the compiler to shift it as one: v_lshrrev_b64 for every field)
+        typedef unsigned int wk_u32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const wk_u32x2 *lds_cu2p;
+        auto raw_at2 = [&](uint32_t c11) __attribute__((always_inline)) -> wk_u32x2 { return *(lds_cu2p)(uintptr_t)((c11 & SM) | raw0); };
         if (tid >= 2 * kBlock) {
             // ---------------- generator lane: the words of the env's noise stream, in order, by position -----------------
             // Word p of the launch goes to s_raw[p & 31][lane]; a batch is made when it fits the lane's window (the walker
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             uint32_t n = 0, rp = 0, pub = 0, published = 0, thr = nd, spins = 0, hstatus = 0;
             bool parked = false;
             uint64_t pr = 0;
-            auto z_put = [&](uint32_t c11, double v) __attribute__((always_inline)) { *(double *)(zb + ((c11 & SM) | lane8)) = v; };
+            auto z_put = [&](uint32_t c11, double v) __attribute__((always_inline)) { *(lds_f64p)(uintptr_t)((c11 & SM) | z0) = v; };
             for (;;) {
                 const uint32_t cons = __hip_atomic_load(&s_cons[wv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef MDPP_ABL_WK_NOCONS
@@ -340,23 +349,28 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                 const uint64_t bcan = __builtin_amdgcn_ballot_w64(can);
                 if (bcan != 0) {
                     const uint32_t allowed = can ? min(min(nlim - n, gp - rp), (uint32_t)NB) : 0u;
-                    uint64_t wd[NB];
+                    wk_u32x2 wd[NB];
 #pragma unroll
-                    for (int u = 0; u < NB; u++) wd[u] = raw_at((rp << 11) + ((uint32_t)u << 11));
+                    for (int u = 0; u < NB; u++) wd[u] = raw_at2((rp << 11) + ((uint32_t)u << 11));
                     ulonglong2 kw[NB];
 #pragma unroll
-                    for (int u = 0; u < NB; u++) kw[u] = s_kw[(uint32_t)wd[u] & 0xffu];
+                    for (int u = 0; u < NB; u++) kw[u] = s_kw[wd[u].x & 0xffu];
                     uint32_t bad = 1u << allowed;
                     double xs[NB];
 #pragma unroll
                     for (int u = 0; u < NB; u++) {
-                        const uint64_t rabs = (wd[u] >> 9) & 0x000fffffffffffffULL;
-                        // (double)rabs, exactly: 2^52 + rabs has rabs as its mantissa
-                        const double t = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
-                        const double x = t * __longlong_as_double((long long)kw[u].y);
-                        // sign = bit 8 of the word -> bit 63 (x, or -x: numpy's `if (sign & 0x1) x = -x`)
-                        xs[u] = __longlong_as_double((long long)((uint64_t)__double_as_longlong(x) ^
-                                                                 ((uint64_t)((uint32_t)wd[u] & 0x100u) << 55)));
+                        // rabs = (r >> 9) & (2^52 - 1) in two 32-bit operations (not a 64-bit shift and a mask)
+                        const uint32_t wlo = wd[u].x, whi = wd[u].y;
+                        const uint32_t rlo = __builtin_amdgcn_alignbit(whi, wlo, 9), rhi = (whi >> 9) & 0xFFFFFu;
+                        const uint64_t rabs = (uint64_t)rlo | ((uint64_t)rhi << 32);
+                        // rabs * wi in ONE rounding: m = 1 + rabs 2^-52 (rabs as the mantissa of a number in [1, 2)), W = wi 2^52:
+                        // fma(m, W, -W) = round((m - 1) W) = round(rabs wi) -- what numpy's `rabs * wi_double[idx]` rounds to
+                        const double mm = __longlong_as_double((long long)(rabs | 0x3FF0000000000000ULL));
+                        const double W = __longlong_as_double((long long)kw[u].y);
+                        const double x = __builtin_fma(mm, W, -W);
+                        // sign = bit 8 of the word -> bit 63 (x >= +0: numpy's `if (sign & 0x1) x = -x`)
+                        const uint64_t xb = (uint64_t)__double_as_longlong(x);
+                        xs[u] = __longlong_as_double((long long)(((uint64_t)(((uint32_t)(xb >> 32) & 0x7FFFFFFFu) | ((wlo << 23) & 0x80000000u)) << 32) | (uint32_t)xb));   // (v_bfi_b32)
 #ifndef MDPP_ABL_WK_NOSLOW
                         bad |= (rabs < kw[u].x) ? 0u : (1u << u);
 #else
@@ -387,7 +401,8 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
                         double x = 0.0, y = 0.0;
                         if (act && !tail) {
                             const uint64_t rabs = (pr >> 9) & 0x000fffffffffffffULL;
-                            x = (double)rabs * __longlong_as_double((long long)s_kw[idx].y);
+                            const double W = __longlong_as_double((long long)s_kw[idx].y);          // (as in the fast attempts)
+                            x = __builtin_fma(__longlong_as_double((long long)(rabs | 0x3FF0000000000000ULL)), W, -W);
                             x = ((uint32_t)pr & 0x100u) ? -x : x;
                             const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
                             rp += 1u;
@@ -799,8 +814,12 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
 #pragma unroll
             for (int d = 0; d < D; d++) nacc[d] = act[d] * inv_inertia;
         } else {
+            // (a real branch: without the volatile statement the compiler computes the D IEEE divisions -- ten instructions each --
+            //  on BOTH paths and selects: 120 of the ~300 vector instructions of a cfg5 consumer step, for nothing at inertia 1)
+            float dv = a.inertia32;
+            asm volatile("" : "+v"(dv));
 #pragma unroll
-            for (int d = 0; d < D; d++) nacc[d] = act[d] / a.inertia32;
+            for (int d = 0; d < D; d++) nacc[d] = act[d] / dv;
         }
         // (the whole wave's actions admitted -- the normal case: no per-element selects; otherwise a lane whose
         // action was rejected keeps every derivative, :1671-1679)
