@@ -1029,7 +1029,7 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
         const int PADW = 8, t = c.img_tpl_size, tp = t + 2 * PADW, half = t / 2;
         const int span = 2 * c.img_r_max + 9 + 4 + 1;      // columns of the near circle's box, at most
         bool ok = (c.img_h % 4 == 0) && ((size_t)c.img_w * c.img_h) % 16 == 0 && tp <= 64 &&
-                  (size_t)c.img_w * c.img_h <= (1u << 20) && span * (c.img_h / 4) + 8 <= 1536 &&
+                  (size_t)c.img_w * c.img_h <= (1u << 20) && span * (c.img_h / 4) + 8 + 4 <= 1536 &&      /* (+ 4: the zero chunk of render_fast_store) */
                   c.img_r_max <= (c.img_w < c.img_h ? c.img_w : c.img_h) / 2 - 1;
         const size_t ntpl = S * n_radii * n_cls_x * n_cls_y;
         for (size_t k = 0; ok && k < ntpl; k++) {

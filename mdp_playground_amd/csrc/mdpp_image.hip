@@ -518,6 +518,22 @@ __device__ __forceinline__ void render_fast_store(const ImageArgs &a, const ColR
                                                   uint8_t *__restrict__ out, int lane) {
     const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, a.W * a.H, 0x00020000);
     const int nchunk = (a.W * a.H) >> 4;
+#if MDPP_IMG_LEAN_LOOP
+    // (round 4) every lane reads unconditionally: chunks outside the box come from the wave's ZERO CHUNK (the last 16 bytes of its
+    // column buffer, cleared once per kernel) -- one v_cndmask_b32 on the address instead of an exec-mask branch around each read,
+    // so the seven LDS reads of an image are in flight together instead of one wait per store
+    typedef __attribute__((address_space(3))) const u32x4 *lds_cu128p;
+    const uint32_t cb = (uint32_t)(uintptr_t)(lds_u32p)const_cast<uint32_t *>(lds_col), zaddr = cb + 4u * (uint32_t)(a.coldw - 4);
+    const uint32_t nin = (uint32_t)(cr.C1 - cr.C0);
+    auto put = [&](int c) {
+        const uint32_t rel = (uint32_t)(c - cr.C0);
+        const u32x4 v = *(lds_cu128p)(uintptr_t)(rel < nin ? cb + 16u * rel : zaddr);
+#ifdef MDPP_IMG_ABL_NOSTORE
+        if (v.x == 0x12345678u)
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, c * 16, 0, MDPP_IMG_ST_AUX);   // beyond the descriptor: dropped
+    };
+#else
     auto put = [&](int c) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         if ((uint32_t)(c - cr.C0) < (uint32_t)(cr.C1 - cr.C0)) v = *(const u32x4 *)(lds_col + 4 * (c - cr.C0));
@@ -526,6 +542,7 @@ __device__ __forceinline__ void render_fast_store(const ImageArgs &a, const ColR
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(v, r_out, c * 16, 0, MDPP_IMG_ST_AUX);   // beyond the descriptor: dropped
     };
+#endif
     if (NST > 0) {
 #pragma unroll
         for (int u = 0; u < NST; u++) put(lane + 64 * u);
@@ -547,6 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
     extern __shared__ __align__(16) uint8_t lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;
+    if (MDPP_IMG_LEAN_LOOP && lane < 4) lds_col[a.coldw - 4 + lane] = 0u;      // the wave's zero chunk (render_fast_store)
     // Work distribution (round 3): a wave CLAIMS its next image from a counter instead of walking j, j + (waves in the grid),
     // ...: the next batch's state / draw / record kernels run beside this kernel on a few CUs, images differ in cost, and with
     // a static split the slowest wave sets the kernel's duration (a 32-step render: 427 us alone, 465-475 us beside them).
@@ -681,7 +699,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
             // LDS per workgroup: the template rows + four column buffers wide enough for the widest box (make_rec: at most
             // 2 R + 13 columns) plus chunk-alignment slack; as many resident workgroups per CU as 160 KiB hold (at most 8)
             const int span_dw = (2 * c.img_r_max + 13) * (c.img_h / 4) + 8;
-            a.coldw = (span_dw + 3) & ~3;
+            a.coldw = ((span_dw + 3) & ~3) + 4;                  // (+ the zero chunk of render_fast_store)
             if (a.coldw > kImgColDw) a.coldw = kImgColDw;
             const size_t lds_bytes = (size_t)a.tplp * 256 + (size_t)(kBlock / 64) * a.coldw * 4;
             unsigned per_cu = (unsigned)((160u * 1024u) / ((lds_bytes + 511) & ~(size_t)511));
