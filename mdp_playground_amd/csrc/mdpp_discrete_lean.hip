@@ -7,8 +7,9 @@
 // A 1024-thread workgroup steps 256 envs, lane l of waves w, w+4, w+8, w+12 serving the same env:
 //   E   waves 0-3    state recurrence, same-step autoreset from the queue of pre-drawn start states;
 //                    three dwords per env step into an LDS ring (13 instructions per step)
-//   O1  waves 4-7    reward path: reward bit, delay line, reward value; stores `reward`
-//   O2  waves 8-11   stores `obs`, `terminated`, `truncated`
+//   O1  waves 4-7    reward path: reward bit, delay line, reward value; stores `reward` (numpy streams, full blocks: hands
+//                    the rewards to the O2 waves through LDS instead -- "whole-row stores" below)
+//   O2  waves 8-11   stores `obs`, `terminated`, `truncated` -- as whole rows of the block where every wave of it is present
 //   H   waves 12-15  own the envs' PCG64 streams for the launch and keep an LDS ring of pre-drawn
 //                    rho_0 start states filled; un-draw what was not used at the end
 // Hand-offs and spin bounds as in mdpp_discrete_pipe.hip (single-producer rings, monotonic counters,
