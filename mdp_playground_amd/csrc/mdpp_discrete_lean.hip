@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     constexpr bool HSS = MDPP_LEAN_H_SSTAB && !PHILOX && NZ == 0 && !IRR;
     __shared__ uint8_t lds_sstab[(NRN || NPN || HSS) ? 2048 : 1];     // start state by r >> 53
     __shared__ uint8_t lds_pntab[NPN ? 4096 : 1];                     // a | b << 4 by r >> 52
-    __shared__ ulonglong2 lds_kw[NRN ? 256 : 1];                       // ziggurat {ki, wi}
+    __shared__ ulonglong2 lds_kw[NRN ? 256 : 1];                       // ziggurat {ki, wi * 2^52}
     __shared__ double lds_fi[NRN ? 256 : 1];
     constexpr int kEN = IRR ? 2 : 1;                // nibbles per start-state entry (relevant, irrelevant)
     // gymnasium's next-step autoreset: the call after an episode's last step IS the reset (action ignored, reward 0,
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         }
     }
     if (NRN)
-        for (int k = tid; k < 256; k += kRoles * kBlock) { lds_kw[k] = make_ulonglong2(d_zig_ki[k], (unsigned long long)__double_as_longlong(d_zig_wi[k])); lds_fi[k] = d_zig_fi[k]; }
+        for (int k = tid; k < 256; k += kRoles * kBlock) { lds_kw[k] = make_ulonglong2(d_zig_ki[k], (unsigned long long)(__double_as_longlong(d_zig_wi[k]) + (52LL << 52)));   /* {ki, W = wi 2^52} */ lds_fi[k] = d_zig_fi[k]; }
     if (tid < kBlock / 64) { lds_prod[tid] = 0; lds_cons[tid][0] = 0; lds_cons[tid][1] = 0; lds_hprod[tid] = 0; lds_pprod[tid] = 0; lds_rprod[tid] = 0; lds_rcons[tid] = 0; }
     if (tid == 0) lds_done = 0;
     __syncthreads();
@@ -498,10 +498,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                                 wdv[u + 1] = ge.next64();
                                 const ulonglong2 kw = lds_kw[(uint32_t)wd & 0xffu];
                                 const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
-                                const double t = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
-                                const double x = t * __longlong_as_double((long long)kw.y);
-                                const double xs = __longlong_as_double((long long)((uint64_t)__double_as_longlong(x) ^
-                                                                                     ((uint64_t)((uint32_t)wd & 0x100u) << 55)));
+                                // rabs * wi in ONE rounding (as in mdpp_continuous_fast.hip's walker): m = 1 + rabs 2^-52 as bits,
+                                // W = wi 2^52 from the table, fma(m, W, -W) = round(rabs wi); the sign (bit 8 of the word) by a bit-field insert
+                                const double W = __longlong_as_double((long long)kw.y);
+                                const double x = __builtin_fma(__longlong_as_double((long long)(rabs | 0x3FF0000000000000ULL)), W, -W);
+                                const uint64_t xb = (uint64_t)__double_as_longlong(x);
+                                const double xs = __longlong_as_double((long long)(((uint64_t)(((uint32_t)(xb >> 32) & 0x7FFFFFFFu) |
+                                                                                   (((uint32_t)wd << 23) & 0x80000000u)) << 32) | (uint32_t)xb));
 #ifdef MDPP_ABL_NP_NOSLOW
                                 const bool ok = rabs < kw.x + 0x7fffffffffffffffULL;
 #else
