@@ -89,7 +89,8 @@ enum { MDPP_OPT_NO_PIPE = 1u << 0,         /* discrete: no three-role k_discrete
        MDPP_OPT_NO_IMGFAST = 1u << 10,     /* polygon images: k_image_obs instead of k_image_obs_fast */
        MDPP_OPT_NO_IMG_OVERLAP = 1u << 11, /* image rollouts: no side-stream pipeline of the batches */
        MDPP_OPT_NO_PHILOX_FAST = 1u << 12, /* Philox handles: general kernels only */
-       MDPP_OPT_NO_LEAN = 1u << 13         /* discrete: no k_discrete_rollout_lean (S <= 8 re-encoding of _pipe) */ };
+       MDPP_OPT_NO_LEAN = 1u << 13,        /* discrete: no k_discrete_rollout_lean (S <= 8 re-encoding of _pipe) */
+       MDPP_OPT_NO_IMG_NEARTAB = 1u << 14  /* polygon images: k_image_obs_fast walks the bounding box instead of the near-dword table */ };
 
 /* what a discrete env's reward table is keyed by */
 enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences, rl_toy_env.py:1837-1841) */

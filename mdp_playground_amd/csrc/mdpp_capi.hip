@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "mdpp_internal.hpp"
@@ -52,7 +54,8 @@ static void free_all(mdpp_env *h) {
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off};
+                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off,
+                    h->d_img_near};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -109,6 +112,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->graph_capture = false;
     h->d_tick_off = nullptr;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
+    h->d_img_near = nullptr;
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
     // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
     // 7 740 us per 512 steps with batches of 16, 7 440 with 32; with the renderer's waves claiming their images, 7 250 / 6 830 /
@@ -1015,7 +1019,7 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
         if (cls_x[k] >= n_cls_x) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_x out of range");
     for (size_t k = 0; k < S * n_radii * H; k++)
         if (cls_y[k] >= n_cls_y) return fail(h, MDPP_EINVAL, "upload_image_templates: cls_y out of range");
-    for (void **p : {&h->d_img_tpl, &h->d_img_tplp, &h->d_img_clsx, &h->d_img_clsy, &h->d_img_rot})
+    for (void **p : {&h->d_img_tpl, &h->d_img_tplp, &h->d_img_clsx, &h->d_img_clsy, &h->d_img_rot, &h->d_img_near})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_img_tpl, tb));
     HIPCHK(h, hipMemcpy(h->d_img_tpl, tpl, tb, hipMemcpyHostToDevice));
@@ -1047,6 +1051,40 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
                     memcpy(&padded[(k * tp + y + PADW) * 64 + PADW], tpl + (k * t + y) * (size_t)t, t);
             HIPCHK(h, hipMalloc(&h->d_img_tplp, padded.size()));
             HIPCHK(h, hipMemcpy(h->d_img_tplp, padded.data(), padded.size(), hipMemcpyHostToDevice));
+            // The near dwords of a polygon as a TABLE (one radius only: no scale transform).  The renderer evaluates the dwords
+            // (column x, dword row q) whose centre lies within R + 4.5 of the polygon's centre; relative to the centre rounded to
+            // whole pixels (off by <= 0.71 px) that set is contained in the disc of radius R + 4.5 + 0.71 -- enumerated here once
+            // per phase of the centre row in the dword grid (cy mod 4), in two orders (x fastest / y fastest: the renderer picks
+            // the one along which its lanes read along template rows), 8 entries (dx, dq as int8 pairs) per lane:
+            // [order][phase][lane][8].  Every pixel of a listed dword is within R + 5.21 + 1.5 + 0.71 < R + 8 of the centre
+            // after the map's rounding: inside the template's zero border.
+            if (n_radii == 1) {
+                const int R = c.img_r_max;
+                const double rt = (double)R + 4.5 + 0.7072, rt2 = rt * rt;
+                std::vector<uint16_t> tab((size_t)2 * 4 * 64 * 8, (uint16_t)0x8080u);      // (dx = dq = -128: never inside a box)
+                bool fits = true;
+                for (int o = 0; o < 2 && fits; o++)
+                    for (int ph = 0; ph < 4 && fits; ph++) {
+                        std::vector<std::pair<int, int>> e;
+                        const int lim = R + 6;
+                        for (int dq = -(lim / 4 + 2); dq <= lim / 4 + 2; dq++)
+                            for (int dx = -lim; dx <= lim; dx++) {
+                                const double dy = 4.0 * dq + 1.5 - (double)ph;
+                                if ((double)dx * dx + dy * dy <= rt2) e.emplace_back(dx, dq);
+                            }
+                        if (e.size() > 512) { fits = false; break; }
+                        if (o == 1) std::sort(e.begin(), e.end());                                       // y fastest: by (dx, dq)
+                        else std::sort(e.begin(), e.end(), [](const std::pair<int, int> &u, const std::pair<int, int> &v) {
+                                 return u.second != v.second ? u.second < v.second : u.first < v.first; });    // x fastest: by (dq, dx)
+                        for (size_t k = 0; k < e.size(); k++)
+                            tab[(((size_t)o * 4 + ph) * 64 + (k & 63)) * 8 + (k >> 6)] =
+                                (uint16_t)(((uint32_t)e[k].first & 0xFFu) | (((uint32_t)e[k].second & 0xFFu) << 8));
+                    }
+                if (fits) {
+                    HIPCHK(h, hipMalloc(&h->d_img_near, tab.size() * 2));
+                    HIPCHK(h, hipMemcpy(h->d_img_near, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+                }
+            }
         }
     }
     HIPCHK(h, hipMalloc(&h->d_img_clsx, S * n_radii * W * 2));

@@ -70,6 +70,7 @@ struct ImageArgs {
     // order the reference draws them (the step's images, then reset()'s where the step ended the episode); an explicit
     // reset() from stream kPhiloxResetImageStream keyed by the reset count
     int32_t coldw;             // fast renderer: dwords of image columns per wave in LDS (host: the widest box + slack)
+    const uint32_t *near_tab;  // fast renderer: the near dwords of a polygon as (dx, dq) int8 pairs, [order][cy mod 4][lane][8] (mdpp_capi.hip), or null
     uint32_t *work_ctr;        // fast renderer: [2][kImgCtrs x 32] work counters of this batch's two render launches, one per group of waves,
                                // 128 B apart (zeroed by k_image_draw)
     int32_t philox, is_reset;
@@ -394,6 +395,17 @@ __device__ __forceinline__ TplRegs load_tpl(const ImageArgs &a, uint32_t tix, in
     return r;
 }
 
+// The lane's eight entries of the near table for an image (record r): order by the walk direction (render_fast_eval), phase by
+// the centre row rounded to whole pixels.
+__device__ __forceinline__ u32x4 load_near(const ImageArgs &a, const RecRegs &r, int lane) {
+    if (!a.near_tab) return u32x4{0u, 0u, 0u, 0u};
+    const int a0 = (int)r.lo[0], a1 = (int)r.lo[1];
+    const uint32_t order = (a0 < 0 ? -a0 : a0) >= (a1 < 0 ? -a1 : a1) ? 0u : 1u;
+    int cyi = (int)rintf(__uint_as_float(r.hi[1]));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(cyi) : "v"(cyi));
+    return ((const u32x4 *)a.near_tab)[((order * 4u + ((uint32_t)cyi & 3u)) * 64u) + (uint32_t)lane];
+}
+
 __device__ __forceinline__ void stage_tpl(const ImageArgs &a, const TplRegs &tp, uint8_t *lds, int wave, int lane) {
 #ifndef MDPP_IMG_ABL_NOTPL
 #pragma unroll
@@ -408,7 +420,7 @@ __device__ __forceinline__ void stage_tpl(const ImageArgs &a, const TplRegs &tp,
 // leaves the image columns of the bounding box in lds_col and returns their chunk range.
 struct ColRange { int C0, C1; };
 __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const RecRegs &r, const uint8_t *lds,
-                                                     uint32_t *lds_col, int wave, int lane) {
+                                                     uint32_t *lds_col, int wave, int lane, const u32x4 near) {
     const int a0 = (int)r.lo[0], a1 = (int)r.lo[1], a2 = (int)r.lo[2], a3 = (int)r.lo[3], a4 = (int)r.lo[4],
               a5 = (int)r.lo[5];
     const int cx = (int)(r.lo[6] & 0xFFFFu), cy = (int)(r.lo[6] >> 16), R = (int)(r.lo[7] & 0x3FFu);
@@ -447,6 +459,39 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
             A5 += (int)(lbase >> 8) << 16;
         }
         const uint32_t cbase = (uint32_t)(uintptr_t)(lds_u32p)lds_col - 4u * (uint32_t)B0, HQ4 = 4u * (uint32_t)HQ;
+        if (MDPP_IMG_LEAN_LOOP && a.near_tab) {
+            // Table-driven enumeration (round 4): the lane's eight (dx, dq) entries, relative to the centre rounded to whole
+            // pixels; an entry outside the record's box (or the padding entry) fails two unsigned compares.  No idle lanes
+            // inside a bounding box, no near test, no walk: 8 rounds of 64 dwords for R = 20 where the box took 10.
+            int cxi = (int)rintf(fcx), cyi = (int)rintf(fcy);
+            asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(cxi) : "v"(cxi));
+            asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(cyi) : "v"(cyi));
+            const int cX = cxi - X0, cQ = (cyi >> 2) - Q0;
+            // x = xr + X0, y = yr + 4 Q0: the box origin folded into the (scalar) constants
+            const int A2t = A2 + a0 * X0 + a1 * 4 * Q0, A5t = A5 + a3 * X0 + a4 * 4 * Q0;
+            const uint32_t cb2 = cbase + (uint32_t)X0 * HQ4 + 4u * (uint32_t)Q0;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const uint32_t ew = (it >> 1) == 0 ? near.x : (it >> 1) == 1 ? near.y : (it >> 1) == 2 ? near.z : near.w;
+                const int xr = __builtin_amdgcn_sbfe((int)ew, (it & 1) * 16, 8) + cX;
+                const int qr = __builtin_amdgcn_sbfe((int)ew, (it & 1) * 16 + 8, 8) + cQ;
+                if ((uint32_t)xr < (uint32_t)bw && (uint32_t)qr < (uint32_t)bhq) {
+                    const int yr = qr << 2;
+                    const int bx = A2t + __mul24(a0, xr) + __mul24(a1, yr);
+                    const int by = A5t + __mul24(a3, xr) + __mul24(a4, yr);
+                    uint32_t px[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const uint32_t addr = __builtin_amdgcn_perm((uint32_t)(by + b * a4), (uint32_t)(bx + b * a1), 0x0c0c0602u);
+                        px[b] = *(lds_u8p)(uintptr_t)addr;
+                    }
+                    const uint32_t word = (px[0] | (px[1] << 8)) | ((px[2] | (px[3] << 8)) << 16);
+                    *(lds_u32p)(uintptr_t)(__umul24((uint32_t)xr, HQ4) + (uint32_t)yr + cb2) = word;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            return ColRange{C0, C1};
+        }
         const int nb = bw * bhq;
         // Which way the 64 lanes of an iteration walk the box (round 4).  A template row is 256 B = all 64 LDS banks once, so
         // source pixels in ONE COLUMN of the template sit in one bank: at rotations near 0 / 180 degrees lanes that walk DOWN
@@ -599,6 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
     claim_issue();                               // (one chunk ahead)
     long j = base;
     RecRegs cur = load_rec(rec + j);
+    u32x4 near_cur = load_near(a, cur, lane);
     stage_tpl(a, load_tpl(a, cur.lo[7] >> 12, lane), lds, wave, lane);
     for (;;) {
         const bool last_of_chunk = j + 1 >= base + kImgClaim || j + 1 >= M;
@@ -612,18 +658,20 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
         const bool skip = cur.lo[7] & (1u << 11);
         const RecRegs nxt = load_rec(rec + (more ? jn : j));
         const TplRegs tp = load_tpl(a, nxt.lo[7] >> 12, lane);
+        const u32x4 near_nxt = load_near(a, nxt, lane);
         ColRange cr{0, 0};
-        if (!skip) cr = render_fast_eval(a, cur, lds, lds_col, wave, lane);
+        if (!skip) cr = render_fast_eval(a, cur, lds, lds_col, wave, lane, near_cur);
         stage_tpl(a, tp, lds, wave, lane);
         if (!skip) render_fast_store<NST>(a, cr, lds_col, img + (size_t)j * isz, lane);
         if (!more) break;
-        j = jn; cur = nxt;
+        j = jn; cur = nxt; near_cur = near_nxt;
     }
 #else
     const int nw = (int)gridDim.x * (kBlock / 64);
     long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
     if (j >= M) return;
     RecRegs cur = load_rec(rec + j);
+    u32x4 near_cur = load_near(a, cur, lane);
     stage_tpl(a, load_tpl(a, cur.lo[7] >> 12, lane), lds, wave, lane);
     for (;;) {
         const long jn = j + nw;
@@ -631,12 +679,13 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
         const bool skip = cur.lo[7] & (1u << 11);
         const RecRegs nxt = load_rec(rec + (more ? jn : j));
         const TplRegs tp = load_tpl(a, nxt.lo[7] >> 12, lane);
+        const u32x4 near_nxt = load_near(a, nxt, lane);
         ColRange cr{0, 0};
-        if (!skip) cr = render_fast_eval(a, cur, lds, lds_col, wave, lane);
+        if (!skip) cr = render_fast_eval(a, cur, lds, lds_col, wave, lane, near_cur);
         stage_tpl(a, tp, lds, wave, lane);
         if (!skip) render_fast_store<NST>(a, cr, lds_col, img + (size_t)j * isz, lane);
         if (!more) break;
-        j = jn; cur = nxt;
+        j = jn; cur = nxt; near_cur = near_nxt;
     }
 #endif
 }
@@ -667,6 +716,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.rng_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_IMAGE];
     a.rng_half = (uint2 *)h->d_rng_half;
     a.tplp_data = (const uint8_t *)h->d_img_tplp; a.tplp = c.img_tpl_size + 2 * kImgPad;
+    a.near_tab = (h->opts & MDPP_OPT_NO_IMG_NEARTAB) ? nullptr : (const uint32_t *)h->d_img_near;
     a.philox = c.rng_mode == MDPP_RNG_PHILOX; a.philox_seed = c.philox_seed; a.env_id_offset = c.env_id_offset;
     // (the state kernel / reset kernel of this batch ran just before and has advanced the handle's counters)
     a.is_reset = term == nullptr;

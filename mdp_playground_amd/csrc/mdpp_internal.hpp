@@ -241,6 +241,7 @@ struct mdpp_env {
     void *d_sd, *d_cur, *d_meta;
     void *d_rng_s[MDPP_NUM_STREAMS], *d_rng_inc[MDPP_NUM_STREAMS], *d_rng_half;
     void *d_img_tpl, *d_img_tplp, *d_img_clsx, *d_img_clsy, *d_img_rot, *d_img_state_out, *d_img_state_final;
+    void *d_img_near;           // fast renderer: table of the near dwords of a polygon (mdpp_image.hip render_fast_eval), or null
     void *d_img_rec;            // ImgRec [2][img_chunk][N] per-image records (mdpp_image.hip), 64 B each
     void *d_img_ctr;            // uint32 [2][2]: the fast renderer's work counters (scratch set x render launch)
     int32_t img_chunk;          // env steps per state-kernel + draw + render batch

@@ -1341,8 +1341,10 @@ def test_cfg4_at_bench_size_fast_vs_general_renderer_and_oracle():
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     c = _venv(num_envs=N, autoreset="same_step", **cfg)
+    d = _venv(num_envs=N, autoreset="same_step", **cfg)
     b.set_kernel_options("NO_IMGFAST")
     c.set_kernel_options("NO_IMG_OVERLAP")
+    d.set_kernel_options("NO_IMG_NEARTAB")              # (the fast renderer walking the bounding box instead of the near-dword table)
     assert a.rollout_kernel_name(K).startswith("k_image_obs_fast<") and b.rollout_kernel_name(K) == "k_image_obs"
     twin = _venv(num_envs=N, autoreset="same_step", **{k: v for k, v in cfg.items() if not k.startswith("image_")})
     words0 = a.get_rng_streams(capi.STREAM_IMAGE).copy()
@@ -1350,12 +1352,14 @@ def test_cfg4_at_bench_size_fast_vs_general_renderer_and_oracle():
     oa, ra, ta, _ = a.rollout(acts)
     ob, rb, tb, _ = b.rollout(acts)
     oc, rc, tc, _ = c.rollout(acts)
+    od, rd, td, _ = d.rollout(acts)
     st, rs, ts, _ = twin.rollout(acts)
     torch.cuda.synchronize()
     assert tuple(oa.shape) == (K, N, 84, 84, 1)
     for k in range(K):                                    # (row by row: a whole-tensor compare allocates another 1.8 GB)
         assert torch.equal(oa[k], ob[k]), k
         assert torch.equal(oa[k], oc[k]), k
+        assert torch.equal(oa[k], od[k]), k
     assert torch.equal(ra, rb) and torch.equal(ta, tb) and torch.equal(ra, rc) and torch.equal(ta, tc)
     assert torch.equal(ra, rs) and torch.equal(ta, ts) and ta.any() and not ta.all()
     for s_ in (capi.STREAM_IMAGE, capi.STREAM_ENV):
@@ -1376,7 +1380,8 @@ def test_cfg4_at_bench_size_fast_vs_general_renderer_and_oracle():
                 _render(m.image, tpl, 0, w)
             assert np.array_equal(_render(m.image, tpl, int(st_h[k, i]), w), got[k]), (i, k)
         assert np.array_equal(w, end[i]), i
-    for e in (a, b, c, twin):
+    assert torch.equal(ra, rd) and torch.equal(ta, td)
+    for e in (a, b, c, d, twin):
         e.close()
 
 
