@@ -325,6 +325,12 @@ def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=
         n += launches
     bad = int((env.status() != 0).sum())
     kname = env.rollout_kernel_name(F)
+    single = None
+    if name in ("cfg3", "cfg5"):                #  the one-launch-per-step API and a replayed HIP graph of 64 such steps
+        try:
+            single = single_step_leg(env, wl, acts[0], N, device, n1=200, reps=5)
+        except Exception as e:                  # a reported extra, never fatal
+            single = {"error": repr(e)}
     env.close()
     per_launch_s = statistics.median(us) * 1e-6
     wall = statistics.median(walls)
@@ -336,7 +342,7 @@ def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=
             "achieved_GBps": achieved, "kernel": kname, "rng": rng,
             "envs": N, "fuse": F, "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg,
             "action_tensors": len(acts), "action_bytes_rotated": len(acts) * acts[0].numel() * acts[0].element_size(),
-            "envs_with_status_bits": bad, "traffic": None, "traffic_source": None}
+            "envs_with_status_bits": bad, "traffic": None, "traffic_source": None, "single_step": single}
 
 
 def self_launch(args, argv):
@@ -891,13 +897,13 @@ def committed_traffic(workload, rng, N, F, kname):
     return None, None
 
 
-def single_step_leg(env, wl, acts, N, device):
-    """The one-launch-per-step API (mdpp_step) and a replayed HIP graph of such steps."""
+def single_step_leg(env, wl, acts, N, device, n1=500, reps=20):
+    """The one-launch-per-step API (mdpp_step) and a replayed HIP graph of such steps (`graph.exact`: how the replay keeps
+    the handle's step counter -- 1 by value, 2 through the device-side tick offset: Philox streams, delay lines)."""
     a1 = acts[0].contiguous()
     for _ in range(50):
         env.step(a1)
     torch.cuda.synchronize(device)
-    n1 = 500
     env.timer_begin()
     t1 = time.perf_counter()
     for _ in range(n1):
@@ -916,7 +922,6 @@ def single_step_leg(env, wl, acts, N, device):
             for _ in range(3):
                 g.replay()
             torch.cuda.synchronize(device)
-            reps = 20
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t2 = time.perf_counter()
             e0.record()
@@ -925,7 +930,8 @@ def single_step_leg(env, wl, acts, N, device):
             e1.record()
             torch.cuda.synchronize(device)
             wall2 = time.perf_counter() - t2
-            single["graph"] = {"steps_per_graph": KG, "env_steps_per_s": N * KG * reps / wall2,
+            single["graph"] = {"steps_per_graph": KG, "exact": 2 if getattr(g, "_by_offset", False) else 1,
+                               "env_steps_per_s": N * KG * reps / wall2,
                                "us_per_step_events": e0.elapsed_time(e1) * 1e3 / (KG * reps),
                                "hbm_frac_events": b1 / (e0.elapsed_time(e1) * 1e-3 / (KG * reps)) / 1e9 / HBM_PEAK_GBS}
         except Exception as e:        # a reported extra, never fatal

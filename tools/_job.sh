@@ -1,5 +1,7 @@
-# scratch job for one gpurun call (GPU box); the last content: the round's final validation + records
 cd $GRAFT_REPO_ROOT
-bash tools/validate_all.sh
-bash tools/prof_r04.sh > gpurun_out/prof_r04.log 2>&1
-tail -n 42 gpurun_out/prof_r04.log | cut -c1-250 | head -10
+export TMPDIR=/tmp
+o=gpurun_out/rows; mkdir -p $o
+{
+for i in 1 2 3; do timeout 900 python3 tools/ablate.py run mdpp_image.hip cfg4 numpy base res0 res16 res32 res64; done
+} > $o/ablate_res.txt 2>&1
+cut -c1-200 $o/ablate_res.txt | grep -v "^$" | tail -16
