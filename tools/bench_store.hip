@@ -153,6 +153,35 @@ __global__ __launch_bounds__(1024) void k_lean_like(const int32_t *act, uint8_t 
     }
 }
 
+// The continuous rollout's shape (cfg3: D = 12 floats of action in, 12 floats of observation out per env step, one lane per env,
+// one wave per SIMD, rows prefetched AH steps ahead): the action row of a lane is 48 contiguous bytes, so its three 16-byte loads
+// sit 48 B apart across the lanes (STRIDED: every instruction touches all 24 cache lines of the wave's 3 KiB); CONTIG: the same
+// 3 KiB as three instructions of 1 KiB each (what an LDS transposition of the loads would issue).  Stores: 1 KiB per instruction.
+template <int AH, bool CONTIG>
+__global__ __launch_bounds__(256) void k_cont_like(const u32x4 *act, u32x4 *obs, int N, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x, ln = threadIdx.x & 63, w0 = i - ln;
+    u32x4 q[AH][3];
+    auto ld = [&](int k, u32x4 (&d)[3]) {
+        const size_t row = (size_t)(k < K ? k : K - 1) * N * 3;
+#pragma unroll
+        for (int j = 0; j < 3; j++) d[j] = CONTIG ? act[row + (size_t)w0 * 3 + j * 64 + ln] : act[row + (size_t)i * 3 + j];
+    };
+#pragma unroll
+    for (int u = 0; u < AH; u++) ld(u, q[u]);
+    u32x4 acc = u32x4{0u, 0u, 0u, 0u};
+    for (int k0 = 0; k0 < K; k0 += AH) {
+#pragma unroll
+        for (int u = 0; u < AH; u++) {
+            const int k = k0 + u;
+            acc = acc + q[u][0] + q[u][1] + q[u][2];
+            ld(k + AH, q[u]);
+            const size_t row = (size_t)k * N * 3 + (size_t)w0 * 3;
+#pragma unroll
+            for (int j = 0; j < 3; j++) __builtin_nontemporal_store(acc + (unsigned)j, obs + row + j * 64 + ln);
+        }
+    }
+}
+
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static int N = 65536, K = 512;
@@ -236,6 +265,35 @@ int main() {
         CHK(hipFree(big));
     }
     printf("N %d envs, K %d rows per launch; x g = g elements per lane and store (g lanes x g steps transposed)\n", N, K);
+    if (getenv("CONT_ONLY")) {
+        u32x4 *ca[4], *co;
+        const size_t rows = (size_t)N * K * 3;
+        for (int j = 0; j < 4; j++) { CHK(hipMalloc(&ca[j], rows * 16)); CHK(hipMemset(ca[j], j + 1, rows * 16)); }
+        CHK(hipMalloc(&co, rows * 16));
+        auto run_c = [&](auto kern, const char *label) {
+            hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                for (int w = 0; w < 2; w++) hipLaunchKernelGGL(kern, dim3(N / 256), dim3(256), 0, 0, ca[w & 3], co, N, K);
+                CHK(hipEventRecord(e0, 0));
+                for (int w = 0; w < 8; w++) hipLaunchKernelGGL(kern, dim3(N / 256), dim3(256), 0, 0, ca[w & 3], co, N, K);
+                CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms / 8 < best) best = ms / 8;
+            }
+            printf("  continuous-shaped, %-34s %8.1f us per launch  %7.1f GB/s\n", label, best * 1e3, (double)N * K * 96.0 / (best * 1e-3) / 1e9);
+            fflush(stdout);
+        };
+        for (int r = 0; r < 2; r++) {
+            run_c(k_cont_like<4, false>, "strided loads, 4 rows ahead");
+            run_c(k_cont_like<4, true>, "contiguous loads, 4 rows ahead");
+            run_c(k_cont_like<8, false>, "strided loads, 8 rows ahead");
+            run_c(k_cont_like<8, true>, "contiguous loads, 8 rows ahead");
+            run_c(k_cont_like<2, false>, "strided loads, 2 rows ahead");
+            run_c(k_cont_like<2, true>, "contiguous loads, 2 rows ahead");
+        }
+        return 0;
+    }
     if (getenv("LEAN_ONLY")) {
         for (int r = 0; r < 2; r++) {
             lean_like<4, true>(true); lean_like<4, true>(false); lean_like<4, false>(true);
