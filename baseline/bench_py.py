@@ -62,16 +62,16 @@ def measure(config, kind, seconds_one=10.0, seconds_all=6.0):
     with contextlib.redirect_stdout(io.StringIO()):
         steps, el = _worker((config, seconds_one, 0))
     ncpu = os.cpu_count() or 1
-    one = {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "python-restatement",
+    one = {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "form": "python-restatement",
            "sample": f"{steps} env-steps of the same workload, one env object stepped in a Python loop with "
                      f"random actions and reset on done (baseline/py_step.py: the reference's step() restated, "
                      f"validated against the reference-generated goldens; reference : restatement speed ratio in "
-                     f"profiles/r02_py_baseline_ratio.json) on 1 host core in {el:.1f} s; "
+                     f"profiles/py_baseline_ratio.json, folded into `reference_equivalent`) on 1 host core in {el:.1f} s; "
                      f"host: {_cpu_model()}, {ncpu} cores"}
     with mp.get_context("fork").Pool(ncpu) as pool, contextlib.redirect_stdout(io.StringIO()):
         res = pool.map(_worker, [(config, seconds_all, w) for w in range(ncpu)])
     total, wall = sum(r[0] for r in res), max(r[1] for r in res)
-    allc = {"value": total / wall, "unit": "env-steps/s", "cores": ncpu, "kind": "python-restatement",
+    allc = {"value": total / wall, "unit": "env-steps/s", "cores": ncpu, "kind": "port", "form": "python-restatement",
             "sample": f"{total} env-steps, one baseline/py_step.py process per core (no inter-process traffic) "
                       f"for {wall:.1f} s"}
     return one, allc

@@ -9,7 +9,7 @@ draws from the same generators in the same order, `scipy.special.factorial` + nu
 the integrator, `np.linalg.norm` for distances, `Box.contains`-style numpy tests.  What is left
 out is only what produces no result: the reference's log-string building and its episode
 statistics counters (the speed ratio reference : this file is measured in the build container by
-tools/refgen/bench_reference.py and committed as profiles/r02_py_baseline_ratio.json).
+tools/refgen/bench_reference.py and committed as profiles/py_baseline_ratio.json).
 
 It is NOT part of the product (nothing under mdp_playground_amd/ imports it) and NOT the oracle:
 tests/test_py_baseline.py pins it to the reference-generated goldens, bench.py times it.

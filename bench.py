@@ -881,6 +881,8 @@ def committed_traffic(workload, rng, N, F, kname):
     for name in (f"r03_traffic_{tag}.json", f"r02_traffic_{tag}.json", f"r02_traffic_{tag}_pipe.json", f"r01_traffic_{tag}.json"):
         tfile = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tfile):
+            tfile = os.path.join(ROOT, "profiles", "archive", name)      # (rounds 1-3)
+        if not os.path.exists(tfile):
             continue
         t = json.load(open(tfile))
         if t.get("envs") != N:
@@ -939,6 +941,27 @@ def single_step_leg(env, wl, acts, N, device, n1=500, reps=20):
     return single
 
 
+def fold_reference_ratio(rec, workload):
+    """The reference's OWN rate next to the restatement's: `reference_equivalent` = value x (reference : restatement speed ratio
+    of this workload, both timed in one process on one core of the build container by tools/refgen/bench_reference.py ->
+    profiles/py_baseline_ratio.json; the reference's files cannot travel to the GPU box).  None when the ratio file has no
+    entry for the workload."""
+    if not isinstance(rec, dict) or "value" not in rec:
+        return rec
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "py_baseline_ratio.json")) as f:
+            r = json.load(f)
+        w = r["workloads"][workload]
+        rec = dict(rec)
+        rec["reference_equivalent"] = {"value": rec["value"] * w["ratio_reference_over_restatement"], "unit": rec["unit"],
+                                       "ratio_reference_over_restatement": w["ratio_reference_over_restatement"],
+                                       "ratio_measured_on": r.get("host"), "ratio_source": "profiles/py_baseline_ratio.json"}
+    except Exception:
+        rec = dict(rec)
+        rec["reference_equivalent"] = None
+    return rec
+
+
 def cpu_baselines_forked(workload):
     """Everything that forks worker processes (must run before this process initialises the GPU):
     the pure-Python restatement on 1 core and on all cores, and the C port on all cores."""
@@ -947,6 +970,7 @@ def cpu_baselines_forked(workload):
     try:
         from baseline import bench_py
         cpu_py, cpu_py_all = bench_py.measure(wl["config"], wl["kind"])
+        cpu_py, cpu_py_all = fold_reference_ratio(cpu_py, workload), fold_reference_ratio(cpu_py_all, workload)
     except Exception as e:          # a reported extra, never fatal
         cpu_py = None
         cpu_py_all = {"error": repr(e)}

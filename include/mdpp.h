@@ -90,7 +90,8 @@ enum { MDPP_OPT_NO_PIPE = 1u << 0,         /* discrete: no three-role k_discrete
        MDPP_OPT_NO_IMG_OVERLAP = 1u << 11, /* image rollouts: no side-stream pipeline of the batches */
        MDPP_OPT_NO_PHILOX_FAST = 1u << 12, /* Philox handles: general kernels only */
        MDPP_OPT_NO_LEAN = 1u << 13,        /* discrete: no k_discrete_rollout_lean (S <= 8 re-encoding of _pipe) */
-       MDPP_OPT_NO_IMG_NEARTAB = 1u << 14  /* polygon images: k_image_obs_fast walks the bounding box instead of the near-dword table */ };
+       MDPP_OPT_NO_IMG_NEARTAB = 1u << 14, /* polygon images: k_image_obs_fast walks the bounding box instead of the near-dword table */
+       MDPP_OPT_NO_STEP1 = 1u << 15        /* mdpp_step (K = 1): the rollout kernels with K = 1 instead of k_discrete_step1 / k_continuous_step1 */ };
 
 /* what a discrete env's reward table is keyed by */
 enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences, rl_toy_env.py:1837-1841) */

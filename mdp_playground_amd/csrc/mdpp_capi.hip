@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <utility>
@@ -55,7 +56,7 @@ static void free_all(mdpp_env *h) {
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
                     h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off,
-                    h->d_img_near};
+                    h->d_img_near, h->d_s1_blob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -113,6 +114,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_tick_off = nullptr;
     h->d_img_tpl = h->d_img_tplp = h->d_img_clsx = h->d_img_clsy = h->d_img_rot = nullptr;
     h->d_img_near = nullptr;
+    h->d_s1_blob = nullptr;
+    memset(&h->s1args, 0, sizeof(h->s1args));
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
     // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
     // 7 740 us per 512 steps with batches of 16, 7 440 with 32; with the renderer's waves claiming their images, 7 250 / 6 830 /
@@ -502,6 +505,37 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             r *= a.scale; r += a.shift;
             if (q & 1) r += a.term_add;
             a.rsel[q] = (float)r;
+        }
+        // ---- one launch = one step (mdpp_discrete_step1.hip): the tables as ONE 1 KiB blob, the arguments as one small block ----
+        Step1Args &s1 = h->s1args;
+        memset(&s1, 0, sizeof(s1));
+        if (a.shape_ok && c.every_n < (1 << 20)) {
+            std::vector<uint32_t> blob(256, 0u);
+            for (size_t act = 0; act < A && act < 16; act++) {
+                uint64_t col = 0;
+                for (size_t st = 0; st < S; st++) col |= (uint64_t)(P[st * A + act] & 0xF) << (4 * st);
+                blob[2 * act] = (uint32_t)col; blob[2 * act + 1] = (uint32_t)(col >> 32);
+            }
+            for (int j = 0; j < 16; j++) { blob[32 + 2 * j] = (uint32_t)a.init_thr[j]; blob[32 + 2 * j + 1] = (uint32_t)(a.init_thr[j] >> 32); }
+            for (uint32_t b = 0; b < h->rbits_stride && b < 512; b++) blob[64 + b / 4] |= (uint32_t)rbits[b] << (8 * (b % 4));
+            for (size_t j = 0; j < 16; j++) {     // searchsorted(cdf, m31 2^-31, 'right') = #{j : ceil(cdf[j] 2^31) <= m31}
+                const double t = j < S ? ceil(ldexp(init_cdf[j], 31)) : 4294967295.0;
+                blob[192 + j] = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+            }
+            if (!h->d_s1_blob) HIPCHK(h, hipMalloc(&h->d_s1_blob, 1024));
+            HIPCHK(h, hipMemcpy(h->d_s1_blob, blob.data(), 1024, hipMemcpyHostToDevice));
+            s1.N = c.num_envs; s1.A = (uint32_t)c.A; s1.S = (uint32_t)c.S; s1.L = (uint32_t)c.L;
+            s1.every_n = (uint32_t)c.every_n; s1.inv_every_n = 1.0 / (double)c.every_n;
+            s1.max_steps = c.max_episode_steps > 0 ? (uint32_t)c.max_episode_steps : 0u;
+            s1.delay = (uint32_t)c.delay; s1.autoreset = c.autoreset != MDPP_AUTORESET_DISABLED ? 1u : 0u;
+            s1.term32 = (uint32_t)a.term_mask; s1.nan_mask = 0xFFu << (8 * c.L);
+            // (one round per launch up to six entries; 1 / 6 / 0 rounds and a fill level of 1 measured the same, 2.48-2.54 us per
+            //  step in a replayed graph of cfg2: profiles/r05_step1_variants.txt)
+            s1.topup_rounds = 1; s1.topup_fill = 6;
+            s1.philox_seed = a.philox_seed; s1.env_id_offset = a.env_id_offset;
+            for (int q = 0; q < 4; q++) s1.rsel[q] = a.rsel[q];
+            s1.blob = (const uint4 *)h->d_s1_blob;
+            s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;
         }
     }
     h->tables_ready = true;
@@ -1407,56 +1441,65 @@ extern "C" int mdpp_timer_end(mdpp_env *h, void *stream, float *ms) {
 }
 
 // ---- what the memory system gives plain streaming kernels (bench.py: the ceiling `roofline.frac` is priced beside) ----
-// 16 bytes per lane, grid-stride, 8 workgroups of 256 lanes per CU: the float4 copy MI355X_MICROARCH.md measures at
-// 6.29 TB/s, a fill and a read of the same shape.
+// 16 bytes per lane: the float4 copy MI355X_MICROARCH.md measures at 6.29 TB/s, a fill and a read of the same shape.
+// ONE-SHOT grids (round 5): a workgroup takes one contiguous 16 KiB tile -- four 16-byte pieces per lane, 4 KiB apart -- and
+// ends; the tiles are dispatched in address order, so the chip's write front stays compact.  (Rounds 3-4 ran the same tiles
+// on a persistent grid of 8 workgroups per CU: 25 % slower for fills, tools/bench_store.hip, profiles/r04_store_pattern.txt
+// -- the product's rollout kernel then BEAT its own "measured ceiling")  NT: non-temporal stores.
 namespace mdpp {
 typedef unsigned int pu4 __attribute__((ext_vector_type(4)));
-// (a workgroup takes contiguous 16 KiB tiles -- four 16-byte pieces per lane, 4 KiB apart -- tile after tile, grid-stride)
-__global__ __launch_bounds__(256) void k_probe_copy(const pu4 *__restrict__ s, pu4 *__restrict__ d, size_t n) {
-    const size_t ntile = n / 1024;
-    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const size_t i = t * 1024 + threadIdx.x;
-        const pu4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
-        d[i] = a; d[i + 256] = b; d[i + 512] = c; d[i + 768] = e;
-    }
-    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+template <bool NT>
+__device__ __forceinline__ void probe_st(pu4 *p, const pu4 &v) {
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
+template <bool NT>
+__global__ __launch_bounds__(256) void k_probe_copy(const pu4 *__restrict__ s, pu4 *__restrict__ d, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i + 768 < n) {
+        const pu4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+        probe_st<NT>(d + i, a); probe_st<NT>(d + i + 256, b); probe_st<NT>(d + i + 512, c); probe_st<NT>(d + i + 768, e);
+    } else {
+        for (size_t j = i; j < n; j += 256) probe_st<NT>(d + j, s[j]);
+    }
+}
+template <bool NT>
 __global__ __launch_bounds__(256) void k_probe_fill(pu4 *__restrict__ d, size_t n) {
     const pu4 v = pu4{threadIdx.x, blockIdx.x, 3u, 4u};
-    const size_t ntile = n / 1024;
-    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const size_t i = t * 1024 + threadIdx.x;
-        d[i] = v; d[i + 256] = v; d[i + 512] = v; d[i + 768] = v;
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i + 768 < n) {
+        probe_st<NT>(d + i, v); probe_st<NT>(d + i + 256, v); probe_st<NT>(d + i + 512, v); probe_st<NT>(d + i + 768, v);
+    } else {
+        for (size_t j = i; j < n; j += 256) probe_st<NT>(d + j, v);
     }
-    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = v;
 }
 __global__ __launch_bounds__(256) void k_probe_read(const pu4 *__restrict__ s, size_t n, uint32_t *out) {
     uint32_t acc = 0;
-    const size_t ntile = n / 1024;
-    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
-        const size_t i = t * 1024 + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i + 768 < n) {
         const pu4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
         acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ e.x ^ e.y ^ e.z ^ e.w;
+    } else {
+        for (size_t j = i; j < n; j += 256) { const pu4 v = s[j]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     }
-    for (size_t i = ntile * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const pu4 v = s[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
     if (acc == 0x12345u) out[0] = acc;          // (keeps the loads alive)
 }
+__global__ void k_probe_empty(uint32_t *p) { if (p && threadIdx.x == 0xFFFFu) p[0] = 1u; }
 } // namespace mdpp
 
 extern "C" int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size_t nbytes, int reps, void *stream, float *ms_out) {
-    if (!ms_out || reps < 1 || nbytes < 16 || mode < 0 || mode > 2) return MDPP_EINVAL;
-    if ((mode != 2 && !dst_dev) || (mode != 1 && !src_dev)) return MDPP_EINVAL;
+    // mode: 0 copy, 1 fill, 2 read (dst_dev: one word of scratch), 3 copy with non-temporal stores, 4 fill with non-temporal stores
+    if (!ms_out || reps < 1 || nbytes < 16 || mode < 0 || mode > 4) return MDPP_EINVAL;
+    if ((mode != 2 && !dst_dev) || (mode != 1 && mode != 4 && !src_dev)) return MDPP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess) return MDPP_EHIP;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const size_t n = nbytes / 16;
-    const dim3 grid((unsigned)(cus * 8)), block(256);
+    const dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MDPP_EHIP;
     auto launch = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(mdpp::k_probe_copy, grid, block, 0, s, (const mdpp::pu4 *)src_dev, (mdpp::pu4 *)dst_dev, n);
-        else if (mode == 1) hipLaunchKernelGGL(mdpp::k_probe_fill, grid, block, 0, s, (mdpp::pu4 *)dst_dev, n);
+        if (mode == 0) hipLaunchKernelGGL(mdpp::k_probe_copy<false>, grid, block, 0, s, (const mdpp::pu4 *)src_dev, (mdpp::pu4 *)dst_dev, n);
+        else if (mode == 3) hipLaunchKernelGGL(mdpp::k_probe_copy<true>, grid, block, 0, s, (const mdpp::pu4 *)src_dev, (mdpp::pu4 *)dst_dev, n);
+        else if (mode == 1) hipLaunchKernelGGL(mdpp::k_probe_fill<false>, grid, block, 0, s, (mdpp::pu4 *)dst_dev, n);
+        else if (mode == 4) hipLaunchKernelGGL(mdpp::k_probe_fill<true>, grid, block, 0, s, (mdpp::pu4 *)dst_dev, n);
         else hipLaunchKernelGGL(mdpp::k_probe_read, grid, block, 0, s, (const mdpp::pu4 *)src_dev, n, (uint32_t *)dst_dev);
     };
     for (int w = 0; w < 2; w++) launch();
@@ -1465,6 +1508,30 @@ extern "C" int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size
     for (int r = 0; r < reps; r++) launch();
     if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
         hipEventElapsedTime(ms_out, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = MDPP_EHIP;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// The device's own floor for ONE launch per step (bench.py `single_step.launch_floor`): n launches of an empty kernel
+// (`workgroups` x 64 threads) back to back on `stream` -- the host's time per hipLaunchKernel call and the device's time per
+// launch (HIP events around all of them; when the host is the slower side the two agree: eager launches are host-bound).
+extern "C" int mdpp_probe_launch(int n, int workgroups, void *stream, float *host_us_out, float *device_us_out) {
+    if (n < 1 || workgroups < 1 || !host_us_out || !device_us_out) return MDPP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MDPP_EHIP;
+    for (int w = 0; w < 20; w++) hipLaunchKernelGGL(mdpp::k_probe_empty, dim3(workgroups), dim3(64), 0, s, (uint32_t *)nullptr);
+    int rc = MDPP_OK;
+    if (hipStreamSynchronize(s) != hipSuccess || hipEventRecord(e0, s) != hipSuccess) rc = MDPP_EHIP;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < n; r++) hipLaunchKernelGGL(mdpp::k_probe_empty, dim3(workgroups), dim3(64), 0, s, (uint32_t *)nullptr);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    float ms = 0.0f;
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+        hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = MDPP_EHIP;
+    *host_us_out = (float)(((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) * 1e-3 / n);
+    *device_us_out = ms * 1e3f / (float)n;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return rc;
 }

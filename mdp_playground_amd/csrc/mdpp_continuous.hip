@@ -813,6 +813,14 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
     a.ptick = h->tick;
     a.dtick = h->graph_capture ? (const uint64_t *)h->d_tick_off : nullptr;     // (launches being captured into a HIP graph)
     a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
+    if (K == 1 && launch_continuous_step1(a, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
+        // mdpp_step on the fast shape: the one-step form of the rollout kernel (mdpp_continuous_step1.hip)
+        if (name_out) return MDPP_OK;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { h->err = std::string("k_continuous_step1 launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+        h->tick += 1;
+        return MDPP_OK;
+    }
     if (a.fast_ok) {
         // common shape: dedicated rollout kernel (mdpp_continuous_fast.hip); its buffer descriptors
         // address < 4 GiB per array, so long rollouts go out as several launches

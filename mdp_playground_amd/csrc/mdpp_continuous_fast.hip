@@ -47,7 +47,7 @@ __device__ __forceinline__ float c_fdiv_or_mul(float x, float div, float inv, bo
 // HELPER (noise only): 512-thread workgroups; waves 4-7 own the envs' PCG64 streams for the launch
 // and produce the D (+1) standard normals of every step into an LDS ring, waves 0-3 integrate and
 // read them back in the reference's draw order.  The numpy-exact ziggurat is ~3/4 of a noisy
-// step's instructions (profiles/r01_rng_microbench.txt) and one wave per SIMD leaves issue slots
+// step's instructions (profiles/archive/r01_rng_microbench.txt) and one wave per SIMD leaves issue slots
 // idle, so running it beside the integrator nearly halves the step time.  Producer and consumer
 // count the same K * (D + 1) draws, so nothing is drawn ahead of what the reference would draw.
 // The producer lanes of a wave are not in lockstep: see "park" below.
@@ -113,7 +113,7 @@ constexpr uint32_t kCStatusInternal = 0x80000000u;
 // two or three producers fill the SIMD's issue slots that one dependent Philox / Box-Muller chain leaves idle.
 // WALK (numpy streams + HELPER, NPROD == 2): three roles on three waves per SIMD instead of producer + consumer.  The helper
 // wave of rounds 1-3 walked ONE sequential PCG64 stream per lane AND decided the ziggurat's data-dependent consumption in
-// the same dependent chain (1 300 vector + 830 scalar instructions per step, profiles/r02_cfg5_sq.txt).  The two halves do
+// the same dependent chain (1 300 vector + 830 scalar instructions per step, profiles/archive/r02_cfg5_sq.txt).  The two halves do
 // not depend on each other the way that code made them:
 //   * the stream's 64-bit WORDS are a function of the position alone -- a generator wave (waves 8-11) makes them in order,
 //     branch-free, into a per-lane LDS ring indexed by stream position (window of kWRing words ahead of the walker);
@@ -124,7 +124,13 @@ constexpr uint32_t kCStatusInternal = 0x80000000u;
 //   * the consumer (waves 0-3) reads a step's normals at the top of the step and frees the slots at once.
 // Per lane the stream is consumed in exactly numpy's order; the generator un-draws the words the walker did not take at
 // the end of the launch (inverse LCG steps), so the stored stream state is the reference's.
-template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1>
+// K1 (round 5): the launch of ONE step (mdpp_step) -- k_continuous_step1 to its callers.  A rollout amortises its prologue
+// over hundreds of steps; a launch of one step IS its prologue, and at 65 536 envs it moves 20-27 MB, so it is paid in bytes
+// and in load round trips: the action row is the first load issued (not the fourth: no rows are fetched ahead), the highest
+// derivative row (overwritten by a / inertia before anything reads it) and the irrelevant coordinates of the last
+// observation are only read by a wave that holds a rejected action ("stay", :1671-1679), no staging of rewards and flags
+// for later groups, and without ziggurat tables the workgroup is ONE wave (no barrier; all 1 024 SIMDs start at once).
+template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1, bool K1 = false>
 __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
@@ -157,7 +163,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     // (three buffers), and wave w writes the block's whole piece of row k0 + w of a group -- 1 KiB of rewards (16 B per lane),
     // 256 B of each flag array (4 B per lane) -- one group LATER, when the other three waves have long staged theirs: per-wave
     // counters (groups staged / groups stored), no barrier (a barrier per group took back most of the gain: 662 -> 641 us).
-    constexpr bool CROWS = MDPP_CONT_ROWS && !HELPER;
+    constexpr bool CROWS = MDPP_CONT_ROWS && !HELPER && !K1;
+    static_assert(!K1 || !HELPER, "one step: no helper waves");
+    constexpr int WG = (K1 && !(NOISE && !PHILOX)) ? 64 : kBlock;      // threads per workgroup of the env waves
     constexpr int kRS = kBlock / 64;            // steps per group = waves per workgroup
     constexpr int kRBufs = 3;
     __shared__ __align__(16) float s_rw[CROWS ? kRBufs * kRS * kBlock : 4];
@@ -166,7 +174,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     if (CROWS && threadIdx.x < kBlock / 64) { s_rprod[threadIdx.x] = 0; s_rcons[threadIdx.x] = 0; }
     if (CROWS) __syncthreads();
     const int tid = threadIdx.x;
-    if (ZIG && !WALK) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
+    // (K1: the tables' loads are the launch's first, their LDS stores and the barrier come after every other load has been issued)
+    uint64_t k1_ki = 0; double k1_wi = 0.0, k1_fi = 0.0;
+    if constexpr (K1 && ZIG) { k1_ki = d_zig_ki[tid]; k1_wi = d_zig_wi[tid]; k1_fi = d_zig_fi[tid]; }
+    if (ZIG && !WALK && !K1) zig_stage(s_ki, s_wi, s_fi, tid, HELPER ? 2 * kBlock : kBlock);
     if (WALK) {
         for (int k = tid; k < 256; k += 3 * kBlock) { s_kw[k] = make_ulonglong2(d_zig_ki[k], __double_as_longlong(d_zig_wi[k]) + (52LL << 52));   /* {ki, W = wi * 2^52 (exact)} */ s_fi[k] = d_zig_fi[k]; }
         if (tid < kBlock) { s_gp[tid] = 0; s_rp[tid] = 0; }
@@ -177,10 +188,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         s_cons[tid] = 0;
         s_done[tid] = 0;
     }
-    if (NOISE) __syncthreads();
+    if (NOISE && !K1) __syncthreads();
     const ZigLds zig{s_ki, s_wi, s_fi};
     const int ln = tid & (kBlock - 1), wv = ln >> 6;
-    const uint32_t i = blockIdx.x * kBlock + ln;
+    const uint32_t i = blockIdx.x * WG + ln;
     if (i >= (uint32_t)a.N) return;             // HELPER launches require N % kBlock == 0
     const uint32_t N = (uint32_t)a.N;
     const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             // rectangle is PARKED with its 64-bit word until kPark lanes wait (or the consumer does),
             // and then the wedge / tail path -- an extra uniform, exp or log1p -- runs once for all of
             // them (checked once per MDPP_NP_ATTEMPTS attempts).  In lockstep, 54 % of a wave's draws have some lane on that path and all 64 pay
-            // for it (profiles/r01_rng_microbench.txt).  Per lane the stream is consumed in exactly
+            // for it (profiles/archive/r01_rng_microbench.txt).  Per lane the stream is consumed in exactly
             // numpy's order: a parked lane draws nothing until its own slow path has run.
             constexpr uint32_t kPark = MDPP_NP_PARK;
             const uint32_t nd = (a.has_p_noise ? (uint32_t)D : 0u) + (a.has_r_noise ? 1u : 0u);
@@ -624,14 +635,33 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     if (HELPER && NPROD > 1) __builtin_amdgcn_s_setprio(MDPP_CONSUMER_PRIO);
     if (HELPER && !PHILOX) __builtin_amdgcn_s_setprio(WALK ? MDPP_WK_CONSUMER_PRIO : MDPP_NP_CONSUMER_PRIO);
 
+    float k1act[K1 ? D : 1];
+    if constexpr (K1) {                         // the step's action row first: everything else of the launch waits for it
+        if constexpr (D == 2) {
+            const float2 v = ((const float2 *)actions)[i];
+            k1act[0] = v.x; k1act[1] = v.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < D / 4; q++) {
+                const float4 v = ((const float4 *)actions)[(size_t)i * (D / 4) + q];
+                k1act[4 * q] = v.x; k1act[4 * q + 1] = v.y; k1act[4 * q + 2] = v.z; k1act[4 * q + 3] = v.w;
+            }
+        }
+    }
     float sd[ORDER + 1][D], cur[D];
 #pragma unroll
     for (int k = 0; k <= ORDER; k++)
 #pragma unroll
-        for (int d = 0; d < D; d++) sd[k][d] = a.sd[((size_t)k * D + d) * N + i];
+        for (int d = 0; d < D; d++) sd[k][d] = (K1 && k == ORDER) ? 0.0f : a.sd[((size_t)k * D + d) * N + i];
 #pragma unroll
-    for (int d = 0; d < D; d++) cur[d] = a.cur[(size_t)d * N + i];
+    for (int d = 0; d < D; d++) cur[d] = (K1 && d >= NREL) ? 0.0f : a.cur[(size_t)d * N + i];
     uint2 meta = a.meta[i];
+    Pcg64 g;
+    if (ZIG && !HELPER) g.load(a.env_s, a.env_inc, i);
+    if constexpr (K1 && ZIG) {                  // (launched with N % 256 == 0: every wave of the block reaches the barrier)
+        s_ki[tid] = k1_ki; s_wi[tid] = k1_wi; s_fi[tid] = k1_fi;
+        __syncthreads();
+    }
     uint32_t steps = meta.x, flags = meta.y, status = 0;
     // gymnasium's next-step autoreset (the call after an episode's last step IS the reset: action ignored, reward 0, no
     // flags); "episode ended" travels in bit 1 of the flags word like in k_continuous_step.  Served here without noise or
@@ -640,8 +670,6 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     bool pend = nextmode && (flags & 2u) != 0u;
     flags &= ~2u;
 
-    Pcg64 g;
-    if (ZIG && !HELPER) g.load(a.env_s, a.env_inc, i);
     const ZT *zslot = s_z + ln;                 // HELPER: this step's normals, set per step
     int zi = 0;
     float zf[NPS];                              // PHILOX without helper waves: this step's normals
@@ -742,13 +770,15 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     constexpr int kCBufs = NOISE ? 1 : MDPP_CBUFS;
     static_assert(kCBufs >= 1 && kCBufs <= 3, "one to three named buffers");
     float pre[kCAhead][D], pre1[kCBufs > 1 ? kCAhead : 1][D], pre2[kCBufs > 2 ? kCAhead : 1][D];
+    if constexpr (!K1) {
 #pragma unroll
     for (int u = 0; u < kCAhead; u++) load_row(u, pre[u]);
-    if constexpr (kCBufs > 1) {
+    }
+    if constexpr (kCBufs > 1 && !K1) {
 #pragma unroll
         for (int u = 0; u < kCAhead; u++) load_row(kCAhead + u, pre1[u]);
     }
-    if constexpr (kCBufs > 2) {
+    if constexpr (kCBufs > 2 && !K1) {
 #pragma unroll
         for (int u = 0; u < kCAhead; u++) load_row(2 * kCAhead + u, pre2[u]);
     }
@@ -802,6 +832,14 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         // ---- C1: Box.contains(action)
         const bool ok = all_within(act, amax);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        if constexpr (K1) {
+            if (__builtin_expect(!all_ok, 0)) {          // a rejected action keeps every derivative and returns the last observation
+#pragma unroll
+                for (int d = 0; d < D; d++) sd[ORDER][d] = a.sd[((size_t)ORDER * D + d) * N + i];
+#pragma unroll
+                for (int d = NREL; d < D; d++) cur[d] = a.cur[(size_t)d * N + i];
+            }
+        }
         // ---- C2
         // The reference updates state_derivatives in place, lowest order first (:1654-1669); row i
         // only reads rows above it, which are still this step's inputs (row n = a / inertia), so
@@ -1067,14 +1105,20 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             step(act, c * kCAhead + u);
         }
     };
-    const int nfull = K / kCAhead, ngrp = nfull / kCBufs;
+    if constexpr (K1) {
+        float act[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) act[d] = k1act[d];
+        step(act, 0);
+    }
+    const int nfull = K1 ? 0 : K / kCAhead, ngrp = nfull / kCBufs;
     for (int gq = 0; gq < ngrp; gq++) {
         chunk(pre, gq * kCBufs);
         if constexpr (kCBufs > 1) chunk(pre1, gq * kCBufs + 1);
         if constexpr (kCBufs > 2) chunk(pre2, gq * kCBufs + 2);
     }
     // the last full chunks and the ragged tail: rows already in the buffers (loads past the end were clamped)
-    for (int k = ngrp * kCBufs * kCAhead; k < K; k++) {
+    for (int k = ngrp * kCBufs * kCAhead; k < (K1 ? 0 : K); k++) {
         float act[D];
         const int rel = k - ngrp * kCBufs * kCAhead, b = rel / kCAhead, u = rel % kCAhead;
 #pragma unroll
@@ -1090,6 +1134,24 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     if constexpr (CROWS) {
         if (crows && k_rows > 0) flush_rows(k_rows / kRS - 1);          // (the last group)
     }
+    if constexpr (K1) {
+        // One step leaves 150-250 B of state per env: as plain stores they sit dirty in the L2s until the launch ends and are
+        // written back THEN, all at once, before the next launch may start (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B
+        // dirty bytes: 10 MB = 1.7 us per step); as non-temporal stores they leave while the other waves still compute.
+#ifndef MDPP_K1_PLAIN_STORES
+#pragma unroll
+        for (int k = 0; k <= ORDER; k++)
+#pragma unroll
+            for (int d = 0; d < D; d++) __builtin_nontemporal_store(sd[k][d], &a.sd[((size_t)k * D + d) * N + i]);
+#pragma unroll
+        for (int d = 0; d < D; d++) __builtin_nontemporal_store(cur[d], &a.cur[(size_t)d * N + i]);
+        __builtin_nontemporal_store(steps, &a.meta[i].x);
+        __builtin_nontemporal_store(flags | (pend ? 2u : 0u), &a.meta[i].y);
+        if (ZIG) g.store(a.env_s, i);
+        if (status) atomicOr(&a.status[i], status);
+        return;
+#endif
+    }
 #pragma unroll
     for (int k = 0; k <= ORDER; k++)
 #pragma unroll
@@ -1101,6 +1163,57 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     if (status) atomicOr(&a.status[i], status);
 }
 
+#ifndef MDPP_CFAST_TU_K1
+#define MDPP_CFAST_TU_K1 0         // 1: this translation unit holds the one-step instantiations (mdpp_continuous_step1.hip)
+#endif
+#if MDPP_CFAST_TU_K1
+// mdpp_step (K = 1) on the fast shape: k_continuous_rollout_fast<..., K1 = true>.  Returns false when the shape is not built
+// here or the launch needs what K1 leaves out (numpy noise streams: whole 256-env blocks) -- the caller then launches the
+// rollout kernel with K = 1 as before.
+template <int D, int ORDER, int NREL, bool NOISE, bool GEN, bool PHILOX>
+static bool launch_k1(const ContinuousArgs &a, const float *actions, float *obs, float *reward, uint8_t *term, uint8_t *trunc,
+                      float *final_obs, hipStream_t s, char *name_out) {
+    constexpr bool ZIG = NOISE && !PHILOX;
+    constexpr int WG = ZIG ? kBlock : 64;
+    if (ZIG && (a.N % kBlock) != 0) return false;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_continuous_step1<D=%d,ORDER=%d,NREL=%d,NOISE=%d,GEN=%d,PHILOX=%d,WG=%d>", D, ORDER, NREL, NOISE, GEN, PHILOX, WG);
+        return true;
+    }
+    hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, NOISE, false, GEN, PHILOX, 1, true>), dim3((a.N + WG - 1) / WG), dim3(WG),
+                       0, s, a, 1, actions, obs, reward, term, trunc, final_obs);
+    return true;
+}
+
+bool launch_continuous_step1(const ContinuousArgs &a, const float *actions, float *obs, float *reward, uint8_t *term,
+                             uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
+    if (!a.fast_ok || (a.opts & (MDPP_OPT_NO_CFAST | MDPP_OPT_NO_STEP1)) || (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST))) return false;
+    const bool gen = a.delay > 0 || a.every_n != 1 || a.n_boxes > 0 || !a.bounded;
+    const bool noise = a.has_p_noise || a.has_r_noise;
+#define MDPP_K1(DD, OO, RR)                                                                                                  \
+    if (a.D == DD && a.order == OO && a.n_rel == RR) {                                                                        \
+        const int sel = (noise ? 4 : 0) | (gen ? 2 : 0) | (a.philox ? 1 : 0);                                                \
+        switch (sel) {                                                                                                        \
+        case 0: return launch_k1<DD, OO, RR, false, false, false>(a, actions, obs, reward, term, trunc, final_obs, s, name_out); \
+        case 1: return launch_k1<DD, OO, RR, false, false, true>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);  \
+        case 2: return launch_k1<DD, OO, RR, false, true, false>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);  \
+        case 3: return launch_k1<DD, OO, RR, false, true, true>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);   \
+        case 4: return launch_k1<DD, OO, RR, true, false, false>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);  \
+        case 5: return launch_k1<DD, OO, RR, true, false, true>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);   \
+        case 6: return launch_k1<DD, OO, RR, true, true, false>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);   \
+        default: return launch_k1<DD, OO, RR, true, true, true>(a, actions, obs, reward, term, trunc, final_obs, s, name_out);   \
+        }                                                                                                                     \
+    }
+    MDPP_K1(12, 1, 4) MDPP_K1(12, 2, 4)
+#ifndef MDPP_CF_SHAPES_MIN
+    MDPP_K1(2, 1, 2) MDPP_K1(2, 2, 2) MDPP_K1(4, 1, 4) MDPP_K1(4, 2, 4)
+    MDPP_K1(8, 1, 8) MDPP_K1(8, 2, 8) MDPP_K1(12, 1, 12) MDPP_K1(12, 2, 12)
+    MDPP_K1(4, 1, 2) MDPP_K1(4, 2, 2) MDPP_K1(8, 1, 4) MDPP_K1(8, 2, 4)
+#endif
+#undef MDPP_K1
+    return false;
+}
+#else
 template <int D, int ORDER, int NREL, bool GEN, bool PHILOX>
 static void launch_g(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
@@ -1168,5 +1281,6 @@ bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions
 #undef MDPP_CF
     return false;
 }
+#endif   // !MDPP_CFAST_TU_K1
 
 } // namespace mdpp

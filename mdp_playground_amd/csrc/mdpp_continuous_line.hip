@@ -5,7 +5,7 @@
 // (:1864-1910, dist_of_pt_from_line :2546-2576) is the same line fit as c_line_reward in mdpp_continuous.hip -- float32
 // mean in numpy's pairwise order, dominant eigenvector of the float64 scatter matrix by repeated squaring, rounded to
 // float32, float64 distances -- organised for one wave per SIMD, where k_continuous_step spends 2 584 vector instructions
-// per step (profiles/r03_sq_line_and_noise.txt):
+// per step (profiles/archive/r03_sq_line_and_noise.txt):
 //   * the L points of every lane live in LDS for the launch (float4 [slot][lane]; HBM is written through, so that
 //     k_continuous_step / mdpp_step can take over at any time);
 //   * the raw moments sum x, sum x x^T of the window are carried in registers and updated by the point that enters and the

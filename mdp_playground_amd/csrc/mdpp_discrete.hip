@@ -462,6 +462,8 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
         }
     }
     if (lean_philox) {
+    } else if (K == 1 && launch_discrete_step1(a, h->s1args, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
+        // mdpp_step on the common shape: the kernel made for a launch of one step (mdpp_discrete_step1.hip)
     } else if (a.fast_ok) {
         // common shape: dedicated rollout kernel (mdpp_discrete_fast.hip); its buffer descriptors
         // address < 4 GiB per output array, so very long rollouts go out as several launches

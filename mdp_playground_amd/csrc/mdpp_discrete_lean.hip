@@ -53,7 +53,7 @@
 //     walks positions: reads meta[p], meta[p + 1], meta[p + 2] (fetched one step ahead), copies x[p] into the step's
 //     record for O1, and moves on by the draw's words (+ 1 if the episode ended); H runs up to 16 positions ahead of the
 //     position E publishes and un-draws what E did not reach at the end of the launch.
-// What the measurements said (profiles/r02_ablation_lean_kernel.txt): with the default cache policy
+// What the measurements said (profiles/archive/r02_ablation_lean_kernel.txt): with the default cache policy
 // the time was set by the stores, whoever issued them (147 us per 512-step launch of 65 536 envs with
 // one, two or three storing waves per SIMD); marked nt they cost 10 us on top of the 95 us the
 // recurrence + start-state draws take, 106 us = 5.7 TB/s.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // Philox streams: the waves that make Philox blocks are the long stages and go first -- H (start states, and with PN
     // the transition-noise words), with RN the O1 wave (normals) -- and the E wave, now the shortest stage, last:
     // cfg2 128 -> 122 us per launch, + transition noise 195 -> 144, + reward noise 181 -> 167, both 227 -> 184
-    // (profiles/r03_ablation_lean_priorities.txt).
+    // (profiles/archive/r03_ablation_lean_priorities.txt).
     // numpy streams with noise: H (both generators) is the long stage: E 3 O 2 H 0 -> 497 us per cfg2 + noise launch, E 2 O 1 H 3 -> 420
     // (profiles/r04_ablation_npnoise.txt)
     constexpr bool kNpNoise = !PHILOX && NZ != 0;

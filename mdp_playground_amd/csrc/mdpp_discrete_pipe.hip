@@ -3,7 +3,7 @@
 // rl_toy_env.py:1992-2125, reset :2250-2278).
 //
 // One wavefront per SIMD — all a 65 536-env job offers when a lane is an env — leaves about half
-// of every SIMD's issue slots idle (measured: profiles/r01_ablation_fast_kernel.txt).  Here a
+// of every SIMD's issue slots idle (measured: profiles/archive/r01_ablation_fast_kernel.txt).  Here a
 // 768-thread workgroup steps 256 envs with three waves per SIMD, each doing a third of the work:
 //   E  waves 0-3   state recurrence: cur -> next, sequence key, episode counters, terminal test,
 //                  same-step autoreset from the queue of pre-drawn start states; one 32-bit
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(3 * kBlock) void k_discrete_rollout_pipe(DiscreteAr
     // Actions are fetched kPipeAhead chunks ahead of their use, columns one chunk ahead.  The buffers rotate by
     // NAME (chunk loop unrolled kPipeAhead times, single exit, no global load in an inner loop): a copy of a
     // register whose load is in flight makes the wave wait for the load, and a `break` in the unrolled body makes
-    // it wait for every load at the loop head (found on k_discrete_rollout_lean, profiles/r02_ablation_lean_kernel.txt)
+    // it wait for every load at the loop head (found on k_discrete_rollout_lean, profiles/archive/r02_ablation_lean_kernel.txt)
     constexpr int kPipeAhead = 2;
     int actq[kPipeAhead][kChunk];   // slot (m - 1) % kPipeAhead holds the actions of chunk m
     uint64_t colq[2][kChunk];       // slot m & 1 holds the columns of chunk m

@@ -15,7 +15,7 @@
 //     env stream is again exactly where the reference's would be.  Nothing else reads the env
 //     stream on this path (no reward noise), so the draws are consumed in stream order.
 // DUO: one wavefront per SIMD -- all a 65 536-env job gives a lane-per-env kernel -- leaves about
-// half of the SIMD's issue slots idle (profiles/r01_ablation_fast_kernel.txt).  With full 256-env
+// half of the SIMD's issue slots idle (profiles/archive/r01_ablation_fast_kernel.txt).  With full 256-env
 // blocks and K >= 32 the step is therefore split over TWO waves per SIMD (512-thread workgroups),
 // like k_discrete_rollout_pipe does for the packed shapes:
 //   E  waves 0-3  state recurrence of both sub-spaces, sequence key, episode counters, terminal

@@ -1,0 +1,190 @@
+// RLToyEnv.step() as ONE launch of ONE step (mdpp_step, K = 1) for the common discrete shape: one shared MDP, unit
+// rewards, no noise, sequence_length <= 3, S <= 16 (DiscreteArgs::fast_ok, the shape of BASELINE cfg 1 / 2; Philox
+// streams: shape_ok, the start state from the tick's word like everywhere else, no queue and no generator state).
+// Same arithmetic as k_discrete_rollout_fast (mdpp_discrete_fast.hip; reference rl_toy_env.py:1992-2125, reset
+// :2250-2278) -- what differs is what a launch of one step is made of.  At 65 536 envs a step moves 2.7 MB: 0.34 us
+// of HBM time; the launch is nothing but latencies in series.  The rollout kernel with K = 1 paid five of them one after
+// another (table BYTE loads -> barrier -> record + generator loads -> action load -> table lookups; 5.3 us per launch,
+// profiles/r04_kernel_stats.csv).  Here:
+//   * every global load of the launch is issued in the first instructions, side by side: the lane's 16-byte piece of a
+//     1 KiB table blob packed at upload (mdpp_upload_discrete_tables), the action, the 16-byte record, the generator;
+//   * 64-thread workgroups: the wave stages the blob into LDS for itself -- no barrier anywhere, and the chip's 1 024
+//     SIMDs all start at once (256-thread workgroups with a barrier: 2.63 instead of 2.51 us per step in a replayed graph);
+//   * the start-state queue (word 1 of the record, shared with the rollout kernels) is topped up AFTER the step's outputs
+//     have been stored, one draw per lane and launch -- a lane pops at most one start state per step, so a queue that
+//     holds one never runs dry and no draw sits between the loads and the observation store;
+//   * `steps % every_n` without an integer division (float64 reciprocal, one conditional subtract).
+// HBM traffic per env step: 4 B action + 16 B record + 32 B generator in; 16 B record + 14 B outputs (+ 16 B generator
+// state for the lanes that drew) out.
+#include "mdpp_internal.hpp"
+#include "mdpp_rng.hpp"
+
+namespace mdpp {
+
+typedef unsigned int s1_u32x2 __attribute__((ext_vector_type(2)));
+
+// The blob: 64 x uint4.  dwords 0-31: column a of P as 16 nibbles (nibble s = P[s][a]), a < 16; dwords 32-63: the
+// rho_0 thresholds ceil(cdf[j] 2^53) (2^64 - 1 beyond S); dwords 64-191: the 4 096 reward bits; dwords 192-207: the
+// thresholds of a Philox start state, ceil(cdf[j] 2^31) (2^32 - 1 beyond S); the rest zero.
+constexpr int kS1Cols = 0, kS1Thr = 32, kS1Rew = 64, kS1Thr31 = 192;
+
+template <bool OBS64, bool PHILOX>
+__global__ __launch_bounds__(64) void k_discrete_step1(Step1Args a) {
+    constexpr int WG = 64;
+    __shared__ __align__(16) uint32_t lds[256];
+    const int tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * WG + tid;
+    const bool live = i < (uint32_t)a.N;
+    const uint32_t ic = live ? i : (uint32_t)a.N - 1u;     // (spare lanes of the last block load lane N - 1's data and store nothing)
+    // ---- every load of the launch, issued together ----
+    const uint4 blob4 = a.blob[tid];
+    const int action = a.actions[ic];
+    const uint4 st = a.state[ic];
+    Pcg64 g;
+    if (!PHILOX) g.load(a.env_s, a.env_inc, ic);
+    const uint64_t tick = PHILOX ? a.ptick + (a.dtick ? *a.dtick : 0ULL) : 0ULL;   // (a graph replay: through the device-side offset)
+    ((uint4 *)lds)[tid] = blob4;
+    __builtin_amdgcn_wave_barrier();                       // one wave: LDS accesses complete in order, nothing to wait for
+    const uint32_t A = a.A, S = a.S, L = a.L;
+    uint32_t status = 0;
+
+    // ---- D1: the action's column of P (numpy negative indexing; anything else out of range is flagged, action 0) ----
+    uint32_t ua = (uint32_t)action;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(ua >= A) != 0, 0)) {
+        ua = (uint32_t)(action + ((action >> 31) & (int)A));
+        const bool bad = ua >= A;
+        status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+        ua = bad ? 0u : ua;
+    }
+    const uint64_t col = ((const uint64_t *)(lds + kS1Cols))[ua];
+
+    // word 1 of the record: numpy streams -- the queue of start states; Philox streams -- history bytes 4-7 (the general kernel's
+    // 64-bit shift register: kept, never read at L <= 3)
+    uint32_t hist = st.x, qv = st.y & 0x00FFFFFFu, qc = (st.y >> 24) & 7u, steps = st.z, ring = st.w;
+    uint32_t hist_hi = (st.y << 8) | (st.x >> 24);
+    const uint32_t cur = hist & 0xFFu;
+    const uint32_t nxt = (uint32_t)(col >> (cur << 2)) & 0xFu;
+    // ---- D3 / D4: sequence key over the last L states (NaN bytes count as 0 and are gated below) ----
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {                         // bytes L-2 .. 0 of the OLD history, then the new state
+        if (j <= (int)L - 2) {
+            const uint32_t b = (hist >> (8 * j)) & 0xFFu;
+            key = key * S + (b == 0xFFu ? 0u : b);
+        }
+    }
+    key = key * S + nxt;
+    hist = (hist << 8) | nxt;
+    steps += 1;
+    const bool full = (hist & a.nan_mask) != a.nan_mask;   // L transitions since reset (:1822)
+    // steps % every_n: q = floor(steps * (1 / every_n)) in float64 is the quotient or one less (every_n < 2^20)
+    uint32_t phase;
+    {
+        const uint32_t q = (uint32_t)((double)steps * a.inv_every_n);
+        phase = steps - q * a.every_n;
+        phase = phase >= a.every_n ? phase - a.every_n : phase;
+    }
+    const uint32_t word = lds[kS1Rew + (key >> 5)];
+    const uint32_t done = (a.term32 >> nxt) & 1u;                                              // D7
+    const uint32_t tr = (a.max_steps && steps >= a.max_steps) ? 1u : 0u;
+    const bool need = a.autoreset && ((done | tr) != 0);
+    // ---- D4-D7: reward bit -> delay line -> every-n mask -> one of four host-made float32 rewards ----
+    uint32_t bit = (word >> (key & 31u)) & (full ? 1u : 0u);
+    if (a.delay) {
+        const uint32_t out = (ring >> (a.delay - 1u)) & 1u;
+        ring = (ring << 1) | bit;
+        bit = out;
+        ring = need ? 0u : ring;                           // reset() clears the FIFO (:2250)
+    }
+    bit = phase == 0 ? bit : 0u;                           // steps % every_n == 0 (:1975)
+    const float rout = done ? (bit ? a.rsel[3] : a.rsel[1]) : (bit ? a.rsel[2] : a.rsel[0]);
+
+    // ---- same-step autoreset: pop a start state; an empty queue (the first step after a reset() / a new seed) draws in place ----
+    auto draw = [&](Pcg64 &gen) -> uint32_t {
+        const uint64_t m = gen.next64() >> 11;
+        uint32_t s0 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s0 += (((const uint64_t *)(lds + kS1Thr))[j] <= m) ? 1u : 0u;
+        if (S > 8) {
+#pragma unroll
+            for (int j = 8; j < 16; j++) s0 += (((const uint64_t *)(lds + kS1Thr))[j] <= m) ? 1u : 0u;
+        }
+        return s0;
+    };
+    bool drew = false;
+    uint32_t ocur = nxt;
+    if constexpr (PHILOX) {
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {      // the tick's word of the start-state stream (mdpp_rng.hpp)
+            const uint32_t m31 = philox_start_m31(a.philox_seed, (uint64_t)(a.env_id_offset + (int64_t)ic), tick, kPhiloxStartStream);
+            uint32_t s0 = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) s0 += (lds[kS1Thr31 + j] <= m31) ? 1u : 0u;
+            if (need) { ocur = s0; hist = 0xFFFFFF00u | s0; hist_hi = 0xFFFFFFFFu; steps = 0; }
+        }
+    } else {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need && qc == 0) != 0, 0)) {
+            Pcg64 n = g;
+            const uint32_t s0 = draw(n);
+            if (need && qc == 0) { g = n; qv = s0; qc = 1; drew = true; }
+        }
+        if (need) {
+            ocur = qv & 0xFu;
+            hist = 0xFFFFFF00u | ocur;
+            steps = 0;
+            qv >>= 4; qc -= 1;
+        }
+    }
+    // ---- outputs ----
+    if (live) {
+        if (__builtin_expect(a.final_obs != nullptr, 0)) {
+            if (need) {
+                if (OBS64) ((s1_u32x2 *)a.final_obs)[i] = s1_u32x2{nxt, 0u};
+                else ((uint32_t *)a.final_obs)[i] = nxt;
+            }
+        }
+        if (OBS64) ((s1_u32x2 *)a.obs)[i] = s1_u32x2{ocur, 0u};
+        else ((uint32_t *)a.obs)[i] = ocur;
+        a.reward[i] = rout;
+        a.term[i] = (uint8_t)done;
+        a.trunc[i] = (uint8_t)tr;
+    }
+    // ---- top the queue up, off the path to the outputs: rounds of one draw per lane that has room ----
+    if (!PHILOX && a.autoreset) {
+        for (uint32_t r = 0; r < a.topup_rounds; r++) {
+            const bool want = qc < a.topup_fill;
+            if (__builtin_amdgcn_ballot_w64(want) == 0) break;
+            Pcg64 n = g;
+            const uint32_t s0 = draw(n);
+            if (want) { g = n; qv |= s0 << (4u * qc); qc += 1; drew = true; }
+        }
+    }
+    if (live) {
+        a.state[i] = make_uint4(hist, PHILOX ? hist_hi : (qv | (qc << 24)), steps, ring);
+        if (drew) g.store(a.env_s, i);
+        if (status) atomicOr(&a.status[i], status);
+    }
+}
+
+bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const int32_t *actions, void *obs, float *reward,
+                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
+    if (!proto.blob || (d.opts & MDPP_OPT_NO_STEP1)) return false;
+    if (d.philox ? (!d.shape_ok || (d.opts & MDPP_OPT_NO_PHILOX_FAST)) : !d.fast_ok) return false;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_step1<OBS64=%d,PHILOX=%d>", !d.obs_i32, d.philox);
+        return true;
+    }
+    Step1Args a = proto;
+    a.actions = actions; a.obs = obs; a.reward = reward; a.term = term; a.trunc = trunc; a.final_obs = final_obs;
+    a.ptick = d.ptick; a.dtick = d.dtick;
+    const int grid = (a.N + 63) / 64;
+    if (d.philox) {
+        if (d.obs_i32) hipLaunchKernelGGL((k_discrete_step1<false, true>), dim3(grid), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_discrete_step1<true, true>), dim3(grid), dim3(64), 0, s, a);
+    } else {
+        if (d.obs_i32) hipLaunchKernelGGL((k_discrete_step1<false, false>), dim3(grid), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((k_discrete_step1<true, false>), dim3(grid), dim3(64), 0, s, a);
+    }
+    return true;
+}
+
+} // namespace mdpp

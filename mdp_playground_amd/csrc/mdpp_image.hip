@@ -11,7 +11,7 @@
 //                 (Doing this inside the render kernel put ~400 scalar instructions per wave on
 //                 the CU's single scalar unit: 6 us of a 20 us launch, and vector loads of the
 //                 per-image scalars wait on vmcnt together with the previous image's stores;
-//                 profiles/r01_ablation_image_kernel.txt.)
+//                 profiles/archive/r01_ablation_image_kernel.txt.)
 //  k_image_obs*   one WAVEFRONT per image, a pure rasteriser: reads the record with scalar loads
 //                 and writes the uint8[W][H][1] observation.  A pixel is produced by walking the
 //                 reference's pipeline backwards:
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_image_obs(ImageArgs a, long M, const
 }
 
 // ---- fast renderer (conditions checked on the host, mdpp_capi.hip: img_fast_ok) ----------------
-// Measured on the general renderer (profiles/r01_ablation_image_kernel.txt): the per-pixel map and
+// Measured on the general renderer (profiles/archive/r01_ablation_image_kernel.txt): the per-pixel map and
 // the four range tests dominate, and stores that leave holes in a cache line are several times
 // slower than full-line stores.  So:
 //  * the four waves of a workgroup share 64 LDS rows of 256 B; wave w owns byte columns

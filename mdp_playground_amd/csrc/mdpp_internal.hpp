@@ -13,7 +13,7 @@ namespace mdpp {
 // Cache policy of the rollout kernels' OUTPUT stores (aux of the raw-buffer store builtins; 2 = nt).  Every
 // output row is written once and never read by the kernel; left at the default policy the write-back
 // traffic of these rows throttled the whole memory pipeline of the CU (cfg2 fused rollout: 147 -> 106 us
-// per launch with nt, profiles/r02_ablation_lean_kernel.txt).  NOT for the picture kernels: their 16-byte
+// per launch with nt, profiles/archive/r02_ablation_lean_kernel.txt).  NOT for the picture kernels: their 16-byte
 // stores of whole pictures ran 0.51 -> 0.44 (polygon pictures) and 0.54 -> 0.18 (continuous pictures) with nt.
 #ifndef MDPP_ST_NT
 #define MDPP_ST_NT 2
@@ -116,6 +116,32 @@ struct DiscreteArgs {
     uint64_t init_thr[16];      // ceil(init_cdf[j] * 2^53): cdf[j] <= u  <=>  init_thr[j] <= (r >> 11)
     float rsel[4];              // reward for {paid*2 + terminal}, formed in float64 like :1987-1990,:2107
     uint64_t minv_lo, minv_hi;  // inverse of the PCG64 LCG multiplier mod 2^128 (un-drawing)
+};
+
+// ---- discrete, one launch = one step (mdpp_discrete_step1.hip): everything the kernel reads, nothing else -- built once at
+// mdpp_upload_discrete_tables (the caller's buffers are filled in per launch)
+struct Step1Args {
+    int32_t N;
+    uint32_t A, S, L, every_n, max_steps, delay, autoreset;
+    uint32_t term32;            // bit s: state s terminal (S <= 16)
+    uint32_t nan_mask;          // 0xFF << 8 L: history byte L is the NaN test (:1822)
+    uint32_t topup_rounds, topup_fill;   // start-state queue: at most this many rounds of one draw per lane after a step, up to this many entries
+    float rsel[4];              // reward for {paid*2 + terminal} (DiscreteArgs::rsel)
+    double inv_every_n;
+    uint64_t ptick;             // Philox streams: env steps taken by this handle before this launch ...
+    const uint64_t *dtick;      // ... plus this device word when the launch is replayed from a graph (tick_now)
+    uint64_t philox_seed;
+    int64_t env_id_offset;
+    const uint4 *blob;          // 1 KiB: P columns as nibbles, rho_0 thresholds, reward bits (layout: mdpp_discrete_step1.hip)
+    const int32_t *actions;
+    void *obs;
+    float *reward;
+    uint8_t *term, *trunc;
+    void *final_obs;
+    uint4 *state;
+    ulonglong2 *env_s;
+    const ulonglong2 *env_inc;
+    uint32_t *status;
 };
 
 struct ContinuousArgs {
@@ -256,6 +282,8 @@ struct mdpp_env {
     hipStream_t side_stream;
     hipEvent_t ev_entry, ev_side[2], ev_render[2];
     mdpp::DiscreteArgs dargs;
+    mdpp::Step1Args s1args;     // k_discrete_step1's argument block (blob == nullptr: the shape does not qualify)
+    void *d_s1_blob;
     mdpp::ContinuousArgs cargs;
     mdpp::GridArgs gargs;
 };
@@ -273,6 +301,8 @@ bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, 
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_continuous_reset(mdpp_env *h, const uint8_t *mask, float *obs, hipStream_t s);
+bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const int32_t *actions, void *obs, float *reward,
+                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_discrete_pipe(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
@@ -281,6 +311,8 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
+bool launch_continuous_step1(const ContinuousArgs &a, const float *actions, float *obs, float *reward, uint8_t *term,
+                             uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
 bool launch_continuous_line(const ContinuousArgs &a, int K, const float *actions, float *obs, float *reward,
                             uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_states, const uint8_t *term,

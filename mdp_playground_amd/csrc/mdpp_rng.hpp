@@ -489,7 +489,7 @@ __device__ __forceinline__ double np_zig_tail(G &g, uint64_t rabs) {
 }
 
 // random_standard_normal: numpy's loop verbatim with the tables in LDS.  Measured at one wave per
-// SIMD (tools/bench_rng.hip, profiles/r01_rng_microbench.txt) this plain form (412 ns per draw per
+// SIMD (tools/bench_rng.hip, profiles/archive/r01_rng_microbench.txt) this plain form (412 ns per draw per
 // wave) beats both a wave-uniform restructuring of the wedge path and a chord/tangent pre-test
 // that avoids exp() (530-750 ns): the rejection branches are short and rarely re-entered.
 __device__ __forceinline__ double np_standard_normal_lds(Philox &g, const ZigLds &) { return g.normal(); }

@@ -12,17 +12,24 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libmdpp_oracle.so")
+# MDPP_ORACLE_SANITIZE=1: load the AddressSanitizer + UBSan build instead (the process must have libasan preloaded:
+# tests/test_oracle_sanitized.py starts such a child)
+_SANITIZE = os.environ.get("MDPP_ORACLE_SANITIZE", "") == "1"
+_SO = os.path.join(_HERE, "_build", "libmdpp_oracle_san.so" if _SANITIZE else "libmdpp_oracle.so")
 
 
-def build(force=False):
+def build(force=False, sanitize=None):
+    """Compile the restatement (gcc; `make -C oracle`).  sanitize=True: the -fsanitize=address,undefined build,
+    oracle/_build/libmdpp_oracle_san.so (`make sanitize`).  Returns the path of the library built."""
+    sanitize = _SANITIZE if sanitize is None else sanitize
+    so = os.path.join(_HERE, "_build", "libmdpp_oracle_san.so" if sanitize else "libmdpp_oracle.so")
     srcs = ["mdpp_oracle.c", "np_random.c", "mdpp_oracle.h", "np_random.h",
             "np_ziggurat_tables.inc", "Makefile"]
-    stale = force or not os.path.exists(_SO) or any(
-        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_SO) for s in srcs)
+    stale = force or not os.path.exists(so) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(so) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
-    return _SO
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + (["sanitize"] if sanitize else []))
+    return so
 
 
 _lib = None

@@ -848,23 +848,34 @@ def _oracle_autoreset_rollout(o, acts, max_steps):
 
 
 @pytest.mark.parametrize("variant", sorted(FAST_VARIANTS))
-@pytest.mark.parametrize("fused,N", [(True, 1000), (True, 1024), (False, 1000)])
+@pytest.mark.parametrize("fused,N", [(True, 1000), (True, 1024), (False, 1000), ("rollout_k1", 1000), ("mixed", 1000)])
 def test_discrete_fast_kernel_vs_oracle(variant, fused, N):
     """N = 1000: partial last block, RNG drawn by the env lanes; N = 1024 and >= 32 fused steps:
-    the helper-wave variant (start states produced by partner waves through an LDS ring)."""
+    the helper-wave variant (start states produced by partner waves through an LDS ring).  Single steps (fused False):
+    k_discrete_step1, the kernel of a one-step launch (round 5); "rollout_k1": the rollout kernel with K = 1, which served
+    mdpp_step before; "mixed": single steps, a fused piece, single steps again -- the queue of start states is shared."""
     cfg, kw, T = FAST_VARIANTS[variant]
     env = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
-    assert env.rollout_kernel_name(1).startswith("k_discrete_rollout_fast")
+    if fused == "rollout_k1":
+        env.set_kernel_options("NO_STEP1")
+        assert env.rollout_kernel_name(1).startswith("k_discrete_rollout_fast")
+        fused = False
+    else:
+        assert env.rollout_kernel_name(1).startswith("k_discrete_step1<"), env.rollout_kernel_name(1)
     A = env.mdps[0].A
     acts = np.random.default_rng(3).integers(0, A, size=(T, N)).astype(np.int32)
     init = env._obs.cpu().numpy().copy()
-    if fused:
+    if fused is True:
         obs, rew, term, trunc = env.rollout(torch.as_tensor(acts, device=env.device))
         obs, rew, term, trunc = (x.cpu().numpy() for x in (obs, rew, term, trunc))
     else:
         obs = np.zeros((T, N), np.int64); rew = np.zeros((T, N), np.float32)
         term = np.zeros((T, N), bool); trunc = np.zeros((T, N), bool)
-        for t in range(T):
+        k0, k1 = (T // 3, T - T // 3) if fused == "mixed" else (T, T)       # [k0, k1): one fused launch
+        for t in list(range(k0)) + list(range(k1, T)):
+            if t == k1 and k1 > k0:
+                fo = env.rollout(torch.as_tensor(acts[k0:k1], device=env.device))
+                obs[k0:k1], rew[k0:k1], term[k0:k1], trunc[k0:k1] = (x.cpu().numpy() for x in fo)
             o, r, te, tr, info = env.step(torch.as_tensor(acts[t], device=env.device))
             obs[t], rew[t], term[t], trunc[t] = (x.cpu().numpy() for x in (o, r, te, tr))
     end_env = env.get_rng_streams(0)
@@ -1662,7 +1673,9 @@ def test_full_size_rollout_equals_single_steps_and_oracle_sample(name, N):
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     if name == "d_cfg2":         # the benchmarked kernel itself is what the oracle sees here
         assert a.rollout_kernel_name(T).startswith("k_discrete_rollout_lean<"), a.rollout_kernel_name(T)
-        assert a.rollout_kernel_name(1).startswith("k_discrete_rollout_fast<")
+        assert a.rollout_kernel_name(1).startswith("k_discrete_step1<")       # (round 5: mdpp_step has its own kernel)
+    if name in ("c_cfg3", "c_cfg5"):
+        assert a.rollout_kernel_name(1).startswith("k_continuous_step1<"), a.rollout_kernel_name(1)
     rng = np.random.default_rng(0)
     from mdp_playground_amd import _capi as capi
     streams = [0, 1]
@@ -2389,4 +2402,79 @@ def test_rollout_is_graph_capturable(what):
         torch.cuda.synchronize()
         ob, rb, tb, _ = b.rollout(acts)
         assert torch.equal(out_a[0], ob) and torch.equal(out_a[1], rb) and torch.equal(out_a[2].view(torch.bool), tb), rep
+    a.close(); b.close()
+
+
+# ----------------------------------------------------------------------------- one launch = one step (round 5)
+_S1_D_CFG2 = dict(gu.CASES["d_cfg2"]["config"], seed=3)
+_S1_C_CFG3 = dict(gu.CASES["c_cfg3"]["config"], seed=3)
+_S1_C_CFG5 = dict(gu.CASES["c_cfg5"]["config"], seed=3)
+STEP1_CASES = {
+    # name: (config, constructor keywords, N, expected kernel prefix or None)
+    "d_cfg2_numpy": (_S1_D_CFG2, dict(autoreset="same_step"), 4096, "k_discrete_step1<OBS64=1,PHILOX=0>"),
+    "d_cfg2_philox": (_S1_D_CFG2, dict(autoreset="same_step", rng="philox"), 4096, "k_discrete_step1<OBS64=1,PHILOX=1>"),
+    "d_cfg2_philox_ragged_disabled": (_S1_D_CFG2, dict(autoreset="disabled", rng="philox"), 1000, "k_discrete_step1<"),
+    "d_s16_trunc": (FAST_VARIANTS["s16_l1_trunc"][0], dict(autoreset="same_step", max_episode_steps=5), 1000, "k_discrete_step1<"),
+    "d_s16_trunc_philox": (FAST_VARIANTS["s16_l1_trunc"][0], dict(autoreset="same_step", max_episode_steps=5, rng="philox"), 1000,
+                           "k_discrete_step1<"),
+    "d_s6_nonpow2_everyn": (dict(FAST_VARIANTS["s6_l2_nonpow2"][0], reward_every_n_steps=3), dict(autoreset="same_step"), 1000,
+                            "k_discrete_step1<"),
+    "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),
+    "c_cfg3_ragged_next_step": (_S1_C_CFG3, dict(autoreset="next_step", max_episode_steps=7), 1000, "k_continuous_step1<"),
+    "c_cfg3_disabled": (_S1_C_CFG3, dict(autoreset="disabled"), 1000, "k_continuous_step1<"),
+    "c_cfg5_numpy": (_S1_C_CFG5, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=2,NREL=4,NOISE=1,GEN=0,PHILOX=0,WG=256>"),
+    "c_cfg5_numpy_ragged": (_S1_C_CFG5, dict(autoreset="same_step"), 1000, "k_continuous_rollout_fast<"),   # (numpy noise: whole blocks only)
+    "c_cfg5_philox": (_S1_C_CFG5, dict(autoreset="same_step", rng="philox"), 1000, "k_continuous_step1<"),
+    "c_boxes": (dict(gu.CASES["c_sparse_term"]["config"], seed=3), dict(autoreset="same_step"), 1000, "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=0,GEN=1"),
+    "c_everyn_rnoise": (dict(gu.CASES["c_small_radius_hit"]["config"], seed=3), dict(autoreset="same_step"), 1024, "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=1,GEN=1"),
+    "c_delay_order2": (dict(state_space_type="continuous", state_space_dim=4, transition_dynamics_order=2, inertia=2.0, time_unit=0.5,
+                            delay=2, action_space_max=1, state_space_max=3, target_point=[0.5, -0.5, 0.0, 1.0], target_radius=0.7,
+                            make_denser=True, reward_function="move_to_a_point", action_loss_weight=0.05, reward_scale=1.5,
+                            reward_shift=-0.25, term_state_reward=2.0, transition_noise=0.05, seed=3),
+                       dict(autoreset="same_step", rng="philox"), 1000, "k_continuous_step1<D=4,ORDER=2,NREL=4,NOISE=1,GEN=1,PHILOX=1"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(STEP1_CASES))
+def test_step1_kernels_equal_the_rollout_kernels_with_k1(case):
+    """mdpp_step's own kernels (k_discrete_step1, k_continuous_step1: every load of the launch issued at once, no
+    rollout prologue) against the kernels that served single steps until round 4 (the rollout kernels with K = 1, selected
+    with NO_STEP1; those are pinned to the oracle and the goldens by the tests above): every output of every step, the end
+    state and every stream's end state, bit for bit -- single steps, a fused piece in between (shared start-state queue),
+    rejected actions (continuous: "stay" makes the kernel read the rows it otherwise skips; discrete: the status bit)."""
+    cfg, kw, N, prefix = STEP1_CASES[case]
+    a, b = _venv(num_envs=N, **kw, **cfg), _venv(num_envs=N, **kw, **cfg)
+    b.set_kernel_options("NO_STEP1")
+    assert a.rollout_kernel_name(1).startswith(prefix), a.rollout_kernel_name(1)
+    assert "step1" not in b.rollout_kernel_name(1)
+    T = 48
+    g = np.random.default_rng(5)
+    if a.kind == "discrete":
+        A = a.mdps[0].A
+        acts = g.integers(0, A, size=(3 * T, N)).astype(np.int32)
+        acts[g.random((3 * T, N)) < 0.01] = -1          # numpy's negative index: the last action
+        acts[g.random((3 * T, N)) < 0.002] = A + 3      # out of range: action 0 and MDPP_STATUS_BAD_ACTION
+    else:
+        D = a.mdps[0].D
+        acts = g.uniform(-1, 1, size=(3 * T, N, D)).astype(np.float32)
+        bad = g.random((3 * T, N)) < 0.01
+        acts[bad, g.integers(0, D, size=int(bad.sum()))] = 1.5      # outside the action box: the env stays where it is
+    acts = torch.as_tensor(acts, device=a.device)
+
+    def same(x, y):
+        return torch.equal(x.view(torch.int32) if x.dtype.is_floating_point else x, y.view(torch.int32) if y.dtype.is_floating_point else y)
+    for t in list(range(T)) + list(range(2 * T, 3 * T)):
+        if t == 2 * T:
+            ra, rb = a.rollout(acts[T:2 * T]), b.rollout(acts[T:2 * T])
+            assert all(same(x, y) for x, y in zip(ra, rb)), (case, "fused piece")
+        ra, rb = a.step(acts[t]), b.step(acts[t])
+        assert all(same(x, y) for x, y in zip(ra[:4], rb[:4])), (case, t)
+    assert np.array_equal(a.status(), b.status())
+    sa, sb = a.get_augmented_state(), b.get_augmented_state()
+    for k in sa:
+        if isinstance(sa[k], np.ndarray):
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (case, k)
+    if kw.get("rng", "numpy") == "numpy":
+        for s in (0, 1):
+            assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (case, s)
     a.close(); b.close()

@@ -7,7 +7,8 @@ Times, on ONE core of this container and in the same process:
     random actions, reset on done; log_level=CRITICAL), and
   * baseline/py_step.py, the pure-Python restatement bench.py times on the GPU box,
 for the BASELINE configs, and writes the speed ratio r = reference / restatement to
-profiles/r02_py_baseline_ratio.json.  On the GPU box the reference's own rate is then
+profiles/py_baseline_ratio.json (bench.py folds it into `cpu_baseline.reference_equivalent`; the round-2 measurement is
+profiles/archive/r02_py_baseline_ratio.json).  On the GPU box the reference's own rate is then
 (restatement rate measured there) x r.
 
     python tools/refgen/bench_reference.py [seconds per leg, default 8]
@@ -63,7 +64,7 @@ def main():
         out["workloads"][w] = {"reference_steps_per_s": r_ref, "restatement_steps_per_s": r_py,
                                "ratio_reference_over_restatement": r_ref / r_py}
         print(w, out["workloads"][w], flush=True)
-    with open(os.path.join(ROOT, "profiles", "r02_py_baseline_ratio.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "py_baseline_ratio.json"), "w") as f:
         json.dump(out, f, indent=1)
 
 
