@@ -92,6 +92,21 @@ WORKLOADS = {
                              action_space_max=1, transition_dynamics_order=2, inertia=1,
                              time_unit=0.1, transition_noise=0.05, reward_noise=0.05,
                              make_denser=True, reward_function="move_to_a_point", seed=0)),
+    # the discrete shapes k_discrete_rollout_lean does not take -- what the reference's own sweeps use:
+    # /root/reference/experiments/dqn_delay_50_states.py (S = A = 50, sequence_length 1, delay in {0, 1, 2, 4, 8}),
+    # rainbow_reward_dist.py (S = A = 24, reward_dist: non-unit rewards), and one MDP PER ENV (seeds=[...], what every golden
+    # uses: tables gathered from HBM / L2 instead of staged in LDS)
+    "d_s50_delay4": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42,
+                         config=dict(state_space_type="discrete", action_space_type="discrete", state_space_size=50,
+                                     action_space_size=50, delay=4, sequence_length=1, reward_density=0.25,
+                                     terminal_state_density=0.25, seed=0)),
+    "d_s24_rdist": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42,
+                        config=dict(state_space_type="discrete", action_space_type="discrete", state_space_size=24,
+                                    action_space_size=24, delay=0, sequence_length=1, reward_density=0.25,
+                                    terminal_state_density=0.25, reward_dist=[0.01, 1], seed=0)),
+    "cfg2_per_env": dict(kind="discrete", envs=8192, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
+                         config=dict(state_space_type="discrete", action_space_type="discrete",
+                                     state_space_size=8, action_space_size=8, delay=4, sequence_length=3)),
     # SURVEY.md §8f rank 2 (not a BASELINE config): the reference's test_grid_env shape, 65 536 envs
     "grid": dict(kind="grid", envs=65536, alg_bytes_fused=30, alg_bytes_step=62,
                  config=dict(state_space_type="grid", grid_shape=(8, 8), reward_function="move_to_a_point",
@@ -245,10 +260,12 @@ def cpu_baseline_all_cores(wl_name, seconds=4.0):
 
 def hbm_ceilings(device, nbytes=1 << 30, reps=10):
     """What the memory system of THIS device gives plain streaming kernels, measured live (SURVEY.md
-    §8d "report against both"), two ways: the library's own 16-bytes-per-lane grid-stride kernels (mdpp_probe_hbm: the
-    float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s, a fill, a read) -- `copy_GBps`, `write_GBps`, `read_GBps` --
-    and torch's copy_ / fill_ kernels (`torch_copy_GBps`, `torch_write_GBps`: what round 3 called the ceiling; torch's
-    copy runs 20 % under the float4 one), HIP events around `reps` launches over `nbytes`."""
+    §8d "report against both"), two ways: the library's own 16-bytes-per-lane one-shot kernels (mdpp_probe_hbm: the
+    float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s, a fill, a read; copy and fill with plain and with non-temporal
+    stores, the FASTER form is the ceiling -- `copy_GBps`, `write_GBps`, `read_GBps`, the forms in `forms_GBps`) and torch's
+    copy_ / fill_ kernels (`torch_copy_GBps`, `torch_write_GBps`), HIP events around `reps` launches over `nbytes`.  A
+    ceiling is the best a plain kernel reaches: `write_GBps` = max over all fill forms incl. torch's, `copy_GBps` likewise
+    (rounds 3-4 ran the probe on a persistent grid, 25 % under a one-shot fill, and the rollout kernel beat it)."""
     import ctypes
     from mdp_playground_amd import _capi
     src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
@@ -256,12 +273,19 @@ def hbm_ceilings(device, nbytes=1 << 30, reps=10):
     out = {}
     lib = _capi.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    for name, mode, moved in (("copy", 0, 2 * nbytes), ("write", 1, nbytes), ("read", 2, nbytes)):
+    forms = {}
+    for name, mode, moved in (("copy", 0, 2 * nbytes), ("write", 1, nbytes), ("read", 2, nbytes), ("copy_nt", 3, 2 * nbytes),
+                              ("write_nt", 4, nbytes)):
         ms = ctypes.c_float(0.0)
         rc = lib.mdpp_probe_hbm(mode, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nbytes, reps, stream,
                                 ctypes.byref(ms))
         if rc == 0 and ms.value > 0:
-            out[name + "_GBps"] = moved * reps / (ms.value * 1e-3) / 1e9
+            forms[name] = moved * reps / (ms.value * 1e-3) / 1e9
+    for name in ("copy", "write", "read"):
+        best = max([v for k, v in forms.items() if k.split("_")[0] == name], default=None)
+        if best is not None:
+            out[name + "_GBps"] = best
+    out["forms_GBps"] = forms
     torch_out = {}
     for name, fn, moved in (("copy", lambda: dst.copy_(src), 2 * nbytes), ("write", lambda: dst.fill_(7), nbytes)):
         for _ in range(3):
@@ -275,8 +299,8 @@ def hbm_ceilings(device, nbytes=1 << 30, reps=10):
         torch_out[name] = moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
     out["torch_copy_GBps"], out["torch_write_GBps"] = torch_out["copy"], torch_out["write"]
-    out.setdefault("copy_GBps", torch_out["copy"])
-    out.setdefault("write_GBps", torch_out["write"])
+    out["copy_GBps"] = max(out.get("copy_GBps", 0.0), torch_out["copy"])
+    out["write_GBps"] = max(out.get("write_GBps", 0.0), torch_out["write"])
     return out
 
 
@@ -292,11 +316,20 @@ def action_rotation(wl, F, N, device, seed, min_total=512 << 20, min_n=4, max_n=
 
 # the other BASELINE.json configs (and cfg2 on the RNG north_star names), timed in the same run after the cfg2 leg
 EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5", "numpy"), ("cfg5", "philox"),
-              ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"))   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
+              ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"),   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
+              ("d_s50_delay4", "numpy"), ("d_s24_rdist", "numpy"), ("cfg2_per_env", "numpy"))   # (+ the discrete shapes beyond the lean kernel)
 
 
 def leg_name(workload, rng):
     return workload if rng == "numpy" else f"{workload}_{rng}"
+
+
+def make_env(wl, N, device, rng, **kw):
+    """The workload's batched env (`per_env_mdps`: env i is built from seed i -- N different MDPs, tables per env)."""
+    from mdp_playground_amd import RLToyVectorEnv
+    if wl.get("per_env_mdps"):
+        return RLToyVectorEnv(seeds=list(range(N)), device=device, rng=rng, autoreset="same_step", **kw, **wl["config"])
+    return RLToyVectorEnv(num_envs=N, device=device, rng=rng, autoreset="same_step", **kw, **wl["config"])
 
 
 def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=5):
@@ -306,7 +339,7 @@ def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=
     wl = WORKLOADS[name]
     N = wl["envs"]
     F = max(1, min(fuse, wl.get("fuse_max", fuse)))
-    env = RLToyVectorEnv(num_envs=N, device=device, rng=rng, autoreset="same_step", **wl["config"])
+    env = make_env(wl, N, device, rng)
     acts = action_rotation(wl, F, N, device, seed)
     out = env.alloc_rollout(F)
     for it in range(max(warmup, 1)):
@@ -412,6 +445,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live PMC traffic measurement (two child rocprofv3 runs)")
+    ap.add_argument("--cpu-baselines-only", default=None, metavar="WORKLOAD", help=argparse.SUPPRESS)
+    ap.add_argument("--peer-copy", action="store_true", help="also time the hipIpc peer-copy gather (mdpp_peer_*) beside the RCCL leg; "
+                    "runs last, never `value`")
     ap.add_argument("--no-collective", action="store_true", help="one-GPU runs: no RCCL group, `value` = the leg without a collective")
     ap.add_argument("--no-workloads", action="store_true", help="skip the legs of the other BASELINE configs (`workloads`)")
     ap.add_argument("--workload-steps", type=int, default=10, help="timed launches of each `workloads` leg")
@@ -426,6 +462,15 @@ def main():
                     help="bench steps of the [K, N_local, ...] all-gather leg (0 = skip)")
     args = ap.parse_args()
 
+    if args.cpu_baselines_only:       # a child of rank 0 of a multi-rank run (fresh process, never touches the GPU)
+        cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.cpu_baselines_only)
+        print("CPU_BASELINES " + json.dumps({"cpu_py": cpu_py, "cpu_py_all": cpu_py_all, "cpu_all": cpu_all}), flush=True)
+        return
+    # preflight: RCCL refuses two ranks on one device -- say so in one line instead of hanging in the rendezvous
+    # (torch.cuda.device_count() does not initialise the GPU runtime on this image)
+    if args.backend == "nccl" and args.gpus > 1 and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} with backend nccl (RCCL) needs {args.gpus} visible devices, "
+                         f"torch.cuda.device_count() = {torch.cuda.device_count()} (several ranks on one device: --backend gloo)")
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
@@ -445,7 +490,10 @@ def main():
             and args.envs is None:
         extra = list(EXTRA_LEGS)
     cpu_py = cpu_py_all = cpu_all = None
-    if rank == 0 and not args.no_cpu_baseline:      # (rank 0 of a multi-rank run too: it has not touched the GPU yet)
+    # one rank: now, before this process initialises the GPU (the baselines fork one worker per core).  Several ranks: at the
+    # END, from a fresh child of rank 0, after the process group is gone -- not while ranks 1..N-1 wait in the rendezvous for
+    # a rank 0 that is busy on every core for half a minute
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
     pmc = None
     if rank == 0 and world == 1 and not args.no_pmc:
@@ -456,6 +504,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist, no_coll_why = init_collective(device, world, args.no_collective, args.backend)
+    backend_used = args.backend if dist is not None else None
 
     from mdp_playground_amd import RLToyVectorEnv
     from mdp_playground_amd.dist import ObsGatherer
@@ -596,73 +645,6 @@ def main():
                         "else running (events around %d of them); added_per_launch_us: (last_row - none) / launches -- what is "
                         "left of the gather after overlap (the rollout grid holds every CU: a gather can only run between launches)" % G)
         del g_last
-        # ---- leg "peer_copy" (reported beside `value`, never `value`): the same exchange without a collective KERNEL -- every
-        # rank's buffer mapped into the others with hipIpc handles, the shard copied device to device on a side stream after
-        # every launch (copy engines; the rollout grid holds every compute unit, an RCCL gather can only run between
-        # launches), a bounded flag wait at the end (include/mdpp.h mdpp_peer_*, dist.PeerGatherer)
-        try:
-            from mdp_playground_amd.dist import PeerGatherer
-
-            class _PeerWork:                        # (the interface run() expects of a collective's Work handle)
-                def __init__(self, g, ticket):
-                    self.g, self.ticket = g, ticket
-
-                def is_completed(self):
-                    return False
-
-                def wait(self):                     # buffer reuse: this rank's copies have left
-                    self.g.fence(self.ticket)
-
-                def finish(self):                   # end of the leg: every rank's shard has arrived
-                    self.g.wait(self.ticket)
-
-            class _PeerStart:
-                def __init__(self, g):
-                    self.g = g
-
-                def start(self):
-                    return _PeerWork(self.g, self.g.start())
-
-            def all_ranks_ok(flag):                 # (the leg has collectives inside: every rank takes it, or none does)
-                if world == 1:
-                    return bool(flag)
-                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(t.item())
-
-            peers, why = [], None
-            try:                                    # local half: buffers + handles
-                peers = [PeerGatherer(o[0][-1], world, rank, dist, slots=2, defer_exchange=True) for o in outs]
-            except Exception as e:
-                why = repr(e)
-            ok = all_ranks_ok(why is None)
-            if ok and world > 1:
-                try:                                # collective half: exchange the handles, map the peers' buffers
-                    for g in peers:
-                        g.exchange(dist)
-                except Exception as e:
-                    why = repr(e)
-                ok = all_ranks_ok(why is None)
-            if ok:
-                g_peer = [_PeerStart(g) for g in peers]
-                run(max(args.warmup, 1), g_peer)
-                reps = timed_reps(args.steps, g_peer)
-                el_peer, legs["peer_copy"] = leg_record(reps, args.steps)
-                st = [g.status() for g in peers]
-                legs["peer_copy"].update({"host_enqueue_s": host_enqueue[0], "bytes_per_rank_per_launch": peers[0].nbytes,
-                                          "timeouts": sum(1 for x in st if x[0]), "finegrained_buffers": bool(st[0][1]),
-                                          "what": "hipIpc-mapped buffers, hipMemcpyAsync device to device on a side stream per launch, "
-                                                  "flag wait at the end of the timed region"})
-                if diag is not None:
-                    diag["peer_copy_added_per_launch_us"] = (el_peer - el_none) * 1e6 / args.steps
-                del g_peer
-            else:
-                legs["peer_copy"] = {"error": why or "the set-up failed on another rank"}
-            for g in peers:
-                g.close()
-            del peers
-        except Exception as e:                      # a reported extra, never fatal for the contract line
-            legs["peer_copy"] = {"error": repr(e)}
         # ---- leg "full": every observation of the rollout, [K, N_local, ...] per rank per launch
         full_bytes = outs[0][0].numel() * outs[0][0].element_size()
         if args.full_gather_steps > 0 and full_bytes * world * NB < (64 << 30):
@@ -673,6 +655,100 @@ def main():
             legs["full"] = {"elapsed_s": el_full, "steps": ks, "env_steps_per_s": world * N * F * ks / el_full,
                             "bytes_per_rank_per_launch": full_bytes}
             del g_full
+        # ---- leg "peer_copy" (opt-in: --peer-copy; reported beside `value`, never `value`; runs LAST, when every number of the
+        # contract line is final -- ADVICE r4): the same exchange without a collective KERNEL -- every rank's buffer mapped into
+        # the others with hipIpc handles, the shard copied device to device on a side stream after every launch, a bounded flag
+        # wait at the end (include/mdpp.h mdpp_peer_*, dist.PeerGatherer).  Every phase is agreed between the ranks before the
+        # next one starts (the leg has collectives inside: every rank takes a phase, or none does).
+        if args.peer_copy:
+            try:
+                from mdp_playground_amd.dist import PeerGatherer
+
+                class _PeerWork:                        # (the interface run() expects of a collective's Work handle)
+                    def __init__(self, g, ticket):
+                        self.g, self.ticket = g, ticket
+
+                    def is_completed(self):
+                        return False
+
+                    def wait(self):                     # buffer reuse: this rank's copies have left
+                        self.g.fence(self.ticket)
+
+                    def finish(self):                   # end of the leg: every rank's shard has arrived
+                        self.g.wait(self.ticket)
+
+                class _PeerStart:
+                    def __init__(self, g):
+                        self.g = g
+
+                    def start(self):
+                        return _PeerWork(self.g, self.g.start())
+
+                def all_ranks_ok(flag):
+                    if world == 1:
+                        return bool(flag)
+                    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    return bool(t.item())
+
+                def phase(fn):                          # run one phase locally, then agree: (ok on every rank, local error)
+                    err = None
+                    try:
+                        fn()
+                    except Exception as e:
+                        err = repr(e)
+                    return all_ranks_ok(err is None), err
+
+                peers, res = [], {}
+
+                def build():                            # local half: buffers + handles (a partial list is closed below)
+                    for o in outs:
+                        peers.append(PeerGatherer(o[0][-1], world, rank, dist, slots=2, defer_exchange=True))
+
+                def exchange():                         # collective half: exchange the handles, map the peers' buffers
+                    if world > 1:
+                        for g in peers:
+                            g.exchange(dist)
+
+                def check():                            # the gathered bytes ARE the shards: the peer gather against RCCL's
+                    peers[0].wait(peers[0].start())
+                    ref = ObsGatherer(outs[0][0][-1], world, dist, always_collective=True)
+                    w = ref.start()
+                    w.wait()
+                    torch.cuda.synchronize(device)
+                    if not torch.equal(peers[0].out.view(torch.uint8).reshape(-1), ref.out.view(torch.uint8).reshape(-1)):
+                        raise RuntimeError("peer-copied rows differ from the RCCL gather of the same buffer")
+
+                def warm():
+                    run(max(args.warmup, 1), [_PeerStart(g) for g in peers])
+
+                def measure():
+                    reps = timed_reps(args.steps, [_PeerStart(g) for g in peers])
+                    res["el"], res["rec"] = leg_record(reps, args.steps)
+
+                why = None
+                for fn in (build, exchange, check, warm, measure):
+                    ok, err = phase(fn)
+                    if not ok:
+                        why = "%s: %s" % (fn.__name__, err or "failed on another rank")
+                        break
+                if why is None:
+                    st = [g.status() for g in peers]
+                    legs["peer_copy"] = res["rec"]
+                    legs["peer_copy"].update({"host_enqueue_s": host_enqueue[0], "bytes_per_rank_per_launch": peers[0].nbytes,
+                                              "timeouts": sum(1 for x in st if x[0]), "finegrained_buffers": bool(st[0][1]),
+                                              "checked_against_rccl": True,
+                                              "what": "hipIpc-mapped buffers, hipMemcpyAsync device to device on a side stream per launch, "
+                                                      "flag wait at the end of the timed region"})
+                    if diag is not None:
+                        diag["peer_copy_added_per_launch_us"] = (res["el"] - el_none) * 1e6 / args.steps
+                else:
+                    legs["peer_copy"] = {"error": why}
+                for g in peers:
+                    g.close()
+                del peers
+            except Exception as e:                      # a reported extra, never fatal for the contract line
+                legs["peer_copy"] = {"error": repr(e)}
     total_steps = world * N * F * args.steps
     value = total_steps / elapsed
 
@@ -731,9 +807,44 @@ def main():
     if rank == 0:
         peaks = hbm_ceilings(device)
         roofline["peak_measured"] = peaks
+        # the fraction that belongs to `value` (the leg WITH the path's all-gather; `frac` is the kernel alone)
+        roofline["frac_value"] = wl["alg_bytes_fused"] * (value / world) / 1e9 / HBM_PEAK_GBS
         roofline["frac_of_measured_copy"] = achieved / peaks["copy_GBps"]
         roofline["frac_of_measured_write"] = achieved / peaks["write_GBps"]
+        roofline["frac_of_measured_read"] = achieved / peaks["read_GBps"] if peaks.get("read_GBps") else None
 
+    # who ran where (the line explains a multi-GPU run by itself): rank -> device of every rank, RCCL's version
+    placement = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": torch.cuda.get_device_name(device),
+                 "pid": os.getpid()}
+    try:
+        placement["device_uuid"] = str(torch.cuda.get_device_properties(device).uuid)
+    except Exception:
+        placement["device_uuid"] = None
+    if dist is not None and world > 1:
+        placements = [None] * world
+        dist.all_gather_object(placements, placement)
+    else:
+        placements = [placement]
+    try:
+        rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        rccl_version = None
+    if dist is not None and world > 1:      # every number that needs the group is final: leave it BEFORE the CPU baselines
+        barrier()
+        dist.destroy_process_group()
+        dist_done = True
+    else:
+        dist_done = False
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baselines-only", args.workload],
+                               capture_output=True, text=True, timeout=600)
+            got = [ln for ln in r.stdout.splitlines() if ln.startswith("CPU_BASELINES ")]
+            rec = json.loads(got[-1][len("CPU_BASELINES "):])
+            cpu_py, cpu_py_all, cpu_all = rec["cpu_py"], rec["cpu_py_all"], rec["cpu_all"]
+        except Exception as e:          # a reported extra, never fatal
+            cpu_py_all = {"error": repr(e)}
     cpu_port = None
     if rank == 0 and not args.no_cpu_baseline and not (
             wl["kind"] == "continuous" and wl["config"].get("image_representations")):
@@ -765,6 +876,8 @@ def main():
             # compare it with lines where it is
             "collective_ok": v_last is not None,
             "multi_rank_diagnostics": diag,
+            "device_count": torch.cuda.device_count(), "rccl_version": rccl_version, "backend": backend_used,
+            "rank_devices": placements,
             "roofline": roofline,
             "cpu_baseline": cpu_py if cpu_py is not None else cpu_port,
             "cpu_baseline_all_cores": cpu_py_all, "cpu_baseline_port": cpu_port,
@@ -773,7 +886,7 @@ def main():
             "launches": args.steps, "elapsed_s": elapsed,
         }
         print(json.dumps(line), flush=True)
-    if dist is not None:
+    if dist is not None and not dist_done:
         dist.destroy_process_group()
 
 
@@ -910,13 +1023,27 @@ def single_step_leg(env, wl, acts, N, device, n1=500, reps=20):
     t1 = time.perf_counter()
     for _ in range(n1):
         env.step(a1)
+    host1 = time.perf_counter() - t1         # the host's part: n1 calls enqueued (nothing waited for yet)
     ms1 = env.timer_end()
     torch.cuda.synchronize(device)
     wall1 = time.perf_counter() - t1
     b1 = wl["alg_bytes_step"] * N
     single = {"env_steps_per_s": N * n1 / wall1, "launch_us_events": ms1 * 1e3 / n1,
+              "host_enqueue_us": host1 * 1e6 / n1,
+              "host_bound": bool(host1 * 1e3 > 0.9 * ms1),
+              "kernel": env.rollout_kernel_name(1),
               "alg_bytes_per_env_step": wl["alg_bytes_step"],
               "hbm_frac_events": b1 / (ms1 / 1e3 / n1) / 1e9 / HBM_PEAK_GBS}
+    try:        # the device's own floor for one launch per step: empty kernels of the same grid, launched from C back to back
+        import ctypes
+        hu, du = ctypes.c_float(0.0), ctypes.c_float(0.0)
+        rc = env._lib.mdpp_probe_launch(2000, max(1, (N + 63) // 64), ctypes.c_void_p(env._raw_stream()), ctypes.byref(hu), ctypes.byref(du))
+        if rc == 0:
+            single["launch_floor"] = {"what": "2000 launches of an EMPTY kernel with this grid, from C, back to back (mdpp_probe_launch)",
+                                      "host_us_per_launch": hu.value, "device_us_per_launch": du.value}
+            single["x_launch_floor"] = single["launch_us_events"] / max(hu.value, du.value)
+    except Exception as e:        # a reported extra, never fatal
+        single["launch_floor"] = {"error": repr(e)}
     if hasattr(env, "step_graph"):
         try:
             KG = 64

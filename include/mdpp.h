@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MDPP_ABI_VERSION 7
+#define MDPP_ABI_VERSION 8
 
 enum { MDPP_OK = 0, MDPP_EINVAL = -1, MDPP_EHIP = -2, MDPP_ENOMEM = -3, MDPP_ESTATE = -4,
        MDPP_EUNSUPPORTED = -5 };
@@ -361,11 +361,17 @@ const char *mdpp_peer_last_error(mdpp_peer *p);
 int mdpp_peer_destroy(mdpp_peer *p);
 
 /* What the memory system of the current device gives plain streaming kernels (no handle; nothing of the reference):
- * `reps` launches of a 16-bytes-per-lane grid-stride kernel over `nbytes` on `stream`, HIP events around them ->
- * *ms_out (all reps).  mode 0: copy src -> dst (2 x nbytes moved per launch; the float4 copy MI355X_MICROARCH.md
- * measures at 6.29 TB/s), 1: fill dst (src unused), 2: read src (dst: a device pointer to 4 scratch bytes).
- * bench.py prices `roofline.frac` beside these (`peak_measured`).  ABI 7. */
+ * `reps` launches of a 16-bytes-per-lane kernel over `nbytes` on `stream` (one 16 KiB tile per workgroup, tiles in address
+ * order), HIP events around them -> *ms_out (all reps).  mode 0: copy src -> dst (2 x nbytes moved per launch; the float4
+ * copy MI355X_MICROARCH.md measures at 6.29 TB/s), 1: fill dst (src unused), 2: read src (dst: a device pointer to 4 scratch
+ * bytes); ABI 8: 3 = copy, 4 = fill with non-temporal stores.  bench.py prices `roofline.frac` beside the fastest form of
+ * each (`peak_measured`). */
 int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size_t nbytes, int reps, void *stream, float *ms_out);
+/* ABI 8.  The floor of the one-launch-per-step API on this device: n launches of an EMPTY kernel (`workgroups` x 64 threads)
+ * back to back on `stream` -> the host's time per launch call and the device's time per launch (HIP events), microseconds.
+ * bench.py reports mdpp_step beside it (`single_step.launch_floor`): below about 3.5 us per launch eager stepping is bound
+ * by the host's launch call, not by the kernel. */
+int mdpp_probe_launch(int n, int workgroups, void *stream, float *host_us_out, float *device_us_out);
 
 /* ---- GymEnvWrapper-style post-processor ---------------------------------------
  * What the reference's mdp_playground/envs/gym_env_wrapper.py does around ANY inner env, for a batch of N

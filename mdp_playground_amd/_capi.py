@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmdpp_hip.so")
 
-MDPP_ABI_VERSION = 7
+MDPP_ABI_VERSION = 8
 MAX_DIM, MAX_ORDER, MAX_BOXES = 32, 4, 8
 KIND_DISCRETE, KIND_CONTINUOUS, KIND_GRID = 0, 1, 2
 REWARD_SEQUENCES, REWARD_STATE_ACTION = 0, 1
@@ -36,7 +36,7 @@ EXPORTS = [
     "mdpp_get_episode_stats", "mdpp_get_line_history", "mdpp_set_line_history",
     "mdpp_post_create", "mdpp_post_destroy", "mdpp_post_last_error", "mdpp_post_seed_streams", "mdpp_post_get_streams",
     "mdpp_post_get_reward_buffer", "mdpp_post_reset", "mdpp_post_actions", "mdpp_post_step", "mdpp_post_step_n",
-    "mdpp_episode_stats", "mdpp_probe_hbm",
+    "mdpp_episode_stats", "mdpp_probe_hbm", "mdpp_probe_launch",
     "mdpp_peer_create", "mdpp_peer_handle", "mdpp_peer_open", "mdpp_peer_push", "mdpp_peer_fence", "mdpp_peer_wait", "mdpp_peer_buffer",
     "mdpp_peer_status", "mdpp_peer_last_error", "mdpp_peer_destroy",
 ]
@@ -159,6 +159,7 @@ def load():
     L.mdpp_post_step_n.argtypes = [vp, i32] + [vp] * 6
     L.mdpp_episode_stats.argtypes = [i32, i32, vp, i32] + [vp] * 9
     L.mdpp_probe_hbm.argtypes = [i32, vp, vp, C.c_size_t, i32, vp, C.POINTER(C.c_float)]
+    L.mdpp_probe_launch.argtypes = [i32, i32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mdpp_peer_create.argtypes = [i32, i32, i32, C.c_size_t, i32, C.POINTER(vp)]
     L.mdpp_peer_handle.argtypes = [vp, vp]
     L.mdpp_peer_open.argtypes = [vp, vp]

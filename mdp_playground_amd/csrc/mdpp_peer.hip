@@ -66,9 +66,16 @@ extern "C" int mdpp_peer_create(int device, int world, int rank, size_t shard_by
     if (hipSetDevice(device) != hipSuccess) { delete p; return MDPP_EHIP; }
     p->flags_off = ((size_t)slots * world * shard_bytes + 255) & ~(size_t)255;
     const size_t bytes = p->flags_off + (size_t)slots * world * sizeof(uint64_t);
-    // fine-grained memory where the runtime gives it (coherent with the other devices' writes without cache maintenance)
+    // Fine-grained memory (coherent with the other devices' writes without cache maintenance).  With several ranks there
+    // is NO fallback to coarse-grained memory: the buffer receives other devices' copy-engine writes, is polled by
+    // k_peer_wait and read by consumers through the local L2, which is not guaranteed coherent with them -- stale flags and
+    // stale rows, silently.  One rank (nothing remote ever writes the buffer) may take plain device memory.
     if (hipExtMallocWithFlags((void **)&p->buf, bytes, hipDeviceMallocFinegrained) == hipSuccess) p->finegrained = true;
-    else { (void)hipGetLastError(); if (hipMalloc((void **)&p->buf, bytes) != hipSuccess) { delete p; return MDPP_EHIP; } }
+    else {
+        (void)hipGetLastError();
+        if (world > 1) { delete p; return MDPP_EUNSUPPORTED; }
+        if (hipMalloc((void **)&p->buf, bytes) != hipSuccess) { delete p; return MDPP_EHIP; }
+    }
     bool ok = hipMemset(p->buf, 0, bytes) == hipSuccess &&
               hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) == hipSuccess &&
@@ -120,7 +127,10 @@ extern "C" int mdpp_peer_push(mdpp_peer *p, int slot, const void *shard_dev, uin
         const int r = (p->rank + 1 + k) % p->world;                   // (start with the neighbour: the ranks' copies fan out over different links)
         PCHK(p, hipMemcpyAsync(p->peer[(size_t)r] + row, shard_dev, p->shard, hipMemcpyDeviceToDevice, p->side));
     }
-    uint64_t *src = p->h_seq + (seq % (uint64_t)kSeqRing);             // (stable until the copies have run: at most kSeqRing pushes in flight)
+    // (the pinned word must stay stable until its flag copies have run: at most kSeqRing pushes in flight -- enforced by
+    //  draining the side stream every kSeqRing / 2 pushes, which an open loop of launches otherwise never does)
+    if (seq % (uint64_t)(kSeqRing / 2) == 0) PCHK(p, hipStreamSynchronize(p->side));
+    uint64_t *src = p->h_seq + (seq % (uint64_t)kSeqRing);
     *src = seq;
     const size_t fo = p->flags_off + ((size_t)slot * p->world + (size_t)p->rank) * sizeof(uint64_t);
     for (int k = 0; k < p->world; k++) {                               // (same stream: a flag lands behind its data)

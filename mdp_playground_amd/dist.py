@@ -113,9 +113,15 @@ class PeerGatherer:
     One process per rank; the buffers' hipIpc handles are exchanged once through `dist_module.all_gather_object`.
     start() pushes the current contents of `local` (behind what the current stream has enqueued) into every rank's
     buffer; wait() makes the current stream wait until every rank's shard of that push has landed here; `out` is the
-    [world, *local.shape] tensor (a view of the library's buffer).  Pushes alternate over `slots` buffers, so a new
-    push does not overwrite what a peer may still be reading.  A rank that never arrives shows up as a status bit
-    (status()), not as a hang."""
+    [world, *local.shape] tensor (a view of the library's buffer).  Pushes alternate over `slots` buffers.  A rank that
+    never arrives shows up as a status bit (status()), not as a hang.
+
+    THE CONTRACT (nothing flows back from a reader to the writers -- ADVICE r4): every rank must wait() for push s, and
+    have enqueued whatever reads `out` on the same stream, BEFORE it start()s push s + slots; a rank that runs `slots` or
+    more pushes ahead of a peer overwrites rows the peer has not read, and the monotone flags would not show it.  close()
+    frees / un-maps the buffers: callers synchronise the ranks (a barrier) before it, and views of `out` die with it.
+    Not validated across a device boundary on the build pool (one GPU per box): experimental beside ObsGatherer, which is
+    the path's collective (RCCL, what north_star names)."""
 
     _ITEM = {1: "|u1", 2: "<u2", 4: "<u4", 8: "<u8"}
 

@@ -4,7 +4,11 @@ step / rollout) and holds the gathered observation tensor against a plain one-pr
 for bit -- BASELINE cfg2 and cfg5, numpy-exact and Philox streams, single steps and fused rollouts, rewards and flags of
 the own shard too.  Started as `python -m torch.distributed.run --nproc-per-node 2 tests/_dist2_child.py` by
 tests/test_gpu_dist.py with both ranks on the box's one GPU (backend gloo: RCCL refuses two ranks on one device; the
-collective call is the same all_gather_into_tensor).  Rank 0 prints DIST2_OK."""
+collective call is the same all_gather_into_tensor).  Rank 0 prints DIST2_OK.
+
+Round 5: the same at WORLD SIZE 8 (`--nproc-per-node 8`, DIST_CHILD_N=65536, DIST_CHILD_CASES=cfg5): 8 x 8 192 envs against
+one 65 536-env run -- BASELINE configs[4]'s sharding with the shard size the one GPU of the box can hold eight of: "a 1-GPU
+run and an 8-GPU run produce identical trajectories" (SURVEY.md 8e)."""
 import os
 import sys
 
@@ -18,7 +22,7 @@ from mdp_playground_amd.dist import PeerGatherer, ShardedVectorEnv, shard_bounds
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-assert world == 2
+assert world in (2, 8), world
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 
@@ -28,9 +32,13 @@ ccfg = dict(state_space_type="continuous", state_space_dim=12, relevant_indices=
             target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10, action_space_max=1,
             transition_dynamics_order=2, inertia=1, time_unit=0.1, transition_noise=0.05, reward_noise=0.05,
             make_denser=True, reward_function="move_to_a_point", seed=0)
-N, T, K = 2048, 12, 64
+N, T, K = int(os.environ.get("DIST_CHILD_N", "2048")), 12, 64
+want = os.environ.get("DIST_CHILD_CASES", "cfg2,cfg5").split(",")
 lo, hi = shard_bounds(N, rank, world)
+assert (lo, hi) == (rank * (N // world), (rank + 1) * (N // world))
 for name, c, rng in (("cfg2", cfg, "numpy"), ("cfg2", cfg, "philox"), ("cfg5", ccfg, "numpy"), ("cfg5", ccfg, "philox")):
+    if name not in want:
+        continue
     kw = dict(rng="philox", philox_seed=77) if rng == "philox" else {}
     sh = ShardedVectorEnv(N, rank, world, dist, device=dev, always_collective=True, autoreset="same_step", **kw, **c)
     whole = RLToyVectorEnv(num_envs=N, device=dev, autoreset="same_step", **kw, **c)

@@ -21,7 +21,7 @@ for spec in sys.argv[2:]:
     wname, rng, envs, fuse = spec.split(":")
     wl = bench.WORKLOADS[wname]
     N, F = int(envs), int(fuse)
-    env = RLToyVectorEnv(num_envs=N, device=dev, autoreset="same_step", rng=rng, **wl["config"])
+    env = bench.make_env(wl, N, dev, rng)
     acts = bench.make_actions(wl, F, N, dev, 12345)
     out = env.alloc_rollout(F)
     for _ in range(launches):
