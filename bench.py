@@ -760,9 +760,12 @@ def main():
     kname = env.rollout_kernel_name(F)          # what the library's dispatch launches (mdpp_kernel_name)
     traffic, traffic_src = committed_traffic(args.workload, args.rng, N, F, kname)
     main_pmc = (pmc or {}).get(leg_name(args.workload, args.rng))
+    main_valu = None
     if main_pmc is not None and kname.split("<")[0] in main_pmc["kernels"]:   # measured in this run, on the kernel that was timed
         traffic, traffic_src = main_pmc["bytes_per_launch"], main_pmc["note"]
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        main_valu = main_pmc.get("valu_insts_per_launch")
+    vr = valu_roofline(main_valu, launch_us, achieved / HBM_PEAK_GBS)
+    roofline = {"bound": "hbm", "bound_measured": vr["bound"], "valu_frac": vr["valu_frac"], "valu": vr, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                 "alg_bytes_per_env_step": wl["alg_bytes_fused"], "alg_bytes_per_launch": alg_bytes,
                 "launch_us": launch_us, "env_steps_per_launch": N * F,
@@ -798,6 +801,7 @@ def main():
                 rec = (pmc or {}).get(key)
                 if rec is not None and leg["kernel"].split("<")[0] in rec["kernels"]:
                     leg["traffic"], leg["traffic_source"] = rec["bytes_per_launch"], rec["note"]
+                    leg.update(valu_roofline(rec.get("valu_insts_per_launch"), leg["launch_us"], leg["frac"]))
                 else:
                     leg["traffic"], leg["traffic_source"] = committed_traffic(w, r, leg["envs"], leg["fuse"], leg["kernel"])
                 workloads[key] = leg
@@ -919,7 +923,7 @@ def _run_group(cmd, timeout, **kw):
         return -999
 
 
-def live_traffic_all(specs, launches=3, timeout=150):
+def live_traffic_all(specs, launches=3, timeout=300):
     """HBM bytes per fused launch from PMC counters, measured NOW, for every (workload, rng, envs, fuse) of `specs`:
     two child rocprofv3 runs (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: they do not fit one pass; no trace domain
     beside them) of tools/pmc_workloads.py, which launches the same fused rollouts workload after workload with a
@@ -935,14 +939,20 @@ def live_traffic_all(specs, launches=3, timeout=150):
     if shutil.which("rocprofv3") is None or _pmc_blocked():
         return None
     tmp = tempfile.mkdtemp(prefix="mdpp_pmc_", dir="/tmp")
-    seg = [{"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "kernels": {}} for _ in specs]
+    seg = [{"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0, "kernels": {}} for _ in specs]
+    valu_ok = True
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        # (third pass: vector instructions issued -- the second roofline of the kernels that are issue-bound, SURVEY.md 8d
+        #  "secondary ceilings"; a failure of THIS pass only drops `valu_frac`)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "tools", "pmc_workloads.py"), str(launches)] + \
                   [f"{w}:{r}:{n}:{f}" for w, r, n, f in specs]
             if _run_group(cmd, timeout, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp")) != 0:
+                if counter == "SQ_INSTS_VALU":
+                    valu_ok = False
+                    continue
                 return None
             rows = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -961,6 +971,9 @@ def live_traffic_all(specs, launches=3, timeout=150):
                 if counter == "WRITE_SIZE":
                     seg[k]["kernels"][name] += 1
             if k != len(specs):
+                if counter == "SQ_INSTS_VALU":
+                    valu_ok = False
+                    continue
                 return None
         res = {}
         for (w, r, n, f), s in zip(specs, seg):
@@ -969,6 +982,7 @@ def live_traffic_all(specs, launches=3, timeout=150):
             res[leg_name(w, r)] = {
                 "bytes_per_launch": int(round((2.0 * s["FETCH_SIZE"] + s["WRITE_SIZE"]) * 1024.0 / launches)),
                 "kernels": " ".join(s["kernels"]),
+                "valu_insts_per_launch": (s["SQ_INSTS_VALU"] / launches) if (valu_ok and s["SQ_INSTS_VALU"] > 0) else None,
                 "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, x2 on FETCH_SIZE), every mdpp:: "
                         f"kernel of {launches} fused launches, in this run"}
         return res or None
@@ -983,6 +997,24 @@ def live_traffic(workload, rng, N, F, launches=3, timeout=75):
     res = live_traffic_all([(workload, rng, N, F)], launches, timeout)
     rec = (res or {}).get(leg_name(workload, rng))
     return None if rec is None else (rec["bytes_per_launch"], rec["kernels"], rec["note"])
+
+
+VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md); a wave64 vector instruction holds its SIMD for >= 4 cycles
+N_SIMDS = 1024              # 256 CUs x 4 SIMDs
+
+
+def valu_roofline(valu_insts_per_launch, launch_us, hbm_frac):
+    """The second roofline of a launch (SURVEY.md 8d "secondary ceilings: integer ALU"): `valu_frac` = the share of the launch
+    during which every SIMD's vector ALU is issuing, at the FLOOR of 4 cycles per wave instruction (float64, 32-bit integer
+    multiplies and transcendentals take longer: the true share is higher) = SQ_INSTS_VALU / 1 024 SIMDs x 4 cycles / 2.4 GHz
+    / launch time.  `bound` = which of the two fractions is the larger one: a kernel at 0.30 of HBM and 0.90 of its issue
+    slots is an instruction-count problem, not a memory one."""
+    if not valu_insts_per_launch or not launch_us:
+        return {"valu_frac": None, "bound": "hbm"}
+    valu_us = valu_insts_per_launch / N_SIMDS * 4.0 / VALU_CLOCK_HZ * 1e6
+    vf = valu_us / launch_us
+    return {"valu_frac": vf, "valu_insts_per_simd_per_launch": valu_insts_per_launch / N_SIMDS, "valu_issue_us_floor": valu_us,
+            "bound": "valu" if vf > hbm_frac else "hbm"}
 
 
 def committed_traffic(workload, rng, N, F, kname):
