@@ -130,8 +130,18 @@ constexpr uint32_t kCStatusInternal = 0x80000000u;
 // derivative row (overwritten by a / inertia before anything reads it) and the irrelevant coordinates of the last
 // observation are only read by a wave that holds a rejected action ("stay", :1671-1679), no staging of rewards and flags
 // for later groups, and without ziggurat tables the workgroup is ONE wave (no barrier; all 1 024 SIMDs start at once).
-template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1, bool K1 = false>
-__global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_continuous_rollout_fast(ContinuousArgs a, int K,
+// PAR (K1 with transition noise on numpy streams): the step's D + 1 ziggurat normals come from ONE sequential PCG64 stream per
+// env -- thirteen dependent draws in one lane were 7 of the launch's 14 us (cfg5).  The stream's WORDS are a function of
+// the position alone (an LCG jumps ahead: s_k = M^k s + (M^(k-1) + ... + 1) inc), and a draw's fast path is a function of its
+// word alone, so: 64 envs per 256-thread workgroup; wave w makes the words at positions 4w .. 4w + 3 of every env's stream
+// (one jump, three steps), evaluates each as if a draw started there -- accepted at once / wedge accepted or rejected with the
+// NEXT position's word as its uniform / anything else -- and posts {word, value, 2-bit kind} in LDS; wave 0 then walks the
+// kinds from position 0 like numpy walks the stream (13 draws, a few bit operations each), reads the values, takes the
+// generator state behind the last word it consumed (posted by the wave that made that word), and integrates.  Tails,
+// three rejected wedges in a row and draws that reach past position 15 (6 in 10 000 env steps) run numpy's own loop on a
+// generator that reads the posted words and continues sequentially behind them -- exact, just not parallel.
+template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1, bool K1 = false, bool PAR = false>
+__global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
                                                                     float *__restrict__ reward,
@@ -152,11 +162,11 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     typedef typename std::conditional<PHILOX, float, double>::type ZT;       // (Philox normals are float32 values)
     // (WALK: both rings are 64 KiB and 64 KiB-aligned -- a slot's byte address is then ONE v_and_or_b32 of the count, the ring mask
     //  and a per-lane constant)
-    __shared__ __attribute__((aligned(WALK ? 65536 : 16))) ZT s_z[HELPER ? (WALK ? kWRing : kNRing * NPS) * kBlock : 1];       // [slot][draw][lane]; WALK: [normal count & 31][lane]
+    __shared__ __attribute__((aligned(WALK ? 65536 : 16))) ZT s_z[HELPER ? (WALK ? kWRing : kNRing * NPS) * kBlock : (PAR ? NPS * 64 : 1)];       // [slot][draw][lane]; WALK: [normal count & 31][lane]
     __shared__ __attribute__((aligned(WALK ? 65536 : 16))) uint64_t s_raw[WALK ? kWRing * kBlock : 1];       // WALK: [stream position & 31][lane]
     __shared__ uint32_t s_gp[WALK ? kBlock : 1], s_rp[WALK ? kBlock : 1], s_done[kBlock / 64];   // words made / taken per lane
     __shared__ uint32_t s_prod[NPROD][kBlock / 64], s_cons[kBlock / 64];     // steps made by producer p / steps consumed
-    __shared__ __align__(16) float s_tr[(D > 4 ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
+    __shared__ __align__(16) float s_tr[((D > 4 && !PAR) ? kBlock / 64 : 1) * 64 * (D > 4 ? D : 4)];   // output transpose tiles
     // Whole-row stores of the small outputs (round 4).  A lane's reward is 4 bytes and its flags one byte each: stored per lane,
     // a wave instruction writes 256 / 64 / 64 bytes -- 6 of the step's 102 bytes that took 8-19 % of a cfg3 launch (573-630 us
     // without them against 685-706).  Without helper waves: the rewards and flags of a GROUP of four steps are staged in LDS
@@ -165,6 +175,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     // counters (groups staged / groups stored), no barrier (a barrier per group took back most of the gain: 662 -> 641 us).
     constexpr bool CROWS = MDPP_CONT_ROWS && !HELPER && !K1;
     static_assert(!K1 || !HELPER, "one step: no helper waves");
+    static_assert(!PAR || (K1 && NOISE && !PHILOX), "parallel draws: one step, numpy streams");
+    constexpr int kPP = 16;                     // PAR: stream positions evaluated side by side (4 per wave)
+    static_assert(!PAR || D + 1 <= kPP, "a step's draws must fit the positions");
+    __shared__ uint64_t p_w[PAR ? kPP * 64 : 1];                    // PAR: the stream's words [position][env]
+    __shared__ double p_v[PAR ? kPP * 64 : 1];                      // ... the normal a draw starting there returns (kinds 0, 1)
+    __shared__ ulonglong2 p_s[PAR ? (kPP - D + 1) * 64 : 1];        // ... the generator state behind word p, p >= D - 1
+    __shared__ uint32_t p_k[PAR ? 64 : 1];                          // ... kinds: byte w = wave w's four positions, 2 bits each
     constexpr int WG = (K1 && !(NOISE && !PHILOX)) ? 64 : kBlock;      // threads per workgroup of the env waves
     constexpr int kRS = kBlock / 64;            // steps per group = waves per workgroup
     constexpr int kRBufs = 3;
@@ -190,8 +207,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     }
     if (NOISE && !K1) __syncthreads();
     const ZigLds zig{s_ki, s_wi, s_fi};
-    const int ln = tid & (kBlock - 1), wv = ln >> 6;
-    const uint32_t i = blockIdx.x * WG + ln;
+    // (PAR: one env wave per workgroup -- "lane" and "wave" of the consumer code below are those of that wave, whichever it is)
+    const int ln = PAR ? (tid & 63) : (tid & (kBlock - 1)), wv = PAR ? 0 : (ln >> 6);
+    const uint32_t i = PAR ? blockIdx.x * 64u + (uint32_t)(tid & 63) : blockIdx.x * WG + ln;
     if (i >= (uint32_t)a.N) return;             // HELPER launches require N % kBlock == 0
     const uint32_t N = (uint32_t)a.N;
     const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)
@@ -636,7 +654,12 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
     if (HELPER && !PHILOX) __builtin_amdgcn_s_setprio(WALK ? MDPP_WK_CONSUMER_PRIO : MDPP_NP_CONSUMER_PRIO);
 
     float k1act[K1 ? D : 1];
-    if constexpr (K1) {                         // the step's action row first: everything else of the launch waits for it
+    // PAR: three of the four waves only make stream words; the fourth also integrates.  WHICH one rotates with the workgroup
+    // index: the four workgroups a CU holds are 256 apart (8 XCDs x 32 CUs, round robin), and with wave 0 everywhere the
+    // integrating waves of all four sat on ONE SIMD while the other three idled through the second half of the launch.
+    const int env_w = PAR ? (int)((blockIdx.x >> 8) & 3u) : 0;
+    const bool env_wave = !PAR || (tid >> 6) == env_w;
+    if constexpr (K1) if (env_wave) {           // the step's action row first: everything else of the launch waits for it
         if constexpr (D == 2) {
             const float2 v = ((const float2 *)actions)[i];
             k1act[0] = v.x; k1act[1] = v.y;
@@ -649,16 +672,188 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         }
     }
     float sd[ORDER + 1][D], cur[D];
+    uint2 meta = make_uint2(0u, 0u);
+    if (env_wave) {
 #pragma unroll
-    for (int k = 0; k <= ORDER; k++)
+        for (int k = 0; k <= ORDER; k++)
 #pragma unroll
-        for (int d = 0; d < D; d++) sd[k][d] = (K1 && k == ORDER) ? 0.0f : a.sd[((size_t)k * D + d) * N + i];
+            for (int d = 0; d < D; d++) sd[k][d] = (K1 && k == ORDER) ? 0.0f : a.sd[((size_t)k * D + d) * N + i];
 #pragma unroll
-    for (int d = 0; d < D; d++) cur[d] = (K1 && d >= NREL) ? 0.0f : a.cur[(size_t)d * N + i];
-    uint2 meta = a.meta[i];
+        for (int d = 0; d < D; d++) cur[d] = (K1 && d >= NREL) ? 0.0f : a.cur[(size_t)d * N + i];
+        meta = a.meta[i];
+    }
     Pcg64 g;
     if (ZIG && !HELPER) g.load(a.env_s, a.env_inc, i);
-    if constexpr (K1 && ZIG) {                  // (launched with N % 256 == 0: every wave of the block reaches the barrier)
+    if constexpr (PAR) {
+        // ---- the words at positions 4w .. 4w + 3 (no tables needed yet: their loads are still in flight) ----
+        const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+        // s_(4w+1) = A s + G inc (mod 2^128), A = M^(4w+1), G = 1 + M + ... + M^(4w)   [w = 0: A = M, G = 1]
+        const uint64_t A_HI[4] = {0x2360ed051fc65da4ULL, 0x16c406e9fbe6c01fULL, 0x18f8f9f7734932a8ULL, 0xd008599933890bf1ULL};
+        const uint64_t A_LO[4] = {0x4385df649fccf645ULL, 0x1712dd28ec4e2775ULL, 0x16509219b4cc2da5ULL, 0xfcce321a884738d5ULL};
+        const uint64_t G_HI[4] = {0x0ULL, 0x55eb531472e35affULL, 0x85f34a8885b1db52ULL, 0x55f2070f3b269f3cULL};
+        const uint64_t G_LO[4] = {0x1ULL, 0x53148145f0c4118dULL, 0xfacc3ec479366459ULL, 0x452c836ab6c04465ULL};
+        uint64_t ahi = A_HI[0], alo = A_LO[0], ghi = G_HI[0], glo = G_LO[0];
+#pragma unroll
+        for (int q = 1; q < 4; q++) { const bool me = w4 == q; ahi = me ? A_HI[q] : ahi; alo = me ? A_LO[q] : alo; ghi = me ? G_HI[q] : ghi; glo = me ? G_LO[q] : glo; }
+        auto mul128lo = [](uint64_t xlo, uint64_t xhi, uint64_t ylo, uint64_t yhi, uint64_t &rlo, uint64_t &rhi) __attribute__((always_inline)) {
+            rlo = xlo * ylo;
+            rhi = __umul64hi(xlo, ylo) + xlo * yhi + xhi * ylo;
+        };
+        auto xsl_rr = [](uint64_t lo, uint64_t hi) __attribute__((always_inline)) -> uint64_t {
+            const uint64_t x = hi ^ lo;
+            const unsigned rot = (unsigned)(hi >> 58);
+            return (x >> rot) | (x << ((64u - rot) & 63u));
+        };
+        Pcg64 t = g;
+        {
+            uint64_t p0, p1, q0, q1;
+            mul128lo(g.s_lo, g.s_hi, alo, ahi, p0, p1);
+            mul128lo(g.inc_lo, g.inc_hi, glo, ghi, q0, q1);
+            t.s_lo = p0 + q0;
+            t.s_hi = p1 + q1 + (t.s_lo < p0 ? 1ULL : 0ULL);
+        }
+        uint64_t wd[4];
+        wd[0] = xsl_rr(t.s_lo, t.s_hi);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q > 0) wd[q] = t.next64();
+            const int p = 4 * w4 + q;
+            p_w[p * 64 + l] = wd[q];
+            if (p >= D - 1) p_s[(p - (D - 1)) * 64 + l] = make_ulonglong2(t.s_lo, t.s_hi);
+        }
+        s_ki[tid] = k1_ki; s_wi[tid] = k1_wi; s_fi[tid] = k1_fi;
+        __syncthreads();
+#ifdef MDPP_ABL_PAR_RET1
+        return;
+#endif
+        // ---- every position as the start of a draw: kind 0 accepted at once, 1 wedge accepted, 2 wedge rejected (two words
+        // either way), 3 anything else (tail; a wedge whose uniform lies behind the last position) ----
+        uint32_t kind[4], idxs[4];
+        double xs[4];
+        bool pend = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint64_t r = wd[q];
+            const int idx = (int)(r & 0xff);
+            r >>= 8;
+            const int sign = (int)(r & 0x1);
+            const uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+            double x = (double)rabs * s_wi[idx];
+            x = sign ? -x : x;
+            const bool ok = rabs < s_ki[idx];
+            const int p = 4 * w4 + q;
+            xs[q] = x; idxs[q] = (uint32_t)idx;
+            kind[q] = ok ? 0u : ((idx == 0 || p + 1 >= kPP) ? 3u : 4u);      // 4: a wedge point, decided below
+            pend = pend || kind[q] == 4u;
+            p_v[p * 64 + l] = x;
+        }
+#ifdef MDPP_ABL_PAR_NOWEDGE
+        pend = false;
+#endif
+        for (int pass = 0; pass < 4 && __builtin_amdgcn_ballot_w64(pend) != 0; pass++) {       // (one pass serves a lane's first open wedge point)
+            int q = 0;
+            double x = 0.0;
+            uint32_t idx = 1;
+#pragma unroll
+            for (int u = 3; u >= 0; u--) { const bool me = kind[u] == 4u; q = me ? u : q; x = me ? xs[u] : x; idx = me ? idxs[u] : idx; }
+            bool accf = false, sure = true;
+            double y = 0.0;
+            if (pend) {
+                const uint64_t nw = p_w[(4 * w4 + q + 1) * 64 + l];
+                const double u1 = (double)(nw >> 11) * (1.0 / 9007199254740992.0);
+                y = (s_fi[idx - 1] - s_fi[idx]) * u1 + s_fi[idx];
+                // exp(-x^2 / 2) = 2^t: a float32 estimate decides wherever y is further than 1e-5 (relative) from it, the float64
+                // exp() the rest -- every decision is the one exp() gives (the walker of the rollout kernel does the same)
+                const double e = (double)__builtin_amdgcn_exp2f((float)(x * x * -0.72134752044448170368));
+                accf = y < e;
+                sure = fabs(y - e) > 1.0e-5 * e;
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pend && !sure) != 0, 0)) {
+                if (pend && !sure) accf = y < exp(-0.5 * x * x);
+            }
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (pend && u == q) kind[u] = accf ? 1u : 2u;
+                more = more || kind[u] == 4u;
+            }
+            pend = more;
+        }
+        ((uint8_t *)p_k)[l * 4 + w4] = (uint8_t)(kind[0] | (kind[1] << 2) | (kind[2] << 4) | (kind[3] << 6));
+        __syncthreads();
+#ifdef MDPP_ABL_PAR_RET2
+        return;
+#endif
+        // ---- ONE wave walks the stream like numpy: draw d starts at position `pos`.  Not the integrating wave: that one holds the
+        // env's state in registers since the top of the launch, and numpy's loop (exp, log1p) inlined into its path spilled
+        // them to scratch (the walk alone then took 4.6 us of a 13.5 us launch, tools/ablate_step1.py); a wave that only made
+        // words has nothing live here.  It also stores the generator state behind the last word consumed. ----
+        if (env_wave) __syncthreads();              // (the walker's normals: every wave of the block passes ONE more barrier)
+        else if ((tid >> 6) != ((env_w + 1) & 3)) { __syncthreads(); return; }
+        else {
+        struct PosGen {                            // next64() = the word at the next position: posted, or made behind the last posted one
+            uint32_t pos;
+            const uint64_t *w;
+            Pcg64 tg;
+            __device__ __forceinline__ uint64_t next64() {
+                uint64_t r = 0;
+                if (pos < (uint32_t)kPP) r = w[pos * 64];
+                else r = tg.next64();
+                pos += 1;
+                return r;
+            }
+        };
+        PosGen pg;
+        pg.pos = 0; pg.w = p_w + l;
+        {
+            const ulonglong2 last = p_s[(kPP - 1 - (D - 1)) * 64 + l];     // the state behind word 15
+            pg.tg.s_lo = last.x; pg.tg.s_hi = last.y; pg.tg.inc_lo = g.inc_lo; pg.tg.inc_hi = g.inc_hi;
+        }
+        const uint32_t kinds = p_k[l];
+        const int nd = D + (a.has_r_noise ? 1 : 0);
+        // A ROLLED loop over the draws (unrolled, its D + 1 copies of numpy's loop -- exp, log1p -- are tens of KB of code that
+        // every wave walks past).  Measured (tools/ablate_step1.py, cfg5 at 65 536 envs, replayed graph): words + kinds 4.1 us of
+        // the launch, this walk 2.4, the integrator and its stores 4.9 -- and 2.9 for numpy's loop below: a TAIL draw (layer 0
+        // beyond |x| = 3.65: two float64 log1p, 2.6 in 10 000 draws) costs about 2 us, a launch of 852 000 draws holds some 220
+        // of them, and the launch ends with its slowest wave.  A variant that settled all draws in registers first and sent
+        // the lanes with a tail through numpy's loop afterwards measured 14.3 us against this form's 12.7.
+#pragma unroll 1
+        for (int d = 0; d < NPS; d++) {
+            if (d < nd) {
+                uint32_t pos = pg.pos;
+                uint32_t k = pos < (uint32_t)kPP ? (kinds >> (2u * pos)) & 3u : 3u;
+#pragma unroll
+                for (int rej = 0; rej < 2; rej++) {                      // up to two rejected wedge points in a row: the draw starts over
+                    const bool r2 = k == 2u;
+                    pos += r2 ? 2u : 0u;
+                    k = r2 ? (pos < (uint32_t)kPP ? (kinds >> (2u * pos)) & 3u : 3u) : k;
+                }
+                const bool slow = k >= 2u;
+                double z = p_v[(pos < (uint32_t)kPP ? pos : 0u) * 64 + l];
+                pg.pos = slow ? pos : pos + (k == 0u ? 1u : 2u);
+#ifndef MDPP_ABL_PAR_NOGEN
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+                    if (slow) z = np_standard_normal_lds(pg, zig);      // numpy's own loop on the words from `pos` on
+                }
+#endif
+                s_z[d * 64 + l] = z;            // (read back by the integrating wave where the step uses the normal)
+            }
+        }
+        // the generator behind the last word consumed (pos >= D words were taken)
+        if (pg.pos <= (uint32_t)kPP) {
+            const ulonglong2 st = p_s[(pg.pos - 1u - (uint32_t)(D - 1)) * 64 + l];
+            g.s_lo = st.x; g.s_hi = st.y;
+        } else {
+            g.s_lo = pg.tg.s_lo; g.s_hi = pg.tg.s_hi;
+        }
+        g.store(a.env_s, i);
+        __syncthreads();
+        return;
+        }
+#ifdef MDPP_ABL_PAR_RET3
+        return;
+#endif
+    } else if constexpr (K1 && ZIG) {           // (launched with N % 256 == 0: every wave of the block reaches the barrier)
         s_ki[tid] = k1_ki; s_wi[tid] = k1_wi; s_fi[tid] = k1_fi;
         __syncthreads();
     }
@@ -733,7 +928,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         // read where they are used (holding a step's 13 doubles in registers spilled the step loop at 168 registers)
         if constexpr (WALK) return (double)s_z[(size_t)((wk_nb + (uint32_t)(zi++)) & (uint32_t)(kWRing - 1)) * kBlock + ln];
         if (HELPER) return (double)zslot[(zi++) * kBlock];
-        if constexpr (PHILOX) {
+        if constexpr (PAR) {
+            return (double)s_z[(zi++) * 64 + ln];
+        } else if constexpr (PHILOX) {
             float v = 0.0f;
 #pragma unroll
             for (int d = 0; d < NPS; d++) v = (d == zi) ? zf[d] : v;      // (zi is a compile-time constant after unrolling)
@@ -829,6 +1026,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             }
         }
         if (NOISE && PHILOX && !HELPER) { philox_step(k, zf); zi = 0; }
+        if (PAR) zi = 0;
         // ---- C1: Box.contains(action)
         const bool ok = all_within(act, amax);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
@@ -934,7 +1132,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         bool done = (flags & 1u) != 0;
         if (!GEN) {
             if (NOISE && a.has_r_noise) {
-                if (HELPER || PHILOX) zi = D;
+                if (HELPER || PHILOX || PAR) zi = D;
                 if (WALK) zi = a.has_p_noise ? D : 0;
                 r = r + (float)(0.0 + a.r_noise * normal());
             }
@@ -956,7 +1154,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
             }
             if (steps % (uint32_t)a.every_n != 0) { rv = 0.0; is32 = false; }
             if (NOISE && a.has_r_noise) {
-                if (HELPER || PHILOX) zi = D;
+                if (HELPER || PHILOX || PAR) zi = D;
                 if (WALK) zi = a.has_p_noise ? D : 0;
                 const double nz = 0.0 + a.r_noise * normal();
                 if (is32) rv = (double)((float)rv + (float)nz); else rv = rv + nz;
@@ -1147,7 +1345,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock) void k_cont
         for (int d = 0; d < D; d++) __builtin_nontemporal_store(cur[d], &a.cur[(size_t)d * N + i]);
         __builtin_nontemporal_store(steps, &a.meta[i].x);
         __builtin_nontemporal_store(flags | (pend ? 2u : 0u), &a.meta[i].y);
-        if (ZIG) g.store(a.env_s, i);
+        if (ZIG && !PAR) g.store(a.env_s, i);       // (PAR: the walking wave stored it)
         if (status) atomicOr(&a.status[i], status);
         return;
 #endif
@@ -1175,6 +1373,18 @@ static bool launch_k1(const ContinuousArgs &a, const float *actions, float *obs,
                       float *final_obs, hipStream_t s, char *name_out) {
     constexpr bool ZIG = NOISE && !PHILOX;
     constexpr int WG = ZIG ? kBlock : 64;
+    // numpy streams with transition noise: the step's draws side by side (PAR: 64 envs per 256-thread workgroup)
+    if constexpr (ZIG && D + 1 <= 16) {
+        if (a.has_p_noise && (a.N % 64) == 0 && !(a.opts & MDPP_OPT_NO_HELPER)) {
+            if (name_out) {
+                snprintf(name_out, kNameLen, "k_continuous_step1<D=%d,ORDER=%d,NREL=%d,NOISE=%d,GEN=%d,PHILOX=%d,PAR=1>", D, ORDER, NREL, NOISE, GEN, PHILOX);
+                return true;
+            }
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, NOISE, false, GEN, PHILOX, 1, true, true>), dim3(a.N / 64), dim3(kBlock),
+                               0, s, a, 1, actions, obs, reward, term, trunc, final_obs);
+            return true;
+        }
+    }
     if (ZIG && (a.N % kBlock) != 0) return false;
     if (name_out) {
         snprintf(name_out, kNameLen, "k_continuous_step1<D=%d,ORDER=%d,NREL=%d,NOISE=%d,GEN=%d,PHILOX=%d,WG=%d>", D, ORDER, NREL, NOISE, GEN, PHILOX, WG);

@@ -2422,8 +2422,13 @@ STEP1_CASES = {
     "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),
     "c_cfg3_ragged_next_step": (_S1_C_CFG3, dict(autoreset="next_step", max_episode_steps=7), 1000, "k_continuous_step1<"),
     "c_cfg3_disabled": (_S1_C_CFG3, dict(autoreset="disabled"), 1000, "k_continuous_step1<"),
-    "c_cfg5_numpy": (_S1_C_CFG5, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=2,NREL=4,NOISE=1,GEN=0,PHILOX=0,WG=256>"),
-    "c_cfg5_numpy_ragged": (_S1_C_CFG5, dict(autoreset="same_step"), 1000, "k_continuous_rollout_fast<"),   # (numpy noise: whole blocks only)
+    "c_cfg5_numpy": (_S1_C_CFG5, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=2,NREL=4,NOISE=1,GEN=0,PHILOX=0,PAR=1>"),
+    "c_cfg5_numpy_ragged": (_S1_C_CFG5, dict(autoreset="same_step"), 1000, "k_continuous_rollout_fast<"),   # (numpy noise: whole 64-env groups only)
+    "c_cfg5_numpy_sequential": (_S1_C_CFG5, dict(autoreset="same_step"), 1024, "k_continuous_step1<D=12,ORDER=2,NREL=4,NOISE=1,GEN=0,PHILOX=0,WG=256>"),
+    "c_cfg5_numpy_heavy_noise": (dict(_S1_C_CFG5, transition_noise=3.0, reward_noise=1.0, state_space_max=4), dict(autoreset="same_step"), 4096,
+                                 "k_continuous_step1<D=12,ORDER=2,NREL=4,NOISE=1,GEN=0,PHILOX=0,PAR=1>"),
+    "c_pnoise_only_d2": (dict(gu.CASES["c_default_target_sparse"]["config"], target_point=[0.5, -0.5], seed=3), dict(autoreset="same_step"), 1024,
+                         "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=1,GEN=1,PHILOX=0,PAR=1>"),
     "c_cfg5_philox": (_S1_C_CFG5, dict(autoreset="same_step", rng="philox"), 1000, "k_continuous_step1<"),
     "c_boxes": (dict(gu.CASES["c_sparse_term"]["config"], seed=3), dict(autoreset="same_step"), 1000, "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=0,GEN=1"),
     "c_everyn_rnoise": (dict(gu.CASES["c_small_radius_hit"]["config"], seed=3), dict(autoreset="same_step"), 1024, "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=1,GEN=1"),
@@ -2445,6 +2450,8 @@ def test_step1_kernels_equal_the_rollout_kernels_with_k1(case):
     cfg, kw, N, prefix = STEP1_CASES[case]
     a, b = _venv(num_envs=N, **kw, **cfg), _venv(num_envs=N, **kw, **cfg)
     b.set_kernel_options("NO_STEP1")
+    if case == "c_cfg5_numpy_sequential":       # the one-step kernel that draws its normals one after the other in the env's lane
+        a.set_kernel_options("NO_HELPER")
     assert a.rollout_kernel_name(1).startswith(prefix), a.rollout_kernel_name(1)
     assert "step1" not in b.rollout_kernel_name(1)
     T = 48
