@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libmdpp_hip.so")
 SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_fast.hip", "mdpp_discrete_step1.hip", "mdpp_discrete_pipe.hip", "mdpp_discrete_lean.hip", "mdpp_discrete_lean_next.hip", "mdpp_discrete_lean_noise.hip", "mdpp_discrete_lean_npnoise.hip",
-           "mdpp_discrete_quiet.hip",
+           "mdpp_discrete_quiet.hip", "mdpp_discrete_quiet_nu.hip",
            "mdpp_continuous.hip", "mdpp_continuous_line8.hip",
            "mdpp_continuous_fast.hip", "mdpp_continuous_step1.hip", "mdpp_continuous_line.hip", "mdpp_image.hip", "mdpp_grid.hip", "mdpp_imagec.hip", "mdpp_post.hip", "mdpp_peer.hip"]
 HEADERS = ["mdpp_internal.hpp", "mdpp_rng.hpp", "mdpp_pcg64_limbs.inc", "np_ziggurat_tables.inc",
            os.path.join("..", "..", "include", "mdpp.h")]
 INCLUDED_SOURCES = {"mdpp_discrete_lean_next.hip": ["mdpp_discrete_lean.hip"], "mdpp_discrete_lean_noise.hip": ["mdpp_discrete_lean.hip"], "mdpp_discrete_lean_npnoise.hip": ["mdpp_discrete_lean.hip"],
-                    "mdpp_continuous_line8.hip": ["mdpp_continuous.hip"], "mdpp_continuous_step1.hip": ["mdpp_continuous_fast.hip"]}   # a .hip that #includes another one
+                    "mdpp_continuous_line8.hip": ["mdpp_continuous.hip"], "mdpp_continuous_step1.hip": ["mdpp_continuous_fast.hip"], "mdpp_discrete_quiet_nu.hip": ["mdpp_discrete_quiet.hip"]}   # a .hip that #includes another one
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
 
     if jobs:
         # the long compiles first (template-heavy kernels: 1.5-3 min each), as many at once as there are cores to spare
-        heavy = ("mdpp_continuous_fast", "mdpp_discrete_lean", "mdpp_discrete_quiet", "mdpp_grid", "mdpp_continuous.")
+        heavy = ("mdpp_continuous_fast", "mdpp_discrete_lean", "mdpp_discrete_quiet", "mdpp_grid", "mdpp_continuous.", "mdpp_continuous_step1")
         jobs.sort(key=lambda c: next((k for k, h in enumerate(heavy) if h in c[-3]), len(heavy)))
         with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), (os.cpu_count() or 4) - 1, 7))) as ex:
             for out in ex.map(run, jobs):

@@ -459,8 +459,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                             const double u1 = (double)(raw_at(rp << 11) >> 11) * (1.0 / 9007199254740992.0);
                             const double u2 = (double)(raw_at((rp + 1u) << 11) >> 11) * (1.0 / 9007199254740992.0);
                             rp += 2u;
+#ifdef MDPP_ABL_WK_CHEAPTAIL        /* timing only: what the two log1p of a tail try cost the launch */
+                            const double xx = u1 * nor_inv_r;
+                            const double yy = u2 + 8.0;
+#else
                             const double xx = -nor_inv_r * log1p(-u1);
                             const double yy = -log1p(-u2);
+#endif
                             if (yy + yy > xx * xx) {
                                 z_put(n << 11, ((pr >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx);
                                 n += 1u;

@@ -81,13 +81,21 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // Box-Muller pairs per four env steps) into an LDS ring; the E wave, whose dependent chain is the step time, then
 // runs no generator at all (two Philox blocks and a Box-Muller pair per step on E were 0.15 of the HBM roofline
 // on cfg2 + noise; one block + one pair per step on the producers 0.24).
-template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0>
+// UR = false (round 5): rewards that are not all 1.0 (reward_dist, :1528-1544 -- the reference's rainbow_reward_dist sweep) on
+// numpy streams without an irrelevant sub-space: the O role looks the step's sequence key up in a float64 table in LDS
+// (DiscreteArgs::rtable), the delay line holds KEYS in HBM (ring_keys[delay][N], the general kernel's, so the two kernels
+// hand a handle to each other mid-episode), and the reward is formed in float64 in the reference's order like
+// k_discrete_step<UNIT = false> does.  Until round 5 these handles ran on the one-role general kernel (0.14 of the HBM
+// roofline at S = 24).
+template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true>
 __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
                                                                    uint8_t *__restrict__ term, uint8_t *__restrict__ trunc,
                                                                    void *__restrict__ final_obs) {
     const uint64_t ptick0 = tick_now(a);               // the step counter at this launch (through the device-side offset of a graph replay)
+    const uint32_t rhead0 = ring_head_now(a, ptick0);    // ... and the head of the key delay line (UR = false)
+    static_assert(UR || (!IRR && !PH && NPH == 0), "non-unit rewards: numpy streams, one sub-space");
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __align__(16) unsigned char lds[];
@@ -116,7 +124,8 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     // shared MDP -> LDS (same carve as k_discrete_step) + the irrelevant sub-space's table and cdf
     for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
     for (int k = tid; k < a.S; k += kThreads) lds[a.lds_term + k] = a.is_term[k];
-    for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k];
+    if (UR) { for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k]; }
+    else { for (uint32_t k = tid; k < a.nkeys; k += kThreads) ((double *)(lds + a.lds_rew))[k] = a.rtable[k]; }
     if (ZIG) zig_stage(s_ki, s_wi, s_fi, tid, kThreads);
     const ZigLds zig{s_ki, s_wi, s_fi};
     // rho_0 as integer thresholds: cdf[j] <= u  <=>  ceil(cdf[j] * 2^53) <= r >> 11 (exact: u is
@@ -173,6 +182,25 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const uint8_t *P = lds + a.lds_P, *is_term = lds + a.lds_term, *rbits = lds + a.lds_rew, *P1 = lds + lds_P1;
     const uint64_t *T0 = (const uint64_t *)(lds + lds_T0), *T1 = (const uint64_t *)(lds + lds_T1);
     const uint64_t *TN = (const uint64_t *)(lds + lds_TN), *TN1 = (const uint64_t *)(lds + lds_TN1);
+    // Large state spaces (round 5; the reference's 24- and 50-state sweeps): rho_0's S thresholds are not searched one by one
+    // (S = 50: 56 64-bit compares per draw, 150 vector instructions -- most of the H wave) but through a bucket table over the
+    // top 12 bits of the 53-bit draw: s_bk[b] = {thresholds at or below the bucket's first value, thresholds strictly inside it};
+    // a draw compares with the few thresholds inside its bucket (none for 99 % of the buckets).  Built here from T0.
+    __shared__ uint16_t s_bk[4096];
+    const bool use_bk = !PH && DUO && S8 > 16u;
+    if (use_bk) {
+        for (uint32_t b = tid; b < 4096u; b += kThreads) {
+            const uint64_t lo = (uint64_t)b << 41, hi = lo + (1ULL << 41);
+            uint32_t c0 = 0, n = 0;
+            for (uint32_t j = 0; j < S8; j++) {
+                const uint64_t t = T0[j];
+                c0 += t <= lo ? 1u : 0u;
+                n += (t > lo && t < hi) ? 1u : 0u;
+            }
+            s_bk[b] = (uint16_t)(c0 | (n << 8));
+        }
+        __syncthreads();
+    }
 
     const uint32_t i = blockIdx.x * kBlock + l;
     if (!DUO && i >= (uint32_t)a.N) return;            // (DUO launches have full blocks only)
@@ -235,9 +263,16 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
         const uint64_t m = g.next64() >> 11;
         uint32_t s0 = 0;
-        for (uint32_t b = 0; b < S8; b += 8) {
+        if (use_bk) {
+            const uint32_t e = s_bk[(uint32_t)(m >> 41)];
+            const uint32_t c0 = e & 0xFFu, nin = e >> 8;
+            s0 = c0;
+            for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < nin) != 0; j++) s0 += (j < nin && T0[j < nin ? c0 + j : 0u] <= m) ? 1u : 0u;
+        } else {
+            for (uint32_t b = 0; b < S8; b += 8) {
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) s0 += (T0[b + j] <= m) ? 1u : 0u;
+                for (uint32_t j = 0; j < 8; j++) s0 += (T0[b + j] <= m) ? 1u : 0u;
+            }
         }
         if (IRR) {
             const uint64_t m1 = g.next64() >> 11;
@@ -529,15 +564,33 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     auto emitO = [&](const uint64_t rec, const double z, const uint32_t so) __attribute__((always_inline)) {
         const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
         const uint32_t k2 = hi >> 5;
-        uint32_t bit = (rbits[k2 >> 3] >> (k2 & 7u)) & 1u;
+        const uint32_t done = hi & 1u;
+        float rout;
+        uint32_t bit = 0;
+        if constexpr (UR) {
+        bit = (rbits[k2 >> 3] >> (k2 & 7u)) & 1u;
         bit = (hi & 8u) ? bit : 0u;                                          // NaN gate: fewer than L transitions yet
         const uint32_t outb = (ringbits >> ((delay - 1u) & 31u)) & 1u;      // D5 (shift register)
         ringbits = delay > 0 ? ((ringbits << 1) | bit) : ringbits;
         bit = delay > 0 ? outb : bit;
         bit = (hi & 16u) ? bit : 0u;                                         // D6
-        const uint32_t done = hi & 1u;
-        float rout;
-        if (RN) {                                                            // :1980-1990, :2107 in float64
+        }
+        if constexpr (!UR) {                                                 // k_discrete_step<UNIT = false>, :1821-1845, :1968-1990
+            uint32_t key = (hi & 8u) ? k2 : kNoKey;                          // NaN gate: no key yet
+            if (delay > 0) {                                                 // D5: the key waits `delay` steps in HBM
+                uint32_t *slot = a.ring_keys + (size_t)((rhead0 + so) % delay) * N + i;
+                const uint32_t out = *slot;
+                *slot = key;
+                key = out;
+            }
+            double r = (key != kNoKey) ? ((const double *)rbits)[key] : 0.0;
+            r = (hi & 16u) ? r : 0.0;                                        // D6: steps % every_n
+            if (RN) r += 0.0 + a.r_noise * z;
+            r *= a.scale;
+            r += a.shift;
+            if (done) r += a.term_add;
+            rout = (float)r;
+        } else if (RN) {                                                     // :1980-1990, :2107 in float64
             double r = bit ? 1.0 : 0.0;
             r += 0.0 + a.r_noise * z;
             r *= a.scale;
@@ -553,6 +606,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             if (need) put_obs(r_fin, so, (lo >> 8) & 0xFFu, lo >> 24);
         }
         ringbits = need ? 0u : ringbits;
+        if constexpr (!UR) {                                                 // reset() empties the delay line (:2250)
+            if (__builtin_amdgcn_ballot_w64(need) != 0 && delay > 0) {
+                if (need) for (uint32_t dd = 0; dd < delay; dd++) a.ring_keys[(size_t)dd * N + i] = kNoKey;
+            }
+        }
         put_obs(r_obs, so, lo & 0xFFu, (lo >> 16) & 0xFFu);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, MDPP_ST_NT);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so * N, MDPP_ST_NT);
@@ -701,10 +759,13 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     if (status) atomicOr(&a.status[i], status);
 }
 
-template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0>
+#ifndef MDPP_QUIET_TU_NU
+#define MDPP_QUIET_TU_NU 0         // 1: this translation unit holds the non-unit-reward instantiations (mdpp_discrete_quiet_nu.hip)
+#endif
+template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true>
 static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH>;
+    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH, UR>;
     if (lds > 48 * 1024) {                        // tables + record ring beyond the default dynamic-LDS limit
         static size_t allowed = 0;                // (per instantiation)
         if (lds > allowed) {
@@ -716,9 +777,59 @@ static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t
     hipLaunchKernelGGL(kern, dim3(grid), dim3((ROLES + NPH) * kBlock), lds, s, a, K, actions, obs, reward, term, trunc, final_obs);
 }
 
+#if MDPP_QUIET_TU_NU
+// The non-unit-reward form (UR = false): numpy streams, no irrelevant sub-space, sequence rewards (not the custom R(s, a)
+// matrix, whose key E does not make).  Same role rules as below.
+bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
+                              uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
+    if (!a.shared_tables || a.unit_rewards || a.rew_sa || !a.rew_in_lds || a.irr || a.philox || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
+        return false;
+    if (a.nkeys >= (1u << 27) || (a.delay > 0 && !a.ring_keys)) return false;       // (the record carries 27 bits of key)
+    if (a.autoreset == MDPP_AUTORESET_NEXT_STEP) return false;                       // (the reset call's ring handling: general kernel)
+    const bool pn = a.has_p_noise != 0, rn = a.has_r_noise != 0;
+    if ((pn || rn) && (a.opts & MDPP_OPT_NO_QUIET_NOISE)) return false;
+    if ((unsigned long long)K * a.N * 8ULL >= (1ULL << 32)) return false;
+    const size_t S8 = (size_t)((a.S + 7) & ~7);
+    size_t lds = ((a.lds_bytes + 15) & ~(size_t)15) + S8 * 8;
+    if (pn) lds += (size_t)a.S * S8 * 8;
+    if (lds > 60 * 1024) return false;
+    const size_t depth = rn ? 16 : kQDepth;
+    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
+    const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
+    const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
+    const int roles = trio ? 3 : duo ? 2 : 1;
+    if (name_out) {
+        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=0,ROLES=%d,PN=%d,RN=%d,PHILOX=0,NPH=0,UNIT=0>", !a.obs_i32, roles, pn, rn);
+        return true;
+    }
+    const size_t l = roles == 1 ? lds : lds_duo;
+#define MDPP_QN_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
+#define MDPP_QN_ROLES(O64, PN_, RN_)                                                                      \
+    do {                                                                                                  \
+        if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, false, 3, PN_, RN_, false, 0, false>(MDPP_QN_ARGS); } \
+        else if (roles == 2) quiet_launch<O64, false, 2, PN_, RN_, false, 0, false>(MDPP_QN_ARGS);        \
+        else quiet_launch<O64, false, 1, PN_, RN_, false, 0, false>(MDPP_QN_ARGS);                        \
+    } while (0)
+#define MDPP_QN_NOISE(O64)                                                                                \
+    do {                                                                                                  \
+        if (pn && rn) MDPP_QN_ROLES(O64, true, true);                                                     \
+        else if (pn) MDPP_QN_ROLES(O64, true, false);                                                     \
+        else if (rn) MDPP_QN_ROLES(O64, false, true);                                                     \
+        else MDPP_QN_ROLES(O64, false, false);                                                            \
+    } while (0)
+    if (a.obs_i32) MDPP_QN_NOISE(false); else MDPP_QN_NOISE(true);
+#undef MDPP_QN_NOISE
+#undef MDPP_QN_ROLES
+#undef MDPP_QN_ARGS
+    return true;
+}
+#else
+bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
+                              uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out);
 // Serves the launch if the handle and the launch shape qualify; false = not taken.
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
+    if (!a.unit_rewards) return launch_discrete_quiet_nu(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     if (!a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
         return false;
     if (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
@@ -776,5 +887,6 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
 #undef MDPP_Q_ARGS
     return true;
 }
+#endif   // !MDPP_QUIET_TU_NU
 
 } // namespace mdpp

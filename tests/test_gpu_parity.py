@@ -2299,6 +2299,18 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     ("cfg2_noise", {"autoreset": "disabled", "terminal_state_density": 0.0}, "NO_LEAN,NO_QUIET", 32768, 128),   # (no resets: H still makes the noise)
     ("cfg2_noise", {"transition_noise": 0.5}, "NO_QUIET", 32768, 128),   # (rows' thresholds differ: the lean kernel declines, quiet vs general)
     ("cfg2_irr", {"transition_noise": 0.1}, "NO_QUIET", 65536, 128),
+    # round 5: rewards that are not all 1.0 (reward_dist) on the role-split quiet kernel (float64 table in LDS, key delay line in
+    # HBM) vs the general kernel -- the shapes of the reference's rainbow_reward_dist / dqn_delay_50_states sweeps
+    ("d_s24_rdist", {}, "NO_QUIET", 65536, 128),
+    ("d_s24_rdist", {"delay": 3, "sequence_length": 2, "reward_scale": 2.5, "reward_shift": -0.75, "term_state_reward": -1.5,
+                     "max_episode_steps": 11}, "NO_QUIET", 32768, 132),
+    ("d_s24_rdist", {"delay": 2, "transition_noise": 0.1, "reward_noise": 0.2, "reward_every_n_steps": 2}, "NO_QUIET", 32768, 128),
+    ("d_s50_delay4", {"reward_dist": [0.25, 1], "sequence_length": 2, "reward_density": 0.01, "autoreset": "disabled"}, "NO_QUIET", 16384, 64),
+    # ... and rho_0 through the bucket table (S > 16, round 5): unit rewards, 24 / 50 / 200 states, against the general kernel's search
+    ("d_s50_delay4", {}, "NO_QUIET", 65536, 128),
+    ("d_s50_delay4", {"state_space_size": 120, "action_space_size": 120, "terminal_state_density": 0.6, "delay": 1, "reward_noise": 0.1},
+     "NO_QUIET", 16384, 128),
+    ("d_s24_rdist", {"reward_dist": None, "terminal_state_density": 0.5}, "NO_QUIET", 32768, 128),
     ("grid", {}, "NO_GFAST", 65536, 128),                            # int64 pairs: one 128-bit store per step
     ("grid", {"irrelevant_features": True, "transition_noise": 0.2, "reward_noise": 0.1}, "NO_GFAST", 32768, 128),
     ("cfg3", {}, "NO_CFAST", 65536, 64),                             # transposed 128-bit stores
