@@ -695,10 +695,20 @@ class RLToyVectorEnv:
                                                  capi.nptr(ring), capi.nptr(is32), capi.nptr(reached))
         capi.check(self._lib, self._h, rc, "mdpp_set_state_continuous")
         if self._line_L:
-            aug = np.ascontiguousarray(state["augmented_state"], dtype=np.float32)
-            if aug.shape != (self.num_envs, self._line_L, self._cfg.n_rel):
+            # two layouts: the [N, sequence_length, n_relevant] window get_augmented_state() returns here, or the REFERENCE's
+            # (rl_toy_env.py:660, :2147-2156): per env a list of sequence_length + delay + 1 full state vectors, oldest first
+            # -- [N, L + delay + 1, D]; the reward reads its last L rows and the relevant columns (:1865-1872), which is what
+            # is kept (the rows before them only feed the delay line, restored through `reward_buffer`)
+            aug = np.asarray(state["augmented_state"], dtype=np.float32)
+            D, L, d = self._cfg.D, self._line_L, self._cfg.delay
+            if aug.shape == (self.num_envs, L + d + 1, D):
+                rel = list(self.mdps[0].relevant_indices)
+                aug = aug[:, -L:, :][:, :, rel]
+            aug = np.ascontiguousarray(aug, dtype=np.float32)
+            if aug.shape != (self.num_envs, L, self._cfg.n_rel):
                 raise ValueError("move_along_a_line: augmented_state must be the [num_envs, sequence_length, n_relevant] history "
-                                 "get_augmented_state() returns")
+                                 "get_augmented_state() returns, or the reference's [num_envs, sequence_length + delay + 1, "
+                                 "state_space_dim] list of states")
             rc = self._lib.mdpp_set_line_history(self._h, capi.nptr(aug))
             capi.check(self._lib, self._h, rc, "mdpp_set_line_history")
 

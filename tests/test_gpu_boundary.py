@@ -607,7 +607,15 @@ def test_line_reward_checkpoint_carries_the_window_of_the_fit(name):
         rel = list(a.mdps[0].relevant_indices)
         assert np.array_equal(st["augmented_state"][:, -1], st["curr_state"][:, rel])       # newest = the current state
         b._lib.mdpp_tick(b._h, split, None)
-        b.set_augmented_state(st)
+        if split == L:
+            # the REFERENCE's layout of augmented_state (a list of sequence_length + delay + 1 full state vectors per env,
+            # rl_toy_env.py:660): accepted too -- the last L rows' relevant columns are the window
+            d_ = cfg.get("delay", 0)
+            full = np.full((N, L + d_ + 1, D), np.nan, np.float32)
+            full[:, -L:, :][:, :, rel] = st["augmented_state"]
+            b.set_augmented_state(dict(st, augmented_state=full))
+        else:
+            b.set_augmented_state(st)
         for s_ in (0, 1):
             b._put_stream(s_, a.get_rng_streams(s_))
         for t in range(split, split + L + 3):

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "specialised_kernels_equal and (rdist or s50)" 2>&1 | grep -v "^$" | tail -4
+bash tools/prof_r05.sh > gpurun_out/r05p_summary.txt 2>&1
+tail -60 gpurun_out/r05p_summary.txt | cut -c1-1000
