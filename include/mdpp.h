@@ -151,7 +151,7 @@ typedef struct {
     double inertia, time_unit, state_space_max, action_space_max;
     double target_radius, action_loss_weight;
     float target[MDPP_MAX_DIM];
-    int32_t n_boxes;            /* terminal hypercubes, rl_toy_env.py:908-952 */
+    int32_t n_boxes;            /* terminal hypercubes, rl_toy_env.py:908-952: [n_boxes][n_rel] packed, n_boxes * n_rel <= 256 (ABI 8; 8 before) */
     float box_lo[MDPP_MAX_BOXES * MDPP_MAX_DIM];
     float box_hi[MDPP_MAX_BOXES * MDPP_MAX_DIM];
 

@@ -284,8 +284,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.sp1_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE_IRR];
     } else if (cfg->kind == MDPP_KIND_CONTINUOUS) {
         if (cfg->D < 1 || cfg->D > MDPP_MAX_DIM || cfg->order < 1 || cfg->order > MDPP_MAX_ORDER ||
-            cfg->n_rel < 1 || cfg->n_rel > cfg->D || cfg->n_boxes < 0 || cfg->n_boxes > MDPP_MAX_BOXES) {
-            g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes <= 8";
+            cfg->n_rel < 1 || cfg->n_rel > cfg->D || cfg->n_boxes < 0 ||
+            // terminal hypercubes: [n_boxes][n_rel] packed into box_lo / box_hi -- as many as fit the arrays (64 at four
+            // relevant dimensions); handles with picture observations draw them from an 8-entry list (mdpp_imagec.hip)
+            (cfg->image ? cfg->n_boxes > MDPP_MAX_BOXES : cfg->n_boxes * cfg->n_rel > MDPP_MAX_BOXES * MDPP_MAX_DIM)) {
+            g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes * n_rel <= 256 (n_boxes <= 8 with image observations)";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         const bool line = cfg->reward_function == MDPP_CREWARD_MOVE_ALONG_A_LINE;
@@ -360,7 +363,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             // (next-step autoreset: without noise or with Philox streams -- numpy noise streams are drawn ahead per step)
             const bool next_ok = cfg->autoreset != MDPP_AUTORESET_NEXT_STEP || cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 ||
                                  (!cfg->has_transition_noise && !cfg->has_reward_noise);
-            a.fast_ok = (a.rel_prefix && !cfg->image && !line && !cfg->target_f64 && next_ok &&
+            // (the fused kernels test the hypercubes in an unrolled loop of MDPP_MAX_BOXES: more than that -> general kernel)
+            a.fast_ok = (a.rel_prefix && !cfg->image && !line && !cfg->target_f64 && next_ok && cfg->n_boxes <= MDPP_MAX_BOXES &&
                          (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;
             a.image_quirk = cfg->image ? 1 : 0;
         }

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/prof_r05.sh > gpurun_out/r05p_summary.txt 2>&1
-tail -60 gpurun_out/r05p_summary.txt | cut -c1-1000
+timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -m gpu -x -q -k "many_boxes or line_reward_checkpoint or sparse_term" 2>&1 | tail -5

@@ -201,6 +201,18 @@ CASES = {
                     term_state_reward=-1.0, reward_scale=2.0,
                     reward_function="move_to_a_point"),
         seeds=list(range(8)), T=200, reset="on_done"),
+    # twelve terminal hypercubes (round 5: the device limit was 8; the reference has none, rl_toy_env.py:891-956) in a
+    # 3-D space with one irrelevant dimension, order 2, delay 1
+    "c_many_boxes": dict(
+        config=dict(state_space_type="continuous", state_space_dim=3, relevant_indices=[0, 2], irrelevant_features=True,
+                    transition_dynamics_order=2, inertia=1.0, time_unit=0.5,
+                    state_space_max=6, action_space_max=1, make_denser=True, delay=1,
+                    target_point=[0.5, -0.5], target_radius=0.4,
+                    terminal_states=[[-5.0, -5.0], [-5.0, 0.0], [-5.0, 5.0], [0.0, -5.0], [0.0, 5.0], [5.0, -5.0],
+                                     [5.0, 0.0], [5.0, 5.0], [-2.5, 2.5], [2.5, -2.5], [-2.5, -2.5], [2.5, 2.5]],
+                    term_state_edge=1.5, term_state_reward=-2.0, reward_scale=1.5,
+                    reward_function="move_to_a_point"),
+        seeds=list(range(8)), T=200, reset="on_done"),
     "c_small_radius_hit": dict(
         config=dict(state_space_type="continuous", state_space_dim=2,
                     transition_dynamics_order=1, inertia=1.0, time_unit=1.0,
