@@ -615,8 +615,14 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
     // a static split the slowest wave sets the kernel's duration (a 32-step render: 427 us alone, 465-475 us beside them).
     // cfg4 on one box: static 7 770 us per launch; claims of 1 / 2 / 4 / 8 images 6 960 / 7 380 / 7 620 / 7 720 (consecutive
     // images in one wave cost more than the coarser balance saves); 8 / 16 / 32 / 64 counters 7 110 / 6 930 / 6 910 / 6 950.
+    // Round 5: ONE picture per wave, then the workgroup ENDS (MDPP_IMG_DYNAMIC = 0 with a grid of one wave per picture): the
+    // hardware's dispatcher hands out the pictures in address order, so the chip's write front is the dispatch order -- the
+    // form in which plain fills run 20 % faster than on a persistent grid (mdpp_probe_hbm, tools/bench_store.hip).  It gives
+    // up the next picture's prefetch under the current one's evaluation (20 waves per CU hide the two round trips instead) and
+    // needs no claim counters: cfg4 6 530-6 550 -> 6 300 us per launch on one lease (0.568 -> 0.589); two / four pictures per
+    // wave 6 460 / 6 640; non-temporal stores 6 384.  The claiming loop stays below for MDPP_IMG_DYNAMIC = 1.
 #ifndef MDPP_IMG_DYNAMIC
-#define MDPP_IMG_DYNAMIC 1
+#define MDPP_IMG_DYNAMIC 0
 #endif
 #ifndef MDPP_IMG_CLAIM
 #define MDPP_IMG_CLAIM 1
@@ -673,6 +679,8 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
     RecRegs cur = load_rec(rec + j);
     u32x4 near_cur = load_near(a, cur, lane);
     stage_tpl(a, load_tpl(a, cur.lo[7] >> 12, lane), lds, wave, lane);
+    // (one-shot grid: the loop body runs once.  Its loads "for the next picture" then re-read this picture's record and template
+    //  -- and a straight-line form without them measured 6 148 us per launch against this one's 5 946, same lease: kept)
     for (;;) {
         const long jn = j + nw;
         const bool more = jn < M;
@@ -769,7 +777,15 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
             reserve = MDPP_IMG_RESERVE;
 #endif
             const unsigned resident = per_cu * (unsigned)h->num_cus - (phase == 2 ? reserve : 0u);
+#ifndef MDPP_IMG_ONESHOT
+#define MDPP_IMG_ONESHOT 1         /* pictures per wave of the one-shot grid (0: the persistent grid of rounds 1-4, with MDPP_IMG_DYNAMIC = 1) */
+#endif
+#if MDPP_IMG_ONESHOT
+            const dim3 grid((nblk + MDPP_IMG_ONESHOT - 1) / MDPP_IMG_ONESHOT);
+            (void)resident;
+#else
             const dim3 grid(nblk < resident ? nblk : resident);
+#endif
             const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);
             for (int pass = 0; pass < (img_final ? 2 : 1); pass++) {
                 const ImgRec *rec = pass ? a.rec1 : a.rec0;

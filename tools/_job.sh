@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -m gpu -x -q -k "many_boxes or line_reward_checkpoint or sparse_term" 2>&1 | tail -5
+python3 tools/ablate.py run mdpp_image.hip cfg4 numpy shipped os_straight shipped os_straight 2>&1 | cut -c1-200
