@@ -89,7 +89,7 @@ def test_live_traffic_all_splits_counter_rows_at_the_marker_dispatches(monkeypat
             nonlocal did
             did += 1
             rows.append(f'{did},"{name}",{counter},{val}')
-        per = {"FETCH_SIZE": (100.0, 1000.0), "WRITE_SIZE": (400.0, 2000.0)}[counter]
+        per = {"FETCH_SIZE": (100.0, 1000.0), "WRITE_SIZE": (400.0, 2000.0), "SQ_INSTS_VALU": (6.0e7, 9.0e8)}[counter]
         for w in range(sum(1 for c in cmd if c.count(":") == 3)):                                  # one segment per workload spec
             row("void mdpp::k_discrete_reset<false>(mdpp::DiscreteArgs)", 5.0)              # constructor reset: excluded
             row("void at::native::vectorized_elementwise_kernel<4>(int)", 77.0)             # torch kernel: excluded
@@ -105,6 +105,20 @@ def test_live_traffic_all_splits_counter_rows_at_the_marker_dispatches(monkeypat
     assert res["cfg2"]["bytes_per_launch"] == int((2 * 100.0 + 400.0) * 1024)
     assert res["cfg3"]["bytes_per_launch"] == int((2 * 1000.0 + 2000.0) * 1024)
     assert "k_discrete_rollout_lean" in res["cfg2"]["kernels"] and "reset" not in res["cfg2"]["kernels"]
+    # round 5: the third pass, vector instructions issued per launch -> valu_frac (a failure of that pass alone only drops it)
+    assert res["cfg2"]["valu_insts_per_launch"] == 6.0e7 and res["cfg3"]["valu_insts_per_launch"] == 9.0e8
+    v = bench.valu_roofline(res["cfg3"]["valu_insts_per_launch"], 600.0, 0.70)
+    assert abs(v["valu_frac"] - 9.0e8 / 1024 * 4 / 2.4e9 * 1e6 / 600.0) < 1e-12 and v["bound"] == "valu"
+    assert bench.valu_roofline(None, 600.0, 0.70) == {"valu_frac": None, "bound": "hbm"}
+    real = fake_run
+
+    def fail_third(cmd, **kw):
+        if "SQ_INSTS_VALU" in cmd:
+            return types.SimpleNamespace(returncode=1)
+        return real(cmd, **kw)
+    monkeypatch.setattr(bench, "_run_group", lambda cmd, timeout, **kw: fail_third(cmd, **kw).returncode)
+    res2 = bench.live_traffic_all(specs, launches=launches)
+    assert res2["cfg2"]["bytes_per_launch"] == res["cfg2"]["bytes_per_launch"] and res2["cfg2"]["valu_insts_per_launch"] is None
     one = bench.live_traffic("cfg2", "numpy", 65536, 512, launches=launches)
     assert one[0] == res["cfg2"]["bytes_per_launch"]
 

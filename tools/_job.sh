@@ -1,2 +1,3 @@
+# scratch job for one gpurun call (GPU box); the last content: the round's validation
 cd $GRAFT_REPO_ROOT
-python3 tools/ablate.py run mdpp_image.hip cfg4 numpy shipped os_straight shipped os_straight 2>&1 | cut -c1-200
+bash tools/validate_all.sh
