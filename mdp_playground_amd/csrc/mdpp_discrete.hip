@@ -68,7 +68,32 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     if (NOISE) zig_stage(s_ki, s_wi, s_fi, tid, kBlock);
     if (NOISE && !LDSTAB) __syncthreads();
     const ZigLds zig{s_ki, s_wi, s_fi};
-    if (LDSTAB) {
+    // One MDP PER ENV (seeds=[...], what every golden uses) with small tables (round 5): each lane copies ITS env's tables
+    // into its own LDS slot once per launch -- 200 B at 8 x 8 -- so that the step's dependent lookups (P[s][a], terminal flag,
+    // reward bit, rho_0) are LDS reads instead of one L2 round trip each: 128 waves of an 8 192-env job ran 1.66 us per step
+    // on gathers from L2 (bench leg cfg2_per_env).  Slot stride = the shared carve + 8 bytes (bank spread, 8-byte alignment kept).
+    const bool per_env_lds = LDSTAB && !a.shared_tables;
+    if (per_env_lds) {
+        unsigned char *slot = lds + (size_t)tid * (a.lds_bytes + 8u);
+        const size_t ti = (size_t)(i < a.N ? i : a.N - 1);
+        const int SA = a.S * a.A;
+        for (int k = 0; k < SA; k++) slot[a.lds_P + k] = a.P[ti * SA + k];
+        for (int k = 0; k < a.S; k++) {
+            slot[a.lds_term + k] = a.is_term[ti * a.S + k];
+            ((double *)(slot + a.lds_init))[k] = a.init_cdf[ti * a.S + k];
+        }
+        if (UNIT)
+            for (uint32_t k = 0; k < a.rbits_stride; k++) slot[a.lds_rew + k] = a.rbits[ti * a.rbits_stride + k];
+        else
+            for (uint32_t k = 0; k < a.nkeys; k++) ((double *)(slot + a.lds_rew))[k] = a.rtable[ti * a.nkeys + k];
+        t.P = slot + a.lds_P;
+        t.is_term = slot + a.lds_term;
+        t.init_cdf = (const double *)(slot + a.lds_init);
+        t.rbits = slot + a.lds_rew;
+        t.rtable = (const double *)(slot + a.lds_rew);
+        t.noise_cdf = a.noise_cdf;                  // (not used: this mode is for handles without transition noise)
+        if (NOISE) __syncthreads();                 // (the ziggurat tables staged above)
+    } else if (LDSTAB) {
         // Stage the shared MDP into LDS: a few hundred bytes for 8x8 (P 64 B + flags 8 B +
         // reward bitmask 64 B + cdf 64 B).
         for (int k = tid; k < a.S * a.A; k += kBlock) lds[a.lds_P + k] = a.P[k];
@@ -393,11 +418,22 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
                           hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
     // (tables beyond the default dynamic-LDS limit -- a large action space -- are read from HBM / L2)
-    const bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds) && a.lds_bytes <= 48u * 1024u;
-    const size_t lds = ldstab ? a.lds_bytes : 0;
+    // (one MDP per env: each lane's tables in its own LDS slot when 256 slots fit 96 KiB and the rollout is long enough to pay
+    //  for the copy; named LDSTAB=2)
+    const size_t env_lds = (size_t)kBlock * (a.lds_bytes + 8u);
+    bool ldsenv = !a.shared_tables && a.rew_in_lds && !a.has_p_noise && !a.irr && K >= 8 && env_lds <= 96u * 1024u &&
+                  !(a.opts & MDPP_OPT_NO_QUIET);
+    bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds) && a.lds_bytes <= 48u * 1024u;
+    if (ldsenv && !name_out) {
+        const void *kern = a.unit_rewards ? (const void *)k_discrete_step<PHILOX, NOISE, true, true, false>
+                                          : (const void *)k_discrete_step<PHILOX, NOISE, false, true, false>;
+        if (!dynamic_lds_ok(kern, env_lds)) ldsenv = false;
+    }
+    if (ldsenv) ldstab = true;
+    const size_t lds = ldsenv ? env_lds : (ldstab ? a.lds_bytes : 0);
     if (name_out) {
         snprintf(name_out, kNameLen, "k_discrete_step<PHILOX=%d,NOISE=%d,UNIT=%d,LDSTAB=%d,IRR=%d>", PHILOX, NOISE,
-                 a.unit_rewards != 0, ldstab, a.irr != 0);
+                 a.unit_rewards != 0, ldsenv ? 2 : (int)ldstab, a.irr != 0);
         return;
     }
 #define MDPP_D_LAUNCH(UNIT, LDSTAB, IRR)                                                               \

@@ -2299,6 +2299,10 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
     ("cfg2_noise", {"autoreset": "disabled", "terminal_state_density": 0.0}, "NO_LEAN,NO_QUIET", 32768, 128),   # (no resets: H still makes the noise)
     ("cfg2_noise", {"transition_noise": 0.5}, "NO_QUIET", 32768, 128),   # (rows' thresholds differ: the lean kernel declines, quiet vs general)
     ("cfg2_irr", {"transition_noise": 0.1}, "NO_QUIET", 65536, 128),
+    # round 5: one MDP per env with each lane's tables in its own LDS slot (k_discrete_step<...,LDSTAB=2>) vs the same kernel
+    # gathering them from L2 (NO_QUIET switches the slots off): unit and reward_dist rewards, reward noise, a ragged batch
+    ("cfg2_per_env", {}, "NO_QUIET", 2048, 96),
+    ("cfg2_per_env", {"reward_dist": [0.1, 1], "sequence_length": 1, "reward_noise": 0.2, "delay": 2, "max_episode_steps": 9}, "NO_QUIET", 1000, 64),
     # round 5: rewards that are not all 1.0 (reward_dist) on the role-split quiet kernel (float64 table in LDS, key delay line in
     # HBM) vs the general kernel -- the shapes of the reference's rainbow_reward_dist / dqn_delay_50_states sweeps
     ("d_s24_rdist", {}, "NO_QUIET", 65536, 128),
@@ -2357,8 +2361,9 @@ def test_specialised_kernels_equal_general_kernels_all_envs(workload, over, flag
     ekw = dict(autoreset=over.pop("autoreset", "same_step"), max_episode_steps=over.pop("max_episode_steps", None))
     cfg = dict(wl["config"], **over)
     cfg = {k: v for k, v in cfg.items() if v is not None}       # (None: drop the key from the workload's config)
-    a = _venv(num_envs=N, rng=rng, **ekw, **cfg)
-    b = _venv(num_envs=N, rng=rng, **ekw, **cfg)
+    nkw = dict(seeds=list(range(N))) if wl.get("per_env_mdps") else dict(num_envs=N)
+    a = _venv(rng=rng, **nkw, **ekw, **cfg)
+    b = _venv(rng=rng, **nkw, **ekw, **cfg)
     b.set_kernel_options(*flag.split(","))
     assert a.rollout_kernel_name(F) != b.rollout_kernel_name(F), (a.rollout_kernel_name(F), flag)
     wl2 = dict(wl, config=cfg)

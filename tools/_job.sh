@@ -1,3 +1,2 @@
-# scratch job for one gpurun call (GPU box); the last content: the round's validation
 cd $GRAFT_REPO_ROOT
-bash tools/validate_all.sh
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "specialised_kernels_equal and per_env" 2>&1 | tail -3
