@@ -1488,12 +1488,39 @@ __global__ __launch_bounds__(256) void k_probe_read(const pu4 *__restrict__ s, s
     if (acc == 0x12345u) out[0] = acc;          // (keeps the loads alive)
 }
 __global__ void k_probe_empty(uint32_t *p) { if (p && threadIdx.x == 0xFFFFu) p[0] = 1u; }
+// The renderer's store shape without anything else (mode 5 / 6): a wave writes ONE picture of `pic` bytes (84 x 84 = 7 056:
+// 16-byte aligned, not cache-line aligned) front to back, 1 KiB per store instruction; four pictures per workgroup, one-shot.
+// mode 6: the WORKGROUP writes its four pictures as one region, 4 KiB per round of its four waves, starting at a 128-byte
+// boundary (the bytes before it belong to the previous workgroup's last round).
+template <int COOP>
+__global__ __launch_bounds__(256) void k_probe_pictures(pu4 *__restrict__ d, size_t nbytes, uint32_t pic) {
+    const pu4 v = pu4{threadIdx.x, blockIdx.x, 5u, 6u};
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (COOP == 3) {                                    // (mode 8: eight pictures per workgroup -- 441 whole lines --, two per wave)
+        for (uint32_t r = 0; r < 2; r++) {
+            const size_t base = ((size_t)blockIdx.x * 8 + r * 4 + wave) * pic;
+            if (base + pic > nbytes) return;
+            for (uint32_t off = lane * 16u; off < pic; off += 1024u) d[(base + off) >> 4] = v;
+        }
+    } else if (!COOP) {
+        const size_t base = ((size_t)blockIdx.x * 4 + wave) * pic;
+        if (base + pic > nbytes) return;
+        for (uint32_t off = lane * 16u; off < pic; off += 1024u) d[(base + off) >> 4] = v;
+    } else {
+        const size_t lo = (size_t)blockIdx.x * 4 * pic, hi = lo + 4ull * pic;
+        if (hi > nbytes) return;
+        size_t a0 = blockIdx.x == 0 ? 0 : ((lo + 127) & ~(size_t)127), a1 = (hi + 127) & ~(size_t)127;   // [a0, a1): this workgroup's lines
+        if (COOP == 2) { a0 = lo; a1 = hi; }            // (mode 7: the workgroup's own bytes only, no line alignment)
+        for (size_t off = a0 + (size_t)threadIdx.x * 16u; off < a1 && off + 16 <= nbytes; off += 4096u) d[off >> 4] = v;
+    }
+}
 } // namespace mdpp
 
 extern "C" int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size_t nbytes, int reps, void *stream, float *ms_out) {
-    // mode: 0 copy, 1 fill, 2 read (dst_dev: one word of scratch), 3 copy with non-temporal stores, 4 fill with non-temporal stores
-    if (!ms_out || reps < 1 || nbytes < 16 || mode < 0 || mode > 4) return MDPP_EINVAL;
-    if ((mode != 2 && !dst_dev) || (mode != 1 && mode != 4 && !src_dev)) return MDPP_EINVAL;
+    // mode: 0 copy, 1 fill, 2 read (dst_dev: one word of scratch), 3 copy with non-temporal stores, 4 fill with non-temporal stores,
+    // 5 / 6: the picture renderer's store shape, per wave / per workgroup (tools only)
+    if (!ms_out || reps < 1 || nbytes < 16 || mode < 0 || mode > 8) return MDPP_EINVAL;
+    if ((mode != 2 && !dst_dev) || (mode != 1 && mode != 4 && mode < 5 && !src_dev)) return MDPP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = nbytes / 16;
     const dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
@@ -1504,6 +1531,10 @@ extern "C" int mdpp_probe_hbm(int mode, void *dst_dev, const void *src_dev, size
         else if (mode == 3) hipLaunchKernelGGL(mdpp::k_probe_copy<true>, grid, block, 0, s, (const mdpp::pu4 *)src_dev, (mdpp::pu4 *)dst_dev, n);
         else if (mode == 1) hipLaunchKernelGGL(mdpp::k_probe_fill<false>, grid, block, 0, s, (mdpp::pu4 *)dst_dev, n);
         else if (mode == 4) hipLaunchKernelGGL(mdpp::k_probe_fill<true>, grid, block, 0, s, (mdpp::pu4 *)dst_dev, n);
+        else if (mode == 5) hipLaunchKernelGGL(mdpp::k_probe_pictures<0>, dim3((unsigned)(nbytes / (4 * 7056))), block, 0, s, (mdpp::pu4 *)dst_dev, nbytes, 7056u);
+        else if (mode == 6) hipLaunchKernelGGL(mdpp::k_probe_pictures<1>, dim3((unsigned)(nbytes / (4 * 7056))), block, 0, s, (mdpp::pu4 *)dst_dev, nbytes, 7056u);
+        else if (mode == 8) hipLaunchKernelGGL(mdpp::k_probe_pictures<3>, dim3((unsigned)(nbytes / (8 * 7056))), block, 0, s, (mdpp::pu4 *)dst_dev, nbytes, 7056u);
+        else if (mode == 7) hipLaunchKernelGGL(mdpp::k_probe_pictures<2>, dim3((unsigned)(nbytes / (4 * 7056))), block, 0, s, (mdpp::pu4 *)dst_dev, nbytes, 7056u);
         else hipLaunchKernelGGL(mdpp::k_probe_read, grid, block, 0, s, (const mdpp::pu4 *)src_dev, n, (uint32_t *)dst_dev);
     };
     for (int w = 0; w < 2; w++) launch();
