@@ -359,7 +359,7 @@ def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=
     bad = int((env.status() != 0).sum())
     kname = env.rollout_kernel_name(F)
     single = None
-    if name in ("cfg3", "cfg5"):                #  the one-launch-per-step API and a replayed HIP graph of 64 such steps
+    if name in ("cfg3", "cfg5", "d_s50_delay4"):    #  the one-launch-per-step API and a replayed HIP graph of 64 such steps
         try:
             single = single_step_leg(env, wl, acts[0], N, device, n1=200, reps=5)
         except Exception as e:                  # a reported extra, never fatal

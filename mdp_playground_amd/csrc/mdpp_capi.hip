@@ -526,8 +526,12 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
                 const double t = j < S ? ceil(ldexp(init_cdf[j], 31)) : 4294967295.0;
                 blob[192 + j] = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
             }
-            if (!h->d_s1_blob) HIPCHK(h, hipMalloc(&h->d_s1_blob, 1024));
-            HIPCHK(h, hipMemcpy(h->d_s1_blob, blob.data(), 1024, hipMemcpyHostToDevice));
+            // (kS1Replicas copies, one per group of workgroups: 1 024 waves reading the SAME lines at the same moment queue up
+            //  at the few L2 channels that hold them)
+            if (h->d_s1_blob) { (void)hipFree(h->d_s1_blob); h->d_s1_blob = nullptr; }
+            HIPCHK(h, hipMalloc(&h->d_s1_blob, (size_t)kS1Replicas * 1024));
+            for (int r = 0; r < kS1Replicas; r++)
+                HIPCHK(h, hipMemcpy((char *)h->d_s1_blob + (size_t)r * 1024, blob.data(), 1024, hipMemcpyHostToDevice));
             s1.N = c.num_envs; s1.A = (uint32_t)c.A; s1.S = (uint32_t)c.S; s1.L = (uint32_t)c.L;
             s1.every_n = (uint32_t)c.every_n; s1.inv_every_n = 1.0 / (double)c.every_n;
             s1.max_steps = c.max_episode_steps > 0 ? (uint32_t)c.max_episode_steps : 0u;
@@ -540,6 +544,63 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             for (int q = 0; q < 4; q++) s1.rsel[q] = a.rsel[q];
             s1.blob = (const uint4 *)h->d_s1_blob;
             s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;
+        } else if (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise && c.L <= 3 && c.delay <= 32 &&
+                   c.autoreset != MDPP_AUTORESET_NEXT_STEP && !c.irrelevant && !c.episode_stats && c.every_n < (1 << 20)) {
+            // the same for state spaces beyond 16 states (k_discrete_step1w; the reference's 24- and 50-state sweeps): P as bytes,
+            // terminal flags, rho_0 thresholds (64-bit for numpy's draw, 31-bit for a Philox word), reward bits -- one blob of at
+            // most 8 KiB that a wave stages for itself
+            const uint32_t S8 = ((uint32_t)S + 7u) & ~7u;
+            const uint32_t off_term = align16((uint32_t)(S * A)), off_thr = align16(off_term + (uint32_t)S);
+            const uint32_t off_thr31 = off_thr + S8 * 8u, off_rew = align16(off_thr31 + S8 * 4u);
+            // + 256 buckets over the top 8 bits of the uniform (the handle's RNG: 53-bit numpy draw / 31-bit Philox word):
+            //   {thresholds at or below the bucket's first value, thresholds strictly inside it}
+            const uint32_t off_bk = align16(off_rew + h->rbits_stride);
+            const uint32_t bytes = (off_bk + 512u + 1023u) & ~1023u;
+            if (bytes <= 8u * 1024u) {
+                std::vector<uint8_t> blob(bytes, 0);
+                memcpy(blob.data(), P, S * A);
+                memcpy(blob.data() + off_term, is_term, S);
+                for (uint32_t j = 0; j < S8; j++) {
+                    const uint64_t t64 = j < S ? (uint64_t)ceil(ldexp(init_cdf[j], 53)) : ~0ULL;
+                    const double t31 = j < S ? ceil(ldexp(init_cdf[j], 31)) : 4294967295.0;
+                    const uint32_t t32 = t31 >= 4294967295.0 ? 4294967295u : (uint32_t)t31;
+                    memcpy(blob.data() + off_thr + 8u * j, &t64, 8);
+                    memcpy(blob.data() + off_thr31 + 4u * j, &t32, 4);
+                }
+                memcpy(blob.data() + off_rew, rbits, h->rbits_stride);
+                {
+                    const bool ph = c.rng_mode == MDPP_RNG_PHILOX;
+                    const int shift = ph ? 23 : 45;
+                    for (uint32_t b = 0; b < 256u; b++) {
+                        const uint64_t lo = (uint64_t)b << shift, hi = lo + (1ULL << shift);
+                        uint32_t c0 = 0, nin = 0;
+                        for (uint32_t j = 0; j < S; j++) {
+                            uint64_t t;
+                            if (ph) { uint32_t t32; memcpy(&t32, blob.data() + off_thr31 + 4u * j, 4); t = t32; }
+                            else memcpy(&t, blob.data() + off_thr + 8u * j, 8);
+                            c0 += t <= lo ? 1u : 0u;
+                            nin += (t > lo && t < hi) ? 1u : 0u;
+                        }
+                        const uint16_t e = (uint16_t)(c0 | (nin << 8));
+                        memcpy(blob.data() + off_bk + 2u * b, &e, 2);
+                    }
+                }
+                if (h->d_s1_blob) { (void)hipFree(h->d_s1_blob); h->d_s1_blob = nullptr; }
+                HIPCHK(h, hipMalloc(&h->d_s1_blob, (size_t)kS1Replicas * bytes));
+                for (int r = 0; r < kS1Replicas; r++)
+                    HIPCHK(h, hipMemcpy((char *)h->d_s1_blob + (size_t)r * bytes, blob.data(), bytes, hipMemcpyHostToDevice));
+                s1.N = c.num_envs; s1.A = (uint32_t)c.A; s1.S = (uint32_t)c.S; s1.L = (uint32_t)c.L;
+                s1.every_n = (uint32_t)c.every_n; s1.inv_every_n = 1.0 / (double)c.every_n;
+                s1.max_steps = c.max_episode_steps > 0 ? (uint32_t)c.max_episode_steps : 0u;
+                s1.delay = (uint32_t)c.delay; s1.autoreset = c.autoreset != MDPP_AUTORESET_DISABLED ? 1u : 0u;
+                s1.nan_mask = 0xFFu << (8 * c.L);
+                s1.philox_seed = a.philox_seed; s1.env_id_offset = a.env_id_offset;
+                for (int q = 0; q < 4; q++) s1.rsel[q] = a.rsel[q];
+                s1.blob = (const uint4 *)h->d_s1_blob;
+                s1.wide = 1; s1.blob_rounds = bytes / 1024u; s1.off_term = off_term; s1.off_thr = off_thr; s1.off_thr31 = off_thr31;
+                s1.off_rew = off_rew; s1.S8 = S8; s1.off_bk = off_bk;
+                s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;
+            }
         }
     }
     h->tables_ready = true;

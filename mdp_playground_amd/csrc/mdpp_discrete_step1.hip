@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void k_discrete_step1(Step1Args a) {
     const bool live = i < (uint32_t)a.N;
     const uint32_t ic = live ? i : (uint32_t)a.N - 1u;     // (spare lanes of the last block load lane N - 1's data and store nothing)
     // ---- every load of the launch, issued together ----
-    const uint4 blob4 = a.blob[tid];
+    const uint4 blob4 = a.blob[(blockIdx.x & (uint32_t)(kS1Replicas - 1)) * 64u + tid];
     const int action = a.actions[ic];
     const uint4 st = a.state[ic];
     Pcg64 g;
@@ -165,9 +165,146 @@ __global__ __launch_bounds__(64) void k_discrete_step1(Step1Args a) {
     }
 }
 
+// k_discrete_step1w: the same launch for state spaces beyond 16 states -- any S <= 255 whose tables (P as bytes, terminal flags,
+// rho_0 thresholds, reward bits) fit 8 KiB, L <= 3, unit rewards, no noise, no irrelevant sub-space: what the reference's own
+// sweeps use (S = A = 24 and 50, /root/reference/experiments/).  These handles keep no queue of start states (word 1 of their
+// record is the general kernel's history bytes 4-7), so an episode's end draws in place: numpy streams -- one PCG64 step and
+// the search of the S thresholds under ballot(need) --, Philox streams -- the tick's word.  The general kernel served these
+// single steps with byte loads -> LDS -> barrier -> record load in series: 6.4 us per step at S = 50.
+template <bool OBS64, bool PHILOX>
+__global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
+    extern __shared__ __align__(16) uint8_t ldsw[];
+    const int tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64u + tid;
+    const bool live = i < (uint32_t)a.N;
+    const uint32_t ic = live ? i : (uint32_t)a.N - 1u;
+    // ---- every load of the launch, issued together: up to eight 1 KiB rounds of the blob, the action, the record, the generator ----
+    // (eight loads issued back to back, UNCONDITIONALLY -- rounds beyond the blob re-read its last one: under `if (r < rounds)`
+    //  the compiler waited for each round before it issued the next, one L2 round trip per KiB: 2.7 us per step at 1 KiB,
+    //  4.0 at 4 KiB, 6.0 at 8 KiB)
+    uint4 bl[8];
+    const uint32_t rbase = (blockIdx.x & (uint32_t)(kS1Replicas - 1)) * a.blob_rounds, rlast = a.blob_rounds - 1u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) bl[r] = a.blob[(rbase + min((uint32_t)r, rlast)) * 64u + tid];
+    const int action = a.actions[ic];
+    const uint4 st = a.state[ic];
+    Pcg64 g;
+    if (!PHILOX) g.load(a.env_s, a.env_inc, ic);
+    const uint64_t tick = PHILOX ? a.ptick + (a.dtick ? *a.dtick : 0ULL) : 0ULL;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        if ((uint32_t)r < a.blob_rounds) ((uint4 *)ldsw)[r * 64 + tid] = bl[r];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t A = a.A, S = a.S, L = a.L;
+    uint32_t status = 0;
+    uint32_t ua = (uint32_t)action;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(ua >= A) != 0, 0)) {
+        ua = (uint32_t)(action + ((action >> 31) & (int)A));
+        const bool bad = ua >= A;
+        status |= bad ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+        ua = bad ? 0u : ua;
+    }
+    uint32_t hist = st.x, hist_hi = (st.y << 8) | (st.x >> 24), steps = st.z, ring = st.w;
+    const uint32_t cur = hist & 0xFFu;
+    const uint32_t nxt = ldsw[cur * A + ua];                                                   // D1
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 2; j >= 0; j--) {
+        if (j <= (int)L - 2) {
+            const uint32_t b = (hist >> (8 * j)) & 0xFFu;
+            key = key * S + (b == 0xFFu ? 0u : b);
+        }
+    }
+    key = key * S + nxt;
+    hist = (hist << 8) | nxt;
+    steps += 1;
+    const bool full = (hist & a.nan_mask) != a.nan_mask;
+    uint32_t phase;
+    {
+        const uint32_t q = (uint32_t)((double)steps * a.inv_every_n);
+        phase = steps - q * a.every_n;
+        phase = phase >= a.every_n ? phase - a.every_n : phase;
+    }
+    const uint32_t word = ((const uint32_t *)(ldsw + a.off_rew))[key >> 5];
+    const uint32_t done = ldsw[a.off_term + nxt] != 0 ? 1u : 0u;                               // D7
+    const uint32_t tr = (a.max_steps && steps >= a.max_steps) ? 1u : 0u;
+    const bool need = a.autoreset && ((done | tr) != 0);
+    uint32_t bit = (word >> (key & 31u)) & (full ? 1u : 0u);
+    if (a.delay) {
+        const uint32_t out = (ring >> (a.delay - 1u)) & 1u;
+        ring = (ring << 1) | bit;
+        bit = out;
+        ring = need ? 0u : ring;
+    }
+    bit = phase == 0 ? bit : 0u;
+    const float rout = done ? (bit ? a.rsel[3] : a.rsel[1]) : (bit ? a.rsel[2] : a.rsel[0]);
+    // ---- same-step autoreset: the start state is drawn now (reset(), :2250-2278) ----
+    bool drew = false;
+    uint32_t ocur = nxt;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        // searchsorted(cdf, u, 'right') = #{j : T[j] <= m}: the bucket of the uniform's top 8 bits knows how many thresholds lie
+        // at or below its first value and how many strictly inside it -- only those are compared (none in most buckets; a
+        // linear search of the S8 thresholds took 1.2 of the launch's 3.8 us at S = 50)
+        uint32_t s0 = 0;
+        const uint16_t *BK = (const uint16_t *)(ldsw + a.off_bk);
+        if constexpr (PHILOX) {
+            const uint32_t m31 = philox_start_m31(a.philox_seed, (uint64_t)(a.env_id_offset + (int64_t)ic), tick, kPhiloxStartStream);
+            const uint32_t *T31 = (const uint32_t *)(ldsw + a.off_thr31);
+            const uint32_t e = BK[m31 >> 23], c0 = e & 0xFFu, nin = e >> 8;
+            s0 = c0;
+            for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < nin) != 0; j++) s0 += (j < nin && T31[j < nin ? c0 + j : 0u] <= m31) ? 1u : 0u;
+        } else {
+            Pcg64 n = g;
+            const uint64_t m = n.next64() >> 11;
+            const uint64_t *T = (const uint64_t *)(ldsw + a.off_thr);
+            const uint32_t e = BK[(uint32_t)(m >> 45)], c0 = e & 0xFFu, nin = e >> 8;
+            s0 = c0;
+            for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < nin) != 0; j++) s0 += (j < nin && T[j < nin ? c0 + j : 0u] <= m) ? 1u : 0u;
+            if (need) { g = n; drew = true; }
+        }
+        if (need) { ocur = s0; hist = 0xFFFFFF00u | s0; hist_hi = 0xFFFFFFFFu; steps = 0; }
+    }
+    if (live) {
+        if (__builtin_expect(a.final_obs != nullptr, 0)) {
+            if (need) {
+                if (OBS64) ((s1_u32x2 *)a.final_obs)[i] = s1_u32x2{nxt, 0u};
+                else ((uint32_t *)a.final_obs)[i] = nxt;
+            }
+        }
+        if (OBS64) ((s1_u32x2 *)a.obs)[i] = s1_u32x2{ocur, 0u};
+        else ((uint32_t *)a.obs)[i] = ocur;
+        a.reward[i] = rout;
+        a.term[i] = (uint8_t)done;
+        a.trunc[i] = (uint8_t)tr;
+        a.state[i] = make_uint4(hist, hist_hi, steps, ring);
+        if (drew) g.store(a.env_s, i);
+        if (status) atomicOr(&a.status[i], status);
+    }
+}
+
 bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     if (!proto.blob || (d.opts & MDPP_OPT_NO_STEP1)) return false;
+    if (proto.wide) {                               // state spaces beyond 16 states: k_discrete_step1w
+        if (d.philox && (d.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
+        if (name_out) {
+            snprintf(name_out, kNameLen, "k_discrete_step1w<OBS64=%d,PHILOX=%d>", !d.obs_i32, d.philox);
+            return true;
+        }
+        Step1Args a = proto;
+        a.actions = actions; a.obs = obs; a.reward = reward; a.term = term; a.trunc = trunc; a.final_obs = final_obs;
+        a.ptick = d.ptick; a.dtick = d.dtick;
+        const int grid = (a.N + 63) / 64;
+        const size_t lds = (size_t)a.blob_rounds * 1024;
+        if (d.philox) {
+            if (d.obs_i32) hipLaunchKernelGGL((k_discrete_step1w<false, true>), dim3(grid), dim3(64), lds, s, a);
+            else hipLaunchKernelGGL((k_discrete_step1w<true, true>), dim3(grid), dim3(64), lds, s, a);
+        } else {
+            if (d.obs_i32) hipLaunchKernelGGL((k_discrete_step1w<false, false>), dim3(grid), dim3(64), lds, s, a);
+            else hipLaunchKernelGGL((k_discrete_step1w<true, false>), dim3(grid), dim3(64), lds, s, a);
+        }
+        return true;
+    }
     if (d.philox ? (!d.shape_ok || (d.opts & MDPP_OPT_NO_PHILOX_FAST)) : !d.fast_ok) return false;
     if (name_out) {
         snprintf(name_out, kNameLen, "k_discrete_step1<OBS64=%d,PHILOX=%d>", !d.obs_i32, d.philox);

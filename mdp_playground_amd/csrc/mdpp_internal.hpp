@@ -120,6 +120,10 @@ struct DiscreteArgs {
 
 // ---- discrete, one launch = one step (mdpp_discrete_step1.hip): everything the kernel reads, nothing else -- built once at
 // mdpp_upload_discrete_tables (the caller's buffers are filled in per launch)
+#ifndef MDPP_S1_REPLICAS
+#define MDPP_S1_REPLICAS 16
+#endif
+constexpr int kS1Replicas = MDPP_S1_REPLICAS;   // copies of the one-step kernels' table blob (power of two), one per group of workgroups
 struct Step1Args {
     int32_t N;
     uint32_t A, S, L, every_n, max_steps, delay, autoreset;
@@ -133,6 +137,8 @@ struct Step1Args {
     uint64_t philox_seed;
     int64_t env_id_offset;
     const uint4 *blob;          // 1 KiB: P columns as nibbles, rho_0 thresholds, reward bits (layout: mdpp_discrete_step1.hip)
+    // k_discrete_step1w (any S <= 255 whose tables fit 8 KiB): byte offsets into the blob, its size in 1 KiB rounds
+    uint32_t wide, blob_rounds, off_term, off_thr, off_thr31, off_rew, S8, off_bk;
     const int32_t *actions;
     void *obs;
     float *reward;

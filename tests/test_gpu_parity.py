@@ -2436,6 +2436,15 @@ STEP1_CASES = {
                            "k_discrete_step1<"),
     "d_s6_nonpow2_everyn": (dict(FAST_VARIANTS["s6_l2_nonpow2"][0], reward_every_n_steps=3), dict(autoreset="same_step"), 1000,
                             "k_discrete_step1<"),
+    # state spaces beyond 16 states (k_discrete_step1w; the reference's 24- and 50-state sweeps)
+    "d_s50_numpy": (dict(__import__("bench").WORKLOADS["d_s50_delay4"]["config"], seed=3), dict(autoreset="same_step"), 4096,
+                    "k_discrete_step1w<OBS64=1,PHILOX=0>"),
+    "d_s50_philox_ragged_trunc": (dict(__import__("bench").WORKLOADS["d_s50_delay4"]["config"], seed=3, sequence_length=2, reward_density=0.02),
+                                  dict(autoreset="same_step", rng="philox", max_episode_steps=6), 1000, "k_discrete_step1w<OBS64=1,PHILOX=1>"),
+    "d_s24_unit_disabled": (dict(__import__("bench").WORKLOADS["d_s24_rdist"]["config"], seed=3, reward_dist=None, delay=3, sequence_length=3,
+                                 reward_every_n_steps=2), dict(autoreset="disabled"), 1000, "k_discrete_step1w<"),
+    "d_s120": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=120, action_space_size=60, delay=1,
+                    sequence_length=1, terminal_state_density=0.5, seed=3), dict(autoreset="same_step"), 1024, "k_discrete_step1w<"),
     "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),
     "c_cfg3_ragged_next_step": (_S1_C_CFG3, dict(autoreset="next_step", max_episode_steps=7), 1000, "k_continuous_step1<"),
     "c_cfg3_disabled": (_S1_C_CFG3, dict(autoreset="disabled"), 1000, "k_continuous_step1<"),
@@ -2465,6 +2474,7 @@ def test_step1_kernels_equal_the_rollout_kernels_with_k1(case):
     state and every stream's end state, bit for bit -- single steps, a fused piece in between (shared start-state queue),
     rejected actions (continuous: "stay" makes the kernel read the rows it otherwise skips; discrete: the status bit)."""
     cfg, kw, N, prefix = STEP1_CASES[case]
+    cfg = {k: v for k, v in cfg.items() if v is not None}
     a, b = _venv(num_envs=N, **kw, **cfg), _venv(num_envs=N, **kw, **cfg)
     b.set_kernel_options("NO_STEP1")
     if case == "c_cfg5_numpy_sequential":       # the one-step kernel that draws its normals one after the other in the env's lane
