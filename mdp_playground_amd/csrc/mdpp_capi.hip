@@ -513,6 +513,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         // ---- one launch = one step (mdpp_discrete_step1.hip): the tables as ONE 1 KiB blob, the arguments as one small block ----
         Step1Args &s1 = h->s1args;
         memset(&s1, 0, sizeof(s1));
+        const bool rew_sa_ = c.reward_kind == MDPP_REWARD_STATE_ACTION;
         if (a.shape_ok && c.every_n < (1 << 20)) {
             std::vector<uint32_t> blob(256, 0u);
             for (size_t act = 0; act < A && act < 16; act++) {
@@ -544,7 +545,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             for (int q = 0; q < 4; q++) s1.rsel[q] = a.rsel[q];
             s1.blob = (const uint4 *)h->d_s1_blob;
             s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;
-        } else if (T == 1 && c.unit_rewards && !c.has_transition_noise && !c.has_reward_noise && c.L <= 3 && c.delay <= 32 &&
+        } else if (T == 1 && (c.unit_rewards ? c.delay <= 32 : !rew_sa_) && !c.has_transition_noise && !c.has_reward_noise && c.L <= 3 &&
                    c.autoreset != MDPP_AUTORESET_NEXT_STEP && !c.irrelevant && !c.episode_stats && c.every_n < (1 << 20)) {
             // the same for state spaces beyond 16 states (k_discrete_step1w; the reference's 24- and 50-state sweeps): P as bytes,
             // terminal flags, rho_0 thresholds (64-bit for numpy's draw, 31-bit for a Philox word), reward bits -- one blob of at
@@ -554,7 +555,9 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             const uint32_t off_thr31 = off_thr + S8 * 8u, off_rew = align16(off_thr31 + S8 * 4u);
             // + 256 buckets over the top 8 bits of the uniform (the handle's RNG: 53-bit numpy draw / 31-bit Philox word):
             //   {thresholds at or below the bucket's first value, thresholds strictly inside it}
-            const uint32_t off_bk = align16(off_rew + h->rbits_stride);
+            // (rewards that are not all 1.0: the float64 table by sequence key instead of the bit table)
+            const uint32_t rew_bytes = c.unit_rewards ? h->rbits_stride : h->nkeys * 8u;
+            const uint32_t off_bk = align16(off_rew + rew_bytes);
             const uint32_t bytes = (off_bk + 512u + 1023u) & ~1023u;
             if (bytes <= 8u * 1024u) {
                 std::vector<uint8_t> blob(bytes, 0);
@@ -567,7 +570,8 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
                     memcpy(blob.data() + off_thr + 8u * j, &t64, 8);
                     memcpy(blob.data() + off_thr31 + 4u * j, &t32, 4);
                 }
-                memcpy(blob.data() + off_rew, rbits, h->rbits_stride);
+                if (c.unit_rewards) memcpy(blob.data() + off_rew, rbits, h->rbits_stride);
+                else memcpy(blob.data() + off_rew, rtable, (size_t)h->nkeys * 8u);
                 {
                     const bool ph = c.rng_mode == MDPP_RNG_PHILOX;
                     const int shift = ph ? 23 : 45;
@@ -599,6 +603,8 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
                 s1.blob = (const uint4 *)h->d_s1_blob;
                 s1.wide = 1; s1.blob_rounds = bytes / 1024u; s1.off_term = off_term; s1.off_thr = off_thr; s1.off_thr31 = off_thr31;
                 s1.off_rew = off_rew; s1.S8 = S8; s1.off_bk = off_bk;
+                s1.unit = c.unit_rewards ? 1u : 0u; s1.ring_keys = a.ring_keys;
+                s1.scale = a.scale; s1.shift = a.shift; s1.term_add = a.term_add;
                 s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;
             }
         }

@@ -171,7 +171,10 @@ __global__ __launch_bounds__(64) void k_discrete_step1(Step1Args a) {
 // record is the general kernel's history bytes 4-7), so an episode's end draws in place: numpy streams -- one PCG64 step and
 // the search of the S thresholds under ballot(need) --, Philox streams -- the tick's word.  The general kernel served these
 // single steps with byte loads -> LDS -> barrier -> record load in series: 6.4 us per step at S = 50.
-template <bool OBS64, bool PHILOX>
+// UR = false: rewards that are not all 1.0 (reward_dist; the reference's rainbow_reward_dist sweep): the reward is read from a
+// float64 table by the sequence key and formed in float64 in the reference's order, the delay line holds KEYS in HBM
+// (ring_keys[delay][N], shared with the general and the quiet kernel) -- like k_discrete_step<UNIT = false>.
+template <bool OBS64, bool PHILOX, bool UR>
 __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
     extern __shared__ __align__(16) uint8_t ldsw[];
     const int tid = threadIdx.x;
@@ -190,7 +193,15 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
     const uint4 st = a.state[ic];
     Pcg64 g;
     if (!PHILOX) g.load(a.env_s, a.env_inc, ic);
-    const uint64_t tick = PHILOX ? a.ptick + (a.dtick ? *a.dtick : 0ULL) : 0ULL;
+    const uint64_t tick = (PHILOX || !UR) ? a.ptick + (a.dtick ? *a.dtick : 0ULL) : 0ULL;
+    // (the key that leaves the delay line this step: loaded now, beside everything else)
+    uint32_t *kslot = nullptr;
+    uint32_t kout = kNoKey;
+    if (!UR && a.delay) {
+        const uint32_t head = a.dtick ? (uint32_t)(tick % (uint64_t)a.delay) : a.ring_head;
+        kslot = a.ring_keys + (size_t)head * (size_t)a.N + ic;
+        kout = *kslot;
+    }
 #pragma unroll
     for (int r = 0; r < 8; r++)
         if ((uint32_t)r < a.blob_rounds) ((uint4 *)ldsw)[r * 64 + tid] = bl[r];
@@ -225,19 +236,37 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
         phase = steps - q * a.every_n;
         phase = phase >= a.every_n ? phase - a.every_n : phase;
     }
-    const uint32_t word = ((const uint32_t *)(ldsw + a.off_rew))[key >> 5];
     const uint32_t done = ldsw[a.off_term + nxt] != 0 ? 1u : 0u;                               // D7
     const uint32_t tr = (a.max_steps && steps >= a.max_steps) ? 1u : 0u;
     const bool need = a.autoreset && ((done | tr) != 0);
-    uint32_t bit = (word >> (key & 31u)) & (full ? 1u : 0u);
-    if (a.delay) {
-        const uint32_t out = (ring >> (a.delay - 1u)) & 1u;
-        ring = (ring << 1) | bit;
-        bit = out;
-        ring = need ? 0u : ring;
+    float rout;
+    if constexpr (UR) {
+        const uint32_t word = ((const uint32_t *)(ldsw + a.off_rew))[key >> 5];
+        uint32_t bit = (word >> (key & 31u)) & (full ? 1u : 0u);
+        if (a.delay) {
+            const uint32_t out = (ring >> (a.delay - 1u)) & 1u;
+            ring = (ring << 1) | bit;
+            bit = out;
+            ring = need ? 0u : ring;
+        }
+        bit = phase == 0 ? bit : 0u;
+        rout = done ? (bit ? a.rsel[3] : a.rsel[1]) : (bit ? a.rsel[2] : a.rsel[0]);
+    } else {                                                                                    // :1821-1845, :1968-1990, :2107
+        uint32_t k = full ? key : kNoKey;
+        if (a.delay) {
+            if (live) *kslot = k;
+            k = kout;
+        }
+        double r = (k != kNoKey) ? ((const double *)(ldsw + a.off_rew))[k] : 0.0;
+        r = phase == 0 ? r : 0.0;
+        r *= a.scale;
+        r += a.shift;
+        if (done) r += a.term_add;
+        rout = (float)r;
+        if (a.delay && __builtin_amdgcn_ballot_w64(need) != 0) {                                // reset() empties the delay line (:2250)
+            if (need && live) for (uint32_t dd = 0; dd < a.delay; dd++) a.ring_keys[(size_t)dd * (size_t)a.N + i] = kNoKey;
+        }
     }
-    bit = phase == 0 ? bit : 0u;
-    const float rout = done ? (bit ? a.rsel[3] : a.rsel[1]) : (bit ? a.rsel[2] : a.rsel[0]);
     // ---- same-step autoreset: the start state is drawn now (reset(), :2250-2278) ----
     bool drew = false;
     uint32_t ocur = nxt;
@@ -288,21 +317,22 @@ bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const 
     if (proto.wide) {                               // state spaces beyond 16 states: k_discrete_step1w
         if (d.philox && (d.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
         if (name_out) {
-            snprintf(name_out, kNameLen, "k_discrete_step1w<OBS64=%d,PHILOX=%d>", !d.obs_i32, d.philox);
+            snprintf(name_out, kNameLen, "k_discrete_step1w<OBS64=%d,PHILOX=%d,UNIT=%d>", !d.obs_i32, d.philox, proto.unit);
             return true;
         }
         Step1Args a = proto;
         a.actions = actions; a.obs = obs; a.reward = reward; a.term = term; a.trunc = trunc; a.final_obs = final_obs;
-        a.ptick = d.ptick; a.dtick = d.dtick;
+        a.ptick = d.ptick; a.dtick = d.dtick; a.ring_head = d.tick;
         const int grid = (a.N + 63) / 64;
         const size_t lds = (size_t)a.blob_rounds * 1024;
-        if (d.philox) {
-            if (d.obs_i32) hipLaunchKernelGGL((k_discrete_step1w<false, true>), dim3(grid), dim3(64), lds, s, a);
-            else hipLaunchKernelGGL((k_discrete_step1w<true, true>), dim3(grid), dim3(64), lds, s, a);
-        } else {
-            if (d.obs_i32) hipLaunchKernelGGL((k_discrete_step1w<false, false>), dim3(grid), dim3(64), lds, s, a);
-            else hipLaunchKernelGGL((k_discrete_step1w<true, false>), dim3(grid), dim3(64), lds, s, a);
-        }
+#define MDPP_S1W(O64, PH)                                                                                           \
+    do {                                                                                                            \
+        if (a.unit) hipLaunchKernelGGL((k_discrete_step1w<O64, PH, true>), dim3(grid), dim3(64), lds, s, a);       \
+        else hipLaunchKernelGGL((k_discrete_step1w<O64, PH, false>), dim3(grid), dim3(64), lds, s, a);             \
+    } while (0)
+        if (d.philox) { if (d.obs_i32) MDPP_S1W(false, true); else MDPP_S1W(true, true); }
+        else { if (d.obs_i32) MDPP_S1W(false, false); else MDPP_S1W(true, false); }
+#undef MDPP_S1W
         return true;
     }
     if (d.philox ? (!d.shape_ok || (d.opts & MDPP_OPT_NO_PHILOX_FAST)) : !d.fast_ok) return false;

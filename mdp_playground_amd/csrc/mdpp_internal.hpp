@@ -139,6 +139,10 @@ struct Step1Args {
     const uint4 *blob;          // 1 KiB: P columns as nibbles, rho_0 thresholds, reward bits (layout: mdpp_discrete_step1.hip)
     // k_discrete_step1w (any S <= 255 whose tables fit 8 KiB): byte offsets into the blob, its size in 1 KiB rounds
     uint32_t wide, blob_rounds, off_term, off_thr, off_thr31, off_rew, S8, off_bk;
+    // ... with rewards that are not all 1.0 (reward_dist): a float64 table by sequence key at off_rew, the delay line of KEYS in HBM
+    uint32_t unit, ring_head;   // ring_head: env steps taken so far mod delay (a graph replay: from ptick + *dtick)
+    uint32_t *ring_keys;        // [delay][N]
+    double scale, shift, term_add;
     const int32_t *actions;
     void *obs;
     float *reward;

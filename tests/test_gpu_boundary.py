@@ -375,7 +375,7 @@ def test_step_graph_counts_its_steps_and_refuses_inexact_handles():
 
 
 @pytest.mark.parametrize("case", ["cfg2-philox", "cfg2noise-philox", "cfg3delay3-numpy", "cfg5-philox", "cfg5-numpy-delay2",
-                                  "custom-reward-delay", "grid-philox"])
+                                  "custom-reward-delay", "grid-philox", "s50-philox", "s24rdist-delay2-philox"])
 def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
     """step() is the API RL code calls; a replayed graph of K single steps is exact for EVERY handle without
     image observations.  Launches captured in the library's capture mode add a device word to the step counter they were
@@ -393,6 +393,10 @@ def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
         cfg, kw = dict(bench.WORKLOADS["cfg5"]["config"]), dict(rng="philox", philox_seed=5)
     elif case == "cfg5-numpy-delay2":
         cfg, kw = dict(bench.WORKLOADS["cfg5"]["config"], delay=2), {}
+    elif case == "s50-philox":                   # round 5: k_discrete_step1w, start states keyed by the tick
+        cfg, kw = dict(bench.WORKLOADS["d_s50_delay4"]["config"]), dict(rng="philox", philox_seed=8)
+    elif case == "s24rdist-delay2-philox":       # ... its float-reward form: the key delay line's head AND the Philox tick move
+        cfg, kw = dict(bench.WORKLOADS["d_s24_rdist"]["config"], delay=2), dict(rng="philox", philox_seed=9)
     elif case == "custom-reward-delay":          # float rewards: the discrete delay line lives in memory (keys awaiting payout)
         cfg, kw = dict(gu.CASES["d_rdist"]["config"], seed=2, delay=3), {}
     else:
@@ -400,6 +404,8 @@ def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
     N, K = 1024, 5
     a = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    if case in ("custom-reward-delay", "s50-philox", "s24rdist-delay2-philox"):
+        assert a.rollout_kernel_name(1).startswith("k_discrete_step1w<"), a.rollout_kernel_name(1)
     assert a._lib.mdpp_graph_replay_exact(a._h, K) == 2, case
     rng = np.random.default_rng(7)
     g = a.step_graph(torch.as_tensor(_rand_actions(a, K, rng), device=a.device))

@@ -2438,11 +2438,18 @@ STEP1_CASES = {
                             "k_discrete_step1<"),
     # state spaces beyond 16 states (k_discrete_step1w; the reference's 24- and 50-state sweeps)
     "d_s50_numpy": (dict(__import__("bench").WORKLOADS["d_s50_delay4"]["config"], seed=3), dict(autoreset="same_step"), 4096,
-                    "k_discrete_step1w<OBS64=1,PHILOX=0>"),
+                    "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=1>"),
     "d_s50_philox_ragged_trunc": (dict(__import__("bench").WORKLOADS["d_s50_delay4"]["config"], seed=3, sequence_length=2, reward_density=0.02),
-                                  dict(autoreset="same_step", rng="philox", max_episode_steps=6), 1000, "k_discrete_step1w<OBS64=1,PHILOX=1>"),
+                                  dict(autoreset="same_step", rng="philox", max_episode_steps=6), 1000, "k_discrete_step1w<OBS64=1,PHILOX=1,UNIT=1>"),
     "d_s24_unit_disabled": (dict(__import__("bench").WORKLOADS["d_s24_rdist"]["config"], seed=3, reward_dist=None, delay=3, sequence_length=3,
                                  reward_every_n_steps=2), dict(autoreset="disabled"), 1000, "k_discrete_step1w<"),
+    "d_s24_rdist": (dict(__import__("bench").WORKLOADS["d_s24_rdist"]["config"], seed=3), dict(autoreset="same_step"), 4096,
+                    "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=0>"),
+    "d_s24_rdist_delay_philox": (dict(__import__("bench").WORKLOADS["d_s24_rdist"]["config"], seed=3, delay=3, sequence_length=2, reward_scale=2.5,
+                                      reward_shift=-0.75, term_state_reward=-1.5), dict(autoreset="same_step", rng="philox", max_episode_steps=7), 1000,
+                                 "k_discrete_step1w<OBS64=1,PHILOX=1,UNIT=0>"),
+    "d_s24_rdist_delay_disabled": (dict(__import__("bench").WORKLOADS["d_s24_rdist"]["config"], seed=3, delay=2, reward_every_n_steps=3),
+                                   dict(autoreset="disabled"), 1000, "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=0>"),
     "d_s120": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=120, action_space_size=60, delay=1,
                     sequence_length=1, terminal_state_density=0.5, seed=3), dict(autoreset="same_step"), 1024, "k_discrete_step1w<"),
     "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),
