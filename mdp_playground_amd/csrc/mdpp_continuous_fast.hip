@@ -1342,6 +1342,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
         // written back THEN, all at once, before the next launch may start (MI355X_MICROARCH.md, "boundary": + B / 6 TB/s for B
         // dirty bytes: 10 MB = 1.7 us per step); as non-temporal stores they leave while the other waves still compute.
 #ifndef MDPP_K1_PLAIN_STORES
+#ifdef MDPP_K1_ABL_NOSTATE          /* timing only: no state stores at all */
+        if (steps == 0x7fffffffu) a.meta[i].x = __float_as_uint(sd[0][0] + cur[0]);
+        return;
+#endif
+        // (where a cfg3 launch's 5.42 us go, tools/ablate_step1.py: without these state stores 3.78, without the observation /
+        //  reward / flag stores 5.21, without both 2.71 -- the stores drain at about 7 TB/s, 13.5 MB of them.  Storing the rows as 16
+        //  bytes per lane through an LDS tile, 9 instructions instead of 37, changed nothing: 5.40 against 5.48 -- bytes, not requests.)
 #pragma unroll
         for (int k = 0; k <= ORDER; k++)
 #pragma unroll
