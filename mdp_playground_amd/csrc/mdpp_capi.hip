@@ -545,7 +545,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             for (int q = 0; q < 4; q++) s1.rsel[q] = a.rsel[q];
             s1.blob = (const uint4 *)h->d_s1_blob;
             s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;
-        } else if (T == 1 && (c.unit_rewards ? c.delay <= 32 : !rew_sa_) && !c.has_transition_noise && !c.has_reward_noise && c.L <= 3 &&
+        } else if (T == 1 && (c.unit_rewards ? c.delay <= 32 : (!rew_sa_ && !c.has_transition_noise && !c.has_reward_noise)) && c.L <= 3 &&
                    c.autoreset != MDPP_AUTORESET_NEXT_STEP && !c.irrelevant && !c.episode_stats && c.every_n < (1 << 20)) {
             // the same for state spaces beyond 16 states (k_discrete_step1w; the reference's 24- and 50-state sweeps): P as bytes,
             // terminal flags, rho_0 thresholds (64-bit for numpy's draw, 31-bit for a Philox word), reward bits -- one blob of at
@@ -558,8 +558,12 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             // (rewards that are not all 1.0: the float64 table by sequence key instead of the bit table)
             const uint32_t rew_bytes = c.unit_rewards ? h->rbits_stride : h->nkeys * 8u;
             const uint32_t off_bk = align16(off_rew + rew_bytes);
-            const uint32_t bytes = (off_bk + 512u + 1023u) & ~1023u;
-            if (bytes <= 8u * 1024u) {
+            // (noise: the thresholds of the S transition-noise categoricals, numpy's ziggurat tables for the reward noise)
+            const bool np_streams = c.rng_mode == MDPP_RNG_NUMPY_PCG64;
+            const uint32_t off_tn = off_bk + 512u;
+            const uint32_t off_zig = off_tn + ((c.has_transition_noise && np_streams) ? (uint32_t)S * S8 * 8u : 0u);
+            const uint32_t bytes = (off_zig + ((c.has_reward_noise && np_streams) ? 6144u : 0u) + 1023u) & ~1023u;
+            if (bytes <= 12u * 1024u) {
                 std::vector<uint8_t> blob(bytes, 0);
                 memcpy(blob.data(), P, S * A);
                 memcpy(blob.data() + off_term, is_term, S);
@@ -589,6 +593,18 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
                         memcpy(blob.data() + off_bk + 2u * b, &e, 2);
                     }
                 }
+                if (c.has_transition_noise && np_streams)
+                    for (uint32_t row = 0; row < S; row++)
+                        for (uint32_t j = 0; j < S8; j++) {
+                            const uint64_t t64 = j < S ? (uint64_t)ceil(ldexp(noise_cdf[row * S + j], 53)) : ~0ULL;
+                            memcpy(blob.data() + off_tn + 8u * (row * S8 + j), &t64, 8);
+                        }
+                if (c.has_reward_noise && np_streams) {
+                    static const uint64_t ki[256] = NPZ_KI_INIT;
+                    static const double wi[256] = NPZ_WI_INIT, fi[256] = NPZ_FI_INIT;
+                    memcpy(blob.data() + off_zig, ki, 2048); memcpy(blob.data() + off_zig + 2048, wi, 2048);
+                    memcpy(blob.data() + off_zig + 4096, fi, 2048);
+                }
                 if (h->d_s1_blob) { (void)hipFree(h->d_s1_blob); h->d_s1_blob = nullptr; }
                 HIPCHK(h, hipMalloc(&h->d_s1_blob, (size_t)kS1Replicas * bytes));
                 for (int r = 0; r < kS1Replicas; r++)
@@ -603,6 +619,9 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
                 s1.blob = (const uint4 *)h->d_s1_blob;
                 s1.wide = 1; s1.blob_rounds = bytes / 1024u; s1.off_term = off_term; s1.off_thr = off_thr; s1.off_thr31 = off_thr31;
                 s1.off_rew = off_rew; s1.S8 = S8; s1.off_bk = off_bk;
+                s1.has_p_noise = c.has_transition_noise ? 1u : 0u; s1.has_r_noise = c.has_reward_noise ? 1u : 0u;
+                s1.off_tn = off_tn; s1.off_zig = off_zig; s1.pn_T = a.pn_T; s1.pn_M = a.pn_M; s1.r_noise = a.r_noise;
+                s1.sp_s = a.sp_s; s1.sp_inc = a.sp_inc;
                 s1.unit = c.unit_rewards ? 1u : 0u; s1.ring_keys = a.ring_keys;
                 s1.scale = a.scale; s1.shift = a.shift; s1.term_add = a.term_add;
                 s1.state = a.state; s1.env_s = a.env_s; s1.env_inc = a.env_inc; s1.status = a.status;

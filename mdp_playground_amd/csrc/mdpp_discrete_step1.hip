@@ -174,8 +174,14 @@ __global__ __launch_bounds__(64) void k_discrete_step1(Step1Args a) {
 // UR = false: rewards that are not all 1.0 (reward_dist; the reference's rainbow_reward_dist sweep): the reward is read from a
 // float64 table by the sequence key and formed in float64 in the reference's order, the delay line holds KEYS in HBM
 // (ring_keys[delay][N], shared with the general and the quiet kernel) -- like k_discrete_step<UNIT = false>.
-template <bool OBS64, bool PHILOX, bool UR>
+// NZ = true: transition and / or reward noise (the reference's p_noise / r_noise sweeps on 8 x 8 envs; unit rewards).  numpy
+// streams: the step's uniform of the state space's stream re-draws the next state from the categorical around the table's entry
+// (:1604-1622; integer thresholds like rho_0), the reward noise is one ziggurat normal of the ENV stream (tables in the blob),
+// drawn before a reset()'s start state as numpy orders them; Philox streams: the tick's words (mdpp_rng.hpp).
+template <bool OBS64, bool PHILOX, bool UR, bool NZ = false>
 __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
+    static_assert(!NZ || UR, "noise: unit rewards");
+    constexpr int kRounds = NZ ? 12 : 8;
     extern __shared__ __align__(16) uint8_t ldsw[];
     const int tid = threadIdx.x;
     const uint32_t i = blockIdx.x * 64u + tid;
@@ -185,15 +191,17 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
     // (eight loads issued back to back, UNCONDITIONALLY -- rounds beyond the blob re-read its last one: under `if (r < rounds)`
     //  the compiler waited for each round before it issued the next, one L2 round trip per KiB: 2.7 us per step at 1 KiB,
     //  4.0 at 4 KiB, 6.0 at 8 KiB)
-    uint4 bl[8];
+    uint4 bl[kRounds];
     const uint32_t rbase = (blockIdx.x & (uint32_t)(kS1Replicas - 1)) * a.blob_rounds, rlast = a.blob_rounds - 1u;
 #pragma unroll
-    for (int r = 0; r < 8; r++) bl[r] = a.blob[(rbase + min((uint32_t)r, rlast)) * 64u + tid];
+    for (int r = 0; r < kRounds; r++) bl[r] = a.blob[(rbase + min((uint32_t)r, rlast)) * 64u + tid];
     const int action = a.actions[ic];
     const uint4 st = a.state[ic];
-    Pcg64 g;
+    Pcg64 g, sp;
     if (!PHILOX) g.load(a.env_s, a.env_inc, ic);
+    if (NZ && !PHILOX && a.has_p_noise) sp.load(a.sp_s, a.sp_inc, ic);
     const uint64_t tick = (PHILOX || !UR) ? a.ptick + (a.dtick ? *a.dtick : 0ULL) : 0ULL;
+    const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)ic);
     // (the key that leaves the delay line this step: loaded now, beside everything else)
     uint32_t *kslot = nullptr;
     uint32_t kout = kNoKey;
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
         kout = *kslot;
     }
 #pragma unroll
-    for (int r = 0; r < 8; r++)
+    for (int r = 0; r < kRounds; r++)
         if ((uint32_t)r < a.blob_rounds) ((uint4 *)ldsw)[r * 64 + tid] = bl[r];
     __builtin_amdgcn_wave_barrier();
     const uint32_t A = a.A, S = a.S, L = a.L;
@@ -217,7 +225,25 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
     }
     uint32_t hist = st.x, hist_hi = (st.y << 8) | (st.x >> 24), steps = st.z, ring = st.w;
     const uint32_t cur = hist & 0xFFu;
-    const uint32_t nxt = ldsw[cur * A + ua];                                                   // D1
+    uint32_t nxt = ldsw[cur * A + ua];                                                         // D1
+    if constexpr (NZ) {
+        if (a.has_p_noise) {                                                                   // D2 (:1604-1622)
+            if constexpr (PHILOX) {
+                uint32_t o[4];
+                philox_start_block(a.philox_seed, genv, tick >> 2, kPhiloxPNoiseStream, o);
+                nxt = philox_pnoise_state(philox_word_of(o, tick), a.pn_T, a.pn_M, nxt);
+            } else {
+                const uint64_t m = sp.next64() >> 11;
+                const uint64_t *row = (const uint64_t *)(ldsw + a.off_tn) + nxt * a.S8;
+                uint32_t c = 0;
+                for (uint32_t b = 0; b < a.S8; b += 8) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) c += (row[b + j] <= m) ? 1u : 0u;
+                }
+                nxt = c;
+            }
+        }
+    }
     uint32_t key = 0;
 #pragma unroll
     for (int j = 2; j >= 0; j--) {
@@ -251,6 +277,29 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
         }
         bit = phase == 0 ? bit : 0u;
         rout = done ? (bit ? a.rsel[3] : a.rsel[1]) : (bit ? a.rsel[2] : a.rsel[0]);
+        if constexpr (NZ) {
+            if (a.has_r_noise) {                                                                // :1980-1990, :2107 in float64
+                double z;
+                if constexpr (PHILOX) {
+                    uint32_t o[4];
+                    philox_start_block(a.philox_seed, genv, tick >> 2, kPhiloxRNoiseStream, o);
+                    float z4[4];
+                    philox_box_muller2(o, z4[0], z4[1], z4[2], z4[3]);
+                    const uint32_t q = (uint32_t)tick & 3u;
+                    z = (double)(q == 0u ? z4[0] : q == 1u ? z4[1] : q == 2u ? z4[2] : z4[3]);
+                } else {
+                    const ZigLds zig{(const uint64_t *)(ldsw + a.off_zig), (const double *)(ldsw + a.off_zig + 2048),
+                                     (const double *)(ldsw + a.off_zig + 4096)};
+                    z = np_standard_normal_lds(g, zig);
+                }
+                double r = bit ? 1.0 : 0.0;
+                r += 0.0 + a.r_noise * z;
+                r *= a.scale;
+                r += a.shift;
+                if (done) r += a.term_add;
+                rout = (float)r;
+            }
+        }
     } else {                                                                                    // :1821-1845, :1968-1990, :2107
         uint32_t k = full ? key : kNoKey;
         if (a.delay) {
@@ -306,7 +355,8 @@ __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
         a.term[i] = (uint8_t)done;
         a.trunc[i] = (uint8_t)tr;
         a.state[i] = make_uint4(hist, hist_hi, steps, ring);
-        if (drew) g.store(a.env_s, i);
+        if (drew || (NZ && !PHILOX && a.has_r_noise)) g.store(a.env_s, i);
+        if (NZ && !PHILOX && a.has_p_noise) sp.store(a.sp_s, i);
         if (status) atomicOr(&a.status[i], status);
     }
 }
@@ -317,6 +367,9 @@ bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const 
     if (proto.wide) {                               // state spaces beyond 16 states: k_discrete_step1w
         if (d.philox && (d.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
         if (name_out) {
+            if (proto.has_p_noise || proto.has_r_noise)
+                snprintf(name_out, kNameLen, "k_discrete_step1w<OBS64=%d,PHILOX=%d,UNIT=1,PN=%d,RN=%d>", !d.obs_i32, d.philox, proto.has_p_noise, proto.has_r_noise);
+            else
             snprintf(name_out, kNameLen, "k_discrete_step1w<OBS64=%d,PHILOX=%d,UNIT=%d>", !d.obs_i32, d.philox, proto.unit);
             return true;
         }
@@ -327,7 +380,8 @@ bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const 
         const size_t lds = (size_t)a.blob_rounds * 1024;
 #define MDPP_S1W(O64, PH)                                                                                           \
     do {                                                                                                            \
-        if (a.unit) hipLaunchKernelGGL((k_discrete_step1w<O64, PH, true>), dim3(grid), dim3(64), lds, s, a);       \
+        if (a.has_p_noise || a.has_r_noise) hipLaunchKernelGGL((k_discrete_step1w<O64, PH, true, true>), dim3(grid), dim3(64), lds, s, a); \
+        else if (a.unit) hipLaunchKernelGGL((k_discrete_step1w<O64, PH, true>), dim3(grid), dim3(64), lds, s, a);   \
         else hipLaunchKernelGGL((k_discrete_step1w<O64, PH, false>), dim3(grid), dim3(64), lds, s, a);             \
     } while (0)
         if (d.philox) { if (d.obs_i32) MDPP_S1W(false, true); else MDPP_S1W(true, true); }

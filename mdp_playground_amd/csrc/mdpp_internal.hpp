@@ -143,6 +143,13 @@ struct Step1Args {
     uint32_t unit, ring_head;   // ring_head: env steps taken so far mod delay (a graph replay: from ptick + *dtick)
     uint32_t *ring_keys;        // [delay][N]
     double scale, shift, term_add;
+    // ... with transition and / or reward noise (k_discrete_step1w<..., NZ = true>): thresholds of the S noise categoricals
+    // [S][S8] (numpy streams) at off_tn, numpy's ziggurat tables ki / wi / fi (3 x 2 KiB) at off_zig; the state space's stream
+    uint32_t has_p_noise, has_r_noise, off_tn, off_zig, pn_T;
+    uint64_t pn_M;
+    double r_noise;
+    ulonglong2 *sp_s;
+    const ulonglong2 *sp_inc;
     const int32_t *actions;
     void *obs;
     float *reward;

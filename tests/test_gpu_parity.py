@@ -2450,6 +2450,15 @@ STEP1_CASES = {
                                  "k_discrete_step1w<OBS64=1,PHILOX=1,UNIT=0>"),
     "d_s24_rdist_delay_disabled": (dict(__import__("bench").WORKLOADS["d_s24_rdist"]["config"], seed=3, delay=2, reward_every_n_steps=3),
                                    dict(autoreset="disabled"), 1000, "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=0>"),
+    # ... with transition / reward noise (the reference's p_noise / r_noise sweeps): numpy streams and Philox streams
+    "d_cfg2_noise_numpy": (dict(__import__("bench").WORKLOADS["cfg2_noise"]["config"], seed=3), dict(autoreset="same_step"), 4096,
+                           "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=1,PN=1,RN=1>"),
+    "d_cfg2_noise_philox_ragged": (dict(__import__("bench").WORKLOADS["cfg2_noise"]["config"], seed=3), dict(autoreset="same_step", rng="philox", max_episode_steps=9),
+                                   1000, "k_discrete_step1w<OBS64=1,PHILOX=1,UNIT=1,PN=1,RN=1>"),
+    "d_s16_pnoise_only": (dict(FAST_VARIANTS["s16_l1_trunc"][0], transition_noise=0.3), dict(autoreset="same_step", max_episode_steps=5), 1000,
+                          "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=1,PN=1,RN=0>"),
+    "d_rnoise_only_disabled": (dict(__import__("bench").WORKLOADS["cfg2_noise"]["config"], seed=3, transition_noise=None, reward_scale=2.5, reward_shift=-1.0,
+                                    term_state_reward=-0.5), dict(autoreset="disabled"), 1000, "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=1,PN=0,RN=1>"),
     "d_s120": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=120, action_space_size=60, delay=1,
                     sequence_length=1, terminal_state_density=0.5, seed=3), dict(autoreset="same_step"), 1024, "k_discrete_step1w<"),
     "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),

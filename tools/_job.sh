@@ -1,4 +1,12 @@
 cd $GRAFT_REPO_ROOT
-python3 tools/ablate_step1.py run mdpp_continuous_step1.hip cfg3 numpy wide narrow wide 2>&1 | cut -c1-200
-python3 tools/ablate_step1.py run mdpp_continuous_step1.hip cfg5 philox wide narrow 2>&1 | cut -c1-200
-python3 tools/ablate_step1.py run mdpp_continuous_step1.hip cfg5 numpy wide narrow 2>&1 | cut -c1-200
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "step1" 2>&1 | tail -4
+python3 - <<'PY'
+import sys, json; sys.path.insert(0, "."); sys.path.insert(0, "tools")
+import torch, bench
+import bench_step1 as b1
+wl = bench.WORKLOADS["cfg2_noise"]
+b1.timing("cfg2_noise", wl, wl["envs"], "numpy", ("NO_STEP1",), "general kernel")
+b1.timing("cfg2_noise", wl, wl["envs"], "numpy", (), "default")
+b1.timing("cfg2_noise", wl, wl["envs"], "philox", ("NO_STEP1",), "general kernel")
+b1.timing("cfg2_noise", wl, wl["envs"], "philox", (), "default")
+PY
