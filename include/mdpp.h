@@ -276,12 +276,13 @@ int mdpp_set_line_history(mdpp_env *h, const float *hist_host);
  * launch replays with the counter it was captured with.
  * mdpp_graph_replay_exact: 1 when a graph of K captured mdpp_step launches replays exactly for this handle
  * (numpy streams, and either no delay line in memory or K a multiple of the delay), 2 when it does through the
- * device-side offset below, 0 when it does not (image observations with such a counter dependence), < 0 on error.
+ * device-side offset below, < 0 on error (0, "does not": image observations keyed by the counter until round 4; no handle now).
  * mdpp_tick: adds `advance` (may be negative) to the step counter and returns the new value in *tick_out (may be
  * NULL): the capture advances the counter although nothing ran (take it back with -K), a replay runs K steps the
  * counter has not seen (add K). */
 int mdpp_graph_replay_exact(mdpp_env *h, int K);
-/* ABI 7 -- graphs that replay exactly for EVERY handle without image observations (Philox streams, any delay line):
+/* ABI 7 -- graphs that replay exactly for EVERY handle (Philox streams, any delay line; round 5: image observations too -- the
+ * kernels that draw a step's image transforms read the same device word):
  * mdpp_graph_replay_exact returns 2 where a by-value capture would not be exact but this protocol is:
  *   mdpp_graph_capture(h, 1);  capture the K mdpp_step launches;  mdpp_graph_capture(h, 0);  mdpp_tick(h, -K, NULL);
  *   per replay:  mdpp_graph_set_tick_offset(h, counter_now - counter_at_capture, stream);  launch the graph on `stream`;

@@ -527,8 +527,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
                 const double t = j < S ? ceil(ldexp(init_cdf[j], 31)) : 4294967295.0;
                 blob[192 + j] = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
             }
-            // (kS1Replicas copies, one per group of workgroups: 1 024 waves reading the SAME lines at the same moment queue up
-            //  at the few L2 channels that hold them)
+            // (kS1Replicas copies, one per group of workgroups: see mdpp_internal.hpp -- one copy by default)
             if (h->d_s1_blob) { (void)hipFree(h->d_s1_blob); h->d_s1_blob = nullptr; }
             HIPCHK(h, hipMalloc(&h->d_s1_blob, (size_t)kS1Replicas * 1024));
             for (int r = 0; r < kS1Replicas; r++)
@@ -828,8 +827,8 @@ extern "C" int mdpp_graph_replay_exact(mdpp_env *h, int K) {
     // by value: numpy streams (a Philox key would repeat), and no ring head that moves between replays
     if (h->cfg.rng_mode != MDPP_RNG_PHILOX && !(ring_in_memory && K % d != 0)) return 1;
     // otherwise: through the device-side offset (mdpp_graph_capture / mdpp_graph_set_tick_offset) -- every step and rollout
-    // kernel reads it; the image pipelines (their draw kernels take the counter by value, side streams) do not
-    return h->cfg.image ? 0 : 2;
+    // kernel reads it, and (round 5) the kernels that draw the image transforms of a step do too
+    return 2;
 }
 
 namespace mdpp {
@@ -840,7 +839,6 @@ __global__ void k_set_tick_offset(uint64_t *p, uint64_t v) { *p = v; }
 // the step counter they were given by value (mdpp_internal.hpp tick_from_device).
 extern "C" int mdpp_graph_capture(mdpp_env *h, int on) {
     if (!h) return MDPP_EINVAL;
-    if (on && h->cfg.image) return fail(h, MDPP_EUNSUPPORTED, "mdpp_graph_capture: handles with image observations take the step counter by value");
     h->graph_capture = on != 0;
     return MDPP_OK;
 }
@@ -1023,6 +1021,21 @@ static int step_common(mdpp_env *h, int K, const void *actions, void *obs, float
                 *so = (int32_t *)h->d_img_state_out + buf * sset;
                 *sf = (int32_t *)h->d_img_state_final + buf * sset;
             };
+            if (K == 1) {
+                // one step: the state kernel, then ONE kernel that draws, builds the record and renders (k_image_step1)
+                int32_t *so, *sf;
+                scratch(0, &so, &sf);
+                int r = launch_discrete_step(h, 1, (const int32_t *)actions, so, reward, term, trunc, sf, s);
+                if (r) return r;
+                r = launch_image_step1(h, so, sf, term, trunc, (uint8_t *)obs, (uint8_t *)final_obs, s);
+                if (r != 0) return r < 0 ? r : MDPP_OK;
+                {
+                    r = launch_image_obs(h, 1, so, sf, term, trunc, nullptr, nullptr, nullptr, s, 1, 0);
+                    if (r) return r;
+                    r = launch_image_obs(h, 1, so, sf, term, trunc, nullptr, (uint8_t *)obs, (uint8_t *)final_obs, s, 6, 0);
+                }
+                return r;
+            }
             return image_batches(
                 h, K, s,
                 [&](int k0, int kc, int buf, hipStream_t st) {
@@ -1104,7 +1117,7 @@ extern "C" const char *mdpp_kernel_name(mdpp_env *h, int K) {
     h->kname[0] = 0;
     if (K < 1 || check_ready(h, "mdpp_kernel_name")) return h->kname;
     if (h->cfg.image) {      // the renderer is the dominant kernel of an image rollout
-        snprintf(h->kname, sizeof h->kname, "%s", h->cfg.kind == MDPP_KIND_DISCRETE ? image_obs_kernel_name(h)
+        snprintf(h->kname, sizeof h->kname, "%s", h->cfg.kind == MDPP_KIND_DISCRETE ? image_obs_kernel_name(h, K)
                  : h->cfg.kind == MDPP_KIND_GRID ? "k_imagec_obs<GRID=1>" : "k_imagec_obs<GRID=0>");
         return h->kname;
     }

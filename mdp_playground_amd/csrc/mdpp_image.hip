@@ -75,6 +75,7 @@ struct ImageArgs {
                                // 128 B apart (zeroed by k_image_draw)
     int32_t philox, is_reset;
     uint64_t philox_seed, ptick;
+    const uint64_t *dtick;     // launches captured into a HIP graph: device word added to ptick at run time (tick_now)
     int64_t env_id_offset;
     ImgRec *rec0, *rec1;       // [M]: the image that goes to img_out / the terminal observation of a
                                // step that ends in a reset (img_final)
@@ -124,41 +125,53 @@ __device__ __forceinline__ Xform draw_xform(const ImageArgs &a, const ShiftBound
     return x;
 }
 
-__device__ __forceinline__ void make_rec(const ImageArgs &a, const Xform &t, int state, bool two, ImgRec *out) {
-    ImgRec r;
+// Records are read through the constant address space: a wave-uniform address there is always a
+// scalar load (lgkmcnt), so fetching the next image's record never waits for this image's stores.
+struct RecRegs { u32x8 lo; u32x4 hi; };
+
+// The twelve words of an image's record (ImgRec's layout).
+__device__ __forceinline__ RecRegs rec_words(const ImageArgs &a, const Xform &t, int state, bool two) {
+    // (all three table reads at once, unconditionally -- the class tables exist for every handle: a load behind a branch waits
+    //  for the loads before it, four round trips in a row where one does)
+    const size_t sr = (size_t)state * a.n_radii + (t.R - a.r_min);
+    const int clx = a.cls_x[sr * a.W + t.cx], cly = a.cls_y[sr * a.H + t.cy];
     int a0 = a.rot[t.angle * 6 + 0], a1 = a.rot[t.angle * 6 + 1], a2 = a.rot[t.angle * 6 + 2];
     int a3 = a.rot[t.angle * 6 + 3], a4 = a.rot[t.angle * 6 + 4], a5 = a.rot[t.angle * 6 + 5];
+    const int cx_cls = a.n_cls_x > 1 ? clx : 0, cy_cls = a.n_cls_y > 1 ? cly : 0;
+    const uint32_t tix = (uint32_t)((sr * a.n_cls_x + cx_cls) * a.n_cls_y + cy_cls);
     // source = A * (fx, fy) + b with (fx, fy) = flip(x, y) folded in
     if (t.flip == 1) { a2 += a0 * (a.W - 1); a5 += a3 * (a.W - 1); a0 = -a0; a3 = -a3; }
     if (t.flip == 2) { a2 += a1 * (a.H - 1); a5 += a4 * (a.H - 1); a1 = -a1; a4 = -a4; }
-    r.a[0] = a0; r.a[1] = a1; r.a[2] = a2; r.a[3] = a3; r.a[4] = a4; r.a[5] = a5;
-    r.cxy = (uint32_t)t.cx | ((uint32_t)t.cy << 16);
-    const size_t sr = (size_t)state * a.n_radii + (t.R - a.r_min);
-    const int cx_cls = a.n_cls_x > 1 ? a.cls_x[sr * a.W + t.cx] : 0;
-    const int cy_cls = a.n_cls_y > 1 ? a.cls_y[sr * a.H + t.cy] : 0;
-    const uint32_t tix = (uint32_t)((sr * a.n_cls_x + cx_cls) * a.n_cls_y + cy_cls);
-    r.meta = (uint32_t)t.R | (two ? 1u << 10 : 0u) | (tix << 12);
+    const uint32_t cxy = (uint32_t)t.cx | ((uint32_t)t.cy << 16);
+    const uint32_t meta = (uint32_t)t.R | (two ? 1u << 10 : 0u) | (tix << 12);
     // centre of the polygon in final-image coordinates: invert the 2x2 part (a rotation, so the
     // inverse is the transpose up to the 16.16 scale); the renderers allow a pixel of slack
     const float fa0 = a0 * (1.0f / 65536.0f), fa1 = a1 * (1.0f / 65536.0f);
     const float fa3 = a3 * (1.0f / 65536.0f), fa4 = a4 * (1.0f / 65536.0f);
     const float sx = (float)t.cx + 0.5f - a2 * (1.0f / 65536.0f), sy = (float)t.cy + 0.5f - a5 * (1.0f / 65536.0f);
     const float det = fa0 * fa4 - fa1 * fa3;
-    r.fcx = (fa4 * sx - fa1 * sy) / det; r.fcy = (fa0 * sy - fa3 * sx) / det;
+    const float fcx = (fa4 * sx - fa1 * sy) / det, fcy = (fa0 * sy - fa3 * sx) / det;
     // bounding box of the "near" circle (radius R + 4.5 around the centre: every dword with a
     // pixel within R + 3) in (column, dword-row) units, a pixel of slack
     const float rr = (float)t.R + 4.5f;
     const int HQ = a.H >> 2;
-    const int X0 = max(0, (int)floorf(r.fcx - rr) - 1), X1 = min(a.W, (int)floorf(r.fcx + rr) + 2);
-    const int Q0 = max(0, (int)floorf((r.fcy - rr - 1.5f) * 0.25f) - 1);
-    const int Q1 = min(HQ, (int)floorf((r.fcy + rr - 1.5f) * 0.25f) + 2);
-    r.xr = (uint32_t)X0 | ((uint32_t)max(X1, X0) << 16);
-    r.qr = (uint32_t)Q0 | ((uint32_t)max(Q1, Q0) << 16);
-    r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0;
+    const int X0 = max(0, (int)floorf(fcx - rr) - 1), X1 = min(a.W, (int)floorf(fcx + rr) + 2);
+    const int Q0 = max(0, (int)floorf((fcy - rr - 1.5f) * 0.25f) - 1);
+    const int Q1 = min(HQ, (int)floorf((fcy + rr - 1.5f) * 0.25f) + 2);
+    const uint32_t xr = (uint32_t)X0 | ((uint32_t)max(X1, X0) << 16);
+    const uint32_t qr = (uint32_t)Q0 | ((uint32_t)max(Q1, Q0) << 16);
+    RecRegs r;
+    r.lo = u32x8{(uint32_t)a0, (uint32_t)a1, (uint32_t)a2, (uint32_t)a3, (uint32_t)a4, (uint32_t)a5, cxy, meta};
+    r.hi = u32x4{__float_as_uint(fcx), __float_as_uint(fcy), xr, qr};
+    return r;
+}
+
+__device__ __forceinline__ void make_rec(const ImageArgs &a, const Xform &t, int state, bool two, ImgRec *out) {
+    const RecRegs r = rec_words(a, t, state, two);
     u32x4 *o = (u32x4 *)out;
-    o[0] = u32x4{(uint32_t)r.a[0], (uint32_t)r.a[1], (uint32_t)r.a[2], (uint32_t)r.a[3]};
-    o[1] = u32x4{(uint32_t)r.a[4], (uint32_t)r.a[5], r.cxy, r.meta};
-    o[2] = u32x4{__float_as_uint(r.fcx), __float_as_uint(r.fcy), r.xr, r.qr};
+    o[0] = u32x4{r.lo[0], r.lo[1], r.lo[2], r.lo[3]};
+    o[1] = u32x4{r.lo[4], r.lo[5], r.lo[6], r.lo[7]};
+    o[2] = r.hi;
 }
 
 __device__ __forceinline__ uint2 xf_pack(const Xform &x) {
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void k_image_draw(ImageArgs a, int K, const
         const long j0 = ((long)k * a.N + i) * SUB;
         const bool two = (twos >> k) & 1ull;
         if constexpr (PHILOX) {                  // this tick's stream; its buffered 32-bit half starts empty
-            g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), a.ptick + (uint64_t)k,
+            g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick_now(a) + (uint64_t)k,
                    a.is_reset ? kPhiloxResetImageStream : (uint32_t)MDPP_STREAM_IMAGE);
             h = Half32{0u, 0u};
         }
@@ -270,9 +283,6 @@ __global__ __launch_bounds__(kBlock) void k_image_rec(ImageArgs a, long M, const
     }
 }
 
-// Records are read through the constant address space: a wave-uniform address there is always a
-// scalar load (lgkmcnt), so fetching the next image's record never waits for this image's stores.
-struct RecRegs { u32x8 lo; u32x4 hi; };
 __device__ __forceinline__ RecRegs load_rec(const ImgRec *p) {
     typedef const __attribute__((address_space(4))) u32x8 *cptr8;
     typedef const __attribute__((address_space(4))) u32x4 *cptr4;
@@ -698,15 +708,9 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
 #endif
 }
 
-// K steps x N envs, arrays time-major; mask (reset only, K = 1) selects envs.  img_out == nullptr:
-// draw only (the reference's reset()/step() consume the variates whether or not anyone looks).
-int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
-                     const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
-                     uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase, int buf) {
+// The launch arguments every image kernel of a batch of K steps shares (buf: the scratch set of a pipelined rollout).
+static ImageArgs image_args(mdpp_env *h, int K, bool is_reset, int buf) {
     const mdpp_config &c = h->cfg;
-    if (K < 1 || K > h->img_chunk || K > kImgChunk || (mask && K != 1)) {
-        h->err = "launch_image_obs: K outside the record scratch"; return MDPP_EINVAL;
-    }
     ImageArgs a;
     a.N = c.num_envs; a.W = c.img_w; a.H = c.img_h;
     a.S = (c.irrelevant && c.S_irr > c.S) ? c.S_irr : c.S;
@@ -727,11 +731,136 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     a.near_tab = (h->opts & MDPP_OPT_NO_IMG_NEARTAB) ? nullptr : (const uint32_t *)h->d_img_near;
     a.philox = c.rng_mode == MDPP_RNG_PHILOX; a.philox_seed = c.philox_seed; a.env_id_offset = c.env_id_offset;
     // (the state kernel / reset kernel of this batch ran just before and has advanced the handle's counters)
-    a.is_reset = term == nullptr;
+    a.is_reset = is_reset;
     a.ptick = a.is_reset ? h->reset_tick - 1 : h->tick - (uint64_t)K;
+    a.dtick = (h->graph_capture && !a.is_reset) ? (const uint64_t *)h->d_tick_off : nullptr;   // (launches being captured into a HIP graph)
     a.rec0 = (ImgRec *)h->d_img_rec + (size_t)buf * 2 * h->img_chunk * c.num_envs * a.SUB;
     a.rec1 = a.rec0 + (size_t)h->img_chunk * c.num_envs * a.SUB;
     a.work_ctr = (uint32_t *)h->d_img_ctr + (size_t)buf * 2 * kImgCtrs * 32;
+    a.coldw = 0;
+    return a;
+}
+
+// LDS of a fast-renderer workgroup: the template rows + four column buffers wide enough for the widest box (rec_words: at most
+// 2 R + 13 columns) plus chunk-alignment slack
+static size_t image_fast_lds(const mdpp_env *h, ImageArgs &a) {
+    const int span_dw = (2 * h->cfg.img_r_max + 13) * (h->cfg.img_h / 4) + 8;
+    a.coldw = ((span_dw + 3) & ~3) + 4;                  // (+ the zero chunk of render_fast_store)
+    if (a.coldw > kImgColDw) a.coldw = kImgColDw;
+    return (size_t)a.tplp * 256 + (size_t)(kBlock / 64) * a.coldw * 4;
+}
+
+// ---- one step of every env: draw + record + render in ONE kernel (round 5) ----------------------
+// mdpp_step() on an image handle was four launches -- the state kernel, k_image_draw<REC> (one lane per env), the renderer
+// over rec0 and again over rec1 (where all but the reset envs' records say "skip") -- 40 us for 8 192 envs of BASELINE cfg4,
+// whose 57.8 MB of pictures take 11 us to store.  Here ONE WAVE per env does the serial part itself, every lane the same
+// arithmetic on the same values (the generator's state through wave-uniform loads; 64 lanes of one wave cost what one lane
+// does): the transform draws in the reference's order -- the step's observation, then reset()'s where the step ended the
+// episode --, the record (in registers, moved to scalar registers), and the picture(s) with the fast renderer's evaluation and
+// store halves.  Lane 0 writes the generator back.  One picture per env (no irrelevant sub-space: its two pictures per env
+// would be two waves that both own the generator); other handles keep the four launches.
+template <int NST, bool PHILOX>
+__global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32_t *__restrict__ state_out,
+                                                        const int32_t *__restrict__ state_final,
+                                                        const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc,
+                                                        uint8_t *__restrict__ img_out, uint8_t *__restrict__ img_final) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;
+    if (MDPP_IMG_LEAN_LOOP && lane < 4) lds_col[a.coldw - 4 + lane] = 0u;      // the wave's zero chunk (render_fast_store)
+    const long i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
+    if (i >= a.N) return;
+    // Everything the wave needs from memory before it can draw, in ONE batch of scalar loads: the generator, the state, and the
+    // step's two flag bytes as the dwords they sit in (there is no scalar byte load, and a vector load -- or a load behind a
+    // branch -- would be waited for before the next one is issued: a round trip each at the head of every wave).
+    typedef const __attribute__((address_space(4))) uint32_t *cptr32;
+    typename std::conditional<PHILOX, Philox, Pcg64>::type g;
+    Half32 h{0u, 0u};
+    if constexpr (PHILOX) {
+        g.init(a.philox_seed, (uint64_t)(a.env_id_offset + i), tick_now(a), (uint32_t)MDPP_STREAM_IMAGE);
+    } else {
+        g.load(a.rng_s, a.rng_inc, i);
+        const uint2 hh = a.rng_half[i];
+        h = Half32{hh.x, hh.y};
+    }
+    const int s_out = state_out[i];
+    const uintptr_t pt = (uintptr_t)term + (uintptr_t)i, pu = (uintptr_t)trunc + (uintptr_t)i;
+    const uint32_t wt = *(cptr32)(pt & ~(uintptr_t)3), wu = *(cptr32)(pu & ~(uintptr_t)3);
+    const uint32_t flags = ((wt >> (8 * (int)(pt & 3))) | (wu >> (8 * (int)(pu & 3)))) & 0xFFu;
+    const bool two = (a.autoreset != 0) & (flags != 0);
+    const int s_fin = state_final[i];               // (read only where two: scratch the state kernel fills for every env)
+    const ShiftBounds sb = shift_bounds(a, a.r0);
+#ifdef MDPP_S1I_ABL_NODRAW                       // (timing only, tools/ablate_step1.py: a made-up transform, no generator)
+    Xform x0{a.r0, a.W / 2 + (int)(i % 7) - 3, a.H / 2 + (int)(i % 5) - 2, (int)(i % 360), 0};
+    Xform x1 = x0;
+    (void)sb;
+#else
+    const Xform x0 = draw_xform(a, sb, g, h);
+    Xform x1 = x0;
+    if (two) x1 = draw_xform(a, sb, g, h);
+#endif
+    if constexpr (!PHILOX) {
+        if (lane == 0) {
+            g.store(a.rng_s, i);
+            a.rng_half[i] = make_uint2(h.has32, h.u32);
+        }
+    }
+    const size_t isz = (size_t)a.W * a.H;
+    auto picture = [&](const Xform &x, int state, bool second, uint8_t *out) __attribute__((always_inline)) {
+        RecRegs r = rec_words(a, x, state, second);
+#pragma unroll
+        for (int k = 0; k < 8; k++) r.lo[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.lo[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.hi[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.hi[k]);
+        const TplRegs tp = load_tpl(a, r.lo[7] >> 12, lane);
+        const u32x4 near = load_near(a, r, lane);
+        stage_tpl(a, tp, lds, wave, lane);
+        const ColRange cr = render_fast_eval(a, r, lds, lds_col, wave, lane, near);
+        render_fast_store<NST>(a, cr, lds_col, out, lane);
+    };
+#ifdef MDPP_S1I_ABL_NOPIC                        // (timing only: the serial head of the wave alone)
+    if (x0.cx == 12345 && lane == 1) img_out[i] = (uint8_t)(x1.cy + s_out + s_fin);
+    return;
+#endif
+    if (two && img_final) picture(x0, s_fin, false, img_final + (size_t)i * isz);
+    picture(two ? x1 : x0, s_out, two, img_out + (size_t)i * isz);
+}
+
+// The fused step above, if this handle can use it (the caller then skips launch_image_obs): 0 = not taken, 1 = launched,
+// < 0 = error.  state_out / state_final / term / trunc: what the state kernel of this step has just written (on s).
+int launch_image_step1(mdpp_env *h, const int32_t *state_out, const int32_t *state_final, const uint8_t *term,
+                       const uint8_t *trunc, uint8_t *img_out, uint8_t *img_final, hipStream_t s) {
+    const mdpp_config &c = h->cfg;
+    if (!h->img_fast_ok || (h->opts & (MDPP_OPT_NO_IMGFAST | MDPP_OPT_NO_STEP1)) || c.irrelevant || !img_out) return 0;
+    ImageArgs a = image_args(h, 1, false, 0);
+    const size_t lds_bytes = image_fast_lds(h, a);
+    const dim3 grid((unsigned)((a.N + kBlock / 64 - 1) / (kBlock / 64)));
+    const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);
+#define MDPP_IMG_S1(NST_)                                                                                                     \
+    do {                                                                                                                      \
+        if (a.philox) hipLaunchKernelGGL((k_image_step1<NST_, true>), grid, dim3(kBlock), lds_bytes, s, a, state_out, state_final, \
+                                         term, trunc, img_out, img_final);                                                    \
+        else hipLaunchKernelGGL((k_image_step1<NST_, false>), grid, dim3(kBlock), lds_bytes, s, a, state_out, state_final,   \
+                                term, trunc, img_out, img_final);                                                             \
+    } while (0)
+    if (nst == 7) MDPP_IMG_S1(7);          // 84 x 84
+    else if (nst == 4) MDPP_IMG_S1(4);     // 64 x 64
+    else MDPP_IMG_S1(0);
+#undef MDPP_IMG_S1
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("k_image_step1 launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    return 1;
+}
+
+// K steps x N envs, arrays time-major; mask (reset only, K = 1) selects envs.  img_out == nullptr:
+// draw only (the reference's reset()/step() consume the variates whether or not anyone looks).
+int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
+                     const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
+                     uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase, int buf) {
+    if (K < 1 || K > h->img_chunk || K > kImgChunk || (mask && K != 1)) {
+        h->err = "launch_image_obs: K outside the record scratch"; return MDPP_EINVAL;
+    }
+    ImageArgs a = image_args(h, K, term == nullptr, buf);
     static_assert(kBlock == 256, "render_fast packs four 64-byte template columns into a 256-byte LDS row");
     if (!(phase & 1)) {
         // records of this batch were made earlier (side stream)
@@ -754,12 +883,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         const long M = (long)K * a.N * a.SUB;
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
         if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST)) {
-            // LDS per workgroup: the template rows + four column buffers wide enough for the widest box (make_rec: at most
-            // 2 R + 13 columns) plus chunk-alignment slack; as many resident workgroups per CU as 160 KiB hold (at most 8)
-            const int span_dw = (2 * c.img_r_max + 13) * (c.img_h / 4) + 8;
-            a.coldw = ((span_dw + 3) & ~3) + 4;                  // (+ the zero chunk of render_fast_store)
-            if (a.coldw > kImgColDw) a.coldw = kImgColDw;
-            const size_t lds_bytes = (size_t)a.tplp * 256 + (size_t)(kBlock / 64) * a.coldw * 4;
+            const size_t lds_bytes = image_fast_lds(h, a);
             unsigned per_cu = (unsigned)((160u * 1024u) / ((lds_bytes + 511) & ~(size_t)511));
             per_cu = per_cu < 1u ? 1u : (per_cu > 8u ? 8u : per_cu);
 #ifdef MDPP_IMG_WG_PER_CU
@@ -807,9 +931,11 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
     return MDPP_OK;
 }
 
-const char *image_obs_kernel_name(const mdpp_env *h) {
+const char *image_obs_kernel_name(const mdpp_env *h, int K) {
     if (!(h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST))) return "k_image_obs";
     const int nst = (int)(((size_t)h->cfg.img_w * h->cfg.img_h / 16 + 63) / 64);
+    if (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1) && !h->cfg.irrelevant)     // (launch_image_step1's conditions)
+        return nst == 7 ? "k_image_step1<NST=7>" : nst == 4 ? "k_image_step1<NST=4>" : "k_image_step1<NST=0>";
     return nst == 7 ? "k_image_obs_fast<NST=7>" : nst == 4 ? "k_image_obs_fast<NST=4>" : "k_image_obs_fast<NST=0>";
 }
 

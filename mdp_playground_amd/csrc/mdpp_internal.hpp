@@ -121,9 +121,12 @@ struct DiscreteArgs {
 // ---- discrete, one launch = one step (mdpp_discrete_step1.hip): everything the kernel reads, nothing else -- built once at
 // mdpp_upload_discrete_tables (the caller's buffers are filled in per launch)
 #ifndef MDPP_S1_REPLICAS
-#define MDPP_S1_REPLICAS 16
+#define MDPP_S1_REPLICAS 1
 #endif
-constexpr int kS1Replicas = MDPP_S1_REPLICAS;   // copies of the one-step kernels' table blob (power of two), one per group of workgroups
+// copies of the one-step kernels' table blob (power of two), one per group of workgroups.  1: sixteen copies measured the
+// same (S = 50: 4.07 against 4.04 us per step) -- 1 024 waves reading the same 4 KiB is not what made that launch slow, the
+// compiler serialising the blob's loads was (mdpp_discrete_step1.hip)
+constexpr int kS1Replicas = MDPP_S1_REPLICAS;
 struct Step1Args {
     int32_t N;
     uint32_t A, S, L, every_n, max_steps, delay, autoreset;
@@ -342,5 +345,9 @@ int launch_grid_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s
 int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t *state_final,
                      const uint8_t *term, const uint8_t *trunc, const uint8_t *mask,
                      uint8_t *img_out, uint8_t *img_final, hipStream_t s, int phase = 3, int buf = 0);
-const char *image_obs_kernel_name(const mdpp_env *h);    // the renderer launch_image_obs() uses
+// One step's draw + record + render in one kernel (mdpp_image.hip k_image_step1): 1 = launched, 0 = this handle keeps
+// launch_image_obs, < 0 = error
+int launch_image_step1(mdpp_env *h, const int32_t *state_out, const int32_t *state_final, const uint8_t *term,
+                       const uint8_t *trunc, uint8_t *img_out, uint8_t *img_final, hipStream_t s);
+const char *image_obs_kernel_name(const mdpp_env *h, int K);    // the renderer launch_image_obs() uses
 } // namespace mdpp

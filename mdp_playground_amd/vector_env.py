@@ -476,16 +476,15 @@ class RLToyVectorEnv:
         exactly -- Philox streams key their draws by the counter, a delay line kept in memory starts at counter mod delay --
         the launches are captured in the library's capture mode instead: they add a device word to the counter, which
         replay() sets to (counter now - counter at capture) right before the graph (mdpp_graph_capture /
-        mdpp_graph_set_tick_offset, round 4).  Only image handles with such a dependence still raise MdppError."""
+        mdpp_graph_set_tick_offset, round 4; image handles too since round 5)."""
         K = int(actions.shape[0])
         ok = self._lib.mdpp_graph_replay_exact(self._h, K)
         if ok < 0:
             capi.check(self._lib, self._h, ok, "mdpp_graph_replay_exact")
         if ok == 0:
             raise capi.MdppError(
-                "step_graph: a captured graph of %d steps does not replay exactly for this handle (image observations: "
-                "rng='philox' keys its draws by the step counter; a delay line kept in memory needs K %% delay == 0, "
-                "delay = %d). Use rollout() (one fused launch) instead." % (K, self._cfg.delay))
+                "step_graph: a captured graph of %d steps does not replay exactly for this handle (delay = %d). "
+                "Use rollout() (one fused launch) instead." % (K, self._cfg.delay))
         by_offset = ok == 2
         a = self._as_actions(actions, K)
         obs, rew, term, trunc = self.alloc_rollout(K)

@@ -364,21 +364,21 @@ def test_step_graph_counts_its_steps_and_refuses_inexact_handles():
         g.replay()
     assert a._lib.mdpp_graph_replay_exact(a._h, d + 1) == 2   # K % delay != 0: exact through the device-side offset (below)
     a.close(); b.close()
-    # image observations whose draws are keyed by the counter: still refused
+    # image observations whose draws are keyed by the counter: refused until round 4, through the device-side offset now (below)
     icfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8, delay=0,
                 image_representations=True, image_width=84, image_height=84, image_transforms="shift,rotate", seed=0)
     p = _venv(num_envs=256, autoreset="same_step", rng="philox", **icfg)
-    assert p._lib.mdpp_graph_replay_exact(p._h, 4) == 0
-    with pytest.raises(capi.MdppError):
-        p.step_graph(torch.zeros((4, 256), dtype=torch.int32, device=p.device))
+    assert p._lib.mdpp_graph_replay_exact(p._h, 4) == 2
     p.close()
 
 
 @pytest.mark.parametrize("case", ["cfg2-philox", "cfg2noise-philox", "cfg3delay3-numpy", "cfg5-philox", "cfg5-numpy-delay2",
-                                  "custom-reward-delay", "grid-philox", "s50-philox", "s24rdist-delay2-philox"])
+                                  "custom-reward-delay", "grid-philox", "s50-philox", "s24rdist-delay2-philox",
+                                  "image-cfg4-philox", "image-cfg4-numpy", "image-irr84-philox", "image-continuous-philox",
+                                  "image-grid-philox"])
 def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
-    """step() is the API RL code calls; a replayed graph of K single steps is exact for EVERY handle without
-    image observations.  Launches captured in the library's capture mode add a device word to the step counter they were
+    """step() is the API RL code calls; a replayed graph of K single steps is exact for EVERY handle (round
+    5: image observations too -- k_image_step1 / k_image_draw key a step's transforms by counter + device word).  Launches captured in the library's capture mode add a device word to the step counter they were
     captured with (Philox keys, the head of a delay line in memory); replay() sets it to (counter now - counter at
     capture).  Replays interleaved with plain steps -- any number of them, so the ring head and the Philox ticks move --
     equal a twin stepped call by call, bit for bit."""
@@ -399,14 +399,34 @@ def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
         cfg, kw = dict(bench.WORKLOADS["d_s24_rdist"]["config"], delay=2), dict(rng="philox", philox_seed=9)
     elif case == "custom-reward-delay":          # float rewards: the discrete delay line lives in memory (keys awaiting payout)
         cfg, kw = dict(gu.CASES["d_rdist"]["config"], seed=2, delay=3), {}
+    elif case.startswith("image-cfg4"):          # polygon pictures: one kernel draws, records and renders (k_image_step1)
+        cfg = dict(bench.WORKLOADS["cfg4"]["config"])
+        kw = dict(rng="philox", philox_seed=10) if case.endswith("philox") else {}
+    elif case == "image-irr84-philox":           # ... two pictures per env: the four launches (k_image_draw<REC> keyed the same way)
+        cfg, kw = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 11], action_space_size=[8, 11],
+                       irrelevant_features=True, delay=0, image_representations=True, image_width=84, image_height=84,
+                       image_transforms="shift,rotate", seed=2), dict(rng="philox", philox_seed=11)
+    elif case == "image-continuous-philox":
+        cfg = dict(state_space_type="continuous", state_space_dim=4, relevant_indices=[0, 1], transition_dynamics_order=2, inertia=1.0,
+                   time_unit=1.0, state_space_max=4, action_space_max=1, make_denser=True, target_point=[1.5, -2.0], target_radius=0.7,
+                   terminal_states=[[-2.0, 2.0], [3.0, 0.0]], term_state_edge=1.5, transition_noise=0.1, reward_noise=0.05,
+                   reward_function="move_to_a_point", image_representations=True, image_width=64, image_height=80, seed=4)
+        kw = dict(rng="philox", philox_seed=12)
+    elif case == "image-grid-philox":
+        cfg = dict(state_space_type="grid", grid_shape=(6, 5), reward_function="move_to_a_point", make_denser=True, target_point=[2, 3],
+                   irrelevant_features=True, transition_noise=0.2, terminal_states=[[0, 0], [5, 4]], image_representations=True,
+                   image_width=48, image_height=64, seed=8)
+        kw = dict(rng="philox", philox_seed=13)
     else:
         cfg, kw = dict(bench.WORKLOADS["grid"]["config"], transition_noise=0.2, reward_noise=0.1), dict(rng="philox", philox_seed=6)
-    N, K = 1024, 5
+    N, K = (256 if case.startswith("image-") else 1024), 5
     a = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
     if case in ("custom-reward-delay", "s50-philox", "s24rdist-delay2-philox"):
         assert a.rollout_kernel_name(1).startswith("k_discrete_step1w<"), a.rollout_kernel_name(1)
-    assert a._lib.mdpp_graph_replay_exact(a._h, K) == 2, case
+    if case.startswith("image-cfg4"):
+        assert a.rollout_kernel_name(1) == "k_image_step1<NST=7>"
+    assert a._lib.mdpp_graph_replay_exact(a._h, K) == (1 if case == "image-cfg4-numpy" else 2), case
     rng = np.random.default_rng(7)
     g = a.step_graph(torch.as_tensor(_rand_actions(a, K, rng), device=a.device))
     for rep in range(4):

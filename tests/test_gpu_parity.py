@@ -2461,6 +2461,14 @@ STEP1_CASES = {
                                     term_state_reward=-0.5), dict(autoreset="disabled"), 1000, "k_discrete_step1w<OBS64=1,PHILOX=0,UNIT=1,PN=0,RN=1>"),
     "d_s120": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=120, action_space_size=60, delay=1,
                     sequence_length=1, terminal_state_density=0.5, seed=3), dict(autoreset="same_step"), 1024, "k_discrete_step1w<"),
+    # polygon pictures: draw + record + render in one kernel (k_image_step1) against the four launches
+    "i_cfg4": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="same_step"), 1000, "k_image_step1<NST=7>"),
+    "i_cfg4_philox_trunc": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="same_step", rng="philox", max_episode_steps=5), 1000, "k_image_step1<NST=7>"),
+    "i_cfg4_disabled": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="disabled"), 333, "k_image_step1<NST=7>"),
+    "i_cfg4_next_step": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="next_step", max_episode_steps=6), 333, "k_image_step1<NST=7>"),
+    "i_rot64": (dict(IMG_CFGS["rot64"], seed=3), dict(autoreset="same_step"), 1000, "k_image_step1<NST=4>"),
+    "i_scale_flip_96x80": (dict(IMG_CFGS["cfg4"], seed=3, image_width=96, image_height=80, image_transforms="shift,scale,rotate,flip",
+                                image_scale_range=(0.5, 1.0), image_sh_quant=2, image_ro_quant=15), dict(autoreset="same_step"), 500, "k_image_step1<NST=0>"),
     "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),
     "c_cfg3_ragged_next_step": (_S1_C_CFG3, dict(autoreset="next_step", max_episode_steps=7), 1000, "k_continuous_step1<"),
     "c_cfg3_disabled": (_S1_C_CFG3, dict(autoreset="disabled"), 1000, "k_continuous_step1<"),
@@ -2519,12 +2527,15 @@ def test_step1_kernels_equal_the_rollout_kernels_with_k1(case):
             assert all(same(x, y) for x, y in zip(ra, rb)), (case, "fused piece")
         ra, rb = a.step(acts[t]), b.step(acts[t])
         assert all(same(x, y) for x, y in zip(ra[:4], rb[:4])), (case, t)
+        if case.startswith("i_"):                       # (the terminal pictures of the envs this step has reset; other rows stay as they were)
+            assert ("final_obs" in ra[4]) == ("final_obs" in rb[4]) == (kw["autoreset"] == "same_step")
+            assert "final_obs" not in ra[4] or torch.equal(ra[4]["final_obs"], rb[4]["final_obs"]), (case, t, "final_obs")
     assert np.array_equal(a.status(), b.status())
     sa, sb = a.get_augmented_state(), b.get_augmented_state()
     for k in sa:
         if isinstance(sa[k], np.ndarray):
             assert np.array_equal(sa[k], sb[k], equal_nan=True), (case, k)
     if kw.get("rng", "numpy") == "numpy":
-        for s in (0, 1):
+        for s in (0, 1) + ((2,) if case.startswith("i_") else ()):
             assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (case, s)
     a.close(); b.close()

@@ -1,3 +1,2 @@
-# scratch job for one gpurun call (GPU box); the last content: the round's validation
 cd $GRAFT_REPO_ROOT
-bash tools/validate_all.sh
+python3 -m pytest tests/test_gpu_boundary.py tests/test_gpu_parity.py -m gpu -q -x -k "graph or step1 or image" 2>&1 | tail -8
