@@ -84,6 +84,15 @@ WORKLOADS = {
                              image_representations=True, image_width=84, image_height=84,
                              image_transforms="shift,rotate", image_sh_quant=1, image_ro_quant=1,
                              seed=0)),
+    # the reference's own image sweeps (/root/reference/experiments/a3c_image_representations.py: 100 x 100 pictures,
+    # image_scale_range (0.5, 2), arm "shift,scale,rotate,flip"): radii 10 ... 40 -- templates past the 64-byte LDS columns of
+    # k_image_obs_fast (k_image_obs_wide since round 5; the general renderer before)
+    "img100_all": dict(kind="discrete", envs=8192, alg_bytes_fused=10026, alg_bytes_step=10026, fuse_max=64,
+                       config=dict(state_space_type="discrete", action_space_type="discrete",
+                                   state_space_size=8, action_space_size=8, delay=0,
+                                   image_representations=True, image_width=100, image_height=100,
+                                   image_transforms="shift,scale,rotate,flip", image_scale_range=(0.5, 2),
+                                   seed=0)),
     # BASELINE.json configs[4] (per-GPU shard of the 524 288-env job)
     "cfg5": dict(kind="continuous", envs=65536, alg_bytes_fused=102, alg_bytes_step=350,
                  config=dict(state_space_type="continuous", state_space_dim=12,

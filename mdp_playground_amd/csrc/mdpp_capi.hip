@@ -128,7 +128,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
 #ifdef MDPP_ABL_IMG_CHUNK
     h->img_chunk = MDPP_ABL_IMG_CHUNK;
 #endif
-    h->img_ready = false; h->img_fast_ok = false; h->img_lines_ready = false;
+    h->img_ready = false; h->img_fast_ok = false; h->img_lines_ready = false; h->img_colb = 64;
     for (int r = 0; r < 32; r++) h->imgc_disc_rows[r] = 0;
     h->img_n_radii = h->img_n_cls_x = h->img_n_cls_y = 0;
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) { h->d_rng_s[s] = h->d_rng_inc[s] = nullptr; h->streams_ready[s] = false; }
@@ -1169,9 +1169,15 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
     {
         const int PADW = 8, t = c.img_tpl_size, tp = t + 2 * PADW, half = t / 2;
         const int span = 2 * c.img_r_max + 9 + 4 + 1;      // columns of the near circle's box, at most
-        bool ok = (c.img_h % 4 == 0) && ((size_t)c.img_w * c.img_h) % 16 == 0 && tp <= 64 &&
-                  (size_t)c.img_w * c.img_h <= (1u << 20) && span * (c.img_h / 4) + 8 + 4 <= 1536 &&      /* (+ 4: the zero chunk of render_fast_store) */
+        // (round 5) templates past 64 bytes: 128-byte LDS columns, two waves per workgroup, no image columns in LDS
+        // (k_image_obs_wide; its chunk -> column division by multiply-shift needs W (H / 4)^2 < 2^24)
+        const int colb = tp <= 64 ? 64 : 128;
+        const int coldw = span * (c.img_h / 4) + 8 + 4;                                                   /* (+ 4: the zero chunk of render_fast_store) */
+        bool ok = (c.img_h % 4 == 0) && ((size_t)c.img_w * c.img_h) % 16 == 0 && tp <= 128 &&
+                  (size_t)c.img_w * c.img_h <= (1u << 20) &&
+                  (colb == 64 ? coldw <= 1536 : (size_t)c.img_w * (c.img_h / 4) * (c.img_h / 4) < (1u << 24)) &&
                   c.img_r_max <= (c.img_w < c.img_h ? c.img_w : c.img_h) / 2 - 1;
+        h->img_colb = colb;
         const size_t ntpl = S * n_radii * n_cls_x * n_cls_y;
         for (size_t k = 0; ok && k < ntpl; k++) {
             const int R = c.img_r_min + (int)((k / ((size_t)n_cls_x * n_cls_y)) % n_radii);
@@ -1182,10 +1188,10 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
         }
         h->img_fast_ok = ok;
         if (ok) {
-            std::vector<uint8_t> padded(ntpl * (size_t)tp * 64, 0);
+            std::vector<uint8_t> padded(ntpl * (size_t)tp * colb, 0);
             for (size_t k = 0; k < ntpl; k++)
                 for (int y = 0; y < t; y++)
-                    memcpy(&padded[(k * tp + y + PADW) * 64 + PADW], tpl + (k * t + y) * (size_t)t, t);
+                    memcpy(&padded[(k * tp + y + PADW) * colb + PADW], tpl + (k * t + y) * (size_t)t, t);
             HIPCHK(h, hipMalloc(&h->d_img_tplp, padded.size()));
             HIPCHK(h, hipMemcpy(h->d_img_tplp, padded.data(), padded.size(), hipMemcpyHostToDevice));
             // The near dwords of a polygon as a TABLE (one radius only: no scale transform).  The renderer evaluates the dwords
@@ -1195,7 +1201,7 @@ extern "C" int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl, int3
             // the one along which its lanes read along template rows), 8 entries (dx, dq as int8 pairs) per lane:
             // [order][phase][lane][8].  Every pixel of a listed dword is within R + 5.21 + 1.5 + 0.71 < R + 8 of the centre
             // after the map's rounding: inside the template's zero border.
-            if (n_radii == 1) {
+            if (n_radii == 1 && colb == 64) {
                 const int R = c.img_r_max;
                 const double rt = (double)R + 4.5 + 0.7072, rt2 = rt * rt;
                 std::vector<uint16_t> tab((size_t)2 * 4 * 64 * 8, (uint16_t)0x8080u);      // (dx = dq = -128: never inside a box)

@@ -61,6 +61,8 @@ struct ImageArgs {
     const uint8_t *tplp_data;  // fast renderer: the same templates inside a kImgPad-wide zero
                                // border, [..][tplp rows][64 B]; tplp = tpl + 2 * kImgPad <= 64
     int32_t tplp;
+    int32_t colb;              // fast renderer: bytes of an LDS row that belong to one wave -- 64 (four waves share a row; tplp <= 64) or 128
+                               // (two waves: templates up to 128 wide, k_image_obs_wide -- the scale transform's radii)
     const int16_t *cls_x;      // [S][n_radii][W]
     const int16_t *cls_y;      // [S][n_radii][H]
     const int32_t *rot;        // [360][6] = a0 a1 a2 a3 a4 a5
@@ -429,6 +431,7 @@ __device__ __forceinline__ void stage_tpl(const ImageArgs &a, const TplRegs &tp,
 // Evaluation half: the template of this image is already in the wave's LDS columns (stage_tpl);
 // leaves the image columns of the bounding box in lds_col and returns their chunk range.
 struct ColRange { int C0, C1; };
+template <int COLB = 64>
 __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const RecRegs &r, const uint8_t *lds,
                                                      uint32_t *lds_col, int wave, int lane, const u32x4 near) {
     const int a0 = (int)r.lo[0], a1 = (int)r.lo[1], a2 = (int)r.lo[2], a3 = (int)r.lo[3], a4 = (int)r.lo[4],
@@ -459,7 +462,7 @@ __device__ __forceinline__ ColRange render_fast_eval(const ImageArgs &a, const R
         // accumulators carry the template-local source coordinates in 16.16:
         // bx >> 16 = xs - (cx - half_p) + 64 wave, by >> 16 = ys - (cy - half_p)
         const int half_p = a.tplp >> 1;
-        const int A2 = a2 - ((cx - half_p) << 16) + ((wave * 64) << 16);
+        const int A2 = a2 - ((cx - half_p) << 16) + ((wave * COLB) << 16);
         int A5 = a5 - ((cy - half_p) << 16);
         // (integer LDS addresses: the template rows start at LDS offset lbase -- 0 for this kernel, which has no static LDS; a
         //  multiple of 256 folds into the row accumulator)
@@ -708,6 +711,90 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
 #endif
 }
 
+// ---- wide templates (round 5) --------------------------------------------------------------------
+// The scale transform draws a radius per picture; the reference's own sweeps use image_scale_range = (0.5, 2) on 100 x 100
+// pictures: radii 10 ... 40, templates 83 wide, 99 inside the zero border -- past the 64-byte LDS columns of k_image_obs_fast, so
+// those handles ran the general renderer (four range tests per pixel, dword stores).  Here TWO waves per workgroup own 128 B
+// of every 256-byte LDS row each: the address of a source pixel is still one v_perm_b32 of the two accumulators (column <
+// 256).  One picture per wave, one shot.  Differences from k_image_obs_fast, all to keep LDS per wave at the template alone
+// (12.4 KiB at tplp = 99; a column buffer for R = 40 would add 9.3 and halve the waves per CU):
+//  * only the template rows the map can reach (within R + 9 of the centre) are staged, straight from memory;
+//  * no image columns in LDS: a lane owns the 16-byte chunks lane, lane + 64, ... of the picture, evaluates the near dwords
+//    among its chunk's four (the same integer near test as render_fast_eval's box walk) and stores the chunk from registers
+//    -- the same front-to-back 1 KiB-per-instruction store pattern; chunks far from the polygon cost one test.
+__device__ __forceinline__ void render_wide(const ImageArgs &a, const RecRegs &r, uint8_t *lds, int wave, int lane,
+                                            uint8_t *__restrict__ out) {
+    const int a0 = (int)r.lo[0], a1 = (int)r.lo[1], a2 = (int)r.lo[2], a3 = (int)r.lo[3], a4 = (int)r.lo[4],
+              a5 = (int)r.lo[5];
+    const int cx = (int)(r.lo[6] & 0xFFFFu), cy = (int)(r.lo[6] >> 16), R = (int)(r.lo[7] & 0x3FFu);
+    const float fcx = __uint_as_float(r.hi[0]), fcy = __uint_as_float(r.hi[1]);
+    const int half_p = a.tplp >> 1;
+    {   // template rows [half_p - R - 9, half_p + R + 9]: everything a near dword can map to (R + 8 around the centre)
+        const u32x4 *gt = (const u32x4 *)(a.tplp_data + (size_t)(r.lo[7] >> 12) * ((size_t)a.tplp * 128));
+        const int r0 = max(0, half_p - R - 9), r1 = min(a.tplp, half_p + R + 10);
+        for (int c = r0 * 8 + lane; c < r1 * 8; c += 64) *(u32x4 *)(lds + (c >> 3) * 256 + wave * 128 + (c & 7) * 16) = gt[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int ncx2, ncy2;                              // (scalar registers, see render_fast_eval)
+    {
+        const int vx = -(int)rintf(2.0f * fcx), vy = 3 - (int)rintf(2.0f * fcy);
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ncx2) : "v"(vx));
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(ncy2) : "v"(vy));
+    }
+    const int rr2i = (2 * R + 10) * (2 * R + 10);             // a dword is near: centre within R + 5 (doubled coordinates)
+    const int rc2i = (2 * R + 28) * (2 * R + 28);             // a chunk (16 rows of one column) can hold a near dword: within R + 14
+    const uint32_t lbase = (uint32_t)(uintptr_t)(lds_u8p)lds;
+    if (__builtin_expect((lbase & 255u) != 0u || lbase > 0x8000u, 0)) __builtin_trap();
+    const int A2 = a2 - ((cx - half_p) << 16) + ((wave * 128) << 16);
+    const int A5 = a5 - ((cy - half_p) << 16) + ((int)(lbase >> 8) << 16);
+    const int HQ = a.H >> 2;
+    const uint32_t inv = (1u << 24) / (uint32_t)HQ + 1u;      // q / HQ == (q * inv) >> 24 for q HQ < 2^24 (host-checked)
+    const int nchunk = (a.W * a.H) >> 4;
+    const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, a.W * a.H, 0x00020000);
+    for (int c0 = 0; c0 < nchunk; c0 += 64) {
+        const int c = c0 + lane;
+        int x = (int)(((uint32_t)(4 * c) * inv) >> 24), yq = 4 * c - x * HQ;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        // the chunk's run of 16 rows: centre at y + 7.5 in column x; a run that wraps into the next column is taken as near
+        const int dxc = 2 * x + ncx2, dyc = 8 * yq + 12 + ncy2;
+        const bool maybe = yq + 4 > HQ || dxc * dxc + dyc * dyc <= rc2i;
+        if (maybe) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int y = 4 * yq;
+                const int dx2 = 2 * x + ncx2, dy2 = 2 * y + ncy2;
+                if (dx2 * dx2 + dy2 * dy2 <= rr2i) {
+                    const int bx = A2 + __mul24(a0, x) + __mul24(a1, y);      // |a_i| <= 2^16, x, y < 2^23
+                    const int by = A5 + __mul24(a3, x) + __mul24(a4, y);
+                    uint32_t px[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        // byte 2 of each accumulator = its integer part (< 256): address = uy * 256 + ux
+                        const uint32_t addr = __builtin_amdgcn_perm((uint32_t)(by + b * a4), (uint32_t)(bx + b * a1), 0x0c0c0602u);
+                        px[b] = *(lds_u8p)(uintptr_t)addr;
+                    }
+                    v[d] = (px[0] | (px[1] << 8)) | ((px[2] | (px[3] << 8)) << 16);
+                }
+                yq += 1;
+                if (yq == HQ) { yq = 0; x += 1; }
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_out, c * 16, 0, 0);          // beyond the descriptor: dropped
+    }
+}
+
+constexpr int kWideBlock = 128;
+__global__ __launch_bounds__(kWideBlock) void k_image_obs_wide(ImageArgs a, long M, const ImgRec *__restrict__ rec,
+                                                               uint8_t *__restrict__ img) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kWideBlock / 64) + wave));
+    if (j >= M) return;
+    const RecRegs r = load_rec(rec + j);
+    if (r.lo[7] & (1u << 11)) return;
+    render_wide(a, r, lds, wave, lane, img + (size_t)j * ((size_t)a.W * a.H));
+}
+
 // The launch arguments every image kernel of a batch of K steps shares (buf: the scratch set of a pipelined rollout).
 static ImageArgs image_args(mdpp_env *h, int K, bool is_reset, int buf) {
     const mdpp_config &c = h->cfg;
@@ -728,7 +815,8 @@ static ImageArgs image_args(mdpp_env *h, int K, bool is_reset, int buf) {
     a.rng_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_IMAGE];
     a.rng_half = (uint2 *)h->d_rng_half;
     a.tplp_data = (const uint8_t *)h->d_img_tplp; a.tplp = c.img_tpl_size + 2 * kImgPad;
-    a.near_tab = (h->opts & MDPP_OPT_NO_IMG_NEARTAB) ? nullptr : (const uint32_t *)h->d_img_near;
+    a.colb = h->img_colb;
+    a.near_tab = ((h->opts & MDPP_OPT_NO_IMG_NEARTAB) || a.colb != 64) ? nullptr : (const uint32_t *)h->d_img_near;
     a.philox = c.rng_mode == MDPP_RNG_PHILOX; a.philox_seed = c.philox_seed; a.env_id_offset = c.env_id_offset;
     // (the state kernel / reset kernel of this batch ran just before and has advanced the handle's counters)
     a.is_reset = is_reset;
@@ -747,6 +835,7 @@ static size_t image_fast_lds(const mdpp_env *h, ImageArgs &a) {
     const int span_dw = (2 * h->cfg.img_r_max + 13) * (h->cfg.img_h / 4) + 8;
     a.coldw = ((span_dw + 3) & ~3) + 4;                  // (+ the zero chunk of render_fast_store)
     if (a.coldw > kImgColDw) a.coldw = kImgColDw;
+    if (a.colb != 64) return (size_t)a.tplp * 256;      // k_image_obs_wide: the template rows alone
     return (size_t)a.tplp * 256 + (size_t)(kBlock / 64) * a.coldw * 4;
 }
 
@@ -759,16 +848,16 @@ static size_t image_fast_lds(const mdpp_env *h, ImageArgs &a) {
 // episode --, the record (in registers, moved to scalar registers), and the picture(s) with the fast renderer's evaluation and
 // store halves.  Lane 0 writes the generator back.  One picture per env (no irrelevant sub-space: its two pictures per env
 // would be two waves that both own the generator); other handles keep the four launches.
-template <int NST, bool PHILOX>
+template <int NST, bool PHILOX, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32_t *__restrict__ state_out,
                                                         const int32_t *__restrict__ state_final,
                                                         const uint8_t *__restrict__ term, const uint8_t *__restrict__ trunc,
                                                         uint8_t *__restrict__ img_out, uint8_t *__restrict__ img_final) {
     extern __shared__ __align__(16) uint8_t lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;
-    if (MDPP_IMG_LEAN_LOOP && lane < 4) lds_col[a.coldw - 4 + lane] = 0u;      // the wave's zero chunk (render_fast_store)
-    const long i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
+    uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;     // (WIDE: no image columns in LDS)
+    if (!WIDE && MDPP_IMG_LEAN_LOOP && lane < 4) lds_col[a.coldw - 4 + lane] = 0u;      // the wave's zero chunk (render_fast_store)
+    const long i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * ((WIDE ? kWideBlock : kBlock) / 64) + wave));
     if (i >= a.N) return;
     // Everything the wave needs from memory before it can draw, in ONE batch of scalar loads: the generator, the state, and the
     // step's two flag bytes as the dwords they sit in (there is no scalar byte load, and a vector load -- or a load behind a
@@ -812,11 +901,15 @@ __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32
         for (int k = 0; k < 8; k++) r.lo[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.lo[k]);
 #pragma unroll
         for (int k = 0; k < 4; k++) r.hi[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.hi[k]);
-        const TplRegs tp = load_tpl(a, r.lo[7] >> 12, lane);
-        const u32x4 near = load_near(a, r, lane);
-        stage_tpl(a, tp, lds, wave, lane);
-        const ColRange cr = render_fast_eval(a, r, lds, lds_col, wave, lane, near);
-        render_fast_store<NST>(a, cr, lds_col, out, lane);
+        if constexpr (WIDE) {
+            render_wide(a, r, lds, wave, lane, out);
+        } else {
+            const TplRegs tp = load_tpl(a, r.lo[7] >> 12, lane);
+            const u32x4 near = load_near(a, r, lane);
+            stage_tpl(a, tp, lds, wave, lane);
+            const ColRange cr = render_fast_eval(a, r, lds, lds_col, wave, lane, near);
+            render_fast_store<NST>(a, cr, lds_col, out, lane);
+        }
     };
 #ifdef MDPP_S1I_ABL_NOPIC                        // (timing only: the serial head of the wave alone)
     if (x0.cx == 12345 && lane == 1) img_out[i] = (uint8_t)(x1.cy + s_out + s_fin);
@@ -834,6 +927,16 @@ int launch_image_step1(mdpp_env *h, const int32_t *state_out, const int32_t *sta
     if (!h->img_fast_ok || (h->opts & (MDPP_OPT_NO_IMGFAST | MDPP_OPT_NO_STEP1)) || c.irrelevant || !img_out) return 0;
     ImageArgs a = image_args(h, 1, false, 0);
     const size_t lds_bytes = image_fast_lds(h, a);
+    if (a.colb != 64) {                          // wide templates: two waves per workgroup (render_wide)
+        const dim3 wgrid((unsigned)((a.N + kWideBlock / 64 - 1) / (kWideBlock / 64)));
+        if (a.philox) hipLaunchKernelGGL((k_image_step1<0, true, true>), wgrid, dim3(kWideBlock), lds_bytes, s, a, state_out, state_final,
+                                         term, trunc, img_out, img_final);
+        else hipLaunchKernelGGL((k_image_step1<0, false, true>), wgrid, dim3(kWideBlock), lds_bytes, s, a, state_out, state_final,
+                                term, trunc, img_out, img_final);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { h->err = std::string("k_image_step1 launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+        return 1;
+    }
     const dim3 grid((unsigned)((a.N + kBlock / 64 - 1) / (kBlock / 64)));
     const int nst = (int)(((size_t)a.W * a.H / 16 + 63) / 64);
 #define MDPP_IMG_S1(NST_)                                                                                                     \
@@ -882,7 +985,12 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         const int per_block = kBlock / 64;
         const long M = (long)K * a.N * a.SUB;
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
-        if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST)) {
+        if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST) && h->img_colb == 128) {
+            const size_t lds_bytes = image_fast_lds(h, a);                  // (host-checked: <= 64 KiB)
+            const dim3 grid((unsigned)((M + kWideBlock / 64 - 1) / (kWideBlock / 64)));
+            hipLaunchKernelGGL(k_image_obs_wide, grid, dim3(kWideBlock), lds_bytes, s, a, M, a.rec0, img_out);
+            if (img_final) hipLaunchKernelGGL(k_image_obs_wide, grid, dim3(kWideBlock), lds_bytes, s, a, M, a.rec1, img_final);
+        } else if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST)) {
             const size_t lds_bytes = image_fast_lds(h, a);
             unsigned per_cu = (unsigned)((160u * 1024u) / ((lds_bytes + 511) & ~(size_t)511));
             per_cu = per_cu < 1u ? 1u : (per_cu > 8u ? 8u : per_cu);
@@ -933,6 +1041,7 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
 
 const char *image_obs_kernel_name(const mdpp_env *h, int K) {
     if (!(h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST))) return "k_image_obs";
+    if (h->img_colb == 128) return (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1) && !h->cfg.irrelevant) ? "k_image_step1<WIDE=1>" : "k_image_obs_wide";
     const int nst = (int)(((size_t)h->cfg.img_w * h->cfg.img_h / 16 + 63) / 64);
     if (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1) && !h->cfg.irrelevant)     // (launch_image_step1's conditions)
         return nst == 7 ? "k_image_step1<NST=7>" : nst == 4 ? "k_image_step1<NST=4>" : "k_image_step1<NST=0>";

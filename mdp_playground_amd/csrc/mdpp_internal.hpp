@@ -294,6 +294,7 @@ struct mdpp_env {
     uint32_t imgc_disc_rows[32]; // continuous image observations: the disc raster, one bitmask per row
     bool img_ready, img_fast_ok, img_lines_ready;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
     int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
+    int32_t img_colb;            // fast renderer: 64 (k_image_obs_fast) or 128 (k_image_obs_wide) bytes of an LDS row per wave
     uint32_t nkeys, rbits_stride;
     bool tables_ready, streams_ready[MDPP_NUM_STREAMS];
     hipEvent_t ev0, ev1;

@@ -1182,8 +1182,7 @@ def test_image_fused_rollout_equals_single_steps(name):
     N, K = (48, 300) if name == "cfg4" else (300, 40)
     a = _venv(num_envs=N, autoreset="same_step", **cfg)
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
-    assert a.rollout_kernel_name(K).startswith("k_image_obs" if name == "all100" else "k_image_obs_fast<")
-    assert (a.rollout_kernel_name(K) == "k_image_obs") == (name == "all100")
+    assert a.rollout_kernel_name(K) == "k_image_obs_wide" if name == "all100" else a.rollout_kernel_name(K).startswith("k_image_obs_fast<")
     acts = torch.as_tensor(_img_actions(cfg, (K, N), 2), device=a.device)
     obs, rew, term, trunc = a.rollout(acts)
     assert term.any() and not term.all()
@@ -2322,6 +2321,8 @@ def test_multi_wave_kernels_equal_single_role_kernels_soak(name, flag):
      "NO_CFAST", 65536, 64),
     ("cfg5", {"delay": 3}, "NO_CFAST", 32768, 48),
     ("cfg4", {}, "NO_IMGFAST", 2048, 40),                            # fast vs general renderer, pipelined batches
+    ("img100_all", {}, "NO_IMGFAST", 2048, 40),                      # ... the wide-template renderer (radii 10 ... 40: k_image_obs_wide)
+    ("img100_all", {"image_transforms": "scale", "image_width": 96, "image_height": 120, "rng": "philox"}, "NO_IMGFAST", 1000, 20),
     # Philox streams: the fused kernels (normals made by producer waves / at the top of the step) vs the general ones
     ("cfg5", {"rng": "philox"}, "NO_PHILOX_FAST", 65536, 64),
     ("cfg5", {"rng": "philox"}, "NO_HELPER", 65536, 64),
@@ -2467,6 +2468,9 @@ STEP1_CASES = {
     "i_cfg4_disabled": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="disabled"), 333, "k_image_step1<NST=7>"),
     "i_cfg4_next_step": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="next_step", max_episode_steps=6), 333, "k_image_step1<NST=7>"),
     "i_rot64": (dict(IMG_CFGS["rot64"], seed=3), dict(autoreset="same_step"), 1000, "k_image_step1<NST=4>"),
+    "i_img100_all_wide": (dict(__import__("bench").WORKLOADS["img100_all"]["config"], seed=3), dict(autoreset="same_step"), 500, "k_image_step1<WIDE=1>"),
+    "i_scale_only_wide_philox": (dict(__import__("bench").WORKLOADS["img100_all"]["config"], seed=3, image_transforms="scale", image_width=96, image_height=120),
+                                 dict(autoreset="same_step", rng="philox", max_episode_steps=5), 333, "k_image_step1<WIDE=1>"),
     "i_scale_flip_96x80": (dict(IMG_CFGS["cfg4"], seed=3, image_width=96, image_height=80, image_transforms="shift,scale,rotate,flip",
                                 image_scale_range=(0.5, 1.0), image_sh_quant=2, image_ro_quant=15), dict(autoreset="same_step"), 500, "k_image_step1<NST=0>"),
     "c_cfg3": (_S1_C_CFG3, dict(autoreset="same_step"), 4096, "k_continuous_step1<D=12,ORDER=1,NREL=4,NOISE=0,GEN=0,PHILOX=0,WG=64>"),
