@@ -326,7 +326,8 @@ def action_rotation(wl, F, N, device, seed, min_total=512 << 20, min_n=4, max_n=
 # the other BASELINE.json configs (and cfg2 on the RNG north_star names), timed in the same run after the cfg2 leg
 EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5", "numpy"), ("cfg5", "philox"),
               ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"),   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
-              ("d_s50_delay4", "numpy"), ("d_s24_rdist", "numpy"), ("cfg2_per_env", "numpy"))   # (+ the discrete shapes beyond the lean kernel)
+              ("d_s50_delay4", "numpy"), ("d_s24_rdist", "numpy"), ("cfg2_per_env", "numpy"),   # (+ the discrete shapes beyond the lean kernel)
+              ("img100_all", "numpy"))                                                           # (+ the reference's own image sweep shape)
 
 
 def leg_name(workload, rng):
@@ -368,7 +369,7 @@ def workload_leg(name, rng, device, fuse, launches, warmup, seed=12345, repeats=
     bad = int((env.status() != 0).sum())
     kname = env.rollout_kernel_name(F)
     single = None
-    if name in ("cfg3", "cfg5", "d_s50_delay4"):    #  the one-launch-per-step API and a replayed HIP graph of 64 such steps
+    if name in ("cfg3", "cfg4", "cfg5", "d_s50_delay4", "img100_all"):    #  the one-launch-per-step API and a replayed HIP graph of 64 such steps
         try:
             single = single_step_leg(env, wl, acts[0], N, device, n1=200, reps=5)
         except Exception as e:                  # a reported extra, never fatal
