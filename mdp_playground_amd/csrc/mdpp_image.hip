@@ -713,11 +713,11 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
 
 // ---- wide templates (round 5) --------------------------------------------------------------------
 // The scale transform draws a radius per picture; the reference's own sweeps use image_scale_range = (0.5, 2) on 100 x 100
-// pictures: radii 10 ... 40, templates 83 wide, 99 inside the zero border -- past the 64-byte LDS columns of k_image_obs_fast, so
+// pictures: radii 9 ... 41, templates 85 wide, 101 inside the zero border -- past the 64-byte LDS columns of k_image_obs_fast, so
 // those handles ran the general renderer (four range tests per pixel, dword stores).  Here TWO waves per workgroup own 128 B
 // of every 256-byte LDS row each: the address of a source pixel is still one v_perm_b32 of the two accumulators (column <
 // 256).  One picture per wave, one shot.  Differences from k_image_obs_fast, all to keep LDS per wave at the template alone
-// (12.4 KiB at tplp = 99; a column buffer for R = 40 would add 9.3 and halve the waves per CU):
+// (12.6 KiB at tplp = 101; a column buffer for R = 40 would add 9.3 and halve the waves per CU):
 //  * only the template rows the map can reach (within R + 9 of the centre) are staged, straight from memory;
 //  * no image columns in LDS: a lane owns the 16-byte chunks lane, lane + 64, ... of the picture, evaluates the near dwords
 //    among its chunk's four (the same integer near test as render_fast_eval's box walk) and stores the chunk from registers
