@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-( time bash tools/prof_r05.sh ) > gpurun_out/prof_r05.log 2>&1
-tail -70 gpurun_out/prof_r05.log | cut -c1-700
+python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden and (i_ or image)" 2>&1 | tail -5

@@ -308,6 +308,13 @@ CASES = {
                     image_sh_quant=2, image_ro_quant=5,
                     image_scale_range=(0.5, 1.5)),
         seeds=[0, 1], T=24, reset="on_done"),
+    # the reference's own image sweeps (experiments/a3c_image_representations.py: 100 x 100, image_scale_range (0.5, 2),
+    # arm "shift,scale,rotate,flip", default quantisation): radii 9 ... 41 -- the wide-template renderer
+    "i_100_sweep": dict(
+        config=dict(CFG1, image_representations=True, image_width=100,
+                    image_height=100, image_transforms="shift,scale,rotate,flip",
+                    image_scale_range=(0.5, 2)),
+        seeds=[0, 1, 2], T=32, reset="on_done"),
     "i_none": dict(
         config=dict(CFG1, image_representations=True, image_width=84,
                     image_height=84),
