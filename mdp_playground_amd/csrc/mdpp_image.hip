@@ -846,8 +846,8 @@ static size_t image_fast_lds(const mdpp_env *h, ImageArgs &a) {
 // arithmetic on the same values (the generator's state through wave-uniform loads; 64 lanes of one wave cost what one lane
 // does): the transform draws in the reference's order -- the step's observation, then reset()'s where the step ended the
 // episode --, the record (in registers, moved to scalar registers), and the picture(s) with the fast renderer's evaluation and
-// store halves.  Lane 0 writes the generator back.  One picture per env (no irrelevant sub-space: its two pictures per env
-// would be two waves that both own the generator); other handles keep the four launches.
+// store halves.  Lane 0 writes the generator back.  An irrelevant sub-space's second picture (same generator, drawn right after
+// the first) is rendered by the same wave, after the first.  The general renderer's handles keep the four launches.
 template <int NST, bool PHILOX, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32_t *__restrict__ state_out,
                                                         const int32_t *__restrict__ state_final,
@@ -872,21 +872,28 @@ __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32
         const uint2 hh = a.rng_half[i];
         h = Half32{hh.x, hh.y};
     }
-    const int s_out = state_out[i];
+    const int SUB = a.SUB;                           // pictures per env: 2 with an irrelevant sub-space (drawn and rendered one after the other)
+    const int s_out0 = state_out[i * SUB], s_out1 = state_out[i * SUB + SUB - 1];
     const uintptr_t pt = (uintptr_t)term + (uintptr_t)i, pu = (uintptr_t)trunc + (uintptr_t)i;
     const uint32_t wt = *(cptr32)(pt & ~(uintptr_t)3), wu = *(cptr32)(pu & ~(uintptr_t)3);
     const uint32_t flags = ((wt >> (8 * (int)(pt & 3))) | (wu >> (8 * (int)(pu & 3)))) & 0xFFu;
     const bool two = (a.autoreset != 0) & (flags != 0);
-    const int s_fin = state_final[i];               // (read only where two: scratch the state kernel fills for every env)
+    const int s_fin0 = state_final[i * SUB], s_fin1 = state_final[i * SUB + SUB - 1];   // (read only where two: scratch the state kernel fills for every env)
     const ShiftBounds sb = shift_bounds(a, a.r0);
 #ifdef MDPP_S1I_ABL_NODRAW                       // (timing only, tools/ablate_step1.py: a made-up transform, no generator)
-    Xform x0{a.r0, a.W / 2 + (int)(i % 7) - 3, a.H / 2 + (int)(i % 5) - 2, (int)(i % 360), 0};
-    Xform x1 = x0;
+    Xform x00{a.r0, a.W / 2 + (int)(i % 7) - 3, a.H / 2 + (int)(i % 5) - 2, (int)(i % 360), 0};
+    Xform x01 = x00, x10 = x00, x11 = x00;
     (void)sb;
 #else
-    const Xform x0 = draw_xform(a, sb, g, h);
-    Xform x1 = x0;
-    if (two) x1 = draw_xform(a, sb, g, h);
+    // the reference's order: the step's observation (one picture per sub-space, relevant then irrelevant), then reset()'s
+    const Xform x00 = draw_xform(a, sb, g, h);
+    Xform x01 = x00;
+    if (SUB == 2) x01 = draw_xform(a, sb, g, h);
+    Xform x10 = x00, x11 = x01;
+    if (two) {
+        x10 = draw_xform(a, sb, g, h);
+        if (SUB == 2) x11 = draw_xform(a, sb, g, h);
+    }
 #endif
     if constexpr (!PHILOX) {
         if (lane == 0) {
@@ -912,11 +919,15 @@ __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32
         }
     };
 #ifdef MDPP_S1I_ABL_NOPIC                        // (timing only: the serial head of the wave alone)
-    if (x0.cx == 12345 && lane == 1) img_out[i] = (uint8_t)(x1.cy + s_out + s_fin);
+    if (x00.cx == 12345 && lane == 1) img_out[i] = (uint8_t)(x10.cy + x11.cy + x01.cy + s_out0 + s_fin0 + s_out1 + s_fin1);
     return;
 #endif
-    if (two && img_final) picture(x0, s_fin, false, img_final + (size_t)i * isz);
-    picture(two ? x1 : x0, s_out, two, img_out + (size_t)i * isz);
+#pragma unroll 1
+    for (int q = 0; q < SUB; q++) {
+        const size_t j = (size_t)i * SUB + q;
+        if (two && img_final) picture(q ? x01 : x00, q ? s_fin1 : s_fin0, false, img_final + j * isz);
+        picture(q ? x11 : x10, q ? s_out1 : s_out0, two, img_out + j * isz);
+    }
 }
 
 // The fused step above, if this handle can use it (the caller then skips launch_image_obs): 0 = not taken, 1 = launched,
@@ -924,7 +935,8 @@ __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32
 int launch_image_step1(mdpp_env *h, const int32_t *state_out, const int32_t *state_final, const uint8_t *term,
                        const uint8_t *trunc, uint8_t *img_out, uint8_t *img_final, hipStream_t s) {
     const mdpp_config &c = h->cfg;
-    if (!h->img_fast_ok || (h->opts & (MDPP_OPT_NO_IMGFAST | MDPP_OPT_NO_STEP1)) || c.irrelevant || !img_out) return 0;
+    if (!h->img_fast_ok || (h->opts & (MDPP_OPT_NO_IMGFAST | MDPP_OPT_NO_STEP1)) || !img_out) return 0;
+    (void)c;
     ImageArgs a = image_args(h, 1, false, 0);
     const size_t lds_bytes = image_fast_lds(h, a);
     if (a.colb != 64) {                          // wide templates: two waves per workgroup (render_wide)
@@ -1041,9 +1053,9 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
 
 const char *image_obs_kernel_name(const mdpp_env *h, int K) {
     if (!(h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST))) return "k_image_obs";
-    if (h->img_colb == 128) return (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1) && !h->cfg.irrelevant) ? "k_image_step1<WIDE=1>" : "k_image_obs_wide";
+    if (h->img_colb == 128) return (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1)) ? "k_image_step1<WIDE=1>" : "k_image_obs_wide";
     const int nst = (int)(((size_t)h->cfg.img_w * h->cfg.img_h / 16 + 63) / 64);
-    if (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1) && !h->cfg.irrelevant)     // (launch_image_step1's conditions)
+    if (K == 1 && !(h->opts & MDPP_OPT_NO_STEP1))     // (launch_image_step1's conditions)
         return nst == 7 ? "k_image_step1<NST=7>" : nst == 4 ? "k_image_step1<NST=4>" : "k_image_step1<NST=0>";
     return nst == 7 ? "k_image_obs_fast<NST=7>" : nst == 4 ? "k_image_obs_fast<NST=4>" : "k_image_obs_fast<NST=0>";
 }

@@ -402,7 +402,7 @@ def test_step_graph_exact_for_every_handle_through_the_tick_offset(case):
     elif case.startswith("image-cfg4"):          # polygon pictures: one kernel draws, records and renders (k_image_step1)
         cfg = dict(bench.WORKLOADS["cfg4"]["config"])
         kw = dict(rng="philox", philox_seed=10) if case.endswith("philox") else {}
-    elif case == "image-irr84-philox":           # ... two pictures per env: the four launches (k_image_draw<REC> keyed the same way)
+    elif case == "image-irr84-philox":           # ... two pictures per env from one stream
         cfg, kw = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 11], action_space_size=[8, 11],
                        irrelevant_features=True, delay=0, image_representations=True, image_width=84, image_height=84,
                        image_transforms="shift,rotate", seed=2), dict(rng="philox", philox_seed=11)

@@ -2468,6 +2468,8 @@ STEP1_CASES = {
     "i_cfg4_disabled": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="disabled"), 333, "k_image_step1<NST=7>"),
     "i_cfg4_next_step": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="next_step", max_episode_steps=6), 333, "k_image_step1<NST=7>"),
     "i_rot64": (dict(IMG_CFGS["rot64"], seed=3), dict(autoreset="same_step"), 1000, "k_image_step1<NST=4>"),
+    "i_irr84": (dict(IMG_CFGS["irr84"], seed=3), dict(autoreset="same_step"), 500, "k_image_step1<NST=7>"),      # two pictures per env, one generator
+    "i_irr84_philox_trunc": (dict(IMG_CFGS["irr84"], seed=3), dict(autoreset="same_step", rng="philox", max_episode_steps=4), 333, "k_image_step1<NST=7>"),
     "i_img100_all_wide": (dict(__import__("bench").WORKLOADS["img100_all"]["config"], seed=3), dict(autoreset="same_step"), 500, "k_image_step1<WIDE=1>"),
     "i_scale_only_wide_philox": (dict(__import__("bench").WORKLOADS["img100_all"]["config"], seed=3, image_transforms="scale", image_width=96, image_height=120),
                                  dict(autoreset="same_step", rng="philox", max_episode_steps=5), 333, "k_image_step1<WIDE=1>"),
@@ -2516,6 +2518,8 @@ def test_step1_kernels_equal_the_rollout_kernels_with_k1(case):
         acts = g.integers(0, A, size=(3 * T, N)).astype(np.int32)
         acts[g.random((3 * T, N)) < 0.01] = -1          # numpy's negative index: the last action
         acts[g.random((3 * T, N)) < 0.002] = A + 3      # out of range: action 0 and MDPP_STATUS_BAD_ACTION
+        if a._irr:                                      # (Tuple spaces: one action per sub-space)
+            acts = np.stack([g.integers(0, A, size=(3 * T, N)), g.integers(0, a.mdps[0].A_irr, size=(3 * T, N))], axis=2).astype(np.int32)
     else:
         D = a.mdps[0].D
         acts = g.uniform(-1, 1, size=(3 * T, N, D)).astype(np.float32)
