@@ -8,10 +8,21 @@ import numpy as np
 
 from oracle import oracle as ora
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = os.environ.get("MDPP_GOLDEN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")    # (the override: scratch
+#                                     sets made by tools/refgen/gen_sweep.py, run through the same tests before any of them is committed)
+# tests/golden_sweep/: the env configurations of the reference's OWN experiment sweeps (/root/reference/experiments/*.py, every
+# RLToy-v0 file: a star over its var_env_configs, duplicates merged -- tools/refgen/gen_sweep.py), recorded from the reference
+# like every other golden; names ?_x<nnn> fall into the lists below by their prefix, so every golden-driven test runs on them too
+SWEEP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_sweep")
 
 with open(os.path.join(GOLDEN, "cases.json")) as _f:
     CASES = json.load(_f)
+_DIR = {k: GOLDEN for k in CASES}
+if os.path.exists(os.path.join(SWEEP, "cases.json")) and not os.environ.get("MDPP_GOLDEN_DIR"):
+    with open(os.path.join(SWEEP, "cases.json")) as _f:
+        for _k, _v in json.load(_f).items():
+            CASES[_k] = _v
+            _DIR[_k] = SWEEP
 
 IRRELEVANT = sorted(k for k in CASES if k.startswith("d_irr"))      # Tuple spaces: pairs of states / actions
 DISCRETE = sorted(k for k in CASES if k.startswith("d_") and k not in IRRELEVANT)
@@ -23,7 +34,7 @@ IMAGE_CONT = sorted(k for k in CASES if k.startswith("ci_"))    # continuous env
 
 
 def load(name):
-    return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return np.load(os.path.join(_DIR.get(name, GOLDEN), name + ".npz"))
 
 
 def case_config(name, e=0):

@@ -77,6 +77,48 @@ def test_error_behaviour_matches_reference():
         mdp.build_mdp({"state_space_type": "discrete", "action_space_size": [8, 8], "seed": 0})
 
 
+def test_sweep_configs_the_reference_rejects_are_rejected_the_same_way():
+    """tools/refgen/gen_sweep.py runs every env configuration of the reference's own experiment files through the reference;
+    ten of them make RLToyEnv raise: eight `AssertionError: target_point should have dimensionality = relevant_state_space
+    dimensionality` (the *_move_to_a_point_irr_dims files name irrelevant dimensions with keys the env does not read, so all
+    state_space_dim dimensions stay relevant against a 2-D target_point), one `AssertionError: Did you mean to turn
+    irrelevant_features? ...` (dqn_irr_dims), one `KeyError: 'action_space_size'` (rainbow_hydra).  The host generator
+    raises the same exceptions with the same messages."""
+    for D in (3, 4, 6, 10):
+        cfg = {"action_loss_weight": 0.0, "action_space_dim": [None], "action_space_max": 1, "action_space_relevant_indices": [0, 1],
+               "action_space_type": "continuous", "delay": 0, "inertia": 1, "make_denser": True, "reward_function": "move_to_a_point",
+               "reward_noise": 0, "reward_scale": 1.0, "seed": 0, "state_space_dim": D, "state_space_max": 10,
+               "state_space_relevant_indices": [0, 1], "state_space_type": "continuous", "target_point": [0, 0], "target_radius": 0.5,
+               "time_unit": 1.0, "transition_dynamics_order": 1, "transition_noise": 0}
+        with pytest.raises(AssertionError, match="target_point should have dimensionality"):
+            mdp.build_mdp(cfg)
+        del cfg["action_space_dim"]                 # (ddpg_ / td3_move_to_a_point_irr_dims: the same without that key)
+        with pytest.raises(AssertionError, match="target_point should have dimensionality"):
+            mdp.build_mdp(cfg)
+    # dqn_irr_dims: list-valued sizes without irrelevant_features; rainbow_hydra: no sizes at all
+    base = {"action_space_type": "discrete", "completely_connected": True, "generate_random_mdp": True, "repeats_in_sequences": False,
+            "seed": 0, "state_space_type": "discrete"}
+    with pytest.raises(AssertionError, match="Did you mean to turn irrelevant_features"):
+        mdp.build_mdp(dict(base, action_space_relevant_indices=[1], action_space_size=[8, 8], delay=0, make_denser=False, reward_density=0.25,
+                           reward_noise=0, reward_scale=1.0, sequence_length=1, state_space_relevant_indices=[1], state_space_size=[8, 8],
+                           terminal_state_density=0.25, transition_noise=0))
+    with pytest.raises(KeyError, match="action_space_size"):
+        mdp.build_mdp(base)
+
+
+def test_sweep_goldens_cover_the_reference_experiments():
+    """tests/golden_sweep/cases.json: one recorded case per unique env configuration of the reference's RLToy-v0 experiment
+    files (a star over var_env_configs); every golden-driven test of the oracle, the host generator and the HIP path runs on them."""
+    sweep = [k for k in gu.CASES if "_x" in k and k.split("_x")[-1].isdigit()]
+    assert len(sweep) >= 160
+    exps = set()
+    for k in sweep:
+        exps.update(gu.CASES[k]["experiments"])
+    assert len(exps) >= 80 and "dqn_delay_50_states" in exps and "a3c_image_representations" in exps and "ddpg_move_to_a_point_p_order_3" in exps
+    kinds = {k.split("_x")[0] for k in sweep}
+    assert {"d", "c", "i"} <= kinds, kinds
+
+
 def test_default_target_point_follows_the_reference():
     """No target_point: float64 zeros of length state_space_dim (rl_toy_env.py:652-654) -- taken (target_default) when
     every dimension is relevant; with fewer relevant dimensions the reference cannot broadcast `state[rel] - target`
