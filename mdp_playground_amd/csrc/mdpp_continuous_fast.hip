@@ -1431,6 +1431,7 @@ bool launch_continuous_step1(const ContinuousArgs &a, const float *actions, floa
     MDPP_K1(2, 1, 2) MDPP_K1(2, 2, 2) MDPP_K1(4, 1, 4) MDPP_K1(4, 2, 4)
     MDPP_K1(8, 1, 8) MDPP_K1(8, 2, 8) MDPP_K1(12, 1, 12) MDPP_K1(12, 2, 12)
     MDPP_K1(4, 1, 2) MDPP_K1(4, 2, 2) MDPP_K1(8, 1, 4) MDPP_K1(8, 2, 4)
+    MDPP_K1(2, 3, 2)                // (the reference's *_move_to_a_point_p_order_3 sweeps)
 #endif
 #undef MDPP_K1
     return false;
@@ -1499,6 +1500,7 @@ bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions
     MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)
     MDPP_CF(8, 1, 8) MDPP_CF(8, 2, 8) MDPP_CF(12, 1, 12) MDPP_CF(12, 2, 12)
     MDPP_CF(4, 1, 2) MDPP_CF(4, 2, 2) MDPP_CF(8, 1, 4) MDPP_CF(8, 2, 4)
+    MDPP_CF(2, 3, 2)                // (the reference's *_move_to_a_point_p_order_3 sweeps)
 #endif
 #undef MDPP_CF
     return false;

@@ -1,0 +1,78 @@
+"""The reference's own experiment configurations AT SCALE (tests/golden_sweep/cases.json, tools/refgen/gen_sweep.py).
+
+The goldens of the sweep step ONE env per configuration: they pin the arithmetic, on the general kernels (a handful of envs
+never selects a specialised one).  A user who switches runs thousands of envs of one MDP -- and then the dispatcher picks
+k_discrete_rollout_lean / _quiet / _fast, k_continuous_rollout_fast, k_image_obs_fast / _wide, the one-launch kernels of
+mdpp_step ... by the configuration's shape.  Here every configuration of the sweep is run as ONE shared MDP over 1 024 envs
+(256 with pictures) on the default dispatch and, beside it, with every specialisation switched off (all MDPP_OPT_NO_* bits:
+the general kernels the goldens pin): two fused rollouts, single steps, a rollout again -- every output of every env and
+every stream's end state, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from test_gpu_boundary import _rand_actions
+from test_gpu_parity import _venv
+
+pytestmark = pytest.mark.gpu
+
+SWEEP = sorted(k for k in gu.CASES if "_x" in k and k.rsplit("_x", 1)[-1].isdigit())
+KERNELS = {}
+
+
+def _same(x, y):
+    return torch.equal(x.view(torch.int32) if x.dtype.is_floating_point else x, y.view(torch.int32) if y.dtype.is_floating_point else y)
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+@pytest.mark.parametrize("name", SWEEP)
+def test_sweep_config_at_scale_specialised_equals_general(name, rng):
+    from mdp_playground_amd import _capi as capi
+    if rng == "philox" and int(name.rsplit("_x", 1)[-1]) % 4 != 0:
+        pytest.skip("Philox streams: every fourth configuration of the sweep")
+    cfg = gu.case_config(name)
+    image = bool(cfg.get("image_representations"))
+    N, F = (256, 24) if image else (1024, 48)
+    kw = dict(rng="philox", philox_seed=5) if rng == "philox" else {}
+    a = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    b.set_kernel_options(*capi.OPTIONS)
+    KERNELS[(name, rng)] = (a.rollout_kernel_name(F), a.rollout_kernel_name(1), b.rollout_kernel_name(F))
+    g = np.random.default_rng(11)
+    for piece in range(2):
+        acts = torch.as_tensor(_rand_actions(a, F, g), device=a.device)
+        ra, rb = a.rollout(acts), b.rollout(acts)
+        torch.cuda.synchronize()
+        assert all(_same(x, y) for x, y in zip(ra, rb)), (name, rng, "rollout", piece, KERNELS[(name, rng)])
+        for t in range(6):
+            sa, sb = a.step(acts[t]), b.step(acts[t])
+            assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (name, rng, "step", piece, t, KERNELS[(name, rng)])
+    assert np.array_equal(a.status(), b.status())
+    if rng == "numpy":
+        streams = [capi.STREAM_ENV, capi.STREAM_SPACE] + ([capi.STREAM_IMAGE] if image and a.kind == "discrete" else [])
+        for s in streams:
+            assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (name, s)
+    a.close(); b.close()
+
+
+def test_sweep_selects_the_specialised_kernels():
+    """(runs after the cases above) what the dispatcher chose for the reference's configurations: most of them leave the
+    general kernels, and every family of specialised kernel is reached by some experiment of the reference."""
+    if len(KERNELS) < len(SWEEP):
+        pytest.skip("needs the parametrised cases of this module to have run")
+    fused = {k: v[0].split("<")[0] for k, v in KERNELS.items() if k[1] == "numpy"}
+    single = {k: v[1].split("<")[0] for k, v in KERNELS.items() if k[1] == "numpy"}
+    general = {k: v[2].split("<")[0] for k, v in KERNELS.items() if k[1] == "numpy"}
+    assert set(general.values()) <= {"k_discrete_step", "k_continuous_step", "k_image_obs"}, set(general.values())
+    special = [k for k in fused if fused[k] != general[k]]
+    assert len(special) >= 0.9 * len(fused), (len(special), len(fused))
+    fam = set(fused.values()) | set(single.values())
+    # (k_discrete_step1, the narrow one-step kernel, is not among them: every discrete experiment file passes reward_noise: 0,
+    #  for which the reference still draws rng.normal(0, 0) per step -- rl_toy_env.py:398-403, :1982 -- so the kernels WITH reward
+    #  noise are what the reference's sweeps select: lean / quiet <RN=1>, k_discrete_step1w<...,RN=1>, continuous NOISE=1)
+    for want in ("k_discrete_rollout_lean", "k_discrete_rollout_quiet", "k_continuous_rollout_fast", "k_image_obs_fast", "k_image_obs_wide",
+                 "k_discrete_step1w", "k_continuous_step1", "k_image_step1"):
+        assert want in fam, (want, sorted(fam))
+    assert all("RN=1" in v[0] for k, v in KERNELS.items() if k[1] == "numpy" and k[0].startswith("d_") and "rollout" in v[0])
+    assert all(v[0].startswith("k_continuous_rollout_fast<") for k, v in KERNELS.items() if k[0].startswith("c_")), "order 3 included (round 5)"
