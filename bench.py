@@ -113,6 +113,14 @@ WORKLOADS = {
                         config=dict(state_space_type="discrete", action_space_type="discrete", state_space_size=24,
                                     action_space_size=24, delay=0, sequence_length=1, reward_density=0.25,
                                     terminal_state_density=0.25, reward_dist=[0.01, 1], seed=0)),
+    # the commonest discrete shape of the reference's experiment files (a3c_del, dqn_del, rainbow_del, ... at delay 0): every one of
+    # them passes reward_noise: 0 and transition_noise: 0, and the reference DRAWS rng.normal(0, 0) per step for a zero sigma
+    # (rl_toy_env.py:398-403, :1982) -- stream-exact parity keeps the draw, so this shape runs the kernels WITH reward noise
+    "d_s8_rn0": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42,
+                     config=dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8,
+                                 delay=0, sequence_length=1, reward_density=0.25, terminal_state_density=0.25, make_denser=False,
+                                 transition_noise=0, reward_noise=0, reward_scale=1.0, completely_connected=True,
+                                 generate_random_mdp=True, repeats_in_sequences=False, seed=0)),
     "cfg2_per_env": dict(kind="discrete", envs=8192, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
                          config=dict(state_space_type="discrete", action_space_type="discrete",
                                      state_space_size=8, action_space_size=8, delay=4, sequence_length=3)),
@@ -327,7 +335,8 @@ def action_rotation(wl, F, N, device, seed, min_total=512 << 20, min_n=4, max_n=
 EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5", "numpy"), ("cfg5", "philox"),
               ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"),   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
               ("d_s50_delay4", "numpy"), ("d_s24_rdist", "numpy"), ("cfg2_per_env", "numpy"),   # (+ the discrete shapes beyond the lean kernel)
-              ("img100_all", "numpy"))                                                           # (+ the reference's own image sweep shape)
+              ("img100_all", "numpy"),                                                           # (+ the reference's own image sweep shape)
+              ("d_s8_rn0", "numpy"), ("d_s8_rn0", "philox"))                                     # (+ its commonest discrete shape: noise keys with sigma 0)
 
 
 def leg_name(workload, rng):

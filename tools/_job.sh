@@ -1,3 +1,12 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python3 -m pytest tests/test_gpu_sweep.py -m gpu -q 2>&1 | tail -12 | cut -c1-600
-timeout 2400 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "continuous" 2>&1 | tail -3 | cut -c1-600
+( time python3 bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/b.json 2> gpurun_out/b.err
+tail -4 gpurun_out/b.err
+python3 - <<'PY'
+import json
+for l in open("gpurun_out/b.json"):
+    if l.startswith('{"metric"'):
+        d = json.loads(l)
+        print("value", d["value"], "frac", d["roofline"]["frac"])
+        for k, v in d["workloads"].items():
+            print(k, {kk: v.get(kk) for kk in ("launch_us", "frac", "valu_frac", "bound", "traffic", "kernel", "error")})
+PY
