@@ -121,6 +121,13 @@ WORKLOADS = {
                                  delay=0, sequence_length=1, reward_density=0.25, terminal_state_density=0.25, make_denser=False,
                                  transition_noise=0, reward_noise=0, reward_scale=1.0, completely_connected=True,
                                  generate_random_mdp=True, repeats_in_sequences=False, seed=0)),
+    # ... and its commonest continuous shape (ddpg / td3 / sac_move_to_a_point_*: two dimensions, order 1, BOTH noise keys at 0 --
+    # three normals drawn per step for nothing)
+    "c_d2_n0": dict(kind="continuous", envs=65536, alg_bytes_fused=22, alg_bytes_step=22 + 16 + 8,
+                    config=dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=2, action_space_dim=2,
+                                transition_dynamics_order=1, inertia=1, time_unit=1.0, state_space_max=10, action_space_max=1,
+                                target_point=[0, 0], target_radius=0.5, make_denser=True, reward_function="move_to_a_point",
+                                action_loss_weight=0.01, delay=0, reward_scale=1.0, transition_noise=0, reward_noise=0, seed=0)),
     "cfg2_per_env": dict(kind="discrete", envs=8192, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
                          config=dict(state_space_type="discrete", action_space_type="discrete",
                                      state_space_size=8, action_space_size=8, delay=4, sequence_length=3)),
@@ -336,7 +343,8 @@ EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5",
               ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"),   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
               ("d_s50_delay4", "numpy"), ("d_s24_rdist", "numpy"), ("cfg2_per_env", "numpy"),   # (+ the discrete shapes beyond the lean kernel)
               ("img100_all", "numpy"),                                                           # (+ the reference's own image sweep shape)
-              ("d_s8_rn0", "numpy"), ("d_s8_rn0", "philox"))                                     # (+ its commonest discrete shape: noise keys with sigma 0)
+              ("d_s8_rn0", "numpy"), ("d_s8_rn0", "philox"),                                     # (+ its commonest discrete shape: noise keys with sigma 0)
+              ("c_d2_n0", "numpy"), ("c_d2_n0", "philox"))                                       # (+ ... and continuous shape: D = 2, both noise keys 0)
 
 
 def leg_name(workload, rng):

@@ -1447,7 +1447,10 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
     const bool helper = noise && can_help && K >= 16 && (a.N % kBlock) == 0 && !(a.opts & MDPP_OPT_NO_HELPER);
     // Philox: several producer waves per consumer wave when the per-step draw count makes it worth it
     // numpy streams: generator + walker waves (WALK) under the same conditions
-    const bool walk = !PHILOX && helper && D >= 8 && !(a.opts & (MDPP_OPT_NO_TRIO | MDPP_OPT_NO_PARK));
+    // (round 5: D = 2 too -- the shape of every continuous experiment file of the reference, whose noise keys at 0 still draw
+    //  D + 1 normals per step: tests/test_gpu_sweep.py, bench leg c_d2_n0)
+    constexpr bool kWalkD = D >= 8 || D == 2;
+    const bool walk = !PHILOX && helper && kWalkD && !(a.opts & (MDPP_OPT_NO_TRIO | MDPP_OPT_NO_PARK));
     const int nprod = (PHILOX && helper && D >= 8 && !(a.opts & MDPP_OPT_NO_TRIO)) ? kPhiloxProducers : (walk ? 2 : 1);
     if (name_out) {
         snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d>", D,
@@ -1462,7 +1465,7 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
                                dim3(grid), dim3((1 + kPhiloxProducers) * kBlock), 0, s, ap, K, actions, obs, reward, term,
                                trunc, final_obs);
         else if (can_help && helper && walk)
-            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help && D >= 8, GEN, false, (can_help && D >= 8 && !PHILOX) ? 2 : 1>), dim3(grid),
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help && kWalkD, GEN, false, (can_help && kWalkD && !PHILOX) ? 2 : 1>), dim3(grid),
                                dim3(3 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
         else if (can_help && helper)
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN, PHILOX>), dim3(grid),
