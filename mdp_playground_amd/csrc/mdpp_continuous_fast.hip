@@ -173,7 +173,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
     // (three buffers), and wave w writes the block's whole piece of row k0 + w of a group -- 1 KiB of rewards (16 B per lane),
     // 256 B of each flag array (4 B per lane) -- one group LATER, when the other three waves have long staged theirs: per-wave
     // counters (groups staged / groups stored), no barrier (a barrier per group took back most of the gain: 662 -> 641 us).
-    constexpr bool CROWS = MDPP_CONT_ROWS && !HELPER && !K1;
+    // (whole-row stores pay where a step is long: cfg3, D = 12, 610 -> 595 us; at D = 2 the row hand-over between the workgroup's
+    //  waves costs more than the stores it saves -- 320 against 281 us per launch, profiles/r05_ablation_d2.txt)
+    constexpr bool CROWS = MDPP_CONT_ROWS && !HELPER && !K1 && D >= 8;
     static_assert(!K1 || !HELPER, "one step: no helper waves");
     static_assert(!PAR || (K1 && NOISE && !PHILOX), "parallel draws: one step, numpy streams");
     constexpr int kPP = 16;                     // PAR: stream positions evaluated side by side (4 per wave)
@@ -1498,6 +1500,10 @@ bool launch_continuous_fast(const ContinuousArgs &a, int K, const float *actions
                             hipStream_t s, char *name_out) {
     if (!a.fast_ok || (a.opts & MDPP_OPT_NO_CFAST) || (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST))) return false;
 #define MDPP_CF(DD, OO, RR) if (a.D == DD && a.order == OO && a.n_rel == RR) { launch_t<DD, OO, RR>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out); return true; }
+#ifdef MDPP_CF_SHAPES_D2             // (disassembly builds: the reference's sweep shape alone)
+    MDPP_CF(2, 1, 2)
+    return false;
+#endif
     MDPP_CF(12, 1, 4) MDPP_CF(12, 2, 4)
 #ifndef MDPP_CF_SHAPES_MIN          // (resource-usage / ablation builds compile the BASELINE shapes only)
     MDPP_CF(2, 1, 2) MDPP_CF(2, 2, 2) MDPP_CF(4, 1, 4) MDPP_CF(4, 2, 4)

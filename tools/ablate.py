@@ -77,6 +77,7 @@ if __name__ == "__main__":
         build(sys.argv[2], sys.argv[3:])
     else:
         rest = sys.argv[3:]
-        wname = rest.pop(0) if rest and rest[0] in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg2_noise", "grid", "line", "cfg2_irr", "img_cont") else "cfg2"
+        import bench
+        wname = rest.pop(0) if rest and rest[0] in bench.WORKLOADS else "cfg2"
         rng = rest.pop(0) if rest and rest[0] in ("numpy", "philox") else "numpy"
         run(sys.argv[2], wname, rng, rest)
