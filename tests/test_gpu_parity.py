@@ -2464,6 +2464,8 @@ STEP1_CASES = {
                     sequence_length=1, terminal_state_density=0.5, seed=3), dict(autoreset="same_step"), 1024, "k_discrete_step1w<"),
     # polygon pictures: draw + record + render in one kernel (k_image_step1) against the four launches
     "i_cfg4": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="same_step"), 1000, "k_image_step1<NST=7>"),
+    "i_cfg4_bench_size": (dict(__import__("bench").WORKLOADS["cfg4"]["config"]), dict(autoreset="same_step"), 8192, "k_image_step1<NST=7>"),   # (1.6 rounds of waves on the chip)
+    "i_img100_all_bench_size": (dict(__import__("bench").WORKLOADS["img100_all"]["config"]), dict(autoreset="same_step"), 8192, "k_image_step1<WIDE=1>"),
     "i_cfg4_philox_trunc": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="same_step", rng="philox", max_episode_steps=5), 1000, "k_image_step1<NST=7>"),
     "i_cfg4_disabled": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="disabled"), 333, "k_image_step1<NST=7>"),
     "i_cfg4_next_step": (dict(IMG_CFGS["cfg4"], seed=3), dict(autoreset="next_step", max_episode_steps=6), 333, "k_image_step1<NST=7>"),
