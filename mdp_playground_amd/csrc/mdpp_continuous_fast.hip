@@ -29,6 +29,9 @@ namespace mdpp {
 #ifndef MDPP_CAHEAD
 #define MDPP_CAHEAD 4
 #endif
+#ifndef MDPP_CAHEAD_SMALL_D
+#define MDPP_CAHEAD_SMALL_D 4      // noisy rollouts at D <= 4: action rows in flight (Philox streams; numpy streams twice as many)
+#endif
 #ifndef MDPP_CONT_ROWS
 #define MDPP_CONT_ROWS 1           // rewards and flags leave as whole rows of the workgroup (see "whole-row stores" in the kernel)
 #endif
@@ -653,7 +656,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
 #ifdef MDPP_ABL_WK_NOCONS
     if (WALK) return;
 #endif
-    constexpr int kCAhead = NOISE ? kCAheadNoise : kCAheadQuiet;
+    // (round 5: a noisy step at D <= 4 takes 0.8 us, less than a load's round trip -- one row ahead left the consumer waiting for its
+    //  action every step; its step body is small enough to unroll four times)
+    //  (c_d2_n0, us per launch at 1 / 2 / 4 / 8 rows ahead: numpy streams 458 / 426 / 402 / 382, Philox 399 / 365 / 342 / 355)
+    constexpr int kCAhead = NOISE ? (D <= 4 ? (PHILOX ? MDPP_CAHEAD_SMALL_D : 2 * MDPP_CAHEAD_SMALL_D) : kCAheadNoise) : kCAheadQuiet;
     constexpr int V = (D == 2) ? 1 : D / 4;      // 16-byte pieces per action / observation row
     // Several producers per consumer: the consumer wave is the critical path (one dependent chain per step, while
     // the producers have a whole step of slack each), so its instructions go first whenever they are ready
