@@ -93,6 +93,12 @@ WORKLOADS = {
                                    image_representations=True, image_width=100, image_height=100,
                                    image_transforms="shift,scale,rotate,flip", image_scale_range=(0.5, 2),
                                    seed=0)),
+    # ... the arms without the scale transform ("shift", "rotate", "flip", "none": 27 of its 38 image configurations): 64-byte templates
+    "img100_shift": dict(kind="discrete", envs=8192, alg_bytes_fused=10026, alg_bytes_step=10026, fuse_max=64,
+                         config=dict(state_space_type="discrete", action_space_type="discrete",
+                                     state_space_size=8, action_space_size=8, delay=0,
+                                     image_representations=True, image_width=100, image_height=100,
+                                     image_transforms="shift", seed=0)),
     # BASELINE.json configs[4] (per-GPU shard of the 524 288-env job)
     "cfg5": dict(kind="continuous", envs=65536, alg_bytes_fused=102, alg_bytes_step=350,
                  config=dict(state_space_type="continuous", state_space_dim=12,
