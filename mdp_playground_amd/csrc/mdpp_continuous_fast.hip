@@ -1394,7 +1394,9 @@ static bool launch_k1(const ContinuousArgs &a, const float *actions, float *obs,
     constexpr bool ZIG = NOISE && !PHILOX;
     constexpr int WG = ZIG ? kBlock : 64;
     // numpy streams with transition noise: the step's draws side by side (PAR: 64 envs per 256-thread workgroup)
-    if constexpr (ZIG && D + 1 <= 16) {
+    // (D >= 8 only: at D = 2, three draws per step, the four-wave hand-over costs more than the draws it spreads -- c_d2_n0 7.9 us per
+    //  step in a replayed graph against 6.4 for the rollout kernel with K = 1; the sequential one-step form below serves small D)
+    if constexpr (ZIG && D + 1 <= 16 && D >= 8) {
         if (a.has_p_noise && (a.N % 64) == 0 && !(a.opts & MDPP_OPT_NO_HELPER)) {
             if (name_out) {
                 snprintf(name_out, kNameLen, "k_continuous_step1<D=%d,ORDER=%d,NREL=%d,NOISE=%d,GEN=%d,PHILOX=%d,PAR=1>", D, ORDER, NREL, NOISE, GEN, PHILOX);

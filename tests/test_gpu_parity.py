@@ -2486,7 +2486,11 @@ STEP1_CASES = {
     "c_cfg5_numpy_heavy_noise": (dict(_S1_C_CFG5, transition_noise=3.0, reward_noise=1.0, state_space_max=4), dict(autoreset="same_step"), 4096,
                                  "k_continuous_step1<D=12,ORDER=2,NREL=4,NOISE=1,GEN=0,PHILOX=0,PAR=1>"),
     "c_pnoise_only_d2": (dict(gu.CASES["c_default_target_sparse"]["config"], target_point=[0.5, -0.5], seed=3), dict(autoreset="same_step"), 1024,
-                         "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=1,GEN=1,PHILOX=0,PAR=1>"),
+                         "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=1,GEN=1,PHILOX=0,WG=256>"),      # (PAR is for D >= 8: round 5)
+    "c_pnoise_only_d8": (dict(state_space_type="continuous", state_space_dim=8, transition_dynamics_order=1, inertia=1, time_unit=0.5, state_space_max=5,
+                              action_space_max=1, target_point=[0.5] * 8, target_radius=1.0, make_denser=True, reward_function="move_to_a_point",
+                              transition_noise=0.3, seed=3), dict(autoreset="same_step"), 1024,
+                         "k_continuous_step1<D=8,ORDER=1,NREL=8,NOISE=1,GEN=0,PHILOX=0,PAR=1>"),
     "c_cfg5_philox": (_S1_C_CFG5, dict(autoreset="same_step", rng="philox"), 1000, "k_continuous_step1<"),
     "c_boxes": (dict(gu.CASES["c_sparse_term"]["config"], seed=3), dict(autoreset="same_step"), 1000, "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=0,GEN=1"),
     "c_everyn_rnoise": (dict(gu.CASES["c_small_radius_hit"]["config"], seed=3), dict(autoreset="same_step"), 1024, "k_continuous_step1<D=2,ORDER=1,NREL=2,NOISE=1,GEN=1"),
