@@ -25,18 +25,20 @@ def _same(x, y):
     return torch.equal(x.view(torch.int32) if x.dtype.is_floating_point else x, y.view(torch.int32) if y.dtype.is_floating_point else y)
 
 
-@pytest.mark.parametrize("rng", ["numpy", "philox", "numpy-next_step", "numpy-disabled-timelimit"])
+@pytest.mark.parametrize("rng", ["numpy", "philox", "numpy-next_step", "numpy-disabled-timelimit", "numpy-ragged"])
 @pytest.mark.parametrize("name", SWEEP)
 def test_sweep_config_at_scale_specialised_equals_general(name, rng):
     from mdp_playground_amd import _capi as capi
     idx = int(name.rsplit("_x", 1)[-1])
     if rng == "philox" and idx % 4 != 0:
         pytest.skip("Philox streams: every fourth configuration of the sweep")
-    if rng.startswith("numpy-") and idx % 5 != (1 if "next" in rng else 3):
-        pytest.skip("the other autoreset modes: every fifth configuration each")
+    if rng.startswith("numpy-") and idx % 5 != (1 if "next" in rng else 3 if "disabled" in rng else 4):
+        pytest.skip("the other autoreset modes / a ragged batch: every fifth configuration each")
     cfg = gu.case_config(name)
     image = bool(cfg.get("image_representations"))
     N, F = (256, 24) if image else (1024, 48)
+    if "ragged" in rng:                         # (not whole workgroups, a short rollout: the kernels without producer waves)
+        N, F = (250, 9) if image else (1000, 9)
     kw = dict(rng="philox", philox_seed=5) if rng == "philox" else {}
     # (gymnasium's next-step autoreset; no autoreset under a TimeLimit of 9 steps: the kernels' other episode-end forms)
     mode = dict(autoreset="next_step") if "next" in rng else dict(autoreset="disabled", max_episode_steps=9) if "disabled" in rng else dict(autoreset="same_step")
