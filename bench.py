@@ -127,6 +127,12 @@ WORKLOADS = {
                                  delay=0, sequence_length=1, reward_density=0.25, terminal_state_density=0.25, make_denser=False,
                                  transition_noise=0, reward_noise=0, reward_scale=1.0, completely_connected=True,
                                  generate_random_mdp=True, repeats_in_sequences=False, seed=0)),
+    # ... the same with 50 states (dqn_*_50_states: the quiet kernel with the reward-noise draw inside the recurrence)
+    "d_s50_rn0": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42,
+                      config=dict(state_space_type="discrete", action_space_type="discrete", state_space_size=50, action_space_size=50,
+                                  delay=0, sequence_length=1, reward_density=0.25, terminal_state_density=0.25, make_denser=False,
+                                  transition_noise=0, reward_noise=0, reward_scale=1.0, completely_connected=True,
+                                  generate_random_mdp=True, repeats_in_sequences=False, seed=0)),
     # ... and its commonest continuous shape (ddpg / td3 / sac_move_to_a_point_*: two dimensions, order 1, BOTH noise keys at 0 --
     # three normals drawn per step for nothing)
     "c_d2_n0": dict(kind="continuous", envs=65536, alg_bytes_fused=22, alg_bytes_step=22 + 16 + 8,
