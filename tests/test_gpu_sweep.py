@@ -30,8 +30,6 @@ def _same(x, y):
 def test_sweep_config_at_scale_specialised_equals_general(name, rng):
     from mdp_playground_amd import _capi as capi
     idx = int(name.rsplit("_x", 1)[-1])
-    if rng == "philox" and idx % 4 != 0:
-        pytest.skip("Philox streams: every fourth configuration of the sweep")
     if rng.startswith("numpy-") and idx % 5 != (1 if "next" in rng else 3 if "disabled" in rng else 4):
         pytest.skip("the other autoreset modes / a ragged batch: every fifth configuration each")
     cfg = gu.case_config(name)
