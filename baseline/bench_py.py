@@ -67,7 +67,8 @@ def measure(config, kind, seconds_one=10.0, seconds_all=6.0):
                      f"random actions and reset on done (baseline/py_step.py: the reference's step() restated, "
                      f"validated against the reference-generated goldens; reference : restatement speed ratio in "
                      f"profiles/py_baseline_ratio.json, folded into `reference_equivalent`) on 1 host core in {el:.1f} s; "
-                     f"host: {_cpu_model()}, {ncpu} cores"}
+                     f"host: {_cpu_model()}, {ncpu} cores",
+           "sample_short": f"{steps} env-steps, 1 env, Python step() loop (baseline/py_step.py), 1 core, {el:.1f} s; {_cpu_model()}"}
     with mp.get_context("fork").Pool(ncpu) as pool, contextlib.redirect_stdout(io.StringIO()):
         res = pool.map(_worker, [(config, seconds_all, w) for w in range(ncpu)])
     total, wall = sum(r[0] for r in res), max(r[1] for r in res)

@@ -497,6 +497,9 @@ def main():
     ap.add_argument("--only-leg", default=None, choices=["rotating", "replayed"],
                     help="profiling: time only this form of the main workload's launches (no collective, no other legs), so that a "
                     "rocprofv3 --kernel-trace --stats of the run holds ONE leg per kernel (profiles/r04_kernel_stats_<leg>.csv)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="the FULL record (every leg, every repeat, prose) goes to this file; stdout gets the compact contract line only")
+    ap.add_argument("--print-detail", action="store_true", help="also print the full record, prefixed BENCH_DETAIL, before the contract line")
     ap.add_argument("--full-gather-steps", type=int, default=4,
                     help="bench steps of the [K, N_local, ...] all-gather leg (0 = skip)")
     args = ap.parse_args()
@@ -528,17 +531,26 @@ def main():
     if world == 1 and args.workload == "cfg2" and args.rng == "numpy" and not args.no_workloads and not args.disable \
             and args.envs is None:
         extra = list(EXTRA_LEGS)
+    phases, _t_last = {}, [time.perf_counter()]
+
+    def mark(name):                     # wall seconds of each phase of this process (detail record: `timing_s`)
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - _t_last[0], 2)
+        _t_last[0] = now
+
     cpu_py = cpu_py_all = cpu_all = None
     # one rank: now, before this process initialises the GPU (the baselines fork one worker per core).  Several ranks: at the
     # END, from a fresh child of rank 0, after the process group is gone -- not while ranks 1..N-1 wait in the rendezvous for
     # a rank 0 that is busy on every core for half a minute
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
+    mark("cpu_baselines_forked")
     pmc = None
     if rank == 0 and world == 1 and not args.no_pmc:
         specs = [(args.workload, args.rng, N, F)] + [
             (w, r, WORKLOADS[w]["envs"], max(1, min(args.fuse, WORKLOADS[w].get("fuse_max", args.fuse)))) for w, r in extra]
         pmc = live_traffic_all(specs)
+    mark("pmc_passes")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -554,6 +566,7 @@ def main():
         env.set_kernel_options(*args.disable.split(","))
     acts = action_rotation(wl, F, N, device, 12345 + rank)
     NA = len(acts)
+    mark("init")
     # output buffers rotate, so a gather can trail a launch; four with a collective: launch k + 1 must not wait for
     # the gather of launch k - 2, which slips in between two launches (a rollout holds every CU)
     outs = [env.alloc_rollout(F) for _ in range(4 if dist is not None else 2)]
@@ -790,6 +803,7 @@ def main():
                 legs["peer_copy"] = {"error": repr(e)}
     total_steps = world * N * F * args.steps
     value = total_steps / elapsed
+    mark("main_legs")
 
     # ---- roofline of the dominant kernel (fused rollout), per launch: the median repeat
     launch_us = statistics.median(kernel_us_runs)
@@ -828,6 +842,7 @@ def main():
         single = single_step_leg(env, wl, acts[0], N, device)
     env.close()
     del outs, acts
+    mark("single_step")
 
     # ---- the other BASELINE configs under the same clock (one GPU; not part of `value`)
     workloads = None
@@ -847,6 +862,7 @@ def main():
             except Exception as e:          # reported extras, never fatal for the contract line
                 workloads[key] = {"error": repr(e)}
             torch.cuda.empty_cache()
+    mark("workloads")
     if rank == 0:
         peaks = hbm_ceilings(device)
         roofline["peak_measured"] = peaks
@@ -892,6 +908,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and not (
             wl["kind"] == "continuous" and wl["config"].get("image_representations")):
         cpu_port = cpu_baseline(wl)      # (the C port has no timed picture path for continuous envs)
+    mark("cpu_port_and_ceilings")
 
     if rank == 0:
         v_none = legs["none"]["env_steps_per_s"]
@@ -928,9 +945,119 @@ def main():
             "single_step": single, "collective_legs": legs, "workloads": workloads,
             "launches": args.steps, "elapsed_s": elapsed,
         }
-        print(json.dumps(line), flush=True)
+        line["config"]["workload_short"] = (f"{args.workload}: {SHORT.get(args.workload, wl['kind'])}; {N} envs/GPU, random actions, "
+                                            f"same-step autoreset; 1 bench step = 1 fused launch of {F} env steps")
+        line["config"]["collective_short"] = ("none" if v_last is None else
+                                              f"all_gather_into_tensor({backend_used}, {world} rank{'s' if world != 1 else ''}) after every launch")
+        line["timing_s"] = phases
+        emit(line, args.detail_out, args.print_detail)
     if dist is not None and not dist_done:
         dist.destroy_process_group()
+
+
+LINE_MAX_BYTES = 4096       # the driver reads a bounded tail of stdout: the contract line must fit it whole (BENCH_r05: 26 KB, parsed = null)
+
+SHORT = {   # one clause per workload for `config.workload` (the full config dicts are in the detail record)
+    "cfg2": "BASELINE configs[1]: discrete 8x8, delay 4, sequence_length 3",
+    "cfg2_noise": "configs[1] + transition_noise 0.1 + reward_noise 0.1",
+    "cfg3": "BASELINE configs[2]: continuous move_to_a_point, 4 relevant + 8 irrelevant dims, order 1",
+    "cfg4": "BASELINE configs[3]: discrete 8x8, 84x84 polygon pictures, shift + rotate",
+    "cfg5": "BASELINE configs[4] shard: continuous move_to_a_point, order 2, p/r noise 0.05",
+    "img100_all": "discrete 8x8, 100x100 pictures, shift+scale+rotate+flip (the reference's image sweep)",
+    "img100_shift": "discrete 8x8, 100x100 pictures, shift",
+}
+
+
+def _r(x, nd=4):
+    """Numbers of the contract line at 4 significant-ish digits (the detail record keeps every bit)."""
+    if x is None or isinstance(x, (bool, int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{nd}g}") if abs(x) < 1e4 else float(f"{float(x):.6g}")
+    except (TypeError, ValueError):
+        return None
+
+
+def compact_line(full):
+    """The driver's contract line from the full record: every contract key, `roofline` and `cpu_baseline` of the dominant kernel,
+    the single-step figures and ONE short list per extra workload -- [launch_us, frac, valu_frac, traffic / algorithmic bytes,
+    step() launch_us or null].  Prose, per-repeat lists and nested per-leg records stay in the detail record
+    (`detail`: the file it was written to).  Always <= LINE_MAX_BYTES (tests/test_bench_host.py)."""
+    roof = full.get("roofline") or {}
+    cpu = full.get("cpu_baseline") or {}
+    cfg = full.get("config") or {}
+    single = full.get("single_step") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 6), _r(line["ms_per_step"], 6)
+    line["config"] = {"workload": cfg.get("workload_short") or str(cfg.get("workload"))[:160],
+                      "envs_per_gpu": cfg.get("envs_per_gpu"), "fuse": cfg.get("fuse"),
+                      "env_steps_per_bench_step": cfg.get("env_steps_per_bench_step"), "rng": cfg.get("rng"),
+                      "collective": cfg.get("collective_short") or str(cfg.get("collective"))[:80]}
+    line["roofline"] = {"bound": roof.get("bound"), "achieved": _r(roof.get("achieved"), 5), "peak": roof.get("peak"),
+                        "unit": roof.get("unit"), "frac": _r(roof.get("frac")), "traffic": roof.get("traffic"),
+                        "frac_value": _r(roof.get("frac_value")), "frac_replayed": _r(roof.get("frac_replayed")),
+                        "valu_frac": _r(roof.get("valu_frac")), "bound_measured": roof.get("bound_measured"),
+                        "kernel": roof.get("kernel"), "alg_bytes_per_env_step": roof.get("alg_bytes_per_env_step"),
+                        "alg_bytes_per_launch": roof.get("alg_bytes_per_launch"), "launch_us": _r(roof.get("launch_us"), 5),
+                        "traffic_source": "pmc, this run" if "in this run" in str(roof.get("traffic_source")) else roof.get("traffic_source")}
+    if cpu:
+        line["cpu_baseline"] = {"value": _r(cpu.get("value"), 6), "unit": cpu.get("unit"), "cores": cpu.get("cores"),
+                                "kind": cpu.get("kind"), "form": cpu.get("form"), "sample": str(cpu.get("sample_short") or cpu.get("sample"))[:140],
+                                "reference_equivalent": _r(((cpu.get("reference_equivalent") or {}).get("value")), 6)}
+    else:
+        line["cpu_baseline"] = None
+    port = full.get("cpu_baseline_port") or {}
+    line["cpu_baseline_port"] = {"value": _r(port.get("value"), 6), "cores": port.get("cores")} if port.get("value") else None
+    line["value_none"], line["value_last_row"] = _r(full.get("value_none"), 6), _r(full.get("value_last_row"), 6)
+    line["collective_ok"] = full.get("collective_ok")
+    line["single_step"] = {"launch_us_events": _r(single.get("launch_us_events")),
+                           "graph_us_per_step": _r((single.get("graph") or {}).get("us_per_step_events")),
+                           "kernel": single.get("kernel")} if single else None
+    wls = full.get("workloads")
+    if wls:
+        out = {}
+        for k, v in wls.items():
+            if "error" in v:
+                out[k] = "error"
+                continue
+            ratio = (v["traffic"] / v["alg_bytes_per_launch"]) if v.get("traffic") and v.get("alg_bytes_per_launch") else None
+            st = (v.get("single_step") or {}).get("launch_us_events")
+            out[k] = [_r(v.get("launch_us")), _r(v.get("frac"), 3), _r(v.get("valu_frac"), 3), _r(ratio, 3), _r(st, 3)]
+        line["workloads"] = out
+        line["workloads_fields"] = "launch_us, hbm frac, valu_frac, pmc traffic / algorithmic, step() us"
+    line["detail"] = full.get("detail_file")
+    line["launches"], line["elapsed_s"] = full.get("launches"), _r(full.get("elapsed_s"), 6)
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_MAX_BYTES:        # never the case for this file's own legs; a longer `workloads` map goes first
+        for k in ("workloads", "workloads_fields", "single_step", "cpu_baseline_port"):
+            line.pop(k, None)
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) <= LINE_MAX_BYTES:
+                break
+    return s
+
+
+def emit(full, detail_out=None, print_detail=False):
+    """Write the full record to `detail_out`, flush C stdio (RCCL prints its version banner through printf into a
+    buffer that would otherwise land AFTER everything Python printed, at exit), then print the contract line: the LAST line of stdout."""
+    if detail_out:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_out)), exist_ok=True)
+            with open(detail_out, "w") as f:
+                json.dump(full, f)
+            full["detail_file"] = os.path.relpath(detail_out, ROOT) if os.path.abspath(detail_out).startswith(ROOT) else detail_out
+        except OSError:
+            full["detail_file"] = None
+    if print_detail:
+        print("BENCH_DETAIL " + json.dumps(full), flush=True)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
 
 
 def _pmc_blocked():

@@ -287,7 +287,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             cfg->n_rel < 1 || cfg->n_rel > cfg->D || cfg->n_boxes < 0 ||
             // terminal hypercubes: [n_boxes][n_rel] packed into box_lo / box_hi -- as many as fit the arrays (64 at four
             // relevant dimensions); handles with picture observations draw them from an 8-entry list (mdpp_imagec.hip)
-            (cfg->image ? cfg->n_boxes > MDPP_MAX_BOXES : cfg->n_boxes * cfg->n_rel > MDPP_MAX_BOXES * MDPP_MAX_DIM)) {
+            (cfg->image ? cfg->n_boxes > MDPP_MAX_BOXES : cfg->n_boxes > (MDPP_MAX_BOXES * MDPP_MAX_DIM) / cfg->n_rel)) {   // (no int32 product to wrap)
             g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes * n_rel <= 256 (n_boxes <= 8 with image observations)";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
@@ -562,7 +562,10 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
             const uint32_t off_tn = off_bk + 512u;
             const uint32_t off_zig = off_tn + ((c.has_transition_noise && np_streams) ? (uint32_t)S * S8 * 8u : 0u);
             const uint32_t bytes = (off_zig + ((c.has_reward_noise && np_streams) ? 6144u : 0u) + 1023u) & ~1023u;
-            if (bytes <= 12u * 1024u) {
+            // (what the selected instantiation stages: k_discrete_step1w<NZ> holds 12 rounds of 1 KiB in registers, the
+            //  noise-free ones 8 -- a longer blob would leave the tail of the reward table and the buckets unwritten in LDS)
+            const uint32_t max_rounds = (c.has_transition_noise || c.has_reward_noise) ? kS1wRoundsNoise : kS1wRounds;
+            if (bytes <= max_rounds * 1024u) {
                 std::vector<uint8_t> blob(bytes, 0);
                 memcpy(blob.data(), P, S * A);
                 memcpy(blob.data() + off_term, is_term, S);

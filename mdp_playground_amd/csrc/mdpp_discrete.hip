@@ -424,7 +424,7 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     bool ldsenv = !a.shared_tables && a.rew_in_lds && !a.has_p_noise && !a.irr && K >= 8 && env_lds <= 96u * 1024u &&
                   !(a.opts & MDPP_OPT_NO_QUIET);
     bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds) && a.lds_bytes <= 48u * 1024u;
-    if (ldsenv && !name_out) {
+    if (ldsenv) {                       // (also when only the name is asked for: the name is the launch's)
         const void *kern = a.unit_rewards ? (const void *)k_discrete_step<PHILOX, NOISE, true, true, false>
                                           : (const void *)k_discrete_step<PHILOX, NOISE, false, true, false>;
         if (!dynamic_lds_ok(kern, env_lds)) ldsenv = false;

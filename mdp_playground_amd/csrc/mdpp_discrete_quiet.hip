@@ -186,7 +186,8 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     // (S = 50: 56 64-bit compares per draw, 150 vector instructions -- most of the H wave) but through a bucket table over the
     // top 12 bits of the 53-bit draw: s_bk[b] = {thresholds at or below the bucket's first value, thresholds strictly inside it};
     // a draw compares with the few thresholds inside its bucket (none for 99 % of the buckets).  Built here from T0.
-    __shared__ uint16_t s_bk[4096];
+    // (8 KiB of static LDS only in the instantiations that can use it: numpy streams, two or three roles)
+    __shared__ uint16_t s_bk[(!PH && ROLES >= 2) ? 4096 : 1];
     const bool use_bk = !PH && DUO && S8 > 16u;
     if (use_bk) {
         for (uint32_t b = tid; b < 4096u; b += kThreads) {

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void k_discrete_step1(Step1Args a) {
 template <bool OBS64, bool PHILOX, bool UR, bool NZ = false>
 __global__ __launch_bounds__(64) void k_discrete_step1w(Step1Args a) {
     static_assert(!NZ || UR, "noise: unit rewards");
-    constexpr int kRounds = NZ ? 12 : 8;
+    constexpr int kRounds = NZ ? (int)kS1wRoundsNoise : (int)kS1wRounds;
     extern __shared__ __align__(16) uint8_t ldsw[];
     const int tid = threadIdx.x;
     const uint32_t i = blockIdx.x * 64u + tid;
@@ -366,6 +366,7 @@ bool launch_discrete_step1(const DiscreteArgs &d, const Step1Args &proto, const 
     if (!proto.blob || (d.opts & MDPP_OPT_NO_STEP1)) return false;
     if (proto.wide) {                               // state spaces beyond 16 states: k_discrete_step1w
         if (d.philox && (d.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;
+        if (proto.blob_rounds > ((proto.has_p_noise || proto.has_r_noise) ? kS1wRoundsNoise : kS1wRounds)) return false;
         if (name_out) {
             if (proto.has_p_noise || proto.has_r_noise)
                 snprintf(name_out, kNameLen, "k_discrete_step1w<OBS64=%d,PHILOX=%d,UNIT=1,PN=%d,RN=%d>", !d.obs_i32, d.philox, proto.has_p_noise, proto.has_r_noise);

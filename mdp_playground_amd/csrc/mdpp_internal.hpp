@@ -123,6 +123,9 @@ struct DiscreteArgs {
 #ifndef MDPP_S1_REPLICAS
 #define MDPP_S1_REPLICAS 1
 #endif
+// 1 KiB rounds of the wide one-step kernel's table blob that ONE wave stages into its LDS (k_discrete_step1w<NZ>: with a
+// noise key / without): the upload refuses the one-step path for a longer blob, the launcher checks again
+constexpr uint32_t kS1wRounds = 8, kS1wRoundsNoise = 12;
 // copies of the one-step kernels' table blob (power of two), one per group of workgroups.  1: sixteen copies measured the
 // same (S = 50: 4.07 against 4.04 us per step) -- 1 024 waves reading the same 4 KiB is not what made that launch slow, the
 // compiler serialising the blob's loads was (mdpp_discrete_step1.hip)

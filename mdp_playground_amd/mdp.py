@@ -195,8 +195,7 @@ def _common(config, kind, sd):
     every_n = config.get("reward_every_n_steps", L if kind == "discrete" else 1)
     rn = config.get("reward_noise", None)
     if callable(rn):
-        raise NotImplementedError("callable reward_noise runs on the host only; the device path "
-                                  "takes a float std (reference rl_toy_env.py:398-403)")
+        raise NotImplementedError("callable reward_noise is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a float std (reference rl_toy_env.py:398-403)")
     return dict(delay=config.get("delay", 0), sequence_length=L, reward_every_n_steps=every_n,
                 reward_noise=None if rn is None else float(rn),
                 reward_scale=config.get("reward_scale", 1.0),
@@ -374,13 +373,12 @@ def build_discrete(config) -> DiscreteMDP:
 
 def _build_discrete_custom(config) -> DiscreteMDP:
     """use_custom_mdp=True with P and R given as MATRICES (rl_toy_env.py:346-348, :586-587,
-    :859-866, :997-1000 + :617-618, :1232-1236, :1259-1267).  Callables stay on the host: a Python
-    function cannot be restated as a table lookup."""
+    :859-866, :997-1000 + :617-618, :1232-1236, :1259-1267).  Callables are refused (NotImplementedError): a Python
+    function cannot be restated as a table lookup, and there is no host path."""
     _require("transition_function" in config, "use_custom_mdp needs transition_function")   # :347
     _require("reward_function" in config, "use_custom_mdp needs reward_function")           # :348
     if callable(config["transition_function"]) or callable(config["reward_function"]):
-        raise NotImplementedError("use_custom_mdp with callables runs on the host only; the device "
-                                  "path takes transition_function / reward_function as S x A arrays")
+        raise NotImplementedError("use_custom_mdp with callables is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass transition_function / reward_function as S x A arrays")
     if config.get("irrelevant_features", False):
         # the reference wraps the given state_space_size in a one-element list for custom MDPs (:586-587) and then reads
         # state_space_size[1] for the irrelevant sub-space (:685): RLToyEnv.__init__ itself raises IndexError
@@ -402,7 +400,7 @@ def _build_discrete_custom(config) -> DiscreteMDP:
     n_term = int(config.get("terminal_state_density", 0.25) * A)           # :868-870 (A, not S)
     if "terminal_states" in config:                                        # :859-866
         if callable(config["terminal_states"]):
-            raise NotImplementedError("callable terminal_states runs on the host only")
+            raise NotImplementedError("callable terminal_states is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a list of states / hypercube centres")
         terminal = np.asarray(config["terminal_states"], dtype=np.int64).reshape(-1)
         terminal = terminal[(terminal >= 0) & (terminal < S)]              # `s in list`: others never match
     else:
@@ -503,11 +501,11 @@ def build_continuous(config) -> ContinuousMDP:
         target_default = False
     tn = config.get("transition_noise", None)
     if callable(tn):
-        raise NotImplementedError("callable transition_noise runs on the host only")
+        raise NotImplementedError("callable transition_noise is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a float")
     box_lo = box_hi = None
     if "terminal_states" in config:
         if callable(config["terminal_states"]):
-            raise NotImplementedError("callable terminal_states runs on the host only")
+            raise NotImplementedError("callable terminal_states is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a list of states / hypercube centres")
         ts = config["terminal_states"]
         for i, c in enumerate(ts):
             _require(len(c) == len(rel), "Specified terminal state centres should have "
@@ -556,7 +554,7 @@ def build_grid(config) -> GridMDP:
     if common["delay"] != 0 or common["sequence_length"] != 1:
         raise NotImplementedError("the reference's grid reward raises for delay > 0 or sequence_length > 1 (:1949)")
     if callable(config.get("terminal_states")):
-        raise NotImplementedError("callable terminal_states runs on the host only")
+        raise NotImplementedError("callable terminal_states is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a list of states / hypercube centres")
     image = None
     if config.get("image_representations", False):
         # ImageContinuous(feature_space, width, height, term_spaces, target_point, circle_radius=5,
@@ -567,7 +565,7 @@ def build_grid(config) -> GridMDP:
             raise NotImplementedError("at most 8 terminal cells are drawn on the device")
     tn = config.get("transition_noise", None)
     if callable(tn):
-        raise NotImplementedError("callable transition_noise runs on the host only")
+        raise NotImplementedError("callable transition_noise is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a float")
     target = [int(x) for x in config["target_point"]]
     _require(len(target) == 2, "target_point must have one coordinate per grid dimension")
     if max(shape) > 254:

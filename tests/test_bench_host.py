@@ -143,3 +143,62 @@ def test_action_rotation_is_larger_than_the_infinity_cache():
     finally:
         mp.undo()
     assert bench.leg_name("cfg5", "philox") == "cfg5_philox" and bench.leg_name("cfg2", "numpy") == "cfg2"
+
+
+def _canned_full_record():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_driver_argv.json")) as f:
+        return json.load(f)        # round 5's own 26 KB line: the one the driver could not parse
+
+
+def test_contract_line_is_compact_and_complete():
+    """BENCH_r05.json `parsed: null`: the one JSON line had grown to 26 KB.  The contract line is now built from the full
+    record by bench.compact_line: every contract key, `roofline` and `cpu_baseline`, <= 4 KiB -- also when the record holds
+    many more workload legs than today's."""
+    import json
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 20000
+    s = bench.compact_line(full)
+    assert len(s.encode()) <= bench.LINE_MAX_BYTES == 4096 and "\n" not in s
+    line = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["config"]["envs_per_gpu"] == 65536 and line["config"]["fuse"] == 512 and len(line["config"]["workload"]) <= 200
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and abs(r["frac"] - full["roofline"]["frac"]) < 1e-3
+    assert r["traffic"] == full["roofline"]["traffic"] and r["kernel"] == full["roofline"]["kernel"]
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and abs(c["value"] / full["cpu_baseline"]["value"] - 1) < 1e-4 and c["sample"]
+    assert abs(line["value"] / full["value"] - 1) < 1e-4 and abs(line["ms_per_step"] / full["ms_per_step"] - 1) < 1e-4
+    assert set(line["workloads"]) == set(full["workloads"])
+    w = line["workloads"]["img100_all"]
+    assert len(w) == 5 and abs(w[1] - full["workloads"]["img100_all"]["frac"]) < 1e-3 and 1.2 < w[3] < 1.35
+    # four times the legs: optional parts are dropped, the contract keys never
+    big = dict(full, workloads={f"{k}_{i}": v for i in range(8) for k, v in full["workloads"].items()})
+    s2 = bench.compact_line(big)
+    line2 = json.loads(s2)
+    assert len(s2.encode()) <= 4096 and "roofline" in line2 and "cpu_baseline" in line2 and line2["value"] == line["value"]
+
+
+def test_contract_line_is_the_last_line_of_stdout(capfd, tmp_path):
+    """emit(): the full record goes to a file, C stdio is flushed FIRST (RCCL's version banner sits in printf's buffer until
+    exit and used to land after the JSON), and the contract line is the last thing on stdout."""
+    import ctypes
+    import json
+    libc = ctypes.CDLL(None)
+    libc.printf(b"RCCL version : 2.26.6-HEAD:64f48b6\nHostname     : runc\n")     # buffered by C stdio (stdout is not a tty here)
+    full = _canned_full_record()
+    out = tmp_path / "sub" / "bench_detail.json"
+    bench.emit(full, str(out))
+    libc.fflush(None)
+    cap = capfd.readouterr().out
+    lines = [ln for ln in cap.splitlines() if ln.strip()]
+    last = json.loads(lines[-1])
+    assert last["metric"] == "env-steps/sec" and "roofline" in last and "cpu_baseline" in last and len(lines[-1]) <= 4096
+    assert any(ln.startswith("RCCL version") for ln in lines[:-1])
+    assert sum(1 for ln in lines if ln.startswith("{")) == 1              # ONE JSON line
+    detail = json.loads(out.read_text())
+    assert detail["workloads"]["cfg4"]["launch_us_runs"] and last["detail"] == str(out)

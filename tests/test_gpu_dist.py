@@ -17,13 +17,33 @@ def test_rccl_one_rank_sharded_env_equals_plain_env(spawn_fresh):
     assert "RCCL_OK" in r["stdout"]
 
 
+def _contract_line_and_detail(stdout, detail_path):
+    """What the driver reads: ONE JSON line, the LAST line of stdout, <= 4 KiB, with every contract key; the legs, repeats and
+    per-rank records behind it are in the detail file (--detail-out).  Returns the detail record after checking that the
+    line's figures are the record's."""
+    import json
+    out_lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in out_lines if ln.startswith('{"metric"')]
+    assert len(lines) == 1 and out_lines[-1] == lines[0] and len(lines[0].encode()) <= 4096, stdout[-2000:]
+    line = json.loads(lines[0])
+    d = json.loads(open(detail_path).read())
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == d[k], k
+    assert abs(line["value"] / d["value"] - 1) < 1e-4 and abs(line["ms_per_step"] / d["ms_per_step"] - 1) < 1e-4
+    assert line["config"]["envs_per_gpu"] == d["config"]["envs_per_gpu"]
+    assert line["config"]["env_steps_per_bench_step"] == d["config"]["env_steps_per_bench_step"]
+    assert line["roofline"]["bound"] == "hbm" and abs(line["roofline"]["frac"] / d["roofline"]["frac"] - 1) < 1e-3
+    assert line["roofline"]["kernel"] == d["roofline"]["kernel"] and line["cpu_baseline"]["value"] > 0
+    assert line["collective_ok"] == d["collective_ok"]
+    return d
+
+
 @pytest.mark.timeout(900)
-def test_bench_multi_rank_path_with_two_ranks_on_one_gpu(spawn_fresh):
+def test_bench_multi_rank_path_with_two_ranks_on_one_gpu(spawn_fresh, tmp_path):
     """The N > 1 code path of bench.py end to end on hardware: `python -m torch.distributed.run --nproc-per-node 2 bench.py
     --gpus 2` with both ranks on the one GPU of the box (backend gloo -- RCCL refuses two ranks on one device; the one-rank
     RCCL path is the test above).  Checks what the driver reads: ONE JSON line from rank 0, n_gpus 2, value = the leg with
     the all-gather, weak scaling (65 536... here 4 096 envs per rank), the three legs and the max-over-ranks timing."""
-    import json
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -31,12 +51,11 @@ def test_bench_multi_rank_path_with_two_ranks_on_one_gpu(spawn_fresh):
     root = os.path.dirname(HERE)
     argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
             "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-            "--envs", "4096", "--fuse", "64", "--backend", "gloo", "--no-single-step", "--full-gather-steps", "2", "--peer-copy"]
+            "--envs", "4096", "--fuse", "64", "--backend", "gloo", "--no-single-step", "--full-gather-steps", "2", "--peer-copy",
+            "--detail-out", str(tmp_path / "detail.json")]
     r = spawn_fresh(argv, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=800)
     assert r["returncode"] == 0, r["stdout"][-2000:] + "\n" + r["stderr"][-6000:]
-    lines = [ln for ln in r["stdout"].splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, r["stdout"][-2000:]
-    d = json.loads(lines[0])
+    d = _contract_line_and_detail(r["stdout"], tmp_path / "detail.json")
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["envs_per_gpu"] == 4096 and d["config"]["env_steps_per_bench_step"] == 2 * 4096 * 64
     assert set(d["collective_legs"]) == {"none", "last_row", "peer_copy", "full"}
@@ -82,22 +101,20 @@ def _free_port():
 
 
 @pytest.mark.timeout(1500)
-def test_bench_world_8_rehearsal_on_one_gpu(spawn_fresh):
+def test_bench_world_8_rehearsal_on_one_gpu(spawn_fresh, tmp_path):
     """What the driver's SCALE run executes at N = 8, rehearsed with eight ranks on the box's one GPU (backend gloo: RCCL
     refuses several ranks on one device; everything else -- torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE, shards
     keyed by the global env id, barriers, max-over-ranks timing, ONE all-gather per launch, eight hipIpc handles in the
     peer-copy leg, CPU baselines after the process group is gone -- is the N = 8 path).  ONE JSON line, n_gpus 8, per-rank
     diagnostics of all eight ranks, the rank -> device map, no timeouts."""
-    import json
     root = os.path.dirname(HERE)
     argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
             "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2",
-            "--envs", "8192", "--fuse", "64", "--backend", "gloo", "--no-single-step", "--full-gather-steps", "2", "--peer-copy"]
+            "--envs", "8192", "--fuse", "64", "--backend", "gloo", "--no-single-step", "--full-gather-steps", "2", "--peer-copy",
+            "--detail-out", str(tmp_path / "detail.json")]
     r = spawn_fresh(argv, env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=1400)
     assert r["returncode"] == 0, r["stdout"][-2000:] + "\n" + r["stderr"][-6000:]
-    lines = [ln for ln in r["stdout"].splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, r["stdout"][-2000:]
-    d = json.loads(lines[0])
+    d = _contract_line_and_detail(r["stdout"], tmp_path / "detail.json")
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["envs_per_gpu"] == 8192
     assert d["config"]["env_steps_per_bench_step"] == 8 * 8192 * 64
     assert abs(d["value"] - 8 * 8192 * 64 * 4 / d["elapsed_s"]) <= 1e-6 * d["value"]

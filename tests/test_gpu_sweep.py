@@ -82,3 +82,39 @@ def test_sweep_selects_the_specialised_kernels():
     assert all("RN=1" in v[0] for k, v in KERNELS.items() if k[1] == "numpy" and k[0].startswith("d_") and "rollout" in v[0])
     assert all(v[0].startswith("k_continuous_rollout_fast<") for k, v in KERNELS.items() if k[0].startswith("c_") and k[1] in ("numpy", "philox")), "order 3 included (round 5)"
     # (next-step autoreset with noise on numpy streams stays on the general continuous kernel by design: mdpp_capi.hip next_ok)
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+@pytest.mark.parametrize("shape", ["s40_l3_unit", "s32_l2_rdist", "s48_l2_unit", "s30_l2_rdist_delay"])
+def test_wide_one_step_kernel_without_a_noise_key_at_blob_sizes_past_8_kib(shape, rng):
+    """k_discrete_step1w without noise stages 8 rounds of 1 KiB, the upload accepted table blobs of up to
+    12 KiB for every handle -- a noise-free handle with a 9-12 KiB blob (S = A = 40, sequence_length 3; S = A = 32,
+    sequence_length 2 with reward_dist) read the tail of its reward table and its bucket table from unwritten LDS.  No
+    experiment file of the reference has such a shape (they all pass a reward_noise key), so the sweep above never met it.
+    mdpp_step() of these shapes against the general kernel, every env, every output, and the streams' end states."""
+    from mdp_playground_amd import _capi as capi
+    cfg = dict(state_space_type="discrete", action_space_type="discrete", reward_density=0.25, terminal_state_density=0.25,
+               make_denser=False, completely_connected=True, repeats_in_sequences=False, generate_random_mdp=True, seed=3)
+    cfg.update({"s40_l3_unit": dict(state_space_size=40, action_space_size=40, sequence_length=3, delay=1, reward_density=0.05),
+                "s32_l2_rdist": dict(state_space_size=32, action_space_size=32, sequence_length=2, delay=0, reward_dist=[0.01, 1]),
+                "s48_l2_unit": dict(state_space_size=48, action_space_size=48, sequence_length=2, delay=2),
+                "s30_l2_rdist_delay": dict(state_space_size=30, action_space_size=30, sequence_length=2, delay=3,
+                                           reward_dist=[0.01, 1])}[shape])
+    kw = dict(rng="philox", philox_seed=9) if rng == "philox" else {}
+    N = 1024
+    a = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **kw, **cfg)
+    b.set_kernel_options(*capi.OPTIONS)
+    assert b.rollout_kernel_name(1).startswith("k_discrete_step<")
+    g = np.random.default_rng(5)
+    acts = torch.as_tensor(_rand_actions(a, 200, g), device=a.device)
+    for t in range(200):
+        sa, sb = a.step(acts[t]), b.step(acts[t])
+        assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (shape, rng, t, a.rollout_kernel_name(1))
+    ra, rb = a.rollout(acts[:40]), b.rollout(acts[:40])
+    assert all(_same(x, y) for x, y in zip(ra, rb))
+    assert np.array_equal(a.status(), b.status()) and not a.status().any()
+    if rng == "numpy":
+        for s in (capi.STREAM_ENV, capi.STREAM_SPACE):
+            assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s))
+    a.close(); b.close()

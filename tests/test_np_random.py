@@ -194,3 +194,29 @@ def test_philox_noise_index_by_invariant_multiplication_is_the_exact_quotient():
                 top = (w * (M >> 32) + ((w * (M & 0xFFFFFFFF)) >> 32)) >> 32     # the device's two multiplies
                 assert top == (w * (S - 1)) // T == (w * M) >> 64, (p, S, w)
                 assert top <= S - 2
+
+
+def test_ziggurat_tables_one_source_two_copies_equal_numpys():
+    """oracle/ and csrc/ each hold np_ziggurat_tables.inc (the checker must not share files with the product): both are
+    the ONE rendering tools/refgen/extract_ziggurat.py makes, and the constants in them are the ones inside the numpy that is
+    installed here -- so a wrong constant cannot hide by being wrong on both sides."""
+    import importlib.util
+    import os
+    import re
+    import struct
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("extract_ziggurat", os.path.join(root, "tools", "refgen", "extract_ziggurat.py"))
+    z = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(z)
+    texts = [open(os.path.join(root, d)).read() for d in z.DESTS]
+    assert texts[0] == texts[1]
+    ki, wi, fi = z.tables()
+    version = re.search(r"numpy (\S+) ziggurat", texts[0]).group(1)
+    assert texts[0] == z.render(ki, wi, fi, version)
+    # ... and parsed back from the text, bit for bit
+    body = texts[0].split("#define ")
+    got_ki = [int(x, 16) for x in re.findall(r"0x([0-9A-F]{16})ULL", body[1])]
+    got_wi = [float.fromhex(x) for x in re.findall(r"0x[0-9a-f.]+p[-+]\d+", body[2])]
+    got_fi = [float.fromhex(x) for x in re.findall(r"0x[0-9a-f.]+p[-+]\d+", body[3])]
+    assert tuple(got_ki) == tuple(ki) and len(got_ki) == 256
+    assert struct.pack("<256d", *got_wi) == struct.pack("<256d", *wi) and struct.pack("<256d", *got_fi) == struct.pack("<256d", *fi)
