@@ -50,7 +50,7 @@ def _cpu_model():
     return platform.processor() or "unknown"
 
 
-def measure(config, kind, seconds_one=10.0, seconds_all=6.0):
+def measure(config, kind, seconds_one=10.0, seconds_all=3.0, all_cores=True):
     """-> (one-core record, all-core record) in bench.py's cpu_baseline format, or (None, None) when
     this config has no pure-Python baseline (grid, move_along_a_line, image observations)."""
     import contextlib
@@ -69,6 +69,8 @@ def measure(config, kind, seconds_one=10.0, seconds_all=6.0):
                      f"profiles/py_baseline_ratio.json, folded into `reference_equivalent`) on 1 host core in {el:.1f} s; "
                      f"host: {_cpu_model()}, {ncpu} cores",
            "sample_short": f"{steps} env-steps, 1 env, Python step() loop (baseline/py_step.py), 1 core, {el:.1f} s; {_cpu_model()}"}
+    if not all_cores:
+        return one, None
     with mp.get_context("fork").Pool(ncpu) as pool, contextlib.redirect_stdout(io.StringIO()):
         res = pool.map(_worker, [(config, seconds_all, w) for w in range(ncpu)])
     total, wall = sum(r[0] for r in res), max(r[1] for r in res)

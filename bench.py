@@ -140,9 +140,14 @@ WORKLOADS = {
                                 transition_dynamics_order=1, inertia=1, time_unit=1.0, state_space_max=10, action_space_max=1,
                                 target_point=[0, 0], target_radius=0.5, make_denser=True, reward_function="move_to_a_point",
                                 action_loss_weight=0.01, delay=0, reward_scale=1.0, transition_noise=0, reward_noise=0, seed=0)),
-    "cfg2_per_env": dict(kind="discrete", envs=8192, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
+    # (65 536 envs since round 6: 8 192 lanes are 128 waves on 1 024 SIMDs -- that leg timed an empty chip; the 8 192-env figure
+    #  stays beside it as cfg2_per_env_8k)
+    "cfg2_per_env": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
                          config=dict(state_space_type="discrete", action_space_type="discrete",
                                      state_space_size=8, action_space_size=8, delay=4, sequence_length=3)),
+    "cfg2_per_env_8k": dict(kind="discrete", envs=8192, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
+                            config=dict(state_space_type="discrete", action_space_type="discrete",
+                                        state_space_size=8, action_space_size=8, delay=4, sequence_length=3)),
     # SURVEY.md §8f rank 2 (not a BASELINE config): the reference's test_grid_env shape, 65 536 envs
     "grid": dict(kind="grid", envs=65536, alg_bytes_fused=30, alg_bytes_step=62,
                  config=dict(state_space_type="grid", grid_shape=(8, 8), reward_function="move_to_a_point",
@@ -192,7 +197,7 @@ def make_actions(wl, K, N, device, seed):
     return (torch.rand((K, N, D), generator=g, device=device, dtype=torch.float32) * 2 - 1) * amax
 
 
-def cpu_baseline(wl, seconds=12.0):
+def cpu_baseline(wl, seconds=6.0):
     """The oracle (a scalar C port of the reference step(), oracle/mdpp_oracle.c) timed on ONE
     host core over a bounded sample of the same workload: 64 env instances stepped with random
     actions and reset-on-done until ~`seconds` of CPU time have been spent."""
@@ -280,7 +285,7 @@ def _cpu_worker(args):
     return steps, time.perf_counter() - t0
 
 
-def cpu_baseline_all_cores(wl_name, seconds=4.0):
+def cpu_baseline_all_cores(wl_name, seconds=2.0):
     """Same C port, one process per host core (discrete workloads), embarrassingly parallel."""
     import contextlib
     import io
@@ -355,7 +360,7 @@ EXTRA_LEGS = (("cfg2", "philox"), ("cfg3", "numpy"), ("cfg4", "numpy"), ("cfg5",
               ("cfg2_noise", "numpy"), ("cfg2_noise", "philox"),   # (+ cfg2 with both noises, reference-exact streams and the north_star RNG)
               ("d_s50_delay4", "numpy"), ("d_s24_rdist", "numpy"), ("cfg2_per_env", "numpy"),   # (+ the discrete shapes beyond the lean kernel)
               ("img100_all", "numpy"),                                                           # (+ the reference's own image sweep shape)
-              ("d_s8_rn0", "numpy"), ("d_s8_rn0", "philox"),                                     # (+ its commonest discrete shape: noise keys with sigma 0)
+              ("d_s8_rn0", "numpy"), ("d_s8_rn0", "philox"), ("d_s50_rn0", "numpy"),                                    # (+ its commonest discrete shape: noise keys with sigma 0)
               ("c_d2_n0", "numpy"), ("c_d2_n0", "philox"))                                       # (+ ... and continuous shape: D = 2, both noise keys 0)
 
 
@@ -363,11 +368,38 @@ def leg_name(workload, rng):
     return workload if rng == "numpy" else f"{workload}_{rng}"
 
 
+PER_ENV_CACHE = "/tmp/mdpp_bench_per_env_%d_%d.pkl"       # (pid of the bench process, envs)
+
+
+def prebuild_per_env(wl, N, cache_pid=None):
+    """The N different MDPs of a `per_env_mdps` workload, built by a pool of forked workers BEFORE this process touches the GPU
+    (mdp.build_many) and pickled for the PMC child, which runs under rocprofv3 and must not fork."""
+    import pickle
+    from mdp_playground_amd import mdp as mdp_mod
+    mdps = mdp_mod.build_many(wl["config"], range(N))
+    wl["_mdps"] = mdps
+    if cache_pid is not None:
+        try:
+            with open(PER_ENV_CACHE % (cache_pid, N), "wb") as f:
+                pickle.dump(mdps, f, protocol=pickle.HIGHEST_PROTOCOL)
+        except OSError:
+            pass
+    return mdps
+
+
 def make_env(wl, N, device, rng, **kw):
     """The workload's batched env (`per_env_mdps`: env i is built from seed i -- N different MDPs, tables per env)."""
     from mdp_playground_amd import RLToyVectorEnv
     if wl.get("per_env_mdps"):
-        return RLToyVectorEnv(seeds=list(range(N)), device=device, rng=rng, autoreset="same_step", **kw, **wl["config"])
+        mdps = wl.get("_mdps")
+        if mdps is None or len(mdps) != N:
+            mdps = None
+            cache = PER_ENV_CACHE % (int(os.environ.get("MDPP_BENCH_PID", "0")), N)
+            if os.path.exists(cache):       # (the PMC child: what the bench process built)
+                import pickle
+                with open(cache, "rb") as f:
+                    mdps = pickle.load(f)
+        return RLToyVectorEnv(seeds=list(range(N)), mdps=mdps, device=device, rng=rng, autoreset="same_step", **kw, **wl["config"])
     return RLToyVectorEnv(num_envs=N, device=device, rng=rng, autoreset="same_step", **kw, **wl["config"])
 
 
@@ -483,8 +515,11 @@ def main():
                     "e.g. NO_HELPER): take specialised kernels out of the dispatch, for A/B timings")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-step", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baselines on every host core (extras `cpu_baseline_all_cores`, "
+                    "`cpu_baseline_port_all_cores`; + ~10 s)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live PMC traffic measurement (two child rocprofv3 runs)")
     ap.add_argument("--cpu-baselines-only", default=None, metavar="WORKLOAD", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", nargs=2, default=None, metavar=("SPECS_JSON", "OUT"), help=argparse.SUPPRESS)
     ap.add_argument("--peer-copy", action="store_true", help="also time the hipIpc peer-copy gather (mdpp_peer_*) beside the RCCL leg; "
                     "runs last, never `value`")
     ap.add_argument("--no-collective", action="store_true", help="one-GPU runs: no RCCL group, `value` = the leg without a collective")
@@ -505,8 +540,13 @@ def main():
     args = ap.parse_args()
 
     if args.cpu_baselines_only:       # a child of rank 0 of a multi-rank run (fresh process, never touches the GPU)
-        cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.cpu_baselines_only)
+        cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.cpu_baselines_only, args.cpu_all_cores)
         print("CPU_BASELINES " + json.dumps({"cpu_py": cpu_py, "cpu_py_all": cpu_py_all, "cpu_all": cpu_all}), flush=True)
+        return
+    if args.pmc_child:                # a child of rank 0 (never touches the GPU itself: it starts the rocprofv3 passes), beside the CPU baselines
+        res = live_traffic_all([tuple(x) for x in json.loads(args.pmc_child[0])])
+        with open(args.pmc_child[1], "w") as f:
+            json.dump(res, f)
         return
     # preflight: RCCL refuses two ranks on one device -- say so in one line instead of hanging in the rendezvous
     # (torch.cuda.device_count() does not initialise the GPU runtime on this image)
@@ -542,15 +582,53 @@ def main():
     # one rank: now, before this process initialises the GPU (the baselines fork one worker per core).  Several ranks: at the
     # END, from a fresh child of rank 0, after the process group is gone -- not while ranks 1..N-1 wait in the rendezvous for
     # a rank 0 that is busy on every core for half a minute
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload)
-    mark("cpu_baselines_forked")
-    pmc = None
-    if rank == 0 and world == 1 and not args.no_pmc:
+    # The PMC passes (child rocprofv3 runs of tools/pmc_workloads.py: counters, not times) run BESIDE the CPU baselines, started by
+    # a child of their own -- this process has not touched the GPU yet and the two do not share anything that is timed
+    # (the GPU is idle while the host cores are timed; BENCH_r05: 89 s of driver time for a 2.4 ms timed region).
+    pmc, pmc_proc, pmc_out = None, None, None
+    per_env_cached = []
+    for w, r in ([(args.workload, args.rng)] + extra) if rank == 0 else []:        # N different MDPs per env: built by forked workers, now
+        if WORKLOADS[w].get("per_env_mdps") and "_mdps" not in WORKLOADS[w]:
+            n_ = N if w == args.workload else WORKLOADS[w]["envs"]
+            prebuild_per_env(WORKLOADS[w], n_, os.getpid())
+            per_env_cached.append(PER_ENV_CACHE % (os.getpid(), n_))
+    mark("per_env_mdps")
+    if rank == 0 and world == 1 and not args.no_pmc and not _pmc_blocked():
+        import subprocess
+        import tempfile
         specs = [(args.workload, args.rng, N, F)] + [
             (w, r, WORKLOADS[w]["envs"], max(1, min(args.fuse, WORKLOADS[w].get("fuse_max", args.fuse)))) for w, r in extra]
-        pmc = live_traffic_all(specs)
-    mark("pmc_passes")
+        fd, pmc_out = tempfile.mkstemp(prefix="mdpp_pmc_", suffix=".json", dir="/tmp")
+        os.close(fd)
+        pmc_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--pmc-child", json.dumps(specs), pmc_out],
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True,
+                                    env=dict(os.environ, MDPP_BENCH_PID=str(os.getpid())))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_py, cpu_py_all, cpu_all = cpu_baselines_forked(args.workload, args.cpu_all_cores)
+    mark("cpu_baselines_forked")
+    if pmc_proc is not None:
+        try:
+            pmc_proc.wait(timeout=400)
+            with open(pmc_out) as f:
+                pmc = json.load(f)
+        except Exception:               # (a reported extra: the line then carries the committed traffic record)
+            import signal
+            try:
+                os.killpg(pmc_proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            pmc = None
+        finally:
+            try:
+                os.unlink(pmc_out)
+            except OSError:
+                pass
+    mark("pmc_passes_wait")
+    for f_ in per_env_cached:
+        try:
+            os.unlink(f_)
+        except OSError:
+            pass
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -897,7 +975,8 @@ def main():
     if rank == 0 and world > 1 and not args.no_cpu_baseline:
         import subprocess
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baselines-only", args.workload],
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baselines-only", args.workload] +
+                               (["--cpu-all-cores"] if args.cpu_all_cores else []),
                                capture_output=True, text=True, timeout=600)
             got = [ln for ln in r.stdout.splitlines() if ln.startswith("CPU_BASELINES ")]
             rec = json.loads(got[-1][len("CPU_BASELINES "):])
@@ -1110,7 +1189,7 @@ def live_traffic_all(specs, launches=3, timeout=300):
     try:
         # (third pass: vector instructions issued -- the second roofline of the kernels that are issue-bound, SURVEY.md 8d
         #  "secondary ceilings"; a failure of THIS pass only drops `valu_frac`)
-        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        for counter in PMC_PASSES:
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "tools", "pmc_workloads.py"), str(launches)] + \
@@ -1165,6 +1244,9 @@ def live_traffic(workload, rng, N, F, launches=3, timeout=75):
     return None if rec is None else (rec["bytes_per_launch"], rec["kernels"], rec["note"])
 
 
+# (one rocprofv3 pass per counter: FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md); SQ_INSTS_VALU rides in a
+#  third -- the three run beside the CPU baselines since round 6, so the third pass is no longer on the driver's clock)
+PMC_PASSES = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")
 VALU_CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md); a wave64 vector instruction holds its SIMD for >= 4 cycles
 N_SIMDS = 1024              # 256 CUs x 4 SIMDs
 
@@ -1298,19 +1380,19 @@ def fold_reference_ratio(rec, workload):
     return rec
 
 
-def cpu_baselines_forked(workload):
+def cpu_baselines_forked(workload, all_cores=False):
     """Everything that forks worker processes (must run before this process initialises the GPU):
-    the pure-Python restatement on 1 core and on all cores, and the C port on all cores."""
+    the pure-Python restatement on 1 core and (all_cores) on all cores, and the C port on all cores."""
     wl = WORKLOADS[workload]
     cpu_py = cpu_py_all = cpu_all = None
     try:
         from baseline import bench_py
-        cpu_py, cpu_py_all = bench_py.measure(wl["config"], wl["kind"])
+        cpu_py, cpu_py_all = bench_py.measure(wl["config"], wl["kind"], all_cores=all_cores)
         cpu_py, cpu_py_all = fold_reference_ratio(cpu_py, workload), fold_reference_ratio(cpu_py_all, workload)
     except Exception as e:          # a reported extra, never fatal
         cpu_py = None
         cpu_py_all = {"error": repr(e)}
-    if (wl["kind"] == "discrete" and not wl["config"].get("image_representations")
+    if (all_cores and wl["kind"] == "discrete" and not wl["config"].get("image_representations")
             and not wl["config"].get("irrelevant_features")):
         try:
             cpu_all = cpu_baseline_all_cores(workload)

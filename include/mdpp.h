@@ -91,7 +91,9 @@ enum { MDPP_OPT_NO_PIPE = 1u << 0,         /* discrete: no three-role k_discrete
        MDPP_OPT_NO_PHILOX_FAST = 1u << 12, /* Philox handles: general kernels only */
        MDPP_OPT_NO_LEAN = 1u << 13,        /* discrete: no k_discrete_rollout_lean (S <= 8 re-encoding of _pipe) */
        MDPP_OPT_NO_IMG_NEARTAB = 1u << 14, /* polygon images: k_image_obs_fast walks the bounding box instead of the near-dword table */
-       MDPP_OPT_NO_STEP1 = 1u << 15        /* mdpp_step (K = 1): the rollout kernels with K = 1 instead of k_discrete_step1 / k_continuous_step1 */ };
+       MDPP_OPT_NO_STEP1 = 1u << 15,       /* mdpp_step (K = 1): the rollout kernels with K = 1 instead of k_discrete_step1 / k_continuous_step1 */
+       MDPP_OPT_NO_SIGMA0 = 1u << 16       /* noise keys present with sigma 0 (the reference draws rng.normal(0, 0): rl_toy_env.py:398-403, :1982):
+                                              form the normals' values anyway instead of advancing the streams alone */ };
 
 /* what a discrete env's reward table is keyed by */
 enum { MDPP_REWARD_SEQUENCES = 0,     /* the last L states (rewardable_sequences, rl_toy_env.py:1837-1841) */

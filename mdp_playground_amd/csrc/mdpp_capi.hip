@@ -55,7 +55,7 @@ static void free_all(mdpp_env *h) {
                     h->d_state, h->d_ring, h->d_status, h->d_sd, h->d_cur, h->d_meta, h->d_rng_half,
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
-                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off,
+                    h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_line_ws, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off,
                     h->d_img_near, h->d_s1_blob};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
@@ -106,7 +106,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_P = h->d_rtable = h->d_rbits = h->d_is_term = h->d_init_cdf = h->d_noise_cdf = nullptr;
     h->d_state = h->d_ring = h->d_status = h->d_sd = h->d_cur = h->d_meta = h->d_rng_half = nullptr;
     h->d_P1 = h->d_init_cdf1 = h->d_noise_cdf1 = h->d_irr_state = nullptr;
-    h->d_line_hist = h->d_ring64 = nullptr;
+    h->d_line_hist = h->d_line_ws = h->d_ring64 = nullptr;
     h->d_est_cur = h->d_est_last = nullptr; h->est_nk = 0;
     h->irr_ready = false;
     h->line_hist_stale = false;
@@ -293,8 +293,8 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         const bool line = cfg->reward_function == MDPP_CREWARD_MOVE_ALONG_A_LINE;
         if ((cfg->reward_function != MDPP_CREWARD_MOVE_TO_A_POINT && !line) ||
-            (line && (cfg->n_rel > 8 || (cfg->n_rel > 4 && cfg->D > 12) || cfg->L < 1 || cfg->L > 64 || cfg->image))) {
-            g_create_err = "mdpp_create: move_along_a_line needs n_rel <= 8 (state_space_dim <= 12 beyond 4), 1 <= L <= 64 and no image observations";
+            (line && (cfg->L < 1 || cfg->L > 64 || cfg->image))) {
+            g_create_err = "mdpp_create: move_along_a_line needs 1 <= L <= 64 and no image observations";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         const size_t D = (size_t)cfg->D;
@@ -307,8 +307,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             }
         }
         const bool rew64 = line || (cfg->target_f64 && cfg->make_denser);
-        const size_t line_nl = cfg->n_rel > 4 ? 8 : 4;          // row width of the history of relevant coordinates
+        // (more than 8 relevant dimensions, or 5 to 8 of more than 12: the fit's matrices in an HBM workspace, rows as wide as n_rel)
+        const bool line_big = line && (cfg->n_rel > 8 || (cfg->n_rel > 4 && cfg->D > 12));
+        const size_t line_nl = line_big ? (size_t)cfg->n_rel : cfg->n_rel > 4 ? 8 : 4;   // row width of the history of relevant coordinates
         if (line) TRY(alloc_zero(h, &h->d_line_hist, (size_t)cfg->L * line_nl * N * sizeof(float)));
+        if (line_big) TRY(alloc_zero(h, &h->d_line_ws, (size_t)(2 * cfg->n_rel * cfg->n_rel + 3 * cfg->n_rel) * N * sizeof(double)));
         if (rew64 && cfg->delay > 0) TRY(alloc_zero(h, &h->d_ring64, (size_t)cfg->delay * N * sizeof(double)));
         TRY(alloc_zero(h, &h->d_sd, (size_t)(cfg->order + 1) * D * N * sizeof(float)));
         TRY(alloc_zero(h, &h->d_cur, D * N * sizeof(float)));
@@ -374,7 +377,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
         a.ring = (uint32_t *)h->d_ring;
-        a.line_L = line ? cfg->L : 0; a.line_NL = cfg->n_rel > 4 ? 8 : 4; a.line_hist = (float *)h->d_line_hist; a.ring64 = (double *)h->d_ring64;
+        a.line_L = line ? cfg->L : 0; a.line_NL = (int32_t)line_nl; a.line_hist = (float *)h->d_line_hist; a.line_ws = (double *)h->d_line_ws; a.ring64 = (double *)h->d_ring64;
         a.target64 = cfg->target_f64 ? 1 : 0; a.rew64 = rew64 ? 1 : 0; a.radius = cfg->target_radius;
         a.est = mdpp::EpisodeStatsDev{(double *)h->d_est_cur, (double *)h->d_est_last, h->est_nk};
         if (cfg->episode_stats) a.fast_ok = 0;

@@ -113,10 +113,10 @@ __device__ __forceinline__ void c_line_put(const ContinuousArgs &a, long i, uint
                                            float4 *lds_line = nullptr) {
     const uint32_t slot = s % (uint32_t)a.line_L;
     const size_t NL = (size_t)a.line_NL;
-    float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        if (j < DMAX && j < a.n_rel) { v[j] = rel[j < DMAX ? j : 0]; a.line_hist[((size_t)slot * NL + j) * a.N + i] = v[j]; }
+    for (int j = 0; j < DMAX; j++)
+        if (j < a.n_rel) { if (j < 4) v[j < 4 ? j : 0] = rel[j]; a.line_hist[((size_t)slot * NL + j) * a.N + i] = rel[j]; }
     if (lds_line) lds_line[slot * kBlock + threadIdx.x] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -341,6 +341,124 @@ __device__ __forceinline__ double c_line_reward(const ContinuousArgs &a, long i,
             next_pt();
             total += dist_of(x);
         }
+    }
+    return 0.0 + -total / (double)L;
+}
+
+// The same fit for MORE than 8 relevant dimensions (or 5 to 8 of more than 12 state dimensions) -- the reference has no limit
+// (:1865-1910): an n x n float64 scatter matrix does not fit a lane's registers beyond n = 8, so the two matrices of the
+// squaring iteration, the column sums and the mean live in a per-env HBM workspace (ContinuousArgs::line_ws,
+// [(2 n n + 3 n)][N] doubles, coalesced over envs; L2-resident while a lane works on it) and every loop runs over the
+// handle's n.  The arithmetic -- summation orders, explicit FMAs, the stopping rule -- is c_line_reward's, statement by
+// statement; only where the operands live differs.  No speed claim: a fit of n = 32, L = 64 is ~10^5 memory operations per
+// env step; the reference's experiments stop at 4 dimensions.
+__device__ __forceinline__ double c_line_reward_big(const ContinuousArgs &a, long i, uint32_t steps) {
+    const int L = a.line_L, n = a.n_rel;
+    const size_t N = (size_t)a.N, NL = (size_t)a.line_NL, nn_ = (size_t)n * n;
+    double *const W0 = a.line_ws + i, *const W1 = W0 + nn_ * N, *const S1 = W1 + nn_ * N, *const MEAN = S1 + (size_t)n * N,
+                 *const VV = MEAN + (size_t)n * N;
+    const uint32_t slot0 = (steps + 1u) % (uint32_t)L;
+    auto pt = [&](int k, int j) -> float {             // coordinate j of the k-th oldest of the L newest states
+        uint32_t slot = slot0 + (uint32_t)k;
+        slot = slot >= (uint32_t)L ? slot - (uint32_t)L : slot;
+        return a.line_hist[((size_t)slot * NL + j) * N + i];
+    };
+    // (1) the float32 mean, numpy's pairwise order (see c_line_reward); column sums and raw moments in float64, point by point
+    for (int j = 0; j < n; j++) {
+        float mean = 0.0f;
+        int k = 0;
+        if (L >= 8) {
+            float r[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) r[q] = pt(q, j);
+            for (k = 8; k < L - (L % 8); k += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) r[q] += pt(k + q, j);
+            }
+            mean = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        }
+        for (; k < L; k++) mean += pt(k, j);
+        mean = mean / (float)L;
+        double s1 = 0.0;
+        for (int kk = 0; kk < L; kk++) s1 += (double)pt(kk, j);
+        S1[(size_t)j * N] = s1;
+        MEAN[(size_t)j * N] = (double)mean;
+    }
+    double tr = 0.0;
+    for (int p = 0; p < n; p++)
+        for (int q = p; q < n; q++) {
+            double acc = 0.0;
+            for (int k = 0; k < L; k++) acc = fma((double)pt(k, p), (double)pt(k, q), acc);
+            const double mp = MEAN[(size_t)p * N], mq = MEAN[(size_t)q * N];
+            acc = acc - mp * S1[(size_t)q * N] - S1[(size_t)p * N] * mq + (double)L * mp * mq;
+            W0[((size_t)p * n + q) * N] = acc;
+            W0[((size_t)q * n + p) * N] = acc;
+            if (q == p) tr += acc;
+        }
+    for (int p = 0; p < n; p++) VV[(size_t)p * N] = p == 0 ? 1.0 : 0.0;     // all points equal: LAPACK's identity, vv[0] = e0
+    if (tr > 0.0) {
+        auto pow2_inv = [](double t) __attribute__((always_inline)) -> double {
+            const uint64_t e = ((uint64_t)__double_as_longlong(t) >> 52) & 0x7FFu;
+            return __longlong_as_double((long long)((2046ull - e - 1ull) << 52));
+        };
+        double sc = pow2_inv(tr);
+        for (size_t e = 0; e < nn_; e++) W0[e * N] *= sc;
+        tr *= sc;
+        double *m = W0, *sq = W1;
+        for (int it = 0; it < 40; it++) {
+            double tr2 = 0.0;
+            for (int p = 0; p < n; p++)
+                for (int q = p; q < n; q++) {
+                    double acc = 0.0;
+                    for (int r = 0; r < n; r++) acc = fma(m[((size_t)p * n + r) * N], m[((size_t)r * n + q) * N], acc);
+                    sq[((size_t)p * n + q) * N] = acc;
+                    if (q == p) tr2 += acc;
+                }
+            const bool conv = (tr * tr - tr2) <= 2e-12 * tr * tr;
+            sc = pow2_inv(tr2);
+            for (int p = 0; p < n; p++)
+                for (int q = p; q < n; q++) {
+                    const double v = sq[((size_t)p * n + q) * N] * sc;
+                    sq[((size_t)p * n + q) * N] = v;
+                    sq[((size_t)q * n + p) * N] = v;
+                }
+            tr = tr2 * sc;
+            double *t = m; m = sq; sq = t;
+            if (__builtin_amdgcn_ballot_w64(!conv) == 0) break;
+        }
+        int bq = 0;
+        double best = m[0];
+        for (int q = 1; q < n; q++) {
+            const double d = m[((size_t)q * n + q) * N];
+            if (d > best) { best = d; bq = q; }
+        }
+        double nn = 0.0;
+        for (int p = 0; p < n; p++) { const double c = m[((size_t)p * n + bq) * N]; nn += c * c; }
+        const double s = 1.0 / sqrt(nn);
+        for (int p = 0; p < n; p++) VV[(size_t)p * N] = m[((size_t)p * n + bq) * N] * s;
+    }
+    // line_end_pts = vv[0] * [-1, 1][:, None] + data_mean; ptA into S1's place, ab into VV's
+    double nab = 0.0;
+    for (int j = 0; j < n; j++) {
+        const double vj = (double)(float)VV[(size_t)j * N], mj = MEAN[(size_t)j * N];
+        const double pa = vj * -1.0 + mj, ab = pa - (vj * 1.0 + mj);
+        S1[(size_t)j * N] = pa;
+        VV[(size_t)j * N] = ab;
+        nab = fma(ab, ab, nab);
+    }
+    const bool degenerate = sqrt(nab) < 1e-13;
+    const double inv_nab2 = 1.0 / nab;
+    double total = 0.0;
+    for (int k = 0; k < L; k++) {
+        double dot = 0.0, nap = 0.0;
+        for (int j = 0; j < n; j++) {
+            const double ap = S1[(size_t)j * N] - (double)pt(k, j);
+            dot = fma(VV[(size_t)j * N], ap, dot);
+            nap = fma(ap, ap, nap);
+        }
+        double sqd = nap - (dot * dot) * inv_nab2;
+        sqd = sqd < 0.0 ? 0.0 : sqd;
+        total += degenerate ? 0.0 : sqrt(sqd);
     }
     return 0.0 + -total / (double)L;
 }
@@ -595,7 +713,8 @@ __global__ __launch_bounds__(kBlock) void k_continuous_step(ContinuousArgs a, in
             c_line_put<DMAX>(a, i, steps, rel, lds_line);
             r.v = 0.0;
             if (steps >= (uint32_t)a.line_L) {
-                if constexpr (NL == 4) r.v = a.line_L <= 16 ? c_line_reward<true, 4>(a, i, steps, lds_line) : c_line_reward<false, 4>(a, i, steps);
+                if constexpr (NL == 4) r.v = a.line_ws ? c_line_reward_big(a, i, steps)
+                                                       : a.line_L <= 16 ? c_line_reward<true, 4>(a, i, steps, lds_line) : c_line_reward<false, 4>(a, i, steps);
                 else r.v = c_line_reward<false, NL>(a, i, steps);
             }
             r.is32 = false;
@@ -756,7 +875,7 @@ static void launch_step_t(const ContinuousArgs &a, int K, const float *actions, 
     }
     // move_along_a_line with L <= 16 (rows of 4), rollouts: the L points of every lane mirrored in (dynamic) LDS for the launch
     ContinuousArgs al = a;
-    al.line_lds = (NL == 4 && a.line_L > 0 && a.line_L <= 16 && K >= 4) ? 1 : 0;
+    al.line_lds = (NL == 4 && !a.line_ws && a.line_L > 0 && a.line_L <= 16 && K >= 4) ? 1 : 0;
     size_t lds = al.line_lds ? (size_t)a.line_L * kBlock * sizeof(float4) : 0;
     const void *kern = a.philox ? (const void *)k_continuous_step<DMAX, OMAX, true, NL> : (const void *)k_continuous_step<DMAX, OMAX, false, NL>;
     if (!dynamic_lds_ok(kern, lds)) { al.line_lds = 0; lds = 0; }        // (no room: the points stay in HBM)
@@ -855,7 +974,7 @@ int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs,
         h->tick += (uint64_t)K;
         return MDPP_OK;
     }
-    if (a.line_L && a.line_NL == 8) {
+    if (a.line_L && a.line_NL == 8 && !a.line_ws) {
         if (!launch_continuous_step_line8(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out)) {
             h->err = "k_continuous_step<NL=8>: move_along_a_line with 5 to 8 relevant dimensions needs state_space_dim <= 12";
             return MDPP_EUNSUPPORTED;

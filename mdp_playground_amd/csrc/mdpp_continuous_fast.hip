@@ -218,6 +218,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
     if (i >= (uint32_t)a.N) return;             // HELPER launches require N % kBlock == 0
     const uint32_t N = (uint32_t)a.N;
     const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)
+    // Z0 (WALK; round 6): every noise key that is present has sigma 0 -- what the reference's continuous experiment files pass
+    // (transition_noise: 0, reward_noise: 0), and the reference still draws rng.normal(0, 0, ...) per step (rl_toy_env.py:
+    // 398-403, :1682-1691, :1980-1987).  numpy forms loc + scale * z = 0.0 + 0.0 z = +0.0 whatever z is (0.0 + -0.0 = +0.0), so
+    // the noise term IS +0.0: only the stream's advance -- how many words each ziggurat draw consumes -- is left of the draws.
+    // The walker then makes the accept decisions alone (no rabs * wi, no sign, no normals ring), and the consumer neither waits
+    // for the walker nor reads a normal: normal() returns 0.0 and 0.0 + sigma * 0.0 is the same +0.0.
+    const bool z0 = WALK && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
     // this step's normals, PHILOX: P-noise of dimension d at [d], reward noise at [D]
     auto philox_step = [&](int k, float (&z)[NPS]) __attribute__((always_inline)) {
         const uint64_t tick = ptick0 + (uint64_t)k;
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
 #ifdef MDPP_ABL_WK_NOCONS
                 const uint32_t nlim = total + (cons & 1u);
 #else
-                const uint32_t nlim = min(total, cons * nd + (uint32_t)kWRing);
+                const uint32_t nlim = z0 ? total : min(total, cons * nd + (uint32_t)kWRing);       // (Z0: no normals ring to respect)
 #endif
                 const uint32_t gp = __hip_atomic_load(&s_gp[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 bool progress = false;
@@ -386,10 +393,31 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                     wk_u32x2 wd[NB];
 #pragma unroll
                     for (int u = 0; u < NB; u++) wd[u] = raw_at2((rp << 11) + ((uint32_t)u << 11));
+                    uint32_t bad = 1u << allowed;
+                    if (z0) {                   // (wave-uniform) the decisions alone: one 8-byte lookup, one 52-bit compare per word
+                        uint64_t kq[NB];
+#pragma unroll
+                        for (int u = 0; u < NB; u++) kq[u] = s_kw[wd[u].x & 0xffu].x;
+#pragma unroll
+                        for (int u = 0; u < NB; u++) {
+                            const uint32_t wlo = wd[u].x, whi = wd[u].y;
+                            const uint32_t rlo = __builtin_amdgcn_alignbit(whi, wlo, 9), rhi = (whi >> 9) & 0xFFFFFu;
+                            const uint64_t rabs = (uint64_t)rlo | ((uint64_t)rhi << 32);
+                            bad |= (rabs < kq[u]) ? 0u : (1u << u);
+                        }
+                        const uint32_t m = (uint32_t)__builtin_ctz(bad);
+                        const bool rej = m < allowed;
+                        if (__builtin_amdgcn_ballot_w64(rej) != 0) {
+                            if (rej) pr = raw_at((rp + m) << 11);
+                        }
+                        n += m;
+                        rp += m + (rej ? 1u : 0u);
+                        parked = parked || rej;
+                        progress = can;
+                    } else {
                     ulonglong2 kw[NB];
 #pragma unroll
                     for (int u = 0; u < NB; u++) kw[u] = s_kw[wd[u].x & 0xffu];
-                    uint32_t bad = 1u << allowed;
                     double xs[NB];
 #pragma unroll
                     for (int u = 0; u < NB; u++) {
@@ -423,6 +451,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                     rp += m + (rej ? 1u : 0u);
                     parked = parked || rej;
                     progress = can;
+                    }
                 }
                 const uint64_t bpark = __builtin_amdgcn_ballot_w64(parked);
                 if (bpark != 0 && ((uint32_t)__builtin_popcountll(bpark) >= kPark || bcan == 0)) {
@@ -452,7 +481,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                             if (!sure) accf = y < exp(-0.5 * x * x);
                         }
                         if (act && !tail) {
-                            if (accf) { z_put(n << 11, x); n += 1u; }
+                            if (accf) { if (!z0) z_put(n << 11, x); n += 1u; }
                             parked = false;
                             progress = true;
                         }
@@ -472,7 +501,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                             const double yy = -log1p(-u2);
 #endif
                             if (yy + yy > xx * xx) {
-                                z_put(n << 11, ((pr >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx);
+                                if (!z0) z_put(n << 11, ((pr >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx);
                                 n += 1u;
                                 parked = false;
                             }
@@ -939,7 +968,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
     auto normal = [&]() -> double {
         // WALK: normals are packed in draw order, slot = (count of the step's first normal + zi) & 31 -- scalar arithmetic;
         // read where they are used (holding a step's 13 doubles in registers spilled the step loop at 168 registers)
-        if constexpr (WALK) return (double)s_z[(size_t)((wk_nb + (uint32_t)(zi++)) & (uint32_t)(kWRing - 1)) * kBlock + ln];
+        if constexpr (WALK) {
+            if (z0) { zi++; return 0.0; }           // (sigma 0: the term is 0.0 + 0.0 z = +0.0 for every z)
+            return (double)s_z[(size_t)((wk_nb + (uint32_t)(zi++)) & (uint32_t)(kWRing - 1)) * kBlock + ln];
+        }
         if (HELPER) return (double)zslot[(zi++) * kBlock];
         if constexpr (PAR) {
             return (double)s_z[(zi++) * 64 + ln];
@@ -1025,6 +1057,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
 #ifdef MDPP_ABL_WK_NOWAIT
             if (!WALK)
 #endif
+            if (!z0)                    // (Z0: nothing of the walker's is read)
             while (__hip_atomic_load(&s_prod[WALK ? 0 : k % NPROD][wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
                    (uint32_t)(WALK ? k + 1 : k / NPROD + 1)) {
                 __builtin_amdgcn_s_sleep(1);
@@ -1463,8 +1496,10 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
     const bool walk = !PHILOX && helper && kWalkD && !(a.opts & (MDPP_OPT_NO_TRIO | MDPP_OPT_NO_PARK));
     const int nprod = (PHILOX && helper && D >= 8 && !(a.opts & MDPP_OPT_NO_TRIO)) ? kPhiloxProducers : (walk ? 2 : 1);
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d>", D,
-                 ORDER, NREL, noise, helper, GEN, PHILOX, helper ? nprod : 0);
+        // (",Z0": the run-time form of the walker role for noise keys whose sigma is 0 -- the same kernel symbol)
+        const bool z0 = walk && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
+        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d>%s", D,
+                 ORDER, NREL, noise, helper, GEN, PHILOX, helper ? nprod : 0, z0 ? ",Z0" : "");
         return;
     }
     if (noise) {

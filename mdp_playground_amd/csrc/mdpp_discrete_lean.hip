@@ -201,6 +201,15 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     //   irrelevant observation, byte 2 truncated
     constexpr bool PN = (NZ & 1) != 0, RN = (NZ & 2) != 0;
     constexpr bool NPN = PN && !PHILOX, NRN = RN && !PHILOX;          // noise on numpy streams
+    // Z0 (NZ bit 2, numpy streams; round 6): the reward_noise key is PRESENT with sigma 0 -- what every discrete experiment file of
+    // the reference passes.  The reference still draws rng.normal(0, 0) per step (rl_toy_env.py:398-403, :1982), so the stream
+    // positions, the ziggurat's accept decisions and the reset words behind them are all kept -- but a normal's VALUE is only
+    // ever multiplied by 0: r + (0.0 + 0 z) == r bit for bit for r in {0.0, 1.0} and finite z.  H then makes meta[p] alone (no
+    // rabs * wi, no sign insert, no lds_x write; x is formed only on the wedge path, which needs it to decide), E copies nothing
+    // per step, and O1 pays from the reward-value table like the noise-free kernel (a.rsel holds the same float64 arithmetic).
+    constexpr bool Z0 = (NZ & 4) != 0;
+    static_assert(!Z0 || NRN, "sigma-0 draws: numpy streams with the reward_noise key");
+    constexpr bool NRX = NRN && !Z0;                                  // ... whose values are used
     constexpr int KD = NRN ? kDepthNp : kDepth;                       // E->O ring depth in steps
     __shared__ __align__(16) uint32_t lds_rec[3][KD][kBlock];
     __shared__ __align__(16) uint32_t lds_V[2048];            // reward bit & NaN gate, by the 4 low nibbles
@@ -252,9 +261,9 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     __shared__ __align__(16) uint32_t lds_pn[(PN && PHILOX) ? kHChunks : 1][kBlock];       // H -> E: the chunk's 8 transition-noise nibbles
     // numpy streams (header): transition-noise bytes of a chunk; per stream position the draw's value and {start state, kind, words}
     __shared__ __align__(16) uint32_t lds_pn2[NPN ? kHChunksNp : 1][2][kBlock];
-    __shared__ __align__(16) double lds_x[NRN ? kXR : 1][kBlock];
+    __shared__ __align__(16) double lds_x[NRX ? kXR : 1][kBlock];
     __shared__ uint16_t lds_meta[NRN ? kXR : 1][kBlock];
-    __shared__ __align__(16) double lds_rx[NRN ? KD : 1][kBlock];      // E -> O1: the step's normal
+    __shared__ __align__(16) double lds_rx[NRX ? KD : 1][kBlock];      // E -> O1: the step's normal
     __shared__ uint32_t lds_hhead[NRN ? kBlock : 1], lds_epos[NRN ? kBlock : 1];   // positions made by H / reached by E
     // the two categorical searches of H by the word's top bits: byte = the answer where the bucket holds no threshold, 0xFF
     // where it does (then the thresholds are counted: a few lanes per thousand)
@@ -496,8 +505,15 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                             for (int u = 0; u < kXB; u++) {
                                 const uint64_t wd = wdv[u];
                                 wdv[u + 1] = ge.next64();
-                                const ulonglong2 kw = lds_kw[(uint32_t)wd & 0xffu];
                                 const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
+                                if constexpr (Z0) {                 // the accept decision alone (an integer compare); no value
+                                    const uint64_t ki = lds_kw[(uint32_t)wd & 0xffu].x;
+                                    const bool ok = rabs < ki;
+                                    rej |= ok ? 0u : (1u << u);
+                                    lds_meta[(hq + (uint32_t)u) & (uint32_t)(kXR - 1)][l] = (uint16_t)(start_of(wd) | (ok ? 0u : (2u << 3)));
+                                    continue;
+                                }
+                                const ulonglong2 kw = lds_kw[(uint32_t)wd & 0xffu];
                                 // rabs * wi in ONE rounding (as in mdpp_continuous_fast.hip's walker): m = 1 + rabs 2^-52 as bits,
                                 // W = wi 2^52 from the table, fma(m, W, -W) = round(rabs wi); the sign (bit 8 of the word) by a bit-field insert
                                 const double W = __longlong_as_double((long long)kw.y);
@@ -555,13 +571,19 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                                         if (yy + yy > xx * xx) { val = ((wd >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx; break; }
                                         if (cnt > 250u) { status |= kStatusInternal; break; }
                                     }
-                                    lds_x[slot][l] = val;
+                                    if constexpr (!Z0) lds_x[slot][l] = val;
                                     // (bits 5-7: the start state of the word BEHIND the tail's words -- E must not have to
                                     //  find it in the ring, a long tail reaches beyond the window H keeps ahead of E)
                                     const uint32_t words = cnt, ssb = start_of(word());
                                     lds_meta[slot][l] = (uint16_t)(ss | (3u << 3) | (ssb << 5) | (words << 8));
                                 } else {                    // wedge: one uniform; a rejected point starts the draw over two words on
-                                    const double x = lds_x[slot][l];
+                                    double x;
+                                    if constexpr (Z0) {             // (formed here, where the decision needs it: |x| suffices, it is squared)
+                                        const double W = __longlong_as_double((long long)lds_kw[idx].y);
+                                        x = __builtin_fma(__longlong_as_double((long long)(((wd >> 9) & 0x000fffffffffffffULL) | 0x3FF0000000000000ULL)), W, -W);
+                                    } else {
+                                        x = lds_x[slot][l];
+                                    }
                                     const double u1 = (double)(wn >> 11) * (1.0 / 9007199254740992.0);
                                     const double y = (lds_fi[idx - 1] - lds_fi[idx]) * u1 + lds_fi[idx];
                                     // exp(-x^2 / 2) by a float32 estimate (relative error < 2e-6); float64 exp() within 1e-5 of it
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 ph = (ra != rb || ph == 0u) ? ph_full : ph;
             }
             float rout;
-            if constexpr (RN) {                                                      // :1975-1990, :2107 in float64
+            if constexpr (RN && !Z0) {                                               // :1975-1990, :2107 in float64
                 double r = (out != 0u && (!EVN || rd == 0u)) ? 1.0 : 0.0;
                 r += 0.0 + a.r_noise * z;
                 if (!plain) {                // (scale 1, shift 0: r * 1.0 and r + 0.0 are r -- it is never -0.0 here)
@@ -787,7 +809,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                 }
                 double zd[kChunk];
 #pragma unroll
-                for (int u = 0; u < kChunk; u++) zd[u] = NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u];    // (numpy streams: the normal E found)
+                for (int u = 0; u < kChunk; u++) zd[u] = NRX ? lds_rx[NRX ? (kbase + u) % KD : 0][l] : (double)zc[u];    // (numpy streams: the normal E found)
                 if (rowc && c >= kRB) {                     // the staging rows of chunk c - kRB: stored by all four O2 waves
                     uint32_t sp2 = 0;
                     while (min4(lds_rcons) < (uint32_t)(c - kRB + 1)) {
@@ -804,7 +826,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
                     if (kbase + u < K)
                         emit(lds_rec[0][(kbase + u) % KD][l], lds_rec[1][(kbase + u) % KD][l],
                              lds_rec[2][(kbase + u) % KD][l], (uint32_t)(kbase + u) * N,
-                             NRN ? lds_rx[(kbase + u) % KD][l] : (double)zc[u], nullptr);
+                             NRX ? lds_rx[NRX ? (kbase + u) % KD : 0][l] : (double)zc[u], nullptr);
             }
             if ((l & 63) == 0) wg_store_rel(&lds_cons[w][0], upto);
             if constexpr (ROWS1) {
@@ -1053,7 +1075,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
         m0 = lds_meta[ep & (uint32_t)(kXR - 1)][l];
         m1 = lds_meta[(ep + 1u) & (uint32_t)(kXR - 1)][l];
         m2 = lds_meta[(ep + 2u) & (uint32_t)(kXR - 1)][l];
-        xv = lds_x[ep & (uint32_t)(kXR - 1)][l];
+        if constexpr (NRX) xv = lds_x[ep & (uint32_t)(kXR - 1)][l];
     };
     if constexpr (NRN) fetch();
     // PN: byte s of {enc_lo, enc_hi} = s | 8 | is_terminal[s] << 7, the column byte of a re-drawn state
@@ -1187,7 +1209,7 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
             uint32_t cntw = kind == 0u ? 1u : 2u, ssm = kind == 0u ? m1 : m2;
             // tail: its words are counted in the high byte, the start state of the word behind them is in bits 5-7
             if (kind == 3u) { cntw = m0 >> 8; ssm = m0 >> 5; }
-            lds_rx[k % KD][l] = xv;
+            if constexpr (NRX) lds_rx[k % KD][l] = xv;
             s0v = (ssm & 7u) | 8u;
             ep += cntw + (need ? 1u : 0u);
             __hip_atomic_store(&lds_epos[l], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (H's window follows E)
@@ -1402,8 +1424,14 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
         return false;
     const int grid = (a.N + kBlock - 1) / kBlock;
     const bool dl = a.delay > 0, hm = a.max_steps > 0, evn = a.every_n > 1;
+    // sigma-0 reward noise on numpy streams (kernel header, Z0): the draws without their values
+    const bool z0 = MDPP_LEAN_TU_NOISE == 2 && (nz & 2) && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);
+    (void)z0;
     if (name_out) {
-        if (nz)
+        if (nz && z0)
+            snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d,NEXT=%d,PN=%d,RN=%d,Z0=1>",
+                     !a.obs_i32, dl, hm, evn, ph, irr, kNext, nz & 1, (nz >> 1) & 1);
+        else if (nz)
             snprintf(name_out, kNameLen, "k_discrete_rollout_lean<OBS64=%d,DELAY=%d,HASMAX=%d,EVN=%d,PHILOX=%d,IRR=%d,NEXT=%d,PN=%d,RN=%d>",
                      !a.obs_i32, dl, hm, evn, ph, irr, kNext, nz & 1, (nz >> 1) & 1);
         else
@@ -1416,7 +1444,9 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
                        0, s, a, K, actions, obs, reward, term, trunc, final_obs)
 #define MDPP_LEAN_LAUNCH(O64, DL, HM, EV)                                                                   \
     do {                                                                                                   \
-        if (nz == 3) MDPP_LEAN_GO(O64, DL, HM, EV, 3);                                                     \
+        if (MDPP_LEAN_TU_NOISE == 2 && z0 && nz == 3) MDPP_LEAN_GO(O64, DL, HM, EV, (MDPP_LEAN_TU_NOISE == 2 ? 7 : 3));   \
+        else if (MDPP_LEAN_TU_NOISE == 2 && z0) MDPP_LEAN_GO(O64, DL, HM, EV, (MDPP_LEAN_TU_NOISE == 2 ? 6 : 2));          \
+        else if (nz == 3) MDPP_LEAN_GO(O64, DL, HM, EV, 3);                                                \
         else if (nz == 2) MDPP_LEAN_GO(O64, DL, HM, EV, 2);                                                \
         else MDPP_LEAN_GO(O64, DL, HM, EV, 1);                                                             \
     } while (0)

@@ -116,6 +116,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     __shared__ uint32_t s_t31[NPH ? 256 : 1];                           // rho_0 as 31-bit thresholds (producers)
     __shared__ uint32_t s_hprod[NPH ? NPH : 1][kBlock / 64];            // producer p has made every step < this of its blocks, for wave w
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
+    const bool rn_z0 = RN && !PH && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);   // the reward_noise key present with sigma 0 (wave-uniform)
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = (ROLES + NPH) * kBlock;
     const int tid = threadIdx.x;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (RN) {                                                           // D6: drawn in reward_function, before any reset
             if constexpr (NPH > 0) z = (double)s_hz[(kstep % kHD) * kBlock + l];
             else if constexpr (PH) z = (double)rnz.normal(a.philox_seed, genv, ptick, kPhiloxRNoiseStream);
-            else { z = 0.0; if (!pend) z = np_standard_normal_lds(g, zig); }
+            else { z = 0.0; if (!pend) { if (rn_z0) np_skip_normal_lds(g, zig); else z = np_standard_normal_lds(g, zig); } }   // (sigma 0: 0.0 + 0.0 z is +0.0 for every z -- the stream's advance alone)
         }
         bool tr = has_max && steps >= max_steps;
         bool need = autoreset && (done || tr);

@@ -197,6 +197,7 @@ struct ContinuousArgs {
     int32_t line_NL;            // row width of line_hist: 4 (at most 4 relevant dimensions) or 8
     int32_t line_lds;           // this launch mirrors the L points of every lane in dynamic LDS (set by launch_step_t)
     float *line_hist;
+    double *line_ws;            // more than 8 relevant dimensions: the fit's matrices in HBM, [(2 n n + 3 n)][N] (c_line_reward_big); else null
     double *ring64;             // [delay][N]
     // the reference's DEFAULT target_point, float64 zeros over every dimension (:652-654): float64 distances, target
     // latch and dense reward; rew64 = the reward is float64 throughout (line reward, or default target + make_denser)
@@ -279,7 +280,7 @@ struct mdpp_env {
     // device allocations
     void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
     void *d_state, *d_ring, *d_status;
-    void *d_line_hist, *d_ring64;                             // continuous, move_along_a_line
+    void *d_line_hist, *d_line_ws, *d_ring64;                             // continuous, move_along_a_line
     void *d_est_cur, *d_est_last;                             // cfg.episode_stats: EpisodeStatsDev rows
     int32_t est_nk;
     void *d_P1, *d_init_cdf1, *d_noise_cdf1, *d_irr_state;   // irrelevant sub-space

@@ -509,6 +509,22 @@ __device__ __forceinline__ double np_standard_normal_lds(G &g, const ZigLds &z) 
     }
 }
 
+// The same draw for a sigma of 0 (round 6): the reference's rng.normal(0, 0) is 0.0 + 0.0 z = +0.0 for every z, so only the
+// words the draw CONSUMES matter -- the fast path is the integer compare alone; the wedge needs |x| (squared), the tail its loop.
+__device__ __forceinline__ void np_skip_normal_lds(Philox &, const ZigLds &) {}
+template <class G>
+__device__ __forceinline__ void np_skip_normal_lds(G &g, const ZigLds &z) {
+    for (;;) {
+        const uint64_t r = g.next64();
+        const int idx = (int)(r & 0xff);
+        const uint64_t rabs = (r >> 9) & 0x000fffffffffffffULL;
+        if (rabs < z.ki[idx]) return;
+        if (idx == 0) { (void)np_zig_tail(g, rabs); return; }
+        const double x = (double)rabs * z.wi[idx];
+        if (((z.fi[idx - 1] - z.fi[idx]) * np_random(g) + z.fi[idx]) < exp(-0.5 * x * x)) return;
+    }
+}
+
 // Generator.integers(low, high) for ranges that fit 32 bits: buffered_bounded_lemire_uint32
 template <class G>
 __device__ __forceinline__ int np_integers(G &g, Half32 &h, int low, int high) {

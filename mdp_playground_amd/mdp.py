@@ -41,11 +41,22 @@ def pcg64_words(gen) -> np.ndarray:
                     dtype=np.uint64)
 
 
+_FRESH_CACHE = {}          # (seed, count, stride) -> words: seeding 65 536 generators takes 0.25 s, and batches of one seed recur
+
+
 def fresh_stream_words(seed, count, stride=1) -> np.ndarray:
-    """PCG64 words of ``count`` freshly seeded generators with seeds seed, seed+stride, ..."""
+    """PCG64 words of ``count`` freshly seeded generators with seeds seed, seed+stride, ...  (a pure function of its
+    arguments for a seed that is not None: the last few results are kept and handed out as copies)"""
+    key = (int(seed), int(count), int(stride)) if seed is not None else None
+    if key is not None and key in _FRESH_CACHE:
+        return _FRESH_CACHE[key].copy()
     out = np.empty((count, 6), dtype=np.uint64)
     for i in range(count):
         out[i] = pcg64_words(new_generator(None if seed is None else seed + i * stride))
+    if key is not None and count >= 1024:
+        if len(_FRESH_CACHE) >= 8:
+            _FRESH_CACHE.pop(next(iter(_FRESH_CACHE)))
+        _FRESH_CACHE[key] = out.copy()
     return out
 
 
@@ -465,12 +476,11 @@ def build_continuous(config) -> ContinuousMDP:
         raise NotImplementedError("ImageContinuous observations: 2 relevant dimensions, and 2 or 4 state "
                                   "dimensions in all (the reference's picture is built from dims [0, 1] and [2, 3])")
     if line:
-        # :1864-1910: the fit runs on the device for up to 8 relevant dimensions (a scatter matrix kept in registers: 4 x 4,
-        # or 8 x 8 in its own kernel instantiation for 5 to 8, which needs state_space_dim <= 12) and up to 64 states;
-        # no target, no target latch (:1719)
-        if len(rel) > 8 or (len(rel) > 4 and D > 12) or common["sequence_length"] > 64:
-            raise NotImplementedError("move_along_a_line: at most 8 relevant dimensions (state_space_dim <= 12 beyond 4) "
-                                      "and sequence_length <= 64")
+        # :1864-1910: the fit runs on the device -- a scatter matrix kept in registers for up to 8 relevant dimensions (4 x 4, or
+        # 8 x 8 in its own kernel instantiation for 5 to 8 of at most 12 state dimensions), in an HBM workspace beyond that
+        # (c_line_reward_big) -- over up to 64 states; no target, no target latch (:1719)
+        if common["sequence_length"] > 64:
+            raise NotImplementedError("move_along_a_line: sequence_length <= 64 (the window of the line fit kept per env)")
         if image is not None:     # :767-775 hands self.target_point to ImageContinuous; only move_to_a_point sets it (:650)
             raise AttributeError("'RLToyEnv' object has no attribute 'target_point' (the reference's constructor fails for "
                                  "move_along_a_line with image_representations)")
@@ -591,3 +601,34 @@ def build_mdp(config):
     if kind == "grid":
         return build_grid(config)
     raise ValueError("Unknown state_space_type")
+
+
+def _build_chunk(args):
+    config, seeds = args
+    return [build_mdp({**config, "seed": s}) for s in seeds]
+
+
+def build_many(config, seeds, workers=None):
+    """[build_mdp({**config, "seed": s}) for s in seeds] -- one MDP per env instance (RLToyVectorEnv(seeds=...)) -- built by a
+    pool of forked worker processes: 65 536 discrete 8 x 8 MDPs take 0.5 ms each in one Python process.  Forks, so call it
+    BEFORE the process has touched the GPU (torch.cuda.is_available() initialises it); a process that already has builds
+    them in line.  The result is what the sequential loop gives (every MDP is a pure function of its config and seed)."""
+    import os
+    seeds = list(seeds)
+    n = workers if workers is not None else min(os.cpu_count() or 1, 64)
+    gpu_touched = False
+    try:
+        import torch
+        gpu_touched = torch.cuda.is_initialized()
+    except Exception:
+        pass
+    if n <= 1 or len(seeds) < 512 or gpu_touched:
+        return _build_chunk((config, seeds))
+    import contextlib
+    import io
+    import multiprocessing as mp
+    step = max(64, -(-len(seeds) // (4 * n)))
+    chunks = [(config, seeds[k:k + step]) for k in range(0, len(seeds), step)]
+    with mp.get_context("fork").Pool(n) as pool, contextlib.redirect_stdout(io.StringIO()):
+        parts = pool.map(_build_chunk, chunks)
+    return [m for part in parts for m in part]

@@ -40,7 +40,7 @@ class RLToyVectorEnv:
 
     def __init__(self, num_envs=None, device=None, *, seeds=None, rng="numpy",
                  autoreset="same_step", max_episode_steps=None, env_id_offset=0,
-                 philox_seed=None, episode_stats=False, **config):
+                 philox_seed=None, episode_stats=False, mdps=None, **config):
         self._lib = capi.load()
         self._h = None
         if not torch.cuda.is_available():
@@ -60,7 +60,12 @@ class RLToyVectorEnv:
             if num_envs is not None and num_envs != len(seeds):
                 raise ValueError("num_envs != len(seeds)")
             num_envs = len(seeds)
-            self.mdps = [mdp_mod.build_mdp({**config, "seed": s}) for s in seeds]
+            if mdps is not None:          # prebuilt (mdp.build_many, before the GPU was touched): one per seed, in order
+                if len(mdps) != len(seeds):
+                    raise ValueError("len(mdps) != len(seeds)")
+                self.mdps = list(mdps)
+            else:
+                self.mdps = [mdp_mod.build_mdp({**config, "seed": s}) for s in seeds]
         else:
             if num_envs is None:
                 num_envs = 1

@@ -118,3 +118,50 @@ def test_wide_one_step_kernel_without_a_noise_key_at_blob_sizes_past_8_kib(shape
         for s in (capi.STREAM_ENV, capi.STREAM_SPACE):
             assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("shape", ["d_s8_rn0", "d_s8_delay_evn_pn", "d_s50_rn0", "d_s24_rdist_rn0", "c_d2_n0", "c_d4_order2_pn0", "c_d2_rn0_only"])
+def test_sigma_zero_noise_keys_advance_only_equals_values_formed(shape):
+    """Round 6: every experiment file of the reference passes its noise keys with sigma 0, and the reference
+    still draws rng.normal(0, 0) per step (rl_toy_env.py:398-403, :1682-1691, :1980-1987) -- the draw's VALUE is multiplied by 0
+    (numpy: 0.0 + 0.0 z = +0.0 whatever z is), only the stream's advance is left.  The default dispatch makes the ziggurat's
+    accept decisions alone (lean Z0, quiet's skip draw, the continuous walker without its normals ring); MDPP_OPT_NO_SIGMA0
+    forms every value as before.  16 384 envs, rollouts of 96 + 40 steps and single steps: every output of every env bit for
+    bit, and the end states of the env and space streams (how many words every draw consumed, wedge and tail paths included)."""
+    from mdp_playground_amd import _capi as capi
+    D = dict(state_space_type="discrete", action_space_type="discrete", reward_density=0.25, terminal_state_density=0.25,
+             make_denser=False, completely_connected=True, generate_random_mdp=True, repeats_in_sequences=False, seed=0)
+    C = dict(state_space_type="continuous", action_space_type="continuous", inertia=1, state_space_max=10, action_space_max=1,
+             target_radius=0.5, make_denser=True, reward_function="move_to_a_point", action_loss_weight=0.01, delay=0, seed=0)
+    cfg = {"d_s8_rn0": dict(D, state_space_size=8, action_space_size=8, delay=0, sequence_length=1, transition_noise=0, reward_noise=0),
+           "d_s8_delay_evn_pn": dict(D, state_space_size=8, action_space_size=8, delay=3, sequence_length=2, reward_every_n_steps=2,
+                                     transition_noise=0.1, reward_noise=0, reward_scale=2.5, reward_shift=-0.5),
+           "d_s50_rn0": dict(D, state_space_size=50, action_space_size=50, delay=1, sequence_length=1, transition_noise=0, reward_noise=0),
+           "d_s24_rdist_rn0": dict(D, state_space_size=24, action_space_size=24, delay=0, sequence_length=1, reward_dist=[0.01, 1],
+                                   reward_noise=0),
+           "c_d2_n0": dict(C, state_space_dim=2, action_space_dim=2, transition_dynamics_order=1, time_unit=1.0, target_point=[0, 0],
+                           transition_noise=0, reward_noise=0),
+           "c_d4_order2_pn0": dict(C, state_space_dim=4, action_space_dim=4, transition_dynamics_order=2, time_unit=0.1,
+                                   target_point=[0, 0, 0, 0], transition_noise=0),
+           "c_d2_rn0_only": dict(C, state_space_dim=2, action_space_dim=2, transition_dynamics_order=1, time_unit=1.0,
+                                 target_point=[1, -1], reward_noise=0, make_denser=False)}[shape]
+    N = 16384
+    a = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b = _venv(num_envs=N, autoreset="same_step", **cfg)
+    b.set_kernel_options("NO_SIGMA0")
+    name = a.rollout_kernel_name(96)
+    if shape.startswith("d_s8"):
+        assert name.startswith("k_discrete_rollout_lean<") and "Z0=1" in name and "Z0" not in b.rollout_kernel_name(96), name
+    g = np.random.default_rng(23)
+    for piece, F in enumerate((96, 40)):
+        acts = torch.as_tensor(_rand_actions(a, F, g), device=a.device)
+        ra, rb = a.rollout(acts), b.rollout(acts)
+        torch.cuda.synchronize()
+        assert all(_same(x, y) for x, y in zip(ra, rb)), (shape, "rollout", piece, name)
+        for t in range(4):
+            sa, sb = a.step(acts[t]), b.step(acts[t])
+            assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (shape, "step", piece, t)
+    assert np.array_equal(a.status(), b.status()) and not a.status().any()
+    for s in (capi.STREAM_ENV, capi.STREAM_SPACE):
+        assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (shape, s)
+    a.close(); b.close()

@@ -13,7 +13,9 @@ import torch  # noqa: E402
 from mdp_playground_amd import RLToyVectorEnv, _capi  # noqa: E402
 import bench  # noqa: E402
 
+import time  # noqa: E402
 launches = int(sys.argv[1])
+t_start = time.perf_counter()
 lib = _capi.load()
 dev = torch.device("cuda", 0)
 mark = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -21,13 +23,16 @@ for spec in sys.argv[2:]:
     wname, rng, envs, fuse = spec.split(":")
     wl = bench.WORKLOADS[wname]
     N, F = int(envs), int(fuse)
+    t0 = time.perf_counter()
     env = bench.make_env(wl, N, dev, rng)
+    t1 = time.perf_counter()
     acts = bench.make_actions(wl, F, N, dev, 12345)
     out = env.alloc_rollout(F)
     for _ in range(launches):
         env.rollout(acts, out)
     torch.cuda.synchronize()
-    print(f"workload={wname} rng={rng} envs={N} fuse={F} launches={launches} kernel={env.rollout_kernel_name(F)}", flush=True)
+    print(f"workload={wname} rng={rng} envs={N} fuse={F} launches={launches} kernel={env.rollout_kernel_name(F)} "
+          f"make_env_s={t1 - t0:.2f} total_s={time.perf_counter() - t0:.2f} since_start_s={time.perf_counter() - t_start:.2f}", flush=True)
     env.close()
     del env, acts, out
     lib.mdpp_philox_normals(1, 0, 0, 0, 1, 1, C.c_void_p(mark.data_ptr()),

@@ -269,6 +269,13 @@ CASES = {
                     sequence_length=7, reward_scale=1.5,
                     reward_function="move_along_a_line"),
         seeds=list(range(3)), T=120, reset="mixed", straight_window=11),
+    "c_line_12of14": dict(   # twelve relevant dimensions: past the register-resident fits (c_line_reward_big, round 6)
+        config=dict(state_space_type="continuous", state_space_dim=14, irrelevant_features=True,
+                    relevant_indices=[0, 1, 2, 4, 5, 6, 7, 8, 10, 11, 12, 13], transition_dynamics_order=1, inertia=1.0,
+                    time_unit=1.0, state_space_max=6, action_space_max=1, delay=1,
+                    sequence_length=7, reward_scale=1.5,
+                    reward_function="move_along_a_line"),
+        seeds=list(range(3)), T=120, reset="mixed", straight_window=11),
     # --- continuous + ImageContinuous observations: RGB pictures, and the
     # reference's quirk that every step takes the clip-and-zero-derivatives branch -----------------
     "ci_2d": dict(
