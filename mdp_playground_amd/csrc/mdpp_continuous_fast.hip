@@ -143,7 +143,7 @@ constexpr uint32_t kCStatusInternal = 0x80000000u;
 // generator state behind the last word it consumed (posted by the wave that made that word), and integrates.  Tails,
 // three rejected wedges in a row and draws that reach past position 15 (6 in 10 000 env steps) run numpy's own loop on a
 // generator that reads the posted words and continues sequentially behind them -- exact, just not parallel.
-template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1, bool K1 = false, bool PAR = false>
+template <int D, int ORDER, int NREL, bool NOISE, bool HELPER, bool GEN, bool PHILOX = false, int NPROD = 1, bool K1 = false, bool PAR = false, bool Z0T = false>
 __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1) void k_continuous_rollout_fast(ContinuousArgs a, int K,
                                                                     const float *__restrict__ actions,
                                                                     float *__restrict__ obs,
@@ -224,7 +224,10 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
     // the noise term IS +0.0: only the stream's advance -- how many words each ziggurat draw consumes -- is left of the draws.
     // The walker then makes the accept decisions alone (no rabs * wi, no sign, no normals ring), and the consumer neither waits
     // for the walker nor reads a normal: normal() returns 0.0 and 0.0 + sigma * 0.0 is the same +0.0.
-    const bool z0 = WALK && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
+    // A template flag, chosen by the launcher and instantiated for D = 2 only (the shape of the reference's continuous
+    // experiments): the D = 12 walker kernels sit at 168 registers with 104 spilled and are left as they were.
+    constexpr bool kZ0 = Z0T;
+    static_assert(!Z0T || (WALK && D == 2), "sigma-0 walker: the D = 2 generator / walker / consumer kernels");
     // this step's normals, PHILOX: P-noise of dimension d at [d], reward noise at [D]
     auto philox_step = [&](int k, float (&z)[NPS]) __attribute__((always_inline)) {
         const uint64_t tick = ptick0 + (uint64_t)k;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
 #ifdef MDPP_ABL_WK_NOCONS
                 const uint32_t nlim = total + (cons & 1u);
 #else
-                const uint32_t nlim = z0 ? total : min(total, cons * nd + (uint32_t)kWRing);       // (Z0: no normals ring to respect)
+                const uint32_t nlim = kZ0 ? total : min(total, cons * nd + (uint32_t)kWRing);       // (Z0: no normals ring to respect)
 #endif
                 const uint32_t gp = __hip_atomic_load(&s_gp[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 bool progress = false;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
 #pragma unroll
                     for (int u = 0; u < NB; u++) wd[u] = raw_at2((rp << 11) + ((uint32_t)u << 11));
                     uint32_t bad = 1u << allowed;
-                    if (z0) {                   // (wave-uniform) the decisions alone: one 8-byte lookup, one 52-bit compare per word
+                    if constexpr (kZ0) {                   // (compile-time) the decisions alone: one 8-byte lookup, one 52-bit compare per word
                         uint64_t kq[NB];
 #pragma unroll
                         for (int u = 0; u < NB; u++) kq[u] = s_kw[wd[u].x & 0xffu].x;
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                             if (!sure) accf = y < exp(-0.5 * x * x);
                         }
                         if (act && !tail) {
-                            if (accf) { if (!z0) z_put(n << 11, x); n += 1u; }
+                            if (accf) { if (!kZ0) z_put(n << 11, x); n += 1u; }
                             parked = false;
                             progress = true;
                         }
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
                             const double yy = -log1p(-u2);
 #endif
                             if (yy + yy > xx * xx) {
-                                if (!z0) z_put(n << 11, ((pr >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx);
+                                if (!kZ0) z_put(n << 11, ((pr >> 17) & 0x1) ? -(nor_r + xx) : nor_r + xx);
                                 n += 1u;
                                 parked = false;
                             }
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
         // WALK: normals are packed in draw order, slot = (count of the step's first normal + zi) & 31 -- scalar arithmetic;
         // read where they are used (holding a step's 13 doubles in registers spilled the step loop at 168 registers)
         if constexpr (WALK) {
-            if (z0) { zi++; return 0.0; }           // (sigma 0: the term is 0.0 + 0.0 z = +0.0 for every z)
+            if (kZ0) { zi++; return 0.0; }           // (sigma 0: the term is 0.0 + 0.0 z = +0.0 for every z)
             return (double)s_z[(size_t)((wk_nb + (uint32_t)(zi++)) & (uint32_t)(kWRing - 1)) * kBlock + ln];
         }
         if (HELPER) return (double)zslot[(zi++) * kBlock];
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
 #ifdef MDPP_ABL_WK_NOWAIT
             if (!WALK)
 #endif
-            if (!z0)                    // (Z0: nothing of the walker's is read)
+            if (!kZ0)                    // (Z0: nothing of the walker's is read)
             while (__hip_atomic_load(&s_prod[WALK ? 0 : k % NPROD][wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
                    (uint32_t)(WALK ? k + 1 : k / NPROD + 1)) {
                 __builtin_amdgcn_s_sleep(1);
@@ -1495,11 +1498,11 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
     constexpr bool kWalkD = D >= 8 || D == 2;
     const bool walk = !PHILOX && helper && kWalkD && !(a.opts & (MDPP_OPT_NO_TRIO | MDPP_OPT_NO_PARK));
     const int nprod = (PHILOX && helper && D >= 8 && !(a.opts & MDPP_OPT_NO_TRIO)) ? kPhiloxProducers : (walk ? 2 : 1);
+    // sigma-0 noise keys (kernel header, Z0): the D = 2 walker kernels without their normals ring
+    const bool z0 = walk && D == 2 && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
     if (name_out) {
-        // (",Z0": the run-time form of the walker role for noise keys whose sigma is 0 -- the same kernel symbol)
-        const bool z0 = walk && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
-        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d>%s", D,
-                 ORDER, NREL, noise, helper, GEN, PHILOX, helper ? nprod : 0, z0 ? ",Z0" : "");
+        snprintf(name_out, kNameLen, "k_continuous_rollout_fast<D=%d,ORDER=%d,NREL=%d,NOISE=%d,HELPER=%d,GEN=%d,PHILOX=%d,NPROD=%d%s>", D,
+                 ORDER, NREL, noise, helper, GEN, PHILOX, helper ? nprod : 0, z0 ? ",Z0=1" : "");
         return;
     }
     if (noise) {
@@ -1509,6 +1512,10 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help, GEN, PHILOX, PHILOX ? kPhiloxProducers : 1>),
                                dim3(grid), dim3((1 + kPhiloxProducers) * kBlock), 0, s, ap, K, actions, obs, reward, term,
                                trunc, final_obs);
+        else if (can_help && helper && walk && D == 2 && z0)
+            hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help && kWalkD, GEN, false, (can_help && kWalkD && !PHILOX) ? 2 : 1, false, false,
+                                                          D == 2 && can_help && !PHILOX>), dim3(grid),
+                               dim3(3 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);
         else if (can_help && helper && walk)
             hipLaunchKernelGGL((k_continuous_rollout_fast<D, ORDER, NREL, true, can_help && kWalkD, GEN, false, (can_help && kWalkD && !PHILOX) ? 2 : 1>), dim3(grid),
                                dim3(3 * kBlock), 0, s, ap, K, actions, obs, reward, term, trunc, final_obs);

@@ -55,6 +55,8 @@ constexpr int kQQ = 4;                         // start states queued per lane
 constexpr int kQRsrc = 0x00020000;
 constexpr int kQDepth = 24;                    // E -> O ring depth in steps (multiple of the chunk of 8)
 constexpr int kHD = 32;                        // Philox producers -> E ring depth in steps
+constexpr int kXR = 16;                        // XR: stream positions the X wave evaluates ahead of E (per lane), kXB per batch
+constexpr int kXB = 4;
 constexpr uint32_t kQSpinLimit = 1u << 22;
 constexpr uint32_t kQStatusInternal = 0x80000000u;
 
@@ -81,6 +83,16 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // Box-Muller pairs per four env steps) into an LDS ring; the E wave, whose dependent chain is the step time, then
 // runs no generator at all (two Philox blocks and a Box-Muller pair per step on E were 0.15 of the HBM roofline
 // on cfg2 + noise; one block + one pair per step on the producers 0.24).
+// XR (round 6: ROLES = 3 with RN on numpy streams, no transition noise, one sub-space, same-step autoreset or none): reward
+// noise put the env stream's generator INSIDE E's recurrence -- per step one PCG64 word and a ziggurat decision, per reset one
+// more word and a categorical search, run by the whole wave whenever one lane resets: 2 200 cycles per step, 490 us per
+// launch at S = 50 where the noise-free kernel takes 220.  The third wave now owns the env stream the way the H wave of
+// k_discrete_rollout_lean<NRN> does (mdpp_discrete_lean.hip header): it evaluates EVERY position p of the stream as if a
+// draw started there -- x_meta[p] = {start state word p would give a reset, kind: accepted at once / wedge accepted (2 words) /
+// wedge rejected (2 words, the draw starts over) / tail (word count, start state behind its words)} and x_val[p] = that
+// draw's value -- into 16-position rings per lane, up to 16 positions ahead of the position E publishes; E walks positions
+// (three metas fetched one step ahead) and runs no generator at all; what E did not reach is un-drawn at the end.  With a
+// sigma of 0 (rn_z0) no value is formed or read.
 // UR = false (round 5): rewards that are not all 1.0 (reward_dist, :1528-1544 -- the reference's rainbow_reward_dist sweep) on
 // numpy streams without an irrelevant sub-space: the O role looks the step's sequence key up in a float64 table in LDS
 // (DiscreteArgs::rtable), the delay line holds KEYS in HBM (ring_keys[delay][N], the general kernel's, so the two kernels
@@ -108,14 +120,19 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     constexpr bool ATNEED = RN || PH;               // start states drawn when an episode ends, not ahead
     __shared__ uint64_t s_ki[ZIG ? 256 : 1];
     __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
-    static_assert(!(ATNEED && ROLES == 3), "reward noise and reset draws share the env stream: no H role");
+    constexpr bool XR = ROLES == 3 && RN && !PH;    // the third wave evaluates the env stream by position (header)
+    static_assert(!XR || (!PN && !IRR && NPH == 0), "XR: reward noise alone, one sub-space");
+    static_assert(!(ATNEED && ROLES == 3) || XR, "reward noise and reset draws share the env stream: no start-state queue");
+    __shared__ uint32_t x_meta[XR ? kXR : 1][kBlock];
+    __shared__ __align__(8) double x_val[XR ? kXR : 1][kBlock];
+    __shared__ uint32_t x_hhead[XR ? kBlock : 1], x_epos[XR ? kBlock : 1];      // positions made by X / reached by E
     static_assert(NPH == 0 || (PH && ROLES == 2 && !IRR), "Philox producers: two roles, one sub-space");
     // producers -> E: per env and step {other-state index j | noisy << 8 | start state << 16} and the reward normal
     __shared__ __align__(8) uint32_t s_hm[NPH ? kHD * kBlock : 1];
     __shared__ float s_hz[(NPH && RN) ? kHD * kBlock : 1];
     __shared__ uint32_t s_t31[NPH ? 256 : 1];                           // rho_0 as 31-bit thresholds (producers)
     __shared__ uint32_t s_hprod[NPH ? NPH : 1][kBlock / 64];            // producer p has made every step < this of its blocks, for wave w
-    constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3;
+    constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3 && !XR;      // (TRIO: the start-state queue's H role)
     const bool rn_z0 = RN && !PH && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);   // the reward_noise key present with sigma 0 (wave-uniform)
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = (ROLES + NPH) * kBlock;
@@ -175,6 +192,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (NPH) for (int p = 0; p < NPH; p++) s_hprod[p][tid] = 0;
     }
     if (TRIO && tid < kBlock) { s_start[tid] = 0; s_head[tid] = 0; }
+    if (XR && tid < kBlock) { x_hhead[tid] = 0; x_epos[tid] = 0; }
     if (tid == 0) s_done = 0;
     __syncthreads();
     // DUO: the record ring follows the tables in dynamic LDS
@@ -361,6 +379,127 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const bool autoreset = a.autoreset != 0, has_max = a.max_steps > 0;
     const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n, delay = (uint32_t)a.delay;
     const bool isE = !DUO || role == 0;
+    // =============================================================== X: the env stream by position (header, XR)
+    if constexpr (XR) if (role == 2) {
+        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
+        uint32_t hq = 0, spins = 0, xstatus = 0;        // positions made
+        uint64_t look = g.next64();                     // the word of position hq (the generator runs one word ahead)
+        // start state of a reset whose word is r: #{j : ceil(cdf[j] 2^53) <= r >> 11} (draw_state's search)
+        auto start_of = [&](uint64_t r) __attribute__((always_inline)) -> uint32_t {
+            const uint64_t m = r >> 11;
+            uint32_t s0 = 0;
+            if (use_bk) {
+                const uint32_t e = s_bk[(uint32_t)(m >> 41)];
+                const uint32_t c0 = e & 0xFFu, nin = e >> 8;
+                s0 = c0;
+                for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < nin) != 0; j++) s0 += (j < nin && T0[j < nin ? c0 + j : 0u] <= m) ? 1u : 0u;
+            } else {
+                for (uint32_t b = 0; b < S8; b += 8) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) s0 += (T0[b + j] <= m) ? 1u : 0u;
+                }
+            }
+            return s0;
+        };
+        for (;;) {
+            if (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == kBlock / 64) break;
+            const uint32_t epos = __hip_atomic_load(&x_epos[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool go = hq + (uint32_t)kXB <= epos + (uint32_t)kXR;
+            if (__builtin_amdgcn_ballot_w64(go) != 0) {
+                // The generator runs ONE word ahead (`look` = the word of position hq): the uniform a wedge point of position p
+                // takes is word p + 1, which the batch has in hand -- no copy of the generator, no saved states
+                uint32_t rej = 0;
+                uint64_t wdv[kXB + 1];
+                if (go) {
+                    wdv[0] = look;
+#pragma unroll
+                    for (int u = 0; u < kXB; u++) {
+                        const uint64_t wd = wdv[u];
+                        wdv[u + 1] = g.next64();
+                        const uint32_t idx = (uint32_t)wd & 0xffu;
+                        const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
+                        const bool ok = rabs < zig.ki[idx];
+                        rej |= ok ? 0u : (1u << u);
+                        const uint32_t slot = (hq + (uint32_t)u) & (uint32_t)(kXR - 1);
+                        if (!rn_z0) {                   // numpy: x = rabs * wi, negated where bit 8 of the word is set
+                            const double x = (double)rabs * zig.wi[idx];
+                            x_val[slot][l] = ((uint32_t)wd & 0x100u) ? -x : x;
+                        }
+                        x_meta[slot][l] = start_of(wd) | (ok ? 0u : (2u << 8));     // (rejected: patched below)
+                    }
+                    look = wdv[kXB];
+                }
+                // the ziggurat's slow path for the rejected words of the batch
+                while (__builtin_amdgcn_ballot_w64(rej != 0u) != 0) {
+                    if (rej != 0u) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(rej);
+                        rej &= rej - 1u;
+                        uint64_t wd = 0, wn = 0;                // the rejected word and the one behind it
+#pragma unroll
+                        for (int u = 0; u < kXB; u++)
+                            if (j == (uint32_t)u) { wd = wdv[u]; wn = wdv[u + 1]; }
+                        const uint32_t idx = (uint32_t)wd & 0xffu;
+                        const uint32_t slot = (hq + j) & (uint32_t)(kXR - 1);
+                        const uint32_t ss = x_meta[slot][l] & 0xFFu;
+                        const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
+                        if (__builtin_expect(idx == 0u, 0)) {   // tail: two uniforms per try (np_zig_tail), 3 in 10^4 draws
+                            const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
+                            // its words: what the batch still holds behind position j, then a copy of the generator
+                            Pcg64 t = g;
+                            uint32_t have = (uint32_t)kXB - j, cnt = 1u;
+                            auto word = [&]() -> uint64_t {
+                                uint64_t r = 0;
+                                if (have != 0u) {
+#pragma unroll
+                                    for (int u = 1; u <= kXB; u++) if ((uint32_t)kXB - have + 1u == (uint32_t)u) r = wdv[u];
+                                    have -= 1u;
+                                } else {
+                                    r = t.next64();
+                                }
+                                cnt += 1u;
+                                return r;
+                            };
+                            double val = 0.0;
+                            for (;;) {
+                                const double u1 = (double)(word() >> 11) * (1.0 / 9007199254740992.0);
+                                const double u2 = (double)(word() >> 11) * (1.0 / 9007199254740992.0);
+                                const double xx = -nor_inv_r * log1p(-u1);
+                                const double yy = -log1p(-u2);
+                                if (yy + yy > xx * xx) { val = ((rabs >> 8) & 0x1) ? -(nor_r + xx) : nor_r + xx; break; }
+                                if (cnt > 250u) { xstatus |= kQStatusInternal; break; }
+                            }
+                            if (!rn_z0) x_val[slot][l] = val;
+                            // (bits 24-31: the start state of the word BEHIND the tail's words -- a long tail reaches beyond the
+                            //  window X keeps ahead of E)
+                            const uint32_t words = cnt, ssb = start_of(word());
+                            x_meta[slot][l] = ss | (3u << 8) | (words << 16) | (ssb << 24);
+                        } else {                                // wedge: one uniform; a rejected point starts the draw over two words on
+                            const double x = (double)rabs * zig.wi[idx];                // (|x|: it is squared)
+                            const double u1 = (double)(wn >> 11) * (1.0 / 9007199254740992.0);
+                            const bool acc = ((zig.fi[idx - 1] - zig.fi[idx]) * u1 + zig.fi[idx]) < exp(-0.5 * x * x);
+                            x_meta[slot][l] = ss | ((acc ? 1u : 2u) << 8);
+                        }
+                    }
+                }
+                if (go) hq += (uint32_t)kXB;
+                __hip_atomic_store(&x_hhead[l], hq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                spins = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kQSpinLimit * 4u) { xstatus |= kQStatusInternal; break; }
+            }
+        }
+        // un-draw what was made and not used (+ the word in hand): s_prev = (s - inc) * M^-1 (mod 2^128)
+        for (uint32_t q = hq + 1u - __hip_atomic_load(&x_epos[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); q > 0; q--) {
+            const uint64_t lo = g.s_lo - g.inc_lo;
+            const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
+            g.s_lo = lo * a.minv_lo;
+            g.s_hi = __umul64hi(lo, a.minv_lo) + lo * a.minv_hi + hi * a.minv_lo;
+        }
+        g.store(a.env_s, i);
+        if (xstatus) atomicOr(&a.status[i], xstatus);
+        return;
+    }
     // =============================================================== H: start-state producer
     if constexpr (TRIO) if (role == 2) {
         __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
@@ -464,6 +603,30 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
     };
 
+    // XR, E's side: ep = position of the next draw; (xm0, xm1, xm2, xv) = x_meta[ep .. ep + 2], x_val[ep], fetched at the end of
+    // the previous step; xhh = positions X has made, as last read
+    uint32_t ep = 0, xhh = 0, xm0 = 0, xm1 = 0, xm2 = 0;
+    double xv = 0.0;
+    auto x_ensure = [&](uint32_t upto) __attribute__((always_inline)) {     // positions < upto are made
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(upto > xhh) != 0, 0)) {
+            uint32_t spins = 0;
+            xhh = __hip_atomic_load(&x_hhead[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__builtin_amdgcn_ballot_w64(upto > xhh) != 0) {
+                __hip_atomic_store(&x_epos[l], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (X's window follows E)
+                __builtin_amdgcn_s_sleep(1);
+                xhh = __hip_atomic_load(&x_hhead[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (++spins > kQSpinLimit) { status |= kQStatusInternal; xhh = upto; break; }
+            }
+        }
+    };
+    auto x_fetch = [&]() __attribute__((always_inline)) {
+        x_ensure(ep + 3u);
+        xm0 = x_meta[ep & (uint32_t)(kXR - 1)][l];
+        xm1 = x_meta[(ep + 1u) & (uint32_t)(kXR - 1)][l];
+        xm2 = x_meta[(ep + 2u) & (uint32_t)(kXR - 1)][l];
+        if (!rn_z0) xv = x_val[ep & (uint32_t)(kXR - 1)][l];
+    };
+    if constexpr (XR) { if (role == 0) x_fetch(); }
     // ---- E: one step of the state recurrence -> record
     auto stepE = [&](const u32x2 act2, double &z, const int kstep) __attribute__((always_inline)) -> uint64_t {
         uint32_t hent = 0;           // NPH: what the producers made for this step
@@ -525,6 +688,28 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             }
         }
         status |= ((bad || bad1) && !pend) ? (uint32_t)MDPP_STATUS_BAD_ACTION : 0u;
+        uint32_t x_cnt = 0, x_ss = 0;                                       // XR: the words this step's normal took, the start state behind them
+        if constexpr (XR) {
+            // this step's draws on the env stream: the normal that starts at position ep, then -- if the episode ends -- one word
+            uint32_t kind = (xm0 >> 8) & 3u;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(kind >= 2u) != 0, 0)) {
+                uint32_t guard = 0;
+                while (__builtin_amdgcn_ballot_w64(kind == 2u) != 0) {      // wedge point rejected: the draw starts over two words on
+                    const bool red = kind == 2u;
+                    ep += red ? 2u : 0u;
+                    const uint32_t o0 = xm0, o1 = xm1, o2 = xm2;
+                    const double ox = xv;
+                    x_fetch();
+                    if (!red) { xm0 = o0; xm1 = o1; xm2 = o2; xv = ox; }
+                    kind = (xm0 >> 8) & 3u;
+                    if (++guard > 64u) { status |= kQStatusInternal; break; }
+                }
+            }
+            x_cnt = kind == 0u ? 1u : 2u;
+            x_ss = (kind == 0u ? xm1 : xm2) & 0xFFu;
+            if (kind == 3u) { x_cnt = (xm0 >> 16) & 0xFFu; x_ss = xm0 >> 24; }      // tail: counted words, the start state behind them
+            z = xv;
+        } else
         if (RN) {                                                           // D6: drawn in reward_function, before any reset
             if constexpr (NPH > 0) z = (double)s_hz[(kstep % kHD) * kBlock + l];
             else if constexpr (PH) z = (double)rnz.normal(a.philox_seed, genv, ptick, kPhiloxRNoiseStream);
@@ -540,6 +725,13 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             tr = pend ? false : tr;
             pend = ended;
         }
+        if constexpr (XR) {                                                  // reset(): the word behind the normal's, evaluated by X
+            queue[0] = need ? x_ss : queue[0];
+            qn = need ? 1u : qn;
+            ep += x_cnt + (need ? 1u : 0u);
+            __hip_atomic_store(&x_epos[l], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (X's window follows E)
+            x_fetch();
+        } else
         if (ATNEED && __builtin_amdgcn_ballot_w64(need) != 0) {              // reset(): drawn now, in stream order
             if constexpr (NPH > 0) { queue[0] = need ? (hent >> 16) : queue[0]; }
             else if (need) { queue[0] = draw_state(ptick0 + (uint64_t)kstep); }
@@ -733,7 +925,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (PN && isE) sp.store(a.sp_s, i);
         if (PN && IRR && isE) sp1.store(a.sp1_s, i);
     }
-    if (TRIO && role == 0) {
+    if (XR && role == 0) {
+        // the position E reached (X un-draws what lies beyond), then that this wave is through
+        __hip_atomic_store(&x_epos[l], ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((l & 63) == 0) __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (TRIO && role == 0) {
         // tell H how many of its start states were really used, then that this wave is through
         __hip_atomic_store(&s_head[l], (head16 - qn) & 0xFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if ((l & 63) == 0) __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -799,7 +995,9 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
     const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
-    const int roles = trio ? 3 : duo ? 2 : 1;
+    // XR (kernel header): reward noise alone -- a third wave evaluates the env stream by position (+ 52 KiB of static LDS)
+    const bool xr = duo && rn && !pn && lds_duo <= 84 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO);
+    const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
     if (name_out) {
         snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=0,ROLES=%d,PN=%d,RN=%d,PHILOX=0,NPH=0,UNIT=0>", !a.obs_i32, roles, pn, rn);
         return true;
@@ -808,7 +1006,7 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
 #define MDPP_QN_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
 #define MDPP_QN_ROLES(O64, PN_, RN_)                                                                      \
     do {                                                                                                  \
-        if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, false, 3, PN_, RN_, false, 0, false>(MDPP_QN_ARGS); } \
+        if (roles == 3) { if constexpr (!RN_ || !PN_) quiet_launch<O64, false, 3, PN_, RN_, false, 0, false>(MDPP_QN_ARGS); } \
         else if (roles == 2) quiet_launch<O64, false, 2, PN_, RN_, false, 0, false>(MDPP_QN_ARGS);        \
         else quiet_launch<O64, false, 1, PN_, RN_, false, 0, false>(MDPP_QN_ARGS);                        \
     } while (0)
@@ -853,7 +1051,11 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
-    const int roles = trio ? 3 : duo ? 2 : 1;
+    // XR (kernel header): reward noise alone on numpy streams -- a third wave evaluates the env stream by position (+ 52 KiB of
+    // static LDS); gymnasium's next-step autoreset (the reset call must not draw) stays on two roles
+    const bool xr = duo && rn && !pn && !ph && !a.irr && a.autoreset != MDPP_AUTORESET_NEXT_STEP && lds_duo <= 84 * 1024 &&
+                    !(a.opts & MDPP_OPT_NO_TRIO);
+    const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
     // Philox handles in two roles without an irrelevant sub-space: two producer waves on top (see NPH)
     const int nph = (ph && duo && !a.irr && a.autoreset && lds_duo + 72 * 1024 <= 150 * 1024 &&
                      !(a.opts & MDPP_OPT_NO_TRIO)) ? 2 : 0;
@@ -871,7 +1073,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
             else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_, true>(MDPP_Q_ARGS);           \
             else quiet_launch<O64, IR, 1, PN_, RN_, true>(MDPP_Q_ARGS);                           \
         }                                                                                         \
-        else if (roles == 3) { if constexpr (!RN_) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
+        else if (roles == 3) { if constexpr (!RN_ || (!PN_ && !IR)) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
         else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_>(MDPP_Q_ARGS);                     \
         else quiet_launch<O64, IR, 1, PN_, RN_>(MDPP_Q_ARGS);                                     \
     } while (0)

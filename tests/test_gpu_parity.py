@@ -1887,7 +1887,7 @@ def test_sigma_zero_bench_shapes_vs_oracle_every_env(workload):
     kname = env.rollout_kernel_name(F)
     assert kname.startswith({"d_s8_rn0": "k_discrete_rollout_lean<", "d_s50_rn0": "k_discrete_rollout_quiet<",
                              "c_d2_n0": "k_continuous_rollout_fast<"}[workload]), kname
-    assert ("Z0=1" in kname) == (workload == "d_s8_rn0")
+    assert ("Z0=1" in kname) == (workload != "d_s50_rn0") and ("ROLES=3" in kname) == (workload == "d_s50_rn0"), kname
     acts = bench.make_actions(wl, F, N, env.device, 12345)
     init = env._obs.cpu().numpy().copy()
     obs, rew, term, trunc = env.rollout(acts)

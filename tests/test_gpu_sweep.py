@@ -150,8 +150,9 @@ def test_sigma_zero_noise_keys_advance_only_equals_values_formed(shape):
     b = _venv(num_envs=N, autoreset="same_step", **cfg)
     b.set_kernel_options("NO_SIGMA0")
     name = a.rollout_kernel_name(96)
-    if shape.startswith("d_s8"):
-        assert name.startswith("k_discrete_rollout_lean<") and "Z0=1" in name and "Z0" not in b.rollout_kernel_name(96), name
+    if shape.startswith("d_s8") or shape in ("c_d2_n0", "c_d2_rn0_only"):
+        assert "Z0=1" in name and "Z0" not in b.rollout_kernel_name(96), name
+        assert name.startswith("k_discrete_rollout_lean<" if shape[0] == "d" else "k_continuous_rollout_fast<D=2,"), name
     g = np.random.default_rng(23)
     for piece, F in enumerate((96, 40)):
         acts = torch.as_tensor(_rand_actions(a, F, g), device=a.device)
