@@ -92,6 +92,7 @@ enum { MDPP_OPT_NO_PIPE = 1u << 0,         /* discrete: no three-role k_discrete
        MDPP_OPT_NO_LEAN = 1u << 13,        /* discrete: no k_discrete_rollout_lean (S <= 8 re-encoding of _pipe) */
        MDPP_OPT_NO_IMG_NEARTAB = 1u << 14, /* polygon images: k_image_obs_fast walks the bounding box instead of the near-dword table */
        MDPP_OPT_NO_STEP1 = 1u << 15,       /* mdpp_step (K = 1): the rollout kernels with K = 1 instead of k_discrete_step1 / k_continuous_step1 */
+       MDPP_OPT_NO_QUIET_SF = 1u << 17,    /* k_discrete_rollout_quiet: no compile-time form of the sweep defaults (sequence_length 1, same-step autoreset, ...) */
        MDPP_OPT_NO_SIGMA0 = 1u << 16       /* noise keys present with sigma 0 (the reference draws rng.normal(0, 0): rl_toy_env.py:398-403, :1982):
                                               form the normals' values anyway instead of advancing the streams alone */ };
 

@@ -21,7 +21,7 @@ PEER_HANDLE_BYTES = 64
 OPTIONS = {"NO_PIPE": 1 << 0, "NO_HELPER": 1 << 1, "NO_PARK": 1 << 2, "NO_CFAST": 1 << 3, "NO_QUIET": 1 << 4,
            "NO_QUIET_NOISE": 1 << 5, "NO_DUO": 1 << 6, "NO_TRIO": 1 << 7, "NO_GFAST": 1 << 8,
            "NO_GFAST_NOISE": 1 << 9, "NO_IMGFAST": 1 << 10, "NO_IMG_OVERLAP": 1 << 11, "NO_PHILOX_FAST": 1 << 12, "NO_LEAN": 1 << 13,
-           "NO_IMG_NEARTAB": 1 << 14, "NO_STEP1": 1 << 15, "NO_SIGMA0": 1 << 16}
+           "NO_IMG_NEARTAB": 1 << 14, "NO_STEP1": 1 << 15, "NO_SIGMA0": 1 << 16, "NO_QUIET_SF": 1 << 17}
 
 EXPORTS = [
     "mdpp_abi_version", "mdpp_create", "mdpp_destroy", "mdpp_last_error",

@@ -99,7 +99,14 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // hand a handle to each other mid-episode), and the reward is formed in float64 in the reference's order like
 // k_discrete_step<UNIT = false> does.  Until round 5 these handles ran on the one-role general kernel (0.14 of the HBM
 // roofline at S = 24).
-template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true>
+// SF (round 6): the E wave is ONE wave that issues ~270 instructions per env step in the general form (vector and scalar:
+// every run-time option is a select or a mask operation on every step), and a wave issues about one instruction per 4 cycles --
+// 1 000 cycles per step, the kernel's whole time at S = 50 (the O wave: 32 vector instructions per step).  SF fixes what the
+// reference's S = 20-50 sweeps leave at their defaults -- sequence_length 1, same-step autoreset, no step limit, every step pays,
+// one sub-space, no transition noise, S <= 128 -- at compile time: the sequence key IS the state, no history window to shift,
+// no phase, no pending reset, the terminal flag rides in bit 7 of the P entry (one LDS round trip per step instead of two
+// dependent ones), and the numpy-indexing fix-up of the action runs only when some lane's action is out of range.
+template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true, bool SF = false>
 __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
@@ -122,6 +129,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     __shared__ double s_wi[ZIG ? 256 : 1], s_fi[ZIG ? 256 : 1];
     constexpr bool XR = ROLES == 3 && RN && !PH;    // the third wave evaluates the env stream by position (header)
     static_assert(!XR || (!PN && !IRR && NPH == 0), "XR: reward noise alone, one sub-space");
+    static_assert(!SF || (ROLES == 3 && !PN && !IRR && !PH && NPH == 0), "SF: three roles, numpy streams, one sub-space, no transition noise");
     static_assert(!(ATNEED && ROLES == 3) || XR, "reward noise and reset draws share the env stream: no start-state queue");
     __shared__ uint32_t x_meta[XR ? kXR : 1][kBlock];
     __shared__ __align__(8) double x_val[XR ? kXR : 1][kBlock];
@@ -140,7 +148,11 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const int role = DUO ? tid / kBlock : 0;        // 0 = E, 1 = O, 2 = H
     const int l = DUO ? (tid & (kBlock - 1)) : tid, w = l >> 6;
     // shared MDP -> LDS (same carve as k_discrete_step) + the irrelevant sub-space's table and cdf
-    for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
+    if constexpr (SF) {                              // entry = next state | is_terminal[next state] << 7 (S <= 128, host-checked)
+        for (int k = tid; k < a.S * a.A; k += kThreads) { const uint8_t nx = a.P[k]; lds[a.lds_P + k] = (uint8_t)(nx | (a.is_term[nx] ? 0x80u : 0u)); }
+    } else {
+        for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
+    }
     for (int k = tid; k < a.S; k += kThreads) lds[a.lds_term + k] = a.is_term[k];
     if (UR) { for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k]; }
     else { for (uint32_t k = tid; k < a.nkeys; k += kThreads) ((double *)(lds + a.lds_rew))[k] = a.rtable[k]; }
@@ -224,12 +236,12 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 
     const uint32_t i = blockIdx.x * kBlock + l;
     if (!DUO && i >= (uint32_t)a.N) return;            // (DUO launches have full blocks only)
-    const uint32_t N = (uint32_t)a.N, S = (uint32_t)a.S, A = (uint32_t)a.A, L = (uint32_t)a.L;
+    const uint32_t N = (uint32_t)a.N, S = (uint32_t)a.S, A = (uint32_t)a.A, L = SF ? 1u : (uint32_t)a.L;
     const uint4 st = a.state[i];
     uint64_t hist = ((uint64_t)st.y << 32) | st.x;               // last L+1 states, newest in byte 0, 0xFF = NaN slot
     // next-step autoreset: "episode ended, reset at the next call" travels in bit 31 of the step counter (k_discrete_step);
     // the reset call ignores the action, draws nothing from the noise streams and returns (start state, 0.0, no flags)
-    const bool nextmode = a.autoreset == MDPP_AUTORESET_NEXT_STEP;
+    const bool nextmode = SF ? false : a.autoreset == MDPP_AUTORESET_NEXT_STEP;
     uint32_t steps = st.z & 0x7FFFFFFFu, ringbits = st.w, status = 0;
     bool pend = nextmode && (st.z >> 31) != 0u;
     uint32_t cur1 = IRR ? a.irr_state[i] : 0u;
@@ -376,14 +388,18 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         if (hstatus) atomicOr(&a.status[i], hstatus);
         return;
     }
-    const bool autoreset = a.autoreset != 0, has_max = a.max_steps > 0;
-    const uint32_t max_steps = (uint32_t)a.max_steps, every_n = (uint32_t)a.every_n, delay = (uint32_t)a.delay;
+    const bool autoreset = SF ? true : a.autoreset != 0, has_max = SF ? false : a.max_steps > 0;
+    const uint32_t max_steps = (uint32_t)a.max_steps, every_n = SF ? 1u : (uint32_t)a.every_n, delay = (uint32_t)a.delay;
     const bool isE = !DUO || role == 0;
     // =============================================================== X: the env stream by position (header, XR)
     if constexpr (XR) if (role == 2) {
         __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
         uint32_t hq = 0, spins = 0, xstatus = 0;        // positions made
-        uint64_t look = g.next64();                     // the word of position hq (the generator runs one word ahead)
+        // (the limb form of the PCG64 step, mdpp_rng.hpp: 31 instead of 46 vector instructions per word -- this wave is a generator
+        //  and little else; its fixed temporaries v150-v157 fit the 168 registers of a 768-thread kernel)
+        Pcg64Limbs gx;
+        gx.from(g);
+        uint64_t look = gx.next64();                    // the word of position hq (the generator runs one word ahead)
         // start state of a reset whose word is r: #{j : ceil(cdf[j] 2^53) <= r >> 11} (draw_state's search)
         auto start_of = [&](uint64_t r) __attribute__((always_inline)) -> uint32_t {
             const uint64_t m = r >> 11;
@@ -415,7 +431,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 #pragma unroll
                     for (int u = 0; u < kXB; u++) {
                         const uint64_t wd = wdv[u];
-                        wdv[u + 1] = g.next64();
+                        wdv[u + 1] = gx.next64();
                         const uint32_t idx = (uint32_t)wd & 0xffu;
                         const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
                         const bool ok = rabs < zig.ki[idx];
@@ -445,7 +461,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                         if (__builtin_expect(idx == 0u, 0)) {   // tail: two uniforms per try (np_zig_tail), 3 in 10^4 draws
                             const double nor_r = 3.6541528853610087963519472518, nor_inv_r = 0.27366123732975827203338247596;
                             // its words: what the batch still holds behind position j, then a copy of the generator
-                            Pcg64 t = g;
+                            Pcg64Limbs t = gx;
                             uint32_t have = (uint32_t)kXB - j, cnt = 1u;
                             auto word = [&]() -> uint64_t {
                                 uint64_t r = 0;
@@ -490,6 +506,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             }
         }
         // un-draw what was made and not used (+ the word in hand): s_prev = (s - inc) * M^-1 (mod 2^128)
+        gx.to(g);
         for (uint32_t q = hq + 1u - __hip_atomic_load(&x_epos[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); q > 0; q--) {
             const uint64_t lo = g.s_lo - g.inc_lo;
             const uint64_t hi = g.s_hi - g.inc_hi - (g.s_lo < g.inc_lo ? 1ULL : 0ULL);
@@ -634,11 +651,16 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         const uint64_t ptick = ptick0 + (uint64_t)kstep;        // (Philox streams)
         if (!ATNEED && __builtin_expect(__builtin_amdgcn_ballot_w64(autoreset && qn == 0u) != 0, 0)) ensure_start();
         int action = (int)act2.x;
-        action += (action < 0 && action >= -(int)A) ? (int)A : 0;           // numpy negative indexing
-        const bool bad = action < 0 || action >= (int)A;
-        action = bad ? 0 : action;
+        bool bad = false;
+        if (!SF || __builtin_expect(__builtin_amdgcn_ballot_w64((uint32_t)action >= A) != 0, 0)) {
+            action += (action < 0 && action >= -(int)A) ? (int)A : 0;       // numpy negative indexing
+            bad = action < 0 || action >= (int)A;
+            action = bad ? 0 : action;
+        }
         const uint32_t cur = (uint32_t)hist & 0xFFu;
-        uint32_t nxt = P[cur * A + (uint32_t)action];                        // D1
+        uint32_t nxt = P[SF ? __umul24(cur, A) + (uint32_t)action : cur * A + (uint32_t)action];   // D1
+        bool done_sf = false;
+        if constexpr (SF) { done_sf = nxt > 0x7Fu; nxt &= 0x7Fu; }          // (bit 7 of the entry: D7)
         if constexpr (PN && PH) {                                            // D2, Philox streams: mdpp_rng.hpp philox_pnoise_*
             uint32_t ent = hent;
             if constexpr (NPH == 0) ent = philox_pnoise_index(pnw.word(a.philox_seed, genv, ptick, kPhiloxPNoiseStream), a.pn_T, pn_M);
@@ -656,13 +678,18 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             }
             nxt = c;
         }
-        const uint32_t oldest = (uint32_t)(hist >> (8 * (L - 1))) & 0xFFu;   // leaves the L-window
-        key = (key - (oldest == 0xFFu ? 0u : oldest) * spow) * S + nxt;     // D4 key, carried
+        if constexpr (SF) {                                                  // sequence_length 1: the key is the state
+            key = nxt;
+        } else {
+            const uint32_t oldest = (uint32_t)(hist >> (8 * (L - 1))) & 0xFFu;   // leaves the L-window
+            key = (key - (oldest == 0xFFu ? 0u : oldest) * spow) * S + nxt;     // D4 key, carried
+        }
         hist = (hist << 8) | nxt;                                            // D3
         valid = min(valid + 1u, L + 1u);
         steps += 1;
         phase = (phase + 1 >= every_n) ? 0u : phase + 1;
-        const bool done = is_term[nxt] != 0;                                 // D7
+        bool done = done_sf;
+        if constexpr (!SF) done = is_term[nxt] != 0;                         // D7
         uint32_t bad1 = 0;
         if (IRR) {                                                           // :2063-2082
             int action1 = (int)act2.y;
@@ -960,10 +987,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 #ifndef MDPP_QUIET_TU_NU
 #define MDPP_QUIET_TU_NU 0         // 1: this translation unit holds the non-unit-reward instantiations (mdpp_discrete_quiet_nu.hip)
 #endif
-template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true>
+template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true, bool SF = false>
 static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH, UR>;
+    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH, UR, SF>;
     if (lds > 48 * 1024) {                        // tables + record ring beyond the default dynamic-LDS limit
         static size_t allowed = 0;                // (per instantiation)
         if (lds > allowed) {
@@ -998,15 +1025,19 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
     // XR (kernel header): reward noise alone -- a third wave evaluates the env stream by position (+ 52 KiB of static LDS)
     const bool xr = duo && rn && !pn && lds_duo <= 84 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
+    // SF (kernel header): the reference's sweep defaults fixed at compile time
+    const bool sf = roles == 3 && !pn && a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
+                    a.S <= 128 && !(a.opts & MDPP_OPT_NO_QUIET_SF);
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=0,ROLES=%d,PN=%d,RN=%d,PHILOX=0,NPH=0,UNIT=0>", !a.obs_i32, roles, pn, rn);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=0,ROLES=%d,PN=%d,RN=%d,PHILOX=0,NPH=0,UNIT=0%s>", !a.obs_i32, roles, pn, rn, sf ? ",SF=1" : "");
         return true;
     }
     const size_t l = roles == 1 ? lds : lds_duo;
 #define MDPP_QN_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
 #define MDPP_QN_ROLES(O64, PN_, RN_)                                                                      \
     do {                                                                                                  \
-        if (roles == 3) { if constexpr (!RN_ || !PN_) quiet_launch<O64, false, 3, PN_, RN_, false, 0, false>(MDPP_QN_ARGS); } \
+        if (roles == 3 && sf) { if constexpr (!PN_) quiet_launch<O64, false, 3, PN_, RN_, false, 0, false, !PN_>(MDPP_QN_ARGS); } \
+        else if (roles == 3) { if constexpr (!RN_ || !PN_) quiet_launch<O64, false, 3, PN_, RN_, false, 0, false>(MDPP_QN_ARGS); } \
         else if (roles == 2) quiet_launch<O64, false, 2, PN_, RN_, false, 0, false>(MDPP_QN_ARGS);        \
         else quiet_launch<O64, false, 1, PN_, RN_, false, 0, false>(MDPP_QN_ARGS);                        \
     } while (0)
@@ -1056,12 +1087,15 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const bool xr = duo && rn && !pn && !ph && !a.irr && a.autoreset != MDPP_AUTORESET_NEXT_STEP && lds_duo <= 84 * 1024 &&
                     !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
+    // SF (kernel header): the reference's sweep defaults fixed at compile time
+    const bool sf = roles == 3 && !pn && !ph && !a.irr && a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 &&
+                    a.every_n == 1 && a.S <= 128 && !(a.opts & MDPP_OPT_NO_QUIET_SF);
     // Philox handles in two roles without an irrelevant sub-space: two producer waves on top (see NPH)
     const int nph = (ph && duo && !a.irr && a.autoreset && lds_duo + 72 * 1024 <= 150 * 1024 &&
                      !(a.opts & MDPP_OPT_NO_TRIO)) ? 2 : 0;
     if (name_out) {
-        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d,NPH=%d>", !a.obs_i32,
-                 a.irr != 0, roles, pn, rn, ph, nph);
+        snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=%d,ROLES=%d,PN=%d,RN=%d,PHILOX=%d,NPH=%d%s>", !a.obs_i32,
+                 a.irr != 0, roles, pn, rn, ph, nph, sf ? ",SF=1" : "");
         return true;
     }
     const size_t l = roles == 1 ? lds : lds_duo;
@@ -1073,6 +1107,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
             else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_, true>(MDPP_Q_ARGS);           \
             else quiet_launch<O64, IR, 1, PN_, RN_, true>(MDPP_Q_ARGS);                           \
         }                                                                                         \
+        else if (roles == 3 && sf) { if constexpr (!PN_ && !IR) quiet_launch<O64, IR, 3, PN_, RN_, false, 0, true, !PN_ && !IR>(MDPP_Q_ARGS); }  \
         else if (roles == 3) { if constexpr (!RN_ || (!PN_ && !IR)) quiet_launch<O64, IR, 3, PN_, RN_>(MDPP_Q_ARGS); }  \
         else if (roles == 2) quiet_launch<O64, IR, 2, PN_, RN_>(MDPP_Q_ARGS);                     \
         else quiet_launch<O64, IR, 1, PN_, RN_>(MDPP_Q_ARGS);                                     \

@@ -212,6 +212,21 @@ QUIET = {
                            sequence_length=1, transition_noise=0.35), {}, 333),
     "pn_rn0_horizon": (dict(state_space_size=20, action_space_size=20, sequence_length=2, delay=2, transition_noise=0.4,
                             reward_noise=0.0, reward_every_n_steps=1), dict(max_episode_steps=9), 256),
+    # round 6: the reference's sweep defaults (sequence_length 1, same-step autoreset, no step limit) -- the compile-time form SF
+    # -- without a noise key (E / O / H), with reward noise (XR: the third wave evaluates the env stream by position; values
+    # used), with the key at sigma 0, a delay line, non-unit rewards; S = 130 is past SF's terminal bit
+    "sf_s50": (dict(state_space_size=50, action_space_size=50, sequence_length=1, delay=0, reward_density=0.25,
+                    terminal_state_density=0.25), {}, 1024),
+    "sf_s50_rn": (dict(state_space_size=50, action_space_size=50, sequence_length=1, delay=2, reward_density=0.25,
+                       terminal_state_density=0.25, reward_noise=0.7, reward_scale=1.5, term_state_reward=-1.0), {}, 1024),
+    "sf_s24_rn0": (dict(state_space_size=24, action_space_size=24, sequence_length=1, delay=1, reward_density=0.25,
+                        terminal_state_density=0.25, reward_noise=0.0), {}, 768),
+    "sf_s24_rdist_rn": (dict(state_space_size=24, action_space_size=24, sequence_length=1, delay=1, reward_density=0.25,
+                             terminal_state_density=0.25, reward_dist=[0.01, 1], reward_noise=0.2), {}, 512),
+    "xr_s20_l2_rn": (dict(state_space_size=20, action_space_size=20, sequence_length=2, delay=1, reward_noise=0.4,
+                          reward_every_n_steps=1), dict(max_episode_steps=11), 512),
+    "xr_s130_rn_noreset": (dict(state_space_size=130, action_space_size=20, sequence_length=1, delay=0, reward_density=0.1,
+                                reward_noise=0.3), dict(autoreset="disabled"), 512),
 }
 
 
@@ -232,6 +247,9 @@ def test_discrete_quiet_rollout_kernel_vs_oracle(variant):
         warnings.simplefilter("ignore")
         env = _venv(num_envs=N, **kw, **cfg)
     assert not env.rollout_kernel_name(64).startswith(("k_discrete_rollout_fast", "k_discrete_rollout_pipe"))
+    if variant.startswith(("sf_", "xr_")):
+        kn = env.rollout_kernel_name(64)
+        assert kn.startswith("k_discrete_rollout_quiet<") and "ROLES=3" in kn and ("SF=1" in kn) == variant.startswith("sf_"), kn
     m = env.mdps[0]
     horizon = env_kw.get("max_episode_steps", 0)
     auto = kw["autoreset"] == "same_step"
