@@ -106,7 +106,14 @@ constexpr uint32_t kQStatusInternal = 0x80000000u;
 // one sub-space, no transition noise, S <= 128 -- at compile time: the sequence key IS the state, no history window to shift,
 // no phase, no pending reset, the terminal flag rides in bit 7 of the P entry (one LDS round trip per step instead of two
 // dependent ones), and the numpy-indexing fix-up of the action runs only when some lane's action is out of range.
-template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true, bool SF = false>
+// PE (round 6): one MDP PER ENV (RLToyVectorEnv(seeds=[...]): env i is the reference's RLToyEnv(seed=seeds[i]), tables per env in
+// HBM -- what every golden uses).  These handles ran the one-role general kernel with each lane's tables in an LDS slot: one
+// wave per SIMD doing everything, 1.1 us per step (0.13 of the HBM roofline at 65 536 envs).  Here the lane's tables -- P
+// (terminal bit folded in under SF), terminal flags, reward bits, rho_0 thresholds; 280 B at 8 x 8 -- are staged into ITS slot
+// of the workgroup's dynamic LDS once per launch (slot stride = the shared carve + the thresholds + 8 bytes: bank spread) and
+// every table pointer of the E / O / H (or X) roles carries the lane's slot offset; everything else is the shared-MDP kernel.
+// S <= 16 (no bucket table), unit rewards, one sub-space, numpy streams, no transition noise, three roles.
+template <bool OBS64, bool IRR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true, bool SF = false, bool PE = false>
 __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_quiet(DiscreteArgs a, int K,
                                                                    const int32_t *__restrict__ actions,
                                                                    void *__restrict__ obs, float *__restrict__ reward,
@@ -131,8 +138,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     static_assert(!XR || (!PN && !IRR && NPH == 0), "XR: reward noise alone, one sub-space");
     static_assert(!SF || (ROLES == 3 && !PN && !IRR && !PH && NPH == 0), "SF: three roles, numpy streams, one sub-space, no transition noise");
     static_assert(!(ATNEED && ROLES == 3) || XR, "reward noise and reset draws share the env stream: no start-state queue");
-    __shared__ uint32_t x_meta[XR ? kXR : 1][kBlock];
-    __shared__ __align__(8) double x_val[XR ? kXR : 1][kBlock];
+    static_assert(!PE || (ROLES == 3 && UR && !PN && !IRR && !PH && NPH == 0), "PE: three roles, unit rewards, numpy streams, one sub-space");
+    constexpr int XRN = PE ? kXR / 2 : kXR;         // positions X runs ahead of E (PE: the lanes' table slots need the LDS)
+    __shared__ uint32_t x_meta[XR ? XRN : 1][kBlock];
+    __shared__ __align__(8) double x_val[XR ? XRN : 1][kBlock];
     __shared__ uint32_t x_hhead[XR ? kBlock : 1], x_epos[XR ? kBlock : 1];      // positions made by X / reached by E
     static_assert(NPH == 0 || (PH && ROLES == 2 && !IRR), "Philox producers: two roles, one sub-space");
     // producers -> E: per env and step {other-state index j | noisy << 8 | start state << 16} and the reward normal
@@ -148,14 +157,36 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const int role = DUO ? tid / kBlock : 0;        // 0 = E, 1 = O, 2 = H
     const int l = DUO ? (tid & (kBlock - 1)) : tid, w = l >> 6;
     // shared MDP -> LDS (same carve as k_discrete_step) + the irrelevant sub-space's table and cdf
+    // (PE: this lane's MDP into its slot -- the three threads that serve lane l share the copy)
+    // (PE's own carve of a slot: P, terminal flags, reward bits, then the S8 thresholds, + 8 bytes of bank spread)
+    const uint32_t pe_S8 = ((uint32_t)a.S + 7u) & ~7u;
+    const uint32_t pe_term = (uint32_t)(a.S * a.A), pe_rew = (pe_term + (uint32_t)a.S + 7u) & ~7u, pe_T0 = (pe_rew + a.rbits_stride + 7u) & ~7u;
+    const uint32_t pe_stride = PE ? pe_T0 + pe_S8 * 8u + 8u : 0u;
+    const uint32_t pe_off = PE ? (uint32_t)l * pe_stride : 0u;
+    if constexpr (PE) {
+        const size_t ti = (size_t)blockIdx.x * kBlock + (size_t)l;          // (full blocks only: three roles)
+        const int SA = a.S * a.A;
+        unsigned char *slot = lds + pe_off;
+        for (int k = role; k < SA; k += ROLES) {
+            const uint8_t nx = a.P[ti * SA + k];
+            slot[k] = SF ? (uint8_t)(nx | (a.is_term[ti * a.S + nx] ? 0x80u : 0u)) : nx;
+        }
+        for (int k = role; k < a.S; k += ROLES) slot[pe_term + k] = a.is_term[ti * a.S + k];
+        for (uint32_t k = role; k < a.rbits_stride; k += ROLES) slot[pe_rew + k] = a.rbits[ti * a.rbits_stride + k];
+        for (uint32_t k = role; k < pe_S8; k += ROLES)
+            ((uint64_t *)(slot + pe_T0))[k] =
+                k < (uint32_t)a.S ? (uint64_t)ceil(a.init_cdf[ti * a.S + k] * 9007199254740992.0) : ~0ULL;
+    } else
     if constexpr (SF) {                              // entry = next state | is_terminal[next state] << 7 (S <= 128, host-checked)
         for (int k = tid; k < a.S * a.A; k += kThreads) { const uint8_t nx = a.P[k]; lds[a.lds_P + k] = (uint8_t)(nx | (a.is_term[nx] ? 0x80u : 0u)); }
     } else {
         for (int k = tid; k < a.S * a.A; k += kThreads) lds[a.lds_P + k] = a.P[k];
     }
+    if constexpr (!PE) {
     for (int k = tid; k < a.S; k += kThreads) lds[a.lds_term + k] = a.is_term[k];
     if (UR) { for (uint32_t k = tid; k < a.rbits_stride; k += kThreads) lds[a.lds_rew + k] = a.rbits[k]; }
     else { for (uint32_t k = tid; k < a.nkeys; k += kThreads) ((double *)(lds + a.lds_rew))[k] = a.rtable[k]; }
+    }
     if (ZIG) zig_stage(s_ki, s_wi, s_fi, tid, kThreads);
     const ZigLds zig{s_ki, s_wi, s_fi};
     // rho_0 as integer thresholds: cdf[j] <= u  <=>  ceil(cdf[j] * 2^53) <= r >> 11 (exact: u is
@@ -166,7 +197,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const uint32_t lds_TN = lds_T1 + S18 * 8u;                 // PN: S rows of S8 thresholds of the noise categoricals
     constexpr bool PNC = PN && !PH;                             // (Philox streams need no cdf: philox_pnoise_*)
     const uint32_t lds_TN1 = lds_TN + (PNC ? (uint32_t)a.S * S8 * 8u : 0u);   // ... and S1 rows of S18 for the irrelevant sub-space
-    const uint32_t lds_end = lds_TN1 + ((PNC && IRR) ? (uint32_t)a.S1 * S18 * 8u : 0u);
+    const uint32_t lds_end = PE ? (uint32_t)kBlock * pe_stride : lds_TN1 + ((PNC && IRR) ? (uint32_t)a.S1 * S18 * 8u : 0u);
     if (PNC) {
         for (uint32_t k = tid; k < (uint32_t)a.S * S8; k += kThreads) {
             const uint32_t row = k / S8, col = k - row * S8;
@@ -181,6 +212,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             }
         }
     }
+    if constexpr (!PE)
     for (uint32_t k = tid; k < S8; k += kThreads)
         ((uint64_t *)(lds + lds_T0))[k] = k < (uint32_t)a.S ? (uint64_t)ceil(a.init_cdf[k] * 9007199254740992.0) : ~0ULL;
     if (NPH)       // cdf[j] <= m31 2^-31  <=>  ceil(cdf[j] 2^31) <= m31; padding never counts
@@ -210,16 +242,17 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     // DUO: the record ring follows the tables in dynamic LDS
     uint64_t *ring = (uint64_t *)(lds + ((lds_end + 15u) & ~15u));
     double *ringz = (double *)(ring + kDepth * kBlock);         // RN: the step's standard normal
-    const uint8_t *P = lds + a.lds_P, *is_term = lds + a.lds_term, *rbits = lds + a.lds_rew, *P1 = lds + lds_P1;
-    const uint64_t *T0 = (const uint64_t *)(lds + lds_T0), *T1 = (const uint64_t *)(lds + lds_T1);
+    const uint8_t *P = lds + (PE ? pe_off : a.lds_P), *is_term = lds + (PE ? pe_off + pe_term : a.lds_term),
+                  *rbits = lds + (PE ? pe_off + pe_rew : a.lds_rew), *P1 = lds + lds_P1;
+    const uint64_t *T0 = (const uint64_t *)(lds + (PE ? pe_off + pe_T0 : lds_T0)), *T1 = (const uint64_t *)(lds + lds_T1);
     const uint64_t *TN = (const uint64_t *)(lds + lds_TN), *TN1 = (const uint64_t *)(lds + lds_TN1);
     // Large state spaces (round 5; the reference's 24- and 50-state sweeps): rho_0's S thresholds are not searched one by one
     // (S = 50: 56 64-bit compares per draw, 150 vector instructions -- most of the H wave) but through a bucket table over the
     // top 12 bits of the 53-bit draw: s_bk[b] = {thresholds at or below the bucket's first value, thresholds strictly inside it};
     // a draw compares with the few thresholds inside its bucket (none for 99 % of the buckets).  Built here from T0.
     // (8 KiB of static LDS only in the instantiations that can use it: numpy streams, two or three roles)
-    __shared__ uint16_t s_bk[(!PH && ROLES >= 2) ? 4096 : 1];
-    const bool use_bk = !PH && DUO && S8 > 16u;
+    __shared__ uint16_t s_bk[(!PH && ROLES >= 2 && !PE) ? 4096 : 1];
+    const bool use_bk = !PH && DUO && !PE && S8 > 16u;
     if (use_bk) {
         for (uint32_t b = tid; b < 4096u; b += kThreads) {
             const uint64_t lo = (uint64_t)b << 41, hi = lo + (1ULL << 41);
@@ -420,7 +453,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         for (;;) {
             if (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == kBlock / 64) break;
             const uint32_t epos = __hip_atomic_load(&x_epos[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool go = hq + (uint32_t)kXB <= epos + (uint32_t)kXR;
+            const bool go = hq + (uint32_t)kXB <= epos + (uint32_t)XRN;
             if (__builtin_amdgcn_ballot_w64(go) != 0) {
                 // The generator runs ONE word ahead (`look` = the word of position hq): the uniform a wedge point of position p
                 // takes is word p + 1, which the batch has in hand -- no copy of the generator, no saved states
@@ -436,7 +469,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                         const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
                         const bool ok = rabs < zig.ki[idx];
                         rej |= ok ? 0u : (1u << u);
-                        const uint32_t slot = (hq + (uint32_t)u) & (uint32_t)(kXR - 1);
+                        const uint32_t slot = (hq + (uint32_t)u) & (uint32_t)(XRN - 1);
                         if (!rn_z0) {                   // numpy: x = rabs * wi, negated where bit 8 of the word is set
                             const double x = (double)rabs * zig.wi[idx];
                             x_val[slot][l] = ((uint32_t)wd & 0x100u) ? -x : x;
@@ -455,7 +488,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                         for (int u = 0; u < kXB; u++)
                             if (j == (uint32_t)u) { wd = wdv[u]; wn = wdv[u + 1]; }
                         const uint32_t idx = (uint32_t)wd & 0xffu;
-                        const uint32_t slot = (hq + j) & (uint32_t)(kXR - 1);
+                        const uint32_t slot = (hq + j) & (uint32_t)(XRN - 1);
                         const uint32_t ss = x_meta[slot][l] & 0xFFu;
                         const uint64_t rabs = (wd >> 9) & 0x000fffffffffffffULL;
                         if (__builtin_expect(idx == 0u, 0)) {   // tail: two uniforms per try (np_zig_tail), 3 in 10^4 draws
@@ -638,10 +671,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     };
     auto x_fetch = [&]() __attribute__((always_inline)) {
         x_ensure(ep + 3u);
-        xm0 = x_meta[ep & (uint32_t)(kXR - 1)][l];
-        xm1 = x_meta[(ep + 1u) & (uint32_t)(kXR - 1)][l];
-        xm2 = x_meta[(ep + 2u) & (uint32_t)(kXR - 1)][l];
-        if (!rn_z0) xv = x_val[ep & (uint32_t)(kXR - 1)][l];
+        xm0 = x_meta[ep & (uint32_t)(XRN - 1)][l];
+        xm1 = x_meta[(ep + 1u) & (uint32_t)(XRN - 1)][l];
+        xm2 = x_meta[(ep + 2u) & (uint32_t)(XRN - 1)][l];
+        if (!rn_z0) xv = x_val[ep & (uint32_t)(XRN - 1)][l];
     };
     if constexpr (XR) { if (role == 0) x_fetch(); }
     // ---- E: one step of the state recurrence -> record
@@ -987,10 +1020,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 #ifndef MDPP_QUIET_TU_NU
 #define MDPP_QUIET_TU_NU 0         // 1: this translation unit holds the non-unit-reward instantiations (mdpp_discrete_quiet_nu.hip)
 #endif
-template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true, bool SF = false>
+template <bool O64, bool IR, int ROLES, bool PN, bool RN, bool PH = false, int NPH = 0, bool UR = true, bool SF = false, bool PE = false>
 static void quiet_launch(const DiscreteArgs &a, int K, size_t lds, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s) {
-    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH, UR, SF>;
+    auto kern = k_discrete_rollout_quiet<O64, IR, ROLES, PN, RN, PH, NPH, UR, SF, PE>;
     if (lds > 48 * 1024) {                        // tables + record ring beyond the default dynamic-LDS limit
         static size_t allowed = 0;                // (per instantiation)
         if (lds > allowed) {
@@ -1061,6 +1094,35 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
 bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                            uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     if (!a.unit_rewards) return launch_discrete_quiet_nu(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    if (!a.shared_tables) {
+        // PE (kernel header): one MDP per env, each lane's tables in its slot of the workgroup's LDS, three roles
+        const bool rn = a.has_r_noise != 0;
+        if (!a.rew_in_lds || a.irr || a.philox || a.has_p_noise || a.S > 16 || K < 32 || (a.N % kBlock) != 0 ||
+            a.autoreset == MDPP_AUTORESET_NEXT_STEP || (!rn && !a.autoreset) ||
+            (a.opts & (MDPP_OPT_NO_QUIET | MDPP_OPT_NO_DUO | MDPP_OPT_NO_TRIO)) || (rn && (a.opts & MDPP_OPT_NO_QUIET_NOISE)))
+            return false;
+        if ((unsigned long long)K * a.N * 8ULL >= (1ULL << 32)) return false;
+        const size_t S8 = (size_t)((a.S + 7) & ~7);
+        const size_t pe_rew = ((size_t)a.S * a.A + a.S + 7) & ~(size_t)7, pe_T0 = (pe_rew + a.rbits_stride + 7) & ~(size_t)7;
+        const size_t stride = pe_T0 + S8 * 8 + 8;             // (the kernel's carve of a lane's slot)
+        const size_t depth = rn ? 16 : kQDepth;
+        const size_t l = ((stride * kBlock + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
+        if (l + (rn ? 40u : 8u) * 1024u > 160u * 1024u) return false;     // (+ the instantiation's static LDS: X rings, ziggurat tables, counters)
+        const bool sf = a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
+                        !(a.opts & MDPP_OPT_NO_QUIET_SF);
+        if (name_out) {
+            snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=0,ROLES=3,PN=0,RN=%d,PHILOX=0,NPH=0%s,PE=1>", !a.obs_i32, rn,
+                     sf ? ",SF=1" : "");
+            return true;
+        }
+#define MDPP_QPE(O64, RN_, SF_) quiet_launch<O64, false, 3, false, RN_, false, 0, true, SF_, true>(a, K, l, actions, obs, reward, term, trunc, final_obs, s)
+#define MDPP_QPE2(O64) do { if (rn) { if (sf) MDPP_QPE(O64, true, true); else MDPP_QPE(O64, true, false); } \
+                            else { if (sf) MDPP_QPE(O64, false, true); else MDPP_QPE(O64, false, false); } } while (0)
+        if (a.obs_i32) MDPP_QPE2(false); else MDPP_QPE2(true);
+#undef MDPP_QPE2
+#undef MDPP_QPE
+        return true;
+    }
     if (!a.shared_tables || !a.unit_rewards || !a.rew_in_lds || a.fast_ok || K < 16 || (a.opts & MDPP_OPT_NO_QUIET))
         return false;
     if (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) return false;

@@ -1947,6 +1947,70 @@ def test_sigma_zero_bench_shapes_vs_oracle_every_env(workload):
     env.close()
 
 
+@pytest.mark.parametrize("variant", ["l3_delay4", "sf_l1", "rn_l2", "sf_rn0", "noreset_rn", "s16_l1"])
+def test_per_env_mdps_on_the_role_split_kernel_vs_oracle(variant):
+    """Round 6: one MDP PER ENV (seeds=[...]: env i is the reference's RLToyEnv(seed=i) -- what every golden
+    uses) on k_discrete_rollout_quiet<PE=1>: each lane's tables in its slot of the workgroup's LDS, E / O / H (or X) roles.
+    1 024 different MDPs; fused rollouts (the role-split kernel), short ones and single steps (the general kernel, same
+    handle: the two hand the state to each other); EVERY env against its own oracle -- observations, rewards, flags and the
+    end states of both streams after every launch."""
+    from mdp_playground_amd import _capi as capi
+    base = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8)
+    cfg, kw = {"l3_delay4": (dict(base, delay=4, sequence_length=3), {}),
+               "sf_l1": (dict(base, delay=1, sequence_length=1, reward_density=0.25, terminal_state_density=0.25), {}),
+               "rn_l2": (dict(base, delay=2, sequence_length=2, reward_noise=0.5, reward_scale=2.0, term_state_reward=-1.0),
+                         dict(max_episode_steps=13)),
+               "sf_rn0": (dict(base, delay=0, sequence_length=1, reward_noise=0.0, reward_density=0.25, terminal_state_density=0.25), {}),
+               "noreset_rn": (dict(base, delay=1, sequence_length=2, reward_noise=0.3), dict(autoreset="disabled")),
+               "s16_l1": (dict(base, state_space_size=16, action_space_size=12, delay=0, sequence_length=1, reward_density=0.2,
+                               terminal_state_density=0.125), {})}[variant]
+    N = 1024
+    kwargs = dict(autoreset="same_step")
+    kwargs.update(kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = _venv(seeds=list(range(100, 100 + N)), **kwargs, **cfg)
+    kn = env.rollout_kernel_name(64)
+    assert kn.startswith("k_discrete_rollout_quiet<") and "PE=1" in kn and ("SF=1" in kn) == (variant in ("sf_l1", "sf_rn0", "s16_l1")), kn
+    assert env.rollout_kernel_name(8).startswith("k_discrete_step<")
+    auto = kwargs["autoreset"] == "same_step"
+    horizon = kwargs.get("max_episode_steps", 0)
+    A = env.mdps[0].A
+    r = np.random.default_rng(7)
+    init = env._obs.cpu().numpy().copy()
+    oracles = []
+    for i in range(N):
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert np.array_equal(np.asarray(o.reset()), init[i])
+        oracles.append([o, 0])
+    for K in (64, 1, 40, 8, 96):
+        acts = r.integers(0, A, size=(K, N)).astype(np.int32)
+        at = torch.as_tensor(acts, device=env.device)
+        if K == 1:
+            o1, r1, t1, tr1, _ = env.step(at[0])
+            obs, rew, term, trunc = (x[None].cpu().numpy() for x in (o1, r1, t1, tr1))
+        else:
+            obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(at))
+        env_end, sp_end = env.get_rng_streams(capi.STREAM_ENV), env.get_rng_streams(capi.STREAM_SPACE)
+        for i, rec in enumerate(oracles):
+            o = rec[0]
+            for t in range(K):
+                st, rr, d = o.step(acts[t, i])
+                rec[1] += 1
+                tr = bool(horizon) and rec[1] >= horizon
+                assert d == bool(term[t, i]) and tr == bool(trunc[t, i]), (variant, K, i, t)
+                assert np.float32(rr) == rew[t, i], (variant, K, i, t, rr, rew[t, i])
+                if auto and (d or tr):
+                    st = o.reset(explicit=False)
+                    rec[1] = 0
+                assert np.array_equal(obs[t, i], np.asarray(st)), (variant, K, i, t)
+            assert np.array_equal(o.get_rng()[0][:4], env_end[i][:4]), (variant, K, i)
+            assert np.array_equal(o.get_rng()[1][:4], sp_end[i][:4]), (variant, K, i)
+    assert int(env.status().sum()) == 0
+    env.close()
+
+
 def test_edge_shapes_and_errors():
     cfg = _cfg("d_cfg2", 1)
     # ragged sizes: 1 env, and a batch that is not a multiple of the wave or block size
