@@ -53,7 +53,10 @@ constexpr int kQQ = 4;                         // start states queued per lane
 // data registers right behind the store) does not exist and inserts no wait state; on gfx950 it does
 // exist: lanes 12-15 of every 16 stored the overwritten register (found by the role-split soak test).
 constexpr int kQRsrc = 0x00020000;
-constexpr int kQDepth = 24;                    // E -> O ring depth in steps (multiple of the chunk of 8)
+#ifndef MDPP_Q_DEPTH
+#define MDPP_Q_DEPTH 24
+#endif
+constexpr int kQDepth = MDPP_Q_DEPTH;          // E -> O ring depth in steps (multiple of the chunk of 8)
 constexpr int kHD = 32;                        // Philox producers -> E ring depth in steps
 constexpr int kXR = 16;                        // XR: stream positions the X wave evaluates ahead of E (per lane), kXB per batch
 constexpr int kXB = 4;
@@ -126,7 +129,25 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ float s_rsel[4];
-    __shared__ uint32_t s_prod[kBlock / 64], s_cons[kBlock / 64];   // steps published by E wave w / consumed by O wave w
+    __shared__ __align__(16) uint32_t s_prod[kBlock / 64], s_cons[kBlock / 64];   // steps published by E wave w / consumed by O wave w
+    // Whole-row stores (round 6; k_discrete_rollout_lean's since round 4).  Every store INSTRUCTION of the O wave cost the launch
+    // about the same whatever it carried (build without the two 64-byte flag stores: 183 -> 162 us at S = 50, without any store
+    // 134): four per step and wave, 64 to 512 bytes each.  Of a chunk's 8 rows O wave w now takes rows w and w + 4 for all 256
+    // envs of the block: observations and flags straight from the other E waves' records in the ring (2 x 1 KiB / 256 B per
+    // instruction), the rewards -- the reward path carries a delay line per lane, so every O wave still computes its own envs'
+    // -- through two staging buffers in LDS (1 KiB per instruction): 10 store instructions per chunk and wave instead of 32.
+    // E waits for ALL four O waves before it reuses a ring slot.  Rollouts of full chunks; a ragged last chunk, final
+    // observations (mdpp_step) and the forms short of LDS keep the per-lane stores.
+    // MEASURED (tools/ablate.py, rows against per-lane stores on one lease): S = 50 unit rewards 0.435 -> 0.435-0.453 of HBM, S = 24
+    // with reward_dist 0.447 -> 0.417-0.421, S = 50 with the noise key 0.221 -> 0.216 -- the hand-over between the workgroup's
+    // waves costs what the fewer stores save wherever the O wave is a long stage.  Built, verified (the sweep and oracle tests ran
+    // green on it), and left OFF: -DMDPP_Q_ROWS=1 turns it on.
+#ifndef MDPP_Q_ROWS
+#define MDPP_Q_ROWS 0
+#endif
+    constexpr bool QROWS = MDPP_Q_ROWS && ROLES >= 2 && !IRR && NPH == 0 && !(PE && RN);
+    __shared__ __align__(16) float s_rw[QROWS ? 2 : 1][QROWS ? 8 : 1][QROWS ? kBlock : 4];
+    __shared__ __align__(16) uint32_t s_rprod[kBlock / 64], s_rcons[kBlock / 64];   // chunks staged / stored by O wave w
     __shared__ __align__(8) uint64_t s_start[ROLES == 3 ? kBlock : 1];   // H -> E
     __shared__ uint32_t s_head[ROLES == 3 ? kBlock : 1];                 // E -> H
     __shared__ uint32_t s_done;                                         // E waves that have finished
@@ -154,6 +175,12 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = (ROLES + NPH) * kBlock;
     const int tid = threadIdx.x;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch): with full blocks every XCD steps one contiguous eighth of the envs, so
+    // that what its L2 writes back per output row is one contiguous range (as in k_discrete_rollout_lean; MDPP_Q_XCD_CONTIG)
+#ifndef MDPP_Q_XCD_CONTIG
+#define MDPP_Q_XCD_CONTIG 1
+#endif
+    const uint32_t eblk = (MDPP_Q_XCD_CONTIG && DUO && (gridDim.x & 7u) == 0u) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int role = DUO ? tid / kBlock : 0;        // 0 = E, 1 = O, 2 = H
     const int l = DUO ? (tid & (kBlock - 1)) : tid, w = l >> 6;
     // shared MDP -> LDS (same carve as k_discrete_step) + the irrelevant sub-space's table and cdf
@@ -164,7 +191,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const uint32_t pe_stride = PE ? pe_T0 + pe_S8 * 8u + 8u : 0u;
     const uint32_t pe_off = PE ? (uint32_t)l * pe_stride : 0u;
     if constexpr (PE) {
-        const size_t ti = (size_t)blockIdx.x * kBlock + (size_t)l;          // (full blocks only: three roles)
+        const size_t ti = (size_t)eblk * kBlock + (size_t)l;          // (full blocks only: three roles)
         const int SA = a.S * a.A;
         unsigned char *slot = lds + pe_off;
         for (int k = role; k < SA; k += ROLES) {
@@ -232,7 +259,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         s_rsel[tid] = (float)r;
     }
     if (tid < kBlock / 64) {
-        s_prod[tid] = 0; s_cons[tid] = 0;
+        s_prod[tid] = 0; s_cons[tid] = 0; s_rprod[tid] = 0; s_rcons[tid] = 0;
         if (NPH) for (int p = 0; p < NPH; p++) s_hprod[p][tid] = 0;
     }
     if (TRIO && tid < kBlock) { s_start[tid] = 0; s_head[tid] = 0; }
@@ -267,7 +294,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         __syncthreads();
     }
 
-    const uint32_t i = blockIdx.x * kBlock + l;
+    const uint32_t i = eblk * kBlock + l;
     if (!DUO && i >= (uint32_t)a.N) return;            // (DUO launches have full blocks only)
     const uint32_t N = (uint32_t)a.N, S = (uint32_t)a.S, A = (uint32_t)a.A, L = SF ? 1u : (uint32_t)a.L;
     const uint4 st = a.state[i];
@@ -424,6 +451,13 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     const bool autoreset = SF ? true : a.autoreset != 0, has_max = SF ? false : a.max_steps > 0;
     const uint32_t max_steps = (uint32_t)a.max_steps, every_n = SF ? 1u : (uint32_t)a.every_n, delay = (uint32_t)a.delay;
     const bool isE = !DUO || role == 0;
+    const bool rows_ok = QROWS && final_obs == nullptr;         // whole-row stores (QROWS above): full blocks are a condition of ROLES >= 2
+    // min over the four waves' counters (two 64-bit LDS reads)
+    auto qmin4 = [&](const uint32_t *p) __attribute__((always_inline)) -> uint32_t {
+        const uint64_t x = __hip_atomic_load((const uint64_t *)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t y = __hip_atomic_load((const uint64_t *)p + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return min(min((uint32_t)x, (uint32_t)(x >> 32)), min((uint32_t)y, (uint32_t)(y >> 32)));
+    };
     // =============================================================== X: the env stream by position (header, XR)
     if constexpr (XR) if (role == 2) {
         __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
@@ -815,7 +849,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         return ((uint64_t)hi << 32) | lo;
     };
     // ---- O: record -> reward, delay line, all global stores of step `so`
-    auto emitO = [&](const uint64_t rec, const double z, const uint32_t so) __attribute__((always_inline)) {
+    auto emitO = [&](const uint64_t rec, const double z, const uint32_t so, float *stage = nullptr) __attribute__((always_inline)) {
         const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
         const uint32_t k2 = hi >> 5;
         const uint32_t done = hi & 1u;
@@ -865,10 +899,17 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                 if (need) for (uint32_t dd = 0; dd < delay; dd++) a.ring_keys[(size_t)dd * N + i] = kNoKey;
             }
         }
+        if (stage) { *stage = rout; return; }           // (whole-row stores: the rows leave later, see QROWS)
+#ifdef MDPP_ABL_Q_NOSTORE       /* timing only: what the O wave's global stores cost the launch */
+        status ^= (lo ^ __float_as_uint(rout) ^ hi) & 0x100u;
+#else
         put_obs(r_obs, so, lo & 0xFFu, (lo >> 16) & 0xFFu);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rout), r_rew, v4, so * N * 4u, MDPP_ST_NT);
+#ifndef MDPP_ABL_Q_NOBYTES
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)done, r_term, v1, so * N, MDPP_ST_NT);
         __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((hi >> 1) & 1u), r_trunc, v1, so * N, MDPP_ST_NT);
+#endif
+#endif
     };
 
     if (!DUO) {
@@ -897,16 +938,32 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     } else if (role == 0) {
         // -------------------------------------------------------------- E waves
         __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_E);
-        u32x2 pre[kPre];
+        // Actions are fetched kEAh chunks ahead of their use; the buffers rotate by NAME (the slot loop is unrolled): copying a
+        // register whose load is in flight makes the wave wait for it.
+#ifndef MDPP_Q_EAHEAD
+#define MDPP_Q_EAHEAD 1         /* (1 / 2 / 4 chunks ahead measure the same: 172-173 us at S = 50 -- the loads of one chunk ahead are hidden) */
+#endif
+        constexpr int kEAh = (ROLES == 3 && !PN && !IRR && !PH && NPH == 0) ? MDPP_Q_EAHEAD : 1;     // (the larger step bodies do not unroll over the slots: the array would go to scratch)
+        static_assert(kEAh == 1 || kEAh == 2 || kEAh == 4, "named buffers");
+        u32x2 preq[kEAh][kPre];      // slot j holds the actions of the chunks c = j (mod kEAh)
 #pragma unroll
-        for (int u = 0; u < kPre; u++) pre[u] = load_act(u);
+        for (int q = 0; q < kEAh; q++)
+#pragma unroll
+            for (int u = 0; u < kPre; u++) preq[q][u] = load_act(q * kPre + u);
         const int nchunks = (K + kPre - 1) / kPre;
-        for (int c = 0; c < nchunks; c++) {
+        // (no lambda around the chunk: an array indexed through a closure stays in scratch memory -- 80 B per lane and 340 us per
+        //  launch instead of 183, measured; the slot loop below is unrolled, so preq[j] is a register array by name)
+        for (int c0 = 0; c0 < nchunks; c0 += kEAh) {
+#pragma unroll
+        for (int j = 0; j < kEAh; j++) {
+            const int c = c0 + j;
+            if (c >= nchunks) continue;
             const int kbase = c * kPre;
             if (kbase + kPre > kDepth) {                // stay within the ring: at most kDepth - 8 steps ahead of O
                 const uint32_t must = (uint32_t)(kbase + kPre - kDepth);
                 uint32_t spins = 0;
-                while (__hip_atomic_load(&s_cons[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < must) {
+                // (whole-row stores: every O wave reads this wave's records)
+                while ((rows_ok ? qmin4(s_cons) : __hip_atomic_load(&s_cons[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < must) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > kQSpinLimit) { status |= kQStatusInternal; break; }
                 }
@@ -932,17 +989,17 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             if (kbase + kPre <= K) {
 #pragma unroll
                 for (int u = 0; u < kPre; u++) {
-                    const u32x2 act = pre[u];
-                    pre[u] = load_act(kbase + kPre + u);
+                    const u32x2 act = preq[j][u];
+                    preq[j][u] = load_act(kbase + kEAh * kPre + u);
                     double z = 0.0;
                     ring[((kbase + u) % kDepth) * kBlock + l] = stepE(act, z, kbase + u);
                     if (RN) ringz[((kbase + u) % kDepth) * kBlock + l] = z;
                 }
             } else {
                 for (int k = kbase; k < K; k++) {
-                    u32x2 act = pre[0];
+                    u32x2 act = preq[j][0];
 #pragma unroll
-                    for (int u = 1; u < kPre; u++) act = (k - kbase == u) ? pre[u] : act;
+                    for (int u = 1; u < kPre; u++) act = (k - kbase == u) ? preq[j][u] : act;
                     double z = 0.0;
                     ring[(k % kDepth) * kBlock + l] = stepE(act, z, k);
                     if (RN) ringz[(k % kDepth) * kBlock + l] = z;
@@ -950,6 +1007,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             }
             if ((l & 63) == 0)
                 __hip_atomic_store(&s_prod[w], (uint32_t)min(kbase + kPre, K), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         }
     } else {
         // -------------------------------------------------------------- O waves
@@ -963,6 +1021,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > kQSpinLimit) { status |= kQStatusInternal; break; }
             }
+            const bool rowc = rows_ok && kbase + kPre <= K;             // (wave-uniform)
             if (kbase + kPre <= K) {
                 uint64_t rec[kPre];
                 double zz[kPre];
@@ -971,8 +1030,45 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                     rec[u] = ring[((kbase + u) % kDepth) * kBlock + l];
                     zz[u] = RN ? ringz[((kbase + u) % kDepth) * kBlock + l] : 0.0;
                 }
+                if (rowc && c >= 2) {                       // the staging buffer of chunk c - 2: stored by all four O waves
+                    uint32_t sp2 = 0;
+                    while (qmin4(s_rcons) < (uint32_t)(c - 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++sp2 > kQSpinLimit) { status |= kQStatusInternal; break; }
+                    }
+                }
 #pragma unroll
-                for (int u = 0; u < kPre; u++) emitO(rec[u], zz[u], (uint32_t)(kbase + u));
+                for (int u = 0; u < kPre; u++) emitO(rec[u], zz[u], (uint32_t)(kbase + u), rowc ? &s_rw[QROWS ? (c & 1) : 0][QROWS ? u : 0][QROWS ? l : 0] : nullptr);
+                if constexpr (QROWS) if (rowc) {
+                    if ((l & 63) == 0) __hip_atomic_store(&s_rprod[w], (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t sp2 = 0;       // all four E waves are through the chunk, all four O waves have staged its rewards
+                    while (qmin4(s_prod) < upto || qmin4(s_rprod) < (uint32_t)(c + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++sp2 > kQSpinLimit) { status |= kQStatusInternal; break; }
+                    }
+                    const uint32_t blk0 = eblk * kBlock, ln = (uint32_t)l & 63u, ws = (uint32_t)__builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+                    for (int h = 0; h < kPre / 4; h++) {
+                        const uint32_t ru = ws + 4u * (uint32_t)h, kk = (uint32_t)kbase + ru;
+                        const uint32_t *recs = (const uint32_t *)(ring + (kk % (uint32_t)kDepth) * kBlock);     // [env]{lo, hi}
+                        // (128-bit stores: the whole offset in the VGPR, see kQRsrc)
+                        const u32x4 rw4 = *(const u32x4 *)&s_rw[QROWS ? (c & 1) : 0][QROWS ? ru : 0][QROWS ? 4u * ln : 0];
+                        __builtin_amdgcn_raw_buffer_store_b128(rw4, r_rew, (blk0 + 4u * ln) * 4u + kk * N * 4u, 0, MDPP_ST_NT);
+                        const u32x4 ra = *(const u32x4 *)(recs + 8u * ln), rb = *(const u32x4 *)(recs + 8u * ln + 4u);      // envs 4 ln .. 4 ln + 3
+                        if (OBS64) {                    // lane ln: envs 2 ln, 2 ln + 1 and 128 + 2 ln, 129 + 2 ln -- 1 KiB per instruction
+                            const u32x4 r0 = *(const u32x4 *)(recs + 4u * ln), r1 = *(const u32x4 *)(recs + 256u + 4u * ln);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{r0.x & 0xFFu, 0u, r0.z & 0xFFu, 0u}, r_obs, (blk0 + 2u * ln) * 8u + kk * N * 8u, 0, MDPP_ST_NT);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{r1.x & 0xFFu, 0u, r1.z & 0xFFu, 0u}, r_obs, (blk0 + 128u + 2u * ln) * 8u + kk * N * 8u, 0, MDPP_ST_NT);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ra.x & 0xFFu, ra.z & 0xFFu, rb.x & 0xFFu, rb.z & 0xFFu}, r_obs, (blk0 + 4u * ln) * 4u + kk * N * 4u, 0, MDPP_ST_NT);
+                        }
+                        // byte j of the flag words = the flag of env 4 ln + j: bits 0 / 1 of its record's high word
+                        const uint32_t hw = (ra.y & 3u) | ((ra.w & 3u) << 8) | ((rb.y & 3u) << 16) | ((rb.w & 3u) << 24);
+                        __builtin_amdgcn_raw_buffer_store_b32(hw & 0x01010101u, r_term, blk0 + 4u * ln, kk * N, MDPP_ST_NT);
+                        __builtin_amdgcn_raw_buffer_store_b32((hw >> 1) & 0x01010101u, r_trunc, blk0 + 4u * ln, kk * N, MDPP_ST_NT);
+                    }
+                    if ((l & 63) == 0) __hip_atomic_store(&s_rcons[w], (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             } else {
                 for (int k = kbase; k < K; k++)
                     emitO(ring[(k % kDepth) * kBlock + l], RN ? ringz[(k % kDepth) * kBlock + l] : 0.0, (uint32_t)k);
@@ -1056,7 +1152,7 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
     // XR (kernel header): reward noise alone -- a third wave evaluates the env stream by position (+ 52 KiB of static LDS)
-    const bool xr = duo && rn && !pn && lds_duo <= 84 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO);
+    const bool xr = duo && rn && !pn && lds_duo <= 72 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
     // SF (kernel header): the reference's sweep defaults fixed at compile time
     const bool sf = roles == 3 && !pn && a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
@@ -1107,7 +1203,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
         const size_t stride = pe_T0 + S8 * 8 + 8;             // (the kernel's carve of a lane's slot)
         const size_t depth = rn ? 16 : kQDepth;
         const size_t l = ((stride * kBlock + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
-        if (l + (rn ? 40u : 8u) * 1024u > 160u * 1024u) return false;     // (+ the instantiation's static LDS: X rings, ziggurat tables, counters)
+        if (l + (rn ? 40u : 20u) * 1024u > 160u * 1024u) return false;     // (+ the instantiation's static LDS: X rings, ziggurat tables, counters)
         const bool sf = a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
                         !(a.opts & MDPP_OPT_NO_QUIET_SF);
         if (name_out) {
@@ -1146,7 +1242,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     // XR (kernel header): reward noise alone on numpy streams -- a third wave evaluates the env stream by position (+ 52 KiB of
     // static LDS); gymnasium's next-step autoreset (the reset call must not draw) stays on two roles
-    const bool xr = duo && rn && !pn && !ph && !a.irr && a.autoreset != MDPP_AUTORESET_NEXT_STEP && lds_duo <= 84 * 1024 &&
+    const bool xr = duo && rn && !pn && !ph && !a.irr && a.autoreset != MDPP_AUTORESET_NEXT_STEP && lds_duo <= 72 * 1024 &&
                     !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
     // SF (kernel header): the reference's sweep defaults fixed at compile time
