@@ -330,7 +330,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 #pragma unroll
     for (int q = 0; q < kQQ; q++) queue[q] = 0;
     uint32_t qn = 0;
-    auto draw_state = [&](const uint64_t tick = 0) __attribute__((always_inline)) -> uint32_t {
+    auto draw_state_g = [&](auto &g, const uint64_t tick) __attribute__((always_inline)) -> uint32_t {     // (g: the lane's env generator, in either form)
         // self._np_random.choice(S, p=rho_0): searchsorted(cdf, u, 'right') (:2255); then the
         // irrelevant start state the same way (:2259-2264)
         if constexpr (PH) {
@@ -377,6 +377,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
         return s0;
     };
+    auto draw_state = [&](const uint64_t tick = 0) __attribute__((always_inline)) -> uint32_t { return draw_state_g(g, tick); };
     auto refill = [&]() __attribute__((always_inline)) {         // (always_inline: no generator / queue behind a pointer)
         for (int round = 0; round < kQQ; round++) {
             if (__builtin_amdgcn_ballot_w64(qn < (uint32_t)kQQ) == 0) break;
@@ -589,6 +590,12 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
         uint64_t vals = 0;
         uint32_t tail = 0, slot = 0;
+        // (the limb form of the PCG64 step: 31 instead of 46 vector instructions per word; v150-v157 fit a 768-thread kernel)
+        Pcg64Limbs gl;
+        gl.from(g);
+#ifndef MDPP_Q_HMIN
+#define MDPP_Q_HMIN 16          /* H draws for the wave once this many lanes have room (or one runs low) */
+#endif
         for (;;) {
             if (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == kBlock / 64) break;
             const uint32_t head = __hip_atomic_load(&s_head[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -596,9 +603,9 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             const bool want = autoreset && cnt < 3u;
             const uint64_t bw = __builtin_amdgcn_ballot_w64(want);
             const bool urgent = __builtin_amdgcn_ballot_w64(want && cnt <= 1u) != 0;
-            if (__builtin_popcountll(bw) >= 16 || urgent) {
+            if (__builtin_popcountll(bw) >= MDPP_Q_HMIN || urgent) {
                 if (want) {
-                    const uint64_t c = draw_state();
+                    const uint64_t c = draw_state_g(gl, 0);
                     const uint32_t sh = slot * 16u;
                     vals = (vals & ~(0xFFFFull << sh)) | (c << sh);
                     slot = slot == 2u ? 0u : slot + 1u;
@@ -611,6 +618,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
             }
         }
         // un-draw what the env lane did not use (its final count is net of what sat in its registers)
+        gl.to(g);
         const uint32_t head = __hip_atomic_load(&s_head[l], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         for (uint32_t q = ((tail - head) & 0xFFFFu) * (IRR ? 2u : 1u); q > 0; q--) {
             const uint64_t lo = g.s_lo - g.inc_lo;
