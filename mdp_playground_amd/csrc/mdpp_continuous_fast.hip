@@ -214,7 +214,13 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
     const ZigLds zig{s_ki, s_wi, s_fi};
     // (PAR: one env wave per workgroup -- "lane" and "wave" of the consumer code below are those of that wave, whichever it is)
     const int ln = PAR ? (tid & 63) : (tid & (kBlock - 1)), wv = PAR ? 0 : (ln >> 6);
-    const uint32_t i = PAR ? blockIdx.x * 64u + (uint32_t)(tid & 63) : blockIdx.x * WG + ln;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch): in a rollout every XCD steps one contiguous eighth of the envs, so that what
+    // its L2 writes back per output row is one contiguous range (MDPP_C_XCD; as in k_discrete_rollout_lean)
+#ifndef MDPP_C_XCD
+#define MDPP_C_XCD 0             /* (measured: cfg3 0.659-0.663 -> 0.649-0.661, cfg5 and c_d2_n0 unchanged: off) */
+#endif
+    const uint32_t bxc = (MDPP_C_XCD && !K1 && (gridDim.x & 7u) == 0u) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t i = PAR ? blockIdx.x * 64u + (uint32_t)(tid & 63) : bxc * WG + ln;
     if (i >= (uint32_t)a.N) return;             // HELPER launches require N % kBlock == 0
     const uint32_t N = (uint32_t)a.N;
     const uint64_t genv = (uint64_t)(a.env_id_offset + (int64_t)i);     // global env id (Philox key)

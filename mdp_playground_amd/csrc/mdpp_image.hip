@@ -36,6 +36,15 @@ namespace mdpp {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch).  With MDPP_IMG_XCD every XCD renders one contiguous eighth of a launch's
+// pictures -- its L2 then writes back ONE sequential range instead of every eighth 28 KiB piece of the output: cfg4 5 970-6 210 ->
+// 5 600 us per launch (0.60-0.62 -> 0.66 of HBM; round 6, tools/ablate.py x0 / x1 on one lease).
+#ifndef MDPP_IMG_XCD
+#define MDPP_IMG_XCD 1
+#endif
+__device__ __forceinline__ uint32_t img_xcd_block() {
+    return (MDPP_IMG_XCD && (gridDim.x & 7u) == 0u) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+}
 constexpr int kImgPad = 8;               // zero border of the fast renderer's templates, pixels
 constexpr int kImgColDw = 1536;          // dwords of LDS image columns per wave (6 KiB)
 
@@ -687,7 +696,8 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
     }
 #else
     const int nw = (int)gridDim.x * (kBlock / 64);
-    long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wave));
+    const uint32_t bx = img_xcd_block();
+    long j = __builtin_amdgcn_readfirstlane((int)(bx * (kBlock / 64) + wave));
     if (j >= M) return;
     RecRegs cur = load_rec(rec + j);
     u32x4 near_cur = load_near(a, cur, lane);
@@ -788,7 +798,10 @@ __global__ __launch_bounds__(kWideBlock) void k_image_obs_wide(ImageArgs a, long
                                                                uint8_t *__restrict__ img) {
     extern __shared__ __align__(16) uint8_t lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const long j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kWideBlock / 64) + wave));
+#ifndef MDPP_IMG_XCD_WIDE
+#define MDPP_IMG_XCD_WIDE MDPP_IMG_XCD
+#endif
+    const long j = __builtin_amdgcn_readfirstlane((int)((MDPP_IMG_XCD_WIDE ? img_xcd_block() : blockIdx.x) * (kWideBlock / 64) + wave));
     if (j >= M) return;
     const RecRegs r = load_rec(rec + j);
     if (r.lo[7] & (1u << 11)) return;
@@ -857,7 +870,10 @@ __global__ __launch_bounds__(kBlock) void k_image_step1(ImageArgs a, const int32
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint32_t *const lds_col = (uint32_t *)(lds + (size_t)a.tplp * 256) + (size_t)wave * a.coldw;     // (WIDE: no image columns in LDS)
     if (!WIDE && MDPP_IMG_LEAN_LOOP && lane < 4) lds_col[a.coldw - 4 + lane] = 0u;      // the wave's zero chunk (render_fast_store)
-    const long i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * ((WIDE ? kWideBlock : kBlock) / 64) + wave));
+#ifndef MDPP_IMG_XCD_STEP1
+#define MDPP_IMG_XCD_STEP1 MDPP_IMG_XCD
+#endif
+    const long i = __builtin_amdgcn_readfirstlane((int)((MDPP_IMG_XCD_STEP1 ? img_xcd_block() : blockIdx.x) * ((WIDE ? kWideBlock : kBlock) / 64) + wave));
     if (i >= a.N) return;
     // Everything the wave needs from memory before it can draw, in ONE batch of scalar loads: the generator, the state, and the
     // step's two flag bytes as the dwords they sit in (there is no scalar byte load, and a vector load -- or a load behind a

@@ -59,7 +59,12 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
                                                        uint8_t *__restrict__ img) {
     extern __shared__ __align__(16) uint32_t lds_codes[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long j = __builtin_amdgcn_readfirstlane((int)((long)blockIdx.x * (kBlock / 64) + wave));
+    // (workgroup b runs on XCD b % 8: every XCD renders one contiguous eighth of the launch's pictures, as in mdpp_image.hip)
+#ifndef MDPP_IMGC_XCD
+#define MDPP_IMGC_XCD 1
+#endif
+    const uint32_t bx = (MDPP_IMGC_XCD && (gridDim.x & 7u) == 0u) ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const long j = __builtin_amdgcn_readfirstlane((int)((long)bx * (kBlock / 64) + wave));
     if (j >= M) return;
     if (mask && !mask[j % a.N]) return;
     if (term && !(term[j] | trunc[j])) return;
