@@ -364,8 +364,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             // (an unbounded box is fine as long as the actions are bounded: states then stay finite, which
             // the fast kernel's clip relies on -- np.clip's NaN propagation lives in the general kernel)
             // (next-step autoreset: without noise or with Philox streams -- numpy noise streams are drawn ahead per step)
+            // (has_p_noise: the continuous handle's transition-noise flag.  Until round 6 this line tested has_transition_noise, the
+            //  discrete / grid field, and a next-step handle with transition noise ALONE on numpy streams went to the fused kernel,
+            //  whose walker draws during the reset call too: found by tests/test_gpu_sweep.py's random configurations)
             const bool next_ok = cfg->autoreset != MDPP_AUTORESET_NEXT_STEP || cfg->rng_mode != MDPP_RNG_NUMPY_PCG64 ||
-                                 (!cfg->has_transition_noise && !cfg->has_reward_noise);
+                                 (!cfg->has_p_noise && !cfg->has_reward_noise);
             // (the fused kernels test the hypercubes in an unrolled loop of MDPP_MAX_BOXES: more than that -> general kernel)
             a.fast_ok = (a.rel_prefix && !cfg->image && !line && !cfg->target_f64 && next_ok && cfg->n_boxes <= MDPP_MAX_BOXES &&
                          (a.bounded || isfinite(cfg->action_space_max))) ? 1u : 0u;

@@ -166,3 +166,100 @@ def test_sigma_zero_noise_keys_advance_only_equals_values_formed(shape):
     for s in (capi.STREAM_ENV, capi.STREAM_SPACE):
         assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (shape, s)
     a.close(); b.close()
+
+
+def _fuzz_configs(n, seed):
+    """Seeded random discrete / continuous configurations around the dispatch conditions of this round's kernel forms (SF: L = 1,
+    same-step autoreset, no step limit, every-step pay; XR: reward noise alone; Z0: sigma 0; PE: seeds=[...])."""
+    r = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        if r.random() < 0.7:
+            S = int(r.choice([4, 8, 8, 12, 16, 24, 50, 130]))
+            A = int(r.choice([S, max(2, S // 2), min(S, 8)]))
+            L = int(r.choice([1, 1, 1, 2, 3]))
+            L = 1 if S > 24 else min(L, 2) if S > 12 else L            # (the host generator enumerates S^L sequences, like the reference)
+            cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=S, action_space_size=A,
+                       sequence_length=L, delay=int(r.choice([0, 0, 1, 2, 5])), reward_density=float(r.choice([0.1, 0.25, 0.5])),
+                       terminal_state_density=float(r.choice([0.1, 0.25])), make_denser=bool(r.random() < 0.2),
+                       completely_connected=True, generate_random_mdp=True, repeats_in_sequences=False, seed=int(r.integers(1000)))
+            if A != S:
+                cfg["completely_connected"] = False
+            if r.random() < 0.5:
+                cfg["reward_noise"] = float(r.choice([0.0, 0.0, 0.3]))
+            if r.random() < 0.25:
+                cfg["transition_noise"] = float(r.choice([0.0, 0.1]))
+            if r.random() < 0.2:
+                cfg["reward_every_n_steps"] = int(r.choice([1, 2, L]))
+            if r.random() < 0.2:
+                cfg["reward_dist"] = [0.01, 1]
+            if r.random() < 0.3:
+                cfg.update(reward_scale=float(r.choice([1.0, 2.5, -1.5])), reward_shift=float(r.choice([0.0, -0.5])),
+                           term_state_reward=float(r.choice([0.0, 1.0])))
+        else:
+            D = int(r.choice([2, 2, 4, 8, 12]))
+            cfg = dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=D, action_space_dim=D,
+                       transition_dynamics_order=int(r.choice([1, 1, 2])), inertia=float(r.choice([1.0, 2.0, 3.0])),
+                       time_unit=float(r.choice([1.0, 0.1])), state_space_max=10, action_space_max=1, target_point=[0.0] * D,
+                       target_radius=float(r.choice([0.5, 2.0])), make_denser=bool(r.random() < 0.7), reward_function="move_to_a_point",
+                       delay=int(r.choice([0, 0, 2])), seed=int(r.integers(1000)))
+            if r.random() < 0.6:
+                cfg["transition_noise"] = float(r.choice([0.0, 0.0, 0.05]))
+            if r.random() < 0.6:
+                cfg["reward_noise"] = float(r.choice([0.0, 0.0, 0.1]))
+        mode = r.choice(["same_step", "same_step", "same_step", "disabled", "next_step", "timelimit"])
+        per_env = cfg["state_space_type"] == "discrete" and cfg["state_space_size"] <= 16 and r.random() < 0.3
+        out.append((cfg, str(mode), per_env))
+    return out
+
+
+FUZZ = _fuzz_configs(48, 20261004) + _fuzz_configs(96, 777)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("k", range(len(FUZZ)))
+def test_random_configurations_specialised_equals_general(k):
+    """Round 6: 144 seeded random configurations around the new dispatch conditions (SF / XR / Z0 / PE and their refusals: S = 130,
+    L > 1, a step limit, next-step autoreset, transition noise beside reward noise, one MDP per env), each as 1 024 envs on the
+    default dispatch beside a handle with every specialisation switched off (the general kernels the goldens pin): two fused
+    rollouts of different lengths, single steps in between, every output of every env and both streams' end states.
+    (Found with it: a continuous next-step handle with transition noise alone on numpy streams was dispatched to the fused kernel,
+    whose walker draws during the reset call -- mdpp_capi.hip `next_ok` tested the discrete field of the config.)"""
+    from mdp_playground_amd import _capi as capi
+    import warnings
+    cfg, mode, per_env = FUZZ[k]
+    N = 1024
+    kw = dict(autoreset="same_step")
+    if mode == "disabled":
+        kw = dict(autoreset="disabled")
+    elif mode == "next_step":
+        kw = dict(autoreset="next_step")
+    elif mode == "timelimit":
+        kw = dict(autoreset="same_step", max_episode_steps=11)
+    nkw = dict(seeds=list(range(7, 7 + N))) if per_env else dict(num_envs=N)
+    cfg = dict(cfg)
+    if per_env:
+        cfg.pop("seed", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            a = _venv(**nkw, **kw, **cfg)
+        except (NotImplementedError, ValueError, AssertionError, IndexError, KeyError) as e:      # (a combination the host generator refuses, like the reference: e.g. reward_dist + make_denser, IndexError in both)
+            pytest.skip(f"refused at construction: {type(e).__name__}")
+        b = _venv(**nkw, **kw, **cfg)
+    b.set_kernel_options(*capi.OPTIONS)
+    g = np.random.default_rng(100 + k)
+    names = (a.rollout_kernel_name(72), b.rollout_kernel_name(72))
+    for piece, F in enumerate((72, 40)):
+        acts = torch.as_tensor(_rand_actions(a, F, g), device=a.device)
+        ra, rb = a.rollout(acts), b.rollout(acts)
+        torch.cuda.synchronize()
+        assert all(_same(x, y) for x, y in zip(ra, rb)), (k, cfg, mode, per_env, "rollout", piece, names)
+        for t in range(3):
+            sa, sb = a.step(acts[t]), b.step(acts[t])
+            assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (k, cfg, mode, per_env, "step", piece, t, names)
+    assert np.array_equal(a.status(), b.status()), (k, names)
+    assert not (a.status() & 0x80000000).any()
+    for s in (capi.STREAM_ENV, capi.STREAM_SPACE):
+        assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (k, cfg, mode, per_env, s, names)
+    a.close(); b.close()
