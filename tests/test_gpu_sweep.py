@@ -263,3 +263,75 @@ def test_random_configurations_specialised_equals_general(k):
     for s in (capi.STREAM_ENV, capi.STREAM_SPACE):
         assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (k, cfg, mode, per_env, s, names)
     a.close(); b.close()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("k", [k for k in range(len(FUZZ)) if FUZZ[k][1] != "next_step"])
+def test_random_configurations_default_dispatch_vs_oracle(k):
+    """The same random configurations on the DEFAULT dispatch (whatever specialised kernel the library picks: lean Z0, quiet SF /
+    XR / PE, the continuous fast kernels ...) against the ORACLE: 512 envs, a fused rollout of 72 steps, three single steps, a rollout
+    of 40; every 37th env stepped through its own oracle -- observations and flags bit for bit, rewards as float32 bit patterns
+    (continuous float64-path rewards within 1e-6 relative), and both streams' end states after every call."""
+    from mdp_playground_amd import _capi as capi
+    from test_gpu_parity import _oracle_for
+    import warnings
+    cfg, mode, per_env = FUZZ[k]
+    N = 512
+    kw = dict(autoreset="same_step")
+    if mode == "disabled":
+        kw = dict(autoreset="disabled")
+    elif mode == "timelimit":
+        kw = dict(autoreset="same_step", max_episode_steps=11)
+    nkw = dict(seeds=list(range(7, 7 + N))) if per_env else dict(num_envs=N)
+    cfg = dict(cfg)
+    if per_env:
+        cfg.pop("seed", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            env = _venv(**nkw, **kw, **cfg)
+        except (NotImplementedError, ValueError, AssertionError, IndexError, KeyError) as e:
+            pytest.skip(f"refused at construction: {type(e).__name__}")
+    auto = kw["autoreset"] == "same_step"
+    horizon = kw.get("max_episode_steps", 0)
+    disc = env.kind == "discrete"
+    init = env._obs.cpu().numpy().copy()
+    sample = list(range(3, N, 37))
+    oracles = []
+    for i in sample:
+        o = _oracle_for(env, i)
+        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+        assert np.array_equal(np.asarray(o.reset()), init[i]), (k, i)
+        oracles.append([o, 0])
+    g = np.random.default_rng(500 + k)
+    for K in (72, 1, 1, 1, 40):
+        acts = _rand_actions(env, K, g)
+        at = torch.as_tensor(acts, device=env.device)
+        if K == 1:
+            o1, r1, t1, tr1, _ = env.step(at[0])
+            obs, rew, term, trunc = (x[None].cpu().numpy() for x in (o1, r1, t1, tr1))
+        else:
+            obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(at))
+        ends = (env.get_rng_streams(capi.STREAM_ENV), env.get_rng_streams(capi.STREAM_SPACE))
+        for (o, i), rec in zip(zip([x[0] for x in oracles], sample), oracles):
+            for t in range(K):
+                if disc:
+                    st, rr, d = o.step(acts[t, i])
+                else:
+                    st, rr, _, d = o.step(acts[t, i])
+                rec[1] += 1
+                tr = bool(horizon) and rec[1] >= horizon
+                assert d == bool(term[t, i]) and tr == bool(trunc[t, i]), (k, cfg, mode, K, i, t, env.rollout_kernel_name(K))
+                if disc:
+                    assert np.float32(rr) == rew[t, i], (k, cfg, mode, K, i, t, rr, rew[t, i], env.rollout_kernel_name(K))
+                else:
+                    assert abs(float(np.float32(rr)) - float(rew[t, i])) <= 1e-6 * max(1.0, abs(rr)), (k, cfg, mode, K, i, t, rr, rew[t, i])
+                if auto and (d or tr):
+                    st = o.reset(explicit=False)
+                    rec[1] = 0
+                assert np.array_equal(np.asarray(obs[t, i]).view(np.uint32 if not disc else obs.dtype),
+                                      np.asarray(st, dtype=obs.dtype).view(np.uint32 if not disc else obs.dtype)), (k, cfg, mode, K, i, t, env.rollout_kernel_name(K))
+            ge, gs = o.get_rng()
+            assert np.array_equal(ge[:4], ends[0][i][:4]) and np.array_equal(gs[:4], ends[1][i][:4]), (k, cfg, mode, K, i, env.rollout_kernel_name(K))
+    assert not (env.status() & 0x80000000).any()
+    env.close()
