@@ -142,6 +142,12 @@ WORKLOADS = {
                                 action_loss_weight=0.01, delay=0, reward_scale=1.0, transition_noise=0, reward_noise=0, seed=0)),
     # (65 536 envs since round 6: 8 192 lanes are 128 waves on 1 024 SIMDs -- that leg timed an empty chip; the 8 192-env figure
     #  stays beside it as cfg2_per_env_8k)
+    # ... the same env without the noise keys (not a default leg: the base D = 2 kernel, for profiles)
+    "c_d2": dict(kind="continuous", envs=65536, alg_bytes_fused=22, alg_bytes_step=22 + 16 + 8,
+                 config=dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=2, action_space_dim=2,
+                             transition_dynamics_order=1, inertia=1, time_unit=1.0, state_space_max=10, action_space_max=1,
+                             target_point=[0, 0], target_radius=0.5, make_denser=True, reward_function="move_to_a_point",
+                             action_loss_weight=0.01, delay=0, reward_scale=1.0, seed=0)),
     "cfg2_per_env": dict(kind="discrete", envs=65536, alg_bytes_fused=18, alg_bytes_step=42, per_env_mdps=True,
                          config=dict(state_space_type="discrete", action_space_type="discrete",
                                      state_space_size=8, action_space_size=8, delay=4, sequence_length=3)),

@@ -1018,7 +1018,9 @@ __global__ __launch_bounds__(HELPER ? (1 + NPROD) * kBlock : kBlock, PAR ? 4 : 1
         }
     };
 
-    constexpr int kCBufs = NOISE ? 1 : MDPP_CBUFS;
+    // (round 6: at D <= 4 a step takes 0.45 us -- four rows ahead were less than a loaded HBM round trip: two buffers of four rows,
+    //  c_d2 0.338 -> 0.391 of HBM; three: 0.393; at D = 12 two buffers measure the same as one and eight rows in ONE buffer go to scratch)
+    constexpr int kCBufs = NOISE ? 1 : (D <= 4 && MDPP_CBUFS < 2) ? 2 : MDPP_CBUFS;
     static_assert(kCBufs >= 1 && kCBufs <= 3, "one to three named buffers");
     float pre[kCAhead][D], pre1[kCBufs > 1 ? kCAhead : 1][D], pre2[kCBufs > 2 ? kCAhead : 1][D];
     if constexpr (!K1) {
