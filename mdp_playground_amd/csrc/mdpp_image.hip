@@ -732,6 +732,30 @@ __global__ __launch_bounds__(kBlock) void k_image_obs_fast(ImageArgs a, long M, 
 //  * no image columns in LDS: a lane owns the 16-byte chunks lane, lane + 64, ... of the picture, evaluates the near dwords
 //    among its chunk's four (the same integer near test as render_fast_eval's box walk) and stores the chunk from registers
 //    -- the same front-to-back 1 KiB-per-instruction store pattern; chunks far from the polygon cost one test.
+constexpr int kWideTplRegs = 16;          // 16-byte template chunks per lane: up to 128 rows of 128 B
+struct WideTpl { u32x4 v[kWideTplRegs]; };
+// The template rows a picture's map can reach, global memory -> registers (loads in flight), and registers -> the wave's LDS columns.
+__device__ __forceinline__ void wide_tpl_load(const ImageArgs &a, const RecRegs &r, int lane, WideTpl &t) {
+    const int R = (int)(r.lo[7] & 0x3FFu), half_p = a.tplp >> 1;
+    const u32x4 *gt = (const u32x4 *)(a.tplp_data + (size_t)(r.lo[7] >> 12) * ((size_t)a.tplp * 128));
+    const int r0 = max(0, half_p - R - 9), r1 = min(a.tplp, half_p + R + 10);
+#pragma unroll
+    for (int q = 0; q < kWideTplRegs; q++) {
+        const int c = r0 * 8 + lane + 64 * q;
+        t.v[q] = gt[c < r1 * 8 ? c : r0 * 8];
+    }
+}
+__device__ __forceinline__ void wide_tpl_stage(const ImageArgs &a, const RecRegs &r, uint8_t *lds, int wave, int lane, const WideTpl &t) {
+    const int R = (int)(r.lo[7] & 0x3FFu), half_p = a.tplp >> 1;
+    const int r0 = max(0, half_p - R - 9), r1 = min(a.tplp, half_p + R + 10);
+#pragma unroll
+    for (int q = 0; q < kWideTplRegs; q++) {
+        const int c = r0 * 8 + lane + 64 * q;
+        if (c < r1 * 8) *(u32x4 *)(lds + (c >> 3) * 256 + wave * 128 + (c & 7) * 16) = t.v[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+template <bool STAGE = true>
 __device__ __forceinline__ void render_wide(const ImageArgs &a, const RecRegs &r, uint8_t *lds, int wave, int lane,
                                             uint8_t *__restrict__ out) {
     const int a0 = (int)r.lo[0], a1 = (int)r.lo[1], a2 = (int)r.lo[2], a3 = (int)r.lo[3], a4 = (int)r.lo[4],
@@ -739,7 +763,7 @@ __device__ __forceinline__ void render_wide(const ImageArgs &a, const RecRegs &r
     const int cx = (int)(r.lo[6] & 0xFFFFu), cy = (int)(r.lo[6] >> 16), R = (int)(r.lo[7] & 0x3FFu);
     const float fcx = __uint_as_float(r.hi[0]), fcy = __uint_as_float(r.hi[1]);
     const int half_p = a.tplp >> 1;
-    {   // template rows [half_p - R - 9, half_p + R + 9]: everything a near dword can map to (R + 8 around the centre)
+    if constexpr (STAGE) {   // template rows [half_p - R - 9, half_p + R + 9]: everything a near dword can map to (R + 8 around the centre)
         const u32x4 *gt = (const u32x4 *)(a.tplp_data + (size_t)(r.lo[7] >> 12) * ((size_t)a.tplp * 128));
         const int r0 = max(0, half_p - R - 9), r1 = min(a.tplp, half_p + R + 10);
         for (int c = r0 * 8 + lane; c < r1 * 8; c += 64) *(u32x4 *)(lds + (c >> 3) * 256 + wave * 128 + (c & 7) * 16) = gt[c];
@@ -801,11 +825,37 @@ __global__ __launch_bounds__(kWideBlock) void k_image_obs_wide(ImageArgs a, long
 #ifndef MDPP_IMG_XCD_WIDE
 #define MDPP_IMG_XCD_WIDE MDPP_IMG_XCD
 #endif
-    const long j = __builtin_amdgcn_readfirstlane((int)((MDPP_IMG_XCD_WIDE ? img_xcd_block() : blockIdx.x) * (kWideBlock / 64) + wave));
+    // MDPP_IMG_WIDE_PAIR (round 6): a wave renders TWO consecutive pictures.  A picture starts with two dependent round trips -- its
+    // record, then the template rows the record names -- which three waves per SIMD (LDS: 12.6 KiB of template per wave) do not hide;
+    // both records are loaded up front, and the second picture's template rows are in flight (in registers) while the first
+    // picture is evaluated and stored: img100_all 1 835 -> 1 567-1 590 us per 64-step launch (0.358 -> 0.415-0.419 of HBM; a rolling
+    // form with three / four / eight pictures per wave: 0.399 / 0.400-0.408 / 0.390 -- tools/ablate.py p0 / p1 / p2 / p4, one lease).
+#ifndef MDPP_IMG_WIDE_PAIR
+#define MDPP_IMG_WIDE_PAIR 1
+#endif
+    const long wid = __builtin_amdgcn_readfirstlane((int)((MDPP_IMG_XCD_WIDE ? img_xcd_block() : blockIdx.x) * (kWideBlock / 64) + wave));
+    const size_t isz = (size_t)a.W * a.H;
+#if MDPP_IMG_WIDE_PAIR == 1
+    const long j0 = 2 * wid, j1 = j0 + 1;
+    if (j0 >= M) return;
+    const bool has1 = j1 < M;
+    const RecRegs r0 = load_rec(rec + j0), r1 = load_rec(rec + (has1 ? j1 : j0));
+    const bool go0 = !(r0.lo[7] & (1u << 11)), go1 = has1 && !(r1.lo[7] & (1u << 11));
+    WideTpl t;
+    if (go0) { wide_tpl_load(a, r0, lane, t); wide_tpl_stage(a, r0, lds, wave, lane, t); }
+    if (go1) wide_tpl_load(a, r1, lane, t);                     // (in flight under the first picture)
+    if (go0) render_wide<false>(a, r0, lds, wave, lane, img + (size_t)j0 * isz);
+    if (go1) {
+        wide_tpl_stage(a, r1, lds, wave, lane, t);
+        render_wide<false>(a, r1, lds, wave, lane, img + (size_t)j1 * isz);
+    }
+#else
+    const long j = wid;
     if (j >= M) return;
     const RecRegs r = load_rec(rec + j);
     if (r.lo[7] & (1u << 11)) return;
-    render_wide(a, r, lds, wave, lane, img + (size_t)j * ((size_t)a.W * a.H));
+    render_wide(a, r, lds, wave, lane, img + (size_t)j * isz);
+#endif
 }
 
 // The launch arguments every image kernel of a batch of K steps shares (buf: the scratch set of a pipelined rollout).
@@ -1015,7 +1065,8 @@ int launch_image_obs(mdpp_env *h, int K, const int32_t *state_out, const int32_t
         const unsigned nblk = (unsigned)((M + per_block - 1) / per_block);
         if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST) && h->img_colb == 128) {
             const size_t lds_bytes = image_fast_lds(h, a);                  // (host-checked: <= 64 KiB)
-            const dim3 grid((unsigned)((M + kWideBlock / 64 - 1) / (kWideBlock / 64)));
+            const long per_wg = (long)(kWideBlock / 64) * (MDPP_IMG_WIDE_PAIR ? 2 : 1);            // pictures per workgroup
+            const dim3 grid((unsigned)((M + per_wg - 1) / per_wg));
             hipLaunchKernelGGL(k_image_obs_wide, grid, dim3(kWideBlock), lds_bytes, s, a, M, a.rec0, img_out);
             if (img_final) hipLaunchKernelGGL(k_image_obs_wide, grid, dim3(kWideBlock), lds_bytes, s, a, M, a.rec1, img_final);
         } else if (h->img_fast_ok && !(h->opts & MDPP_OPT_NO_IMGFAST)) {
