@@ -21,6 +21,27 @@ from mdp_playground_amd import RLToyVectorEnv  # noqa: E402
 
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "docs", "dispatch.md")
 dev = torch.device("cuda", 0)
+
+RULES = """## The rules behind the tables (first match wins; sources: the `launch_*` functions named)
+
+| kernel | serves | file: function |
+|---|---|---|
+| `k_discrete_step1` / `k_discrete_step1w` | `mdpp_step` (K = 1): one shared MDP, L <= 3, same-step autoreset or none, no irrelevant sub-space, no episode statistics; S <= 16 without noise (`step1`) or any S <= 255 whose table blob fits the rounds a wave stages -- 8 KiB, 12 KiB with a noise key (`step1w`: unit rewards with delay <= 32, or non-unit sequence rewards without noise) | `mdpp_discrete_step1.hip`: `launch_discrete_step1`; the blob: `mdpp_capi.hip`: `mdpp_upload_discrete_tables` |
+| `k_discrete_rollout_lean<...,PHILOX,IRR,NEXT,PN,RN,Z0>` | K >= 32, N >= 256: one shared MDP, unit rewards, L <= 3, S <= 8, A <= 16, delay <= 32, every_n <= 64, max_steps < 65 536; noise on numpy streams only where the S noise categoricals share their thresholds (host check); `Z0`: the reward-noise key with sigma 0 | `mdpp_discrete_lean.hip`: `launch_discrete_lean` (+ `_next`, `_noise`, `_npnoise`) |
+| `k_discrete_rollout_pipe` / `_fast` | the same quiet shape up to S = 16 (three roles for long rollouts of full blocks / one role: short rollouts, the state kernel of image handles) | `mdpp_discrete_pipe.hip`, `mdpp_discrete_fast.hip` |
+| `k_discrete_rollout_quiet<...,ROLES,PN,RN,PHILOX,NPH,UNIT,SF,PE>` | K >= 16: one shared MDP whose tables fit 60 KiB of LDS, any S <= 255, L <= 7, irrelevant sub-space, both noises, non-unit sequence rewards (`UNIT=0`: numpy streams, no irrelevant sub-space); ROLES = 2 / 3 for full blocks and K >= 32 (3: autoreset without reward noise = a start-state queue wave; or reward noise alone on numpy streams = `XR`, the env stream by position); `SF`: ROLES = 3, L = 1, same-step autoreset, no step limit, every-step pay, S <= 128; `PE`: one MDP per env, S <= 16, unit rewards, numpy streams, no transition noise | `mdpp_discrete_quiet.hip`: `launch_discrete_quiet`, `launch_discrete_quiet_nu` |
+| `k_discrete_step<PHILOX,NOISE,UNIT,LDSTAB,IRR>` | everything else (per-env MDPs in short rollouts, custom R(s, a), tables beyond LDS, episode statistics, ...) | `mdpp_discrete.hip`: `launch_discrete_step` |
+| `k_continuous_step1<...,PAR>` | `mdpp_step` on the fast continuous shapes (`PAR = 1`: transition noise on numpy streams at D >= 8) | `mdpp_continuous_fast.hip`: `launch_continuous_step1` |
+| `k_continuous_rollout_fast<D,ORDER,NREL,NOISE,HELPER,GEN,PHILOX,NPROD,Z0>` | move_to_a_point, relevant dimensions = the first n_rel, no pictures, an explicit target_point, <= 8 terminal cubes, (D, order, n_rel) one of the built shapes (D in {2, 4, 8, 12}, orders 1-2, n_rel = D or a prefix; D = 2 also order 3); next-step autoreset only without noise or on Philox streams; `HELPER`: noise, K >= 16, full blocks; `NPROD = 2` on numpy streams (generator / walker / consumer) at D >= 8 or D = 2; `Z0`: D = 2 with every present noise key at sigma 0 | `mdpp_continuous_fast.hip`: `launch_continuous_fast`; the shape flag: `mdpp_capi.hip` (`fast_ok`, `next_ok`) |
+| `k_continuous_line_rollout` | move_along_a_line with every dimension relevant, D in {2, 4}, order <= 2, no noise, delay 0, K >= 4 | `mdpp_continuous_line.hip`: `launch_continuous_line` |
+| `k_continuous_step<DMAX,OMAX,PHILOX,NL>` | everything else (`NL = 8`: the line fit with 5-8 relevant of <= 12 dimensions; beyond that the fit's matrices live in an HBM workspace) | `mdpp_continuous.hip`: `launch_continuous_step` |
+| `k_image_step1<NST,PHILOX,WIDE>` | `mdpp_step` on polygon-picture handles the fast / wide renderer serves | `mdpp_image.hip` |
+| `k_image_obs_fast<NST>` / `k_image_obs_wide` / `k_image_obs` | polygon pictures: padded templates up to 64 / 128 pixels wide with the polygon never leaving the picture (host check) / the general renderer | `mdpp_image.hip`: `launch_image_obs`; `mdpp_capi.hip`: `mdpp_upload_image_templates` (`img_fast_ok`, `img_colb`) |
+| `k_grid_rollout_fast` / `k_grid_step`, `k_imagec_obs` | grid envs; pictures of continuous and grid envs | `mdpp_grid.hip`, `mdpp_imagec.hip` |
+
+`mdpp_set_options` (`MDPP_OPT_NO_*`, `include/mdpp.h`) takes kernels out of this order per handle; `mdpp_kernel_name` answers for a handle and a launch length.
+
+"""
 rows = []
 
 
@@ -80,6 +101,7 @@ with open(out, "w") as f:
             "instances (8 192 with pictures), same-step autoreset; `rollout` = a fused launch of 512 steps (64 with pictures), `step` = "
             "`mdpp_step`.  Template arguments are the dispatch's run-time decisions; every specialised kernel is checked against the "
             "general one on every env by `tests/test_gpu_sweep.py`, the general ones against the reference-generated goldens.\n\n"
+            + RULES +
             "## BASELINE / bench workloads\n\n| workload | rng | shape | rollout kernel | step kernel |\n|---|---|---|---|---|\n")
     for w, rng, shp, a, b, _ in rows:
         f.write(f"| {w} | {rng} | {shp} | `{a}` | `{b}` |\n")
