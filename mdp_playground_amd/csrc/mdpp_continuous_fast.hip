@@ -1465,7 +1465,9 @@ bool launch_continuous_step1(const ContinuousArgs &a, const float *actions, floa
                              uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
     if (!a.fast_ok || (a.opts & (MDPP_OPT_NO_CFAST | MDPP_OPT_NO_STEP1)) || (a.philox && (a.opts & MDPP_OPT_NO_PHILOX_FAST))) return false;
     const bool gen = a.delay > 0 || a.every_n != 1 || a.n_boxes > 0 || !a.bounded;
-    const bool noise = a.has_p_noise || a.has_r_noise;
+    // (Philox streams carry no state: noise keys whose sigma is 0 add +0.0 whatever the normal is -- the noise-free instantiation serves them)
+    const bool sig0 = a.philox && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
+    const bool noise = (a.has_p_noise || a.has_r_noise) && !sig0;
 #define MDPP_K1(DD, OO, RR)                                                                                                  \
     if (a.D == DD && a.order == OO && a.n_rel == RR) {                                                                        \
         const int sel = (noise ? 4 : 0) | (gen ? 2 : 0) | (a.philox ? 1 : 0);                                                \
@@ -1496,7 +1498,9 @@ static void launch_g(const ContinuousArgs &a, int K, const float *actions, float
                      uint8_t *term, uint8_t *trunc, float *final_obs, hipStream_t s, char *name_out) {
     const int grid = (a.N + kBlock - 1) / kBlock;
     constexpr bool can_help = (size_t)kNRing * (D + 1) * kBlock * 8 <= 120 * 1024;
-    const bool noise = a.has_p_noise || a.has_r_noise;
+    // (Philox streams carry no state: noise keys whose sigma is 0 add +0.0 whatever the normal is -- the noise-free instantiation serves them)
+    const bool sig0 = PHILOX && (!a.has_p_noise || a.p_noise == 0.0) && (!a.has_r_noise || a.r_noise == 0.0) && !(a.opts & MDPP_OPT_NO_SIGMA0);
+    const bool noise = (a.has_p_noise || a.has_r_noise) && !sig0;
     // producer/consumer split for long rollouts of full blocks (LDS ring: 4 * (D+1) * 2 KiB)
     const bool helper = noise && can_help && K >= 16 && (a.N % kBlock) == 0 && !(a.opts & MDPP_OPT_NO_HELPER);
     // Philox: several producer waves per consumer wave when the per-step draw count makes it worth it

@@ -1404,7 +1404,10 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
         return launch_discrete_lean_next(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     if ((a.has_p_noise || a.has_r_noise) && !a.philox)
         return launch_discrete_lean_npnoise(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
-    if (a.has_p_noise || a.has_r_noise)
+    // (Philox streams carry no state: a reward-noise key whose sigma is 0 adds 0.0 + 0.0 z = +0.0 whatever the normal is -- the
+    //  noise-free instantiation, whose reward-value table holds the same float64 arithmetic, serves the handle)
+    const bool ph_sig0 = a.philox && !a.has_p_noise && a.has_r_noise && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);
+    if ((a.has_p_noise || a.has_r_noise) && !ph_sig0)
         return launch_discrete_lean_noise(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     const int nz = 0;
 #endif
@@ -1413,7 +1416,7 @@ bool launch_discrete_lean(const DiscreteArgs &a, int K, const int32_t *actions, 
     const bool shape = a.autoreset == MDPP_AUTORESET_NEXT_STEP ? a.lean_next_ok != 0
                        : (nz && !ph) ? a.shape_ok_noise_np != 0
                        : nz ? a.shape_ok_noise != 0
-                       : irr ? a.shape_ok_irr != 0 : (ph ? a.shape_ok != 0 : a.fast_ok != 0);
+                       : irr ? a.shape_ok_irr != 0 : (ph ? (a.shape_ok != 0 || (MDPP_LEAN_TU_NOISE == 0 && !MDPP_LEAN_TU_NEXT && a.shape_ok_noise != 0 && a.r_noise == 0.0 && !a.has_p_noise)) : a.fast_ok != 0);
     if (!shape || (ph && (a.opts & MDPP_OPT_NO_PHILOX_FAST)) || K < 32 || a.N < kBlock ||
         (a.opts & (MDPP_OPT_NO_PIPE | MDPP_OPT_NO_LEAN)))
         return false;
