@@ -12,9 +12,16 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import bench  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
 rng = sys.argv[sys.argv.index("--rng") + 1] if "--rng" in sys.argv else "numpy"
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
+args, skip = [], False
+for a in sys.argv[1:]:
+    if skip:
+        skip = False
+    elif a in ("--rng", "--reps"):
+        skip = True
+    else:
+        args.append(a)
 dev = torch.device("cuda", 0)
 for spec in args:
     name, _, opts = spec.partition(":")
