@@ -210,7 +210,13 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     constexpr bool Z0 = (NZ & 4) != 0;
     static_assert(!Z0 || NRN, "sigma-0 draws: numpy streams with the reward_noise key");
     constexpr bool NRX = NRN && !Z0;                                  // ... whose values are used
-    constexpr int KD = NRN ? kDepthNp : kDepth;                       // E->O ring depth in steps
+    // (Z0 without transition noise: the records carry no normal and the O waves are the noise-free kernel's -- the deep ring and the
+    //  whole-row stores of the noise-free form, MDPP_LEAN_Z0_ROWS)
+#ifndef MDPP_LEAN_Z0_ROWS
+#define MDPP_LEAN_Z0_ROWS 0        /* measured: d_s8_rn0 236 -> 233-238 us, nothing -- the H / E position pipeline bounds this form, not its stores */
+#endif
+    constexpr bool ZROWS = MDPP_LEAN_Z0_ROWS && Z0 && !PN;
+    constexpr int KD = (NRN && !ZROWS) ? kDepthNp : kDepth;           // E->O ring depth in steps
     __shared__ __align__(16) uint32_t lds_rec[3][KD][kBlock];
     __shared__ __align__(16) uint32_t lds_V[2048];            // reward bit & NaN gate, by the 4 low nibbles
     __shared__ __align__(16) uint2 lds_col[16];               // action a, byte s: P[s][a] | 8 | is_term[P[s][a]] << 7
@@ -229,11 +235,11 @@ __global__ __launch_bounds__(kRoles * kBlock) void k_discrete_rollout_lean(Discr
     // wave -- its reward path carries state from step to step -- computes its own envs' 8 rewards as before and hands
     // them to the O2 waves through lds_rw (kRB chunks deep), which store them too.  Blocks with spare lanes (N % 256)
     // keep the per-lane stores.
-    constexpr bool ROWS2 = (MDPP_LEAN_ROWS & 1) != 0 && !IRR && (NZ == 0 || (MDPP_LEAN_ROWS & 4) != 0);   // (noise: the O waves are long stages there -- no gain, measured)
+    constexpr bool ROWS2 = (MDPP_LEAN_ROWS & 1) != 0 && !IRR && (NZ == 0 || ZROWS || (MDPP_LEAN_ROWS & 4) != 0);   // (noise: the O waves are long stages there -- no gain, measured)
     // (rewards through the O2 waves: numpy streams only -- with Philox streams, where E runs at the lowest priority, 124-128 us per cfg2
     //  launch became 132-133; numpy streams 115-120 -> 112-118; without whole-row stores 129-137, all on one lease)
-    constexpr bool ROWS1 = (MDPP_LEAN_ROWS & 2) != 0 && ROWS2 && !PHILOX && !NRN;
-    constexpr int kRB = 4;                                    // chunks of staged rewards (the O1 waves run this far ahead of the stores)
+    constexpr bool ROWS1 = (MDPP_LEAN_ROWS & 2) != 0 && ROWS2 && !PHILOX && (!NRN || ZROWS);
+    constexpr int kRB = ZROWS ? 2 : 4;                        // chunks of staged rewards (the O1 waves run this far ahead of the stores; Z0: LDS)
     __shared__ __align__(16) float lds_rw[ROWS1 ? kRB : 1][kChunk][ROWS1 ? kBlock : 4];
     __shared__ __align__(16) uint32_t lds_rprod[kBlock / 64], lds_rcons[kBlock / 64];   // chunks staged by O1 wave w / stored by O2 wave w
     typedef typename std::conditional<IRR, uint64_t, uint32_t>::type S0Word;   // a nibble per tick; with an irrelevant sub-space two
