@@ -160,9 +160,10 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     static_assert(!SF || (ROLES == 3 && !PN && !IRR && !PH && NPH == 0), "SF: three roles, numpy streams, one sub-space, no transition noise");
     static_assert(!(ATNEED && ROLES == 3) || XR, "reward noise and reset draws share the env stream: no start-state queue");
     static_assert(!PE || (ROLES == 3 && UR && !PN && !IRR && !PH && NPH == 0), "PE: three roles, unit rewards, numpy streams, one sub-space");
-    constexpr int XRN = PE ? kXR / 2 : kXR;         // positions X runs ahead of E (PE: the lanes' table slots need the LDS)
+    constexpr int XRN = kXR;                        // positions X runs ahead of E (8 with batches of 4 serialised the two waves: 905 us per launch)
     __shared__ uint32_t x_meta[XR ? XRN : 1][kBlock];
-    __shared__ __align__(8) double x_val[XR ? XRN : 1][kBlock];
+    // (x_val -- the draws' values, unless sigma is 0 -- lives in DYNAMIC LDS behind the record ring: the launcher adds its 32 KiB only
+    //  for handles that form values; with one MDP per env there is room for it only at sigma 0)
     __shared__ uint32_t x_hhead[XR ? kBlock : 1], x_epos[XR ? kBlock : 1];      // positions made by X / reached by E
     static_assert(NPH == 0 || (PH && ROLES == 2 && !IRR), "Philox producers: two roles, one sub-space");
     // producers -> E: per env and step {other-state index j | noisy << 8 | start state << 16} and the reward normal
@@ -269,6 +270,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     // DUO: the record ring follows the tables in dynamic LDS
     uint64_t *ring = (uint64_t *)(lds + ((lds_end + 15u) & ~15u));
     double *ringz = (double *)(ring + kDepth * kBlock);         // RN: the step's standard normal
+    double *x_val = ringz + kDepth * kBlock;                    // XR, values formed: [XRN][kBlock] (launcher: xr_val_bytes)
     const uint8_t *P = lds + (PE ? pe_off : a.lds_P), *is_term = lds + (PE ? pe_off + pe_term : a.lds_term),
                   *rbits = lds + (PE ? pe_off + pe_rew : a.lds_rew), *P1 = lds + lds_P1;
     const uint64_t *T0 = (const uint64_t *)(lds + (PE ? pe_off + pe_T0 : lds_T0)), *T1 = (const uint64_t *)(lds + lds_T1);
@@ -507,7 +509,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                         const uint32_t slot = (hq + (uint32_t)u) & (uint32_t)(XRN - 1);
                         if (!rn_z0) {                   // numpy: x = rabs * wi, negated where bit 8 of the word is set
                             const double x = (double)rabs * zig.wi[idx];
-                            x_val[slot][l] = ((uint32_t)wd & 0x100u) ? -x : x;
+                            x_val[slot * kBlock + l] = ((uint32_t)wd & 0x100u) ? -x : x;
                         }
                         x_meta[slot][l] = start_of(wd) | (ok ? 0u : (2u << 8));     // (rejected: patched below)
                     }
@@ -552,7 +554,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                                 if (yy + yy > xx * xx) { val = ((rabs >> 8) & 0x1) ? -(nor_r + xx) : nor_r + xx; break; }
                                 if (cnt > 250u) { xstatus |= kQStatusInternal; break; }
                             }
-                            if (!rn_z0) x_val[slot][l] = val;
+                            if (!rn_z0) x_val[slot * kBlock + l] = val;
                             // (bits 24-31: the start state of the word BEHIND the tail's words -- a long tail reaches beyond the
                             //  window X keeps ahead of E)
                             const uint32_t words = cnt, ssb = start_of(word());
@@ -716,7 +718,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         xm0 = x_meta[ep & (uint32_t)(XRN - 1)][l];
         xm1 = x_meta[(ep + 1u) & (uint32_t)(XRN - 1)][l];
         xm2 = x_meta[(ep + 2u) & (uint32_t)(XRN - 1)][l];
-        if (!rn_z0) xv = x_val[ep & (uint32_t)(XRN - 1)][l];
+        if (!rn_z0) xv = x_val[(ep & (uint32_t)(XRN - 1)) * kBlock + l];
     };
     if constexpr (XR) { if (role == 0) x_fetch(); }
     // ---- E: one step of the state recurrence -> record
@@ -1160,7 +1162,10 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
     // XR (kernel header): reward noise alone -- a third wave evaluates the env stream by position (+ 52 KiB of static LDS)
-    const bool xr = duo && rn && !pn && lds_duo <= 72 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO);
+    // (XR's static LDS: 16 KiB of position records, the ziggurat tables, the bucket table, counters ~ 36 KiB; its values ring -- 32 KiB,
+    //  none at sigma 0 -- rides behind the record ring in dynamic LDS)
+    const size_t xr_val_bytes = (rn && !(a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0))) ? (size_t)kXR * kBlock * 8 : 0;
+    const bool xr = duo && rn && !pn && lds_duo + xr_val_bytes <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
     // SF (kernel header): the reference's sweep defaults fixed at compile time
     const bool sf = roles == 3 && !pn && a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
@@ -1169,7 +1174,7 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
         snprintf(name_out, kNameLen, "k_discrete_rollout_quiet<OBS64=%d,IRR=0,ROLES=%d,PN=%d,RN=%d,PHILOX=0,NPH=0,UNIT=0%s>", !a.obs_i32, roles, pn, rn, sf ? ",SF=1" : "");
         return true;
     }
-    const size_t l = roles == 1 ? lds : lds_duo;
+    const size_t l = roles == 1 ? lds : lds_duo + (xr ? xr_val_bytes : 0);
 #define MDPP_QN_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
 #define MDPP_QN_ROLES(O64, PN_, RN_)                                                                      \
     do {                                                                                                  \
@@ -1210,8 +1215,9 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
         const size_t pe_rew = ((size_t)a.S * a.A + a.S + 7) & ~(size_t)7, pe_T0 = (pe_rew + a.rbits_stride + 7) & ~(size_t)7;
         const size_t stride = pe_T0 + S8 * 8 + 8;             // (the kernel's carve of a lane's slot)
         const size_t depth = rn ? 16 : kQDepth;
-        const size_t l = ((stride * kBlock + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
-        if (l + (rn ? 40u : 20u) * 1024u > 160u * 1024u) return false;     // (+ the instantiation's static LDS: X rings, ziggurat tables, counters)
+        const bool z0 = rn && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);
+        const size_t l = ((stride * kBlock + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8) + ((rn && !z0) ? (size_t)kXR * kBlock * 8 : 0);
+        if (l + (rn ? 32u : 20u) * 1024u > 160u * 1024u) return false;     // (+ the instantiation's static LDS: X's meta ring, ziggurat tables, counters)
         const bool sf = a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
                         !(a.opts & MDPP_OPT_NO_QUIET_SF);
         if (name_out) {
@@ -1250,7 +1256,8 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     // XR (kernel header): reward noise alone on numpy streams -- a third wave evaluates the env stream by position (+ 52 KiB of
     // static LDS); gymnasium's next-step autoreset (the reset call must not draw) stays on two roles
-    const bool xr = duo && rn && !pn && !ph && !a.irr && a.autoreset != MDPP_AUTORESET_NEXT_STEP && lds_duo <= 72 * 1024 &&
+    const size_t xr_val_bytes = (rn && !(a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0))) ? (size_t)kXR * kBlock * 8 : 0;
+    const bool xr = duo && rn && !pn && !ph && !a.irr && a.autoreset != MDPP_AUTORESET_NEXT_STEP && lds_duo + xr_val_bytes <= 120 * 1024 &&
                     !(a.opts & MDPP_OPT_NO_TRIO);
     const int roles = (trio || xr) ? 3 : duo ? 2 : 1;
     // SF (kernel header): the reference's sweep defaults fixed at compile time
@@ -1264,7 +1271,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
                  a.irr != 0, roles, pn, rn, ph, nph, sf ? ",SF=1" : "");
         return true;
     }
-    const size_t l = roles == 1 ? lds : lds_duo;
+    const size_t l = roles == 1 ? lds : lds_duo + (xr ? xr_val_bytes : 0);
 #define MDPP_Q_ARGS a, K, l, actions, obs, reward, term, trunc, final_obs, s
 #define MDPP_Q_ROLES(O64, IR, PN_, RN_)                                                           \
     do {                                                                                          \

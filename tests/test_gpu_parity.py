@@ -1971,7 +1971,10 @@ def test_per_env_mdps_on_the_role_split_kernel_vs_oracle(variant):
         warnings.simplefilter("ignore")
         env = _venv(seeds=list(range(100, 100 + N)), **kwargs, **cfg)
     kn = env.rollout_kernel_name(64)
-    assert kn.startswith("k_discrete_rollout_quiet<") and "PE=1" in kn and ("SF=1" in kn) == (variant in ("sf_l1", "sf_rn0", "s16_l1")), kn
+    if variant in ("rn_l2", "noreset_rn"):       # (values formed: the X wave's 32 KiB values ring does not fit beside 256 table slots -> the general kernel)
+        assert kn.startswith("k_discrete_step<"), kn
+    else:
+        assert kn.startswith("k_discrete_rollout_quiet<") and "PE=1" in kn and ("SF=1" in kn) == (variant in ("sf_l1", "sf_rn0", "s16_l1")), kn
     assert env.rollout_kernel_name(8).startswith("k_discrete_step<")
     auto = kwargs["autoreset"] == "same_step"
     horizon = kwargs.get("max_episode_steps", 0)
