@@ -38,6 +38,11 @@
 
 namespace mdpp {
 
+#if defined(MDPP_Q_PRIO_E) || defined(MDPP_Q_PRIO_O) || defined(MDPP_Q_PRIO_H)
+#define MDPP_Q_PRIO_FORCED 1       // (tools/ablate.py: the same priorities for every form)
+#else
+#define MDPP_Q_PRIO_FORCED 0
+#endif
 #ifndef MDPP_Q_PRIO_E
 #define MDPP_Q_PRIO_E 0
 #endif
@@ -173,6 +178,12 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     __shared__ uint32_t s_hprod[NPH ? NPH : 1][kBlock / 64];            // producer p has made every step < this of its blocks, for wave w
     constexpr bool DUO = ROLES >= 2, TRIO = ROLES == 3 && !XR;      // (TRIO: the start-state queue's H role)
     const bool rn_z0 = RN && !PH && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);   // the reward_noise key present with sigma 0 (wave-uniform)
+    // Wave priorities (s_setprio; round 6, tools/ablate.py on one lease).  XR: the position wave is the long stage -- X 3, E 2, O 1:
+    // d_s50_rn0 0.216 -> 0.255 of HBM (E 1 / O 0 / X 3: 0.254; E 3 / O 1 / X 2: 0.240).  The start-state queue's three roles: E 3,
+    // O 1, H 2 (0.404 -> 0.416, the other orders within a percent).  One and two roles: all equal, as before.
+    constexpr int kPrioE = MDPP_Q_PRIO_FORCED ? MDPP_Q_PRIO_E : XR ? 2 : TRIO ? 3 : 0;
+    constexpr int kPrioO = MDPP_Q_PRIO_FORCED ? MDPP_Q_PRIO_O : (XR || TRIO) ? 1 : 0;
+    constexpr int kPrioH = MDPP_Q_PRIO_FORCED ? MDPP_Q_PRIO_H : XR ? 3 : TRIO ? 2 : 0;
     constexpr int kDepth = RN ? 16 : kQDepth;       // RN records carry a double: 16 B per step
     constexpr int kThreads = (ROLES + NPH) * kBlock;
     const int tid = threadIdx.x;
@@ -394,7 +405,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     if constexpr (NPH > 0) if (role >= 2) {
         // =========================================================== Philox producer (see NPH above)
         const int me = role - 2;
-        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
+        __builtin_amdgcn_s_setprio(kPrioH);
         uint32_t hstatus = 0;
         const uint64_t G0 = ptick0 >> 2;
         const int nG = (int)(((ptick0 + (uint64_t)K - 1u) >> 2) - G0) + 1;
@@ -463,7 +474,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     };
     // =============================================================== X: the env stream by position (header, XR)
     if constexpr (XR) if (role == 2) {
-        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
+        __builtin_amdgcn_s_setprio(kPrioH);
         uint32_t hq = 0, spins = 0, xstatus = 0;        // positions made
         // (the limb form of the PCG64 step, mdpp_rng.hpp: 31 instead of 46 vector instructions per word -- this wave is a generator
         //  and little else; its fixed temporaries v150-v157 fit the 168 registers of a 768-thread kernel)
@@ -589,7 +600,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     }
     // =============================================================== H: start-state producer
     if constexpr (TRIO) if (role == 2) {
-        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_H);
+        __builtin_amdgcn_s_setprio(kPrioH);
         uint64_t vals = 0;
         uint32_t tail = 0, slot = 0;
         // (the limb form of the PCG64 step: 31 instead of 46 vector instructions per word; v150-v157 fit a 768-thread kernel)
@@ -947,7 +958,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
     } else if (role == 0) {
         // -------------------------------------------------------------- E waves
-        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_E);
+        __builtin_amdgcn_s_setprio(kPrioE);
         // Actions are fetched kEAh chunks ahead of their use; the buffers rotate by NAME (the slot loop is unrolled): copying a
         // register whose load is in flight makes the wave wait for it.
 #ifndef MDPP_Q_EAHEAD
@@ -1021,7 +1032,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
         }
     } else {
         // -------------------------------------------------------------- O waves
-        __builtin_amdgcn_s_setprio(MDPP_Q_PRIO_O);
+        __builtin_amdgcn_s_setprio(kPrioO);
         const int nchunks = (K + kPre - 1) / kPre;
         for (int c = 0; c < nchunks; c++) {
             const int kbase = c * kPre;
