@@ -212,7 +212,11 @@ int mdpp_upload_discrete_irrelevant(mdpp_env *h, const uint8_t *P_irr_host, cons
                                     const double *noise_cdf_irr_host);
 
 /* Image templates (host): uint8 [S][n_radii][n_cls][tpl][tpl], polygon rasters centred in the
- * template; cls_x/cls_y int16 [S][n_radii][W or H] map a centre coordinate to its template class. */
+ * template; cls_x/cls_y int16 [S][n_radii][W or H] map a centre coordinate to its template class.
+ * A centre whose polygon is CUT by the picture's edge (a quantised shift (v // q) * q rounds towards -inf and can leave the
+ * draw's own range, image_multi_discrete.py:172-181) must be a class of its own whose template is cut the same way: the
+ * specialised renderers apply Pillow's "source outside the picture reads 0" rule through the template alone
+ * (mdp_playground_amd/image_obs.py _edge_clip; golden i_shq5_rot). */
 int mdpp_upload_image_templates(mdpp_env *h, const uint8_t *tpl_host, int32_t n_radii, int32_t n_cls_x,
                                 int32_t n_cls_y, const int16_t *cls_x_host, const int16_t *cls_y_host);
 

@@ -922,6 +922,7 @@ static void launch_reset_t(const ContinuousArgs &a, uint64_t reset_tick, const u
         else if (D_ <= 12) { CALL(12, 4); }                                         \
         else if (D_ <= 16 && O_ <= 2) { CALL(16, 2); }                              \
         else if (D_ <= 32 && O_ <= 2) { CALL(32, 2); }                              \
+        else if (D_ <= 32) { CALL(32, 4); }                                         \
         else { return MDPP_EUNSUPPORTED; }                                          \
     } while (0)
 

@@ -23,6 +23,15 @@ def _vertex_offsets(c, R, k, fn):
     return tuple(int(c + R * fn((2 * np.pi / k) * i)) - c for i in range(k))
 
 
+def _edge_clip(c, R, size):
+    """How many of the polygon's 2 R + 1 columns (rows) around centre c lie before 0 / past size - 1.  A quantised shift
+    ``(v // q) * q`` rounds towards -inf and can leave the draw's own range -mw + 1 .. mw - 1 (:172-181: q = 4 at 100 x 100
+    moves the centre by -32 against mw = 30), so the polygon is cut by the picture's edge when Pillow draws it -- and a rotation
+    afterwards samples the CUT picture.  A cut centre is its own template class: the template is cut the same way, and the
+    renderers' rule "the source pixel outside the picture reads 0" holds on the template alone."""
+    return (max(0, R - c), max(0, c + R - (size - 1)))
+
+
 def radius_range(params):
     R0 = params["circle_radius"]
     if "scale" in params["transforms"]:
@@ -68,26 +77,32 @@ def build_templates(S, params, check=True):
             for c in centre_range(params, R, W):
                 if not (0 <= c < W):
                     continue
-                p = _vertex_offsets(c, R, k, np.cos)
+                p = _vertex_offsets(c, R, k, np.cos) + _edge_clip(c, R, W)
                 if p not in xs:
                     xs.append(p)
                 cls_x[s, ri, c] = xs.index(p)
             for c in centre_range(params, R, H):
                 if not (0 <= c < H):
                     continue
-                p = _vertex_offsets(c, R, k, np.sin)
+                p = _vertex_offsets(c, R, k, np.sin) + _edge_clip(c, R, H)
                 if p not in ys:
                     ys.append(p)
                 cls_y[s, ri, c] = ys.index(p)
-            patterns[(s, ri)] = (xs or [(0,) * k], ys or [(0,) * k])
+            patterns[(s, ri)] = (xs or [(0,) * (k + 2)], ys or [(0,) * (k + 2)])
             ncx, ncy = max(ncx, len(xs)), max(ncy, len(ys))
     tpl = np.zeros((S, nR, ncx, ncy, t, t), np.uint8)
     for (s, ri), (xs, ys) in patterns.items():
         for ix, px in enumerate(xs):
             for iy, py in enumerate(ys):
                 img = Image.new("L", (t, t))
-                ImageDraw.Draw(img).polygon([(half + dx, half + dy) for dx, dy in zip(px, py)], fill=255)
-                tpl[s, ri, ix, iy] = np.array(img)
+                ImageDraw.Draw(img).polygon([(half + dx, half + dy) for dx, dy in zip(px[:-2], py[:-2])], fill=255)
+                arr = np.array(img)
+                R = r_min + ri                   # the picture's edge cuts the polygon BEFORE the rotation samples it (_edge_clip)
+                arr[:, :half - R + px[-2]] = 0
+                arr[:, half + R + 1 - px[-1]:] = 0
+                arr[:half - R + py[-2], :] = 0
+                arr[half + R + 1 - py[-1]:, :] = 0
+                tpl[s, ri, ix, iy] = arr
     out = dict(tpl=tpl, cls_x=cls_x, cls_y=cls_y, r_min=r_min, r_max=r_max, tpl_size=t,
                n_cls_x=ncx, n_cls_y=ncy, log_min_r=0.0, log_max_r=0.0)
     if "scale" in params["transforms"]:

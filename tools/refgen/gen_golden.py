@@ -322,6 +322,14 @@ CASES = {
                     image_height=100, image_transforms="shift,scale,rotate,flip",
                     image_scale_range=(0.5, 2)),
         seeds=[0, 1, 2], T=32, reset="on_done"),
+    # a quantised shift that leaves the draw's own range: (v // q) * q rounds towards -inf, so with q = 5 at 84 x 84 (mw = 22, v in
+    # -21 .. 21) the centre moves by -25 and the polygon is CLIPPED by the picture's edge (3 px) before the rotation samples it
+    # (the reference's own sh_quant sweeps have it: 100 x 100, q = 4 / 8 / 16 -> -32 against mw = 30)
+    "i_shq5_rot": dict(
+        config=dict(CFG1, image_representations=True, image_width=84,
+                    image_height=84, image_transforms="shift,rotate,flip",
+                    image_sh_quant=5, image_ro_quant=3),
+        seeds=[0, 1, 2, 3], T=48, reset="on_done"),
     "i_none": dict(
         config=dict(CFG1, image_representations=True, image_width=84,
                     image_height=84),
