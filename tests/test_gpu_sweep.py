@@ -269,6 +269,9 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
                 assert np.array_equal(o.get_rng_irr()[:4], env.get_rng_streams(capi.STREAM_SPACE_IRR)[i][:4]), (k, cfg, mode, K, i)
 
 
+# (env counts: fewer than 8 workgroups, exactly 8 and a multiple of 8 -- the XCD-contiguous block order is on for those only --, 9
+#  workgroups, a ragged last workgroup)
+_FUZZ_SIZES = (1024, 2048, 1000, 4096, 2304, 2048 + 77)
 FUZZ = _fuzz_configs(48, 20261004) + _fuzz_configs(96, 777) if "MDPP_FUZZ_SEEDS" not in os.environ else \
     sum((_fuzz_configs(160, int(x)) for x in os.environ["MDPP_FUZZ_SEEDS"].split(",")), [])
 
@@ -285,7 +288,7 @@ def test_random_configurations_specialised_equals_general(k):
     from mdp_playground_amd import _capi as capi
     import warnings
     cfg, mode, per_env = FUZZ[k]
-    N = 1024
+    N = _FUZZ_SIZES[(7 * k + 3) % len(_FUZZ_SIZES)]
     kw = dict(autoreset="same_step")
     if mode == "disabled":
         kw = dict(autoreset="disabled")
@@ -469,7 +472,7 @@ def test_random_widened_configurations_specialised_equals_general(k):
     import warnings
     fam, cfg, mode, rng, ragged = FUZZ_WIDE[k]
     image = bool(cfg.get("image_representations"))
-    N, F = (256, 20) if image else (1024, 48)
+    N, F = (256, 20) if image else (_FUZZ_SIZES[(7 * k + 3) % len(_FUZZ_SIZES)], 48)
     if ragged:
         N, F = (250, 9) if image else (1000, 11)
     kw = dict(autoreset="same_step")
@@ -538,3 +541,91 @@ def test_random_widened_configurations_default_dispatch_vs_oracle(k):
     _check_vs_oracle(env, k, cfg, mode, kw, 1500 + k, scale=1.05 if env.kind == "continuous" else 1.0, stride=29)
     assert not (env.status() & 0x80000000).any()
     env.close()
+
+
+_OPS_CASES = [("d", k) for k in range(0, len(FUZZ), 4)] + [("w", k) for k in range(1, len(FUZZ_WIDE), 3)]
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("fam,k", _OPS_CASES)
+def test_random_operation_sequences_specialised_equals_general(fam, k):
+    """Every fourth / third configuration of the two random families under a random SEQUENCE of calls instead of the fixed
+    rollout-steps-rollout: fused rollouts of 1 / 2 / 7 / 33 / 130 / 257 steps, runs of single steps, reset() of everything, reset(mask=...)
+    of a random third, seed(), and a get_augmented_state() -> set_augmented_state() round trip on the specialised handle alone
+    (which must change nothing).  After every call: every output of every env against the general kernels; at the end every
+    stream's state and the status words."""
+    from mdp_playground_amd import _capi as capi
+    import warnings
+    if fam == "d":
+        cfg, mode, per_env = FUZZ[k]
+        rng, image = "numpy", False
+        N = _FUZZ_SIZES[(5 * k + 1) % len(_FUZZ_SIZES)]
+    else:
+        _, cfg, mode, rng, ragged = FUZZ_WIDE[k]
+        per_env = False
+        image = bool(cfg.get("image_representations"))
+        N = (250 if ragged else 256) if image else _FUZZ_SIZES[(5 * k + 1) % len(_FUZZ_SIZES)]
+    kw = dict(autoreset="same_step")
+    if mode == "disabled":
+        kw = dict(autoreset="disabled")
+    elif mode == "next_step":
+        kw = dict(autoreset="next_step")
+    elif mode == "timelimit":
+        kw = dict(autoreset="same_step", max_episode_steps=9)
+    if rng == "philox":
+        kw.update(rng="philox", philox_seed=31)
+    nkw = dict(seeds=list(range(3, 3 + N))) if per_env else dict(num_envs=N)
+    cfg = dict(cfg)
+    if per_env:
+        cfg.pop("seed", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            a = _venv(**nkw, **kw, **cfg)
+        except (NotImplementedError, ValueError, AssertionError, IndexError, KeyError, TypeError) as e:
+            pytest.skip(f"refused at construction: {type(e).__name__}")
+        b = _venv(**nkw, **kw, **cfg)
+    b.set_kernel_options(*capi.OPTIONS)
+    g = np.random.default_rng(4000 + k)
+    scale = np.float32(1.05) if a.kind == "continuous" else None
+    log = []
+    for _ in range(9):
+        op = str(g.choice(["rollout", "rollout", "rollout", "steps", "reset", "reset_mask", "seed", "state"]))
+        if op == "rollout":
+            F = int(g.choice([1, 2, 7, 33, 130, 257] if not image else [1, 2, 7, 19]))
+            log.append((op, F))
+            acts = _rand_actions(a, F, g)
+            acts = torch.as_tensor(acts if scale is None else (acts * scale).astype(np.float32), device=a.device)
+            ra, rb = a.rollout(acts), b.rollout(acts)
+            torch.cuda.synchronize()
+            assert all(_same(x, y) for x, y in zip(ra, rb)), (fam, k, cfg, mode, rng, N, log, a.rollout_kernel_name(F))
+        elif op == "steps":
+            n = int(g.integers(1, 6))
+            log.append((op, n))
+            acts = _rand_actions(a, n, g)
+            acts = torch.as_tensor(acts if scale is None else (acts * scale).astype(np.float32), device=a.device)
+            for t in range(n):
+                sa, sb = a.step(acts[t]), b.step(acts[t])
+                assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (fam, k, cfg, mode, rng, N, log, t, a.rollout_kernel_name(1))
+        elif op in ("reset", "reset_mask"):
+            mask = None if op == "reset" else torch.as_tensor(g.random(N) < 0.33)
+            log.append((op,))
+            oa, ob = a.reset(mask=mask)[0], b.reset(mask=mask)[0]
+            assert _same(oa, ob), (fam, k, cfg, mode, rng, N, log)
+        elif op == "seed":
+            if rng == "philox":
+                continue
+            sd = int(g.integers(1 << 30))
+            log.append((op, sd))
+            a.seed(sd); b.seed(sd)
+        else:
+            log.append((op,))
+            a.set_augmented_state(a.get_augmented_state())
+    assert np.array_equal(a.status(), b.status()), (fam, k, log)
+    assert not (a.status() & 0x80000000).any()
+    if rng != "philox":
+        streams = [capi.STREAM_ENV, capi.STREAM_SPACE] + ([capi.STREAM_IMAGE] if image and a.kind == "discrete" else []) \
+            + ([capi.STREAM_SPACE_IRR] if a.kind == "discrete" and a._irr else []) + ([capi.STREAM_ACTION] if a.kind == "grid" else [])
+        for s in streams:
+            assert np.array_equal(a.get_rng_streams(s), b.get_rng_streams(s)), (fam, k, cfg, mode, s, log)
+    a.close(); b.close()
