@@ -440,6 +440,10 @@ class RLToyVectorEnv:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
+            src = getattr(self, "_obs_src", None)
+            if src is not None:          # the rows of the envs NOT reset: their observation after the last rollout() / graph replay
+                self._obs.copy_(src)
+        self._obs_src = None
         rc = self._lib.mdpp_reset(self._h, mptr, C.c_void_p(self._obs.data_ptr()), self._stream())
         capi.check(self._lib, self._h, rc, "mdpp_reset")
         return self._obs
@@ -531,6 +535,7 @@ class RLToyVectorEnv:
                              self._p_trunc, self._p_final, self._raw_stream())
         if rc:
             capi.check(self._lib, self._h, rc, "mdpp_step")
+        self._obs_src = None
         return self._obs, self._reward, self._term_b, self._trunc_b, self._info
 
     def rollout(self, actions, out=None):
@@ -546,6 +551,7 @@ class RLToyVectorEnv:
                                    C.c_void_p(rew.data_ptr()), C.c_void_p(term.data_ptr()),
                                    C.c_void_p(trunc.data_ptr()), self._stream())
         capi.check(self._lib, self._h, rc, "mdpp_step_n")
+        self._obs_src = obs[K - 1]        # (a view: reset(mask=...) shows it for the envs it leaves alone)
         return obs, rew, term.view(torch.bool), trunc.view(torch.bool)
 
     def rollout_kernel_name(self, K):
@@ -811,6 +817,7 @@ class StepGraph:
                                      "(length %d) would be read at the captured ring head" % (int(now.value) - self._tick0, d))
         self._g.replay()
         capi.check(env._lib, env._h, env._lib.mdpp_tick(env._h, self.K, None), "mdpp_tick")
+        env._obs_src = self.obs[self.K - 1]
 
 
 def make_vec(env_id="RLToyVec-v0", num_envs=1, **kwargs):

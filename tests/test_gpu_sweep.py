@@ -271,7 +271,8 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
 
 # (env counts: fewer than 8 workgroups, exactly 8 and a multiple of 8 -- the XCD-contiguous block order is on for those only --, 9
 #  workgroups, a ragged last workgroup)
-_FUZZ_SIZES = (1024, 2048, 1000, 4096, 2304, 2048 + 77)
+_FUZZ_SIZES = tuple(int(x) for x in os.environ["MDPP_FUZZ_SIZES"].split(",")) if "MDPP_FUZZ_SIZES" in os.environ else \
+    (1024, 2048, 1000, 4096, 2304, 2048 + 77)
 FUZZ = _fuzz_configs(48, 20261004) + _fuzz_configs(96, 777) if "MDPP_FUZZ_SEEDS" not in os.environ else \
     sum((_fuzz_configs(160, int(x)) for x in os.environ["MDPP_FUZZ_SEEDS"].split(",")), [])
 
@@ -551,7 +552,7 @@ _OPS_CASES = [("d", k) for k in range(0, len(FUZZ), 4)] + [("w", k) for k in ran
 def test_random_operation_sequences_specialised_equals_general(fam, k):
     """Every fourth / third configuration of the two random families under a random SEQUENCE of calls instead of the fixed
     rollout-steps-rollout: fused rollouts of 1 / 2 / 7 / 33 / 130 / 257 steps, runs of single steps, reset() of everything, reset(mask=...)
-    of a random third, seed(), and a get_augmented_state() -> set_augmented_state() round trip on the specialised handle alone
+    of a random third, seed(), a HIP graph of 2-5 captured single steps replayed twice, and a get_augmented_state() -> set_augmented_state() round trip on the specialised handle alone
     (which must change nothing).  After every call: every output of every env against the general kernels; at the end every
     stream's state and the status words."""
     from mdp_playground_amd import _capi as capi
@@ -590,7 +591,7 @@ def test_random_operation_sequences_specialised_equals_general(fam, k):
     scale = np.float32(1.05) if a.kind == "continuous" else None
     log = []
     for _ in range(9):
-        op = str(g.choice(["rollout", "rollout", "rollout", "steps", "reset", "reset_mask", "seed", "state"]))
+        op = str(g.choice(["rollout", "rollout", "rollout", "steps", "reset", "reset_mask", "seed", "state", "graph"]))
         if op == "rollout":
             F = int(g.choice([1, 2, 7, 33, 130, 257] if not image else [1, 2, 7, 19]))
             log.append((op, F))
@@ -598,7 +599,7 @@ def test_random_operation_sequences_specialised_equals_general(fam, k):
             acts = torch.as_tensor(acts if scale is None else (acts * scale).astype(np.float32), device=a.device)
             ra, rb = a.rollout(acts), b.rollout(acts)
             torch.cuda.synchronize()
-            assert all(_same(x, y) for x, y in zip(ra, rb)), (fam, k, cfg, mode, rng, N, log, a.rollout_kernel_name(F))
+            assert all(_same(x, y) for x, y in zip(ra, rb)), (log, a.rollout_kernel_name(F), fam, k, mode, rng, N, cfg)
         elif op == "steps":
             n = int(g.integers(1, 6))
             log.append((op, n))
@@ -606,18 +607,39 @@ def test_random_operation_sequences_specialised_equals_general(fam, k):
             acts = torch.as_tensor(acts if scale is None else (acts * scale).astype(np.float32), device=a.device)
             for t in range(n):
                 sa, sb = a.step(acts[t]), b.step(acts[t])
-                assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (fam, k, cfg, mode, rng, N, log, t, a.rollout_kernel_name(1))
+                assert all(_same(x, y) for x, y in zip(sa[:4], sb[:4])), (log, t, a.rollout_kernel_name(1), fam, k, mode, rng, N, cfg)
         elif op in ("reset", "reset_mask"):
             mask = None if op == "reset" else torch.as_tensor(g.random(N) < 0.33)
             log.append((op,))
             oa, ob = a.reset(mask=mask)[0], b.reset(mask=mask)[0]
-            assert _same(oa, ob), (fam, k, cfg, mode, rng, N, log)
+            assert _same(oa, ob), (log, fam, k, mode, rng, N, cfg)
         elif op == "seed":
             if rng == "philox":
                 continue
             sd = int(g.integers(1 << 30))
             log.append((op, sd))
             a.seed(sd); b.seed(sd)
+        elif op == "graph":
+            # a HIP graph of K captured mdpp_step launches on the specialised handle, replayed twice (new actions written into its
+            # action tensor in between), against 2 K step() calls of the general handle
+            K = int(g.integers(2, 6))
+            acts = _rand_actions(a, 2 * K, g)
+            acts = torch.as_tensor(acts if scale is None else (acts * scale).astype(np.float32), device=a.device)
+            try:
+                sg = a.step_graph(acts[:K].clone())
+            except capi.MdppError as e:
+                assert "does not replay exactly" in str(e), e
+                continue
+            log.append((op, K))
+            for half in range(2):
+                sg.actions.copy_(acts[half * K:(half + 1) * K])
+                sg.replay()
+                torch.cuda.synchronize()
+                for t in range(K):
+                    sb = b.step(acts[half * K + t])
+                    got = (sg.obs[t], sg.reward[t], sg.terminated[t], sg.truncated[t])
+                    assert all(_same(x, y) for x, y in zip(got, sb[:4])), (log, half, t, [bool(_same(x, y)) for x, y in zip(got, sb[:4])], a.rollout_kernel_name(1), fam, k, mode, rng, N, cfg)
+            del sg
         else:
             log.append((op,))
             a.set_augmented_state(a.get_augmented_state())

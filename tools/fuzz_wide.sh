@@ -4,5 +4,5 @@
 mkdir -p gpurun_out/fz
 export MDPP_FUZZ_WIDE_SEEDS=${1:-606}
 [ -n "$2" ] && export MDPP_FUZZ_SEEDS=$2
-timeout 2400 python -m pytest tests/test_gpu_sweep.py -m gpu -q -k "${3:-random}" --maxfail 12 -p no:cacheprovider 2>&1 | tail -150 > gpurun_out/fz/wide.txt
+timeout 2400 python -m pytest tests/test_gpu_sweep.py -m gpu -q -k "${3:-random}" --maxfail 12 -p no:cacheprovider 2>&1 | tail -400 > gpurun_out/fz/wide.txt
 grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/fz/wide.txt | tail -30
