@@ -711,3 +711,72 @@ def test_pictures_of_fused_rollouts_vs_oracle(src, key):
     end = env.get_rng_streams(capi.STREAM_IMAGE)
     assert all(np.array_equal(words[i][:4], end[i][:4]) for i in range(2, N, 5))
     env.close(); twin.close()
+
+
+_SHARD_CASES = [("d", k) for k in range(2, len(FUZZ), 5)] + [("w", k) for k in range(0, len(FUZZ_WIDE), 4)]
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("fam,k", _SHARD_CASES)
+def test_random_configurations_two_unequal_shards_equal_one_batch(fam, k):
+    """envs are sharded contiguously and every stream is keyed by the GLOBAL env id, so a run's results do not depend on
+    how many devices it was split over.  Every fifth / fourth configuration of the two random families as ONE batch of N envs beside
+    two handles of 3 N / 8 and 5 N / 8 envs with env_id_offset 0 and 3 N / 8 (different grid sizes, the second shard not starting
+    on a workgroup boundary of the whole batch): a rollout, single steps, a rollout -- every output of every env of the two shards
+    equal to the whole batch's rows, on the default dispatch."""
+    import warnings
+    if fam == "d":
+        cfg, mode, per_env = FUZZ[k]
+        rng, image = "numpy" if k % 2 else "philox", False
+    else:
+        _, cfg, mode, rng, _ = FUZZ_WIDE[k]
+        per_env = False
+        image = bool(cfg.get("image_representations"))
+    N = 256 if image else 2048
+    cut = 3 * N // 8
+    kw = dict(autoreset="same_step")
+    if mode == "disabled":
+        kw = dict(autoreset="disabled")
+    elif mode == "next_step":
+        kw = dict(autoreset="next_step")
+    elif mode == "timelimit":
+        kw = dict(autoreset="same_step", max_episode_steps=9)
+    if rng == "philox":
+        kw.update(rng="philox", philox_seed=31)
+    cfg = dict(cfg)
+    if per_env:
+        cfg.pop("seed", None)
+    seeds = list(range(3, 3 + N))
+
+    def make(lo, hi):
+        nkw = dict(seeds=seeds[lo:hi]) if per_env else dict(num_envs=hi - lo)
+        return _venv(env_id_offset=lo, **nkw, **kw, **cfg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            whole = make(0, N)
+        except (NotImplementedError, ValueError, AssertionError, IndexError, KeyError, TypeError) as e:
+            pytest.skip(f"refused at construction: {type(e).__name__}")
+        parts = [(0, cut, make(0, cut)), (cut, N, make(cut, N))]
+    g = np.random.default_rng(7000 + k)
+    assert all(_same(whole._obs[lo:hi], p._obs) for lo, hi, p in parts), (fam, k, "initial observations")
+    for piece, F in enumerate((40, 1, 1, 23)):
+        acts = _rand_actions(whole, F, g)
+        if whole.kind == "continuous":
+            acts = (acts * np.float32(1.05)).astype(np.float32)
+        acts = torch.as_tensor(acts, device=whole.device)
+        if F == 1:
+            rw = [x[None] for x in whole.step(acts[0])[:4]]
+            rp = [[x[None] for x in p.step(acts[0, lo:hi].contiguous())[:4]] for lo, hi, p in parts]
+        else:
+            rw = whole.rollout(acts)
+            rp = [p.rollout(acts[:, lo:hi].contiguous()) for lo, hi, p in parts]
+        torch.cuda.synchronize()
+        for (lo, hi, p), r in zip(parts, rp):
+            assert all(_same(x[:, lo:hi].contiguous(), y) for x, y in zip(rw, r)), (piece, F, lo, hi, fam, k, mode, rng, whole.rollout_kernel_name(F),
+                                                                                    p.rollout_kernel_name(F), cfg)
+    st = whole.status()                   # (sticky bits, cleared by the call: read once)
+    for lo, hi, p in parts:
+        assert np.array_equal(st[lo:hi], p.status()), (fam, k, lo, hi)
+        p.close()
+    whole.close()
