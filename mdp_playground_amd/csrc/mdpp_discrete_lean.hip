@@ -141,6 +141,9 @@ constexpr uint32_t kStatusInternal = 0x80000000u;
 constexpr uint32_t kQueueCap = 6;
 constexpr int kHChunks = 8;               // Philox streams: H runs up to this many chunks ahead of E
 constexpr int kHChunksNp = 4;             // numpy transition noise: ... this many (LDS)
+// (Measured and not kept, round 6: H running TWO words ahead so that a position's meta carries the start states of both words behind it
+//  and E reads one entry per step instead of three -- d_s8_rn0 232 -> 248 us, cfg2 + both noises 274 -> 277: H is the long stage of
+//  this form, work moved onto it costs more than E saves.)
 constexpr int kXR = 16;                   // numpy reward noise: stream positions H evaluates ahead of E (per lane)
 constexpr int kXB = 4;                    // ... per batch (divides kXR; 8 with kXR = 16 leaves E too little lead: 497 -> 586 us)
 constexpr int kDepthNp = 16;              // ... and the E->O ring depth of these instantiations (records carry the normal)
