@@ -143,7 +143,9 @@ constexpr int kHChunks = 8;               // Philox streams: H runs up to this m
 constexpr int kHChunksNp = 4;             // numpy transition noise: ... this many (LDS)
 // (Measured and not kept, round 6: H running TWO words ahead so that a position's meta carries the start states of both words behind it
 //  and E reads one entry per step instead of three -- d_s8_rn0 232 -> 248 us, cfg2 + both noises 274 -> 277: H is the long stage of
-//  this form, work moved onto it costs more than E saves.)
+//  this form, work moved onto it costs more than E saves.  The other direction -- Z0: a 32-bit meta with the word's top 11 bits, E looks the
+//  start state up itself, the words kept in LDS for the <= 8 buckets of 2 048 a threshold falls into -- 232 -> 253 us: + 40 KB of LDS,
+//  one workgroup per CU instead of two.)
 constexpr int kXR = 16;                   // numpy reward noise: stream positions H evaluates ahead of E (per lane)
 constexpr int kXB = 4;                    // ... per batch (divides kXR; 8 with kXR = 16 leaves E too little lead: 497 -> 586 us)
 constexpr int kDepthNp = 16;              // ... and the E->O ring depth of these instantiations (records carry the normal)
