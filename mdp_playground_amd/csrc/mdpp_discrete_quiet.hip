@@ -280,7 +280,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
     __syncthreads();
     // DUO: the record ring follows the tables in dynamic LDS
     uint64_t *ring = (uint64_t *)(lds + ((lds_end + 15u) & ~15u));
-    double *ringz = (double *)(ring + kDepth * kBlock);         // RN: the step's standard normal
+    double *ringz = (double *)(ring + kDepth * kBlock);         // RN: the step's standard normal (sigma 0: not allocated, not touched)
     double *x_val = ringz + kDepth * kBlock;                    // XR, values formed: [XRN][kBlock] (launcher: xr_val_bytes)
     const uint8_t *P = lds + (PE ? pe_off : a.lds_P), *is_term = lds + (PE ? pe_off + pe_term : a.lds_term),
                   *rbits = lds + (PE ? pe_off + pe_rew : a.lds_rew), *P1 = lds + lds_P1;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                     preq[j][u] = load_act(kbase + kEAh * kPre + u);
                     double z = 0.0;
                     ring[((kbase + u) % kDepth) * kBlock + l] = stepE(act, z, kbase + u);
-                    if (RN) ringz[((kbase + u) % kDepth) * kBlock + l] = z;
+                    if (RN && !rn_z0) ringz[((kbase + u) % kDepth) * kBlock + l] = z;
                 }
             } else {
                 for (int k = kbase; k < K; k++) {
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                     for (int u = 1; u < kPre; u++) act = (k - kbase == u) ? preq[j][u] : act;
                     double z = 0.0;
                     ring[(k % kDepth) * kBlock + l] = stepE(act, z, k);
-                    if (RN) ringz[(k % kDepth) * kBlock + l] = z;
+                    if (RN && !rn_z0) ringz[(k % kDepth) * kBlock + l] = z;
                 }
             }
             if ((l & 63) == 0)
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
 #pragma unroll
                 for (int u = 0; u < kPre; u++) {
                     rec[u] = ring[((kbase + u) % kDepth) * kBlock + l];
-                    zz[u] = RN ? ringz[((kbase + u) % kDepth) * kBlock + l] : 0.0;
+                    zz[u] = (RN && !rn_z0) ? ringz[((kbase + u) % kDepth) * kBlock + l] : 0.0;
                 }
                 if (rowc && c >= 2) {                       // the staging buffer of chunk c - 2: stored by all four O waves
                     uint32_t sp2 = 0;
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__((ROLES + NPH) * kBlock) void k_discrete_rollout_qui
                 }
             } else {
                 for (int k = kbase; k < K; k++)
-                    emitO(ring[(k % kDepth) * kBlock + l], RN ? ringz[(k % kDepth) * kBlock + l] : 0.0, (uint32_t)k);
+                    emitO(ring[(k % kDepth) * kBlock + l], (RN && !rn_z0) ? ringz[(k % kDepth) * kBlock + l] : 0.0, (uint32_t)k);
             }
             if ((l & 63) == 0)
                 __hip_atomic_store(&s_cons[w], upto, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1169,7 +1169,9 @@ bool launch_discrete_quiet_nu(const DiscreteArgs &a, int K, const int32_t *actio
     if (pn) lds += (size_t)a.S * S8 * 8;
     if (lds > 60 * 1024) return false;
     const size_t depth = rn ? 16 : kQDepth;
-    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
+    // (sigma 0 on numpy streams: the records carry no normal -- 32 KiB less, two workgroups per CU)
+    const bool rz0 = rn && !a.philox && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);
+    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * ((rn && !rz0) ? 16 : 8);
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !(a.opts & MDPP_OPT_NO_TRIO);
     // XR (kernel header): reward noise alone -- a third wave evaluates the env stream by position (+ 52 KiB of static LDS)
@@ -1227,7 +1229,7 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
         const size_t stride = pe_T0 + S8 * 8 + 8;             // (the kernel's carve of a lane's slot)
         const size_t depth = rn ? 16 : kQDepth;
         const bool z0 = rn && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);
-        const size_t l = ((stride * kBlock + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8) + ((rn && !z0) ? (size_t)kXR * kBlock * 8 : 0);
+        const size_t l = ((stride * kBlock + 15) & ~(size_t)15) + depth * kBlock * ((rn && !z0) ? 16 : 8) + ((rn && !z0) ? (size_t)kXR * kBlock * 8 : 0);
         if (l + (rn ? 32u : 20u) * 1024u > 160u * 1024u) return false;     // (+ the instantiation's static LDS: X's meta ring, ziggurat tables, counters)
         const bool sf = a.L == 1 && a.autoreset == MDPP_AUTORESET_SAME_STEP && a.max_steps == 0 && a.every_n == 1 &&
                         !(a.opts & MDPP_OPT_NO_QUIET_SF);
@@ -1262,7 +1264,8 @@ bool launch_discrete_quiet(const DiscreteArgs &a, int K, const int32_t *actions,
     // two / three waves per SIMD (E / O / H roles) when the blocks are full and the rollout is long
     // enough to fill the ring
     const size_t depth = rn ? 16 : kQDepth;
-    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * (rn ? 16 : 8);
+    const bool rz0 = rn && !a.philox && a.r_noise == 0.0 && !(a.opts & MDPP_OPT_NO_SIGMA0);      // (as above)
+    const size_t lds_duo = ((lds + 15) & ~(size_t)15) + depth * kBlock * ((rn && !rz0) ? 16 : 8);
     const bool duo = (a.N % kBlock) == 0 && K >= 32 && lds_duo <= 120 * 1024 && !(a.opts & MDPP_OPT_NO_DUO);
     const bool trio = duo && a.autoreset && !rn && !ph && !(a.opts & MDPP_OPT_NO_TRIO);
     // XR (kernel header): reward noise alone on numpy streams -- a third wave evaluates the env stream by position (+ 52 KiB of
