@@ -1,2 +1,3 @@
 #!/bin/bash
-for w in d_s50_delay4 d_s24_rdist; do python3 tools/ablate.py run mdpp_discrete_quiet.hip $w numpy o0 o6 o0 o6 2>&1 | grep -v "^$" | tail -4; done
+bash tools/prof_r06.sh 2>&1 | tail -30
+bash tools/gpu_suite.sh 2>&1 | tail -4
