@@ -457,8 +457,76 @@ def _fuzz_wide(n, seed):
     return out
 
 
+def _fuzz_more(n, seed):
+    """A third seeded family, the corners the two above leave out: unbounded state / action boxes (the reset then draws normals,
+    rl_toy_env.py:2286), order 4, every-n / delay / terminal reward on continuous envs, pictures WITH an irrelevant sub-space, large
+    discrete tables (S up to 255, S^L up to 32 768 keys, sequence_length up to 7), grids up to 30 x 40 cells."""
+    r = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        fam = str(r.choice(["c_unb", "c_order4", "c_evn", "d_image_irr", "d_big", "d_big", "grid_big"]))
+        if fam in ("c_unb", "c_order4", "c_evn"):
+            D = int(r.choice([2, 3, 4, 6]))
+            cfg = dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=D, action_space_dim=D,
+                       transition_dynamics_order=int(r.choice([1, 2])), inertia=float(r.choice([1.0, 0.5, 4.0])), time_unit=float(r.choice([1.0, 0.25, 0.01])),
+                       state_space_max=float(r.choice([3, 10])), action_space_max=float(r.choice([1, 0.5, 2])), delay=int(r.choice([0, 1, 4])),
+                       reward_function="move_to_a_point", target_point=[float(x) for x in np.round(r.uniform(-1, 1, D), 2)],
+                       target_radius=float(r.choice([0.2, 1.0])), make_denser=bool(r.random() < 0.5), seed=int(r.integers(1000)))
+            if fam == "c_unb":
+                if r.random() < 0.7:
+                    cfg.pop("state_space_max")
+                if r.random() < 0.5:
+                    cfg.pop("action_space_max")
+            elif fam == "c_order4":
+                cfg["transition_dynamics_order"] = int(r.choice([3, 4]))
+            else:
+                cfg.update(reward_every_n_steps=int(r.choice([2, 3])), term_state_reward=float(r.choice([-1.0, 2.0])),
+                           reward_scale=float(r.choice([1.0, -0.5])), reward_shift=float(r.choice([0.0, 1.0])),
+                           terminal_states=[[float(x) for x in np.round(r.uniform(-2, 2, D), 1)]], term_state_edge=1.0)
+            if r.random() < 0.5:
+                cfg["transition_noise"] = float(r.choice([0.0, 0.02]))
+            if r.random() < 0.5:
+                cfg["reward_noise"] = float(r.choice([0.0, 0.5]))
+        elif fam == "d_image_irr":
+            S, S2 = int(r.choice([4, 8])), int(r.choice([3, 6, 11]))
+            W = int(r.choice([32, 64, 84]))
+            tr = [t for t in ("shift", "scale", "flip", "rotate") if r.random() < 0.5]
+            cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[S, S2], action_space_size=[S, S2],
+                       irrelevant_features=True, delay=int(r.choice([0, 2])), sequence_length=int(r.choice([1, 2])), seed=int(r.integers(1000)),
+                       image_representations=True, image_width=W, image_height=W, image_transforms=",".join(tr) if tr else "none",
+                       image_sh_quant=int(r.choice([1, 3, 4])), image_ro_quant=int(r.choice([1, 7])))
+            if "scale" in tr:
+                cfg["image_scale_range"] = (0.5, 1.5)
+        elif fam == "d_big":
+            S, L = [(100, 1), (200, 1), (255, 1), (30, 3), (8, 5), (4, 7), (16, 3), (60, 2)][int(r.integers(8))]
+            cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=S, action_space_size=S, sequence_length=L,
+                       delay=int(r.choice([0, 1, 7])), reward_density=float(r.choice([0.05, 0.25])), terminal_state_density=float(r.choice([0.05, 0.25])),
+                       make_denser=bool(r.random() < 0.2), seed=int(r.integers(1000)))
+            if r.random() < 0.5:
+                cfg["reward_noise"] = float(r.choice([0.0, 0.2]))
+            if r.random() < 0.3:
+                cfg["transition_noise"] = float(r.choice([0.0, 0.05]))
+            if r.random() < 0.3:
+                cfg["reward_dist"] = [0.01, 1]
+        else:
+            G = [int(r.integers(10, 31)), int(r.integers(10, 41))]
+            cfg = dict(state_space_type="grid", grid_shape=G, reward_function="move_to_a_point", make_denser=bool(r.random() < 0.5),
+                       target_point=[int(r.integers(0, G[0])), int(r.integers(0, G[1]))], seed=int(r.integers(1000)),
+                       terminal_states=[[int(r.integers(0, G[0])), int(r.integers(0, G[1]))] for _ in range(int(r.integers(0, 4)))])
+            if r.random() < 0.5:
+                cfg["transition_noise"] = float(r.choice([0.0, 0.3]))
+            if r.random() < 0.5:
+                cfg["reward_noise"] = float(r.choice([0.0, 0.2]))
+            if r.random() < 0.5:
+                cfg.update(image_representations=True, image_width=100, image_height=100)
+        mode = str(r.choice(["same_step", "same_step", "same_step", "disabled", "next_step", "timelimit"]))
+        out.append((fam, cfg, mode, str(r.choice(["numpy", "numpy", "philox"])), bool(r.random() < 0.25)))
+    return out
+
+
 # (MDPP_FUZZ_WIDE_SEEDS=1,2,3 in the environment: an exploration run over other seeds -- tools/fuzz_wide.sh)
-FUZZ_WIDE = sum((_fuzz_wide(160, int(x)) for x in os.environ.get("MDPP_FUZZ_WIDE_SEEDS", "606").split(",")), [])
+FUZZ_WIDE = sum((_fuzz_wide(160, int(x)) for x in os.environ.get("MDPP_FUZZ_WIDE_SEEDS", "606").split(",")), []) + \
+    sum((_fuzz_more(64, int(x)) for x in os.environ.get("MDPP_FUZZ_MORE_SEEDS", "17").split(",")), [])
 
 
 @pytest.mark.timeout(180)
@@ -517,7 +585,7 @@ def test_random_widened_configurations_specialised_equals_general(k):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("k", [k for k in range(len(FUZZ_WIDE)) if FUZZ_WIDE[k][0] in ("d_irr", "d_diam", "d_rep", "d_custom", "c_wide", "c_line")
+@pytest.mark.parametrize("k", [k for k in range(len(FUZZ_WIDE)) if FUZZ_WIDE[k][0] in ("d_irr", "d_diam", "d_rep", "d_custom", "c_wide", "c_line", "c_unb", "c_order4", "c_evn", "d_big")
                                and FUZZ_WIDE[k][2] != "next_step" and FUZZ_WIDE[k][3] == "numpy"])
 def test_random_widened_configurations_default_dispatch_vs_oracle(k):
     """The widened random configurations without pictures, on numpy streams, against the ORACLE on the default dispatch: 512 envs
@@ -674,7 +742,7 @@ def test_sweep_config_at_scale_default_dispatch_vs_oracle(name):
 
 
 _PICTURE_CASES = [("sweep", n) for n in SWEEP if gu.CASES[n]["config"].get("image_representations")] + \
-                 [("fuzz", k) for k in range(len(FUZZ_WIDE)) if FUZZ_WIDE[k][0] == "d_image"]
+                 [("fuzz", k) for k in range(len(FUZZ_WIDE)) if FUZZ_WIDE[k][0] == "d_image"]      # (d_image_irr: test_gpu_parity.py's i_irr cases)
 
 
 @pytest.mark.timeout(300)

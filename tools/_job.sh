@@ -1,3 +1,3 @@
 #!/bin/bash
-bash tools/prof_r06.sh 2>&1 | tail -30
-bash tools/gpu_suite.sh 2>&1 | tail -4
+export MDPP_FUZZ_MORE_SEEDS=1,2,3,4,5,6,7,8,9,10,11,12
+bash tools/fuzz_wide.sh "606" "" random
