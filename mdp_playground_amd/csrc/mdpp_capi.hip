@@ -56,7 +56,7 @@ static void free_all(mdpp_env *h) {
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
                     h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_line_ws, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off,
-                    h->d_img_near, h->d_s1_blob};
+                    h->d_img_near, h->d_s1_blob, h->d_imgc_boxes};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -117,6 +117,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     h->d_s1_blob = nullptr;
     memset(&h->s1args, 0, sizeof(h->s1args));
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
+    h->d_imgc_boxes = nullptr;
     // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
     // 7 740 us per 512 steps with batches of 16, 7 440 with 32; with the renderer's waves claiming their images, 7 250 / 6 830 /
     // 6 660 with 16 / 32 / 64: fewer kernel tails and hand-overs; a long rollout starts with batches of 8 and 16 because
@@ -286,9 +287,9 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         if (cfg->D < 1 || cfg->D > MDPP_MAX_DIM || cfg->order < 1 || cfg->order > MDPP_MAX_ORDER ||
             cfg->n_rel < 1 || cfg->n_rel > cfg->D || cfg->n_boxes < 0 ||
             // terminal hypercubes: [n_boxes][n_rel] packed into box_lo / box_hi -- as many as fit the arrays (64 at four
-            // relevant dimensions); handles with picture observations draw them from an 8-entry list (mdpp_imagec.hip)
-            (cfg->image ? cfg->n_boxes > MDPP_MAX_BOXES : cfg->n_boxes > (MDPP_MAX_BOXES * MDPP_MAX_DIM) / cfg->n_rel)) {   // (no int32 product to wrap)
-            g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes * n_rel <= 256 (n_boxes <= 8 with image observations)";
+            // relevant dimensions); handles with picture observations draw them from a device list (mdpp_imagec.hip; round 6: no cap of its own)
+            cfg->n_boxes > (MDPP_MAX_BOXES * MDPP_MAX_DIM) / cfg->n_rel) {   // (no int32 product to wrap)
+            g_create_err = "mdpp_create: continuous needs 1 <= D <= 32, 1 <= order <= 4, n_boxes * n_rel <= 256";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         const bool line = cfg->reward_function == MDPP_CREWARD_MOVE_ALONG_A_LINE;
@@ -376,6 +377,16 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         }
         if (cfg->image) {   // scratch of one batch of img_chunk env steps: the states the pictures are made from
             TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * D * sizeof(float)));     // two sets (pipeline)
+            {   // the rectangles the pictures draw: the first two relevant dimensions of every hypercube
+                std::vector<float> bx((size_t)(cfg->n_boxes > 0 ? cfg->n_boxes : 1) * 4, 0.0f);
+                for (int b = 0; b < cfg->n_boxes; b++)
+                    for (int d = 0; d < 2 && d < cfg->n_rel; d++) {
+                        bx[4 * b + d] = cfg->box_lo[b * cfg->n_rel + d];
+                        bx[4 * b + 2 + d] = cfg->box_hi[b * cfg->n_rel + d];
+                    }
+                TRY(alloc_zero(h, &h->d_imgc_boxes, bx.size() * sizeof(float)));
+                TRYHIP(hipMemcpy(h->d_imgc_boxes, bx.data(), bx.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * D * sizeof(float)));
         }
         a.sd = (float *)h->d_sd; a.cur = (float *)h->d_cur; a.meta = (uint2 *)h->d_meta;
@@ -393,15 +404,21 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         for (int d = 0; ok && d < cfg->grid_dims; d++) ok = cfg->grid_shape[d] >= 1 && cfg->grid_shape[d] <= 254;
         if (ok && cfg->image)
             ok = cfg->img_w >= 1 && cfg->img_h >= 1 && ((size_t)cfg->img_w * cfg->img_h) % 16 == 0 &&
-                 cfg->img_r0 >= 1 && cfg->img_r0 <= 15 && cfg->n_boxes >= 0 && cfg->n_boxes <= MDPP_MAX_BOXES;
+                 cfg->img_r0 >= 1 && cfg->img_r0 <= 15 && cfg->n_boxes >= 0 && cfg->n_boxes <= (MDPP_MAX_BOXES * MDPP_MAX_DIM) / 2;
         if (!ok) {
             g_create_err = "mdpp_create: grid needs 2 (or 4) dimensions of 1..254 cells and delay 0; with image "
-                           "observations also width * height divisible by 16, disc radius 1..15, <= 8 terminal cells";
+                           "observations also width * height divisible by 16, disc radius 1..15, <= 128 terminal cells";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         TRY(alloc_zero(h, &h->d_state, N * sizeof(uint4)));
         if (cfg->image) {   // scratch of one batch of img_chunk env steps: the cells the pictures are made from
             TRY(alloc_zero(h, &h->d_img_state_out, 2 * (size_t)h->img_chunk * N * cfg->grid_dims * 4));     // two sets (pipeline)
+            {   // the terminal cells the pictures draw (they ride in box_lo, two coordinates each)
+                std::vector<float> bx((size_t)(cfg->n_boxes > 0 ? cfg->n_boxes : 1) * 4, 0.0f);
+                for (int b = 0; b < cfg->n_boxes; b++) { bx[4 * b] = cfg->box_lo[2 * b]; bx[4 * b + 1] = cfg->box_lo[2 * b + 1]; }
+                TRY(alloc_zero(h, &h->d_imgc_boxes, bx.size() * sizeof(float)));
+                TRYHIP(hipMemcpy(h->d_imgc_boxes, bx.data(), bx.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * cfg->grid_dims * 4));
             TRY(alloc_zero(h, &h->d_img_tpl, (size_t)(cfg->grid_dims / 2) * cfg->img_w * cfg->img_h / 16 * 2));   // grid-line bits
         }

@@ -33,10 +33,10 @@ struct ImageCArgs {
     int32_t N, D, W, H, R, n_sub, n_boxes, autoreset;
     float smax;
     float target[2];
-    float box_lo[MDPP_MAX_BOXES * 2], box_hi[MDPP_MAX_BOXES * 2];   // first two relevant dimensions
+    const float *boxes;         // [n_boxes]{lo0, lo1, hi0, hi1}: the hypercubes' first two relevant dimensions (grid: {cell0, cell1, -, -})
     uint32_t disc_rows[32];     // bit dx of row dy: pixel (dx, dy) of the (2R+1)^2 disc raster
     // grid envs
-    int32_t G, shape[4], gtarget[2], term_cells[MDPP_MAX_BOXES * 2];
+    int32_t G, shape[4], gtarget[2];
     const uint16_t *lines;      // [n_sub W H / 16] grid-line bits of 16 consecutive pixels
 };
 
@@ -85,12 +85,14 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
     // terminal hypercubes (relevant picture only), inclusive pixel rectangles
     for (int b = 0; b < a.n_boxes; b++) {
         int x0, y0, x1, y1;
+        const float b0 = a.boxes[4 * b], b1 = a.boxes[4 * b + 1], b2 = a.boxes[4 * b + 2], b3 = a.boxes[4 * b + 3];     // (wave-uniform: scalar loads)
         if (GRID) {
-            x0 = ig_px(a.term_cells[2 * b], a.shape[0], a.W); y0 = ig_px(a.term_cells[2 * b + 1], a.shape[1], a.H);
-            x1 = ig_px(a.term_cells[2 * b] + 1.0, a.shape[0], a.W); y1 = ig_px(a.term_cells[2 * b + 1] + 1.0, a.shape[1], a.H);
+            const int c0 = (int)b0, c1 = (int)b1;
+            x0 = ig_px(c0, a.shape[0], a.W); y0 = ig_px(c1, a.shape[1], a.H);
+            x1 = ig_px(c0 + 1.0, a.shape[0], a.W); y1 = ig_px(c1 + 1.0, a.shape[1], a.H);
         } else {
-            x0 = ic_px(a.box_lo[2 * b], a.smax, a.W); y0 = ic_px(a.box_lo[2 * b + 1], a.smax, a.H);
-            x1 = ic_px(a.box_hi[2 * b], a.smax, a.W); y1 = ic_px(a.box_hi[2 * b + 1], a.smax, a.H);
+            x0 = ic_px(b0, a.smax, a.W); y0 = ic_px(b1, a.smax, a.H);
+            x1 = ic_px(b2, a.smax, a.W); y1 = ic_px(b3, a.smax, a.H);
         }
         x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, a.W - 1); y1 = min(y1, a.H - 1);
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
@@ -187,21 +189,16 @@ int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_
     memset(&a, 0, sizeof(a));
     a.N = c.num_envs; a.W = c.img_w; a.H = c.img_h; a.R = c.img_r0;
     a.n_boxes = c.n_boxes; a.autoreset = c.autoreset;
+    a.boxes = (const float *)h->d_imgc_boxes;
     if (grid) {
         a.G = c.grid_dims; a.D = c.grid_dims; a.n_sub = c.grid_dims / 2;
         for (int d = 0; d < c.grid_dims; d++) a.shape[d] = c.grid_shape[d];
         a.gtarget[0] = c.grid_target[0]; a.gtarget[1] = c.grid_target[1];
-        for (int b = 0; b < c.n_boxes * 2; b++) a.term_cells[b] = (int32_t)c.box_lo[b];   // terminal cells ride in box_lo
         a.lines = (const uint16_t *)h->d_img_tpl;
     } else {
         a.D = c.D; a.n_sub = c.D > 2 ? 2 : 1;
         a.smax = (float)c.state_space_max;
         a.target[0] = c.target[0]; a.target[1] = c.target[1];
-        for (int b = 0; b < c.n_boxes; b++)
-            for (int d = 0; d < 2; d++) {
-                a.box_lo[2 * b + d] = c.box_lo[b * c.n_rel + d];
-                a.box_hi[2 * b + d] = c.box_hi[b * c.n_rel + d];
-            }
     }
     for (int r = 0; r < 32; r++) a.disc_rows[r] = h->imgc_disc_rows[r];
     const long M = (long)K * a.N;

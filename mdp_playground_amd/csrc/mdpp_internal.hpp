@@ -296,6 +296,7 @@ struct mdpp_env {
     void *d_img_ctr;            // uint32 [2][2]: the fast renderer's work counters (scratch set x render launch)
     int32_t img_chunk;          // env steps per state-kernel + draw + render batch
     uint32_t imgc_disc_rows[32]; // continuous image observations: the disc raster, one bitmask per row
+    void *d_imgc_boxes;          // ... and the terminal hypercubes / cells it draws: [n_boxes]{lo0, lo1, hi0, hi1} float32 (grid: {c0, c1, 0, 0})
     bool img_ready, img_fast_ok, img_lines_ready;   // img_fast_ok: k_image_obs<true> applies (mdpp_image.hip)
     int32_t img_n_radii, img_n_cls_x, img_n_cls_y;
     int32_t img_colb;            // fast renderer: 64 (k_image_obs_fast) or 128 (k_image_obs_wide) bytes of an LDS row per wave

@@ -571,8 +571,8 @@ def build_grid(config) -> GridMDP:
         # grid_shape=...) (:800-811): RGB, grid lines, terminal cells drawn (though they never terminate)
         image = dict(width=config.get("image_width", 100), height=config.get("image_height", 100),
                      circle_radius=5)
-        if len(config.get("terminal_states") or []) > 8:
-            raise NotImplementedError("at most 8 terminal cells are drawn on the device")
+        if len(config.get("terminal_states") or []) > 128:
+            raise NotImplementedError("at most 128 terminal cells are drawn on the device")
     tn = config.get("transition_noise", None)
     if callable(tn):
         raise NotImplementedError("callable transition_noise is not supported: a Python function cannot be evaluated on the device, and no host path is shipped; pass a float")

@@ -287,10 +287,10 @@ class RLToyVectorEnv:
         cfg.target_radius, cfg.action_loss_weight = float(m.target_radius), float(m.action_loss_weight)
         nb = 0 if m.box_lo is None else len(m.box_lo)
         # (the reference has no limit, rl_toy_env.py:891-956; here the cubes ride in the handle's argument block, [nb][n_rel]
-        #  floats in arrays of MAX_BOXES * MAX_DIM: 64 cubes at four relevant dimensions; pictures draw from 8 entries)
-        if (nb > capi.MAX_BOXES) if m.image is not None else (nb * cfg.n_rel > capi.MAX_BOXES * capi.MAX_DIM):
+        #  floats in arrays of MAX_BOXES * MAX_DIM: 64 cubes at four relevant dimensions; pictures draw them from a device list)
+        if nb * cfg.n_rel > capi.MAX_BOXES * capi.MAX_DIM:
             raise NotImplementedError(f"at most {capi.MAX_BOXES * capi.MAX_DIM // max(cfg.n_rel, 1)} terminal hypercubes at "
-                                      f"{cfg.n_rel} relevant dimensions ({capi.MAX_BOXES} with image observations)")
+                                      f"{cfg.n_rel} relevant dimensions")
         cfg.n_boxes = nb
         for b in range(nb):
             for j in range(cfg.n_rel):

@@ -294,7 +294,24 @@ CASES = {
                     reward_function="move_to_a_point", image_representations=True,
                     image_width=64, image_height=48),
         seeds=[0, 1], T=40, reset="mixed"),
+    # (round 6: more drawn rectangles than the 8 the picture kernel's argument block used to hold: 14 cubes, overlapping ones too)
+    "ci_14_boxes": dict(
+        config=dict(state_space_type="continuous", state_space_dim=2, transition_dynamics_order=1,
+                    inertia=1.0, time_unit=1.0, state_space_max=8, action_space_max=1,
+                    make_denser=True, target_point=[0.5, -0.5], target_radius=0.4,
+                    terminal_states=[[-6.0, -6.0], [-6.0, 0.0], [-6.0, 6.0], [0.0, -6.0], [0.0, 6.0], [6.0, -6.0], [6.0, 0.0],
+                                     [6.0, 6.0], [-3.0, 3.0], [3.0, -3.0], [-3.0, -3.0], [3.0, 3.0], [3.5, 3.5], [-7.5, 7.5]],
+                    term_state_edge=1.5, term_state_reward=-1.0,
+                    reward_function="move_to_a_point", image_representations=True,
+                    image_width=84, image_height=84),
+        seeds=[0, 1, 2], T=48, reset="on_done"),
     # --- grid + ImageContinuous observations (grid lines, terminal cells drawn as rectangles) ----
+    "gi_12_cells": dict(
+        config=dict(state_space_type="grid", grid_shape=(9, 7), reward_function="move_to_a_point",
+                    make_denser=True, target_point=[4, 3],
+                    terminal_states=[[0, 0], [0, 6], [8, 0], [8, 6], [2, 2], [2, 4], [6, 2], [6, 4], [4, 0], [4, 6], [0, 3], [8, 3]],
+                    image_representations=True, image_width=72, image_height=56),
+        seeds=[0, 1], T=40, reset="on_done"),
     "gi_8x8": dict(
         config=dict(state_space_type="grid", grid_shape=(8, 8), reward_function="move_to_a_point",
                     make_denser=True, target_point=[5, 5], reward_scale=3.0,
