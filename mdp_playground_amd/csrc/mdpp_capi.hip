@@ -179,9 +179,9 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     }
     if (cfg->image && cfg->kind == MDPP_KIND_CONTINUOUS &&
         ((cfg->D != 2 && cfg->D != 4) || !isfinite(cfg->state_space_max) || cfg->img_w < 1 || cfg->img_h < 1 ||
-         ((size_t)cfg->img_w * cfg->img_h) % 16 != 0 || cfg->img_r0 < 1 || cfg->img_r0 > 15)) {
-        g_create_err = "mdpp_create: ImageContinuous observations need 2 or 4 bounded state dimensions, "
-                       "width * height divisible by 16 and a disc radius of 1..15";
+         cfg->img_r0 < 1 || cfg->img_r0 > 15)) {
+        g_create_err = "mdpp_create: ImageContinuous observations need 2 or 4 bounded state dimensions "
+                       "and a disc radius of 1..15";
         free_all(h); delete h; return MDPP_EUNSUPPORTED;
     }
     if (cfg->image) {      // image rollouts pipeline their batches over a side stream (step_common)
@@ -403,11 +403,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         bool ok = (cfg->grid_dims == 2 || cfg->grid_dims == 4) && cfg->delay == 0;
         for (int d = 0; ok && d < cfg->grid_dims; d++) ok = cfg->grid_shape[d] >= 1 && cfg->grid_shape[d] <= 254;
         if (ok && cfg->image)
-            ok = cfg->img_w >= 1 && cfg->img_h >= 1 && ((size_t)cfg->img_w * cfg->img_h) % 16 == 0 &&
+            ok = cfg->img_w >= 1 && cfg->img_h >= 1 &&
                  cfg->img_r0 >= 1 && cfg->img_r0 <= 15 && cfg->n_boxes >= 0 && cfg->n_boxes <= (MDPP_MAX_BOXES * MDPP_MAX_DIM) / 2;
         if (!ok) {
             g_create_err = "mdpp_create: grid needs 2 (or 4) dimensions of 1..254 cells and delay 0; with image "
-                           "observations also width * height divisible by 16, disc radius 1..15, <= 128 terminal cells";
+                           "observations also a disc radius of 1..15 and <= 128 terminal cells";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         TRY(alloc_zero(h, &h->d_state, N * sizeof(uint4)));
@@ -420,7 +420,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
                 TRYHIP(hipMemcpy(h->d_imgc_boxes, bx.data(), bx.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             TRY(alloc_zero(h, &h->d_img_state_final, 2 * (size_t)h->img_chunk * N * cfg->grid_dims * 4));
-            TRY(alloc_zero(h, &h->d_img_tpl, (size_t)(cfg->grid_dims / 2) * cfg->img_w * cfg->img_h / 16 * 2));   // grid-line bits
+            TRY(alloc_zero(h, &h->d_img_tpl, (((size_t)(cfg->grid_dims / 2) * cfg->img_w * cfg->img_h + 15) / 16) * 2));   // grid-line bits
         }
         GridArgs &a = h->gargs;
         memset(&a, 0, sizeof(a));
@@ -694,7 +694,7 @@ extern "C" int mdpp_upload_image_lines(mdpp_env *h, const uint8_t *lines) {
     if (h->cfg.kind != MDPP_KIND_GRID || !h->cfg.image)
         return fail(h, MDPP_EINVAL, "upload_image_lines: not a grid handle with image observations");
     const size_t npix = (size_t)(h->cfg.grid_dims / 2) * h->cfg.img_w * h->cfg.img_h;
-    std::vector<uint16_t> bits(npix / 16, 0);
+    std::vector<uint16_t> bits((npix + 15) / 16, 0);
     for (size_t p = 0; p < npix; p++)
         if (lines[p]) bits[p >> 4] |= (uint16_t)(1u << (p & 15));
     HIPCHK(h, hipSetDevice(h->device));

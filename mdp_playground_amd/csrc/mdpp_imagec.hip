@@ -37,7 +37,7 @@ struct ImageCArgs {
     uint32_t disc_rows[32];     // bit dx of row dy: pixel (dx, dy) of the (2R+1)^2 disc raster
     // grid envs
     int32_t G, shape[4], gtarget[2];
-    const uint16_t *lines;      // [n_sub W H / 16] grid-line bits of 16 consecutive pixels
+    const uint16_t *lines;      // [ceil(n_sub W H / 16)] grid-line bits of 16 consecutive pixels
 };
 
 __device__ __forceinline__ int ic_px(float v, float smax, int size) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
     if (j >= M) return;
     if (mask && !mask[j % a.N]) return;
     if (term && !(term[j] | trunc[j])) return;
-    const int npix = a.n_sub * a.W * a.H, ngroup = npix >> 4;      // W * H % 16 == 0 (host-checked)
+    const int npix = a.n_sub * a.W * a.H, ngroup = (npix + 15) >> 4;   // (a ragged last group: the byte-store form below)
     const int ngpad = (ngroup + 3) & ~3;                                 // (the slab behind the codes stays 16-byte aligned)
     uint32_t *codes = lds_codes + (size_t)wave * (ngpad + 768);          // (+ the wave's 3 KiB store slab)
     uint32_t *slab = codes + ngpad;
@@ -125,6 +125,16 @@ __global__ __launch_bounds__(kBlock) void k_imagec_obs(ImageCArgs a, long M, con
 
     // phase 2: 16 pixels -> 48 bytes per lane
     const size_t isz = (size_t)npix * 3;
+    if (npix & 15) {                        // pictures whose pixel count is not a multiple of 16 (50 x 50 ...): pictures then start at
+        uint8_t *o = img + (size_t)j * isz; // any byte address -- one pixel per lane, three byte stores (the reference has no such rule;
+        for (int p = lane; p < npix; p += 64) {     // round 6: accepted, at the price of this form's store rate)
+            const uint32_t code = (codes[p >> 4] >> (2 * (p & 15))) & 3u;
+            const uint32_t bg = (GRID && ((a.lines[p >> 4] >> (p & 15)) & 1u)) ? 0xFFFFFFu : 0xD0D0D0u;
+            const uint32_t px = code == 0 ? bg : code == 1 ? 0u : code == 2 ? 0x00FF00u : 0xFF0000u;
+            o[3 * (size_t)p] = (uint8_t)px; o[3 * (size_t)p + 1] = (uint8_t)(px >> 8); o[3 * (size_t)p + 2] = (uint8_t)(px >> 16);
+        }
+        return;
+    }
     const auto r_out = __builtin_amdgcn_make_buffer_rsrc((void *)(img + (size_t)j * isz), 0, (int)isz, 0x00020000);
 #ifdef MDPP_IMGC_DIRECT
     for (int g = lane; g < ngroup; g += 64) {
@@ -203,7 +213,7 @@ int launch_imagec_obs(mdpp_env *h, int K, const void *states, const void *final_
     for (int r = 0; r < 32; r++) a.disc_rows[r] = h->imgc_disc_rows[r];
     const long M = (long)K * a.N;
     const int per_block = kBlock / 64;
-    const size_t lds = (size_t)per_block * ((((size_t)a.n_sub * a.W * a.H / 16 + 3) & ~(size_t)3) + 768) * 4;
+    const size_t lds = (size_t)per_block * (((((size_t)a.n_sub * a.W * a.H + 15) / 16 + 3) & ~(size_t)3) + 768) * 4;
     if (lds > 64 * 1024) { h->err = "k_imagec_obs: image too large for the LDS colour map"; return MDPP_EUNSUPPORTED; }
     const dim3 grd((unsigned)((M + per_block - 1) / per_block));
 #define MDPP_IC_LAUNCH(GR, st, te, tr, im) hipLaunchKernelGGL((k_imagec_obs<GR>), grd, dim3(kBlock), lds, s, a, M, st, te, tr, mask, im)

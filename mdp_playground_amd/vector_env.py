@@ -250,9 +250,6 @@ class RLToyVectorEnv:
             # ImageContinuous with grid lines (:800-811): uint8 [n_sub * W][H][3]
             from . import image_obs
             im = m.image
-            if (im["width"] * im["height"]) % 16 != 0:
-                raise NotImplementedError("ImageContinuous on the device: image_width * image_height must be "
-                                          "divisible by 16")
             self._image = dict(im, disc=image_obs.disc_template(im["circle_radius"]), n_sub=G // 2,
                                lines=image_obs.grid_line_mask(im["width"], im["height"], list(m.grid_shape)))
             cfg.image, cfg.img_w, cfg.img_h, cfg.img_r0 = 1, im["width"], im["height"], im["circle_radius"]
@@ -305,9 +302,6 @@ class RLToyVectorEnv:
             # ImageContinuous observations (:770-778): uint8 [n_sub * W][H][3]; no random transforms
             from . import image_obs
             im = m.image
-            if (im["width"] * im["height"]) % 16 != 0:
-                raise NotImplementedError("ImageContinuous on the device: image_width * image_height must be "
-                                          "divisible by 16")
             if not np.isfinite(m.state_space_max):
                 raise AssertionError("ImageContinuous needs a bounded feature space")   # image_continuous.py:62-63
             self._image = dict(im, disc=image_obs.disc_template(im["circle_radius"]), n_sub=2 if m.D > 2 else 1)

@@ -305,7 +305,20 @@ CASES = {
                     reward_function="move_to_a_point", image_representations=True,
                     image_width=84, image_height=84),
         seeds=[0, 1, 2], T=48, reset="on_done"),
+    # (round 6: a pixel count that is not a multiple of 16 -- the byte-store form of k_imagec_obs; 4 state dimensions: two pictures)
+    "ci_50x50_4d": dict(
+        config=dict(state_space_type="continuous", state_space_dim=4, transition_dynamics_order=1,
+                    inertia=1.0, time_unit=1.0, state_space_max=4, action_space_max=1, relevant_indices=[0, 1],
+                    make_denser=False, target_point=[1.0, 1.0], target_radius=0.8, terminal_states=[[-2.0, -2.0]], term_state_edge=1.0,
+                    reward_function="move_to_a_point", image_representations=True,
+                    image_width=50, image_height=50),
+        seeds=[0, 1], T=40, reset="on_done"),
     # --- grid + ImageContinuous observations (grid lines, terminal cells drawn as rectangles) ----
+    "gi_45x35": dict(
+        config=dict(state_space_type="grid", grid_shape=(5, 7), reward_function="move_to_a_point",
+                    make_denser=False, target_point=[3, 4], terminal_states=[[1, 1]], transition_noise=0.2,
+                    image_representations=True, image_width=45, image_height=35),
+        seeds=[0, 1], T=40, reset="on_done"),
     "gi_12_cells": dict(
         config=dict(state_space_type="grid", grid_shape=(9, 7), reward_function="move_to_a_point",
                     make_denser=True, target_point=[4, 3],
