@@ -192,6 +192,8 @@ const char *mdpp_last_error(const mdpp_env *h);   /* h may be NULL: last create(
 
 /* Discrete tables (host pointers; T = cfg.num_tables):
  *   P        uint8 [T][S][A]      transition matrix                       rl_toy_env.py:1050-1151
+ *            (cfg.S > 255, up to 65 535 -- round 6: uint16 [T][S][A] behind the same pointer; such handles run the general
+ *            kernel alone, without image observations or an irrelevant sub-space: mdpp_discrete_wide.hip)
  *   rtable   double[T][S^L] (MDPP_REWARD_SEQUENCES) or double[T][S][A] (MDPP_REWARD_STATE_ACTION:
  *            use_custom_mdp with a reward matrix, R(s, a) of the transition s, a -> s', :1259-1267)
  *            or, when cfg.unit_rewards, NULL with

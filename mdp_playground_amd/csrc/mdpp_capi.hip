@@ -56,7 +56,7 @@ static void free_all(mdpp_env *h) {
                     h->d_P1, h->d_init_cdf1, h->d_noise_cdf1, h->d_irr_state,
                     h->d_img_tpl, h->d_img_tplp, h->d_img_clsx, h->d_img_clsy, h->d_img_rot, h->d_img_state_out,
                     h->d_img_state_final, h->d_img_rec, h->d_img_ctr, h->d_line_hist, h->d_line_ws, h->d_ring64, h->d_est_cur, h->d_est_last, h->d_tick_off,
-                    h->d_img_near, h->d_s1_blob, h->d_imgc_boxes};
+                    h->d_img_near, h->d_s1_blob, h->d_imgc_boxes, h->d_hist_hi};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < MDPP_NUM_STREAMS; s++) {
         if (h->d_rng_s[s]) (void)hipFree(h->d_rng_s[s]);
@@ -118,6 +118,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     memset(&h->s1args, 0, sizeof(h->s1args));
     h->d_img_state_out = h->d_img_state_final = h->d_img_rec = h->d_img_ctr = nullptr;
     h->d_imgc_boxes = nullptr;
+    h->d_hist_hi = nullptr;
     // env steps per batch of an image rollout, while the records of two batches stay below about 1 GiB: 64 (cfg4, round 3:
     // 7 740 us per 512 steps with batches of 16, 7 440 with 32; with the renderer's waves claiming their images, 7 250 / 6 830 /
     // 6 660 with 16 / 32 / 64: fewer kernel tails and hand-overs; a long rollout starts with batches of 8 and 16 because
@@ -200,10 +201,13 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             TRYHIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     if (cfg->kind == MDPP_KIND_DISCRETE) {
-        if (cfg->S < 2 || cfg->S > 255 || cfg->A < 1 || cfg->L < 1 || cfg->L > 7) {
-            g_create_err = "mdpp_create: discrete needs 2 <= S <= 255, A >= 1, 1 <= L <= 7";
+        // (S > 255 -- round 6: 16-bit table entries and history fields, served by the general kernel alone, mdpp_discrete_wide.hip;
+        //  without picture observations and without an irrelevant sub-space)
+        if (cfg->S < 2 || cfg->S > 65535 || cfg->A < 1 || cfg->L < 1 || cfg->L > 7 || (cfg->S > 255 && (cfg->image || cfg->irrelevant))) {
+            g_create_err = "mdpp_create: discrete needs 2 <= S <= 65535 (<= 255 with image observations or an irrelevant sub-space), A >= 1, 1 <= L <= 7";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
+        const bool wide = cfg->S > 255;
         if (cfg->num_tables != 1 && cfg->num_tables != cfg->num_envs) {
             g_create_err = "mdpp_create: num_tables must be 1 or num_envs"; free_all(h); delete h; return MDPP_EINVAL;
         }
@@ -231,7 +235,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
                 TRY(alloc_zero(h, &h->d_noise_cdf1, (size_t)cfg->S_irr * cfg->S_irr * sizeof(double)));
             TRY(alloc_zero(h, &h->d_irr_state, N * sizeof(uint32_t)));
         }
-        TRY(alloc_zero(h, &h->d_P, T * cfg->S * cfg->A));
+        TRY(alloc_zero(h, &h->d_P, T * cfg->S * cfg->A * (wide ? 2 : 1)));
+        if (wide) {
+            TRY(alloc_zero(h, &h->d_hist_hi, N * sizeof(uint64_t)));
+            TRYHIP(hipMemset(h->d_hist_hi, 0xFF, N * sizeof(uint64_t)));
+        }
         TRY(alloc_zero(h, &h->d_is_term, T * cfg->S));
         TRY(alloc_zero(h, &h->d_init_cdf, T * cfg->S * sizeof(double)));
         if (cfg->unit_rewards) TRY(alloc_zero(h, &h->d_rbits, T * h->rbits_stride));
@@ -273,7 +281,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
         a.noise_in_lds = cfg->has_transition_noise && noise_bytes <= 32u * 1024u;
         a.lds_noise = off; if (a.noise_in_lds) off = align16(off + noise_bytes);
         a.lds_bytes = off;
-        a.state = (uint4 *)h->d_state; a.ring_keys = (uint32_t *)h->d_ring;
+        a.state = (uint4 *)h->d_state; a.ring_keys = (uint32_t *)h->d_ring; a.hist_hi = (uint64_t *)h->d_hist_hi;
         a.env_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_ENV]; a.env_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_ENV];
         a.sp_s = (ulonglong2 *)h->d_rng_s[MDPP_STREAM_SPACE]; a.sp_inc = (ulonglong2 *)h->d_rng_inc[MDPP_STREAM_SPACE];
         a.status = (uint32_t *)h->d_status;
@@ -466,10 +474,11 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
     if (h->cfg.has_transition_noise && !noise_cdf) return fail(h, MDPP_EINVAL, "upload_discrete_tables: noise_cdf missing");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t T = (size_t)h->cfg.num_tables, S = (size_t)h->cfg.S, A = (size_t)h->cfg.A;
+    const bool wide = S > 255;          // (P is then uint16[T][S][A] behind the same pointer)
     // every P entry must be a valid state id: the kernels index tables with it unchecked
     for (size_t k = 0; k < T * S * A; k++)
-        if (P[k] >= S) return fail(h, MDPP_EINVAL, "upload_discrete_tables: P entry out of range");
-    HIPCHK(h, hipMemcpy(h->d_P, P, T * S * A, hipMemcpyHostToDevice));
+        if ((wide ? (size_t)((const uint16_t *)P)[k] : (size_t)P[k]) >= S) return fail(h, MDPP_EINVAL, "upload_discrete_tables: P entry out of range");
+    HIPCHK(h, hipMemcpy(h->d_P, P, T * S * A * (wide ? 2 : 1), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_is_term, is_term, T * S, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_init_cdf, init_cdf, T * S * sizeof(double), hipMemcpyHostToDevice));
     if (h->cfg.unit_rewards)
@@ -478,6 +487,14 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         HIPCHK(h, hipMemcpy(h->d_rtable, rtable, T * (size_t)h->nkeys * sizeof(double), hipMemcpyHostToDevice));
     if (h->cfg.has_transition_noise)
         HIPCHK(h, hipMemcpy(h->d_noise_cdf, noise_cdf, S * S * sizeof(double), hipMemcpyHostToDevice));
+    if (wide) {     // no specialised kernel serves such a handle (launch_discrete_step: mdpp_discrete_wide.hip)
+        DiscreteArgs &a = h->dargs;
+        a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = a.shape_ok_noise = a.shape_ok_noise_np = 0u;
+        a.minv_lo = (uint64_t)pcg_mult_inverse(); a.minv_hi = (uint64_t)(pcg_mult_inverse() >> 64);
+        memset(&h->s1args, 0, sizeof(h->s1args));
+        h->tables_ready = true;
+        return MDPP_OK;
+    }
     // ---- derived constants of the fused fast path (see DiscreteArgs) ----
     {
         DiscreteArgs &a = h->dargs;
@@ -1305,9 +1322,18 @@ extern "C" int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist, int32_t *step
         rt.resize(T * h->nkeys);
         HIPCHK(h, hipMemcpy(rt.data(), h->d_rtable, rt.size() * 8, hipMemcpyDeviceToHost));
     }
+    const bool wide = h->cfg.S > 255;   // (16-bit history fields, the older four in d_hist_hi)
+    std::vector<uint64_t> hhi;
+    if (wide) { hhi.resize(N); HIPCHK(h, hipMemcpy(hhi.data(), h->d_hist_hi, N * 8, hipMemcpyDeviceToHost)); }
     for (size_t i = 0; i < N; i++) {
         uint64_t hb = ((uint64_t)st[4 * i + 1] << 32) | st[4 * i];
-        if (hist)
+        if (hist && wide)
+            for (int j = 0; j <= L; j++) {
+                const int f = L - j;
+                const uint32_t b = (uint32_t)((f < 4 ? hb >> (16 * f) : hhi[i] >> (16 * (f - 4))) & 0xFFFFu);
+                hist[i * (L + 1) + j] = (b == 0xFFFFu) ? -1 : (int32_t)b;
+            }
+        else if (hist)
             for (int j = 0; j <= L; j++) { // hist[0] oldest ... hist[L] newest
                 uint32_t b = (uint32_t)((hb >> (8 * (L - j))) & 0xFF);
                 hist[i * (L + 1) + j] = (b == 0xFF) ? -1 : (int32_t)b;
@@ -1371,12 +1397,16 @@ extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const i
         }
         HIPCHK(h, hipMemcpy(h->d_ring, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
     }
+    const bool wide = h->cfg.S > 255;
+    std::vector<uint64_t> hhi(wide ? N : 0);
     for (size_t i = 0; i < N; i++) {
-        uint64_t hb = ~0ULL;
+        uint64_t hb = ~0ULL, hh = ~0ULL;
         for (int j = 0; j <= L; j++) {
             int32_t v = hist[i * (L + 1) + j];
-            hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v);
+            if (wide) { hh = (hh << 16) | (hb >> 48); hb = (hb << 16) | (uint64_t)(v < 0 ? 0xFFFF : v); }
+            else hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v);
         }
+        if (wide) hhi[i] = hh;
         st[4 * i] = (uint32_t)hb;
         if (!h->dargs.fast_ok) st[4 * i + 1] = (uint32_t)(hb >> 32); // fast path: word 1 is the draw queue
         st[4 * i + 2] = (uint32_t)steps[i];
@@ -1387,6 +1417,7 @@ extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const i
         }
     }
     HIPCHK(h, hipMemcpy(h->d_state, st.data(), N * 16, hipMemcpyHostToDevice));
+    if (wide) HIPCHK(h, hipMemcpy(h->d_hist_hi, hhi.data(), N * 8, hipMemcpyHostToDevice));
     return MDPP_OK;
 }
 

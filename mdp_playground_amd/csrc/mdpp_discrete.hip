@@ -18,6 +18,15 @@
 #include "mdpp_internal.hpp"
 #include "mdpp_rng.hpp"
 
+#ifdef MDPP_D_WIDE        /* (second compilation of this file, mdpp_discrete_wide.hip: its own symbol names) */
+#define k_discrete_step k_discrete_step_wide
+#define k_discrete_reset k_discrete_reset_wide
+#define d_reset_draw d_reset_draw_wide
+#define DTables DTablesWide
+#define DHist DHistWide
+#define launch_step_t launch_step_wide_t
+#endif
+
 namespace mdpp {
 
 struct DTables {
@@ -32,9 +41,34 @@ __device__ __forceinline__ uint32_t d_reset_draw(const DiscreteArgs &a, const DT
     return (uint32_t)searchsorted_right(t.init_cdf, a.S, u);
 }
 
-__device__ __forceinline__ uint64_t d_fresh_hist(uint32_t s0) {
-    return 0xFFFFFFFFFFFFFF00ULL | (uint64_t)s0;
-}
+// The last L + 1 states, newest first.  S <= 255: eight byte fields of one 64-bit word, 0xFF = NaN (this file as it is compiled);
+// S up to 65 535 (MDPP_D_WIDE, mdpp_discrete_wide.hip compiles this file a second time under other names): eight 16-bit fields,
+// 0xFFFF = NaN, the older four in DiscreteArgs::hist_hi; P entries are 16-bit there.
+#ifdef MDPP_D_WIDE
+typedef uint16_t DPEntry;
+constexpr uint32_t kDNaN = 0xFFFFu;
+struct DHist {
+    uint64_t lo, hi;
+    __device__ __forceinline__ static DHist fresh(uint32_t s0) { return DHist{0xFFFFFFFFFFFF0000ULL | (uint64_t)s0, ~0ULL}; }
+    __device__ __forceinline__ static DHist load(const DiscreteArgs &a, long i, const uint4 &st) { return DHist{((uint64_t)st.y << 32) | st.x, a.hist_hi[i]}; }
+    __device__ __forceinline__ void store_hi(const DiscreteArgs &a, long i) const { a.hist_hi[i] = hi; }
+    __device__ __forceinline__ uint32_t cur() const { return (uint32_t)lo & 0xFFFFu; }
+    __device__ __forceinline__ void push(uint32_t n) { hi = (hi << 16) | (lo >> 48); lo = (lo << 16) | n; }
+    __device__ __forceinline__ uint32_t at(int j) const { return (uint32_t)((j < 4 ? lo >> (16 * j) : hi >> (16 * (j - 4))) & 0xFFFFu); }
+};
+#else
+typedef uint8_t DPEntry;
+constexpr uint32_t kDNaN = 0xFFu;
+struct DHist {
+    uint64_t lo;
+    __device__ __forceinline__ static DHist fresh(uint32_t s0) { return DHist{0xFFFFFFFFFFFFFF00ULL | (uint64_t)s0}; }
+    __device__ __forceinline__ static DHist load(const DiscreteArgs &, long, const uint4 &st) { return DHist{((uint64_t)st.y << 32) | st.x}; }
+    __device__ __forceinline__ void store_hi(const DiscreteArgs &, long) const {}
+    __device__ __forceinline__ uint32_t cur() const { return (uint32_t)lo & 0xFFu; }
+    __device__ __forceinline__ void push(uint32_t n) { lo = (lo << 8) | n; }
+    __device__ __forceinline__ uint32_t at(int j) const { return (uint32_t)((lo >> (8 * j)) & 0xFFu); }
+};
+#endif
 
 constexpr int kPrefetch = 8; // actions fetched this many steps ahead of their use
 
@@ -120,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     if (i >= a.N) return;
     if (!LDSTAB) {
         const size_t ti = a.shared_tables ? 0 : (size_t)i;
-        t.P = a.P + ti * a.S * a.A;
+        t.P = a.P + ti * a.S * a.A * sizeof(DPEntry);
         t.is_term = a.is_term + ti * a.S;
         t.init_cdf = a.init_cdf + ti * a.S;
         t.rbits = a.rbits + ti * a.rbits_stride;
@@ -131,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
     const long N = a.N;
 
     uint4 st = a.state[i];
-    uint64_t hist = ((uint64_t)st.y << 32) | st.x;
+    DHist hist = DHist::load(a, i, st);
     uint32_t steps = st.z, ringbits = st.w, status = 0;
     // next-step autoreset (gymnasium >= 1.0 vector envs): an env whose episode ended is reset by the NEXT
     // step() call, which ignores its action and returns the first observation with reward 0 and no flags.
@@ -216,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                     s0 = d_reset_draw(a, t, env_pcg);
                     if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(env_pcg));
                 }
-                hist = d_fresh_hist(s0);
+                hist = DHist::fresh(s0);
                 if (a.est.cur) est_roll(a.est, N, i, steps);                        // reset(): :2231-2247, :2360-2369
                 steps = 0; phase = 0; ringbits = 0;
                 if (!UNIT)
@@ -233,8 +267,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
             }
             if (action < 0 && action >= -A) action += A;       // numpy negative indexing
             if (action < 0 || action >= A) { status |= MDPP_STATUS_BAD_ACTION; action = 0; }
-            const uint32_t cur = (uint32_t)hist & 0xFFu;
-            uint32_t nxt = t.P[cur * A + action];                                   // D1
+            const uint32_t cur = hist.cur();
+            uint32_t nxt = ((const DPEntry *)t.P)[cur * A + action];                // D1
             if (NOISE && a.has_p_noise) {                                           // D2
                 // (Philox streams: one word of the tick decides "noisy" and which other state, mdpp_rng.hpp philox_pnoise_*;
                 //  numpy streams: the state space's own generator and the categorical's cdf, as in the reference)
@@ -244,13 +278,13 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                 if (a.est.cur && noisy != nxt) est_add(a.est, N, i, 2, 1.0);        // total_noisy_transitions_episode, :1620
                 nxt = noisy;
             }
-            hist = (hist << 8) | nxt;                                               // D3
+            hist.push(nxt);                                                         // D3
             steps += 1;
             phase = (phase + 1 == (uint32_t)a.every_n) ? 0u : phase + 1;
             uint32_t key = kNoKey;                                                  // D4
-            if (((hist >> (8 * L)) & 0xFF) != 0xFF) {
+            if (hist.at(L) != kDNaN) {
                 key = 0;
-                for (int j = L - 1; j >= 0; j--) key = key * S + (uint32_t)((hist >> (8 * j)) & 0xFF);
+                for (int j = L - 1; j >= 0; j--) key = key * S + hist.at(j);
             }
             // custom reward matrix: R(s, a) of this transition, whatever s' (noise included) was (:1259-1267)
             if (!UNIT && a.rew_sa) key = cur * (uint32_t)A + (uint32_t)action;
@@ -334,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
                     s0 = d_reset_draw(a, t, env_pcg);
                     if (IRR) cur1 = (uint32_t)searchsorted_right(init_cdf1, a.S1, np_random(env_pcg));
                 }
-                hist = d_fresh_hist(s0);
+                hist = DHist::fresh(s0);
                 if (a.est.cur) est_roll(a.est, N, i, steps);                        // reset(): :2231-2247, :2360-2369
                 steps = 0; phase = 0; ringbits = 0;
                 if (!UNIT)
@@ -353,7 +387,8 @@ __global__ __launch_bounds__(kBlock) void k_discrete_step(DiscreteArgs a, int K,
         }
     }
 
-    a.state[i] = make_uint4((uint32_t)hist, (uint32_t)(hist >> 32), steps | (pending ? 0x80000000u : 0u), ringbits);
+    a.state[i] = make_uint4((uint32_t)hist.lo, (uint32_t)(hist.lo >> 32), steps | (pending ? 0x80000000u : 0u), ringbits);
+    hist.store_hi(a, i);
     if (!PHILOX) {
         if (use_env) env_pcg.store(a.env_s, i);
         if (use_sp) sp_pcg.store(a.sp_s, i);
@@ -397,8 +432,9 @@ __global__ __launch_bounds__(kBlock) void k_discrete_reset(DiscreteArgs a, uint6
     }
     if (a.irr) a.irr_state[i] = s1;
     if (a.est.cur) est_roll(a.est, a.N, i, a.state[i].z & 0x7FFFFFFFu);
-    uint64_t hist = d_fresh_hist(s0);
-    a.state[i] = make_uint4((uint32_t)hist, a.fast_ok ? queue : (uint32_t)(hist >> 32), 0u, 0u);
+    const DHist hist = DHist::fresh(s0);
+    a.state[i] = make_uint4((uint32_t)hist.lo, a.fast_ok ? queue : (uint32_t)(hist.lo >> 32), 0u, 0u);
+    hist.store_hi(a, i);
     if (!a.unit_rewards)
         for (int d = 0; d < a.delay; d++) a.ring_keys[(size_t)d * a.N + i] = kNoKey;
     if (obs) {
@@ -424,6 +460,9 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     bool ldsenv = !a.shared_tables && a.rew_in_lds && !a.has_p_noise && !a.irr && K >= 8 && env_lds <= 96u * 1024u &&
                   !(a.opts & MDPP_OPT_NO_QUIET);
     bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds) && a.lds_bytes <= 48u * 1024u;
+#ifdef MDPP_D_WIDE
+    ldsenv = ldstab = false;            // (16-bit table entries: read where they are, in HBM / L2)
+#endif
     if (ldsenv) {                       // (also when only the name is asked for: the name is the launch's)
         const void *kern = a.unit_rewards ? (const void *)k_discrete_step<PHILOX, NOISE, true, true, false>
                                           : (const void *)k_discrete_step<PHILOX, NOISE, false, true, false>;
@@ -432,13 +471,20 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     if (ldsenv) ldstab = true;
     const size_t lds = ldsenv ? env_lds : (ldstab ? a.lds_bytes : 0);
     if (name_out) {
+#ifdef MDPP_D_WIDE
+        snprintf(name_out, kNameLen, "k_discrete_step_wide<PHILOX=%d,NOISE=%d,UNIT=%d>", PHILOX, NOISE, a.unit_rewards != 0);
+#else
         snprintf(name_out, kNameLen, "k_discrete_step<PHILOX=%d,NOISE=%d,UNIT=%d,LDSTAB=%d,IRR=%d>", PHILOX, NOISE,
                  a.unit_rewards != 0, ldsenv ? 2 : (int)ldstab, a.irr != 0);
+#endif
         return;
     }
 #define MDPP_D_LAUNCH(UNIT, LDSTAB, IRR)                                                               \
     hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB, IRR>), dim3(grid), dim3(kBlock), \
                        lds, s, a, K, actions, obs, reward, term, trunc, final_obs)
+#ifdef MDPP_D_WIDE
+    if (a.unit_rewards) MDPP_D_LAUNCH(true, false, false); else MDPP_D_LAUNCH(false, false, false);
+#else
     if (a.irr) {
         if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true, true); else MDPP_D_LAUNCH(true, false, true); }
         else { if (ldstab) MDPP_D_LAUNCH(false, true, true); else MDPP_D_LAUNCH(false, false, true); }
@@ -446,11 +492,50 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
         if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true, false); else MDPP_D_LAUNCH(true, false, false); }
         else { if (ldstab) MDPP_D_LAUNCH(false, true, false); else MDPP_D_LAUNCH(false, false, false); }
     }
+#endif
 #undef MDPP_D_LAUNCH
 }
 
+#ifdef MDPP_D_WIDE
+int launch_discrete_step_wide(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
+                              uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
+    DiscreteArgs a = h->dargs;
+    a.opts = h->opts;
+    a.ptick = h->tick;
+    a.dtick = h->graph_capture ? (const uint64_t *)h->d_tick_off : nullptr;
+    a.tick = a.delay > 0 ? (uint32_t)(h->tick % (uint64_t)a.delay) : 0u;
+    const bool noise = a.has_p_noise || a.has_r_noise;
+    if (a.philox) {
+        if (noise) launch_step_t<true, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+        else launch_step_t<true, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    } else {
+        if (noise) launch_step_t<false, true>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+        else launch_step_t<false, false>(a, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    }
+    if (name_out) return MDPP_OK;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("k_discrete_step_wide launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    h->tick += (uint64_t)K;
+    return MDPP_OK;
+}
+
+int launch_discrete_reset_wide(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
+    DiscreteArgs a = h->dargs;
+    const int grid = (a.N + kBlock - 1) / kBlock;
+    if (a.philox)
+        hipLaunchKernelGGL(k_discrete_reset<true>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
+    else
+        hipLaunchKernelGGL(k_discrete_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("k_discrete_reset_wide launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    h->reset_tick += 1;
+    return MDPP_OK;
+}
+#else
+
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
+    if (h->cfg.S > 255) return launch_discrete_step_wide(h, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     DiscreteArgs a = h->dargs;
     a.opts = h->opts;
     // image handles: this is the state kernel of a batch of the image pipeline, which runs BESIDE the persistent renderer of the
@@ -541,6 +626,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
 }
 
 int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
+    if (h->cfg.S > 255) return launch_discrete_reset_wide(h, mask, obs, s);
     DiscreteArgs a = h->dargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox)
@@ -552,5 +638,6 @@ int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream
     h->reset_tick += 1;
     return MDPP_OK;
 }
+#endif   // MDPP_D_WIDE
 
 } // namespace mdpp

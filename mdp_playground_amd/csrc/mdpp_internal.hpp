@@ -85,6 +85,7 @@ struct DiscreteArgs {
     uint32_t rew_in_lds, noise_in_lds;
     // per-env state (device)
     uint4 *state;               // {hist bytes 0-3, hist bytes 4-7, steps, ring bits}
+    uint64_t *hist_hi;          // S > 255 (mdpp_discrete_wide.hip): states are 16-bit fields, the four oldest of the L + 1 live here
     uint32_t *ring_keys;        // [delay][N] keys awaiting payout (unit_rewards == 0)
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc; // PCG64 streams
     uint32_t *status;
@@ -280,6 +281,7 @@ struct mdpp_env {
     // device allocations
     void *d_P, *d_rtable, *d_rbits, *d_is_term, *d_init_cdf, *d_noise_cdf;
     void *d_state, *d_ring, *d_status;
+    void *d_hist_hi;            // discrete, S > 255
     void *d_line_hist, *d_line_ws, *d_ring64;                             // continuous, move_along_a_line
     void *d_est_cur, *d_est_last;                             // cfg.episode_stats: EpisodeStatsDev rows
     int32_t est_nk;
@@ -322,6 +324,10 @@ constexpr int kNameLen = 192;
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
+// state spaces of 256 ... 65 535 states: the general kernel alone, 16-bit table entries and history fields (mdpp_discrete_wide.hip)
+int launch_discrete_step_wide(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
+                              uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out);
+int launch_discrete_reset_wide(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
 bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,

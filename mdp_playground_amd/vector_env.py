@@ -194,7 +194,7 @@ class RLToyVectorEnv:
     def _upload_discrete(self):
         ms = self.mdps
         unit = bool(self._cfg.unit_rewards)
-        P = _stack([m.P for m in ms], np.uint8)
+        P = _stack([m.P for m in ms], np.uint8 if ms[0].S <= 255 else np.uint16)      # (S > 255: 16-bit entries, mdpp_discrete_wide.hip)
         is_term = _stack([m.is_terminal_table() for m in ms], np.uint8)
         init_cdf = _stack([m.init_cdf() for m in ms], np.float64)
         rtable = rbits = None

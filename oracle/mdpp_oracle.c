@@ -153,11 +153,14 @@ void ora_d_step(ora_discrete *e, int action, int64_t *obs, double *reward, uint8
         if (e->philox) {     /* the build's own streams: one word of the tick, no cdf (np_random.c np_philox_pnoise_state) */
             noisy = np_philox_pnoise_state(np_philox_tick_word(e->ph_seed, e->ph_env, t0, ORA_PHILOX_PNOISE), e->p_noise, S, nxt);
         } else {             /* numpy streams: the state space's generator, as the reference */
-            double cdf[256], probs[256];
+            double cdf_s[256], probs_s[256];     /* (S > 255, round 6: on the heap) */
+            double *cdf = S <= 256 ? cdf_s : (double *)malloc(sizeof(double) * (size_t)S);
+            double *probs = S <= 256 ? probs_s : (double *)malloc(sizeof(double) * (size_t)S);
             for (int i = 0; i < S; i++) probs[i] = 1.0 * e->p_noise / (double)(S - 1);
             probs[nxt] = 1 - e->p_noise;
             np_build_cdf(probs, S, cdf);
             noisy = np_choice_cdf(&e->space_rng, cdf, S);
+            if (S > 256) { free(cdf); free(probs); }
         }
         if (noisy != nxt) e->st[2] += 1.0;              /* :1620 */
         nxt = noisy;

@@ -103,6 +103,17 @@ CASES = {
                     state_space_size=12, action_space_size=6, diameter=2, delay=0,
                     sequence_length=3, terminal_state_density=0.34),
         seeds=list(range(4)), T=200, reset="on_done"),
+    # (round 6: state spaces beyond 255 states -- 16-bit table entries and history fields, mdpp_discrete_wide.hip)
+    "d_s300_noise": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=300, action_space_size=300, delay=1, sequence_length=1,
+                    reward_density=0.25, terminal_state_density=0.05, transition_noise=0.1, reward_noise=0.2, reward_scale=1.5),
+        seeds=list(range(3)), T=120, reset="on_done"),
+    "d_s300_diam50_l2": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=300, action_space_size=6, diameter=50, delay=2,
+                    sequence_length=2, terminal_state_density=0.34),
+        seeds=list(range(3)), T=300, reset="on_done"),
     "d_notmax": dict(
         config=dict(BASE_D, delay=0, sequence_length=2, maximally_connected=False),
         seeds=list(range(4)), T=100, reset="on_done"),
