@@ -132,7 +132,8 @@ typedef struct {
     double reward_scale, reward_shift, term_state_reward;
 
     /* ---- discrete ---- */
-    int32_t S, A, L;            /* state_space_size, action_space_size, sequence_length */
+    int32_t S, A, L;            /* state_space_size (<= 65 535), action_space_size, sequence_length (<= 15; S^L < 4e9) -- S > 255 and L > 7: the general
+                                   kernel alone, not together, without image observations or an irrelevant sub-space */
     int32_t num_tables;         /* 1 = one MDP shared by all envs; num_envs = one MDP per env */
     int32_t unit_rewards;       /* 1: every rewardable sequence pays exactly 1.0 (bitmask table) */
     int32_t reward_kind;        /* MDPP_REWARD_*: what the reward table is keyed by */

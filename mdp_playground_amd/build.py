@@ -13,13 +13,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libmdpp_hip.so")
-SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_wide.hip", "mdpp_discrete_fast.hip", "mdpp_discrete_step1.hip", "mdpp_discrete_pipe.hip", "mdpp_discrete_lean.hip", "mdpp_discrete_lean_next.hip", "mdpp_discrete_lean_noise.hip", "mdpp_discrete_lean_npnoise.hip",
+SOURCES = ["mdpp_capi.hip", "mdpp_discrete.hip", "mdpp_discrete_wide.hip", "mdpp_discrete_long.hip", "mdpp_discrete_fast.hip", "mdpp_discrete_step1.hip", "mdpp_discrete_pipe.hip", "mdpp_discrete_lean.hip", "mdpp_discrete_lean_next.hip", "mdpp_discrete_lean_noise.hip", "mdpp_discrete_lean_npnoise.hip",
            "mdpp_discrete_quiet.hip", "mdpp_discrete_quiet_nu.hip",
            "mdpp_continuous.hip", "mdpp_continuous_line8.hip",
            "mdpp_continuous_fast.hip", "mdpp_continuous_step1.hip", "mdpp_continuous_line.hip", "mdpp_image.hip", "mdpp_grid.hip", "mdpp_imagec.hip", "mdpp_post.hip", "mdpp_peer.hip"]
 HEADERS = ["mdpp_internal.hpp", "mdpp_rng.hpp", "mdpp_pcg64_limbs.inc", "np_ziggurat_tables.inc",
            os.path.join("..", "..", "include", "mdpp.h")]
-INCLUDED_SOURCES = {"mdpp_discrete_wide.hip": ["mdpp_discrete.hip"], "mdpp_discrete_lean_next.hip": ["mdpp_discrete_lean.hip"], "mdpp_discrete_lean_noise.hip": ["mdpp_discrete_lean.hip"], "mdpp_discrete_lean_npnoise.hip": ["mdpp_discrete_lean.hip"],
+INCLUDED_SOURCES = {"mdpp_discrete_wide.hip": ["mdpp_discrete.hip"], "mdpp_discrete_long.hip": ["mdpp_discrete.hip"], "mdpp_discrete_lean_next.hip": ["mdpp_discrete_lean.hip"], "mdpp_discrete_lean_noise.hip": ["mdpp_discrete_lean.hip"], "mdpp_discrete_lean_npnoise.hip": ["mdpp_discrete_lean.hip"],
                     "mdpp_continuous_line8.hip": ["mdpp_continuous.hip"], "mdpp_continuous_step1.hip": ["mdpp_continuous_fast.hip"], "mdpp_discrete_quiet_nu.hip": ["mdpp_discrete_quiet.hip"]}   # a .hip that #includes another one
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]

@@ -203,11 +203,14 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     if (cfg->kind == MDPP_KIND_DISCRETE) {
         // (S > 255 -- round 6: 16-bit table entries and history fields, served by the general kernel alone, mdpp_discrete_wide.hip;
         //  without picture observations and without an irrelevant sub-space)
-        if (cfg->S < 2 || cfg->S > 65535 || cfg->A < 1 || cfg->L < 1 || cfg->L > 7 || (cfg->S > 255 && (cfg->image || cfg->irrelevant))) {
-            g_create_err = "mdpp_create: discrete needs 2 <= S <= 65535 (<= 255 with image observations or an irrelevant sub-space), A >= 1, 1 <= L <= 7";
+        // (sequence_length 8 ... 15 -- round 6: a history of sixteen byte fields, mdpp_discrete_long.hip; S <= 255 there)
+        const bool wide = cfg->S > 255, lng = cfg->L > 7;
+        if (cfg->S < 2 || cfg->S > 65535 || cfg->A < 1 || cfg->L < 1 || cfg->L > 15 || ((wide || lng) && (cfg->image || cfg->irrelevant)) ||
+            (wide && lng)) {
+            g_create_err = "mdpp_create: discrete needs 2 <= S <= 65535, A >= 1, 1 <= L <= 15 (S <= 255 and L <= 7 with image observations or "
+                           "an irrelevant sub-space; not S > 255 together with L > 7)";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
-        const bool wide = cfg->S > 255;
         if (cfg->num_tables != 1 && cfg->num_tables != cfg->num_envs) {
             g_create_err = "mdpp_create: num_tables must be 1 or num_envs"; free_all(h); delete h; return MDPP_EINVAL;
         }
@@ -236,7 +239,7 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
             TRY(alloc_zero(h, &h->d_irr_state, N * sizeof(uint32_t)));
         }
         TRY(alloc_zero(h, &h->d_P, T * cfg->S * cfg->A * (wide ? 2 : 1)));
-        if (wide) {
+        if (wide || lng) {
             TRY(alloc_zero(h, &h->d_hist_hi, N * sizeof(uint64_t)));
             TRYHIP(hipMemset(h->d_hist_hi, 0xFF, N * sizeof(uint64_t)));
         }
@@ -487,7 +490,7 @@ extern "C" int mdpp_upload_discrete_tables(mdpp_env *h, const uint8_t *P, const 
         HIPCHK(h, hipMemcpy(h->d_rtable, rtable, T * (size_t)h->nkeys * sizeof(double), hipMemcpyHostToDevice));
     if (h->cfg.has_transition_noise)
         HIPCHK(h, hipMemcpy(h->d_noise_cdf, noise_cdf, S * S * sizeof(double), hipMemcpyHostToDevice));
-    if (wide) {     // no specialised kernel serves such a handle (launch_discrete_step: mdpp_discrete_wide.hip)
+    if (wide || h->cfg.L > 7) {     // no specialised kernel serves such a handle (launch_discrete_step: mdpp_discrete_wide.hip / _long.hip)
         DiscreteArgs &a = h->dargs;
         a.shape_ok = a.fast_ok = a.shape_ok_irr = a.lean_next_ok = a.shape_ok_noise = a.shape_ok_noise_np = 0u;
         a.minv_lo = (uint64_t)pcg_mult_inverse(); a.minv_hi = (uint64_t)(pcg_mult_inverse() >> 64);
@@ -1323,8 +1326,9 @@ extern "C" int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist, int32_t *step
         HIPCHK(h, hipMemcpy(rt.data(), h->d_rtable, rt.size() * 8, hipMemcpyDeviceToHost));
     }
     const bool wide = h->cfg.S > 255;   // (16-bit history fields, the older four in d_hist_hi)
+    const bool lng = h->cfg.L > 7;      // (sixteen byte fields, the older eight in d_hist_hi)
     std::vector<uint64_t> hhi;
-    if (wide) { hhi.resize(N); HIPCHK(h, hipMemcpy(hhi.data(), h->d_hist_hi, N * 8, hipMemcpyDeviceToHost)); }
+    if (wide || lng) { hhi.resize(N); HIPCHK(h, hipMemcpy(hhi.data(), h->d_hist_hi, N * 8, hipMemcpyDeviceToHost)); }
     for (size_t i = 0; i < N; i++) {
         uint64_t hb = ((uint64_t)st[4 * i + 1] << 32) | st[4 * i];
         if (hist && wide)
@@ -1335,7 +1339,8 @@ extern "C" int mdpp_get_state_discrete(mdpp_env *h, int32_t *hist, int32_t *step
             }
         else if (hist)
             for (int j = 0; j <= L; j++) { // hist[0] oldest ... hist[L] newest
-                uint32_t b = (uint32_t)((hb >> (8 * (L - j))) & 0xFF);
+                const int f = L - j;
+                uint32_t b = (uint32_t)((f < 8 ? hb >> (8 * f) : hhi[i] >> (8 * (f - 8))) & 0xFF);
                 hist[i * (L + 1) + j] = (b == 0xFF) ? -1 : (int32_t)b;
             }
         if (steps) steps[i] = (int32_t)(st[4 * i + 2] & 0x7FFFFFFFu);    // (bit 31: next-step autoreset pending)
@@ -1397,16 +1402,16 @@ extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const i
         }
         HIPCHK(h, hipMemcpy(h->d_ring, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
     }
-    const bool wide = h->cfg.S > 255;
-    std::vector<uint64_t> hhi(wide ? N : 0);
+    const bool wide = h->cfg.S > 255, lng = L > 7;
+    std::vector<uint64_t> hhi((wide || lng) ? N : 0);
     for (size_t i = 0; i < N; i++) {
         uint64_t hb = ~0ULL, hh = ~0ULL;
         for (int j = 0; j <= L; j++) {
             int32_t v = hist[i * (L + 1) + j];
             if (wide) { hh = (hh << 16) | (hb >> 48); hb = (hb << 16) | (uint64_t)(v < 0 ? 0xFFFF : v); }
-            else hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v);
+            else { hh = (hh << 8) | (hb >> 56); hb = (hb << 8) | (uint64_t)(v < 0 ? 0xFF : v); }
         }
-        if (wide) hhi[i] = hh;
+        if (wide || lng) hhi[i] = hh;
         st[4 * i] = (uint32_t)hb;
         if (!h->dargs.fast_ok) st[4 * i + 1] = (uint32_t)(hb >> 32); // fast path: word 1 is the draw queue
         st[4 * i + 2] = (uint32_t)steps[i];
@@ -1417,7 +1422,7 @@ extern "C" int mdpp_set_state_discrete(mdpp_env *h, const int32_t *hist, const i
         }
     }
     HIPCHK(h, hipMemcpy(h->d_state, st.data(), N * 16, hipMemcpyHostToDevice));
-    if (wide) HIPCHK(h, hipMemcpy(h->d_hist_hi, hhi.data(), N * 8, hipMemcpyHostToDevice));
+    if (wide || lng) HIPCHK(h, hipMemcpy(h->d_hist_hi, hhi.data(), N * 8, hipMemcpyHostToDevice));
     return MDPP_OK;
 }
 

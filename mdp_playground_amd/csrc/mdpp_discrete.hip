@@ -25,6 +25,20 @@
 #define DTables DTablesWide
 #define DHist DHistWide
 #define launch_step_t launch_step_wide_t
+#define launch_discrete_step_var launch_discrete_step_wide
+#define launch_discrete_reset_var launch_discrete_reset_wide
+#define MDPP_D_VARIANT "wide"
+#endif
+#ifdef MDPP_D_LONG        /* (third compilation, mdpp_discrete_long.hip: sequence_length 8 ... 15) */
+#define k_discrete_step k_discrete_step_long
+#define k_discrete_reset k_discrete_reset_long
+#define d_reset_draw d_reset_draw_long
+#define DTables DTablesLong
+#define DHist DHistLong
+#define launch_step_t launch_step_long_t
+#define launch_discrete_step_var launch_discrete_step_long
+#define launch_discrete_reset_var launch_discrete_reset_long
+#define MDPP_D_VARIANT "long"
 #endif
 
 namespace mdpp {
@@ -55,6 +69,19 @@ struct DHist {
     __device__ __forceinline__ uint32_t cur() const { return (uint32_t)lo & 0xFFFFu; }
     __device__ __forceinline__ void push(uint32_t n) { hi = (hi << 16) | (lo >> 48); lo = (lo << 16) | n; }
     __device__ __forceinline__ uint32_t at(int j) const { return (uint32_t)((j < 4 ? lo >> (16 * j) : hi >> (16 * (j - 4))) & 0xFFFFu); }
+};
+#elif defined(MDPP_D_LONG)
+// sequence_length 8 ... 15 (S <= 255): sixteen byte fields, the older eight in DiscreteArgs::hist_hi
+typedef uint8_t DPEntry;
+constexpr uint32_t kDNaN = 0xFFu;
+struct DHist {
+    uint64_t lo, hi;
+    __device__ __forceinline__ static DHist fresh(uint32_t s0) { return DHist{0xFFFFFFFFFFFFFF00ULL | (uint64_t)s0, ~0ULL}; }
+    __device__ __forceinline__ static DHist load(const DiscreteArgs &a, long i, const uint4 &st) { return DHist{((uint64_t)st.y << 32) | st.x, a.hist_hi[i]}; }
+    __device__ __forceinline__ void store_hi(const DiscreteArgs &a, long i) const { a.hist_hi[i] = hi; }
+    __device__ __forceinline__ uint32_t cur() const { return (uint32_t)lo & 0xFFu; }
+    __device__ __forceinline__ void push(uint32_t n) { hi = (hi << 8) | (lo >> 56); lo = (lo << 8) | n; }
+    __device__ __forceinline__ uint32_t at(int j) const { return (uint32_t)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFFu); }
 };
 #else
 typedef uint8_t DPEntry;
@@ -460,8 +487,8 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     bool ldsenv = !a.shared_tables && a.rew_in_lds && !a.has_p_noise && !a.irr && K >= 8 && env_lds <= 96u * 1024u &&
                   !(a.opts & MDPP_OPT_NO_QUIET);
     bool ldstab = a.shared_tables && a.rew_in_lds && (!a.has_p_noise || a.noise_in_lds) && a.lds_bytes <= 48u * 1024u;
-#ifdef MDPP_D_WIDE
-    ldsenv = ldstab = false;            // (16-bit table entries: read where they are, in HBM / L2)
+#ifdef MDPP_D_VARIANT
+    ldsenv = ldstab = false;            // (wide: 16-bit table entries; long: up to S^15 keys -- read where they are, in HBM / L2)
 #endif
     if (ldsenv) {                       // (also when only the name is asked for: the name is the launch's)
         const void *kern = a.unit_rewards ? (const void *)k_discrete_step<PHILOX, NOISE, true, true, false>
@@ -471,8 +498,8 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     if (ldsenv) ldstab = true;
     const size_t lds = ldsenv ? env_lds : (ldstab ? a.lds_bytes : 0);
     if (name_out) {
-#ifdef MDPP_D_WIDE
-        snprintf(name_out, kNameLen, "k_discrete_step_wide<PHILOX=%d,NOISE=%d,UNIT=%d>", PHILOX, NOISE, a.unit_rewards != 0);
+#ifdef MDPP_D_VARIANT
+        snprintf(name_out, kNameLen, "k_discrete_step_" MDPP_D_VARIANT "<PHILOX=%d,NOISE=%d,UNIT=%d>", PHILOX, NOISE, a.unit_rewards != 0);
 #else
         snprintf(name_out, kNameLen, "k_discrete_step<PHILOX=%d,NOISE=%d,UNIT=%d,LDSTAB=%d,IRR=%d>", PHILOX, NOISE,
                  a.unit_rewards != 0, ldsenv ? 2 : (int)ldstab, a.irr != 0);
@@ -482,7 +509,7 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
 #define MDPP_D_LAUNCH(UNIT, LDSTAB, IRR)                                                               \
     hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB, IRR>), dim3(grid), dim3(kBlock), \
                        lds, s, a, K, actions, obs, reward, term, trunc, final_obs)
-#ifdef MDPP_D_WIDE
+#ifdef MDPP_D_VARIANT
     if (a.unit_rewards) MDPP_D_LAUNCH(true, false, false); else MDPP_D_LAUNCH(false, false, false);
 #else
     if (a.irr) {
@@ -496,8 +523,8 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
 #undef MDPP_D_LAUNCH
 }
 
-#ifdef MDPP_D_WIDE
-int launch_discrete_step_wide(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
+#ifdef MDPP_D_VARIANT
+int launch_discrete_step_var(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                               uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     DiscreteArgs a = h->dargs;
     a.opts = h->opts;
@@ -514,12 +541,12 @@ int launch_discrete_step_wide(mdpp_env *h, int K, const int32_t *actions, void *
     }
     if (name_out) return MDPP_OK;
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { h->err = std::string("k_discrete_step_wide launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    if (e != hipSuccess) { h->err = std::string("k_discrete_step_" MDPP_D_VARIANT " launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->tick += (uint64_t)K;
     return MDPP_OK;
 }
 
-int launch_discrete_reset_wide(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
+int launch_discrete_reset_var(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
     DiscreteArgs a = h->dargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox)
@@ -527,7 +554,7 @@ int launch_discrete_reset_wide(mdpp_env *h, const uint8_t *mask, void *obs, hipS
     else
         hipLaunchKernelGGL(k_discrete_reset<false>, dim3(grid), dim3(kBlock), 0, s, a, h->reset_tick, mask, obs);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { h->err = std::string("k_discrete_reset_wide launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
+    if (e != hipSuccess) { h->err = std::string("k_discrete_reset_" MDPP_D_VARIANT " launch: ") + hipGetErrorString(e); return MDPP_EHIP; }
     h->reset_tick += 1;
     return MDPP_OK;
 }
@@ -536,6 +563,7 @@ int launch_discrete_reset_wide(mdpp_env *h, const uint8_t *mask, void *obs, hipS
 int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                          uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out) {
     if (h->cfg.S > 255) return launch_discrete_step_wide(h, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
+    if (h->cfg.L > 7) return launch_discrete_step_long(h, K, actions, obs, reward, term, trunc, final_obs, s, name_out);
     DiscreteArgs a = h->dargs;
     a.opts = h->opts;
     // image handles: this is the state kernel of a batch of the image pipeline, which runs BESIDE the persistent renderer of the
@@ -627,6 +655,7 @@ int launch_discrete_step(mdpp_env *h, int K, const int32_t *actions, void *obs, 
 
 int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s) {
     if (h->cfg.S > 255) return launch_discrete_reset_wide(h, mask, obs, s);
+    if (h->cfg.L > 7) return launch_discrete_reset_long(h, mask, obs, s);
     DiscreteArgs a = h->dargs;
     const int grid = (a.N + kBlock - 1) / kBlock;
     if (a.philox)
@@ -638,6 +667,6 @@ int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream
     h->reset_tick += 1;
     return MDPP_OK;
 }
-#endif   // MDPP_D_WIDE
+#endif   // MDPP_D_VARIANT
 
 } // namespace mdpp

@@ -85,7 +85,7 @@ struct DiscreteArgs {
     uint32_t rew_in_lds, noise_in_lds;
     // per-env state (device)
     uint4 *state;               // {hist bytes 0-3, hist bytes 4-7, steps, ring bits}
-    uint64_t *hist_hi;          // S > 255 (mdpp_discrete_wide.hip): states are 16-bit fields, the four oldest of the L + 1 live here
+    uint64_t *hist_hi;          // S > 255 (mdpp_discrete_wide.hip): states are 16-bit fields, the four oldest of the L + 1 live here; L > 7 (mdpp_discrete_long.hip): the eight oldest bytes
     uint32_t *ring_keys;        // [delay][N] keys awaiting payout (unit_rewards == 0)
     ulonglong2 *env_s, *env_inc, *sp_s, *sp_inc; // PCG64 streams
     uint32_t *status;
@@ -328,6 +328,10 @@ int launch_discrete_reset(mdpp_env *h, const uint8_t *mask, void *obs, hipStream
 int launch_discrete_step_wide(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
                               uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out);
 int launch_discrete_reset_wide(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
+// sequence_length 8 ... 15: the same with a history of sixteen byte fields (mdpp_discrete_long.hip)
+int launch_discrete_step_long(mdpp_env *h, int K, const int32_t *actions, void *obs, float *reward,
+                              uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out);
+int launch_discrete_reset_long(mdpp_env *h, const uint8_t *mask, void *obs, hipStream_t s);
 bool launch_discrete_fast(const DiscreteArgs &a, int K, const int32_t *actions, void *obs, float *reward,
                           uint8_t *term, uint8_t *trunc, void *final_obs, hipStream_t s, char *name_out = nullptr);
 int launch_continuous_step(mdpp_env *h, int K, const float *actions, float *obs, float *reward,

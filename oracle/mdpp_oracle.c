@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ORA_MAX_L 8
+#define ORA_MAX_L 16
 #define ORA_MAX_DELAY 64
 #define ORA_MAX_DIM 64
 #define ORA_MAX_ORDER 8

@@ -114,6 +114,17 @@ CASES = {
                     state_space_size=300, action_space_size=6, diameter=50, delay=2,
                     sequence_length=2, terminal_state_density=0.34),
         seeds=list(range(3)), T=300, reset="on_done"),
+    # (round 6: sequence_length beyond 7 -- a history of sixteen byte fields, mdpp_discrete_long.hip)
+    "d_l9_repeats": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=4, action_space_size=4, delay=2, sequence_length=9, repeats_in_sequences=True,
+                    reward_density=0.3, terminal_state_density=0.25, reward_noise=0.1),
+        seeds=list(range(3)), T=200, reset="on_done"),
+    "d_l8_s5": dict(
+        config=dict(state_space_type="discrete", action_space_type="discrete",
+                    state_space_size=5, action_space_size=5, delay=0, sequence_length=8, repeats_in_sequences=True,
+                    reward_density=0.5, terminal_state_density=0.2, reward_dist=[0.01, 1]),
+        seeds=list(range(2)), T=300, reset="on_done"),
     "d_notmax": dict(
         config=dict(BASE_D, delay=0, sequence_length=2, maximally_connected=False),
         seeds=list(range(4)), T=100, reset="on_done"),
