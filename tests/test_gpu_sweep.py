@@ -899,6 +899,18 @@ def test_state_spaces_beyond_255_states_vs_oracle(shape, mode):
     acts = torch.as_tensor(_rand_actions(env, 24, g), device=env.device)
     ra, rb = env.rollout(acts), twin.rollout(acts)
     assert all(_same(x, y) for x, y in zip(ra, rb)), (shape, mode)
+    # a captured graph of three single steps on one handle, three step() calls on the other
+    try:
+        sg = env.step_graph(acts[:3].clone())
+    except capi.MdppError as e:
+        assert "does not replay exactly" in str(e)
+        sg = None
+    if sg is not None:
+        sg.replay()
+        torch.cuda.synchronize()
+        for t in range(3):
+            sb = twin.step(acts[t])
+            assert all(_same(x, y) for x, y in zip((sg.obs[t], sg.reward[t], sg.terminated[t], sg.truncated[t]), sb[:4])), (shape, mode, "graph", t)
     assert not (env.status() & 0x80000000).any()
     env.close(); twin.close()
 
@@ -943,5 +955,17 @@ def test_sequence_lengths_beyond_7_vs_oracle(shape, mode):
     acts = torch.as_tensor(_rand_actions(env, 40, np.random.default_rng(8)), device=env.device)
     ra, rb = env.rollout(acts), twin.rollout(acts)
     assert all(_same(x, y) for x, y in zip(ra, rb)), (shape, mode)
+    # a captured graph of three single steps on one handle, three step() calls on the other
+    try:
+        sg = env.step_graph(acts[:3].clone())
+    except capi.MdppError as e:
+        assert "does not replay exactly" in str(e)
+        sg = None
+    if sg is not None:
+        sg.replay()
+        torch.cuda.synchronize()
+        for t in range(3):
+            sb = twin.step(acts[t])
+            assert all(_same(x, y) for x, y in zip((sg.obs[t], sg.reward[t], sg.terminated[t], sg.truncated[t]), sb[:4])), (shape, mode, "graph", t)
     assert not (env.status() & 0x80000000).any()
     env.close(); twin.close()
