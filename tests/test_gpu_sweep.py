@@ -460,7 +460,7 @@ def _fuzz_wide(n, seed):
 def _fuzz_more(n, seed):
     """A third seeded family, the corners the two above leave out: unbounded state / action boxes (the reset then draws normals,
     rl_toy_env.py:2286), order 4, every-n / delay / terminal reward on continuous envs, pictures WITH an irrelevant sub-space, large
-    discrete tables (S up to 255, S^L up to 32 768 keys, sequence_length up to 7), grids up to 30 x 40 cells."""
+    discrete tables (S up to 1 000, S^L up to 531 441 keys, sequence_length up to 12), grids up to 30 x 40 cells."""
     r = np.random.default_rng(seed)
     out = []
     for k in range(n):
@@ -498,7 +498,8 @@ def _fuzz_more(n, seed):
             if "scale" in tr:
                 cfg["image_scale_range"] = (0.5, 1.5)
         elif fam == "d_big":
-            S, L = [(100, 1), (200, 1), (255, 1), (30, 3), (8, 5), (4, 7), (16, 3), (60, 2)][int(r.integers(8))]
+            # (S > 255: k_discrete_step_wide; L > 7: k_discrete_step_long -- with repeats, the no-repeats generator needs L <= non-terminal states)
+            S, L = [(100, 1), (200, 1), (255, 1), (30, 3), (8, 5), (4, 7), (16, 3), (60, 2), (300, 1), (1000, 1), (300, 2), (4, 9), (3, 12), (256, 1)][int(r.integers(14))]
             cfg = dict(state_space_type="discrete", action_space_type="discrete", state_space_size=S, action_space_size=S, sequence_length=L,
                        delay=int(r.choice([0, 1, 7])), reward_density=float(r.choice([0.05, 0.25])), terminal_state_density=float(r.choice([0.05, 0.25])),
                        make_denser=bool(r.random() < 0.2), seed=int(r.integers(1000)))
@@ -508,6 +509,8 @@ def _fuzz_more(n, seed):
                 cfg["transition_noise"] = float(r.choice([0.0, 0.05]))
             if r.random() < 0.3:
                 cfg["reward_dist"] = [0.01, 1]
+            if L > 7:
+                cfg["repeats_in_sequences"] = True
         else:
             G = [int(r.integers(10, 31)), int(r.integers(10, 41))]
             cfg = dict(state_space_type="grid", grid_shape=G, reward_function="move_to_a_point", make_denser=bool(r.random() < 0.5),
