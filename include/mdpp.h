@@ -133,7 +133,7 @@ typedef struct {
 
     /* ---- discrete ---- */
     int32_t S, A, L;            /* state_space_size (<= 65 535), action_space_size, sequence_length (<= 15; S^L < 4e9) -- S > 255 and L > 7: the general
-                                   kernel alone, not together, without image observations or an irrelevant sub-space */
+                                   kernel alone, not together, without image observations */
     int32_t num_tables;         /* 1 = one MDP shared by all envs; num_envs = one MDP per env */
     int32_t unit_rewards;       /* 1: every rewardable sequence pays exactly 1.0 (bitmask table) */
     int32_t reward_kind;        /* MDPP_REWARD_*: what the reward table is keyed by */
@@ -194,7 +194,7 @@ const char *mdpp_last_error(const mdpp_env *h);   /* h may be NULL: last create(
 /* Discrete tables (host pointers; T = cfg.num_tables):
  *   P        uint8 [T][S][A]      transition matrix                       rl_toy_env.py:1050-1151
  *            (cfg.S > 255, up to 65 535 -- round 6: uint16 [T][S][A] behind the same pointer; such handles run the general
- *            kernel alone, without image observations or an irrelevant sub-space: mdpp_discrete_wide.hip)
+ *            kernel alone, without image observations: mdpp_discrete_wide.hip)
  *   rtable   double[T][S^L] (MDPP_REWARD_SEQUENCES) or double[T][S][A] (MDPP_REWARD_STATE_ACTION:
  *            use_custom_mdp with a reward matrix, R(s, a) of the transition s, a -> s', :1259-1267)
  *            or, when cfg.unit_rewards, NULL with

@@ -202,13 +202,12 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
     }
     if (cfg->kind == MDPP_KIND_DISCRETE) {
         // (S > 255 -- round 6: 16-bit table entries and history fields, served by the general kernel alone, mdpp_discrete_wide.hip;
-        //  without picture observations and without an irrelevant sub-space)
+        //  without picture observations; an irrelevant sub-space keeps its own limit of 255 states)
         // (sequence_length 8 ... 15 -- round 6: a history of sixteen byte fields, mdpp_discrete_long.hip; S <= 255 there)
         const bool wide = cfg->S > 255, lng = cfg->L > 7;
-        if (cfg->S < 2 || cfg->S > 65535 || cfg->A < 1 || cfg->L < 1 || cfg->L > 15 || ((wide || lng) && (cfg->image || cfg->irrelevant)) ||
-            (wide && lng)) {
-            g_create_err = "mdpp_create: discrete needs 2 <= S <= 65535, A >= 1, 1 <= L <= 15 (S <= 255 and L <= 7 with image observations or "
-                           "an irrelevant sub-space; not S > 255 together with L > 7)";
+        if (cfg->S < 2 || cfg->S > 65535 || cfg->A < 1 || cfg->L < 1 || cfg->L > 15 || ((wide || lng) && cfg->image) || (wide && lng)) {
+            g_create_err = "mdpp_create: discrete needs 2 <= S <= 65535, A >= 1, 1 <= L <= 15 (S <= 255 and L <= 7 with image observations; "
+                           "not S > 255 together with L > 7)";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
         if (cfg->num_tables != 1 && cfg->num_tables != cfg->num_envs) {

@@ -499,7 +499,7 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     const size_t lds = ldsenv ? env_lds : (ldstab ? a.lds_bytes : 0);
     if (name_out) {
 #ifdef MDPP_D_VARIANT
-        snprintf(name_out, kNameLen, "k_discrete_step_" MDPP_D_VARIANT "<PHILOX=%d,NOISE=%d,UNIT=%d>", PHILOX, NOISE, a.unit_rewards != 0);
+        snprintf(name_out, kNameLen, "k_discrete_step_" MDPP_D_VARIANT "<PHILOX=%d,NOISE=%d,UNIT=%d,IRR=%d>", PHILOX, NOISE, a.unit_rewards != 0, a.irr != 0);
 #else
         snprintf(name_out, kNameLen, "k_discrete_step<PHILOX=%d,NOISE=%d,UNIT=%d,LDSTAB=%d,IRR=%d>", PHILOX, NOISE,
                  a.unit_rewards != 0, ldsenv ? 2 : (int)ldstab, a.irr != 0);
@@ -510,7 +510,8 @@ static void launch_step_t(const DiscreteArgs &a, int K, const int32_t *actions, 
     hipLaunchKernelGGL((k_discrete_step<PHILOX, NOISE, UNIT, LDSTAB, IRR>), dim3(grid), dim3(kBlock), \
                        lds, s, a, K, actions, obs, reward, term, trunc, final_obs)
 #ifdef MDPP_D_VARIANT
-    if (a.unit_rewards) MDPP_D_LAUNCH(true, false, false); else MDPP_D_LAUNCH(false, false, false);
+    if (a.irr) { if (a.unit_rewards) MDPP_D_LAUNCH(true, false, true); else MDPP_D_LAUNCH(false, false, true); }
+    else { if (a.unit_rewards) MDPP_D_LAUNCH(true, false, false); else MDPP_D_LAUNCH(false, false, false); }
 #else
     if (a.irr) {
         if (a.unit_rewards) { if (ldstab) MDPP_D_LAUNCH(true, true, true); else MDPP_D_LAUNCH(true, false, true); }

@@ -26,8 +26,8 @@ RULES = """## The rules behind the tables (first match wins; sources: the `launc
 
 | kernel | serves | file: function |
 |---|---|---|
-| `k_discrete_step_wide<PHILOX,NOISE,UNIT>` | state_space_size 256 ... 65 535 (16-bit table entries and history fields; the general kernel compiled a second time): every call |
-| `k_discrete_step_long<PHILOX,NOISE,UNIT>` | sequence_length 8 ... 15 (a history of sixteen byte fields; the general kernel compiled a third time): every call |
+| `k_discrete_step_wide<PHILOX,NOISE,UNIT,IRR>` | state_space_size 256 ... 65 535 (16-bit table entries and history fields; the general kernel compiled a second time): every call |
+| `k_discrete_step_long<PHILOX,NOISE,UNIT,IRR>` | sequence_length 8 ... 15 (a history of sixteen byte fields; the general kernel compiled a third time): every call |
 | `k_discrete_step1` / `k_discrete_step1w` | `mdpp_step` (K = 1): one shared MDP, L <= 3, same-step autoreset or none, no irrelevant sub-space, no episode statistics; S <= 16 without noise (`step1`) or any S <= 255 whose table blob fits the rounds a wave stages -- 8 KiB, 12 KiB with a noise key (`step1w`: unit rewards with delay <= 32, or non-unit sequence rewards without noise) | `mdpp_discrete_step1.hip`: `launch_discrete_step1`; the blob: `mdpp_capi.hip`: `mdpp_upload_discrete_tables` |
 | `k_discrete_rollout_lean<...,PHILOX,IRR,NEXT,PN,RN,Z0>` | K >= 32, N >= 256: one shared MDP, unit rewards, L <= 3, S <= 8, A <= 16, delay <= 32, every_n <= 64, max_steps < 65 536; noise on numpy streams only where the S noise categoricals share their thresholds (host check); `Z0`: the reward-noise key with sigma 0 | `mdpp_discrete_lean.hip`: `launch_discrete_lean` (+ `_next`, `_noise`, `_npnoise`) |
 | `k_discrete_rollout_pipe` / `_fast` | the same quiet shape up to S = 16 (three roles for long rollouts of full blocks / one role: short rollouts, the state kernel of image handles) | `mdpp_discrete_pipe.hip`, `mdpp_discrete_fast.hip` |
