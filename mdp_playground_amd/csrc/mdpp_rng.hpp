@@ -392,10 +392,11 @@ __device__ __forceinline__ uint32_t philox_pnoise_index(uint32_t w, uint32_t T, 
     return (w < T && M != 0ull) ? (j | 0x100u) : 0u;
 }
 // the state a step lands in: `nxt` (the table's) unless the tick's word says noisy
+// (the index whole: state spaces beyond 256 states -- mdpp_discrete_wide.hip -- have indices beyond the byte philox_pnoise_index packs)
 __device__ __forceinline__ uint32_t philox_pnoise_state(uint32_t w, uint32_t T, uint64_t M, uint32_t nxt) {
-    const uint32_t e = philox_pnoise_index(w, T, M);
-    const uint32_t j = e & 0xFFu;
-    return (e & 0x100u) ? j + (j >= nxt ? 1u : 0u) : nxt;
+    const uint64_t t = (uint64_t)w * (uint32_t)(M >> 32) + (uint64_t)__umulhi(w, (uint32_t)M);
+    const uint32_t j = (uint32_t)(t >> 32);
+    return (w < T && M != 0ull) ? j + (j >= nxt ? 1u : 0u) : nxt;
 }
 
 template <class G>

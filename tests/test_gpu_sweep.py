@@ -976,3 +976,43 @@ def test_sequence_lengths_beyond_7_vs_oracle(shape, mode):
             assert all(_same(x, y) for x, y in zip((sg.obs[t], sg.reward[t], sg.terminated[t], sg.truncated[t]), sb[:4])), (shape, mode, "graph", t)
     assert not (env.status() & 0x80000000).any()
     env.close(); twin.close()
+
+
+@pytest.mark.parametrize("shape", ["s1000_both_noises", "l9_s4_both_noises"])
+def test_wide_and_long_handles_on_philox_streams_vs_oracle(shape):
+    """The wide / long kernels on the build's own Philox streams (transition noise by one word of the tick -- a multiply-shift over
+    S - 1 states, here S = 1 000 --, reward noise, resets keyed by the tick) against the oracle's C restatement of those streams:
+    1 024 envs, a rollout of 64 with same-step autoreset then 8 single steps, every 11th env."""
+    from test_gpu_parity import _oracle_for
+    import warnings
+    D = dict(state_space_type="discrete", action_space_type="discrete", reward_density=0.25, terminal_state_density=0.1, seed=11)
+    cfg = {"s1000_both_noises": dict(D, state_space_size=1000, action_space_size=1000, sequence_length=1, delay=2, transition_noise=0.2, reward_noise=0.3,
+                                     reward_scale=1.5),
+           "l9_s4_both_noises": dict(D, state_space_size=4, action_space_size=4, sequence_length=9, repeats_in_sequences=True, delay=1,
+                                     terminal_state_density=0.25, transition_noise=0.2, reward_noise=0.3)}[shape]
+    N, T, T1 = 1024, 64, 8
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = _venv(num_envs=N, autoreset="same_step", rng="philox", philox_seed=99, **cfg)
+    assert env.rollout_kernel_name(T).startswith("k_discrete_step_wide<PHILOX=1" if shape[0] == "s" else "k_discrete_step_long<PHILOX=1")
+    A = cfg["action_space_size"]
+    acts = np.random.default_rng(6).integers(0, A, size=(T + T1, N)).astype(np.int32)
+    init = env._obs.cpu().numpy().copy()
+    obs, rew, term, trunc = env.rollout(torch.as_tensor(acts[:T], device=env.device))
+    obs, rew, term = obs.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+    single = []
+    for t in range(T, T + T1):
+        o1, r1, d1, _, _ = env.step(torch.as_tensor(acts[t], device=env.device))
+        single.append((o1.cpu().numpy().copy(), r1.cpu().numpy().copy(), d1.cpu().numpy().copy()))
+    for i in range(0, N, 11):
+        o = _oracle_for(env, i)
+        o.set_philox(99, i)
+        assert o.reset() == int(init[i])
+        eo, er, ed, ero = o.rollout(acts[:, i], None)
+        exp = eo.copy()
+        exp[ed] = ero[ed]
+        assert np.array_equal(obs[:, i], exp[:T]) and np.array_equal(term[:, i], ed[:T]), i
+        assert np.allclose(rew[:, i], er[:T].astype(np.float32), rtol=1e-6, atol=1e-6), i
+        for k, (o1, r1, d1) in enumerate(single):
+            assert o1[i] == exp[T + k] and d1[i] == ed[T + k] and np.allclose(r1[i], np.float32(er[T + k]), rtol=1e-6, atol=1e-6), (i, k)
+    env.close()
