@@ -210,6 +210,11 @@ extern "C" int mdpp_create(const mdpp_config *cfg, int device, mdpp_env **out) {
                            "not S > 255 together with L > 7)";
             free_all(h); delete h; return MDPP_EUNSUPPORTED;
         }
+        if (cfg->has_transition_noise && cfg->S > 8192) {
+            // (the S x S table of the noise categoricals' cdfs is uploaded whole, 8 S^2 bytes: 512 MiB at 8 192 states)
+            g_create_err = "mdpp_create: transition noise needs S <= 8192 (the S x S cdf table)";
+            free_all(h); delete h; return MDPP_EUNSUPPORTED;
+        }
         if (cfg->num_tables != 1 && cfg->num_tables != cfg->num_envs) {
             g_create_err = "mdpp_create: num_tables must be 1 or num_envs"; free_all(h); delete h; return MDPP_EINVAL;
         }
