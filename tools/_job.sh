@@ -1,3 +1,3 @@
 #!/bin/bash
-export MDPP_FUZZ_MORE_SEEDS=61,62,63,64,65,66,67,68
-bash tools/fuzz_wide.sh "71,72,73,74,75,76,77,78" "81,82,83,84,85,86" random
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "bench_shape or golden" -p no:cacheprovider 2>&1 | tail -2
