@@ -221,6 +221,7 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
     from test_gpu_parity import _oracle_for
     N = env.num_envs
     auto = kw["autoreset"] == "same_step"
+    nextm = kw["autoreset"] == "next_step"        # gymnasium >= 1.0: the call after an episode's last step IS that env's reset()
     horizon = kw.get("max_episode_steps", 0)
     disc = env.kind == "discrete"
     init = env._obs.cpu().numpy().copy()
@@ -232,7 +233,7 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
         if disc and env._irr:
             o.set_rng_irr(env.seeded_streams[capi.STREAM_SPACE_IRR][i])
         assert np.array_equal(np.asarray(o.reset()), init[i]), (k, i)
-        oracles.append([o, 0])
+        oracles.append([o, 0, False])
     g = np.random.default_rng(seed)
     for K in (72, 1, 1, 1, 40):
         acts = _rand_actions(env, K, g)
@@ -247,12 +248,21 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
         ends = (env.get_rng_streams(capi.STREAM_ENV), env.get_rng_streams(capi.STREAM_SPACE))
         for (o, i), rec in zip(zip([x[0] for x in oracles], sample), oracles):
             for t in range(K):
+                if nextm and rec[2]:             # (ignores the action, returns the first observation, reward 0, no flags; draws nothing else)
+                    st, rr, d, tr = o.reset(), 0.0, False, False
+                    rec[1], rec[2] = 0, False
+                    assert not term[t, i] and not trunc[t, i] and rew[t, i] == 0.0, (k, cfg, mode, K, i, t)
+                    assert np.array_equal(np.asarray(obs[t, i]).view(np.uint32 if not disc else obs.dtype),
+                                          np.asarray(st, dtype=obs.dtype).view(np.uint32 if not disc else obs.dtype)), (k, cfg, mode, K, i, t, "reset call")
+                    continue
                 if disc:
                     st, rr, d = o.step(acts[t, i])
                 else:
                     st, rr, _, d = o.step(acts[t, i])
                 rec[1] += 1
                 tr = bool(horizon) and rec[1] >= horizon
+                if nextm:
+                    rec[2] = d or tr
                 assert d == bool(term[t, i]) and tr == bool(trunc[t, i]), (k, cfg, mode, K, i, t, env.rollout_kernel_name(K))
                 if disc:
                     assert np.float32(rr) == rew[t, i], (k, cfg, mode, K, i, t, rr, rew[t, i], env.rollout_kernel_name(K))
@@ -327,7 +337,7 @@ def test_random_configurations_specialised_equals_general(k):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("k", [k for k in range(len(FUZZ)) if FUZZ[k][1] != "next_step"])
+@pytest.mark.parametrize("k", range(len(FUZZ)))
 def test_random_configurations_default_dispatch_vs_oracle(k):
     """The same random configurations on the DEFAULT dispatch (whatever specialised kernel the library picks: lean Z0, quiet SF /
     XR / PE, the continuous fast kernels ...) against the ORACLE: 512 envs, a fused rollout of 72 steps, three single steps, a rollout
@@ -341,6 +351,8 @@ def test_random_configurations_default_dispatch_vs_oracle(k):
     kw = dict(autoreset="same_step")
     if mode == "disabled":
         kw = dict(autoreset="disabled")
+    elif mode == "next_step":
+        kw = dict(autoreset="next_step")
     elif mode == "timelimit":
         kw = dict(autoreset="same_step", max_episode_steps=11)
     nkw = dict(seeds=list(range(7, 7 + N))) if per_env else dict(num_envs=N)
@@ -589,7 +601,7 @@ def test_random_widened_configurations_specialised_equals_general(k):
 
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("k", [k for k in range(len(FUZZ_WIDE)) if FUZZ_WIDE[k][0] in ("d_irr", "d_diam", "d_rep", "d_custom", "c_wide", "c_line", "c_unb", "c_order4", "c_evn", "d_big")
-                               and FUZZ_WIDE[k][2] != "next_step" and FUZZ_WIDE[k][3] == "numpy"])
+                               and FUZZ_WIDE[k][3] == "numpy"])
 def test_random_widened_configurations_default_dispatch_vs_oracle(k):
     """The widened random configurations without pictures, on numpy streams, against the ORACLE on the default dispatch: 512 envs
     (500 on the ragged ones), every 29th env through its own oracle instance -- observations and flags bit for bit, discrete
@@ -602,6 +614,8 @@ def test_random_widened_configurations_default_dispatch_vs_oracle(k):
     kw = dict(autoreset="same_step")
     if mode == "disabled":
         kw = dict(autoreset="disabled")
+    elif mode == "next_step":
+        kw = dict(autoreset="next_step")
     elif mode == "timelimit":
         kw = dict(autoreset="same_step", max_episode_steps=7)
     with warnings.catch_warnings():
@@ -886,12 +900,7 @@ def test_state_spaces_beyond_255_states_vs_oracle(shape, mode):
         warnings.simplefilter("ignore")
         env = _venv(num_envs=512, **kw, **cfg)
     assert env.rollout_kernel_name(72).startswith("k_discrete_step_wide<") and env.rollout_kernel_name(1).startswith("k_discrete_step_wide<")
-    if mode != "next_step":
-        _check_vs_oracle(env, shape, cfg, mode, kw, 99)
-    else:       # (the oracle loop of that mode: test_gpu_boundary.py; here against a Philox-free twin through a state round trip)
-        g = np.random.default_rng(4)
-        acts = torch.as_tensor(_rand_actions(env, 30, g), device=env.device)
-        env.rollout(acts[:20])
+    _check_vs_oracle(env, shape, cfg, mode, kw, 99)
     # state round trip into a fresh handle: the same next outputs (streams copied too)
     from mdp_playground_amd import _capi as capi
     with warnings.catch_warnings():
