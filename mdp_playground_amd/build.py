@@ -23,6 +23,15 @@ INCLUDED_SOURCES = {"mdpp_discrete_wide.hip": ["mdpp_discrete.hip"], "mdpp_discr
                     "mdpp_continuous_line8.hip": ["mdpp_continuous.hip"], "mdpp_continuous_step1.hip": ["mdpp_continuous_fast.hip"], "mdpp_discrete_quiet_nu.hip": ["mdpp_discrete_quiet.hip"]}   # a .hip that #includes another one
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# The GENERAL kernels keep whole state vectors in registers and spill (k_continuous_step<DMAX=32, OMAX=4>: 3 KB of scratch per lane).
+# With the compiler's default, SGPRs are spilled into the lanes of a VGPR, and where that VGPR is itself spilled inside divergent control
+# flow the values parked in the inactive lanes are lost: k_continuous_step<32, 4, PHILOX> ended episodes that had not ended (lanes 43-60
+# of a wave, whenever another lane of the wave ran the in-step reset; round 6, found by the random configurations against the oracle,
+# tools/repro_c14.py).  These translation units spill SGPRs to memory instead; the hand-tuned rollout kernels do not spill and keep
+# the default.
+SPILL_SAFE = ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]
+EXTRA_FLAGS = {s: SPILL_SAFE for s in ("mdpp_continuous.hip", "mdpp_continuous_line8.hip", "mdpp_discrete.hip", "mdpp_discrete_wide.hip",
+                                       "mdpp_discrete_long.hip")}
 
 
 def _hipcc():
@@ -50,7 +59,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         extra = [os.path.join(CSRC, d) for d in INCLUDED_SOURCES.get(s, [])]
         if force or _stale(obj, [src] + extra + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -222,6 +222,9 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
     N = env.num_envs
     auto = kw["autoreset"] == "same_step"
     nextm = kw["autoreset"] == "next_step"        # gymnasium >= 1.0: the call after an episode's last step IS that env's reset()
+    philox = env.rng == "philox"
+    if philox and nextm:     # (Philox streams are keyed by the BATCH's tick, which also advances on an env's reset call: this per-env loop does not model that)
+        pytest.skip("next-step autoreset on Philox streams: test_gpu_boundary.py / the specialised-equals-general comparison")
     horizon = kw.get("max_episode_steps", 0)
     disc = env.kind == "discrete"
     init = env._obs.cpu().numpy().copy()
@@ -229,9 +232,12 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
     oracles = []
     for i in sample:
         o = _oracle_for(env, i)
-        o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
-        if disc and env._irr:
-            o.set_rng_irr(env.seeded_streams[capi.STREAM_SPACE_IRR][i])
+        if philox:       # the build's own counter-based streams, keyed by (seed, global env id): the oracle's C restatement of them
+            o.set_philox(int(env._cfg.philox_seed), env.env_id_offset + i)
+        else:
+            o.set_rng(env.seeded_streams[0][i], env.seeded_streams[1][i])
+            if disc and env._irr:
+                o.set_rng_irr(env.seeded_streams[capi.STREAM_SPACE_IRR][i])
         assert np.array_equal(np.asarray(o.reset()), init[i]), (k, i)
         oracles.append([o, 0, False])
     g = np.random.default_rng(seed)
@@ -245,7 +251,7 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
             obs, rew, term, trunc = (x[None].cpu().numpy() for x in (o1, r1, t1, tr1))
         else:
             obs, rew, term, trunc = (x.cpu().numpy() for x in env.rollout(at))
-        ends = (env.get_rng_streams(capi.STREAM_ENV), env.get_rng_streams(capi.STREAM_SPACE))
+        ends = None if philox else (env.get_rng_streams(capi.STREAM_ENV), env.get_rng_streams(capi.STREAM_SPACE))
         for (o, i), rec in zip(zip([x[0] for x in oracles], sample), oracles):
             for t in range(K):
                 if nextm and rec[2]:             # (ignores the action, returns the first observation, reward 0, no flags; draws nothing else)
@@ -264,15 +270,18 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
                 if nextm:
                     rec[2] = d or tr
                 assert d == bool(term[t, i]) and tr == bool(trunc[t, i]), (k, cfg, mode, K, i, t, env.rollout_kernel_name(K))
-                if disc:
+                if disc and not philox:
                     assert np.float32(rr) == rew[t, i], (k, cfg, mode, K, i, t, rr, rew[t, i], env.rollout_kernel_name(K))
-                else:
-                    assert abs(float(np.float32(rr)) - float(rew[t, i])) <= 1e-6 * max(1.0, abs(rr)), (k, cfg, mode, K, i, t, rr, rew[t, i])
+                else:       # (the line reward: the upstream tolerance -- LAPACK's float32 SVD is not a function of its inputs alone)
+                    tol = 1e-5 if isinstance(cfg, dict) and cfg.get("reward_function") == "move_along_a_line" else 1e-6
+                    assert abs(float(np.float32(rr)) - float(rew[t, i])) <= tol * max(1.0, abs(rr)), (k, cfg, mode, K, i, t, rr, rew[t, i])
                 if auto and (d or tr):
                     st = o.reset(explicit=False)
                     rec[1] = 0
                 assert np.array_equal(np.asarray(obs[t, i]).view(np.uint32 if not disc else obs.dtype),
                                       np.asarray(st, dtype=obs.dtype).view(np.uint32 if not disc else obs.dtype)), (k, cfg, mode, K, i, t, env.rollout_kernel_name(K))
+            if philox:
+                continue
             ge, gs = o.get_rng()
             assert np.array_equal(ge[:4], ends[0][i][:4]) and np.array_equal(gs[:4], ends[1][i][:4]), (k, cfg, mode, K, i, env.rollout_kernel_name(K))
             if disc and env._irr:
@@ -601,7 +610,7 @@ def test_random_widened_configurations_specialised_equals_general(k):
 
 @pytest.mark.timeout(180)
 @pytest.mark.parametrize("k", [k for k in range(len(FUZZ_WIDE)) if FUZZ_WIDE[k][0] in ("d_irr", "d_diam", "d_rep", "d_custom", "c_wide", "c_line", "c_unb", "c_order4", "c_evn", "d_big")
-                               and FUZZ_WIDE[k][3] == "numpy"])
+                               ])
 def test_random_widened_configurations_default_dispatch_vs_oracle(k):
     """The widened random configurations without pictures, on numpy streams, against the ORACLE on the default dispatch: 512 envs
     (500 on the ragged ones), every 29th env through its own oracle instance -- observations and flags bit for bit, discrete
@@ -618,6 +627,8 @@ def test_random_widened_configurations_default_dispatch_vs_oracle(k):
         kw = dict(autoreset="next_step")
     elif mode == "timelimit":
         kw = dict(autoreset="same_step", max_episode_steps=7)
+    if rng == "philox":
+        kw.update(rng="philox", philox_seed=77)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
@@ -1024,4 +1035,28 @@ def test_wide_and_long_handles_on_philox_streams_vs_oracle(shape):
         assert np.allclose(rew[:, i], er[:T].astype(np.float32), rtol=1e-6, atol=1e-6), i
         for k, (o1, r1, d1) in enumerate(single):
             assert o1[i] == exp[T + k] and d1[i] == ed[T + k] and np.allclose(r1[i], np.float32(er[T + k]), rtol=1e-6, atol=1e-6), (i, k)
+    env.close()
+
+
+@pytest.mark.parametrize("order,D,horizon", [(3, 14, 7), (4, 14, 0), (3, 20, 0), (4, 20, 7), (2, 30, 7)])
+def test_general_continuous_kernel_beyond_12_dimensions_on_philox_streams_vs_oracle(order, D, horizon):
+    """Found by the random configurations on Philox streams against the oracle (not by specialised-equals-general: both sides were
+    this kernel): k_continuous_step<DMAX=32, OMAX=4, PHILOX> -- 3 KB of scratch per lane -- ended episodes that had not ended, in
+    lanes 43-60 of a wave, whenever another lane of the wave ran the in-step reset.  The compiler parks spilled SGPRs in the lanes of
+    a VGPR, and where that VGPR is itself spilled inside divergent control flow the inactive lanes' values are lost; the general
+    kernels' translation units now spill SGPRs to memory (build.py SPILL_SAFE).  512 envs, every 29th through its own oracle
+    (env 119 = lane 55 among them), same-step autoreset with and without a step limit."""
+    import warnings
+    cfg = dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=D, action_space_dim=D, transition_dynamics_order=order,
+               inertia=2.0, time_unit=1.0, state_space_max=6.0, action_space_max=1, delay=1, seed=249, reward_scale=1.0, reward_shift=0.5,
+               relevant_indices=[2, 9, 10], irrelevant_features=True, reward_function="move_to_a_point", target_point=[-0.44, -0.53, -0.57],
+               target_radius=1.0, make_denser=True, action_loss_weight=0.5)
+    kw = dict(autoreset="same_step", rng="philox", philox_seed=77)
+    if horizon:
+        kw["max_episode_steps"] = horizon
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = _venv(num_envs=512, **kw, **cfg)
+    assert env.rollout_kernel_name(72).startswith("k_continuous_step<DMAX=32,")
+    _check_vs_oracle(env, (order, D), cfg, "timelimit" if horizon else "same_step", kw, 1509, scale=1.05, stride=29)
     env.close()
