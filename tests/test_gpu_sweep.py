@@ -1060,3 +1060,54 @@ def test_general_continuous_kernel_beyond_12_dimensions_on_philox_streams_vs_ora
     assert env.rollout_kernel_name(72).startswith("k_continuous_step<DMAX=32,")
     _check_vs_oracle(env, (order, D), cfg, "timelimit" if horizon else "same_step", kw, 1509, scale=1.05, stride=29)
     env.close()
+
+
+_EVERY_LANE = {
+    # (kernels of the hot translation units that have VGPR scratch: docs/round6.md section 10)
+    "lean_philox_irr": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 5], action_space_size=[8, 5], irrelevant_features=True,
+                             delay=2, sequence_length=2, seed=5), dict(autoreset="same_step", rng="philox", philox_seed=9), "k_discrete_rollout_lean<"),
+    "lean_philox_irr_limit": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 5], action_space_size=[8, 5], irrelevant_features=True,
+                                   delay=0, sequence_length=3, seed=6), dict(autoreset="same_step", rng="philox", philox_seed=9, max_episode_steps=7), "k_discrete_rollout_lean<"),
+    "lean_numpy_both_noises": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8, delay=4, sequence_length=3,
+                                    transition_noise=0.1, reward_noise=0.3, seed=0), dict(autoreset="same_step"), "k_discrete_rollout_lean<"),
+    "lean_next_irr": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 6], action_space_size=[8, 6], irrelevant_features=True,
+                           delay=1, sequence_length=2, seed=7), dict(autoreset="next_step", max_episode_steps=9), "k_discrete_rollout_lean<"),
+    "quiet_philox_noise": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=20, action_space_size=20, delay=3, sequence_length=2,
+                                transition_noise=0.1, reward_noise=0.2, seed=8), dict(autoreset="same_step", rng="philox", philox_seed=9), "k_discrete_rollout_quiet<"),
+    "cfast_philox_noise": (dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=12, action_space_dim=12, relevant_indices=[0, 1, 2, 3],
+                                irrelevant_features=True, target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10, action_space_max=1,
+                                transition_dynamics_order=2, inertia=1, time_unit=0.1, make_denser=True, reward_function="move_to_a_point",
+                                transition_noise=0.05, reward_noise=0.05, seed=0), dict(autoreset="same_step", rng="philox", philox_seed=9, max_episode_steps=11), "k_continuous_rollout_fast<"),
+    "cfast_d2_sigma0": (dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=2, action_space_dim=2, target_point=[0, 0], target_radius=0.5,
+                             state_space_max=10, action_space_max=1, transition_dynamics_order=1, inertia=1, time_unit=1.0, make_denser=True,
+                             reward_function="move_to_a_point", transition_noise=0, reward_noise=0, seed=0), dict(autoreset="same_step", max_episode_steps=13), "k_continuous_rollout_fast<"),
+    "cfast_d4_order2_both": (dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=4, action_space_dim=4, target_point=[0, 0, 0, 0], target_radius=0.5,
+                                  state_space_max=5, action_space_max=1, transition_dynamics_order=2, inertia=2, time_unit=0.5, make_denser=False, delay=2,
+                                  reward_function="move_to_a_point", transition_noise=0.05, reward_noise=0.1, seed=1), dict(autoreset="same_step", max_episode_steps=9), "k_continuous_rollout_fast<"),
+    "cfast_d8_order3_pn": (dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=8, action_space_dim=8, relevant_indices=[0, 1, 2, 3], irrelevant_features=True,
+                                target_point=[0, 0, 0, 0], target_radius=1.0, state_space_max=4, action_space_max=1, transition_dynamics_order=3, inertia=1, time_unit=0.5,
+                                make_denser=True, reward_function="move_to_a_point", transition_noise=0.02, seed=2), dict(autoreset="same_step"), "k_continuous_step<DMAX=12,OMAX=4"),   # (general kernel, 36 B of scratch)
+    "cfast_numpy_noise_limit": (dict(state_space_type="continuous", action_space_type="continuous", state_space_dim=12, action_space_dim=12, relevant_indices=[0, 1, 2, 3],
+                                     irrelevant_features=True, target_point=[0, 0, 0, 0], target_radius=0.05, state_space_max=10, action_space_max=1,
+                                     transition_dynamics_order=1, inertia=1, time_unit=1.0, make_denser=True, reward_function="move_to_a_point",
+                                     transition_noise=0.05, seed=0), dict(autoreset="same_step", max_episode_steps=9), "k_continuous_rollout_fast<"),
+}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("name", sorted(_EVERY_LANE))
+def test_rollout_kernels_with_register_spills_every_lane_vs_oracle(name):
+    """docs/round6.md section 10: the compiler parks spilled SGPRs in VGPR lanes, and a kernel that also spills VGPRs inside divergent control
+    flow can lose them -- in particular lanes.  The hand-tuned rollout kernels keep that spilling (it is what makes cfg2 110 us instead of
+    157); those of their instantiations that HAVE VGPR scratch are compared here with the oracle on EVERY lane: 512 envs = 8 full
+    waves, rollouts with in-step resets (a step limit where episodes would otherwise be long), single steps, both stream kinds."""
+    import warnings
+    cfg, kw, kernel = _EVERY_LANE[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = _venv(num_envs=512, **kw, **cfg)
+    assert env.rollout_kernel_name(72).startswith(kernel), env.rollout_kernel_name(72)
+    mode = "next_step" if kw["autoreset"] == "next_step" else "timelimit" if kw.get("max_episode_steps") else "same_step"
+    _check_vs_oracle(env, name, cfg, mode, kw, 321, stride=1)
+    assert not (env.status() & 0x80000000).any()
+    env.close()
