@@ -220,6 +220,7 @@ def _check_vs_oracle(env, k, cfg, mode, kw, seed, scale=1.0, stride=37):
     from mdp_playground_amd import _capi as capi
     from test_gpu_parity import _oracle_for
     N = env.num_envs
+    stride = int(os.environ.get("MDPP_FUZZ_STRIDE", stride))        # (exploration: MDPP_FUZZ_STRIDE=1 -- every lane of every wave)
     auto = kw["autoreset"] == "same_step"
     nextm = kw["autoreset"] == "next_step"        # gymnasium >= 1.0: the call after an episode's last step IS that env's reset()
     philox = env.rng == "philox"
