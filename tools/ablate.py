@@ -28,7 +28,7 @@ def build(src, variants):
 
     def one(v):
         name, flags = (v.split(":", 1) + [""])[:2]
-        cmd = [B._hipcc()] + B.FLAGS + flags.split() + ["-c", os.path.join(CSRC, src), "-o", obj_of(src, name)]
+        cmd = [B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + flags.split() + ["-c", os.path.join(CSRC, src), "-o", obj_of(src, name)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         return name, r.returncode, r.stdout[-2000:]
     with ThreadPoolExecutor(max_workers=min(7, len(variants))) as ex:
