@@ -1071,6 +1071,12 @@ _EVERY_LANE = {
                                    delay=0, sequence_length=3, seed=6), dict(autoreset="same_step", rng="philox", philox_seed=9, max_episode_steps=7), "k_discrete_rollout_lean<"),
     "lean_numpy_both_noises": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8, delay=4, sequence_length=3,
                                     transition_noise=0.1, reward_noise=0.3, seed=0), dict(autoreset="same_step"), "k_discrete_rollout_lean<"),
+    "lean_numpy_both_noises_limit": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8, delay=2, sequence_length=2,
+                                          transition_noise=0.2, reward_noise=0.3, reward_every_n_steps=1, seed=1), dict(autoreset="same_step", max_episode_steps=7), "k_discrete_rollout_lean<"),
+    "lean_numpy_rn_only_off": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=8, action_space_size=8, delay=0, sequence_length=1,
+                                    reward_noise=0.5, seed=2), dict(autoreset="disabled"), "k_discrete_rollout_"),
+    "lean_numpy_pn_only": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=6, action_space_size=6, delay=1, sequence_length=3,
+                                transition_noise=0.3, seed=3), dict(autoreset="same_step"), "k_discrete_rollout_"),   # (S = 6: the noise thresholds are not row-independent -> quiet)
     "lean_next_irr": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=[8, 6], action_space_size=[8, 6], irrelevant_features=True,
                            delay=1, sequence_length=2, seed=7), dict(autoreset="next_step", max_episode_steps=9), "k_discrete_rollout_lean<"),
     "quiet_philox_noise": (dict(state_space_type="discrete", action_space_type="discrete", state_space_size=20, action_space_size=20, delay=3, sequence_length=2,
